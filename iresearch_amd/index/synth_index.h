@@ -1,0 +1,102 @@
+/* Synthetic IResearch segment builder (host only, no GPU, no oracle).
+ *
+ * Produces, for one segment, exactly the inputs the hot path consumes in the
+ * reference:
+ *   - the bytes of a `.doc` postings file as `irs::postings_writer` lays them
+ *     out (reference: core/formats/formats_10.cpp:621-1025, bitpack.hpp:75-108),
+ *     in either the scalar ("1_5") or the simdcomp 4-lane ("1_5simd") layout;
+ *   - the `version10::term_meta` of every term
+ *     (core/formats/formats_10_attributes.hpp:30-50);
+ *   - the dense Norm2 column (core/index/norm.hpp:135-182): field length per
+ *     doc, 1 byte wide;
+ *   - the field statistics BM25/TF-IDF collectors read
+ *     (core/search/bm25.cpp:52-58).
+ *
+ * The corpus is defined by a pure function of (seed, global doc id, token
+ * position) so any thread count (and any segment split) yields identical
+ * bytes.  See DESIGN.md "Synthetic index".
+ */
+#ifndef IRS_SYNTH_INDEX_H
+#define IRS_SYNTH_INDEX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Mirrors irs::version10::term_meta (formats_10_attributes.hpp:30-50). */
+typedef struct irs_synth_term_meta {
+  uint32_t docs_count; /* irs::term_meta::docs_count  (formats.hpp:97)  */
+  uint32_t freq;       /* irs::term_meta::freq (total tf, formats.hpp:100) */
+  uint64_t doc_start;  /* offset of the term's postings in `.doc` */
+  uint64_t pos_start;
+  uint64_t pos_end;    /* address_limits::invalid() == UINT64_MAX when unset */
+  uint64_t pay_start;
+  uint64_t e_skip_start; /* union with e_single_doc (low 32 bits) */
+} irs_synth_term_meta;
+
+enum { IRS_SYNTH_LAYOUT_SCALAR = 0, IRS_SYNTH_LAYOUT_SIMD4 = 1 };
+
+typedef struct irs_synth_params {
+  uint64_t seed;          /* 20260926 for every BASELINE config             */
+  uint64_t first_doc;     /* global id (0-based) of this segment's doc 1    */
+  uint32_t num_docs;      /* docs in this segment, local ids 1..num_docs    */
+  uint32_t vocab_log2;    /* V = 2^vocab_log2 term ranks, Zipf s = 1        */
+  uint32_t max_rank;      /* ranks 1..max_rank get posting lists            */
+  uint32_t layout;        /* IRS_SYNTH_LAYOUT_*                             */
+  uint32_t mean_len;      /* doc length ~ IrwinHall12 approx N(mean, sd)    */
+  uint32_t stddev_len;    /*   clamped to [1,255]                           */
+  uint32_t threads;       /* 0 = hardware_concurrency                       */
+  uint32_t keep_postings; /* keep decoded (doc, tf) lists for verification  */
+} irs_synth_params;
+
+typedef struct irs_synth_index irs_synth_index;
+
+int irs_synth_build(const irs_synth_params* p, irs_synth_index** out);
+void irs_synth_free(irs_synth_index* idx);
+
+const uint8_t* irs_synth_doc_bytes(const irs_synth_index* idx, uint64_t* len);
+/* norms[i] = field length of local doc id (i + 1) */
+const uint8_t* irs_synth_norms(const irs_synth_index* idx, uint64_t* count);
+/* metas[r - 1] = term_meta of rank r */
+const irs_synth_term_meta* irs_synth_term_metas(const irs_synth_index* idx,
+                                                uint32_t* count);
+uint64_t irs_synth_docs_with_field(const irs_synth_index* idx);
+uint64_t irs_synth_total_term_freq(const irs_synth_index* idx);
+/* only when keep_postings: pointers into the builder's own arrays */
+int irs_synth_postings(const irs_synth_index* idx, uint32_t rank,
+                       const uint32_t** docs, const uint32_t** freqs,
+                       uint32_t* count);
+
+/* Encode one explicit posting list (docs ascending, local ids >= 1) the way
+ * postings_writer::write does; used by tests to feed literal lists such as
+ * tests/golden/postings_6098.txt.  `segment_docs` sizes the skip list
+ * (skip_list.cpp:47-48).  Returns bytes written (term starts at offset 0 of
+ * `out`), or a negative error. */
+int64_t irs_synth_encode_term(const uint32_t* docs, const uint32_t* freqs,
+                              uint32_t count, uint32_t segment_docs,
+                              uint32_t layout, uint8_t* out, uint64_t out_cap,
+                              irs_synth_term_meta* meta);
+
+/* Wrap concatenated term bytes into a complete `.doc` file image:
+ * header (format_utils.cpp:57-61) + body + footer (:63-67). Returns total
+ * length; `body_offset` receives the header length to add to doc_start. */
+int64_t irs_synth_wrap_doc_file(const uint8_t* body, uint64_t body_len,
+                                uint32_t layout, uint8_t* out,
+                                uint64_t out_cap, uint64_t* body_offset);
+
+/* Corpus primitives exposed for tests. */
+uint32_t irs_synth_doc_length(uint64_t seed, uint64_t global_doc,
+                              uint32_t mean_len, uint32_t stddev_len);
+
+/* Query workload: `n_queries` x `n_terms` distinct ranks, log-uniform in
+ * [lo_rank, hi_rank]. ranks_out is row-major. */
+int irs_synth_queries(uint64_t seed, uint32_t n_queries, uint32_t n_terms,
+                      uint32_t lo_rank, uint32_t hi_rank, uint32_t* ranks_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,184 @@
+"""ctypes view of libirs_synth.so — the synthetic IResearch segment builder
+(iresearch_amd/index/synth_index.h).  Host only; used by tests and bench.py to
+produce `.doc` bytes, term metas, the Norm2 column and field statistics."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _build
+
+LAYOUT_SCALAR = 0  # "1_5"      formats_10.cpp:86-131
+LAYOUT_SIMD4 = 1   # "1_5simd"  formats_10.cpp:4122-4157
+SEED = 20260926
+
+# version10::term_meta (formats_10_attributes.hpp:30-50)
+TERM_META = np.dtype(
+    [("docs_count", "<u4"), ("freq", "<u4"), ("doc_start", "<u8"), ("pos_start", "<u8"),
+     ("pos_end", "<u8"), ("pay_start", "<u8"), ("e_skip_start", "<u8")],
+    align=True,
+)
+assert TERM_META.itemsize == 48
+
+
+class _Params(C.Structure):
+    _fields_ = [
+        ("seed", C.c_uint64), ("first_doc", C.c_uint64), ("num_docs", C.c_uint32),
+        ("vocab_log2", C.c_uint32), ("max_rank", C.c_uint32), ("layout", C.c_uint32),
+        ("mean_len", C.c_uint32), ("stddev_len", C.c_uint32), ("threads", C.c_uint32),
+        ("keep_postings", C.c_uint32),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(str(_build.build_synth()))
+        L.irs_synth_build.argtypes = [C.POINTER(_Params), C.POINTER(C.c_void_p)]
+        L.irs_synth_build.restype = C.c_int
+        L.irs_synth_free.argtypes = [C.c_void_p]
+        L.irs_synth_free.restype = None
+        for name in ("irs_synth_doc_bytes", "irs_synth_norms"):
+            f = getattr(L, name)
+            f.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+            f.restype = C.c_void_p
+        L.irs_synth_term_metas.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        L.irs_synth_term_metas.restype = C.c_void_p
+        for name in ("irs_synth_docs_with_field", "irs_synth_total_term_freq"):
+            f = getattr(L, name)
+            f.argtypes = [C.c_void_p]
+            f.restype = C.c_uint64
+        L.irs_synth_postings.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p),
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]
+        L.irs_synth_postings.restype = C.c_int
+        L.irs_synth_encode_term.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                            C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.irs_synth_encode_term.restype = C.c_int64
+        L.irs_synth_wrap_doc_file.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
+                                              C.c_uint64, C.POINTER(C.c_uint64)]
+        L.irs_synth_wrap_doc_file.restype = C.c_int64
+        L.irs_synth_doc_length.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
+        L.irs_synth_doc_length.restype = C.c_uint32
+        L.irs_synth_queries.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                        C.c_uint32, C.c_void_p]
+        L.irs_synth_queries.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _view(ptr, nbytes, dtype):
+    buf = (C.c_uint8 * nbytes).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype)
+
+
+@dataclass
+class SynthSegment:
+    """One synthetic segment: everything the hot path reads in the reference."""
+    doc_file: np.ndarray        # uint8, the whole `.doc` image (header+terms+footer)
+    norms: np.ndarray           # uint8, Norm2 of local doc ids 1..N
+    metas: np.ndarray           # TERM_META[max_rank]; metas[r-1] = rank r
+    docs_with_field: int        # term_reader::docs_count()   (bm25.cpp:54)
+    total_term_freq: int        # field frequency attribute    (bm25.cpp:55-57)
+    layout: int
+    num_docs: int
+    postings: dict | None = None  # rank -> (docs u32[], freqs u32[]) when kept
+
+    def meta(self, rank: int) -> np.void:
+        return self.metas[rank - 1]
+
+
+def build_segment(num_docs: int, max_rank: int = 4096, *, layout: int = LAYOUT_SIMD4,
+                  seed: int = SEED, first_doc: int = 0, vocab_log2: int = 20,
+                  mean_len: int = 100, stddev_len: int = 30, threads: int = 0,
+                  keep_postings: bool = False) -> SynthSegment:
+    L = lib()
+    p = _Params(seed, first_doc, num_docs, vocab_log2, max_rank, layout, mean_len,
+                stddev_len, threads, int(keep_postings))
+    h = C.c_void_p()
+    rc = L.irs_synth_build(C.byref(p), C.byref(h))
+    if rc != 0:
+        raise ValueError("irs_synth_build failed: %d" % rc)
+    try:
+        n = C.c_uint64()
+        ptr = L.irs_synth_doc_bytes(h, C.byref(n))
+        doc_file = _view(ptr, n.value, np.uint8).copy()
+        ptr = L.irs_synth_norms(h, C.byref(n))
+        norms = _view(ptr, n.value, np.uint8).copy()
+        m = C.c_uint32()
+        ptr = L.irs_synth_term_metas(h, C.byref(m))
+        metas = _view(ptr, m.value * TERM_META.itemsize, TERM_META).copy()
+        postings = None
+        if keep_postings:
+            postings = {}
+            for r in range(1, max_rank + 1):
+                d, f, c = C.c_void_p(), C.c_void_p(), C.c_uint32()
+                L.irs_synth_postings(h, r, C.byref(d), C.byref(f), C.byref(c))
+                if c.value:
+                    postings[r] = (_view(d.value, 4 * c.value, np.uint32).copy(),
+                                   _view(f.value, 4 * c.value, np.uint32).copy())
+                else:
+                    postings[r] = (np.zeros(0, np.uint32), np.zeros(0, np.uint32))
+        return SynthSegment(doc_file, norms, metas, L.irs_synth_docs_with_field(h),
+                            L.irs_synth_total_term_freq(h), layout, num_docs, postings)
+    finally:
+        L.irs_synth_free(h)
+
+
+def encode_term(docs, freqs, segment_docs: int, layout: int = LAYOUT_SIMD4):
+    """postings_writer::write for one explicit list -> (bytes, meta)."""
+    docs = np.ascontiguousarray(docs, dtype=np.uint32)
+    freqs = np.ascontiguousarray(freqs, dtype=np.uint32)
+    assert docs.shape == freqs.shape
+    cap = 64 + 12 * len(docs) + 1024
+    out = np.zeros(cap, np.uint8)
+    meta = np.zeros(1, TERM_META)
+    n = lib().irs_synth_encode_term(docs.ctypes.data, freqs.ctypes.data, len(docs),
+                                    segment_docs, layout, out.ctypes.data, cap,
+                                    meta.ctypes.data)
+    if n < 0:
+        raise ValueError("irs_synth_encode_term failed: %d" % n)
+    return out[:n].copy(), meta[0]
+
+
+def segment_from_lists(lists, num_docs: int, layout: int = LAYOUT_SIMD4, norms=None):
+    """Build a `.doc` image from explicit [(docs, freqs), ...] posting lists."""
+    body = []
+    metas = np.zeros(len(lists), TERM_META)
+    off = 0
+    for i, (d, f) in enumerate(lists):
+        b, m = encode_term(d, f, num_docs, layout)
+        metas[i] = m
+        metas[i]["doc_start"] = off
+        off += len(b)
+        body.append(b)
+    body = np.concatenate(body) if body else np.zeros(0, np.uint8)
+    out = np.zeros(len(body) + 128, np.uint8)
+    hdr = C.c_uint64()
+    n = lib().irs_synth_wrap_doc_file(body.ctypes.data, len(body), layout, out.ctypes.data,
+                                      len(out), C.byref(hdr))
+    if n < 0:
+        raise ValueError("irs_synth_wrap_doc_file failed")
+    metas["doc_start"] += hdr.value
+    if norms is None:
+        norms = np.ones(num_docs, np.uint8)
+    ttf = int(np.asarray(norms, dtype=np.uint64).sum())
+    return SynthSegment(out[:n].copy(), np.ascontiguousarray(norms, np.uint8), metas,
+                        num_docs, ttf, layout, num_docs, None)
+
+
+def make_queries(n_queries: int, n_terms: int, lo_rank: int = 16, hi_rank: int = 4096,
+                 seed: int = SEED + 2) -> np.ndarray:
+    out = np.zeros((n_queries, n_terms), np.uint32)
+    rc = lib().irs_synth_queries(seed, n_queries, n_terms, lo_rank, hi_rank, out.ctypes.data)
+    if rc != 0:
+        raise ValueError("irs_synth_queries failed")
+    return out
+
+
+def doc_length(global_doc: int, seed: int = SEED, mean_len: int = 100, stddev_len: int = 30):
+    return lib().irs_synth_doc_length(seed, global_doc, mean_len, stddev_len)

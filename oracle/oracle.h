@@ -1,0 +1,151 @@
+/* oracle/ — CPU restatement of the IResearch query hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may
+ * load this library; the product path (iresearch_amd/, include/) never does.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - block codec (orc_unpack_*, orc_pack_*): PINNED against the reference's own
+ *     compiled code (oracle/_ref: core/utils/bit_packing.cpp and
+ *     external/simdcomp/src/simdbitpacking.c) for every bit width, and against
+ *     the literal vector of tests/utils/bit_packing_tests.cpp:102-114;
+ *   - posting-list reader: restatement of formats_10.cpp reader code, checked by
+ *     round trip against an independent emitter on the reference's own test
+ *     lists (formats_10_tests.cpp:452-457, tests/resources/postings.txt);
+ *   - scores: "parity unpinned" numerically — the reference's tests hold no
+ *     float literals; the formulas are restated line by line
+ *     and cross-checked in double precision.
+ */
+#ifndef IRS_ORACLE_H
+#define IRS_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ORC_LAYOUT_SCALAR = 0, ORC_LAYOUT_SIMD4 = 1 };
+
+/* version10::term_meta — formats_10_attributes.hpp:30-50 */
+typedef struct orc_term_meta {
+  uint32_t docs_count;
+  uint32_t freq;
+  uint64_t doc_start;
+  uint64_t pos_start;
+  uint64_t pos_end;
+  uint64_t pay_start;
+  uint64_t e_skip_start; /* union with e_single_doc */
+} orc_term_meta;
+
+/* ---- block codec ---------------------------------- */
+void orc_pack_scalar(const uint32_t* in128, uint32_t bits, uint32_t* out);
+void orc_unpack_scalar(const uint32_t* in, uint32_t bits, uint32_t* out128);
+void orc_pack_simd4(const uint32_t* in128, uint32_t bits, uint32_t* out);
+void orc_unpack_simd4(const uint32_t* in, uint32_t bits, uint32_t* out128);
+/* packed::at — bit_packing.hpp (random access into the scalar layout) */
+uint32_t orc_at_scalar(const uint32_t* in, uint32_t i, uint32_t bits);
+/* bitpack::read_block32<128> — returns bytes consumed, <0 on truncation */
+int64_t orc_read_block(const uint8_t* p, const uint8_t* end, int layout,
+                       uint32_t* out128);
+int64_t orc_skip_block(const uint8_t* p, const uint8_t* end);
+
+/* ---- posting list reader (a1/a4/a5/a6) ---------------------------------- */
+/* Decodes the whole list of one term by driving the restated
+ * doc_iterator::next() until eof. freqs may be NULL (iterator without
+ * frequency: freq blocks are skipped, formats_10.cpp:1746-1750). Returns the
+ * number of postings or <0 on corruption. */
+int64_t orc_decode_term(const uint8_t* doc_file, uint64_t len, int layout,
+                        const orc_term_meta* meta, uint32_t* docs,
+                        uint32_t* freqs, uint64_t cap);
+/* Level-0 skip entries of a term with docs_count > 128: absolute last doc of
+ * each skipped block and absolute file offset of the following block. */
+int64_t orc_read_skip0(const uint8_t* doc_file, uint64_t len,
+                       const orc_term_meta* meta, uint32_t* last_docs,
+                       uint64_t* next_block_ptrs, uint64_t cap,
+                       uint32_t* num_levels);
+/* check_header for `.doc` — format_utils.cpp:74-; returns body offset and
+ * stores the PostingsFormat version, <0 on mismatch */
+int64_t orc_check_doc_header(const uint8_t* doc_file, uint64_t len,
+                             int32_t* version);
+
+/* ---- scorers (a9/a10/a11) ------------------------------------------------ */
+typedef struct orc_bm25_stats { /* BM25Stats — bm25.hpp:48-57 */
+  float idf;
+  float norm_const;
+  float norm_length;
+  float norm_cache[256];
+} orc_bm25_stats;
+
+void orc_bm25_collect(float k, float b, uint64_t docs_with_field,
+                      uint64_t docs_with_term, uint64_t total_term_freq,
+                      orc_bm25_stats* stats /* in/out: idf accumulates */);
+float orc_tfidf_idf(uint64_t docs_with_field, uint64_t docs_with_term);
+
+enum {
+  ORC_SCORER_BM25 = 0, /* k, b as given; picks BM1/BM15/BM25 like bm25.cpp:447-455 */
+  ORC_SCORER_TFIDF = 1 /* with_norms selects tfidf.cpp:307 */
+};
+enum { ORC_OP_OR = 0, ORC_OP_AND = 1 };
+
+typedef struct orc_segment {
+  const uint8_t* doc_file;
+  uint64_t doc_file_len;
+  int32_t layout;
+  uint32_t num_docs;
+  const uint8_t* norms; /* dense Norm2 column, big-endian, doc 1 first; NULL = none */
+  uint32_t norm_width;  /* 1, 2 or 4 bytes */
+  uint32_t reserved;
+} orc_segment;
+
+typedef struct orc_scorer {
+  int32_t kind;
+  float k;
+  float b;
+  int32_t with_norms; /* TFIDF only */
+} orc_scorer;
+
+typedef struct orc_hit {
+  float score;
+  uint32_t doc;
+  uint32_t segment;
+} orc_hit;
+
+/* One query, restating utils/index-search.cpp:698-787 over `nsegs` segments:
+ * by_term (n_terms == 1) / Or / And of by_term filters on one field.
+ * metas[s * n_terms + t] = term_meta of query term t in segment s
+ * (docs_count == 0 => term absent there).  Field statistics are summed over
+ * segments as by_term::prepare does (term_filter.cpp:102-125).
+ * out must hold k entries; returns the number of hits written (<= k). */
+int64_t orc_search(const orc_segment* segs, uint32_t nsegs,
+                   const orc_term_meta* metas, uint32_t n_terms, int32_t op,
+                   const orc_scorer* scorer, const float* boosts /*may be NULL*/,
+                   const uint64_t* docs_with_field /*per seg*/,
+                   const uint64_t* total_term_freq /*per seg*/, uint32_t k,
+                   orc_hit* out, uint64_t* hits_total);
+
+/* Batch of queries sharing (op, n_terms, scorer, k), run by `threads` workers
+ * popping tasks from one queue like index-search --threads (index-search.cpp
+ * :673-691). metas is [q][s][t]; out is [q][k]; counts[q] = hits written. */
+int64_t orc_search_batch(const orc_segment* segs, uint32_t nsegs,
+                         const orc_term_meta* metas, uint32_t n_queries,
+                         uint32_t n_terms, int32_t op, const orc_scorer* scorer,
+                         const uint64_t* docs_with_field,
+                         const uint64_t* total_term_freq, uint32_t k,
+                         uint32_t threads, orc_hit* out, uint32_t* counts,
+                         uint64_t* hits_total);
+
+/* Exhaustive scoring of one query on ONE segment: scores[doc] for doc in
+ * [0, num_docs], matched[doc] = 1 when the iterator returned the doc.  Global
+ * statistics are supplied explicitly. Used to validate tie members. */
+int64_t orc_score_all(const orc_segment* seg, const orc_term_meta* metas,
+                      uint32_t n_terms, int32_t op, const orc_scorer* scorer,
+                      const float* boosts, uint64_t docs_with_field,
+                      const uint64_t* docs_with_term /*per term, global*/,
+                      uint64_t total_term_freq, float* scores,
+                      uint8_t* matched);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,366 @@
+/* oracle/postings_oracle.c — TEST INFRASTRUCTURE ONLY (see oracle.h).
+ *
+ * Plain-C restatement of the reference's posting decode path:
+ *   block codec   core/utils/bit_packing.cpp:48-843 (fastpack/fastunpack<N>),
+ *                 external/simdcomp/src/simdbitpacking.c (simdpackwithoutmask /
+ *                 simdunpack), core/formats/formats_10.cpp:96-116, 4131-4142
+ *   framing       core/utils/bitpack.hpp:60-69, 149-177
+ *   iterator      core/formats/formats_10.cpp:1741-1792 (refill/read_tail_block),
+ *                 2089-2119 (next), 2238-2302 (prepare), 1803-1919 (single doc)
+ *   skip data     core/formats/skip_list.cpp:111-156, formats_10.cpp:1063-1080
+ */
+#include <string.h>
+
+#include "oracle.h"
+#include "oracle_internal.h"
+
+
+
+/* ------------------------------------------------------------------ codec */
+
+/* fastpack<N> semantics: value i of a 32-value sub-block, masked to N bits, is
+ * OR-ed at bit (N*i)%32 of word (N*i)/32 and spills into the next word
+ * (bit_packing.cpp:48-60 pattern, repeated 32 times); four sub-blocks are laid
+ * back to back `bits` words apart (formats_10.cpp:96-105). */
+void orc_pack_scalar(const uint32_t* in, uint32_t bits, uint32_t* out) {
+  uint32_t sb, i;
+  memset(out, 0, 16u * bits);
+  for (sb = 0; sb < 4; ++sb) {
+    uint32_t* o = out + sb * bits;
+    const uint32_t* v = in + sb * 32;
+    if (bits == 32) { /* bit_packing.cpp: case 32 -> memcpy */
+      memcpy(o, v, 128);
+      continue;
+    }
+    for (i = 0; i < 32; ++i) {
+      const uint32_t x = v[i] % (1u << bits);
+      const uint32_t bit = bits * i;
+      const uint32_t w = bit >> 5, s = bit & 31;
+      o[w] |= x << s;
+      if (s + bits > 32) o[w + 1] |= x >> (32 - s);
+    }
+  }
+}
+
+/* fastunpack<N> (bit_packing.cpp:644-843) */
+void orc_unpack_scalar(const uint32_t* in, uint32_t bits, uint32_t* out) {
+  uint32_t sb, i;
+  for (sb = 0; sb < 4; ++sb) {
+    const uint32_t* p = in + sb * bits;
+    uint32_t* v = out + sb * 32;
+    if (bits == 32) {
+      memcpy(v, p, 128);
+      continue;
+    }
+    for (i = 0; i < 32; ++i) {
+      const uint32_t bit = bits * i;
+      const uint32_t w = bit >> 5, s = bit & 31;
+      uint32_t x = p[w] >> s;
+      if (s + bits > 32) x |= p[w + 1] << (32 - s);
+      v[i] = x & ((1u << bits) - 1u);
+    }
+  }
+}
+
+uint32_t orc_at_scalar(const uint32_t* in, uint32_t i, uint32_t bits) {
+  /* packed::at -> fastpack_at(encoded + bit*(i/32), i%32, bit) */
+  const uint32_t* p = in + bits * (i / 32);
+  const uint32_t bit = bits * (i % 32);
+  const uint32_t w = bit >> 5, s = bit & 31;
+  uint32_t x;
+  if (bits == 32) return p[i % 32];
+  x = p[w] >> s;
+  if (s + bits > 32) x |= p[w + 1] << (32 - s);
+  return x & ((1u << bits) - 1u);
+}
+
+/* simdpackwithoutmask: row r (= one __m128i of 4 consecutive inputs) is
+ * shifted left by (r*bits)%32 and OR-ed into output vector (r*bits)/32, the
+ * spill going to the next vector — per 32-bit lane independently
+ * (e.g. __SIMD_fastpackwithoutmask5_32, simdbitpacking.c:338-). No masking. */
+void orc_pack_simd4(const uint32_t* in, uint32_t bits, uint32_t* out) {
+  uint32_t r, l;
+  memset(out, 0, 16u * bits);
+  if (bits == 32) {
+    memcpy(out, in, 512);
+    return;
+  }
+  for (r = 0; r < 32; ++r) {
+    const uint32_t bit = r * bits;
+    const uint32_t k = bit >> 5, s = bit & 31;
+    for (l = 0; l < 4; ++l) {
+      const uint32_t x = in[4 * r + l];
+      out[4 * k + l] |= x << s;
+      if (s + bits > 32) out[4 * (k + 1) + l] |= x >> (32 - s);
+    }
+  }
+}
+
+/* simdunpack (e.g. __SIMD_fastunpack5_32, simdbitpacking.c:9513-) */
+void orc_unpack_simd4(const uint32_t* in, uint32_t bits, uint32_t* out) {
+  uint32_t r, l;
+  if (bits == 0) { /* simdunpack case 0: zero fill */
+    memset(out, 0, 512);
+    return;
+  }
+  if (bits == 32) {
+    memcpy(out, in, 512);
+    return;
+  }
+  for (r = 0; r < 32; ++r) {
+    const uint32_t bit = r * bits;
+    const uint32_t k = bit >> 5, s = bit & 31;
+    for (l = 0; l < 4; ++l) {
+      uint32_t x = in[4 * k + l] >> s;
+      if (s + bits > 32) x |= in[4 * (k + 1) + l] << (32 - s);
+      out[4 * r + l] = x & ((1u << bits) - 1u);
+    }
+  }
+}
+
+/* ------------------------------------------------------------ byte stream */
+
+
+
+static uint8_t in_byte(orc_in* in) {
+  if (in->p >= in->end) {
+    in->bad = 1;
+    return 0;
+  }
+  return *in->p++;
+}
+
+/* bytes_io<uint32_t>::vread — bytes_utils.hpp:176-206 */
+static uint32_t in_vint(orc_in* in) {
+  uint32_t out = 0, shift = 0, i;
+  for (i = 0; i < 5; ++i) {
+    const uint32_t b = in_byte(in);
+    out |= (b & 0x7Fu) << shift;
+    if (!(b & 0x80u)) break;
+    shift += 7;
+  }
+  return out;
+}
+/* bytes_io<uint64_t>::vread */
+static uint64_t in_vlong(orc_in* in) {
+  uint64_t out = 0;
+  uint32_t shift = 0, i;
+  for (i = 0; i < 10; ++i) {
+    const uint64_t b = in_byte(in);
+    out |= (b & 0x7Fu) << shift;
+    if (!(b & 0x80u)) break;
+    shift += 7;
+  }
+  return out;
+}
+
+/* bitpack::read_block_impl32 — bitpack.hpp:149-177 */
+static void in_block(orc_in* in, int layout, uint32_t* out) {
+  const uint32_t bits = in_byte(in);
+  uint32_t i;
+  if (bits == 0) { /* ALL_EQUAL: std::fill_n(decoded, size, read_vint()) */
+    const uint32_t v = in_vint(in);
+    for (i = 0; i < ORC_BLOCK; ++i) out[i] = v;
+    return;
+  }
+  if (bits > 32 || (size_t)(in->end - in->p) < 16u * bits) {
+    in->bad = 1;
+    return;
+  }
+  {
+    uint32_t enc[ORC_BLOCK];
+    memcpy(enc, in->p, 16u * bits); /* stream is byte-unaligned */
+    in->p += 16u * bits;
+    if (layout == ORC_LAYOUT_SIMD4)
+      orc_unpack_simd4(enc, bits, out);
+    else
+      orc_unpack_scalar(enc, bits, out);
+  }
+}
+/* bitpack::skip_block32 — bitpack.hpp:60-69 */
+static void in_skip_block(orc_in* in) {
+  const uint32_t bits = in_byte(in);
+  if (bits == 0) {
+    (void)in_vint(in);
+  } else if (bits > 32 || (size_t)(in->end - in->p) < 16u * bits) {
+    in->bad = 1;
+  } else {
+    in->p += 16u * bits;
+  }
+}
+
+int64_t orc_read_block(const uint8_t* p, const uint8_t* end, int layout,
+                       uint32_t* out128) {
+  orc_in in = {p, end, 0};
+  in_block(&in, layout, out128);
+  return in.bad ? -1 : (int64_t)(in.p - p);
+}
+int64_t orc_skip_block(const uint8_t* p, const uint8_t* end) {
+  orc_in in = {p, end, 0};
+  in_skip_block(&in);
+  return in.bad ? -1 : (int64_t)(in.p - p);
+}
+
+/* -------------------------------------------------------------- iterator */
+
+void orc_it_prepare(orc_doc_iterator* it, const uint8_t* file, uint64_t len,
+                       int layout, const orc_term_meta* m, int want_freq) {
+  memset(it, 0, sizeof *it);
+  it->layout = layout;
+  it->want_freq = want_freq;
+  it->begin = ORC_BLOCK;
+  it->in.end = file + len;
+  if (m->docs_count == 1) { /* single_doc_iterator::prepare :1876-1890 */
+    it->single = 1;
+    it->next_single = 1u + (uint32_t)m->e_skip_start; /* min() + e_single_doc */
+    it->freq = m->freq;
+    it->in.p = it->in.end;
+    return;
+  }
+  it->left = m->docs_count; /* :2248 */
+  if (m->doc_start > len) {
+    it->in.bad = 1;
+    it->in.p = it->in.end;
+  } else {
+    it->in.p = file + m->doc_start; /* :2262 */
+  }
+  /* docs_count < 128 && wand disabled -> SkipWandData(): no scorers were
+   * registered at index time, so there are zero bytes to skip (:2298-2301). */
+}
+
+/* doc_iterator_base::read_tail_block :1765-1792 */
+static void it_read_tail(orc_doc_iterator* it) {
+  uint32_t i = ORC_BLOCK - it->left;
+  it->begin = i;
+  for (; i < ORC_BLOCK; ++i) {
+    const uint32_t v = in_vint(&it->in);
+    it->docs[i] = v >> 1; /* shift_unpack_32 */
+    if (v & 1u) {
+      it->freqs[i] = 1;
+    } else {
+      it->freqs[i] = in_vint(&it->in);
+    }
+  }
+  it->left = 0;
+}
+
+/* doc_iterator_base::refill :1741-1762 */
+static void it_refill(orc_doc_iterator* it) {
+  if (it->left >= ORC_BLOCK) {
+    in_block(&it->in, it->layout, it->docs);
+    if (it->want_freq)
+      in_block(&it->in, it->layout, it->freqs);
+    else
+      in_skip_block(&it->in);
+    it->begin = 0;
+    it->left -= ORC_BLOCK;
+  } else {
+    it_read_tail(it);
+  }
+}
+
+/* doc_iterator::next :2089-2119, single_doc_iterator::next :1861-1873 */
+int orc_it_next(orc_doc_iterator* it) {
+  if (it->single) {
+    it->doc = it->next_single;
+    it->next_single = UINT32_MAX;
+    return it->doc != UINT32_MAX;
+  }
+  if (it->begin == ORC_BLOCK) {
+    if (!it->left) {
+      it->doc = UINT32_MAX; /* doc_limits::eof() */
+      return 0;
+    }
+    it_refill(it);
+    if (it->in.bad) {
+      it->doc = UINT32_MAX;
+      return 0;
+    }
+    it->doc += (it->doc == 0); /* :2103 */
+  }
+  it->freq = it->freqs[it->begin];
+  it->doc += it->docs[it->begin++];
+  return 1;
+}
+
+int64_t orc_decode_term(const uint8_t* doc_file, uint64_t len, int layout,
+                        const orc_term_meta* meta, uint32_t* docs,
+                        uint32_t* freqs, uint64_t cap) {
+  orc_doc_iterator it;
+  uint64_t n = 0;
+  if (meta->docs_count == 0) return 0;
+  orc_it_prepare(&it, doc_file, len, layout, meta, freqs != NULL);
+  while (orc_it_next(&it)) {
+    if (n >= cap) return -2;
+    docs[n] = it.doc;
+    if (freqs) freqs[n] = it.freq;
+    ++n;
+  }
+  return it.in.bad ? -1 : (int64_t)n;
+}
+
+/* SkipReaderBase::Prepare (skip_list.cpp:111-156) + ReadState
+ * (formats_10.cpp:1063-1080) for level 0 only. */
+int64_t orc_read_skip0(const uint8_t* doc_file, uint64_t len,
+                       const orc_term_meta* meta, uint32_t* last_docs,
+                       uint64_t* next_block_ptrs, uint64_t cap,
+                       uint32_t* num_levels) {
+  orc_in in;
+  uint32_t levels, l;
+  uint64_t n = 0, ptr;
+  if (meta->docs_count <= ORC_BLOCK) return 0;
+  if (meta->doc_start + meta->e_skip_start > len) return -1;
+  in.p = doc_file + meta->doc_start + meta->e_skip_start;
+  in.end = doc_file + len;
+  in.bad = 0;
+  levels = in_vint(&in);
+  if (num_levels) *num_levels = levels;
+  if (!levels) return 0;
+  for (l = levels; l-- > 1;) { /* levels n..1: vlong length, bytes */
+    const uint64_t length = in_vlong(&in);
+    if (!length || (uint64_t)(in.end - in.p) < length) return -1;
+    in.p += length;
+  }
+  {
+    const uint64_t length = in_vlong(&in);
+    const uint8_t* stop;
+    if (!length || (uint64_t)(in.end - in.p) < length) return -1;
+    stop = in.p + length;
+    ptr = meta->doc_start;
+    while (in.p < stop && !in.bad) {
+      const uint32_t doc = in_vint(&in);
+      ptr += in_vlong(&in);
+      if (n >= cap) return -2;
+      last_docs[n] = doc;
+      next_block_ptrs[n] = ptr;
+      ++n;
+    }
+  }
+  return in.bad ? -1 : (int64_t)n;
+}
+
+/* format_utils::check_header — format_utils.cpp:74-105 */
+int64_t orc_check_doc_header(const uint8_t* f, uint64_t len, int32_t* version) {
+  static const char name[] = "iresearch_10_postings_documents";
+  const uint32_t nlen = (uint32_t)sizeof(name) - 1;
+  orc_in in = {f, f + len, 0};
+  uint32_t magic = 0, ver = 0, i, slen;
+  for (i = 0; i < 4; ++i) magic = (magic << 8) | in_byte(&in);
+  if (magic != 0x3fd76c17u) return -1;
+  slen = in_vint(&in);
+  if (slen != nlen || (uint64_t)(in.end - in.p) < nlen ||
+      memcmp(in.p, name, nlen) != 0)
+    return -1;
+  in.p += nlen;
+  for (i = 0; i < 4; ++i) ver = (ver << 8) | in_byte(&in);
+  if (in.bad) return -1;
+  if (version) *version = (int32_t)ver;
+  return (int64_t)(in.p - f);
+}
+
+uint32_t orc_it_seek(orc_doc_iterator* it, uint32_t target) {
+  while (it->doc < target) {
+    if (!orc_it_next(it)) break;
+  }
+  return it->doc;
+}
