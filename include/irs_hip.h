@@ -1,0 +1,220 @@
+/* irs_hip.h — C ABI of the MI355X-native IResearch query-execution path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no
+ * exceptions, no STL, no torch types.  A C++ adapter deriving
+ * irs::postings_reader / irs::filter::prepared binds these entry points (see
+ * INTEGRATION.md); each function below names the reference interface it
+ * replaces (paths relative to the IResearch tree, v1.3).
+ *
+ * Device: AMD gfx950 (MI355X) only.  Every entry point fails with
+ * IRS_HIP_EHIP when no such device is usable — there is no CPU fallback.
+ */
+#ifndef IRS_HIP_H
+#define IRS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IRS_HIP_ABI_VERSION 1
+#define IRS_HIP_BLOCK_SIZE 128u  /* postings per block, formats_10.cpp:90 */
+#define IRS_HIP_MAX_TERMS 16u    /* terms per boolean query               */
+#define IRS_HIP_MAX_K 4096u      /* largest top-k                         */
+#define IRS_HIP_NO_TERM 0xFFFFFFFFu
+
+/* Errors replace the reference's exceptions (io_error / index_error,
+ * formats_10.cpp:158-160, 3410-3415): never thrown across this boundary. */
+typedef enum irs_hip_status {
+  IRS_HIP_OK = 0,
+  IRS_HIP_EINVAL = -1,       /* illegal_argument                          */
+  IRS_HIP_ECORRUPT = -2,     /* index_error: malformed `.doc` bytes       */
+  IRS_HIP_ENOMEM = -3,
+  IRS_HIP_EHIP = -4,         /* HIP runtime failure / no gfx950 device    */
+  IRS_HIP_EOVERFLOW = -5,    /* candidate buffer exhausted (see DESIGN)   */
+  IRS_HIP_EUNSUPPORTED = -6
+} irs_hip_status;
+
+typedef enum irs_hip_layout {
+  IRS_HIP_LAYOUT_SCALAR = 0, /* formats "1_0".."1_5": format_traits, formats_10.cpp:86-131   */
+  IRS_HIP_LAYOUT_SIMD4 = 1   /* "1_2simd".."1_5simd": format_traits_sse4, :4122-4157         */
+} irs_hip_layout;
+
+/* irs::version10::term_meta — core/formats/formats_10_attributes.hpp:30-50,
+ * as filled by postings_reader_base::decode (formats_10.cpp:3421-3456). */
+typedef struct irs_hip_term_meta {
+  uint32_t docs_count;   /* irs::term_meta::docs_count */
+  uint32_t freq;         /* irs::term_meta::freq       */
+  uint64_t doc_start;
+  uint64_t pos_start;
+  uint64_t pos_end;
+  uint64_t pay_start;
+  uint64_t e_skip_start; /* union { doc_id_t e_single_doc; uint64_t e_skip_start; } */
+} irs_hip_term_meta;
+
+/* What postings_reader::prepare (formats_10.cpp:3352-3419) and the Norm2
+ * column reader (norm.hpp:210-251, columnstore2.cpp:650-789) see of one
+ * segment.  All pointers are HOST pointers borrowed for the call only. */
+typedef struct irs_hip_segment_desc {
+  int32_t device;           /* HIP device ordinal                                  */
+  int32_t layout;           /* irs_hip_layout                                      */
+  const uint8_t* doc_file;  /* whole `.doc` file: index_input::read_buffer(0, len,  */
+  uint64_t doc_file_len;    /*   BufferHint::PERSISTENT) (data_input.hpp:136-137)  */
+  uint32_t num_docs;        /* docs in the segment; ids are 1..num_docs            */
+  uint32_t has_freq;        /* field indexed with IndexFeatures::FREQ              */
+  const uint8_t* norms;     /* dense Norm2 column bytes (big-endian values), or NULL */
+  uint32_t norm_width;      /* 1, 2 or 4 (Norm2Header::num_bytes, norm.hpp:83-125) */
+  uint32_t norm_min_doc;    /* header.min: doc id of norms[0] (normally 1)         */
+  uint64_t norm_count;      /* number of values in `norms`                         */
+  const irs_hip_term_meta* terms; /* the field's term table (term dictionary walk) */
+  uint32_t num_terms;
+  uint32_t reserved;
+} irs_hip_segment_desc;
+
+typedef struct irs_hip_segment irs_hip_segment; /* opaque, immutable after open */
+
+/* Replaces postings_reader::prepare + the per-iterator reopen()/seek()
+ * (formats_10.cpp:3352-3419, 2251-2262): stages the `.doc` bytes and the norm
+ * column into HBM and builds the per-term block directory ON THE GPU by
+ * walking block headers (bitpack.hpp:52-69).  Validates the file header
+ * (format_utils.cpp:74-105) and that `layout` matches its version. */
+int irs_hip_segment_open(const irs_hip_segment_desc* desc, irs_hip_segment** out);
+void irs_hip_segment_close(irs_hip_segment* seg);
+
+/* postings_reader::CountMappedMemory analogue: bytes resident in HBM. */
+uint64_t irs_hip_segment_device_bytes(const irs_hip_segment* seg);
+
+/* Replaces `postings_reader::iterator(...)` + `while (it->next())`
+ * (formats_10.cpp:3491-3533, 2089-2119): decodes the whole posting list of
+ * term ordinal `term` bit-exactly into host arrays. freqs may be NULL
+ * (iterator requested without IndexFeatures::FREQ). */
+int irs_hip_decode_term(irs_hip_segment* seg, uint32_t term, uint32_t* docs,
+                        uint32_t* freqs, uint32_t cap, uint32_t* count);
+
+/* The block directory of one term, for inspection/tests: absolute last doc id
+ * and `.doc` byte offset of every full 128-doc block — the information the
+ * reference keeps in skip level 0 (formats_10.cpp:501-533). */
+int irs_hip_term_directory(irs_hip_segment* seg, uint32_t term,
+                           uint32_t* last_docs, uint64_t* offsets, uint32_t cap,
+                           uint32_t* count);
+
+/* ------------------------------------------------------------ queries -- */
+
+typedef enum irs_hip_op {
+  IRS_HIP_OP_OR = 0, /* irs::Or / by_term: disjunction.hpp MakeDisjunction :1411-1467 */
+  IRS_HIP_OP_AND = 1 /* irs::And: conjunction.hpp MakeConjunction :436-490            */
+} irs_hip_op;
+
+/* Which ScoreFunction Scorer::prepare_scorer would have built. */
+typedef enum irs_hip_scorer_kind {
+  IRS_HIP_SCORE_BM25 = 0,      /* bm25.cpp:321-364; norm path by segment norm_width (:466-476);
+                                  no norm column => norm == 1 (:487-489)               */
+  IRS_HIP_SCORE_BM15 = 1,      /* bm25.cpp:288-319 (b == 0)                            */
+  IRS_HIP_SCORE_BM1 = 2,       /* bm25.cpp:262-286 (k == 0): constant                  */
+  IRS_HIP_SCORE_TFIDF = 3,     /* tfidf.cpp:185-187, 251                                */
+  IRS_HIP_SCORE_TFIDF_NORM = 4 /* tfidf.cpp:253, normalize() == true                   */
+} irs_hip_scorer_kind;
+
+/* One query term = the (term cookie, stats blob, boost) triple TermQuery::execute
+ * hands to postings()/CompileScore (term_query.cpp:35-74), flattened. */
+typedef struct irs_hip_term_scorer {
+  uint32_t term;      /* ordinal in the segment's term table; IRS_HIP_NO_TERM = absent here */
+  int32_t kind;       /* irs_hip_scorer_kind                                            */
+  float c0;           /* BM25: boost*(k+1)*idf (bm25.cpp:201); TFIDF: boost*idf (tfidf.cpp:199) */
+  float norm_const;   /* BM25Stats::norm_const  (bm25.hpp:52)                            */
+  float norm_length;  /* BM25Stats::norm_length (bm25.hpp:54)                            */
+} irs_hip_term_scorer;
+
+typedef struct irs_hip_query {
+  int32_t op;          /* irs_hip_op                                   */
+  uint32_t n_terms;    /* 1..IRS_HIP_MAX_TERMS                         */
+  uint32_t first_term; /* index of the first entry in the `terms` array */
+  uint32_t k;          /* top-k, 1..IRS_HIP_MAX_K (index-search --topN) */
+} irs_hip_query;
+
+/* (score, segment-local doc) exactly as utils/index-search.cpp:745-787 keeps. */
+typedef struct irs_hip_hit {
+  float score;
+  uint32_t doc;
+} irs_hip_hit;
+
+typedef struct irs_hip_batch irs_hip_batch; /* opaque: one batch of queries on one segment */
+
+/* Replaces, for a whole batch of prepared queries on one segment,
+ *   filter::prepared::execute(ExecutionContext{segment, scorers, wand}) and the
+ *   harness loop `while (docs->next()) { score; heap }` + final sort
+ *   (filter.hpp:52-78, utils/index-search.cpp:719-787).
+ * create : validates, uploads descriptors, sizes scratch (no query work).
+ * run    : enqueues every kernel of the batch on `stream` (a hipStream_t, may
+ *          be NULL = default stream); asynchronous.
+ * results: waits for the stream and copies the per-query top-k to the host:
+ *          hits[q * k_stride + i], i < counts[q], ordered (score desc, doc asc);
+ *          total_hits[q] = number of matching docs (index-search `hits=`).
+ * Results are deterministic: ties are broken by ascending doc id. */
+int irs_hip_batch_create(irs_hip_segment* seg, const irs_hip_query* queries,
+                         uint32_t n_queries, const irs_hip_term_scorer* terms,
+                         uint32_t n_term_entries, irs_hip_batch** out);
+int irs_hip_batch_run(irs_hip_batch* batch, void* stream);
+int irs_hip_batch_results(irs_hip_batch* batch, irs_hip_hit* hits,
+                          uint32_t k_stride, uint32_t* counts,
+                          uint64_t* total_hits);
+/* Device-resident results for a caller that merges on the GPU (RCCL path):
+ * d_hits is [n_queries][k_max] irs_hip_hit, d_counts [n_queries] uint32. */
+int irs_hip_batch_device_results(irs_hip_batch* batch, void** d_hits,
+                                 void** d_counts, uint32_t* k_max);
+void irs_hip_batch_destroy(irs_hip_batch* batch);
+
+/* Convenience: create + run + results + destroy. */
+int irs_hip_query_batch(irs_hip_segment* seg, const irs_hip_query* queries,
+                        uint32_t n_queries, const irs_hip_term_scorer* terms,
+                        uint32_t n_term_entries, irs_hip_hit* hits,
+                        uint32_t k_stride, uint32_t* counts,
+                        uint64_t* total_hits);
+
+/* Tuning knobs (0 keeps the default). tile_docs in {4096, 8192, 16384};
+ * pilot_stride P: every P-th doc tile is scored first to bound the k-th score
+ * (P == 1: exact two-pass); cand_cap: candidate slots per query. */
+int irs_hip_batch_configure(irs_hip_batch* batch, uint32_t tile_docs,
+                            uint32_t pilot_stride, uint32_t cand_cap);
+
+/* Kernel timing with HIP events recorded on the batch's own stream.
+ * When enabled, every run() brackets each kernel launch with events;
+ * timings() waits for the stream and returns the durations (ms) of the last run. */
+enum {
+  IRS_HIP_K_PLAN = 0,   /* block-range planning + tail decode       */
+  IRS_HIP_K_PILOT = 1,  /* pilot tiles -> per-query score threshold */
+  IRS_HIP_K_SCORE = 2,  /* decode + score + accumulate + candidates */
+  IRS_HIP_K_SELECT = 3, /* exact top-k of the candidates            */
+  IRS_HIP_K_COUNT = 4
+};
+int irs_hip_batch_profile(irs_hip_batch* batch, int enable);
+int irs_hip_batch_timings(irs_hip_batch* batch, float ms[IRS_HIP_K_COUNT]);
+/* Work accounting for the roofline: algorithmic bytes A(q)
+ * summed over the batch = posting bytes of every query term + 1 norm byte per
+ * posting (norm_width) + 8*k result bytes; and the number of postings. */
+int irs_hip_batch_work(irs_hip_batch* batch, uint64_t* algorithmic_bytes,
+                       uint64_t* postings);
+
+/* Multi-segment / multi-GPU merge: merges `n_lists` per-query
+ * top-k lists (device pointers, each [n_queries][k] hits + [n_queries] counts,
+ * list i belonging to segment ordinal seg_ids[i]) into the global top-k ordered
+ * (score desc, segment asc, doc asc) — the order tests/search/wand_test.cpp:72-86
+ * defines.  Outputs are device pointers: d_out [n_queries][k] hits,
+ * d_out_seg [n_queries][k] uint32, d_out_counts [n_queries]. */
+int irs_hip_merge_topk(int32_t device, const void* const* d_lists,
+                       const void* const* d_counts, const uint32_t* seg_ids,
+                       uint32_t n_lists, uint32_t n_queries, uint32_t k,
+                       void* d_out, void* d_out_seg, void* d_out_counts,
+                       void* stream);
+
+const char* irs_hip_strerror(int status);
+uint32_t irs_hip_abi_version(void);
+/* Name of the device the library would use, e.g. "gfx950"; EHIP when none. */
+int irs_hip_device_arch(int32_t device, char* buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IRS_HIP_H */

@@ -50,7 +50,7 @@ def hip_sources():
 
 
 def hip_deps():
-    return hip_sources() + sorted(HIP_DIR.glob("*.h")) + sorted((REPO / "include").glob("*.h"))
+    return hip_sources() + sorted(HIP_DIR.glob("*.h")) + sorted((HIP_DIR / "hip").glob("*.h")) + sorted((REPO / "include").glob("*.h"))
 
 
 def hipcc_path() -> str | None:
@@ -73,7 +73,7 @@ def build_hip(force: bool = False) -> Path:
     # and no FMA fusion, so per-term scores are bit-identical to the CPU path.
     _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
           "-ffp-contract=off", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
-          "-I", REPO / "include", "-I", HIP_DIR, "-o", HIP_LIB, *hip_sources()])
+          "-I", REPO / "include", "-I", HIP_DIR, "-I", HIP_DIR / "hip", "-o", HIP_LIB, *hip_sources()])
     return HIP_LIB
 
 

@@ -1,0 +1,115 @@
+"""ctypes binding of the C ABI in include/irs_hip.h.
+
+The product library is iresearch_amd/csrc/libirs_hip.so (hipcc, gfx950).  It is
+the only library this module ever loads by itself, and loading it — or opening a
+segment on a machine without a gfx950 GPU — fails loudly: there is no CPU
+fallback.  (`bind()` is exposed so that the CPU-only test tier can attach the
+same prototypes to the fiber-emulator build under tests/sim.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _build
+
+OK, EINVAL, ECORRUPT, ENOMEM, EHIP, EOVERFLOW, EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
+LAYOUT_SCALAR, LAYOUT_SIMD4 = 0, 1
+OP_OR, OP_AND = 0, 1
+SCORE_BM25, SCORE_BM15, SCORE_BM1, SCORE_TFIDF, SCORE_TFIDF_NORM = 0, 1, 2, 3, 4
+NO_TERM = 0xFFFFFFFF
+MAX_TERMS, MAX_K = 16, 4096
+K_PLAN, K_PILOT, K_SCORE, K_SELECT, K_COUNT = 0, 1, 2, 3, 4
+KERNEL_NAMES = ("k_plan", "k_pilot", "k_score", "k_select")
+
+TERM_META = np.dtype(
+    [("docs_count", "<u4"), ("freq", "<u4"), ("doc_start", "<u8"), ("pos_start", "<u8"),
+     ("pos_end", "<u8"), ("pay_start", "<u8"), ("e_skip_start", "<u8")], align=True)
+TERM_SCORER = np.dtype(
+    [("term", "<u4"), ("kind", "<i4"), ("c0", "<f4"), ("norm_const", "<f4"),
+     ("norm_length", "<f4")], align=True)
+QUERY = np.dtype([("op", "<i4"), ("n_terms", "<u4"), ("first_term", "<u4"), ("k", "<u4")],
+                 align=True)
+HIT = np.dtype([("score", "<f4"), ("doc", "<u4")], align=True)
+assert TERM_META.itemsize == 48 and TERM_SCORER.itemsize == 20
+assert QUERY.itemsize == 16 and HIT.itemsize == 8
+
+
+class SegmentDesc(C.Structure):
+    _fields_ = [
+        ("device", C.c_int32), ("layout", C.c_int32), ("doc_file", C.c_void_p),
+        ("doc_file_len", C.c_uint64), ("num_docs", C.c_uint32), ("has_freq", C.c_uint32),
+        ("norms", C.c_void_p), ("norm_width", C.c_uint32), ("norm_min_doc", C.c_uint32),
+        ("norm_count", C.c_uint64), ("terms", C.c_void_p), ("num_terms", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+class IrsHipError(RuntimeError):
+    def __init__(self, status: int, what: str, message: str):
+        super().__init__("%s: %s (%d)" % (what, message, status))
+        self.status = status
+
+
+SYMBOLS = (
+    "irs_hip_abi_version", "irs_hip_strerror", "irs_hip_device_arch", "irs_hip_segment_open",
+    "irs_hip_segment_close", "irs_hip_segment_device_bytes", "irs_hip_decode_term",
+    "irs_hip_term_directory", "irs_hip_batch_create", "irs_hip_batch_run",
+    "irs_hip_batch_results", "irs_hip_batch_device_results", "irs_hip_batch_destroy",
+    "irs_hip_query_batch", "irs_hip_batch_configure", "irs_hip_batch_profile",
+    "irs_hip_batch_timings", "irs_hip_batch_work", "irs_hip_merge_topk",
+)
+
+
+def bind(L: C.CDLL) -> C.CDLL:
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
+    P = C.POINTER
+    L.irs_hip_abi_version.argtypes, L.irs_hip_abi_version.restype = [], u32
+    L.irs_hip_strerror.argtypes, L.irs_hip_strerror.restype = [C.c_int], C.c_char_p
+    L.irs_hip_device_arch.argtypes, L.irs_hip_device_arch.restype = [i32, C.c_char_p, C.c_size_t], C.c_int
+    L.irs_hip_segment_open.argtypes = [P(SegmentDesc), P(vp)]
+    L.irs_hip_segment_open.restype = C.c_int
+    L.irs_hip_segment_close.argtypes, L.irs_hip_segment_close.restype = [vp], None
+    L.irs_hip_segment_device_bytes.argtypes = [vp]
+    L.irs_hip_segment_device_bytes.restype = u64
+    L.irs_hip_decode_term.argtypes = [vp, u32, vp, vp, u32, P(u32)]
+    L.irs_hip_decode_term.restype = C.c_int
+    L.irs_hip_term_directory.argtypes = [vp, u32, vp, vp, u32, P(u32)]
+    L.irs_hip_term_directory.restype = C.c_int
+    L.irs_hip_batch_create.argtypes = [vp, vp, u32, vp, u32, P(vp)]
+    L.irs_hip_batch_create.restype = C.c_int
+    L.irs_hip_batch_run.argtypes, L.irs_hip_batch_run.restype = [vp, vp], C.c_int
+    L.irs_hip_batch_results.argtypes = [vp, vp, u32, vp, vp]
+    L.irs_hip_batch_results.restype = C.c_int
+    L.irs_hip_batch_device_results.argtypes = [vp, P(vp), P(vp), P(u32)]
+    L.irs_hip_batch_device_results.restype = C.c_int
+    L.irs_hip_batch_destroy.argtypes, L.irs_hip_batch_destroy.restype = [vp], None
+    L.irs_hip_query_batch.argtypes = [vp, vp, u32, vp, u32, vp, u32, vp, vp]
+    L.irs_hip_query_batch.restype = C.c_int
+    L.irs_hip_batch_configure.argtypes = [vp, u32, u32, u32]
+    L.irs_hip_batch_configure.restype = C.c_int
+    L.irs_hip_batch_profile.argtypes, L.irs_hip_batch_profile.restype = [vp, C.c_int], C.c_int
+    L.irs_hip_batch_timings.argtypes = [vp, P(C.c_float)]
+    L.irs_hip_batch_timings.restype = C.c_int
+    L.irs_hip_batch_work.argtypes = [vp, P(u64), P(u64)]
+    L.irs_hip_batch_work.restype = C.c_int
+    L.irs_hip_merge_topk.argtypes = [i32, vp, vp, vp, u32, u32, u32, vp, vp, vp, vp]
+    L.irs_hip_merge_topk.restype = C.c_int
+    return L
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """The product library. Raises if it cannot be built/loaded."""
+    global _lib
+    if _lib is None:
+        _lib = bind(C.CDLL(str(_build.build_hip())))
+    return _lib
+
+
+def check(L: C.CDLL, status: int, what: str):
+    if status != OK:
+        raise IrsHipError(status, what, L.irs_hip_strerror(status).decode())

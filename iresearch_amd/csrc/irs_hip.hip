@@ -1,0 +1,704 @@
+// irs_hip.hip — host side of the C ABI declared in include/irs_hip.h:
+// staging into HBM, kernel orchestration on a HIP stream, result hand-back.
+// Nothing here touches oracle/; there is no CPU execution path.
+#include "irs_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "gpu_rt.h"
+#include "kernels.h"
+
+using namespace irs_hip;
+
+namespace {
+
+constexpr uint32_t kDefaultTile = 8192;
+constexpr uint32_t kDefaultStride = 16;
+
+struct DevBuf {  // owning device allocation
+  void* p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { rt::dfree(p); }
+  bool alloc(size_t bytes) {
+    rt::dfree(p);
+    p = rt::dmalloc(bytes);
+    n = p ? bytes : 0;
+    return p != nullptr;
+  }
+  void release() {
+    rt::dfree(p);
+    p = nullptr;
+    n = 0;
+  }
+  template<typename T>
+  T* as() const { return static_cast<T*>(p); }
+};
+
+bool device_usable(int device) {
+  if (device < 0 || device >= rt::device_count()) return false;
+  char arch[64] = {0};
+  if (!rt::device_arch(device, arch, sizeof arch)) return false;
+  // gfx950 only (the sim runtime of the CPU test tier reports "gfx950-sim")
+  if (std::strncmp(arch, "gfx950", 6) != 0) return false;
+  return rt::set_device(device);
+}
+
+// format_utils::check_header for `.doc` (format_utils.cpp:74-105,
+// formats_10.cpp:325-326, 3356-3361); returns header length or 0.
+size_t check_doc_header(const uint8_t* f, uint64_t len, int32_t* version) {
+  static const char name[] = "iresearch_10_postings_documents";
+  const size_t nlen = sizeof(name) - 1;
+  if (len < 4 + 1 + nlen + 4 + 16) return 0;
+  const uint32_t magic = (uint32_t(f[0]) << 24) | (uint32_t(f[1]) << 16) |
+                         (uint32_t(f[2]) << 8) | f[3];
+  if (magic != 0x3fd76c17u) return 0;
+  if (f[4] != nlen || std::memcmp(f + 5, name, nlen) != 0) return 0;
+  const uint8_t* v = f + 5 + nlen;
+  *version = int32_t((uint32_t(v[0]) << 24) | (uint32_t(v[1]) << 16) |
+                     (uint32_t(v[2]) << 8) | v[3]);
+  return 5 + nlen + 4;
+}
+
+}  // namespace
+
+struct irs_hip_segment {
+  int device = 0;
+  DevSegment dev{};
+  DevBuf d_doc, d_norms, d_terms, d_blk_off, d_blk_last, d_blk_bits, d_status;
+  std::vector<DevTerm> terms;  // host mirror incl. the fields the dir kernel filled
+  uint64_t total_blocks = 0;
+  uint64_t device_bytes = 0;
+};
+
+struct irs_hip_batch {
+  irs_hip_segment* seg = nullptr;
+  uint32_t nq = 0, jt = 0, k_max = 0;
+  uint32_t tile = kDefaultTile, stride = kDefaultStride, cand_cap = 0;
+  uint32_t n_tiles = 0;
+  bool any_and = false;
+  bool scratch_ready = false;
+  std::vector<DevQuery> queries;
+  std::vector<DevQTerm> qterms;
+  DevBuf d_queries, d_qterms, d_first, d_tails, d_bstar, d_cands, d_cand_count, d_hits,
+    d_out, d_out_count, d_status;
+  uint64_t alg_bytes = 0, postings = 0;
+  bool profile = false;
+  bool events_ready = false;
+  rt::event_t ev[2 * IRS_HIP_K_COUNT];
+  rt::stream_t stream = nullptr;
+  bool ran = false;
+};
+
+namespace {
+
+template<int LAYOUT>
+int build_directory(irs_hip_segment* s) {
+  const uint32_t grid = (s->dev.num_terms + kWaves - 1) / kWaves;
+  if (!rt::dmemset(s->d_status.p, 0, 4, nullptr)) return IRS_HIP_EHIP;
+  if (grid) {
+    RT_LAUNCH((k_build_directory<LAYOUT>), grid, kThreads, 0, nullptr, s->dev,
+              s->d_terms.as<DevTerm>(), s->d_blk_off.as<uint32_t>(),
+              s->d_blk_last.as<uint32_t>(), s->d_blk_bits.as<uint16_t>(),
+              s->d_status.as<uint32_t>());
+  }
+  if (!rt::last_error_ok()) return IRS_HIP_EHIP;
+  uint32_t status = 0;
+  if (!rt::d2h(&status, s->d_status.p, 4, nullptr) ||
+      !rt::d2h(s->terms.data(), s->d_terms.p, s->terms.size() * sizeof(DevTerm), nullptr) ||
+      !rt::sync(nullptr))
+    return IRS_HIP_EHIP;
+  if (status & kStatusCorrupt) return IRS_HIP_ECORRUPT;
+  for (const DevTerm& t : s->terms) {
+    if (t.docs_count && (t.last_doc > s->dev.num_docs || t.last_doc < kDocMin))
+      return IRS_HIP_ECORRUPT;
+  }
+  return IRS_HIP_OK;
+}
+
+template<typename K>
+bool big_smem(K kernel, size_t bytes) {
+  return rt::allow_dynamic_smem(reinterpret_cast<const void*>(kernel), bytes);
+}
+
+// launch helpers: one instantiation per (layout, tile, AND)
+template<int LAYOUT, int TILE, bool AND>
+bool launch_pilot(irs_hip_batch* b, rt::stream_t st) {
+  const size_t smem = tile_smem_bytes<TILE, AND>() + kBins * sizeof(uint32_t);
+  auto kern = k_pilot<LAYOUT, TILE, AND>;
+  if (!big_smem(kern, smem)) return false;
+  RT_LAUNCH(kern, b->nq, kThreads, smem, st, b->seg->dev, b->d_queries.as<DevQuery>(),
+            b->d_qterms.as<DevQTerm>(), b->jt, b->n_tiles, b->stride,
+            b->d_first.as<uint32_t>(), b->d_tails.as<DevTail>(), b->d_bstar.as<uint32_t>());
+  return rt::last_error_ok();
+}
+
+template<int LAYOUT, int TILE, bool AND>
+bool launch_score(irs_hip_batch* b, rt::stream_t st) {
+  const size_t smem = tile_smem_bytes<TILE, AND>() + kLocalCands * sizeof(uint64_t) + 16;
+  auto kern = k_score<LAYOUT, TILE, AND>;
+  if (!big_smem(kern, smem)) return false;
+  const uint64_t n_work64 = uint64_t(b->nq) * b->n_tiles;
+  if (n_work64 > 0x7FFFFFF0ull) return false;
+  const uint32_t n_work = uint32_t(n_work64);
+  const uint32_t grid = ((n_work + 7u) / 8u) * 8u;
+  RT_LAUNCH(kern, grid, kThreads, smem, st, b->seg->dev, b->d_queries.as<DevQuery>(),
+            b->d_qterms.as<DevQTerm>(), b->jt, b->n_tiles, n_work,
+            b->d_first.as<uint32_t>(), b->d_tails.as<DevTail>(), b->d_bstar.as<uint32_t>(),
+            b->d_cands.as<uint64_t>(), b->cand_cap, b->d_cand_count.as<uint32_t>(),
+            b->d_hits.as<unsigned long long>());
+  return rt::last_error_ok();
+}
+
+template<int LAYOUT, int TILE>
+bool launch_pilot_and(irs_hip_batch* b, rt::stream_t st) {
+  return b->any_and ? launch_pilot<LAYOUT, TILE, true>(b, st)
+                    : launch_pilot<LAYOUT, TILE, false>(b, st);
+}
+template<int LAYOUT, int TILE>
+bool launch_score_and(irs_hip_batch* b, rt::stream_t st) {
+  return b->any_and ? launch_score<LAYOUT, TILE, true>(b, st)
+                    : launch_score<LAYOUT, TILE, false>(b, st);
+}
+template<int LAYOUT>
+bool launch_pilot_tile(irs_hip_batch* b, rt::stream_t st) {
+  switch (b->tile) {
+    case 4096: return launch_pilot_and<LAYOUT, 4096>(b, st);
+    case 16384: return launch_pilot_and<LAYOUT, 16384>(b, st);
+    default: return launch_pilot_and<LAYOUT, 8192>(b, st);
+  }
+}
+template<int LAYOUT>
+bool launch_score_tile(irs_hip_batch* b, rt::stream_t st) {
+  switch (b->tile) {
+    case 4096: return launch_score_and<LAYOUT, 4096>(b, st);
+    case 16384: return launch_score_and<LAYOUT, 16384>(b, st);
+    default: return launch_score_and<LAYOUT, 8192>(b, st);
+  }
+}
+
+bool ensure_scratch(irs_hip_batch* b) {
+  if (b->scratch_ready) return true;
+  const irs_hip_segment* s = b->seg;
+  b->n_tiles = (s->dev.num_docs + b->tile - 1) / b->tile;
+  if (b->cand_cap == 0) {
+    uint64_t cap = 4ull * b->stride * b->k_max;
+    cap = std::min<uint64_t>(std::max<uint64_t>(cap, 16384), 262144);
+    b->cand_cap = uint32_t(cap);
+  }
+  const uint64_t rows = uint64_t(b->nq) * b->jt;
+  if (!b->d_first.alloc(rows * (b->n_tiles + 1) * sizeof(uint32_t)) ||
+      !b->d_tails.alloc(rows * sizeof(DevTail)) ||
+      !b->d_bstar.alloc(b->nq * sizeof(uint32_t)) ||
+      !b->d_cands.alloc(uint64_t(b->nq) * b->cand_cap * sizeof(uint64_t)) ||
+      !b->d_cand_count.alloc(b->nq * sizeof(uint32_t)) ||
+      !b->d_hits.alloc(b->nq * sizeof(uint64_t)) ||
+      !b->d_out.alloc(uint64_t(b->nq) * b->k_max * sizeof(Hit)) ||
+      !b->d_out_count.alloc(b->nq * sizeof(uint32_t)) || !b->d_status.alloc(4))
+    return false;
+  b->scratch_ready = true;
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t irs_hip_abi_version(void) { return IRS_HIP_ABI_VERSION; }
+
+const char* irs_hip_strerror(int status) {
+  switch (status) {
+    case IRS_HIP_OK: return "ok";
+    case IRS_HIP_EINVAL: return "invalid argument";
+    case IRS_HIP_ECORRUPT: return "corrupt postings data";
+    case IRS_HIP_ENOMEM: return "out of memory";
+    case IRS_HIP_EHIP: return "HIP runtime error or no gfx950 device";
+    case IRS_HIP_EOVERFLOW: return "candidate buffer overflow";
+    case IRS_HIP_EUNSUPPORTED: return "unsupported";
+    default: return "unknown status";
+  }
+}
+
+int irs_hip_device_arch(int32_t device, char* buf, size_t cap) {
+  if (!buf || !cap) return IRS_HIP_EINVAL;
+  if (device < 0 || device >= rt::device_count() || !rt::device_arch(device, buf, cap))
+    return IRS_HIP_EHIP;
+  return IRS_HIP_OK;
+}
+
+int irs_hip_segment_open(const irs_hip_segment_desc* d, irs_hip_segment** out) {
+  if (!d || !out) return IRS_HIP_EINVAL;
+  *out = nullptr;
+  if (!d->doc_file || !d->num_docs || d->num_docs > 0x7FFF0000u ||
+      (d->layout != IRS_HIP_LAYOUT_SCALAR && d->layout != IRS_HIP_LAYOUT_SIMD4) ||
+      (d->num_terms && !d->terms))
+    return IRS_HIP_EINVAL;
+  if (d->norms) {
+    if (d->norm_width != 1 && d->norm_width != 2 && d->norm_width != 4) return IRS_HIP_EINVAL;
+    // dense column covering every doc (columnstore2.cpp:650-789); sparse columns
+    // are not on the benchmark path
+    if (d->norm_min_doc != kDocMin || d->norm_count < d->num_docs) return IRS_HIP_EUNSUPPORTED;
+  }
+  int32_t version = -1;
+  const size_t hdr = check_doc_header(d->doc_file, d->doc_file_len, &version);
+  if (!hdr) return IRS_HIP_ECORRUPT;
+  // PostingsFormat: odd versions are the SSE (simd4) layouts (formats_10.cpp:283-313)
+  if (version < 0 || version > 5) return IRS_HIP_ECORRUPT;
+  if ((version & 1) != (d->layout == IRS_HIP_LAYOUT_SIMD4 ? 1 : 0)) return IRS_HIP_EINVAL;
+  if (!device_usable(d->device)) return IRS_HIP_EHIP;
+
+  irs_hip_segment* s = new (std::nothrow) irs_hip_segment;
+  if (!s) return IRS_HIP_ENOMEM;
+  s->device = d->device;
+  int rc = IRS_HIP_OK;
+  do {
+    try {
+      s->terms.resize(d->num_terms);
+    } catch (...) {
+      rc = IRS_HIP_ENOMEM;
+      break;
+    }
+    uint64_t blocks = 0;
+    for (uint32_t i = 0; i < d->num_terms && rc == IRS_HIP_OK; ++i) {
+      const irs_hip_term_meta& m = d->terms[i];
+      DevTerm t{};
+      t.docs_count = m.docs_count;
+      if (m.docs_count == 1) {
+        t.single_doc = kDocMin + uint32_t(m.e_skip_start);  // formats_10.cpp:1887
+        t.single_freq = m.freq;
+        t.doc_start = 0;
+      } else if (m.docs_count > 1) {
+        if (m.doc_start < hdr || m.doc_start >= d->doc_file_len) rc = IRS_HIP_ECORRUPT;
+        t.doc_start = m.doc_start;
+        t.nblk = m.docs_count / kBlock;
+        t.tail_n = m.docs_count % kBlock;
+        t.dir_off = blocks;
+        blocks += t.nblk;
+        // block offsets are kept as u32 relative to doc_start
+        if (m.docs_count > kBlock && m.e_skip_start > 0xFFFFFFFFull) rc = IRS_HIP_EUNSUPPORTED;
+      }
+      s->terms[i] = t;
+    }
+    if (rc != IRS_HIP_OK) break;
+    s->total_blocks = blocks;
+    const uint64_t norm_bytes = d->norms ? uint64_t(d->norm_width) * d->norm_count : 0;
+    if (!s->d_doc.alloc(d->doc_file_len + kPadBytes) ||
+        (d->norms && !s->d_norms.alloc(norm_bytes + kPadBytes)) ||
+        !s->d_terms.alloc(std::max<size_t>(1, s->terms.size()) * sizeof(DevTerm)) ||
+        !s->d_blk_off.alloc((blocks + 1) * 4) || !s->d_blk_last.alloc((blocks + 1) * 4) ||
+        !s->d_blk_bits.alloc((blocks + 1) * 2) || !s->d_status.alloc(4)) {
+      rc = IRS_HIP_ENOMEM;
+      break;
+    }
+    bool okc = rt::h2d(s->d_doc.p, d->doc_file, d->doc_file_len, nullptr) &&
+               rt::dmemset(s->d_doc.as<uint8_t>() + d->doc_file_len, 0, kPadBytes, nullptr) &&
+               rt::h2d(s->d_terms.p, s->terms.data(), s->terms.size() * sizeof(DevTerm), nullptr);
+    if (d->norms) {
+      okc = okc && rt::h2d(s->d_norms.p, d->norms, norm_bytes, nullptr) &&
+            rt::dmemset(s->d_norms.as<uint8_t>() + norm_bytes, 0, kPadBytes, nullptr);
+    }
+    if (!okc || !rt::sync(nullptr)) {
+      rc = IRS_HIP_EHIP;
+      break;
+    }
+    DevSegment& v = s->dev;
+    v.doc = s->d_doc.as<uint8_t>();
+    v.doc_len = d->doc_file_len;
+    v.norms = d->norms ? s->d_norms.as<uint8_t>() : nullptr;
+    v.norm_width = d->norms ? d->norm_width : 0;
+    v.norm_min_doc = d->norms ? d->norm_min_doc : kDocMin;
+    v.norm_count = d->norms ? d->norm_count : 0;
+    v.terms = s->d_terms.as<DevTerm>();
+    v.num_terms = d->num_terms;
+    v.num_docs = d->num_docs;
+    v.blk_off = s->d_blk_off.as<uint32_t>();
+    v.blk_last = s->d_blk_last.as<uint32_t>();
+    v.blk_bits = s->d_blk_bits.as<uint16_t>();
+    v.has_freq = d->has_freq ? 1 : 0;
+    v.layout = d->layout;
+    rc = d->layout == IRS_HIP_LAYOUT_SIMD4 ? build_directory<kSimd4>(s)
+                                           : build_directory<kScalar>(s);
+    s->device_bytes = s->d_doc.n + s->d_norms.n + s->d_terms.n + s->d_blk_off.n +
+                      s->d_blk_last.n + s->d_blk_bits.n;
+  } while (false);
+  if (rc != IRS_HIP_OK) {
+    delete s;
+    return rc;
+  }
+  *out = s;
+  return IRS_HIP_OK;
+}
+
+void irs_hip_segment_close(irs_hip_segment* seg) {
+  if (!seg) return;
+  rt::set_device(seg->device);
+  delete seg;
+}
+
+uint64_t irs_hip_segment_device_bytes(const irs_hip_segment* seg) {
+  return seg ? seg->device_bytes : 0;
+}
+
+int irs_hip_decode_term(irs_hip_segment* seg, uint32_t term, uint32_t* docs, uint32_t* freqs,
+                        uint32_t cap, uint32_t* count) {
+  if (!seg || !docs || !count || term >= seg->dev.num_terms) return IRS_HIP_EINVAL;
+  if (freqs && !seg->dev.has_freq) return IRS_HIP_EINVAL;
+  if (!rt::set_device(seg->device)) return IRS_HIP_EHIP;
+  const DevTerm& t = seg->terms[term];
+  *count = t.docs_count;
+  if (t.docs_count == 0) return IRS_HIP_OK;
+  if (cap < t.docs_count) return IRS_HIP_EINVAL;
+  DevBuf dd, df;
+  const size_t bytes = size_t(t.docs_count) * 4;
+  if (!dd.alloc(bytes) || (freqs && !df.alloc(bytes))) return IRS_HIP_ENOMEM;
+  const uint32_t items = t.nblk + 1;
+  const uint32_t grid = (items + kWaves - 1) / kWaves;
+  if (seg->dev.layout == kSimd4) {
+    RT_LAUNCH((k_decode_term<kSimd4>), grid, kThreads, 0, nullptr, seg->dev, term,
+              dd.as<uint32_t>(), freqs ? df.as<uint32_t>() : nullptr);
+  } else {
+    RT_LAUNCH((k_decode_term<kScalar>), grid, kThreads, 0, nullptr, seg->dev, term,
+              dd.as<uint32_t>(), freqs ? df.as<uint32_t>() : nullptr);
+  }
+  if (!rt::last_error_ok() || !rt::d2h(docs, dd.p, bytes, nullptr) ||
+      (freqs && !rt::d2h(freqs, df.p, bytes, nullptr)) || !rt::sync(nullptr))
+    return IRS_HIP_EHIP;
+  return IRS_HIP_OK;
+}
+
+int irs_hip_term_directory(irs_hip_segment* seg, uint32_t term, uint32_t* last_docs,
+                           uint64_t* offsets, uint32_t cap, uint32_t* count) {
+  if (!seg || !count || term >= seg->dev.num_terms) return IRS_HIP_EINVAL;
+  if (!rt::set_device(seg->device)) return IRS_HIP_EHIP;
+  const DevTerm& t = seg->terms[term];
+  *count = t.nblk;
+  if (!t.nblk) return IRS_HIP_OK;
+  if (cap < t.nblk || !last_docs || !offsets) return IRS_HIP_EINVAL;
+  std::vector<uint32_t> rel(t.nblk);
+  if (!rt::d2h(last_docs, seg->d_blk_last.as<uint32_t>() + t.dir_off, size_t(t.nblk) * 4,
+               nullptr) ||
+      !rt::d2h(rel.data(), seg->d_blk_off.as<uint32_t>() + t.dir_off, size_t(t.nblk) * 4,
+               nullptr) ||
+      !rt::sync(nullptr))
+    return IRS_HIP_EHIP;
+  for (uint32_t i = 0; i < t.nblk; ++i) offsets[i] = t.doc_start + rel[i];
+  return IRS_HIP_OK;
+}
+
+// ----------------------------------------------------------------- batch --
+
+int irs_hip_batch_create(irs_hip_segment* seg, const irs_hip_query* queries, uint32_t nq,
+                         const irs_hip_term_scorer* terms, uint32_t n_entries,
+                         irs_hip_batch** out) {
+  if (!seg || !queries || !terms || !out || !nq) return IRS_HIP_EINVAL;
+  *out = nullptr;
+  if (!seg->dev.has_freq) return IRS_HIP_EUNSUPPORTED;  // scorers need IndexFeatures::FREQ
+  if (!rt::set_device(seg->device)) return IRS_HIP_EHIP;
+  irs_hip_batch* b = new (std::nothrow) irs_hip_batch;
+  if (!b) return IRS_HIP_ENOMEM;
+  b->seg = seg;
+  b->nq = nq;
+  int rc = IRS_HIP_OK;
+  try {
+    b->queries.resize(nq);
+    b->qterms.reserve(n_entries);
+    for (uint32_t q = 0; q < nq && rc == IRS_HIP_OK; ++q) {
+      const irs_hip_query& in = queries[q];
+      if ((in.op != IRS_HIP_OP_OR && in.op != IRS_HIP_OP_AND) || in.n_terms == 0 ||
+          in.n_terms > IRS_HIP_MAX_TERMS || in.k == 0 || in.k > IRS_HIP_MAX_K ||
+          uint64_t(in.first_term) + in.n_terms > n_entries) {
+        rc = IRS_HIP_EINVAL;
+        break;
+      }
+      std::vector<DevQTerm> row;
+      bool absent = false;
+      double upper = 0.0;
+      for (uint32_t j = 0; j < in.n_terms; ++j) {
+        const irs_hip_term_scorer& ts = terms[in.first_term + j];
+        DevQTerm qt{};
+        qt.term = ts.term;
+        qt.c0 = ts.c0;
+        qt.norm_const = ts.norm_const;
+        qt.norm_length = ts.norm_length;
+        qt.cache_id = kMaxCaches;
+        if (ts.term != IRS_HIP_NO_TERM && ts.term >= seg->dev.num_terms) rc = IRS_HIP_EINVAL;
+        if (!(ts.c0 >= 0.f) || !std::isfinite(ts.c0)) rc = IRS_HIP_EINVAL;
+        if (rc != IRS_HIP_OK) break;
+        // a zero score would be indistinguishable from "no match" in the accumulators
+        if (ts.c0 == 0.f) rc = IRS_HIP_EUNSUPPORTED;
+        const bool norms = seg->dev.norms != nullptr;
+        switch (ts.kind) {
+          case IRS_HIP_SCORE_BM25:
+            qt.kind = norms ? (seg->dev.norm_width == 1 ? kBM25Tiny : kBM25Wide) : kBM25One;
+            if (!(ts.norm_const + ts.norm_length > 0.f)) rc = IRS_HIP_EINVAL;
+            break;
+          case IRS_HIP_SCORE_BM15:
+            qt.kind = kBM15;
+            if (!(ts.norm_const > 0.f)) rc = IRS_HIP_EINVAL;
+            break;
+          case IRS_HIP_SCORE_BM1: qt.kind = kBM1; break;
+          case IRS_HIP_SCORE_TFIDF: qt.kind = kTfidf; break;
+          case IRS_HIP_SCORE_TFIDF_NORM:
+            qt.kind = norms ? (seg->dev.norm_width == 1 ? kTfidfTiny : kTfidfWide) : kTfidf;
+            break;
+          default: rc = IRS_HIP_EINVAL;
+        }
+        if (rc != IRS_HIP_OK) break;
+        // TermQuery::execute: no term state in this segment -> empty iterator
+        // (term_query.cpp:41-43)
+        if (qt.term == IRS_HIP_NO_TERM || seg->terms[qt.term].docs_count == 0) {
+          absent = true;
+          continue;
+        }
+        const DevTerm& t = seg->terms[qt.term];
+        const bool tfidf = qt.kind == kTfidf || qt.kind == kTfidfTiny || qt.kind == kTfidfWide;
+        upper += tfidf ? double(qt.c0) * std::sqrt(double(t.tf_bound)) : double(qt.c0);
+        b->postings += t.docs_count;
+        b->alg_bytes += uint64_t(t.blocks_bytes) + t.tail_bytes;
+        if (qt.kind == kBM25Tiny || qt.kind == kBM25Wide || qt.kind == kTfidfTiny ||
+            qt.kind == kTfidfWide)
+          b->alg_bytes += uint64_t(t.docs_count) * seg->dev.norm_width;
+        row.push_back(qt);
+      }
+      if (rc != IRS_HIP_OK) break;
+      b->alg_bytes += 8ull * in.k;
+      DevQuery& dq = b->queries[q];
+      dq.op = in.op;
+      dq.k = in.k;
+      if (in.op == IRS_HIP_OP_AND) {
+        // MakeScoreAdapters<true>: one empty sub-iterator empties the conjunction
+        // (boolean_query.cpp:50-53); MakeConjunction sorts by cost (conjunction.hpp:450-453)
+        if (absent) row.clear();
+        std::stable_sort(row.begin(), row.end(), [&](const DevQTerm& x, const DevQTerm& y) {
+          return seg->terms[x.term].docs_count < seg->terms[y.term].docs_count;
+        });
+        b->any_and = true;
+      }
+      // norm_cache slots: one per distinct (norm_const, norm_length)
+      uint32_t n_caches = 0;
+      float cnc[kMaxCaches], cnl[kMaxCaches];
+      for (DevQTerm& qt : row) {
+        if (qt.kind != kBM25Tiny) continue;
+        uint32_t c = 0;
+        for (; c < n_caches; ++c)
+          if (cnc[c] == qt.norm_const && cnl[c] == qt.norm_length) break;
+        if (c == n_caches && n_caches < kMaxCaches) {
+          cnc[c] = qt.norm_const;
+          cnl[c] = qt.norm_length;
+          ++n_caches;
+        }
+        qt.cache_id = c < kMaxCaches ? c : kMaxCaches;
+      }
+      dq.n_caches = n_caches;
+      dq.n_terms = uint32_t(row.size());
+      dq.first_term = uint32_t(b->qterms.size());
+      upper *= 1.0 + 1e-6;
+      if (!row.empty() && !(upper > 0.0 && std::isfinite(upper))) {
+        rc = IRS_HIP_EUNSUPPORTED;
+        break;
+      }
+      dq.bin_scale = row.empty() ? 0.f : float(double(kBins) / upper);
+      b->qterms.insert(b->qterms.end(), row.begin(), row.end());
+      b->jt = std::max(b->jt, dq.n_terms);
+      b->k_max = std::max(b->k_max, in.k);
+    }
+  } catch (...) {
+    rc = IRS_HIP_ENOMEM;
+  }
+  if (rc == IRS_HIP_OK) {
+    if (b->jt == 0) b->jt = 1;
+    if (b->qterms.empty()) b->qterms.push_back(DevQTerm{});
+    if (!b->d_queries.alloc(b->queries.size() * sizeof(DevQuery)) ||
+        !b->d_qterms.alloc(b->qterms.size() * sizeof(DevQTerm))) {
+      rc = IRS_HIP_ENOMEM;
+    } else if (!rt::h2d(b->d_queries.p, b->queries.data(), b->queries.size() * sizeof(DevQuery),
+                        nullptr) ||
+               !rt::h2d(b->d_qterms.p, b->qterms.data(), b->qterms.size() * sizeof(DevQTerm),
+                        nullptr) ||
+               !rt::sync(nullptr)) {
+      rc = IRS_HIP_EHIP;
+    }
+  }
+  if (rc != IRS_HIP_OK) {
+    delete b;
+    return rc;
+  }
+  *out = b;
+  return IRS_HIP_OK;
+}
+
+int irs_hip_batch_configure(irs_hip_batch* b, uint32_t tile_docs, uint32_t pilot_stride,
+                            uint32_t cand_cap) {
+  if (!b) return IRS_HIP_EINVAL;
+  if (tile_docs && tile_docs != 4096 && tile_docs != 8192 && tile_docs != 16384)
+    return IRS_HIP_EINVAL;
+  if (cand_cap && cand_cap < b->k_max) return IRS_HIP_EINVAL;
+  if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
+  if (b->ran && !rt::sync(b->stream)) return IRS_HIP_EHIP;
+  if (tile_docs) b->tile = tile_docs;
+  if (pilot_stride) b->stride = pilot_stride;
+  b->cand_cap = cand_cap;
+  b->scratch_ready = false;
+  return IRS_HIP_OK;
+}
+
+int irs_hip_batch_profile(irs_hip_batch* b, int enable) {
+  if (!b) return IRS_HIP_EINVAL;
+  if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
+  if (enable && !b->events_ready) {
+    for (auto& e : b->ev)
+      if (!rt::event_create(&e)) return IRS_HIP_EHIP;
+    b->events_ready = true;
+  }
+  b->profile = enable != 0;
+  return IRS_HIP_OK;
+}
+
+int irs_hip_batch_run(irs_hip_batch* b, void* stream) {
+  if (!b) return IRS_HIP_EINVAL;
+  if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
+  if (!ensure_scratch(b)) return IRS_HIP_ENOMEM;
+  rt::stream_t st = static_cast<rt::stream_t>(stream);
+  b->stream = st;
+  const bool simd = b->seg->dev.layout == kSimd4;
+  auto mark = [&](int i) { return !b->profile || rt::event_record(b->ev[i], st); };
+  bool ok = rt::dmemset(b->d_cand_count.p, 0, b->d_cand_count.n, st) &&
+            rt::dmemset(b->d_hits.p, 0, b->d_hits.n, st) &&
+            rt::dmemset(b->d_status.p, 0, 4, st);
+  // 1. plan: tile -> first block tables, tail decode
+  ok = ok && mark(2 * IRS_HIP_K_PLAN);
+  if (ok) {
+    RT_LAUNCH(k_plan, b->nq * b->jt, kThreads, 0, st, b->seg->dev, b->d_queries.as<DevQuery>(),
+              b->d_qterms.as<DevQTerm>(), b->jt, b->tile, b->n_tiles, b->d_first.as<uint32_t>(),
+              b->d_tails.as<DevTail>());
+    ok = rt::last_error_ok();
+  }
+  ok = ok && mark(2 * IRS_HIP_K_PLAN + 1);
+  // 2. pilot: per-query score-bin threshold
+  ok = ok && mark(2 * IRS_HIP_K_PILOT);
+  ok = ok && (simd ? launch_pilot_tile<kSimd4>(b, st) : launch_pilot_tile<kScalar>(b, st));
+  ok = ok && mark(2 * IRS_HIP_K_PILOT + 1);
+  // 3. score every tile
+  ok = ok && mark(2 * IRS_HIP_K_SCORE);
+  ok = ok && (simd ? launch_score_tile<kSimd4>(b, st) : launch_score_tile<kScalar>(b, st));
+  ok = ok && mark(2 * IRS_HIP_K_SCORE + 1);
+  // 4. exact top-k
+  ok = ok && mark(2 * IRS_HIP_K_SELECT);
+  if (ok) {
+    RT_LAUNCH(k_select, b->nq, kThreads, 0, st, b->d_queries.as<DevQuery>(),
+              b->d_cands.as<uint64_t>(), b->cand_cap, b->d_cand_count.as<uint32_t>(),
+              b->d_out.as<Hit>(), b->k_max, b->d_out_count.as<uint32_t>(),
+              b->d_status.as<uint32_t>());
+    ok = rt::last_error_ok();
+  }
+  ok = ok && mark(2 * IRS_HIP_K_SELECT + 1);
+  b->ran = true;
+  return ok ? IRS_HIP_OK : IRS_HIP_EHIP;
+}
+
+int irs_hip_batch_timings(irs_hip_batch* b, float ms[IRS_HIP_K_COUNT]) {
+  if (!b || !ms || !b->profile || !b->ran) return IRS_HIP_EINVAL;
+  if (!rt::set_device(b->seg->device) || !rt::sync(b->stream)) return IRS_HIP_EHIP;
+  for (int i = 0; i < IRS_HIP_K_COUNT; ++i)
+    if (!rt::event_elapsed(&ms[i], b->ev[2 * i], b->ev[2 * i + 1])) return IRS_HIP_EHIP;
+  return IRS_HIP_OK;
+}
+
+int irs_hip_batch_work(irs_hip_batch* b, uint64_t* algorithmic_bytes, uint64_t* postings) {
+  if (!b) return IRS_HIP_EINVAL;
+  if (algorithmic_bytes) *algorithmic_bytes = b->alg_bytes;
+  if (postings) *postings = b->postings;
+  return IRS_HIP_OK;
+}
+
+int irs_hip_batch_results(irs_hip_batch* b, irs_hip_hit* hits, uint32_t k_stride,
+                          uint32_t* counts, uint64_t* total_hits) {
+  if (!b || !hits || !counts || !b->ran || k_stride < b->k_max) return IRS_HIP_EINVAL;
+  if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
+  uint32_t status = 0;
+  std::vector<Hit> tmp;
+  try {
+    tmp.resize(size_t(b->nq) * b->k_max);
+  } catch (...) {
+    return IRS_HIP_ENOMEM;
+  }
+  if (!rt::d2h(&status, b->d_status.p, 4, b->stream) ||
+      !rt::d2h(tmp.data(), b->d_out.p, tmp.size() * sizeof(Hit), b->stream) ||
+      !rt::d2h(counts, b->d_out_count.p, size_t(b->nq) * 4, b->stream) ||
+      (total_hits && !rt::d2h(total_hits, b->d_hits.p, size_t(b->nq) * 8, b->stream)) ||
+      !rt::sync(b->stream))
+    return IRS_HIP_EHIP;
+  if (status & kStatusOverflow) return IRS_HIP_EOVERFLOW;
+  for (uint32_t q = 0; q < b->nq; ++q) {
+    for (uint32_t i = 0; i < counts[q]; ++i) {
+      const Hit& h = tmp[size_t(q) * b->k_max + i];
+      hits[size_t(q) * k_stride + i].score = h.score;
+      hits[size_t(q) * k_stride + i].doc = h.doc;
+    }
+  }
+  return IRS_HIP_OK;
+}
+
+int irs_hip_batch_device_results(irs_hip_batch* b, void** d_hits, void** d_counts,
+                                 uint32_t* k_max) {
+  if (!b || !b->scratch_ready) return IRS_HIP_EINVAL;
+  if (d_hits) *d_hits = b->d_out.p;
+  if (d_counts) *d_counts = b->d_out_count.p;
+  if (k_max) *k_max = b->k_max;
+  return IRS_HIP_OK;
+}
+
+void irs_hip_batch_destroy(irs_hip_batch* b) {
+  if (!b) return;
+  rt::set_device(b->seg->device);
+  if (b->ran) rt::sync(b->stream);
+  if (b->events_ready)
+    for (auto& e : b->ev) rt::event_destroy(e);
+  delete b;
+}
+
+int irs_hip_query_batch(irs_hip_segment* seg, const irs_hip_query* queries, uint32_t nq,
+                        const irs_hip_term_scorer* terms, uint32_t n_entries,
+                        irs_hip_hit* hits, uint32_t k_stride, uint32_t* counts,
+                        uint64_t* total_hits) {
+  irs_hip_batch* b = nullptr;
+  int rc = irs_hip_batch_create(seg, queries, nq, terms, n_entries, &b);
+  if (rc != IRS_HIP_OK) return rc;
+  rc = irs_hip_batch_run(b, nullptr);
+  if (rc == IRS_HIP_OK) rc = irs_hip_batch_results(b, hits, k_stride, counts, total_hits);
+  irs_hip_batch_destroy(b);
+  return rc;
+}
+
+int irs_hip_merge_topk(int32_t device, const void* const* d_lists, const void* const* d_counts,
+                       const uint32_t* seg_ids, uint32_t n_lists, uint32_t n_queries,
+                       uint32_t k, void* d_out, void* d_out_seg, void* d_out_counts,
+                       void* stream) {
+  if (!d_lists || !d_counts || !seg_ids || !n_lists || n_lists > 16 || !n_queries || !k ||
+      !d_out || !d_out_seg || !d_out_counts)
+    return IRS_HIP_EINVAL;
+  if (uint64_t(n_lists) * k > kMergeMax) return IRS_HIP_EUNSUPPORTED;
+  if (!device_usable(device)) return IRS_HIP_EHIP;
+  MergeLists ml{};
+  for (uint32_t i = 0; i < n_lists; ++i) {
+    ml.hits[i] = static_cast<const Hit*>(d_lists[i]);
+    ml.counts[i] = static_cast<const uint32_t*>(d_counts[i]);
+    ml.seg_ids[i] = seg_ids[i];
+  }
+  uint32_t p2 = 1;
+  while (p2 < n_lists * k) p2 <<= 1;
+  const size_t smem = size_t(p2) * sizeof(MergeItem);
+  if (!big_smem(k_merge_topk, smem)) return IRS_HIP_EHIP;
+  RT_LAUNCH(k_merge_topk, n_queries, kThreads, smem, static_cast<rt::stream_t>(stream), ml,
+            n_lists, k, static_cast<Hit*>(d_out), static_cast<uint32_t*>(d_out_seg),
+            static_cast<uint32_t*>(d_out_counts));
+  return rt::last_error_ok() ? IRS_HIP_OK : IRS_HIP_EHIP;
+}
+
+}  // extern "C"

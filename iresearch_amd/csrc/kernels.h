@@ -1,0 +1,731 @@
+// kernels.h — the CDNA4 kernels of the query path.  No MFMA on purpose:
+// nothing here is a dense contraction; the work is byte/integer streaming
+// bounded by HBM bandwidth (DESIGN.md "Kernels").
+//
+//   k_build_directory  segment open: walk block headers, record per-block
+//                      offset / last doc / bit widths (no decoded data kept)
+//   k_decode_term      bulk decode of one posting list (bit-exact test surface)
+//   k_plan             per (query, term): first block of every doc tile + tail decode
+//   k_pilot            score every P-th doc tile, derive a per-query score-bin
+//                      threshold that provably keeps the top-k
+//   k_score            decode + score + accumulate every doc tile in LDS,
+//                      emit candidates above the threshold, count hits
+//   k_select           exact top-k (score desc, doc asc) of the candidates
+//   k_merge_topk       multi-segment merge (score desc, segment asc, doc asc)
+#pragma once
+#include "decode.h"
+#include "types.h"
+#include "wave.h"
+
+namespace irs_hip {
+
+constexpr uint32_t kNoTerm = 0xFFFFFFFFu;
+constexpr uint32_t kThreads = 256;      // 4 wavefronts per workgroup
+constexpr uint32_t kWaves = kThreads / 64;
+constexpr uint32_t kLocalCands = 256;   // per-tile candidate staging slots in LDS
+constexpr uint32_t kSelectLds = 4096;   // keys sorted in LDS by k_select
+
+enum : uint32_t {
+  kStatusCorrupt = 1u,   // malformed block header / out-of-bounds offset
+  kStatusOverflow = 2u,  // candidate buffer exhausted
+};
+
+// ------------------------------------------------------------- directory --
+
+// One wavefront per term walks the term's full blocks front to back: header
+// byte -> payload size (bitpack::skip_block32, bitpack.hpp:60-69); the block's
+// last doc is base + sum(deltas).  Lane 0 then walks the vint tail
+// (formats_10.cpp:1765-1792) to find its end.  Nothing decoded is stored.
+template<int LAYOUT>
+__global__ void __launch_bounds__(kThreads)
+k_build_directory(DevSegment seg, DevTerm* terms, uint32_t* blk_off,
+                  uint32_t* blk_last, uint16_t* blk_bits, uint32_t* status) {
+  const unsigned lane = threadIdx.x & 63u;
+  const uint32_t term = blockIdx.x * kWaves + (threadIdx.x >> 6);
+  if (term >= seg.num_terms) return;
+  DevTerm t = terms[term];
+  if (t.docs_count == 0) return;
+  if (t.docs_count == 1) {  // single_doc_iterator, formats_10.cpp:1876-1890
+    if (lane == 0) {
+      terms[term].last_doc = t.single_doc;
+      terms[term].tf_bound = t.single_freq;
+      terms[term].tail_off = t.doc_start;
+      terms[term].tail_base = kDocMin;
+    }
+    return;
+  }
+  uint64_t cur = t.doc_start;
+  uint32_t base = kDocMin;  // formats_10.cpp:636 / :2100-2105
+  uint32_t tfb = 0;
+  bool bad = false;
+  for (uint32_t b = 0; b < t.nblk; ++b) {
+    if (cur + 2 > seg.doc_len) { bad = true; break; }
+    const uint8_t* blk = seg.doc + cur;
+    const uint32_t dbits = blk[0];
+    if (dbits > 32 || cur + 1 + 16ull * dbits > seg.doc_len) { bad = true; break; }
+    uint32_t x0, x1;
+    uint32_t size = read_block_pair<LAYOUT>(blk, dbits, lane, x0, x1);
+    const uint32_t last = base + wave::reduce_add(x0 + x1);
+    uint32_t fbits = 0;
+    if (seg.has_freq) {
+      if (cur + size + 2 > seg.doc_len) { bad = true; break; }
+      const uint8_t* fb = blk + size;
+      fbits = fb[0];
+      if (fbits > 32 || cur + size + 1 + 16ull * fbits > seg.doc_len) { bad = true; break; }
+      if (fbits) {
+        size += 1u + 16u * fbits;
+        const uint32_t bound = fbits >= 32 ? 0xFFFFFFFFu : ((1u << fbits) - 1u);
+        tfb = bound > tfb ? bound : tfb;
+      } else {
+        uint32_t len;
+        const uint32_t v = vint_from(wave::load_u64(fb + 1), &len);
+        size += 1u + len;
+        tfb = v > tfb ? v : tfb;
+      }
+    }
+    if (lane == 0) {
+      blk_off[t.dir_off + b] = uint32_t(cur - t.doc_start);
+      blk_last[t.dir_off + b] = last;
+      blk_bits[t.dir_off + b] = uint16_t(dbits | (fbits << 8));
+    }
+    cur += size;
+    base = last;
+  }
+  if (lane == 0) {
+    const uint64_t tail_off = cur;
+    uint32_t doc = base;
+    if (!bad) {
+      for (uint32_t i = 0; i < t.tail_n; ++i) {
+        if (cur + 1 > seg.doc_len) { bad = true; break; }
+        uint32_t len;
+        const uint32_t v = vint_from(wave::load_u64(seg.doc + cur), &len);
+        cur += len;
+        if (seg.has_freq) {
+          doc += v >> 1;  // shift_unpack_32, store_utils.hpp:266-269
+          if (v & 1u) {
+            tfb = tfb ? tfb : 1u;
+          } else {
+            const uint32_t f = vint_from(wave::load_u64(seg.doc + cur), &len);
+            cur += len;
+            tfb = f > tfb ? f : tfb;
+          }
+        } else {
+          doc += v;
+        }
+      }
+      if (cur > seg.doc_len) bad = true;
+    }
+    terms[term].tail_off = tail_off;
+    terms[term].tail_base = base;
+    terms[term].tail_bytes = uint32_t(cur - tail_off);
+    terms[term].blocks_bytes = uint32_t(tail_off - t.doc_start);
+    terms[term].tf_bound = seg.has_freq ? tfb : 1u;
+    terms[term].last_doc = doc;
+    if (bad) atomicOr(status, kStatusCorrupt);
+  }
+}
+
+// LEB128 read one byte at a time (safe for LDS and for unaligned global bytes).
+__device__ __forceinline__ uint32_t vint_bytes(const uint8_t* p, uint32_t* len) {
+  uint32_t v = 0, n = 0, shift = 0;
+  for (;;) {
+    const uint32_t b = p[n++];
+    v |= (b & 0x7Fu) << shift;
+    if (!(b & 0x80u) || n == 5) break;
+    shift += 7;
+  }
+  *len = n;
+  return v;
+}
+
+// One-lane sequential decode of a vint tail
+// (doc_iterator_base::read_tail_block, formats_10.cpp:1765-1792).
+__device__ __forceinline__ void decode_tail_serial(const uint8_t* p, uint32_t n,
+                                                   uint32_t base, bool has_freq,
+                                                   uint32_t* docs, uint32_t* freqs,
+                                                   uint32_t* last_out) {
+  uint32_t doc = base;
+  for (uint32_t i = 0; i < n; ++i) {
+    uint32_t len;
+    const uint32_t v = vint_bytes(p, &len);
+    p += len;
+    uint32_t f = 1;
+    if (has_freq) {
+      doc += v >> 1;  // shift_unpack_32, store_utils.hpp:266-269
+      if (!(v & 1u)) {
+        f = vint_bytes(p, &len);
+        p += len;
+      }
+    } else {
+      doc += v;
+    }
+    docs[i] = doc;
+    if (freqs) freqs[i] = f;
+  }
+  *last_out = doc;
+}
+
+// ----------------------------------------------------------- bulk decode --
+
+// grid.x = nblk + 1 wave-sized work items of ONE term, kWaves per workgroup.
+template<int LAYOUT>
+__global__ void __launch_bounds__(kThreads)
+k_decode_term(DevSegment seg, uint32_t term, uint32_t* out_docs,
+              uint32_t* out_freqs) {
+  const unsigned lane = threadIdx.x & 63u;
+  const DevTerm t = seg.terms[term];
+  const uint32_t item = blockIdx.x * kWaves + (threadIdx.x >> 6);
+  if (t.docs_count == 1) {
+    if (item == 0 && lane == 0) {
+      out_docs[0] = t.single_doc;
+      if (out_freqs) out_freqs[0] = t.single_freq;
+    }
+    return;
+  }
+  if (item < t.nblk) {
+    const uint64_t e = t.dir_off + item;
+    const uint32_t bits = seg.blk_bits[e];
+    const uint32_t base = item ? seg.blk_last[e - 1] : kDocMin;
+    uint32_t d0, d1, f0, f1;
+    const uint8_t* blk = seg.doc + t.doc_start + seg.blk_off[e];
+    if (seg.has_freq) {
+      decode_block<LAYOUT, true>(blk, bits & 0xFFu, bits >> 8, base, lane, d0, d1, f0, f1);
+    } else {
+      decode_block<LAYOUT, false>(blk, bits & 0xFFu, 0, base, lane, d0, d1, f0, f1);
+    }
+    const uint32_t o = item * kBlock + 2u * lane;
+    out_docs[o] = d0;
+    out_docs[o + 1] = d1;
+    if (out_freqs) {
+      out_freqs[o] = f0;
+      out_freqs[o + 1] = f1;
+    }
+  } else if (item == t.nblk && lane == 0 && t.tail_n) {
+    uint32_t last;
+    decode_tail_serial(seg.doc + t.tail_off, t.tail_n, t.tail_base, seg.has_freq != 0,
+                       out_docs + t.nblk * kBlock,
+                       out_freqs ? out_freqs + t.nblk * kBlock : nullptr, &last);
+  }
+}
+
+// ------------------------------------------------------------------ plan --
+
+// One workgroup per (query, term slot).  Threads binary-search the block
+// directory for the first block whose last doc reaches each tile's first doc
+// (what SkipReader::Seek does per iterator, skip_list.hpp:208-249); thread 0
+// decodes the term's vint tail into the batch scratch.
+__global__ void __launch_bounds__(kThreads)
+k_plan(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms,
+       uint32_t jt /*term slots per query*/, uint32_t tile_docs, uint32_t n_tiles,
+       uint32_t* first /*[q][jt][n_tiles+1]*/, DevTail* tails /*[q][jt]*/) {
+  __shared__ uint8_t tail_bytes[kTailBytesMax + 16];
+  const uint32_t q = blockIdx.x / jt, j = blockIdx.x % jt;
+  const DevQuery qd = queries[q];
+  DevTail* tl = tails + (uint64_t(q) * jt + j);
+  if (j >= qd.n_terms || qterms[qd.first_term + j].term == kNoTerm) {
+    if (threadIdx.x == 0) { tl->n = 0; tl->first_doc = 0; tl->last_doc = 0; }
+    return;
+  }
+  const DevTerm t = seg.terms[qterms[qd.first_term + j].term];
+  uint32_t* row = first + (uint64_t(q) * jt + j) * (n_tiles + 1);
+  const uint32_t* last = seg.blk_last + t.dir_off;
+  for (uint32_t tile = threadIdx.x; tile <= n_tiles; tile += blockDim.x) {
+    const uint64_t lo64 = uint64_t(kDocMin) + uint64_t(tile) * tile_docs;
+    const uint32_t lo = lo64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : uint32_t(lo64);
+    uint32_t a = 0, b = t.nblk;  // lower_bound(last, lo)
+    while (a < b) {
+      const uint32_t m = (a + b) >> 1;
+      if (last[m] < lo) a = m + 1; else b = m;
+    }
+    row[tile] = a;
+  }
+  // tail bytes -> LDS (coalesced), then a serial LEB128 walk by one lane
+  uint32_t nbytes = 0;
+  if (t.docs_count > 1 && t.tail_n) {
+    nbytes = t.tail_bytes;
+    for (uint32_t i = threadIdx.x; i < nbytes + 8; i += blockDim.x)
+      tail_bytes[i] = i < nbytes ? seg.doc[t.tail_off + i] : uint8_t(0);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (t.docs_count == 1) {
+      tl->n = 1;
+      tl->docs[0] = t.single_doc;
+      tl->freqs[0] = t.single_freq;
+      tl->first_doc = tl->last_doc = t.single_doc;
+    } else if (t.tail_n) {
+      uint32_t lastd;
+      decode_tail_serial(tail_bytes, t.tail_n, t.tail_base, seg.has_freq != 0,
+                         tl->docs, tl->freqs, &lastd);
+      tl->n = t.tail_n;
+      tl->first_doc = tl->docs[0];
+      tl->last_doc = lastd;
+    } else {
+      tl->n = 0; tl->first_doc = 0; tl->last_doc = 0;
+    }
+  }
+}
+
+// ------------------------------------------------------------ tile score --
+
+struct TileSmem {
+  float* acc;        // [TILE] score accumulators (block_disjunction::score_buf, 512 -> TILE docs)
+  uint32_t* cnt;     // [TILE/4] per-doc match counters, 1 byte each (AND only)
+  uint8_t* lnorm;    // [TILE] Norm2 bytes of the tile
+  float* caches;     // [kMaxCaches][256] BM25Stats::norm_cache
+};
+
+__device__ __forceinline__ uint32_t norm_global(const DevSegment& seg, uint32_t doc) {
+  // dense fixed-length column, big-endian values (columnstore2.cpp:736-740, norm.hpp:170-182)
+  const uint8_t* p = seg.norms + uint64_t(seg.norm_width) * (doc - seg.norm_min_doc);
+  if (seg.norm_width == 2) return (uint32_t(p[0]) << 8) | p[1];
+  return (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | p[3];
+}
+
+// Score of one posting — the reference's float expressions, evaluated in the
+// same order with no FMA contraction (bm25.cpp:313, 353, 359; tfidf.cpp:185-187, 251-253).
+__device__ __forceinline__ float score_posting(const DevSegment& seg, const DevQTerm& qt,
+                                               float inv_one, const TileSmem& sm,
+                                               uint32_t freq, uint32_t doc, uint32_t idx) {
+  const float tf = static_cast<float>(freq);
+  switch (qt.kind) {
+    case kBM1:
+      return qt.c0;
+    case kBM15:
+      return qt.c0 - qt.c0 / (1.f + tf / qt.norm_const);
+    case kBM25Tiny: {
+      const uint32_t n = sm.lnorm[idx];
+      float inv;
+      if (qt.cache_id < kMaxCaches) {
+        inv = sm.caches[qt.cache_id * 256u + n];
+      } else {
+        inv = n ? 1.f / (qt.norm_const + qt.norm_length * static_cast<float>(n)) : 0.f;
+      }
+      return qt.c0 - qt.c0 / (1.f + tf * inv);
+    }
+    case kBM25One:
+      return qt.c0 - qt.c0 / (1.f + tf * inv_one);
+    case kBM25Wide: {
+      const float c1 = qt.norm_const +
+                       qt.norm_length * static_cast<float>(norm_global(seg, doc));
+      return qt.c0 - qt.c0 * c1 / (c1 + tf);
+    }
+    case kTfidf:
+      return sqrtf(tf) * qt.c0;
+    case kTfidfTiny: {
+      const uint32_t n = sm.lnorm[idx];
+      const float r = n ? 1.f / sqrtf(static_cast<float>(n)) : 0.f;
+      return sqrtf(tf) * qt.c0 * r;
+    }
+    default: {  // kTfidfWide
+      const uint32_t n = norm_global(seg, doc);
+      const float r = n ? 1.f / sqrtf(static_cast<float>(n)) : 0.f;
+      return sqrtf(tf) * qt.c0 * r;
+    }
+  }
+}
+
+// Zero the accumulators, stage the tile's norms, build the norm caches.
+template<int TILE, bool AND>
+__device__ __forceinline__ void tile_begin(const DevSegment& seg, const DevQuery& qd,
+                                           const DevQTerm* qts, uint32_t tile,
+                                           const TileSmem& sm, bool build_caches) {
+  for (uint32_t i = threadIdx.x; i < TILE; i += blockDim.x) sm.acc[i] = 0.f;
+  if (AND) {
+    for (uint32_t i = threadIdx.x; i < TILE / 4; i += blockDim.x) sm.cnt[i] = 0u;
+  }
+  if (seg.norms && seg.norm_width == 1) {
+    const uint64_t first = uint64_t(tile) * TILE + (kDocMin - seg.norm_min_doc);
+    for (uint32_t i = threadIdx.x * 4; i < TILE; i += blockDim.x * 4) {
+      // norms are staged with kPadBytes of slack, 4-byte granules stay in bounds
+      uint32_t w = 0;
+      if (first + i < seg.norm_count) w = wave::load_u32(seg.norms + first + i);
+      *reinterpret_cast<uint32_t*>(sm.lnorm + i) = w;
+    }
+  }
+  if (build_caches) {
+    // BM25::collect: norm_cache[i] = 1/(norm_const + norm_length*i), [0] = 0 (bm25.cpp:404-409)
+    for (uint32_t e = threadIdx.x; e < qd.n_caches * 256u; e += blockDim.x) {
+      const uint32_t c = e >> 8, n = e & 255u;
+      float nc = 0.f, nl = 0.f;
+      for (uint32_t j = 0; j < qd.n_terms; ++j) {
+        if (qts[j].cache_id == c) { nc = qts[j].norm_const; nl = qts[j].norm_length; break; }
+      }
+      sm.caches[e] = n ? 1.f / (nc + nl * static_cast<float>(n)) : 0.f;
+    }
+  }
+}
+
+// All postings of the query's terms that fall into doc tile `tile`, term by
+// term in query order (deterministic float sums): the GPU form of
+// block_disjunction::refill (disjunction.hpp:1240-1351) with the 512-doc window
+// widened to TILE docs held in LDS, and of Conjunction via per-doc counters.
+template<int LAYOUT, int TILE, bool AND>
+__device__ __forceinline__ void tile_accumulate(const DevSegment& seg, const DevQuery& qd,
+                                                const DevQTerm* qts, const uint32_t* first_q,
+                                                uint32_t n_tiles, const DevTail* tails_q,
+                                                uint32_t tile, const TileSmem& sm) {
+  const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const uint32_t nw = blockDim.x >> 6;
+  const uint32_t lo = kDocMin + tile * TILE;
+  const uint32_t span = (seg.num_docs + kDocMin - lo) < uint32_t(TILE)
+                          ? (seg.num_docs + kDocMin - lo) : uint32_t(TILE);
+  for (uint32_t j = 0; j < qd.n_terms; ++j) {
+    const DevQTerm qt = qts[j];
+    if (qt.term != kNoTerm) {
+      const DevTerm& t = seg.terms[qt.term];
+      const uint32_t* row = first_q + uint64_t(j) * (n_tiles + 1);
+      const uint32_t b0 = row[tile];
+      uint32_t b1 = row[tile + 1] + 1u;
+      b1 = b1 < t.nblk ? b1 : t.nblk;
+      const float inv_one = 1.f / (qt.norm_const + qt.norm_length * 1.f);
+      auto apply = [&](uint32_t doc, uint32_t freq) {
+        const uint32_t idx = doc - lo;  // doc < lo wraps to a huge value
+        if (idx < span) {
+          const float s = score_posting(seg, qt, inv_one, sm, freq, doc, idx);
+          wave::lds_add(&sm.acc[idx], s);
+          if (AND) atomicAdd(&sm.cnt[idx >> 2], 1u << (8u * (idx & 3u)));
+        }
+      };
+      for (uint32_t b = b0 + wv; b < b1; b += nw) {
+        const uint64_t e = t.dir_off + b;
+        const uint32_t bits = seg.blk_bits[e];
+        const uint32_t base = b ? seg.blk_last[e - 1] : kDocMin;
+        const uint8_t* blk = seg.doc + t.doc_start + seg.blk_off[e];
+        uint32_t d0, d1, f0, f1;
+        decode_block<LAYOUT, true>(blk, bits & 0xFFu, bits >> 8, base, lane, d0, d1, f0, f1);
+        apply(d0, f0);
+        apply(d1, f1);
+      }
+      const DevTail& tl = tails_q[j];
+      if (wv == 0 && tl.n && tl.first_doc < lo + span && tl.last_doc >= lo) {
+        for (uint32_t i = lane; i < tl.n; i += 64) apply(tl.docs[i], tl.freqs[i]);
+      }
+    }
+    __syncthreads();  // term order == summation order
+  }
+}
+
+__device__ __forceinline__ uint32_t score_bin(float v, float scale) {
+  const float x = fminf(v * scale, float(kBins - 1));
+  return uint32_t(x);
+}
+
+template<int TILE, bool AND>
+__device__ __forceinline__ TileSmem carve(unsigned char* smem, unsigned char** rest) {
+  TileSmem sm;
+  sm.acc = reinterpret_cast<float*>(smem);
+  smem += sizeof(float) * TILE;
+  sm.cnt = reinterpret_cast<uint32_t*>(smem);
+  if (AND) smem += TILE;
+  sm.lnorm = smem;
+  smem += TILE;
+  sm.caches = reinterpret_cast<float*>(smem);
+  smem += sizeof(float) * 256 * kMaxCaches;
+  *rest = smem;
+  return sm;
+}
+
+template<int TILE, bool AND>
+constexpr uint32_t tile_smem_bytes() {
+  return sizeof(float) * TILE + (AND ? TILE : 0) + TILE + sizeof(float) * 256 * kMaxCaches;
+}
+
+// Did doc slot i match the query?  OR: any posting landed (scores are > 0);
+// AND: every term's posting landed (Conjunction::converge, conjunction.hpp:207-223).
+template<bool AND>
+__device__ __forceinline__ bool doc_matched(const DevQuery& qd, const TileSmem& sm, uint32_t i,
+                                            float v, uint32_t need) {
+  if (AND && qd.op == 1)
+    return need && ((sm.cnt[i >> 2] >> (8u * (i & 3u))) & 0xFFu) == need;
+  return v != 0.f;
+}
+
+// number of query terms present in this segment (AND needs all of them)
+__device__ __forceinline__ uint32_t present_terms(const DevQuery& qd, const DevQTerm* qts) {
+  uint32_t n = 0;
+  for (uint32_t j = 0; j < qd.n_terms; ++j) n += qts[j].term != kNoTerm;
+  return n;
+}
+
+// ----------------------------------------------------------------- pilot --
+
+// One workgroup per query scores the tiles {phase, phase+P, ...}, histograms
+// their scores into kBins linear bins over [0, U] and picks the largest bin b*
+// with at least k docs at or above it.  Those docs exist, so the final k-th
+// score is >= the lower edge of b*: k_score may drop everything below b*.
+template<int LAYOUT, int TILE, bool AND>
+__global__ void __launch_bounds__(kThreads)
+k_pilot(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_t jt,
+        uint32_t n_tiles, uint32_t stride, const uint32_t* first, const DevTail* tails,
+        uint32_t* bstar) {
+  RT_DYN_SMEM(smem);
+  unsigned char* rest;
+  const TileSmem sm = carve<TILE, AND>(smem, &rest);
+  uint32_t* hist = reinterpret_cast<uint32_t*>(rest);  // [kBins]
+  const uint32_t q = blockIdx.x;
+  const DevQuery qd = queries[q];
+  const DevQTerm* qts = qterms + qd.first_term;
+  const uint32_t* first_q = first + uint64_t(q) * jt * (n_tiles + 1);
+  const DevTail* tails_q = tails + uint64_t(q) * jt;
+  const uint32_t need = present_terms(qd, qts);
+  for (uint32_t i = threadIdx.x; i < kBins; i += blockDim.x) hist[i] = 0u;
+  bool first_tile = true;
+  for (uint32_t tile = (q * 7u) % stride; tile < n_tiles; tile += stride) {
+    tile_begin<TILE, AND>(seg, qd, qts, tile, sm, first_tile);
+    first_tile = false;
+    __syncthreads();
+    tile_accumulate<LAYOUT, TILE, AND>(seg, qd, qts, first_q, n_tiles, tails_q, tile, sm);
+    for (uint32_t i = threadIdx.x; i < TILE; i += blockDim.x) {
+      const float v = sm.acc[i];
+      if (doc_matched<AND>(qd, sm, i, v, need))
+        atomicAdd(&hist[score_bin(v, qd.bin_scale)], 1u);
+    }
+    __syncthreads();
+  }
+  // suffix search: lane L of wave 0 owns the 8 bins of chunk 63-L
+  if (threadIdx.x < 64) {
+    const unsigned lane = threadIdx.x;
+    const uint32_t chunk = 63u - lane;
+    uint32_t s = 0;
+    for (uint32_t i = 0; i < kBins / 64; ++i) s += hist[chunk * (kBins / 64) + i];
+    const uint32_t incl = wave::inclusive_scan(s);  // docs in chunks >= chunk
+    const uint64_t reach = wave::ballot(incl >= qd.k);
+    uint32_t result = 0;
+    if (reach) {
+      const int src = __builtin_ctzll(reach);  // highest chunk reaching k
+      const uint32_t above = wave::bcast(incl - s, src);
+      const uint32_t c = 63u - uint32_t(src);
+      uint32_t cum = above;
+      for (int i = int(kBins / 64) - 1; i >= 0; --i) {
+        cum += hist[c * (kBins / 64) + uint32_t(i)];
+        if (cum >= qd.k) { result = c * (kBins / 64) + uint32_t(i); break; }
+      }
+    }
+    if (lane == 0) bstar[q] = result;
+  }
+}
+
+// ----------------------------------------------------------------- score --
+
+// One workgroup per (query, doc tile); work ids are remapped so that each XCD
+// (private L2) walks a contiguous run of tiles of the same queries.
+template<int LAYOUT, int TILE, bool AND>
+__global__ void __launch_bounds__(kThreads)
+k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_t jt,
+        uint32_t n_tiles, uint32_t n_work, const uint32_t* first, const DevTail* tails,
+        const uint32_t* bstar, uint64_t* cands, uint32_t cand_cap, uint32_t* cand_count,
+        unsigned long long* hits) {
+  RT_DYN_SMEM(smem);
+  unsigned char* rest;
+  const TileSmem sm = carve<TILE, AND>(smem, &rest);
+  uint64_t* lcand = reinterpret_cast<uint64_t*>(rest);            // [kLocalCands]
+  uint32_t* lvars = reinterpret_cast<uint32_t*>(lcand + kLocalCands);  // [4]
+  // XCD-aware remap: block b runs on XCD b % 8; give XCD x the contiguous
+  // work range [x*per, (x+1)*per).
+  const uint32_t per = (n_work + 7u) / 8u;
+  const uint32_t w = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+  if ((blockIdx.x >> 3) >= per || w >= n_work) return;
+  const uint32_t q = w / n_tiles, tile = w % n_tiles;
+  const DevQuery qd = queries[q];
+  const DevQTerm* qts = qterms + qd.first_term;
+  const uint32_t need = present_terms(qd, qts);
+  if (threadIdx.x < 4) lvars[threadIdx.x] = 0u;
+  tile_begin<TILE, AND>(seg, qd, qts, tile, sm, true);
+  __syncthreads();
+  tile_accumulate<LAYOUT, TILE, AND>(seg, qd, qts, first + uint64_t(q) * jt * (n_tiles + 1),
+                                     n_tiles, tails + uint64_t(q) * jt, tile, sm);
+  const uint32_t lo = kDocMin + tile * TILE;
+  const uint32_t bs = bstar[q];
+  uint32_t my_hits = 0;
+  for (uint32_t i = threadIdx.x; i < TILE; i += blockDim.x) {
+    const float v = sm.acc[i];
+    if (doc_matched<AND>(qd, sm, i, v, need)) {
+      ++my_hits;
+      if (score_bin(v, qd.bin_scale) >= bs) {
+        const uint64_t key = make_key(v, lo + i);
+        const uint32_t slot = atomicAdd(&lvars[0], 1u);
+        if (slot < kLocalCands) {
+          lcand[slot] = key;
+        } else {  // rare: more candidates in one tile than staging slots
+          const uint32_t g = atomicAdd(&cand_count[q], 1u);
+          if (g < cand_cap) cands[uint64_t(q) * cand_cap + g] = key;
+        }
+      }
+    }
+  }
+  my_hits = wave::reduce_add(my_hits);
+  if ((threadIdx.x & 63u) == 0 && my_hits) atomicAdd(&lvars[1], my_hits);
+  __syncthreads();
+  const uint32_t n = lvars[0] < kLocalCands ? lvars[0] : kLocalCands;
+  if (threadIdx.x == 0) {
+    if (lvars[1]) atomicAdd(&hits[q], (unsigned long long)lvars[1]);
+    lvars[2] = n ? atomicAdd(&cand_count[q], n) : 0u;
+  }
+  __syncthreads();
+  const uint32_t gbase = lvars[2];
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const uint32_t g = gbase + i;
+    if (g < cand_cap) cands[uint64_t(q) * cand_cap + g] = lcand[i];
+  }
+}
+
+// ---------------------------------------------------------------- select --
+
+// in-LDS bitonic sort, descending, n a power of two
+__device__ __forceinline__ void bitonic_desc(uint64_t* a, uint32_t n) {
+  for (uint32_t size = 2; size <= n; size <<= 1) {
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (uint32_t i = threadIdx.x; i < n / 2; i += blockDim.x) {
+        const uint32_t pos = 2u * i - (i & (stride - 1u));
+        const uint32_t other = pos + stride;
+        const bool desc = (pos & size) == 0;
+        const uint64_t x = a[pos], y = a[other];
+        if ((x < y) == desc) { a[pos] = y; a[other] = x; }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// One workgroup per query: exact top-k of the candidate keys.  Keys are unique
+// ((score, doc) pairs), descending key order == (score desc, doc asc) — the
+// deterministic refinement of the harness heap (index-search.cpp:745-787).
+__global__ void __launch_bounds__(kThreads)
+k_select(const DevQuery* queries, const uint64_t* cands, uint32_t cand_cap,
+         const uint32_t* cand_count, Hit* out, uint32_t k_max, uint32_t* out_count,
+         uint32_t* status) {
+  __shared__ uint64_t keys[kSelectLds];
+  __shared__ uint32_t hist[256];
+  __shared__ uint64_t sh_prefix;
+  __shared__ uint32_t sh_want, sh_n;
+  const uint32_t q = blockIdx.x;
+  const DevQuery qd = queries[q];
+  uint32_t n = cand_count[q];
+  if (n > cand_cap) {
+    if (threadIdx.x == 0) atomicOr(status, kStatusOverflow);
+    n = cand_cap;
+  }
+  const uint64_t* src = cands + uint64_t(q) * cand_cap;
+  const uint32_t kk = qd.k < n ? qd.k : n;
+  uint32_t m = n;  // keys that end up in LDS
+  if (n > kSelectLds) {
+    // MSB-first radix select of the kk-th largest key, 8 bits per pass
+    if (threadIdx.x == 0) { sh_prefix = 0; sh_want = kk; }
+    for (int pass = 0; pass < 8; ++pass) {
+      const int shift = 56 - 8 * pass;
+      if (threadIdx.x < 256) hist[threadIdx.x] = 0u;
+      __syncthreads();
+      const uint64_t prefix = sh_prefix;
+      for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint64_t key = src[i];
+        if (pass == 0 || (key >> (shift + 8)) == prefix)
+          atomicAdd(&hist[uint32_t(key >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        uint32_t want = sh_want, cum = 0;
+        int d = 255;
+        for (; d > 0; --d) {
+          if (cum + hist[d] >= want) break;
+          cum += hist[d];
+        }
+        sh_want = want - cum;
+        sh_prefix = (prefix << 8) | uint64_t(d);
+      }
+      __syncthreads();
+    }
+    const uint64_t kth = sh_prefix;
+    if (threadIdx.x == 0) sh_n = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+      const uint64_t key = src[i];
+      if (key >= kth) {
+        const uint32_t slot = atomicAdd(&sh_n, 1u);
+        if (slot < kSelectLds) keys[slot] = key;
+      }
+    }
+    __syncthreads();
+    m = sh_n < kSelectLds ? sh_n : kSelectLds;
+  } else {
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) keys[i] = src[i];
+  }
+  uint32_t p2 = 1;
+  while (p2 < m) p2 <<= 1;
+  __syncthreads();
+  for (uint32_t i = m + threadIdx.x; i < p2; i += blockDim.x) keys[i] = 0;
+  bitonic_desc(keys, p2);
+  for (uint32_t i = threadIdx.x; i < kk; i += blockDim.x)
+    out[uint64_t(q) * k_max + i] = key_hit(keys[i]);
+  if (threadIdx.x == 0) out_count[q] = kk;
+}
+
+// ----------------------------------------------------------------- merge --
+
+struct MergeItem {
+  uint32_t score_bits;
+  uint32_t seg;
+  uint32_t doc;
+};
+__device__ __forceinline__ bool merge_before(const MergeItem& a, const MergeItem& b) {
+  // score desc, segment asc, doc asc (tests/search/wand_test.cpp:72-86)
+  if (a.score_bits != b.score_bits) return a.score_bits > b.score_bits;
+  if (a.seg != b.seg) return a.seg < b.seg;
+  return a.doc < b.doc;
+}
+constexpr uint32_t kMergeMax = 8192;
+
+struct MergeLists {
+  const Hit* hits[16];
+  const uint32_t* counts[16];
+  uint32_t seg_ids[16];
+};
+
+__global__ void __launch_bounds__(kThreads)
+k_merge_topk(MergeLists lists, uint32_t n_lists, uint32_t k, Hit* out, uint32_t* out_seg,
+             uint32_t* out_counts) {
+  RT_DYN_SMEM(smem);
+  MergeItem* items = reinterpret_cast<MergeItem*>(smem);
+  const uint32_t q = blockIdx.x;
+  uint32_t total = 0;
+  uint32_t p2 = 1;
+  while (p2 < n_lists * k) p2 <<= 1;
+  for (uint32_t i = threadIdx.x; i < p2; i += blockDim.x) {
+    MergeItem it;
+    it.score_bits = 0; it.seg = 0xFFFFFFFFu; it.doc = 0xFFFFFFFFu;  // sorts last
+    const uint32_t l = i / k, r = i % k;
+    if (l < n_lists && r < lists.counts[l][q]) {
+      const Hit h = lists.hits[l][uint64_t(q) * k + r];
+      __builtin_memcpy(&it.score_bits, &h.score, 4);
+      it.seg = lists.seg_ids[l];
+      it.doc = h.doc;
+    }
+    items[i] = it;
+  }
+  for (uint32_t l = 0; l < n_lists; ++l) total += lists.counts[l][q];
+  for (uint32_t size = 2; size <= p2; size <<= 1) {
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (uint32_t i = threadIdx.x; i < p2 / 2; i += blockDim.x) {
+        const uint32_t pos = 2u * i - (i & (stride - 1u));
+        const uint32_t other = pos + stride;
+        const bool fwd = (pos & size) == 0;
+        const MergeItem x = items[pos], y = items[other];
+        if (merge_before(y, x) == fwd) { items[pos] = y; items[other] = x; }
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t kk = total < k ? total : k;
+  for (uint32_t i = threadIdx.x; i < kk; i += blockDim.x) {
+    Hit h;
+    __builtin_memcpy(&h.score, &items[i].score_bits, 4);
+    h.doc = items[i].doc;
+    out[uint64_t(q) * k + i] = h;
+    out_seg[uint64_t(q) * k + i] = items[i].seg;
+  }
+  if (threadIdx.x == 0) out_counts[q] = kk;
+}
+
+}  // namespace irs_hip

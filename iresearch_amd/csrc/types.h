@@ -1,0 +1,117 @@
+// types.h — device-side data layout of a staged segment and of a query batch.
+// See DESIGN.md "Data layout in HBM".
+#pragma once
+#include <cstdint>
+
+namespace irs_hip {
+
+constexpr uint32_t kBlock = 128;       // postings per block (formats_10.cpp:90)
+constexpr uint32_t kDocMin = 1;        // doc_limits::min() (type_limits.hpp:45)
+constexpr uint32_t kMaxTerms = 16;     // IRS_HIP_MAX_TERMS
+constexpr uint32_t kMaxK = 4096;       // IRS_HIP_MAX_K
+constexpr uint32_t kBins = 512;        // score histogram bins (pilot threshold)
+constexpr uint32_t kMaxCaches = 4;     // distinct (norm_const, norm_length) per query in LDS
+constexpr uint32_t kPadBytes = 64;     // zero padding after the staged `.doc` bytes
+constexpr uint32_t kTailBytesMax = 127 * 10;  // 127 entries x 2 vints x 5 bytes
+
+enum Layout : int32_t { kScalar = 0, kSimd4 = 1 };
+
+// Scorer kinds after resolving the norm source against the segment
+// (bm25.cpp:447-489, tfidf.cpp:307-352).
+enum Kind : int32_t {
+  kBM1 = 0,
+  kBM15 = 1,
+  kBM25Tiny = 2,   // Norm2 1 byte: c0 - c0/(1 + tf*norm_cache[norm])   bm25.cpp:348-353
+  kBM25Wide = 3,   // Norm2 2/4 bytes: c0 - c0*c1/(c1 + tf)              bm25.cpp:355-359
+  kBM25One = 4,    // no norm column: norm == 1 through the tiny path   bm25.cpp:487-489
+  kTfidf = 5,
+  kTfidfTiny = 6,  // * kRSQRT.get<false>(norm)
+  kTfidfWide = 7,  // * kRSQRT.get<true>(norm)
+};
+
+// One term of the segment's term table, as staged on the device.
+struct DevTerm {
+  uint64_t doc_start;   // absolute offset of the term's postings in the staged file
+  uint64_t dir_off;     // index of the term's first entry in the block directory
+  uint64_t tail_off;    // [dir kernel] absolute offset of the vint tail
+  uint32_t docs_count;
+  uint32_t nblk;        // full 128-doc blocks
+  uint32_t tail_n;      // docs_count % 128 (0 for a single-doc term)
+  uint32_t tail_base;   // [dir kernel] last doc of the last full block (1 if none)
+  uint32_t tail_bytes;  // [dir kernel] encoded length of the tail
+  uint32_t blocks_bytes;// [dir kernel] encoded length of all full blocks
+  uint32_t single_doc;  // docs_count == 1: the doc id (1 + e_single_doc), else 0
+  uint32_t single_freq; // docs_count == 1: term_meta::freq
+  uint32_t tf_bound;    // [dir kernel] upper bound of tf over the whole list
+  uint32_t last_doc;    // [dir kernel] last doc id of the list
+};
+
+struct DevSegment {
+  const uint8_t* doc;        // staged `.doc` bytes (+ kPadBytes zeros)
+  uint64_t doc_len;
+  const uint8_t* norms;      // Norm2 column bytes, may be null
+  uint32_t norm_width;
+  uint32_t norm_min_doc;
+  uint64_t norm_count;
+  const DevTerm* terms;
+  uint32_t num_terms;
+  uint32_t num_docs;
+  // block directory, one entry per full block of every term
+  const uint32_t* blk_off;   // byte offset relative to the term's doc_start
+  const uint32_t* blk_last;  // absolute last doc id of the block
+  const uint16_t* blk_bits;  // doc bits | freq bits << 8 (0 = all-equal block)
+  int32_t has_freq;
+  int32_t layout;
+};
+
+struct DevQuery {
+  int32_t op;
+  uint32_t n_terms;
+  uint32_t first_term;  // into the DevQTerm array
+  uint32_t k;
+  float bin_scale;      // kBins / (upper bound of the query's score)
+  uint32_t n_caches;
+  uint32_t pad0, pad1;
+};
+
+struct DevQTerm {
+  uint32_t term;        // ordinal in the term table, 0xFFFFFFFF = absent
+  int32_t kind;         // Kind
+  float c0;
+  float norm_const;
+  float norm_length;
+  uint32_t cache_id;    // < kMaxCaches: norm_cache slot in LDS; else compute on the fly
+  uint32_t pad0, pad1;
+};
+
+// A term's vint tail (or single doc) decoded once per (query, term) by the
+// plan kernel: at most 127 postings with absolute doc ids.
+struct DevTail {
+  uint32_t n;
+  uint32_t first_doc;
+  uint32_t last_doc;
+  uint32_t pad;
+  uint32_t docs[kBlock];
+  uint32_t freqs[kBlock];
+};
+
+struct Hit {
+  float score;
+  uint32_t doc;
+};
+
+// candidate key: descending key order == (score desc, doc asc); scores are > 0
+__host__ __device__ inline uint64_t make_key(float score, uint32_t doc) {
+  uint32_t bits;
+  __builtin_memcpy(&bits, &score, 4);
+  return (uint64_t(bits) << 32) | uint64_t(0xFFFFFFFFu - doc);
+}
+__host__ __device__ inline Hit key_hit(uint64_t key) {
+  Hit h;
+  const uint32_t bits = uint32_t(key >> 32);
+  __builtin_memcpy(&h.score, &bits, 4);
+  h.doc = 0xFFFFFFFFu - uint32_t(key);
+  return h;
+}
+
+}  // namespace irs_hip

@@ -1,0 +1,317 @@
+"""Host-side mirror of the reference interfaces on the hot path, above the C ABI.
+
+Names follow IResearch: a *segment* holds posting lists of *terms*; a *filter*
+(`by_term`, `Or`, `And`) is `prepare`d against an *index* (all segments) to
+collect statistics, then executed per segment; a *scorer* (`BM25`, `TFIDF`)
+turns statistics into per-term score functions.
+
+  irs::BM25::collect          core/search/bm25.cpp:366-410     -> BM25.collect
+  irs::TFIDF::collect         core/search/tfidf.cpp:263-278    -> TFIDF.collect
+  by_term::prepare            core/search/term_filter.cpp:92-129 -> prepare()
+  filter::prepared::execute   core/search/filter.hpp:52-78     -> SegmentReader.execute()
+  utils/index-search.cpp:719-787 (heap over all segments)     -> Index.search()
+
+This module holds no posting decode or scoring arithmetic of its own beyond the
+per-term statistics (which the reference also computes on the CPU once per
+query): everything per posting happens in libirs_hip.so on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from ._lib import (HIT, NO_TERM, OP_AND, OP_OR, QUERY, SCORE_BM1, SCORE_BM15, SCORE_BM25,
+                   SCORE_TFIDF, SCORE_TFIDF_NORM, TERM_META, TERM_SCORER, SegmentDesc)
+
+f32 = np.float32
+
+
+# ------------------------------------------------------------------ scorers --
+
+@dataclass(frozen=True)
+class TermStats:
+    """BM25Stats minus the cache (bm25.hpp:48-57) / TFIDFStats."""
+    idf: np.float32
+    norm_const: np.float32 = f32(0)
+    norm_length: np.float32 = f32(0)
+
+
+class BM25:
+    """irs::BM25 (bm25.hpp:59-117): k = 1.2, b = 0.75 by default."""
+
+    def __init__(self, k: float = 1.2, b: float = 0.75):
+        self.k, self.b = f32(k), f32(b)
+
+    def collect(self, docs_with_field: int, docs_with_term: int, total_term_freq: int):
+        # bm25.cpp:381-383 — double log1p, then cast
+        idf = f32(math.log1p((float(docs_with_field - docs_with_term) + 0.5) /
+                             (float(docs_with_term) + 0.5)))
+        if self.k == 0 or self.b == 0:  # !NeedsNorm() bm25.cpp:387-390
+            return TermStats(idf, self.k, f32(0))
+        kb = f32(self.k * self.b)
+        norm_const = f32(self.k - kb)
+        if total_term_freq and docs_with_field:
+            avg_dl = f32(f32(total_term_freq) / f32(docs_with_field))
+            norm_length = f32(kb / avg_dl)
+        else:
+            norm_length = kb
+        return TermStats(idf, norm_const, norm_length)
+
+    def term_scorer(self, st: TermStats, boost: float = 1.0):
+        # BM1Context: num = boost * (k + 1) * idf (bm25.cpp:201)
+        c0 = f32(f32(f32(boost) * f32(self.k + f32(1))) * st.idf)
+        if self.k == 0:
+            kind = SCORE_BM1
+        elif self.b == 0:
+            kind = SCORE_BM15
+        else:
+            kind = SCORE_BM25
+        return kind, c0, st.norm_const, st.norm_length
+
+
+class TFIDF:
+    """irs::TFIDF (tfidf.hpp): with_norms == normalize()."""
+
+    def __init__(self, with_norms: bool = False):
+        self.with_norms = bool(with_norms)
+
+    def collect(self, docs_with_field: int, docs_with_term: int, total_term_freq: int):
+        return TermStats(f32(math.log1p((docs_with_field + 1.0) / (docs_with_term + 1.0))))
+
+    def term_scorer(self, st: TermStats, boost: float = 1.0):
+        c0 = f32(f32(boost) * st.idf)  # TFIDFContext: idf = boost * idf.value
+        return (SCORE_TFIDF_NORM if self.with_norms else SCORE_TFIDF), c0, f32(0), f32(0)
+
+
+# ------------------------------------------------------------------ filters --
+
+@dataclass
+class by_term:
+    """irs::by_term on the benchmark field; `term` is the ordinal in the term table."""
+    term: int
+    boost: float = 1.0
+
+
+@dataclass
+class Or:
+    subs: list
+    op: int = OP_OR
+
+
+@dataclass
+class And:
+    subs: list
+    op: int = OP_AND
+
+
+def _terms_of(flt):
+    if isinstance(flt, by_term):
+        return OP_OR, [flt]
+    if not flt.subs or any(not isinstance(s, by_term) for s in flt.subs):
+        raise ValueError("only flat Or/And of by_term are on the GPU path")
+    return flt.op, list(flt.subs)
+
+
+@dataclass
+class PreparedQuery:
+    """filter::prepared: the op plus (term, global stats, boost) per sub-filter."""
+    op: int
+    terms: list            # term ordinals
+    scorers: list          # (kind, c0, norm_const, norm_length) per term
+
+
+# ------------------------------------------------------------------ segment --
+
+class SegmentReader:
+    """irs::SubReader + postings_reader of one segment, resident on one GPU."""
+
+    def __init__(self, doc_file, metas, num_docs, layout, norms=None, norm_width=1,
+                 docs_with_field=None, total_term_freq=0, device=0, has_freq=True, L=None):
+        self.L = L or _lib.lib()
+        self.doc_file = np.ascontiguousarray(doc_file, np.uint8)
+        self.metas = np.zeros(len(metas), TERM_META)
+        for name in TERM_META.names:
+            self.metas[name] = np.asarray(metas)[name]
+        self.num_docs, self.layout, self.device = int(num_docs), int(layout), int(device)
+        self.norms = None if norms is None else np.ascontiguousarray(norms, np.uint8)
+        self.norm_width = norm_width
+        self.docs_with_field = int(num_docs if docs_with_field is None else docs_with_field)
+        self.total_term_freq = int(total_term_freq)
+        desc = SegmentDesc(
+            device, layout, self.doc_file.ctypes.data, self.doc_file.size, num_docs,
+            int(has_freq), None if self.norms is None else self.norms.ctypes.data, norm_width, 1,
+            0 if self.norms is None else self.norms.size // norm_width,
+            self.metas.ctypes.data, len(self.metas), 0)
+        h = C.c_void_p()
+        _lib.check(self.L, self.L.irs_hip_segment_open(C.byref(desc), C.byref(h)),
+                   "irs_hip_segment_open")
+        self.handle = h
+
+    @classmethod
+    def from_synth(cls, seg, device=0, L=None):
+        return cls(seg.doc_file, seg.metas, seg.num_docs, seg.layout, seg.norms, 1,
+                   seg.docs_with_field, seg.total_term_freq, device, True, L)
+
+    def close(self):
+        if self.handle:
+            self.L.irs_hip_segment_close(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_bytes(self) -> int:
+        return self.L.irs_hip_segment_device_bytes(self.handle)
+
+    def decode_term(self, term: int, want_freq: bool = True):
+        n = int(self.metas[term]["docs_count"])
+        docs = np.zeros(max(n, 1), np.uint32)
+        freqs = np.zeros(max(n, 1), np.uint32) if want_freq else None
+        cnt = C.c_uint32()
+        _lib.check(self.L, self.L.irs_hip_decode_term(
+            self.handle, term, docs.ctypes.data, None if freqs is None else freqs.ctypes.data,
+            docs.size, C.byref(cnt)), "irs_hip_decode_term")
+        return docs[:cnt.value], (None if freqs is None else freqs[:cnt.value])
+
+    def term_directory(self, term: int):
+        nb = int(self.metas[term]["docs_count"]) // 128
+        last = np.zeros(max(nb, 1), np.uint32)
+        offs = np.zeros(max(nb, 1), np.uint64)
+        cnt = C.c_uint32()
+        _lib.check(self.L, self.L.irs_hip_term_directory(
+            self.handle, term, last.ctypes.data, offs.ctypes.data, last.size, C.byref(cnt)),
+            "irs_hip_term_directory")
+        return last[:cnt.value], offs[:cnt.value]
+
+    def batch(self, prepared, k: int):
+        return QueryBatch(self, prepared, k)
+
+
+class QueryBatch:
+    """A batch of prepared queries on one segment (irs_hip_batch)."""
+
+    def __init__(self, seg: SegmentReader, prepared, k: int):
+        self.seg, self.L, self.k = seg, seg.L, int(k)
+        self.nq = len(prepared)
+        n_entries = sum(len(p.terms) for p in prepared)
+        self.queries = np.zeros(self.nq, QUERY)
+        self.terms = np.zeros(max(n_entries, 1), TERM_SCORER)
+        at = 0
+        for q, p in enumerate(prepared):
+            self.queries[q] = (p.op, len(p.terms), at, self.k)
+            for t, (kind, c0, nc, nl) in zip(p.terms, p.scorers):
+                present = t is not None and 0 <= t < len(seg.metas)
+                self.terms[at] = (t if present else NO_TERM, kind, c0, nc, nl)
+                at += 1
+        h = C.c_void_p()
+        _lib.check(self.L, self.L.irs_hip_batch_create(
+            seg.handle, self.queries.ctypes.data, self.nq, self.terms.ctypes.data, n_entries,
+            C.byref(h)), "irs_hip_batch_create")
+        self.handle = h
+
+    def configure(self, tile_docs=0, pilot_stride=0, cand_cap=0):
+        _lib.check(self.L, self.L.irs_hip_batch_configure(self.handle, tile_docs, pilot_stride,
+                                                          cand_cap), "irs_hip_batch_configure")
+        return self
+
+    def profile(self, enable=True):
+        _lib.check(self.L, self.L.irs_hip_batch_profile(self.handle, int(enable)),
+                   "irs_hip_batch_profile")
+        return self
+
+    def run(self, stream=None):
+        _lib.check(self.L, self.L.irs_hip_batch_run(self.handle, stream), "irs_hip_batch_run")
+        return self
+
+    def timings(self):
+        ms = (C.c_float * _lib.K_COUNT)()
+        _lib.check(self.L, self.L.irs_hip_batch_timings(self.handle, ms), "irs_hip_batch_timings")
+        return [float(x) for x in ms]
+
+    def work(self):
+        a, p = C.c_uint64(), C.c_uint64()
+        _lib.check(self.L, self.L.irs_hip_batch_work(self.handle, C.byref(a), C.byref(p)),
+                   "irs_hip_batch_work")
+        return a.value, p.value
+
+    def results(self):
+        hits = np.zeros((self.nq, self.k), HIT)
+        counts = np.zeros(self.nq, np.uint32)
+        totals = np.zeros(self.nq, np.uint64)
+        _lib.check(self.L, self.L.irs_hip_batch_results(
+            self.handle, hits.ctypes.data, self.k, counts.ctypes.data, totals.ctypes.data),
+            "irs_hip_batch_results")
+        return hits, counts, totals
+
+    def device_results(self):
+        dh, dc, km = C.c_void_p(), C.c_void_p(), C.c_uint32()
+        _lib.check(self.L, self.L.irs_hip_batch_device_results(
+            self.handle, C.byref(dh), C.byref(dc), C.byref(km)), "irs_hip_batch_device_results")
+        return dh.value, dc.value, km.value
+
+    def close(self):
+        if self.handle:
+            self.L.irs_hip_batch_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# -------------------------------------------------------------------- index --
+
+@dataclass
+class SegmentStats:
+    """What by_term::prepare reads from a segment without touching postings."""
+    docs_with_field: int
+    total_term_freq: int
+    docs_count: np.ndarray  # per term ordinal: term_meta::docs_count
+
+
+def prepare(filters, scorer, segment_stats):
+    """filter::prepare for a list of filters against ALL segments: statistics are
+    index-global (term_filter.cpp:102-125): D = sum docs_with_field,
+    d = sum docs_count of the term, avgdl from the summed field frequency."""
+    dwf = sum(s.docs_with_field for s in segment_stats)
+    ttf = sum(s.total_term_freq for s in segment_stats)
+    out = []
+    for flt in filters:
+        op, subs = _terms_of(flt)
+        scorers = []
+        for s in subs:
+            dwt = 0
+            for st in segment_stats:
+                if 0 <= s.term < len(st.docs_count):
+                    dwt += int(st.docs_count[s.term])
+            stats = scorer.collect(dwf, dwt, ttf)
+            scorers.append(scorer.term_scorer(stats, s.boost))
+        out.append(PreparedQuery(op, [s.term for s in subs], scorers))
+    return out
+
+
+def merge_topk_host(per_segment, k: int):
+    """Global top-k over segments ordered (score desc, segment asc, doc asc) —
+    the ordering tests/search/wand_test.cpp:72-86 fixes for the harness heap.
+    per_segment: list of (hits HIT[nq][k], counts[nq]). Host-side variant used by
+    tests; the GPU variant is irs_hip_merge_topk."""
+    nq = len(per_segment[0][1])
+    out = []
+    for q in range(nq):
+        rows = []
+        for s, (hits, counts) in enumerate(per_segment):
+            n = int(counts[q])
+            for i in range(n):
+                rows.append((-float(hits[q, i]["score"]), s, int(hits[q, i]["doc"])))
+        rows.sort()
+        out.append([(-a, s, d) for a, s, d in rows[:k]])
+    return out

@@ -1,0 +1,90 @@
+"""Parity helpers shared by the CPU (emulator) and GPU tests: run the same
+prepared queries through the C ABI and through the oracle and compare."""
+from __future__ import annotations
+
+import numpy as np
+
+import oracle
+from iresearch_amd import search
+from iresearch_amd._lib import OP_AND, OP_OR
+
+REL_TOL = 1e-5  # BASELINE.json north_star: top-k within 1e-5 relative
+
+
+def oracle_scorer(scorer) -> oracle.Scorer:
+    if isinstance(scorer, search.BM25):
+        return oracle.Scorer(oracle.SCORER_BM25, float(scorer.k), float(scorer.b), 0)
+    return oracle.Scorer(oracle.SCORER_TFIDF, 0.0, 0.0, int(scorer.with_norms))
+
+
+def oracle_view(seg) -> oracle.SegmentView:
+    return oracle.SegmentView(seg.doc_file, seg.norms, seg.layout, seg.num_docs,
+                              seg.docs_with_field, seg.total_term_freq)
+
+
+def segment_stats(seg) -> search.SegmentStats:
+    return search.SegmentStats(seg.docs_with_field, seg.total_term_freq,
+                               np.asarray(seg.metas["docs_count"]))
+
+
+def metas_for(seg, terms):
+    out = np.zeros(len(terms), oracle.TERM_META)
+    for i, t in enumerate(terms):
+        if t is not None and 0 <= t < len(seg.metas):
+            for name in oracle.TERM_META.names:
+                out[i][name] = seg.metas[t][name]
+    return out
+
+
+def check_single_segment(seg, filters, scorer, k, hits, counts, totals, all_segs=None):
+    """Compares GPU results of `filters` on `seg` with the oracle.  Statistics are
+    global over `all_segs` (default: just this segment)."""
+    all_segs = all_segs or [seg]
+    osc = oracle_scorer(scorer)
+    view = oracle_view(seg)
+    dwf = sum(s.docs_with_field for s in all_segs)
+    ttf = sum(s.total_term_freq for s in all_segs)
+    for q, flt in enumerate(filters):
+        op, subs = search._terms_of(flt)
+        terms = [s.term for s in subs]
+        boosts = [s.boost for s in subs]
+        metas = metas_for(seg, terms)
+        dwt = [sum(int(s.metas[t]["docs_count"]) if 0 <= t < len(s.metas) else 0
+                   for s in all_segs) for t in terms]
+        scores, matched = oracle.score_all(view, metas, op, osc, dwf, dwt, ttf, boosts)
+        n_match = int(matched.sum())
+        assert int(totals[q]) == n_match, ("total hits", q, int(totals[q]), n_match)
+        n = int(counts[q])
+        assert n == min(k, n_match), ("count", q, n, k, n_match)
+        if n == 0:
+            continue
+        h = hits[q, :n]
+        docs = h["doc"].astype(np.int64)
+        assert len(set(docs.tolist())) == n, ("duplicate docs", q)
+        assert matched[docs].all(), ("unmatched doc returned", q)
+        ref = scores[docs]
+        rel = np.abs(h["score"] - ref) / np.maximum(np.abs(ref), 1e-30)
+        assert rel.max() <= REL_TOL, ("score mismatch", q, float(rel.max()))
+        # ordered (score desc, doc asc)
+        s, d = h["score"], h["doc"]
+        assert ((s[:-1] > s[1:]) | ((s[:-1] == s[1:]) & (d[:-1] < d[1:]))).all(), ("order", q)
+        # set parity around the k-th score
+        ms = np.sort(scores[matched.astype(bool)])[::-1]
+        thr = ms[n - 1]
+        must = np.nonzero(matched.astype(bool) & (scores > thr * (1 + 2 * REL_TOL)))[0]
+        assert np.isin(must, docs).all(), ("missing doc above the k-th score", q)
+        assert (ref >= thr * (1 - 2 * REL_TOL)).all(), ("doc below the k-th score", q)
+
+
+def oracle_topk(segs, filters, scorer, k):
+    """The oracle's own harness run (index-search.cpp:719-787) per query."""
+    osc = oracle_scorer(scorer)
+    views = [oracle_view(s) for s in segs]
+    out = []
+    for flt in filters:
+        op, subs = search._terms_of(flt)
+        terms = [s.term for s in subs]
+        metas = np.stack([metas_for(s, terms) for s in segs])
+        hits, total = oracle.search(views, metas, op, osc, k, [s.boost for s in subs])
+        out.append((hits, total))
+    return out
