@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py — queries/sec of the MI355X query path on BASELINE.json's headline
+workload: OR-of-8-terms BM25 top-1000 on a synthetic 10M-doc Zipfian index.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A *step* is one pass of the hot path over one batch of 1000 queries (plan ->
+pilot -> score -> select, plus the RCCL top-k all-gather + merge when N > 1).
+N = 1 is BASELINE config 3 (one 10M-doc segment on one GPU); N > 1 is config 4:
+the same 10M docs split into 8 segments, 8/N per GPU, global statistics, one
+all-gather of per-segment top-k per step ("strong" scaling: total work fixed).
+
+Rank 0 prints ONE JSON line.  `value` is whole-job queries/sec with the index
+already resident in HBM.  `roofline` prices the dominant kernel (k_score)
+against HBM bandwidth using ALGORITHMIC bytes and its average
+duration measured with HIP events on the launch stream.  `cpu_baseline` is the
+oracle's restatement of utils/index-search timed on this host (N = 1, rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(seg, ranks, k, seconds_hint=15.0):
+    """Oracle (port of the index-search loop) on a bounded sample of the same
+    queries.  Imports oracle/ here and only here."""
+    import oracle
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import parity
+    cores = os.cpu_count() or 1
+    view = parity.oracle_view(seg)
+    sc = oracle.Scorer(oracle.SCORER_BM25, 1.2, 0.75, 0)
+
+    def metas_of(rows):
+        return np.stack([parity.metas_for(seg, [int(r) - 1 for r in row])[None] for row in rows])
+
+    # calibrate on a few queries, then size the sample for ~seconds_hint of wall time
+    probe = ranks[: min(len(ranks), max(2, cores))]
+    t0 = time.perf_counter()
+    oracle.search_batch([view], metas_of(probe), oracle.OP_OR, sc, k, cores)
+    dt = max(time.perf_counter() - t0, 1e-6)
+    n = int(min(len(ranks), max(len(probe), len(probe) * seconds_hint / dt)))
+    sample = ranks[:n]
+    t0 = time.perf_counter()
+    oracle.search_batch([view], metas_of(sample), oracle.OP_OR, sc, k, cores)
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 3), "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": "first %d of the %d bench queries, %d threads popping one task queue "
+                      "(index-search --threads), %.1f s" % (n, len(ranks), cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--docs", type=int, default=10_000_000)
+    ap.add_argument("--queries", type=int, default=1000)
+    ap.add_argument("--terms", type=int, default=8)
+    ap.add_argument("--k", type=int, default=1000)
+    ap.add_argument("--segments", type=int, default=8, help="segments of the index when --gpus > 1")
+    ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--stride", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from iresearch_amd import _lib, distributed, search, synth
+    from iresearch_amd.search import BM25, Or, by_term
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    L = _lib.lib()
+
+    # ---- index: built on the host, staged to HBM once (not timed) ------------
+    t0 = time.perf_counter()
+    if world == 1:
+        n_segments = 1
+        my = [0]
+    else:
+        n_segments = args.segments
+        my = distributed.segments_of_rank(n_segments, rank, world)
+    per = args.docs // n_segments
+    segs = {}
+    for s in my:
+        n = per if s < n_segments - 1 else args.docs - per * (n_segments - 1)
+        segs[s] = synth.build_segment(n, 4096, first_doc=s * per)
+    log("built %d segment(s) in %.1f s" % (len(my), time.perf_counter() - t0))
+    local_stats = {s: (segs[s].docs_with_field, segs[s].total_term_freq,
+                       np.asarray(segs[s].metas["docs_count"])) for s in my}
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, local_stats)
+        all_stats = {}
+        for g in gathered:
+            all_stats.update(g)
+    else:
+        all_stats = local_stats
+    seg_stats = [search.SegmentStats(*all_stats[s]) for s in range(n_segments)]
+
+    t0 = time.perf_counter()
+    readers = {s: search.SegmentReader.from_synth(segs[s], device=local_rank, L=L) for s in my}
+    log("staged to HBM in %.1f s (%.1f MB resident on rank 0)" %
+        (time.perf_counter() - t0, sum(r.device_bytes() for r in readers.values()) / 1e6))
+
+    # ---- queries: prepared once (statistics are index-global) ---------------
+    ranks = synth.make_queries(args.queries, args.terms, 16, 4096, synth.SEED + 2)
+    filters = [Or([by_term(int(r) - 1) for r in row]) for row in ranks]
+    prepared = search.prepare(filters, BM25(), seg_stats)
+    batches = {}
+    for s in my:
+        b = readers[s].batch(prepared, args.k)
+        if args.tile or args.stride:
+            b.configure(args.tile, args.stride, 0)
+        b.profile(True)
+        batches[s] = b
+    stream = torch.cuda.current_stream(dev)
+    sptr = C_void(stream.cuda_stream)
+    nq, k = args.queries, args.k
+    recv = {s: (torch.zeros((nq, k), dtype=torch.int64, device=dev),
+                torch.zeros((nq,), dtype=torch.int32, device=dev)) for s in my}
+
+    def step():
+        for s in my:
+            batches[s].run(sptr)
+        if world > 1:
+            lists = []
+            for s in my:
+                batches[s].results_to_device(recv[s][0].data_ptr(), recv[s][1].data_ptr(), sptr)
+                lists.append((s, recv[s][0], recv[s][1]))
+            return distributed.gather_merge(L, local_rank, lists, n_segments, rank, world, nq, k,
+                                            dev, sptr)
+        return None
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    # sanity: results are retrievable (also triggers the overflow re-run path if needed)
+    for s in my:
+        batches[s].results()
+    score_ms = []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        if world == 1:
+            # per-kernel HIP-event timings of this step (waits for the stream)
+            score_ms.append(batches[my[0]].timings())
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    alg_bytes = sum(batches[s].work()[0] for s in my)
+    postings = sum(batches[s].work()[1] for s in my)
+    if world > 1:
+        t = torch.tensor([alg_bytes, postings], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        alg_bytes, postings = float(t[0].item()), float(t[1].item())
+
+    out = None
+    if rank == 0:
+        qps = args.steps * nq / elapsed
+        roof = None
+        if world == 1 and score_ms:
+            ms = np.array(score_ms)                    # [steps][K_COUNT]
+            avg = ms.mean(axis=0)
+            achieved = alg_bytes / (avg[_lib.K_SCORE] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "k_score", "achieved": round(achieved, 2),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                    "traffic": None,
+                    "algorithmic_bytes_per_launch": int(alg_bytes),
+                    "avg_launch_ms": round(float(avg[_lib.K_SCORE]), 4),
+                    "kernel_ms": {n: round(float(v), 4) for n, v in zip(_lib.KERNEL_NAMES, avg)}}
+        out = {
+            "metric": "queries/sec BM25 top-1000, OR-8-terms, 10M-doc Zipfian index @1/2/4/8 GPU",
+            "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u32+f32", "data": "synthetic",
+            "config": {
+                "workload": "OR-of-%d terms BM25 top-%d, %d-doc Zipfian index, %d segment(s), "
+                            "%d queries/step" % (args.terms, k, args.docs, n_segments, nq),
+                "segments": n_segments, "queries_per_step": nq, "layout": "1_5simd",
+                "postings_per_step": int(postings), "algorithmic_bytes_per_step": int(alg_bytes),
+                "parallelism": "segments x%d + RCCL all-gather top-k" % world if world > 1
+                               else "1 segment on 1 GPU"},
+            "roofline": roof,
+        }
+    if rank == 0 and world == 1 and not args.no_cpu:
+        for b in batches.values():
+            b.close()
+        out["cpu_baseline"] = cpu_baseline(segs[0], ranks, k)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def C_void(v):
+    import ctypes
+    return ctypes.c_void_p(v)
+
+
+if __name__ == "__main__":
+    main()

@@ -33,7 +33,7 @@ typedef enum irs_hip_status {
   IRS_HIP_ECORRUPT = -2,     /* index_error: malformed `.doc` bytes       */
   IRS_HIP_ENOMEM = -3,
   IRS_HIP_EHIP = -4,         /* HIP runtime failure / no gfx950 device    */
-  IRS_HIP_EOVERFLOW = -5,    /* candidate buffer exhausted (see DESIGN)   */
+  IRS_HIP_EOVERFLOW = -5,    /* candidates exceed the memory budget even after the exact re-run */
   IRS_HIP_EUNSUPPORTED = -6
 } irs_hip_status;
 
@@ -164,6 +164,10 @@ int irs_hip_batch_results(irs_hip_batch* batch, irs_hip_hit* hits,
  * d_hits is [n_queries][k_max] irs_hip_hit, d_counts [n_queries] uint32. */
 int irs_hip_batch_device_results(irs_hip_batch* batch, void** d_hits,
                                  void** d_counts, uint32_t* k_max);
+/* Same, copied (device to device, async on `stream`) into caller-owned device
+ * buffers: d_hits [n_queries][k_max] irs_hip_hit, d_counts [n_queries] uint32. */
+int irs_hip_batch_results_to_device(irs_hip_batch* batch, void* d_hits,
+                                    void* d_counts, void* stream);
 void irs_hip_batch_destroy(irs_hip_batch* batch);
 
 /* Convenience: create + run + results + destroy. */

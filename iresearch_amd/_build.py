@@ -77,21 +77,6 @@ def build_hip(force: bool = False) -> Path:
     return HIP_LIB
 
 
-def build_oracle(force: bool = False) -> Path:
-    """Builds the TEST oracle (and oracle/_ref where /root/reference exists).
-    Building the checker is not using it: nothing in iresearch_amd imports it."""
-    odir = REPO / "oracle"
-    lib = odir / "liboracle.so"
-    deps = [odir / n for n in ("postings_oracle.c", "search_oracle.cpp", "oracle.h",
-                                "oracle_internal.h")]
-    if force or _stale(lib, deps):
-        _run(["make", "-C", odir, "liboracle.so"])
-    if Path("/root/reference/core/utils").is_dir():
-        _run(["make", "-C", odir, "ref"])
-    return lib
-
-
 def build_all(force: bool = False):
     build_synth(force)
     build_hip(force)
-    build_oracle(force)

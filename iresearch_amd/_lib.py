@@ -56,7 +56,8 @@ SYMBOLS = (
     "irs_hip_abi_version", "irs_hip_strerror", "irs_hip_device_arch", "irs_hip_segment_open",
     "irs_hip_segment_close", "irs_hip_segment_device_bytes", "irs_hip_decode_term",
     "irs_hip_term_directory", "irs_hip_batch_create", "irs_hip_batch_run",
-    "irs_hip_batch_results", "irs_hip_batch_device_results", "irs_hip_batch_destroy",
+    "irs_hip_batch_results", "irs_hip_batch_device_results",
+    "irs_hip_batch_results_to_device", "irs_hip_batch_destroy",
     "irs_hip_query_batch", "irs_hip_batch_configure", "irs_hip_batch_profile",
     "irs_hip_batch_timings", "irs_hip_batch_work", "irs_hip_merge_topk",
 )
@@ -84,6 +85,8 @@ def bind(L: C.CDLL) -> C.CDLL:
     L.irs_hip_batch_results.restype = C.c_int
     L.irs_hip_batch_device_results.argtypes = [vp, P(vp), P(vp), P(u32)]
     L.irs_hip_batch_device_results.restype = C.c_int
+    L.irs_hip_batch_results_to_device.argtypes = [vp, vp, vp, vp]
+    L.irs_hip_batch_results_to_device.restype = C.c_int
     L.irs_hip_batch_destroy.argtypes, L.irs_hip_batch_destroy.restype = [vp], None
     L.irs_hip_query_batch.argtypes = [vp, vp, u32, vp, u32, vp, u32, vp, vp]
     L.irs_hip_query_batch.restype = C.c_int

@@ -41,6 +41,9 @@ inline bool h2d(void* d, const void* h, size_t n, stream_t s) {
 inline bool d2h(void* h, const void* d, size_t n, stream_t s) {
   return n == 0 || ok(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s));
 }
+inline bool d2d(void* dst, const void* src, size_t n, stream_t s) {
+  return n == 0 || ok(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, s));
+}
 inline bool dmemset(void* d, int v, size_t n, stream_t s) {
   return n == 0 || ok(hipMemsetAsync(d, v, n, s));
 }

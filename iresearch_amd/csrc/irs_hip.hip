@@ -82,6 +82,7 @@ struct irs_hip_batch {
   uint32_t nq = 0, jt = 0, k_max = 0;
   uint32_t tile = kDefaultTile, stride = kDefaultStride, cand_cap = 0;
   uint32_t n_tiles = 0;
+  uint32_t stride_eff = 1;  // pilot stride actually used (>= 4 pilot tiles when possible)
   bool any_and = false;
   bool scratch_ready = false;
   std::vector<DevQuery> queries;
@@ -134,7 +135,7 @@ bool launch_pilot(irs_hip_batch* b, rt::stream_t st) {
   auto kern = k_pilot<LAYOUT, TILE, AND>;
   if (!big_smem(kern, smem)) return false;
   RT_LAUNCH(kern, b->nq, kThreads, smem, st, b->seg->dev, b->d_queries.as<DevQuery>(),
-            b->d_qterms.as<DevQTerm>(), b->jt, b->n_tiles, b->stride,
+            b->d_qterms.as<DevQTerm>(), b->jt, b->n_tiles, b->stride_eff,
             b->d_first.as<uint32_t>(), b->d_tails.as<DevTail>(), b->d_bstar.as<uint32_t>());
   return rt::last_error_ok();
 }
@@ -187,6 +188,7 @@ bool ensure_scratch(irs_hip_batch* b) {
   if (b->scratch_ready) return true;
   const irs_hip_segment* s = b->seg;
   b->n_tiles = (s->dev.num_docs + b->tile - 1) / b->tile;
+  b->stride_eff = std::max<uint32_t>(1, std::min<uint32_t>(b->stride, b->n_tiles / 4));
   if (b->cand_cap == 0) {
     uint64_t cap = 4ull * b->stride * b->k_max;
     cap = std::min<uint64_t>(std::max<uint64_t>(cap, 16384), 262144);
@@ -560,11 +562,8 @@ int irs_hip_batch_profile(irs_hip_batch* b, int enable) {
   return IRS_HIP_OK;
 }
 
-int irs_hip_batch_run(irs_hip_batch* b, void* stream) {
-  if (!b) return IRS_HIP_EINVAL;
-  if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
+static int run_impl(irs_hip_batch* b, rt::stream_t st) {
   if (!ensure_scratch(b)) return IRS_HIP_ENOMEM;
-  rt::stream_t st = static_cast<rt::stream_t>(stream);
   b->stream = st;
   const bool simd = b->seg->dev.layout == kSimd4;
   auto mark = [&](int i) { return !b->profile || rt::event_record(b->ev[i], st); };
@@ -602,6 +601,42 @@ int irs_hip_batch_run(irs_hip_batch* b, void* stream) {
   return ok ? IRS_HIP_OK : IRS_HIP_EHIP;
 }
 
+int irs_hip_batch_run(irs_hip_batch* b, void* stream) {
+  if (!b) return IRS_HIP_EINVAL;
+  if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
+  return run_impl(b, static_cast<rt::stream_t>(stream));
+}
+
+// The candidate buffer overflowed (k_select flagged it): the pilot sample was
+// not representative, or many docs tie at the k-th score bin.  Re-run exactly:
+// first with a full histogram pass (stride 1), then with the buffer grown to the
+// largest candidate count seen.  Results are never silently truncated.
+static int recover_overflow(irs_hip_batch* b) {
+  constexpr uint64_t kMaxCandBytes = 16ull << 30;
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    if (b->stride_eff != 1) {
+      b->stride_eff = 1;
+    } else {
+      std::vector<uint32_t> cc(b->nq);
+      if (!rt::d2h(cc.data(), b->d_cand_count.p, size_t(b->nq) * 4, b->stream) ||
+          !rt::sync(b->stream))
+        return IRS_HIP_EHIP;
+      const uint64_t need = uint64_t(*std::max_element(cc.begin(), cc.end())) + 1024;
+      if (need <= b->cand_cap || need * b->nq * sizeof(uint64_t) > kMaxCandBytes)
+        return IRS_HIP_EOVERFLOW;
+      if (!b->d_cands.alloc(need * b->nq * sizeof(uint64_t))) return IRS_HIP_ENOMEM;
+      b->cand_cap = uint32_t(need);
+    }
+    int rc = run_impl(b, b->stream);
+    if (rc != IRS_HIP_OK) return rc;
+    uint32_t status = 0;
+    if (!rt::d2h(&status, b->d_status.p, 4, b->stream) || !rt::sync(b->stream))
+      return IRS_HIP_EHIP;
+    if (!(status & kStatusOverflow)) return IRS_HIP_OK;
+  }
+  return IRS_HIP_EOVERFLOW;
+}
+
 int irs_hip_batch_timings(irs_hip_batch* b, float ms[IRS_HIP_K_COUNT]) {
   if (!b || !ms || !b->profile || !b->ran) return IRS_HIP_EINVAL;
   if (!rt::set_device(b->seg->device) || !rt::sync(b->stream)) return IRS_HIP_EHIP;
@@ -628,8 +663,14 @@ int irs_hip_batch_results(irs_hip_batch* b, irs_hip_hit* hits, uint32_t k_stride
   } catch (...) {
     return IRS_HIP_ENOMEM;
   }
-  if (!rt::d2h(&status, b->d_status.p, 4, b->stream) ||
-      !rt::d2h(tmp.data(), b->d_out.p, tmp.size() * sizeof(Hit), b->stream) ||
+  if (!rt::d2h(&status, b->d_status.p, 4, b->stream) || !rt::sync(b->stream))
+    return IRS_HIP_EHIP;
+  if (status & kStatusOverflow) {
+    const int rc = recover_overflow(b);
+    if (rc != IRS_HIP_OK) return rc;
+    status = 0;
+  }
+  if (!rt::d2h(tmp.data(), b->d_out.p, tmp.size() * sizeof(Hit), b->stream) ||
       !rt::d2h(counts, b->d_out_count.p, size_t(b->nq) * 4, b->stream) ||
       (total_hits && !rt::d2h(total_hits, b->d_hits.p, size_t(b->nq) * 8, b->stream)) ||
       !rt::sync(b->stream))
@@ -651,6 +692,25 @@ int irs_hip_batch_device_results(irs_hip_batch* b, void** d_hits, void** d_count
   if (d_hits) *d_hits = b->d_out.p;
   if (d_counts) *d_counts = b->d_out_count.p;
   if (k_max) *k_max = b->k_max;
+  return IRS_HIP_OK;
+}
+
+int irs_hip_batch_results_to_device(irs_hip_batch* b, void* d_hits, void* d_counts,
+                                    void* stream) {
+  if (!b || !b->ran || !d_hits || !d_counts) return IRS_HIP_EINVAL;
+  if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
+  rt::stream_t st = static_cast<rt::stream_t>(stream);
+  uint32_t status = 0;
+  if (!rt::d2h(&status, b->d_status.p, 4, b->stream) || !rt::sync(b->stream))
+    return IRS_HIP_EHIP;
+  if (status & kStatusOverflow) {
+    const int rc = recover_overflow(b);
+    if (rc != IRS_HIP_OK) return rc;
+    if (!rt::sync(b->stream)) return IRS_HIP_EHIP;
+  }
+  if (!rt::d2d(d_hits, b->d_out.p, size_t(b->nq) * b->k_max * sizeof(Hit), st) ||
+      !rt::d2d(d_counts, b->d_out_count.p, size_t(b->nq) * 4, st))
+    return IRS_HIP_EHIP;
   return IRS_HIP_OK;
 }
 

@@ -256,6 +256,10 @@ class QueryBatch:
             self.handle, C.byref(dh), C.byref(dc), C.byref(km)), "irs_hip_batch_device_results")
         return dh.value, dc.value, km.value
 
+    def results_to_device(self, d_hits: int, d_counts: int, stream=None):
+        _lib.check(self.L, self.L.irs_hip_batch_results_to_device(
+            self.handle, d_hits, d_counts, stream), "irs_hip_batch_results_to_device")
+
     def close(self):
         if self.handle:
             self.L.irs_hip_batch_destroy(self.handle)

@@ -164,6 +164,9 @@ def segment_from_lists(lists, num_docs: int, layout: int = LAYOUT_SIMD4, norms=N
     if n < 0:
         raise ValueError("irs_synth_wrap_doc_file failed")
     metas["doc_start"] += hdr.value
+    if norms is False:  # no Norm2 column at all
+        return SynthSegment(out[:n].copy(), None, metas, num_docs, num_docs, layout, num_docs,
+                            None)
     if norms is None:
         norms = np.ones(num_docs, np.uint8)
     ttf = int(np.asarray(norms, dtype=np.uint64).sum())

@@ -46,11 +46,11 @@ _lib = None
 _ref = None
 
 
-def build():
+def build(force: bool = False):
     deps = [HERE / n for n in ("postings_oracle.c", "search_oracle.cpp", "oracle.h",
                                "oracle_internal.h")]
     lib = HERE / "liboracle.so"
-    if not lib.exists() or any(d.stat().st_mtime > lib.stat().st_mtime for d in deps):
+    if force or not lib.exists() or any(d.stat().st_mtime > lib.stat().st_mtime for d in deps):
         subprocess.run(["make", "-C", str(HERE), "liboracle.so"], check=True,
                        capture_output=True)
     return lib

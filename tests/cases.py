@@ -1,0 +1,323 @@
+"""Test bodies shared by the emulator tier (CPU, not gpu) and the GPU tier:
+each takes the bound C-ABI library `L` and a size scale."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+import parity
+from iresearch_amd import _lib, search, synth
+from iresearch_amd.search import BM25, TFIDF, And, Or, by_term
+
+GOLDEN = __import__("pathlib").Path(__file__).parent / "golden"
+
+
+def open_lists(L, lists, num_docs, layout, norms=None):
+    seg = synth.segment_from_lists(lists, num_docs, layout, norms)
+    return seg, search.SegmentReader.from_synth(seg, L=L)
+
+
+def assert_decode(sr, seg, term, docs, freqs):
+    d, f = sr.decode_term(term)
+    assert np.array_equal(d, np.asarray(docs, np.uint32)), ("docs", term)
+    assert np.array_equal(f, np.asarray(freqs, np.uint32)), ("freqs", term)
+    od, of = oracle.decode_term(seg.doc_file, seg.metas[term], seg.layout)
+    assert np.array_equal(d, od) and np.array_equal(f, of), ("oracle", term)
+    d2, f2 = sr.decode_term(term, want_freq=False)
+    assert np.array_equal(d2, d) and f2 is None
+
+
+# ------------------------------------------------------------------ decode --
+
+def case_decode_reference_lists(L, layout):
+    """The literal lists of tests/formats/formats_10_tests.cpp:452-457 and the
+    6098 doc ids of tests/resources/postings.txt (ires336, :775-864)."""
+    docs0 = [1, 3, 5, 7, 79, 101, 124]
+    docs1 = [2, 7, 9, 19]
+    p6098 = np.loadtxt(GOLDEN / "postings_6098.txt", dtype=np.uint32)
+    assert p6098.size == 6098
+    lists = [(docs0, [10] * 7), (docs1, [10] * 4), (p6098, np.ones(6098, np.uint32)),
+             (p6098, (np.arange(6098) % 7 + 1).astype(np.uint32))]
+    seg, sr = open_lists(L, lists, int(p6098.max()) + 10, layout)
+    for t, (d, f) in enumerate(lists):
+        assert_decode(sr, seg, t, d, f)
+    # block directory == skip level 0 written by the emitter (formats_10.cpp:501-533)
+    last, offs = sr.term_directory(2)
+    sl, sp, levels = oracle.read_skip0(seg.doc_file, seg.metas[2])
+    assert len(last) == 6098 // 128 == 47 and levels >= 1
+    assert np.array_equal(last[:len(sl)], sl) and np.array_equal(offs[1:], sp[:len(offs) - 1])
+    assert np.array_equal(last, p6098[127::128][:47])
+    sr.close()
+
+
+def case_decode_sizes(L, layout, sizes=(1, 2, 117, 127, 128, 129, 255, 256, 319, 1024, 10_000)):
+    """Sizes of tests/formats/formats_15_tests.cpp:695-764 plus block edges; freqs
+    ~ Normal(50, 14) as GenerateDocs (:553-567)."""
+    rng = np.random.default_rng(7)
+    lists = []
+    n_docs = 200_000
+    for n in sizes:
+        docs = np.sort(rng.choice(np.arange(1, n_docs + 1), n, replace=False)).astype(np.uint32)
+        freqs = np.clip(np.rint(rng.normal(50, 14, n)), 1, None).astype(np.uint32)
+        lists.append((docs, freqs))
+    seg, sr = open_lists(L, lists, n_docs, layout)
+    for t, (d, f) in enumerate(lists):
+        assert_decode(sr, seg, t, d, f)
+    sr.close()
+
+
+def case_decode_edge_blocks(L, layout):
+    """All-equal doc and freq blocks (bitpack.hpp:82-86), every bit width up to the
+    maxima (31-bit gaps, 32-bit freqs), freq == 1 tails, first doc == 1."""
+    lists = []
+    n_docs = 0x7FFE0000
+    # consecutive docs from 1: all deltas equal (first delta = doc - 1 = 0 breaks it: start at 2)
+    d = np.arange(2, 2 + 300, dtype=np.uint32)
+    lists.append((d, np.full(300, 3, np.uint32)))             # all-equal deltas & freqs
+    d = np.arange(1, 1 + 256, dtype=np.uint32)
+    lists.append((d, np.ones(256, np.uint32)))                  # doc 1 first: delta 0 then 1s
+    for bits in (1, 2, 5, 8, 13, 17, 24, 29, 31):
+        rng = np.random.default_rng(bits)
+        gaps = rng.integers(1, min(1 << bits, 1 << 22), 200, dtype=np.int64)
+        gaps[0] = min((1 << bits) - 1, 1 << 22)
+        d = np.cumsum(gaps).astype(np.uint32)
+        fb = min(bits + 1, 32)
+        f = rng.integers(1, (1 << fb) - 1, 200, dtype=np.uint64).astype(np.uint32)
+        f[5] = (1 << fb) - 1
+        lists.append((d, f))
+    # one huge gap: 31-bit delta
+    d = np.concatenate([np.arange(1, 129), [0x7FFD0000], 0x7FFD0000 + np.arange(1, 140)]).astype(np.uint32)
+    f = np.ones(d.size, np.uint32)
+    f[::3] = 0xFFFFFFFF
+    lists.append((d, f))
+    seg, sr = open_lists(L, lists, n_docs, layout, norms=False)
+    for t, (dd, ff) in enumerate(lists):
+        assert_decode(sr, seg, t, dd, ff)
+    sr.close()
+
+
+def case_decode_synth(L, layout, num_docs, max_rank, step=1):
+    seg = synth.build_segment(num_docs, max_rank, layout=layout, keep_postings=True)
+    sr = search.SegmentReader.from_synth(seg, L=L)
+    for r in range(1, max_rank + 1, step):
+        d, f = seg.postings[r]
+        got_d, got_f = sr.decode_term(r - 1)
+        assert np.array_equal(got_d, d) and np.array_equal(got_f, f), r
+        last, offs = sr.term_directory(r - 1)
+        assert np.array_equal(last, d[127::128][:len(d) // 128]), r
+    sr.close()
+    return seg
+
+
+# ----------------------------------------------------------------- queries --
+
+def run_and_check(L, seg, filters, scorer, k, tile=0, stride=0, cap=0, sr=None):
+    own = sr is None
+    sr = sr or search.SegmentReader.from_synth(seg, L=L)
+    prep = search.prepare(filters, scorer, [parity.segment_stats(seg)])
+    b = sr.batch(prep, k)
+    if tile or stride or cap:
+        b.configure(tile, stride, cap)
+    hits, counts, totals = b.run().results()
+    parity.check_single_segment(seg, filters, scorer, k, hits, counts, totals)
+    b.close()
+    if own:
+        sr.close()
+    return hits, counts, totals
+
+
+def standard_filters(max_rank, n_or8=4, seed=synth.SEED + 2):
+    lo = max(2, max_rank // 256)
+    ranks = synth.make_queries(n_or8, 8, lo, max_rank, seed)
+    fl = [Or([by_term(int(r) - 1) for r in row]) for row in ranks]
+    pairs = synth.make_queries(3, 2, lo, max_rank, seed + 1)
+    fl += [Or([by_term(int(r) - 1) for r in row]) for row in pairs]
+    fl += [by_term(max_rank // 2), by_term(0)]
+    fl += [And([by_term(3), by_term(max_rank // 8), by_term(1)]),
+           And([by_term(max_rank - 1), by_term(max_rank - 2)])]
+    fl += [Or([by_term(max_rank - 1, 2.5), by_term(max_rank - 2), by_term(max_rank - 3, 0.5)])]
+    return fl
+
+
+def case_queries_all_scorers(L, num_docs, max_rank, layout=synth.LAYOUT_SIMD4, ks=(10, 1000)):
+    seg = synth.build_segment(num_docs, max_rank, layout=layout)
+    sr = search.SegmentReader.from_synth(seg, L=L)
+    filters = standard_filters(max_rank)
+    for scorer in (BM25(), BM25(1.2, 0.0), BM25(2.0, 1.0), TFIDF(False), TFIDF(True)):
+        for k in ks:
+            run_and_check(L, seg, filters, scorer, k, sr=sr)
+    sr.close()
+
+
+def case_queries_tiles_and_strides(L, num_docs, max_rank):
+    seg = synth.build_segment(num_docs, max_rank)
+    sr = search.SegmentReader.from_synth(seg, L=L)
+    filters = standard_filters(max_rank, n_or8=2)
+    ref = None
+    for tile in (4096, 8192, 16384):
+        for stride in (1, 3, 16, 1000):
+            hits, counts, totals = run_and_check(L, seg, filters, BM25(), 100, tile, stride, sr=sr)
+            # results do not depend on the tiling or on the pilot sample
+            if ref is None:
+                ref = (hits.copy(), counts.copy(), totals.copy())
+            else:
+                assert np.array_equal(ref[1], counts) and np.array_equal(ref[2], totals)
+                assert np.array_equal(ref[0], hits)
+    sr.close()
+
+
+def case_queries_ragged(L, layout=synth.LAYOUT_SIMD4):
+    """Absent terms, single-doc terms, df < 128, df == 128, tail-only and
+    block-only lists, k larger than the number of hits, empty results."""
+    rng = np.random.default_rng(3)
+    n_docs = 30_000
+    def mk(n):
+        d = np.sort(rng.choice(np.arange(1, n_docs + 1), n, replace=False)).astype(np.uint32)
+        return d, rng.integers(1, 9, n).astype(np.uint32)
+    lists = [mk(1), mk(5), mk(127), mk(128), mk(129), mk(256), mk(3000), mk(12_000), mk(1)]
+    lists.append((np.array([n_docs], np.uint32), np.array([4], np.uint32)))      # last doc only
+    lists.append((np.array([1], np.uint32), np.array([1], np.uint32)))           # first doc only
+    norms = rng.integers(1, 256, n_docs).astype(np.uint8)
+    seg, sr = open_lists(L, lists, n_docs, layout, norms)
+    nt = len(lists)
+    filters = [by_term(t) for t in range(nt)]
+    filters += [Or([by_term(0), by_term(8)]), Or([by_term(t) for t in range(nt)]),
+                Or([by_term(1), by_term(nt + 5), by_term(2)]),         # absent middle term
+                Or([by_term(nt + 1), by_term(nt + 2)]),                # all absent: empty
+                And([by_term(6), by_term(7)]), And([by_term(6), by_term(nt + 1)]),
+                And([by_term(0), by_term(8)]), And([by_term(7), by_term(6), by_term(5)]),
+                Or([by_term(9), by_term(10)])]
+    for scorer in (BM25(), TFIDF(True)):
+        for k in (1, 7, 4096):
+            run_and_check(L, seg, filters, scorer, k, 4096, 2, sr=sr)
+    sr.close()
+
+
+def case_no_norms(L):
+    seg = synth.build_segment(20_000, 128)
+    seg.norms = None
+    sr = search.SegmentReader(seg.doc_file, seg.metas, seg.num_docs, seg.layout, None, 1,
+                              seg.docs_with_field, seg.total_term_freq, L=L)
+    filters = standard_filters(128, n_or8=2)
+    for scorer in (BM25(), TFIDF(True)):
+        run_and_check(L, seg, filters, scorer, 50, sr=sr)
+    sr.close()
+
+
+def case_multi_segment(L, num_docs, max_rank, n_segs=3, k=100, device_merge=True):
+    """Segments are independent units with private doc ids; statistics are global
+    (term_filter.cpp:102-125); one heap over all segments (index-search.cpp:719-779)."""
+    per = num_docs // n_segs
+    segs = [synth.build_segment(per, max_rank, first_doc=i * per) for i in range(n_segs)]
+    # a term missing from one segment
+    segs[1].metas[max_rank - 1]["docs_count"] = 0
+    readers = [search.SegmentReader.from_synth(s, L=L) for s in segs]
+    filters = standard_filters(max_rank, n_or8=3)
+    scorer = BM25()
+    prep = search.prepare(filters, scorer, [parity.segment_stats(s) for s in segs])
+    per_seg = []
+    batches = []
+    for s, r in zip(segs, readers):
+        b = r.batch(prep, k)
+        hits, counts, totals = b.run().results()
+        parity.check_single_segment(s, filters, scorer, k, hits, counts, totals, segs)
+        per_seg.append((hits, counts))
+        batches.append(b)
+    merged = search.merge_topk_host(per_seg, k)
+    ref = parity.oracle_topk(segs, filters, scorer, k)
+    for q, (rows, (ohits, total)) in enumerate(zip(merged, ref)):
+        assert len(rows) == len(ohits), q
+        if not rows:
+            continue
+        # same score multiset as the reference harness (ties may pick other docs)
+        a = np.array([r[0] for r in rows], np.float32)
+        o = np.sort(ohits["score"])[::-1]
+        assert np.allclose(a, o, rtol=parity.REL_TOL, atol=0), q
+    if device_merge:
+        import torch
+        from iresearch_amd import distributed
+        dev = "cuda" if (torch.cuda.is_available() and "sim" not in str(L._name)) else "cpu"
+        lists = []
+        for i, b in enumerate(batches):
+            h = torch.zeros((len(filters), k), dtype=torch.int64, device=dev)
+            c = torch.zeros((len(filters),), dtype=torch.int32, device=dev)
+            b.results_to_device(h.data_ptr(), c.data_ptr())
+            if dev == "cuda":
+                torch.cuda.synchronize()
+            lists.append((i, h, c))
+        oh, os_, oc = distributed.gather_merge(L, 0, lists, n_segs, 0, 1, len(filters), k, dev)
+        if dev == "cuda":
+            torch.cuda.synchronize()
+        gh = distributed.hits_from_int64(oh)
+        gs, gc = os_.cpu().numpy(), oc.cpu().numpy()
+        for q, rows in enumerate(merged):
+            assert gc[q] == len(rows)
+            got = [(float(gh[q, i]["score"]), int(gs[q, i]), int(gh[q, i]["doc"]))
+                   for i in range(len(rows))]
+            assert got == [(float(np.float32(a)), s, d) for a, s, d in rows], q
+    for b in batches:
+        b.close()
+    for r in readers:
+        r.close()
+
+
+# ------------------------------------------------------------------ errors --
+
+def case_errors(L):
+    seg = synth.build_segment(5000, 64)
+    sr = search.SegmentReader.from_synth(seg, L=L)
+
+    def open_with(**kw):
+        args = dict(doc_file=seg.doc_file, metas=seg.metas, num_docs=seg.num_docs,
+                    layout=seg.layout, norms=seg.norms, norm_width=1,
+                    docs_with_field=seg.docs_with_field, total_term_freq=seg.total_term_freq, L=L)
+        args.update(kw)
+        return search.SegmentReader(**args)
+
+    bad = seg.doc_file.copy()
+    bad[0] ^= 0xFF                                   # magic
+    with pytest.raises(_lib.IrsHipError) as e:
+        open_with(doc_file=bad)
+    assert e.value.status == _lib.ECORRUPT
+    with pytest.raises(_lib.IrsHipError) as e:       # version says simd4
+        open_with(layout=synth.LAYOUT_SCALAR)
+    assert e.value.status == _lib.EINVAL
+    bad = seg.doc_file.copy()
+    bad[int(seg.metas[0]["doc_start"])] = 77         # block header: 77 bits
+    with pytest.raises(_lib.IrsHipError) as e:
+        open_with(doc_file=bad)
+    assert e.value.status == _lib.ECORRUPT
+    metas = seg.metas.copy()
+    metas[3]["doc_start"] = seg.doc_file.size + 5
+    with pytest.raises(_lib.IrsHipError) as e:
+        open_with(metas=metas)
+    assert e.value.status == _lib.ECORRUPT
+    with pytest.raises(_lib.IrsHipError) as e:       # no such device
+        search.SegmentReader(seg.doc_file, seg.metas, seg.num_docs, seg.layout, seg.norms, 1,
+                             device=99, L=L)
+    assert e.value.status == _lib.EHIP
+
+    prep = search.prepare([by_term(1)], BM25(), [parity.segment_stats(seg)])
+    for k in (0, _lib.MAX_K + 1):
+        with pytest.raises(_lib.IrsHipError) as e:
+            sr.batch(prep, k)
+        assert e.value.status == _lib.EINVAL
+    many = [Or([by_term(i) for i in range(_lib.MAX_TERMS + 1)])]
+    with pytest.raises(_lib.IrsHipError) as e:
+        sr.batch(search.prepare(many, BM25(), [parity.segment_stats(seg)]), 10)
+    assert e.value.status == _lib.EINVAL
+    zero = search.prepare([by_term(1, boost=0.0)], BM25(), [parity.segment_stats(seg)])
+    with pytest.raises(_lib.IrsHipError) as e:
+        sr.batch(zero, 10)
+    assert e.value.status == _lib.EUNSUPPORTED
+    # candidate buffer too small -> exact re-run (full histogram, then a grown
+    # buffer), never a silently wrong top-k
+    fl = [Or([by_term(0), by_term(1), by_term(2)]), by_term(5)]
+    run_and_check(L, seg, fl, BM25(), 16, 4096, 1000, 16, sr=sr)
+    run_and_check(L, seg, fl, BM25(0.0, 0.0), 16, 4096, 1000, 16, sr=sr)  # BM1: all scores tie
+    cnt = C.c_uint32()
+    assert L.irs_hip_decode_term(sr.handle, 10_000, None, None, 0, C.byref(cnt)) == _lib.EINVAL
+    sr.close()

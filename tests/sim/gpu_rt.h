@@ -35,6 +35,10 @@ inline bool d2h(void* h, const void* d, size_t n, stream_t) {
   if (n) std::memcpy(h, d, n);
   return true;
 }
+inline bool d2d(void* dst, const void* src, size_t n, stream_t) {
+  if (n) std::memcpy(dst, src, n);
+  return true;
+}
 inline bool dmemset(void* d, int v, size_t n, stream_t) {
   if (n) std::memset(d, v, n);
   return true;

@@ -1,0 +1,55 @@
+"""CPU tier: the product sources (host code + kernels, unmodified) compiled against
+the fiber emulator in tests/sim, driven through the C ABI, checked against the
+oracle.  Small sizes; the same bodies run on the real GPU in test_gpu_parity.py."""
+import pytest
+
+import cases
+from iresearch_amd import synth
+
+LAYOUTS = [synth.LAYOUT_SIMD4, synth.LAYOUT_SCALAR]
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_decode_reference_lists(simlib, layout):
+    cases.case_decode_reference_lists(simlib, layout)
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_decode_sizes(simlib, layout):
+    cases.case_decode_sizes(simlib, layout)
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_decode_edge_blocks(simlib, layout):
+    cases.case_decode_edge_blocks(simlib, layout)
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_decode_synth(simlib, layout):
+    cases.case_decode_synth(simlib, layout, 20_000, 300, step=3)
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_queries_all_scorers(simlib, layout):
+    cases.case_queries_all_scorers(simlib, 30_000, 256, layout)
+
+
+def test_queries_tiles_and_strides(simlib):
+    cases.case_queries_tiles_and_strides(simlib, 40_000, 256)
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_queries_ragged(simlib, layout):
+    cases.case_queries_ragged(simlib, layout)
+
+
+def test_no_norms(simlib):
+    cases.case_no_norms(simlib)
+
+
+def test_multi_segment(simlib):
+    cases.case_multi_segment(simlib, 45_000, 256)
+
+
+def test_errors(simlib):
+    cases.case_errors(simlib)

@@ -1,0 +1,163 @@
+"""The oracle against the reference's golden vectors and its own compiled codec
+(SURVEY.md §8c), plus internal consistency of the restated search loop."""
+import math
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle
+import parity
+from iresearch_amd import search, synth
+from iresearch_amd.search import BM25, TFIDF, And, Or, by_term
+
+GOLDEN = Path(__file__).parent / "golden"
+LAYOUTS = {"scalar": oracle.LAYOUT_SCALAR, "simd4": oracle.LAYOUT_SIMD4}
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(GOLDEN / "codec_golden.npz")
+
+
+@pytest.mark.parametrize("layout", ["scalar", "simd4"])
+def test_codec_matches_reference_golden(golden, layout):
+    """Packed words produced by the REFERENCE's compiled packers
+    (tests/golden/make_golden.py) for the literal vector of
+    tests/utils/bit_packing_tests.cpp:102-114 and for random data, bits 1..32."""
+    lay = LAYOUTS[layout]
+    lit = golden["literal"]
+    for bits in range(1, 33):
+        mask = np.uint32(0xFFFFFFFF if bits == 32 else (1 << bits) - 1)
+        for name, vals in (("lit", lit & mask), ("rnd", golden["random_b%d" % bits])):
+            want = golden["%s_%s_b%d" % (layout, name, bits)]
+            assert np.array_equal(oracle.pack(vals, bits, lay), want), (name, bits)
+            assert np.array_equal(oracle.unpack(want, bits, lay), vals), (name, bits)
+
+
+def test_packed_at_random_access(golden):
+    """packed::at, bit_packing_tests.cpp:162-174."""
+    lit = golden["literal"]
+    for bits in range(1, 33):
+        mask = np.uint32(0xFFFFFFFF if bits == 32 else (1 << bits) - 1)
+        words = golden["scalar_lit_b%d" % bits]
+        for i in range(126):
+            assert oracle.lib().orc_at_scalar(words.ctypes.data, i, bits) == int(lit[i] & mask)
+
+
+def test_codec_against_live_reference():
+    """Only where oracle/_ref exists (build container): the reference's own
+    unpackers on fresh random data."""
+    R = oracle.ref()
+    if R is None:
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    rng = np.random.default_rng(5)
+    for bits in range(1, 33):
+        for _ in range(4):
+            v = rng.integers(0, 1 << bits, 128, dtype=np.uint64).astype(np.uint32)
+            for lay, rp, ru in ((0, R.ref_pack_scalar, R.ref_unpack_scalar),
+                                (1, R.ref_pack_simd4, R.ref_unpack_simd4)):
+                ref = np.zeros(4 * bits, np.uint32)
+                rp(v.ctypes.data, bits, ref.ctypes.data)
+                assert np.array_equal(oracle.pack(v, bits, lay), ref)
+                out = np.zeros(128, np.uint32)
+                ru(ref.ctypes.data, bits, out.ctypes.data)
+                assert np.array_equal(out, v) and np.array_equal(oracle.unpack(ref, bits, lay), v)
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+def test_reader_roundtrip_reference_lists(layout):
+    """Independent emitter -> oracle reader on the reference's own test lists
+    (formats_10_tests.cpp:452-457; tests/resources/postings.txt, :775-864)."""
+    p = np.loadtxt(GOLDEN / "postings_6098.txt", dtype=np.uint32)
+    lists = [([1, 3, 5, 7, 79, 101, 124], [10] * 7), ([2, 7, 9, 19], [10] * 4),
+             (p, np.ones(p.size, np.uint32)), ([42], [3])]
+    seg = synth.segment_from_lists(lists, 10_000, layout)
+    for t, (d, f) in enumerate(lists):
+        od, of = oracle.decode_term(seg.doc_file, seg.metas[t], layout)
+        assert np.array_equal(od, np.asarray(d, np.uint32))
+        assert np.array_equal(of, np.asarray(f, np.uint32))
+        od2, _ = oracle.decode_term(seg.doc_file, seg.metas[t], layout, want_freq=False)
+        assert np.array_equal(od2, od)
+    # 6098 = 47 full blocks + 82 tail; skip entries: one per block boundary but the last
+    last, ptrs, levels = oracle.read_skip0(seg.doc_file, seg.metas[2])
+    assert len(last) == 47 and levels == 2  # 1 + log8(10000 / 128), skip_list.cpp:38-41
+    assert np.array_equal(last, p[127::128][:47])
+    ver = __import__("ctypes").c_int32()
+    assert oracle.lib().orc_check_doc_header(seg.doc_file.ctypes.data, seg.doc_file.size,
+                                             ver) > 0
+    assert ver.value == (5 if layout else 4)
+
+
+def test_bm25_stats_formulas():
+    """BM25::collect (bm25.cpp:366-410) restated twice (oracle C++, host Python)
+    and cross-checked in double precision."""
+    for (k, b, D, d, ttf) in [(1.2, 0.75, 10_000_000, 123_456, 1_000_123_456),
+                              (2.0, 1.0, 1000, 1, 5000), (1.2, 0.0, 500, 499, 777),
+                              (0.0, 0.75, 500, 10, 5000)]:
+        st = oracle.bm25_stats(k, b, D, d, ttf)
+        hs = BM25(k, b).collect(D, d, ttf)
+        assert np.float32(st.idf) == hs.idf
+        assert np.float32(st.norm_const) == hs.norm_const
+        if k != 0 and b != 0:
+            assert np.float32(st.norm_length) == hs.norm_length
+            avgdl = ttf / D
+            for n in (1, 7, 100, 255):
+                exact = 1.0 / (k * (1 - b) + k * b * n / avgdl)
+                assert abs(st.norm_cache[n] - exact) <= 2e-6 * exact
+            assert st.norm_cache[0] == 0.0
+        assert abs(float(st.idf) - math.log1p((D - d + 0.5) / (d + 0.5))) < 1e-6
+    assert np.float32(oracle.lib().orc_tfidf_idf(1000, 10)) == TFIDF().collect(1000, 10, 0).idf
+
+
+def test_harness_matches_exhaustive_scores():
+    """The restated index-search heap (index-search.cpp:719-787) returns the k best
+    of the exhaustive scores; OR-2 / OR-n / AND / single term; BM25 vs float64."""
+    seg = synth.build_segment(30_000, 200, keep_postings=True)
+    view = parity.oracle_view(seg)
+    sc = parity.oracle_scorer(BM25())
+    filters = [Or([by_term(3), by_term(50), by_term(120), by_term(7)]),
+               Or([by_term(10), by_term(150)]), by_term(99),
+               And([by_term(2), by_term(30), by_term(60)])]
+    res = parity.oracle_topk([seg], filters, BM25(), 50)
+    D, ttf = seg.docs_with_field, seg.total_term_freq
+    for flt, (hits, total) in zip(filters, res):
+        op, subs = search._terms_of(flt)
+        terms = [s.term for s in subs]
+        dwt = [int(seg.metas[t]["docs_count"]) for t in terms]
+        scores, matched = oracle.score_all(view, parity.metas_for(seg, terms), op, sc, D, dwt, ttf)
+        assert total == int(matched.sum())
+        want = np.sort(scores[matched.astype(bool)])[::-1][:50]
+        assert np.array_equal(np.sort(hits["score"])[::-1], want)
+        assert (hits["score"][:-1] >= hits["score"][1:]).all()
+        assert np.array_equal(scores[hits["doc"]], hits["score"])
+        # float64 model of BM25 over the raw postings
+        exact = np.zeros(seg.num_docs + 1)
+        cnt = np.zeros(seg.num_docs + 1, np.int32)
+        avgdl = ttf / D
+        for t in terms:
+            d, f = seg.postings[t + 1]
+            idf = math.log1p((D - len(d) + 0.5) / (len(d) + 0.5))
+            dl = seg.norms[d - 1].astype(np.float64)
+            tf = f.astype(np.float64)
+            exact[d] += idf * 2.2 * tf / (tf + 1.2 * (0.25 + 0.75 * dl / avgdl))
+            cnt[d] += 1
+        m = cnt == len(terms) if op == oracle.OP_AND else cnt > 0
+        assert np.array_equal(m, matched.astype(bool))
+        assert np.allclose(scores[m], exact[m], rtol=3e-6)
+
+
+def test_multi_segment_statistics_are_global():
+    """idf/avgdl come from all segments (term_filter.cpp:102-125): splitting an
+    index must not change scores."""
+    whole = synth.build_segment(20_000, 100)
+    parts = [synth.build_segment(10_000, 100, first_doc=0),
+             synth.build_segment(10_000, 100, first_doc=10_000)]
+    flt = [Or([by_term(5), by_term(40), by_term(77)])]
+    a = parity.oracle_topk([whole], flt, BM25(), 30)[0][0]
+    b = parity.oracle_topk(parts, flt, BM25(), 30)[0][0]
+    assert np.array_equal(np.sort(a["score"]), np.sort(b["score"]))
+    docs_b = np.sort(b["doc"] + 10_000 * b["segment"])
+    ties = len(np.unique(a["score"])) < 30
+    if not ties:
+        assert np.array_equal(np.sort(a["doc"]), docs_b)
