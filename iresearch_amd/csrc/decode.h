@@ -38,37 +38,63 @@ __device__ __forceinline__ uint32_t vint_from(uint64_t x, uint32_t* len) {
   return v;
 }
 
-// Values 2*lane and 2*lane+1 of a packed block payload of `bits` bits/value.
+// The two 8-byte words lane `lane` needs from a block payload to extract its
+// values 2*lane and 2*lane+1 (issued early so the loads overlap other work).
+struct RawPair {
+  uint64_t a, b;
+};
+
+template<int LAYOUT>
+__device__ __forceinline__ RawPair raw_load(const uint8_t* payload, uint32_t bits,
+                                            unsigned lane) {
+  RawPair r;
+  if (bits == 0) {  // ALL_EQUAL: the vint value follows the header byte
+    r.a = wave::load_u64(payload);
+    r.b = 0;
+  } else if (LAYOUT == kSimd4) {
+    // value j = 4r + l sits in SSE lane l at bit r*bits of that lane's stream;
+    // stream word k of lane l is u32 index 4k + l.  j = 2*lane, 2*lane+1 share
+    // r = lane>>1 and are the adjacent lanes l0, l0+1.
+    const uint32_t r_ = lane >> 1, l0 = (lane & 1u) << 1;
+    const uint32_t k = (r_ * bits) >> 5;
+    const uint8_t* p = payload + 4u * (4u * k + l0);
+    r.a = wave::load_u64(p);       // words (k, l0), (k, l0+1)
+    r.b = wave::load_u64(p + 16);  // words (k+1, l0), (k+1, l0+1)
+  } else {
+    // one little-endian bitstream, value j at bit j*bits
+    const uint32_t w = (2u * lane * bits) >> 5;
+    const uint8_t* p = payload + 4u * w;
+    r.a = wave::load_u64(p);      // words w, w+1
+    r.b = wave::load_u64(p + 4);  // words w+1, w+2
+  }
+  return r;
+}
+
+template<int LAYOUT>
+__device__ __forceinline__ void raw_extract(const RawPair& r, uint32_t bits, unsigned lane,
+                                            uint32_t& v0, uint32_t& v1) {
+  const uint32_t mask = bits >= 32 ? 0xFFFFFFFFu : ((1u << bits) - 1u);
+  if (LAYOUT == kSimd4) {
+    const uint32_t s = ((lane >> 1) * bits) & 31u;
+    const uint64_t a = (uint64_t(uint32_t(r.b)) << 32) | uint32_t(r.a);
+    const uint64_t b = (r.b & 0xFFFFFFFF00000000ull) | (r.a >> 32);
+    v0 = uint32_t(a >> s) & mask;
+    v1 = uint32_t(b >> s) & mask;
+  } else {
+    const uint32_t s = (2u * lane * bits) & 31u;
+    v0 = uint32_t(r.a >> s) & mask;
+    const uint32_t s1 = s + bits;  // <= 63
+    v1 = (s1 < 32u ? uint32_t(r.a >> s1) : uint32_t(r.b >> (s1 - 32u))) & mask;
+  }
+}
+
+// Values 2*lane and 2*lane+1 of a packed block payload of `bits` (> 0) bits/value.
 template<int LAYOUT>
 __device__ __forceinline__ void unpack_pair(const uint8_t* payload, uint32_t bits,
                                             unsigned lane, uint32_t& v0,
                                             uint32_t& v1) {
-  const uint32_t mask = bits >= 32 ? 0xFFFFFFFFu : ((1u << bits) - 1u);
-  if (LAYOUT == kSimd4) {
-    // value j = 4r + l sits in SSE lane l at bit r*bits of that lane's stream;
-    // stream word k of lane l is u32 index 4k + l.  j = 2*lane, 2*lane+1 share
-    // r = lane>>1 and are the adjacent lanes l0, l0+1.
-    const uint32_t r = lane >> 1, l0 = (lane & 1u) << 1;
-    const uint32_t bit = r * bits;
-    const uint32_t k = bit >> 5, s = bit & 31u;
-    const uint8_t* p = payload + 4u * (4u * k + l0);
-    const uint64_t lo = wave::load_u64(p);        // words (k, l0), (k, l0+1)
-    const uint64_t hi = wave::load_u64(p + 16);   // words (k+1, l0), (k+1, l0+1)
-    const uint64_t a = (uint64_t(uint32_t(hi)) << 32) | uint32_t(lo);
-    const uint64_t b = (hi & 0xFFFFFFFF00000000ull) | (lo >> 32);
-    v0 = uint32_t(a >> s) & mask;
-    v1 = uint32_t(b >> s) & mask;
-  } else {
-    // one little-endian bitstream, value j at bit j*bits
-    const uint32_t bit = 2u * lane * bits;
-    const uint32_t w = bit >> 5, s = bit & 31u;
-    const uint8_t* p = payload + 4u * w;
-    const uint64_t a = wave::load_u64(p);      // words w, w+1
-    const uint64_t b = wave::load_u64(p + 4);  // words w+1, w+2
-    v0 = uint32_t(a >> s) & mask;
-    const uint32_t s1 = s + bits;              // <= 63
-    v1 = (s1 < 32u ? uint32_t(a >> s1) : uint32_t(b >> (s1 - 32u))) & mask;
-  }
+  const RawPair r = raw_load<LAYOUT>(payload, bits, lane);
+  raw_extract<LAYOUT>(r, bits, lane, v0, v1);
 }
 
 // One framed block (header byte + payload): returns the two values of this

@@ -16,7 +16,7 @@ using namespace irs_hip;
 
 namespace {
 
-constexpr uint32_t kDefaultTile = 8192;
+constexpr uint32_t kDefaultTile = 4096;
 constexpr uint32_t kDefaultStride = 16;
 
 struct DevBuf {  // owning device allocation
@@ -170,17 +170,17 @@ bool launch_score_and(irs_hip_batch* b, rt::stream_t st) {
 template<int LAYOUT>
 bool launch_pilot_tile(irs_hip_batch* b, rt::stream_t st) {
   switch (b->tile) {
-    case 4096: return launch_pilot_and<LAYOUT, 4096>(b, st);
-    case 16384: return launch_pilot_and<LAYOUT, 16384>(b, st);
-    default: return launch_pilot_and<LAYOUT, 8192>(b, st);
+    case 2048: return launch_pilot_and<LAYOUT, 2048>(b, st);
+    case 8192: return launch_pilot_and<LAYOUT, 8192>(b, st);
+    default: return launch_pilot_and<LAYOUT, 4096>(b, st);
   }
 }
 template<int LAYOUT>
 bool launch_score_tile(irs_hip_batch* b, rt::stream_t st) {
   switch (b->tile) {
-    case 4096: return launch_score_and<LAYOUT, 4096>(b, st);
-    case 16384: return launch_score_and<LAYOUT, 16384>(b, st);
-    default: return launch_score_and<LAYOUT, 8192>(b, st);
+    case 2048: return launch_score_and<LAYOUT, 2048>(b, st);
+    case 8192: return launch_score_and<LAYOUT, 8192>(b, st);
+    default: return launch_score_and<LAYOUT, 4096>(b, st);
   }
 }
 
@@ -506,6 +506,17 @@ int irs_hip_batch_create(irs_hip_segment* seg, const irs_hip_query* queries, uin
         break;
       }
       dq.bin_scale = row.empty() ? 0.f : float(double(kBins) / upper);
+      // fixed-point accumulation: upper < 2^e, so every partial sum * 2^(61-e) < 2^61
+      int e = 0;
+      if (!row.empty()) {
+        (void)std::frexp(upper, &e);
+        if (e < -60 || e > 60) {
+          rc = IRS_HIP_EUNSUPPORTED;
+          break;
+        }
+      }
+      dq.fx_mul = std::ldexp(1.f, 29 - e);
+      dq.fx_inv = std::ldexp(1.f, e - 61);
       b->qterms.insert(b->qterms.end(), row.begin(), row.end());
       b->jt = std::max(b->jt, dq.n_terms);
       b->k_max = std::max(b->k_max, in.k);
@@ -538,7 +549,7 @@ int irs_hip_batch_create(irs_hip_segment* seg, const irs_hip_query* queries, uin
 int irs_hip_batch_configure(irs_hip_batch* b, uint32_t tile_docs, uint32_t pilot_stride,
                             uint32_t cand_cap) {
   if (!b) return IRS_HIP_EINVAL;
-  if (tile_docs && tile_docs != 4096 && tile_docs != 8192 && tile_docs != 16384)
+  if (tile_docs && tile_docs != 2048 && tile_docs != 4096 && tile_docs != 8192)
     return IRS_HIP_EINVAL;
   if (cand_cap && cand_cap < b->k_max) return IRS_HIP_EINVAL;
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;

@@ -24,6 +24,7 @@ constexpr uint32_t kThreads = 256;      // 4 wavefronts per workgroup
 constexpr uint32_t kWaves = kThreads / 64;
 constexpr uint32_t kLocalCands = 256;   // per-tile candidate staging slots in LDS
 constexpr uint32_t kSelectLds = 4096;   // keys sorted in LDS by k_select
+constexpr uint32_t kItemChunk = 256;    // (term, block) work items staged in LDS at a time
 
 enum : uint32_t {
   kStatusCorrupt = 1u,   // malformed block header / out-of-bounds offset
@@ -267,13 +268,86 @@ k_plan(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms,
 }
 
 // ------------------------------------------------------------ tile score --
+//
+// A workgroup owns one doc tile [lo, lo+TILE) of one query.  Per-doc score
+// accumulators live in LDS as 64-bit FIXED-POINT integers: integer addition is
+// associative, so the (term, block) work items of the tile can be processed by
+// the four wavefronts in any order, with no barrier between terms, and the sum
+// is still bit-reproducible.  Each per-posting score is the reference's float
+// expression, evaluated in the reference's order (bit-identical to the CPU
+// value); the fixed-point sum of those floats is exact, so the final float
+// differs from the reference's sequential float sum by rounding only (~1e-7).
+
+struct TermL {          // one query term of this tile, staged in LDS
+  uint64_t doc_start;   // absolute offset of the term's postings
+  uint64_t dir_off;     // first directory entry of the term
+  uint32_t b0;          // first block overlapping the tile
+  uint32_t nb;          // number of blocks overlapping the tile
+  uint32_t item_off;    // prefix sum of nb over the query's terms
+  uint32_t tail_n;      // > 0: the decoded tail intersects the tile
+};
+
+struct ItemL {          // one (term, block) work item
+  uint32_t rel_off;     // block offset relative to the term's doc_start
+  uint32_t base;        // last doc of the preceding block (kDocMin for block 0)
+  uint32_t bits_term;   // doc bits | freq bits << 8 | term slot << 16
+};
 
 struct TileSmem {
-  float* acc;        // [TILE] score accumulators (block_disjunction::score_buf, 512 -> TILE docs)
+  unsigned long long* acc;  // [TILE] fixed-point score accumulators (score_buf of
+                            // block_disjunction, disjunction.hpp:1087-1092, widened to TILE docs)
   uint32_t* cnt;     // [TILE/4] per-doc match counters, 1 byte each (AND only)
   uint8_t* lnorm;    // [TILE] Norm2 bytes of the tile
   float* caches;     // [kMaxCaches][256] BM25Stats::norm_cache
+  DevQTerm* qts;     // [kMaxTerms] the query's term scorers
+  TermL* tl;         // [kMaxTerms]
+  ItemL* items;      // [kItemChunk]
+  uint32_t* vars;    // [8] 0: item count
 };
+
+template<int TILE, bool AND>
+constexpr uint32_t tile_smem_bytes() {
+  return 8u * TILE + (AND ? TILE : 0) + TILE + sizeof(float) * 256 * kMaxCaches +
+         sizeof(DevQTerm) * kMaxTerms + sizeof(TermL) * kMaxTerms + sizeof(ItemL) * kItemChunk +
+         32;
+}
+
+template<int TILE, bool AND>
+__device__ __forceinline__ TileSmem carve(unsigned char* smem, unsigned char** rest) {
+  TileSmem sm;
+  sm.acc = reinterpret_cast<unsigned long long*>(smem);
+  smem += 8u * TILE;
+  sm.cnt = reinterpret_cast<uint32_t*>(smem);
+  if (AND) smem += TILE;
+  sm.lnorm = smem;
+  smem += TILE;
+  sm.caches = reinterpret_cast<float*>(smem);
+  smem += sizeof(float) * 256 * kMaxCaches;
+  sm.qts = reinterpret_cast<DevQTerm*>(smem);
+  smem += sizeof(DevQTerm) * kMaxTerms;
+  sm.tl = reinterpret_cast<TermL*>(smem);
+  smem += sizeof(TermL) * kMaxTerms;
+  sm.items = reinterpret_cast<ItemL*>(smem);
+  smem += sizeof(ItemL) * kItemChunk;
+  sm.vars = reinterpret_cast<uint32_t*>(smem);
+  smem += 32;
+  *rest = smem;
+  return sm;
+}
+
+// float score (>= 0, <= the query's upper bound) -> 64-bit fixed point with
+// 2^E units; `| 1` keeps every posting's contribution non-zero so that
+// "accumulator != 0" means "matched".
+__device__ __forceinline__ unsigned long long to_fixed(float s, float fx_mul) {
+  const float x = s * fx_mul;                       // exact: fx_mul is a power of two
+  const uint32_t hi = static_cast<uint32_t>(x);     // truncates; x < 2^29
+  const float rem = x - static_cast<float>(hi);     // exact
+  const uint32_t lo = static_cast<uint32_t>(rem * 4294967296.f);
+  return ((static_cast<unsigned long long>(hi) << 32) | lo) | 1ull;
+}
+__device__ __forceinline__ float from_fixed(unsigned long long a, float fx_inv) {
+  return static_cast<float>(a) * fx_inv;
+}
 
 __device__ __forceinline__ uint32_t norm_global(const DevSegment& seg, uint32_t doc) {
   // dense fixed-length column, big-endian values (columnstore2.cpp:736-740, norm.hpp:170-182)
@@ -325,12 +399,47 @@ __device__ __forceinline__ float score_posting(const DevSegment& seg, const DevQ
   }
 }
 
-// Zero the accumulators, stage the tile's norms, build the norm caches.
+// Prologue of one tile: zero the accumulators, stage the tile's norms, and —
+// all terms in parallel, one thread each — fetch every term's block range for
+// this tile so that no later phase waits on a chain of dependent global loads.
 template<int TILE, bool AND>
 __device__ __forceinline__ void tile_begin(const DevSegment& seg, const DevQuery& qd,
-                                           const DevQTerm* qts, uint32_t tile,
-                                           const TileSmem& sm, bool build_caches) {
-  for (uint32_t i = threadIdx.x; i < TILE; i += blockDim.x) sm.acc[i] = 0.f;
+                                           const DevQTerm* qts_g, const uint32_t* first_q,
+                                           uint32_t n_tiles, const DevTail* tails_q,
+                                           uint32_t tile, const TileSmem& sm,
+                                           bool build_caches) {
+  const uint32_t lo = kDocMin + tile * TILE;
+  const uint32_t span = (seg.num_docs + kDocMin - lo) < uint32_t(TILE)
+                          ? (seg.num_docs + kDocMin - lo) : uint32_t(TILE);
+  if (threadIdx.x < qd.n_terms) {
+    const uint32_t j = threadIdx.x;
+    if (build_caches) sm.qts[j] = qts_g[j];
+    const uint32_t term = qts_g[j].term;
+    uint64_t doc_start = 0, dir_off = 0;
+    uint32_t tb0 = 0, tnb = 0, ttail = 0;
+    if (term != kNoTerm) {
+      const DevTerm* t = seg.terms + term;
+      const uint32_t* row = first_q + uint64_t(j) * (n_tiles + 1);
+      const uint32_t b0 = row[tile];
+      uint32_t b1 = row[tile + 1] + 1u;
+      const uint32_t nblk = t->nblk;
+      b1 = b1 < nblk ? b1 : nblk;
+      doc_start = t->doc_start;
+      dir_off = t->dir_off;
+      tb0 = b0;
+      tnb = b1 > b0 ? b1 - b0 : 0u;
+      const DevTail* tl = tails_q + j;
+      const uint32_t tn = tl->n;
+      if (tn && tl->first_doc < lo + span && tl->last_doc >= lo) ttail = tn;
+    }
+    sm.tl[j].doc_start = doc_start;
+    sm.tl[j].dir_off = dir_off;
+    sm.tl[j].b0 = tb0;
+    sm.tl[j].nb = tnb;
+    sm.tl[j].item_off = 0;
+    sm.tl[j].tail_n = ttail;
+  }
+  for (uint32_t i = threadIdx.x; i < TILE; i += blockDim.x) sm.acc[i] = 0ull;
   if (AND) {
     for (uint32_t i = threadIdx.x; i < TILE / 4; i += blockDim.x) sm.cnt[i] = 0u;
   }
@@ -343,67 +452,142 @@ __device__ __forceinline__ void tile_begin(const DevSegment& seg, const DevQuery
       *reinterpret_cast<uint32_t*>(sm.lnorm + i) = w;
     }
   }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t off = 0;
+    for (uint32_t j = 0; j < qd.n_terms; ++j) {
+      sm.tl[j].item_off = off;
+      off += sm.tl[j].nb;
+    }
+    sm.vars[0] = off;
+  }
   if (build_caches) {
     // BM25::collect: norm_cache[i] = 1/(norm_const + norm_length*i), [0] = 0 (bm25.cpp:404-409)
     for (uint32_t e = threadIdx.x; e < qd.n_caches * 256u; e += blockDim.x) {
       const uint32_t c = e >> 8, n = e & 255u;
       float nc = 0.f, nl = 0.f;
       for (uint32_t j = 0; j < qd.n_terms; ++j) {
-        if (qts[j].cache_id == c) { nc = qts[j].norm_const; nl = qts[j].norm_length; break; }
+        if (sm.qts[j].cache_id == c) {
+          nc = sm.qts[j].norm_const;
+          nl = sm.qts[j].norm_length;
+          break;
+        }
       }
       sm.caches[e] = n ? 1.f / (nc + nl * static_cast<float>(n)) : 0.f;
     }
   }
+  __syncthreads();
 }
 
-// All postings of the query's terms that fall into doc tile `tile`, term by
-// term in query order (deterministic float sums): the GPU form of
-// block_disjunction::refill (disjunction.hpp:1240-1351) with the 512-doc window
-// widened to TILE docs held in LDS, and of Conjunction via per-doc counters.
+// All postings of the query's terms that fall into doc tile `tile`: the GPU
+// form of block_disjunction::refill (disjunction.hpp:1240-1351), with the
+// 512-doc window widened to TILE docs in LDS, and of Conjunction via per-doc
+// match counters.  Work items are (term, block) pairs; a wavefront decodes one
+// block at a time and always has the NEXT item's payload loads in flight.
 template<int LAYOUT, int TILE, bool AND>
 __device__ __forceinline__ void tile_accumulate(const DevSegment& seg, const DevQuery& qd,
-                                                const DevQTerm* qts, const uint32_t* first_q,
-                                                uint32_t n_tiles, const DevTail* tails_q,
-                                                uint32_t tile, const TileSmem& sm) {
+                                                const DevTail* tails_q, uint32_t tile,
+                                                const TileSmem& sm) {
   const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
   const uint32_t nw = blockDim.x >> 6;
   const uint32_t lo = kDocMin + tile * TILE;
   const uint32_t span = (seg.num_docs + kDocMin - lo) < uint32_t(TILE)
                           ? (seg.num_docs + kDocMin - lo) : uint32_t(TILE);
-  for (uint32_t j = 0; j < qd.n_terms; ++j) {
-    const DevQTerm qt = qts[j];
-    if (qt.term != kNoTerm) {
-      const DevTerm& t = seg.terms[qt.term];
-      const uint32_t* row = first_q + uint64_t(j) * (n_tiles + 1);
-      const uint32_t b0 = row[tile];
-      uint32_t b1 = row[tile + 1] + 1u;
-      b1 = b1 < t.nblk ? b1 : t.nblk;
-      const float inv_one = 1.f / (qt.norm_const + qt.norm_length * 1.f);
-      auto apply = [&](uint32_t doc, uint32_t freq) {
-        const uint32_t idx = doc - lo;  // doc < lo wraps to a huge value
-        if (idx < span) {
-          const float s = score_posting(seg, qt, inv_one, sm, freq, doc, idx);
-          wave::lds_add(&sm.acc[idx], s);
-          if (AND) atomicAdd(&sm.cnt[idx >> 2], 1u << (8u * (idx & 3u)));
-        }
-      };
-      for (uint32_t b = b0 + wv; b < b1; b += nw) {
-        const uint64_t e = t.dir_off + b;
-        const uint32_t bits = seg.blk_bits[e];
-        const uint32_t base = b ? seg.blk_last[e - 1] : kDocMin;
-        const uint8_t* blk = seg.doc + t.doc_start + seg.blk_off[e];
-        uint32_t d0, d1, f0, f1;
-        decode_block<LAYOUT, true>(blk, bits & 0xFFu, bits >> 8, base, lane, d0, d1, f0, f1);
-        apply(d0, f0);
-        apply(d1, f1);
-      }
-      const DevTail& tl = tails_q[j];
-      if (wv == 0 && tl.n && tl.first_doc < lo + span && tl.last_doc >= lo) {
-        for (uint32_t i = lane; i < tl.n; i += 64) apply(tl.docs[i], tl.freqs[i]);
-      }
+  const float fx_mul = qd.fx_mul;
+  const uint32_t n_items = sm.vars[0];
+
+  auto apply = [&](const DevQTerm& qt, float inv_one, uint32_t doc, uint32_t freq) {
+    const uint32_t idx = doc - lo;  // doc < lo wraps to a huge value
+    if (idx < span) {
+      const float s = score_posting(seg, qt, inv_one, sm, freq, doc, idx);
+      atomicAdd(&sm.acc[idx], to_fixed(s, fx_mul));
+      if (AND) atomicAdd(&sm.cnt[idx >> 2], 1u << (8u * (idx & 3u)));
     }
-    __syncthreads();  // term order == summation order
+  };
+  // raw payload words of item `it` (two per block part), loaded ahead of use
+  auto load_item = [&](uint32_t it, uint64_t& da, uint64_t& db, uint64_t& fa, uint64_t& fb) {
+    const uint32_t bt = sm.items[it].bits_term;
+    const uint32_t dbits = bt & 0xFFu, fbits = (bt >> 8) & 0xFFu;
+    const uint8_t* blk = seg.doc + sm.tl[bt >> 16].doc_start + sm.items[it].rel_off;
+    const RawPair d = raw_load<LAYOUT>(blk + 1, dbits, lane);
+    da = d.a;
+    db = d.b;
+    // the freq block starts right after the doc block; an ALL_EQUAL doc block
+    // (vint payload) has a data-dependent size and is fetched at use instead
+    if (dbits) {
+      const RawPair f = raw_load<LAYOUT>(blk + 2u + 16u * dbits, fbits, lane);
+      fa = f.a;
+      fb = f.b;
+    }
+  };
+  auto compute_item = [&](uint32_t it, uint64_t da, uint64_t db, uint64_t fa, uint64_t fb) {
+    const uint32_t bt = sm.items[it].bits_term;
+    const uint32_t base = sm.items[it].base;
+    const uint32_t dbits = bt & 0xFFu, fbits = (bt >> 8) & 0xFFu;
+    const uint32_t j = bt >> 16;
+    const DevQTerm qt = sm.qts[j];
+    const float inv_one = 1.f / (qt.norm_const + qt.norm_length * 1.f);
+    uint32_t x0, x1, f0, f1;
+    RawPair rd, rf;
+    rd.a = da; rd.b = db; rf.a = fa; rf.b = fb;
+    if (dbits) {
+      raw_extract<LAYOUT>(rd, dbits, lane, x0, x1);
+    } else {
+      uint32_t len;
+      x0 = x1 = vint_from(da, &len);
+      const uint8_t* blk = seg.doc + sm.tl[j].doc_start + sm.items[it].rel_off;
+      rf = raw_load<LAYOUT>(blk + 2u + len, fbits, lane);
+    }
+    if (fbits) {
+      raw_extract<LAYOUT>(rf, fbits, lane, f0, f1);
+    } else {
+      uint32_t len;
+      f0 = f1 = vint_from(rf.a, &len);
+    }
+    const uint32_t d1 = base + wave::inclusive_scan(x0 + x1);
+    apply(qt, inv_one, d1 - x1, f0);
+    apply(qt, inv_one, d1, f1);
+  };
+
+  for (uint32_t c0 = 0; c0 < n_items; c0 += kItemChunk) {
+    const uint32_t n = (n_items - c0) < kItemChunk ? (n_items - c0) : kItemChunk;
+    if (c0) __syncthreads();  // previous chunk fully consumed
+    if (threadIdx.x < n) {
+      const uint32_t id = c0 + threadIdx.x;
+      uint32_t j = 0;
+      while (id >= sm.tl[j].item_off + sm.tl[j].nb) ++j;
+      const uint32_t b = sm.tl[j].b0 + (id - sm.tl[j].item_off);
+      const uint64_t e = sm.tl[j].dir_off + b;
+      ItemL I;
+      I.rel_off = seg.blk_off[e];
+      I.base = b ? seg.blk_last[e - 1] : kDocMin;
+      I.bits_term = uint32_t(seg.blk_bits[e]) | (j << 16);
+      sm.items[threadIdx.x] = I;
+    }
+    __syncthreads();
+    uint32_t it = wv;
+    uint64_t cda = 0, cdb = 0, cfa = 0, cfb = 0;
+    if (it < n) load_item(it, cda, cdb, cfa, cfb);
+    while (it < n) {
+      const uint32_t ni = it + nw;
+      uint64_t nda = 0, ndb = 0, nfa = 0, nfb = 0;
+      if (ni < n) load_item(ni, nda, ndb, nfa, nfb);
+      compute_item(it, cda, cdb, cfa, cfb);
+      cda = nda; cdb = ndb; cfa = nfa; cfb = nfb;
+      it = ni;
+    }
   }
+  // decoded vint tails / single-doc terms (k_plan), one term per wavefront
+  for (uint32_t j = wv; j < qd.n_terms; j += nw) {
+    const uint32_t tn = sm.tl[j].tail_n;
+    if (tn) {
+      const DevQTerm qt = sm.qts[j];
+      const float inv_one = 1.f / (qt.norm_const + qt.norm_length * 1.f);
+      const DevTail* tl = tails_q + j;
+      for (uint32_t i = lane; i < tn; i += 64) apply(qt, inv_one, tl->docs[i], tl->freqs[i]);
+    }
+  }
+  __syncthreads();
 }
 
 __device__ __forceinline__ uint32_t score_bin(float v, float scale) {
@@ -411,41 +595,15 @@ __device__ __forceinline__ uint32_t score_bin(float v, float scale) {
   return uint32_t(x);
 }
 
-template<int TILE, bool AND>
-__device__ __forceinline__ TileSmem carve(unsigned char* smem, unsigned char** rest) {
-  TileSmem sm;
-  sm.acc = reinterpret_cast<float*>(smem);
-  smem += sizeof(float) * TILE;
-  sm.cnt = reinterpret_cast<uint32_t*>(smem);
-  if (AND) smem += TILE;
-  sm.lnorm = smem;
-  smem += TILE;
-  sm.caches = reinterpret_cast<float*>(smem);
-  smem += sizeof(float) * 256 * kMaxCaches;
-  *rest = smem;
-  return sm;
-}
-
-template<int TILE, bool AND>
-constexpr uint32_t tile_smem_bytes() {
-  return sizeof(float) * TILE + (AND ? TILE : 0) + TILE + sizeof(float) * 256 * kMaxCaches;
-}
-
-// Did doc slot i match the query?  OR: any posting landed (scores are > 0);
-// AND: every term's posting landed (Conjunction::converge, conjunction.hpp:207-223).
+// Did doc slot i match the query?  OR: any posting landed (every posting adds a
+// non-zero amount); AND: every term's posting landed (Conjunction::converge,
+// conjunction.hpp:207-223).
 template<bool AND>
 __device__ __forceinline__ bool doc_matched(const DevQuery& qd, const TileSmem& sm, uint32_t i,
-                                            float v, uint32_t need) {
+                                            unsigned long long a) {
   if (AND && qd.op == 1)
-    return need && ((sm.cnt[i >> 2] >> (8u * (i & 3u))) & 0xFFu) == need;
-  return v != 0.f;
-}
-
-// number of query terms present in this segment (AND needs all of them)
-__device__ __forceinline__ uint32_t present_terms(const DevQuery& qd, const DevQTerm* qts) {
-  uint32_t n = 0;
-  for (uint32_t j = 0; j < qd.n_terms; ++j) n += qts[j].term != kNoTerm;
-  return n;
+    return qd.n_terms && ((sm.cnt[i >> 2] >> (8u * (i & 3u))) & 0xFFu) == qd.n_terms;
+  return a != 0ull;
 }
 
 // ----------------------------------------------------------------- pilot --
@@ -468,18 +626,16 @@ k_pilot(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
   const DevQTerm* qts = qterms + qd.first_term;
   const uint32_t* first_q = first + uint64_t(q) * jt * (n_tiles + 1);
   const DevTail* tails_q = tails + uint64_t(q) * jt;
-  const uint32_t need = present_terms(qd, qts);
   for (uint32_t i = threadIdx.x; i < kBins; i += blockDim.x) hist[i] = 0u;
   bool first_tile = true;
   for (uint32_t tile = (q * 7u) % stride; tile < n_tiles; tile += stride) {
-    tile_begin<TILE, AND>(seg, qd, qts, tile, sm, first_tile);
+    tile_begin<TILE, AND>(seg, qd, qts, first_q, n_tiles, tails_q, tile, sm, first_tile);
     first_tile = false;
-    __syncthreads();
-    tile_accumulate<LAYOUT, TILE, AND>(seg, qd, qts, first_q, n_tiles, tails_q, tile, sm);
+    tile_accumulate<LAYOUT, TILE, AND>(seg, qd, tails_q, tile, sm);
     for (uint32_t i = threadIdx.x; i < TILE; i += blockDim.x) {
-      const float v = sm.acc[i];
-      if (doc_matched<AND>(qd, sm, i, v, need))
-        atomicAdd(&hist[score_bin(v, qd.bin_scale)], 1u);
+      const unsigned long long a = sm.acc[i];
+      if (doc_matched<AND>(qd, sm, i, a))
+        atomicAdd(&hist[score_bin(from_fixed(a, qd.fx_inv), qd.bin_scale)], 1u);
     }
     __syncthreads();
   }
@@ -528,20 +684,20 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
   if ((blockIdx.x >> 3) >= per || w >= n_work) return;
   const uint32_t q = w / n_tiles, tile = w % n_tiles;
   const DevQuery qd = queries[q];
-  const DevQTerm* qts = qterms + qd.first_term;
-  const uint32_t need = present_terms(qd, qts);
+  const DevTail* tails_q = tails + uint64_t(q) * jt;
   if (threadIdx.x < 4) lvars[threadIdx.x] = 0u;
-  tile_begin<TILE, AND>(seg, qd, qts, tile, sm, true);
-  __syncthreads();
-  tile_accumulate<LAYOUT, TILE, AND>(seg, qd, qts, first + uint64_t(q) * jt * (n_tiles + 1),
-                                     n_tiles, tails + uint64_t(q) * jt, tile, sm);
+  tile_begin<TILE, AND>(seg, qd, qterms + qd.first_term,
+                        first + uint64_t(q) * jt * (n_tiles + 1), n_tiles, tails_q, tile, sm,
+                        true);
+  tile_accumulate<LAYOUT, TILE, AND>(seg, qd, tails_q, tile, sm);
   const uint32_t lo = kDocMin + tile * TILE;
   const uint32_t bs = bstar[q];
   uint32_t my_hits = 0;
   for (uint32_t i = threadIdx.x; i < TILE; i += blockDim.x) {
-    const float v = sm.acc[i];
-    if (doc_matched<AND>(qd, sm, i, v, need)) {
+    const unsigned long long a = sm.acc[i];
+    if (doc_matched<AND>(qd, sm, i, a)) {
       ++my_hits;
+      const float v = from_fixed(a, qd.fx_inv);
       if (score_bin(v, qd.bin_scale) >= bs) {
         const uint64_t key = make_key(v, lo + i);
         const uint32_t slot = atomicAdd(&lvars[0], 1u);

@@ -69,9 +69,10 @@ struct DevQuery {
   uint32_t n_terms;
   uint32_t first_term;  // into the DevQTerm array
   uint32_t k;
-  float bin_scale;      // kBins / (upper bound of the query's score)
+  float bin_scale;      // kBins / (upper bound U of the query's score)
   uint32_t n_caches;
-  uint32_t pad0, pad1;
+  float fx_mul;         // 2^(E-32): float score -> high word of the fixed-point value
+  float fx_inv;         // 2^-E, E = 61 - ceil(log2 U): fixed-point sum -> float
 };
 
 struct DevQTerm {

@@ -157,7 +157,7 @@ def case_queries_tiles_and_strides(L, num_docs, max_rank):
     sr = search.SegmentReader.from_synth(seg, L=L)
     filters = standard_filters(max_rank, n_or8=2)
     ref = None
-    for tile in (4096, 8192, 16384):
+    for tile in (2048, 4096, 8192):
         for stride in (1, 3, 16, 1000):
             hits, counts, totals = run_and_check(L, seg, filters, BM25(), 100, tile, stride, sr=sr)
             # results do not depend on the tiling or on the pilot sample
@@ -239,7 +239,10 @@ def case_multi_segment(L, num_docs, max_rank, n_segs=3, k=100, device_merge=True
     if device_merge:
         import torch
         from iresearch_amd import distributed
-        dev = "cuda" if (torch.cuda.is_available() and "sim" not in str(L._name)) else "cpu"
+        import ctypes
+        arch = ctypes.create_string_buffer(64)
+        L.irs_hip_device_arch(0, arch, 64)
+        dev = "cpu" if arch.value.endswith(b"-sim") else "cuda"
         lists = []
         for i, b in enumerate(batches):
             h = torch.zeros((len(filters), k), dtype=torch.int64, device=dev)

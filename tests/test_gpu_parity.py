@@ -82,6 +82,6 @@ def test_config3_or8_top1000_subset(gpulib):
     filters = [Or([by_term(int(r) - 1) for r in row]) for row in ranks]
     sr = search.SegmentReader.from_synth(seg, L=gpulib)
     h1, c1, t1 = cases.run_and_check(gpulib, seg, filters, BM25(), 1000, sr=sr)
-    h2, c2, t2 = cases.run_and_check(gpulib, seg, filters, BM25(), 1000, 16384, 4, sr=sr)
+    h2, c2, t2 = cases.run_and_check(gpulib, seg, filters, BM25(), 1000, 8192, 4, sr=sr)
     assert np.array_equal(h1, h2) and np.array_equal(c1, c2) and np.array_equal(t1, t2)
     sr.close()

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Dev utility: build the bench index once, then time several batch
+configurations (tile size, pilot stride) back to back on one GPU.
+  python tools/sweep.py --docs 10000000 --configs 8192:16,4096:16,16384:16,8192:64
+"""
+import argparse
+import ctypes
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--docs", type=int, default=10_000_000)
+    ap.add_argument("--queries", type=int, default=1000)
+    ap.add_argument("--k", type=int, default=1000)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--configs", default="4096:16")
+    args = ap.parse_args()
+    import torch
+
+    from iresearch_amd import _lib, search, synth
+    from iresearch_amd.search import BM25, Or, by_term
+    L = _lib.lib()
+    seg = synth.build_segment(args.docs, 4096)
+    sr = search.SegmentReader.from_synth(seg, L=L)
+    ranks = synth.make_queries(args.queries, 8, 16, 4096, synth.SEED + 2)
+    filters = [Or([by_term(int(r) - 1) for r in row]) for row in ranks]
+    st = search.SegmentStats(seg.docs_with_field, seg.total_term_freq,
+                             np.asarray(seg.metas["docs_count"]))
+    prep = search.prepare(filters, BM25(), [st])
+    ref = None
+    for cfg in args.configs.split(","):
+        tile, stride = (int(x) for x in cfg.split(":"))
+        b = sr.batch(prep, args.k).configure(tile, stride, 0).profile(True)
+        b.run()
+        hits, counts, totals = b.results()
+        if ref is None:
+            ref = hits.copy()
+        same = bool(np.array_equal(ref, hits))
+        ms = []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            b.run()
+            ms.append(b.timings())
+        dt = (time.perf_counter() - t0) / args.steps
+        avg = np.mean(ms, axis=0)
+        alg, post = b.work()
+        print("tile=%d stride=%d  step %.2f ms  qps %.0f  plan %.2f pilot %.2f score %.2f select %.2f"
+              "  score GB/s %.1f  same_hits=%s" % (tile, stride, dt * 1e3, args.queries / dt, *avg,
+                                                    alg / avg[2] / 1e6, same), flush=True)
+        b.close()
+
+
+if __name__ == "__main__":
+    main()
