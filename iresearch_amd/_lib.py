@@ -109,6 +109,13 @@ def lib() -> C.CDLL:
     """The product library. Raises if it cannot be built/loaded."""
     global _lib
     if _lib is None:
+        try:
+            # One HIP runtime per process: torch bundles its own libamdhip64.so.7;
+            # loading it first makes libirs_hip.so (same SONAME) share it, so that
+            # torch.distributed/RCCL tensors and our kernels see the same device context.
+            import torch  # noqa: F401
+        except ImportError:  # the C ABI itself does not need torch
+            pass
         _lib = bind(C.CDLL(str(_build.build_hip())))
     return _lib
 

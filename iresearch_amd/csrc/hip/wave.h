@@ -1,4 +1,4 @@
-// wave.h — wavefront (64-lane) primitives for gfx950.
+// wave.h — wavefront (64-lane) primitives for gfx950 (CDNA4).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -10,13 +10,22 @@ namespace wave {
 
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
 
-// Inclusive prefix sum across the 64 lanes of a wavefront.
+// DPP move with zero fill for lanes whose source is out of range / masked off.
+template<int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_zero(uint32_t v) {
+  return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), CTRL, ROW_MASK, 0xF, true));
+}
+
+// Inclusive prefix sum across the 64 lanes of a wavefront, entirely in the
+// VALU cross-lane network (no LDS traffic): row_shr 1/2/4/8 inside each row of
+// 16 lanes, then row_bcast:15 (rows 1,3) and row_bcast:31 (rows 2,3).
 __device__ __forceinline__ uint32_t inclusive_scan(uint32_t v) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t up = __shfl_up(v, d, 64);
-    if (lane_id() >= unsigned(d)) v += up;
-  }
+  v += dpp_zero<0x111, 0xF>(v);  // row_shr:1
+  v += dpp_zero<0x112, 0xF>(v);  // row_shr:2
+  v += dpp_zero<0x114, 0xF>(v);  // row_shr:4
+  v += dpp_zero<0x118, 0xF>(v);  // row_shr:8
+  v += dpp_zero<0x142, 0xA>(v);  // row_bcast:15 -> rows 1 and 3
+  v += dpp_zero<0x143, 0xC>(v);  // row_bcast:31 -> rows 2 and 3
   return v;
 }
 
@@ -37,6 +46,18 @@ __device__ __forceinline__ uint32_t bcast(uint32_t v, int src_lane) {
   return __shfl(v, src_lane, 64);
 }
 __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+
+// A value known to be identical in every lane -> SGPR, so that branches on it
+// are scalar branches instead of exec-mask juggling.
+__device__ __forceinline__ uint32_t uniform(uint32_t v) {
+  return uint32_t(__builtin_amdgcn_readfirstlane(int(v)));
+}
+__device__ __forceinline__ float uniform_f(float v) {
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+
+// v_rcp_f32: <= 1 ulp
+__device__ __forceinline__ float fast_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
 
 // LDS float accumulate without a returned value -> ds_add_f32
 __device__ __forceinline__ void lds_add(float* p, float v) { atomicAdd(p, v); }

@@ -496,6 +496,7 @@ __device__ __forceinline__ void tile_accumulate(const DevSegment& seg, const Dev
   const float fx_mul = qd.fx_mul;
   const uint32_t n_items = sm.vars[0];
 
+  // generic scorer (every kind), used off the hot path
   auto apply = [&](const DevQTerm& qt, float inv_one, uint32_t doc, uint32_t freq) {
     const uint32_t idx = doc - lo;  // doc < lo wraps to a huge value
     if (idx < span) {
@@ -504,11 +505,28 @@ __device__ __forceinline__ void tile_accumulate(const DevSegment& seg, const Dev
       if (AND) atomicAdd(&sm.cnt[idx >> 2], 1u << (8u * (idx & 3u)));
     }
   };
-  // raw payload words of item `it` (two per block part), loaded ahead of use
+  // hot path: BM25 with 1-byte norms through the LDS norm_cache
+  // (bm25.cpp:348-353): c0 - c0/(1 + tf*cache[norm]); the division is one
+  // v_rcp_f32 (<= 1 ulp, far inside the 1e-5 parity tolerance)
+  auto apply_bm25 = [&](float c0, const float* cache, uint32_t doc, uint32_t freq) {
+    const uint32_t idx = doc - lo;
+    if (idx < span) {
+      const float x = static_cast<float>(freq) * cache[sm.lnorm[idx]];
+      const float s = c0 - c0 * wave::fast_rcp(1.f + x);
+      atomicAdd(&sm.acc[idx], to_fixed(s, fx_mul));
+      if (AND) atomicAdd(&sm.cnt[idx >> 2], 1u << (8u * (idx & 3u)));
+    }
+  };
+  // raw payload words of item `it` (two per block part), loaded ahead of use;
+  // everything read from the item table is wave-uniform -> scalar registers
   auto load_item = [&](uint32_t it, uint64_t& da, uint64_t& db, uint64_t& fa, uint64_t& fb) {
-    const uint32_t bt = sm.items[it].bits_term;
+    const uint32_t bt = wave::uniform(sm.items[it].bits_term);
+    const uint32_t rel = wave::uniform(sm.items[it].rel_off);
     const uint32_t dbits = bt & 0xFFu, fbits = (bt >> 8) & 0xFFu;
-    const uint8_t* blk = seg.doc + sm.tl[bt >> 16].doc_start + sm.items[it].rel_off;
+    const uint64_t ds = sm.tl[bt >> 16].doc_start;
+    const uint64_t start = (uint64_t(wave::uniform(uint32_t(ds >> 32))) << 32) |
+                           wave::uniform(uint32_t(ds));
+    const uint8_t* blk = seg.doc + start + rel;
     const RawPair d = raw_load<LAYOUT>(blk + 1, dbits, lane);
     da = d.a;
     db = d.b;
@@ -521,12 +539,10 @@ __device__ __forceinline__ void tile_accumulate(const DevSegment& seg, const Dev
     }
   };
   auto compute_item = [&](uint32_t it, uint64_t da, uint64_t db, uint64_t fa, uint64_t fb) {
-    const uint32_t bt = sm.items[it].bits_term;
-    const uint32_t base = sm.items[it].base;
+    const uint32_t bt = wave::uniform(sm.items[it].bits_term);
+    const uint32_t base = wave::uniform(sm.items[it].base);
     const uint32_t dbits = bt & 0xFFu, fbits = (bt >> 8) & 0xFFu;
     const uint32_t j = bt >> 16;
-    const DevQTerm qt = sm.qts[j];
-    const float inv_one = 1.f / (qt.norm_const + qt.norm_length * 1.f);
     uint32_t x0, x1, f0, f1;
     RawPair rd, rf;
     rd.a = da; rd.b = db; rf.a = fa; rf.b = fb;
@@ -545,8 +561,19 @@ __device__ __forceinline__ void tile_accumulate(const DevSegment& seg, const Dev
       f0 = f1 = vint_from(rf.a, &len);
     }
     const uint32_t d1 = base + wave::inclusive_scan(x0 + x1);
-    apply(qt, inv_one, d1 - x1, f0);
-    apply(qt, inv_one, d1, f1);
+    const uint32_t kind = wave::uniform(uint32_t(sm.qts[j].kind));
+    const uint32_t cid = wave::uniform(sm.qts[j].cache_id);
+    if (kind == uint32_t(kBM25Tiny) && cid < kMaxCaches) {
+      const float c0 = wave::uniform_f(sm.qts[j].c0);
+      const float* cache = sm.caches + cid * 256u;
+      apply_bm25(c0, cache, d1 - x1, f0);
+      apply_bm25(c0, cache, d1, f1);
+    } else {
+      const DevQTerm qt = sm.qts[j];
+      const float inv_one = 1.f / (qt.norm_const + qt.norm_length * 1.f);
+      apply(qt, inv_one, d1 - x1, f0);
+      apply(qt, inv_one, d1, f1);
+    }
   };
 
   for (uint32_t c0 = 0; c0 < n_items; c0 += kItemChunk) {
@@ -692,11 +719,19 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
   tile_accumulate<LAYOUT, TILE, AND>(seg, qd, tails_q, tile, sm);
   const uint32_t lo = kDocMin + tile * TILE;
   const uint32_t bs = bstar[q];
+  // cheap pre-filter in the fixed-point domain: a conservative lower bound of the
+  // accumulator value at the lower edge of bin `bs`; the exact bin test follows
+  unsigned long long thr = 1ull;
+  if (bs) {
+    const double edge = double(bs) / double(qd.bin_scale);
+    thr = static_cast<unsigned long long>(edge / double(qd.fx_inv) * (1.0 - 1e-6));
+  }
   uint32_t my_hits = 0;
   for (uint32_t i = threadIdx.x; i < TILE; i += blockDim.x) {
     const unsigned long long a = sm.acc[i];
     if (doc_matched<AND>(qd, sm, i, a)) {
       ++my_hits;
+      if (a < thr) continue;
       const float v = from_fixed(a, qd.fx_inv);
       if (score_bin(v, qd.bin_scale) >= bs) {
         const uint64_t key = make_key(v, lo + i);

@@ -1,0 +1,63 @@
+// tests/sim/wave.h — TEST INFRASTRUCTURE ONLY: portable (shuffle-based) versions of
+// iresearch_amd/csrc/hip/wave.h for the CPU fiber emulator.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#define IRS_WAVE 64
+
+namespace wave {
+
+__device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
+
+// Inclusive prefix sum across the 64 lanes of a wavefront.
+__device__ __forceinline__ uint32_t inclusive_scan(uint32_t v) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = __shfl_up(v, d, 64);
+    if (lane_id() >= unsigned(d)) v += up;
+  }
+  return v;
+}
+
+__device__ __forceinline__ uint32_t reduce_add(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+__device__ __forceinline__ uint32_t reduce_max(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const uint32_t o = __shfl_xor(v, d, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+__device__ __forceinline__ uint32_t bcast(uint32_t v, int src_lane) {
+  return __shfl(v, src_lane, 64);
+}
+__device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+
+// LDS float accumulate without a returned value -> ds_add_f32
+__device__ __forceinline__ void lds_add(float* p, float v) { atomicAdd(p, v); }
+
+// Unaligned little-endian loads from the byte-granular `.doc` stream.
+__device__ __forceinline__ uint64_t load_u64(const uint8_t* p) {
+  uint64_t v;
+  __builtin_memcpy(&v, p, 8);
+  return v;
+}
+__device__ __forceinline__ uint32_t load_u32(const uint8_t* p) {
+  uint32_t v;
+  __builtin_memcpy(&v, p, 4);
+  return v;
+}
+
+// wave-uniform value -> scalar register on the GPU; identity here
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return v; }
+__device__ __forceinline__ float uniform_f(float v) { return v; }
+// v_rcp_f32 on the GPU (<= 1 ulp); exact division here
+__device__ __forceinline__ float fast_rcp(float v) { return 1.0f / v; }
+
+}  // namespace wave

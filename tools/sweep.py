@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--k", type=int, default=1000)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--configs", default="4096:16")
+    ap.add_argument("--nocheck", action="store_true")
     args = ap.parse_args()
     import torch
 
