@@ -29,6 +29,23 @@ __device__ __forceinline__ uint32_t inclusive_scan(uint32_t v) {
   return v;
 }
 
+// Two independent scans interleaved: each DPP step of one chain fills the
+// wait states of the other.
+__device__ __forceinline__ void inclusive_scan2(uint32_t& a, uint32_t& b) {
+  a += dpp_zero<0x111, 0xF>(a);
+  b += dpp_zero<0x111, 0xF>(b);
+  a += dpp_zero<0x112, 0xF>(a);
+  b += dpp_zero<0x112, 0xF>(b);
+  a += dpp_zero<0x114, 0xF>(a);
+  b += dpp_zero<0x114, 0xF>(b);
+  a += dpp_zero<0x118, 0xF>(a);
+  b += dpp_zero<0x118, 0xF>(b);
+  a += dpp_zero<0x142, 0xA>(a);
+  b += dpp_zero<0x142, 0xA>(b);
+  a += dpp_zero<0x143, 0xC>(a);
+  b += dpp_zero<0x143, 0xC>(b);
+}
+
 __device__ __forceinline__ uint32_t reduce_add(uint32_t v) {
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
@@ -54,6 +71,14 @@ __device__ __forceinline__ uint32_t uniform(uint32_t v) {
 }
 __device__ __forceinline__ float uniform_f(float v) {
   return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+
+// Lane `k` (wave-uniform index) of a per-lane value -> SGPR (v_readlane_b32).
+__device__ __forceinline__ uint32_t read_lane(uint32_t v, uint32_t k) {
+  return uint32_t(__builtin_amdgcn_readlane(int(v), int(k)));
+}
+__device__ __forceinline__ float read_lane_f(float v, uint32_t k) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), int(k)));
 }
 
 // v_rcp_f32: <= 1 ulp

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -83,6 +84,7 @@ struct irs_hip_batch {
   uint32_t tile = kDefaultTile, stride = kDefaultStride, cand_cap = 0;
   uint32_t n_tiles = 0;
   uint32_t stride_eff = 1;  // pilot stride actually used (>= 4 pilot tiles when possible)
+  uint32_t wg_threads = kThreads;  // threads per pilot/score workgroup
   bool any_and = false;
   bool scratch_ready = false;
   std::vector<DevQuery> queries;
@@ -134,7 +136,7 @@ bool launch_pilot(irs_hip_batch* b, rt::stream_t st) {
   const size_t smem = tile_smem_bytes<TILE, AND>() + kBins * sizeof(uint32_t);
   auto kern = k_pilot<LAYOUT, TILE, AND>;
   if (!big_smem(kern, smem)) return false;
-  RT_LAUNCH(kern, b->nq, kThreads, smem, st, b->seg->dev, b->d_queries.as<DevQuery>(),
+  RT_LAUNCH(kern, b->nq, b->wg_threads, smem, st, b->seg->dev, b->d_queries.as<DevQuery>(),
             b->d_qterms.as<DevQTerm>(), b->jt, b->n_tiles, b->stride_eff,
             b->d_first.as<uint32_t>(), b->d_tails.as<DevTail>(), b->d_bstar.as<uint32_t>());
   return rt::last_error_ok();
@@ -149,7 +151,7 @@ bool launch_score(irs_hip_batch* b, rt::stream_t st) {
   if (n_work64 > 0x7FFFFFF0ull) return false;
   const uint32_t n_work = uint32_t(n_work64);
   const uint32_t grid = ((n_work + 7u) / 8u) * 8u;
-  RT_LAUNCH(kern, grid, kThreads, smem, st, b->seg->dev, b->d_queries.as<DevQuery>(),
+  RT_LAUNCH(kern, grid, b->wg_threads, smem, st, b->seg->dev, b->d_queries.as<DevQuery>(),
             b->d_qterms.as<DevQTerm>(), b->jt, b->n_tiles, n_work,
             b->d_first.as<uint32_t>(), b->d_tails.as<DevTail>(), b->d_bstar.as<uint32_t>(),
             b->d_cands.as<uint64_t>(), b->cand_cap, b->d_cand_count.as<uint32_t>(),
@@ -189,6 +191,10 @@ bool ensure_scratch(irs_hip_batch* b) {
   const irs_hip_segment* s = b->seg;
   b->n_tiles = (s->dev.num_docs + b->tile - 1) / b->tile;
   b->stride_eff = std::max<uint32_t>(1, std::min<uint32_t>(b->stride, b->n_tiles / 4));
+  if (const char* e = std::getenv("IRS_HIP_WG_THREADS")) {  // tuning knob
+    const uint32_t t = uint32_t(std::atoi(e));
+    if (t == 256 || t == 512 || t == 1024) b->wg_threads = t;
+  }
   if (b->cand_cap == 0) {
     uint64_t cap = 4ull * b->stride * b->k_max;
     cap = std::min<uint64_t>(std::max<uint64_t>(cap, 16384), 262144);

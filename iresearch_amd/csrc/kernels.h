@@ -20,7 +20,8 @@
 namespace irs_hip {
 
 constexpr uint32_t kNoTerm = 0xFFFFFFFFu;
-constexpr uint32_t kThreads = 256;      // 4 wavefronts per workgroup
+constexpr uint32_t kThreads = 256;      // 4 wavefronts per workgroup (utility kernels)
+constexpr uint32_t kTileThreadsMax = 1024;  // pilot/score workgroups: 256..1024 threads
 constexpr uint32_t kWaves = kThreads / 64;
 constexpr uint32_t kLocalCands = 256;   // per-tile candidate staging slots in LDS
 constexpr uint32_t kSelectLds = 4096;   // keys sorted in LDS by k_select
@@ -307,7 +308,7 @@ struct TileSmem {
 
 template<int TILE, bool AND>
 constexpr uint32_t tile_smem_bytes() {
-  return 8u * TILE + (AND ? TILE : 0) + TILE + sizeof(float) * 256 * kMaxCaches +
+  return 8u * (TILE + 64) + (AND ? TILE : 0) + TILE + sizeof(float) * 256 * kMaxCaches +
          sizeof(DevQTerm) * kMaxTerms + sizeof(TermL) * kMaxTerms + sizeof(ItemL) * kItemChunk +
          32;
 }
@@ -316,7 +317,7 @@ template<int TILE, bool AND>
 __device__ __forceinline__ TileSmem carve(unsigned char* smem, unsigned char** rest) {
   TileSmem sm;
   sm.acc = reinterpret_cast<unsigned long long*>(smem);
-  smem += 8u * TILE;
+  smem += 8u * (TILE + 64);  // + one private dummy slot per lane (see post_bm25)
   sm.cnt = reinterpret_cast<uint32_t*>(smem);
   if (AND) smem += TILE;
   sm.lnorm = smem;
@@ -505,74 +506,20 @@ __device__ __forceinline__ void tile_accumulate(const DevSegment& seg, const Dev
       if (AND) atomicAdd(&sm.cnt[idx >> 2], 1u << (8u * (idx & 3u)));
     }
   };
-  // hot path: BM25 with 1-byte norms through the LDS norm_cache
-  // (bm25.cpp:348-353): c0 - c0/(1 + tf*cache[norm]); the division is one
-  // v_rcp_f32 (<= 1 ulp, far inside the 1e-5 parity tolerance)
-  auto apply_bm25 = [&](float c0, const float* cache, uint32_t doc, uint32_t freq) {
-    const uint32_t idx = doc - lo;
-    if (idx < span) {
-      const float x = static_cast<float>(freq) * cache[sm.lnorm[idx]];
-      const float s = c0 - c0 * wave::fast_rcp(1.f + x);
-      atomicAdd(&sm.acc[idx], to_fixed(s, fx_mul));
-      if (AND) atomicAdd(&sm.cnt[idx >> 2], 1u << (8u * (idx & 3u)));
-    }
-  };
-  // raw payload words of item `it` (two per block part), loaded ahead of use;
-  // everything read from the item table is wave-uniform -> scalar registers
-  auto load_item = [&](uint32_t it, uint64_t& da, uint64_t& db, uint64_t& fa, uint64_t& fb) {
-    const uint32_t bt = wave::uniform(sm.items[it].bits_term);
-    const uint32_t rel = wave::uniform(sm.items[it].rel_off);
-    const uint32_t dbits = bt & 0xFFu, fbits = (bt >> 8) & 0xFFu;
-    const uint64_t ds = sm.tl[bt >> 16].doc_start;
-    const uint64_t start = (uint64_t(wave::uniform(uint32_t(ds >> 32))) << 32) |
-                           wave::uniform(uint32_t(ds));
-    const uint8_t* blk = seg.doc + start + rel;
-    const RawPair d = raw_load<LAYOUT>(blk + 1, dbits, lane);
-    da = d.a;
-    db = d.b;
-    // the freq block starts right after the doc block; an ALL_EQUAL doc block
-    // (vint payload) has a data-dependent size and is fetched at use instead
-    if (dbits) {
-      const RawPair f = raw_load<LAYOUT>(blk + 2u + 16u * dbits, fbits, lane);
-      fa = f.a;
-      fb = f.b;
-    }
-  };
-  auto compute_item = [&](uint32_t it, uint64_t da, uint64_t db, uint64_t fa, uint64_t fb) {
-    const uint32_t bt = wave::uniform(sm.items[it].bits_term);
-    const uint32_t base = wave::uniform(sm.items[it].base);
-    const uint32_t dbits = bt & 0xFFu, fbits = (bt >> 8) & 0xFFu;
-    const uint32_t j = bt >> 16;
-    uint32_t x0, x1, f0, f1;
-    RawPair rd, rf;
-    rd.a = da; rd.b = db; rf.a = fa; rf.b = fb;
-    if (dbits) {
-      raw_extract<LAYOUT>(rd, dbits, lane, x0, x1);
-    } else {
-      uint32_t len;
-      x0 = x1 = vint_from(da, &len);
-      const uint8_t* blk = seg.doc + sm.tl[j].doc_start + sm.items[it].rel_off;
-      rf = raw_load<LAYOUT>(blk + 2u + len, fbits, lane);
-    }
-    if (fbits) {
-      raw_extract<LAYOUT>(rf, fbits, lane, f0, f1);
-    } else {
-      uint32_t len;
-      f0 = f1 = vint_from(rf.a, &len);
-    }
-    const uint32_t d1 = base + wave::inclusive_scan(x0 + x1);
-    const uint32_t kind = wave::uniform(uint32_t(sm.qts[j].kind));
-    const uint32_t cid = wave::uniform(sm.qts[j].cache_id);
-    if (kind == uint32_t(kBM25Tiny) && cid < kMaxCaches) {
-      const float c0 = wave::uniform_f(sm.qts[j].c0);
-      const float* cache = sm.caches + cid * 256u;
-      apply_bm25(c0, cache, d1 - x1, f0);
-      apply_bm25(c0, cache, d1, f1);
-    } else {
-      const DevQTerm qt = sm.qts[j];
-      const float inv_one = 1.f / (qt.norm_const + qt.norm_length * 1.f);
-      apply(qt, inv_one, d1 - x1, f0);
-      apply(qt, inv_one, d1, f1);
+  // Branch-free scoring of one posting on the hot path (BM25, 1-byte norms,
+  // LDS norm_cache — bm25.cpp:348-353: c0 - c0/(1 + tf*cache[norm]); the
+  // division is one v_rcp_f32, <= 1 ulp, far inside the 1e-5 parity tolerance).
+  // Postings outside the tile add 0 to a private dummy slot instead of
+  // branching, so that several postings' LDS lookups overlap.
+  auto post_bm25 = [&](float c0, const float* cache, uint32_t doc, uint32_t freq) {
+    const uint32_t idx = doc - lo;  // doc < lo wraps to a huge value
+    const bool in = idx < span;
+    const uint32_t li = in ? idx : (uint32_t(TILE) + lane);
+    const float x = static_cast<float>(freq) * cache[sm.lnorm[in ? idx : 0u]];
+    const float s = c0 - c0 * wave::fast_rcp(1.f + x);
+    atomicAdd(&sm.acc[li], in ? to_fixed(s, fx_mul) : 0ull);
+    if (AND) {
+      if (in) atomicAdd(&sm.cnt[idx >> 2], 1u << (8u * (idx & 3u)));
     }
   };
 
@@ -592,16 +539,143 @@ __device__ __forceinline__ void tile_accumulate(const DevSegment& seg, const Dev
       sm.items[threadIdx.x] = I;
     }
     __syncthreads();
-    uint32_t it = wv;
-    uint64_t cda = 0, cdb = 0, cfa = 0, cfb = 0;
-    if (it < n) load_item(it, cda, cdb, cfa, cfb);
-    while (it < n) {
-      const uint32_t ni = it + nw;
-      uint64_t nda = 0, ndb = 0, nfa = 0, nfb = 0;
-      if (ni < n) load_item(ni, nda, ndb, nfa, nfb);
-      compute_item(it, cda, cdb, cfa, cfb);
-      cda = nda; cdb = ndb; cfa = nfa; cfb = nfb;
-      it = ni;
+
+    // This wavefront's items are wv, wv+nw, ...: lane k keeps the metadata of the
+    // k-th one in registers; the loop broadcasts it with v_readlane (scalar
+    // results), so no LDS round trip sits on an item's critical path.
+    const uint32_t my_n = n > wv ? (n - wv + nw - 1) / nw : 0u;  // <= 64
+    uint32_t m_bt = 0, m_base = 0, m_rel = 0, m_dslo = 0, m_dshi = 0, m_kc = 0xFFu;
+    float m_c0 = 0.f;
+    if (lane < my_n) {
+      const uint32_t it = wv + lane * nw;
+      m_bt = sm.items[it].bits_term;
+      m_base = sm.items[it].base;
+      m_rel = sm.items[it].rel_off;
+      const uint32_t j = m_bt >> 16;
+      const uint64_t ds = sm.tl[j].doc_start;
+      m_dslo = uint32_t(ds);
+      m_dshi = uint32_t(ds >> 32);
+      const uint32_t cid = sm.qts[j].cache_id;
+      m_kc = uint32_t(sm.qts[j].kind) | ((cid < 255u ? cid : 255u) << 8);
+      m_c0 = sm.qts[j].c0;
+    }
+    auto item_blk = [&](uint32_t k) -> const uint8_t* {
+      const uint64_t start = (uint64_t(wave::read_lane(m_dshi, k)) << 32) |
+                             wave::read_lane(m_dslo, k);
+      return seg.doc + start + wave::read_lane(m_rel, k);
+    };
+    // raw payload words of the k-th item (two per block part), loaded ahead of use
+    auto load_k = [&](uint32_t k, uint64_t& da, uint64_t& db, uint64_t& fa, uint64_t& fb) {
+      const uint32_t bt = wave::read_lane(m_bt, k);
+      const uint32_t dbits = bt & 0xFFu, fbits = (bt >> 8) & 0xFFu;
+      const uint8_t* blk = item_blk(k);
+      const RawPair d = raw_load<LAYOUT>(blk + 1, dbits, lane);
+      da = d.a;
+      db = d.b;
+      // the freq block starts right after the doc block; an ALL_EQUAL doc block
+      // (vint payload) has a data-dependent size and is fetched at use instead
+      if (dbits) {
+        const RawPair f = raw_load<LAYOUT>(blk + 2u + 16u * dbits, fbits, lane);
+        fa = f.a;
+        fb = f.b;
+      }
+    };
+    auto is_fast = [&](uint32_t bt, uint32_t kc) {
+      return (bt & 0xFFu) != 0u && ((bt >> 8) & 0xFFu) != 0u &&
+             (kc & 0xFFu) == uint32_t(kBM25Tiny) && (kc >> 8) < kMaxCaches;
+    };
+    // generic item: any block framing, any scorer
+    auto slow_item = [&](uint32_t k, uint64_t da, uint64_t db, uint64_t fa, uint64_t fb) {
+      const uint32_t bt = wave::read_lane(m_bt, k);
+      const uint32_t base = wave::read_lane(m_base, k);
+      const uint32_t dbits = bt & 0xFFu, fbits = (bt >> 8) & 0xFFu;
+      const uint32_t j = bt >> 16;
+      uint32_t x0, x1, f0, f1;
+      RawPair rd, rf;
+      rd.a = da; rd.b = db; rf.a = fa; rf.b = fb;
+      if (dbits) {
+        raw_extract<LAYOUT>(rd, dbits, lane, x0, x1);
+      } else {
+        uint32_t len;
+        x0 = x1 = vint_from(da, &len);
+        rf = raw_load<LAYOUT>(item_blk(k) + 2u + len, fbits, lane);
+      }
+      if (fbits) {
+        raw_extract<LAYOUT>(rf, fbits, lane, f0, f1);
+      } else {
+        uint32_t len;
+        f0 = f1 = vint_from(rf.a, &len);
+      }
+      const uint32_t d1 = base + wave::inclusive_scan(x0 + x1);
+      const DevQTerm qt = sm.qts[j];
+      const float inv_one = 1.f / (qt.norm_const + qt.norm_length * 1.f);
+      apply(qt, inv_one, d1 - x1, f0);
+      apply(qt, inv_one, d1, f1);
+    };
+    // hot path, one item: straight-line code
+    auto fast_item = [&](uint32_t k, uint64_t da, uint64_t db, uint64_t fa, uint64_t fb) {
+      const uint32_t bt = wave::read_lane(m_bt, k);
+      const uint32_t kc = wave::read_lane(m_kc, k);
+      const float c0 = wave::read_lane_f(m_c0, k);
+      const float* cache = sm.caches + (kc >> 8) * 256u;
+      uint32_t x0, x1, f0, f1;
+      RawPair rd, rf;
+      rd.a = da; rd.b = db; rf.a = fa; rf.b = fb;
+      raw_extract<LAYOUT>(rd, bt & 0xFFu, lane, x0, x1);
+      raw_extract<LAYOUT>(rf, (bt >> 8) & 0xFFu, lane, f0, f1);
+      const uint32_t d1 = wave::read_lane(m_base, k) + wave::inclusive_scan(x0 + x1);
+      post_bm25(c0, cache, d1 - x1, f0);
+      post_bm25(c0, cache, d1, f1);
+    };
+    // hot path, two items fused: 4 postings per lane in flight, two independent
+    // DPP scan chains, all LDS lookups issued back to back
+    auto fast_pair = [&](uint32_t k, uint64_t ada, uint64_t adb, uint64_t afa, uint64_t afb,
+                         uint64_t bda, uint64_t bdb, uint64_t bfa, uint64_t bfb) {
+      const uint32_t btA = wave::read_lane(m_bt, k), btB = wave::read_lane(m_bt, k + 1);
+      const uint32_t kcA = wave::read_lane(m_kc, k), kcB = wave::read_lane(m_kc, k + 1);
+      const float c0A = wave::read_lane_f(m_c0, k), c0B = wave::read_lane_f(m_c0, k + 1);
+      const float* cacheA = sm.caches + (kcA >> 8) * 256u;
+      const float* cacheB = sm.caches + (kcB >> 8) * 256u;
+      uint32_t ax0, ax1, af0, af1, bx0, bx1, bf0, bf1;
+      RawPair r;
+      r.a = ada; r.b = adb;
+      raw_extract<LAYOUT>(r, btA & 0xFFu, lane, ax0, ax1);
+      r.a = bda; r.b = bdb;
+      raw_extract<LAYOUT>(r, btB & 0xFFu, lane, bx0, bx1);
+      r.a = afa; r.b = afb;
+      raw_extract<LAYOUT>(r, (btA >> 8) & 0xFFu, lane, af0, af1);
+      r.a = bfa; r.b = bfb;
+      raw_extract<LAYOUT>(r, (btB >> 8) & 0xFFu, lane, bf0, bf1);
+      uint32_t sa = ax0 + ax1, sb = bx0 + bx1;
+      wave::inclusive_scan2(sa, sb);
+      const uint32_t ad1 = wave::read_lane(m_base, k) + sa;
+      const uint32_t bd1 = wave::read_lane(m_base, k + 1) + sb;
+      post_bm25(c0A, cacheA, ad1 - ax1, af0);
+      post_bm25(c0A, cacheA, ad1, af1);
+      post_bm25(c0B, cacheB, bd1 - bx1, bf0);
+      post_bm25(c0B, cacheB, bd1, bf1);
+    };
+
+    uint64_t ada = 0, adb = 0, afa = 0, afb = 0, bda = 0, bdb = 0, bfa = 0, bfb = 0;
+    if (0 < my_n) load_k(0, ada, adb, afa, afb);
+    if (1 < my_n) load_k(1, bda, bdb, bfa, bfb);
+    for (uint32_t k = 0; k < my_n; k += 2) {
+      uint64_t nada = 0, nadb = 0, nafa = 0, nafb = 0, nbda = 0, nbdb = 0, nbfa = 0, nbfb = 0;
+      if (k + 2 < my_n) load_k(k + 2, nada, nadb, nafa, nafb);
+      if (k + 3 < my_n) load_k(k + 3, nbda, nbdb, nbfa, nbfb);
+      const bool hasB = k + 1 < my_n;
+      const bool okA = is_fast(wave::read_lane(m_bt, k), wave::read_lane(m_kc, k));
+      const bool okB = hasB && is_fast(wave::read_lane(m_bt, k + 1), wave::read_lane(m_kc, k + 1));
+      if (okA && okB) {
+        fast_pair(k, ada, adb, afa, afb, bda, bdb, bfa, bfb);
+      } else {
+        if (okA) fast_item(k, ada, adb, afa, afb); else slow_item(k, ada, adb, afa, afb);
+        if (hasB) {
+          if (okB) fast_item(k + 1, bda, bdb, bfa, bfb); else slow_item(k + 1, bda, bdb, bfa, bfb);
+        }
+      }
+      ada = nada; adb = nadb; afa = nafa; afb = nafb;
+      bda = nbda; bdb = nbdb; bfa = nbfa; bfb = nbfb;
     }
   }
   // decoded vint tails / single-doc terms (k_plan), one term per wavefront
@@ -640,7 +714,7 @@ __device__ __forceinline__ bool doc_matched(const DevQuery& qd, const TileSmem& 
 // with at least k docs at or above it.  Those docs exist, so the final k-th
 // score is >= the lower edge of b*: k_score may drop everything below b*.
 template<int LAYOUT, int TILE, bool AND>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kTileThreadsMax)
 k_pilot(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_t jt,
         uint32_t n_tiles, uint32_t stride, const uint32_t* first, const DevTail* tails,
         uint32_t* bstar) {
@@ -694,7 +768,7 @@ k_pilot(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
 // One workgroup per (query, doc tile); work ids are remapped so that each XCD
 // (private L2) walks a contiguous run of tiles of the same queries.
 template<int LAYOUT, int TILE, bool AND>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kTileThreadsMax)
 k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_t jt,
         uint32_t n_tiles, uint32_t n_work, const uint32_t* first, const DevTail* tails,
         const uint32_t* bstar, uint64_t* cands, uint32_t cand_cap, uint32_t* cand_count,

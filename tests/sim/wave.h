@@ -57,6 +57,12 @@ __device__ __forceinline__ uint32_t load_u32(const uint8_t* p) {
 // wave-uniform value -> scalar register on the GPU; identity here
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return v; }
 __device__ __forceinline__ float uniform_f(float v) { return v; }
+__device__ __forceinline__ void inclusive_scan2(uint32_t& a, uint32_t& b) {
+  a = inclusive_scan(a);
+  b = inclusive_scan(b);
+}
+__device__ __forceinline__ uint32_t read_lane(uint32_t v, uint32_t k) { return __shfl(v, int(k), 64); }
+__device__ __forceinline__ float read_lane_f(float v, uint32_t k) { return __shfl(v, int(k), 64); }
 // v_rcp_f32 on the GPU (<= 1 ulp); exact division here
 __device__ __forceinline__ float fast_rcp(float v) { return 1.0f / v; }
 
