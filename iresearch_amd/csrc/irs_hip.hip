@@ -19,6 +19,7 @@ namespace {
 
 constexpr uint32_t kDefaultTile = 4096;
 constexpr uint32_t kDefaultStride = 16;
+constexpr uint32_t kDefaultWgThreads = 512;  // 8 wavefronts share one tile (measured best)
 
 struct DevBuf {  // owning device allocation
   void* p = nullptr;
@@ -84,7 +85,7 @@ struct irs_hip_batch {
   uint32_t tile = kDefaultTile, stride = kDefaultStride, cand_cap = 0;
   uint32_t n_tiles = 0;
   uint32_t stride_eff = 1;  // pilot stride actually used (>= 4 pilot tiles when possible)
-  uint32_t wg_threads = kThreads;  // threads per pilot/score workgroup
+  uint32_t wg_threads = kDefaultWgThreads;  // threads per pilot/score workgroup
   bool any_and = false;
   bool scratch_ready = false;
   std::vector<DevQuery> queries;

@@ -219,17 +219,23 @@ k_decode_term(DevSegment seg, uint32_t term, uint32_t* out_docs,
 __global__ void __launch_bounds__(kThreads)
 k_plan(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms,
        uint32_t jt /*term slots per query*/, uint32_t tile_docs, uint32_t n_tiles,
-       uint32_t* first /*[q][jt][n_tiles+1]*/, DevTail* tails /*[q][jt]*/) {
+       uint32_t* first /*[q][n_tiles+1][jt]*/, DevTail* tails /*[q][jt]*/) {
   __shared__ uint8_t tail_bytes[kTailBytesMax + 16];
   const uint32_t q = blockIdx.x / jt, j = blockIdx.x % jt;
   const DevQuery qd = queries[q];
   DevTail* tl = tails + (uint64_t(q) * jt + j);
+  // table layout [q][tile][term slot]: one tile's entries for all terms are adjacent
+  uint32_t* col = first + uint64_t(q) * (n_tiles + 1) * jt + j;
   if (j >= qd.n_terms || qterms[qd.first_term + j].term == kNoTerm) {
-    if (threadIdx.x == 0) { tl->n = 0; tl->first_doc = 0; tl->last_doc = 0; }
+    for (uint32_t tile = threadIdx.x; tile <= n_tiles; tile += blockDim.x)
+      col[uint64_t(tile) * jt] = 0;
+    if (threadIdx.x == 0) {
+      tl->n = 0; tl->first_doc = 0; tl->last_doc = 0;
+      tl->nblk = 0; tl->doc_start = 0; tl->dir_off = 0;
+    }
     return;
   }
   const DevTerm t = seg.terms[qterms[qd.first_term + j].term];
-  uint32_t* row = first + (uint64_t(q) * jt + j) * (n_tiles + 1);
   const uint32_t* last = seg.blk_last + t.dir_off;
   for (uint32_t tile = threadIdx.x; tile <= n_tiles; tile += blockDim.x) {
     const uint64_t lo64 = uint64_t(kDocMin) + uint64_t(tile) * tile_docs;
@@ -239,7 +245,7 @@ k_plan(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms,
       const uint32_t m = (a + b) >> 1;
       if (last[m] < lo) a = m + 1; else b = m;
     }
-    row[tile] = a;
+    col[uint64_t(tile) * jt] = a;
   }
   // tail bytes -> LDS (coalesced), then a serial LEB128 walk by one lane
   uint32_t nbytes = 0;
@@ -250,6 +256,9 @@ k_plan(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms,
   }
   __syncthreads();
   if (threadIdx.x == 0) {
+    tl->nblk = t.nblk;
+    tl->doc_start = t.doc_start;
+    tl->dir_off = t.dir_off;
     if (t.docs_count == 1) {
       tl->n = 1;
       tl->docs[0] = t.single_doc;
@@ -406,7 +415,7 @@ __device__ __forceinline__ float score_posting(const DevSegment& seg, const DevQ
 template<int TILE, bool AND>
 __device__ __forceinline__ void tile_begin(const DevSegment& seg, const DevQuery& qd,
                                            const DevQTerm* qts_g, const uint32_t* first_q,
-                                           uint32_t n_tiles, const DevTail* tails_q,
+                                           uint32_t jt, const DevTail* tails_q,
                                            uint32_t tile, const TileSmem& sm,
                                            bool build_caches) {
   const uint32_t lo = kDocMin + tile * TILE;
@@ -414,25 +423,18 @@ __device__ __forceinline__ void tile_begin(const DevSegment& seg, const DevQuery
                           ? (seg.num_docs + kDocMin - lo) : uint32_t(TILE);
   if (threadIdx.x < qd.n_terms) {
     const uint32_t j = threadIdx.x;
+    // every load below is independent of the others: one memory round trip
     if (build_caches) sm.qts[j] = qts_g[j];
-    const uint32_t term = qts_g[j].term;
-    uint64_t doc_start = 0, dir_off = 0;
-    uint32_t tb0 = 0, tnb = 0, ttail = 0;
-    if (term != kNoTerm) {
-      const DevTerm* t = seg.terms + term;
-      const uint32_t* row = first_q + uint64_t(j) * (n_tiles + 1);
-      const uint32_t b0 = row[tile];
-      uint32_t b1 = row[tile + 1] + 1u;
-      const uint32_t nblk = t->nblk;
-      b1 = b1 < nblk ? b1 : nblk;
-      doc_start = t->doc_start;
-      dir_off = t->dir_off;
-      tb0 = b0;
-      tnb = b1 > b0 ? b1 - b0 : 0u;
-      const DevTail* tl = tails_q + j;
-      const uint32_t tn = tl->n;
-      if (tn && tl->first_doc < lo + span && tl->last_doc >= lo) ttail = tn;
-    }
+    const DevTail* tl = tails_q + j;
+    const uint32_t nblk = tl->nblk, tn = tl->n;
+    const uint32_t tfirst = tl->first_doc, tlast = tl->last_doc;
+    const uint64_t doc_start = tl->doc_start, dir_off = tl->dir_off;
+    const uint32_t b0 = first_q[uint64_t(tile) * jt + j];
+    uint32_t b1 = first_q[uint64_t(tile + 1) * jt + j] + 1u;
+    b1 = b1 < nblk ? b1 : nblk;
+    const uint32_t tb0 = b0;
+    const uint32_t tnb = b1 > b0 ? b1 - b0 : 0u;
+    const uint32_t ttail = (tn && tfirst < lo + span && tlast >= lo) ? tn : 0u;
     sm.tl[j].doc_start = doc_start;
     sm.tl[j].dir_off = dir_off;
     sm.tl[j].b0 = tb0;
@@ -725,12 +727,12 @@ k_pilot(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
   const uint32_t q = blockIdx.x;
   const DevQuery qd = queries[q];
   const DevQTerm* qts = qterms + qd.first_term;
-  const uint32_t* first_q = first + uint64_t(q) * jt * (n_tiles + 1);
+  const uint32_t* first_q = first + uint64_t(q) * (n_tiles + 1) * jt;
   const DevTail* tails_q = tails + uint64_t(q) * jt;
   for (uint32_t i = threadIdx.x; i < kBins; i += blockDim.x) hist[i] = 0u;
   bool first_tile = true;
   for (uint32_t tile = (q * 7u) % stride; tile < n_tiles; tile += stride) {
-    tile_begin<TILE, AND>(seg, qd, qts, first_q, n_tiles, tails_q, tile, sm, first_tile);
+    tile_begin<TILE, AND>(seg, qd, qts, first_q, jt, tails_q, tile, sm, first_tile);
     first_tile = false;
     tile_accumulate<LAYOUT, TILE, AND>(seg, qd, tails_q, tile, sm);
     for (uint32_t i = threadIdx.x; i < TILE; i += blockDim.x) {
@@ -787,12 +789,11 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
   const DevQuery qd = queries[q];
   const DevTail* tails_q = tails + uint64_t(q) * jt;
   if (threadIdx.x < 4) lvars[threadIdx.x] = 0u;
+  const uint32_t bs = bstar[q];  // loaded up front: off the epilogue's critical path
   tile_begin<TILE, AND>(seg, qd, qterms + qd.first_term,
-                        first + uint64_t(q) * jt * (n_tiles + 1), n_tiles, tails_q, tile, sm,
-                        true);
+                        first + uint64_t(q) * (n_tiles + 1) * jt, jt, tails_q, tile, sm, true);
   tile_accumulate<LAYOUT, TILE, AND>(seg, qd, tails_q, tile, sm);
   const uint32_t lo = kDocMin + tile * TILE;
-  const uint32_t bs = bstar[q];
   // cheap pre-filter in the fixed-point domain: a conservative lower bound of the
   // accumulator value at the lower edge of bin `bs`; the exact bin test follows
   unsigned long long thr = 1ull;

@@ -91,7 +91,9 @@ struct DevTail {
   uint32_t n;
   uint32_t first_doc;
   uint32_t last_doc;
-  uint32_t pad;
+  uint32_t nblk;        // copy of DevTerm::nblk      } so that a tile workgroup finds
+  uint64_t doc_start;   // copy of DevTerm::doc_start } everything about the term with
+  uint64_t dir_off;     // copy of DevTerm::dir_off   } ONE load, not a dependent chain
   uint32_t docs[kBlock];
   uint32_t freqs[kBlock];
 };
