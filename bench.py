@@ -174,9 +174,9 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        if world == 1:
-            # per-kernel HIP-event timings of this step (waits for the stream)
-            score_ms.append(batches[my[0]].timings())
+        # per-kernel HIP-event timings of this step on rank 0 (waits for the stream)
+        if rank == 0:
+            score_ms.append(np.sum([batches[s].timings() for s in my], axis=0))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -188,6 +188,7 @@ def main():
 
     alg_bytes = sum(batches[s].work()[0] for s in my)
     postings = sum(batches[s].work()[1] for s in my)
+    rank0_alg_bytes = alg_bytes
     if world > 1:
         t = torch.tensor([alg_bytes, postings], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -197,14 +198,16 @@ def main():
     if rank == 0:
         qps = args.steps * nq / elapsed
         roof = None
-        if world == 1 and score_ms:
+        if score_ms:
+            # k_score on rank 0: its algorithmic bytes / its summed launch time per step
             ms = np.array(score_ms)                    # [steps][K_COUNT]
             avg = ms.mean(axis=0)
-            achieved = alg_bytes / (avg[_lib.K_SCORE] * 1e-3) / 1e9
+            achieved = rank0_alg_bytes / (avg[_lib.K_SCORE] * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": "k_score", "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": None,
-                    "algorithmic_bytes_per_launch": int(alg_bytes),
+                    "traffic": measured_traffic(len(my)),
+                    "algorithmic_bytes_per_launch": int(rank0_alg_bytes / len(my)),
+                    "launches_per_step": len(my),
                     "avg_launch_ms": round(float(avg[_lib.K_SCORE]), 4),
                     "kernel_ms": {n: round(float(v), 4) for n, v in zip(_lib.KERNEL_NAMES, avg)}}
         out = {
@@ -233,6 +236,18 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_traffic(n_launches):
+    """HBM bytes per k_score launch from rocprofv3 PMC passes of this same command
+    (FETCH_SIZE and WRITE_SIZE in their own --pmc runs), committed under profiles/."""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        return t if n_launches == 1 else None
+    except OSError:
+        return None
 
 
 def C_void(v):

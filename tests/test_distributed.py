@@ -1,0 +1,100 @@
+"""N > 1 path on CPU: two processes (gloo), one segment each, global statistics,
+all-gather of per-segment top-k, device-side merge (run here by the emulator
+build) — compared with the oracle's single heap over both segments
+(utils/index-search.cpp:719-779)."""
+import ctypes as C
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parents[1]
+K = 50
+N_SEGS = 4
+DOCS = 12_000
+MAX_RANK = 128
+
+
+def _filters():
+    from iresearch_amd import synth
+    from iresearch_amd.search import And, Or, by_term
+    ranks = synth.make_queries(5, 8, 2, MAX_RANK)
+    fl = [Or([by_term(int(r) - 1) for r in row]) for row in ranks]
+    fl += [by_term(7), Or([by_term(3), by_term(99)]), And([by_term(1), by_term(20)])]
+    return fl
+
+
+def _worker(rank, world, port, sim_path, out_dir):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from iresearch_amd import _lib, distributed, search, synth
+    from iresearch_amd.search import BM25
+    L = _lib.bind(C.CDLL(sim_path))
+    my = distributed.segments_of_rank(N_SEGS, rank, world)
+    segs = {s: synth.build_segment(DOCS, MAX_RANK, first_doc=s * DOCS) for s in my}
+    local = {s: (segs[s].docs_with_field, segs[s].total_term_freq,
+                 np.asarray(segs[s].metas["docs_count"])) for s in my}
+    gathered = [None] * world
+    dist.all_gather_object(gathered, local)
+    stats = {}
+    for g in gathered:
+        stats.update(g)
+    seg_stats = [search.SegmentStats(*stats[s]) for s in range(N_SEGS)]
+    filters = _filters()
+    prep = search.prepare(filters, BM25(), seg_stats)
+    nq = len(filters)
+    lists = []
+    keep = []
+    for s in my:
+        r = search.SegmentReader.from_synth(segs[s], L=L)
+        b = r.batch(prep, K).run()
+        h = torch.zeros((nq, K), dtype=torch.int64)
+        c = torch.zeros((nq,), dtype=torch.int32)
+        b.results_to_device(h.data_ptr(), c.data_ptr())
+        lists.append((s, h, c))
+        keep.append((r, b))
+    oh, osg, oc = distributed.gather_merge(L, 0, lists, N_SEGS, rank, world, nq, K, "cpu")
+    np.save(os.path.join(out_dir, "hits_%d.npy" % rank), oh.numpy())
+    np.save(os.path.join(out_dir, "segs_%d.npy" % rank), osg.numpy())
+    np.save(os.path.join(out_dir, "counts_%d.npy" % rank), oc.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_gloo_matches_oracle(simlib, tmp_path):
+    sim_path = simlib._name
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, sim_path, str(tmp_path)), nprocs=2, join=True)
+    import oracle
+    import parity
+    from iresearch_amd import _lib, synth
+    from iresearch_amd.search import BM25
+    r0 = [np.load(tmp_path / ("%s_0.npy" % n)) for n in ("hits", "segs", "counts")]
+    r1 = [np.load(tmp_path / ("%s_1.npy" % n)) for n in ("hits", "segs", "counts")]
+    for a, b in zip(r0, r1):                      # every rank holds the same merged result
+        assert np.array_equal(a, b)
+    hits = r0[0].view(_lib.HIT).reshape(r0[0].shape)
+    segs_of = r0[1]
+    counts = r0[2]
+    segs = [synth.build_segment(DOCS, MAX_RANK, first_doc=s * DOCS) for s in range(N_SEGS)]
+    filters = _filters()
+    ref = parity.oracle_topk(segs, filters, BM25(), K)
+    views = [parity.oracle_view(s) for s in segs]
+    for q, (ohits, total) in enumerate(ref):
+        n = int(counts[q])
+        assert n == len(ohits)
+        got = hits[q, :n]
+        want = np.sort(ohits["score"])[::-1]
+        assert np.allclose(got["score"], want, rtol=parity.REL_TOL, atol=0), q
+        # ordered (score desc, segment asc, doc asc) — wand_test.cpp:72-86
+        key = list(zip(-got["score"].astype(np.float64), segs_of[q, :n], got["doc"]))
+        assert key == sorted(key), q
+        assert (segs_of[q, :n] < N_SEGS).all()
