@@ -28,6 +28,10 @@ inline bool device_arch(int dev, char* buf, size_t cap) {
   if (cap) buf[cap - 1] = 0;
   return true;
 }
+inline int device_cus(int dev) {
+  hipDeviceProp_t p;
+  return ok(hipGetDeviceProperties(&p, dev)) ? p.multiProcessorCount : 0;
+}
 inline void* dmalloc(size_t n) {
   void* p = nullptr;
   return ok(hipMalloc(&p, n ? n : 1)) ? p : nullptr;

@@ -77,6 +77,7 @@ struct irs_hip_segment {
   std::vector<DevTerm> terms;  // host mirror incl. the fields the dir kernel filled
   uint64_t total_blocks = 0;
   uint64_t device_bytes = 0;
+  uint32_t cus = 1;  // compute units of the device (persistent grid sizing)
 };
 
 struct irs_hip_batch {
@@ -91,7 +92,7 @@ struct irs_hip_batch {
   std::vector<DevQuery> queries;
   std::vector<DevQTerm> qterms;
   DevBuf d_queries, d_qterms, d_first, d_tails, d_bstar, d_cands, d_cand_count, d_hits,
-    d_out, d_out_count, d_status;
+    d_out, d_out_count, d_status, d_work;
   uint64_t alg_bytes = 0, postings = 0;
   bool profile = false;
   bool events_ready = false;
@@ -145,18 +146,22 @@ bool launch_pilot(irs_hip_batch* b, rt::stream_t st) {
 
 template<int LAYOUT, int TILE, bool AND>
 bool launch_score(irs_hip_batch* b, rt::stream_t st) {
-  const size_t smem = tile_smem_bytes<TILE, AND>() + kLocalCands * sizeof(uint64_t) + 16;
+  const size_t smem = score_smem_bytes<TILE, AND>();
   auto kern = k_score<LAYOUT, TILE, AND>;
   if (!big_smem(kern, smem)) return false;
-  const uint64_t n_work64 = uint64_t(b->nq) * b->n_tiles;
-  if (n_work64 > 0x7FFFFFF0ull) return false;
-  const uint32_t n_work = uint32_t(n_work64);
-  const uint32_t grid = ((n_work + 7u) / 8u) * 8u;
+  // persistent grid: as many workgroups as stay resident on the chip at once
+  const uint32_t waves = b->wg_threads / 64;
+  uint32_t per_cu = uint32_t((160u * 1024u) / smem);
+  per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 32u / waves));
+  const uint64_t chunks = uint64_t(b->nq) * ((b->n_tiles + kChunkTiles - 1) / kChunkTiles);
+  if (chunks > 0xFFFF0000ull) return false;
+  const uint32_t grid = uint32_t(std::min<uint64_t>(chunks, uint64_t(b->seg->cus) * per_cu));
+  if (!rt::dmemset(b->d_work.p, 0, 4, st)) return false;
   RT_LAUNCH(kern, grid, b->wg_threads, smem, st, b->seg->dev, b->d_queries.as<DevQuery>(),
-            b->d_qterms.as<DevQTerm>(), b->jt, b->n_tiles, n_work,
+            b->d_qterms.as<DevQTerm>(), b->jt, b->n_tiles, b->nq,
             b->d_first.as<uint32_t>(), b->d_tails.as<DevTail>(), b->d_bstar.as<uint32_t>(),
             b->d_cands.as<uint64_t>(), b->cand_cap, b->d_cand_count.as<uint32_t>(),
-            b->d_hits.as<unsigned long long>());
+            b->d_hits.as<unsigned long long>(), b->d_work.as<uint32_t>());
   return rt::last_error_ok();
 }
 
@@ -209,7 +214,8 @@ bool ensure_scratch(irs_hip_batch* b) {
       !b->d_cand_count.alloc(b->nq * sizeof(uint32_t)) ||
       !b->d_hits.alloc(b->nq * sizeof(uint64_t)) ||
       !b->d_out.alloc(uint64_t(b->nq) * b->k_max * sizeof(Hit)) ||
-      !b->d_out_count.alloc(b->nq * sizeof(uint32_t)) || !b->d_status.alloc(4))
+      !b->d_out_count.alloc(b->nq * sizeof(uint32_t)) || !b->d_status.alloc(4) ||
+      !b->d_work.alloc(4))
     return false;
   b->scratch_ready = true;
   return true;
@@ -265,6 +271,7 @@ int irs_hip_segment_open(const irs_hip_segment_desc* d, irs_hip_segment** out) {
   irs_hip_segment* s = new (std::nothrow) irs_hip_segment;
   if (!s) return IRS_HIP_ENOMEM;
   s->device = d->device;
+  s->cus = std::max(1, rt::device_cus(d->device));
   int rc = IRS_HIP_OK;
   do {
     try {

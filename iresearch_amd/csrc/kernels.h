@@ -482,49 +482,219 @@ __device__ __forceinline__ void tile_begin(const DevSegment& seg, const DevQuery
   __syncthreads();
 }
 
+// generic scorer (every kind), used off the hot path
+template<int TILE, bool AND>
+__device__ __forceinline__ void tile_apply(const DevSegment& seg, const TileSmem& sm,
+                                           const DevQTerm& qt, float inv_one, uint32_t doc,
+                                           uint32_t freq, uint32_t lo, uint32_t span,
+                                           float fx_mul) {
+  const uint32_t idx = doc - lo;  // doc < lo wraps to a huge value
+  if (idx < span) {
+    const float s = score_posting(seg, qt, inv_one, sm, freq, doc, idx);
+    atomicAdd(&sm.acc[idx], to_fixed(s, fx_mul));
+    if (AND) atomicAdd(&sm.cnt[idx >> 2], 1u << (8u * (idx & 3u)));
+  }
+}
+
+// Branch-free scoring of one posting on the hot path (BM25, 1-byte norms,
+// LDS norm_cache — bm25.cpp:348-353: c0 - c0/(1 + tf*cache[norm]); the
+// division is one v_rcp_f32, <= 1 ulp, far inside the 1e-5 parity tolerance).
+// Postings outside the tile add 0 to a private dummy slot instead of
+// branching, so that several postings' LDS lookups overlap.
+template<int TILE, bool AND>
+__device__ __forceinline__ void tile_post_bm25(const TileSmem& sm, float c0, const float* cache,
+                                               uint32_t doc, uint32_t freq, uint32_t lo,
+                                               uint32_t span, float fx_mul, unsigned lane) {
+  const uint32_t idx = doc - lo;  // doc < lo wraps to a huge value
+  const bool in = idx < span;
+  const uint32_t li = in ? idx : (uint32_t(TILE) + lane);
+  const float x = static_cast<float>(freq) * cache[sm.lnorm[in ? idx : 0u]];
+  const float s = c0 - c0 * wave::fast_rcp(1.f + x);
+  atomicAdd(&sm.acc[li], in ? to_fixed(s, fx_mul) : 0ull);
+  if (AND) {
+    if (in) atomicAdd(&sm.cnt[idx >> 2], 1u << (8u * (idx & 3u)));
+  }
+}
+
+// Decode + score + accumulate the `n` (term, block) work items of `items`
+// (n <= kItemChunk): wavefront w takes items w, w+nw, ...
+template<int LAYOUT, int TILE, bool AND>
+__device__ __forceinline__ void process_items(const DevSegment& seg, const TileSmem& sm,
+                                              const ItemL* items, uint32_t n, uint32_t lo,
+                                              uint32_t span, float fx_mul) {
+  const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const uint32_t nw = blockDim.x >> 6;
+  // This wavefront's items are wv, wv+nw, ...: lane k keeps the metadata of the
+  // k-th one in registers; the loop broadcasts it with v_readlane (scalar
+  // results), so no LDS round trip sits on an item's critical path.
+  const uint32_t my_n = n > wv ? (n - wv + nw - 1) / nw : 0u;  // <= 64
+  uint32_t m_bt = 0, m_base = 0, m_rel = 0, m_dslo = 0, m_dshi = 0, m_kc = 0xFFu;
+  float m_c0 = 0.f;
+  if (lane < my_n) {
+    const uint32_t it = wv + lane * nw;
+    m_bt = items[it].bits_term;
+    m_base = items[it].base;
+    m_rel = items[it].rel_off;
+    const uint32_t j = m_bt >> 16;
+    const uint64_t ds = sm.tl[j].doc_start;
+    m_dslo = uint32_t(ds);
+    m_dshi = uint32_t(ds >> 32);
+    const uint32_t cid = sm.qts[j].cache_id;
+    m_kc = uint32_t(sm.qts[j].kind) | ((cid < 255u ? cid : 255u) << 8);
+    m_c0 = sm.qts[j].c0;
+  }
+  auto item_blk = [&](uint32_t k) -> const uint8_t* {
+    const uint64_t start = (uint64_t(wave::read_lane(m_dshi, k)) << 32) |
+                           wave::read_lane(m_dslo, k);
+    return seg.doc + start + wave::read_lane(m_rel, k);
+  };
+  // raw payload words of the k-th item (two per block part), loaded ahead of use
+  auto load_k = [&](uint32_t k, uint64_t& da, uint64_t& db, uint64_t& fa, uint64_t& fb) {
+    const uint32_t bt = wave::read_lane(m_bt, k);
+    const uint32_t dbits = bt & 0xFFu, fbits = (bt >> 8) & 0xFFu;
+    const uint8_t* blk = item_blk(k);
+    const RawPair d = raw_load<LAYOUT>(blk + 1, dbits, lane);
+    da = d.a;
+    db = d.b;
+    // the freq block starts right after the doc block; an ALL_EQUAL doc block
+    // (vint payload) has a data-dependent size and is fetched at use instead
+    if (dbits) {
+      const RawPair f = raw_load<LAYOUT>(blk + 2u + 16u * dbits, fbits, lane);
+      fa = f.a;
+      fb = f.b;
+    }
+  };
+  auto is_fast = [&](uint32_t bt, uint32_t kc) {
+    return (bt & 0xFFu) != 0u && ((bt >> 8) & 0xFFu) != 0u &&
+           (kc & 0xFFu) == uint32_t(kBM25Tiny) && (kc >> 8) < kMaxCaches;
+  };
+  // generic item: any block framing, any scorer
+  auto slow_item = [&](uint32_t k, uint64_t da, uint64_t db, uint64_t fa, uint64_t fb) {
+    const uint32_t bt = wave::read_lane(m_bt, k);
+    const uint32_t base = wave::read_lane(m_base, k);
+    const uint32_t dbits = bt & 0xFFu, fbits = (bt >> 8) & 0xFFu;
+    const uint32_t j = bt >> 16;
+    uint32_t x0, x1, f0, f1;
+    RawPair rd, rf;
+    rd.a = da; rd.b = db; rf.a = fa; rf.b = fb;
+    if (dbits) {
+      raw_extract<LAYOUT>(rd, dbits, lane, x0, x1);
+    } else {
+      uint32_t len;
+      x0 = x1 = vint_from(da, &len);
+      rf = raw_load<LAYOUT>(item_blk(k) + 2u + len, fbits, lane);
+    }
+    if (fbits) {
+      raw_extract<LAYOUT>(rf, fbits, lane, f0, f1);
+    } else {
+      uint32_t len;
+      f0 = f1 = vint_from(rf.a, &len);
+    }
+    const uint32_t d1 = base + wave::inclusive_scan(x0 + x1);
+    const DevQTerm qt = sm.qts[j];
+    const float inv_one = 1.f / (qt.norm_const + qt.norm_length * 1.f);
+    tile_apply<TILE, AND>(seg, sm, qt, inv_one, d1 - x1, f0, lo, span, fx_mul);
+    tile_apply<TILE, AND>(seg, sm, qt, inv_one, d1, f1, lo, span, fx_mul);
+  };
+  // hot path, one item: straight-line code
+  auto fast_item = [&](uint32_t k, uint64_t da, uint64_t db, uint64_t fa, uint64_t fb) {
+    const uint32_t bt = wave::read_lane(m_bt, k);
+    const uint32_t kc = wave::read_lane(m_kc, k);
+    const float c0 = wave::read_lane_f(m_c0, k);
+    const float* cache = sm.caches + (kc >> 8) * 256u;
+    uint32_t x0, x1, f0, f1;
+    RawPair rd, rf;
+    rd.a = da; rd.b = db; rf.a = fa; rf.b = fb;
+    raw_extract<LAYOUT>(rd, bt & 0xFFu, lane, x0, x1);
+    raw_extract<LAYOUT>(rf, (bt >> 8) & 0xFFu, lane, f0, f1);
+    const uint32_t d1 = wave::read_lane(m_base, k) + wave::inclusive_scan(x0 + x1);
+    tile_post_bm25<TILE, AND>(sm, c0, cache, d1 - x1, f0, lo, span, fx_mul, lane);
+    tile_post_bm25<TILE, AND>(sm, c0, cache, d1, f1, lo, span, fx_mul, lane);
+  };
+  // hot path, two items fused: 4 postings per lane in flight, two independent
+  // DPP scan chains, all LDS lookups issued back to back
+  auto fast_pair = [&](uint32_t k, uint64_t ada, uint64_t adb, uint64_t afa, uint64_t afb,
+                       uint64_t bda, uint64_t bdb, uint64_t bfa, uint64_t bfb) {
+    const uint32_t btA = wave::read_lane(m_bt, k), btB = wave::read_lane(m_bt, k + 1);
+    const uint32_t kcA = wave::read_lane(m_kc, k), kcB = wave::read_lane(m_kc, k + 1);
+    const float c0A = wave::read_lane_f(m_c0, k), c0B = wave::read_lane_f(m_c0, k + 1);
+    const float* cacheA = sm.caches + (kcA >> 8) * 256u;
+    const float* cacheB = sm.caches + (kcB >> 8) * 256u;
+    uint32_t ax0, ax1, af0, af1, bx0, bx1, bf0, bf1;
+    RawPair r;
+    r.a = ada; r.b = adb;
+    raw_extract<LAYOUT>(r, btA & 0xFFu, lane, ax0, ax1);
+    r.a = bda; r.b = bdb;
+    raw_extract<LAYOUT>(r, btB & 0xFFu, lane, bx0, bx1);
+    r.a = afa; r.b = afb;
+    raw_extract<LAYOUT>(r, (btA >> 8) & 0xFFu, lane, af0, af1);
+    r.a = bfa; r.b = bfb;
+    raw_extract<LAYOUT>(r, (btB >> 8) & 0xFFu, lane, bf0, bf1);
+    uint32_t sa = ax0 + ax1, sb = bx0 + bx1;
+    wave::inclusive_scan2(sa, sb);
+    const uint32_t ad1 = wave::read_lane(m_base, k) + sa;
+    const uint32_t bd1 = wave::read_lane(m_base, k + 1) + sb;
+    tile_post_bm25<TILE, AND>(sm, c0A, cacheA, ad1 - ax1, af0, lo, span, fx_mul, lane);
+    tile_post_bm25<TILE, AND>(sm, c0A, cacheA, ad1, af1, lo, span, fx_mul, lane);
+    tile_post_bm25<TILE, AND>(sm, c0B, cacheB, bd1 - bx1, bf0, lo, span, fx_mul, lane);
+    tile_post_bm25<TILE, AND>(sm, c0B, cacheB, bd1, bf1, lo, span, fx_mul, lane);
+  };
+
+  uint64_t ada = 0, adb = 0, afa = 0, afb = 0, bda = 0, bdb = 0, bfa = 0, bfb = 0;
+  if (0 < my_n) load_k(0, ada, adb, afa, afb);
+  if (1 < my_n) load_k(1, bda, bdb, bfa, bfb);
+  for (uint32_t k = 0; k < my_n; k += 2) {
+    uint64_t nada = 0, nadb = 0, nafa = 0, nafb = 0, nbda = 0, nbdb = 0, nbfa = 0, nbfb = 0;
+    if (k + 2 < my_n) load_k(k + 2, nada, nadb, nafa, nafb);
+    if (k + 3 < my_n) load_k(k + 3, nbda, nbdb, nbfa, nbfb);
+    const bool hasB = k + 1 < my_n;
+    const bool okA = is_fast(wave::read_lane(m_bt, k), wave::read_lane(m_kc, k));
+    const bool okB = hasB && is_fast(wave::read_lane(m_bt, k + 1), wave::read_lane(m_kc, k + 1));
+    if (okA && okB) {
+      fast_pair(k, ada, adb, afa, afb, bda, bdb, bfa, bfb);
+    } else {
+      if (okA) fast_item(k, ada, adb, afa, afb); else slow_item(k, ada, adb, afa, afb);
+      if (hasB) {
+        if (okB) fast_item(k + 1, bda, bdb, bfa, bfb); else slow_item(k + 1, bda, bdb, bfa, bfb);
+      }
+    }
+    ada = nada; adb = nadb; afa = nafa; afb = nafb;
+    bda = nbda; bdb = nbdb; bfa = nbfa; bfb = nbfb;
+  }
+}
+
+// decoded vint tails / single-doc terms (k_plan), one term per wavefront
+template<int TILE, bool AND>
+__device__ __forceinline__ void apply_tails(const DevSegment& seg, const DevQuery& qd,
+                                            const DevTail* tails_q, const TileSmem& sm,
+                                            uint32_t lo, uint32_t span, float fx_mul) {
+  const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const uint32_t nw = blockDim.x >> 6;
+  for (uint32_t j = wv; j < qd.n_terms; j += nw) {
+    const uint32_t tn = sm.tl[j].tail_n;
+    const DevTail* tl = tails_q + j;
+    if (tn && tl->first_doc < lo + span && tl->last_doc >= lo) {
+      const DevQTerm qt = sm.qts[j];
+      const float inv_one = 1.f / (qt.norm_const + qt.norm_length * 1.f);
+      for (uint32_t i = lane; i < tn; i += 64)
+        tile_apply<TILE, AND>(seg, sm, qt, inv_one, tl->docs[i], tl->freqs[i], lo, span, fx_mul);
+    }
+  }
+}
+
 // All postings of the query's terms that fall into doc tile `tile`: the GPU
 // form of block_disjunction::refill (disjunction.hpp:1240-1351), with the
 // 512-doc window widened to TILE docs in LDS, and of Conjunction via per-doc
-// match counters.  Work items are (term, block) pairs; a wavefront decodes one
-// block at a time and always has the NEXT item's payload loads in flight.
+// match counters.  (Used by k_pilot; k_score pipelines the same pieces.)
 template<int LAYOUT, int TILE, bool AND>
 __device__ __forceinline__ void tile_accumulate(const DevSegment& seg, const DevQuery& qd,
                                                 const DevTail* tails_q, uint32_t tile,
                                                 const TileSmem& sm) {
-  const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-  const uint32_t nw = blockDim.x >> 6;
   const uint32_t lo = kDocMin + tile * TILE;
   const uint32_t span = (seg.num_docs + kDocMin - lo) < uint32_t(TILE)
                           ? (seg.num_docs + kDocMin - lo) : uint32_t(TILE);
   const float fx_mul = qd.fx_mul;
   const uint32_t n_items = sm.vars[0];
-
-  // generic scorer (every kind), used off the hot path
-  auto apply = [&](const DevQTerm& qt, float inv_one, uint32_t doc, uint32_t freq) {
-    const uint32_t idx = doc - lo;  // doc < lo wraps to a huge value
-    if (idx < span) {
-      const float s = score_posting(seg, qt, inv_one, sm, freq, doc, idx);
-      atomicAdd(&sm.acc[idx], to_fixed(s, fx_mul));
-      if (AND) atomicAdd(&sm.cnt[idx >> 2], 1u << (8u * (idx & 3u)));
-    }
-  };
-  // Branch-free scoring of one posting on the hot path (BM25, 1-byte norms,
-  // LDS norm_cache — bm25.cpp:348-353: c0 - c0/(1 + tf*cache[norm]); the
-  // division is one v_rcp_f32, <= 1 ulp, far inside the 1e-5 parity tolerance).
-  // Postings outside the tile add 0 to a private dummy slot instead of
-  // branching, so that several postings' LDS lookups overlap.
-  auto post_bm25 = [&](float c0, const float* cache, uint32_t doc, uint32_t freq) {
-    const uint32_t idx = doc - lo;  // doc < lo wraps to a huge value
-    const bool in = idx < span;
-    const uint32_t li = in ? idx : (uint32_t(TILE) + lane);
-    const float x = static_cast<float>(freq) * cache[sm.lnorm[in ? idx : 0u]];
-    const float s = c0 - c0 * wave::fast_rcp(1.f + x);
-    atomicAdd(&sm.acc[li], in ? to_fixed(s, fx_mul) : 0ull);
-    if (AND) {
-      if (in) atomicAdd(&sm.cnt[idx >> 2], 1u << (8u * (idx & 3u)));
-    }
-  };
-
   for (uint32_t c0 = 0; c0 < n_items; c0 += kItemChunk) {
     const uint32_t n = (n_items - c0) < kItemChunk ? (n_items - c0) : kItemChunk;
     if (c0) __syncthreads();  // previous chunk fully consumed
@@ -541,155 +711,9 @@ __device__ __forceinline__ void tile_accumulate(const DevSegment& seg, const Dev
       sm.items[threadIdx.x] = I;
     }
     __syncthreads();
-
-    // This wavefront's items are wv, wv+nw, ...: lane k keeps the metadata of the
-    // k-th one in registers; the loop broadcasts it with v_readlane (scalar
-    // results), so no LDS round trip sits on an item's critical path.
-    const uint32_t my_n = n > wv ? (n - wv + nw - 1) / nw : 0u;  // <= 64
-    uint32_t m_bt = 0, m_base = 0, m_rel = 0, m_dslo = 0, m_dshi = 0, m_kc = 0xFFu;
-    float m_c0 = 0.f;
-    if (lane < my_n) {
-      const uint32_t it = wv + lane * nw;
-      m_bt = sm.items[it].bits_term;
-      m_base = sm.items[it].base;
-      m_rel = sm.items[it].rel_off;
-      const uint32_t j = m_bt >> 16;
-      const uint64_t ds = sm.tl[j].doc_start;
-      m_dslo = uint32_t(ds);
-      m_dshi = uint32_t(ds >> 32);
-      const uint32_t cid = sm.qts[j].cache_id;
-      m_kc = uint32_t(sm.qts[j].kind) | ((cid < 255u ? cid : 255u) << 8);
-      m_c0 = sm.qts[j].c0;
-    }
-    auto item_blk = [&](uint32_t k) -> const uint8_t* {
-      const uint64_t start = (uint64_t(wave::read_lane(m_dshi, k)) << 32) |
-                             wave::read_lane(m_dslo, k);
-      return seg.doc + start + wave::read_lane(m_rel, k);
-    };
-    // raw payload words of the k-th item (two per block part), loaded ahead of use
-    auto load_k = [&](uint32_t k, uint64_t& da, uint64_t& db, uint64_t& fa, uint64_t& fb) {
-      const uint32_t bt = wave::read_lane(m_bt, k);
-      const uint32_t dbits = bt & 0xFFu, fbits = (bt >> 8) & 0xFFu;
-      const uint8_t* blk = item_blk(k);
-      const RawPair d = raw_load<LAYOUT>(blk + 1, dbits, lane);
-      da = d.a;
-      db = d.b;
-      // the freq block starts right after the doc block; an ALL_EQUAL doc block
-      // (vint payload) has a data-dependent size and is fetched at use instead
-      if (dbits) {
-        const RawPair f = raw_load<LAYOUT>(blk + 2u + 16u * dbits, fbits, lane);
-        fa = f.a;
-        fb = f.b;
-      }
-    };
-    auto is_fast = [&](uint32_t bt, uint32_t kc) {
-      return (bt & 0xFFu) != 0u && ((bt >> 8) & 0xFFu) != 0u &&
-             (kc & 0xFFu) == uint32_t(kBM25Tiny) && (kc >> 8) < kMaxCaches;
-    };
-    // generic item: any block framing, any scorer
-    auto slow_item = [&](uint32_t k, uint64_t da, uint64_t db, uint64_t fa, uint64_t fb) {
-      const uint32_t bt = wave::read_lane(m_bt, k);
-      const uint32_t base = wave::read_lane(m_base, k);
-      const uint32_t dbits = bt & 0xFFu, fbits = (bt >> 8) & 0xFFu;
-      const uint32_t j = bt >> 16;
-      uint32_t x0, x1, f0, f1;
-      RawPair rd, rf;
-      rd.a = da; rd.b = db; rf.a = fa; rf.b = fb;
-      if (dbits) {
-        raw_extract<LAYOUT>(rd, dbits, lane, x0, x1);
-      } else {
-        uint32_t len;
-        x0 = x1 = vint_from(da, &len);
-        rf = raw_load<LAYOUT>(item_blk(k) + 2u + len, fbits, lane);
-      }
-      if (fbits) {
-        raw_extract<LAYOUT>(rf, fbits, lane, f0, f1);
-      } else {
-        uint32_t len;
-        f0 = f1 = vint_from(rf.a, &len);
-      }
-      const uint32_t d1 = base + wave::inclusive_scan(x0 + x1);
-      const DevQTerm qt = sm.qts[j];
-      const float inv_one = 1.f / (qt.norm_const + qt.norm_length * 1.f);
-      apply(qt, inv_one, d1 - x1, f0);
-      apply(qt, inv_one, d1, f1);
-    };
-    // hot path, one item: straight-line code
-    auto fast_item = [&](uint32_t k, uint64_t da, uint64_t db, uint64_t fa, uint64_t fb) {
-      const uint32_t bt = wave::read_lane(m_bt, k);
-      const uint32_t kc = wave::read_lane(m_kc, k);
-      const float c0 = wave::read_lane_f(m_c0, k);
-      const float* cache = sm.caches + (kc >> 8) * 256u;
-      uint32_t x0, x1, f0, f1;
-      RawPair rd, rf;
-      rd.a = da; rd.b = db; rf.a = fa; rf.b = fb;
-      raw_extract<LAYOUT>(rd, bt & 0xFFu, lane, x0, x1);
-      raw_extract<LAYOUT>(rf, (bt >> 8) & 0xFFu, lane, f0, f1);
-      const uint32_t d1 = wave::read_lane(m_base, k) + wave::inclusive_scan(x0 + x1);
-      post_bm25(c0, cache, d1 - x1, f0);
-      post_bm25(c0, cache, d1, f1);
-    };
-    // hot path, two items fused: 4 postings per lane in flight, two independent
-    // DPP scan chains, all LDS lookups issued back to back
-    auto fast_pair = [&](uint32_t k, uint64_t ada, uint64_t adb, uint64_t afa, uint64_t afb,
-                         uint64_t bda, uint64_t bdb, uint64_t bfa, uint64_t bfb) {
-      const uint32_t btA = wave::read_lane(m_bt, k), btB = wave::read_lane(m_bt, k + 1);
-      const uint32_t kcA = wave::read_lane(m_kc, k), kcB = wave::read_lane(m_kc, k + 1);
-      const float c0A = wave::read_lane_f(m_c0, k), c0B = wave::read_lane_f(m_c0, k + 1);
-      const float* cacheA = sm.caches + (kcA >> 8) * 256u;
-      const float* cacheB = sm.caches + (kcB >> 8) * 256u;
-      uint32_t ax0, ax1, af0, af1, bx0, bx1, bf0, bf1;
-      RawPair r;
-      r.a = ada; r.b = adb;
-      raw_extract<LAYOUT>(r, btA & 0xFFu, lane, ax0, ax1);
-      r.a = bda; r.b = bdb;
-      raw_extract<LAYOUT>(r, btB & 0xFFu, lane, bx0, bx1);
-      r.a = afa; r.b = afb;
-      raw_extract<LAYOUT>(r, (btA >> 8) & 0xFFu, lane, af0, af1);
-      r.a = bfa; r.b = bfb;
-      raw_extract<LAYOUT>(r, (btB >> 8) & 0xFFu, lane, bf0, bf1);
-      uint32_t sa = ax0 + ax1, sb = bx0 + bx1;
-      wave::inclusive_scan2(sa, sb);
-      const uint32_t ad1 = wave::read_lane(m_base, k) + sa;
-      const uint32_t bd1 = wave::read_lane(m_base, k + 1) + sb;
-      post_bm25(c0A, cacheA, ad1 - ax1, af0);
-      post_bm25(c0A, cacheA, ad1, af1);
-      post_bm25(c0B, cacheB, bd1 - bx1, bf0);
-      post_bm25(c0B, cacheB, bd1, bf1);
-    };
-
-    uint64_t ada = 0, adb = 0, afa = 0, afb = 0, bda = 0, bdb = 0, bfa = 0, bfb = 0;
-    if (0 < my_n) load_k(0, ada, adb, afa, afb);
-    if (1 < my_n) load_k(1, bda, bdb, bfa, bfb);
-    for (uint32_t k = 0; k < my_n; k += 2) {
-      uint64_t nada = 0, nadb = 0, nafa = 0, nafb = 0, nbda = 0, nbdb = 0, nbfa = 0, nbfb = 0;
-      if (k + 2 < my_n) load_k(k + 2, nada, nadb, nafa, nafb);
-      if (k + 3 < my_n) load_k(k + 3, nbda, nbdb, nbfa, nbfb);
-      const bool hasB = k + 1 < my_n;
-      const bool okA = is_fast(wave::read_lane(m_bt, k), wave::read_lane(m_kc, k));
-      const bool okB = hasB && is_fast(wave::read_lane(m_bt, k + 1), wave::read_lane(m_kc, k + 1));
-      if (okA && okB) {
-        fast_pair(k, ada, adb, afa, afb, bda, bdb, bfa, bfb);
-      } else {
-        if (okA) fast_item(k, ada, adb, afa, afb); else slow_item(k, ada, adb, afa, afb);
-        if (hasB) {
-          if (okB) fast_item(k + 1, bda, bdb, bfa, bfb); else slow_item(k + 1, bda, bdb, bfa, bfb);
-        }
-      }
-      ada = nada; adb = nadb; afa = nafa; afb = nafb;
-      bda = nbda; bdb = nbdb; bfa = nbfa; bfb = nbfb;
-    }
+    process_items<LAYOUT, TILE, AND>(seg, sm, sm.items, n, lo, span, fx_mul);
   }
-  // decoded vint tails / single-doc terms (k_plan), one term per wavefront
-  for (uint32_t j = wv; j < qd.n_terms; j += nw) {
-    const uint32_t tn = sm.tl[j].tail_n;
-    if (tn) {
-      const DevQTerm qt = sm.qts[j];
-      const float inv_one = 1.f / (qt.norm_const + qt.norm_length * 1.f);
-      const DevTail* tl = tails_q + j;
-      for (uint32_t i = lane; i < tn; i += 64) apply(qt, inv_one, tl->docs[i], tl->freqs[i]);
-    }
-  }
+  apply_tails<TILE, AND>(seg, qd, tails_q, sm, lo, span, fx_mul);
   __syncthreads();
 }
 
@@ -766,73 +790,324 @@ k_pilot(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
 }
 
 // ----------------------------------------------------------------- score --
+//
+// Persistent, software-pipelined workgroups.  The grid is sized to fill the
+// chip once; every workgroup pulls CHUNKS of kChunkTiles consecutive doc tiles
+// of one query from a global counter and walks them with a 2-stage pipeline:
+// while the wavefronts decode/score tile u out of LDS tables, the directory
+// entries and norm bytes of tile u+1 are already in flight into registers, the
+// returning atomic that reserves candidate slots for tile u-1 is in flight,
+// and so is the dequeue of the next chunk.  No global-memory latency sits on
+// the critical path of a tile except the payload loads, which run two work
+// items ahead inside process_items.
 
-// One workgroup per (query, doc tile); work ids are remapped so that each XCD
-// (private L2) walks a contiguous run of tiles of the same queries.
+constexpr uint32_t kChunkTiles = 16;
+constexpr uint32_t kScoreCands = 128;   // per-tile candidate staging slots (x2 buffers)
+
+enum : uint32_t {  // indices into the workgroup's LDS scratch words
+  kVChunk = 0,     // current chunk id
+  kVHits = 1,      // hits of this chunk
+  kVBase = 2,      // global candidate base of the previous tile
+  kVBaseLast = 3,  // ... of the chunk's last tile (own word: slow threads may still read kVBase)
+  kVNc0 = 4,       // kVNc0 + (u % 3): candidate count of tile u
+  kVWords = 8,
+};
+
+template<int TILE, bool AND>
+constexpr uint32_t score_smem_bytes() {
+  return tile_smem_bytes<TILE, AND>()                      // acc, cnt, lnorm, caches, qts, tl, items[0]
+         + sizeof(ItemL) * kItemChunk                      // items[1]
+         + 4u * (kChunkTiles + 1) * kMaxTerms              // rows
+         + 4u * 3u * kMaxTerms                             // nblk, tail first, tail last
+         + 8u * 2u * kScoreCands                           // candidate staging x2
+         + 4u * kVWords;
+}
+
 template<int LAYOUT, int TILE, bool AND>
 __global__ void __launch_bounds__(kTileThreadsMax)
 k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_t jt,
-        uint32_t n_tiles, uint32_t n_work, const uint32_t* first, const DevTail* tails,
+        uint32_t n_tiles, uint32_t n_queries, const uint32_t* first, const DevTail* tails,
         const uint32_t* bstar, uint64_t* cands, uint32_t cand_cap, uint32_t* cand_count,
-        unsigned long long* hits) {
+        unsigned long long* hits, uint32_t* work_counter) {
   RT_DYN_SMEM(smem);
   unsigned char* rest;
   const TileSmem sm = carve<TILE, AND>(smem, &rest);
-  uint64_t* lcand = reinterpret_cast<uint64_t*>(rest);            // [kLocalCands]
-  uint32_t* lvars = reinterpret_cast<uint32_t*>(lcand + kLocalCands);  // [4]
-  // XCD-aware remap: block b runs on XCD b % 8; give XCD x the contiguous
-  // work range [x*per, (x+1)*per).
-  const uint32_t per = (n_work + 7u) / 8u;
-  const uint32_t w = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-  if ((blockIdx.x >> 3) >= per || w >= n_work) return;
-  const uint32_t q = w / n_tiles, tile = w % n_tiles;
-  const DevQuery qd = queries[q];
-  const DevTail* tails_q = tails + uint64_t(q) * jt;
-  if (threadIdx.x < 4) lvars[threadIdx.x] = 0u;
-  const uint32_t bs = bstar[q];  // loaded up front: off the epilogue's critical path
-  tile_begin<TILE, AND>(seg, qd, qterms + qd.first_term,
-                        first + uint64_t(q) * (n_tiles + 1) * jt, jt, tails_q, tile, sm, true);
-  tile_accumulate<LAYOUT, TILE, AND>(seg, qd, tails_q, tile, sm);
-  const uint32_t lo = kDocMin + tile * TILE;
-  // cheap pre-filter in the fixed-point domain: a conservative lower bound of the
-  // accumulator value at the lower edge of bin `bs`; the exact bin test follows
-  unsigned long long thr = 1ull;
-  if (bs) {
-    const double edge = double(bs) / double(qd.bin_scale);
-    thr = static_cast<unsigned long long>(edge / double(qd.fx_inv) * (1.0 - 1e-6));
+  ItemL* items1 = reinterpret_cast<ItemL*>(rest);
+  rest += sizeof(ItemL) * kItemChunk;
+  uint32_t* rows = reinterpret_cast<uint32_t*>(rest);      // [kChunkTiles + 1][kMaxTerms]
+  rest += 4u * (kChunkTiles + 1) * kMaxTerms;
+  uint32_t* tnblk = reinterpret_cast<uint32_t*>(rest);
+  uint32_t* tfirst = tnblk + kMaxTerms;
+  uint32_t* tlast = tfirst + kMaxTerms;
+  rest += 4u * 3u * kMaxTerms;
+  uint64_t* lcand = reinterpret_cast<uint64_t*>(rest);      // [2][kScoreCands]
+  rest += 8u * 2u * kScoreCands;
+  uint32_t* vars = reinterpret_cast<uint32_t*>(rest);
+  ItemL* const item_buf[2] = {sm.items, items1};
+
+  const uint32_t tid = threadIdx.x;
+  const unsigned lane = tid & 63u, wv = tid >> 6;
+  const uint32_t nw = blockDim.x >> 6;
+  const uint32_t cpq = (n_tiles + kChunkTiles - 1) / kChunkTiles;  // chunks per query
+  const uint32_t total_chunks = n_queries * cpq;
+
+  for (uint32_t i = tid; i < uint32_t(TILE) + 64u; i += blockDim.x) sm.acc[i] = 0ull;
+  if (AND) {
+    for (uint32_t i = tid; i < uint32_t(TILE) / 4; i += blockDim.x) sm.cnt[i] = 0u;
   }
-  uint32_t my_hits = 0;
-  for (uint32_t i = threadIdx.x; i < TILE; i += blockDim.x) {
-    const unsigned long long a = sm.acc[i];
-    if (doc_matched<AND>(qd, sm, i, a)) {
-      ++my_hits;
-      if (a < thr) continue;
-      const float v = from_fixed(a, qd.fx_inv);
-      if (score_bin(v, qd.bin_scale) >= bs) {
-        const uint64_t key = make_key(v, lo + i);
-        const uint32_t slot = atomicAdd(&lvars[0], 1u);
-        if (slot < kLocalCands) {
-          lcand[slot] = key;
-        } else {  // rare: more candidates in one tile than staging slots
-          const uint32_t g = atomicAdd(&cand_count[q], 1u);
-          if (g < cand_cap) cands[uint64_t(q) * cand_cap + g] = key;
+  if (tid < kVWords) vars[tid] = 0u;
+  if (tid == 0) vars[kVChunk] = atomicAdd(work_counter, 1u);
+  __syncthreads();
+  uint32_t chunk = vars[kVChunk];
+
+  while (chunk < total_chunks) {
+    // dequeue of the NEXT chunk: issued now, consumed after this chunk
+    uint32_t next_chunk = 0;
+    if (tid == 0) next_chunk = atomicAdd(work_counter, 1u);
+
+    const uint32_t q = chunk / cpq;
+    const uint32_t tile0 = (chunk % cpq) * kChunkTiles;
+    const uint32_t ntile = (n_tiles - tile0) < kChunkTiles ? (n_tiles - tile0) : kChunkTiles;
+    const DevQuery qd = queries[q];
+    const DevTail* tails_q = tails + uint64_t(q) * jt;
+    const uint32_t* first_q = first + uint64_t(q) * (n_tiles + 1) * jt;
+    const uint32_t bs = bstar[q];
+    const float fx_mul = qd.fx_mul;
+
+    // ---- chunk prologue: everything that is per query / per chunk ----------
+    if (tid < qd.n_terms) {
+      sm.qts[tid] = qterms[qd.first_term + tid];
+      const DevTail* tl = tails_q + tid;
+      sm.tl[tid].doc_start = tl->doc_start;
+      sm.tl[tid].dir_off = tl->dir_off;
+      sm.tl[tid].tail_n = tl->n;
+      tnblk[tid] = tl->nblk;
+      tfirst[tid] = tl->first_doc;
+      tlast[tid] = tl->last_doc;
+    }
+    for (uint32_t i = tid; i < (ntile + 1) * jt; i += blockDim.x) {
+      const uint32_t c = i / jt, j = i % jt;
+      rows[c * kMaxTerms + j] = first_q[uint64_t(tile0 + c) * jt + j];
+    }
+    __syncthreads();
+    for (uint32_t e = tid; e < qd.n_caches * 256u; e += blockDim.x) {
+      const uint32_t c = e >> 8, n = e & 255u;
+      float nc = 0.f, nl = 0.f;
+      for (uint32_t j = 0; j < qd.n_terms; ++j) {
+        if (sm.qts[j].cache_id == c) {
+          nc = sm.qts[j].norm_const;
+          nl = sm.qts[j].norm_length;
+          break;
         }
       }
+      sm.caches[e] = n ? 1.f / (nc + nl * static_cast<float>(n)) : 0.f;
     }
-  }
-  my_hits = wave::reduce_add(my_hits);
-  if ((threadIdx.x & 63u) == 0 && my_hits) atomicAdd(&lvars[1], my_hits);
-  __syncthreads();
-  const uint32_t n = lvars[0] < kLocalCands ? lvars[0] : kLocalCands;
-  if (threadIdx.x == 0) {
-    if (lvars[1]) atomicAdd(&hits[q], (unsigned long long)lvars[1]);
-    lvars[2] = n ? atomicAdd(&cand_count[q], n) : 0u;
-  }
-  __syncthreads();
-  const uint32_t gbase = lvars[2];
-  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-    const uint32_t g = gbase + i;
-    if (g < cand_cap) cands[uint64_t(q) * cand_cap + g] = lcand[i];
+    // conservative fixed-point image of the lower edge of bin `bs` (exact bin test follows)
+    unsigned long long thr = 1ull;
+    if (bs) {
+      const double edge = double(bs) / double(qd.bin_scale);
+      thr = static_cast<unsigned long long>(edge / double(qd.fx_inv) * (1.0 - 1e-6));
+    }
+
+    // The (term, block) item this thread owns in local tile c (first kItemChunk
+    // items), found by walking the per-term block counts in LDS; issues the
+    // directory loads and returns the tile's total item count.
+    auto fetch_item = [&](uint32_t c, uint32_t skip, uint32_t& r_off, uint32_t& r_base,
+                          uint32_t& r_bt) -> uint32_t {
+      uint32_t off = 0, my_j = kNoTerm, my_b = 0;
+      const uint32_t id = skip + tid;
+      for (uint32_t j = 0; j < qd.n_terms; ++j) {
+        const uint32_t b0 = rows[c * kMaxTerms + j];
+        uint32_t b1 = rows[(c + 1) * kMaxTerms + j] + 1u;
+        b1 = b1 < tnblk[j] ? b1 : tnblk[j];
+        const uint32_t nb = b1 > b0 ? b1 - b0 : 0u;
+        if (id >= off && id < off + nb) {
+          my_j = j;
+          my_b = b0 + (id - off);
+        }
+        off += nb;
+      }
+      if (my_j != kNoTerm && tid < kItemChunk) {
+        const uint64_t e = sm.tl[my_j].dir_off + my_b;
+        r_off = seg.blk_off[e];
+        r_base = my_b ? seg.blk_last[e - 1] : kDocMin;
+        r_bt = uint32_t(seg.blk_bits[e]) | (my_j << 16);
+      }
+      return off;
+    };
+    auto norm_words = [&](uint32_t tile, uint32_t& w0, uint32_t& w1) {
+      // TILE bytes / blockDim threads: up to 2 dwords per thread at 512+ threads;
+      // generic loop below covers smaller workgroups
+      w0 = w1 = 0;
+      if (seg.norms && seg.norm_width == 1) {
+        const uint64_t base = uint64_t(tile) * TILE + (kDocMin - seg.norm_min_doc);
+        const uint32_t i0 = tid * 4u, i1 = (tid + blockDim.x) * 4u;
+        if (i0 < uint32_t(TILE) && base + i0 < seg.norm_count) w0 = wave::load_u32(seg.norms + base + i0);
+        if (i1 < uint32_t(TILE) && base + i1 < seg.norm_count) w1 = wave::load_u32(seg.norms + base + i1);
+      }
+    };
+    auto store_norm_words = [&](uint32_t tile, uint32_t w0, uint32_t w1) {
+      const uint32_t i0 = tid * 4u, i1 = (tid + blockDim.x) * 4u;
+      if (i0 < uint32_t(TILE)) *reinterpret_cast<uint32_t*>(sm.lnorm + i0) = w0;
+      if (i1 < uint32_t(TILE)) *reinterpret_cast<uint32_t*>(sm.lnorm + i1) = w1;
+      // workgroups smaller than TILE/8 threads: remaining words loaded in place
+      if (seg.norms && seg.norm_width == 1) {
+        const uint64_t base = uint64_t(tile) * TILE + (kDocMin - seg.norm_min_doc);
+        for (uint32_t i = (tid + 2u * blockDim.x) * 4u; i < uint32_t(TILE); i += blockDim.x * 4u) {
+          uint32_t w = 0;
+          if (base + i < seg.norm_count) w = wave::load_u32(seg.norms + base + i);
+          *reinterpret_cast<uint32_t*>(sm.lnorm + i) = w;
+        }
+      }
+    };
+
+    // ---- prime the pipeline with local tile 0 -------------------------------
+    uint32_t r_off = 0, r_base = 0, r_bt = 0, nw0 = 0, nw1 = 0;
+    uint32_t n_cur = fetch_item(0, 0, r_off, r_base, r_bt);
+    norm_words(tile0, nw0, nw1);
+    if (tid < n_cur && tid < kItemChunk) {
+      ItemL I;
+      I.rel_off = r_off; I.base = r_base; I.bits_term = r_bt;
+      item_buf[0][tid] = I;
+    }
+    store_norm_words(tile0, nw0, nw1);
+    __syncthreads();
+
+    uint32_t pend_base = 0;   // thread 0: reserved candidate base of the previous tile (in flight)
+    for (uint32_t u = 0; u < ntile; ++u) {
+      const uint32_t tile = tile0 + u;
+      const uint32_t lo = kDocMin + tile * TILE;
+      const uint32_t span = (seg.num_docs + kDocMin - lo) < uint32_t(TILE)
+                              ? (seg.num_docs + kDocMin - lo) : uint32_t(TILE);
+      ItemL* items = item_buf[u & 1u];
+      // stage 1 of tile u+1: directory + norm loads go out now, land after compute
+      uint32_t n_next = 0;
+      const bool has_next = u + 1 < ntile;
+      if (has_next) {
+        n_next = fetch_item(u + 1, 0, r_off, r_base, r_bt);
+        norm_words(tile + 1, nw0, nw1);
+      }
+      // stage 2 of tile u: decode + score + accumulate
+      process_items<LAYOUT, TILE, AND>(seg, sm, items, n_cur < kItemChunk ? n_cur : kItemChunk,
+                                       lo, span, fx_mul);
+      for (uint32_t done = kItemChunk; done < n_cur; done += kItemChunk) {  // rare: > 256 items
+        __syncthreads();
+        uint32_t xo = 0, xb = 0, xt = 0;
+        fetch_item(u, done, xo, xb, xt);
+        if (tid < kItemChunk && done + tid < n_cur) {
+          ItemL I;
+          I.rel_off = xo; I.base = xb; I.bits_term = xt;
+          items[tid] = I;
+        }
+        __syncthreads();
+        const uint32_t n = (n_cur - done) < kItemChunk ? (n_cur - done) : kItemChunk;
+        process_items<LAYOUT, TILE, AND>(seg, sm, items, n, lo, span, fx_mul);
+      }
+      for (uint32_t j = wv; j < qd.n_terms; j += nw) {  // decoded vint tails / single docs
+        const uint32_t tn = sm.tl[j].tail_n;
+        if (tn && tfirst[j] < lo + span && tlast[j] >= lo) {
+          const DevQTerm qt = sm.qts[j];
+          const float inv_one = 1.f / (qt.norm_const + qt.norm_length * 1.f);
+          const DevTail* tl = tails_q + j;
+          for (uint32_t i = lane; i < tn; i += 64)
+            tile_apply<TILE, AND>(seg, sm, qt, inv_one, tl->docs[i], tl->freqs[i], lo, span, fx_mul);
+        }
+      }
+      __syncthreads();  // B1: every accumulation of tile u has landed
+
+      // epilogue of tile u: read + clear the accumulators, count hits, stage candidates
+      uint64_t* lc = lcand + (u & 1u) * kScoreCands;
+      uint32_t* ncand = vars + kVNc0 + (u % 3u);
+      uint32_t my_hits = 0;
+      for (uint32_t i = tid; i < uint32_t(TILE); i += blockDim.x) {
+        const unsigned long long a = sm.acc[i];
+        bool m = a != 0ull;
+        if (a) sm.acc[i] = 0ull;
+        if (AND) {
+          const uint32_t cw = sm.cnt[i >> 2];
+          if (qd.op == 1) m = qd.n_terms && ((cw >> (8u * (i & 3u))) & 0xFFu) == qd.n_terms;
+        }
+        if (m) {
+          ++my_hits;
+          if (a >= thr) {
+            const float v = from_fixed(a, qd.fx_inv);
+            if (score_bin(v, qd.bin_scale) >= bs) {
+              const uint64_t key = make_key(v, lo + i);
+              const uint32_t slot = atomicAdd(ncand, 1u);
+              if (slot < kScoreCands) {
+                lc[slot] = key;
+              } else {  // rare: more candidates in one tile than staging slots
+                const uint32_t g = atomicAdd(&cand_count[q], 1u);
+                if (g < cand_cap) cands[uint64_t(q) * cand_cap + g] = key;
+              }
+            }
+          }
+        }
+      }
+      if (AND) {
+        __syncthreads();  // counters are packed 4 per word: clear only after all reads
+        for (uint32_t i = tid; i < uint32_t(TILE) / 4; i += blockDim.x) sm.cnt[i] = 0u;
+      }
+      my_hits = wave::reduce_add(my_hits);
+      if (lane == 0 && my_hits) atomicAdd(&vars[kVHits], my_hits);
+      // stage 1 of tile u+1 lands in the other table / the norm bytes
+      if (has_next) {
+        if (tid < n_next && tid < kItemChunk) {
+          ItemL I;
+          I.rel_off = r_off; I.base = r_base; I.bits_term = r_bt;
+          item_buf[(u + 1u) & 1u][tid] = I;
+        }
+        store_norm_words(tile + 1, nw0, nw1);
+      }
+      if (tid == 0) {
+        vars[kVBase] = pend_base;                 // tile u-1's reservation has arrived by now
+        vars[kVNc0 + ((u + 1u) % 3u)] = 0u;       // counter of tile u+1 (last used by tile u-2)
+      }
+      __syncthreads();  // B2
+      // flush tile u-1's staged candidates to its reserved global range
+      if (u > 0) {
+        const uint32_t pn_raw = vars[kVNc0 + ((u - 1u) % 3u)];
+        const uint32_t pn = pn_raw < kScoreCands ? pn_raw : kScoreCands;
+        const uint32_t gbase = vars[kVBase];
+        const uint64_t* pl = lcand + ((u - 1u) & 1u) * kScoreCands;
+        for (uint32_t i = tid; i < pn; i += blockDim.x) {
+          const uint32_t g = gbase + i;
+          if (g < cand_cap) cands[uint64_t(q) * cand_cap + g] = pl[i];
+        }
+      }
+      // reserve global slots for tile u (returning atomic; consumed one tile later)
+      if (tid == 0) {
+        const uint32_t cn_raw = *ncand;
+        const uint32_t cn = cn_raw < kScoreCands ? cn_raw : kScoreCands;
+        pend_base = cn ? atomicAdd(&cand_count[q], cn) : 0u;
+      }
+      n_cur = n_next;
+    }
+    // ---- chunk epilogue: flush the last tile, publish hits, pick up the next chunk
+    if (tid == 0) {
+      vars[kVBaseLast] = pend_base;
+      vars[kVChunk] = next_chunk;
+    }
+    __syncthreads();
+    {
+      const uint32_t lu = ntile - 1u;
+      const uint32_t pn_raw = vars[kVNc0 + (lu % 3u)];
+      const uint32_t pn = pn_raw < kScoreCands ? pn_raw : kScoreCands;
+      const uint32_t gbase = vars[kVBaseLast];
+      const uint64_t* pl = lcand + (lu & 1u) * kScoreCands;
+      for (uint32_t i = tid; i < pn; i += blockDim.x) {
+        const uint32_t g = gbase + i;
+        if (g < cand_cap) cands[uint64_t(q) * cand_cap + g] = pl[i];
+      }
+    }
+    chunk = vars[kVChunk];
+    __syncthreads();  // everyone has read the chunk id and the staging buffers
+    if (tid == 0) {
+      if (vars[kVHits]) atomicAdd(&hits[q], (unsigned long long)vars[kVHits]);
+      vars[kVHits] = 0u;
+      vars[kVNc0] = vars[kVNc0 + 1] = vars[kVNc0 + 2] = 0u;
+    }
+    __syncthreads();
   }
 }
 

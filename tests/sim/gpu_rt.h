@@ -21,6 +21,7 @@ inline bool device_arch(int, char* buf, size_t cap) {
   if (cap) buf[cap - 1] = 0;
   return true;
 }
+inline int device_cus(int) { return 3; }  // a few persistent workgroups
 inline void* dmalloc(size_t n) {
   void* p = std::malloc(n ? n : 1);
   if (p) std::memset(p, 0xCD, n ? n : 1);  // hipMalloc does not zero: poison
