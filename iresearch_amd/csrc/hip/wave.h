@@ -81,6 +81,10 @@ __device__ __forceinline__ float read_lane_f(float v, uint32_t k) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), int(k)));
 }
 
+// Optimisation barrier: the value must exist in a VGPR at this program point.
+__device__ __forceinline__ void keep(uint32_t& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void keep_f(float& v) { asm volatile("" : "+v"(v)); }
+
 // v_rcp_f32: <= 1 ulp
 __device__ __forceinline__ float fast_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
 

@@ -496,23 +496,52 @@ __device__ __forceinline__ void tile_apply(const DevSegment& seg, const TileSmem
   }
 }
 
-// Branch-free scoring of one posting on the hot path (BM25, 1-byte norms,
-// LDS norm_cache — bm25.cpp:348-353: c0 - c0/(1 + tf*cache[norm]); the
-// division is one v_rcp_f32, <= 1 ulp, far inside the 1e-5 parity tolerance).
-// Postings outside the tile add 0 to a private dummy slot instead of
-// branching, so that several postings' LDS lookups overlap.
-template<int TILE, bool AND>
-__device__ __forceinline__ void tile_post_bm25(const TileSmem& sm, float c0, const float* cache,
-                                               uint32_t doc, uint32_t freq, uint32_t lo,
+// Scoring of N postings at once on the hot path (BM25, 1-byte norms, LDS
+// norm_cache — bm25.cpp:348-353: c0 - c0/(1 + tf*cache[norm]); the division is
+// one v_rcp_f32, <= 1 ulp, far inside the 1e-5 parity tolerance).  Staged so
+// that the N norm-byte reads, then the N cache reads, then the N LDS atomics
+// are issued back to back: one LDS latency per stage instead of one per
+// posting.  wave::keep() pins each stage (the compiler would otherwise sink
+// the whole computation behind a per-posting branch).  Postings outside the
+// tile add 0 to a private dummy slot instead of branching.
+template<int TILE, bool AND, int N>
+__device__ __forceinline__ void tile_post_bm25(const TileSmem& sm, const float (&c0)[N],
+                                               const float* const (&cache)[N],
+                                               const uint32_t (&doc)[N],
+                                               const uint32_t (&freq)[N], uint32_t lo,
                                                uint32_t span, float fx_mul, unsigned lane) {
-  const uint32_t idx = doc - lo;  // doc < lo wraps to a huge value
-  const bool in = idx < span;
-  const uint32_t li = in ? idx : (uint32_t(TILE) + lane);
-  const float x = static_cast<float>(freq) * cache[sm.lnorm[in ? idx : 0u]];
-  const float s = c0 - c0 * wave::fast_rcp(1.f + x);
-  atomicAdd(&sm.acc[li], in ? to_fixed(s, fx_mul) : 0ull);
-  if (AND) {
-    if (in) atomicAdd(&sm.cnt[idx >> 2], 1u << (8u * (idx & 3u)));
+  uint32_t idx[N], nb[N];
+  bool in[N];
+  float inv[N];
+  unsigned long long fx[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    idx[k] = doc[k] - lo;  // doc < lo wraps to a huge value
+    in[k] = idx[k] < span;
+    nb[k] = sm.lnorm[in[k] ? idx[k] : 0u];
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) wave::keep(nb[k]);
+#pragma unroll
+  for (int k = 0; k < N; ++k) inv[k] = cache[k][nb[k]];
+#pragma unroll
+  for (int k = 0; k < N; ++k) wave::keep_f(inv[k]);
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const float x = static_cast<float>(freq[k]) * inv[k];
+    const float s = c0[k] - c0[k] * wave::fast_rcp(1.f + x);
+    fx[k] = to_fixed(s, fx_mul);
+    uint32_t lo32 = uint32_t(fx[k]), hi32 = uint32_t(fx[k] >> 32);
+    wave::keep(lo32);
+    wave::keep(hi32);
+    fx[k] = (static_cast<unsigned long long>(hi32) << 32) | lo32;
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    atomicAdd(&sm.acc[in[k] ? idx[k] : (uint32_t(TILE) + lane)], in[k] ? fx[k] : 0ull);
+    if (AND) {
+      if (in[k]) atomicAdd(&sm.cnt[idx[k] >> 2], 1u << (8u * (idx[k] & 3u)));
+    }
   }
 }
 
@@ -608,8 +637,11 @@ __device__ __forceinline__ void process_items(const DevSegment& seg, const TileS
     raw_extract<LAYOUT>(rd, bt & 0xFFu, lane, x0, x1);
     raw_extract<LAYOUT>(rf, (bt >> 8) & 0xFFu, lane, f0, f1);
     const uint32_t d1 = wave::read_lane(m_base, k) + wave::inclusive_scan(x0 + x1);
-    tile_post_bm25<TILE, AND>(sm, c0, cache, d1 - x1, f0, lo, span, fx_mul, lane);
-    tile_post_bm25<TILE, AND>(sm, c0, cache, d1, f1, lo, span, fx_mul, lane);
+    const float c0s[2] = {c0, c0};
+    const float* const caches2[2] = {cache, cache};
+    const uint32_t docs2[2] = {d1 - x1, d1};
+    const uint32_t freqs2[2] = {f0, f1};
+    tile_post_bm25<TILE, AND, 2>(sm, c0s, caches2, docs2, freqs2, lo, span, fx_mul, lane);
   };
   // hot path, two items fused: 4 postings per lane in flight, two independent
   // DPP scan chains, all LDS lookups issued back to back
@@ -634,10 +666,11 @@ __device__ __forceinline__ void process_items(const DevSegment& seg, const TileS
     wave::inclusive_scan2(sa, sb);
     const uint32_t ad1 = wave::read_lane(m_base, k) + sa;
     const uint32_t bd1 = wave::read_lane(m_base, k + 1) + sb;
-    tile_post_bm25<TILE, AND>(sm, c0A, cacheA, ad1 - ax1, af0, lo, span, fx_mul, lane);
-    tile_post_bm25<TILE, AND>(sm, c0A, cacheA, ad1, af1, lo, span, fx_mul, lane);
-    tile_post_bm25<TILE, AND>(sm, c0B, cacheB, bd1 - bx1, bf0, lo, span, fx_mul, lane);
-    tile_post_bm25<TILE, AND>(sm, c0B, cacheB, bd1, bf1, lo, span, fx_mul, lane);
+    const float c0s[4] = {c0A, c0A, c0B, c0B};
+    const float* const caches4[4] = {cacheA, cacheA, cacheB, cacheB};
+    const uint32_t docs4[4] = {ad1 - ax1, ad1, bd1 - bx1, bd1};
+    const uint32_t freqs4[4] = {af0, af1, bf0, bf1};
+    tile_post_bm25<TILE, AND, 4>(sm, c0s, caches4, docs4, freqs4, lo, span, fx_mul, lane);
   };
 
   uint64_t ada = 0, adb = 0, afa = 0, afb = 0, bda = 0, bdb = 0, bfa = 0, bfb = 0;

@@ -63,6 +63,8 @@ __device__ __forceinline__ void inclusive_scan2(uint32_t& a, uint32_t& b) {
 }
 __device__ __forceinline__ uint32_t read_lane(uint32_t v, uint32_t k) { return __shfl(v, int(k), 64); }
 __device__ __forceinline__ float read_lane_f(float v, uint32_t k) { return __shfl(v, int(k), 64); }
+__device__ __forceinline__ void keep(uint32_t&) {}
+__device__ __forceinline__ void keep_f(float&) {}
 // v_rcp_f32 on the GPU (<= 1 ulp); exact division here
 __device__ __forceinline__ float fast_rcp(float v) { return 1.0f / v; }
 
