@@ -177,7 +177,7 @@ int irs_hip_query_batch(irs_hip_segment* seg, const irs_hip_query* queries,
                         uint32_t k_stride, uint32_t* counts,
                         uint64_t* total_hits);
 
-/* Tuning knobs (0 keeps the default). tile_docs in {2048, 4096, 8192};
+/* Tuning knobs (0 keeps the default). tile_docs in {4096, 8192};
  * pilot_stride P: every P-th doc tile is scored first to bound the k-th score
  * (P == 1: exact two-pass); cand_cap: candidate slots per query. */
 int irs_hip_batch_configure(irs_hip_batch* batch, uint32_t tile_docs,

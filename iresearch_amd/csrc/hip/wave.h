@@ -81,6 +81,17 @@ __device__ __forceinline__ float read_lane_f(float v, uint32_t k) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), int(k)));
 }
 
+// Cheap integer helpers that map to single full-rate instructions.
+__device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }
+// ({hi, lo} >> s) & 0xffffffff, s in 0..31 (v_alignbit_b32)
+__device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t s) {
+  return __builtin_amdgcn_alignbit(hi, lo, s);
+}
+// low `bits` bits of x, 1 <= bits <= 31 (v_bfe_u32)
+__device__ __forceinline__ uint32_t bfe(uint32_t x, uint32_t bits) {
+  return __builtin_amdgcn_ubfe(x, 0u, bits);
+}
+
 // Optimisation barrier: the value must exist in a VGPR at this program point.
 __device__ __forceinline__ void keep(uint32_t& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void keep_f(float& v) { asm volatile("" : "+v"(v)); }

@@ -88,6 +88,7 @@ struct irs_hip_batch {
   uint32_t stride_eff = 1;  // pilot stride actually used (>= 4 pilot tiles when possible)
   uint32_t wg_threads = kDefaultWgThreads;  // threads per pilot/score workgroup
   bool any_and = false;
+  bool acc32 = true;   // 32-bit fixed-point accumulators are precise enough for every query
   bool scratch_ready = false;
   std::vector<DevQuery> queries;
   std::vector<DevQTerm> qterms;
@@ -132,11 +133,11 @@ bool big_smem(K kernel, size_t bytes) {
   return rt::allow_dynamic_smem(reinterpret_cast<const void*>(kernel), bytes);
 }
 
-// launch helpers: one instantiation per (layout, tile, AND)
-template<int LAYOUT, int TILE, bool AND>
+// launch helpers: one instantiation per (accumulator width, layout, tile, AND)
+template<typename ACC, int LAYOUT, int TILE, bool AND>
 bool launch_pilot(irs_hip_batch* b, rt::stream_t st) {
-  const size_t smem = tile_smem_bytes<TILE, AND>() + kBins * sizeof(uint32_t);
-  auto kern = k_pilot<LAYOUT, TILE, AND>;
+  const size_t smem = tile_smem_bytes<ACC, TILE, AND>() + kBins * sizeof(uint32_t);
+  auto kern = k_pilot<ACC, LAYOUT, TILE, AND>;
   if (!big_smem(kern, smem)) return false;
   RT_LAUNCH(kern, b->nq, b->wg_threads, smem, st, b->seg->dev, b->d_queries.as<DevQuery>(),
             b->d_qterms.as<DevQTerm>(), b->jt, b->n_tiles, b->stride_eff,
@@ -144,10 +145,10 @@ bool launch_pilot(irs_hip_batch* b, rt::stream_t st) {
   return rt::last_error_ok();
 }
 
-template<int LAYOUT, int TILE, bool AND>
+template<typename ACC, int LAYOUT, int TILE, bool AND>
 bool launch_score(irs_hip_batch* b, rt::stream_t st) {
-  const size_t smem = score_smem_bytes<TILE, AND>();
-  auto kern = k_score<LAYOUT, TILE, AND>;
+  const size_t smem = score_smem_bytes<ACC, TILE, AND>();
+  auto kern = k_score<ACC, LAYOUT, TILE, AND>;
   if (!big_smem(kern, smem)) return false;
   // persistent grid: as many workgroups as stay resident on the chip at once
   const uint32_t waves = b->wg_threads / 64;
@@ -165,31 +166,35 @@ bool launch_score(irs_hip_batch* b, rt::stream_t st) {
   return rt::last_error_ok();
 }
 
-template<int LAYOUT, int TILE>
+template<typename ACC, int LAYOUT, int TILE>
 bool launch_pilot_and(irs_hip_batch* b, rt::stream_t st) {
-  return b->any_and ? launch_pilot<LAYOUT, TILE, true>(b, st)
-                    : launch_pilot<LAYOUT, TILE, false>(b, st);
+  return b->any_and ? launch_pilot<ACC, LAYOUT, TILE, true>(b, st)
+                    : launch_pilot<ACC, LAYOUT, TILE, false>(b, st);
 }
-template<int LAYOUT, int TILE>
+template<typename ACC, int LAYOUT, int TILE>
 bool launch_score_and(irs_hip_batch* b, rt::stream_t st) {
-  return b->any_and ? launch_score<LAYOUT, TILE, true>(b, st)
-                    : launch_score<LAYOUT, TILE, false>(b, st);
+  return b->any_and ? launch_score<ACC, LAYOUT, TILE, true>(b, st)
+                    : launch_score<ACC, LAYOUT, TILE, false>(b, st);
 }
-template<int LAYOUT>
+template<typename ACC, int LAYOUT>
 bool launch_pilot_tile(irs_hip_batch* b, rt::stream_t st) {
-  switch (b->tile) {
-    case 2048: return launch_pilot_and<LAYOUT, 2048>(b, st);
-    case 8192: return launch_pilot_and<LAYOUT, 8192>(b, st);
-    default: return launch_pilot_and<LAYOUT, 4096>(b, st);
-  }
+  return b->tile == 8192 ? launch_pilot_and<ACC, LAYOUT, 8192>(b, st)
+                         : launch_pilot_and<ACC, LAYOUT, 4096>(b, st);
+}
+template<typename ACC, int LAYOUT>
+bool launch_score_tile(irs_hip_batch* b, rt::stream_t st) {
+  return b->tile == 8192 ? launch_score_and<ACC, LAYOUT, 8192>(b, st)
+                         : launch_score_and<ACC, LAYOUT, 4096>(b, st);
 }
 template<int LAYOUT>
-bool launch_score_tile(irs_hip_batch* b, rt::stream_t st) {
-  switch (b->tile) {
-    case 2048: return launch_score_and<LAYOUT, 2048>(b, st);
-    case 8192: return launch_score_and<LAYOUT, 8192>(b, st);
-    default: return launch_score_and<LAYOUT, 4096>(b, st);
-  }
+bool launch_pilot_acc(irs_hip_batch* b, rt::stream_t st) {
+  return b->acc32 ? launch_pilot_tile<uint32_t, LAYOUT>(b, st)
+                  : launch_pilot_tile<unsigned long long, LAYOUT>(b, st);
+}
+template<int LAYOUT>
+bool launch_score_acc(irs_hip_batch* b, rt::stream_t st) {
+  return b->acc32 ? launch_score_tile<uint32_t, LAYOUT>(b, st)
+                  : launch_score_tile<unsigned long long, LAYOUT>(b, st);
 }
 
 bool ensure_scratch(irs_hip_batch* b) {
@@ -263,6 +268,7 @@ int irs_hip_segment_open(const irs_hip_segment_desc* d, irs_hip_segment** out) {
   int32_t version = -1;
   const size_t hdr = check_doc_header(d->doc_file, d->doc_file_len, &version);
   if (!hdr) return IRS_HIP_ECORRUPT;
+  if (d->doc_file_len >= 0xFFFFFF00ull) return IRS_HIP_EUNSUPPORTED;  // block offsets are u32
   // PostingsFormat: odd versions are the SSE (simd4) layouts (formats_10.cpp:283-313)
   if (version < 0 || version > 5) return IRS_HIP_ECORRUPT;
   if ((version & 1) != (d->layout == IRS_HIP_LAYOUT_SIMD4 ? 1 : 0)) return IRS_HIP_EINVAL;
@@ -424,6 +430,8 @@ int irs_hip_batch_create(irs_hip_segment* seg, const irs_hip_query* queries, uin
   try {
     b->queries.resize(nq);
     b->qterms.reserve(n_entries);
+    std::vector<int> exps;
+    exps.reserve(nq);
     for (uint32_t q = 0; q < nq && rc == IRS_HIP_OK; ++q) {
       const irs_hip_query& in = queries[q];
       if ((in.op != IRS_HIP_OP_OR && in.op != IRS_HIP_OP_AND) || in.n_terms == 0 ||
@@ -434,7 +442,7 @@ int irs_hip_batch_create(irs_hip_segment* seg, const irs_hip_query* queries, uin
       }
       std::vector<DevQTerm> row;
       bool absent = false;
-      double upper = 0.0;
+      double upper = 0.0, min_score = 1e300;
       for (uint32_t j = 0; j < in.n_terms; ++j) {
         const irs_hip_term_scorer& ts = terms[in.first_term + j];
         DevQTerm qt{};
@@ -473,6 +481,21 @@ int irs_hip_batch_create(irs_hip_segment* seg, const irs_hip_query* queries, uin
           continue;
         }
         const DevTerm& t = seg->terms[qt.term];
+        {
+          // smallest score one posting of this term can have (tf = 1, longest doc)
+          const double c0 = qt.c0, nc = qt.norm_const, nl = qt.norm_length;
+          double smin = 0.0;
+          switch (qt.kind) {
+            case kBM1: smin = c0; break;
+            case kBM15: smin = c0 - c0 / (1.0 + 1.0 / nc); break;
+            case kBM25Tiny: smin = c0 - c0 / (1.0 + 1.0 / (nc + nl * 255.0)); break;
+            case kBM25One: smin = c0 - c0 / (1.0 + 1.0 / (nc + nl)); break;
+            case kTfidf: smin = c0; break;
+            case kTfidfTiny: smin = c0 / std::sqrt(255.0); break;
+            default: smin = 0.0;  // wide norms: unbounded below
+          }
+          min_score = std::min(min_score, smin);
+        }
         const bool tfidf = qt.kind == kTfidf || qt.kind == kTfidfTiny || qt.kind == kTfidfWide;
         upper += tfidf ? double(qt.c0) * std::sqrt(double(t.tf_bound)) : double(qt.c0);
         b->postings += t.docs_count;
@@ -520,7 +543,9 @@ int irs_hip_batch_create(irs_hip_segment* seg, const irs_hip_query* queries, uin
         break;
       }
       dq.bin_scale = row.empty() ? 0.f : float(double(kBins) / upper);
-      // fixed-point accumulation: upper < 2^e, so every partial sum * 2^(61-e) < 2^61
+      // fixed-point accumulation: upper < 2^e.  32-bit accumulators (2^(30-e) units) lose at
+      // most one unit per posting, i.e. <= upper / (2^29 * min_score) relative to any doc's
+      // score: used only while that stays below 2e-6 for every query of the batch.
       int e = 0;
       if (!row.empty()) {
         (void)std::frexp(upper, &e);
@@ -528,12 +553,20 @@ int irs_hip_batch_create(irs_hip_segment* seg, const irs_hip_query* queries, uin
           rc = IRS_HIP_EUNSUPPORTED;
           break;
         }
+        if (!(min_score > 0.0) || upper / min_score > 1000.0) b->acc32 = false;
       }
-      dq.fx_mul = std::ldexp(1.f, 29 - e);
-      dq.fx_inv = std::ldexp(1.f, e - 61);
+      exps.push_back(e);
       b->qterms.insert(b->qterms.end(), row.begin(), row.end());
       b->jt = std::max(b->jt, dq.n_terms);
       b->k_max = std::max(b->k_max, in.k);
+    }
+    if (const char* env = std::getenv("IRS_HIP_ACC")) {  // tuning / test knob
+      if (std::atoi(env) == 64) b->acc32 = false;
+    }
+    for (uint32_t q = 0; q < nq && rc == IRS_HIP_OK && q < exps.size(); ++q) {
+      const int e = exps[q];
+      b->queries[q].fx_mul = std::ldexp(1.f, (b->acc32 ? 30 : 29) - e);
+      b->queries[q].fx_inv = std::ldexp(1.f, e - (b->acc32 ? 30 : 61));
     }
   } catch (...) {
     rc = IRS_HIP_ENOMEM;
@@ -563,7 +596,7 @@ int irs_hip_batch_create(irs_hip_segment* seg, const irs_hip_query* queries, uin
 int irs_hip_batch_configure(irs_hip_batch* b, uint32_t tile_docs, uint32_t pilot_stride,
                             uint32_t cand_cap) {
   if (!b) return IRS_HIP_EINVAL;
-  if (tile_docs && tile_docs != 2048 && tile_docs != 4096 && tile_docs != 8192)
+  if (tile_docs && tile_docs != 4096 && tile_docs != 8192)
     return IRS_HIP_EINVAL;
   if (cand_cap && cand_cap < b->k_max) return IRS_HIP_EINVAL;
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
@@ -606,11 +639,11 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st) {
   ok = ok && mark(2 * IRS_HIP_K_PLAN + 1);
   // 2. pilot: per-query score-bin threshold
   ok = ok && mark(2 * IRS_HIP_K_PILOT);
-  ok = ok && (simd ? launch_pilot_tile<kSimd4>(b, st) : launch_pilot_tile<kScalar>(b, st));
+  ok = ok && (simd ? launch_pilot_acc<kSimd4>(b, st) : launch_pilot_acc<kScalar>(b, st));
   ok = ok && mark(2 * IRS_HIP_K_PILOT + 1);
   // 3. score every tile
   ok = ok && mark(2 * IRS_HIP_K_SCORE);
-  ok = ok && (simd ? launch_score_tile<kSimd4>(b, st) : launch_score_tile<kScalar>(b, st));
+  ok = ok && (simd ? launch_score_acc<kSimd4>(b, st) : launch_score_acc<kScalar>(b, st));
   ok = ok && mark(2 * IRS_HIP_K_SCORE + 1);
   // 4. exact top-k
   ok = ok && mark(2 * IRS_HIP_K_SELECT);

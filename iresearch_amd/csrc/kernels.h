@@ -280,13 +280,16 @@ k_plan(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms,
 // ------------------------------------------------------------ tile score --
 //
 // A workgroup owns one doc tile [lo, lo+TILE) of one query.  Per-doc score
-// accumulators live in LDS as 64-bit FIXED-POINT integers: integer addition is
-// associative, so the (term, block) work items of the tile can be processed by
-// the four wavefronts in any order, with no barrier between terms, and the sum
-// is still bit-reproducible.  Each per-posting score is the reference's float
-// expression, evaluated in the reference's order (bit-identical to the CPU
-// value); the fixed-point sum of those floats is exact, so the final float
-// differs from the reference's sequential float sum by rounding only (~1e-7).
+// accumulators live in LDS as FIXED-POINT integers (ACC = 64-bit, or 32-bit when
+// the query's score range allows it): integer addition is associative, so the
+// (term, block) work items of a tile are processed by the wavefronts in any
+// order, with no barrier between terms, and the sum is still bit-reproducible.
+// Each posting's score follows the reference's float expression; the fixed-point
+// sum differs from the reference's sequential float sum by rounding only.
+//
+// The kernel is bound by instruction issue (VALU + SALU), not by HBM, LDS or
+// latency (rocprofv3 PMC, profiles/): everything below is written to minimise
+// wave-instructions per 128-posting block.
 
 struct TermL {          // one query term of this tile, staged in LDS
   uint64_t doc_start;   // absolute offset of the term's postings
@@ -294,18 +297,20 @@ struct TermL {          // one query term of this tile, staged in LDS
   uint32_t b0;          // first block overlapping the tile
   uint32_t nb;          // number of blocks overlapping the tile
   uint32_t item_off;    // prefix sum of nb over the query's terms
-  uint32_t tail_n;      // > 0: the decoded tail intersects the tile
+  uint32_t tail_n;      // postings in the term's decoded tail
 };
 
 struct ItemL {          // one (term, block) work item
-  uint32_t rel_off;     // block offset relative to the term's doc_start
+  uint32_t off;         // byte offset of the block in the staged `.doc` file
   uint32_t base;        // last doc of the preceding block (kDocMin for block 0)
   uint32_t bits_term;   // doc bits | freq bits << 8 | term slot << 16
 };
 
-struct TileSmem {
-  unsigned long long* acc;  // [TILE] fixed-point score accumulators (score_buf of
-                            // block_disjunction, disjunction.hpp:1087-1092, widened to TILE docs)
+template<typename ACC>
+struct TileSmemT {
+  ACC* acc;          // [TILE + 64] fixed-point score accumulators (score_buf of
+                     // block_disjunction, disjunction.hpp:1087-1092, widened to TILE docs)
+                     // + one private dummy slot per lane
   uint32_t* cnt;     // [TILE/4] per-doc match counters, 1 byte each (AND only)
   uint8_t* lnorm;    // [TILE] Norm2 bytes of the tile
   float* caches;     // [kMaxCaches][256] BM25Stats::norm_cache
@@ -315,18 +320,18 @@ struct TileSmem {
   uint32_t* vars;    // [8] 0: item count
 };
 
-template<int TILE, bool AND>
+template<typename ACC, int TILE, bool AND>
 constexpr uint32_t tile_smem_bytes() {
-  return 8u * (TILE + 64) + (AND ? TILE : 0) + TILE + sizeof(float) * 256 * kMaxCaches +
-         sizeof(DevQTerm) * kMaxTerms + sizeof(TermL) * kMaxTerms + sizeof(ItemL) * kItemChunk +
-         32;
+  return uint32_t(sizeof(ACC)) * (TILE + 64) + (AND ? TILE : 0) + TILE +
+         sizeof(float) * 256 * kMaxCaches + sizeof(DevQTerm) * kMaxTerms +
+         sizeof(TermL) * kMaxTerms + sizeof(ItemL) * kItemChunk + 32;
 }
 
-template<int TILE, bool AND>
-__device__ __forceinline__ TileSmem carve(unsigned char* smem, unsigned char** rest) {
-  TileSmem sm;
-  sm.acc = reinterpret_cast<unsigned long long*>(smem);
-  smem += 8u * (TILE + 64);  // + one private dummy slot per lane (see post_bm25)
+template<typename ACC, int TILE, bool AND>
+__device__ __forceinline__ TileSmemT<ACC> carve(unsigned char* smem, unsigned char** rest) {
+  TileSmemT<ACC> sm;
+  sm.acc = reinterpret_cast<ACC*>(smem);
+  smem += sizeof(ACC) * (TILE + 64);
   sm.cnt = reinterpret_cast<uint32_t*>(smem);
   if (AND) smem += TILE;
   sm.lnorm = smem;
@@ -345,17 +350,25 @@ __device__ __forceinline__ TileSmem carve(unsigned char* smem, unsigned char** r
   return sm;
 }
 
-// float score (>= 0, <= the query's upper bound) -> 64-bit fixed point with
-// 2^E units; `| 1` keeps every posting's contribution non-zero so that
-// "accumulator != 0" means "matched".
-__device__ __forceinline__ unsigned long long to_fixed(float s, float fx_mul) {
-  const float x = s * fx_mul;                       // exact: fx_mul is a power of two
-  const uint32_t hi = static_cast<uint32_t>(x);     // truncates; x < 2^29
-  const float rem = x - static_cast<float>(hi);     // exact
+// A score already multiplied by DevQuery::fx_mul (a power of two) -> fixed point.
+// 64-bit: x < 2^29 is the HIGH word, the fraction becomes the low word (2^E units,
+// E = 61 - ceil(log2 U)).  32-bit: x < 2^30 truncated (2^(30-e) units).  `| 1`
+// keeps every posting's contribution non-zero: "accumulator != 0" == "matched".
+template<typename ACC>
+__device__ __forceinline__ ACC fixed_from_scaled(float x);
+template<>
+__device__ __forceinline__ unsigned long long fixed_from_scaled<unsigned long long>(float x) {
+  const uint32_t hi = static_cast<uint32_t>(x);   // truncates
+  const float rem = x - static_cast<float>(hi);   // exact
   const uint32_t lo = static_cast<uint32_t>(rem * 4294967296.f);
   return ((static_cast<unsigned long long>(hi) << 32) | lo) | 1ull;
 }
-__device__ __forceinline__ float from_fixed(unsigned long long a, float fx_inv) {
+template<>
+__device__ __forceinline__ uint32_t fixed_from_scaled<uint32_t>(float x) {
+  return static_cast<uint32_t>(x) | 1u;
+}
+template<typename ACC>
+__device__ __forceinline__ float from_fixed(ACC a, float fx_inv) {
   return static_cast<float>(a) * fx_inv;
 }
 
@@ -368,9 +381,10 @@ __device__ __forceinline__ uint32_t norm_global(const DevSegment& seg, uint32_t 
 
 // Score of one posting — the reference's float expressions, evaluated in the
 // same order with no FMA contraction (bm25.cpp:313, 353, 359; tfidf.cpp:185-187, 251-253).
+template<typename SM>
 __device__ __forceinline__ float score_posting(const DevSegment& seg, const DevQTerm& qt,
-                                               float inv_one, const TileSmem& sm,
-                                               uint32_t freq, uint32_t doc, uint32_t idx) {
+                                               float inv_one, const SM& sm, uint32_t freq,
+                                               uint32_t doc, uint32_t idx) {
   const float tf = static_cast<float>(freq);
   switch (qt.kind) {
     case kBM1:
@@ -409,40 +423,259 @@ __device__ __forceinline__ float score_posting(const DevSegment& seg, const DevQ
   }
 }
 
-// Prologue of one tile: zero the accumulators, stage the tile's norms, and —
-// all terms in parallel, one thread each — fetch every term's block range for
-// this tile so that no later phase waits on a chain of dependent global loads.
-template<int TILE, bool AND>
+// generic scorer (every kind), used off the hot path
+template<typename ACC, int TILE, bool AND>
+__device__ __forceinline__ void tile_apply(const DevSegment& seg, const TileSmemT<ACC>& sm,
+                                           const DevQTerm& qt, float inv_one, uint32_t doc,
+                                           uint32_t freq, uint32_t lo, uint32_t span,
+                                           float fx_mul) {
+  const uint32_t idx = doc - lo;  // doc < lo wraps to a huge value
+  if (idx < span) {
+    const float s = score_posting(seg, qt, inv_one, sm, freq, doc, idx);
+    atomicAdd(&sm.acc[idx], fixed_from_scaled<ACC>(s * fx_mul));
+    if (AND) atomicAdd(&sm.cnt[idx >> 2], 1u << (8u * (idx & 3u)));
+  }
+}
+
+// Scoring of N postings at once on the hot path (BM25, 1-byte norms, LDS
+// norm_cache — bm25.cpp:348-353: c0 - c0/(1 + tf*cache[norm]); the division is
+// one v_rcp_f32, <= 1 ulp, far inside the 1e-5 parity tolerance; `cs` is c0
+// pre-multiplied by fx_mul so the result is already in fixed-point units).
+// Staged so that the N norm-byte reads, then the N cache reads, then the N LDS
+// atomics are issued back to back: one LDS latency per stage instead of one per
+// posting.  wave::keep() pins each stage (the compiler would otherwise sink the
+// whole computation behind a per-posting branch).  Postings outside the tile add
+// 0 to a private dummy slot instead of branching.
+template<typename ACC, int TILE, bool AND, int N>
+__device__ __forceinline__ void tile_post_bm25(const TileSmemT<ACC>& sm, const float (&cs)[N],
+                                               const float* const (&cache)[N],
+                                               const uint32_t (&doc)[N],
+                                               const uint32_t (&freq)[N], uint32_t lo,
+                                               uint32_t span, unsigned lane) {
+  uint32_t idx[N], nb[N];
+  bool in[N];
+  float inv[N];
+  ACC fx[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    idx[k] = doc[k] - lo;  // doc < lo wraps to a huge value
+    in[k] = idx[k] < span;
+    nb[k] = sm.lnorm[in[k] ? idx[k] : 0u];
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) wave::keep(nb[k]);
+#pragma unroll
+  for (int k = 0; k < N; ++k) inv[k] = cache[k][nb[k]];
+#pragma unroll
+  for (int k = 0; k < N; ++k) wave::keep_f(inv[k]);
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const float x = static_cast<float>(freq[k]) * inv[k];
+    float scaled = cs[k] - cs[k] * wave::fast_rcp(1.f + x);
+    wave::keep_f(scaled);
+    fx[k] = fixed_from_scaled<ACC>(scaled);
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    atomicAdd(&sm.acc[in[k] ? idx[k] : (uint32_t(TILE) + lane)], in[k] ? fx[k] : ACC(0));
+    if (AND) {
+      if (in[k]) atomicAdd(&sm.cnt[idx[k] >> 2], 1u << (8u * (idx[k] & 3u)));
+    }
+  }
+}
+
+// Values 2*lane, 2*lane+1 out of the prefetched payload words, for 1 <= bits <= 31:
+// one funnel shift (v_alignbit_b32) + one bit-field extract (v_bfe_u32) each.
+template<int LAYOUT>
+__device__ __forceinline__ void extract_fast(uint64_t a, uint64_t b, uint32_t bits,
+                                             unsigned lane, uint32_t& v0, uint32_t& v1) {
+  if (LAYOUT == kSimd4) {
+    const uint32_t s = wave::mul24(lane >> 1, bits) & 31u;
+    v0 = wave::bfe(wave::funnel(uint32_t(b), uint32_t(a), s), bits);
+    v1 = wave::bfe(wave::funnel(uint32_t(b >> 32), uint32_t(a >> 32), s), bits);
+  } else {
+    const uint32_t s = wave::mul24(lane << 1, bits) & 31u;
+    const uint32_t w0 = uint32_t(a), w1 = uint32_t(a >> 32), w2 = uint32_t(b >> 32);
+    v0 = wave::bfe(wave::funnel(w1, w0, s), bits);
+    const uint32_t s1 = s + bits;  // <= 62
+    const bool hi = s1 >= 32u;
+    v1 = wave::bfe(wave::funnel(hi ? w2 : w1, hi ? w1 : w0, s1 & 31u), bits);
+  }
+}
+
+// Decode + score + accumulate the `n` (term, block) work items of `items`
+// (n <= kItemChunk): wavefront w takes items w, w+nw, ...
+template<typename ACC, int LAYOUT, int TILE, bool AND>
+__device__ __forceinline__ void process_items(const DevSegment& seg, const TileSmemT<ACC>& sm,
+                                              const ItemL* items, uint32_t n, uint32_t lo,
+                                              uint32_t span, float fx_mul) {
+  const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const uint32_t nw = blockDim.x >> 6;
+  // This wavefront's items are wv, wv+nw, ...: lane k keeps the metadata of the
+  // k-th one in registers; the loop broadcasts it with v_readlane (scalar
+  // results), so no LDS round trip sits on an item's critical path.
+  //   m_pack: doc bits | freq bits << 8 | cache slot << 16 | term slot << 20 | fast << 31
+  const uint32_t my_n = n > wv ? (n - wv + nw - 1) / nw : 0u;  // <= 64
+  uint32_t m_pack = 0, m_base = 0, m_off = 0;
+  float m_cs = 0.f;
+  if (lane < my_n) {
+    const uint32_t it = wv + lane * nw;
+    const uint32_t bt = items[it].bits_term;
+    m_base = items[it].base;
+    m_off = items[it].off;
+    const uint32_t j = bt >> 16, dbits = bt & 0xFFu, fbits = (bt >> 8) & 0xFFu;
+    const uint32_t cid = sm.qts[j].cache_id;
+    const bool fast = dbits >= 1u && dbits <= 31u && fbits >= 1u && fbits <= 31u &&
+                      sm.qts[j].kind == kBM25Tiny && cid < kMaxCaches;
+    m_pack = (bt & 0xFFFFu) | ((cid < 15u ? cid : 15u) << 16) | (j << 20) | (fast ? 0x80000000u : 0u);
+    m_cs = sm.qts[j].c0 * fx_mul;
+  }
+  // raw payload words of the k-th item (two per block part), loaded ahead of use
+  auto load_k = [&](uint32_t k, uint64_t& da, uint64_t& db, uint64_t& fa, uint64_t& fb) {
+    const uint32_t pack = wave::read_lane(m_pack, k);
+    const uint32_t dbits = pack & 0xFFu, fbits = (pack >> 8) & 0xFFu;
+    const uint8_t* blk = seg.doc + wave::read_lane(m_off, k);
+    const RawPair d = raw_load<LAYOUT>(blk + 1, dbits, lane);
+    da = d.a;
+    db = d.b;
+    // the freq block starts right after the doc block; an ALL_EQUAL doc block
+    // (vint payload) has a data-dependent size and is fetched at use instead
+    if (dbits) {
+      const RawPair f = raw_load<LAYOUT>(blk + 2u + 16u * dbits, fbits, lane);
+      fa = f.a;
+      fb = f.b;
+    }
+  };
+  // generic item: any block framing, any scorer
+  auto slow_item = [&](uint32_t k, uint64_t da, uint64_t db, uint64_t fa, uint64_t fb) {
+    const uint32_t pack = wave::read_lane(m_pack, k);
+    const uint32_t base = wave::read_lane(m_base, k);
+    const uint32_t dbits = pack & 0xFFu, fbits = (pack >> 8) & 0xFFu;
+    const uint32_t j = (pack >> 20) & 0x1Fu;
+    uint32_t x0, x1, f0, f1;
+    RawPair rd, rf;
+    rd.a = da; rd.b = db; rf.a = fa; rf.b = fb;
+    if (dbits) {
+      raw_extract<LAYOUT>(rd, dbits, lane, x0, x1);
+    } else {
+      uint32_t len;
+      x0 = x1 = vint_from(da, &len);
+      rf = raw_load<LAYOUT>(seg.doc + wave::read_lane(m_off, k) + 2u + len, fbits, lane);
+    }
+    if (fbits) {
+      raw_extract<LAYOUT>(rf, fbits, lane, f0, f1);
+    } else {
+      uint32_t len;
+      f0 = f1 = vint_from(rf.a, &len);
+    }
+    const uint32_t d1 = base + wave::inclusive_scan(x0 + x1);
+    const DevQTerm qt = sm.qts[j];
+    const float inv_one = 1.f / (qt.norm_const + qt.norm_length * 1.f);
+    tile_apply<ACC, TILE, AND>(seg, sm, qt, inv_one, d1 - x1, f0, lo, span, fx_mul);
+    tile_apply<ACC, TILE, AND>(seg, sm, qt, inv_one, d1, f1, lo, span, fx_mul);
+  };
+  // hot path, one item: straight-line code
+  auto fast_item = [&](uint32_t k, uint64_t da, uint64_t db, uint64_t fa, uint64_t fb) {
+    const uint32_t pack = wave::read_lane(m_pack, k);
+    const float cs = wave::read_lane_f(m_cs, k);
+    const float* cache = sm.caches + ((pack >> 16) & 0xFu) * 256u;
+    uint32_t x0, x1, f0, f1;
+    extract_fast<LAYOUT>(da, db, pack & 0xFFu, lane, x0, x1);
+    extract_fast<LAYOUT>(fa, fb, (pack >> 8) & 0xFFu, lane, f0, f1);
+    const uint32_t d1 = wave::read_lane(m_base, k) + wave::inclusive_scan(x0 + x1);
+    const float css[2] = {cs, cs};
+    const float* const caches2[2] = {cache, cache};
+    const uint32_t docs2[2] = {d1 - x1, d1};
+    const uint32_t freqs2[2] = {f0, f1};
+    tile_post_bm25<ACC, TILE, AND, 2>(sm, css, caches2, docs2, freqs2, lo, span, lane);
+  };
+  // hot path, two items fused: 4 postings per lane in flight, two independent
+  // DPP scan chains, all LDS lookups issued back to back
+  auto fast_pair = [&](uint32_t k, uint64_t ada, uint64_t adb, uint64_t afa, uint64_t afb,
+                       uint64_t bda, uint64_t bdb, uint64_t bfa, uint64_t bfb) {
+    const uint32_t pA = wave::read_lane(m_pack, k), pB = wave::read_lane(m_pack, k + 1);
+    const float csA = wave::read_lane_f(m_cs, k), csB = wave::read_lane_f(m_cs, k + 1);
+    const float* cacheA = sm.caches + ((pA >> 16) & 0xFu) * 256u;
+    const float* cacheB = sm.caches + ((pB >> 16) & 0xFu) * 256u;
+    uint32_t ax0, ax1, af0, af1, bx0, bx1, bf0, bf1;
+    extract_fast<LAYOUT>(ada, adb, pA & 0xFFu, lane, ax0, ax1);
+    extract_fast<LAYOUT>(bda, bdb, pB & 0xFFu, lane, bx0, bx1);
+    extract_fast<LAYOUT>(afa, afb, (pA >> 8) & 0xFFu, lane, af0, af1);
+    extract_fast<LAYOUT>(bfa, bfb, (pB >> 8) & 0xFFu, lane, bf0, bf1);
+    uint32_t sa = ax0 + ax1, sb = bx0 + bx1;
+    wave::inclusive_scan2(sa, sb);
+    const uint32_t ad1 = wave::read_lane(m_base, k) + sa;
+    const uint32_t bd1 = wave::read_lane(m_base, k + 1) + sb;
+    const float css[4] = {csA, csA, csB, csB};
+    const float* const caches4[4] = {cacheA, cacheA, cacheB, cacheB};
+    const uint32_t docs4[4] = {ad1 - ax1, ad1, bd1 - bx1, bd1};
+    const uint32_t freqs4[4] = {af0, af1, bf0, bf1};
+    tile_post_bm25<ACC, TILE, AND, 4>(sm, css, caches4, docs4, freqs4, lo, span, lane);
+  };
+
+  uint64_t ada = 0, adb = 0, afa = 0, afb = 0, bda = 0, bdb = 0, bfa = 0, bfb = 0;
+  if (0 < my_n) load_k(0, ada, adb, afa, afb);
+  if (1 < my_n) load_k(1, bda, bdb, bfa, bfb);
+  for (uint32_t k = 0; k < my_n; k += 2) {
+    uint64_t nada = 0, nadb = 0, nafa = 0, nafb = 0, nbda = 0, nbdb = 0, nbfa = 0, nbfb = 0;
+    if (k + 2 < my_n) load_k(k + 2, nada, nadb, nafa, nafb);
+    if (k + 3 < my_n) load_k(k + 3, nbda, nbdb, nbfa, nbfb);
+    const bool hasB = k + 1 < my_n;
+    const bool okA = (wave::read_lane(m_pack, k) >> 31) != 0u;
+    const bool okB = hasB && (wave::read_lane(m_pack, k + 1) >> 31) != 0u;
+    if (okA && okB) {
+      fast_pair(k, ada, adb, afa, afb, bda, bdb, bfa, bfb);
+    } else {
+      if (okA) fast_item(k, ada, adb, afa, afb); else slow_item(k, ada, adb, afa, afb);
+      if (hasB) {
+        if (okB) fast_item(k + 1, bda, bdb, bfa, bfb); else slow_item(k + 1, bda, bdb, bfa, bfb);
+      }
+    }
+    ada = nada; adb = nadb; afa = nafa; afb = nafb;
+    bda = nbda; bdb = nbdb; bfa = nbfa; bfb = nbfb;
+  }
+}
+
+__device__ __forceinline__ uint32_t score_bin(float v, float scale) {
+  const float x = fminf(v * scale, float(kBins - 1));
+  return uint32_t(x);
+}
+
+// A conservative fixed-point image of the lower edge of score bin `bs` (the
+// exact float bin test follows for the few accumulators that pass it).
+template<typename ACC>
+__device__ __forceinline__ ACC bin_threshold(uint32_t bs, const DevQuery& qd) {
+  if (!bs) return ACC(1);
+  const double edge = double(bs) / double(qd.bin_scale);
+  return static_cast<ACC>(edge / double(qd.fx_inv) * (1.0 - 1e-6));
+}
+
+// ----------------------------------------------------------------- pilot --
+
+// Zero the accumulators, stage the tile's norms, and — all terms in parallel,
+// one thread each, every load independent — fetch each term's block range.
+template<typename ACC, int TILE, bool AND>
 __device__ __forceinline__ void tile_begin(const DevSegment& seg, const DevQuery& qd,
                                            const DevQTerm* qts_g, const uint32_t* first_q,
-                                           uint32_t jt, const DevTail* tails_q,
-                                           uint32_t tile, const TileSmem& sm,
-                                           bool build_caches) {
-  const uint32_t lo = kDocMin + tile * TILE;
-  const uint32_t span = (seg.num_docs + kDocMin - lo) < uint32_t(TILE)
-                          ? (seg.num_docs + kDocMin - lo) : uint32_t(TILE);
+                                           uint32_t jt, const DevTail* tails_q, uint32_t tile,
+                                           const TileSmemT<ACC>& sm, bool build_caches) {
   if (threadIdx.x < qd.n_terms) {
     const uint32_t j = threadIdx.x;
-    // every load below is independent of the others: one memory round trip
     if (build_caches) sm.qts[j] = qts_g[j];
     const DevTail* tl = tails_q + j;
     const uint32_t nblk = tl->nblk, tn = tl->n;
-    const uint32_t tfirst = tl->first_doc, tlast = tl->last_doc;
     const uint64_t doc_start = tl->doc_start, dir_off = tl->dir_off;
     const uint32_t b0 = first_q[uint64_t(tile) * jt + j];
     uint32_t b1 = first_q[uint64_t(tile + 1) * jt + j] + 1u;
     b1 = b1 < nblk ? b1 : nblk;
-    const uint32_t tb0 = b0;
-    const uint32_t tnb = b1 > b0 ? b1 - b0 : 0u;
-    const uint32_t ttail = (tn && tfirst < lo + span && tlast >= lo) ? tn : 0u;
     sm.tl[j].doc_start = doc_start;
     sm.tl[j].dir_off = dir_off;
-    sm.tl[j].b0 = tb0;
-    sm.tl[j].nb = tnb;
+    sm.tl[j].b0 = b0;
+    sm.tl[j].nb = b1 > b0 ? b1 - b0 : 0u;
     sm.tl[j].item_off = 0;
-    sm.tl[j].tail_n = ttail;
+    sm.tl[j].tail_n = tn;
   }
-  for (uint32_t i = threadIdx.x; i < TILE; i += blockDim.x) sm.acc[i] = 0ull;
+  for (uint32_t i = threadIdx.x; i < uint32_t(TILE) + 64u; i += blockDim.x) sm.acc[i] = ACC(0);
   if (AND) {
     for (uint32_t i = threadIdx.x; i < TILE / 4; i += blockDim.x) sm.cnt[i] = 0u;
   }
@@ -482,247 +715,16 @@ __device__ __forceinline__ void tile_begin(const DevSegment& seg, const DevQuery
   __syncthreads();
 }
 
-// generic scorer (every kind), used off the hot path
-template<int TILE, bool AND>
-__device__ __forceinline__ void tile_apply(const DevSegment& seg, const TileSmem& sm,
-                                           const DevQTerm& qt, float inv_one, uint32_t doc,
-                                           uint32_t freq, uint32_t lo, uint32_t span,
-                                           float fx_mul) {
-  const uint32_t idx = doc - lo;  // doc < lo wraps to a huge value
-  if (idx < span) {
-    const float s = score_posting(seg, qt, inv_one, sm, freq, doc, idx);
-    atomicAdd(&sm.acc[idx], to_fixed(s, fx_mul));
-    if (AND) atomicAdd(&sm.cnt[idx >> 2], 1u << (8u * (idx & 3u)));
-  }
-}
-
-// Scoring of N postings at once on the hot path (BM25, 1-byte norms, LDS
-// norm_cache — bm25.cpp:348-353: c0 - c0/(1 + tf*cache[norm]); the division is
-// one v_rcp_f32, <= 1 ulp, far inside the 1e-5 parity tolerance).  Staged so
-// that the N norm-byte reads, then the N cache reads, then the N LDS atomics
-// are issued back to back: one LDS latency per stage instead of one per
-// posting.  wave::keep() pins each stage (the compiler would otherwise sink
-// the whole computation behind a per-posting branch).  Postings outside the
-// tile add 0 to a private dummy slot instead of branching.
-template<int TILE, bool AND, int N>
-__device__ __forceinline__ void tile_post_bm25(const TileSmem& sm, const float (&c0)[N],
-                                               const float* const (&cache)[N],
-                                               const uint32_t (&doc)[N],
-                                               const uint32_t (&freq)[N], uint32_t lo,
-                                               uint32_t span, float fx_mul, unsigned lane) {
-  uint32_t idx[N], nb[N];
-  bool in[N];
-  float inv[N];
-  unsigned long long fx[N];
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    idx[k] = doc[k] - lo;  // doc < lo wraps to a huge value
-    in[k] = idx[k] < span;
-    nb[k] = sm.lnorm[in[k] ? idx[k] : 0u];
-  }
-#pragma unroll
-  for (int k = 0; k < N; ++k) wave::keep(nb[k]);
-#pragma unroll
-  for (int k = 0; k < N; ++k) inv[k] = cache[k][nb[k]];
-#pragma unroll
-  for (int k = 0; k < N; ++k) wave::keep_f(inv[k]);
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    const float x = static_cast<float>(freq[k]) * inv[k];
-    const float s = c0[k] - c0[k] * wave::fast_rcp(1.f + x);
-    fx[k] = to_fixed(s, fx_mul);
-    uint32_t lo32 = uint32_t(fx[k]), hi32 = uint32_t(fx[k] >> 32);
-    wave::keep(lo32);
-    wave::keep(hi32);
-    fx[k] = (static_cast<unsigned long long>(hi32) << 32) | lo32;
-  }
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    atomicAdd(&sm.acc[in[k] ? idx[k] : (uint32_t(TILE) + lane)], in[k] ? fx[k] : 0ull);
-    if (AND) {
-      if (in[k]) atomicAdd(&sm.cnt[idx[k] >> 2], 1u << (8u * (idx[k] & 3u)));
-    }
-  }
-}
-
-// Decode + score + accumulate the `n` (term, block) work items of `items`
-// (n <= kItemChunk): wavefront w takes items w, w+nw, ...
-template<int LAYOUT, int TILE, bool AND>
-__device__ __forceinline__ void process_items(const DevSegment& seg, const TileSmem& sm,
-                                              const ItemL* items, uint32_t n, uint32_t lo,
-                                              uint32_t span, float fx_mul) {
-  const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-  const uint32_t nw = blockDim.x >> 6;
-  // This wavefront's items are wv, wv+nw, ...: lane k keeps the metadata of the
-  // k-th one in registers; the loop broadcasts it with v_readlane (scalar
-  // results), so no LDS round trip sits on an item's critical path.
-  const uint32_t my_n = n > wv ? (n - wv + nw - 1) / nw : 0u;  // <= 64
-  uint32_t m_bt = 0, m_base = 0, m_rel = 0, m_dslo = 0, m_dshi = 0, m_kc = 0xFFu;
-  float m_c0 = 0.f;
-  if (lane < my_n) {
-    const uint32_t it = wv + lane * nw;
-    m_bt = items[it].bits_term;
-    m_base = items[it].base;
-    m_rel = items[it].rel_off;
-    const uint32_t j = m_bt >> 16;
-    const uint64_t ds = sm.tl[j].doc_start;
-    m_dslo = uint32_t(ds);
-    m_dshi = uint32_t(ds >> 32);
-    const uint32_t cid = sm.qts[j].cache_id;
-    m_kc = uint32_t(sm.qts[j].kind) | ((cid < 255u ? cid : 255u) << 8);
-    m_c0 = sm.qts[j].c0;
-  }
-  auto item_blk = [&](uint32_t k) -> const uint8_t* {
-    const uint64_t start = (uint64_t(wave::read_lane(m_dshi, k)) << 32) |
-                           wave::read_lane(m_dslo, k);
-    return seg.doc + start + wave::read_lane(m_rel, k);
-  };
-  // raw payload words of the k-th item (two per block part), loaded ahead of use
-  auto load_k = [&](uint32_t k, uint64_t& da, uint64_t& db, uint64_t& fa, uint64_t& fb) {
-    const uint32_t bt = wave::read_lane(m_bt, k);
-    const uint32_t dbits = bt & 0xFFu, fbits = (bt >> 8) & 0xFFu;
-    const uint8_t* blk = item_blk(k);
-    const RawPair d = raw_load<LAYOUT>(blk + 1, dbits, lane);
-    da = d.a;
-    db = d.b;
-    // the freq block starts right after the doc block; an ALL_EQUAL doc block
-    // (vint payload) has a data-dependent size and is fetched at use instead
-    if (dbits) {
-      const RawPair f = raw_load<LAYOUT>(blk + 2u + 16u * dbits, fbits, lane);
-      fa = f.a;
-      fb = f.b;
-    }
-  };
-  auto is_fast = [&](uint32_t bt, uint32_t kc) {
-    return (bt & 0xFFu) != 0u && ((bt >> 8) & 0xFFu) != 0u &&
-           (kc & 0xFFu) == uint32_t(kBM25Tiny) && (kc >> 8) < kMaxCaches;
-  };
-  // generic item: any block framing, any scorer
-  auto slow_item = [&](uint32_t k, uint64_t da, uint64_t db, uint64_t fa, uint64_t fb) {
-    const uint32_t bt = wave::read_lane(m_bt, k);
-    const uint32_t base = wave::read_lane(m_base, k);
-    const uint32_t dbits = bt & 0xFFu, fbits = (bt >> 8) & 0xFFu;
-    const uint32_t j = bt >> 16;
-    uint32_t x0, x1, f0, f1;
-    RawPair rd, rf;
-    rd.a = da; rd.b = db; rf.a = fa; rf.b = fb;
-    if (dbits) {
-      raw_extract<LAYOUT>(rd, dbits, lane, x0, x1);
-    } else {
-      uint32_t len;
-      x0 = x1 = vint_from(da, &len);
-      rf = raw_load<LAYOUT>(item_blk(k) + 2u + len, fbits, lane);
-    }
-    if (fbits) {
-      raw_extract<LAYOUT>(rf, fbits, lane, f0, f1);
-    } else {
-      uint32_t len;
-      f0 = f1 = vint_from(rf.a, &len);
-    }
-    const uint32_t d1 = base + wave::inclusive_scan(x0 + x1);
-    const DevQTerm qt = sm.qts[j];
-    const float inv_one = 1.f / (qt.norm_const + qt.norm_length * 1.f);
-    tile_apply<TILE, AND>(seg, sm, qt, inv_one, d1 - x1, f0, lo, span, fx_mul);
-    tile_apply<TILE, AND>(seg, sm, qt, inv_one, d1, f1, lo, span, fx_mul);
-  };
-  // hot path, one item: straight-line code
-  auto fast_item = [&](uint32_t k, uint64_t da, uint64_t db, uint64_t fa, uint64_t fb) {
-    const uint32_t bt = wave::read_lane(m_bt, k);
-    const uint32_t kc = wave::read_lane(m_kc, k);
-    const float c0 = wave::read_lane_f(m_c0, k);
-    const float* cache = sm.caches + (kc >> 8) * 256u;
-    uint32_t x0, x1, f0, f1;
-    RawPair rd, rf;
-    rd.a = da; rd.b = db; rf.a = fa; rf.b = fb;
-    raw_extract<LAYOUT>(rd, bt & 0xFFu, lane, x0, x1);
-    raw_extract<LAYOUT>(rf, (bt >> 8) & 0xFFu, lane, f0, f1);
-    const uint32_t d1 = wave::read_lane(m_base, k) + wave::inclusive_scan(x0 + x1);
-    const float c0s[2] = {c0, c0};
-    const float* const caches2[2] = {cache, cache};
-    const uint32_t docs2[2] = {d1 - x1, d1};
-    const uint32_t freqs2[2] = {f0, f1};
-    tile_post_bm25<TILE, AND, 2>(sm, c0s, caches2, docs2, freqs2, lo, span, fx_mul, lane);
-  };
-  // hot path, two items fused: 4 postings per lane in flight, two independent
-  // DPP scan chains, all LDS lookups issued back to back
-  auto fast_pair = [&](uint32_t k, uint64_t ada, uint64_t adb, uint64_t afa, uint64_t afb,
-                       uint64_t bda, uint64_t bdb, uint64_t bfa, uint64_t bfb) {
-    const uint32_t btA = wave::read_lane(m_bt, k), btB = wave::read_lane(m_bt, k + 1);
-    const uint32_t kcA = wave::read_lane(m_kc, k), kcB = wave::read_lane(m_kc, k + 1);
-    const float c0A = wave::read_lane_f(m_c0, k), c0B = wave::read_lane_f(m_c0, k + 1);
-    const float* cacheA = sm.caches + (kcA >> 8) * 256u;
-    const float* cacheB = sm.caches + (kcB >> 8) * 256u;
-    uint32_t ax0, ax1, af0, af1, bx0, bx1, bf0, bf1;
-    RawPair r;
-    r.a = ada; r.b = adb;
-    raw_extract<LAYOUT>(r, btA & 0xFFu, lane, ax0, ax1);
-    r.a = bda; r.b = bdb;
-    raw_extract<LAYOUT>(r, btB & 0xFFu, lane, bx0, bx1);
-    r.a = afa; r.b = afb;
-    raw_extract<LAYOUT>(r, (btA >> 8) & 0xFFu, lane, af0, af1);
-    r.a = bfa; r.b = bfb;
-    raw_extract<LAYOUT>(r, (btB >> 8) & 0xFFu, lane, bf0, bf1);
-    uint32_t sa = ax0 + ax1, sb = bx0 + bx1;
-    wave::inclusive_scan2(sa, sb);
-    const uint32_t ad1 = wave::read_lane(m_base, k) + sa;
-    const uint32_t bd1 = wave::read_lane(m_base, k + 1) + sb;
-    const float c0s[4] = {c0A, c0A, c0B, c0B};
-    const float* const caches4[4] = {cacheA, cacheA, cacheB, cacheB};
-    const uint32_t docs4[4] = {ad1 - ax1, ad1, bd1 - bx1, bd1};
-    const uint32_t freqs4[4] = {af0, af1, bf0, bf1};
-    tile_post_bm25<TILE, AND, 4>(sm, c0s, caches4, docs4, freqs4, lo, span, fx_mul, lane);
-  };
-
-  uint64_t ada = 0, adb = 0, afa = 0, afb = 0, bda = 0, bdb = 0, bfa = 0, bfb = 0;
-  if (0 < my_n) load_k(0, ada, adb, afa, afb);
-  if (1 < my_n) load_k(1, bda, bdb, bfa, bfb);
-  for (uint32_t k = 0; k < my_n; k += 2) {
-    uint64_t nada = 0, nadb = 0, nafa = 0, nafb = 0, nbda = 0, nbdb = 0, nbfa = 0, nbfb = 0;
-    if (k + 2 < my_n) load_k(k + 2, nada, nadb, nafa, nafb);
-    if (k + 3 < my_n) load_k(k + 3, nbda, nbdb, nbfa, nbfb);
-    const bool hasB = k + 1 < my_n;
-    const bool okA = is_fast(wave::read_lane(m_bt, k), wave::read_lane(m_kc, k));
-    const bool okB = hasB && is_fast(wave::read_lane(m_bt, k + 1), wave::read_lane(m_kc, k + 1));
-    if (okA && okB) {
-      fast_pair(k, ada, adb, afa, afb, bda, bdb, bfa, bfb);
-    } else {
-      if (okA) fast_item(k, ada, adb, afa, afb); else slow_item(k, ada, adb, afa, afb);
-      if (hasB) {
-        if (okB) fast_item(k + 1, bda, bdb, bfa, bfb); else slow_item(k + 1, bda, bdb, bfa, bfb);
-      }
-    }
-    ada = nada; adb = nadb; afa = nafa; afb = nafb;
-    bda = nbda; bdb = nbdb; bfa = nbfa; bfb = nbfb;
-  }
-}
-
-// decoded vint tails / single-doc terms (k_plan), one term per wavefront
-template<int TILE, bool AND>
-__device__ __forceinline__ void apply_tails(const DevSegment& seg, const DevQuery& qd,
-                                            const DevTail* tails_q, const TileSmem& sm,
-                                            uint32_t lo, uint32_t span, float fx_mul) {
-  const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-  const uint32_t nw = blockDim.x >> 6;
-  for (uint32_t j = wv; j < qd.n_terms; j += nw) {
-    const uint32_t tn = sm.tl[j].tail_n;
-    const DevTail* tl = tails_q + j;
-    if (tn && tl->first_doc < lo + span && tl->last_doc >= lo) {
-      const DevQTerm qt = sm.qts[j];
-      const float inv_one = 1.f / (qt.norm_const + qt.norm_length * 1.f);
-      for (uint32_t i = lane; i < tn; i += 64)
-        tile_apply<TILE, AND>(seg, sm, qt, inv_one, tl->docs[i], tl->freqs[i], lo, span, fx_mul);
-    }
-  }
-}
-
 // All postings of the query's terms that fall into doc tile `tile`: the GPU
 // form of block_disjunction::refill (disjunction.hpp:1240-1351), with the
 // 512-doc window widened to TILE docs in LDS, and of Conjunction via per-doc
 // match counters.  (Used by k_pilot; k_score pipelines the same pieces.)
-template<int LAYOUT, int TILE, bool AND>
+template<typename ACC, int LAYOUT, int TILE, bool AND>
 __device__ __forceinline__ void tile_accumulate(const DevSegment& seg, const DevQuery& qd,
                                                 const DevTail* tails_q, uint32_t tile,
-                                                const TileSmem& sm) {
+                                                const TileSmemT<ACC>& sm) {
+  const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const uint32_t nw = blockDim.x >> 6;
   const uint32_t lo = kDocMin + tile * TILE;
   const uint32_t span = (seg.num_docs + kDocMin - lo) < uint32_t(TILE)
                           ? (seg.num_docs + kDocMin - lo) : uint32_t(TILE);
@@ -738,48 +740,41 @@ __device__ __forceinline__ void tile_accumulate(const DevSegment& seg, const Dev
       const uint32_t b = sm.tl[j].b0 + (id - sm.tl[j].item_off);
       const uint64_t e = sm.tl[j].dir_off + b;
       ItemL I;
-      I.rel_off = seg.blk_off[e];
+      I.off = uint32_t(sm.tl[j].doc_start) + seg.blk_off[e];
       I.base = b ? seg.blk_last[e - 1] : kDocMin;
       I.bits_term = uint32_t(seg.blk_bits[e]) | (j << 16);
       sm.items[threadIdx.x] = I;
     }
     __syncthreads();
-    process_items<LAYOUT, TILE, AND>(seg, sm, sm.items, n, lo, span, fx_mul);
+    process_items<ACC, LAYOUT, TILE, AND>(seg, sm, sm.items, n, lo, span, fx_mul);
   }
-  apply_tails<TILE, AND>(seg, qd, tails_q, sm, lo, span, fx_mul);
+  // decoded vint tails / single-doc terms (k_plan), one term per wavefront
+  for (uint32_t j = wv; j < qd.n_terms; j += nw) {
+    const uint32_t tn = sm.tl[j].tail_n;
+    const DevTail* tl = tails_q + j;
+    if (tn && tl->first_doc < lo + span && tl->last_doc >= lo) {
+      const DevQTerm qt = sm.qts[j];
+      const float inv_one = 1.f / (qt.norm_const + qt.norm_length * 1.f);
+      for (uint32_t i = lane; i < tn; i += 64)
+        tile_apply<ACC, TILE, AND>(seg, sm, qt, inv_one, tl->docs[i], tl->freqs[i], lo, span,
+                                   fx_mul);
+    }
+  }
   __syncthreads();
 }
-
-__device__ __forceinline__ uint32_t score_bin(float v, float scale) {
-  const float x = fminf(v * scale, float(kBins - 1));
-  return uint32_t(x);
-}
-
-// Did doc slot i match the query?  OR: any posting landed (every posting adds a
-// non-zero amount); AND: every term's posting landed (Conjunction::converge,
-// conjunction.hpp:207-223).
-template<bool AND>
-__device__ __forceinline__ bool doc_matched(const DevQuery& qd, const TileSmem& sm, uint32_t i,
-                                            unsigned long long a) {
-  if (AND && qd.op == 1)
-    return qd.n_terms && ((sm.cnt[i >> 2] >> (8u * (i & 3u))) & 0xFFu) == qd.n_terms;
-  return a != 0ull;
-}
-
-// ----------------------------------------------------------------- pilot --
 
 // One workgroup per query scores the tiles {phase, phase+P, ...}, histograms
 // their scores into kBins linear bins over [0, U] and picks the largest bin b*
 // with at least k docs at or above it.  Those docs exist, so the final k-th
 // score is >= the lower edge of b*: k_score may drop everything below b*.
-template<int LAYOUT, int TILE, bool AND>
+template<typename ACC, int LAYOUT, int TILE, bool AND>
 __global__ void __launch_bounds__(kTileThreadsMax)
 k_pilot(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_t jt,
         uint32_t n_tiles, uint32_t stride, const uint32_t* first, const DevTail* tails,
         uint32_t* bstar) {
   RT_DYN_SMEM(smem);
   unsigned char* rest;
-  const TileSmem sm = carve<TILE, AND>(smem, &rest);
+  const TileSmemT<ACC> sm = carve<ACC, TILE, AND>(smem, &rest);
   uint32_t* hist = reinterpret_cast<uint32_t*>(rest);  // [kBins]
   const uint32_t q = blockIdx.x;
   const DevQuery qd = queries[q];
@@ -789,13 +784,15 @@ k_pilot(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
   for (uint32_t i = threadIdx.x; i < kBins; i += blockDim.x) hist[i] = 0u;
   bool first_tile = true;
   for (uint32_t tile = (q * 7u) % stride; tile < n_tiles; tile += stride) {
-    tile_begin<TILE, AND>(seg, qd, qts, first_q, jt, tails_q, tile, sm, first_tile);
+    tile_begin<ACC, TILE, AND>(seg, qd, qts, first_q, jt, tails_q, tile, sm, first_tile);
     first_tile = false;
-    tile_accumulate<LAYOUT, TILE, AND>(seg, qd, tails_q, tile, sm);
+    tile_accumulate<ACC, LAYOUT, TILE, AND>(seg, qd, tails_q, tile, sm);
     for (uint32_t i = threadIdx.x; i < TILE; i += blockDim.x) {
-      const unsigned long long a = sm.acc[i];
-      if (doc_matched<AND>(qd, sm, i, a))
-        atomicAdd(&hist[score_bin(from_fixed(a, qd.fx_inv), qd.bin_scale)], 1u);
+      const ACC a = sm.acc[i];
+      bool m = a != ACC(0);
+      if (AND && qd.op == 1)
+        m = qd.n_terms && ((sm.cnt[i >> 2] >> (8u * (i & 3u))) & 0xFFu) == qd.n_terms;
+      if (m) atomicAdd(&hist[score_bin(from_fixed<ACC>(a, qd.fx_inv), qd.bin_scale)], 1u);
     }
     __syncthreads();
   }
@@ -830,9 +827,7 @@ k_pilot(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
 // while the wavefronts decode/score tile u out of LDS tables, the directory
 // entries and norm bytes of tile u+1 are already in flight into registers, the
 // returning atomic that reserves candidate slots for tile u-1 is in flight,
-// and so is the dequeue of the next chunk.  No global-memory latency sits on
-// the critical path of a tile except the payload loads, which run two work
-// items ahead inside process_items.
+// and so is the dequeue of the next chunk.
 
 constexpr uint32_t kChunkTiles = 16;
 constexpr uint32_t kScoreCands = 128;   // per-tile candidate staging slots (x2 buffers)
@@ -846,17 +841,18 @@ enum : uint32_t {  // indices into the workgroup's LDS scratch words
   kVWords = 8,
 };
 
-template<int TILE, bool AND>
+template<typename ACC, int TILE, bool AND>
 constexpr uint32_t score_smem_bytes() {
-  return tile_smem_bytes<TILE, AND>()                      // acc, cnt, lnorm, caches, qts, tl, items[0]
+  return tile_smem_bytes<ACC, TILE, AND>()                 // acc, cnt, lnorm, caches, qts, tl, items[0]
          + sizeof(ItemL) * kItemChunk                      // items[1]
          + 4u * (kChunkTiles + 1) * kMaxTerms              // rows
+         + 4u * kChunkTiles * (kMaxTerms + 1)              // per-tile item prefix sums
          + 4u * 3u * kMaxTerms                             // nblk, tail first, tail last
          + 8u * 2u * kScoreCands                           // candidate staging x2
          + 4u * kVWords;
 }
 
-template<int LAYOUT, int TILE, bool AND>
+template<typename ACC, int LAYOUT, int TILE, bool AND>
 __global__ void __launch_bounds__(kTileThreadsMax)
 k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_t jt,
         uint32_t n_tiles, uint32_t n_queries, const uint32_t* first, const DevTail* tails,
@@ -864,11 +860,13 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
         unsigned long long* hits, uint32_t* work_counter) {
   RT_DYN_SMEM(smem);
   unsigned char* rest;
-  const TileSmem sm = carve<TILE, AND>(smem, &rest);
+  const TileSmemT<ACC> sm = carve<ACC, TILE, AND>(smem, &rest);
   ItemL* items1 = reinterpret_cast<ItemL*>(rest);
   rest += sizeof(ItemL) * kItemChunk;
   uint32_t* rows = reinterpret_cast<uint32_t*>(rest);      // [kChunkTiles + 1][kMaxTerms]
   rest += 4u * (kChunkTiles + 1) * kMaxTerms;
+  uint32_t* toff = reinterpret_cast<uint32_t*>(rest);      // [kChunkTiles][kMaxTerms + 1]
+  rest += 4u * kChunkTiles * (kMaxTerms + 1);
   uint32_t* tnblk = reinterpret_cast<uint32_t*>(rest);
   uint32_t* tfirst = tnblk + kMaxTerms;
   uint32_t* tlast = tfirst + kMaxTerms;
@@ -884,7 +882,7 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
   const uint32_t cpq = (n_tiles + kChunkTiles - 1) / kChunkTiles;  // chunks per query
   const uint32_t total_chunks = n_queries * cpq;
 
-  for (uint32_t i = tid; i < uint32_t(TILE) + 64u; i += blockDim.x) sm.acc[i] = 0ull;
+  for (uint32_t i = tid; i < uint32_t(TILE) + 64u; i += blockDim.x) sm.acc[i] = ACC(0);
   if (AND) {
     for (uint32_t i = tid; i < uint32_t(TILE) / 4; i += blockDim.x) sm.cnt[i] = 0u;
   }
@@ -935,42 +933,37 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
       }
       sm.caches[e] = n ? 1.f / (nc + nl * static_cast<float>(n)) : 0.f;
     }
-    // conservative fixed-point image of the lower edge of bin `bs` (exact bin test follows)
-    unsigned long long thr = 1ull;
-    if (bs) {
-      const double edge = double(bs) / double(qd.bin_scale);
-      thr = static_cast<unsigned long long>(edge / double(qd.fx_inv) * (1.0 - 1e-6));
-    }
-
-    // The (term, block) item this thread owns in local tile c (first kItemChunk
-    // items), found by walking the per-term block counts in LDS; issues the
-    // directory loads and returns the tile's total item count.
-    auto fetch_item = [&](uint32_t c, uint32_t skip, uint32_t& r_off, uint32_t& r_base,
-                          uint32_t& r_bt) -> uint32_t {
-      uint32_t off = 0, my_j = kNoTerm, my_b = 0;
-      const uint32_t id = skip + tid;
+    // per-tile exclusive prefix sums of each term's block count: toff[c][j], total at [c][n_terms]
+    if (tid < ntile) {
+      uint32_t off = 0;
       for (uint32_t j = 0; j < qd.n_terms; ++j) {
-        const uint32_t b0 = rows[c * kMaxTerms + j];
-        uint32_t b1 = rows[(c + 1) * kMaxTerms + j] + 1u;
+        toff[tid * (kMaxTerms + 1) + j] = off;
+        const uint32_t b0 = rows[tid * kMaxTerms + j];
+        uint32_t b1 = rows[(tid + 1) * kMaxTerms + j] + 1u;
         b1 = b1 < tnblk[j] ? b1 : tnblk[j];
-        const uint32_t nb = b1 > b0 ? b1 - b0 : 0u;
-        if (id >= off && id < off + nb) {
-          my_j = j;
-          my_b = b0 + (id - off);
-        }
-        off += nb;
+        off += b1 > b0 ? b1 - b0 : 0u;
       }
-      if (my_j != kNoTerm && tid < kItemChunk) {
-        const uint64_t e = sm.tl[my_j].dir_off + my_b;
-        r_off = seg.blk_off[e];
-        r_base = my_b ? seg.blk_last[e - 1] : kDocMin;
-        r_bt = uint32_t(seg.blk_bits[e]) | (my_j << 16);
+      toff[tid * (kMaxTerms + 1) + qd.n_terms] = off;
+    }
+    const ACC thr = bin_threshold<ACC>(bs, qd);
+    __syncthreads();
+
+    // Directory entry of item `skip + tid` of local tile c (issues the loads).
+    auto fetch_item = [&](uint32_t c, uint32_t skip, uint32_t& r_off, uint32_t& r_base,
+                          uint32_t& r_bt) {
+      const uint32_t* to = toff + c * (kMaxTerms + 1);
+      const uint32_t id = skip + tid;
+      if (tid < kItemChunk && id < to[qd.n_terms]) {
+        uint32_t j = 0;
+        while (id >= to[j + 1]) ++j;
+        const uint32_t b = rows[c * kMaxTerms + j] + (id - to[j]);
+        const uint64_t e = sm.tl[j].dir_off + b;
+        r_off = uint32_t(sm.tl[j].doc_start) + seg.blk_off[e];
+        r_base = b ? seg.blk_last[e - 1] : kDocMin;
+        r_bt = uint32_t(seg.blk_bits[e]) | (j << 16);
       }
-      return off;
     };
     auto norm_words = [&](uint32_t tile, uint32_t& w0, uint32_t& w1) {
-      // TILE bytes / blockDim threads: up to 2 dwords per thread at 512+ threads;
-      // generic loop below covers smaller workgroups
       w0 = w1 = 0;
       if (seg.norms && seg.norm_width == 1) {
         const uint64_t base = uint64_t(tile) * TILE + (kDocMin - seg.norm_min_doc);
@@ -983,7 +976,7 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
       const uint32_t i0 = tid * 4u, i1 = (tid + blockDim.x) * 4u;
       if (i0 < uint32_t(TILE)) *reinterpret_cast<uint32_t*>(sm.lnorm + i0) = w0;
       if (i1 < uint32_t(TILE)) *reinterpret_cast<uint32_t*>(sm.lnorm + i1) = w1;
-      // workgroups smaller than TILE/8 threads: remaining words loaded in place
+      // workgroups with fewer than TILE/8 threads: remaining words loaded in place
       if (seg.norms && seg.norm_width == 1) {
         const uint64_t base = uint64_t(tile) * TILE + (kDocMin - seg.norm_min_doc);
         for (uint32_t i = (tid + 2u * blockDim.x) * 4u; i < uint32_t(TILE); i += blockDim.x * 4u) {
@@ -993,16 +986,20 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
         }
       }
     };
+    auto store_item = [&](ItemL* dst, uint32_t n, uint32_t r_off, uint32_t r_base, uint32_t r_bt) {
+      if (tid < kItemChunk && tid < n) {
+        dst[tid].off = r_off;
+        dst[tid].base = r_base;
+        dst[tid].bits_term = r_bt;
+      }
+    };
 
     // ---- prime the pipeline with local tile 0 -------------------------------
     uint32_t r_off = 0, r_base = 0, r_bt = 0, nw0 = 0, nw1 = 0;
-    uint32_t n_cur = fetch_item(0, 0, r_off, r_base, r_bt);
+    uint32_t n_cur = toff[qd.n_terms];
+    fetch_item(0, 0, r_off, r_base, r_bt);
     norm_words(tile0, nw0, nw1);
-    if (tid < n_cur && tid < kItemChunk) {
-      ItemL I;
-      I.rel_off = r_off; I.base = r_base; I.bits_term = r_bt;
-      item_buf[0][tid] = I;
-    }
+    store_item(item_buf[0], n_cur, r_off, r_base, r_bt);
     store_norm_words(tile0, nw0, nw1);
     __syncthreads();
 
@@ -1014,27 +1011,25 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
                               ? (seg.num_docs + kDocMin - lo) : uint32_t(TILE);
       ItemL* items = item_buf[u & 1u];
       // stage 1 of tile u+1: directory + norm loads go out now, land after compute
-      uint32_t n_next = 0;
       const bool has_next = u + 1 < ntile;
+      uint32_t n_next = 0;
       if (has_next) {
-        n_next = fetch_item(u + 1, 0, r_off, r_base, r_bt);
+        n_next = toff[(u + 1) * (kMaxTerms + 1) + qd.n_terms];
+        fetch_item(u + 1, 0, r_off, r_base, r_bt);
         norm_words(tile + 1, nw0, nw1);
       }
       // stage 2 of tile u: decode + score + accumulate
-      process_items<LAYOUT, TILE, AND>(seg, sm, items, n_cur < kItemChunk ? n_cur : kItemChunk,
-                                       lo, span, fx_mul);
+      process_items<ACC, LAYOUT, TILE, AND>(seg, sm, items,
+                                            n_cur < kItemChunk ? n_cur : kItemChunk, lo, span,
+                                            fx_mul);
       for (uint32_t done = kItemChunk; done < n_cur; done += kItemChunk) {  // rare: > 256 items
         __syncthreads();
         uint32_t xo = 0, xb = 0, xt = 0;
         fetch_item(u, done, xo, xb, xt);
-        if (tid < kItemChunk && done + tid < n_cur) {
-          ItemL I;
-          I.rel_off = xo; I.base = xb; I.bits_term = xt;
-          items[tid] = I;
-        }
+        store_item(items, n_cur - done, xo, xb, xt);
         __syncthreads();
         const uint32_t n = (n_cur - done) < kItemChunk ? (n_cur - done) : kItemChunk;
-        process_items<LAYOUT, TILE, AND>(seg, sm, items, n, lo, span, fx_mul);
+        process_items<ACC, LAYOUT, TILE, AND>(seg, sm, items, n, lo, span, fx_mul);
       }
       for (uint32_t j = wv; j < qd.n_terms; j += nw) {  // decoded vint tails / single docs
         const uint32_t tn = sm.tl[j].tail_n;
@@ -1043,7 +1038,8 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
           const float inv_one = 1.f / (qt.norm_const + qt.norm_length * 1.f);
           const DevTail* tl = tails_q + j;
           for (uint32_t i = lane; i < tn; i += 64)
-            tile_apply<TILE, AND>(seg, sm, qt, inv_one, tl->docs[i], tl->freqs[i], lo, span, fx_mul);
+            tile_apply<ACC, TILE, AND>(seg, sm, qt, inv_one, tl->docs[i], tl->freqs[i], lo, span,
+                                       fx_mul);
         }
       }
       __syncthreads();  // B1: every accumulation of tile u has landed
@@ -1052,28 +1048,40 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
       uint64_t* lc = lcand + (u & 1u) * kScoreCands;
       uint32_t* ncand = vars + kVNc0 + (u % 3u);
       uint32_t my_hits = 0;
-      for (uint32_t i = tid; i < uint32_t(TILE); i += blockDim.x) {
-        const unsigned long long a = sm.acc[i];
-        bool m = a != 0ull;
-        if (a) sm.acc[i] = 0ull;
-        if (AND) {
-          const uint32_t cw = sm.cnt[i >> 2];
-          if (qd.op == 1) m = qd.n_terms && ((cw >> (8u * (i & 3u))) & 0xFFu) == qd.n_terms;
+      auto candidate = [&](uint32_t i, ACC a) {
+        const float v = from_fixed<ACC>(a, qd.fx_inv);
+        if (score_bin(v, qd.bin_scale) >= bs) {
+          const uint64_t key = make_key(v, lo + i);
+          const uint32_t slot = atomicAdd(ncand, 1u);
+          if (slot < kScoreCands) {
+            lc[slot] = key;
+          } else {  // rare: more candidates in one tile than staging slots
+            const uint32_t g = atomicAdd(&cand_count[q], 1u);
+            if (g < cand_cap) cands[uint64_t(q) * cand_cap + g] = key;
+          }
         }
-        if (m) {
-          ++my_hits;
-          if (a >= thr) {
-            const float v = from_fixed(a, qd.fx_inv);
-            if (score_bin(v, qd.bin_scale) >= bs) {
-              const uint64_t key = make_key(v, lo + i);
-              const uint32_t slot = atomicAdd(ncand, 1u);
-              if (slot < kScoreCands) {
-                lc[slot] = key;
-              } else {  // rare: more candidates in one tile than staging slots
-                const uint32_t g = atomicAdd(&cand_count[q], 1u);
-                if (g < cand_cap) cands[uint64_t(q) * cand_cap + g] = key;
-              }
-            }
+      };
+      if (AND && qd.op == 1) {
+        for (uint32_t i = tid; i < uint32_t(TILE); i += blockDim.x) {
+          const ACC a = sm.acc[i];
+          if (a != ACC(0)) sm.acc[i] = ACC(0);
+          const bool m = qd.n_terms &&
+                         ((sm.cnt[i >> 2] >> (8u * (i & 3u))) & 0xFFu) == qd.n_terms;
+          if (m) {
+            ++my_hits;
+            if (a >= thr) candidate(i, a);
+          }
+        }
+      } else {
+        // two accumulators per lane per step: one wide LDS read, one wide clear
+        for (uint32_t i = tid * 2u; i < uint32_t(TILE); i += blockDim.x * 2u) {
+          const ACC a0 = sm.acc[i], a1 = sm.acc[i + 1];
+          sm.acc[i] = ACC(0);
+          sm.acc[i + 1] = ACC(0);
+          my_hits += (a0 != ACC(0)) + (a1 != ACC(0));
+          if (a0 >= thr || a1 >= thr) {
+            if (a0 >= thr) candidate(i, a0);
+            if (a1 >= thr) candidate(i + 1, a1);
           }
         }
       }
@@ -1085,11 +1093,7 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
       if (lane == 0 && my_hits) atomicAdd(&vars[kVHits], my_hits);
       // stage 1 of tile u+1 lands in the other table / the norm bytes
       if (has_next) {
-        if (tid < n_next && tid < kItemChunk) {
-          ItemL I;
-          I.rel_off = r_off; I.base = r_base; I.bits_term = r_bt;
-          item_buf[(u + 1u) & 1u][tid] = I;
-        }
+        store_item(item_buf[(u + 1u) & 1u], n_next, r_off, r_base, r_bt);
         store_norm_words(tile + 1, nw0, nw1);
       }
       if (tid == 0) {

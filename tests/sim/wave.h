@@ -63,6 +63,11 @@ __device__ __forceinline__ void inclusive_scan2(uint32_t& a, uint32_t& b) {
 }
 __device__ __forceinline__ uint32_t read_lane(uint32_t v, uint32_t k) { return __shfl(v, int(k), 64); }
 __device__ __forceinline__ float read_lane_f(float v, uint32_t k) { return __shfl(v, int(k), 64); }
+__device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
+__device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t s) {
+  return uint32_t(((uint64_t(hi) << 32) | lo) >> (s & 31u));
+}
+__device__ __forceinline__ uint32_t bfe(uint32_t x, uint32_t bits) { return x & ((1u << bits) - 1u); }
 __device__ __forceinline__ void keep(uint32_t&) {}
 __device__ __forceinline__ void keep_f(float&) {}
 // v_rcp_f32 on the GPU (<= 1 ulp); exact division here
