@@ -104,7 +104,10 @@ int irs_hip_term_directory(irs_hip_segment* seg, uint32_t term,
 
 typedef enum irs_hip_op {
   IRS_HIP_OP_OR = 0, /* irs::Or / by_term: disjunction.hpp MakeDisjunction :1411-1467 */
-  IRS_HIP_OP_AND = 1 /* irs::And: conjunction.hpp MakeConjunction :436-490            */
+  IRS_HIP_OP_AND = 1, /* irs::And: conjunction.hpp MakeConjunction :436-490           */
+  IRS_HIP_OP_MINMATCH = 2 /* irs::Or with min_match_count: MinMatchQuery::execute
+                             (boolean_query.cpp:212-247) -> min_match_iterator =
+                             block_disjunction<kMinMatch> (disjunction.hpp:1378-1383)   */
 } irs_hip_op;
 
 /* Which ScoreFunction Scorer::prepare_scorer would have built. */
@@ -132,6 +135,7 @@ typedef struct irs_hip_query {
   uint32_t n_terms;    /* 1..IRS_HIP_MAX_TERMS                         */
   uint32_t first_term; /* index of the first entry in the `terms` array */
   uint32_t k;          /* top-k, 1..IRS_HIP_MAX_K (index-search --topN) */
+  uint32_t min_match;  /* IRS_HIP_OP_MINMATCH: Or::min_match_count(); else ignored */
 } irs_hip_query;
 
 /* (score, segment-local doc) exactly as utils/index-search.cpp:745-787 keeps. */

@@ -16,7 +16,7 @@ from . import _build
 
 OK, EINVAL, ECORRUPT, ENOMEM, EHIP, EOVERFLOW, EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 LAYOUT_SCALAR, LAYOUT_SIMD4 = 0, 1
-OP_OR, OP_AND = 0, 1
+OP_OR, OP_AND, OP_MINMATCH = 0, 1, 2
 SCORE_BM25, SCORE_BM15, SCORE_BM1, SCORE_TFIDF, SCORE_TFIDF_NORM = 0, 1, 2, 3, 4
 NO_TERM = 0xFFFFFFFF
 MAX_TERMS, MAX_K = 16, 4096
@@ -29,11 +29,11 @@ TERM_META = np.dtype(
 TERM_SCORER = np.dtype(
     [("term", "<u4"), ("kind", "<i4"), ("c0", "<f4"), ("norm_const", "<f4"),
      ("norm_length", "<f4")], align=True)
-QUERY = np.dtype([("op", "<i4"), ("n_terms", "<u4"), ("first_term", "<u4"), ("k", "<u4")],
-                 align=True)
+QUERY = np.dtype([("op", "<i4"), ("n_terms", "<u4"), ("first_term", "<u4"), ("k", "<u4"),
+                  ("min_match", "<u4")], align=True)
 HIT = np.dtype([("score", "<f4"), ("doc", "<u4")], align=True)
 assert TERM_META.itemsize == 48 and TERM_SCORER.itemsize == 20
-assert QUERY.itemsize == 16 and HIT.itemsize == 8
+assert QUERY.itemsize == 20 and HIT.itemsize == 8
 
 
 class SegmentDesc(C.Structure):

@@ -83,7 +83,7 @@ struct irs_hip_segment {
 struct irs_hip_batch {
   irs_hip_segment* seg = nullptr;
   uint32_t nq = 0, jt = 0, k_max = 0;
-  uint32_t tile = kDefaultTile, stride = kDefaultStride, cand_cap = 0;
+  uint32_t tile = 0 /* 0 = pick by accumulator width */, stride = kDefaultStride, cand_cap = 0;
   uint32_t n_tiles = 0;
   uint32_t stride_eff = 1;  // pilot stride actually used (>= 4 pilot tiles when possible)
   uint32_t wg_threads = kDefaultWgThreads;  // threads per pilot/score workgroup
@@ -200,6 +200,8 @@ bool launch_score_acc(irs_hip_batch* b, rt::stream_t st) {
 bool ensure_scratch(irs_hip_batch* b) {
   if (b->scratch_ready) return true;
   const irs_hip_segment* s = b->seg;
+  // 32-bit accumulators halve the LDS per doc: twice the tile at the same residency
+  if (b->tile == 0) b->tile = b->acc32 ? 8192 : kDefaultTile;
   b->n_tiles = (s->dev.num_docs + b->tile - 1) / b->tile;
   b->stride_eff = std::max<uint32_t>(1, std::min<uint32_t>(b->stride, b->n_tiles / 4));
   if (const char* e = std::getenv("IRS_HIP_WG_THREADS")) {  // tuning knob
@@ -434,7 +436,8 @@ int irs_hip_batch_create(irs_hip_segment* seg, const irs_hip_query* queries, uin
     exps.reserve(nq);
     for (uint32_t q = 0; q < nq && rc == IRS_HIP_OK; ++q) {
       const irs_hip_query& in = queries[q];
-      if ((in.op != IRS_HIP_OP_OR && in.op != IRS_HIP_OP_AND) || in.n_terms == 0 ||
+      if ((in.op != IRS_HIP_OP_OR && in.op != IRS_HIP_OP_AND && in.op != IRS_HIP_OP_MINMATCH) ||
+          in.n_terms == 0 ||
           in.n_terms > IRS_HIP_MAX_TERMS || in.k == 0 || in.k > IRS_HIP_MAX_K ||
           uint64_t(in.first_term) + in.n_terms > n_entries) {
         rc = IRS_HIP_EINVAL;
@@ -508,16 +511,30 @@ int irs_hip_batch_create(irs_hip_segment* seg, const irs_hip_query* queries, uin
       if (rc != IRS_HIP_OK) break;
       b->alg_bytes += 8ull * in.k;
       DevQuery& dq = b->queries[q];
-      dq.op = in.op;
       dq.k = in.k;
+      // How many of the (present) terms a doc must match.  Or: 1.  And: all, and one absent
+      // term empties it (MakeScoreAdapters<true>, boolean_query.cpp:50-53).  MinMatch(m)
+      // (MinMatchQuery::execute, boolean_query.cpp:212-247): m > #sub-queries or m > #present
+      // -> empty; m == #present -> conjunction; m <= 1 -> disjunction; otherwise the
+      // min-match block disjunction: every matching term scores, docs with < m matches drop.
+      uint32_t need = 1;
       if (in.op == IRS_HIP_OP_AND) {
-        // MakeScoreAdapters<true>: one empty sub-iterator empties the conjunction
-        // (boolean_query.cpp:50-53); MakeConjunction sorts by cost (conjunction.hpp:450-453)
-        if (absent) row.clear();
-        std::stable_sort(row.begin(), row.end(), [&](const DevQTerm& x, const DevQTerm& y) {
-          return seg->terms[x.term].docs_count < seg->terms[y.term].docs_count;
-        });
+        need = absent ? 0xFFu : uint32_t(row.size());
+      } else if (in.op == IRS_HIP_OP_MINMATCH) {
+        const uint32_t m = std::max<uint32_t>(1, in.min_match);
+        need = (m > in.n_terms || m > row.size()) ? 0xFFu : m;
+      }
+      if (need == 0xFFu) row.clear();
+      dq.op = 0;
+      if (need > 1 && !row.empty()) {
+        dq.op = int32_t(1u | (need << 8));
         b->any_and = true;
+        if (need == row.size()) {
+          // MakeConjunction sorts by cost (conjunction.hpp:450-453); sums are order-free here
+          std::stable_sort(row.begin(), row.end(), [&](const DevQTerm& x, const DevQTerm& y) {
+            return seg->terms[x.term].docs_count < seg->terms[y.term].docs_count;
+          });
+        }
       }
       // norm_cache slots: one per distinct (norm_const, norm_length)
       uint32_t n_caches = 0;

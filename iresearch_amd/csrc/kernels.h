@@ -790,8 +790,8 @@ k_pilot(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
     for (uint32_t i = threadIdx.x; i < TILE; i += blockDim.x) {
       const ACC a = sm.acc[i];
       bool m = a != ACC(0);
-      if (AND && qd.op == 1)
-        m = qd.n_terms && ((sm.cnt[i >> 2] >> (8u * (i & 3u))) & 0xFFu) == qd.n_terms;
+      if (AND && (qd.op & 0xFF) == 1)  // AND / min-match: op = 1 | required matches << 8
+        m = ((sm.cnt[i >> 2] >> (8u * (i & 3u))) & 0xFFu) >= uint32_t(qd.op >> 8);
       if (m) atomicAdd(&hist[score_bin(from_fixed<ACC>(a, qd.fx_inv), qd.bin_scale)], 1u);
     }
     __syncthreads();
@@ -1061,12 +1061,12 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
           }
         }
       };
-      if (AND && qd.op == 1) {
+      if (AND && (qd.op & 0xFF) == 1) {  // AND / min-match: op = 1 | required matches << 8
+        const uint32_t need = uint32_t(qd.op >> 8);
         for (uint32_t i = tid; i < uint32_t(TILE); i += blockDim.x) {
           const ACC a = sm.acc[i];
           if (a != ACC(0)) sm.acc[i] = ACC(0);
-          const bool m = qd.n_terms &&
-                         ((sm.cnt[i >> 2] >> (8u * (i & 3u))) & 0xFFu) == qd.n_terms;
+          const bool m = ((sm.cnt[i >> 2] >> (8u * (i & 3u))) & 0xFFu) >= need;
           if (m) {
             ++my_hits;
             if (a >= thr) candidate(i, a);

@@ -24,7 +24,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import _lib
-from ._lib import (HIT, NO_TERM, OP_AND, OP_OR, QUERY, SCORE_BM1, SCORE_BM15, SCORE_BM25,
+from ._lib import (HIT, NO_TERM, OP_AND, OP_MINMATCH, OP_OR, QUERY, SCORE_BM1, SCORE_BM15, SCORE_BM25,
                    SCORE_TFIDF, SCORE_TFIDF_NORM, TERM_META, TERM_SCORER, SegmentDesc)
 
 f32 = np.float32
@@ -98,14 +98,20 @@ class by_term:
 
 @dataclass
 class Or:
+    """irs::Or; min_match > 1 is Or::min_match_count() (boolean_filter.hpp)."""
     subs: list
-    op: int = OP_OR
+    min_match: int = 1
+
+    @property
+    def op(self):
+        return OP_MINMATCH if self.min_match > 1 else OP_OR
 
 
 @dataclass
 class And:
     subs: list
     op: int = OP_AND
+    min_match: int = 0
 
 
 def _terms_of(flt):
@@ -122,6 +128,7 @@ class PreparedQuery:
     op: int
     terms: list            # term ordinals
     scorers: list          # (kind, c0, norm_const, norm_length) per term
+    min_match: int = 0
 
 
 # ------------------------------------------------------------------ segment --
@@ -205,7 +212,7 @@ class QueryBatch:
         self.terms = np.zeros(max(n_entries, 1), TERM_SCORER)
         at = 0
         for q, p in enumerate(prepared):
-            self.queries[q] = (p.op, len(p.terms), at, self.k)
+            self.queries[q] = (p.op, len(p.terms), at, self.k, p.min_match)
             for t, (kind, c0, nc, nl) in zip(p.terms, p.scorers):
                 present = t is not None and 0 <= t < len(seg.metas)
                 self.terms[at] = (t if present else NO_TERM, kind, c0, nc, nl)
@@ -299,7 +306,8 @@ def prepare(filters, scorer, segment_stats):
                     dwt += int(st.docs_count[s.term])
             stats = scorer.collect(dwf, dwt, ttf)
             scorers.append(scorer.term_scorer(stats, s.boost))
-        out.append(PreparedQuery(op, [s.term for s in subs], scorers))
+        out.append(PreparedQuery(op, [s.term for s in subs], scorers,
+                                 int(getattr(flt, "min_match", 0))))
     return out
 
 

@@ -16,7 +16,7 @@ HERE = Path(__file__).resolve().parent
 
 LAYOUT_SCALAR, LAYOUT_SIMD4 = 0, 1
 SCORER_BM25, SCORER_TFIDF = 0, 1
-OP_OR, OP_AND = 0, 1
+OP_OR, OP_AND, OP_MINMATCH = 0, 1, 2  # MINMATCH: op | (min_match << 8)
 
 TERM_META = np.dtype(
     [("docs_count", "<u4"), ("freq", "<u4"), ("doc_start", "<u8"), ("pos_start", "<u8"),

@@ -86,7 +86,7 @@ enum {
   ORC_SCORER_BM25 = 0, /* k, b as given; picks BM1/BM15/BM25 like bm25.cpp:447-455 */
   ORC_SCORER_TFIDF = 1 /* with_norms selects tfidf.cpp:307 */
 };
-enum { ORC_OP_OR = 0, ORC_OP_AND = 1 };
+enum { ORC_OP_OR = 0, ORC_OP_AND = 1, ORC_OP_MINMATCH = 2 /* + (min_match << 8) */ };
 
 typedef struct orc_segment {
   const uint8_t* doc_file;

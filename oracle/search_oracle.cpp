@@ -172,11 +172,16 @@ void run_or2(Sub& lhs, Sub& rhs, Emit&& emit) {
 }
 
 // block_disjunction<kMatch, no readahead, 8 x 64> — disjunction.hpp:889-1369
+// min_match > 1 selects the kMinMatch traits (min_match_iterator, :1378-1383):
+// per-slot match counters (min_match_buffer :56-78), docs below min_match are
+// skipped in next() (:963-970), buffers are reset on every refill round (:1255-1259).
 template<typename Emit>
-void run_block_or(std::vector<Sub>& itrs, Emit&& emit) {
+void run_block_or(std::vector<Sub>& itrs, Emit&& emit, uint32_t min_match = 1) {
   constexpr uint32_t kWindow = 512;  // kBlockSize * kNumBlocks :1087-1092
   uint64_t mask[8];
   float score_buf[kWindow];
+  uint32_t match_count[kWindow];
+  const bool mm = min_match > 1;
   uint32_t doc_base = 0;  // doc_limits::invalid()
   uint32_t min = 1;       // doc_limits::min()  :1358
   uint32_t max = 0;
@@ -186,8 +191,16 @@ void run_block_or(std::vector<Sub>& itrs, Emit&& emit) {
     if (itrs.empty()) return;
     std::memset(mask, 0, sizeof mask);  // reset()
     std::memset(score_buf, 0, sizeof score_buf);
+    if (mm) std::memset(match_count, 0, sizeof match_count);
     bool empty = true;
+    bool first_round = true;
     do {
+      if (mm && !first_round) {  // kMinMatch: reset() inside the loop
+        std::memset(mask, 0, sizeof mask);
+        std::memset(score_buf, 0, sizeof score_buf);
+        std::memset(match_count, 0, sizeof match_count);
+      }
+      first_round = false;
       doc_base = min;
       max = min + kWindow;
       min = kEof;
@@ -209,7 +222,11 @@ void run_block_or(std::vector<Sub>& itrs, Emit&& emit) {
             const uint32_t offset = value - doc_base;
             mask[offset / 64] |= uint64_t(1) << (offset % 64);
             score_buf[offset] += s.score();  // SumMerger
-            empty = false;
+            if (mm) {
+              empty &= (++match_count[offset] < min_match);  // match_buf_.inc :1341
+            } else {
+              empty = false;
+            }
             if (!orc_it_next(&s.it)) {
               alive = false;
               break;
@@ -223,6 +240,8 @@ void run_block_or(std::vector<Sub>& itrs, Emit&& emit) {
           ++i;
         }
       }
+      // kMinMatch: fewer iterators left than min_match -> nothing later can match (:1218-1226)
+      if (mm && itrs.size() < min_match) itrs.clear();
     } while (empty && !itrs.empty());
     if (empty) return;
     // next() :939-986 — ascending set bits
@@ -231,6 +250,7 @@ void run_block_or(std::vector<Sub>& itrs, Emit&& emit) {
       while (cur) {
         const uint32_t off = uint32_t(__builtin_ctzll(cur));
         cur &= cur - 1;
+        if (mm && match_count[w * 64 + off] < min_match) continue;  // next() :963-970
         emit(doc_base + w * 64 + off, score_buf[w * 64 + off]);
       }
     }
@@ -264,6 +284,14 @@ template<typename Emit>
 void execute_segment(const orc_segment& seg, const orc_term_meta* metas,
                      uint32_t n_terms, int32_t op, const orc_scorer& scorer,
                      const float* boosts, const TermStats* stats, Emit&& emit) {
+  // op = ORC_OP_OR | ORC_OP_AND | ORC_OP_MINMATCH + (min_match << 8)
+  uint32_t min_match = 1;
+  if ((op & 0xFF) == ORC_OP_MINMATCH) {
+    // MinMatchQuery::execute — boolean_query.cpp:212-247
+    min_match = std::max<uint32_t>(1u, uint32_t(op) >> 8);
+    if (min_match > n_terms) return;
+    op = min_match == n_terms ? ORC_OP_AND : ORC_OP_OR;
+  }
   std::vector<Sub> itrs;
   itrs.reserve(n_terms);
   for (uint32_t t = 0; t < n_terms; ++t) {
@@ -282,6 +310,16 @@ void execute_segment(const orc_segment& seg, const orc_term_meta* metas,
     s.cost = metas[t].docs_count;
   }
   if (itrs.empty()) return;
+  if (op == ORC_OP_OR && min_match > 1) {
+    // MakeWeakDisjunction — disjunction.hpp:1469-1513
+    if (min_match > itrs.size()) return;
+    if (min_match == itrs.size()) {
+      op = ORC_OP_AND;  // pure conjunction :1491-1494
+    } else {
+      run_block_or(itrs, emit, min_match);
+      return;
+    }
+  }
   if (itrs.size() == 1) {  // MakeDisjunction :1422-1426 / MakeConjunction :444
     Sub& s = itrs[0];
     while (orc_it_next(&s.it)) emit(s.it.doc, s.score());

@@ -139,6 +139,10 @@ def standard_filters(max_rank, n_or8=4, seed=synth.SEED + 2):
     fl += [And([by_term(3), by_term(max_rank // 8), by_term(1)]),
            And([by_term(max_rank - 1), by_term(max_rank - 2)])]
     fl += [Or([by_term(max_rank - 1, 2.5), by_term(max_rank - 2), by_term(max_rank - 3, 0.5)])]
+    # Or::min_match_count (MinMatchQuery, boolean_query.cpp:212-247)
+    mm = [by_term(2), by_term(max_rank // 16), by_term(max_rank // 4), by_term(5), by_term(9)]
+    fl += [Or(mm, min_match=2), Or(mm, min_match=4), Or(mm[:3], min_match=3),
+           Or(mm[:2], min_match=3), Or(mm + [by_term(10 * max_rank)], min_match=5)]
     return fl
 
 
@@ -204,6 +208,37 @@ def case_no_norms(L):
     filters = standard_filters(128, n_or8=2)
     for scorer in (BM25(), TFIDF(True)):
         run_and_check(L, seg, filters, scorer, 50, sr=sr)
+    sr.close()
+
+
+def case_wide_norms(L, width):
+    """Norm2 columns wider than one byte (big-endian values, norm.hpp:170-182) take the
+    other BM25 expression c0 - c0*c1/(c1 + tf) (bm25.cpp:355-359) and kRSQRT.get<true>."""
+    seg = synth.build_segment(20_000, 128)
+    rng = np.random.default_rng(width)
+    lengths = rng.integers(1, 60_000 if width == 2 else 3_000_000, seg.num_docs)
+    be = lengths.astype(">u2" if width == 2 else ">u4")
+    seg.norms = np.frombuffer(be.tobytes(), np.uint8).copy()
+    seg.norm_width = width
+    seg.total_term_freq = int(lengths.sum())
+    sr = search.SegmentReader(seg.doc_file, seg.metas, seg.num_docs, seg.layout, seg.norms, width,
+                              seg.docs_with_field, seg.total_term_freq, L=L)
+    filters = standard_filters(128, n_or8=2)
+    for scorer in (BM25(), TFIDF(True)):
+        run_and_check(L, seg, filters, scorer, 50, sr=sr)
+    sr.close()
+
+
+def case_decode_without_freq(L, layout):
+    """Iterator requested without IndexFeatures::FREQ on a FREQ field: freq blocks are
+    skipped (formats_10.cpp:1746-1750) — docs must be identical."""
+    seg = synth.build_segment(8_000, 64, layout=layout, keep_postings=True)
+    sr = search.SegmentReader.from_synth(seg, L=L)
+    for r in (1, 2, 17, 40, 64):
+        d, f = sr.decode_term(r - 1, want_freq=False)
+        assert f is None and np.array_equal(d, seg.postings[r][0])
+        od, _ = oracle.decode_term(seg.doc_file, seg.metas[r - 1], layout, want_freq=False)
+        assert np.array_equal(d, od)
     sr.close()
 
 

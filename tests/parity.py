@@ -17,9 +17,16 @@ def oracle_scorer(scorer) -> oracle.Scorer:
     return oracle.Scorer(oracle.SCORER_TFIDF, 0.0, 0.0, int(scorer.with_norms))
 
 
+def oracle_op(flt, op):
+    """Or with min_match > 1 -> ORC_OP_MINMATCH | (min_match << 8)."""
+    mm = int(getattr(flt, "min_match", 0) or 0)
+    return oracle.OP_MINMATCH | (mm << 8) if op == oracle.OP_MINMATCH else op
+
+
 def oracle_view(seg) -> oracle.SegmentView:
     return oracle.SegmentView(seg.doc_file, seg.norms, seg.layout, seg.num_docs,
-                              seg.docs_with_field, seg.total_term_freq)
+                              seg.docs_with_field, seg.total_term_freq,
+                              getattr(seg, "norm_width", 1))
 
 
 def segment_stats(seg) -> search.SegmentStats:
@@ -46,6 +53,7 @@ def check_single_segment(seg, filters, scorer, k, hits, counts, totals, all_segs
     ttf = sum(s.total_term_freq for s in all_segs)
     for q, flt in enumerate(filters):
         op, subs = search._terms_of(flt)
+        op = oracle_op(flt, op)
         terms = [s.term for s in subs]
         boosts = [s.boost for s in subs]
         metas = metas_for(seg, terms)
@@ -83,6 +91,7 @@ def oracle_topk(segs, filters, scorer, k):
     out = []
     for flt in filters:
         op, subs = search._terms_of(flt)
+        op = oracle_op(flt, op)
         terms = [s.term for s in subs]
         metas = np.stack([metas_for(s, terms) for s in segs])
         hits, total = oracle.search(views, metas, op, osc, k, [s.boost for s in subs])

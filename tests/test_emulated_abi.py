@@ -47,6 +47,16 @@ def test_no_norms(simlib):
     cases.case_no_norms(simlib)
 
 
+@pytest.mark.parametrize("width", [2, 4])
+def test_wide_norms(simlib, width):
+    cases.case_wide_norms(simlib, width)
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_decode_without_freq(simlib, layout):
+    cases.case_decode_without_freq(simlib, layout)
+
+
 def test_multi_segment(simlib):
     cases.case_multi_segment(simlib, 45_000, 256)
 

@@ -52,6 +52,16 @@ def test_no_norms(gpulib):
     cases.case_no_norms(gpulib)
 
 
+@pytest.mark.parametrize("width", [2, 4])
+def test_wide_norms(gpulib, width):
+    cases.case_wide_norms(gpulib, width)
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_decode_without_freq(gpulib, layout):
+    cases.case_decode_without_freq(gpulib, layout)
+
+
 def test_multi_segment(gpulib):
     cases.case_multi_segment(gpulib, 600_000, 1024, n_segs=4, k=1000)
 
