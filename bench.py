@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--stride", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--force-segments", action="store_true",
+                    help="use the multi-segment path (merge kernel) even on one GPU")
     args = ap.parse_args()
 
     import torch
@@ -103,7 +105,8 @@ def main():
 
     # ---- index: built on the host, staged to HBM once (not timed) ------------
     t0 = time.perf_counter()
-    if world == 1:
+    multi = world > 1 or args.force_segments
+    if not multi:
         n_segments = 1
         my = [0]
     else:
@@ -152,7 +155,7 @@ def main():
     def step():
         for s in my:
             batches[s].run(sptr)
-        if world > 1:
+        if multi:
             lists = []
             for s in my:
                 batches[s].results_to_device(recv[s][0].data_ptr(), recv[s][1].data_ptr(), sptr)
@@ -221,11 +224,12 @@ def main():
                             "%d queries/step" % (args.terms, k, args.docs, n_segments, nq),
                 "segments": n_segments, "queries_per_step": nq, "layout": "1_5simd",
                 "postings_per_step": int(postings), "algorithmic_bytes_per_step": int(alg_bytes),
-                "parallelism": "segments x%d + RCCL all-gather top-k" % world if world > 1
+                "parallelism": ("%d segments over %d GPU(s) + RCCL all-gather of per-segment "
+                                "top-k + GPU merge" % (n_segments, world)) if multi
                                else "1 segment on 1 GPU"},
             "roofline": roof,
         }
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and not multi and not args.no_cpu:
         for b in batches.values():
             b.close()
         out["cpu_baseline"] = cpu_baseline(segs[0], ranks, k)
