@@ -95,9 +95,14 @@ __device__ __forceinline__ uint32_t bfe(uint32_t x, uint32_t bits) {
 // Optimisation barrier: the value must exist in a VGPR at this program point.
 __device__ __forceinline__ void keep(uint32_t& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void keep_f(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void keep_acc(uint32_t& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void keep_acc(unsigned long long& v) { asm volatile("" : "+v"(v)); }
 
 // v_rcp_f32: <= 1 ulp
 __device__ __forceinline__ float fast_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
+
+// a*b + c in one rounding (v_fma_f32), independent of -ffp-contract
+__device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
 // LDS float accumulate without a returned value -> ds_add_f32
 __device__ __forceinline__ void lds_add(float* p, float v) { atomicAdd(p, v); }

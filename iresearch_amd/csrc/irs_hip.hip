@@ -150,15 +150,17 @@ bool launch_score(irs_hip_batch* b, rt::stream_t st) {
   const size_t smem = score_smem_bytes<ACC, TILE, AND>();
   auto kern = k_score<ACC, LAYOUT, TILE, AND>;
   if (!big_smem(kern, smem)) return false;
+  // k_score stages 16 norm bytes per thread per tile
+  const uint32_t threads = std::max<uint32_t>(b->wg_threads, uint32_t(TILE) / 16u);
   // persistent grid: as many workgroups as stay resident on the chip at once
-  const uint32_t waves = b->wg_threads / 64;
+  const uint32_t waves = threads / 64;
   uint32_t per_cu = uint32_t((160u * 1024u) / smem);
   per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 32u / waves));
   const uint64_t chunks = uint64_t(b->nq) * ((b->n_tiles + kChunkTiles - 1) / kChunkTiles);
   if (chunks > 0xFFFF0000ull) return false;
   const uint32_t grid = uint32_t(std::min<uint64_t>(chunks, uint64_t(b->seg->cus) * per_cu));
   if (!rt::dmemset(b->d_work.p, 0, 4, st)) return false;
-  RT_LAUNCH(kern, grid, b->wg_threads, smem, st, b->seg->dev, b->d_queries.as<DevQuery>(),
+  RT_LAUNCH(kern, grid, threads, smem, st, b->seg->dev, b->d_queries.as<DevQuery>(),
             b->d_qterms.as<DevQTerm>(), b->jt, b->n_tiles, b->nq,
             b->d_first.as<uint32_t>(), b->d_tails.as<DevTail>(), b->d_bstar.as<uint32_t>(),
             b->d_cands.as<uint64_t>(), b->cand_cap, b->d_cand_count.as<uint32_t>(),

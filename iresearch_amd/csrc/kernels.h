@@ -300,11 +300,26 @@ struct TermL {          // one query term of this tile, staged in LDS
   uint32_t tail_n;      // postings in the term's decoded tail
 };
 
-struct ItemL {          // one (term, block) work item
+struct alignas(16) ItemL {   // one (term, block) work item: one 16-byte LDS read per lane
   uint32_t off;         // byte offset of the block in the staged `.doc` file
   uint32_t base;        // last doc of the preceding block (kDocMin for block 0)
-  uint32_t bits_term;   // doc bits | freq bits << 8 | term slot << 16
+  uint32_t pack;        // doc bits | freq bits << 8 | cache slot << 16 | term slot << 20 | fast << 31
+  float cs;             // the term's c0 pre-multiplied by the fixed-point scale
 };
+
+// Bits 16.. of ItemL::pack for term slot j; bit 30 = "this scorer has a fast path"
+// (BM25 over 1-byte norms with an LDS norm_cache), resolved against the block's
+// bit widths by item_pack().
+__device__ __forceinline__ uint32_t term_pack(uint32_t j, int32_t kind, uint32_t cache_id) {
+  const bool fk = kind == kBM25Tiny && cache_id < kMaxCaches;
+  return ((cache_id < 15u ? cache_id : 15u) << 16) | (j << 20) | (fk ? 0x40000000u : 0u);
+}
+__device__ __forceinline__ uint32_t item_pack(uint32_t bits16, uint32_t tpack) {
+  const uint32_t dbits = bits16 & 0xFFu, fbits = (bits16 >> 8) & 0xFFu;
+  // the straight-line decoder handles 1..31-bit packed blocks
+  const bool fast = (tpack & 0x40000000u) && (dbits - 1u) <= 30u && (fbits - 1u) <= 30u;
+  return (bits16 & 0xFFFFu) | (tpack & 0x01FF0000u) | (fast ? 0x80000000u : 0u);
+}
 
 template<typename ACC>
 struct TileSmemT {
@@ -439,28 +454,34 @@ __device__ __forceinline__ void tile_apply(const DevSegment& seg, const TileSmem
 
 // Scoring of N postings at once on the hot path (BM25, 1-byte norms, LDS
 // norm_cache — bm25.cpp:348-353: c0 - c0/(1 + tf*cache[norm]); the division is
-// one v_rcp_f32, <= 1 ulp, far inside the 1e-5 parity tolerance; `cs` is c0
+// one v_rcp_f32 and the two multiply-adds are fused, within 2 ulp of the
+// reference expression, far inside the 1e-5 parity tolerance; `cs` is c0
 // pre-multiplied by fx_mul so the result is already in fixed-point units).
 // Staged so that the N norm-byte reads, then the N cache reads, then the N LDS
 // atomics are issued back to back: one LDS latency per stage instead of one per
 // posting.  wave::keep() pins each stage (the compiler would otherwise sink the
-// whole computation behind a per-posting branch).  Postings outside the tile add
-// 0 to a private dummy slot instead of branching.
+// whole computation behind a per-posting branch).
+// Postings outside the tile are not branched around: `doc - lo` wraps to a huge
+// value for doc < lo, and one v_min clamps every out-of-tile index to the lane's
+// private dummy accumulator acc[TILE + lane]; whatever byte sits at
+// lnorm[TILE + lane] (the next LDS array) yields some finite garbage that is
+// added to that dummy slot, which nothing ever reads.  (The last tile of a
+// segment needs no extra test: docs >= lo + span do not exist.)
 template<typename ACC, int TILE, bool AND, int N>
 __device__ __forceinline__ void tile_post_bm25(const TileSmemT<ACC>& sm, const float (&cs)[N],
                                                const float* const (&cache)[N],
                                                const uint32_t (&doc)[N],
                                                const uint32_t (&freq)[N], uint32_t lo,
-                                               uint32_t span, unsigned lane) {
+                                               unsigned lane) {
   uint32_t idx[N], nb[N];
-  bool in[N];
   float inv[N];
   ACC fx[N];
+  const uint32_t dummy = uint32_t(TILE) + lane;
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    idx[k] = doc[k] - lo;  // doc < lo wraps to a huge value
-    in[k] = idx[k] < span;
-    nb[k] = sm.lnorm[in[k] ? idx[k] : 0u];
+    const uint32_t raw = doc[k] - lo;
+    idx[k] = raw < dummy ? raw : dummy;
+    nb[k] = sm.lnorm[idx[k]];
   }
 #pragma unroll
   for (int k = 0; k < N; ++k) wave::keep(nb[k]);
@@ -470,17 +491,38 @@ __device__ __forceinline__ void tile_post_bm25(const TileSmemT<ACC>& sm, const f
   for (int k = 0; k < N; ++k) wave::keep_f(inv[k]);
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    const float x = static_cast<float>(freq[k]) * inv[k];
-    float scaled = cs[k] - cs[k] * wave::fast_rcp(1.f + x);
+    const float r = wave::fast_rcp(wave::fma(static_cast<float>(freq[k]), inv[k], 1.f));
+    float scaled = wave::fma(-cs[k], r, cs[k]);
     wave::keep_f(scaled);
     fx[k] = fixed_from_scaled<ACC>(scaled);
   }
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    atomicAdd(&sm.acc[in[k] ? idx[k] : (uint32_t(TILE) + lane)], in[k] ? fx[k] : ACC(0));
+    atomicAdd(&sm.acc[idx[k]], fx[k]);
     if (AND) {
-      if (in[k]) atomicAdd(&sm.cnt[idx[k] >> 2], 1u << (8u * (idx[k] & 3u)));
+      if (idx[k] < uint32_t(TILE)) atomicAdd(&sm.cnt[idx[k] >> 2], 1u << (8u * (idx[k] & 3u)));
     }
+  }
+}
+
+// Payload words of values 2*lane, 2*lane+1 of a packed block, 1 <= bits <= 32, with no
+// branch on `bits` (any other framing is re-read by the generic path): the
+// same address arithmetic as raw_load.  Reads at most 16 bytes past the block.
+template<int LAYOUT>
+__device__ __forceinline__ void raw_load_packed(const uint8_t* payload, uint32_t bits,
+                                                unsigned lane, uint64_t& a, uint64_t& b) {
+#ifdef IRS_ABL_ALIGNED   // timing experiment only (wrong results): 8-byte aligned addresses
+  payload = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(payload) & ~uintptr_t(7));
+#endif
+  if (LAYOUT == kSimd4) {
+    const uint32_t k = wave::mul24(lane >> 1, bits) >> 5;
+    const uint32_t voff = 16u * k + ((lane & 1u) << 3);
+    a = wave::load_u64(payload + voff);
+    b = wave::load_u64(payload + voff + 16);
+  } else {
+    const uint32_t voff = (wave::mul24(lane << 1, bits) >> 5) << 2;
+    a = wave::load_u64(payload + voff);
+    b = wave::load_u64(payload + voff + 4);
   }
 }
 
@@ -503,98 +545,102 @@ __device__ __forceinline__ void extract_fast(uint64_t a, uint64_t b, uint32_t bi
   }
 }
 
-// Decode + score + accumulate the `n` (term, block) work items of `items`
-// (n <= kItemChunk): wavefront w takes items w, w+nw, ...
-template<typename ACC, int LAYOUT, int TILE, bool AND>
-__device__ __forceinline__ void process_items(const DevSegment& seg, const TileSmemT<ACC>& sm,
-                                              const ItemL* items, uint32_t n, uint32_t lo,
-                                              uint32_t span, float fx_mul) {
-  const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-  const uint32_t nw = blockDim.x >> 6;
-  // This wavefront's items are wv, wv+nw, ...: lane k keeps the metadata of the
-  // k-th one in registers; the loop broadcasts it with v_readlane (scalar
-  // results), so no LDS round trip sits on an item's critical path.
-  //   m_pack: doc bits | freq bits << 8 | cache slot << 16 | term slot << 20 | fast << 31
-  const uint32_t my_n = n > wv ? (n - wv + nw - 1) / nw : 0u;  // <= 64
-  uint32_t m_pack = 0, m_base = 0, m_off = 0;
-  float m_cs = 0.f;
-  if (lane < my_n) {
-    const uint32_t it = wv + lane * nw;
-    const uint32_t bt = items[it].bits_term;
-    m_base = items[it].base;
-    m_off = items[it].off;
-    const uint32_t j = bt >> 16, dbits = bt & 0xFFu, fbits = (bt >> 8) & 0xFFu;
-    const uint32_t cid = sm.qts[j].cache_id;
-    const bool fast = dbits >= 1u && dbits <= 31u && fbits >= 1u && fbits <= 31u &&
-                      sm.qts[j].kind == kBM25Tiny && cid < kMaxCaches;
-    m_pack = (bt & 0xFFFFu) | ((cid < 15u ? cid : 15u) << 16) | (j << 20) | (fast ? 0x80000000u : 0u);
-    m_cs = sm.qts[j].c0 * fx_mul;
+// The work items of one tile are processed in two steps so that k_score can put
+// a whole tile epilogue between them:
+//   items_prepare: wavefront w takes items w, w+nw, ...; lane k loads the metadata
+//     of the k-th one (the loop broadcasts it with v_readlane: scalar results, no
+//     LDS round trip on an item's critical path) and the payload words of the
+//     first two items are requested;
+//   items_run: decode + score + accumulate, always two items ahead with the loads.
+struct ItemRegs {
+  uint32_t n;                        // items of this wavefront (<= 64), wave-uniform
+  uint32_t pack, base, off;          // lane k: metadata of the k-th item
+  float cs;
+  uint64_t ada, adb, afa, afb;       // payload words of the next item pair
+  uint64_t bda, bdb, bfa, bfb;
+};
+
+// raw payload words of item k (two per block part); no branch on the bit widths.
+// (Lanes past the last item hold a copy of the last item, so items_prepare may
+// request items 0 and 1 without a bounds test.)
+template<int LAYOUT>
+__device__ __forceinline__ void item_load(const DevSegment& seg, const ItemRegs& r, uint32_t k,
+                                          unsigned lane, uint64_t& da, uint64_t& db,
+                                          uint64_t& fa, uint64_t& fb) {
+  const uint32_t pack = wave::read_lane(r.pack, k & 63u);
+  const uint32_t dbits = pack & 0xFFu, fbits = (pack >> 8) & 0xFFu;
+  const uint8_t* blk = seg.doc + wave::read_lane(r.off, k & 63u);
+  raw_load_packed<LAYOUT>(blk + 1, dbits, lane, da, db);
+  // the freq block starts right after the doc block (an ALL_EQUAL doc block has a
+  // data-dependent size: those items take the generic path, which reads for itself)
+  raw_load_packed<LAYOUT>(blk + 2u + 16u * dbits, fbits, lane, fa, fb);
+}
+
+template<int LAYOUT>
+__device__ __forceinline__ void items_prepare(const DevSegment& seg, const ItemL* items,
+                                              uint32_t n, ItemRegs& r) {
+  const unsigned lane = threadIdx.x & 63u;
+  const uint32_t wv = wave::uniform(threadIdx.x >> 6);
+  const uint32_t nw = blockDim.x >> 6;  // workgroups are 256/512/1024 threads: a power of two
+  r.n = wave::uniform(n > wv ? (n - wv + nw - 1) >> (31 - __builtin_clz(nw)) : 0u);
+  // lanes past the last item: a harmless 1-bit block at file offset 0 (no items at
+  // all) or a copy of the last item, so that look-ahead loads need no bounds test
+  // and do not all hit one address
+  r.pack = 0x0101u;
+  r.base = 0;
+  r.off = 0;
+  r.cs = 0.f;
+  if (r.n) {
+    const uint32_t mine = lane < r.n ? lane : r.n - 1u;
+    const ItemL I = items[wv + mine * nw];
+    r.off = I.off;
+    r.base = I.base;
+    r.pack = lane < r.n ? I.pack : (I.pack & 0xFFFFu);
+    r.cs = I.cs;
   }
-  // raw payload words of the k-th item (two per block part), loaded ahead of use
-  auto load_k = [&](uint32_t k, uint64_t& da, uint64_t& db, uint64_t& fa, uint64_t& fb) {
-    const uint32_t pack = wave::read_lane(m_pack, k);
-    const uint32_t dbits = pack & 0xFFu, fbits = (pack >> 8) & 0xFFu;
-    const uint8_t* blk = seg.doc + wave::read_lane(m_off, k);
-    const RawPair d = raw_load<LAYOUT>(blk + 1, dbits, lane);
-    da = d.a;
-    db = d.b;
-    // the freq block starts right after the doc block; an ALL_EQUAL doc block
-    // (vint payload) has a data-dependent size and is fetched at use instead
-    if (dbits) {
-      const RawPair f = raw_load<LAYOUT>(blk + 2u + 16u * dbits, fbits, lane);
-      fa = f.a;
-      fb = f.b;
-    }
-  };
-  // generic item: any block framing, any scorer
-  auto slow_item = [&](uint32_t k, uint64_t da, uint64_t db, uint64_t fa, uint64_t fb) {
-    const uint32_t pack = wave::read_lane(m_pack, k);
-    const uint32_t base = wave::read_lane(m_base, k);
-    const uint32_t dbits = pack & 0xFFu, fbits = (pack >> 8) & 0xFFu;
+  item_load<LAYOUT>(seg, r, 0, lane, r.ada, r.adb, r.afa, r.afb);
+  item_load<LAYOUT>(seg, r, 1, lane, r.bda, r.bdb, r.bfa, r.bfb);
+}
+
+template<typename ACC, int LAYOUT, int TILE, bool AND>
+__device__ __forceinline__ void items_run(const DevSegment& seg, const TileSmemT<ACC>& sm,
+                                          ItemRegs& r, uint32_t lo, uint32_t span,
+                                          float fx_mul) {
+  const unsigned lane = threadIdx.x & 63u;
+  // generic item: any block framing, any scorer; does its own loads
+  auto slow_item = [&](uint32_t k) {
+    const uint32_t pack = wave::read_lane(r.pack, k);
+    const uint32_t base = wave::read_lane(r.base, k);
     const uint32_t j = (pack >> 20) & 0x1Fu;
-    uint32_t x0, x1, f0, f1;
-    RawPair rd, rf;
-    rd.a = da; rd.b = db; rf.a = fa; rf.b = fb;
-    if (dbits) {
-      raw_extract<LAYOUT>(rd, dbits, lane, x0, x1);
-    } else {
-      uint32_t len;
-      x0 = x1 = vint_from(da, &len);
-      rf = raw_load<LAYOUT>(seg.doc + wave::read_lane(m_off, k) + 2u + len, fbits, lane);
-    }
-    if (fbits) {
-      raw_extract<LAYOUT>(rf, fbits, lane, f0, f1);
-    } else {
-      uint32_t len;
-      f0 = f1 = vint_from(rf.a, &len);
-    }
-    const uint32_t d1 = base + wave::inclusive_scan(x0 + x1);
+    uint32_t d0, d1, f0, f1;
+    decode_block<LAYOUT, true>(seg.doc + wave::read_lane(r.off, k), pack & 0xFFu,
+                               (pack >> 8) & 0xFFu, base, lane, d0, d1, f0, f1);
     const DevQTerm qt = sm.qts[j];
     const float inv_one = 1.f / (qt.norm_const + qt.norm_length * 1.f);
-    tile_apply<ACC, TILE, AND>(seg, sm, qt, inv_one, d1 - x1, f0, lo, span, fx_mul);
+    tile_apply<ACC, TILE, AND>(seg, sm, qt, inv_one, d0, f0, lo, span, fx_mul);
     tile_apply<ACC, TILE, AND>(seg, sm, qt, inv_one, d1, f1, lo, span, fx_mul);
   };
   // hot path, one item: straight-line code
   auto fast_item = [&](uint32_t k, uint64_t da, uint64_t db, uint64_t fa, uint64_t fb) {
-    const uint32_t pack = wave::read_lane(m_pack, k);
-    const float cs = wave::read_lane_f(m_cs, k);
+    const uint32_t pack = wave::read_lane(r.pack, k);
+    const float cs = wave::read_lane_f(r.cs, k);
     const float* cache = sm.caches + ((pack >> 16) & 0xFu) * 256u;
     uint32_t x0, x1, f0, f1;
     extract_fast<LAYOUT>(da, db, pack & 0xFFu, lane, x0, x1);
     extract_fast<LAYOUT>(fa, fb, (pack >> 8) & 0xFFu, lane, f0, f1);
-    const uint32_t d1 = wave::read_lane(m_base, k) + wave::inclusive_scan(x0 + x1);
+    const uint32_t d1 = wave::read_lane(r.base, k) + wave::inclusive_scan(x0 + x1);
     const float css[2] = {cs, cs};
     const float* const caches2[2] = {cache, cache};
     const uint32_t docs2[2] = {d1 - x1, d1};
     const uint32_t freqs2[2] = {f0, f1};
-    tile_post_bm25<ACC, TILE, AND, 2>(sm, css, caches2, docs2, freqs2, lo, span, lane);
+    tile_post_bm25<ACC, TILE, AND, 2>(sm, css, caches2, docs2, freqs2, lo, lane);
   };
   // hot path, two items fused: 4 postings per lane in flight, two independent
   // DPP scan chains, all LDS lookups issued back to back
   auto fast_pair = [&](uint32_t k, uint64_t ada, uint64_t adb, uint64_t afa, uint64_t afb,
                        uint64_t bda, uint64_t bdb, uint64_t bfa, uint64_t bfb) {
-    const uint32_t pA = wave::read_lane(m_pack, k), pB = wave::read_lane(m_pack, k + 1);
-    const float csA = wave::read_lane_f(m_cs, k), csB = wave::read_lane_f(m_cs, k + 1);
+    const uint32_t pA = wave::read_lane(r.pack, k), pB = wave::read_lane(r.pack, k + 1);
+    const float csA = wave::read_lane_f(r.cs, k), csB = wave::read_lane_f(r.cs, k + 1);
     const float* cacheA = sm.caches + ((pA >> 16) & 0xFu) * 256u;
     const float* cacheB = sm.caches + ((pB >> 16) & 0xFu) * 256u;
     uint32_t ax0, ax1, af0, af1, bx0, bx1, bf0, bf1;
@@ -604,36 +650,48 @@ __device__ __forceinline__ void process_items(const DevSegment& seg, const TileS
     extract_fast<LAYOUT>(bfa, bfb, (pB >> 8) & 0xFFu, lane, bf0, bf1);
     uint32_t sa = ax0 + ax1, sb = bx0 + bx1;
     wave::inclusive_scan2(sa, sb);
-    const uint32_t ad1 = wave::read_lane(m_base, k) + sa;
-    const uint32_t bd1 = wave::read_lane(m_base, k + 1) + sb;
+    const uint32_t ad1 = wave::read_lane(r.base, k) + sa;
+    const uint32_t bd1 = wave::read_lane(r.base, k + 1) + sb;
     const float css[4] = {csA, csA, csB, csB};
     const float* const caches4[4] = {cacheA, cacheA, cacheB, cacheB};
     const uint32_t docs4[4] = {ad1 - ax1, ad1, bd1 - bx1, bd1};
     const uint32_t freqs4[4] = {af0, af1, bf0, bf1};
-    tile_post_bm25<ACC, TILE, AND, 4>(sm, css, caches4, docs4, freqs4, lo, span, lane);
+    tile_post_bm25<ACC, TILE, AND, 4>(sm, css, caches4, docs4, freqs4, lo, lane);
   };
 
-  uint64_t ada = 0, adb = 0, afa = 0, afb = 0, bda = 0, bdb = 0, bfa = 0, bfb = 0;
-  if (0 < my_n) load_k(0, ada, adb, afa, afb);
-  if (1 < my_n) load_k(1, bda, bdb, bfa, bfb);
+  uint64_t ada = r.ada, adb = r.adb, afa = r.afa, afb = r.afb;
+  uint64_t bda = r.bda, bdb = r.bdb, bfa = r.bfa, bfb = r.bfb;
+  const uint32_t my_n = r.n;
   for (uint32_t k = 0; k < my_n; k += 2) {
-    uint64_t nada = 0, nadb = 0, nafa = 0, nafb = 0, nbda = 0, nbdb = 0, nbfa = 0, nbfb = 0;
-    if (k + 2 < my_n) load_k(k + 2, nada, nadb, nafa, nafb);
-    if (k + 3 < my_n) load_k(k + 3, nbda, nbdb, nbfa, nbfb);
+    uint64_t nada, nadb, nafa, nafb, nbda, nbdb, nbfa, nbfb;
+    // (scalar branches; measured faster than unconditional look-ahead loads: the
+    // vector memory pipeline is a scarce resource here)
+    nada = nadb = nafa = nafb = nbda = nbdb = nbfa = nbfb = 0;
+    if (k + 2 < my_n) item_load<LAYOUT>(seg, r, k + 2, lane, nada, nadb, nafa, nafb);
+    if (k + 3 < my_n) item_load<LAYOUT>(seg, r, k + 3, lane, nbda, nbdb, nbfa, nbfb);
     const bool hasB = k + 1 < my_n;
-    const bool okA = (wave::read_lane(m_pack, k) >> 31) != 0u;
-    const bool okB = hasB && (wave::read_lane(m_pack, k + 1) >> 31) != 0u;
+    const bool okA = (wave::read_lane(r.pack, k) >> 31) != 0u;
+    const bool okB = hasB && (wave::read_lane(r.pack, k + 1) >> 31) != 0u;
     if (okA && okB) {
       fast_pair(k, ada, adb, afa, afb, bda, bdb, bfa, bfb);
     } else {
-      if (okA) fast_item(k, ada, adb, afa, afb); else slow_item(k, ada, adb, afa, afb);
+      if (okA) fast_item(k, ada, adb, afa, afb); else slow_item(k);
       if (hasB) {
-        if (okB) fast_item(k + 1, bda, bdb, bfa, bfb); else slow_item(k + 1, bda, bdb, bfa, bfb);
+        if (okB) fast_item(k + 1, bda, bdb, bfa, bfb); else slow_item(k + 1);
       }
     }
     ada = nada; adb = nadb; afa = nafa; afb = nafb;
     bda = nbda; bdb = nbdb; bfa = nbfa; bfb = nbfb;
   }
+}
+
+template<typename ACC, int LAYOUT, int TILE, bool AND>
+__device__ __forceinline__ void process_items(const DevSegment& seg, const TileSmemT<ACC>& sm,
+                                              const ItemL* items, uint32_t n, uint32_t lo,
+                                              uint32_t span, float fx_mul) {
+  ItemRegs r;
+  items_prepare<LAYOUT>(seg, items, n, r);
+  items_run<ACC, LAYOUT, TILE, AND>(seg, sm, r, lo, span, fx_mul);
 }
 
 __device__ __forceinline__ uint32_t score_bin(float v, float scale) {
@@ -742,7 +800,8 @@ __device__ __forceinline__ void tile_accumulate(const DevSegment& seg, const Dev
       ItemL I;
       I.off = uint32_t(sm.tl[j].doc_start) + seg.blk_off[e];
       I.base = b ? seg.blk_last[e - 1] : kDocMin;
-      I.bits_term = uint32_t(seg.blk_bits[e]) | (j << 16);
+      I.pack = item_pack(seg.blk_bits[e], term_pack(j, sm.qts[j].kind, sm.qts[j].cache_id));
+      I.cs = sm.qts[j].c0 * fx_mul;
       sm.items[threadIdx.x] = I;
     }
     __syncthreads();
@@ -823,14 +882,23 @@ k_pilot(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
 //
 // Persistent, software-pipelined workgroups.  The grid is sized to fill the
 // chip once; every workgroup pulls CHUNKS of kChunkTiles consecutive doc tiles
-// of one query from a global counter and walks them with a 2-stage pipeline:
-// while the wavefronts decode/score tile u out of LDS tables, the directory
-// entries and norm bytes of tile u+1 are already in flight into registers, the
-// returning atomic that reserves candidate slots for tile u-1 is in flight,
-// and so is the dequeue of the next chunk.
+// of one query from a global counter and walks them with a 3-deep pipeline.
+// While the wavefronts decode/score tile u out of registers and LDS,
+//   * the directory entries and norm bytes of tile u+1 are in flight into
+//     registers (requested during tile u-1), landing in LDS after the compute,
+//   * right after the compute barrier the requests for tile u+2 go out, every
+//     wavefront picks up its work items of tile u+1 and requests the payload of
+//     the first two — all of it covered by tile u's epilogue,
+//   * the returning atomic that reserves candidate slots for tile u-1 and the
+//     dequeue of the next chunk are in flight the same way.
+// Loaded values are kept RAW in registers until they are stored: any arithmetic
+// on them would make the compiler wait for the load where it was issued.
 
 constexpr uint32_t kChunkTiles = 16;
 constexpr uint32_t kScoreCands = 128;   // per-tile candidate staging slots (x2 buffers)
+constexpr uint32_t kToffStride = 20;    // words per row of the per-tile prefix table:
+                                        // [0..16] exclusive prefix sums of the terms' block counts
+                                        // (0xFFFFFFFF past n_terms), [17] the tile's item count
 
 enum : uint32_t {  // indices into the workgroup's LDS scratch words
   kVChunk = 0,     // current chunk id
@@ -841,13 +909,24 @@ enum : uint32_t {  // indices into the workgroup's LDS scratch words
   kVWords = 8,
 };
 
+struct alignas(16) TermC {   // per-chunk view of one query term (aliases TileSmemT::tl)
+  uint64_t dir_off;     // first entry of the term in the block directory
+  uint32_t dstart;      // byte offset of the term's posting list in `.doc`
+  uint32_t tpack;       // term_pack()
+  float cs;             // c0 * fx_mul
+  uint32_t tail_n;
+  uint32_t pad[2];
+};
+static_assert(sizeof(TermC) == sizeof(TermL), "TermC aliases the TermL table");
+
 template<typename ACC, int TILE, bool AND>
 constexpr uint32_t score_smem_bytes() {
   return tile_smem_bytes<ACC, TILE, AND>()                 // acc, cnt, lnorm, caches, qts, tl, items[0]
          + sizeof(ItemL) * kItemChunk                      // items[1]
          + 4u * (kChunkTiles + 1) * kMaxTerms              // rows
-         + 4u * kChunkTiles * (kMaxTerms + 1)              // per-tile item prefix sums
+         + 4u * kChunkTiles * kToffStride                  // per-tile item prefix sums
          + 4u * 3u * kMaxTerms                             // nblk, tail first, tail last
+         + 4u * kChunkTiles                                // per-tile tail masks
          + 8u * 2u * kScoreCands                           // candidate staging x2
          + 4u * kVWords;
 }
@@ -861,23 +940,32 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
   RT_DYN_SMEM(smem);
   unsigned char* rest;
   const TileSmemT<ACC> sm = carve<ACC, TILE, AND>(smem, &rest);
-  ItemL* items1 = reinterpret_cast<ItemL*>(rest);
+  // the two item tables are addressed as base + (u & 1) * delta: plain LDS pointer
+  // arithmetic (selecting between two pointers would degrade to flat addressing)
+  unsigned char* const items_b = reinterpret_cast<unsigned char*>(sm.items);
+  const uint32_t items_delta = uint32_t(rest - items_b);
   rest += sizeof(ItemL) * kItemChunk;
   uint32_t* rows = reinterpret_cast<uint32_t*>(rest);      // [kChunkTiles + 1][kMaxTerms]
   rest += 4u * (kChunkTiles + 1) * kMaxTerms;
-  uint32_t* toff = reinterpret_cast<uint32_t*>(rest);      // [kChunkTiles][kMaxTerms + 1]
-  rest += 4u * kChunkTiles * (kMaxTerms + 1);
+  uint32_t* toff = reinterpret_cast<uint32_t*>(rest);      // [kChunkTiles][kToffStride]
+  rest += 4u * kChunkTiles * kToffStride;
   uint32_t* tnblk = reinterpret_cast<uint32_t*>(rest);
   uint32_t* tfirst = tnblk + kMaxTerms;
   uint32_t* tlast = tfirst + kMaxTerms;
   rest += 4u * 3u * kMaxTerms;
+  uint32_t* tmask = reinterpret_cast<uint32_t*>(rest);     // [kChunkTiles]
+  rest += 4u * kChunkTiles;
   uint64_t* lcand = reinterpret_cast<uint64_t*>(rest);      // [2][kScoreCands]
   rest += 8u * 2u * kScoreCands;
   uint32_t* vars = reinterpret_cast<uint32_t*>(rest);
-  ItemL* const item_buf[2] = {sm.items, items1};
+  TermC* tc = reinterpret_cast<TermC*>(sm.tl);
+  auto items_of = [&](uint32_t u) {
+    return reinterpret_cast<ItemL*>(items_b + (u & 1u) * items_delta);
+  };
 
   const uint32_t tid = threadIdx.x;
-  const unsigned lane = tid & 63u, wv = tid >> 6;
+  const unsigned lane = tid & 63u;
+  const uint32_t wv = wave::uniform(tid >> 6);
   const uint32_t nw = blockDim.x >> 6;
   const uint32_t cpq = (n_tiles + kChunkTiles - 1) / kChunkTiles;  // chunks per query
   const uint32_t total_chunks = n_queries * cpq;
@@ -889,7 +977,7 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
   if (tid < kVWords) vars[tid] = 0u;
   if (tid == 0) vars[kVChunk] = atomicAdd(work_counter, 1u);
   __syncthreads();
-  uint32_t chunk = vars[kVChunk];
+  uint32_t chunk = wave::uniform(vars[kVChunk]);
 
   while (chunk < total_chunks) {
     // dequeue of the NEXT chunk: issued now, consumed after this chunk
@@ -907,11 +995,17 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
 
     // ---- chunk prologue: everything that is per query / per chunk ----------
     if (tid < qd.n_terms) {
-      sm.qts[tid] = qterms[qd.first_term + tid];
+      const DevQTerm qt = qterms[qd.first_term + tid];
+      sm.qts[tid] = qt;
       const DevTail* tl = tails_q + tid;
-      sm.tl[tid].doc_start = tl->doc_start;
-      sm.tl[tid].dir_off = tl->dir_off;
-      sm.tl[tid].tail_n = tl->n;
+      TermC c;
+      c.dir_off = tl->dir_off;
+      c.dstart = uint32_t(tl->doc_start);
+      c.tpack = term_pack(tid, qt.kind, qt.cache_id);
+      c.cs = qt.c0 * fx_mul;
+      c.tail_n = tl->n;
+      c.pad[0] = c.pad[1] = 0;
+      tc[tid] = c;
       tnblk[tid] = tl->nblk;
       tfirst[tid] = tl->first_doc;
       tlast[tid] = tl->last_doc;
@@ -933,75 +1027,105 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
       }
       sm.caches[e] = n ? 1.f / (nc + nl * static_cast<float>(n)) : 0.f;
     }
-    // per-tile exclusive prefix sums of each term's block count: toff[c][j], total at [c][n_terms]
+    // per tile: exclusive prefix sums of each term's block count, and the set of
+    // terms whose decoded tail reaches into the tile
     if (tid < ntile) {
-      uint32_t off = 0;
+      uint32_t* to = toff + tid * kToffStride;
+      const uint32_t tlo = kDocMin + (tile0 + tid) * uint32_t(TILE);
+      uint32_t off = 0, mask = 0;
       for (uint32_t j = 0; j < qd.n_terms; ++j) {
-        toff[tid * (kMaxTerms + 1) + j] = off;
+        to[j] = off;
         const uint32_t b0 = rows[tid * kMaxTerms + j];
         uint32_t b1 = rows[(tid + 1) * kMaxTerms + j] + 1u;
         b1 = b1 < tnblk[j] ? b1 : tnblk[j];
         off += b1 > b0 ? b1 - b0 : 0u;
+        // (tiles past the end of the segment hold no docs: no need to clip to span)
+        if (tc[j].tail_n && tfirst[j] < tlo + uint32_t(TILE) && tlast[j] >= tlo) mask |= 1u << j;
       }
-      toff[tid * (kMaxTerms + 1) + qd.n_terms] = off;
+      to[qd.n_terms] = off;
+      for (uint32_t j = qd.n_terms + 1; j <= kMaxTerms; ++j) to[j] = 0xFFFFFFFFu;
+      to[kMaxTerms + 1] = off;
+      tmask[tid] = mask;
     }
     const ACC thr = bin_threshold<ACC>(bs, qd);
     __syncthreads();
 
-    // Directory entry of item `skip + tid` of local tile c (issues the loads).
-    auto fetch_item = [&](uint32_t c, uint32_t skip, uint32_t& r_off, uint32_t& r_base,
-                          uint32_t& r_bt) {
-      const uint32_t* to = toff + c * (kMaxTerms + 1);
+    // Requests the directory entry of item `skip + tid` of local tile c. The loaded
+    // words stay raw (x_off, x_last, x_bits); store_item() combines them later.
+    auto fetch_item = [&](uint32_t c, uint32_t skip, uint32_t& x_off, uint32_t& x_last,
+                          uint32_t& x_bits, uint32_t& x_meta, uint32_t& x_dstart, float& x_cs) {
+      const uint32_t* to = toff + c * kToffStride;
       const uint32_t id = skip + tid;
-      if (tid < kItemChunk && id < to[qd.n_terms]) {
+      if (tid < kItemChunk && id < to[kMaxTerms + 1]) {
+        // term slot j: to[j] <= id < to[j+1]  <=>  j = #{t >= 1 : to[t] <= id}; all the
+        // reads are issued together (one LDS round trip, no search loop)
         uint32_t j = 0;
-        while (id >= to[j + 1]) ++j;
+#pragma unroll
+        for (uint32_t t = 1; t <= 8; ++t) j += to[t] <= id ? 1u : 0u;
+        if (qd.n_terms > 8) {
+#pragma unroll
+          for (uint32_t t = 9; t <= kMaxTerms; ++t) j += to[t] <= id ? 1u : 0u;
+        }
+        const TermC T = tc[j];
         const uint32_t b = rows[c * kMaxTerms + j] + (id - to[j]);
-        const uint64_t e = sm.tl[j].dir_off + b;
-        r_off = uint32_t(sm.tl[j].doc_start) + seg.blk_off[e];
-        r_base = b ? seg.blk_last[e - 1] : kDocMin;
-        r_bt = uint32_t(seg.blk_bits[e]) | (j << 16);
+        const uint64_t e = T.dir_off + b;
+        x_dstart = T.dstart;
+        x_cs = T.cs;
+        x_meta = T.tpack | (b ? 0u : 0x20000000u);   // bit 29: first block of the term
+        x_off = seg.blk_off[e];
+        x_last = seg.blk_last[e - (b ? 1u : 0u)];
+        x_bits = seg.blk_bits[e];
       }
     };
-    auto norm_words = [&](uint32_t tile, uint32_t& w0, uint32_t& w1) {
+    auto store_item = [&](ItemL* dst, uint32_t n, uint32_t x_off, uint32_t x_last,
+                          uint32_t x_bits, uint32_t x_meta, uint32_t x_dstart, float x_cs) {
+      if (tid < kItemChunk && tid < n) {
+        ItemL I;
+        I.off = x_dstart + x_off;
+        I.base = (x_meta & 0x20000000u) ? kDocMin : x_last;
+        I.pack = item_pack(x_bits, x_meta);
+        I.cs = x_cs;
+        dst[tid] = I;
+      }
+    };
+    // 16 norm bytes per thread (the host sizes workgroups to >= TILE/16 threads)
+    auto norm_load = [&](uint32_t tile, uint64_t& w0, uint64_t& w1) {
       w0 = w1 = 0;
       if (seg.norms && seg.norm_width == 1) {
         const uint64_t base = uint64_t(tile) * TILE + (kDocMin - seg.norm_min_doc);
-        const uint32_t i0 = tid * 4u, i1 = (tid + blockDim.x) * 4u;
-        if (i0 < uint32_t(TILE) && base + i0 < seg.norm_count) w0 = wave::load_u32(seg.norms + base + i0);
-        if (i1 < uint32_t(TILE) && base + i1 < seg.norm_count) w1 = wave::load_u32(seg.norms + base + i1);
-      }
-    };
-    auto store_norm_words = [&](uint32_t tile, uint32_t w0, uint32_t w1) {
-      const uint32_t i0 = tid * 4u, i1 = (tid + blockDim.x) * 4u;
-      if (i0 < uint32_t(TILE)) *reinterpret_cast<uint32_t*>(sm.lnorm + i0) = w0;
-      if (i1 < uint32_t(TILE)) *reinterpret_cast<uint32_t*>(sm.lnorm + i1) = w1;
-      // workgroups with fewer than TILE/8 threads: remaining words loaded in place
-      if (seg.norms && seg.norm_width == 1) {
-        const uint64_t base = uint64_t(tile) * TILE + (kDocMin - seg.norm_min_doc);
-        for (uint32_t i = (tid + 2u * blockDim.x) * 4u; i < uint32_t(TILE); i += blockDim.x * 4u) {
-          uint32_t w = 0;
-          if (base + i < seg.norm_count) w = wave::load_u32(seg.norms + base + i);
-          *reinterpret_cast<uint32_t*>(sm.lnorm + i) = w;
+        const uint32_t i0 = tid * 16u;
+        if (i0 < uint32_t(TILE) && base + i0 < seg.norm_count) {
+          w0 = wave::load_u64(seg.norms + base + i0);
+          w1 = wave::load_u64(seg.norms + base + i0 + 8);
         }
       }
     };
-    auto store_item = [&](ItemL* dst, uint32_t n, uint32_t r_off, uint32_t r_base, uint32_t r_bt) {
-      if (tid < kItemChunk && tid < n) {
-        dst[tid].off = r_off;
-        dst[tid].base = r_base;
-        dst[tid].bits_term = r_bt;
+    auto norm_store = [&](uint64_t w0, uint64_t w1) {
+      const uint32_t i0 = tid * 16u;
+      if (i0 < uint32_t(TILE)) {
+        uint64_t* d = reinterpret_cast<uint64_t*>(sm.lnorm + i0);
+        d[0] = w0;
+        d[1] = w1;
       }
     };
 
-    // ---- prime the pipeline with local tile 0 -------------------------------
-    uint32_t r_off = 0, r_base = 0, r_bt = 0, nw0 = 0, nw1 = 0;
-    uint32_t n_cur = toff[qd.n_terms];
-    fetch_item(0, 0, r_off, r_base, r_bt);
-    norm_words(tile0, nw0, nw1);
-    store_item(item_buf[0], n_cur, r_off, r_base, r_bt);
-    store_norm_words(tile0, nw0, nw1);
+    // ---- prime the pipeline: tile 0 synchronously, requests for tile 1 --------
+    uint32_t x_off = 0, x_last = 0, x_bits = 0, x_meta = 0, x_dstart = 0;
+    float x_cs = 0.f;
+    uint64_t nw0 = 0, nw1 = 0;
+    uint32_t n_cur = toff[kMaxTerms + 1], n_next = 0;
+    fetch_item(0, 0, x_off, x_last, x_bits, x_meta, x_dstart, x_cs);
+    norm_load(tile0, nw0, nw1);
+    store_item(items_of(0), n_cur, x_off, x_last, x_bits, x_meta, x_dstart, x_cs);
+    norm_store(nw0, nw1);
     __syncthreads();
+    if (1 < ntile) {
+      n_next = toff[kToffStride + kMaxTerms + 1];
+      fetch_item(1, 0, x_off, x_last, x_bits, x_meta, x_dstart, x_cs);
+      norm_load(tile0 + 1, nw0, nw1);
+    }
+    ItemRegs R;
+    items_prepare<LAYOUT>(seg, items_of(0), n_cur < kItemChunk ? n_cur : kItemChunk, R);
 
     uint32_t pend_base = 0;   // thread 0: reserved candidate base of the previous tile (in flight)
     for (uint32_t u = 0; u < ntile; ++u) {
@@ -1009,45 +1133,52 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
       const uint32_t lo = kDocMin + tile * TILE;
       const uint32_t span = (seg.num_docs + kDocMin - lo) < uint32_t(TILE)
                               ? (seg.num_docs + kDocMin - lo) : uint32_t(TILE);
-      ItemL* items = item_buf[u & 1u];
-      // stage 1 of tile u+1: directory + norm loads go out now, land after compute
       const bool has_next = u + 1 < ntile;
-      uint32_t n_next = 0;
-      if (has_next) {
-        n_next = toff[(u + 1) * (kMaxTerms + 1) + qd.n_terms];
-        fetch_item(u + 1, 0, r_off, r_base, r_bt);
-        norm_words(tile + 1, nw0, nw1);
-      }
-      // stage 2 of tile u: decode + score + accumulate
-      process_items<ACC, LAYOUT, TILE, AND>(seg, sm, items,
-                                            n_cur < kItemChunk ? n_cur : kItemChunk, lo, span,
-                                            fx_mul);
+      // compute of tile u: decode + score + accumulate
+      items_run<ACC, LAYOUT, TILE, AND>(seg, sm, R, lo, span, fx_mul);
       for (uint32_t done = kItemChunk; done < n_cur; done += kItemChunk) {  // rare: > 256 items
         __syncthreads();
-        uint32_t xo = 0, xb = 0, xt = 0;
-        fetch_item(u, done, xo, xb, xt);
-        store_item(items, n_cur - done, xo, xb, xt);
+        uint32_t yo = 0, yl = 0, yb = 0, ym = 0, yd = 0;
+        float yc = 0.f;
+        fetch_item(u, done, yo, yl, yb, ym, yd, yc);
+        store_item(items_of(u), n_cur - done, yo, yl, yb, ym, yd, yc);
         __syncthreads();
         const uint32_t n = (n_cur - done) < kItemChunk ? (n_cur - done) : kItemChunk;
-        process_items<ACC, LAYOUT, TILE, AND>(seg, sm, items, n, lo, span, fx_mul);
+        process_items<ACC, LAYOUT, TILE, AND>(seg, sm, items_of(u), n, lo, span, fx_mul);
       }
-      for (uint32_t j = wv; j < qd.n_terms; j += nw) {  // decoded vint tails / single docs
-        const uint32_t tn = sm.tl[j].tail_n;
-        if (tn && tfirst[j] < lo + span && tlast[j] >= lo) {
-          const DevQTerm qt = sm.qts[j];
-          const float inv_one = 1.f / (qt.norm_const + qt.norm_length * 1.f);
-          const DevTail* tl = tails_q + j;
-          for (uint32_t i = lane; i < tn; i += 64)
-            tile_apply<ACC, TILE, AND>(seg, sm, qt, inv_one, tl->docs[i], tl->freqs[i], lo, span,
-                                       fx_mul);
+      const uint32_t tm = wave::uniform(tmask[u]);
+      if (tm) {  // decoded vint tails / single docs reaching into this tile
+        for (uint32_t j = wv; j < qd.n_terms; j += nw) {
+          if ((tm >> j) & 1u) {
+            const DevQTerm qt = sm.qts[j];
+            const float inv_one = 1.f / (qt.norm_const + qt.norm_length * 1.f);
+            const DevTail* tl = tails_q + j;
+            const uint32_t tn = tc[j].tail_n;
+            for (uint32_t i = lane; i < tn; i += 64)
+              tile_apply<ACC, TILE, AND>(seg, sm, qt, inv_one, tl->docs[i], tl->freqs[i], lo,
+                                         span, fx_mul);
+          }
         }
       }
-      __syncthreads();  // B1: every accumulation of tile u has landed
+      // the directory entries of tile u+1 (requested a tile ago) land in the other table
+      if (has_next) store_item(items_of(u + 1u), n_next, x_off, x_last, x_bits, x_meta, x_dstart, x_cs);
+      __syncthreads();  // B1: every accumulation of tile u has landed; items of u+1 visible
+
+      uint32_t n_next2 = 0;
+      if (has_next) {
+        norm_store(nw0, nw1);  // norms of tile u+1 (tile u no longer reads them)
+        if (u + 2 < ntile) {   // requests for tile u+2
+          n_next2 = toff[(u + 2u) * kToffStride + kMaxTerms + 1];
+          fetch_item(u + 2u, 0, x_off, x_last, x_bits, x_meta, x_dstart, x_cs);
+          norm_load(tile + 2u, nw0, nw1);
+        }
+        // this wavefront's items of tile u+1 and the payload of the first two
+        items_prepare<LAYOUT>(seg, items_of(u + 1u), n_next < kItemChunk ? n_next : kItemChunk, R);
+      }
 
       // epilogue of tile u: read + clear the accumulators, count hits, stage candidates
       uint64_t* lc = lcand + (u & 1u) * kScoreCands;
       uint32_t* ncand = vars + kVNc0 + (u % 3u);
-      uint32_t my_hits = 0;
       auto candidate = [&](uint32_t i, ACC a) {
         const float v = from_fixed<ACC>(a, qd.fx_inv);
         if (score_bin(v, qd.bin_scale) >= bs) {
@@ -1063,6 +1194,7 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
       };
       if (AND && (qd.op & 0xFF) == 1) {  // AND / min-match: op = 1 | required matches << 8
         const uint32_t need = uint32_t(qd.op >> 8);
+        uint32_t my_hits = 0;
         for (uint32_t i = tid; i < uint32_t(TILE); i += blockDim.x) {
           const ACC a = sm.acc[i];
           if (a != ACC(0)) sm.acc[i] = ACC(0);
@@ -1072,35 +1204,62 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
             if (a >= thr) candidate(i, a);
           }
         }
+        my_hits = wave::reduce_add(my_hits);
+        if (lane == 0 && my_hits) atomicAdd(&vars[kVHits], my_hits);
       } else {
-        // two accumulators per lane per step: one wide LDS read, one wide clear
-        for (uint32_t i = tid * 2u; i < uint32_t(TILE); i += blockDim.x * 2u) {
-          const ACC a0 = sm.acc[i], a1 = sm.acc[i + 1];
-          sm.acc[i] = ACC(0);
-          sm.acc[i + 1] = ACC(0);
-          my_hits += (a0 != ACC(0)) + (a1 != ACC(0));
-          if (a0 >= thr || a1 >= thr) {
-            if (a0 >= thr) candidate(i, a0);
-            if (a1 >= thr) candidate(i + 1, a1);
+        // eight accumulators per lane per step: two 4-wide LDS reads in flight, two
+        // wide clears; hits are counted per wavefront with ballots (SALU adds)
+        uint32_t wave_hits = 0;
+        const uint32_t step = blockDim.x * 4u;
+        for (uint32_t i = tid * 4u; i < uint32_t(TILE); i += 2u * step) {
+          const bool two = i + step < uint32_t(TILE);  // same for the whole workgroup
+          const uint32_t i2 = two ? i + step : i;
+          ACC a[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[e] = sm.acc[i + e];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[4 + e] = sm.acc[i2 + e];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) wave::keep_acc(a[e]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sm.acc[i + e] = ACC(0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sm.acc[i2 + e] = ACC(0);
+          if (!two) {
+#pragma unroll
+            for (int e = 4; e < 8; ++e) a[e] = ACC(0);
+          }
+          ACC top = a[0];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            wave_hits += uint32_t(__builtin_popcountll(wave::ballot(a[e] != ACC(0))));
+            top = a[e] > top ? a[e] : top;
+          }
+          if (top >= thr) {  // rare: one copy of the candidate code, per-lane loop
+            uint32_t cm = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cm |= a[e] >= thr ? (1u << e) : 0u;
+            while (cm) {
+              const uint32_t e = uint32_t(__builtin_ctz(cm));
+              cm &= cm - 1u;
+              ACC x = a[0];
+#pragma unroll
+              for (int f = 1; f < 8; ++f) x = e == uint32_t(f) ? a[f] : x;
+              candidate((e < 4u ? i : i2 - 4u) + e, x);
+            }
           }
         }
+        if (lane == 0 && wave_hits) atomicAdd(&vars[kVHits], wave_hits);
       }
       if (AND) {
         __syncthreads();  // counters are packed 4 per word: clear only after all reads
         for (uint32_t i = tid; i < uint32_t(TILE) / 4; i += blockDim.x) sm.cnt[i] = 0u;
       }
-      my_hits = wave::reduce_add(my_hits);
-      if (lane == 0 && my_hits) atomicAdd(&vars[kVHits], my_hits);
-      // stage 1 of tile u+1 lands in the other table / the norm bytes
-      if (has_next) {
-        store_item(item_buf[(u + 1u) & 1u], n_next, r_off, r_base, r_bt);
-        store_norm_words(tile + 1, nw0, nw1);
-      }
       if (tid == 0) {
         vars[kVBase] = pend_base;                 // tile u-1's reservation has arrived by now
         vars[kVNc0 + ((u + 1u) % 3u)] = 0u;       // counter of tile u+1 (last used by tile u-2)
       }
-      __syncthreads();  // B2
+      __syncthreads();  // B2: accumulators are clear again
       // flush tile u-1's staged candidates to its reserved global range
       if (u > 0) {
         const uint32_t pn_raw = vars[kVNc0 + ((u - 1u) % 3u)];
@@ -1119,6 +1278,7 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
         pend_base = cn ? atomicAdd(&cand_count[q], cn) : 0u;
       }
       n_cur = n_next;
+      n_next = n_next2;
     }
     // ---- chunk epilogue: flush the last tile, publish hits, pick up the next chunk
     if (tid == 0) {
@@ -1137,7 +1297,7 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
         if (g < cand_cap) cands[uint64_t(q) * cand_cap + g] = pl[i];
       }
     }
-    chunk = vars[kVChunk];
+    chunk = wave::uniform(vars[kVChunk]);
     __syncthreads();  // everyone has read the chunk id and the staging buffers
     if (tid == 0) {
       if (vars[kVHits]) atomicAdd(&hits[q], (unsigned long long)vars[kVHits]);

@@ -70,7 +70,10 @@ __device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t s)
 __device__ __forceinline__ uint32_t bfe(uint32_t x, uint32_t bits) { return x & ((1u << bits) - 1u); }
 __device__ __forceinline__ void keep(uint32_t&) {}
 __device__ __forceinline__ void keep_f(float&) {}
+__device__ __forceinline__ void keep_acc(uint32_t&) {}
+__device__ __forceinline__ void keep_acc(unsigned long long&) {}
 // v_rcp_f32 on the GPU (<= 1 ulp); exact division here
 __device__ __forceinline__ float fast_rcp(float v) { return 1.0f / v; }
+__device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
 }  // namespace wave

@@ -23,12 +23,13 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--configs", default="4096:16")
     ap.add_argument("--nocheck", action="store_true")
+    ap.add_argument("--lib", default=None, help="alternative build of libirs_hip.so (A/B runs)")
     args = ap.parse_args()
     import torch
 
     from iresearch_amd import _lib, search, synth
     from iresearch_amd.search import BM25, Or, by_term
-    L = _lib.lib()
+    L = _lib.bind(ctypes.CDLL(args.lib)) if args.lib else _lib.lib()
     seg = synth.build_segment(args.docs, 4096)
     sr = search.SegmentReader.from_synth(seg, L=L)
     ranks = synth.make_queries(args.queries, 8, 16, 4096, synth.SEED + 2)
