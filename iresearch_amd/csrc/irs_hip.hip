@@ -828,9 +828,7 @@ int irs_hip_merge_topk(int32_t device, const void* const* d_lists, const void* c
     ml.counts[i] = static_cast<const uint32_t*>(d_counts[i]);
     ml.seg_ids[i] = seg_ids[i];
   }
-  uint32_t p2 = 1;
-  while (p2 < n_lists * k) p2 <<= 1;
-  const size_t smem = size_t(p2) * sizeof(MergeItem);
+  const size_t smem = merge_smem_bytes(n_lists, k);
   if (!big_smem(k_merge_topk, smem)) return IRS_HIP_EHIP;
   RT_LAUNCH(k_merge_topk, n_queries, kThreads, smem, static_cast<rt::stream_t>(stream), ml,
             n_lists, k, static_cast<Hit*>(d_out), static_cast<uint32_t*>(d_out_seg),

@@ -515,8 +515,13 @@ __device__ __forceinline__ void raw_load_packed(const uint8_t* payload, uint32_t
   payload = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(payload) & ~uintptr_t(7));
 #endif
   if (LAYOUT == kSimd4) {
+#ifdef IRS_ABL_PINNED    // timing experiment only (wrong results): every lane reads the same 8 bytes
+    const uint32_t k = 0;
+    const uint32_t voff = 0;
+#else
     const uint32_t k = wave::mul24(lane >> 1, bits) >> 5;
     const uint32_t voff = 16u * k + ((lane & 1u) << 3);
+#endif
     a = wave::load_u64(payload + voff);
     b = wave::load_u64(payload + voff + 16);
   } else {
@@ -1162,7 +1167,9 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
       }
       // the directory entries of tile u+1 (requested a tile ago) land in the other table
       if (has_next) store_item(items_of(u + 1u), n_next, x_off, x_last, x_bits, x_meta, x_dstart, x_cs);
+#ifndef IRS_ABL_NOBAR1   // timing experiment only
       __syncthreads();  // B1: every accumulation of tile u has landed; items of u+1 visible
+#endif
 
       uint32_t n_next2 = 0;
       if (has_next) {
@@ -1259,7 +1266,9 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
         vars[kVBase] = pend_base;                 // tile u-1's reservation has arrived by now
         vars[kVNc0 + ((u + 1u) % 3u)] = 0u;       // counter of tile u+1 (last used by tile u-2)
       }
+#ifndef IRS_ABL_NOBAR2   // timing experiment only
       __syncthreads();  // B2: accumulators are clear again
+#endif
       // flush tile u-1's staged candidates to its reserved global range
       if (u > 0) {
         const uint32_t pn_raw = vars[kVNc0 + ((u - 1u) % 3u)];
@@ -1401,69 +1410,95 @@ k_select(const DevQuery* queries, const uint64_t* cands, uint32_t cand_cap,
 
 // ----------------------------------------------------------------- merge --
 
-struct MergeItem {
-  uint32_t score_bits;
-  uint32_t seg;
-  uint32_t doc;
-};
-__device__ __forceinline__ bool merge_before(const MergeItem& a, const MergeItem& b) {
-  // score desc, segment asc, doc asc (tests/search/wand_test.cpp:72-86)
-  if (a.score_bits != b.score_bits) return a.score_bits > b.score_bits;
-  if (a.seg != b.seg) return a.seg < b.seg;
-  return a.doc < b.doc;
-}
-constexpr uint32_t kMergeMax = 8192;
+// Merge of per-segment top-k lists in the order (score desc, segment asc, doc asc)
+// (tests/search/wand_test.cpp:72-86).  Every input list is already sorted, so the
+// final position of element p of list l is
+//   p + sum over the other lists m of #{x in m : x before the element},
+// and "before" only needs the score: x.score > s, or x.score >= s when m's segment
+// id is the smaller one.  One workgroup per query stages the score bits of all
+// lists in LDS (positive floats order like their bit patterns) and every thread
+// ranks its elements with binary searches, giving up as soon as the rank
+// reaches k.  No sort, no barriers after the staging.
+constexpr uint32_t kMergeMax = 32768;   // n_lists * k score words staged in LDS (128 KB)
+constexpr uint32_t kMergeLists = 16;
 
 struct MergeLists {
-  const Hit* hits[16];
-  const uint32_t* counts[16];
-  uint32_t seg_ids[16];
+  const Hit* hits[kMergeLists];
+  const uint32_t* counts[kMergeLists];
+  uint32_t seg_ids[kMergeLists];
 };
+
+constexpr uint32_t merge_smem_bytes(uint32_t n_lists, uint32_t k) {
+  return 4u * n_lists * k + 4u * kMergeLists * 2u;
+}
 
 __global__ void __launch_bounds__(kThreads)
 k_merge_topk(MergeLists lists, uint32_t n_lists, uint32_t k, Hit* out, uint32_t* out_seg,
              uint32_t* out_counts) {
   RT_DYN_SMEM(smem);
-  MergeItem* items = reinterpret_cast<MergeItem*>(smem);
+  uint32_t* sc = reinterpret_cast<uint32_t*>(smem);   // [n_lists][k], descending
+  uint32_t* cnt = sc + n_lists * k;                     // [kMergeLists]
+  uint32_t* sid = cnt + kMergeLists;                    // [kMergeLists]
   const uint32_t q = blockIdx.x;
-  uint32_t total = 0;
-  uint32_t p2 = 1;
-  while (p2 < n_lists * k) p2 <<= 1;
-  for (uint32_t i = threadIdx.x; i < p2; i += blockDim.x) {
-    MergeItem it;
-    it.score_bits = 0; it.seg = 0xFFFFFFFFu; it.doc = 0xFFFFFFFFu;  // sorts last
-    const uint32_t l = i / k, r = i % k;
-    if (l < n_lists && r < lists.counts[l][q]) {
-      const Hit h = lists.hits[l][uint64_t(q) * k + r];
-      __builtin_memcpy(&it.score_bits, &h.score, 4);
-      it.seg = lists.seg_ids[l];
-      it.doc = h.doc;
+  if (threadIdx.x < kMergeLists) {
+    uint32_t c = 0, id = 0;
+    // (kernel-argument arrays are only indexed by unrolled constants)
+#pragma unroll
+    for (uint32_t l = 0; l < kMergeLists; ++l) {
+      if (l == threadIdx.x && l < n_lists) {
+        c = lists.counts[l][q];
+        id = lists.seg_ids[l];
+      }
     }
-    items[i] = it;
+    cnt[threadIdx.x] = c < k ? c : k;
+    sid[threadIdx.x] = id;
   }
-  for (uint32_t l = 0; l < n_lists; ++l) total += lists.counts[l][q];
-  for (uint32_t size = 2; size <= p2; size <<= 1) {
-    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-      __syncthreads();
-      for (uint32_t i = threadIdx.x; i < p2 / 2; i += blockDim.x) {
-        const uint32_t pos = 2u * i - (i & (stride - 1u));
-        const uint32_t other = pos + stride;
-        const bool fwd = (pos & size) == 0;
-        const MergeItem x = items[pos], y = items[other];
-        if (merge_before(y, x) == fwd) { items[pos] = y; items[other] = x; }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t l = 0; l < kMergeLists; ++l) {
+    if (l < n_lists) {
+      const Hit* src = lists.hits[l] + uint64_t(q) * k;
+      const uint32_t c = cnt[l];
+      for (uint32_t r = threadIdx.x; r < c; r += blockDim.x) {
+        const float f = src[r].score;
+        uint32_t bits;
+        __builtin_memcpy(&bits, &f, 4);
+        sc[l * k + r] = bits;
       }
     }
   }
   __syncthreads();
-  const uint32_t kk = total < k ? total : k;
-  for (uint32_t i = threadIdx.x; i < kk; i += blockDim.x) {
-    Hit h;
-    __builtin_memcpy(&h.score, &items[i].score_bits, 4);
-    h.doc = items[i].doc;
-    out[uint64_t(q) * k + i] = h;
-    out_seg[uint64_t(q) * k + i] = items[i].seg;
+  uint32_t total = 0;
+  for (uint32_t l = 0; l < n_lists; ++l) total += cnt[l];
+  // element i -> (list i % n_lists, position i / n_lists): a wavefront works at one depth
+  for (uint32_t i = threadIdx.x; i < n_lists * k; i += blockDim.x) {
+    const uint32_t l = i % n_lists, p = i / n_lists;
+    if (p >= cnt[l]) continue;
+    const uint32_t s = sc[l * k + p], my_id = sid[l];
+    uint32_t rank = p;
+    for (uint32_t m = 0; m < n_lists && rank < k; ++m) {
+      if (m == l) continue;
+      const bool ties_first = sid[m] < my_id;
+      const uint32_t* v = sc + m * k;
+      uint32_t lo = 0, hi = cnt[m];
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint32_t x = v[mid];
+        if (ties_first ? x >= s : x > s) lo = mid + 1u; else hi = mid;
+      }
+      rank += lo;
+    }
+    if (rank < k) {
+      Hit h{};
+#pragma unroll
+      for (uint32_t m = 0; m < kMergeLists; ++m) {
+        if (m == l) h = lists.hits[m][uint64_t(q) * k + p];
+      }
+      out[uint64_t(q) * k + rank] = h;
+      out_seg[uint64_t(q) * k + rank] = my_id;
+    }
   }
-  if (threadIdx.x == 0) out_counts[q] = kk;
+  if (threadIdx.x == 0) out_counts[q] = total < k ? total : k;
 }
 
 }  // namespace irs_hip

@@ -302,6 +302,55 @@ def case_multi_segment(L, num_docs, max_rank, n_segs=3, k=100, device_merge=True
         r.close()
 
 
+def case_merge_ties(L, n_lists=5, nq=7, k=64, seed=11):
+    """irs_hip_merge_topk alone: few distinct scores (heavy ties across segments), ragged
+    counts including empty lists, segment ids not in list order.  Expected order:
+    (score desc, segment asc, doc asc) — tests/search/wand_test.cpp:72-86."""
+    import ctypes
+    import torch
+    from iresearch_amd import _lib, distributed
+    arch = ctypes.create_string_buffer(64)
+    L.irs_hip_device_arch(0, arch, 64)
+    dev = "cpu" if arch.value.endswith(b"-sim") else "cuda"
+    rng = np.random.default_rng(seed)
+    seg_ids = rng.permutation(n_lists).astype(np.uint32)
+    levels = np.array([0.5, 1.25, 1.25000012, 3.0, 7.5], np.float32)
+    hs, cs, expect = [], [], [[] for _ in range(nq)]
+    for l in range(n_lists):
+        h = np.zeros((nq, k), _lib.HIT)
+        c = np.zeros(nq, np.uint32)
+        for q in range(nq):
+            n = int(rng.integers(0, k + 1)) if (q + l) % 4 else (0 if q % 2 else k)
+            sc = np.sort(rng.choice(levels, n))[::-1]
+            docs = np.zeros(n, np.uint32)
+            # doc ascending inside a run of equal scores (what k_select emits)
+            for v in np.unique(sc):
+                m = sc == v
+                docs[m] = np.sort(rng.choice(100000, int(m.sum()), replace=False)) + 1
+            h[q, :n]["score"], h[q, :n]["doc"], c[q] = sc, docs, n
+            expect[q] += [(float(a), int(seg_ids[l]), int(d)) for a, d in zip(sc, docs)]
+        hs.append(torch.from_numpy(h.view(np.int64).reshape(nq, k).copy()).to(dev))
+        cs.append(torch.from_numpy(c.view(np.int32).copy()).to(dev))
+    out_h = torch.zeros((nq, k), dtype=torch.int64, device=dev)
+    out_s = torch.zeros((nq, k), dtype=torch.int32, device=dev)
+    out_c = torch.zeros((nq,), dtype=torch.int32, device=dev)
+    lists = (ctypes.c_void_p * n_lists)(*[t.data_ptr() for t in hs])
+    counts = (ctypes.c_void_p * n_lists)(*[t.data_ptr() for t in cs])
+    _lib.check(L, L.irs_hip_merge_topk(0, lists, counts, seg_ids.ctypes.data, n_lists, nq, k,
+                                       out_h.data_ptr(), out_s.data_ptr(), out_c.data_ptr(),
+                                       None), "merge")
+    if dev == "cuda":
+        torch.cuda.synchronize()
+    gh = distributed.hits_from_int64(out_h)
+    gs, gc = out_s.cpu().numpy(), out_c.cpu().numpy()
+    for q in range(nq):
+        want = sorted(expect[q], key=lambda t: (-t[0], t[1], t[2]))[:k]
+        assert gc[q] == len(want), q
+        got = [(float(gh[q, i]["score"]), int(gs[q, i]), int(gh[q, i]["doc"]))
+               for i in range(len(want))]
+        assert got == want, q
+
+
 # ------------------------------------------------------------------ errors --
 
 def case_errors(L):

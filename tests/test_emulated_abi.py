@@ -61,5 +61,9 @@ def test_multi_segment(simlib):
     cases.case_multi_segment(simlib, 45_000, 256)
 
 
+def test_merge_ties(simlib):
+    cases.case_merge_ties(simlib)
+
+
 def test_errors(simlib):
     cases.case_errors(simlib)

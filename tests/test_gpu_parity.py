@@ -66,6 +66,11 @@ def test_multi_segment(gpulib):
     cases.case_multi_segment(gpulib, 600_000, 1024, n_segs=4, k=1000)
 
 
+def test_merge_ties(gpulib):
+    cases.case_merge_ties(gpulib)
+    cases.case_merge_ties(gpulib, n_lists=8, nq=5, k=1000, seed=5)
+
+
 def test_errors(gpulib):
     cases.case_errors(gpulib)
 
