@@ -93,6 +93,16 @@ uint64_t irs_hip_segment_device_bytes(const irs_hip_segment* seg);
 int irs_hip_decode_term(irs_hip_segment* seg, uint32_t term, uint32_t* docs,
                         uint32_t* freqs, uint32_t cap, uint32_t* count);
 
+/* postings_reader::bit_union (core/formats/formats_10.cpp:3716-3806; virtual at
+ * core/formats/formats.hpp:182-190): ORs bit `doc` into the caller's bitset
+ * (`size_t* set` in the reference: 64-bit little-endian words, bit index = doc id,
+ * so the set needs num_docs + 1 bits) for every posting of every listed term;
+ * freq blocks are skipped.  IRS_HIP_NO_TERM entries are ignored.  *count receives
+ * what the reference returns: the SUM of the terms' docs_count (not a popcount).
+ * Docs at or beyond 64 * n_words are not representable and are dropped. */
+int irs_hip_bit_union(irs_hip_segment* seg, const uint32_t* terms, uint32_t n_terms,
+                      uint64_t* set, uint64_t n_words, uint64_t* count);
+
 /* The block directory of one term, for inspection/tests: absolute last doc id
  * and `.doc` byte offset of every full 128-doc block — the information the
  * reference keeps in skip level 0 (formats_10.cpp:501-533). */

@@ -398,6 +398,40 @@ int irs_hip_decode_term(irs_hip_segment* seg, uint32_t term, uint32_t* docs, uin
   return IRS_HIP_OK;
 }
 
+int irs_hip_bit_union(irs_hip_segment* seg, const uint32_t* terms, uint32_t n_terms,
+                      uint64_t* set, uint64_t n_words, uint64_t* count) {
+  if (!seg || (!terms && n_terms) || !set || !n_words) return IRS_HIP_EINVAL;
+  if (!rt::set_device(seg->device)) return IRS_HIP_EHIP;
+  uint64_t total = 0;
+  for (uint32_t i = 0; i < n_terms; ++i) {
+    if (terms[i] == IRS_HIP_NO_TERM) continue;
+    if (terms[i] >= seg->dev.num_terms) return IRS_HIP_EINVAL;
+    total += seg->terms[terms[i]].docs_count;  // formats_10.cpp:3796, 3802
+  }
+  if (count) *count = total;
+  if (!n_terms) return IRS_HIP_OK;
+  DevBuf d_terms, d_set;
+  const size_t set_bytes = size_t(n_words) * 8;
+  if (!d_terms.alloc(size_t(n_terms) * 4) || !d_set.alloc(set_bytes)) return IRS_HIP_ENOMEM;
+  if (!rt::h2d(d_terms.p, terms, size_t(n_terms) * 4, nullptr) ||
+      !rt::h2d(d_set.p, set, set_bytes, nullptr))  // bits already set by the caller are kept
+    return IRS_HIP_EHIP;
+  // enough slices to spread the longest lists over the chip, few enough that short
+  // ones do not drown in empty workgroups
+  const uint32_t slices = std::max<uint32_t>(1, std::min<uint32_t>(64, seg->cus * 8 / n_terms));
+  const uint64_t n_bits = n_words * 64;
+  if (seg->dev.layout == kSimd4) {
+    RT_LAUNCH((k_bit_union<kSimd4>), n_terms * slices, kThreads, 0, nullptr, seg->dev,
+              d_terms.as<uint32_t>(), slices, d_set.as<uint32_t>(), n_bits);
+  } else {
+    RT_LAUNCH((k_bit_union<kScalar>), n_terms * slices, kThreads, 0, nullptr, seg->dev,
+              d_terms.as<uint32_t>(), slices, d_set.as<uint32_t>(), n_bits);
+  }
+  if (!rt::last_error_ok() || !rt::d2h(set, d_set.p, set_bytes, nullptr) || !rt::sync(nullptr))
+    return IRS_HIP_EHIP;
+  return IRS_HIP_OK;
+}
+
 int irs_hip_term_directory(irs_hip_segment* seg, uint32_t term, uint32_t* last_docs,
                            uint64_t* offsets, uint32_t cap, uint32_t* count) {
   if (!seg || !count || term >= seg->dev.num_terms) return IRS_HIP_EINVAL;

@@ -5,6 +5,7 @@
 //   k_build_directory  segment open: walk block headers, record per-block
 //                      offset / last doc / bit widths (no decoded data kept)
 //   k_decode_term      bulk decode of one posting list (bit-exact test surface)
+//   k_bit_union        doc bitset of many posting lists (postings_reader::bit_union)
 //   k_plan             per (query, term): first block of every doc tile + tail decode
 //   k_pilot            score every P-th doc tile, derive a per-query score-bin
 //                      threshold that provably keeps the top-k
@@ -207,6 +208,63 @@ k_decode_term(DevSegment seg, uint32_t term, uint32_t* out_docs,
     decode_tail_serial(seg.doc + t.tail_off, t.tail_n, t.tail_base, seg.has_freq != 0,
                        out_docs + t.nblk * kBlock,
                        out_freqs ? out_freqs + t.nblk * kBlock : nullptr, &last);
+  }
+}
+
+// ------------------------------------------------------------- bit union --
+
+// postings_reader::bit_union (formats_10.cpp:3716-3806): set bit `doc` of a doc
+// bitset for every posting of every given term; freq blocks are never touched
+// (the directory knows where each doc block starts).  grid = n_terms * slices:
+// wavefront (slice, w) of a term takes blocks slice*kWaves + w, then strides by
+// slices*kWaves; the wavefront that would take block `nblk` walks the vint tail.
+template<int LAYOUT>
+__global__ void __launch_bounds__(kThreads)
+k_bit_union(DevSegment seg, const uint32_t* term_ids, uint32_t slices, uint32_t* set32,
+            uint64_t n_bits) {
+  const unsigned lane = threadIdx.x & 63u;
+  const uint32_t slice = blockIdx.x % slices;
+  const uint32_t term = term_ids[blockIdx.x / slices];
+  if (term == kNoTerm) return;
+  const DevTerm t = seg.terms[term];
+  auto mark = [&](uint32_t doc) {
+    if (doc < n_bits) atomicOr(&set32[doc >> 5], 1u << (doc & 31u));
+  };
+  const uint32_t first = slice * kWaves + (threadIdx.x >> 6);
+  if (t.docs_count == 0) return;
+  if (t.docs_count == 1) {  // formats_10.cpp:3797-3801
+    if (first == 0 && lane == 0) mark(t.single_doc);
+    return;
+  }
+  const uint32_t stride = slices * kWaves;
+  for (uint32_t item = first; item <= t.nblk; item += stride) {
+    if (item < t.nblk) {
+      const uint64_t e = t.dir_off + item;
+      const uint32_t base = item ? seg.blk_last[e - 1] : kDocMin;
+      uint32_t d0, d1, f0, f1;
+      decode_block<LAYOUT, false>(seg.doc + t.doc_start + seg.blk_off[e],
+                                  seg.blk_bits[e] & 0xFFu, 0, base, lane, d0, d1, f0, f1);
+      mark(d0);
+      mark(d1);
+    } else if (lane == 0 && t.tail_n) {
+      const uint8_t* p = seg.doc + t.tail_off;
+      uint32_t doc = t.tail_base;
+      for (uint32_t i = 0; i < t.tail_n; ++i) {
+        uint32_t len;
+        const uint32_t v = vint_bytes(p, &len);
+        p += len;
+        if (seg.has_freq) {
+          doc += v >> 1;  // shift_unpack_32, store_utils.hpp:266-269
+          if (!(v & 1u)) {
+            vint_bytes(p, &len);
+            p += len;
+          }
+        } else {
+          doc += v;
+        }
+        mark(doc);
+      }
+    }
   }
 }
 

@@ -177,10 +177,10 @@ void encode_term(const uint32_t* docs, const uint32_t* freqs, uint32_t count,
     }
     // BeginDocument :865-878
     buf_docs[n] = docs[i];
-    buf_freqs[n] = freqs[i];
+    buf_freqs[n] = freqs ? freqs[i] : 1u;
     last = docs[i];
     ++n;
-    total_freq += freqs[i];
+    total_freq += freqs ? freqs[i] : 0u;
     if (n == kBlock) {
       // simd::delta_encode<128>(docs, block_last) — simd_utils.hpp:200-249
       uint32_t prev = block_last;
@@ -190,7 +190,7 @@ void encode_term(const uint32_t* docs, const uint32_t* freqs, uint32_t count,
         prev = cur;
       }
       write_block(o, buf_docs, layout);
-      write_block(o, buf_freqs, layout);
+      if (freqs) write_block(o, buf_freqs, layout);  // only fields with IndexFeatures::FREQ (:875-877)
       // EndDocument :639-657
       block_last = last;
       n = 0;
@@ -205,7 +205,9 @@ void encode_term(const uint32_t* docs, const uint32_t* freqs, uint32_t count,
     uint32_t prev = block_last;
     for (uint32_t k = 0; k < n; ++k) {  // tail :689-704
       const uint32_t delta = buf_docs[k] - prev;
-      if (buf_freqs[k] == 1) {
+      if (!freqs) {
+        put_vint(o, delta);  // field without FREQ (:705-709)
+      } else if (buf_freqs[k] == 1) {
         put_vint(o, (delta << 1) | 1u);
       } else {
         put_vint(o, delta << 1);
@@ -350,10 +352,10 @@ int64_t irs_synth_encode_term(const uint32_t* docs, const uint32_t* freqs,
                               uint32_t count, uint32_t segment_docs,
                               uint32_t layout, uint8_t* out, uint64_t out_cap,
                               irs_synth_term_meta* meta) {
-  if (!meta || (count && (!docs || !freqs))) return -1;
+  if (!meta || (count && !docs)) return -1;  // freqs == NULL: a field without FREQ
   for (uint32_t i = 0; i < count; ++i) {
     // formats_10.cpp:866, 885-889: docs must be strictly ascending and valid
-    if (docs[i] < kDocMin || (i && docs[i] <= docs[i - 1]) || freqs[i] == 0)
+    if (docs[i] < kDocMin || (i && docs[i] <= docs[i - 1]) || (freqs && freqs[i] == 0))
       return -1;
   }
   Bytes o;

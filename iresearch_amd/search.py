@@ -159,9 +159,9 @@ class SegmentReader:
         self.handle = h
 
     @classmethod
-    def from_synth(cls, seg, device=0, L=None):
+    def from_synth(cls, seg, device=0, L=None, has_freq=True):
         return cls(seg.doc_file, seg.metas, seg.num_docs, seg.layout, seg.norms, 1,
-                   seg.docs_with_field, seg.total_term_freq, device, True, L)
+                   seg.docs_with_field, seg.total_term_freq, device, has_freq, L)
 
     def close(self):
         if self.handle:
@@ -186,6 +186,17 @@ class SegmentReader:
             self.handle, term, docs.ctypes.data, None if freqs is None else freqs.ctypes.data,
             docs.size, C.byref(cnt)), "irs_hip_decode_term")
         return docs[:cnt.value], (None if freqs is None else freqs[:cnt.value])
+
+    def bit_union(self, terms, n_words: int, initial=None):
+        """postings_reader::bit_union: (bitset as uint64 words, sum of docs_count)."""
+        t = np.ascontiguousarray(terms, np.uint32)
+        bits = np.zeros(n_words, np.uint64) if initial is None else \
+            np.ascontiguousarray(initial, np.uint64).copy()
+        cnt = C.c_uint64()
+        _lib.check(self.L, self.L.irs_hip_bit_union(
+            self.handle, t.ctypes.data if t.size else None, t.size, bits.ctypes.data, n_words,
+            C.byref(cnt)), "irs_hip_bit_union")
+        return bits, cnt.value
 
     def term_directory(self, term: int):
         nb = int(self.metas[term]["docs_count"]) // 128

@@ -132,12 +132,14 @@ def build_segment(num_docs: int, max_rank: int = 4096, *, layout: int = LAYOUT_S
 def encode_term(docs, freqs, segment_docs: int, layout: int = LAYOUT_SIMD4):
     """postings_writer::write for one explicit list -> (bytes, meta)."""
     docs = np.ascontiguousarray(docs, dtype=np.uint32)
-    freqs = np.ascontiguousarray(freqs, dtype=np.uint32)
-    assert docs.shape == freqs.shape
+    if freqs is not None:  # None: a field without IndexFeatures::FREQ
+        freqs = np.ascontiguousarray(freqs, dtype=np.uint32)
+        assert docs.shape == freqs.shape
     cap = 64 + 12 * len(docs) + 1024
     out = np.zeros(cap, np.uint8)
     meta = np.zeros(1, TERM_META)
-    n = lib().irs_synth_encode_term(docs.ctypes.data, freqs.ctypes.data, len(docs),
+    n = lib().irs_synth_encode_term(docs.ctypes.data,
+                                    None if freqs is None else freqs.ctypes.data, len(docs),
                                     segment_docs, layout, out.ctypes.data, cap,
                                     meta.ctypes.data)
     if n < 0:

@@ -70,6 +70,10 @@ def lib():
         L.orc_read_block.restype = C.c_int64
         L.orc_decode_term.argtypes = [vp, u64, C.c_int, vp, vp, vp, u64]
         L.orc_decode_term.restype = C.c_int64
+        L.orc_decode_term_field.argtypes = [vp, u64, C.c_int, C.c_int, vp, vp, vp, u64]
+        L.orc_decode_term_field.restype = C.c_int64
+        L.orc_bit_union.argtypes = [vp, u64, C.c_int, C.c_int, vp, u32, vp, u64]
+        L.orc_bit_union.restype = C.c_int64
         L.orc_read_skip0.argtypes = [vp, u64, vp, vp, vp, u64, C.POINTER(u32)]
         L.orc_read_skip0.restype = C.c_int64
         L.orc_check_doc_header.argtypes = [vp, u64, C.POINTER(i32)]
@@ -129,18 +133,34 @@ def unpack(words, bits: int, layout: int) -> np.ndarray:
     return out
 
 
-def decode_term(doc_file: np.ndarray, meta, layout: int, want_freq: bool = True):
+def decode_term(doc_file: np.ndarray, meta, layout: int, want_freq: bool = True,
+                field_has_freq: bool = True):
     m = np.zeros(1, TERM_META)
     for k in TERM_META.names:
         m[0][k] = meta[k]
     n = int(m[0]["docs_count"])
     docs = np.zeros(n, np.uint32)
     freqs = np.zeros(n, np.uint32) if want_freq else None
-    got = lib().orc_decode_term(doc_file.ctypes.data, doc_file.size, layout, m.ctypes.data,
-                                docs.ctypes.data, freqs.ctypes.data if want_freq else None, n)
+    got = lib().orc_decode_term_field(doc_file.ctypes.data, doc_file.size, layout,
+                                      int(field_has_freq), m.ctypes.data, docs.ctypes.data,
+                                      freqs.ctypes.data if want_freq else None, n)
     if got != n:
         raise ValueError("orc_decode_term: %d != %d" % (got, n))
     return docs, freqs
+
+
+def bit_union(doc_file: np.ndarray, metas, layout: int, has_freq: bool, n_words: int,
+              initial: np.ndarray | None = None):
+    m = np.zeros(len(metas), TERM_META)
+    for i, meta in enumerate(metas):
+        for k in TERM_META.names:
+            m[i][k] = meta[k]
+    bits = np.zeros(n_words, np.uint64) if initial is None else initial.copy()
+    n = lib().orc_bit_union(doc_file.ctypes.data, doc_file.size, layout, int(has_freq),
+                            m.ctypes.data, len(metas), bits.ctypes.data, n_words)
+    if n < 0:
+        raise ValueError("orc_bit_union failed: %d" % n)
+    return bits, int(n)
 
 
 def read_skip0(doc_file: np.ndarray, meta):

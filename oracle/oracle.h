@@ -58,6 +58,16 @@ int64_t orc_skip_block(const uint8_t* p, const uint8_t* end);
 int64_t orc_decode_term(const uint8_t* doc_file, uint64_t len, int layout,
                         const orc_term_meta* meta, uint32_t* docs,
                         uint32_t* freqs, uint64_t cap);
+/* Same for a field indexed without IndexFeatures::FREQ when field_has_freq == 0
+ * (no freq blocks, tail entries are plain vint deltas; freqs must be NULL). */
+int64_t orc_decode_term_field(const uint8_t* doc_file, uint64_t len, int layout,
+                              int field_has_freq, const orc_term_meta* meta,
+                              uint32_t* docs, uint32_t* freqs, uint64_t cap);
+/* postings_reader::bit_union (formats_10.cpp:3716-3806): ORs bit `doc` into `set`
+ * for every posting of every term; returns the sum of docs_count. */
+int64_t orc_bit_union(const uint8_t* doc_file, uint64_t len, int layout,
+                      int has_freq, const orc_term_meta* metas,
+                      uint32_t n_terms, uint64_t* set, uint64_t n_words);
 /* Level-0 skip entries of a term with docs_count > 128: absolute last doc of
  * each skipped block and absolute file offset of the following block. */
 int64_t orc_read_skip0(const uint8_t* doc_file, uint64_t len,

@@ -20,6 +20,7 @@ typedef struct {
   orc_in in;
   int layout;
   int want_freq;
+  int field_no_freq; /* FieldTraits::frequency() == false: no freq blocks, tail = vint(delta) */
   uint32_t docs[ORC_BLOCK];
   uint32_t freqs[ORC_BLOCK];
   uint32_t begin; /* index into docs; ORC_BLOCK == end */

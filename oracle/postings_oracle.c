@@ -234,6 +234,11 @@ static void it_read_tail(orc_doc_iterator* it) {
   it->begin = i;
   for (; i < ORC_BLOCK; ++i) {
     const uint32_t v = in_vint(&it->in);
+    if (it->field_no_freq) { /* :1786-1788 */
+      it->docs[i] = v;
+      it->freqs[i] = 1;
+      continue;
+    }
     it->docs[i] = v >> 1; /* shift_unpack_32 */
     if (v & 1u) {
       it->freqs[i] = 1;
@@ -248,7 +253,9 @@ static void it_read_tail(orc_doc_iterator* it) {
 static void it_refill(orc_doc_iterator* it) {
   if (it->left >= ORC_BLOCK) {
     in_block(&it->in, it->layout, it->docs);
-    if (it->want_freq)
+    if (it->field_no_freq)
+      ; /* nothing follows the doc block (:1746-1750) */
+    else if (it->want_freq)
       in_block(&it->in, it->layout, it->freqs);
     else
       in_skip_block(&it->in);
@@ -286,10 +293,18 @@ int orc_it_next(orc_doc_iterator* it) {
 int64_t orc_decode_term(const uint8_t* doc_file, uint64_t len, int layout,
                         const orc_term_meta* meta, uint32_t* docs,
                         uint32_t* freqs, uint64_t cap) {
+  return orc_decode_term_field(doc_file, len, layout, 1, meta, docs, freqs, cap);
+}
+
+int64_t orc_decode_term_field(const uint8_t* doc_file, uint64_t len, int layout,
+                              int field_has_freq, const orc_term_meta* meta,
+                              uint32_t* docs, uint32_t* freqs, uint64_t cap) {
   orc_doc_iterator it;
   uint64_t n = 0;
   if (meta->docs_count == 0) return 0;
+  if (!field_has_freq && freqs) return -3; /* cannot request FREQ from such a field */
   orc_it_prepare(&it, doc_file, len, layout, meta, freqs != NULL);
+  it.field_no_freq = !field_has_freq;
   while (orc_it_next(&it)) {
     if (n >= cap) return -2;
     docs[n] = it.doc;
@@ -297,6 +312,61 @@ int64_t orc_decode_term(const uint8_t* doc_file, uint64_t len, int layout,
     ++n;
   }
   return it.in.bad ? -1 : (int64_t)n;
+}
+
+/* postings_reader::bit_union + the free ::bit_union — formats_10.cpp:3716-3806.
+ * A separate code path of the reference (no iterator): read doc block, skip freq
+ * block, `doc += delta; set_bit(set[doc / 64], doc % 64)`; then the vint tail.
+ * Wand data (`FormatTraits::wand() && docs_count < 128`, :3776-3779) is absent
+ * from the indexes used here (0 scorers at index time). Returns the sum of
+ * docs_count like the reference, or <0 on corruption. */
+int64_t orc_bit_union(const uint8_t* doc_file, uint64_t len, int layout,
+                      int has_freq, const orc_term_meta* metas,
+                      uint32_t n_terms, uint64_t* set, uint64_t n_words) {
+  uint32_t docs[ORC_BLOCK];
+  uint64_t count = 0;
+  uint32_t t;
+  for (t = 0; t < n_terms; ++t) {
+    const orc_term_meta* m = &metas[t];
+    if (m->docs_count > 1) {
+      orc_in in;
+      uint32_t nb = m->docs_count / ORC_BLOCK, left = m->docs_count % ORC_BLOCK;
+      uint32_t doc = 1; /* doc_limits::min() :3721 */
+      if (m->doc_start > len) return -1;
+      in.p = doc_file + m->doc_start;
+      in.end = doc_file + len;
+      in.bad = 0;
+      while (nb--) {
+        uint32_t i;
+        in_block(&in, layout, docs);
+        if (has_freq) in_skip_block(&in);
+        if (in.bad) return -1;
+        for (i = 0; i < ORC_BLOCK; ++i) {
+          doc += docs[i];
+          if (doc / 64 < n_words) set[doc / 64] |= (uint64_t)1 << (doc % 64);
+        }
+      }
+      while (left--) {
+        uint32_t delta;
+        if (has_freq) {
+          const uint32_t v = in_vint(&in); /* shift_unpack_32 :3743-3745 */
+          delta = v >> 1;
+          if (!(v & 1u)) (void)in_vint(&in);
+        } else {
+          delta = in_vint(&in);
+        }
+        if (in.bad) return -1;
+        doc += delta;
+        if (doc / 64 < n_words) set[doc / 64] |= (uint64_t)1 << (doc % 64);
+      }
+      count += m->docs_count;
+    } else if (m->docs_count == 1) {
+      const uint32_t doc = 1u + (uint32_t)m->e_skip_start; /* e_single_doc :3797 */
+      if (doc / 64 < n_words) set[doc / 64] |= (uint64_t)1 << (doc % 64);
+      ++count;
+    }
+  }
+  return (int64_t)count;
 }
 
 /* SkipReaderBase::Prepare (skip_list.cpp:111-156) + ReadState

@@ -242,6 +242,50 @@ def case_decode_without_freq(L, layout):
     sr.close()
 
 
+def case_bit_union(L, layout, has_freq=True):
+    """postings_reader::bit_union (formats_10.cpp:3716-3806): bit-exact bitset and the
+    reference's return value (sum of docs_count), over single-doc terms, tail-only terms,
+    exact multiples of 128, all-equal blocks, duplicates and pre-set bits."""
+    rng = np.random.default_rng(99)
+    n_docs = 70_000
+    lists = [
+        np.array([7], np.uint32),                                        # single doc
+        np.sort(rng.choice(n_docs, 100, replace=False)).astype(np.uint32) + 1,   # tail only
+        np.arange(1, 129, dtype=np.uint32),                              # one ALL_EQUAL block
+        np.arange(5, 5 + 3 * 384, 3, dtype=np.uint32),                   # 3 ALL_EQUAL blocks
+        np.sort(rng.choice(n_docs, 128 * 40 + 77, replace=False)).astype(np.uint32) + 1,
+        np.sort(rng.choice(n_docs, 128 * 9, replace=False)).astype(np.uint32) + 1,
+        np.array([n_docs], np.uint32),                                   # last representable doc
+    ]
+    freqs = [rng.integers(1, 9, l.size).astype(np.uint32) if has_freq else None for l in lists]
+    seg = synth.segment_from_lists(list(zip(lists, freqs)), n_docs, layout, norms=False)
+    sr = search.SegmentReader.from_synth(seg, L=L, has_freq=has_freq)
+    if not has_freq:  # the no-FREQ framing also goes through the plain decoder
+        for t, l in enumerate(lists):
+            d, _ = sr.decode_term(t, want_freq=False)
+            od, _ = oracle.decode_term(seg.doc_file, seg.metas[t], layout, want_freq=False,
+                                       field_has_freq=False)
+            assert np.array_equal(d, l) and np.array_equal(od, l), t
+    n_words = (n_docs + 1 + 63) // 64
+    for terms in ([0], [1, 2], [4], list(range(len(lists))), [4, 4, 0], []):
+        init = np.zeros(n_words, np.uint64)
+        init[3] = np.uint64(0x8000000000000001)   # bits already set by the caller survive
+        got, cnt = sr.bit_union(terms, n_words, init)
+        want, ocnt = oracle.bit_union(seg.doc_file, [seg.metas[t] for t in terms], layout,
+                                      has_freq, n_words, init)
+        assert cnt == ocnt == sum(lists[t].size for t in terms)
+        assert np.array_equal(got, want), terms
+        expect = init.copy()
+        for t in terms:
+            np.bitwise_or.at(expect, lists[t] // 64, np.uint64(1) << (lists[t] % 64).astype(np.uint64))
+        assert np.array_equal(got, expect), terms
+    # a bitset too short for the segment: docs beyond it are dropped, nothing is written past it
+    got, cnt = sr.bit_union([4], 100)
+    want, _ = oracle.bit_union(seg.doc_file, [seg.metas[4]], layout, has_freq, 100)
+    assert np.array_equal(got, want) and cnt == lists[4].size
+    sr.close()
+
+
 def case_multi_segment(L, num_docs, max_rank, n_segs=3, k=100, device_merge=True):
     """Segments are independent units with private doc ids; statistics are global
     (term_filter.cpp:102-125); one heap over all segments (index-search.cpp:719-779)."""

@@ -57,6 +57,12 @@ def test_decode_without_freq(simlib, layout):
     cases.case_decode_without_freq(simlib, layout)
 
 
+@pytest.mark.parametrize("layout", [0, 1])
+def test_bit_union(simlib, layout):
+    cases.case_bit_union(simlib, layout)
+    cases.case_bit_union(simlib, layout, has_freq=False)
+
+
 def test_multi_segment(simlib):
     cases.case_multi_segment(simlib, 45_000, 256)
 

@@ -62,6 +62,12 @@ def test_decode_without_freq(gpulib, layout):
     cases.case_decode_without_freq(gpulib, layout)
 
 
+@pytest.mark.parametrize("layout", [0, 1])
+def test_bit_union(gpulib, layout):
+    cases.case_bit_union(gpulib, layout)
+    cases.case_bit_union(gpulib, layout, has_freq=False)
+
+
 def test_multi_segment(gpulib):
     cases.case_multi_segment(gpulib, 600_000, 1024, n_segs=4, k=1000)
 
