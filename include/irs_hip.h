@@ -214,6 +214,11 @@ int irs_hip_batch_timings(irs_hip_batch* batch, float ms[IRS_HIP_K_COUNT]);
  * posting (norm_width) + 8*k result bytes; and the number of postings. */
 int irs_hip_batch_work(irs_hip_batch* batch, uint64_t* algorithmic_bytes,
                        uint64_t* postings);
+/* How many times fetching results had to re-execute the batch so far: the pilot's
+ * estimated threshold left fewer than k candidates for some query (re-run with the
+ * provable threshold), or the candidate buffer overflowed (exact re-run, then a
+ * larger buffer).  Results are exact either way; this only tells what it cost. */
+int irs_hip_batch_reruns(irs_hip_batch* batch, uint32_t* count);
 
 /* Multi-segment / multi-GPU merge: merges `n_lists` per-query
  * top-k lists (device pointers, each [n_queries][k] hits + [n_queries] counts,

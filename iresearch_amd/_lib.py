@@ -59,7 +59,7 @@ SYMBOLS = (
     "irs_hip_batch_results", "irs_hip_batch_device_results",
     "irs_hip_batch_results_to_device", "irs_hip_batch_destroy",
     "irs_hip_query_batch", "irs_hip_batch_configure", "irs_hip_batch_profile",
-    "irs_hip_batch_timings", "irs_hip_batch_work", "irs_hip_merge_topk",
+    "irs_hip_batch_timings", "irs_hip_batch_work", "irs_hip_batch_reruns", "irs_hip_merge_topk",
 )
 
 
@@ -97,6 +97,7 @@ def bind(L: C.CDLL) -> C.CDLL:
     L.irs_hip_batch_profile.argtypes, L.irs_hip_batch_profile.restype = [vp, C.c_int], C.c_int
     L.irs_hip_batch_timings.argtypes = [vp, P(C.c_float)]
     L.irs_hip_batch_timings.restype = C.c_int
+    L.irs_hip_batch_reruns.argtypes, L.irs_hip_batch_reruns.restype = [vp, P(u32)], C.c_int
     L.irs_hip_batch_work.argtypes = [vp, P(u64), P(u64)]
     L.irs_hip_batch_work.restype = C.c_int
     L.irs_hip_merge_topk.argtypes = [i32, vp, vp, vp, u32, u32, u32, vp, vp, vp, vp]

@@ -18,7 +18,8 @@ using namespace irs_hip;
 namespace {
 
 constexpr uint32_t kDefaultTile = 4096;
-constexpr uint32_t kDefaultStride = 16;
+constexpr uint32_t kDefaultStride = 64;
+constexpr uint32_t kPilotMargin = 3;   // estimated threshold: aim at margin * k candidates
 constexpr uint32_t kDefaultWgThreads = 512;  // 8 wavefronts share one tile (measured best)
 
 struct DevBuf {  // owning device allocation
@@ -84,6 +85,8 @@ struct irs_hip_batch {
   irs_hip_segment* seg = nullptr;
   uint32_t nq = 0, jt = 0, k_max = 0;
   uint32_t tile = 0 /* 0 = pick by accumulator width */, stride = kDefaultStride, cand_cap = 0;
+  bool estimate = true;  // k_pilot picks an estimated threshold (falls back to the sound one)
+  uint32_t reruns = 0;   // recoveries so far (underflow or overflow re-runs)
   uint32_t n_tiles = 0;
   uint32_t stride_eff = 1;  // pilot stride actually used (>= 4 pilot tiles when possible)
   uint32_t wg_threads = kDefaultWgThreads;  // threads per pilot/score workgroup
@@ -133,6 +136,13 @@ bool big_smem(K kernel, size_t bytes) {
   return rt::allow_dynamic_smem(reinterpret_cast<const void*>(kernel), bytes);
 }
 
+// Candidate slots per query.  An estimated threshold aims at kPilotMargin * k
+// candidates; the sound one admits about k * (pilot stride).
+static uint32_t default_cand_cap(const irs_hip_batch* b) {
+  const uint64_t per_k = b->estimate ? 16ull : 4ull * b->stride_eff;
+  return uint32_t(std::min<uint64_t>(std::max<uint64_t>(per_k * b->k_max, 16384), 262144));
+}
+
 // launch helpers: one instantiation per (accumulator width, layout, tile, AND)
 template<typename ACC, int LAYOUT, int TILE, bool AND>
 bool launch_pilot(irs_hip_batch* b, rt::stream_t st) {
@@ -141,7 +151,8 @@ bool launch_pilot(irs_hip_batch* b, rt::stream_t st) {
   if (!big_smem(kern, smem)) return false;
   RT_LAUNCH(kern, b->nq, b->wg_threads, smem, st, b->seg->dev, b->d_queries.as<DevQuery>(),
             b->d_qterms.as<DevQTerm>(), b->jt, b->n_tiles, b->stride_eff,
-            b->d_first.as<uint32_t>(), b->d_tails.as<DevTail>(), b->d_bstar.as<uint32_t>());
+            b->d_first.as<uint32_t>(), b->d_tails.as<DevTail>(), b->d_bstar.as<uint32_t>(),
+            b->estimate ? kPilotMargin : 0u);
   return rt::last_error_ok();
 }
 
@@ -210,11 +221,7 @@ bool ensure_scratch(irs_hip_batch* b) {
     const uint32_t t = uint32_t(std::atoi(e));
     if (t == 256 || t == 512 || t == 1024) b->wg_threads = t;
   }
-  if (b->cand_cap == 0) {
-    uint64_t cap = 4ull * b->stride * b->k_max;
-    cap = std::min<uint64_t>(std::max<uint64_t>(cap, 16384), 262144);
-    b->cand_cap = uint32_t(cap);
-  }
+  if (b->cand_cap == 0) b->cand_cap = default_cand_cap(b);
   const uint64_t rows = uint64_t(b->nq) * b->jt;
   if (!b->d_first.alloc(rows * (b->n_tiles + 1) * sizeof(uint32_t)) ||
       !b->d_tails.alloc(rows * sizeof(DevTail)) ||
@@ -701,11 +708,18 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st) {
   // 4. exact top-k
   ok = ok && mark(2 * IRS_HIP_K_SELECT);
   if (ok) {
-    RT_LAUNCH(k_select, b->nq, kThreads, 0, st, b->d_queries.as<DevQuery>(),
-              b->d_cands.as<uint64_t>(), b->cand_cap, b->d_cand_count.as<uint32_t>(),
-              b->d_out.as<Hit>(), b->k_max, b->d_out_count.as<uint32_t>(),
-              b->d_status.as<uint32_t>());
-    ok = rt::last_error_ok();
+    uint32_t sort_cap = 64;
+    while (sort_cap < b->k_max) sort_cap <<= 1;
+    const uint32_t stage_cap = std::min<uint32_t>(b->cand_cap, kSelectStage);
+    const size_t smem = size_t(sort_cap + stage_cap) * sizeof(uint64_t);
+    ok = big_smem(k_select, smem);
+    if (ok) {
+      RT_LAUNCH(k_select, b->nq, kThreads, smem, st, b->d_queries.as<DevQuery>(),
+                b->d_cands.as<uint64_t>(), b->cand_cap, b->d_cand_count.as<uint32_t>(),
+                b->d_hits.as<unsigned long long>(), b->d_out.as<Hit>(), b->k_max,
+                b->d_out_count.as<uint32_t>(), b->d_status.as<uint32_t>(), stage_cap, sort_cap);
+      ok = rt::last_error_ok();
+    }
   }
   ok = ok && mark(2 * IRS_HIP_K_SELECT + 1);
   b->ran = true;
@@ -718,10 +732,33 @@ int irs_hip_batch_run(irs_hip_batch* b, void* stream) {
   return run_impl(b, static_cast<rt::stream_t>(stream));
 }
 
-// The candidate buffer overflowed (k_select flagged it): the pilot sample was
-// not representative, or many docs tie at the k-th score bin.  Re-run exactly:
-// first with a full histogram pass (stride 1), then with the buffer grown to the
-// largest candidate count seen.  Results are never silently truncated.
+// k_select flagged a problem with the candidates of some query.
+//   underflow: the estimated threshold was too high.  Re-run with the sound one
+//     (the batch stays in sound mode from then on).
+//   overflow: the candidate buffer was too small — the pilot sample was not
+//     representative, or many docs tie at the k-th score bin.  Re-run exactly:
+//     first with a full histogram pass (stride 1), then with the buffer grown to
+//     the largest candidate count seen.
+// Results are never silently truncated.
+static int recover_overflow(irs_hip_batch* b);
+static int recover(irs_hip_batch* b, uint32_t status) {
+  ++b->reruns;
+  if (status & kStatusUnderflow) {
+    b->estimate = false;
+    const uint32_t cap = default_cand_cap(b);  // the sound threshold admits more candidates
+    if (cap > b->cand_cap) {
+      if (!b->d_cands.alloc(uint64_t(b->nq) * cap * sizeof(uint64_t))) return IRS_HIP_ENOMEM;
+      b->cand_cap = cap;
+    }
+    const int rc = run_impl(b, b->stream);
+    if (rc != IRS_HIP_OK) return rc;
+    if (!rt::d2h(&status, b->d_status.p, 4, b->stream) || !rt::sync(b->stream))
+      return IRS_HIP_EHIP;
+    if (status & kStatusUnderflow) return IRS_HIP_EHIP;  // cannot happen with a sound threshold
+  }
+  return (status & kStatusOverflow) ? recover_overflow(b) : IRS_HIP_OK;
+}
+
 static int recover_overflow(irs_hip_batch* b) {
   constexpr uint64_t kMaxCandBytes = 16ull << 30;
   for (int attempt = 0; attempt < 3; ++attempt) {
@@ -756,6 +793,12 @@ int irs_hip_batch_timings(irs_hip_batch* b, float ms[IRS_HIP_K_COUNT]) {
   return IRS_HIP_OK;
 }
 
+int irs_hip_batch_reruns(irs_hip_batch* b, uint32_t* count) {
+  if (!b || !count) return IRS_HIP_EINVAL;
+  *count = b->reruns;
+  return IRS_HIP_OK;
+}
+
 int irs_hip_batch_work(irs_hip_batch* b, uint64_t* algorithmic_bytes, uint64_t* postings) {
   if (!b) return IRS_HIP_EINVAL;
   if (algorithmic_bytes) *algorithmic_bytes = b->alg_bytes;
@@ -776,8 +819,8 @@ int irs_hip_batch_results(irs_hip_batch* b, irs_hip_hit* hits, uint32_t k_stride
   }
   if (!rt::d2h(&status, b->d_status.p, 4, b->stream) || !rt::sync(b->stream))
     return IRS_HIP_EHIP;
-  if (status & kStatusOverflow) {
-    const int rc = recover_overflow(b);
+  if (status & (kStatusOverflow | kStatusUnderflow)) {
+    const int rc = recover(b, status);
     if (rc != IRS_HIP_OK) return rc;
     status = 0;
   }
@@ -814,8 +857,8 @@ int irs_hip_batch_results_to_device(irs_hip_batch* b, void* d_hits, void* d_coun
   uint32_t status = 0;
   if (!rt::d2h(&status, b->d_status.p, 4, b->stream) || !rt::sync(b->stream))
     return IRS_HIP_EHIP;
-  if (status & kStatusOverflow) {
-    const int rc = recover_overflow(b);
+  if (status & (kStatusOverflow | kStatusUnderflow)) {
+    const int rc = recover(b, status);
     if (rc != IRS_HIP_OK) return rc;
     if (!rt::sync(b->stream)) return IRS_HIP_EHIP;
   }

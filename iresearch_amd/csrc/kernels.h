@@ -25,12 +25,12 @@ constexpr uint32_t kThreads = 256;      // 4 wavefronts per workgroup (utility k
 constexpr uint32_t kTileThreadsMax = 1024;  // pilot/score workgroups: 256..1024 threads
 constexpr uint32_t kWaves = kThreads / 64;
 constexpr uint32_t kLocalCands = 256;   // per-tile candidate staging slots in LDS
-constexpr uint32_t kSelectLds = 4096;   // keys sorted in LDS by k_select
 constexpr uint32_t kItemChunk = 256;    // (term, block) work items staged in LDS at a time
 
 enum : uint32_t {
   kStatusCorrupt = 1u,   // malformed block header / out-of-bounds offset
   kStatusOverflow = 2u,  // candidate buffer exhausted
+  kStatusUnderflow = 4u, // an estimated threshold left fewer than k candidates
 };
 
 // ------------------------------------------------------------- directory --
@@ -886,14 +886,23 @@ __device__ __forceinline__ void tile_accumulate(const DevSegment& seg, const Dev
 }
 
 // One workgroup per query scores the tiles {phase, phase+P, ...}, histograms
-// their scores into kBins linear bins over [0, U] and picks the largest bin b*
-// with at least k docs at or above it.  Those docs exist, so the final k-th
-// score is >= the lower edge of b*: k_score may drop everything below b*.
+// their scores into kBins linear bins over [0, U] and picks a bin b*; k_score
+// drops everything below b*.
+//   sound (margin == 0): the largest bin with at least k sampled docs at or above
+//     it.  Those docs exist, so the final k-th score is >= the lower edge of b*.
+//     The full set then holds about k*P candidates.
+//   estimated (margin > 0): the largest bin with at least margin*k*(sampled
+//     tiles)/(all tiles) sampled docs at or above it (never more than k, never less
+//     than kPilotMinSample), i.e. an expected margin*k candidates.  Not a proof:
+//     k_select checks "fewer than k candidates although more docs matched"
+//     (kStatusUnderflow) and the host then re-runs the batch in sound mode.
+constexpr uint32_t kPilotMinSample = 48;
+
 template<typename ACC, int LAYOUT, int TILE, bool AND>
 __global__ void __launch_bounds__(kTileThreadsMax)
 k_pilot(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_t jt,
         uint32_t n_tiles, uint32_t stride, const uint32_t* first, const DevTail* tails,
-        uint32_t* bstar) {
+        uint32_t* bstar, uint32_t margin) {
   RT_DYN_SMEM(smem);
   unsigned char* rest;
   const TileSmemT<ACC> sm = carve<ACC, TILE, AND>(smem, &rest);
@@ -918,6 +927,15 @@ k_pilot(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
     }
     __syncthreads();
   }
+  // docs the sample must show at or above b*
+  uint32_t need = qd.k;
+  if (margin) {
+    const uint32_t phase = (q * 7u) % stride;
+    const uint32_t sampled = phase < n_tiles ? (n_tiles - phase + stride - 1) / stride : 0u;
+    const uint64_t est = (uint64_t(margin) * qd.k * sampled + n_tiles - 1) / n_tiles;
+    const uint32_t lo = est < kPilotMinSample ? kPilotMinSample : uint32_t(est < 0xFFFFFFFFull ? est : 0xFFFFFFFFull);
+    need = lo < qd.k ? lo : qd.k;
+  }
   // suffix search: lane L of wave 0 owns the 8 bins of chunk 63-L
   if (threadIdx.x < 64) {
     const unsigned lane = threadIdx.x;
@@ -925,16 +943,16 @@ k_pilot(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
     uint32_t s = 0;
     for (uint32_t i = 0; i < kBins / 64; ++i) s += hist[chunk * (kBins / 64) + i];
     const uint32_t incl = wave::inclusive_scan(s);  // docs in chunks >= chunk
-    const uint64_t reach = wave::ballot(incl >= qd.k);
+    const uint64_t reach = wave::ballot(incl >= need);
     uint32_t result = 0;
     if (reach) {
-      const int src = __builtin_ctzll(reach);  // highest chunk reaching k
+      const int src = __builtin_ctzll(reach);  // highest chunk reaching `need`
       const uint32_t above = wave::bcast(incl - s, src);
       const uint32_t c = 63u - uint32_t(src);
       uint32_t cum = above;
       for (int i = int(kBins / 64) - 1; i >= 0; --i) {
         cum += hist[c * (kBins / 64) + uint32_t(i)];
-        if (cum >= qd.k) { result = c * (kBins / 64) + uint32_t(i); break; }
+        if (cum >= need) { result = c * (kBins / 64) + uint32_t(i); break; }
       }
     }
     if (lane == 0) bstar[q] = result;
@@ -1394,76 +1412,105 @@ __device__ __forceinline__ void bitonic_desc(uint64_t* a, uint32_t n) {
   __syncthreads();
 }
 
-// One workgroup per query: exact top-k of the candidate keys.  Keys are unique
-// ((score, doc) pairs), descending key order == (score desc, doc asc) — the
+// One workgroup (kThreads) per query: exact top-k of the candidate keys.  Keys are
+// unique ((score, doc) pairs), descending key order == (score desc, doc asc) — the
 // deterministic refinement of the harness heap (index-search.cpp:745-787).
+//   1. the candidates are staged in LDS once (up to `stage_cap`; beyond that the
+//      passes re-read them from global memory);
+//   2. if there are more than `sort_cap` of them, an MSB-first radix select (8 bits
+//      per pass, histogram in LDS, bucket search by a 256-thread suffix scan) finds
+//      the smallest key that still belongs to the top k; it stops at the first pass
+//      whose bucket is needed entirely;
+//   3. the survivors (exactly min(k, n): keys are unique) are sorted by a bitonic
+//      network in LDS.
+// Dynamic LDS: stage_cap + sort_cap keys; sort_cap = pow2ceil(k_max).
+constexpr uint32_t kSelectStage = 8192;
+
 __global__ void __launch_bounds__(kThreads)
 k_select(const DevQuery* queries, const uint64_t* cands, uint32_t cand_cap,
-         const uint32_t* cand_count, Hit* out, uint32_t k_max, uint32_t* out_count,
-         uint32_t* status) {
-  __shared__ uint64_t keys[kSelectLds];
+         const uint32_t* cand_count, const unsigned long long* hits, Hit* out, uint32_t k_max,
+         uint32_t* out_count, uint32_t* status, uint32_t stage_cap, uint32_t sort_cap) {
+  RT_DYN_SMEM(smem);
+  uint64_t* keys = reinterpret_cast<uint64_t*>(smem);         // [sort_cap]
+  uint64_t* stage = keys + sort_cap;                          // [stage_cap]
   __shared__ uint32_t hist[256];
+  __shared__ uint32_t wsum[kWaves];
   __shared__ uint64_t sh_prefix;
-  __shared__ uint32_t sh_want, sh_n;
+  __shared__ uint32_t sh_want, sh_n, sh_done;
+  const uint32_t tid = threadIdx.x;
+  const unsigned lane = tid & 63u, wv = tid >> 6;
   const uint32_t q = blockIdx.x;
   const DevQuery qd = queries[q];
   uint32_t n = cand_count[q];
   if (n > cand_cap) {
-    if (threadIdx.x == 0) atomicOr(status, kStatusOverflow);
+    if (tid == 0) atomicOr(status, kStatusOverflow);
     n = cand_cap;
   }
+  // an estimated threshold (k_pilot) cut off docs that belong to the top k
+  if (n < qd.k && hits[q] > n && tid == 0) atomicOr(status, kStatusUnderflow);
   const uint64_t* src = cands + uint64_t(q) * cand_cap;
   const uint32_t kk = qd.k < n ? qd.k : n;
-  uint32_t m = n;  // keys that end up in LDS
-  if (n > kSelectLds) {
-    // MSB-first radix select of the kk-th largest key, 8 bits per pass
-    if (threadIdx.x == 0) { sh_prefix = 0; sh_want = kk; }
+  const bool staged = n <= stage_cap;
+  uint32_t m = n;  // keys that end up in the sort region
+  if (n <= sort_cap) {
+    for (uint32_t i = tid; i < n; i += blockDim.x) keys[i] = src[i];
+  } else {
+    if (staged) {
+      for (uint32_t i = tid; i < n; i += blockDim.x) stage[i] = src[i];
+    }
+    if (tid == 0) { sh_prefix = 0; sh_want = kk; sh_done = 0; }
+    uint64_t kth = 0;
     for (int pass = 0; pass < 8; ++pass) {
       const int shift = 56 - 8 * pass;
-      if (threadIdx.x < 256) hist[threadIdx.x] = 0u;
+      if (tid < 256) hist[tid] = 0u;
       __syncthreads();
       const uint64_t prefix = sh_prefix;
-      for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint64_t key = src[i];
+      const uint32_t want = sh_want;
+      for (uint32_t i = tid; i < n; i += blockDim.x) {
+        const uint64_t key = staged ? stage[i] : src[i];
         if (pass == 0 || (key >> (shift + 8)) == prefix)
           atomicAdd(&hist[uint32_t(key >> shift) & 255u], 1u);
       }
       __syncthreads();
-      if (threadIdx.x == 0) {
-        uint32_t want = sh_want, cum = 0;
-        int d = 255;
-        for (; d > 0; --d) {
-          if (cum + hist[d] >= want) break;
-          cum += hist[d];
+      // thread t looks at digit 255 - t: `before` = keys in larger digits
+      const uint32_t d = 255u - tid;
+      const uint32_t h = tid < 256 ? hist[d] : 0u;
+      const uint32_t incl = wave::inclusive_scan(h);
+      if (lane == 63 && wv < kWaves) wsum[wv] = incl;
+      __syncthreads();
+      if (tid < 256) {
+        uint32_t before = incl - h;
+        for (uint32_t w = 0; w < wv; ++w) before += wsum[w];
+        if (before < want && want <= before + h) {  // exactly one thread
+          sh_want = want - before;
+          sh_prefix = (prefix << 8) | uint64_t(d);
+          sh_done = (h == want - before) ? 1u : 0u;  // the whole bucket is needed
         }
-        sh_want = want - cum;
-        sh_prefix = (prefix << 8) | uint64_t(d);
       }
       __syncthreads();
+      kth = sh_prefix << shift;  // smallest possible key of the bucket
+      if (sh_done) break;
     }
-    const uint64_t kth = sh_prefix;
-    if (threadIdx.x == 0) sh_n = 0;
+    if (tid == 0) sh_n = 0;
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-      const uint64_t key = src[i];
+    for (uint32_t i = tid; i < n; i += blockDim.x) {
+      const uint64_t key = staged ? stage[i] : src[i];
       if (key >= kth) {
         const uint32_t slot = atomicAdd(&sh_n, 1u);
-        if (slot < kSelectLds) keys[slot] = key;
+        if (slot < sort_cap) keys[slot] = key;
       }
     }
     __syncthreads();
-    m = sh_n < kSelectLds ? sh_n : kSelectLds;
-  } else {
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) keys[i] = src[i];
+    m = sh_n < sort_cap ? sh_n : sort_cap;
   }
   uint32_t p2 = 1;
   while (p2 < m) p2 <<= 1;
   __syncthreads();
-  for (uint32_t i = m + threadIdx.x; i < p2; i += blockDim.x) keys[i] = 0;
+  for (uint32_t i = m + tid; i < p2; i += blockDim.x) keys[i] = 0;
   bitonic_desc(keys, p2);
-  for (uint32_t i = threadIdx.x; i < kk; i += blockDim.x)
+  for (uint32_t i = tid; i < kk; i += blockDim.x)
     out[uint64_t(q) * k_max + i] = key_hit(keys[i]);
-  if (threadIdx.x == 0) out_count[q] = kk;
+  if (tid == 0) out_count[q] = kk;
 }
 
 // ----------------------------------------------------------------- merge --

@@ -253,6 +253,12 @@ class QueryBatch:
         _lib.check(self.L, self.L.irs_hip_batch_timings(self.handle, ms), "irs_hip_batch_timings")
         return [float(x) for x in ms]
 
+    def reruns(self) -> int:
+        n = C.c_uint32()
+        _lib.check(self.L, self.L.irs_hip_batch_reruns(self.handle, C.byref(n)),
+                   "irs_hip_batch_reruns")
+        return n.value
+
     def work(self):
         a, p = C.c_uint64(), C.c_uint64()
         _lib.check(self.L, self.L.irs_hip_batch_work(self.handle, C.byref(a), C.byref(p)),

@@ -200,6 +200,36 @@ def case_queries_ragged(L, layout=synth.LAYOUT_SIMD4):
     sr.close()
 
 
+def case_pilot_misled(L, k=600):
+    """The pilot only sees every 16th doc tile.  Here every high-scoring doc sits in exactly
+    the tiles query 0 samples, so the estimated threshold (which extrapolates the sample)
+    is far too high; k_select must notice (fewer than k candidates although more docs
+    matched) and the batch must re-run with the sound threshold."""
+    tile, stride, n_tiles = 4096, 16, 64
+    n_docs = tile * n_tiles
+    rng = np.random.default_rng(21)
+    sampled = [t for t in range(n_tiles) if t % stride == 0]      # phase of query 0 is 0
+    hot = np.concatenate([1 + t * tile + np.sort(rng.choice(tile, 500, replace=False))
+                          for t in sampled]).astype(np.uint32)
+    hot_f = rng.integers(1, 200, hot.size).astype(np.uint32)      # spread over many score bins
+    cold = np.sort(rng.choice(n_docs, 3000, replace=False)).astype(np.uint32) + 1
+    lists = [(hot, hot_f), (cold, np.ones(cold.size, np.uint32))]
+    seg, sr = open_lists(L, lists, n_docs, synth.LAYOUT_SIMD4, norms=False)
+    filters = [by_term(0), Or([by_term(0), by_term(1)]), by_term(1)]
+    for scorer in (TFIDF(False), BM25(1.2, 0.0)):
+        run_and_check(L, seg, filters, scorer, k, tile, stride, sr=sr)
+    # the fallback really is what produced those results
+    prep = search.prepare(filters, TFIDF(False), [parity.segment_stats(seg)])
+    b = sr.batch(prep, k).configure(tile, stride, 0)
+    assert b.reruns() == 0
+    b.run().results()
+    assert b.reruns() == 1
+    b.run().results()            # the batch stays in sound mode: no further re-run
+    assert b.reruns() == 1
+    b.close()
+    sr.close()
+
+
 def case_no_norms(L):
     seg = synth.build_segment(20_000, 128)
     seg.norms = None

@@ -63,6 +63,10 @@ def test_bit_union(simlib, layout):
     cases.case_bit_union(simlib, layout, has_freq=False)
 
 
+def test_pilot_misled(simlib):
+    cases.case_pilot_misled(simlib)
+
+
 def test_multi_segment(simlib):
     cases.case_multi_segment(simlib, 45_000, 256)
 

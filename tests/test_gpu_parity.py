@@ -68,6 +68,10 @@ def test_bit_union(gpulib, layout):
     cases.case_bit_union(gpulib, layout, has_freq=False)
 
 
+def test_pilot_misled(gpulib):
+    cases.case_pilot_misled(gpulib)
+
+
 def test_multi_segment(gpulib):
     cases.case_multi_segment(gpulib, 600_000, 1024, n_segs=4, k=1000)
 

@@ -55,8 +55,9 @@ def main():
         avg = np.mean(ms, axis=0)
         alg, post = b.work()
         print("tile=%d stride=%d  step %.2f ms  qps %.0f  plan %.2f pilot %.2f score %.2f select %.2f"
-              "  score GB/s %.1f  same_hits=%s" % (tile, stride, dt * 1e3, args.queries / dt, *avg,
-                                                    alg / avg[2] / 1e6, same), flush=True)
+              "  score GB/s %.1f  same_hits=%s reruns=%d" % (tile, stride, dt * 1e3, args.queries / dt,
+                                                              *avg, alg / avg[2] / 1e6, same,
+                                                              b.reruns()), flush=True)
         b.close()
 
 
