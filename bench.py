@@ -153,16 +153,19 @@ def main():
                 torch.zeros((nq,), dtype=torch.int32, device=dev)) for s in my}
 
     def step():
+        # every step ends with a checked, device-resident top-k: results_to_device reads the
+        # batch status (4 bytes) and re-runs the batch if a threshold estimate or the
+        # candidate buffer fell short (irs_hip_batch_reruns counts those)
         for s in my:
             batches[s].run(sptr)
+        lists = []
+        for s in my:
+            batches[s].results_to_device(recv[s][0].data_ptr(), recv[s][1].data_ptr(), sptr)
+            lists.append((s, recv[s][0], recv[s][1]))
         if multi:
-            lists = []
-            for s in my:
-                batches[s].results_to_device(recv[s][0].data_ptr(), recv[s][1].data_ptr(), sptr)
-                lists.append((s, recv[s][0], recv[s][1]))
             return distributed.gather_merge(L, local_rank, lists, n_segments, rank, world, nq, k,
                                             dev, sptr)
-        return None
+        return lists[0]
 
     for _ in range(args.warmup):
         step()
@@ -189,6 +192,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    reruns = sum(batches[s].reruns() for s in my)
     alg_bytes = sum(batches[s].work()[0] for s in my)
     postings = sum(batches[s].work()[1] for s in my)
     rank0_alg_bytes = alg_bytes
@@ -224,6 +228,7 @@ def main():
                             "%d queries/step" % (args.terms, k, args.docs, n_segments, nq),
                 "segments": n_segments, "queries_per_step": nq, "layout": "1_5simd",
                 "postings_per_step": int(postings), "algorithmic_bytes_per_step": int(alg_bytes),
+                "reruns_rank0": int(reruns),
                 "parallelism": ("%d segments over %d GPU(s) + RCCL all-gather of per-segment "
                                 "top-k + GPU merge" % (n_segments, world)) if multi
                                else "1 segment on 1 GPU"},

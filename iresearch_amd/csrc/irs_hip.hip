@@ -75,6 +75,7 @@ struct irs_hip_segment {
   int device = 0;
   DevSegment dev{};
   DevBuf d_doc, d_norms, d_terms, d_blk_off, d_blk_last, d_blk_bits, d_status;
+  DevBuf d_blk_aoff, d_pk;     // packed-payload image (DevSegment::pk) and its offsets
   std::vector<DevTerm> terms;  // host mirror incl. the fields the dir kernel filled
   uint64_t total_blocks = 0;
   uint64_t device_bytes = 0;
@@ -107,6 +108,40 @@ struct irs_hip_batch {
 
 namespace {
 
+// Packed-payload image: block sizes (left in blk_aoff by the directory kernel) ->
+// exclusive prefix sum in place -> one copy pass.  Everything on the device.
+int build_packed_image(irs_hip_segment* s) {
+  const uint64_t n = s->total_blocks;
+  uint64_t total_units = 0;
+  if (n) {
+    const uint32_t parts = uint32_t((n + kScanChunk - 1) / kScanChunk);
+    DevBuf totals;
+    if (!totals.alloc((uint64_t(parts) + 1) * 8)) return IRS_HIP_ENOMEM;
+    RT_LAUNCH(k_scan_totals, parts, kThreads, 0, nullptr, s->d_blk_aoff.as<uint32_t>(), n,
+              totals.as<uint64_t>());
+    RT_LAUNCH(k_scan_parts, 1, 64, 0, nullptr, totals.as<uint64_t>(), parts);
+    if (!rt::last_error_ok() ||
+        !rt::d2h(&total_units, totals.as<uint64_t>() + parts, 8, nullptr) || !rt::sync(nullptr))
+      return IRS_HIP_EHIP;
+    if (total_units > 0xFFFFFFFFull) return IRS_HIP_EUNSUPPORTED;  // offsets are u32 units (64 GB)
+    RT_LAUNCH(k_scan_apply, parts, kThreads, 0, nullptr, s->d_blk_aoff.as<uint32_t>(), n,
+              totals.as<uint64_t>());
+    if (!rt::last_error_ok() || !rt::sync(nullptr)) return IRS_HIP_EHIP;
+  }
+  const uint64_t bytes = total_units * 16;
+  if (!s->d_pk.alloc(bytes + kPadBytes)) return IRS_HIP_ENOMEM;
+  if (!rt::dmemset(s->d_pk.as<uint8_t>() + bytes, 0, kPadBytes, nullptr)) return IRS_HIP_EHIP;
+  s->dev.pk = s->d_pk.as<uint8_t>();
+  if (total_units && s->dev.num_terms) {
+    const uint32_t slices =
+        std::max<uint32_t>(1, std::min<uint32_t>(64, s->cus * 8 / s->dev.num_terms));
+    RT_LAUNCH(k_pack_payloads, s->dev.num_terms * slices, kThreads, 0, nullptr, s->dev, slices,
+              s->d_pk.as<uint8_t>());
+    if (!rt::last_error_ok() || !rt::sync(nullptr)) return IRS_HIP_EHIP;
+  }
+  return IRS_HIP_OK;
+}
+
 template<int LAYOUT>
 int build_directory(irs_hip_segment* s) {
   const uint32_t grid = (s->dev.num_terms + kWaves - 1) / kWaves;
@@ -115,7 +150,7 @@ int build_directory(irs_hip_segment* s) {
     RT_LAUNCH((k_build_directory<LAYOUT>), grid, kThreads, 0, nullptr, s->dev,
               s->d_terms.as<DevTerm>(), s->d_blk_off.as<uint32_t>(),
               s->d_blk_last.as<uint32_t>(), s->d_blk_bits.as<uint16_t>(),
-              s->d_status.as<uint32_t>());
+              s->d_blk_aoff.as<uint32_t>(), s->d_status.as<uint32_t>());
   }
   if (!rt::last_error_ok()) return IRS_HIP_EHIP;
   uint32_t status = 0;
@@ -128,7 +163,7 @@ int build_directory(irs_hip_segment* s) {
     if (t.docs_count && (t.last_doc > s->dev.num_docs || t.last_doc < kDocMin))
       return IRS_HIP_ECORRUPT;
   }
-  return IRS_HIP_OK;
+  return build_packed_image(s);
 }
 
 template<typename K>
@@ -325,7 +360,8 @@ int irs_hip_segment_open(const irs_hip_segment_desc* d, irs_hip_segment** out) {
         (d->norms && !s->d_norms.alloc(norm_bytes + kPadBytes)) ||
         !s->d_terms.alloc(std::max<size_t>(1, s->terms.size()) * sizeof(DevTerm)) ||
         !s->d_blk_off.alloc((blocks + 1) * 4) || !s->d_blk_last.alloc((blocks + 1) * 4) ||
-        !s->d_blk_bits.alloc((blocks + 1) * 2) || !s->d_status.alloc(4)) {
+        !s->d_blk_bits.alloc((blocks + 1) * 2) || !s->d_blk_aoff.alloc((blocks + 1) * 4) ||
+        !s->d_status.alloc(4)) {
       rc = IRS_HIP_ENOMEM;
       break;
     }
@@ -353,12 +389,14 @@ int irs_hip_segment_open(const irs_hip_segment_desc* d, irs_hip_segment** out) {
     v.blk_off = s->d_blk_off.as<uint32_t>();
     v.blk_last = s->d_blk_last.as<uint32_t>();
     v.blk_bits = s->d_blk_bits.as<uint16_t>();
+    v.blk_aoff = s->d_blk_aoff.as<uint32_t>();
+    v.pk = nullptr;  // set by build_packed_image
     v.has_freq = d->has_freq ? 1 : 0;
     v.layout = d->layout;
     rc = d->layout == IRS_HIP_LAYOUT_SIMD4 ? build_directory<kSimd4>(s)
                                            : build_directory<kScalar>(s);
     s->device_bytes = s->d_doc.n + s->d_norms.n + s->d_terms.n + s->d_blk_off.n +
-                      s->d_blk_last.n + s->d_blk_bits.n;
+                      s->d_blk_last.n + s->d_blk_bits.n + s->d_blk_aoff.n + s->d_pk.n;
   } while (false);
   if (rc != IRS_HIP_OK) {
     delete s;

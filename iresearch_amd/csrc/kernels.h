@@ -35,6 +35,12 @@ enum : uint32_t {
 
 // ------------------------------------------------------------- directory --
 
+// 16-byte units a block occupies in the packed-payload image (DevSegment::pk):
+// only blocks the straight-line decoder handles (both parts 1..31-bit packed).
+__device__ __forceinline__ uint32_t pk_units(uint32_t dbits, uint32_t fbits) {
+  return ((dbits - 1u) <= 30u && (fbits - 1u) <= 30u) ? dbits + fbits : 0u;
+}
+
 // One wavefront per term walks the term's full blocks front to back: header
 // byte -> payload size (bitpack::skip_block32, bitpack.hpp:60-69); the block's
 // last doc is base + sum(deltas).  Lane 0 then walks the vint tail
@@ -42,7 +48,8 @@ enum : uint32_t {
 template<int LAYOUT>
 __global__ void __launch_bounds__(kThreads)
 k_build_directory(DevSegment seg, DevTerm* terms, uint32_t* blk_off,
-                  uint32_t* blk_last, uint16_t* blk_bits, uint32_t* status) {
+                  uint32_t* blk_last, uint16_t* blk_bits, uint32_t* blk_units,
+                  uint32_t* status) {
   const unsigned lane = threadIdx.x & 63u;
   const uint32_t term = blockIdx.x * kWaves + (threadIdx.x >> 6);
   if (term >= seg.num_terms) return;
@@ -90,6 +97,7 @@ k_build_directory(DevSegment seg, DevTerm* terms, uint32_t* blk_off,
       blk_off[t.dir_off + b] = uint32_t(cur - t.doc_start);
       blk_last[t.dir_off + b] = last;
       blk_bits[t.dir_off + b] = uint16_t(dbits | (fbits << 8));
+      blk_units[t.dir_off + b] = pk_units(dbits, fbits);
     }
     cur += size;
     base = last;
@@ -125,6 +133,96 @@ k_build_directory(DevSegment seg, DevTerm* terms, uint32_t* blk_off,
     terms[term].tf_bound = seg.has_freq ? tfb : 1u;
     terms[term].last_doc = doc;
     if (bad) atomicOr(status, kStatusCorrupt);
+  }
+}
+
+// Exclusive prefix sum of n u32 values in place (block sizes -> block offsets),
+// three launches: per-chunk totals, scan of the totals (one workgroup), apply.
+constexpr uint32_t kScanChunk = kThreads * 8;
+
+__global__ void __launch_bounds__(kThreads)
+k_scan_totals(const uint32_t* v, uint64_t n, uint64_t* totals) {
+  __shared__ uint32_t wsum[kWaves];
+  const uint64_t base = uint64_t(blockIdx.x) * kScanChunk;
+  uint32_t s = 0;
+  for (uint32_t i = threadIdx.x; i < kScanChunk; i += blockDim.x)
+    if (base + i < n) s += v[base + i];
+  s = wave::reduce_add(s);
+  if ((threadIdx.x & 63u) == 0) wsum[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint64_t t = 0;
+    for (uint32_t w = 0; w < kWaves; ++w) t += wsum[w];
+    totals[blockIdx.x] = t;
+  }
+}
+
+// totals[i] -> sum of totals[0..i), totals[n_parts] = grand total (one wavefront)
+__global__ void __launch_bounds__(64)
+k_scan_parts(uint64_t* totals, uint32_t n_parts) {
+  const unsigned lane = threadIdx.x;
+  uint64_t carry = 0;
+  for (uint32_t i0 = 0; i0 < n_parts; i0 += 64) {
+    const uint32_t i = i0 + lane;
+    const uint64_t x = i < n_parts ? totals[i] : 0;
+    // chunk totals are < 2^32 * kScanChunk: scan the halves separately
+    const uint32_t lo = wave::inclusive_scan(uint32_t(x & 0xFFFFu));
+    const uint32_t mid = wave::inclusive_scan(uint32_t((x >> 16) & 0xFFFFu));
+    const uint32_t hi = wave::inclusive_scan(uint32_t(x >> 32));
+    const uint64_t incl = uint64_t(lo) + (uint64_t(mid) << 16) + (uint64_t(hi) << 32);
+    if (i < n_parts) totals[i] = carry + incl - x;
+    const uint32_t l2 = wave::bcast(lo, 63), m2 = wave::bcast(mid, 63), h2 = wave::bcast(hi, 63);
+    carry += uint64_t(l2) + (uint64_t(m2) << 16) + (uint64_t(h2) << 32);
+  }
+  if (lane == 0) totals[n_parts] = carry;
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_scan_apply(uint32_t* v, uint64_t n, const uint64_t* totals) {
+  __shared__ uint32_t wsum[kWaves];
+  const uint64_t base = uint64_t(blockIdx.x) * kScanChunk;
+  const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  // thread t owns 8 consecutive values
+  const uint64_t at = base + uint64_t(threadIdx.x) * 8u;
+  uint32_t x[8], s = 0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    x[e] = at + e < n ? v[at + e] : 0u;
+    s += x[e];
+  }
+  const uint32_t incl = wave::inclusive_scan(s);
+  if (lane == 63) wsum[wv] = incl;
+  __syncthreads();
+  uint64_t off = totals[blockIdx.x] + (incl - s);
+  for (uint32_t w = 0; w < wv; ++w) off += wsum[w];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    if (at + e < n) v[at + e] = uint32_t(off);   // the host checked the grand total fits
+    off += x[e];
+  }
+}
+
+// Copies the payloads of the decodable blocks into the packed-payload image.
+// grid = num_terms * slices, as k_bit_union.
+__global__ void __launch_bounds__(kThreads)
+k_pack_payloads(DevSegment seg, uint32_t slices, uint8_t* pk) {
+  const unsigned lane = threadIdx.x & 63u;
+  const uint32_t slice = blockIdx.x % slices;
+  const DevTerm t = seg.terms[blockIdx.x / slices];
+  if (t.docs_count < 2) return;
+  for (uint32_t b = slice * kWaves + (threadIdx.x >> 6); b < t.nblk; b += slices * kWaves) {
+    const uint64_t e = t.dir_off + b;
+    const uint32_t bits = seg.blk_bits[e];
+    const uint32_t dbits = bits & 0xFFu, fbits = bits >> 8;
+    if (!pk_units(dbits, fbits)) continue;
+    const uint8_t* blk = seg.doc + t.doc_start + seg.blk_off[e];
+    uint64_t* dst = reinterpret_cast<uint64_t*>(pk + (uint64_t(seg.blk_aoff[e]) << 4));
+    // 8-byte pieces: 2*dbits of the doc payload (after its header byte), then
+    // 2*fbits of the freq payload (after the second header byte)
+    for (uint32_t i = lane; i < 2u * (dbits + fbits); i += 64) {
+      const uint8_t* src = i < 2u * dbits ? blk + 1u + 8u * i : blk + 2u + 8u * i;
+      dst[i] = wave::load_u64(src);
+    }
   }
 }
 
@@ -359,7 +457,8 @@ struct TermL {          // one query term of this tile, staged in LDS
 };
 
 struct alignas(16) ItemL {   // one (term, block) work item: one 16-byte LDS read per lane
-  uint32_t off;         // byte offset of the block in the staged `.doc` file
+  uint32_t off;         // straight-line item: offset in the packed-payload image (16-byte
+                        // units); generic item: byte offset of the block in `.doc`
   uint32_t base;        // last doc of the preceding block (kDocMin for block 0)
   uint32_t pack;        // doc bits | freq bits << 8 | cache slot << 16 | term slot << 20 | fast << 31
   float cs;             // the term's c0 pre-multiplied by the fixed-point scale
@@ -623,20 +722,20 @@ struct ItemRegs {
   uint64_t bda, bdb, bfa, bfb;
 };
 
-// raw payload words of item k (two per block part); no branch on the bit widths.
-// (Lanes past the last item hold a copy of the last item, so items_prepare may
-// request items 0 and 1 without a bounds test.)
+// raw payload words of item k (two per block part), from the packed-payload image
+// where every part starts 16-byte aligned; no branch on the bit widths.  Items of
+// the generic path read `.doc` for themselves.
 template<int LAYOUT>
 __device__ __forceinline__ void item_load(const DevSegment& seg, const ItemRegs& r, uint32_t k,
                                           unsigned lane, uint64_t& da, uint64_t& db,
                                           uint64_t& fa, uint64_t& fb) {
   const uint32_t pack = wave::read_lane(r.pack, k & 63u);
-  const uint32_t dbits = pack & 0xFFu, fbits = (pack >> 8) & 0xFFu;
-  const uint8_t* blk = seg.doc + wave::read_lane(r.off, k & 63u);
-  raw_load_packed<LAYOUT>(blk + 1, dbits, lane, da, db);
-  // the freq block starts right after the doc block (an ALL_EQUAL doc block has a
-  // data-dependent size: those items take the generic path, which reads for itself)
-  raw_load_packed<LAYOUT>(blk + 2u + 16u * dbits, fbits, lane, fa, fb);
+  if (pack >> 31) {   // scalar branch: only straight-line items live in the packed image
+    const uint32_t dbits = pack & 0xFFu, fbits = (pack >> 8) & 0xFFu;
+    const uint8_t* blk = seg.pk + (uint64_t(wave::read_lane(r.off, k & 63u)) << 4);
+    raw_load_packed<LAYOUT>(blk, dbits, lane, da, db);
+    raw_load_packed<LAYOUT>(blk + 16u * dbits, fbits, lane, fa, fb);   // right behind
+  }
 }
 
 template<int LAYOUT>
@@ -646,9 +745,7 @@ __device__ __forceinline__ void items_prepare(const DevSegment& seg, const ItemL
   const uint32_t wv = wave::uniform(threadIdx.x >> 6);
   const uint32_t nw = blockDim.x >> 6;  // workgroups are 256/512/1024 threads: a power of two
   r.n = wave::uniform(n > wv ? (n - wv + nw - 1) >> (31 - __builtin_clz(nw)) : 0u);
-  // lanes past the last item: a harmless 1-bit block at file offset 0 (no items at
-  // all) or a copy of the last item, so that look-ahead loads need no bounds test
-  // and do not all hit one address
+  // lanes past the last item never carry the straight-line flag: nothing is loaded
   r.pack = 0x0101u;
   r.base = 0;
   r.off = 0;
@@ -661,6 +758,7 @@ __device__ __forceinline__ void items_prepare(const DevSegment& seg, const ItemL
     r.pack = lane < r.n ? I.pack : (I.pack & 0xFFFFu);
     r.cs = I.cs;
   }
+  r.ada = r.adb = r.afa = r.afb = r.bda = r.bdb = r.bfa = r.bfb = 0;
   item_load<LAYOUT>(seg, r, 0, lane, r.ada, r.adb, r.afa, r.afb);
   item_load<LAYOUT>(seg, r, 1, lane, r.bda, r.bdb, r.bfa, r.bfb);
 }
@@ -861,9 +959,9 @@ __device__ __forceinline__ void tile_accumulate(const DevSegment& seg, const Dev
       const uint32_t b = sm.tl[j].b0 + (id - sm.tl[j].item_off);
       const uint64_t e = sm.tl[j].dir_off + b;
       ItemL I;
-      I.off = uint32_t(sm.tl[j].doc_start) + seg.blk_off[e];
       I.base = b ? seg.blk_last[e - 1] : kDocMin;
       I.pack = item_pack(seg.blk_bits[e], term_pack(j, sm.qts[j].kind, sm.qts[j].cache_id));
+      I.off = (I.pack >> 31) ? seg.blk_aoff[e] : uint32_t(sm.tl[j].doc_start) + seg.blk_off[e];
       I.cs = sm.qts[j].c0 * fx_mul;
       sm.items[threadIdx.x] = I;
     }
@@ -1133,8 +1231,9 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
 
     // Requests the directory entry of item `skip + tid` of local tile c. The loaded
     // words stay raw (x_off, x_last, x_bits); store_item() combines them later.
-    auto fetch_item = [&](uint32_t c, uint32_t skip, uint32_t& x_off, uint32_t& x_last,
-                          uint32_t& x_bits, uint32_t& x_meta, uint32_t& x_dstart, float& x_cs) {
+    auto fetch_item = [&](uint32_t c, uint32_t skip, uint32_t& x_off, uint32_t& x_aoff,
+                          uint32_t& x_last, uint32_t& x_bits, uint32_t& x_meta,
+                          uint32_t& x_dstart, float& x_cs) {
       const uint32_t* to = toff + c * kToffStride;
       const uint32_t id = skip + tid;
       if (tid < kItemChunk && id < to[kMaxTerms + 1]) {
@@ -1154,17 +1253,19 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
         x_cs = T.cs;
         x_meta = T.tpack | (b ? 0u : 0x20000000u);   // bit 29: first block of the term
         x_off = seg.blk_off[e];
+        x_aoff = seg.blk_aoff[e];
         x_last = seg.blk_last[e - (b ? 1u : 0u)];
         x_bits = seg.blk_bits[e];
       }
     };
-    auto store_item = [&](ItemL* dst, uint32_t n, uint32_t x_off, uint32_t x_last,
-                          uint32_t x_bits, uint32_t x_meta, uint32_t x_dstart, float x_cs) {
+    auto store_item = [&](ItemL* dst, uint32_t n, uint32_t x_off, uint32_t x_aoff,
+                          uint32_t x_last, uint32_t x_bits, uint32_t x_meta, uint32_t x_dstart,
+                          float x_cs) {
       if (tid < kItemChunk && tid < n) {
         ItemL I;
-        I.off = x_dstart + x_off;
         I.base = (x_meta & 0x20000000u) ? kDocMin : x_last;
         I.pack = item_pack(x_bits, x_meta);
+        I.off = (I.pack >> 31) ? x_aoff : x_dstart + x_off;
         I.cs = x_cs;
         dst[tid] = I;
       }
@@ -1191,18 +1292,18 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
     };
 
     // ---- prime the pipeline: tile 0 synchronously, requests for tile 1 --------
-    uint32_t x_off = 0, x_last = 0, x_bits = 0, x_meta = 0, x_dstart = 0;
+    uint32_t x_off = 0, x_aoff = 0, x_last = 0, x_bits = 0, x_meta = 0, x_dstart = 0;
     float x_cs = 0.f;
     uint64_t nw0 = 0, nw1 = 0;
     uint32_t n_cur = toff[kMaxTerms + 1], n_next = 0;
-    fetch_item(0, 0, x_off, x_last, x_bits, x_meta, x_dstart, x_cs);
+    fetch_item(0, 0, x_off, x_aoff, x_last, x_bits, x_meta, x_dstart, x_cs);
     norm_load(tile0, nw0, nw1);
-    store_item(items_of(0), n_cur, x_off, x_last, x_bits, x_meta, x_dstart, x_cs);
+    store_item(items_of(0), n_cur, x_off, x_aoff, x_last, x_bits, x_meta, x_dstart, x_cs);
     norm_store(nw0, nw1);
     __syncthreads();
     if (1 < ntile) {
       n_next = toff[kToffStride + kMaxTerms + 1];
-      fetch_item(1, 0, x_off, x_last, x_bits, x_meta, x_dstart, x_cs);
+      fetch_item(1, 0, x_off, x_aoff, x_last, x_bits, x_meta, x_dstart, x_cs);
       norm_load(tile0 + 1, nw0, nw1);
     }
     ItemRegs R;
@@ -1219,10 +1320,10 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
       items_run<ACC, LAYOUT, TILE, AND>(seg, sm, R, lo, span, fx_mul);
       for (uint32_t done = kItemChunk; done < n_cur; done += kItemChunk) {  // rare: > 256 items
         __syncthreads();
-        uint32_t yo = 0, yl = 0, yb = 0, ym = 0, yd = 0;
+        uint32_t yo = 0, ya = 0, yl = 0, yb = 0, ym = 0, yd = 0;
         float yc = 0.f;
-        fetch_item(u, done, yo, yl, yb, ym, yd, yc);
-        store_item(items_of(u), n_cur - done, yo, yl, yb, ym, yd, yc);
+        fetch_item(u, done, yo, ya, yl, yb, ym, yd, yc);
+        store_item(items_of(u), n_cur - done, yo, ya, yl, yb, ym, yd, yc);
         __syncthreads();
         const uint32_t n = (n_cur - done) < kItemChunk ? (n_cur - done) : kItemChunk;
         process_items<ACC, LAYOUT, TILE, AND>(seg, sm, items_of(u), n, lo, span, fx_mul);
@@ -1242,7 +1343,8 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
         }
       }
       // the directory entries of tile u+1 (requested a tile ago) land in the other table
-      if (has_next) store_item(items_of(u + 1u), n_next, x_off, x_last, x_bits, x_meta, x_dstart, x_cs);
+      if (has_next)
+        store_item(items_of(u + 1u), n_next, x_off, x_aoff, x_last, x_bits, x_meta, x_dstart, x_cs);
 #ifndef IRS_ABL_NOBAR1   // timing experiment only
       __syncthreads();  // B1: every accumulation of tile u has landed; items of u+1 visible
 #endif
@@ -1252,7 +1354,7 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
         norm_store(nw0, nw1);  // norms of tile u+1 (tile u no longer reads them)
         if (u + 2 < ntile) {   // requests for tile u+2
           n_next2 = toff[(u + 2u) * kToffStride + kMaxTerms + 1];
-          fetch_item(u + 2u, 0, x_off, x_last, x_bits, x_meta, x_dstart, x_cs);
+          fetch_item(u + 2u, 0, x_off, x_aoff, x_last, x_bits, x_meta, x_dstart, x_cs);
           norm_load(tile + 2u, nw0, nw1);
         }
         // this wavefront's items of tile u+1 and the payload of the first two

@@ -60,6 +60,12 @@ struct DevSegment {
   const uint32_t* blk_off;   // byte offset relative to the term's doc_start
   const uint32_t* blk_last;  // absolute last doc id of the block
   const uint16_t* blk_bits;  // doc bits | freq bits << 8 (0 = all-equal block)
+  // packed-payload image: the doc and freq payloads of every block whose two parts
+  // are 1..31-bit packed, headers dropped, back to back — every payload starts on a
+  // 16-byte boundary (a payload is 16*bits bytes), unlike in `.doc` where the 1-byte
+  // headers leave all of them misaligned.  The hot decoder reads this copy.
+  const uint8_t* pk;
+  const uint32_t* blk_aoff;  // offset of the block in `pk`, in 16-byte units
   int32_t has_freq;
   int32_t layout;
 };
