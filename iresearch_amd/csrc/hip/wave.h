@@ -98,6 +98,13 @@ __device__ __forceinline__ void keep_f(float& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void keep_acc(uint32_t& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void keep_acc(unsigned long long& v) { asm volatile("" : "+v"(v)); }
 
+// A register whose content does not matter (no instruction is emitted).
+__device__ __forceinline__ uint64_t undef64() {
+  uint64_t v;
+  asm volatile("" : "=v"(v));
+  return v;
+}
+
 // v_rcp_f32: <= 1 ulp
 __device__ __forceinline__ float fast_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
 

@@ -641,11 +641,11 @@ __device__ __forceinline__ void tile_post_bm25(const TileSmemT<ACC>& sm, const f
     nb[k] = sm.lnorm[idx[k]];
   }
 #pragma unroll
-  for (int k = 0; k < N; ++k) wave::keep(nb[k]);
+  for (int k = N - 1; k >= 0; --k) wave::keep(nb[k]);   // last issued first: one wait
 #pragma unroll
   for (int k = 0; k < N; ++k) inv[k] = cache[k][nb[k]];
 #pragma unroll
-  for (int k = 0; k < N; ++k) wave::keep_f(inv[k]);
+  for (int k = N - 1; k >= 0; --k) wave::keep_f(inv[k]);
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     const float r = wave::fast_rcp(wave::fma(static_cast<float>(freq[k]), inv[k], 1.f));
@@ -714,6 +714,8 @@ __device__ __forceinline__ void extract_fast(uint64_t a, uint64_t b, uint32_t bi
 //     LDS round trip on an item's critical path) and the payload words of the
 //     first two items are requested;
 //   items_run: decode + score + accumulate, always two items ahead with the loads.
+constexpr uint32_t kPackPair = 0x40000000u;   // ItemRegs::pack, set by items_prepare
+
 struct ItemRegs {
   uint32_t n;                        // items of this wavefront (<= 64), wave-uniform
   uint32_t pack, base, off;          // lane k: metadata of the k-th item
@@ -758,6 +760,9 @@ __device__ __forceinline__ void items_prepare(const DevSegment& seg, const ItemL
     r.pack = lane < r.n ? I.pack : (I.pack & 0xFFFFu);
     r.cs = I.cs;
   }
+  // bit 30 of lane k: items k and k+1 are both straight-line (read for even k only)
+  const uint32_t next = __shfl_down(r.pack, 1, 64);
+  if ((r.pack & next) >> 31) r.pack |= kPackPair;
   r.ada = r.adb = r.afa = r.afb = r.bda = r.bdb = r.bfa = r.bfb = 0;
   item_load<LAYOUT>(seg, r, 0, lane, r.ada, r.adb, r.afa, r.afb);
   item_load<LAYOUT>(seg, r, 1, lane, r.bda, r.bdb, r.bfa, r.bfb);
@@ -824,21 +829,23 @@ __device__ __forceinline__ void items_run(const DevSegment& seg, const TileSmemT
   uint64_t bda = r.bda, bdb = r.bdb, bfa = r.bfa, bfb = r.bfb;
   const uint32_t my_n = r.n;
   for (uint32_t k = 0; k < my_n; k += 2) {
-    uint64_t nada, nadb, nafa, nafb, nbda, nbdb, nbfa, nbfb;
-    // (scalar branches; measured faster than unconditional look-ahead loads: the
-    // vector memory pipeline is a scarce resource here)
-    nada = nadb = nafa = nafb = nbda = nbdb = nbfa = nbfb = 0;
-    if (k + 2 < my_n) item_load<LAYOUT>(seg, r, k + 2, lane, nada, nadb, nafa, nafb);
-    if (k + 3 < my_n) item_load<LAYOUT>(seg, r, k + 3, lane, nbda, nbdb, nbfa, nbfb);
-    const bool hasB = k + 1 < my_n;
-    const bool okA = (wave::read_lane(r.pack, k) >> 31) != 0u;
-    const bool okB = hasB && (wave::read_lane(r.pack, k + 1) >> 31) != 0u;
-    if (okA && okB) {
+    // look-ahead loads of items k+2, k+3 (scalar branches on the items' straight-line
+    // flag — lanes past the last item never carry it; measured faster than
+    // unconditional loads: the vector memory pipeline is a scarce resource here).
+    // Registers of an item that is not loaded are never read: left undefined.
+    uint64_t nada = wave::undef64(), nadb = wave::undef64(), nafa = wave::undef64(),
+             nafb = wave::undef64(), nbda = wave::undef64(), nbdb = wave::undef64(),
+             nbfa = wave::undef64(), nbfb = wave::undef64();
+    item_load<LAYOUT>(seg, r, k + 2, lane, nada, nadb, nafa, nafb);
+    item_load<LAYOUT>(seg, r, k + 3, lane, nbda, nbdb, nbfa, nbfb);
+    const uint32_t pA = wave::read_lane(r.pack, k);
+    if (pA & kPackPair) {   // items k and k+1 both exist and are straight-line
       fast_pair(k, ada, adb, afa, afb, bda, bdb, bfa, bfb);
     } else {
-      if (okA) fast_item(k, ada, adb, afa, afb); else slow_item(k);
-      if (hasB) {
-        if (okB) fast_item(k + 1, bda, bdb, bfa, bfb); else slow_item(k + 1);
+      if (pA >> 31) fast_item(k, ada, adb, afa, afb); else slow_item(k);
+      if (k + 1 < my_n) {
+        if (wave::read_lane(r.pack, k + 1) >> 31) fast_item(k + 1, bda, bdb, bfa, bfb);
+        else slow_item(k + 1);
       }
     }
     ada = nada; adb = nadb; afa = nafa; afb = nafb;

@@ -68,6 +68,7 @@ __device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t s)
   return uint32_t(((uint64_t(hi) << 32) | lo) >> (s & 31u));
 }
 __device__ __forceinline__ uint32_t bfe(uint32_t x, uint32_t bits) { return x & ((1u << bits) - 1u); }
+__device__ __forceinline__ uint64_t undef64() { return 0; }
 __device__ __forceinline__ void keep(uint32_t&) {}
 __device__ __forceinline__ void keep_f(float&) {}
 __device__ __forceinline__ void keep_acc(uint32_t&) {}
