@@ -1236,14 +1236,18 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
     const ACC thr = bin_threshold<ACC>(bs, qd);
     __syncthreads();
 
-    // Requests the directory entry of item `skip + tid` of local tile c. The loaded
+    // Requests the directory entry of item `skip + ftid` of local tile c. The loaded
     // words stay raw (x_off, x_last, x_bits); store_item() combines them later.
+    // Items are handed out from the LAST thread down: the tables are filled by the
+    // last wavefront(s), which have the fewest work items of the tile (wavefront w
+    // decodes items w, w+nw, ...), so this duty evens the wavefronts out.
+    const uint32_t ftid = blockDim.x - 1u - tid;
     auto fetch_item = [&](uint32_t c, uint32_t skip, uint32_t& x_off, uint32_t& x_aoff,
                           uint32_t& x_last, uint32_t& x_bits, uint32_t& x_meta,
                           uint32_t& x_dstart, float& x_cs) {
       const uint32_t* to = toff + c * kToffStride;
-      const uint32_t id = skip + tid;
-      if (tid < kItemChunk && id < to[kMaxTerms + 1]) {
+      const uint32_t id = skip + ftid;
+      if (ftid < kItemChunk && id < to[kMaxTerms + 1]) {
         // term slot j: to[j] <= id < to[j+1]  <=>  j = #{t >= 1 : to[t] <= id}; all the
         // reads are issued together (one LDS round trip, no search loop)
         uint32_t j = 0;
@@ -1268,13 +1272,13 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
     auto store_item = [&](ItemL* dst, uint32_t n, uint32_t x_off, uint32_t x_aoff,
                           uint32_t x_last, uint32_t x_bits, uint32_t x_meta, uint32_t x_dstart,
                           float x_cs) {
-      if (tid < kItemChunk && tid < n) {
+      if (ftid < kItemChunk && ftid < n) {
         ItemL I;
         I.base = (x_meta & 0x20000000u) ? kDocMin : x_last;
         I.pack = item_pack(x_bits, x_meta);
         I.off = (I.pack >> 31) ? x_aoff : x_dstart + x_off;
         I.cs = x_cs;
-        dst[tid] = I;
+        dst[ftid] = I;
       }
     };
     // 16 norm bytes per thread (the host sizes workgroups to >= TILE/16 threads)
