@@ -201,7 +201,11 @@ bool launch_score(irs_hip_batch* b, rt::stream_t st) {
   // persistent grid: as many workgroups as stay resident on the chip at once
   const uint32_t waves = threads / 64;
   uint32_t per_cu = uint32_t((160u * 1024u) / smem);
-  per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 32u / waves));
+#ifdef IRS_SCORE_WAVES_PER_EU
+  per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 4u * IRS_SCORE_WAVES_PER_EU / waves));
+#else
+  per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 16u / waves));  // 128 VGPRs: 4 waves/SIMD
+#endif
   const uint64_t chunks = uint64_t(b->nq) * ((b->n_tiles + kChunkTiles - 1) / kChunkTiles);
   if (chunks > 0xFFFF0000ull) return false;
   const uint32_t grid = uint32_t(std::min<uint64_t>(chunks, uint64_t(b->seg->cus) * per_cu));

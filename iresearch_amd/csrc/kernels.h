@@ -25,7 +25,10 @@ constexpr uint32_t kThreads = 256;      // 4 wavefronts per workgroup (utility k
 constexpr uint32_t kTileThreadsMax = 1024;  // pilot/score workgroups: 256..1024 threads
 constexpr uint32_t kWaves = kThreads / 64;
 constexpr uint32_t kLocalCands = 256;   // per-tile candidate staging slots in LDS
-constexpr uint32_t kItemChunk = 256;    // (term, block) work items staged in LDS at a time
+#ifndef IRS_ITEM_CHUNK
+#define IRS_ITEM_CHUNK 256
+#endif
+constexpr uint32_t kItemChunk = IRS_ITEM_CHUNK;    // (term, block) work items staged in LDS at a time
 
 enum : uint32_t {
   kStatusCorrupt = 1u,   // malformed block header / out-of-bounds offset
@@ -1081,7 +1084,10 @@ k_pilot(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
 // on them would make the compiler wait for the load where it was issued.
 
 constexpr uint32_t kChunkTiles = 16;
-constexpr uint32_t kScoreCands = 128;   // per-tile candidate staging slots (x2 buffers)
+#ifndef IRS_SCORE_CANDS
+#define IRS_SCORE_CANDS 128
+#endif
+constexpr uint32_t kScoreCands = IRS_SCORE_CANDS;   // per-tile candidate staging slots (x2 buffers)
 constexpr uint32_t kToffStride = 20;    // words per row of the per-tile prefix table:
                                         // [0..16] exclusive prefix sums of the terms' block counts
                                         // (0xFFFFFFFF past n_terms), [17] the tile's item count
@@ -1117,8 +1123,13 @@ constexpr uint32_t score_smem_bytes() {
          + 4u * kVWords;
 }
 
+#ifndef IRS_SCORE_WAVES_PER_EU
+#define IRS_SCORE_ATTR
+#else
+#define IRS_SCORE_ATTR __attribute__((amdgpu_waves_per_eu(IRS_SCORE_WAVES_PER_EU, IRS_SCORE_WAVES_PER_EU)))
+#endif
 template<typename ACC, int LAYOUT, int TILE, bool AND>
-__global__ void __launch_bounds__(kTileThreadsMax)
+__global__ void __launch_bounds__(kTileThreadsMax) IRS_SCORE_ATTR
 k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_t jt,
         uint32_t n_tiles, uint32_t n_queries, const uint32_t* first, const DevTail* tails,
         const uint32_t* bstar, uint64_t* cands, uint32_t cand_cap, uint32_t* cand_count,
