@@ -191,9 +191,12 @@ int irs_hip_query_batch(irs_hip_segment* seg, const irs_hip_query* queries,
                         uint32_t k_stride, uint32_t* counts,
                         uint64_t* total_hits);
 
-/* Tuning knobs (0 keeps the default). tile_docs in {4096, 8192};
+/* Tuning knobs (0 keeps the default). tile_docs in {4096, 6144, 8192, 12288}: docs
+ * per LDS accumulator tile (default: the largest one that lets two workgroups share
+ * a compute unit's LDS, 12288 with 32-bit and 6144 with 64-bit accumulators);
  * pilot_stride P: every P-th doc tile is scored first to bound the k-th score
- * (P == 1: exact two-pass); cand_cap: candidate slots per query. */
+ * (P == 1: exact two-pass); cand_cap: candidate slots per query.  Results do not
+ * depend on any of them. */
 int irs_hip_batch_configure(irs_hip_batch* batch, uint32_t tile_docs,
                             uint32_t pilot_stride, uint32_t cand_cap);
 

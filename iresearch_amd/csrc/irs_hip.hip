@@ -17,7 +17,6 @@ using namespace irs_hip;
 
 namespace {
 
-constexpr uint32_t kDefaultTile = 4096;
 constexpr uint32_t kDefaultStride = 64;
 constexpr uint32_t kPilotMargin = 3;   // estimated threshold: aim at margin * k candidates
 constexpr uint32_t kDefaultWgThreads = 512;  // 8 wavefronts share one tile (measured best)
@@ -197,7 +196,7 @@ bool launch_score(irs_hip_batch* b, rt::stream_t st) {
   auto kern = k_score<ACC, LAYOUT, TILE, AND>;
   if (!big_smem(kern, smem)) return false;
   // k_score stages 16 norm bytes per thread per tile
-  const uint32_t threads = std::max<uint32_t>(b->wg_threads, uint32_t(TILE) / 16u);
+  const uint32_t threads = std::max<uint32_t>(b->wg_threads, uint32_t(TILE) / (TILE > 8192 ? 24u : 16u));
   // persistent grid: as many workgroups as stay resident on the chip at once
   const uint32_t waves = threads / 64;
   uint32_t per_cu = uint32_t((160u * 1024u) / smem);
@@ -230,13 +229,21 @@ bool launch_score_and(irs_hip_batch* b, rt::stream_t st) {
 }
 template<typename ACC, int LAYOUT>
 bool launch_pilot_tile(irs_hip_batch* b, rt::stream_t st) {
-  return b->tile == 8192 ? launch_pilot_and<ACC, LAYOUT, 8192>(b, st)
-                         : launch_pilot_and<ACC, LAYOUT, 4096>(b, st);
+  switch (b->tile) {
+    case 12288: return launch_pilot_and<ACC, LAYOUT, 12288>(b, st);
+    case 8192: return launch_pilot_and<ACC, LAYOUT, 8192>(b, st);
+    case 6144: return launch_pilot_and<ACC, LAYOUT, 6144>(b, st);
+    default: return launch_pilot_and<ACC, LAYOUT, 4096>(b, st);
+  }
 }
 template<typename ACC, int LAYOUT>
 bool launch_score_tile(irs_hip_batch* b, rt::stream_t st) {
-  return b->tile == 8192 ? launch_score_and<ACC, LAYOUT, 8192>(b, st)
-                         : launch_score_and<ACC, LAYOUT, 4096>(b, st);
+  switch (b->tile) {
+    case 12288: return launch_score_and<ACC, LAYOUT, 12288>(b, st);
+    case 8192: return launch_score_and<ACC, LAYOUT, 8192>(b, st);
+    case 6144: return launch_score_and<ACC, LAYOUT, 6144>(b, st);
+    default: return launch_score_and<ACC, LAYOUT, 4096>(b, st);
+  }
 }
 template<int LAYOUT>
 bool launch_pilot_acc(irs_hip_batch* b, rt::stream_t st) {
@@ -253,7 +260,8 @@ bool ensure_scratch(irs_hip_batch* b) {
   if (b->scratch_ready) return true;
   const irs_hip_segment* s = b->seg;
   // 32-bit accumulators halve the LDS per doc: twice the tile at the same residency
-  if (b->tile == 0) b->tile = b->acc32 ? 8192 : kDefaultTile;
+  // the largest tile that still lets two workgroups share a CU's 160 KB of LDS
+  if (b->tile == 0) b->tile = b->acc32 ? 12288 : 6144;
   b->n_tiles = (s->dev.num_docs + b->tile - 1) / b->tile;
   b->stride_eff = std::max<uint32_t>(1, std::min<uint32_t>(b->stride, b->n_tiles / 4));
   if (const char* e = std::getenv("IRS_HIP_WG_THREADS")) {  // tuning knob
@@ -698,7 +706,8 @@ int irs_hip_batch_create(irs_hip_segment* seg, const irs_hip_query* queries, uin
 int irs_hip_batch_configure(irs_hip_batch* b, uint32_t tile_docs, uint32_t pilot_stride,
                             uint32_t cand_cap) {
   if (!b) return IRS_HIP_EINVAL;
-  if (tile_docs && tile_docs != 4096 && tile_docs != 8192)
+  if (tile_docs && tile_docs != 4096 && tile_docs != 6144 && tile_docs != 8192 &&
+      tile_docs != 12288)
     return IRS_HIP_EINVAL;
   if (cand_cap && cand_cap < b->k_max) return IRS_HIP_EINVAL;
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;

@@ -1292,41 +1292,45 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
         dst[ftid] = I;
       }
     };
-    // 16 norm bytes per thread (the host sizes workgroups to >= TILE/16 threads)
-    auto norm_load = [&](uint32_t tile, uint64_t& w0, uint64_t& w1) {
-      w0 = w1 = 0;
+    // kNormPieces 8-byte pieces of the tile's norm bytes per thread (the host sizes
+    // workgroups to >= TILE / (8 * kNormPieces) threads)
+    constexpr int kNormPieces = TILE > 8192 ? 3 : 2;
+    struct NormRegs { uint64_t w[kNormPieces]; };
+    auto norm_load = [&](uint32_t tile, NormRegs& r) {
+#pragma unroll
+      for (int e = 0; e < kNormPieces; ++e) r.w[e] = 0;
       if (seg.norms && seg.norm_width == 1) {
         const uint64_t base = uint64_t(tile) * TILE + (kDocMin - seg.norm_min_doc);
-        const uint32_t i0 = tid * 16u;
+        const uint32_t i0 = tid * (8u * kNormPieces);
         if (i0 < uint32_t(TILE) && base + i0 < seg.norm_count) {
-          w0 = wave::load_u64(seg.norms + base + i0);
-          w1 = wave::load_u64(seg.norms + base + i0 + 8);
+#pragma unroll
+          for (int e = 0; e < kNormPieces; ++e) r.w[e] = wave::load_u64(seg.norms + base + i0 + 8 * e);
         }
       }
     };
-    auto norm_store = [&](uint64_t w0, uint64_t w1) {
-      const uint32_t i0 = tid * 16u;
+    auto norm_store = [&](const NormRegs& r) {
+      const uint32_t i0 = tid * (8u * kNormPieces);
       if (i0 < uint32_t(TILE)) {
         uint64_t* d = reinterpret_cast<uint64_t*>(sm.lnorm + i0);
-        d[0] = w0;
-        d[1] = w1;
+#pragma unroll
+        for (int e = 0; e < kNormPieces; ++e) d[e] = r.w[e];
       }
     };
 
     // ---- prime the pipeline: tile 0 synchronously, requests for tile 1 --------
     uint32_t x_off = 0, x_aoff = 0, x_last = 0, x_bits = 0, x_meta = 0, x_dstart = 0;
     float x_cs = 0.f;
-    uint64_t nw0 = 0, nw1 = 0;
+    NormRegs nrm;
     uint32_t n_cur = toff[kMaxTerms + 1], n_next = 0;
     fetch_item(0, 0, x_off, x_aoff, x_last, x_bits, x_meta, x_dstart, x_cs);
-    norm_load(tile0, nw0, nw1);
+    norm_load(tile0, nrm);
     store_item(items_of(0), n_cur, x_off, x_aoff, x_last, x_bits, x_meta, x_dstart, x_cs);
-    norm_store(nw0, nw1);
+    norm_store(nrm);
     __syncthreads();
     if (1 < ntile) {
       n_next = toff[kToffStride + kMaxTerms + 1];
       fetch_item(1, 0, x_off, x_aoff, x_last, x_bits, x_meta, x_dstart, x_cs);
-      norm_load(tile0 + 1, nw0, nw1);
+      norm_load(tile0 + 1, nrm);
     }
     ItemRegs R;
     items_prepare<LAYOUT>(seg, items_of(0), n_cur < kItemChunk ? n_cur : kItemChunk, R);
@@ -1373,11 +1377,11 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
 
       uint32_t n_next2 = 0;
       if (has_next) {
-        norm_store(nw0, nw1);  // norms of tile u+1 (tile u no longer reads them)
+        norm_store(nrm);  // norms of tile u+1 (tile u no longer reads them)
         if (u + 2 < ntile) {   // requests for tile u+2
           n_next2 = toff[(u + 2u) * kToffStride + kMaxTerms + 1];
           fetch_item(u + 2u, 0, x_off, x_aoff, x_last, x_bits, x_meta, x_dstart, x_cs);
-          norm_load(tile + 2u, nw0, nw1);
+          norm_load(tile + 2u, nrm);
         }
         // this wavefront's items of tile u+1 and the payload of the first two
         items_prepare<LAYOUT>(seg, items_of(u + 1u), n_next < kItemChunk ? n_next : kItemChunk, R);

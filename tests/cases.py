@@ -161,7 +161,7 @@ def case_queries_tiles_and_strides(L, num_docs, max_rank):
     sr = search.SegmentReader.from_synth(seg, L=L)
     filters = standard_filters(max_rank, n_or8=2)
     ref = None
-    for tile in (4096, 8192):
+    for tile in (4096, 6144, 8192, 12288):
         for stride in (1, 3, 16, 1000):
             hits, counts, totals = run_and_check(L, seg, filters, BM25(), 100, tile, stride, sr=sr)
             # results do not depend on the tiling or on the pilot sample
