@@ -70,7 +70,12 @@ typedef struct irs_hip_segment_desc {
   uint64_t norm_count;      /* number of values in `norms`                         */
   const irs_hip_term_meta* terms; /* the field's term table (term dictionary walk) */
   uint32_t num_terms;
-  uint32_t reserved;
+  uint32_t wand_count;      /* scorers the field was indexed with — the `wand_count` the
+                             * reference passes to postings_reader::iterator()
+                             * (formats.hpp:160-168): formats 1_4/1_5 interleave that many
+                             * (size byte, payload) pairs of "wand data" in front of short
+                             * lists' tails (formats_10.cpp:686-688, skipped as :2298-2301)
+                             * and inside the skip data (never read here). 0..16. */
 } irs_hip_segment_desc;
 
 typedef struct irs_hip_segment irs_hip_segment; /* opaque, immutable after open */

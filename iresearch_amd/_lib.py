@@ -42,7 +42,7 @@ class SegmentDesc(C.Structure):
         ("doc_file_len", C.c_uint64), ("num_docs", C.c_uint32), ("has_freq", C.c_uint32),
         ("norms", C.c_void_p), ("norm_width", C.c_uint32), ("norm_min_doc", C.c_uint32),
         ("norm_count", C.c_uint64), ("terms", C.c_void_p), ("num_terms", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("wand_count", C.c_uint32),
     ]
 
 

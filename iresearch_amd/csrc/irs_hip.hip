@@ -315,7 +315,7 @@ int irs_hip_segment_open(const irs_hip_segment_desc* d, irs_hip_segment** out) {
   *out = nullptr;
   if (!d->doc_file || !d->num_docs || d->num_docs > 0x7FFF0000u ||
       (d->layout != IRS_HIP_LAYOUT_SCALAR && d->layout != IRS_HIP_LAYOUT_SIMD4) ||
-      (d->num_terms && !d->terms))
+      (d->num_terms && !d->terms) || d->wand_count > 16)
     return IRS_HIP_EINVAL;
   if (d->norms) {
     if (d->norm_width != 1 && d->norm_width != 2 && d->norm_width != 4) return IRS_HIP_EINVAL;
@@ -405,6 +405,7 @@ int irs_hip_segment_open(const irs_hip_segment_desc* d, irs_hip_segment** out) {
     v.pk = nullptr;  // set by build_packed_image
     v.has_freq = d->has_freq ? 1 : 0;
     v.layout = d->layout;
+    v.wand_count = d->wand_count;
     rc = d->layout == IRS_HIP_LAYOUT_SIMD4 ? build_directory<kSimd4>(s)
                                            : build_directory<kScalar>(s);
     s->device_bytes = s->d_doc.n + s->d_norms.n + s->d_terms.n + s->d_blk_off.n +

@@ -106,6 +106,20 @@ k_build_directory(DevSegment seg, DevTerm* terms, uint32_t* blk_off,
     base = last;
   }
   if (lane == 0) {
+    // a list without a skip list carries its wand root in front of the tail
+    // (formats_10.cpp:686-688): one size byte per scorer, then the payloads
+    // (CommonSkipWandData :1962-1979).  A 128-doc list has it behind its only block,
+    // where nothing is read any more.
+    if (!bad && t.nblk == 0 && seg.wand_count) {
+      uint64_t skip = 0;
+      if (cur + seg.wand_count > seg.doc_len) {
+        bad = true;
+      } else {
+        for (uint32_t w = 0; w < seg.wand_count; ++w) skip += seg.doc[cur + w];
+        cur += seg.wand_count + skip;
+        if (cur > seg.doc_len) bad = true;
+      }
+    }
     const uint64_t tail_off = cur;
     uint32_t doc = base;
     if (!bad) {
@@ -132,7 +146,7 @@ k_build_directory(DevSegment seg, DevTerm* terms, uint32_t* blk_off,
     terms[term].tail_off = tail_off;
     terms[term].tail_base = base;
     terms[term].tail_bytes = uint32_t(cur - tail_off);
-    terms[term].blocks_bytes = uint32_t(tail_off - t.doc_start);
+    terms[term].blocks_bytes = t.nblk ? uint32_t(tail_off - t.doc_start) : 0u;  // not the wand root
     terms[term].tf_bound = seg.has_freq ? tfb : 1u;
     terms[term].last_doc = doc;
     if (bad) atomicOr(status, kStatusCorrupt);

@@ -68,6 +68,7 @@ struct DevSegment {
   const uint32_t* blk_aoff;  // offset of the block in `pk`, in 16-byte units
   int32_t has_freq;
   int32_t layout;
+  uint32_t wand_count;       // scorers the field was indexed with (wand data in front of short tails)
 };
 
 struct DevQuery {

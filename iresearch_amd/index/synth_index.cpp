@@ -124,12 +124,56 @@ uint32_t count_max_levels(uint32_t skip0, uint32_t skipn, uint64_t count) {
   return skip0 < count ? 1 + ilog(count / skip0, skipn) : 0;
 }
 
+// ---- wand data (formats 1_4 / 1_5 written with scorers) ------------------
+// FreqNormProducer<Tag> — wand_writer.hpp:152-342.  One accumulator per skip level
+// (+1 for the whole list), per scorer; the payload of an entry is
+// vint(freq) [+ vint(norm - freq) when the tag carries a norm and norm != freq].
+struct WandEntry {
+  uint32_t freq = 1;
+  uint32_t norm = 0xFFFFFFFFu;
+};
+struct WandSpec {
+  const uint8_t* norms;     // 1-byte Norm2 column, norms[doc - 1]; needed by MinNorm / DivNorm
+  uint32_t count;           // scorers the field was indexed with
+  const uint32_t* kinds;    // IRS_SYNTH_WAND_* per scorer
+};
+// Produce(const Entry& from, Entry& to) — :171-195; also Produce(Entry& to) from a doc :258-291
+void wand_produce(uint32_t kind, uint32_t freq, uint32_t norm, WandEntry& to) {
+  if (kind == IRS_SYNTH_WAND_DIV_NORM) {
+    if (uint64_t(freq) * to.norm > uint64_t(to.freq) * norm) {
+      to.freq = freq;
+      to.norm = norm;
+    }
+    return;
+  }
+  if (freq > to.freq) to.freq = freq;
+  if (kind == IRS_SYNTH_WAND_MIN_NORM) {
+    if (norm < to.norm) to.norm = norm;
+    if (to.norm < to.freq) to.norm = to.freq;
+  }
+}
+uint32_t vint_size(uint32_t v) {
+  uint32_t n = 1;
+  while (v >= 0x80) { v >>= 7; ++n; }
+  return n;
+}
+// Size(Entry) :210-220 and Write(Entry, out) :197-208
+uint8_t wand_size(uint32_t kind, const WandEntry& e) {
+  uint32_t n = vint_size(e.freq);
+  if (kind != IRS_SYNTH_WAND_MAX_FREQ && e.norm != e.freq) n += vint_size(e.norm - e.freq);
+  return uint8_t(n);
+}
+void wand_write(uint32_t kind, const WandEntry& e, Bytes& o) {
+  put_vint(o, e.freq);
+  if (kind != IRS_SYNTH_WAND_MAX_FREQ && e.norm != e.freq) put_vint(o, e.norm - e.freq);
+}
+
 // One term: postings_writer<>::write + BeginDocument + EndDocument + EndTerm
 // (formats_10.cpp:942-1025, 865-891, 639-657, 662-798) for a FREQ-only field
 // written with no scorers (no wand bytes: valid_writers_ empty, :453-458).
 void encode_term(const uint32_t* docs, const uint32_t* freqs, uint32_t count,
                  uint32_t segment_docs, uint32_t layout, Bytes& o,
-                 irs_synth_term_meta& meta) {
+                 irs_synth_term_meta& meta, const WandSpec* wand = nullptr) {
   const size_t start = o.size();
   meta = irs_synth_term_meta{};
   meta.pos_end = UINT64_MAX;
@@ -149,12 +193,34 @@ void encode_term(const uint32_t* docs, const uint32_t* freqs, uint32_t count,
   uint32_t last = 0;       // doc_.last (invalid)
   uint64_t total_freq = 0;
 
-  // postings_writer_base::WriteSkip — :501-533 (no POS features)
+  // WandWriterImpl::levels_ — wand_writer.hpp:40-98: [scorer][level], level max_levels = root
+  const uint32_t wn = wand ? wand->count : 0;
+  std::vector<std::vector<WandEntry>> wl(wn, std::vector<WandEntry>(max_levels + 1));
+
+  // postings_writer_base::WriteSkip — :501-533 (no POS features), then, in formats with
+  // wand data, one size byte per scorer followed by the payloads (:990-999);
+  // WandWriterImpl::Write folds the entry into the level above and clears it (:61-67)
   auto write_skip = [&](uint32_t level, Bytes& out) {
     const uint64_t doc_ptr = o.size();
     put_vint(out, block_last);
     put_vlong(out, doc_ptr - skip_ptr[level]);
     skip_ptr[level] = doc_ptr;
+    for (uint32_t w = 0; w < wn; ++w) out.push_back(wand_size(wand->kinds[w], wl[w][level]));
+    for (uint32_t w = 0; w < wn; ++w) {
+      WandEntry& e = wl[w][level];
+      wand_produce(wand->kinds[w], e.freq, e.norm, wl[w][level + 1]);
+      wand_write(wand->kinds[w], e, out);
+      e = WandEntry{};
+    }
+  };
+  // EndTerm's write_max_score(level) — :669-675; SizeRoot cascades the levels below (:80-88)
+  auto write_max_score = [&](uint32_t level) {
+    for (uint32_t w = 0; w < wn; ++w) {
+      for (uint32_t l = 0; l < level; ++l)
+        wand_produce(wand->kinds[w], wl[w][l].freq, wl[w][l].norm, wl[w][l + 1]);
+      o.push_back(wand_size(wand->kinds[w], wl[w][level]));
+    }
+    for (uint32_t w = 0; w < wn; ++w) wand_write(wand->kinds[w], wl[w][level], o);
   };
 
   for (uint32_t i = 0; i < count; ++i) {
@@ -181,6 +247,9 @@ void encode_term(const uint32_t* docs, const uint32_t* freqs, uint32_t count,
     last = docs[i];
     ++n;
     total_freq += freqs ? freqs[i] : 0u;
+    for (uint32_t w = 0; w < wn; ++w)  // writer.Update() :1005-1006
+      wand_produce(wand->kinds[w], freqs ? freqs[i] : 1u,
+                   wand->norms ? wand->norms[docs[i] - 1] : 0xFFFFFFFFu, wl[w][0]);
     if (n == kBlock) {
       // simd::delta_encode<128>(docs, block_last) — simd_utils.hpp:200-249
       uint32_t prev = block_last;
@@ -202,6 +271,7 @@ void encode_term(const uint32_t* docs, const uint32_t* freqs, uint32_t count,
   if (count == 1) {
     meta.e_skip_start = uint64_t(buf_docs[0] - kDocMin);  // e_single_doc :677
   } else {
+    if (!(kBlock < count)) write_max_score(0);  // no skip list: wand root before the tail :686-688
     uint32_t prev = block_last;
     for (uint32_t k = 0; k < n; ++k) {  // tail :689-704
       const uint32_t delta = buf_docs[k] - prev;
@@ -220,6 +290,7 @@ void encode_term(const uint32_t* docs, const uint32_t* freqs, uint32_t count,
       // SkipWriter::CountLevels — skip_list.cpp:62-74
       uint32_t num_levels = max_levels;
       while (num_levels && levels[num_levels - 1].empty()) --num_levels;
+      write_max_score(num_levels);  // wand root of the whole list :778
       // FlushLevels — skip_list.cpp:76-92
       put_vint(o, num_levels);
       for (uint32_t l = num_levels; l-- > 0;) {
@@ -365,6 +436,34 @@ int64_t irs_synth_encode_term(const uint32_t* docs, const uint32_t* freqs,
   return int64_t(o.size());
 }
 
+int64_t irs_synth_encode_term_wand(const uint32_t* docs, const uint32_t* freqs,
+                                   uint32_t count, uint32_t segment_docs,
+                                   uint32_t layout, const uint8_t* norms,
+                                   const uint32_t* wand_kinds, uint32_t wand_count,
+                                   uint8_t* out, uint64_t out_cap,
+                                   irs_synth_term_meta* meta) {
+  if (!meta || (count && !docs) || wand_count > 8 || (wand_count && !wand_kinds)) return -1;
+  bool uses_norms = false;
+  for (uint32_t w = 0; w < wand_count; ++w) {
+    if (wand_kinds[w] > IRS_SYNTH_WAND_DIV_NORM) return -1;
+    uses_norms |= wand_kinds[w] != IRS_SYNTH_WAND_MAX_FREQ;
+  }
+  if (uses_norms && !norms) return -1;
+  for (uint32_t i = 0; i < count; ++i) {
+    if (docs[i] < kDocMin || docs[i] > segment_docs || (i && docs[i] <= docs[i - 1]) ||
+        (freqs && freqs[i] == 0))
+      return -1;
+    // a doc's field length is at least the term's frequency in it (wand_writer.hpp:201)
+    if (uses_norms && freqs && norms[docs[i] - 1] < freqs[i]) return -1;
+  }
+  const WandSpec spec{norms, wand_count, wand_kinds};
+  Bytes o;
+  encode_term(docs, freqs, count, segment_docs, layout, o, *meta, wand_count ? &spec : nullptr);
+  if (o.size() > out_cap) return -2;
+  if (!o.empty()) std::memcpy(out, o.data(), o.size());
+  return int64_t(o.size());
+}
+
 int64_t irs_synth_wrap_doc_file(const uint8_t* body, uint64_t body_len,
                                 uint32_t layout, uint8_t* out,
                                 uint64_t out_cap, uint64_t* body_offset) {
@@ -385,7 +484,8 @@ int64_t irs_synth_wrap_doc_file(const uint8_t* body, uint64_t body_len,
 int irs_synth_build(const irs_synth_params* p, irs_synth_index** out) {
   if (!p || !out || p->num_docs == 0 || p->max_rank == 0 ||
       p->vocab_log2 == 0 || p->vocab_log2 > 24 ||
-      p->max_rank > (1u << p->vocab_log2) || p->num_docs >= 0x7FFFFFF0u)
+      p->max_rank > (1u << p->vocab_log2) || p->num_docs >= 0x7FFFFFF0u ||
+      p->wand_count > 8 || p->wand_kind > IRS_SYNTH_WAND_DIV_NORM)
     return -1;
   auto idx = std::make_unique<irs_synth_index>();
   const uint32_t N = p->num_docs;
@@ -440,6 +540,11 @@ int irs_synth_build(const irs_synth_params* p, irs_synth_index** out) {
   idx->docs_with_field = N;
   for (uint64_t v : ttf) idx->total_term_freq += v;
 
+  // scorers the field is indexed with (0 = none: no wand bytes, as index-put writes)
+  uint32_t wand_kinds[8];
+  for (uint32_t w = 0; w < 8; ++w) wand_kinds[w] = p->wand_kind;
+  const WandSpec wand{idx->norms.data(), p->wand_count, wand_kinds};
+
   // ---- pass 2: encode terms in parallel (rank order = LPT order) ---------
   std::vector<Bytes> term_bytes(R);
   idx->metas.resize(R);
@@ -471,7 +576,7 @@ int irs_synth_build(const irs_synth_params* p, irs_synth_index** out) {
             std::vector<uint8_t>().swap(fv);
           }
           encode_term(d.data(), f.data(), uint32_t(total), N, p->layout,
-                      term_bytes[r], idx->metas[r]);
+                      term_bytes[r], idx->metas[r], wand.count ? &wand : nullptr);
           if (p->keep_postings) {
             idx->docs[r] = d;
             idx->freqs[r] = f;

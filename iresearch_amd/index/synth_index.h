@@ -38,6 +38,12 @@ typedef struct irs_synth_term_meta {
 } irs_synth_term_meta;
 
 enum { IRS_SYNTH_LAYOUT_SCALAR = 0, IRS_SYNTH_LAYOUT_SIMD4 = 1 };
+/* wand data kinds: which FreqNormProducer a scorer indexes with (wand_writer.hpp:130-148) */
+enum {
+  IRS_SYNTH_WAND_MAX_FREQ = 0, /* kWandTagMaxFreq: BM15, TFIDF without norms */
+  IRS_SYNTH_WAND_MIN_NORM = 1, /* kWandTagMinNorm: BM25 (bm25.cpp:518)        */
+  IRS_SYNTH_WAND_DIV_NORM = 2  /* kWandTagDivNorm: BM11, TFIDF with norms     */
+};
 
 typedef struct irs_synth_params {
   uint64_t seed;          /* 20260926 for every BASELINE config             */
@@ -50,6 +56,8 @@ typedef struct irs_synth_params {
   uint32_t stddev_len;    /*   clamped to [1,255]                           */
   uint32_t threads;       /* 0 = hardware_concurrency                       */
   uint32_t keep_postings; /* keep decoded (doc, tf) lists for verification  */
+  uint32_t wand_count;    /* scorers the field is indexed with (0..8): wand data */
+  uint32_t wand_kind;     /* IRS_SYNTH_WAND_* of every one of them           */
 } irs_synth_params;
 
 typedef struct irs_synth_index irs_synth_index;
@@ -79,6 +87,19 @@ int64_t irs_synth_encode_term(const uint32_t* docs, const uint32_t* freqs,
                               uint32_t count, uint32_t segment_docs,
                               uint32_t layout, uint8_t* out, uint64_t out_cap,
                               irs_synth_term_meta* meta);
+
+/* Same for a field indexed WITH scorers (formats 1_4/1_5 "wand data"): one
+ * FreqNormProducer per scorer (core/formats/wand_writer.hpp:152-342) — a size byte
+ * and a payload per scorer in front of the tail of lists without a skip list
+ * (formats_10.cpp:686-688), in front of the skip levels (:778) and in every skip
+ * entry (:990-999).  norms = 1-byte Norm2 column (norms[doc - 1]), required by the
+ * MIN_NORM / DIV_NORM kinds. */
+int64_t irs_synth_encode_term_wand(const uint32_t* docs, const uint32_t* freqs,
+                                   uint32_t count, uint32_t segment_docs,
+                                   uint32_t layout, const uint8_t* norms,
+                                   const uint32_t* wand_kinds, uint32_t wand_count,
+                                   uint8_t* out, uint64_t out_cap,
+                                   irs_synth_term_meta* meta);
 
 /* Wrap concatenated term bytes into a complete `.doc` file image:
  * header (format_utils.cpp:57-61) + body + footer (:63-67). Returns total

@@ -137,7 +137,8 @@ class SegmentReader:
     """irs::SubReader + postings_reader of one segment, resident on one GPU."""
 
     def __init__(self, doc_file, metas, num_docs, layout, norms=None, norm_width=1,
-                 docs_with_field=None, total_term_freq=0, device=0, has_freq=True, L=None):
+                 docs_with_field=None, total_term_freq=0, device=0, has_freq=True, L=None,
+                 wand_count=0):
         self.L = L or _lib.lib()
         self.doc_file = np.ascontiguousarray(doc_file, np.uint8)
         self.metas = np.zeros(len(metas), TERM_META)
@@ -152,7 +153,7 @@ class SegmentReader:
             device, layout, self.doc_file.ctypes.data, self.doc_file.size, num_docs,
             int(has_freq), None if self.norms is None else self.norms.ctypes.data, norm_width, 1,
             0 if self.norms is None else self.norms.size // norm_width,
-            self.metas.ctypes.data, len(self.metas), 0)
+            self.metas.ctypes.data, len(self.metas), int(wand_count))
         h = C.c_void_p()
         _lib.check(self.L, self.L.irs_hip_segment_open(C.byref(desc), C.byref(h)),
                    "irs_hip_segment_open")
@@ -161,7 +162,8 @@ class SegmentReader:
     @classmethod
     def from_synth(cls, seg, device=0, L=None, has_freq=True):
         return cls(seg.doc_file, seg.metas, seg.num_docs, seg.layout, seg.norms, 1,
-                   seg.docs_with_field, seg.total_term_freq, device, has_freq, L)
+                   seg.docs_with_field, seg.total_term_freq, device, has_freq, L,
+                   getattr(seg, "wand_count", 0))
 
     def close(self):
         if self.handle:

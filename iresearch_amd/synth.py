@@ -12,6 +12,7 @@ from . import _build
 
 LAYOUT_SCALAR = 0  # "1_5"      formats_10.cpp:86-131
 LAYOUT_SIMD4 = 1   # "1_5simd"  formats_10.cpp:4122-4157
+WAND_MAX_FREQ, WAND_MIN_NORM, WAND_DIV_NORM = 0, 1, 2   # wand_writer.hpp:130-148
 SEED = 20260926
 
 # version10::term_meta (formats_10_attributes.hpp:30-50)
@@ -28,7 +29,7 @@ class _Params(C.Structure):
         ("seed", C.c_uint64), ("first_doc", C.c_uint64), ("num_docs", C.c_uint32),
         ("vocab_log2", C.c_uint32), ("max_rank", C.c_uint32), ("layout", C.c_uint32),
         ("mean_len", C.c_uint32), ("stddev_len", C.c_uint32), ("threads", C.c_uint32),
-        ("keep_postings", C.c_uint32),
+        ("keep_postings", C.c_uint32), ("wand_count", C.c_uint32), ("wand_kind", C.c_uint32),
     ]
 
 
@@ -59,6 +60,10 @@ def lib():
         L.irs_synth_encode_term.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                             C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]
         L.irs_synth_encode_term.restype = C.c_int64
+        L.irs_synth_encode_term_wand.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                                 C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
+                                                 C.c_void_p, C.c_uint64, C.c_void_p]
+        L.irs_synth_encode_term_wand.restype = C.c_int64
         L.irs_synth_wrap_doc_file.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
                                               C.c_uint64, C.POINTER(C.c_uint64)]
         L.irs_synth_wrap_doc_file.restype = C.c_int64
@@ -87,6 +92,7 @@ class SynthSegment:
     layout: int
     num_docs: int
     postings: dict | None = None  # rank -> (docs u32[], freqs u32[]) when kept
+    wand_count: int = 0           # scorers the field was indexed with (wand data in `.doc`)
 
     def meta(self, rank: int) -> np.void:
         return self.metas[rank - 1]
@@ -95,10 +101,11 @@ class SynthSegment:
 def build_segment(num_docs: int, max_rank: int = 4096, *, layout: int = LAYOUT_SIMD4,
                   seed: int = SEED, first_doc: int = 0, vocab_log2: int = 20,
                   mean_len: int = 100, stddev_len: int = 30, threads: int = 0,
-                  keep_postings: bool = False) -> SynthSegment:
+                  keep_postings: bool = False, wand_count: int = 0,
+                  wand_kind: int = WAND_MIN_NORM) -> SynthSegment:
     L = lib()
     p = _Params(seed, first_doc, num_docs, vocab_log2, max_rank, layout, mean_len,
-                stddev_len, threads, int(keep_postings))
+                stddev_len, threads, int(keep_postings), wand_count, wand_kind)
     h = C.c_void_p()
     rc = L.irs_synth_build(C.byref(p), C.byref(h))
     if rc != 0:
@@ -124,13 +131,16 @@ def build_segment(num_docs: int, max_rank: int = 4096, *, layout: int = LAYOUT_S
                 else:
                     postings[r] = (np.zeros(0, np.uint32), np.zeros(0, np.uint32))
         return SynthSegment(doc_file, norms, metas, L.irs_synth_docs_with_field(h),
-                            L.irs_synth_total_term_freq(h), layout, num_docs, postings)
+                            L.irs_synth_total_term_freq(h), layout, num_docs, postings,
+                            wand_count)
     finally:
         L.irs_synth_free(h)
 
 
-def encode_term(docs, freqs, segment_docs: int, layout: int = LAYOUT_SIMD4):
-    """postings_writer::write for one explicit list -> (bytes, meta)."""
+def encode_term(docs, freqs, segment_docs: int, layout: int = LAYOUT_SIMD4, norms=None,
+                wand_kinds=()):
+    """postings_writer::write for one explicit list -> (bytes, meta).  wand_kinds: one WAND_*
+    per scorer the field is indexed with (norms = 1-byte Norm2 column, norms[doc - 1])."""
     docs = np.ascontiguousarray(docs, dtype=np.uint32)
     if freqs is not None:  # None: a field without IndexFeatures::FREQ
         freqs = np.ascontiguousarray(freqs, dtype=np.uint32)
@@ -138,22 +148,34 @@ def encode_term(docs, freqs, segment_docs: int, layout: int = LAYOUT_SIMD4):
     cap = 64 + 12 * len(docs) + 1024
     out = np.zeros(cap, np.uint8)
     meta = np.zeros(1, TERM_META)
-    n = lib().irs_synth_encode_term(docs.ctypes.data,
-                                    None if freqs is None else freqs.ctypes.data, len(docs),
-                                    segment_docs, layout, out.ctypes.data, cap,
-                                    meta.ctypes.data)
+    kinds = np.ascontiguousarray(wand_kinds, dtype=np.uint32)
+    cap += 16 * len(kinds) * (len(docs) // 128 + 4)
+    out = np.zeros(cap, np.uint8)
+    nrm = None if norms is None else np.ascontiguousarray(norms, np.uint8)
+    n = lib().irs_synth_encode_term_wand(docs.ctypes.data,
+                                         None if freqs is None else freqs.ctypes.data, len(docs),
+                                         segment_docs, layout,
+                                         None if nrm is None else nrm.ctypes.data,
+                                         kinds.ctypes.data if kinds.size else None, kinds.size,
+                                         out.ctypes.data, cap, meta.ctypes.data)
     if n < 0:
         raise ValueError("irs_synth_encode_term failed: %d" % n)
     return out[:n].copy(), meta[0]
 
 
-def segment_from_lists(lists, num_docs: int, layout: int = LAYOUT_SIMD4, norms=None):
+def segment_from_lists(lists, num_docs: int, layout: int = LAYOUT_SIMD4, norms=None,
+                       wand_kinds=()):
     """Build a `.doc` image from explicit [(docs, freqs), ...] posting lists."""
+    if len(wand_kinds) and (norms is None or norms is False) and \
+            any(k != WAND_MAX_FREQ for k in wand_kinds):
+        raise ValueError("MIN_NORM / DIV_NORM wand data needs the norm column")
     body = []
     metas = np.zeros(len(lists), TERM_META)
     off = 0
     for i, (d, f) in enumerate(lists):
-        b, m = encode_term(d, f, num_docs, layout)
+        b, m = encode_term(d, f, num_docs, layout,
+                           norms if len(wand_kinds) and norms is not None and norms is not False
+                           else None, wand_kinds)
         metas[i] = m
         metas[i]["doc_start"] = off
         off += len(b)
@@ -168,12 +190,12 @@ def segment_from_lists(lists, num_docs: int, layout: int = LAYOUT_SIMD4, norms=N
     metas["doc_start"] += hdr.value
     if norms is False:  # no Norm2 column at all
         return SynthSegment(out[:n].copy(), None, metas, num_docs, num_docs, layout, num_docs,
-                            None)
+                            None, len(wand_kinds))
     if norms is None:
         norms = np.ones(num_docs, np.uint8)
     ttf = int(np.asarray(norms, dtype=np.uint64).sum())
     return SynthSegment(out[:n].copy(), np.ascontiguousarray(norms, np.uint8), metas,
-                        num_docs, ttf, layout, num_docs, None)
+                        num_docs, ttf, layout, num_docs, None, len(wand_kinds))
 
 
 def make_queries(n_queries: int, n_terms: int, lo_rank: int = 16, hi_rank: int = 4096,

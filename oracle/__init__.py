@@ -29,7 +29,7 @@ HIT = np.dtype([("score", "<f4"), ("doc", "<u4"), ("segment", "<u4")])
 class Segment(C.Structure):
     _fields_ = [("doc_file", C.c_void_p), ("doc_file_len", C.c_uint64), ("layout", C.c_int32),
                 ("num_docs", C.c_uint32), ("norms", C.c_void_p), ("norm_width", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("wand_count", C.c_uint32)]
 
 
 class Scorer(C.Structure):
@@ -70,8 +70,12 @@ def lib():
         L.orc_read_block.restype = C.c_int64
         L.orc_decode_term.argtypes = [vp, u64, C.c_int, vp, vp, vp, u64]
         L.orc_decode_term.restype = C.c_int64
-        L.orc_decode_term_field.argtypes = [vp, u64, C.c_int, C.c_int, vp, vp, vp, u64]
-        L.orc_decode_term_field.restype = C.c_int64
+        L.orc_decode_term_wand.argtypes = [vp, u64, C.c_int, C.c_int, u32, vp, vp, vp, u64]
+        L.orc_decode_term_wand.restype = C.c_int64
+        L.orc_bit_union_wand.argtypes = [vp, u64, C.c_int, C.c_int, u32, vp, u32, vp, u64]
+        L.orc_bit_union_wand.restype = C.c_int64
+        L.orc_read_skip0_wand.argtypes = [vp, u64, u32, vp, vp, vp, u64, C.POINTER(u32), vp, vp]
+        L.orc_read_skip0_wand.restype = C.c_int64
         L.orc_bit_union.argtypes = [vp, u64, C.c_int, C.c_int, vp, u32, vp, u64]
         L.orc_bit_union.restype = C.c_int64
         L.orc_read_skip0.argtypes = [vp, u64, vp, vp, vp, u64, C.POINTER(u32)]
@@ -134,47 +138,54 @@ def unpack(words, bits: int, layout: int) -> np.ndarray:
 
 
 def decode_term(doc_file: np.ndarray, meta, layout: int, want_freq: bool = True,
-                field_has_freq: bool = True):
+                field_has_freq: bool = True, wand_count: int = 0):
     m = np.zeros(1, TERM_META)
     for k in TERM_META.names:
         m[0][k] = meta[k]
     n = int(m[0]["docs_count"])
     docs = np.zeros(n, np.uint32)
     freqs = np.zeros(n, np.uint32) if want_freq else None
-    got = lib().orc_decode_term_field(doc_file.ctypes.data, doc_file.size, layout,
-                                      int(field_has_freq), m.ctypes.data, docs.ctypes.data,
-                                      freqs.ctypes.data if want_freq else None, n)
+    got = lib().orc_decode_term_wand(doc_file.ctypes.data, doc_file.size, layout,
+                                     int(field_has_freq), wand_count, m.ctypes.data,
+                                     docs.ctypes.data, freqs.ctypes.data if want_freq else None, n)
     if got != n:
         raise ValueError("orc_decode_term: %d != %d" % (got, n))
     return docs, freqs
 
 
 def bit_union(doc_file: np.ndarray, metas, layout: int, has_freq: bool, n_words: int,
-              initial: np.ndarray | None = None):
+              initial: np.ndarray | None = None, wand_count: int = 0):
     m = np.zeros(len(metas), TERM_META)
     for i, meta in enumerate(metas):
         for k in TERM_META.names:
             m[i][k] = meta[k]
     bits = np.zeros(n_words, np.uint64) if initial is None else initial.copy()
-    n = lib().orc_bit_union(doc_file.ctypes.data, doc_file.size, layout, int(has_freq),
-                            m.ctypes.data, len(metas), bits.ctypes.data, n_words)
+    n = lib().orc_bit_union_wand(doc_file.ctypes.data, doc_file.size, layout, int(has_freq),
+                                 wand_count, m.ctypes.data, len(metas), bits.ctypes.data, n_words)
     if n < 0:
         raise ValueError("orc_bit_union failed: %d" % n)
     return bits, int(n)
 
 
-def read_skip0(doc_file: np.ndarray, meta):
+def read_skip0(doc_file: np.ndarray, meta, wand_count: int = 0, with_wand: bool = False):
+    """Level-0 skip entries: (last docs, next block pointers, #levels) and, with_wand, the
+    (max freq, norm) payload of scorer 0 in every entry."""
     m = np.zeros(1, TERM_META)
     for k in TERM_META.names:
         m[0][k] = meta[k]
     cap = int(m[0]["docs_count"]) // 128 + 1
     last = np.zeros(cap, np.uint32)
     ptrs = np.zeros(cap, np.uint64)
+    mf = np.zeros(cap, np.uint32)
+    nm = np.zeros(cap, np.uint32)
     lv = C.c_uint32()
-    n = lib().orc_read_skip0(doc_file.ctypes.data, doc_file.size, m.ctypes.data,
-                             last.ctypes.data, ptrs.ctypes.data, cap, C.byref(lv))
+    n = lib().orc_read_skip0_wand(doc_file.ctypes.data, doc_file.size, wand_count,
+                                  m.ctypes.data, last.ctypes.data, ptrs.ctypes.data, cap,
+                                  C.byref(lv), mf.ctypes.data, nm.ctypes.data)
     if n < 0:
         raise ValueError("orc_read_skip0 failed: %d" % n)
+    if with_wand:
+        return last[:n], ptrs[:n], lv.value, mf[:n], nm[:n]
     return last[:n], ptrs[:n], lv.value
 
 
@@ -189,15 +200,17 @@ class SegmentView:
     """Keeps the numpy buffers of one segment alive next to the C struct."""
 
     def __init__(self, doc_file, norms, layout, num_docs, docs_with_field, total_term_freq,
-                 norm_width=1):
+                 norm_width=1, wand_count=0):
         self.doc_file = np.ascontiguousarray(doc_file, np.uint8)
         self.norms = None if norms is None else np.ascontiguousarray(norms, np.uint8)
         self.layout, self.num_docs, self.norm_width = layout, num_docs, norm_width
         self.docs_with_field, self.total_term_freq = docs_with_field, total_term_freq
+        self.wand_count = wand_count
 
     def struct(self) -> Segment:
         return Segment(self.doc_file.ctypes.data, self.doc_file.size, self.layout, self.num_docs,
-                       None if self.norms is None else self.norms.ctypes.data, self.norm_width, 0)
+                       None if self.norms is None else self.norms.ctypes.data, self.norm_width,
+                       self.wand_count)
 
 
 def _metas_array(metas) -> np.ndarray:

@@ -63,6 +63,23 @@ int64_t orc_decode_term(const uint8_t* doc_file, uint64_t len, int layout,
 int64_t orc_decode_term_field(const uint8_t* doc_file, uint64_t len, int layout,
                               int field_has_freq, const orc_term_meta* meta,
                               uint32_t* docs, uint32_t* freqs, uint64_t cap);
+/* ... and for a field indexed with `wand_count` scorers: formats 1_4/1_5 interleave
+ * "wand data" (per scorer a size byte + a FreqNormProducer payload,
+ * wand_writer.hpp:152-342) in front of short lists' tails, in front of the skip
+ * levels and in every skip entry. */
+int64_t orc_decode_term_wand(const uint8_t* doc_file, uint64_t len, int layout,
+                             int field_has_freq, uint32_t wand_count,
+                             const orc_term_meta* meta, uint32_t* docs,
+                             uint32_t* freqs, uint64_t cap);
+int64_t orc_bit_union_wand(const uint8_t* doc_file, uint64_t len, int layout,
+                           int has_freq, uint32_t wand_count,
+                           const orc_term_meta* metas, uint32_t n_terms,
+                           uint64_t* set, uint64_t n_words);
+int64_t orc_read_skip0_wand(const uint8_t* doc_file, uint64_t len, uint32_t wand_count,
+                            const orc_term_meta* meta, uint32_t* last_docs,
+                            uint64_t* next_block_ptrs, uint64_t cap,
+                            uint32_t* num_levels, uint32_t* max_freq,
+                            uint32_t* norm_of_max);
 /* postings_reader::bit_union (formats_10.cpp:3716-3806): ORs bit `doc` into `set`
  * for every posting of every term; returns the sum of docs_count. */
 int64_t orc_bit_union(const uint8_t* doc_file, uint64_t len, int layout,
@@ -105,7 +122,7 @@ typedef struct orc_segment {
   uint32_t num_docs;
   const uint8_t* norms; /* dense Norm2 column, big-endian, doc 1 first; NULL = none */
   uint32_t norm_width;  /* 1, 2 or 4 bytes */
-  uint32_t reserved;
+  uint32_t wand_count;  /* scorers the field was indexed with (wand data to skip) */
 } orc_segment;
 
 typedef struct orc_scorer {

@@ -35,6 +35,10 @@ typedef struct {
 
 void orc_it_prepare(orc_doc_iterator* it, const uint8_t* file, uint64_t len,
                     int layout, const orc_term_meta* m, int want_freq);
+/* same, for a field indexed with `wand_count` scorers (wand data in `.doc`) */
+void orc_it_prepare_wand(orc_doc_iterator* it, const uint8_t* file, uint64_t len,
+                         int layout, const orc_term_meta* m, int want_freq,
+                         uint32_t wand_count);
 /* doc_iterator::next — returns 0 at eof (doc == UINT32_MAX) */
 int orc_it_next(orc_doc_iterator* it);
 /* doc_iterator::seek — first doc >= target (formats_10.cpp:2304-2365; the

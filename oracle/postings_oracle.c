@@ -203,6 +203,30 @@ int64_t orc_skip_block(const uint8_t* p, const uint8_t* end) {
 
 /* -------------------------------------------------------------- iterator */
 
+/* CommonSkipWandData — formats_10.cpp:1962-1979: one size byte per scorer the field
+ * was indexed with, then the payloads. */
+static void in_skip_wand(orc_in* in, uint32_t wand_count) {
+  uint64_t skip = 0;
+  uint32_t i;
+  for (i = 0; i < wand_count; ++i) skip += in_byte(in);
+  if ((uint64_t)(in->end - in->p) < skip) {
+    in->bad = 1;
+    in->p = in->end;
+  } else {
+    in->p += skip;
+  }
+}
+
+void orc_it_prepare_wand(orc_doc_iterator* it, const uint8_t* file, uint64_t len,
+                         int layout, const orc_term_meta* m, int want_freq,
+                         uint32_t wand_count) {
+  orc_it_prepare(it, file, len, layout, m, want_freq);
+  /* lists without a skip list carry their wand root in front of the tail
+   * (written :686-688); a reader that does not use it skips it when the list is
+   * shorter than one block (:2298-2301) — a 128-doc list reads its block first */
+  if (m->docs_count > 1 && m->docs_count < ORC_BLOCK) in_skip_wand(&it->in, wand_count);
+}
+
 void orc_it_prepare(orc_doc_iterator* it, const uint8_t* file, uint64_t len,
                        int layout, const orc_term_meta* m, int want_freq) {
   memset(it, 0, sizeof *it);
@@ -224,8 +248,8 @@ void orc_it_prepare(orc_doc_iterator* it, const uint8_t* file, uint64_t len,
   } else {
     it->in.p = file + m->doc_start; /* :2262 */
   }
-  /* docs_count < 128 && wand disabled -> SkipWandData(): no scorers were
-   * registered at index time, so there are zero bytes to skip (:2298-2301). */
+  /* docs_count < 128 && wand disabled -> SkipWandData() (:2298-2301): see
+   * orc_it_prepare_wand; this entry point is for fields indexed without scorers. */
 }
 
 /* doc_iterator_base::read_tail_block :1765-1792 */
@@ -299,11 +323,18 @@ int64_t orc_decode_term(const uint8_t* doc_file, uint64_t len, int layout,
 int64_t orc_decode_term_field(const uint8_t* doc_file, uint64_t len, int layout,
                               int field_has_freq, const orc_term_meta* meta,
                               uint32_t* docs, uint32_t* freqs, uint64_t cap) {
+  return orc_decode_term_wand(doc_file, len, layout, field_has_freq, 0, meta, docs, freqs, cap);
+}
+
+int64_t orc_decode_term_wand(const uint8_t* doc_file, uint64_t len, int layout,
+                             int field_has_freq, uint32_t wand_count,
+                             const orc_term_meta* meta, uint32_t* docs,
+                             uint32_t* freqs, uint64_t cap) {
   orc_doc_iterator it;
   uint64_t n = 0;
   if (meta->docs_count == 0) return 0;
   if (!field_has_freq && freqs) return -3; /* cannot request FREQ from such a field */
-  orc_it_prepare(&it, doc_file, len, layout, meta, freqs != NULL);
+  orc_it_prepare_wand(&it, doc_file, len, layout, meta, freqs != NULL, wand_count);
   it.field_no_freq = !field_has_freq;
   while (orc_it_next(&it)) {
     if (n >= cap) return -2;
@@ -317,12 +348,17 @@ int64_t orc_decode_term_field(const uint8_t* doc_file, uint64_t len, int layout,
 /* postings_reader::bit_union + the free ::bit_union — formats_10.cpp:3716-3806.
  * A separate code path of the reference (no iterator): read doc block, skip freq
  * block, `doc += delta; set_bit(set[doc / 64], doc % 64)`; then the vint tail.
- * Wand data (`FormatTraits::wand() && docs_count < 128`, :3776-3779) is absent
- * from the indexes used here (0 scorers at index time). Returns the sum of
- * docs_count like the reference, or <0 on corruption. */
+ * Returns the sum of docs_count like the reference, or <0 on corruption. */
 int64_t orc_bit_union(const uint8_t* doc_file, uint64_t len, int layout,
                       int has_freq, const orc_term_meta* metas,
                       uint32_t n_terms, uint64_t* set, uint64_t n_words) {
+  return orc_bit_union_wand(doc_file, len, layout, has_freq, 0, metas, n_terms, set, n_words);
+}
+
+int64_t orc_bit_union_wand(const uint8_t* doc_file, uint64_t len, int layout,
+                           int has_freq, uint32_t wand_count,
+                           const orc_term_meta* metas, uint32_t n_terms,
+                           uint64_t* set, uint64_t n_words) {
   uint32_t docs[ORC_BLOCK];
   uint64_t count = 0;
   uint32_t t;
@@ -336,6 +372,7 @@ int64_t orc_bit_union(const uint8_t* doc_file, uint64_t len, int layout,
       in.p = doc_file + m->doc_start;
       in.end = doc_file + len;
       in.bad = 0;
+      if (m->docs_count < ORC_BLOCK) in_skip_wand(&in, wand_count); /* :3776-3779 */
       while (nb--) {
         uint32_t i;
         in_block(&in, layout, docs);
@@ -375,6 +412,20 @@ int64_t orc_read_skip0(const uint8_t* doc_file, uint64_t len,
                        const orc_term_meta* meta, uint32_t* last_docs,
                        uint64_t* next_block_ptrs, uint64_t cap,
                        uint32_t* num_levels) {
+  return orc_read_skip0_wand(doc_file, len, 0, meta, last_docs, next_block_ptrs, cap,
+                             num_levels, NULL, NULL);
+}
+
+/* With wand data: the root entry sits in front of `num_levels` (:2223) and every
+ * skip entry ends with one size byte per scorer + the payloads (:990-999).  The
+ * payload of scorer 0 (FreqNormSource::Read, wand_writer.hpp:318-334: vint freq
+ * [+ vint(norm - freq)]) is returned per level-0 entry when max_freq/min_norm are
+ * given. */
+int64_t orc_read_skip0_wand(const uint8_t* doc_file, uint64_t len, uint32_t wand_count,
+                            const orc_term_meta* meta, uint32_t* last_docs,
+                            uint64_t* next_block_ptrs, uint64_t cap,
+                            uint32_t* num_levels, uint32_t* max_freq,
+                            uint32_t* norm_of_max) {
   orc_in in;
   uint32_t levels, l;
   uint64_t n = 0, ptr;
@@ -383,6 +434,7 @@ int64_t orc_read_skip0(const uint8_t* doc_file, uint64_t len,
   in.p = doc_file + meta->doc_start + meta->e_skip_start;
   in.end = doc_file + len;
   in.bad = 0;
+  in_skip_wand(&in, wand_count);
   levels = in_vint(&in);
   if (num_levels) *num_levels = levels;
   if (!levels) return 0;
@@ -403,6 +455,22 @@ int64_t orc_read_skip0(const uint8_t* doc_file, uint64_t len,
       if (n >= cap) return -2;
       last_docs[n] = doc;
       next_block_ptrs[n] = ptr;
+      if (wand_count) {
+        uint32_t sizes[16], w, total = 0;
+        if (wand_count > 16) return -1;
+        for (w = 0; w < wand_count; ++w) total += (sizes[w] = in_byte(&in));
+        if ((uint64_t)(in.end - in.p) < total) return -1;
+        if (max_freq || norm_of_max) {
+          orc_in pl = in;
+          const uint8_t* start = pl.p;
+          const uint32_t f = in_vint(&pl);
+          uint32_t nrm = f;
+          if ((uint32_t)(pl.p - start) != sizes[0]) nrm += in_vint(&pl);
+          if (max_freq) max_freq[n] = f;
+          if (norm_of_max) norm_of_max[n] = nrm;
+        }
+        in.p += total;
+      }
       ++n;
     }
   }

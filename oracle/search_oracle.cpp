@@ -304,8 +304,8 @@ void execute_segment(const orc_segment& seg, const orc_term_meta* metas,
     }
     itrs.emplace_back();
     Sub& s = itrs.back();
-    orc_it_prepare(&s.it, seg.doc_file, seg.doc_file_len, seg.layout, &metas[t],
-                   1);
+    orc_it_prepare_wand(&s.it, seg.doc_file, seg.doc_file_len, seg.layout, &metas[t], 1,
+                        seg.wand_count);
     make_term_scorer(scorer, seg, stats[t], boosts ? boosts[t] : 1.f, &s.sc);
     s.cost = metas[t].docs_count;
   }

@@ -272,6 +272,63 @@ def case_decode_without_freq(L, layout):
     sr.close()
 
 
+def case_wand_data(L, layout):
+    """Fields indexed WITH scorers (formats 1_4/1_5): "wand data" sits in front of short
+    lists' tails, in front of the skip levels and in every skip entry (formats_10.cpp:686-688,
+    :778, :990-999).  Decode, block directory, bit_union and query results must be what they
+    are for the same lists written without scorers."""
+    rng = np.random.default_rng(5)
+    n_docs = 40_000
+    norms = rng.integers(40, 256, n_docs).astype(np.uint8)
+    sizes = (1, 2, 90, 127, 128, 129, 255, 256, 1500, 9000)
+    lists = []
+    for n in sizes:
+        d = np.sort(rng.choice(n_docs, n, replace=False)).astype(np.uint32) + 1
+        f = np.minimum(rng.integers(1, 30, n), norms[d - 1]).astype(np.uint32)
+        lists.append((d, f))
+    plain = synth.segment_from_lists(lists, n_docs, layout, norms)
+    for kinds in ([synth.WAND_MIN_NORM], [synth.WAND_MAX_FREQ, synth.WAND_DIV_NORM, synth.WAND_MIN_NORM]):
+        seg = synth.segment_from_lists(lists, n_docs, layout, norms, wand_kinds=kinds)
+        wc = len(kinds)
+        assert seg.wand_count == wc and seg.doc_file.size > plain.doc_file.size
+        sr = search.SegmentReader.from_synth(seg, L=L)
+        for t, (d, f) in enumerate(lists):
+            gd, gf = sr.decode_term(t)
+            od, of = oracle.decode_term(seg.doc_file, seg.metas[t], layout, wand_count=wc)
+            assert np.array_equal(gd, d) and np.array_equal(gf, f), t
+            assert np.array_equal(od, d) and np.array_equal(of, f), t
+            last, offs = sr.term_directory(t)
+            sl, sp, levels, mf, nm = oracle.read_skip0(seg.doc_file, seg.metas[t], wc, True)
+            assert np.array_equal(last[:len(sl)], sl)
+            assert np.array_equal(offs[1:], sp[:max(len(offs) - 1, 0)])
+            # scorer 0's payload of every skip entry: the block's max freq [and min norm]
+            for b in range(len(sl)):
+                blk = slice(128 * b, 128 * b + 128)
+                assert mf[b] == f[blk].max(), (t, b)
+                if kinds[0] == synth.WAND_MIN_NORM:
+                    assert nm[b] == max(int(norms[d[blk] - 1].min()), int(f[blk].max())), (t, b)
+        n_words = (n_docs + 64) // 64
+        terms = list(range(len(lists)))
+        got, cnt = sr.bit_union(terms, n_words)
+        want, ocnt = oracle.bit_union(seg.doc_file, [seg.metas[t] for t in terms], layout, True,
+                                      n_words, wand_count=wc)
+        assert cnt == ocnt and np.array_equal(got, want)
+        # same query results as on the segment written without scorers
+        filters = [by_term(2), by_term(0), Or([by_term(t) for t in range(10)]),
+                   And([by_term(8), by_term(9)]), Or([by_term(2), by_term(3)], min_match=2)]
+        h1, c1, t1 = run_and_check(L, seg, filters, BM25(), 50, sr=sr)
+        h0, c0, t0 = run_and_check(L, plain, filters, BM25(), 50)
+        assert np.array_equal(h0, h1) and np.array_equal(c0, c1) and np.array_equal(t0, t1)
+        sr.close()
+    # the whole-corpus builder writes the same framing
+    a = synth.build_segment(6_000, 64, layout=layout, keep_postings=True, wand_count=2)
+    sr = search.SegmentReader.from_synth(a, L=L)
+    for r in (1, 7, 30, 64):
+        gd, gf = sr.decode_term(r - 1)
+        assert np.array_equal(gd, a.postings[r][0]) and np.array_equal(gf, a.postings[r][1])
+    sr.close()
+
+
 def case_bit_union(L, layout, has_freq=True):
     """postings_reader::bit_union (formats_10.cpp:3716-3806): bit-exact bitset and the
     reference's return value (sum of docs_count), over single-doc terms, tail-only terms,

@@ -26,7 +26,7 @@ def oracle_op(flt, op):
 def oracle_view(seg) -> oracle.SegmentView:
     return oracle.SegmentView(seg.doc_file, seg.norms, seg.layout, seg.num_docs,
                               seg.docs_with_field, seg.total_term_freq,
-                              getattr(seg, "norm_width", 1))
+                              getattr(seg, "norm_width", 1), getattr(seg, "wand_count", 0))
 
 
 def segment_stats(seg) -> search.SegmentStats:

@@ -58,6 +58,11 @@ def test_decode_without_freq(simlib, layout):
 
 
 @pytest.mark.parametrize("layout", [0, 1])
+def test_wand_data(simlib, layout):
+    cases.case_wand_data(simlib, layout)
+
+
+@pytest.mark.parametrize("layout", [0, 1])
 def test_bit_union(simlib, layout):
     cases.case_bit_union(simlib, layout)
     cases.case_bit_union(simlib, layout, has_freq=False)

@@ -63,6 +63,11 @@ def test_decode_without_freq(gpulib, layout):
 
 
 @pytest.mark.parametrize("layout", [0, 1])
+def test_wand_data(gpulib, layout):
+    cases.case_wand_data(gpulib, layout)
+
+
+@pytest.mark.parametrize("layout", [0, 1])
 def test_bit_union(gpulib, layout):
     cases.case_bit_union(gpulib, layout)
     cases.case_bit_union(gpulib, layout, has_freq=False)
