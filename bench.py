@@ -149,8 +149,11 @@ def main():
     stream = torch.cuda.current_stream(dev)
     sptr = C_void(stream.cuda_stream)
     nq, k = args.queries, args.k
-    recv = {s: (torch.zeros((nq, k), dtype=torch.int64, device=dev),
-                torch.zeros((nq,), dtype=torch.int32, device=dev)) for s in my}
+    # every buffer of the exchange step is allocated once; each local segment's results
+    # are written straight into its slot of the send buffer
+    exchange = distributed.TopkExchange(L, local_rank, n_segments if multi else 1, rank, world,
+                                        nq, k, dev)
+    slots = {s: exchange.slot(i) for i, s in enumerate(my)}
 
     def step():
         # every step ends with a checked, device-resident top-k: results_to_device reads the
@@ -158,14 +161,11 @@ def main():
         # candidate buffer fell short (irs_hip_batch_reruns counts those)
         for s in my:
             batches[s].run(sptr)
-        lists = []
         for s in my:
-            batches[s].results_to_device(recv[s][0].data_ptr(), recv[s][1].data_ptr(), sptr)
-            lists.append((s, recv[s][0], recv[s][1]))
+            batches[s].results_to_device(slots[s][0], slots[s][1], sptr)
         if multi:
-            return distributed.gather_merge(L, local_rank, lists, n_segments, rank, world, nq, k,
-                                            dev, sptr)
-        return lists[0]
+            return exchange.run(sptr)   # one all-gather (RCCL) + GPU merge
+        return exchange.send
 
     for _ in range(args.warmup):
         step()

@@ -33,35 +33,67 @@ def _ptr_array(ptrs):
     return (C.c_void_p * len(ptrs))(*ptrs)
 
 
+class TopkExchange:
+    """The one exchange step of the path, with every buffer allocated once.
+
+    Each rank owns `per` segment slots.  Its send buffer is ONE int64 tensor: `per` hit
+    tables [nq][k] (an int64 carries one irs_hip_hit) followed by `per` count tables [nq]
+    (int32, two per int64) — `slot(i)` hands out the device pointers of slot i so that
+    irs_hip_batch_results_to_device writes straight into it.  `run()` = one
+    all_gather_into_tensor (RCCL over xGMI with backend "nccl") + irs_hip_merge_topk.
+    """
+
+    def __init__(self, L, device_index: int, n_segments: int, rank: int, world: int, nq: int,
+                 k: int, tensor_device):
+        self.L, self.device_index, self.nq, self.k = L, device_index, nq, k
+        self.world, self.rank = world, rank
+        self.per = per = (n_segments + world - 1) // world
+        self.n_lists = min(n_segments, world * per)
+        self.hit_words = per * nq * k
+        self.cnt_words = (per * nq + 1) // 2
+        words = self.hit_words + self.cnt_words
+        self.send = torch.zeros((words,), dtype=torch.int64, device=tensor_device)
+        self.recv = (torch.zeros((world * words,), dtype=torch.int64, device=tensor_device)
+                     if world > 1 else self.send)
+        self.out_h = torch.zeros((nq, k), dtype=torch.int64, device=tensor_device)
+        self.out_s = torch.zeros((nq, k), dtype=torch.int32, device=tensor_device)
+        self.out_c = torch.zeros((nq,), dtype=torch.int32, device=tensor_device)
+        base = self.recv.data_ptr()
+        lists, counts = [], []
+        for i in range(self.n_lists):       # global segment ordinal i = rank r, slot j
+            r, j = divmod(i, per)
+            blk = base + 8 * r * words
+            lists.append(blk + 8 * j * nq * k)
+            counts.append(blk + 8 * self.hit_words + 4 * j * nq)
+        self._lists, self._counts = _ptr_array(lists), _ptr_array(counts)
+        self._seg_ids = np.arange(self.n_lists, dtype=np.uint32)
+
+    def slot(self, i: int):
+        """(hits pointer, counts pointer) of local segment slot i in the send buffer."""
+        base = self.send.data_ptr()
+        return base + 8 * i * self.nq * self.k, base + 8 * self.hit_words + 4 * i * self.nq
+
+    def run(self, stream=None):
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.recv, self.send)
+        _lib.check(self.L, self.L.irs_hip_merge_topk(
+            self.device_index, self._lists, self._counts, self._seg_ids.ctypes.data,
+            self.n_lists, self.nq, self.k, self.out_h.data_ptr(), self.out_s.data_ptr(),
+            self.out_c.data_ptr(), stream), "irs_hip_merge_topk")
+        return self.out_h, self.out_s, self.out_c
+
+
 def gather_merge(L, device_index: int, local_lists, n_segments: int, rank: int, world: int,
                  nq: int, k: int, tensor_device, stream=None):
     """local_lists: [(segment ordinal, hits tensor int64 [nq, k], counts tensor int32 [nq])]
-    for this rank's segments (an int64 carries one irs_hip_hit).  Returns tensors
-    (hits int64 [nq, k], seg int32 [nq, k], counts int32 [nq]) identical on all ranks."""
-    per = (n_segments + world - 1) // world
-    send_h = torch.zeros((per, nq, k), dtype=torch.int64, device=tensor_device)
-    send_c = torch.zeros((per, nq), dtype=torch.int32, device=tensor_device)
+    for this rank's segments.  Returns tensors (hits int64 [nq, k], seg int32 [nq, k],
+    counts int32 [nq]) identical on all ranks.  (One-shot form of TopkExchange.)"""
+    ex = TopkExchange(L, device_index, n_segments, rank, world, nq, k, tensor_device)
+    cnt32 = ex.send[ex.hit_words:].view(torch.int32)
     for i, (_, h, c) in enumerate(local_lists):
-        send_h[i].copy_(h)
-        send_c[i].copy_(c)
-    if world > 1:
-        all_h = torch.empty((world * per, nq, k), dtype=torch.int64, device=tensor_device)
-        all_c = torch.empty((world * per, nq), dtype=torch.int32, device=tensor_device)
-        dist.all_gather_into_tensor(all_h, send_h)
-        dist.all_gather_into_tensor(all_c, send_c)
-    else:
-        all_h, all_c = send_h, send_c
-    n_lists = min(n_segments, world * per)
-    seg_ids = np.arange(n_lists, dtype=np.uint32)
-    out_h = torch.empty((nq, k), dtype=torch.int64, device=tensor_device)
-    out_s = torch.empty((nq, k), dtype=torch.int32, device=tensor_device)
-    out_c = torch.empty((nq,), dtype=torch.int32, device=tensor_device)
-    lists = _ptr_array([all_h[i].data_ptr() for i in range(n_lists)])
-    counts = _ptr_array([all_c[i].data_ptr() for i in range(n_lists)])
-    _lib.check(L, L.irs_hip_merge_topk(device_index, lists, counts, seg_ids.ctypes.data, n_lists,
-                                       nq, k, out_h.data_ptr(), out_s.data_ptr(),
-                                       out_c.data_ptr(), stream), "irs_hip_merge_topk")
-    return out_h, out_s, out_c
+        ex.send[i * nq * k:(i + 1) * nq * k].copy_(h.reshape(-1))
+        cnt32[i * nq:(i + 1) * nq].copy_(c)
+    return ex.run(stream)
 
 
 def hits_from_int64(t: torch.Tensor) -> np.ndarray:
