@@ -266,7 +266,7 @@ bool ensure_scratch(irs_hip_batch* b) {
   b->stride_eff = std::max<uint32_t>(1, std::min<uint32_t>(b->stride, b->n_tiles / 4));
   if (const char* e = std::getenv("IRS_HIP_WG_THREADS")) {  // tuning knob
     const uint32_t t = uint32_t(std::atoi(e));
-    if (t == 256 || t == 512 || t == 1024) b->wg_threads = t;
+    if (t >= 256 && t <= 1024 && t % 64 == 0) b->wg_threads = t;
   }
   if (b->cand_cap == 0) b->cand_cap = default_cand_cap(b);
   const uint64_t rows = uint64_t(b->nq) * b->jt;

@@ -759,11 +759,12 @@ __device__ __forceinline__ void item_load(const DevSegment& seg, const ItemRegs&
 
 template<int LAYOUT>
 __device__ __forceinline__ void items_prepare(const DevSegment& seg, const ItemL* items,
-                                              uint32_t n, ItemRegs& r) {
+                                              uint32_t n, uint32_t inv_nw, ItemRegs& r) {
   const unsigned lane = threadIdx.x & 63u;
   const uint32_t wv = wave::uniform(threadIdx.x >> 6);
-  const uint32_t nw = blockDim.x >> 6;  // workgroups are 256/512/1024 threads: a power of two
-  r.n = wave::uniform(n > wv ? (n - wv + nw - 1) >> (31 - __builtin_clz(nw)) : 0u);
+  const uint32_t nw = blockDim.x >> 6;
+  // ceil((n - wv) / nw) for n <= 256, nw <= 16, with inv_nw = ceil(2^16 / nw)
+  r.n = wave::uniform(n > wv ? ((n - wv + nw - 1) * inv_nw) >> 16 : 0u);
   // lanes past the last item never carry the straight-line flag: nothing is loaded
   r.pack = 0x0101u;
   r.base = 0;
@@ -875,7 +876,8 @@ __device__ __forceinline__ void process_items(const DevSegment& seg, const TileS
                                               const ItemL* items, uint32_t n, uint32_t lo,
                                               uint32_t span, float fx_mul) {
   ItemRegs r;
-  items_prepare<LAYOUT>(seg, items, n, r);
+  const uint32_t nw = blockDim.x >> 6;
+  items_prepare<LAYOUT>(seg, items, n, (65536u + nw - 1) / nw, r);
   items_run<ACC, LAYOUT, TILE, AND>(seg, sm, r, lo, span, fx_mul);
 }
 
@@ -1178,6 +1180,7 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
   const unsigned lane = tid & 63u;
   const uint32_t wv = wave::uniform(tid >> 6);
   const uint32_t nw = blockDim.x >> 6;
+  const uint32_t inv_nw = (65536u + nw - 1) / nw;   // wavefronts per workgroup: 4..16
   const uint32_t cpq = (n_tiles + kChunkTiles - 1) / kChunkTiles;  // chunks per query
   const uint32_t total_chunks = n_queries * cpq;
 
@@ -1347,7 +1350,7 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
       norm_load(tile0 + 1, nrm);
     }
     ItemRegs R;
-    items_prepare<LAYOUT>(seg, items_of(0), n_cur < kItemChunk ? n_cur : kItemChunk, R);
+    items_prepare<LAYOUT>(seg, items_of(0), n_cur < kItemChunk ? n_cur : kItemChunk, inv_nw, R);
 
     uint32_t pend_base = 0;   // thread 0: reserved candidate base of the previous tile (in flight)
     for (uint32_t u = 0; u < ntile; ++u) {
@@ -1398,7 +1401,8 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
           norm_load(tile + 2u, nrm);
         }
         // this wavefront's items of tile u+1 and the payload of the first two
-        items_prepare<LAYOUT>(seg, items_of(u + 1u), n_next < kItemChunk ? n_next : kItemChunk, R);
+        items_prepare<LAYOUT>(seg, items_of(u + 1u), n_next < kItemChunk ? n_next : kItemChunk,
+                              inv_nw, R);
       }
 
       // epilogue of tile u: read + clear the accumulators, count hits, stage candidates
