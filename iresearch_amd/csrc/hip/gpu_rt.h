@@ -75,3 +75,4 @@ inline bool event_elapsed(float* ms, event_t a, event_t b) {
 
 // Dynamic LDS carve base, 16-byte aligned (cdna guide G17).
 #define RT_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+

@@ -98,6 +98,15 @@ __device__ __forceinline__ void keep_f(float& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void keep_acc(uint32_t& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void keep_acc(unsigned long long& v) { asm volatile("" : "+v"(v)); }
 
+__device__ __forceinline__ void keep_all(uint32_t (&v)[2]) { asm volatile("" : "+v"(v[0]), "+v"(v[1])); }
+__device__ __forceinline__ void keep_all(uint32_t (&v)[4]) {
+  asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+}
+__device__ __forceinline__ void keep_all_f(float (&v)[2]) { asm volatile("" : "+v"(v[0]), "+v"(v[1])); }
+__device__ __forceinline__ void keep_all_f(float (&v)[4]) {
+  asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+}
+
 // A register whose content does not matter (no instruction is emitted).
 __device__ __forceinline__ uint64_t undef64() {
   uint64_t v;

@@ -657,12 +657,10 @@ __device__ __forceinline__ void tile_post_bm25(const TileSmemT<ACC>& sm, const f
     idx[k] = raw < dummy ? raw : dummy;
     nb[k] = sm.lnorm[idx[k]];
   }
-#pragma unroll
-  for (int k = N - 1; k >= 0; --k) wave::keep(nb[k]);   // last issued first: one wait
+  wave::keep_all(nb);   // one asm statement over all N values: one s_waitcnt
 #pragma unroll
   for (int k = 0; k < N; ++k) inv[k] = cache[k][nb[k]];
-#pragma unroll
-  for (int k = N - 1; k >= 0; --k) wave::keep_f(inv[k]);
+  wave::keep_all_f(inv);
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     const float r = wave::fast_rcp(wave::fma(static_cast<float>(freq[k]), inv[k], 1.f));

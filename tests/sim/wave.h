@@ -69,6 +69,8 @@ __device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t s)
 }
 __device__ __forceinline__ uint32_t bfe(uint32_t x, uint32_t bits) { return x & ((1u << bits) - 1u); }
 __device__ __forceinline__ uint64_t undef64() { return 0; }
+template<int N> __device__ __forceinline__ void keep_all(uint32_t (&)[N]) {}
+template<int N> __device__ __forceinline__ void keep_all_f(float (&)[N]) {}
 __device__ __forceinline__ void keep(uint32_t&) {}
 __device__ __forceinline__ void keep_f(float&) {}
 __device__ __forceinline__ void keep_acc(uint32_t&) {}
