@@ -261,7 +261,8 @@ bool ensure_scratch(irs_hip_batch* b) {
   const irs_hip_segment* s = b->seg;
   // 32-bit accumulators halve the LDS per doc: twice the tile at the same residency
   // the largest tile that still lets two workgroups share a CU's 160 KB of LDS
-  if (b->tile == 0) b->tile = b->acc32 ? 12288 : 6144;
+  // (AND / min-match batches also keep a match counter byte per doc)
+  if (b->tile == 0) b->tile = b->acc32 ? (b->any_and ? 8192 : 12288) : 6144;
   b->n_tiles = (s->dev.num_docs + b->tile - 1) / b->tile;
   b->stride_eff = std::max<uint32_t>(1, std::min<uint32_t>(b->stride, b->n_tiles / 4));
   if (const char* e = std::getenv("IRS_HIP_WG_THREADS")) {  // tuning knob

@@ -500,7 +500,7 @@ struct TileSmemT {
   ACC* acc;          // [TILE + 64] fixed-point score accumulators (score_buf of
                      // block_disjunction, disjunction.hpp:1087-1092, widened to TILE docs)
                      // + one private dummy slot per lane
-  uint32_t* cnt;     // [TILE/4] per-doc match counters, 1 byte each (AND only)
+  uint32_t* cnt;     // [(TILE + 64)/4] per-doc match counters, 1 byte each (AND only; + dummies)
   uint8_t* lnorm;    // [TILE] Norm2 bytes of the tile
   float* caches;     // [kMaxCaches][256] BM25Stats::norm_cache
   DevQTerm* qts;     // [kMaxTerms] the query's term scorers
@@ -511,7 +511,7 @@ struct TileSmemT {
 
 template<typename ACC, int TILE, bool AND>
 constexpr uint32_t tile_smem_bytes() {
-  return uint32_t(sizeof(ACC)) * (TILE + 64) + (AND ? TILE : 0) + TILE +
+  return uint32_t(sizeof(ACC)) * (TILE + 64) + (AND ? TILE + 64 : 0) + TILE +
          sizeof(float) * 256 * kMaxCaches + sizeof(DevQTerm) * kMaxTerms +
          sizeof(TermL) * kMaxTerms + sizeof(ItemL) * kItemChunk + 32;
 }
@@ -522,7 +522,7 @@ __device__ __forceinline__ TileSmemT<ACC> carve(unsigned char* smem, unsigned ch
   sm.acc = reinterpret_cast<ACC*>(smem);
   smem += sizeof(ACC) * (TILE + 64);
   sm.cnt = reinterpret_cast<uint32_t*>(smem);
-  if (AND) smem += TILE;
+  if (AND) smem += TILE + 64;
   sm.lnorm = smem;
   smem += TILE;
   sm.caches = reinterpret_cast<float*>(smem);
@@ -671,9 +671,8 @@ __device__ __forceinline__ void tile_post_bm25(const TileSmemT<ACC>& sm, const f
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     atomicAdd(&sm.acc[idx[k]], fx[k]);
-    if (AND) {
-      if (idx[k] < uint32_t(TILE)) atomicAdd(&sm.cnt[idx[k] >> 2], 1u << (8u * (idx[k] & 3u)));
-    }
+    // (out-of-tile postings bump a dummy counter byte, like their dummy accumulator)
+    if (AND) atomicAdd(&sm.cnt[idx[k] >> 2], 1u << (8u * (idx[k] & 3u)));
   }
 }
 
@@ -1419,21 +1418,9 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
           }
         }
       };
-      if (AND && (qd.op & 0xFF) == 1) {  // AND / min-match: op = 1 | required matches << 8
+      {
+        const bool is_and = AND && (qd.op & 0xFF) == 1;  // op = 1 | required matches << 8
         const uint32_t need = uint32_t(qd.op >> 8);
-        uint32_t my_hits = 0;
-        for (uint32_t i = tid; i < uint32_t(TILE); i += blockDim.x) {
-          const ACC a = sm.acc[i];
-          if (a != ACC(0)) sm.acc[i] = ACC(0);
-          const bool m = ((sm.cnt[i >> 2] >> (8u * (i & 3u))) & 0xFFu) >= need;
-          if (m) {
-            ++my_hits;
-            if (a >= thr) candidate(i, a);
-          }
-        }
-        my_hits = wave::reduce_add(my_hits);
-        if (lane == 0 && my_hits) atomicAdd(&vars[kVHits], my_hits);
-      } else {
         // eight accumulators per lane per step: two 4-wide LDS reads in flight, two
         // wide clears; hits are counted per wavefront with ballots (SALU adds)
         uint32_t wave_hits = 0;
@@ -1448,13 +1435,31 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
           for (int e = 0; e < 4; ++e) a[4 + e] = sm.acc[i2 + e];
 #pragma unroll
           for (int e = 0; e < 8; ++e) wave::keep_acc(a[e]);
+          uint32_t cw0 = 0, cw1 = 0;   // match counters of docs i..i+3 / i2..i2+3, a byte each
+          if (AND) {
+            cw0 = sm.cnt[i >> 2];
+            cw1 = sm.cnt[i2 >> 2];
+          }
 #pragma unroll
           for (int e = 0; e < 4; ++e) sm.acc[i + e] = ACC(0);
 #pragma unroll
           for (int e = 0; e < 4; ++e) sm.acc[i2 + e] = ACC(0);
+          if (AND) {   // this thread is the only reader of those counter words: clear them here
+            sm.cnt[i >> 2] = 0u;
+            sm.cnt[i2 >> 2] = 0u;
+          }
           if (!two) {
 #pragma unroll
             for (int e = 4; e < 8; ++e) a[e] = ACC(0);
+          }
+          if (AND && is_and) {
+            // AND / min-match: a doc counts only with >= `need` matching terms; the others
+            // are made to look untouched
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const uint32_t c = ((e < 4 ? cw0 : cw1) >> (8u * (uint32_t(e) & 3u))) & 0xFFu;
+              a[e] = c >= need ? a[e] : ACC(0);
+            }
           }
           ACC top = a[0];
 #pragma unroll
@@ -1477,10 +1482,6 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
           }
         }
         if (lane == 0 && wave_hits) atomicAdd(&vars[kVHits], wave_hits);
-      }
-      if (AND) {
-        __syncthreads();  // counters are packed 4 per word: clear only after all reads
-        for (uint32_t i = tid; i < uint32_t(TILE) / 4; i += blockDim.x) sm.cnt[i] = 0u;
       }
       if (tid == 0) {
         vars[kVBase] = pend_base;                 // tile u-1's reservation has arrived by now

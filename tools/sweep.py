@@ -23,20 +23,29 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--configs", default="4096:16")
     ap.add_argument("--nocheck", action="store_true")
+    ap.add_argument("--op", default="or", choices=["or", "and", "mm"], help="Or / And / Or(min_match=terms-1)")
+    ap.add_argument("--terms", type=int, default=8)
+    ap.add_argument("--scorer", default="bm25", choices=["bm25", "tfidf", "bm15"])
     ap.add_argument("--lib", default=None, help="alternative build of libirs_hip.so (A/B runs)")
     args = ap.parse_args()
     import torch
 
     from iresearch_amd import _lib, search, synth
-    from iresearch_amd.search import BM25, Or, by_term
+    from iresearch_amd.search import BM25, TFIDF, And, Or, by_term
     L = _lib.bind(ctypes.CDLL(args.lib)) if args.lib else _lib.lib()
     seg = synth.build_segment(args.docs, 4096)
     sr = search.SegmentReader.from_synth(seg, L=L)
-    ranks = synth.make_queries(args.queries, 8, 16, 4096, synth.SEED + 2)
-    filters = [Or([by_term(int(r) - 1) for r in row]) for row in ranks]
+    ranks = synth.make_queries(args.queries, args.terms, 16, 4096, synth.SEED + 2)
+    if args.op == "and":
+        filters = [And([by_term(int(r) - 1) for r in row]) for row in ranks]
+    elif args.op == "mm":
+        filters = [Or([by_term(int(r) - 1) for r in row], min_match=args.terms - 1) for row in ranks]
+    else:
+        filters = [Or([by_term(int(r) - 1) for r in row]) for row in ranks]
+    scorer = {"bm25": BM25(), "tfidf": TFIDF(True), "bm15": BM25(1.2, 0.0)}[args.scorer]
     st = search.SegmentStats(seg.docs_with_field, seg.total_term_freq,
                              np.asarray(seg.metas["docs_count"]))
-    prep = search.prepare(filters, BM25(), [st])
+    prep = search.prepare(filters, scorer, [st])
     ref = None
     for cfg in args.configs.split(","):
         tile, stride = (int(x) for x in cfg.split(":"))
