@@ -117,6 +117,9 @@ __device__ __forceinline__ uint64_t undef64() {
 // v_rcp_f32: <= 1 ulp
 __device__ __forceinline__ float fast_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
 
+// v_sqrt_f32: <= 1 ulp
+__device__ __forceinline__ float fast_sqrt(float v) { return __builtin_amdgcn_sqrtf(v); }
+
 // a*b + c in one rounding (v_fma_f32), independent of -ffp-contract
 __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 

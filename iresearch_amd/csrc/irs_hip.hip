@@ -631,15 +631,19 @@ int irs_hip_batch_create(irs_hip_segment* seg, const irs_hip_query* queries, uin
           });
         }
       }
-      // norm_cache slots: one per distinct (norm_const, norm_length)
+      // table slots (kernels.h "table_kind"): one per distinct (kind, norm_const, norm_length)
       uint32_t n_caches = 0;
       float cnc[kMaxCaches], cnl[kMaxCaches];
+      int32_t ckind[kMaxCaches];
       for (DevQTerm& qt : row) {
-        if (qt.kind != kBM25Tiny) continue;
+        if (qt.kind != kBM25Tiny && qt.kind != kBM25One && qt.kind != kBM15 &&
+            qt.kind != kTfidf && qt.kind != kTfidfTiny)
+          continue;
         uint32_t c = 0;
         for (; c < n_caches; ++c)
-          if (cnc[c] == qt.norm_const && cnl[c] == qt.norm_length) break;
+          if (ckind[c] == qt.kind && cnc[c] == qt.norm_const && cnl[c] == qt.norm_length) break;
         if (c == n_caches && n_caches < kMaxCaches) {
+          ckind[c] = qt.kind;
           cnc[c] = qt.norm_const;
           cnl[c] = qt.norm_length;
           ++n_caches;

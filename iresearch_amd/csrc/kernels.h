@@ -481,18 +481,63 @@ struct alignas(16) ItemL {   // one (term, block) work item: one 16-byte LDS rea
   float cs;             // the term's c0 pre-multiplied by the fixed-point scale
 };
 
-// Bits 16.. of ItemL::pack for term slot j; bit 30 = "this scorer has a fast path"
-// (BM25 over 1-byte norms with an LDS norm_cache), resolved against the block's
-// bit widths by item_pack().
+// Scorers of the straight-line path are all evaluated from one 256-entry table row
+// `tab` in LDS (indexed by the doc's norm byte), in one of two forms:
+//   reciprocal form  score = c0 - c0 / (1 + tf * tab[norm])
+//     BM25, 1-byte norms  tab[n] = norm_cache[n] = 1/(norm_const + norm_length*n), [0] = 0
+//                         (bm25.cpp:348-353, 404-409)
+//     BM25, no norms      tab[n] = 1/(norm_const + norm_length)   (norm == 1, bm25.cpp:487-489)
+//     BM15                tab[n] = 1/norm_const                    (bm25.cpp:313)
+//   square-root form score = sqrt(tf) * c0 * tab[norm]
+//     TF-IDF              tab[n] = 1                               (tfidf.cpp:185-187)
+//     TF-IDF with norms   tab[n] = 1/sqrt(n), [0] = 0              (tfidf.cpp:251-253)
+// Rows that ignore the norm are constant, so whatever byte the norm stage reads is fine.
+__device__ __forceinline__ bool table_kind(int32_t kind) {
+  return kind == kBM25Tiny || kind == kBM25One || kind == kBM15 || kind == kTfidf ||
+         kind == kTfidfTiny;
+}
+__device__ __forceinline__ bool sqrt_kind(int32_t kind) {
+  return kind == kTfidf || kind == kTfidfTiny;
+}
+__device__ __forceinline__ float table_value(int32_t kind, float nc, float nl, uint32_t n) {
+  switch (kind) {
+    case kBM25Tiny: return n ? 1.f / (nc + nl * static_cast<float>(n)) : 0.f;
+    case kBM25One: return 1.f / (nc + nl * 1.f);
+    case kBM15: return 1.f / nc;
+    case kTfidf: return 1.f;
+    default: return n ? 1.f / sqrtf(static_cast<float>(n)) : 0.f;  // kTfidfTiny
+  }
+}
+// One thread per table entry: the row of slot c comes from the first term using it.
+template<typename SM>
+__device__ __forceinline__ void build_tables(const SM& sm, uint32_t n_caches, uint32_t n_terms) {
+  for (uint32_t e = threadIdx.x; e < n_caches * 256u; e += blockDim.x) {
+    const uint32_t c = e >> 8, n = e & 255u;
+    float v = 0.f;
+    for (uint32_t j = 0; j < n_terms; ++j) {
+      if (sm.qts[j].cache_id == c) {
+        v = table_value(sm.qts[j].kind, sm.qts[j].norm_const, sm.qts[j].norm_length, n);
+        break;
+      }
+    }
+    sm.caches[e] = v;
+  }
+}
+
+// Bits 16.. of ItemL::pack for term slot j: table slot (16-19), term slot (20-24),
+// square-root form (25); bit 30 = "this scorer has a straight-line path", resolved
+// against the block's bit widths by item_pack().
+constexpr uint32_t kPackSqrt = 0x02000000u;
 __device__ __forceinline__ uint32_t term_pack(uint32_t j, int32_t kind, uint32_t cache_id) {
-  const bool fk = kind == kBM25Tiny && cache_id < kMaxCaches;
-  return ((cache_id < 15u ? cache_id : 15u) << 16) | (j << 20) | (fk ? 0x40000000u : 0u);
+  const bool fk = table_kind(kind) && cache_id < kMaxCaches;
+  return ((cache_id < 15u ? cache_id : 15u) << 16) | (j << 20) |
+         (sqrt_kind(kind) ? kPackSqrt : 0u) | (fk ? 0x40000000u : 0u);
 }
 __device__ __forceinline__ uint32_t item_pack(uint32_t bits16, uint32_t tpack) {
   const uint32_t dbits = bits16 & 0xFFu, fbits = (bits16 >> 8) & 0xFFu;
   // the straight-line decoder handles 1..31-bit packed blocks
   const bool fast = (tpack & 0x40000000u) && (dbits - 1u) <= 30u && (fbits - 1u) <= 30u;
-  return (bits16 & 0xFFFFu) | (tpack & 0x01FF0000u) | (fast ? 0x80000000u : 0u);
+  return (bits16 & 0xFFFFu) | (tpack & 0x03FF0000u) | (fast ? 0x80000000u : 0u);
 }
 
 template<typename ACC>
@@ -646,7 +691,7 @@ __device__ __forceinline__ void tile_post_bm25(const TileSmemT<ACC>& sm, const f
                                                const float* const (&cache)[N],
                                                const uint32_t (&doc)[N],
                                                const uint32_t (&freq)[N], uint32_t lo,
-                                               unsigned lane) {
+                                               unsigned lane, bool sqrt_form) {
   uint32_t idx[N], nb[N];
   float inv[N];
   ACC fx[N];
@@ -661,12 +706,21 @@ __device__ __forceinline__ void tile_post_bm25(const TileSmemT<ACC>& sm, const f
 #pragma unroll
   for (int k = 0; k < N; ++k) inv[k] = cache[k][nb[k]];
   wave::keep_all_f(inv);
+  if (sqrt_form) {   // wave-uniform: one scorer per query
 #pragma unroll
-  for (int k = 0; k < N; ++k) {
-    const float r = wave::fast_rcp(wave::fma(static_cast<float>(freq[k]), inv[k], 1.f));
-    float scaled = wave::fma(-cs[k], r, cs[k]);
-    wave::keep_f(scaled);
-    fx[k] = fixed_from_scaled<ACC>(scaled);
+    for (int k = 0; k < N; ++k) {
+      float scaled = wave::fast_sqrt(static_cast<float>(freq[k])) * cs[k] * inv[k];
+      wave::keep_f(scaled);
+      fx[k] = fixed_from_scaled<ACC>(scaled);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const float r = wave::fast_rcp(wave::fma(static_cast<float>(freq[k]), inv[k], 1.f));
+      float scaled = wave::fma(-cs[k], r, cs[k]);
+      wave::keep_f(scaled);
+      fx[k] = fixed_from_scaled<ACC>(scaled);
+    }
   }
 #pragma unroll
   for (int k = 0; k < N; ++k) {
@@ -775,9 +829,9 @@ __device__ __forceinline__ void items_prepare(const DevSegment& seg, const ItemL
     r.pack = lane < r.n ? I.pack : (I.pack & 0xFFFFu);
     r.cs = I.cs;
   }
-  // bit 30 of lane k: items k and k+1 are both straight-line (read for even k only)
+  // bit 30 of lane k: items k and k+1 are both straight-line, same score form (read for even k only)
   const uint32_t next = __shfl_down(r.pack, 1, 64);
-  if ((r.pack & next) >> 31) r.pack |= kPackPair;
+  if (((r.pack & next) >> 31) && !((r.pack ^ next) & kPackSqrt)) r.pack |= kPackPair;
   r.ada = r.adb = r.afa = r.afb = r.bda = r.bdb = r.bfa = r.bfb = 0;
   item_load<LAYOUT>(seg, r, 0, lane, r.ada, r.adb, r.afa, r.afb);
   item_load<LAYOUT>(seg, r, 1, lane, r.bda, r.bdb, r.bfa, r.bfb);
@@ -814,7 +868,8 @@ __device__ __forceinline__ void items_run(const DevSegment& seg, const TileSmemT
     const float* const caches2[2] = {cache, cache};
     const uint32_t docs2[2] = {d1 - x1, d1};
     const uint32_t freqs2[2] = {f0, f1};
-    tile_post_bm25<ACC, TILE, AND, 2>(sm, css, caches2, docs2, freqs2, lo, lane);
+    tile_post_bm25<ACC, TILE, AND, 2>(sm, css, caches2, docs2, freqs2, lo, lane,
+                                      (pack & kPackSqrt) != 0u);
   };
   // hot path, two items fused: 4 postings per lane in flight, two independent
   // DPP scan chains, all LDS lookups issued back to back
@@ -837,7 +892,8 @@ __device__ __forceinline__ void items_run(const DevSegment& seg, const TileSmemT
     const float* const caches4[4] = {cacheA, cacheA, cacheB, cacheB};
     const uint32_t docs4[4] = {ad1 - ax1, ad1, bd1 - bx1, bd1};
     const uint32_t freqs4[4] = {af0, af1, bf0, bf1};
-    tile_post_bm25<ACC, TILE, AND, 4>(sm, css, caches4, docs4, freqs4, lo, lane);
+    tile_post_bm25<ACC, TILE, AND, 4>(sm, css, caches4, docs4, freqs4, lo, lane,
+                                      (pA & kPackSqrt) != 0u);
   };
 
   uint64_t ada = r.ada, adb = r.adb, afa = r.afa, afb = r.afb;
@@ -940,19 +996,7 @@ __device__ __forceinline__ void tile_begin(const DevSegment& seg, const DevQuery
     sm.vars[0] = off;
   }
   if (build_caches) {
-    // BM25::collect: norm_cache[i] = 1/(norm_const + norm_length*i), [0] = 0 (bm25.cpp:404-409)
-    for (uint32_t e = threadIdx.x; e < qd.n_caches * 256u; e += blockDim.x) {
-      const uint32_t c = e >> 8, n = e & 255u;
-      float nc = 0.f, nl = 0.f;
-      for (uint32_t j = 0; j < qd.n_terms; ++j) {
-        if (sm.qts[j].cache_id == c) {
-          nc = sm.qts[j].norm_const;
-          nl = sm.qts[j].norm_length;
-          break;
-        }
-      }
-      sm.caches[e] = n ? 1.f / (nc + nl * static_cast<float>(n)) : 0.f;
-    }
+    build_tables(sm, qd.n_caches, qd.n_terms);
   }
   __syncthreads();
 }
@@ -1226,18 +1270,7 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
       rows[c * kMaxTerms + j] = first_q[uint64_t(tile0 + c) * jt + j];
     }
     __syncthreads();
-    for (uint32_t e = tid; e < qd.n_caches * 256u; e += blockDim.x) {
-      const uint32_t c = e >> 8, n = e & 255u;
-      float nc = 0.f, nl = 0.f;
-      for (uint32_t j = 0; j < qd.n_terms; ++j) {
-        if (sm.qts[j].cache_id == c) {
-          nc = sm.qts[j].norm_const;
-          nl = sm.qts[j].norm_length;
-          break;
-        }
-      }
-      sm.caches[e] = n ? 1.f / (nc + nl * static_cast<float>(n)) : 0.f;
-    }
+    build_tables(sm, qd.n_caches, qd.n_terms);
     // per tile: exclusive prefix sums of each term's block count, and the set of
     // terms whose decoded tail reaches into the tile
     if (tid < ntile) {

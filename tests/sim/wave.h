@@ -78,5 +78,6 @@ __device__ __forceinline__ void keep_acc(unsigned long long&) {}
 // v_rcp_f32 on the GPU (<= 1 ulp); exact division here
 __device__ __forceinline__ float fast_rcp(float v) { return 1.0f / v; }
 __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ float fast_sqrt(float v) { return __builtin_sqrtf(v); }
 
 }  // namespace wave
