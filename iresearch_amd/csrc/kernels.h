@@ -706,6 +706,9 @@ __device__ __forceinline__ void tile_post_bm25(const TileSmemT<ACC>& sm, const f
 #pragma unroll
   for (int k = 0; k < N; ++k) inv[k] = cache[k][nb[k]];
   wave::keep_all_f(inv);
+#ifdef IRS_NO_SQRT_FORM   // A/B experiment only
+  sqrt_form = false;
+#endif
   if (sqrt_form) {   // wave-uniform: one scorer per query
 #pragma unroll
     for (int k = 0; k < N; ++k) {
@@ -1140,7 +1143,10 @@ k_pilot(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
 // Loaded values are kept RAW in registers until they are stored: any arithmetic
 // on them would make the compiler wait for the load where it was issued.
 
-constexpr uint32_t kChunkTiles = 16;
+#ifndef IRS_CHUNK_TILES
+#define IRS_CHUNK_TILES 16
+#endif
+constexpr uint32_t kChunkTiles = IRS_CHUNK_TILES;
 #ifndef IRS_SCORE_CANDS
 #define IRS_SCORE_CANDS 128
 #endif
