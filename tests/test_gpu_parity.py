@@ -115,3 +115,91 @@ def test_config3_or8_top1000_subset(gpulib):
     h2, c2, t2 = cases.run_and_check(gpulib, seg, filters, BM25(), 1000, 8192, 4, sr=sr)
     assert np.array_equal(h1, h2) and np.array_equal(c1, c2) and np.array_equal(t1, t2)
     sr.close()
+
+
+def test_config3_full_size_properties(gpulib):
+    """BASELINE config 3/4 at FULL size (10 M docs, OR-of-8, top-1000), checked through
+    size-independent properties plus the oracle on a few queries:
+      * order (score desc, doc asc), counts = min(k, hits);
+      * hits of an OR query == popcount of irs_hip_bit_union over its terms (an independent
+        kernel that never looks at frequencies or scores);
+      * bitwise the same answer for another tile size / pilot stride;
+      * the index cut into 8 segments (private doc ids, global statistics) and merged on the
+        device gives the same top-k as the single segment, doc ids mapped back;
+      * full oracle parity for the first queries."""
+    import ctypes
+
+    import torch
+
+    from iresearch_amd import distributed
+    n_docs, n_segs, k, nq = 10_000_000, 8, 1000, 48
+    seg = synth.build_segment(n_docs, 4096)
+    ranks = synth.make_queries(nq, 8, 16, 4096, synth.SEED + 2)
+    filters = [Or([by_term(int(r) - 1) for r in row]) for row in ranks]
+    sr = search.SegmentReader.from_synth(seg, L=gpulib)
+    st = [parity.segment_stats(seg)]
+    prep = search.prepare(filters, BM25(), st)
+    b = sr.batch(prep, k)
+    hits, counts, totals = b.run().results()
+    assert b.reruns() == 0
+    b.close()
+    n_words = (n_docs + 64) // 64
+    for q in range(nq):
+        n = int(counts[q])
+        assert n == min(k, int(totals[q]))
+        s, d = hits[q, :n]["score"], hits[q, :n]["doc"]
+        assert ((s[:-1] > s[1:]) | ((s[:-1] == s[1:]) & (d[:-1] < d[1:]))).all(), q
+        assert d.min() >= 1 and d.max() <= n_docs and len(set(d.tolist())) == n
+    for q in range(0, nq, 6):
+        bits, cnt = sr.bit_union([int(r) - 1 for r in ranks[q]], n_words)
+        assert int(np.unpackbits(bits.view(np.uint8)).sum()) == int(totals[q]), q
+        assert cnt == sum(int(seg.metas[int(r) - 1]["docs_count"]) for r in ranks[q])
+    b2 = sr.batch(prep, k).configure(4096, 16, 0)
+    h2, c2, t2 = b2.run().results()
+    b2.close()
+    assert np.array_equal(hits, h2) and np.array_equal(counts, c2) and np.array_equal(totals, t2)
+    parity.check_single_segment(seg, filters[:6], BM25(), k, hits[:6], counts[:6], totals[:6])
+    sr.close()
+
+    per = n_docs // n_segs
+    segs = [synth.build_segment(per, 4096, first_doc=i * per) for i in range(n_segs)]
+    assert sum(s.docs_with_field for s in segs) == seg.docs_with_field
+    assert sum(s.total_term_freq for s in segs) == seg.total_term_freq
+    prep8 = search.prepare(filters, BM25(), [parity.segment_stats(s) for s in segs])
+    ex = distributed.TopkExchange(gpulib, 0, n_segs, 0, 1, nq, k, "cuda")
+    readers, batches = [], []
+    tot8 = np.zeros(nq, np.uint64)
+    for i, s in enumerate(segs):
+        r = search.SegmentReader.from_synth(s, L=gpulib)
+        bb = r.batch(prep8, k).run()
+        hp, cp = ex.slot(i)
+        bb.results_to_device(hp, cp)
+        tot8 += bb.results()[2]
+        readers.append(r)
+        batches.append(bb)
+    oh, osg, oc = ex.run()
+    torch.cuda.synchronize()
+    gh = distributed.hits_from_int64(oh)
+    gs, gc = osg.cpu().numpy(), oc.cpu().numpy()
+    assert np.array_equal(tot8, totals)
+    for q in range(nq):
+        n = int(counts[q])
+        assert int(gc[q]) == n
+        glob = gh[q, :n]["doc"].astype(np.int64) + gs[q, :n].astype(np.int64) * per
+        # same statistics, same postings => the same per-posting scores; the fixed-point
+        # scale follows each segment's own score bound, so sums agree to the tolerance and
+        # docs may only differ where scores tie with the k-th one
+        a = dict(zip(hits[q, :n]["doc"].astype(np.int64).tolist(), hits[q, :n]["score"].tolist()))
+        m = dict(zip(glob.tolist(), gh[q, :n]["score"].tolist()))
+        assert np.allclose(gh[q, :n]["score"], hits[q, :n]["score"], rtol=parity.REL_TOL, atol=0), q
+        kth = float(hits[q, n - 1]["score"])
+        for d in set(a) ^ set(m):
+            sc = a.get(d, m.get(d))
+            assert abs(sc - kth) <= 4 * parity.REL_TOL * kth, (q, d, sc, kth)
+        for d in set(a) & set(m):
+            assert abs(a[d] - m[d]) <= parity.REL_TOL * a[d], (q, d)
+        assert len(set(a) & set(m)) >= n - 8, q
+    for bb in batches:
+        bb.close()
+    for r in readers:
+        r.close()
