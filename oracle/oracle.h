@@ -11,9 +11,12 @@
  *   - posting-list reader: restatement of formats_10.cpp reader code, checked by
  *     round trip against an independent emitter on the reference's own test
  *     lists (formats_10_tests.cpp:452-457, tests/resources/postings.txt);
- *   - scores: "parity unpinned" numerically — the reference's tests hold no
- *     float literals; the formulas are restated line by line
- *     and cross-checked in double precision.
+ *   - scores: the ORDER of results is pinned by every ranking the reference's
+ *     own tests assert on tests/resources/simple_sequential_order.json
+ *     (bm25_test.cpp / tfidf_test.cpp, 16 vectors incl. two-segment ones:
+ *     tests/cases.py REFERENCE_ORDERS); score MAGNITUDES are "parity unpinned" —
+ *     those tests hold no float literals; the formulas are
+ *     restated line by line and cross-checked in double precision.
  */
 #ifndef IRS_ORACLE_H
 #define IRS_ORACLE_H

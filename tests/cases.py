@@ -200,6 +200,98 @@ def case_queries_ragged(L, layout=synth.LAYOUT_SIMD4):
     sr.close()
 
 
+# ------------------------------------------ the reference's own score-order vectors --
+
+def reference_order_corpus():
+    """tests/resources/simple_sequential_order.json of the reference (committed as
+    tests/golden/): 8 docs, field "field" = a list of one-character terms.  Returns
+    (posting lists per term '0'..'9' as (docs, freqs) with doc id = seq + 1, field lengths)."""
+    import json
+    rows = json.loads((GOLDEN / "simple_sequential_order.json").read_text())
+    assert [r["seq"] for r in rows] == list(range(8))
+    lists = []
+    for t in "0123456789":
+        d = [(r["seq"] + 1, r["field"].count(t)) for r in rows if t in r["field"]]
+        lists.append((np.array([x for x, _ in d], np.uint32), np.array([f for _, f in d], np.uint32)))
+    lengths = np.array([len(r["field"]) for r in rows], np.uint8)
+    assert int(lengths.sum()) == 52          # "TotalFreq = 52", bm25_test.cpp:67-71
+    return lists, lengths
+
+
+# (scorer, norms?, filter terms) -> doc "seq" values in descending score order, exactly as
+# the reference's tests assert them (equal scores keep doc order: std::multimap insertion)
+REFERENCE_ORDERS = [
+    # tests/search/bm25_test.cpp — BM25(k=1.2, b=0.75)
+    ("bm25", False, "7", [0, 1, 5, 7]),                 # :557-570 by_term
+    ("bm25", False, "8", [3, 7]),                       # :973-992 by_range [8, 9)
+    ("bm25", False, "78", [7, 3, 0, 1, 5]),             # :1027-1044 by_range (6, 8]
+    ("bm25", False, "678", [7, 0, 5, 3, 2, 1]),         # :1078-1095 by_range [6, 8]
+    ("bm25", True, "78", [7, 3, 0, 1, 5]),              # :127-144 with Norm2
+    ("bm25", True, "678", [0, 7, 5, 3, 2, 1]),          # :179-197 with Norm2
+    # tests/search/tfidf_test.cpp — TFIDF
+    ("tfidf", False, "7", [0, 1, 5, 7]),                # :565-568
+    ("tfidf", False, "8", [3, 7]),                      # :983-992
+    ("tfidf", False, "78", [7, 0, 1, 3, 5]),            # :1035-1043
+    ("tfidf", False, "678", [0, 7, 5, 1, 3, 2]),        # :1086-1094
+    ("tfidf", True, "78", [7, 0, 3, 1, 5]),             # :133-142 with norms
+    ("tfidf", True, "678", [0, 7, 5, 2, 3, 1]),         # :187-196 with norms
+]
+# two segments (docs 0,2,4,6 | 1,3,5,7), statistics over both: bm25_test.cpp:653-662, 755-775;
+# tfidf_test.cpp:655-661, 759-773
+REFERENCE_ORDERS_2SEG = [("6", [0, 2, 5]), ("68", [3, 7, 0, 2, 5])]
+
+
+def _order_scorer(name, with_norms):
+    return BM25() if name == "bm25" else TFIDF(with_norms)
+
+
+def case_reference_score_orders(L):
+    """The only score-related vectors the reference's tests hold: the ORDER in which
+    bm25_test.cpp / tfidf_test.cpp expect docs of simple_sequential_order.json to be ranked
+    (by_range over single-character terms == Or of by_term: every scored term brings its own
+    statistics, scores are summed — multiterm_query.cpp).  Checked through the C ABI and
+    through the oracle's harness."""
+    lists, lengths = reference_order_corpus()
+    for layout in (synth.LAYOUT_SCALAR, synth.LAYOUT_SIMD4):
+        for name, with_norms, terms, want in REFERENCE_ORDERS:
+            seg = synth.segment_from_lists(lists, 8, layout, lengths if with_norms else False)
+            seg.total_term_freq = 52
+            flt = [Or([by_term(int(t)) for t in terms]) if len(terms) > 1 else by_term(int(terms))]
+            scorer = _order_scorer(name, with_norms)
+            hits, counts, totals = run_and_check(L, seg, flt, scorer, 8)
+            got = [int(d) - 1 for d in hits[0, :int(counts[0])]["doc"]]
+            assert got == want, (name, with_norms, terms, got, want)
+            ohits, _ = parity.oracle_topk([seg], flt, scorer, 8)[0]
+            # the harness heap sorts unstably: compare score classes, then the doc order inside
+            key = sorted(zip(-ohits["score"].astype(np.float64), ohits["doc"]))
+            assert [int(d) - 1 for _, d in key] == want, ("oracle", name, with_norms, terms)
+        # two segments, global statistics, one ranking
+        even = [(np.array([(x + 1) // 2 for x in d if x % 2 == 1], np.uint32),
+                 np.array([f for x, f in zip(d, fr) if x % 2 == 1], np.uint32)) for d, fr in lists]
+        odd = [(np.array([x // 2 for x in d if x % 2 == 0], np.uint32),
+                np.array([f for x, f in zip(d, fr) if x % 2 == 0], np.uint32)) for d, fr in lists]
+        segs = [synth.segment_from_lists(even, 4, layout, False),
+                synth.segment_from_lists(odd, 4, layout, False)]
+        segs[0].total_term_freq = int(lengths[0::2].sum())
+        segs[1].total_term_freq = int(lengths[1::2].sum())
+        for name in ("bm25", "tfidf"):
+            scorer = _order_scorer(name, False)
+            for terms, want in REFERENCE_ORDERS_2SEG:
+                flt = [Or([by_term(int(t)) for t in terms]) if len(terms) > 1 else by_term(int(terms))]
+                prep = search.prepare(flt, scorer, [parity.segment_stats(s) for s in segs])
+                per_seg = []
+                for s in segs:
+                    sr = search.SegmentReader.from_synth(s, L=L)
+                    b = sr.batch(prep, 8)
+                    h, c, _ = b.run().results()
+                    per_seg.append((h, c))
+                    b.close()
+                    sr.close()
+                merged = search.merge_topk_host(per_seg, 8)[0]
+                got = [2 * (d - 1) + s for _, s, d in merged]      # (segment, local doc) -> seq
+                assert got == want, (name, terms, got, want)
+
+
 def case_pilot_misled(L, k=600):
     """The pilot only sees every 16th doc tile.  Here every high-scoring doc sits in exactly
     the tiles query 0 samples, so the estimated threshold (which extrapolates the sample)

@@ -68,6 +68,10 @@ def test_bit_union(simlib, layout):
     cases.case_bit_union(simlib, layout, has_freq=False)
 
 
+def test_reference_score_orders(simlib):
+    cases.case_reference_score_orders(simlib)
+
+
 def test_pilot_misled(simlib):
     cases.case_pilot_misled(simlib)
 

@@ -73,6 +73,10 @@ def test_bit_union(gpulib, layout):
     cases.case_bit_union(gpulib, layout, has_freq=False)
 
 
+def test_reference_score_orders(gpulib):
+    cases.case_reference_score_orders(gpulib)
+
+
 def test_pilot_misled(gpulib):
     cases.case_pilot_misled(gpulib)
 
