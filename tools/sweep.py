@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--nocheck", action="store_true")
     ap.add_argument("--op", default="or", choices=["or", "and", "mm"], help="Or / And / Or(min_match=terms-1)")
     ap.add_argument("--terms", type=int, default=8)
+    ap.add_argument("--layout", type=int, default=1, help="0 = scalar (1_5), 1 = simd4 (1_5simd)")
     ap.add_argument("--scorer", default="bm25", choices=["bm25", "tfidf", "bm15"])
     ap.add_argument("--lib", default=None, help="alternative build of libirs_hip.so (A/B runs)")
     args = ap.parse_args()
@@ -33,7 +34,7 @@ def main():
     from iresearch_amd import _lib, search, synth
     from iresearch_amd.search import BM25, TFIDF, And, Or, by_term
     L = _lib.bind(ctypes.CDLL(args.lib)) if args.lib else _lib.lib()
-    seg = synth.build_segment(args.docs, 4096)
+    seg = synth.build_segment(args.docs, 4096, layout=args.layout)
     sr = search.SegmentReader.from_synth(seg, L=L)
     ranks = synth.make_queries(args.queries, args.terms, 16, 4096, synth.SEED + 2)
     if args.op == "and":
