@@ -171,7 +171,12 @@ typedef struct irs_hip_batch irs_hip_batch; /* opaque: one batch of queries on o
  * results: waits for the stream and copies the per-query top-k to the host:
  *          hits[q * k_stride + i], i < counts[q], ordered (score desc, doc asc);
  *          total_hits[q] = number of matching docs (index-search `hits=`).
- * Results are deterministic: ties are broken by ascending doc id. */
+ * Results are deterministic: ties are broken by ascending doc id.
+ * Lifetime / threading: a segment is immutable after open and may be shared by any
+ * number of threads; a batch belongs to one thread at a time and must be destroyed
+ * before its segment is closed.  results / results_to_device also verify the run
+ * (candidate buffer, threshold estimate) and transparently re-execute the batch when
+ * that check fails — irs_hip_batch_reruns counts those; results are exact either way. */
 int irs_hip_batch_create(irs_hip_segment* seg, const irs_hip_query* queries,
                          uint32_t n_queries, const irs_hip_term_scorer* terms,
                          uint32_t n_term_entries, irs_hip_batch** out);
@@ -179,7 +184,8 @@ int irs_hip_batch_run(irs_hip_batch* batch, void* stream);
 int irs_hip_batch_results(irs_hip_batch* batch, irs_hip_hit* hits,
                           uint32_t k_stride, uint32_t* counts,
                           uint64_t* total_hits);
-/* Device-resident results for a caller that merges on the GPU (RCCL path):
+/* Device-resident results for a caller that merges on the GPU (RCCL path): waits for
+ * and verifies the run like `results`, then hands out the batch's own buffers:
  * d_hits is [n_queries][k_max] irs_hip_hit, d_counts [n_queries] uint32. */
 int irs_hip_batch_device_results(irs_hip_batch* batch, void** d_hits,
                                  void** d_counts, uint32_t* k_max);

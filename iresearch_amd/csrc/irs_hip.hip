@@ -897,9 +897,27 @@ int irs_hip_batch_results(irs_hip_batch* b, irs_hip_hit* hits, uint32_t k_stride
   return IRS_HIP_OK;
 }
 
+// Waits for the batch, reads its status word and re-executes it when the candidate
+// buffer or the threshold estimate fell short.  Afterwards d_out / d_out_count hold the
+// exact top-k.
+static int verify_run(irs_hip_batch* b) {
+  uint32_t status = 0;
+  if (!rt::d2h(&status, b->d_status.p, 4, b->stream) || !rt::sync(b->stream))
+    return IRS_HIP_EHIP;
+  if (status & (kStatusOverflow | kStatusUnderflow)) {
+    const int rc = recover(b, status);
+    if (rc != IRS_HIP_OK) return rc;
+    if (!rt::sync(b->stream)) return IRS_HIP_EHIP;
+  }
+  return IRS_HIP_OK;
+}
+
 int irs_hip_batch_device_results(irs_hip_batch* b, void** d_hits, void** d_counts,
                                  uint32_t* k_max) {
-  if (!b || !b->scratch_ready) return IRS_HIP_EINVAL;
+  if (!b || !b->ran) return IRS_HIP_EINVAL;
+  if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
+  const int rc = verify_run(b);
+  if (rc != IRS_HIP_OK) return rc;
   if (d_hits) *d_hits = b->d_out.p;
   if (d_counts) *d_counts = b->d_out_count.p;
   if (k_max) *k_max = b->k_max;
@@ -911,14 +929,8 @@ int irs_hip_batch_results_to_device(irs_hip_batch* b, void* d_hits, void* d_coun
   if (!b || !b->ran || !d_hits || !d_counts) return IRS_HIP_EINVAL;
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
   rt::stream_t st = static_cast<rt::stream_t>(stream);
-  uint32_t status = 0;
-  if (!rt::d2h(&status, b->d_status.p, 4, b->stream) || !rt::sync(b->stream))
-    return IRS_HIP_EHIP;
-  if (status & (kStatusOverflow | kStatusUnderflow)) {
-    const int rc = recover(b, status);
-    if (rc != IRS_HIP_OK) return rc;
-    if (!rt::sync(b->stream)) return IRS_HIP_EHIP;
-  }
+  const int rc = verify_run(b);
+  if (rc != IRS_HIP_OK) return rc;
   if (!rt::d2d(d_hits, b->d_out.p, size_t(b->nq) * b->k_max * sizeof(Hit), st) ||
       !rt::d2d(d_counts, b->d_out_count.p, size_t(b->nq) * 4, st))
     return IRS_HIP_EHIP;
