@@ -173,6 +173,26 @@ def case_queries_tiles_and_strides(L, num_docs, max_rank):
     sr.close()
 
 
+def case_many_items(L, num_docs=40_000):
+    """16 of the densest terms in one query: far more (term, block) work items per doc tile
+    than the kernels stage at once (256), so the multi-round item path runs; also AND and
+    MinMatch over the same terms, every tile size."""
+    seg = synth.build_segment(num_docs, 32)
+    sr = search.SegmentReader.from_synth(seg, L=L)
+    terms = [by_term(t) for t in range(16)]
+    filters = [Or(terms), And(terms[:6]), Or(terms, min_match=12), Or(terms[:9])]
+    ref = None
+    for tile in (4096, 6144, 8192, 12288):
+        hits, counts, totals = run_and_check(L, seg, filters, BM25(), 200, tile, 3, sr=sr)
+        if ref is None:
+            ref = (hits.copy(), counts.copy(), totals.copy())
+        else:
+            assert np.array_equal(ref[0], hits) and np.array_equal(ref[1], counts)
+            assert np.array_equal(ref[2], totals)
+    run_and_check(L, seg, filters[:2], TFIDF(True), 50, sr=sr)
+    sr.close()
+
+
 def case_queries_ragged(L, layout=synth.LAYOUT_SIMD4):
     """Absent terms, single-doc terms, df < 128, df == 128, tail-only and
     block-only lists, k larger than the number of hits, empty results."""

@@ -77,6 +77,10 @@ def test_reference_score_orders(gpulib):
     cases.case_reference_score_orders(gpulib)
 
 
+def test_many_items(gpulib):
+    cases.case_many_items(gpulib, 300_000)
+
+
 def test_pilot_misled(gpulib):
     cases.case_pilot_misled(gpulib)
 
