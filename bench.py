@@ -95,13 +95,28 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # IRS_BENCH_SIM=<path of tests/sim/libirs_hip_sim.so>: CONTROL-FLOW dry run for the CPU
+    # test tier (tests/test_distributed.py) — the emulator library, CPU tensors, gloo instead
+    # of RCCL.  Its timings mean nothing; it exists so that the multi-rank path the driver
+    # launches is executed before it ever reaches an 8-GPU node.
+    sim = os.environ.get("IRS_BENCH_SIM")
+    if sim:
+        import ctypes
+        dev = torch.device("cpu")
+        L = _lib.bind(ctypes.CDLL(sim))
+        local_rank = 0
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        L = _lib.lib()
+    sync = (lambda: None) if sim else torch.cuda.synchronize
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-    L = _lib.lib()
+        if sim:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     # ---- index: built on the host, staged to HBM once (not timed) ------------
     t0 = time.perf_counter()
@@ -146,8 +161,7 @@ def main():
             b.configure(args.tile, args.stride, 0)
         b.profile(True)
         batches[s] = b
-    stream = torch.cuda.current_stream(dev)
-    sptr = C_void(stream.cuda_stream)
+    sptr = None if sim else C_void(torch.cuda.current_stream(dev).cuda_stream)
     nq, k = args.queries, args.k
     # every buffer of the exchange step is allocated once; each local segment's results
     # are written straight into its slot of the send buffer
@@ -169,21 +183,21 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    sync()
     # sanity: results are retrievable (also triggers the overflow re-run path if needed)
     for s in my:
         batches[s].results()
     score_ms = []
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
         # per-kernel HIP-event timings of this step on rank 0 (waits for the stream)
         if rank == 0:
             score_ms.append(np.sum([batches[s].timings() for s in my], axis=0))
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -222,7 +236,7 @@ def main():
             "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "u32+f32", "data": "synthetic",
+            "dtype": "u32+f32", "data": "synthetic" if not sim else "synthetic (EMULATOR DRY RUN)",
             "config": {
                 "workload": "OR-of-%d terms BM25 top-%d, %d-doc Zipfian index, %d segment(s), "
                             "%d queries/step" % (args.terms, k, args.docs, n_segments, nq),

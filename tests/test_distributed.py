@@ -98,3 +98,30 @@ def test_two_ranks_gloo_matches_oracle(simlib, tmp_path):
         key = list(zip(-got["score"].astype(np.float64), segs_of[q, :n], got["doc"]))
         assert key == sorted(key), q
         assert (segs_of[q, :n] < N_SEGS).all()
+
+
+def test_bench_is_launchable_on_two_ranks(simlib):
+    """bench.py under the driver's own multi-GPU launch line (torch.distributed.run, one
+    process per rank, MASTER_ADDR 127.0.0.1), in its emulator dry-run mode: the whole
+    multi-rank control flow — segment partition, global statistics, per-segment batches,
+    one all-gather per step, merge, MAX-over-ranks timing, ONE JSON line from rank 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29500 + ((os.getpid() * 7 + 13) % 2000)
+    env = dict(os.environ, IRS_BENCH_SIM=simlib._name, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--docs", "48000", "--queries", "5", "--k", "20", "--segments", "4", "--no-cpu"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["value"] > 0 and d["unit"] == "queries/s" and d["scaling"] == "strong"
+    assert d["config"]["segments"] == 4 and d["config"]["reruns_rank0"] == 0
+    assert d["roofline"]["launches_per_step"] == 2       # rank 0 owns 2 of the 4 segments
+    assert d["cpu_baseline"] is None
