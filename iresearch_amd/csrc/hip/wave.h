@@ -123,6 +123,34 @@ __device__ __forceinline__ float fast_sqrt(float v) { return __builtin_amdgcn_sq
 // a*b + c in one rounding (v_fma_f32), independent of -ffp-contract
 __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
+// ---- LDS by absolute address ------------------------------------------------
+// The dynamic LDS block of a kernel WITHOUT static __shared__ variables starts at LDS
+// address 0, but the compiler only learns the address of `extern __shared__` after
+// instruction selection and then leaves a `v_add 0` in front of every access.  On the
+// hot path the tile arrays are therefore addressed by their compile-time byte offsets
+// (TileSmemT layout) through address-space-3 pointers built from integers: the carve
+// offset lands in the instruction's immediate field and no address arithmetic is left.
+// `base` is only used by the CPU emulator twin of this header; lds_is_at_zero() lets a
+// kernel verify the assumption once.
+#define IRS_LDS __attribute__((address_space(3)))
+__device__ __forceinline__ bool lds_is_at_zero(const unsigned char* smem) {
+  return uint32_t(uintptr_t((IRS_LDS const unsigned char*)smem)) == 0u;
+}
+__device__ __forceinline__ uint32_t lds_u8(const unsigned char*, uint32_t off) {
+  return *(const IRS_LDS uint8_t*)(uintptr_t)off;
+}
+__device__ __forceinline__ float lds_f32(const unsigned char*, uint32_t off) {
+  return *(const IRS_LDS float*)(uintptr_t)off;
+}
+__device__ __forceinline__ void lds_add(const unsigned char*, uint32_t off, uint32_t v) {
+  __hip_atomic_fetch_add((IRS_LDS uint32_t*)(uintptr_t)off, v, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_add(const unsigned char*, uint32_t off, unsigned long long v) {
+  __hip_atomic_fetch_add((IRS_LDS unsigned long long*)(uintptr_t)off, v, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // LDS float accumulate without a returned value -> ds_add_f32
 __device__ __forceinline__ void lds_add(float* p, float v) { atomicAdd(p, v); }
 

@@ -561,6 +561,16 @@ constexpr uint32_t tile_smem_bytes() {
          sizeof(TermL) * kMaxTerms + sizeof(ItemL) * kItemChunk + 32;
 }
 
+// Byte offsets of the tile arrays inside the workgroup's LDS block (== carve() below);
+// the hot path addresses them absolutely (wave::lds_*).
+template<typename ACC, int TILE, bool AND>
+struct TileOff {
+  static constexpr uint32_t acc = 0;
+  static constexpr uint32_t cnt = uint32_t(sizeof(ACC)) * (TILE + 64);
+  static constexpr uint32_t lnorm = cnt + (AND ? TILE + 64 : 0);
+  static constexpr uint32_t caches = lnorm + TILE;
+};
+
 template<typename ACC, int TILE, bool AND>
 __device__ __forceinline__ TileSmemT<ACC> carve(unsigned char* smem, unsigned char** rest) {
   TileSmemT<ACC> sm;
@@ -688,10 +698,12 @@ __device__ __forceinline__ void tile_apply(const DevSegment& seg, const TileSmem
 // segment needs no extra test: docs >= lo + span do not exist.)
 template<typename ACC, int TILE, bool AND, int N>
 __device__ __forceinline__ void tile_post_bm25(const TileSmemT<ACC>& sm, const float (&cs)[N],
-                                               const float* const (&cache)[N],
+                                               const uint32_t (&tab)[N],
                                                const uint32_t (&doc)[N],
                                                const uint32_t (&freq)[N], uint32_t lo,
                                                unsigned lane, bool sqrt_form) {
+  using Off = TileOff<ACC, TILE, AND>;
+  const unsigned char* base = reinterpret_cast<const unsigned char*>(sm.acc);  // LDS offset 0
   uint32_t idx[N], nb[N];
   float inv[N];
   ACC fx[N];
@@ -700,11 +712,11 @@ __device__ __forceinline__ void tile_post_bm25(const TileSmemT<ACC>& sm, const f
   for (int k = 0; k < N; ++k) {
     const uint32_t raw = doc[k] - lo;
     idx[k] = raw < dummy ? raw : dummy;
-    nb[k] = sm.lnorm[idx[k]];
+    nb[k] = wave::lds_u8(base, Off::lnorm + idx[k]);
   }
   wave::keep_all(nb);   // one asm statement over all N values: one s_waitcnt
 #pragma unroll
-  for (int k = 0; k < N; ++k) inv[k] = cache[k][nb[k]];
+  for (int k = 0; k < N; ++k) inv[k] = wave::lds_f32(base, tab[k] + nb[k] * 4u);
   wave::keep_all_f(inv);
 #ifdef IRS_NO_SQRT_FORM   // A/B experiment only
   sqrt_form = false;
@@ -727,9 +739,9 @@ __device__ __forceinline__ void tile_post_bm25(const TileSmemT<ACC>& sm, const f
   }
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    atomicAdd(&sm.acc[idx[k]], fx[k]);
+    wave::lds_add(base, Off::acc + idx[k] * uint32_t(sizeof(ACC)), fx[k]);
     // (out-of-tile postings bump a dummy counter byte, like their dummy accumulator)
-    if (AND) atomicAdd(&sm.cnt[idx[k] >> 2], 1u << (8u * (idx[k] & 3u)));
+    if (AND) wave::lds_add(base, Off::cnt + (idx[k] & ~3u), 1u << (8u * (idx[k] & 3u)));
   }
 }
 
@@ -862,16 +874,16 @@ __device__ __forceinline__ void items_run(const DevSegment& seg, const TileSmemT
   auto fast_item = [&](uint32_t k, uint64_t da, uint64_t db, uint64_t fa, uint64_t fb) {
     const uint32_t pack = wave::read_lane(r.pack, k);
     const float cs = wave::read_lane_f(r.cs, k);
-    const float* cache = sm.caches + ((pack >> 16) & 0xFu) * 256u;
+    const uint32_t tab = TileOff<ACC, TILE, AND>::caches + ((pack >> 16) & 0xFu) * 1024u;
     uint32_t x0, x1, f0, f1;
     extract_fast<LAYOUT>(da, db, pack & 0xFFu, lane, x0, x1);
     extract_fast<LAYOUT>(fa, fb, (pack >> 8) & 0xFFu, lane, f0, f1);
     const uint32_t d1 = wave::read_lane(r.base, k) + wave::inclusive_scan(x0 + x1);
     const float css[2] = {cs, cs};
-    const float* const caches2[2] = {cache, cache};
+    const uint32_t tabs2[2] = {tab, tab};
     const uint32_t docs2[2] = {d1 - x1, d1};
     const uint32_t freqs2[2] = {f0, f1};
-    tile_post_bm25<ACC, TILE, AND, 2>(sm, css, caches2, docs2, freqs2, lo, lane,
+    tile_post_bm25<ACC, TILE, AND, 2>(sm, css, tabs2, docs2, freqs2, lo, lane,
                                       (pack & kPackSqrt) != 0u);
   };
   // hot path, two items fused: 4 postings per lane in flight, two independent
@@ -880,8 +892,8 @@ __device__ __forceinline__ void items_run(const DevSegment& seg, const TileSmemT
                        uint64_t bda, uint64_t bdb, uint64_t bfa, uint64_t bfb) {
     const uint32_t pA = wave::read_lane(r.pack, k), pB = wave::read_lane(r.pack, k + 1);
     const float csA = wave::read_lane_f(r.cs, k), csB = wave::read_lane_f(r.cs, k + 1);
-    const float* cacheA = sm.caches + ((pA >> 16) & 0xFu) * 256u;
-    const float* cacheB = sm.caches + ((pB >> 16) & 0xFu) * 256u;
+    const uint32_t tabA = TileOff<ACC, TILE, AND>::caches + ((pA >> 16) & 0xFu) * 1024u;
+    const uint32_t tabB = TileOff<ACC, TILE, AND>::caches + ((pB >> 16) & 0xFu) * 1024u;
     uint32_t ax0, ax1, af0, af1, bx0, bx1, bf0, bf1;
     extract_fast<LAYOUT>(ada, adb, pA & 0xFFu, lane, ax0, ax1);
     extract_fast<LAYOUT>(bda, bdb, pB & 0xFFu, lane, bx0, bx1);
@@ -892,10 +904,10 @@ __device__ __forceinline__ void items_run(const DevSegment& seg, const TileSmemT
     const uint32_t ad1 = wave::read_lane(r.base, k) + sa;
     const uint32_t bd1 = wave::read_lane(r.base, k + 1) + sb;
     const float css[4] = {csA, csA, csB, csB};
-    const float* const caches4[4] = {cacheA, cacheA, cacheB, cacheB};
+    const uint32_t tabs4[4] = {tabA, tabA, tabB, tabB};
     const uint32_t docs4[4] = {ad1 - ax1, ad1, bd1 - bx1, bd1};
     const uint32_t freqs4[4] = {af0, af1, bf0, bf1};
-    tile_post_bm25<ACC, TILE, AND, 4>(sm, css, caches4, docs4, freqs4, lo, lane,
+    tile_post_bm25<ACC, TILE, AND, 4>(sm, css, tabs4, docs4, freqs4, lo, lane,
                                       (pA & kPackSqrt) != 0u);
   };
 
@@ -1072,6 +1084,7 @@ k_pilot(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
         uint32_t n_tiles, uint32_t stride, const uint32_t* first, const DevTail* tails,
         uint32_t* bstar, uint32_t margin) {
   RT_DYN_SMEM(smem);
+  if (!wave::lds_is_at_zero(smem)) __builtin_trap();  // the tile arrays are addressed absolutely
   unsigned char* rest;
   const TileSmemT<ACC> sm = carve<ACC, TILE, AND>(smem, &rest);
   uint32_t* hist = reinterpret_cast<uint32_t*>(rest);  // [kBins]
@@ -1198,6 +1211,7 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
         const uint32_t* bstar, uint64_t* cands, uint32_t cand_cap, uint32_t* cand_count,
         unsigned long long* hits, uint32_t* work_counter) {
   RT_DYN_SMEM(smem);
+  if (!wave::lds_is_at_zero(smem)) __builtin_trap();  // the tile arrays are addressed absolutely
   unsigned char* rest;
   const TileSmemT<ACC> sm = carve<ACC, TILE, AND>(smem, &rest);
   // the two item tables are addressed as base + (u & 1) * delta: plain LDS pointer

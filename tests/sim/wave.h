@@ -69,6 +69,20 @@ __device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t s)
 }
 __device__ __forceinline__ uint32_t bfe(uint32_t x, uint32_t bits) { return x & ((1u << bits) - 1u); }
 __device__ __forceinline__ uint64_t undef64() { return 0; }
+// LDS "by absolute address" (hip/wave.h): here simply base + offset
+__device__ __forceinline__ bool lds_is_at_zero(const unsigned char*) { return true; }
+__device__ __forceinline__ uint32_t lds_u8(const unsigned char* base, uint32_t off) { return base[off]; }
+__device__ __forceinline__ float lds_f32(const unsigned char* base, uint32_t off) {
+  float v;
+  __builtin_memcpy(&v, base + off, 4);
+  return v;
+}
+__device__ __forceinline__ void lds_add(const unsigned char* base, uint32_t off, uint32_t v) {
+  atomicAdd(reinterpret_cast<uint32_t*>(const_cast<unsigned char*>(base) + off), v);
+}
+__device__ __forceinline__ void lds_add(const unsigned char* base, uint32_t off, unsigned long long v) {
+  atomicAdd(reinterpret_cast<unsigned long long*>(const_cast<unsigned char*>(base) + off), v);
+}
 template<int N> __device__ __forceinline__ void keep_all(uint32_t (&)[N]) {}
 template<int N> __device__ __forceinline__ void keep_all_f(float (&)[N]) {}
 __device__ __forceinline__ void keep(uint32_t&) {}
