@@ -681,14 +681,17 @@ __device__ __forceinline__ void tile_apply(const DevSegment& seg, const TileSmem
   }
 }
 
-// Scoring of N postings at once on the hot path (BM25, 1-byte norms, LDS
-// norm_cache — bm25.cpp:348-353: c0 - c0/(1 + tf*cache[norm]); the division is
-// one v_rcp_f32 and the two multiply-adds are fused, within 2 ulp of the
-// reference expression, far inside the 1e-5 parity tolerance; `cs` is c0
-// pre-multiplied by fx_mul so the result is already in fixed-point units).
-// Staged so that the N norm-byte reads, then the N cache reads, then the N LDS
+// Scoring of N postings at once on the hot path: any scorer of the table family
+// (see table_kind above; `tab[k]` is the LDS byte offset of posting k's table row).
+// Reciprocal form, e.g. BM25 over 1-byte norms — bm25.cpp:348-353:
+// c0 - c0/(1 + tf*norm_cache[norm]): the division is one v_rcp_f32 and the two
+// multiply-adds are fused; square-root form (TF-IDF): one v_sqrt_f32 and two
+// multiplies.  Either is within 2 ulp of the reference expression, far inside the
+// 1e-5 parity tolerance; `cs` is c0 pre-multiplied by fx_mul so the result is
+// already in fixed-point units.
+// Staged so that the N norm-byte reads, then the N table reads, then the N LDS
 // atomics are issued back to back: one LDS latency per stage instead of one per
-// posting.  wave::keep() pins each stage (the compiler would otherwise sink the
+// posting.  wave::keep*() pins each stage (the compiler would otherwise sink the
 // whole computation behind a per-posting branch).
 // Postings outside the tile are not branched around: `doc - lo` wraps to a huge
 // value for doc < lo, and one v_min clamps every out-of-tile index to the lane's
