@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--stride", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--per-segment-batches", action="store_true",
+                    help="one batch per local segment instead of one batch over all of them (A/B)")
     ap.add_argument("--force-segments", action="store_true",
                     help="use the multi-segment path (merge kernel) even on one GPU")
     args = ap.parse_args()
@@ -154,28 +156,38 @@ def main():
     ranks = synth.make_queries(args.queries, args.terms, 16, 4096, synth.SEED + 2)
     filters = [Or([by_term(int(r) - 1) for r in row]) for row in ranks]
     prepared = search.prepare(filters, BM25(), seg_stats)
+    # ONE batch per rank over all of its segments (irs_hip_batch_create_multi): every kernel is
+    # launched once for all (segment, query) pairs.  --per-segment-batches: one batch per
+    # segment, back to back (A/B).
     batches = {}
-    for s in my:
-        b = readers[s].batch(prepared, args.k)
+    if len(my) > 1 and not args.per_segment_batches:
+        groups = {my[0]: list(my)}
+    else:
+        groups = {s: [s] for s in my}
+    for lead, members in groups.items():
+        b = search.QueryBatch([readers[s] for s in members], prepared, args.k) \
+            if len(members) > 1 else readers[lead].batch(prepared, args.k)
         if args.tile or args.stride:
             b.configure(args.tile, args.stride, 0)
         b.profile(True)
-        batches[s] = b
+        batches[lead] = b
     sptr = None if sim else C_void(torch.cuda.current_stream(dev).cuda_stream)
     nq, k = args.queries, args.k
     # every buffer of the exchange step is allocated once; each local segment's results
     # are written straight into its slot of the send buffer
     exchange = distributed.TopkExchange(L, local_rank, n_segments if multi else 1, rank, world,
                                         nq, k, dev)
-    slots = {s: exchange.slot(i) for i, s in enumerate(my)}
+    # a multi-segment batch writes [segment][query][k] hits and [segment][query] counts: exactly
+    # consecutive slots of the send buffer
+    slots = {lead: exchange.slot(my.index(lead)) for lead in batches}
 
     def step():
         # every step ends with a checked, device-resident top-k: results_to_device reads the
         # batch status (4 bytes) and re-runs the batch if a threshold estimate or the
         # candidate buffer fell short (irs_hip_batch_reruns counts those)
-        for s in my:
+        for s in batches:
             batches[s].run(sptr)
-        for s in my:
+        for s in batches:
             batches[s].results_to_device(slots[s][0], slots[s][1], sptr)
         if multi:
             return exchange.run(sptr)   # one all-gather (RCCL) + GPU merge
@@ -185,7 +197,7 @@ def main():
         step()
     sync()
     # sanity: results are retrievable (also triggers the overflow re-run path if needed)
-    for s in my:
+    for s in batches:
         batches[s].results()
     score_ms = []
     if world > 1:
@@ -196,7 +208,7 @@ def main():
         step()
         # per-kernel HIP-event timings of this step on rank 0 (waits for the stream)
         if rank == 0:
-            score_ms.append(np.sum([batches[s].timings() for s in my], axis=0))
+            score_ms.append(np.sum([batches[s].timings() for s in batches], axis=0))
     sync()
     if world > 1:
         dist.barrier()
@@ -206,9 +218,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    reruns = sum(batches[s].reruns() for s in my)
-    alg_bytes = sum(batches[s].work()[0] for s in my)
-    postings = sum(batches[s].work()[1] for s in my)
+    reruns = sum(batches[s].reruns() for s in batches)
+    alg_bytes = sum(batches[s].work()[0] for s in batches)
+    postings = sum(batches[s].work()[1] for s in batches)
     rank0_alg_bytes = alg_bytes
     if world > 1:
         t = torch.tensor([alg_bytes, postings], dtype=torch.float64, device=dev)
@@ -226,9 +238,9 @@ def main():
             achieved = rank0_alg_bytes / (avg[_lib.K_SCORE] * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": "k_score", "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": measured_traffic(len(my)),
-                    "algorithmic_bytes_per_launch": int(rank0_alg_bytes / len(my)),
-                    "launches_per_step": len(my),
+                    "traffic": None if multi else measured_traffic(1),
+                    "algorithmic_bytes_per_launch": int(rank0_alg_bytes / len(batches)),
+                    "launches_per_step": len(batches),
                     "avg_launch_ms": round(float(avg[_lib.K_SCORE]), 4),
                     "kernel_ms": {n: round(float(v), 4) for n, v in zip(_lib.KERNEL_NAMES, avg)}}
         out = {

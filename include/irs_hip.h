@@ -180,6 +180,19 @@ typedef struct irs_hip_batch irs_hip_batch; /* opaque: one batch of queries on o
 int irs_hip_batch_create(irs_hip_segment* seg, const irs_hip_query* queries,
                          uint32_t n_queries, const irs_hip_term_scorer* terms,
                          uint32_t n_term_entries, irs_hip_batch** out);
+/* The same batch of queries over SEVERAL segments of one device in one go — what the
+ * harness loop `for (auto& segment : reader)` (utils/index-search.cpp:719-779) does
+ * segment after segment.  Every kernel is launched once for all (segment, query) pairs, so
+ * small segments do not pay per-segment launch tails.  `terms` holds n_segs consecutive
+ * arrays of n_term_entries entries: the same scorers (statistics are index-global,
+ * term_filter.cpp:102-125) with each segment's own term ordinals.  All result calls then
+ * index by unit = segment * n_queries + query: hits[unit * k_stride + i], counts[unit],
+ * total_hits[unit]; irs_hip_merge_topk turns the per-segment lists into the global top-k.
+ * Segments must live on the same device and use the same block layout. */
+int irs_hip_batch_create_multi(irs_hip_segment* const* segs, uint32_t n_segs,
+                               const irs_hip_query* queries, uint32_t n_queries,
+                               const irs_hip_term_scorer* terms, uint32_t n_term_entries,
+                               irs_hip_batch** out);
 int irs_hip_batch_run(irs_hip_batch* batch, void* stream);
 int irs_hip_batch_results(irs_hip_batch* batch, irs_hip_hit* hits,
                           uint32_t k_stride, uint32_t* counts,

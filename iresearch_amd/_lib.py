@@ -55,7 +55,8 @@ class IrsHipError(RuntimeError):
 SYMBOLS = (
     "irs_hip_abi_version", "irs_hip_strerror", "irs_hip_device_arch", "irs_hip_segment_open",
     "irs_hip_segment_close", "irs_hip_segment_device_bytes", "irs_hip_decode_term",
-    "irs_hip_term_directory", "irs_hip_bit_union", "irs_hip_batch_create", "irs_hip_batch_run",
+    "irs_hip_term_directory", "irs_hip_bit_union", "irs_hip_batch_create",
+    "irs_hip_batch_create_multi", "irs_hip_batch_run",
     "irs_hip_batch_results", "irs_hip_batch_device_results",
     "irs_hip_batch_results_to_device", "irs_hip_batch_destroy",
     "irs_hip_query_batch", "irs_hip_batch_configure", "irs_hip_batch_profile",
@@ -82,6 +83,8 @@ def bind(L: C.CDLL) -> C.CDLL:
     L.irs_hip_term_directory.restype = C.c_int
     L.irs_hip_batch_create.argtypes = [vp, vp, u32, vp, u32, P(vp)]
     L.irs_hip_batch_create.restype = C.c_int
+    L.irs_hip_batch_create_multi.argtypes = [vp, u32, vp, u32, vp, u32, P(vp)]
+    L.irs_hip_batch_create_multi.restype = C.c_int
     L.irs_hip_batch_run.argtypes, L.irs_hip_batch_run.restype = [vp, vp], C.c_int
     L.irs_hip_batch_results.argtypes = [vp, vp, u32, vp, vp]
     L.irs_hip_batch_results.restype = C.c_int

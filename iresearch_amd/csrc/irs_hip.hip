@@ -82,12 +82,15 @@ struct irs_hip_segment {
 };
 
 struct irs_hip_batch {
-  irs_hip_segment* seg = nullptr;
-  uint32_t nq = 0, jt = 0, k_max = 0;
+  irs_hip_segment* seg = nullptr;          // segs[0]: device, CU count
+  std::vector<irs_hip_segment*> segs;      // a batch spans one or more segments of one device
+  uint32_t nq_user = 0;                    // queries per segment
+  uint32_t nq = 0 /* execution units = segments x queries */, jt = 0, k_max = 0;
   uint32_t tile = 0 /* 0 = pick by accumulator width */, stride = kDefaultStride, cand_cap = 0;
   bool estimate = true;  // k_pilot picks an estimated threshold (falls back to the sound one)
   uint32_t reruns = 0;   // recoveries so far (underflow or overflow re-runs)
-  uint32_t n_tiles = 0;
+  uint32_t n_tiles = 0;     // of the segment with the FEWEST tiles (pilot stride, recovery)
+  uint32_t max_tiles = 0;   // ... with the most (chunk ids per unit)
   uint32_t stride_eff = 1;  // pilot stride actually used (>= 4 pilot tiles when possible)
   uint32_t wg_threads = kDefaultWgThreads;  // threads per pilot/score workgroup
   bool any_and = false;
@@ -95,7 +98,7 @@ struct irs_hip_batch {
   bool scratch_ready = false;
   std::vector<DevQuery> queries;
   std::vector<DevQTerm> qterms;
-  DevBuf d_queries, d_qterms, d_first, d_tails, d_bstar, d_cands, d_cand_count, d_hits,
+  DevBuf d_segs, d_queries, d_qterms, d_first, d_tails, d_bstar, d_cands, d_cand_count, d_hits,
     d_out, d_out_count, d_status, d_work;
   uint64_t alg_bytes = 0, postings = 0;
   bool profile = false;
@@ -183,8 +186,8 @@ bool launch_pilot(irs_hip_batch* b, rt::stream_t st) {
   const size_t smem = tile_smem_bytes<ACC, TILE, AND>() + kBins * sizeof(uint32_t);
   auto kern = k_pilot<ACC, LAYOUT, TILE, AND>;
   if (!big_smem(kern, smem)) return false;
-  RT_LAUNCH(kern, b->nq, b->wg_threads, smem, st, b->seg->dev, b->d_queries.as<DevQuery>(),
-            b->d_qterms.as<DevQTerm>(), b->jt, b->n_tiles, b->stride_eff,
+  RT_LAUNCH(kern, b->nq, b->wg_threads, smem, st, b->d_segs.as<DevSegment>(),
+            b->d_queries.as<DevQuery>(), b->d_qterms.as<DevQTerm>(), b->jt, b->stride_eff,
             b->d_first.as<uint32_t>(), b->d_tails.as<DevTail>(), b->d_bstar.as<uint32_t>(),
             b->estimate ? kPilotMargin : 0u);
   return rt::last_error_ok();
@@ -205,12 +208,13 @@ bool launch_score(irs_hip_batch* b, rt::stream_t st) {
 #else
   per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 16u / waves));  // 128 VGPRs: 4 waves/SIMD
 #endif
-  const uint64_t chunks = uint64_t(b->nq) * ((b->n_tiles + kChunkTiles - 1) / kChunkTiles);
+  const uint32_t cpq = (b->max_tiles + kChunkTiles - 1) / kChunkTiles;  // chunk ids per unit
+  const uint64_t chunks = uint64_t(b->nq) * cpq;
   if (chunks > 0xFFFF0000ull) return false;
   const uint32_t grid = uint32_t(std::min<uint64_t>(chunks, uint64_t(b->seg->cus) * per_cu));
   if (!rt::dmemset(b->d_work.p, 0, 4, st)) return false;
-  RT_LAUNCH(kern, grid, threads, smem, st, b->seg->dev, b->d_queries.as<DevQuery>(),
-            b->d_qterms.as<DevQTerm>(), b->jt, b->n_tiles, b->nq,
+  RT_LAUNCH(kern, grid, threads, smem, st, b->d_segs.as<DevSegment>(),
+            b->d_queries.as<DevQuery>(), b->d_qterms.as<DevQTerm>(), b->jt, cpq, b->nq,
             b->d_first.as<uint32_t>(), b->d_tails.as<DevTail>(), b->d_bstar.as<uint32_t>(),
             b->d_cands.as<uint64_t>(), b->cand_cap, b->d_cand_count.as<uint32_t>(),
             b->d_hits.as<unsigned long long>(), b->d_work.as<uint32_t>());
@@ -258,12 +262,22 @@ bool launch_score_acc(irs_hip_batch* b, rt::stream_t st) {
 
 bool ensure_scratch(irs_hip_batch* b) {
   if (b->scratch_ready) return true;
-  const irs_hip_segment* s = b->seg;
   // 32-bit accumulators halve the LDS per doc: twice the tile at the same residency
   // the largest tile that still lets two workgroups share a CU's 160 KB of LDS
   // (AND / min-match batches also keep a match counter byte per doc)
   if (b->tile == 0) b->tile = b->acc32 ? (b->any_and ? 8192 : 12288) : 6144;
-  b->n_tiles = (s->dev.num_docs + b->tile - 1) / b->tile;
+  // per unit: tiles of its segment and its slice of the plan table
+  uint64_t first_words = 0;
+  b->n_tiles = 0xFFFFFFFFu;
+  b->max_tiles = 0;
+  for (uint32_t u = 0; u < b->nq; ++u) {
+    DevQuery& dq = b->queries[u];
+    dq.n_tiles = (b->segs[dq.seg]->dev.num_docs + b->tile - 1) / b->tile;
+    dq.first_off = first_words;
+    first_words += uint64_t(dq.n_tiles + 1) * b->jt;
+    b->n_tiles = std::min(b->n_tiles, dq.n_tiles);
+    b->max_tiles = std::max(b->max_tiles, dq.n_tiles);
+  }
   b->stride_eff = std::max<uint32_t>(1, std::min<uint32_t>(b->stride, b->n_tiles / 4));
   if (const char* e = std::getenv("IRS_HIP_WG_THREADS")) {  // tuning knob
     const uint32_t t = uint32_t(std::atoi(e));
@@ -271,7 +285,10 @@ bool ensure_scratch(irs_hip_batch* b) {
   }
   if (b->cand_cap == 0) b->cand_cap = default_cand_cap(b);
   const uint64_t rows = uint64_t(b->nq) * b->jt;
-  if (!b->d_first.alloc(rows * (b->n_tiles + 1) * sizeof(uint32_t)) ||
+  if (!rt::h2d(b->d_queries.p, b->queries.data(), b->queries.size() * sizeof(DevQuery), nullptr) ||
+      !rt::sync(nullptr))
+    return false;
+  if (!b->d_first.alloc(std::max<uint64_t>(first_words, 1) * sizeof(uint32_t)) ||
       !b->d_tails.alloc(rows * sizeof(DevTail)) ||
       !b->d_bstar.alloc(b->nq * sizeof(uint32_t)) ||
       !b->d_cands.alloc(uint64_t(b->nq) * b->cand_cap * sizeof(uint64_t)) ||
@@ -515,22 +532,42 @@ int irs_hip_term_directory(irs_hip_segment* seg, uint32_t term, uint32_t* last_d
 int irs_hip_batch_create(irs_hip_segment* seg, const irs_hip_query* queries, uint32_t nq,
                          const irs_hip_term_scorer* terms, uint32_t n_entries,
                          irs_hip_batch** out) {
-  if (!seg || !queries || !terms || !out || !nq) return IRS_HIP_EINVAL;
+  return irs_hip_batch_create_multi(&seg, 1, queries, nq, terms, n_entries, out);
+}
+
+int irs_hip_batch_create_multi(irs_hip_segment* const* segs, uint32_t n_segs,
+                               const irs_hip_query* queries, uint32_t nq_user,
+                               const irs_hip_term_scorer* all_terms, uint32_t n_entries,
+                               irs_hip_batch** out) {
+  if (!segs || !n_segs || !queries || !all_terms || !out || !nq_user) return IRS_HIP_EINVAL;
   *out = nullptr;
-  if (!seg->dev.has_freq) return IRS_HIP_EUNSUPPORTED;  // scorers need IndexFeatures::FREQ
-  if (!rt::set_device(seg->device)) return IRS_HIP_EHIP;
+  if (uint64_t(n_segs) * nq_user > 0x7FFFFFFFull) return IRS_HIP_EINVAL;
+  for (uint32_t s = 0; s < n_segs; ++s) {
+    if (!segs[s]) return IRS_HIP_EINVAL;
+    if (!segs[s]->dev.has_freq) return IRS_HIP_EUNSUPPORTED;  // scorers need IndexFeatures::FREQ
+    // one launch per kernel covers every segment: same device, same block layout
+    if (segs[s]->device != segs[0]->device) return IRS_HIP_EINVAL;
+    if (segs[s]->dev.layout != segs[0]->dev.layout) return IRS_HIP_EUNSUPPORTED;
+  }
+  if (!rt::set_device(segs[0]->device)) return IRS_HIP_EHIP;
   irs_hip_batch* b = new (std::nothrow) irs_hip_batch;
   if (!b) return IRS_HIP_ENOMEM;
-  b->seg = seg;
+  b->seg = segs[0];
+  const uint32_t nq = n_segs * nq_user;
   b->nq = nq;
+  b->nq_user = nq_user;
   int rc = IRS_HIP_OK;
   try {
+    b->segs.assign(segs, segs + n_segs);
     b->queries.resize(nq);
-    b->qterms.reserve(n_entries);
+    b->qterms.reserve(size_t(n_entries) * n_segs);
     std::vector<int> exps;
     exps.reserve(nq);
     for (uint32_t q = 0; q < nq && rc == IRS_HIP_OK; ++q) {
-      const irs_hip_query& in = queries[q];
+      // unit q = (segment q / nq_user, query q % nq_user); the segment's own term entries
+      irs_hip_segment* seg = segs[q / nq_user];
+      const irs_hip_term_scorer* terms = all_terms + size_t(q / nq_user) * n_entries;
+      const irs_hip_query& in = queries[q % nq_user];
       if ((in.op != IRS_HIP_OP_OR && in.op != IRS_HIP_OP_AND && in.op != IRS_HIP_OP_MINMATCH) ||
           in.n_terms == 0 ||
           in.n_terms > IRS_HIP_MAX_TERMS || in.k == 0 || in.k > IRS_HIP_MAX_K ||
@@ -607,6 +644,7 @@ int irs_hip_batch_create(irs_hip_segment* seg, const irs_hip_query* queries, uin
       b->alg_bytes += 8ull * in.k;
       DevQuery& dq = b->queries[q];
       dq.k = in.k;
+      dq.seg = q / nq_user;
       // How many of the (present) terms a doc must match.  Or: 1.  And: all, and one absent
       // term empties it (MakeScoreAdapters<true>, boolean_query.cpp:50-53).  MinMatch(m)
       // (MinMatchQuery::execute, boolean_query.cpp:212-247): m > #sub-queries or m > #present
@@ -690,10 +728,14 @@ int irs_hip_batch_create(irs_hip_segment* seg, const irs_hip_query* queries, uin
   if (rc == IRS_HIP_OK) {
     if (b->jt == 0) b->jt = 1;
     if (b->qterms.empty()) b->qterms.push_back(DevQTerm{});
+    std::vector<DevSegment> dsegs;
+    for (irs_hip_segment* sg : b->segs) dsegs.push_back(sg->dev);
     if (!b->d_queries.alloc(b->queries.size() * sizeof(DevQuery)) ||
-        !b->d_qterms.alloc(b->qterms.size() * sizeof(DevQTerm))) {
+        !b->d_qterms.alloc(b->qterms.size() * sizeof(DevQTerm)) ||
+        !b->d_segs.alloc(dsegs.size() * sizeof(DevSegment))) {
       rc = IRS_HIP_ENOMEM;
-    } else if (!rt::h2d(b->d_queries.p, b->queries.data(), b->queries.size() * sizeof(DevQuery),
+    } else if (!rt::h2d(b->d_segs.p, dsegs.data(), dsegs.size() * sizeof(DevSegment), nullptr) ||
+               !rt::h2d(b->d_queries.p, b->queries.data(), b->queries.size() * sizeof(DevQuery),
                         nullptr) ||
                !rt::h2d(b->d_qterms.p, b->qterms.data(), b->qterms.size() * sizeof(DevQTerm),
                         nullptr) ||
@@ -748,9 +790,9 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st) {
   // 1. plan: tile -> first block tables, tail decode
   ok = ok && mark(2 * IRS_HIP_K_PLAN);
   if (ok) {
-    RT_LAUNCH(k_plan, b->nq * b->jt, kThreads, 0, st, b->seg->dev, b->d_queries.as<DevQuery>(),
-              b->d_qterms.as<DevQTerm>(), b->jt, b->tile, b->n_tiles, b->d_first.as<uint32_t>(),
-              b->d_tails.as<DevTail>());
+    RT_LAUNCH(k_plan, b->nq * b->jt, kThreads, 0, st, b->d_segs.as<DevSegment>(),
+              b->d_queries.as<DevQuery>(), b->d_qterms.as<DevQTerm>(), b->jt, b->tile,
+              b->d_first.as<uint32_t>(), b->d_tails.as<DevTail>());
     ok = rt::last_error_ok();
   }
   ok = ok && mark(2 * IRS_HIP_K_PLAN + 1);

@@ -390,15 +390,17 @@ k_bit_union(DevSegment seg, const uint32_t* term_ids, uint32_t slices, uint32_t*
 // (what SkipReader::Seek does per iterator, skip_list.hpp:208-249); thread 0
 // decodes the term's vint tail into the batch scratch.
 __global__ void __launch_bounds__(kThreads)
-k_plan(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms,
-       uint32_t jt /*term slots per query*/, uint32_t tile_docs, uint32_t n_tiles,
-       uint32_t* first /*[q][n_tiles+1][jt]*/, DevTail* tails /*[q][jt]*/) {
+k_plan(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms,
+       uint32_t jt /*term slots per query*/, uint32_t tile_docs,
+       uint32_t* first /*per unit: [n_tiles+1][jt]*/, DevTail* tails /*[unit][jt]*/) {
   __shared__ uint8_t tail_bytes[kTailBytesMax + 16];
-  const uint32_t q = blockIdx.x / jt, j = blockIdx.x % jt;
+  const uint32_t q = blockIdx.x / jt, j = blockIdx.x % jt;   // q: (segment, query) unit
   const DevQuery qd = queries[q];
+  const DevSegment seg = segs[qd.seg];
+  const uint32_t n_tiles = qd.n_tiles;
   DevTail* tl = tails + (uint64_t(q) * jt + j);
-  // table layout [q][tile][term slot]: one tile's entries for all terms are adjacent
-  uint32_t* col = first + uint64_t(q) * (n_tiles + 1) * jt + j;
+  // table layout [unit][tile][term slot]: one tile's entries for all terms are adjacent
+  uint32_t* col = first + qd.first_off + j;
   if (j >= qd.n_terms || qterms[qd.first_term + j].term == kNoTerm) {
     for (uint32_t tile = threadIdx.x; tile <= n_tiles; tile += blockDim.x)
       col[uint64_t(tile) * jt] = 0;
@@ -1083,8 +1085,8 @@ constexpr uint32_t kPilotMinSample = 48;
 
 template<typename ACC, int LAYOUT, int TILE, bool AND>
 __global__ void __launch_bounds__(kTileThreadsMax)
-k_pilot(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_t jt,
-        uint32_t n_tiles, uint32_t stride, const uint32_t* first, const DevTail* tails,
+k_pilot(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms, uint32_t jt,
+        uint32_t stride, const uint32_t* first, const DevTail* tails,
         uint32_t* bstar, uint32_t margin) {
   RT_DYN_SMEM(smem);
   if (!wave::lds_is_at_zero(smem)) __builtin_trap();  // the tile arrays are addressed absolutely
@@ -1094,7 +1096,9 @@ k_pilot(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
   const uint32_t q = blockIdx.x;
   const DevQuery qd = queries[q];
   const DevQTerm* qts = qterms + qd.first_term;
-  const uint32_t* first_q = first + uint64_t(q) * (n_tiles + 1) * jt;
+  const DevSegment seg = segs[qd.seg];
+  const uint32_t n_tiles = qd.n_tiles;
+  const uint32_t* first_q = first + qd.first_off;
   const DevTail* tails_q = tails + uint64_t(q) * jt;
   for (uint32_t i = threadIdx.x; i < kBins; i += blockDim.x) hist[i] = 0u;
   bool first_tile = true;
@@ -1209,8 +1213,9 @@ constexpr uint32_t score_smem_bytes() {
 #endif
 template<typename ACC, int LAYOUT, int TILE, bool AND>
 __global__ void __launch_bounds__(kTileThreadsMax) IRS_SCORE_ATTR
-k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_t jt,
-        uint32_t n_tiles, uint32_t n_queries, const uint32_t* first, const DevTail* tails,
+k_score(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms, uint32_t jt,
+        uint32_t cpq /*chunks per unit*/, uint32_t n_queries, const uint32_t* first,
+        const DevTail* tails,
         const uint32_t* bstar, uint64_t* cands, uint32_t cand_cap, uint32_t* cand_count,
         unsigned long long* hits, uint32_t* work_counter) {
   RT_DYN_SMEM(smem);
@@ -1245,7 +1250,8 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
   const uint32_t wv = wave::uniform(tid >> 6);
   const uint32_t nw = blockDim.x >> 6;
   const uint32_t inv_nw = (65536u + nw - 1) / nw;   // wavefronts per workgroup: 4..16
-  const uint32_t cpq = (n_tiles + kChunkTiles - 1) / kChunkTiles;  // chunks per query
+  // every (segment, query) unit owns `cpq` chunk ids (sized for the segment with the most
+  // tiles; ids past a shorter segment's last tile are empty chunks)
   const uint32_t total_chunks = n_queries * cpq;
 
   for (uint32_t i = tid; i < uint32_t(TILE) + 64u; i += blockDim.x) sm.acc[i] = ACC(0);
@@ -1256,6 +1262,7 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
   if (tid == 0) vars[kVChunk] = atomicAdd(work_counter, 1u);
   __syncthreads();
   uint32_t chunk = wave::uniform(vars[kVChunk]);
+  __syncthreads();  // (an empty chunk has no barrier before thread 0 publishes the next id)
 
   while (chunk < total_chunks) {
     // dequeue of the NEXT chunk: issued now, consumed after this chunk
@@ -1264,13 +1271,18 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
 
     const uint32_t q = chunk / cpq;
     const uint32_t tile0 = (chunk % cpq) * kChunkTiles;
-    const uint32_t ntile = (n_tiles - tile0) < kChunkTiles ? (n_tiles - tile0) : kChunkTiles;
     const DevQuery qd = queries[q];
+    const DevSegment seg = segs[qd.seg];
+    const uint32_t n_tiles = qd.n_tiles;
+    const uint32_t ntile = tile0 >= n_tiles ? 0u
+                           : ((n_tiles - tile0) < kChunkTiles ? (n_tiles - tile0) : kChunkTiles);
     const DevTail* tails_q = tails + uint64_t(q) * jt;
-    const uint32_t* first_q = first + uint64_t(q) * (n_tiles + 1) * jt;
+    const uint32_t* first_q = first + qd.first_off;
     const uint32_t bs = bstar[q];
     const float fx_mul = qd.fx_mul;
 
+    uint32_t pend_base = 0;   // thread 0: reserved candidate base of the previous tile (in flight)
+    if (ntile) {   // (an empty chunk id of a shorter segment only runs the hand-over below)
     // ---- chunk prologue: everything that is per query / per chunk ----------
     if (tid < qd.n_terms) {
       const DevQTerm qt = qterms[qd.first_term + tid];
@@ -1405,7 +1417,6 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
     ItemRegs R;
     items_prepare<LAYOUT>(seg, items_of(0), n_cur < kItemChunk ? n_cur : kItemChunk, inv_nw, R);
 
-    uint32_t pend_base = 0;   // thread 0: reserved candidate base of the previous tile (in flight)
     for (uint32_t u = 0; u < ntile; ++u) {
       const uint32_t tile = tile0 + u;
       const uint32_t lo = kDocMin + tile * TILE;
@@ -1566,6 +1577,7 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
       n_cur = n_next;
       n_next = n_next2;
     }
+    }
     // ---- chunk epilogue: flush the last tile, publish hits, pick up the next chunk
     if (tid == 0) {
       vars[kVBaseLast] = pend_base;
@@ -1573,7 +1585,7 @@ k_score(DevSegment seg, const DevQuery* queries, const DevQTerm* qterms, uint32_
     }
     __syncthreads();
     {
-      const uint32_t lu = ntile - 1u;
+      const uint32_t lu = ntile ? ntile - 1u : 0u;
       const uint32_t pn_raw = vars[kVNc0 + (lu % 3u)];
       const uint32_t pn = pn_raw < kScoreCands ? pn_raw : kScoreCands;
       const uint32_t gbase = vars[kVBaseLast];

@@ -80,6 +80,10 @@ struct DevQuery {
   uint32_t n_caches;
   float fx_mul;         // 2^(E-32): float score -> high word of the fixed-point value
   float fx_inv;         // 2^-E, E = 61 - ceil(log2 U): fixed-point sum -> float
+  // A batch may span several segments: a (segment, query) pair is one execution unit.
+  uint32_t seg;         // index into the batch's DevSegment array
+  uint32_t n_tiles;     // doc tiles of that segment
+  uint64_t first_off;   // start of the unit's [n_tiles + 1][jt] slice of the plan table
 };
 
 struct DevQTerm {

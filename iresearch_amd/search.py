@@ -215,25 +215,33 @@ class SegmentReader:
 
 
 class QueryBatch:
-    """A batch of prepared queries on one segment (irs_hip_batch)."""
+    """A batch of prepared queries on one segment — or on several segments of one device
+    at once (irs_hip_batch_create_multi): then every result array gets a leading segment
+    axis, [n_segs][nq]..., in the order the readers were given."""
 
-    def __init__(self, seg: SegmentReader, prepared, k: int):
-        self.seg, self.L, self.k = seg, seg.L, int(k)
-        self.nq = len(prepared)
+    def __init__(self, seg, prepared, k: int):
+        self.segs = list(seg) if isinstance(seg, (list, tuple)) else [seg]
+        self.multi = isinstance(seg, (list, tuple))
+        self.seg, self.L, self.k = self.segs[0], self.segs[0].L, int(k)
+        self.nq_user = len(prepared)
+        self.nq = self.nq_user * len(self.segs)          # execution units
         n_entries = sum(len(p.terms) for p in prepared)
-        self.queries = np.zeros(self.nq, QUERY)
-        self.terms = np.zeros(max(n_entries, 1), TERM_SCORER)
+        self.queries = np.zeros(self.nq_user, QUERY)
+        self.terms = np.zeros((len(self.segs), max(n_entries, 1)), TERM_SCORER)
         at = 0
         for q, p in enumerate(prepared):
             self.queries[q] = (p.op, len(p.terms), at, self.k, p.min_match)
             for t, (kind, c0, nc, nl) in zip(p.terms, p.scorers):
-                present = t is not None and 0 <= t < len(seg.metas)
-                self.terms[at] = (t if present else NO_TERM, kind, c0, nc, nl)
+                for s, sr in enumerate(self.segs):       # same scorer, the segment's own ordinal
+                    present = t is not None and 0 <= t < len(sr.metas)
+                    self.terms[s, at] = (t if present else NO_TERM, kind, c0, nc, nl)
                 at += 1
         h = C.c_void_p()
-        _lib.check(self.L, self.L.irs_hip_batch_create(
-            seg.handle, self.queries.ctypes.data, self.nq, self.terms.ctypes.data, n_entries,
-            C.byref(h)), "irs_hip_batch_create")
+        handles = (C.c_void_p * len(self.segs))(*[sr.handle for sr in self.segs])
+        _lib.check(self.L, self.L.irs_hip_batch_create_multi(
+            handles, len(self.segs), self.queries.ctypes.data, self.nq_user,
+            self.terms.ctypes.data, self.terms.shape[1], C.byref(h)),
+            "irs_hip_batch_create_multi")
         self.handle = h
 
     def configure(self, tile_docs=0, pilot_stride=0, cand_cap=0):
@@ -274,6 +282,10 @@ class QueryBatch:
         _lib.check(self.L, self.L.irs_hip_batch_results(
             self.handle, hits.ctypes.data, self.k, counts.ctypes.data, totals.ctypes.data),
             "irs_hip_batch_results")
+        if self.multi:
+            n = len(self.segs)
+            return (hits.reshape(n, self.nq_user, self.k), counts.reshape(n, self.nq_user),
+                    totals.reshape(n, self.nq_user))
         return hits, counts, totals
 
     def device_results(self):

@@ -545,6 +545,39 @@ def case_multi_segment(L, num_docs, max_rank, n_segs=3, k=100, device_merge=True
         r.close()
 
 
+def case_multi_segment_batch(L, sizes=(30_000, 9_000, 140_000), max_rank=256, k=100):
+    """irs_hip_batch_create_multi: ONE batch over segments of different sizes (so the shorter
+    ones have empty chunk ids) gives, per segment, bit for bit what a batch on that segment
+    alone gives — for every op, with a term missing from one segment, for every tile size —
+    and it matches the oracle."""
+    first = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    segs = [synth.build_segment(int(n), max_rank, first_doc=int(f)) for n, f in zip(sizes, first)]
+    segs[1].metas[max_rank - 1]["docs_count"] = 0
+    readers = [search.SegmentReader.from_synth(s, L=L) for s in segs]
+    filters = standard_filters(max_rank, n_or8=3)
+    for scorer in (BM25(), TFIDF(True)):
+        prep = search.prepare(filters, scorer, [parity.segment_stats(s) for s in segs])
+        for tile in (0, 4096, 12288):
+            mb = search.QueryBatch(readers, prep, k)
+            if tile:
+                mb.configure(tile, 5, 0)
+            mh, mc, mt = mb.run().results()
+            assert mh.shape == (len(segs), len(filters), k)
+            for i, (s, r) in enumerate(zip(segs, readers)):
+                b = r.batch(prep, k)
+                if tile:
+                    b.configure(tile, 5, 0)
+                h, c, t = b.run().results()
+                b.close()
+                assert np.array_equal(mc[i], c) and np.array_equal(mt[i], t), (i, tile)
+                assert np.array_equal(mh[i], h), (i, tile)
+                if tile == 0:
+                    parity.check_single_segment(s, filters, scorer, k, mh[i], mc[i], mt[i], segs)
+            mb.close()
+    for r in readers:
+        r.close()
+
+
 def case_merge_ties(L, n_lists=5, nq=7, k=64, seed=11):
     """irs_hip_merge_topk alone: few distinct scores (heavy ties across segments), ragged
     counts including empty lists, segment ids not in list order.  Expected order:

@@ -123,5 +123,5 @@ def test_bench_is_launchable_on_two_ranks(simlib):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1
     assert d["value"] > 0 and d["unit"] == "queries/s" and d["scaling"] == "strong"
     assert d["config"]["segments"] == 4 and d["config"]["reruns_rank0"] == 0
-    assert d["roofline"]["launches_per_step"] == 2       # rank 0 owns 2 of the 4 segments
+    assert d["roofline"]["launches_per_step"] == 1       # ONE batch over rank 0's 2 segments
     assert d["cpu_baseline"] is None

@@ -84,6 +84,10 @@ def test_multi_segment(simlib):
     cases.case_multi_segment(simlib, 45_000, 256)
 
 
+def test_multi_segment_batch(simlib):
+    cases.case_multi_segment_batch(simlib)
+
+
 def test_merge_ties(simlib):
     cases.case_merge_ties(simlib)
 

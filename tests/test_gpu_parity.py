@@ -89,6 +89,10 @@ def test_multi_segment(gpulib):
     cases.case_multi_segment(gpulib, 600_000, 1024, n_segs=4, k=1000)
 
 
+def test_multi_segment_batch(gpulib):
+    cases.case_multi_segment_batch(gpulib, sizes=(700_000, 90_000, 1_300_000), max_rank=1024, k=1000)
+
+
 def test_merge_ties(gpulib):
     cases.case_merge_ties(gpulib)
     cases.case_merge_ties(gpulib, n_lists=8, nq=5, k=1000, seed=5)
