@@ -91,7 +91,7 @@ struct irs_hip_batch {
   uint32_t reruns = 0;   // recoveries so far (underflow or overflow re-runs)
   uint32_t n_tiles = 0;     // of the segment with the FEWEST tiles (pilot stride, recovery)
   uint32_t max_tiles = 0;   // ... with the most (chunk ids per unit)
-  uint32_t stride_eff = 1;  // pilot stride actually used (>= 4 pilot tiles when possible)
+  uint32_t stride_eff = 1;  // pilot stride actually used (>= 2 pilot tiles per segment when possible)
   uint32_t wg_threads = kDefaultWgThreads;  // threads per pilot/score workgroup
   bool any_and = false;
   bool acc32 = true;   // 32-bit fixed-point accumulators are precise enough for every query
@@ -278,7 +278,7 @@ bool ensure_scratch(irs_hip_batch* b) {
     b->n_tiles = std::min(b->n_tiles, dq.n_tiles);
     b->max_tiles = std::max(b->max_tiles, dq.n_tiles);
   }
-  b->stride_eff = std::max<uint32_t>(1, std::min<uint32_t>(b->stride, b->n_tiles / 4));
+  b->stride_eff = std::max<uint32_t>(1, std::min<uint32_t>(b->stride, b->n_tiles / 2));
   if (const char* e = std::getenv("IRS_HIP_WG_THREADS")) {  // tuning knob
     const uint32_t t = uint32_t(std::atoi(e));
     if (t >= 256 && t <= 1024 && t % 64 == 0) b->wg_threads = t;
