@@ -1269,8 +1269,10 @@ k_score(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms,
     uint32_t next_chunk = 0;
     if (tid == 0) next_chunk = atomicAdd(work_counter, 1u);
 
-    const uint32_t q = chunk / cpq;
-    const uint32_t tile0 = (chunk % cpq) * kChunkTiles;
+    // chunk-major ids: every unit's first chunk, then every unit's second, ... so the short
+    // last chunks of the units are handed out at the very end (smaller tail)
+    const uint32_t q = chunk % n_queries;
+    const uint32_t tile0 = (chunk / n_queries) * kChunkTiles;
     const DevQuery qd = queries[q];
     const DevSegment seg = segs[qd.seg];
     const uint32_t n_tiles = qd.n_tiles;
