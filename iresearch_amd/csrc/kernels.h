@@ -1749,7 +1749,7 @@ struct MergeLists {
 };
 
 constexpr uint32_t merge_smem_bytes(uint32_t n_lists, uint32_t k) {
-  return 4u * n_lists * k + 4u * kMergeLists * 2u;
+  return 4u * n_lists * k + 4u * kMergeLists * 2u + 8u * kMergeLists + 8u;
 }
 
 __global__ void __launch_bounds__(kThreads)
@@ -1759,6 +1759,9 @@ k_merge_topk(MergeLists lists, uint32_t n_lists, uint32_t k, Hit* out, uint32_t*
   uint32_t* sc = reinterpret_cast<uint32_t*>(smem);   // [n_lists][k], descending
   uint32_t* cnt = sc + n_lists * k;                     // [kMergeLists]
   uint32_t* sid = cnt + kMergeLists;                    // [kMergeLists]
+  // the lists' base pointers, so that a thread can fetch its element without a
+  // 16-way select over kernel arguments (8-byte aligned: 4*n_lists*k + 128 bytes in)
+  const Hit** hp = reinterpret_cast<const Hit**>(sid + kMergeLists + ((n_lists * k) & 1u));
   const uint32_t q = blockIdx.x;
   if (threadIdx.x < kMergeLists) {
     uint32_t c = 0, id = 0;
@@ -1772,6 +1775,12 @@ k_merge_topk(MergeLists lists, uint32_t n_lists, uint32_t k, Hit* out, uint32_t*
     }
     cnt[threadIdx.x] = c < k ? c : k;
     sid[threadIdx.x] = id;
+    const Hit* base = nullptr;
+#pragma unroll
+    for (uint32_t l = 0; l < kMergeLists; ++l) {
+      if (l == threadIdx.x && l < n_lists) base = lists.hits[l] + uint64_t(q) * k;
+    }
+    hp[threadIdx.x] = base;
   }
   __syncthreads();
 #pragma unroll
@@ -1790,11 +1799,22 @@ k_merge_topk(MergeLists lists, uint32_t n_lists, uint32_t k, Hit* out, uint32_t*
   __syncthreads();
   uint32_t total = 0;
   for (uint32_t l = 0; l < n_lists; ++l) total += cnt[l];
+  // Cheap lower bound of the final k-th score: with g = ceil(k / n_lists), if every list
+  // holds at least g elements then the union holds >= k elements scoring at least
+  // min_l score_l[g - 1], so nothing below that can be in the top k.  Most elements are
+  // dismissed by this one comparison; only about k of them are ranked.
+  const uint32_t g = (k + n_lists - 1) / n_lists;
+  uint32_t floor_bits = 0xFFFFFFFFu;
+  for (uint32_t l = 0; l < n_lists; ++l)
+    floor_bits = cnt[l] >= g ? (sc[l * k + g - 1] < floor_bits ? sc[l * k + g - 1] : floor_bits) : 0u;
+  // (a list shorter than g voids the bound: floor 0 keeps everything; the loop above lets
+  // a later list raise it again only through `<`, so once 0 it stays 0)
   // element i -> (list i % n_lists, position i / n_lists): a wavefront works at one depth
   for (uint32_t i = threadIdx.x; i < n_lists * k; i += blockDim.x) {
     const uint32_t l = i % n_lists, p = i / n_lists;
     if (p >= cnt[l]) continue;
     const uint32_t s = sc[l * k + p], my_id = sid[l];
+    if (s < floor_bits) continue;
     uint32_t rank = p;
     for (uint32_t m = 0; m < n_lists && rank < k; ++m) {
       if (m == l) continue;
@@ -1809,12 +1829,7 @@ k_merge_topk(MergeLists lists, uint32_t n_lists, uint32_t k, Hit* out, uint32_t*
       rank += lo;
     }
     if (rank < k) {
-      Hit h{};
-#pragma unroll
-      for (uint32_t m = 0; m < kMergeLists; ++m) {
-        if (m == l) h = lists.hits[m][uint64_t(q) * k + p];
-      }
-      out[uint64_t(q) * k + rank] = h;
+      out[uint64_t(q) * k + rank] = hp[l][p];
       out_seg[uint64_t(q) * k + rank] = my_id;
     }
   }
