@@ -51,17 +51,25 @@ def _worker(rank, world, port, sim_path, out_dir):
     filters = _filters()
     prep = search.prepare(filters, BM25(), seg_stats)
     nq = len(filters)
+    # the production flow (bench.py): ONE batch over the rank's segments, results written
+    # straight into its slots of the exchange buffer, one collective, device-side merge
+    readers = [search.SegmentReader.from_synth(segs[s], L=L) for s in my]
+    ex = distributed.TopkExchange(L, 0, N_SEGS, rank, world, nq, K, "cpu")
+    b = search.QueryBatch(readers, prep, K).run()
+    hp, cp = ex.slot(0)
+    b.results_to_device(hp, cp)
+    oh, osg, oc = ex.run()
+    # ... and the one-shot form over per-segment batches must agree with it
     lists = []
-    keep = []
-    for s in my:
-        r = search.SegmentReader.from_synth(segs[s], L=L)
-        b = r.batch(prep, K).run()
+    for i, r in enumerate(readers):
+        sb = r.batch(prep, K).run()
         h = torch.zeros((nq, K), dtype=torch.int64)
         c = torch.zeros((nq,), dtype=torch.int32)
-        b.results_to_device(h.data_ptr(), c.data_ptr())
-        lists.append((s, h, c))
-        keep.append((r, b))
-    oh, osg, oc = distributed.gather_merge(L, 0, lists, N_SEGS, rank, world, nq, K, "cpu")
+        sb.results_to_device(h.data_ptr(), c.data_ptr())
+        lists.append((my[i], h, c))
+        sb.close()
+    oh2, osg2, oc2 = distributed.gather_merge(L, 0, lists, N_SEGS, rank, world, nq, K, "cpu")
+    assert torch.equal(oh, oh2) and torch.equal(osg, osg2) and torch.equal(oc, oc2)
     np.save(os.path.join(out_dir, "hits_%d.npy" % rank), oh.numpy())
     np.save(os.path.join(out_dir, "segs_%d.npy" % rank), osg.numpy())
     np.save(os.path.join(out_dir, "counts_%d.npy" % rank), oc.numpy())
