@@ -107,6 +107,12 @@ __device__ __forceinline__ void keep_all_f(float (&v)[4]) {
   asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
 }
 
+// A wave-uniform value the optimiser may not reason about (stays in an SGPR).
+__device__ __forceinline__ uint32_t opaque(uint32_t v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
+
 // A register whose content does not matter (no instruction is emitted).
 __device__ __forceinline__ uint64_t undef64() {
   uint64_t v;

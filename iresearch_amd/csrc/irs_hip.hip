@@ -75,6 +75,7 @@ struct irs_hip_segment {
   DevSegment dev{};
   DevBuf d_doc, d_norms, d_terms, d_blk_off, d_blk_last, d_blk_bits, d_status;
   DevBuf d_blk_aoff, d_pk;     // packed-payload image (DevSegment::pk) and its offsets
+  DevBuf d_tail_docs, d_tail_freqs;  // decoded vint tails, [num_terms][128]
   std::vector<DevTerm> terms;  // host mirror incl. the fields the dir kernel filled
   uint64_t total_blocks = 0;
   uint64_t device_bytes = 0;
@@ -152,7 +153,8 @@ int build_directory(irs_hip_segment* s) {
     RT_LAUNCH((k_build_directory<LAYOUT>), grid, kThreads, 0, nullptr, s->dev,
               s->d_terms.as<DevTerm>(), s->d_blk_off.as<uint32_t>(),
               s->d_blk_last.as<uint32_t>(), s->d_blk_bits.as<uint16_t>(),
-              s->d_blk_aoff.as<uint32_t>(), s->d_status.as<uint32_t>());
+              s->d_blk_aoff.as<uint32_t>(), s->d_tail_docs.as<uint32_t>(),
+              s->d_tail_freqs.as<uint32_t>(), s->d_status.as<uint32_t>());
   }
   if (!rt::last_error_ok()) return IRS_HIP_EHIP;
   uint32_t status = 0;
@@ -391,6 +393,8 @@ int irs_hip_segment_open(const irs_hip_segment_desc* d, irs_hip_segment** out) {
         !s->d_terms.alloc(std::max<size_t>(1, s->terms.size()) * sizeof(DevTerm)) ||
         !s->d_blk_off.alloc((blocks + 1) * 4) || !s->d_blk_last.alloc((blocks + 1) * 4) ||
         !s->d_blk_bits.alloc((blocks + 1) * 2) || !s->d_blk_aoff.alloc((blocks + 1) * 4) ||
+        !s->d_tail_docs.alloc((uint64_t(d->num_terms) + 1) * kBlock * 4) ||
+        !s->d_tail_freqs.alloc((uint64_t(d->num_terms) + 1) * kBlock * 4) ||
         !s->d_status.alloc(4)) {
       rc = IRS_HIP_ENOMEM;
       break;
@@ -420,6 +424,8 @@ int irs_hip_segment_open(const irs_hip_segment_desc* d, irs_hip_segment** out) {
     v.blk_last = s->d_blk_last.as<uint32_t>();
     v.blk_bits = s->d_blk_bits.as<uint16_t>();
     v.blk_aoff = s->d_blk_aoff.as<uint32_t>();
+    v.tail_docs = s->d_tail_docs.as<uint32_t>();
+    v.tail_freqs = s->d_tail_freqs.as<uint32_t>();
     v.pk = nullptr;  // set by build_packed_image
     v.has_freq = d->has_freq ? 1 : 0;
     v.layout = d->layout;
@@ -427,7 +433,8 @@ int irs_hip_segment_open(const irs_hip_segment_desc* d, irs_hip_segment** out) {
     rc = d->layout == IRS_HIP_LAYOUT_SIMD4 ? build_directory<kSimd4>(s)
                                            : build_directory<kScalar>(s);
     s->device_bytes = s->d_doc.n + s->d_norms.n + s->d_terms.n + s->d_blk_off.n +
-                      s->d_blk_last.n + s->d_blk_bits.n + s->d_blk_aoff.n + s->d_pk.n;
+                      s->d_blk_last.n + s->d_blk_bits.n + s->d_blk_aoff.n + s->d_pk.n +
+                      s->d_tail_docs.n + s->d_tail_freqs.n;
   } while (false);
   if (rc != IRS_HIP_OK) {
     delete s;

@@ -52,7 +52,7 @@ template<int LAYOUT>
 __global__ void __launch_bounds__(kThreads)
 k_build_directory(DevSegment seg, DevTerm* terms, uint32_t* blk_off,
                   uint32_t* blk_last, uint16_t* blk_bits, uint32_t* blk_units,
-                  uint32_t* status) {
+                  uint32_t* tail_docs, uint32_t* tail_freqs, uint32_t* status) {
   const unsigned lane = threadIdx.x & 63u;
   const uint32_t term = blockIdx.x * kWaves + (threadIdx.x >> 6);
   if (term >= seg.num_terms) return;
@@ -60,6 +60,8 @@ k_build_directory(DevSegment seg, DevTerm* terms, uint32_t* blk_off,
   if (t.docs_count == 0) return;
   if (t.docs_count == 1) {  // single_doc_iterator, formats_10.cpp:1876-1890
     if (lane == 0) {
+      tail_docs[uint64_t(term) * kBlock] = t.single_doc;
+      tail_freqs[uint64_t(term) * kBlock] = t.single_freq;
       terms[term].last_doc = t.single_doc;
       terms[term].tf_bound = t.single_freq;
       terms[term].tail_off = t.doc_start;
@@ -128,18 +130,22 @@ k_build_directory(DevSegment seg, DevTerm* terms, uint32_t* blk_off,
         uint32_t len;
         const uint32_t v = vint_from(wave::load_u64(seg.doc + cur), &len);
         cur += len;
+        uint32_t f = 1;
         if (seg.has_freq) {
           doc += v >> 1;  // shift_unpack_32, store_utils.hpp:266-269
           if (v & 1u) {
             tfb = tfb ? tfb : 1u;
           } else {
-            const uint32_t f = vint_from(wave::load_u64(seg.doc + cur), &len);
+            f = vint_from(wave::load_u64(seg.doc + cur), &len);
             cur += len;
             tfb = f > tfb ? f : tfb;
           }
         } else {
           doc += v;
         }
+        // the decoded tail (read_tail_block, formats_10.cpp:1765-1792) is kept per term
+        tail_docs[uint64_t(term) * kBlock + i] = doc;
+        tail_freqs[uint64_t(term) * kBlock + i] = f;
       }
       if (cur > seg.doc_len) bad = true;
     }
@@ -393,7 +399,6 @@ __global__ void __launch_bounds__(kThreads)
 k_plan(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms,
        uint32_t jt /*term slots per query*/, uint32_t tile_docs,
        uint32_t* first /*per unit: [n_tiles+1][jt]*/, DevTail* tails /*[unit][jt]*/) {
-  __shared__ uint8_t tail_bytes[kTailBytesMax + 16];
   const uint32_t q = blockIdx.x / jt, j = blockIdx.x % jt;   // q: (segment, query) unit
   const DevQuery qd = queries[q];
   const DevSegment seg = segs[qd.seg];
@@ -407,6 +412,7 @@ k_plan(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms,
     if (threadIdx.x == 0) {
       tl->n = 0; tl->first_doc = 0; tl->last_doc = 0;
       tl->nblk = 0; tl->doc_start = 0; tl->dir_off = 0;
+      tl->term = 0; tl->pad = 0;
     }
     return;
   }
@@ -422,33 +428,17 @@ k_plan(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms,
     }
     col[uint64_t(tile) * jt] = a;
   }
-  // tail bytes -> LDS (coalesced), then a serial LEB128 walk by one lane
-  uint32_t nbytes = 0;
-  if (t.docs_count > 1 && t.tail_n) {
-    nbytes = t.tail_bytes;
-    for (uint32_t i = threadIdx.x; i < nbytes + 8; i += blockDim.x)
-      tail_bytes[i] = i < nbytes ? seg.doc[t.tail_off + i] : uint8_t(0);
-  }
-  __syncthreads();
   if (threadIdx.x == 0) {
+    const uint32_t term = qterms[qd.first_term + j].term;
     tl->nblk = t.nblk;
     tl->doc_start = t.doc_start;
     tl->dir_off = t.dir_off;
-    if (t.docs_count == 1) {
-      tl->n = 1;
-      tl->docs[0] = t.single_doc;
-      tl->freqs[0] = t.single_freq;
-      tl->first_doc = tl->last_doc = t.single_doc;
-    } else if (t.tail_n) {
-      uint32_t lastd;
-      decode_tail_serial(tail_bytes, t.tail_n, t.tail_base, seg.has_freq != 0,
-                         tl->docs, tl->freqs, &lastd);
-      tl->n = t.tail_n;
-      tl->first_doc = tl->docs[0];
-      tl->last_doc = lastd;
-    } else {
-      tl->n = 0; tl->first_doc = 0; tl->last_doc = 0;
-    }
+    tl->term = term;
+    tl->pad = 0;
+    // the tail's postings were decoded when the segment was opened
+    tl->n = t.docs_count == 1 ? 1u : t.tail_n;
+    tl->first_doc = tl->n ? seg.tail_docs[uint64_t(term) * kBlock] : 0u;
+    tl->last_doc = tl->n ? t.last_doc : 0u;
   }
 }
 
@@ -1063,7 +1053,9 @@ __device__ __forceinline__ void tile_accumulate(const DevSegment& seg, const Dev
       const DevQTerm qt = sm.qts[j];
       const float inv_one = 1.f / (qt.norm_const + qt.norm_length * 1.f);
       for (uint32_t i = lane; i < tn; i += 64)
-        tile_apply<ACC, TILE, AND>(seg, sm, qt, inv_one, tl->docs[i], tl->freqs[i], lo, span,
+        tile_apply<ACC, TILE, AND>(seg, sm, qt, inv_one,
+                                   seg.tail_docs[uint64_t(tl->term) * kBlock + i],
+                                   seg.tail_freqs[uint64_t(tl->term) * kBlock + i], lo, span,
                                    fx_mul);
     }
   }
@@ -1439,14 +1431,20 @@ k_score(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms,
       }
       const uint32_t tm = wave::uniform(tmask[u]);
       if (tm) {  // decoded vint tails / single docs reaching into this tile
+        // rare path: the table pointers are re-read from the segment record here instead of
+        // living in scalar registers across the whole tile loop (wave::opaque stops the
+        // compiler from hoisting the loads)
+        const DevSegment* sp = segs + wave::opaque(wave::uniform(qd.seg));
+        const uint32_t* tdocs = sp->tail_docs;
+        const uint32_t* tfreqs = sp->tail_freqs;
         for (uint32_t j = wv; j < qd.n_terms; j += nw) {
           if ((tm >> j) & 1u) {
             const DevQTerm qt = sm.qts[j];
             const float inv_one = 1.f / (qt.norm_const + qt.norm_length * 1.f);
-            const DevTail* tl = tails_q + j;
+            const uint64_t row = uint64_t(tails_q[j].term) * kBlock;
             const uint32_t tn = tc[j].tail_n;
             for (uint32_t i = lane; i < tn; i += 64)
-              tile_apply<ACC, TILE, AND>(seg, sm, qt, inv_one, tl->docs[i], tl->freqs[i], lo,
+              tile_apply<ACC, TILE, AND>(seg, sm, qt, inv_one, tdocs[row + i], tfreqs[row + i], lo,
                                          span, fx_mul);
           }
         }

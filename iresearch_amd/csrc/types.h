@@ -12,7 +12,6 @@ constexpr uint32_t kMaxK = 4096;       // IRS_HIP_MAX_K
 constexpr uint32_t kBins = 512;        // score histogram bins (pilot threshold)
 constexpr uint32_t kMaxCaches = 4;     // distinct (norm_const, norm_length) per query in LDS
 constexpr uint32_t kPadBytes = 64;     // zero padding after the staged `.doc` bytes
-constexpr uint32_t kTailBytesMax = 127 * 10;  // 127 entries x 2 vints x 5 bytes
 
 enum Layout : int32_t { kScalar = 0, kSimd4 = 1 };
 
@@ -66,6 +65,9 @@ struct DevSegment {
   // headers leave all of them misaligned.  The hot decoder reads this copy.
   const uint8_t* pk;
   const uint32_t* blk_aoff;  // offset of the block in `pk`, in 16-byte units
+  // decoded vint tails / single docs: [num_terms][kBlock] absolute doc ids and frequencies
+  const uint32_t* tail_docs;
+  const uint32_t* tail_freqs;
   int32_t has_freq;
   int32_t layout;
   uint32_t wand_count;       // scorers the field was indexed with (wand data in front of short tails)
@@ -96,17 +98,19 @@ struct DevQTerm {
   uint32_t pad0, pad1;
 };
 
-// A term's vint tail (or single doc) decoded once per (query, term) by the
-// plan kernel: at most 127 postings with absolute doc ids.
+// What a tile workgroup needs to know about one term of one query, gathered by the plan
+// kernel into ONE record (no dependent chain of loads in the chunk prologue).  The
+// postings of the term's vint tail (or its single doc) — at most 127 of them — are decoded
+// once per TERM when the segment is opened (DevSegment::tail_docs / tail_freqs).
 struct DevTail {
-  uint32_t n;
+  uint32_t n;           // postings in the decoded tail (1 for a single-doc term)
   uint32_t first_doc;
   uint32_t last_doc;
-  uint32_t nblk;        // copy of DevTerm::nblk      } so that a tile workgroup finds
-  uint64_t doc_start;   // copy of DevTerm::doc_start } everything about the term with
-  uint64_t dir_off;     // copy of DevTerm::dir_off   } ONE load, not a dependent chain
-  uint32_t docs[kBlock];
-  uint32_t freqs[kBlock];
+  uint32_t nblk;        // copy of DevTerm::nblk
+  uint64_t doc_start;   // copy of DevTerm::doc_start
+  uint64_t dir_off;     // copy of DevTerm::dir_off
+  uint32_t term;        // ordinal: row of the decoded-tail tables
+  uint32_t pad;
 };
 
 struct Hit {

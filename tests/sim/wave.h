@@ -69,6 +69,7 @@ __device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t s)
 }
 __device__ __forceinline__ uint32_t bfe(uint32_t x, uint32_t bits) { return x & ((1u << bits) - 1u); }
 __device__ __forceinline__ uint64_t undef64() { return 0; }
+__device__ __forceinline__ uint32_t opaque(uint32_t v) { return v; }
 // LDS "by absolute address" (hip/wave.h): here simply base + offset
 __device__ __forceinline__ bool lds_is_at_zero(const unsigned char*) { return true; }
 __device__ __forceinline__ uint32_t lds_u8(const unsigned char* base, uint32_t off) { return base[off]; }
