@@ -171,14 +171,28 @@ void wand_write(uint32_t kind, const WandEntry& e, Bytes& o) {
 // One term: postings_writer<>::write + BeginDocument + EndDocument + EndTerm
 // (formats_10.cpp:942-1025, 865-891, 639-657, 662-798) for a FREQ-only field
 // written with no scorers (no wand bytes: valid_writers_ empty, :453-458).
+// With `positions` (the field has IndexFeatures::POS; Σ freqs entries, ascending and >= 1
+// within a doc) the `.pos` stream of the term is appended to `*pos`: AddPosition :894-933
+// (delta to the previous position of the doc, first one relative to pos_min() == 0 in the
+// zero-based formats 1_3+, packed in blocks of 128 across docs), EndTerm :713-760 (vint tail,
+// pos_end), and every skip entry also carries vint(pend_pos) + vlong(Δpos_ptr) (:511-518).
 void encode_term(const uint32_t* docs, const uint32_t* freqs, uint32_t count,
                  uint32_t segment_docs, uint32_t layout, Bytes& o,
-                 irs_synth_term_meta& meta, const WandSpec* wand = nullptr) {
+                 irs_synth_term_meta& meta, const WandSpec* wand = nullptr,
+                 const uint32_t* positions = nullptr, Bytes* pos = nullptr) {
   const size_t start = o.size();
   meta = irs_synth_term_meta{};
   meta.pos_end = UINT64_MAX;
   meta.docs_count = count;
   if (count == 0) return;
+  const bool has_pos = positions && pos && freqs;
+  const uint64_t pos_start = has_pos ? pos->size() : 0;  // BeginTerm :626
+  uint64_t pos_skip_ptr[kMaxSkipLevels];
+  std::fill_n(pos_skip_ptr, kMaxSkipLevels, pos_start);   // :627
+  uint32_t pos_buf[kBlock];
+  uint32_t pos_n = 0;           // pos_.size
+  uint32_t pos_block_last = 0;  // pos_.block_last: positions pending at the last doc-block end
+  uint64_t pos_at = 0;          // cursor in `positions`
 
   // SkipWriter::Prepare — skip_list.cpp:47-48
   const uint32_t max_levels = std::min(
@@ -205,6 +219,12 @@ void encode_term(const uint32_t* docs, const uint32_t* freqs, uint32_t count,
     put_vint(out, block_last);
     put_vlong(out, doc_ptr - skip_ptr[level]);
     skip_ptr[level] = doc_ptr;
+    if (has_pos) {  // :511-518
+      const uint64_t pos_ptr = pos->size();
+      put_vint(out, pos_block_last);
+      put_vlong(out, pos_ptr - pos_skip_ptr[level]);
+      pos_skip_ptr[level] = pos_ptr;
+    }
     for (uint32_t w = 0; w < wn; ++w) out.push_back(wand_size(wand->kinds[w], wl[w][level]));
     for (uint32_t w = 0; w < wn; ++w) {
       WandEntry& e = wl[w][level];
@@ -250,6 +270,7 @@ void encode_term(const uint32_t* docs, const uint32_t* freqs, uint32_t count,
     for (uint32_t w = 0; w < wn; ++w)  // writer.Update() :1005-1006
       wand_produce(wand->kinds[w], freqs ? freqs[i] : 1u,
                    wand->norms ? wand->norms[docs[i] - 1] : 0xFFFFFFFFu, wl[w][0]);
+    const bool doc_block_full = n == kBlock;
     if (n == kBlock) {
       // simd::delta_encode<128>(docs, block_last) — simd_utils.hpp:200-249
       uint32_t prev = block_last;
@@ -264,8 +285,26 @@ void encode_term(const uint32_t* docs, const uint32_t* freqs, uint32_t count,
       block_last = last;
       n = 0;
     }
+    if (has_pos) {
+      uint32_t pos_last = 0;  // FormatTraits::pos_min() of the zero-based formats (:883, :4196)
+      for (uint32_t k = 0; k < freqs[i]; ++k) {  // AddPosition :894-913
+        const uint32_t p = positions[pos_at++];
+        pos_buf[pos_n++] = p - pos_last;
+        pos_last = p;
+        if (pos_n == kBlock) {
+          write_block(*pos, pos_buf, layout);
+          pos_n = 0;
+        }
+      }
+      if (doc_block_full) pos_block_last = pos_n;  // EndDocument :645-649
+    }
   }
   meta.freq = uint32_t(total_freq);
+  if (has_pos) {  // EndTerm :713-760
+    if (meta.freq > kBlock) meta.pos_end = pos->size() - pos_start;
+    for (uint32_t k = 0; k < pos_n; ++k) put_vint(*pos, pos_buf[k]);
+    meta.pos_start = pos_start;
+  }
 
   // EndTerm :662-798
   if (count == 1) {
@@ -320,11 +359,13 @@ uint32_t crc32c(const uint8_t* p, size_t n) {
 }
 
 constexpr char kDocFormatName[] = "iresearch_10_postings_documents";  // :325
+constexpr char kPosFormatName[] = "iresearch_10_postings_positions";  // :328
 
-void make_header(Bytes& o, uint32_t layout) {
+void make_header(Bytes& o, uint32_t layout, const char* name = kDocFormatName) {
+  const size_t len = std::strlen(name);
   put_be32(o, 0x3fd76c17u);  // kFormatMagic format_utils.hpp:36
-  put_vint(o, uint32_t(sizeof(kDocFormatName) - 1));
-  o.insert(o.end(), kDocFormatName, kDocFormatName + sizeof(kDocFormatName) - 1);
+  put_vint(o, uint32_t(len));
+  o.insert(o.end(), name, name + len);
   // PostingsFormat::WAND_SSE (5) / WAND (4) — formats_10.cpp:305-311
   put_be32(o, layout == IRS_SYNTH_LAYOUT_SIMD4 ? 5u : 4u);
 }
@@ -397,12 +438,14 @@ struct Zipf {
 struct ThreadPostings {
   std::vector<std::vector<uint32_t>> docs;
   std::vector<std::vector<uint8_t>> tfs;
+  std::vector<std::vector<uint8_t>> poss;  // with_positions: 1-based token positions (<= 255)
 };
 
 }  // namespace
 
 struct irs_synth_index {
   Bytes doc_file;
+  Bytes pos_file;  // with_positions
   std::vector<uint8_t> norms;
   std::vector<irs_synth_term_meta> metas;
   uint64_t docs_with_field = 0;
@@ -410,6 +453,7 @@ struct irs_synth_index {
   // keep_postings
   std::vector<std::vector<uint32_t>> docs;
   std::vector<std::vector<uint32_t>> freqs;
+  std::vector<std::vector<uint32_t>> positions;
 };
 
 extern "C" {
@@ -481,6 +525,61 @@ int64_t irs_synth_wrap_doc_file(const uint8_t* body, uint64_t body_len,
   return int64_t(o.size());
 }
 
+int64_t irs_synth_wrap_pos_file(const uint8_t* body, uint64_t body_len,
+                                uint32_t layout, uint8_t* out,
+                                uint64_t out_cap, uint64_t* body_offset) {
+  Bytes o;
+  make_header(o, layout, kPosFormatName);
+  const uint64_t hdr = o.size();
+  o.insert(o.end(), body, body + body_len);
+  put_be32(o, uint32_t(-int32_t(0x3fd76c17)));
+  put_be32(o, 0);
+  put_be64(o, crc32c(o.data(), o.size()));
+  if (o.size() > out_cap) return -2;
+  std::memcpy(out, o.data(), o.size());
+  if (body_offset) *body_offset = hdr;
+  return int64_t(o.size());
+}
+
+int64_t irs_synth_encode_term_pos(const uint32_t* docs, const uint32_t* freqs,
+                                  const uint32_t* positions, uint32_t count,
+                                  uint32_t segment_docs, uint32_t layout,
+                                  const uint8_t* norms, const uint32_t* wand_kinds,
+                                  uint32_t wand_count, uint8_t* out, uint64_t out_cap,
+                                  uint8_t* pos_out, uint64_t pos_cap, uint64_t* pos_len,
+                                  irs_synth_term_meta* meta) {
+  if (!meta || !freqs || !positions || !pos_len || (count && !docs) || wand_count > 8 ||
+      (wand_count && !wand_kinds))
+    return -1;
+  bool uses_norms = false;
+  for (uint32_t w = 0; w < wand_count; ++w) {
+    if (wand_kinds[w] > IRS_SYNTH_WAND_DIV_NORM) return -1;
+    uses_norms |= wand_kinds[w] != IRS_SYNTH_WAND_MAX_FREQ;
+  }
+  if (uses_norms && !norms) return -1;
+  uint64_t at = 0;
+  for (uint32_t i = 0; i < count; ++i) {
+    if (docs[i] < kDocMin || docs[i] > segment_docs || (i && docs[i] <= docs[i - 1]) ||
+        freqs[i] == 0)
+      return -1;
+    if (uses_norms && norms[docs[i] - 1] < freqs[i]) return -1;
+    for (uint32_t k = 0; k < freqs[i]; ++k, ++at) {  // pos_limits::valid, ascending (:1012)
+      if (positions[at] == 0 || positions[at] == UINT32_MAX ||
+          (k && positions[at] <= positions[at - 1]))
+        return -1;
+    }
+  }
+  const WandSpec spec{norms, wand_count, wand_kinds};
+  Bytes o, po;
+  encode_term(docs, freqs, count, segment_docs, layout, o, *meta,
+              wand_count ? &spec : nullptr, positions, &po);
+  if (o.size() > out_cap || po.size() > pos_cap) return -2;
+  if (!o.empty()) std::memcpy(out, o.data(), o.size());
+  if (!po.empty()) std::memcpy(pos_out, po.data(), po.size());
+  *pos_len = po.size();
+  return int64_t(o.size());
+}
+
 int irs_synth_build(const irs_synth_params* p, irs_synth_index** out) {
   if (!p || !out || p->num_docs == 0 || p->max_rank == 0 ||
       p->vocab_log2 == 0 || p->vocab_log2 > 24 ||
@@ -508,9 +607,10 @@ int irs_synth_build(const irs_synth_params* p, irs_synth_index** out) {
         auto& mine = tp[t];
         mine.docs.resize(R);
         mine.tfs.resize(R);
+        if (p->with_positions) mine.poss.resize(R);
         const uint32_t lo = uint32_t(uint64_t(N) * t / T);
         const uint32_t hi = uint32_t(uint64_t(N) * (t + 1) / T);
-        uint32_t ranks[256];
+        uint32_t ranks[256];  // (rank << 8) | 1-based token position
         uint64_t local_ttf = 0;
         for (uint32_t d = lo; d < hi; ++d) {
           const uint64_t g = p->first_doc + d;
@@ -521,14 +621,17 @@ int irs_synth_build(const irs_synth_params* p, irs_synth_index** out) {
           uint32_t m = 0;
           for (uint32_t i = 0; i < len; ++i) {
             const uint32_t r = zipf.sample(token_hash(p->seed, g, i));
-            if (r) ranks[m++] = r;
+            if (r) ranks[m++] = (r << 8) | (i + 1);
           }
           std::sort(ranks, ranks + m);
           for (uint32_t i = 0; i < m;) {
             uint32_t j = i + 1;
-            while (j < m && ranks[j] == ranks[i]) ++j;
-            mine.docs[ranks[i] - 1].push_back(d + kDocMin);
-            mine.tfs[ranks[i] - 1].push_back(uint8_t(j - i));
+            const uint32_t r = ranks[i] >> 8;
+            while (j < m && (ranks[j] >> 8) == r) ++j;
+            mine.docs[r - 1].push_back(d + kDocMin);
+            mine.tfs[r - 1].push_back(uint8_t(j - i));
+            if (p->with_positions)
+              for (uint32_t k = i; k < j; ++k) mine.poss[r - 1].push_back(uint8_t(ranks[k]));
             i = j;
           }
         }
@@ -547,17 +650,19 @@ int irs_synth_build(const irs_synth_params* p, irs_synth_index** out) {
 
   // ---- pass 2: encode terms in parallel (rank order = LPT order) ---------
   std::vector<Bytes> term_bytes(R);
+  std::vector<Bytes> term_pos(p->with_positions ? R : 0);
   idx->metas.resize(R);
   if (p->keep_postings) {
     idx->docs.resize(R);
     idx->freqs.resize(R);
+    if (p->with_positions) idx->positions.resize(R);
   }
   {
     std::atomic<uint32_t> next{0};
     std::vector<std::thread> pool;
     for (uint32_t t = 0; t < T; ++t) {
       pool.emplace_back([&] {
-        std::vector<uint32_t> d, f;
+        std::vector<uint32_t> d, f, ps;
         for (;;) {
           const uint32_t r = next.fetch_add(1);
           if (r >= R) break;
@@ -575,11 +680,22 @@ int irs_synth_build(const irs_synth_params* p, irs_synth_index** out) {
             std::vector<uint32_t>().swap(dv);
             std::vector<uint8_t>().swap(fv);
           }
+          if (p->with_positions) {
+            ps.clear();
+            for (uint32_t k = 0; k < T; ++k) {
+              auto& pv = tp[k].poss[r];
+              ps.insert(ps.end(), pv.begin(), pv.end());
+              std::vector<uint8_t>().swap(pv);
+            }
+          }
           encode_term(d.data(), f.data(), uint32_t(total), N, p->layout,
-                      term_bytes[r], idx->metas[r], wand.count ? &wand : nullptr);
+                      term_bytes[r], idx->metas[r], wand.count ? &wand : nullptr,
+                      p->with_positions ? ps.data() : nullptr,
+                      p->with_positions ? &term_pos[r] : nullptr);
           if (p->keep_postings) {
             idx->docs[r] = d;
             idx->freqs[r] = f;
+            if (p->with_positions) idx->positions[r] = ps;
           }
         }
       });
@@ -604,6 +720,24 @@ int irs_synth_build(const irs_synth_params* p, irs_synth_index** out) {
   put_be32(file, 0);
   put_be64(file, crc32c(file.data(), file.size()));
 
+  if (p->with_positions) {  // the `.pos` image, same framing (:544-547)
+    Bytes& pf = idx->pos_file;
+    make_header(pf, p->layout, kPosFormatName);
+    uint64_t at = pf.size();
+    for (uint32_t r = 0; r < R; ++r) {
+      idx->metas[r].pos_start += at;
+      at += term_pos[r].size();
+    }
+    pf.reserve(at + 16);
+    for (uint32_t r = 0; r < R; ++r) {
+      pf.insert(pf.end(), term_pos[r].begin(), term_pos[r].end());
+      Bytes().swap(term_pos[r]);
+    }
+    put_be32(pf, uint32_t(-int32_t(0x3fd76c17)));
+    put_be32(pf, 0);
+    put_be64(pf, crc32c(pf.data(), pf.size()));
+  }
+
   *out = idx.release();
   return 0;
 }
@@ -613,6 +747,17 @@ void irs_synth_free(irs_synth_index* idx) { delete idx; }
 const uint8_t* irs_synth_doc_bytes(const irs_synth_index* idx, uint64_t* len) {
   if (len) *len = idx->doc_file.size();
   return idx->doc_file.data();
+}
+const uint8_t* irs_synth_pos_bytes(const irs_synth_index* idx, uint64_t* len) {
+  if (len) *len = idx->pos_file.size();
+  return idx->pos_file.empty() ? nullptr : idx->pos_file.data();
+}
+int irs_synth_positions(const irs_synth_index* idx, uint32_t rank,
+                        const uint32_t** positions, uint64_t* count) {
+  if (rank == 0 || rank > idx->positions.size()) return -1;
+  *positions = idx->positions[rank - 1].data();
+  *count = idx->positions[rank - 1].size();
+  return 0;
 }
 const uint8_t* irs_synth_norms(const irs_synth_index* idx, uint64_t* count) {
   if (count) *count = idx->norms.size();

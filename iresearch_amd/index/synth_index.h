@@ -58,6 +58,9 @@ typedef struct irs_synth_params {
   uint32_t keep_postings; /* keep decoded (doc, tf) lists for verification  */
   uint32_t wand_count;    /* scorers the field is indexed with (0..8): wand data */
   uint32_t wand_kind;     /* IRS_SYNTH_WAND_* of every one of them           */
+  uint32_t with_positions;/* field has IndexFeatures::POS: also emit the `.pos` stream
+                             (position of a token = its 1-based index in the doc)   */
+  uint32_t reserved;
 } irs_synth_params;
 
 typedef struct irs_synth_index irs_synth_index;
@@ -66,6 +69,11 @@ int irs_synth_build(const irs_synth_params* p, irs_synth_index** out);
 void irs_synth_free(irs_synth_index* idx);
 
 const uint8_t* irs_synth_doc_bytes(const irs_synth_index* idx, uint64_t* len);
+/* `.pos` file image (NULL unless with_positions) */
+const uint8_t* irs_synth_pos_bytes(const irs_synth_index* idx, uint64_t* len);
+/* only when keep_postings && with_positions: the rank's positions, doc after doc */
+int irs_synth_positions(const irs_synth_index* idx, uint32_t rank,
+                        const uint32_t** positions, uint64_t* count);
 /* norms[i] = field length of local doc id (i + 1) */
 const uint8_t* irs_synth_norms(const irs_synth_index* idx, uint64_t* count);
 /* metas[r - 1] = term_meta of rank r */
@@ -100,6 +108,22 @@ int64_t irs_synth_encode_term_wand(const uint32_t* docs, const uint32_t* freqs,
                                    const uint32_t* wand_kinds, uint32_t wand_count,
                                    uint8_t* out, uint64_t out_cap,
                                    irs_synth_term_meta* meta);
+
+/* Same for a field with IndexFeatures::POS: `positions` holds Σ freqs entries (per doc
+ * ascending, >= 1).  The term's `.pos` bytes (AddPosition formats_10.cpp:894-933, tail
+ * :713-760; zero-based storage of formats 1_3+) go to `pos_out`; meta->pos_start is
+ * relative to it, meta->pos_end as EndTerm sets it; skip entries carry pend_pos +
+ * Δpos_ptr (:511-518). */
+int64_t irs_synth_encode_term_pos(const uint32_t* docs, const uint32_t* freqs,
+                                  const uint32_t* positions, uint32_t count,
+                                  uint32_t segment_docs, uint32_t layout,
+                                  const uint8_t* norms, const uint32_t* wand_kinds,
+                                  uint32_t wand_count, uint8_t* out, uint64_t out_cap,
+                                  uint8_t* pos_out, uint64_t pos_cap, uint64_t* pos_len,
+                                  irs_synth_term_meta* meta);
+int64_t irs_synth_wrap_pos_file(const uint8_t* body, uint64_t body_len,
+                                uint32_t layout, uint8_t* out,
+                                uint64_t out_cap, uint64_t* body_offset);
 
 /* Wrap concatenated term bytes into a complete `.doc` file image:
  * header (format_utils.cpp:57-61) + body + footer (:63-67). Returns total

@@ -30,6 +30,7 @@ class _Params(C.Structure):
         ("vocab_log2", C.c_uint32), ("max_rank", C.c_uint32), ("layout", C.c_uint32),
         ("mean_len", C.c_uint32), ("stddev_len", C.c_uint32), ("threads", C.c_uint32),
         ("keep_postings", C.c_uint32), ("wand_count", C.c_uint32), ("wand_kind", C.c_uint32),
+        ("with_positions", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
 
@@ -44,7 +45,7 @@ def lib():
         L.irs_synth_build.restype = C.c_int
         L.irs_synth_free.argtypes = [C.c_void_p]
         L.irs_synth_free.restype = None
-        for name in ("irs_synth_doc_bytes", "irs_synth_norms"):
+        for name in ("irs_synth_doc_bytes", "irs_synth_norms", "irs_synth_pos_bytes"):
             f = getattr(L, name)
             f.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
             f.restype = C.c_void_p
@@ -57,6 +58,17 @@ def lib():
         L.irs_synth_postings.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p),
                                          C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]
         L.irs_synth_postings.restype = C.c_int
+        L.irs_synth_positions.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p),
+                                          C.POINTER(C.c_uint64)]
+        L.irs_synth_positions.restype = C.c_int
+        L.irs_synth_encode_term_pos.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                                C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                                C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p,
+                                                C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]
+        L.irs_synth_encode_term_pos.restype = C.c_int64
+        L.irs_synth_wrap_pos_file.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
+                                              C.c_uint64, C.POINTER(C.c_uint64)]
+        L.irs_synth_wrap_pos_file.restype = C.c_int64
         L.irs_synth_encode_term.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                             C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]
         L.irs_synth_encode_term.restype = C.c_int64
@@ -93,6 +105,8 @@ class SynthSegment:
     num_docs: int
     postings: dict | None = None  # rank -> (docs u32[], freqs u32[]) when kept
     wand_count: int = 0           # scorers the field was indexed with (wand data in `.doc`)
+    pos_file: np.ndarray | None = None   # uint8, the whole `.pos` image (field with POS)
+    positions: dict | None = None        # rank -> u32[Σ freqs] positions, doc after doc, when kept
 
     def meta(self, rank: int) -> np.void:
         return self.metas[rank - 1]
@@ -102,10 +116,11 @@ def build_segment(num_docs: int, max_rank: int = 4096, *, layout: int = LAYOUT_S
                   seed: int = SEED, first_doc: int = 0, vocab_log2: int = 20,
                   mean_len: int = 100, stddev_len: int = 30, threads: int = 0,
                   keep_postings: bool = False, wand_count: int = 0,
-                  wand_kind: int = WAND_MIN_NORM) -> SynthSegment:
+                  wand_kind: int = WAND_MIN_NORM, with_positions: bool = False) -> SynthSegment:
     L = lib()
     p = _Params(seed, first_doc, num_docs, vocab_log2, max_rank, layout, mean_len,
-                stddev_len, threads, int(keep_postings), wand_count, wand_kind)
+                stddev_len, threads, int(keep_postings), wand_count, wand_kind,
+                int(with_positions), 0)
     h = C.c_void_p()
     rc = L.irs_synth_build(C.byref(p), C.byref(h))
     if rc != 0:
@@ -119,6 +134,17 @@ def build_segment(num_docs: int, max_rank: int = 4096, *, layout: int = LAYOUT_S
         m = C.c_uint32()
         ptr = L.irs_synth_term_metas(h, C.byref(m))
         metas = _view(ptr, m.value * TERM_META.itemsize, TERM_META).copy()
+        pos_file = positions = None
+        if with_positions:
+            ptr = L.irs_synth_pos_bytes(h, C.byref(n))
+            pos_file = _view(ptr, n.value, np.uint8).copy()
+            if keep_postings:
+                positions = {}
+                for r in range(1, max_rank + 1):
+                    pp, c = C.c_void_p(), C.c_uint64()
+                    L.irs_synth_positions(h, r, C.byref(pp), C.byref(c))
+                    positions[r] = (_view(pp.value, 4 * c.value, np.uint32).copy() if c.value
+                                    else np.zeros(0, np.uint32))
         postings = None
         if keep_postings:
             postings = {}
@@ -132,9 +158,36 @@ def build_segment(num_docs: int, max_rank: int = 4096, *, layout: int = LAYOUT_S
                     postings[r] = (np.zeros(0, np.uint32), np.zeros(0, np.uint32))
         return SynthSegment(doc_file, norms, metas, L.irs_synth_docs_with_field(h),
                             L.irs_synth_total_term_freq(h), layout, num_docs, postings,
-                            wand_count)
+                            wand_count, pos_file, positions)
     finally:
         L.irs_synth_free(h)
+
+
+def encode_term_pos(docs, freqs, positions, segment_docs: int, layout: int = LAYOUT_SIMD4,
+                    norms=None, wand_kinds=()):
+    """postings_writer::write for one list of a field with POS -> (doc bytes, pos bytes, meta);
+    positions = Σ freqs values, doc after doc (ascending and >= 1 within a doc)."""
+    docs = np.ascontiguousarray(docs, dtype=np.uint32)
+    freqs = np.ascontiguousarray(freqs, dtype=np.uint32)
+    positions = np.ascontiguousarray(positions, dtype=np.uint32)
+    assert docs.shape == freqs.shape and positions.size == int(freqs.sum())
+    kinds = np.ascontiguousarray(wand_kinds, dtype=np.uint32)
+    cap = 64 + 12 * len(docs) + 1024 + (16 * len(kinds) + 16) * (len(docs) // 128 + 4)
+    out = np.zeros(cap, np.uint8)
+    pcap = 64 + 5 * positions.size
+    pout = np.zeros(pcap, np.uint8)
+    plen = C.c_uint64()
+    meta = np.zeros(1, TERM_META)
+    nrm = None if norms is None else np.ascontiguousarray(norms, np.uint8)
+    n = lib().irs_synth_encode_term_pos(docs.ctypes.data, freqs.ctypes.data,
+                                        positions.ctypes.data, len(docs), segment_docs, layout,
+                                        None if nrm is None else nrm.ctypes.data,
+                                        kinds.ctypes.data if kinds.size else None, kinds.size,
+                                        out.ctypes.data, cap, pout.ctypes.data, pcap,
+                                        C.byref(plen), meta.ctypes.data)
+    if n < 0:
+        raise ValueError("irs_synth_encode_term_pos failed: %d" % n)
+    return out[:n].copy(), pout[:plen.value].copy(), meta[0]
 
 
 def encode_term(docs, freqs, segment_docs: int, layout: int = LAYOUT_SIMD4, norms=None,
@@ -170,17 +223,37 @@ def segment_from_lists(lists, num_docs: int, layout: int = LAYOUT_SIMD4, norms=N
             any(k != WAND_MAX_FREQ for k in wand_kinds):
         raise ValueError("MIN_NORM / DIV_NORM wand data needs the norm column")
     body = []
+    pbody = []
     metas = np.zeros(len(lists), TERM_META)
-    off = 0
-    for i, (d, f) in enumerate(lists):
-        b, m = encode_term(d, f, num_docs, layout,
-                           norms if len(wand_kinds) and norms is not None and norms is not False
-                           else None, wand_kinds)
-        metas[i] = m
+    off = poff = 0
+    with_pos = bool(lists) and len(lists[0]) == 3   # [(docs, freqs, positions), ...]: field with POS
+    for i, entry in enumerate(lists):
+        wn = norms if len(wand_kinds) and norms is not None and norms is not False else None
+        if with_pos:
+            b, pb, m = encode_term_pos(entry[0], entry[1], entry[2], num_docs, layout, wn,
+                                       wand_kinds)
+            metas[i] = m
+            metas[i]["pos_start"] = poff
+            poff += len(pb)
+            pbody.append(pb)
+        else:
+            b, m = encode_term(entry[0], entry[1], num_docs, layout, wn, wand_kinds)
+            metas[i] = m
         metas[i]["doc_start"] = off
         off += len(b)
         body.append(b)
     body = np.concatenate(body) if body else np.zeros(0, np.uint8)
+    pos_file = None
+    if with_pos:
+        pbody = np.concatenate(pbody) if pbody else np.zeros(0, np.uint8)
+        pout = np.zeros(len(pbody) + 128, np.uint8)
+        phdr = C.c_uint64()
+        pn = lib().irs_synth_wrap_pos_file(pbody.ctypes.data, len(pbody), layout,
+                                           pout.ctypes.data, len(pout), C.byref(phdr))
+        if pn < 0:
+            raise ValueError("irs_synth_wrap_pos_file failed")
+        metas["pos_start"] += phdr.value
+        pos_file = pout[:pn].copy()
     out = np.zeros(len(body) + 128, np.uint8)
     hdr = C.c_uint64()
     n = lib().irs_synth_wrap_doc_file(body.ctypes.data, len(body), layout, out.ctypes.data,
@@ -190,12 +263,12 @@ def segment_from_lists(lists, num_docs: int, layout: int = LAYOUT_SIMD4, norms=N
     metas["doc_start"] += hdr.value
     if norms is False:  # no Norm2 column at all
         return SynthSegment(out[:n].copy(), None, metas, num_docs, num_docs, layout, num_docs,
-                            None, len(wand_kinds))
+                            None, len(wand_kinds), pos_file)
     if norms is None:
         norms = np.ones(num_docs, np.uint8)
     ttf = int(np.asarray(norms, dtype=np.uint64).sum())
     return SynthSegment(out[:n].copy(), np.ascontiguousarray(norms, np.uint8), metas,
-                        num_docs, ttf, layout, num_docs, None, len(wand_kinds))
+                        num_docs, ttf, layout, num_docs, None, len(wand_kinds), pos_file)
 
 
 def make_queries(n_queries: int, n_terms: int, lo_rank: int = 16, hi_rank: int = 4096,

@@ -29,7 +29,7 @@ HIT = np.dtype([("score", "<f4"), ("doc", "<u4"), ("segment", "<u4")])
 class Segment(C.Structure):
     _fields_ = [("doc_file", C.c_void_p), ("doc_file_len", C.c_uint64), ("layout", C.c_int32),
                 ("num_docs", C.c_uint32), ("norms", C.c_void_p), ("norm_width", C.c_uint32),
-                ("wand_count", C.c_uint32)]
+                ("wand_count", C.c_uint32), ("pos_file", C.c_void_p), ("pos_file_len", C.c_uint64)]
 
 
 class Scorer(C.Structure):
@@ -95,6 +95,19 @@ def lib():
         L.orc_score_all.argtypes = [C.POINTER(Segment), vp, u32, i32, C.POINTER(Scorer), vp, u64,
                                     vp, u64, vp, vp]
         L.orc_score_all.restype = C.c_int64
+        L.orc_read_skip0_pos.argtypes = [vp, u64, u32, C.c_int, vp, vp, vp, u64, C.POINTER(u32),
+                                         vp, vp, vp, vp]
+        L.orc_read_skip0_pos.restype = C.c_int64
+        L.orc_decode_positions.argtypes = [vp, u64, vp, u64, C.c_int, u32, vp, u32, vp, u64]
+        L.orc_decode_positions.restype = C.c_int64
+        L.orc_check_pos_header.argtypes = [vp, u64, C.POINTER(i32)]
+        L.orc_check_pos_header.restype = C.c_int64
+        L.orc_search_phrase.argtypes = [vp, u32, vp, u32, vp, C.POINTER(Scorer), C.c_float, vp, vp,
+                                        u32, vp, C.POINTER(u64)]
+        L.orc_search_phrase.restype = C.c_int64
+        L.orc_score_all_phrase.argtypes = [C.POINTER(Segment), vp, u32, vp, C.POINTER(Scorer),
+                                           C.c_float, u64, vp, u64, vp, vp]
+        L.orc_score_all_phrase.restype = C.c_int64
         _lib = L
     return _lib
 
@@ -153,6 +166,42 @@ def decode_term(doc_file: np.ndarray, meta, layout: int, want_freq: bool = True,
     return docs, freqs
 
 
+def decode_positions(doc_file: np.ndarray, pos_file: np.ndarray, meta, layout: int,
+                     wand_count: int = 0, stride: int = 1) -> np.ndarray:
+    """All positions of one term, doc after doc (Σ freq values); stride > 1 drains every
+    stride-th doc only (the rest goes through position::skip and reads as 0)."""
+    m = np.zeros(1, TERM_META)
+    for k in TERM_META.names:
+        m[0][k] = meta[k]
+    n = int(m[0]["freq"])
+    out = np.zeros(n, np.uint32)
+    got = lib().orc_decode_positions(doc_file.ctypes.data, doc_file.size, pos_file.ctypes.data,
+                                     pos_file.size, layout, wand_count, m.ctypes.data, stride,
+                                     out.ctypes.data, n)
+    if got != n:
+        raise ValueError("orc_decode_positions: %d != %d" % (got, n))
+    return out
+
+
+def read_skip0_pos(doc_file: np.ndarray, meta, wand_count: int = 0):
+    """Level-0 skip entries of a field with POS: (last docs, doc ptrs, pend_pos, pos ptrs)."""
+    m = np.zeros(1, TERM_META)
+    for k in TERM_META.names:
+        m[0][k] = meta[k]
+    cap = int(m[0]["docs_count"]) // 128 + 1
+    last = np.zeros(cap, np.uint32)
+    ptrs = np.zeros(cap, np.uint64)
+    pend = np.zeros(cap, np.uint32)
+    pptr = np.zeros(cap, np.uint64)
+    lv = C.c_uint32()
+    n = lib().orc_read_skip0_pos(doc_file.ctypes.data, doc_file.size, wand_count, 1,
+                                 m.ctypes.data, last.ctypes.data, ptrs.ctypes.data, cap,
+                                 C.byref(lv), None, None, pend.ctypes.data, pptr.ctypes.data)
+    if n < 0:
+        raise ValueError("orc_read_skip0_pos failed: %d" % n)
+    return last[:n], ptrs[:n], pend[:n], pptr[:n]
+
+
 def bit_union(doc_file: np.ndarray, metas, layout: int, has_freq: bool, n_words: int,
               initial: np.ndarray | None = None, wand_count: int = 0):
     m = np.zeros(len(metas), TERM_META)
@@ -200,17 +249,20 @@ class SegmentView:
     """Keeps the numpy buffers of one segment alive next to the C struct."""
 
     def __init__(self, doc_file, norms, layout, num_docs, docs_with_field, total_term_freq,
-                 norm_width=1, wand_count=0):
+                 norm_width=1, wand_count=0, pos_file=None):
         self.doc_file = np.ascontiguousarray(doc_file, np.uint8)
         self.norms = None if norms is None else np.ascontiguousarray(norms, np.uint8)
         self.layout, self.num_docs, self.norm_width = layout, num_docs, norm_width
         self.docs_with_field, self.total_term_freq = docs_with_field, total_term_freq
         self.wand_count = wand_count
+        self.pos_file = None if pos_file is None else np.ascontiguousarray(pos_file, np.uint8)
 
     def struct(self) -> Segment:
         return Segment(self.doc_file.ctypes.data, self.doc_file.size, self.layout, self.num_docs,
                        None if self.norms is None else self.norms.ctypes.data, self.norm_width,
-                       self.wand_count)
+                       self.wand_count,
+                       None if self.pos_file is None else self.pos_file.ctypes.data,
+                       0 if self.pos_file is None else self.pos_file.size)
 
 
 def _metas_array(metas) -> np.ndarray:
@@ -273,3 +325,41 @@ def score_all(segment: SegmentView, metas, op: int, scorer: Scorer, docs_with_fi
     if n < 0:
         raise ValueError("orc_score_all failed")
     return scores, matched
+
+
+
+def search_phrase(segments, metas, offsets, scorer: Scorer, k: int, boost: float = 1.0):
+    """by_phrase with fixed offsets; metas: TERM_META [nsegs][n_terms]. -> (hits HIT[], total)."""
+    metas = _metas_array(metas)
+    nsegs, n_terms = metas.shape
+    segs = (Segment * nsegs)(*[s.struct() for s in segments])
+    dwf = np.array([s.docs_with_field for s in segments], np.uint64)
+    ttf = np.array([s.total_term_freq for s in segments], np.uint64)
+    offs = np.ascontiguousarray(offsets, np.uint32)
+    assert offs.size == n_terms
+    out = np.zeros(max(k, 1), HIT)
+    total = C.c_uint64()
+    n = lib().orc_search_phrase(segs, nsegs, metas.ctypes.data, n_terms, offs.ctypes.data,
+                                C.byref(scorer), boost, dwf.ctypes.data, ttf.ctypes.data, k,
+                                out.ctypes.data, C.byref(total))
+    if n < 0:
+        raise ValueError("orc_search_phrase failed")
+    return out[:n], total.value
+
+
+def score_all_phrase(segment: SegmentView, metas, offsets, scorer: Scorer, docs_with_field: int,
+                     docs_with_term, total_term_freq: int, boost: float = 1.0):
+    """-> (scores f32[num_docs + 1], phrase_freq u32[num_docs + 1])."""
+    metas = _metas_array(metas)
+    n_terms = metas.shape[0]
+    seg = segment.struct()
+    scores = np.zeros(segment.num_docs + 1, np.float32)
+    pf = np.zeros(segment.num_docs + 1, np.uint32)
+    dwt = np.ascontiguousarray(docs_with_term, np.uint64)
+    offs = np.ascontiguousarray(offsets, np.uint32)
+    n = lib().orc_score_all_phrase(C.byref(seg), metas.ctypes.data, n_terms, offs.ctypes.data,
+                                   C.byref(scorer), boost, docs_with_field, dwt.ctypes.data,
+                                   total_term_freq, scores.ctypes.data, pf.ctypes.data)
+    if n < 0:
+        raise ValueError("orc_score_all_phrase failed")
+    return scores, pf

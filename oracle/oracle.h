@@ -83,6 +83,21 @@ int64_t orc_read_skip0_wand(const uint8_t* doc_file, uint64_t len, uint32_t wand
                             uint64_t* next_block_ptrs, uint64_t cap,
                             uint32_t* num_levels, uint32_t* max_freq,
                             uint32_t* norm_of_max);
+int64_t orc_read_skip0_pos(const uint8_t* doc_file, uint64_t len, uint32_t wand_count,
+                           int field_has_pos, const orc_term_meta* meta, uint32_t* last_docs,
+                           uint64_t* next_block_ptrs, uint64_t cap, uint32_t* num_levels,
+                           uint32_t* max_freq, uint32_t* norm_of_max, uint32_t* pend_pos,
+                           uint64_t* pos_ptrs);
+/* ---- positions (field with IndexFeatures::POS) ------------------
+ * All positions of one term, doc after doc, by driving the restated doc iterator and
+ * its position attribute (formats_10.cpp:1457-1682).  stride > 1 drains only every
+ * stride-th doc (others are skipped through position::skip and reported as 0).
+ * Returns Σ freq, <0 on corruption. */
+int64_t orc_decode_positions(const uint8_t* doc_file, uint64_t len, const uint8_t* pos_file,
+                             uint64_t pos_len, int layout, uint32_t wand_count,
+                             const orc_term_meta* meta, uint32_t stride, uint32_t* out,
+                             uint64_t cap);
+int64_t orc_check_pos_header(const uint8_t* pos_file, uint64_t len, int32_t* version);
 /* postings_reader::bit_union (formats_10.cpp:3716-3806): ORs bit `doc` into `set`
  * for every posting of every term; returns the sum of docs_count. */
 int64_t orc_bit_union(const uint8_t* doc_file, uint64_t len, int layout,
@@ -116,7 +131,8 @@ enum {
   ORC_SCORER_BM25 = 0, /* k, b as given; picks BM1/BM15/BM25 like bm25.cpp:447-455 */
   ORC_SCORER_TFIDF = 1 /* with_norms selects tfidf.cpp:307 */
 };
-enum { ORC_OP_OR = 0, ORC_OP_AND = 1, ORC_OP_MINMATCH = 2 /* + (min_match << 8) */ };
+enum { ORC_OP_OR = 0, ORC_OP_AND = 1, ORC_OP_MINMATCH = 2 /* + (min_match << 8) */,
+       ORC_OP_PHRASE = 3 /* orc_search_phrase / orc_score_all_phrase only */ };
 
 typedef struct orc_segment {
   const uint8_t* doc_file;
@@ -126,6 +142,8 @@ typedef struct orc_segment {
   const uint8_t* norms; /* dense Norm2 column, big-endian, doc 1 first; NULL = none */
   uint32_t norm_width;  /* 1, 2 or 4 bytes */
   uint32_t wand_count;  /* scorers the field was indexed with (wand data to skip) */
+  const uint8_t* pos_file; /* `.pos` image of a field with POS, or NULL */
+  uint64_t pos_file_len;
 } orc_segment;
 
 typedef struct orc_scorer {
@@ -174,6 +192,25 @@ int64_t orc_score_all(const orc_segment* seg, const orc_term_meta* metas,
                       const uint64_t* docs_with_term /*per term, global*/,
                       uint64_t total_term_freq, float* scores,
                       uint8_t* matched);
+
+/* by_phrase with fixed offsets (FixedPhraseQuery, phrase_query.cpp:44-111;
+ * PhraseIterator + FixedPhraseFrequency, phrase_iterator.hpp:75-166, 540-626):
+ * conjunction of the terms' iterators, phrase frequency from their positions
+ * (offsets[t] = position of term t relative to the first; offsets[0] == 0), score =
+ * scorer(tf = phrase frequency) with the statistics of ALL phrase terms accumulated
+ * into one stats blob (FixedPrepareCollect, phrase_filter.cpp:212-293: idf sums).
+ * Same harness loop and outputs as orc_search. */
+int64_t orc_search_phrase(const orc_segment* segs, uint32_t nsegs,
+                          const orc_term_meta* metas, uint32_t n_terms,
+                          const uint32_t* offsets, const orc_scorer* scorer, float boost,
+                          const uint64_t* docs_with_field, const uint64_t* total_term_freq,
+                          uint32_t k, orc_hit* out, uint64_t* hits_total);
+/* Exhaustive form on one segment: phrase_freq[doc] (0 = no match) and scores[doc]. */
+int64_t orc_score_all_phrase(const orc_segment* seg, const orc_term_meta* metas,
+                             uint32_t n_terms, const uint32_t* offsets,
+                             const orc_scorer* scorer, float boost, uint64_t docs_with_field,
+                             const uint64_t* docs_with_term, uint64_t total_term_freq,
+                             float* scores, uint32_t* phrase_freq);
 
 #ifdef __cplusplus
 }

@@ -45,6 +45,27 @@ int orc_it_next(orc_doc_iterator* it);
  * skip-list acceleration does not change the result and is not restated) */
 uint32_t orc_it_seek(orc_doc_iterator* it, uint32_t target);
 
+/* Restates position<IteratorTraits, FieldTraits> + position_impl<..., false, false>
+ * (formats_10.cpp:1457-1682): a field with POS and neither offsets nor payloads,
+ * zero-based storage (formats 1_3+, one_based_position_storage() == false). */
+typedef struct {
+  orc_in in;
+  const uint8_t* file;
+  int layout;
+  uint32_t pos_deltas[ORC_BLOCK];
+  uint64_t pend_pos;    /* how many positions "behind" we are */
+  uint64_t tail_start;  /* file pointer of the vint-coded last block */
+  uint32_t tail_length;
+  uint32_t buf_pos;     /* ORC_BLOCK = buffer consumed */
+  uint32_t value;       /* 0 = pos_limits::invalid(), UINT32_MAX = eof */
+} orc_pos_iterator;
+
+void orc_pos_prepare(orc_pos_iterator* p, const uint8_t* pos_file, uint64_t len, int layout,
+                     const orc_term_meta* m);
+void orc_pos_notify(orc_pos_iterator* p, uint32_t n); /* + clear(): doc iterator moved on */
+int orc_pos_next(orc_pos_iterator* p, uint32_t freq);
+uint32_t orc_pos_seek(orc_pos_iterator* p, uint32_t freq, uint32_t target);
+
 #ifdef __cplusplus
 }
 #endif

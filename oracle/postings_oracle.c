@@ -458,6 +458,19 @@ int64_t orc_read_skip0_wand(const uint8_t* doc_file, uint64_t len, uint32_t wand
                             uint64_t* next_block_ptrs, uint64_t cap,
                             uint32_t* num_levels, uint32_t* max_freq,
                             uint32_t* norm_of_max) {
+  return orc_read_skip0_pos(doc_file, len, wand_count, 0, meta, last_docs, next_block_ptrs,
+                            cap, num_levels, max_freq, norm_of_max, NULL, NULL);
+}
+
+/* ... and for a field with POS every entry also holds vint(pend_pos) + vlong(Δpos_ptr)
+ * (ReadState :1063-1080): positions pending at the block border and where the `.pos`
+ * stream stands there. */
+int64_t orc_read_skip0_pos(const uint8_t* doc_file, uint64_t len, uint32_t wand_count,
+                           int field_has_pos, const orc_term_meta* meta, uint32_t* last_docs,
+                           uint64_t* next_block_ptrs, uint64_t cap, uint32_t* num_levels,
+                           uint32_t* max_freq, uint32_t* norm_of_max, uint32_t* pend_pos,
+                           uint64_t* pos_ptrs) {
+  uint64_t pos_ptr = meta->pos_start; /* CopyState(SkipState&, term_meta) :1097 */
   orc_in in;
   uint32_t levels, l;
   uint64_t n = 0, ptr;
@@ -487,6 +500,12 @@ int64_t orc_read_skip0_wand(const uint8_t* doc_file, uint64_t len, uint32_t wand
       if (n >= cap) return -2;
       last_docs[n] = doc;
       next_block_ptrs[n] = ptr;
+      if (field_has_pos) {
+        const uint32_t pend = in_vint(&in);
+        pos_ptr += in_vlong(&in);
+        if (pend_pos) pend_pos[n] = pend;
+        if (pos_ptrs) pos_ptrs[n] = pos_ptr;
+      }
       if (wand_count) {
         uint32_t sizes[16], w, total = 0;
         if (wand_count > 16) return -1;
@@ -533,4 +552,153 @@ uint32_t orc_it_seek(orc_doc_iterator* it, uint32_t target) {
     if (!orc_it_next(it)) break;
   }
   return it->doc;
+}
+
+
+/* -------------------------------------------------------------- positions */
+
+/* position_impl::prepare(const DocState&) :1472-1491 with the tail location
+ * doc_iterator::prepare computes (:2270-2285; single_doc_iterator :1896-1913) */
+void orc_pos_prepare(orc_pos_iterator* p, const uint8_t* pos_file, uint64_t len, int layout,
+                     const orc_term_meta* m) {
+  memset(p, 0, sizeof *p);
+  p->file = pos_file;
+  p->layout = layout;
+  p->in.end = pos_file + len;
+  p->buf_pos = ORC_BLOCK;
+  if (m->pos_start > len) {
+    p->in.bad = 1;
+    p->in.p = p->in.end;
+  } else {
+    p->in.p = pos_file + m->pos_start; /* pos_in_->seek(pos_start) :1488 */
+  }
+  if (m->freq < ORC_BLOCK)
+    p->tail_start = m->pos_start;
+  else if (m->freq == ORC_BLOCK)
+    p->tail_start = UINT64_MAX; /* address_limits::invalid() */
+  else
+    p->tail_start = m->pos_start + m->pos_end;
+  p->tail_length = m->freq % ORC_BLOCK;
+}
+
+/* position::refill :1653-1659, read_tail_block :1515-1537 (no payloads/offsets) */
+static void pos_refill(orc_pos_iterator* p) {
+  if ((uint64_t)(p->in.p - p->file) == p->tail_start) {
+    uint32_t i;
+    for (i = 0; i < p->tail_length; ++i) p->pos_deltas[i] = in_vint(&p->in);
+  } else {
+    in_block(&p->in, p->layout, p->pos_deltas);
+  }
+}
+
+/* position::skip :1661-1680 */
+static void pos_skip(orc_pos_iterator* p, uint32_t count) {
+  uint32_t left = ORC_BLOCK - p->buf_pos;
+  if (count >= left) {
+    count -= left;
+    while (count >= ORC_BLOCK) {
+      in_skip_block(&p->in);
+      count -= ORC_BLOCK;
+    }
+    pos_refill(p);
+    p->buf_pos = 0;
+    left = ORC_BLOCK;
+  }
+  if (count < left) p->buf_pos += count;
+  p->value = 0; /* clear() */
+}
+
+/* position::notify + clear, as doc_iterator::next calls them (:2108-2112) */
+void orc_pos_notify(orc_pos_iterator* p, uint32_t n) {
+  p->pend_pos += n;
+  p->value = 0;
+}
+
+/* position::next :1606-1633 */
+int orc_pos_next(orc_pos_iterator* p, uint32_t freq) {
+  if (p->pend_pos == 0) {
+    p->value = UINT32_MAX;
+    return 0;
+  }
+  if (p->pend_pos > freq) {
+    pos_skip(p, (uint32_t)(p->pend_pos - freq));
+    p->pend_pos = freq;
+  }
+  if (p->buf_pos == ORC_BLOCK) {
+    pos_refill(p);
+    p->buf_pos = 0;
+  }
+  p->value += p->pos_deltas[p->buf_pos];
+  ++p->buf_pos;
+  --p->pend_pos;
+  return !p->in.bad;
+}
+
+/* position::seek :1578-1604 */
+uint32_t orc_pos_seek(orc_pos_iterator* p, uint32_t freq, uint32_t target) {
+  if (p->pend_pos > freq) {
+    pos_skip(p, (uint32_t)(p->pend_pos - freq));
+    p->pend_pos = freq;
+  }
+  while (p->value < target && p->pend_pos) {
+    if (p->buf_pos == ORC_BLOCK) {
+      pos_refill(p);
+      p->buf_pos = 0;
+    }
+    p->value += p->pos_deltas[p->buf_pos];
+    ++p->buf_pos;
+    --p->pend_pos;
+  }
+  if (p->pend_pos == 0 && p->value < target) p->value = UINT32_MAX;
+  return p->value;
+}
+
+/* Every position of every doc of one term: the doc iterator is advanced doc by doc and
+ * the position attribute drained (`stride` = 1), or only every stride-th doc is drained
+ * so that the skip() path (:1661-1680) runs too; positions of skipped docs are written as 0. */
+int64_t orc_decode_positions(const uint8_t* doc_file, uint64_t len, const uint8_t* pos_file,
+                             uint64_t pos_len, int layout, uint32_t wand_count,
+                             const orc_term_meta* meta, uint32_t stride, uint32_t* out,
+                             uint64_t cap) {
+  orc_doc_iterator it;
+  orc_pos_iterator pos;
+  uint64_t n = 0, d = 0;
+  if (meta->docs_count == 0) return 0;
+  if (!stride) stride = 1;
+  orc_it_prepare_wand(&it, doc_file, len, layout, meta, 1, wand_count);
+  orc_pos_prepare(&pos, pos_file, pos_len, layout, meta);
+  while (orc_it_next(&it)) {
+    uint32_t k;
+    orc_pos_notify(&pos, it.freq);
+    if (n + it.freq > cap) return -2;
+    if (d++ % stride == 0) {
+      for (k = 0; k < it.freq; ++k) {
+        if (!orc_pos_next(&pos, it.freq)) return -1;
+        out[n + k] = pos.value;
+      }
+      if (orc_pos_next(&pos, it.freq) || pos.value != UINT32_MAX) return -4; /* eof after freq */
+    } else {
+      for (k = 0; k < it.freq; ++k) out[n + k] = 0;
+    }
+    n += it.freq;
+  }
+  return (it.in.bad || pos.in.bad) ? -1 : (int64_t)n;
+}
+
+/* check_header for `.pos` (prepare_input, formats_10.cpp:3369-3381) */
+int64_t orc_check_pos_header(const uint8_t* f, uint64_t len, int32_t* version) {
+  static const char name[] = "iresearch_10_postings_positions";
+  const uint32_t nlen = (uint32_t)sizeof(name) - 1;
+  orc_in in = {f, f + len, 0};
+  uint32_t magic = 0, ver = 0, i, slen;
+  for (i = 0; i < 4; ++i) magic = (magic << 8) | in_byte(&in);
+  if (magic != 0x3fd76c17u) return -1;
+  slen = in_vint(&in);
+  if (slen != nlen || (uint64_t)(in.end - in.p) < nlen || memcmp(in.p, name, nlen) != 0)
+    return -1;
+  in.p += nlen;
+  for (i = 0; i < 4; ++i) ver = (ver << 8) | in_byte(&in);
+  if (in.bad) return -1;
+  if (version) *version = (int32_t)ver;
+  return (int64_t)(in.p - f);
 }

@@ -336,6 +336,93 @@ void execute_segment(const orc_segment& seg, const orc_term_meta* metas,
   }
 }
 
+// ---------------------------------------------------------------------------
+// by_phrase (fixed offsets)
+
+struct PSub {  // doc iterator + its position attribute + desired offset in the phrase
+  orc_doc_iterator it;
+  orc_pos_iterator pos;
+  uint32_t offset;
+  uint32_t cost;
+};
+inline bool pnext(PSub& s) {  // doc_iterator::next with IteratorTraits::position() :2106-2113
+  if (!orc_it_next(&s.it)) return false;
+  orc_pos_notify(&s.pos, s.it.freq);
+  return true;
+}
+inline uint32_t pseek(PSub& s, uint32_t target) {
+  while (s.it.doc < target) {
+    if (!pnext(s)) break;
+  }
+  return s.it.doc;
+}
+
+// FixedPhraseFrequency<false, true>::NextPosition — phrase_iterator.hpp:109-151
+uint32_t phrase_frequency(std::vector<PSub*>& pos) {
+  uint32_t phrase_freq = 0;
+  PSub& lead = *pos.front();
+  orc_pos_next(&lead.pos, lead.it.freq);
+  while (lead.pos.value != UINT32_MAX) {
+    const uint32_t base_position = lead.pos.value;
+    bool match = true;
+    for (size_t i = 1; i < pos.size(); ++i) {
+      PSub& p = *pos[i];
+      const uint32_t term_position = base_position + p.offset;
+      if (term_position == 0) return phrase_freq;  // !pos_limits::valid
+      const uint32_t sought = orc_pos_seek(&p.pos, p.it.freq, term_position);
+      if (sought == UINT32_MAX) return phrase_freq;  // exhausted
+      if (sought != term_position) {  // sought too far from the lead
+        match = false;
+        orc_pos_seek(&lead.pos, lead.it.freq, sought - p.offset);
+        break;
+      }
+    }
+    if (match) {
+      ++phrase_freq;
+      orc_pos_next(&lead.pos, lead.it.freq);
+    }
+  }
+  return phrase_freq;
+}
+
+// FixedPhraseQuery::execute (phrase_query.cpp:44-111) + PhraseIterator::next
+// (phrase_iterator.hpp:590-596): conjunction ordered by cost, then EvaluateFreq
+template<typename Emit>
+void execute_phrase(const orc_segment& seg, const orc_term_meta* metas, uint32_t n_terms,
+                    const uint32_t* offsets, Emit&& emit) {
+  if (!seg.pos_file) return;
+  std::vector<PSub> subs(n_terms);
+  for (uint32_t t = 0; t < n_terms; ++t) {
+    if (metas[t].docs_count == 0) return;  // phrase state absent for the segment
+    PSub& s = subs[t];
+    orc_it_prepare_wand(&s.it, seg.doc_file, seg.doc_file_len, seg.layout, &metas[t], 1,
+                        seg.wand_count);
+    orc_pos_prepare(&s.pos, seg.pos_file, seg.pos_file_len, seg.layout, &metas[t]);
+    s.offset = offsets[t];
+    s.cost = metas[t].docs_count;
+  }
+  std::vector<PSub*> phrase(n_terms), conj(n_terms);
+  for (uint32_t t = 0; t < n_terms; ++t) phrase[t] = conj[t] = &subs[t];
+  std::stable_sort(conj.begin(), conj.end(),
+                   [](const PSub* a, const PSub* b) { return a->cost < b->cost; });
+  PSub& front = *conj.front();
+  for (;;) {  // Conjunction::next/converge — conjunction.hpp:191-223
+    if (!pnext(front)) return;
+    uint32_t target = front.it.doc;
+  restart:
+    for (size_t i = 1; i < conj.size(); ++i) {
+      const uint32_t doc = pseek(*conj[i], target);
+      if (target < doc) {
+        target = pseek(front, doc);
+        if (target != kEof) goto restart;
+        return;
+      }
+    }
+    const uint32_t pf = phrase_frequency(phrase);
+    if (pf) emit(target, pf);
+  }
+}
+
 void collect_stats(const orc_scorer& scorer, uint64_t dwf, uint64_t dwt,
                    uint64_t ttf, TermStats* st) {
   std::memset(st, 0, sizeof *st);  // stats are zero-initialised scorer.hpp:143
@@ -482,6 +569,88 @@ int64_t orc_search_batch(const orc_segment* segs, uint32_t nsegs,
   worker();
   for (auto& th : pool) th.join();
   return failed ? -1 : int64_t(n_queries);
+}
+
+namespace {
+// term_stats.finish(stats_buf, term_idx, ...) for every phrase term on ONE buffer
+// (phrase_filter.cpp:281-287): BM25::collect / TFIDF::collect accumulate idf
+void phrase_stats(const orc_scorer& scorer, uint64_t dwf, const uint64_t* dwt,
+                  uint32_t n_terms, uint64_t ttf, TermStats* st) {
+  std::memset(st, 0, sizeof *st);
+  for (uint32_t t = 0; t < n_terms; ++t) {
+    if (scorer.kind == ORC_SCORER_BM25)
+      orc_bm25_collect(scorer.k, scorer.b, dwf, dwt[t], ttf, &st->bm25);
+    else
+      st->tfidf_idf += orc_tfidf_idf(dwf, dwt[t]);
+  }
+}
+}  // namespace
+
+int64_t orc_search_phrase(const orc_segment* segs, uint32_t nsegs,
+                          const orc_term_meta* metas, uint32_t n_terms,
+                          const uint32_t* offsets, const orc_scorer* scorer, float boost,
+                          const uint64_t* docs_with_field, const uint64_t* total_term_freq,
+                          uint32_t k, orc_hit* out, uint64_t* hits_total) {
+  if (!segs || !metas || !scorer || !n_terms || !offsets || offsets[0] != 0) return -1;
+  uint64_t dwf = 0, ttf = 0;
+  for (uint32_t s = 0; s < nsegs; ++s) {
+    dwf += docs_with_field[s];
+    ttf += total_term_freq[s];
+  }
+  std::vector<uint64_t> dwt(n_terms, 0);
+  for (uint32_t t = 0; t < n_terms; ++t)
+    for (uint32_t s = 0; s < nsegs; ++s) dwt[t] += metas[size_t(s) * n_terms + t].docs_count;
+  TermStats st;
+  phrase_stats(*scorer, dwf, dwt.data(), n_terms, ttf, &st);
+
+  std::vector<orc_hit> sorted;  // index-search.cpp:719-787
+  sorted.reserve(k);
+  uint64_t doc_count = 0;
+  uint32_t left = k;
+  for (uint32_t s = 0; s < nsegs; ++s) {
+    TermScorer sc;
+    make_term_scorer(*scorer, segs[s], st, boost, &sc);
+    execute_phrase(segs[s], metas + size_t(s) * n_terms, n_terms, offsets,
+                   [&](uint32_t doc, uint32_t pf) {
+                     const float score_value = score_posting(sc, pf, doc);
+                     ++doc_count;
+                     if (left) {
+                       sorted.push_back(orc_hit{score_value, doc, s});
+                       if (0 == --left) std::make_heap(sorted.begin(), sorted.end(), ByScoreDesc{});
+                     } else if (k && sorted.front().score < score_value) {
+                       std::pop_heap(sorted.begin(), sorted.end(), ByScoreDesc{});
+                       sorted.back() = orc_hit{score_value, doc, s};
+                       std::push_heap(sorted.begin(), sorted.end(), ByScoreDesc{});
+                     }
+                   });
+  }
+  std::sort(sorted.begin(), sorted.end(), ByScoreDesc{});
+  if (!sorted.empty()) std::memcpy(out, sorted.data(), sorted.size() * sizeof(orc_hit));
+  if (hits_total) *hits_total = doc_count;
+  return int64_t(sorted.size());
+}
+
+int64_t orc_score_all_phrase(const orc_segment* seg, const orc_term_meta* metas,
+                             uint32_t n_terms, const uint32_t* offsets,
+                             const orc_scorer* scorer, float boost, uint64_t docs_with_field,
+                             const uint64_t* docs_with_term, uint64_t total_term_freq,
+                             float* scores, uint32_t* phrase_freq) {
+  if (!seg || !metas || !scorer || !n_terms || !offsets || offsets[0] != 0) return -1;
+  TermStats st;
+  phrase_stats(*scorer, docs_with_field, docs_with_term, n_terms, total_term_freq, &st);
+  TermScorer sc;
+  make_term_scorer(*scorer, *seg, st, boost, &sc);
+  std::memset(scores, 0, sizeof(float) * (size_t(seg->num_docs) + 1));
+  std::memset(phrase_freq, 0, sizeof(uint32_t) * (size_t(seg->num_docs) + 1));
+  int64_t n = 0;
+  execute_phrase(*seg, metas, n_terms, offsets, [&](uint32_t doc, uint32_t pf) {
+    if (doc <= seg->num_docs) {
+      scores[doc] = score_posting(sc, pf, doc);
+      phrase_freq[doc] = pf;
+      ++n;
+    }
+  });
+  return n;
 }
 
 int64_t orc_score_all(const orc_segment* seg, const orc_term_meta* metas,
