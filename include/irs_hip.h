@@ -19,10 +19,11 @@
 extern "C" {
 #endif
 
-#define IRS_HIP_ABI_VERSION 1
+#define IRS_HIP_ABI_VERSION 2
 #define IRS_HIP_BLOCK_SIZE 128u  /* postings per block, formats_10.cpp:90 */
 #define IRS_HIP_MAX_TERMS 16u    /* terms per boolean query               */
 #define IRS_HIP_MAX_K 4096u      /* largest top-k                         */
+#define IRS_HIP_MAX_PHRASE_TERMS 8u /* terms of one by_phrase query       */
 #define IRS_HIP_NO_TERM 0xFFFFFFFFu
 
 /* Errors replace the reference's exceptions (io_error / index_error,
@@ -76,6 +77,11 @@ typedef struct irs_hip_segment_desc {
                              * (size byte, payload) pairs of "wand data" in front of short
                              * lists' tails (formats_10.cpp:686-688, skipped as :2298-2301)
                              * and inside the skip data (never read here). 0..16. */
+  const uint8_t* pos_file;  /* whole `.pos` file of a field with IndexFeatures::POS (and no
+                             * offsets / payloads), formats 1_3+ (zero-based position storage,
+                             * formats_10.cpp:297-304) — what postings_reader::prepare opens
+                             * as pos_in_ (:3369-3381); NULL: no positions, no phrase queries */
+  uint64_t pos_file_len;
 } irs_hip_segment_desc;
 
 typedef struct irs_hip_segment irs_hip_segment; /* opaque, immutable after open */
@@ -97,6 +103,14 @@ uint64_t irs_hip_segment_device_bytes(const irs_hip_segment* seg);
  * (iterator requested without IndexFeatures::FREQ). */
 int irs_hip_decode_term(irs_hip_segment* seg, uint32_t term, uint32_t* docs,
                         uint32_t* freqs, uint32_t cap, uint32_t* count);
+
+/* Replaces draining the `position` attribute behind `while (it->next())`
+ * (position::next, formats_10.cpp:1606-1633, fed by doc_iterator::next :2106-2113):
+ * every position of every doc of term ordinal `term`, doc after doc — term_meta::freq
+ * values in all (freqs from irs_hip_decode_term say where each doc's run ends).
+ * Needs a segment opened with pos_file. */
+int irs_hip_decode_positions(irs_hip_segment* seg, uint32_t term, uint32_t* positions,
+                             uint64_t cap, uint64_t* count);
 
 /* postings_reader::bit_union (core/formats/formats_10.cpp:3716-3806; virtual at
  * core/formats/formats.hpp:182-190): ORs bit `doc` into the caller's bitset
@@ -120,9 +134,19 @@ int irs_hip_term_directory(irs_hip_segment* seg, uint32_t term,
 typedef enum irs_hip_op {
   IRS_HIP_OP_OR = 0, /* irs::Or / by_term: disjunction.hpp MakeDisjunction :1411-1467 */
   IRS_HIP_OP_AND = 1, /* irs::And: conjunction.hpp MakeConjunction :436-490           */
-  IRS_HIP_OP_MINMATCH = 2 /* irs::Or with min_match_count: MinMatchQuery::execute
+  IRS_HIP_OP_MINMATCH = 2, /* irs::Or with min_match_count: MinMatchQuery::execute
                              (boolean_query.cpp:212-247) -> min_match_iterator =
                              block_disjunction<kMinMatch> (disjunction.hpp:1378-1383)   */
+  IRS_HIP_OP_PHRASE = 3   /* irs::by_phrase of plain terms: FixedPhraseQuery::execute
+                             (phrase_query.cpp:44-111) -> PhraseIterator<Conjunction,
+                             FixedPhraseFrequency> (phrase_iterator.hpp:75-166, 540-626).
+                             terms[first_term + i] = i-th phrase term with its
+                             phrase_offset; every entry carries the SAME scorer values: the
+                             phrase's one stats blob, into which every term's statistics
+                             were finished (phrase_filter.cpp:281-287: idf sums), times
+                             the filter boost.  score = that scorer at tf = phrase
+                             frequency.  An absent term empties the query in that segment.
+                             A batch holds phrase queries only, or none.               */
 } irs_hip_op;
 
 /* Which ScoreFunction Scorer::prepare_scorer would have built. */
@@ -143,11 +167,14 @@ typedef struct irs_hip_term_scorer {
   float c0;           /* BM25: boost*(k+1)*idf (bm25.cpp:201); TFIDF: boost*idf (tfidf.cpp:199) */
   float norm_const;   /* BM25Stats::norm_const  (bm25.hpp:52)                            */
   float norm_length;  /* BM25Stats::norm_length (bm25.hpp:54)                            */
+  uint32_t phrase_offset; /* IRS_HIP_OP_PHRASE: position of the term relative to the phrase's
+                             first term (FixedPhraseQuery::positions_t, phrase_filter.cpp
+                             :279-284; 0 for the first); ignored by the other ops          */
 } irs_hip_term_scorer;
 
 typedef struct irs_hip_query {
   int32_t op;          /* irs_hip_op                                   */
-  uint32_t n_terms;    /* 1..IRS_HIP_MAX_TERMS                         */
+  uint32_t n_terms;    /* 1..IRS_HIP_MAX_TERMS (PHRASE: ..IRS_HIP_MAX_PHRASE_TERMS) */
   uint32_t first_term; /* index of the first entry in the `terms` array */
   uint32_t k;          /* top-k, 1..IRS_HIP_MAX_K (index-search --topN) */
   uint32_t min_match;  /* IRS_HIP_OP_MINMATCH: Or::min_match_count(); else ignored */

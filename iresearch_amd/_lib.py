@@ -16,10 +16,10 @@ from . import _build
 
 OK, EINVAL, ECORRUPT, ENOMEM, EHIP, EOVERFLOW, EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 LAYOUT_SCALAR, LAYOUT_SIMD4 = 0, 1
-OP_OR, OP_AND, OP_MINMATCH = 0, 1, 2
+OP_OR, OP_AND, OP_MINMATCH, OP_PHRASE = 0, 1, 2, 3
 SCORE_BM25, SCORE_BM15, SCORE_BM1, SCORE_TFIDF, SCORE_TFIDF_NORM = 0, 1, 2, 3, 4
 NO_TERM = 0xFFFFFFFF
-MAX_TERMS, MAX_K = 16, 4096
+MAX_TERMS, MAX_K, MAX_PHRASE_TERMS = 16, 4096, 8
 K_PLAN, K_PILOT, K_SCORE, K_SELECT, K_COUNT = 0, 1, 2, 3, 4
 KERNEL_NAMES = ("k_plan", "k_pilot", "k_score", "k_select")
 
@@ -28,11 +28,11 @@ TERM_META = np.dtype(
      ("pos_end", "<u8"), ("pay_start", "<u8"), ("e_skip_start", "<u8")], align=True)
 TERM_SCORER = np.dtype(
     [("term", "<u4"), ("kind", "<i4"), ("c0", "<f4"), ("norm_const", "<f4"),
-     ("norm_length", "<f4")], align=True)
+     ("norm_length", "<f4"), ("phrase_offset", "<u4")], align=True)
 QUERY = np.dtype([("op", "<i4"), ("n_terms", "<u4"), ("first_term", "<u4"), ("k", "<u4"),
                   ("min_match", "<u4")], align=True)
 HIT = np.dtype([("score", "<f4"), ("doc", "<u4")], align=True)
-assert TERM_META.itemsize == 48 and TERM_SCORER.itemsize == 20
+assert TERM_META.itemsize == 48 and TERM_SCORER.itemsize == 24
 assert QUERY.itemsize == 20 and HIT.itemsize == 8
 
 
@@ -42,7 +42,7 @@ class SegmentDesc(C.Structure):
         ("doc_file_len", C.c_uint64), ("num_docs", C.c_uint32), ("has_freq", C.c_uint32),
         ("norms", C.c_void_p), ("norm_width", C.c_uint32), ("norm_min_doc", C.c_uint32),
         ("norm_count", C.c_uint64), ("terms", C.c_void_p), ("num_terms", C.c_uint32),
-        ("wand_count", C.c_uint32),
+        ("wand_count", C.c_uint32), ("pos_file", C.c_void_p), ("pos_file_len", C.c_uint64),
     ]
 
 
@@ -55,6 +55,7 @@ class IrsHipError(RuntimeError):
 SYMBOLS = (
     "irs_hip_abi_version", "irs_hip_strerror", "irs_hip_device_arch", "irs_hip_segment_open",
     "irs_hip_segment_close", "irs_hip_segment_device_bytes", "irs_hip_decode_term",
+    "irs_hip_decode_positions",
     "irs_hip_term_directory", "irs_hip_bit_union", "irs_hip_batch_create",
     "irs_hip_batch_create_multi", "irs_hip_batch_run",
     "irs_hip_batch_results", "irs_hip_batch_device_results",
@@ -77,6 +78,8 @@ def bind(L: C.CDLL) -> C.CDLL:
     L.irs_hip_segment_device_bytes.restype = u64
     L.irs_hip_decode_term.argtypes = [vp, u32, vp, vp, u32, P(u32)]
     L.irs_hip_decode_term.restype = C.c_int
+    L.irs_hip_decode_positions.argtypes = [vp, u32, vp, u64, P(u64)]
+    L.irs_hip_decode_positions.restype = C.c_int
     L.irs_hip_bit_union.argtypes = [vp, vp, u32, vp, u64, P(u64)]
     L.irs_hip_bit_union.restype = C.c_int
     L.irs_hip_term_directory.argtypes = [vp, u32, vp, vp, u32, P(u32)]

@@ -12,6 +12,7 @@
 
 #include "gpu_rt.h"
 #include "kernels.h"
+#include "phrase.h"
 
 using namespace irs_hip;
 
@@ -54,9 +55,8 @@ bool device_usable(int device) {
 
 // format_utils::check_header for `.doc` (format_utils.cpp:74-105,
 // formats_10.cpp:325-326, 3356-3361); returns header length or 0.
-size_t check_doc_header(const uint8_t* f, uint64_t len, int32_t* version) {
-  static const char name[] = "iresearch_10_postings_documents";
-  const size_t nlen = sizeof(name) - 1;
+size_t check_header(const uint8_t* f, uint64_t len, const char* name, int32_t* version) {
+  const size_t nlen = std::strlen(name);
   if (len < 4 + 1 + nlen + 4 + 16) return 0;
   const uint32_t magic = (uint32_t(f[0]) << 24) | (uint32_t(f[1]) << 16) |
                          (uint32_t(f[2]) << 8) | f[3];
@@ -67,6 +67,13 @@ size_t check_doc_header(const uint8_t* f, uint64_t len, int32_t* version) {
                      (uint32_t(v[2]) << 8) | v[3]);
   return 5 + nlen + 4;
 }
+size_t check_doc_header(const uint8_t* f, uint64_t len, int32_t* version) {
+  return check_header(f, len, "iresearch_10_postings_documents", version);
+}
+// `.pos`: formats_10.cpp:327-328, 3369-3381
+size_t check_pos_header(const uint8_t* f, uint64_t len, int32_t* version) {
+  return check_header(f, len, "iresearch_10_postings_positions", version);
+}
 
 }  // namespace
 
@@ -76,6 +83,10 @@ struct irs_hip_segment {
   DevBuf d_doc, d_norms, d_terms, d_blk_off, d_blk_last, d_blk_bits, d_status;
   DevBuf d_blk_aoff, d_pk;     // packed-payload image (DevSegment::pk) and its offsets
   DevBuf d_tail_docs, d_tail_freqs;  // decoded vint tails, [num_terms][128]
+  // positions (fields with POS): `.pos` bytes, per-term records, pos block directory,
+  // positions in front of every doc block, decoded position tails
+  DevBuf d_pos, d_pterms, d_pblk_off, d_pblk_bits, d_blk_pos, d_ptail;
+  std::vector<DevPosTerm> pterms;
   std::vector<DevTerm> terms;  // host mirror incl. the fields the dir kernel filled
   uint64_t total_blocks = 0;
   uint64_t device_bytes = 0;
@@ -95,6 +106,7 @@ struct irs_hip_batch {
   uint32_t stride_eff = 1;  // pilot stride actually used (>= 2 pilot tiles per segment when possible)
   uint32_t wg_threads = kDefaultWgThreads;  // threads per pilot/score workgroup
   bool any_and = false;
+  bool phrase = false;  // a batch of by_phrase queries (k_phrase instead of k_pilot + k_score)
   bool acc32 = true;   // 32-bit fixed-point accumulators are precise enough for every query
   bool scratch_ready = false;
   std::vector<DevQuery> queries;
@@ -113,24 +125,29 @@ namespace {
 
 // Packed-payload image: block sizes (left in blk_aoff by the directory kernel) ->
 // exclusive prefix sum in place -> one copy pass.  Everything on the device.
+// In-place exclusive prefix sum of n u32 values on the device; *total = their sum, which
+// must fit 32 bits (the scanned values are offsets kept as u32).
+int scan_exclusive(uint32_t* d_values, uint64_t n, uint64_t* total) {
+  *total = 0;
+  if (!n) return IRS_HIP_OK;
+  const uint32_t parts = uint32_t((n + kScanChunk - 1) / kScanChunk);
+  DevBuf totals;
+  if (!totals.alloc((uint64_t(parts) + 1) * 8)) return IRS_HIP_ENOMEM;
+  RT_LAUNCH(k_scan_totals, parts, kThreads, 0, nullptr, d_values, n, totals.as<uint64_t>());
+  RT_LAUNCH(k_scan_parts, 1, 64, 0, nullptr, totals.as<uint64_t>(), parts);
+  if (!rt::last_error_ok() || !rt::d2h(total, totals.as<uint64_t>() + parts, 8, nullptr) ||
+      !rt::sync(nullptr))
+    return IRS_HIP_EHIP;
+  if (*total > 0xFFFFFFFFull) return IRS_HIP_EUNSUPPORTED;
+  RT_LAUNCH(k_scan_apply, parts, kThreads, 0, nullptr, d_values, n, totals.as<uint64_t>());
+  if (!rt::last_error_ok() || !rt::sync(nullptr)) return IRS_HIP_EHIP;
+  return IRS_HIP_OK;
+}
+
 int build_packed_image(irs_hip_segment* s) {
   const uint64_t n = s->total_blocks;
-  uint64_t total_units = 0;
-  if (n) {
-    const uint32_t parts = uint32_t((n + kScanChunk - 1) / kScanChunk);
-    DevBuf totals;
-    if (!totals.alloc((uint64_t(parts) + 1) * 8)) return IRS_HIP_ENOMEM;
-    RT_LAUNCH(k_scan_totals, parts, kThreads, 0, nullptr, s->d_blk_aoff.as<uint32_t>(), n,
-              totals.as<uint64_t>());
-    RT_LAUNCH(k_scan_parts, 1, 64, 0, nullptr, totals.as<uint64_t>(), parts);
-    if (!rt::last_error_ok() ||
-        !rt::d2h(&total_units, totals.as<uint64_t>() + parts, 8, nullptr) || !rt::sync(nullptr))
-      return IRS_HIP_EHIP;
-    if (total_units > 0xFFFFFFFFull) return IRS_HIP_EUNSUPPORTED;  // offsets are u32 units (64 GB)
-    RT_LAUNCH(k_scan_apply, parts, kThreads, 0, nullptr, s->d_blk_aoff.as<uint32_t>(), n,
-              totals.as<uint64_t>());
-    if (!rt::last_error_ok() || !rt::sync(nullptr)) return IRS_HIP_EHIP;
-  }
+  uint64_t total_units = 0;  // offsets are u32 units of 16 bytes (64 GB)
+  if (const int rc = scan_exclusive(s->d_blk_aoff.as<uint32_t>(), n, &total_units)) return rc;
   const uint64_t bytes = total_units * 16;
   if (!s->d_pk.alloc(bytes + kPadBytes)) return IRS_HIP_ENOMEM;
   if (!rt::dmemset(s->d_pk.as<uint8_t>() + bytes, 0, kPadBytes, nullptr)) return IRS_HIP_EHIP;
@@ -168,6 +185,42 @@ int build_directory(irs_hip_segment* s) {
       return IRS_HIP_ECORRUPT;
   }
   return build_packed_image(s);
+}
+
+// Positions: frequency sums per doc block -> exclusive scan (blk_pos), then the pos block
+// directory and the decoded position tails.  `pos_end` = term_meta::pos_end per term.
+template<int LAYOUT>
+int build_positions(irs_hip_segment* s, const std::vector<uint64_t>& pos_end) {
+  const uint64_t n = s->total_blocks;
+  if (!rt::dmemset(s->d_blk_pos.p, 0, s->d_blk_pos.n, nullptr)) return IRS_HIP_EHIP;
+  if (n && s->dev.num_terms) {
+    const uint32_t slices =
+        std::max<uint32_t>(1, std::min<uint32_t>(64, s->cus * 8 / s->dev.num_terms));
+    RT_LAUNCH((k_freq_sums<LAYOUT>), s->dev.num_terms * slices, kThreads, 0, nullptr, s->dev,
+              slices, s->d_blk_pos.as<uint32_t>());
+    if (!rt::last_error_ok() || !rt::sync(nullptr)) return IRS_HIP_EHIP;
+  }
+  uint64_t total = 0;
+  if (const int rc = scan_exclusive(s->d_blk_pos.as<uint32_t>(), n, &total)) return rc;
+  const uint32_t total32 = uint32_t(total);  // sentinel row: everything in front of "row n"
+  if (!rt::h2d(s->d_blk_pos.as<uint32_t>() + n, &total32, 4, nullptr)) return IRS_HIP_EHIP;
+  DevBuf d_pos_end;
+  if (!d_pos_end.alloc(std::max<size_t>(1, pos_end.size()) * 8)) return IRS_HIP_ENOMEM;
+  if (!rt::h2d(d_pos_end.p, pos_end.data(), pos_end.size() * 8, nullptr) ||
+      !rt::dmemset(s->d_status.p, 0, 4, nullptr))
+    return IRS_HIP_EHIP;
+  const uint32_t grid = (s->dev.num_terms + kWaves - 1) / kWaves;
+  if (grid) {
+    RT_LAUNCH(k_pos_directory, grid, kThreads, 0, nullptr, s->dev, s->d_pterms.as<DevPosTerm>(),
+              s->d_pblk_off.as<uint32_t>(), s->d_pblk_bits.as<uint8_t>(),
+              s->d_ptail.as<uint32_t>(), d_pos_end.as<uint64_t>(), s->d_status.as<uint32_t>());
+  }
+  uint32_t status = 0;
+  if (!rt::last_error_ok() || !rt::d2h(&status, s->d_status.p, 4, nullptr) ||
+      !rt::d2h(s->pterms.data(), s->d_pterms.p, s->pterms.size() * sizeof(DevPosTerm), nullptr) ||
+      !rt::sync(nullptr))
+    return IRS_HIP_EHIP;
+  return (status & kStatusCorrupt) ? IRS_HIP_ECORRUPT : IRS_HIP_OK;
 }
 
 template<typename K>
@@ -262,8 +315,30 @@ bool launch_score_acc(irs_hip_batch* b, rt::stream_t st) {
                   : launch_score_tile<unsigned long long, LAYOUT>(b, st);
 }
 
+template<int LAYOUT, int MT>
+bool launch_phrase(irs_hip_batch* b, rt::stream_t st) {
+  const size_t smem = phrase_smem_bytes(b->jt);
+  auto kern = k_phrase<LAYOUT, MT>;
+  if (!big_smem(kern, smem)) return false;
+  const uint32_t cpq = (b->max_tiles + kPhraseChunk - 1) / kPhraseChunk;
+  const uint64_t grid = uint64_t(b->nq) * cpq;
+  if (grid > 0x7FFFFFFFull) return false;
+  RT_LAUNCH(kern, uint32_t(grid), kPhraseThreads, smem, st, b->d_segs.as<DevSegment>(),
+            b->d_queries.as<DevQuery>(), b->d_qterms.as<DevQTerm>(), b->jt, cpq,
+            b->d_first.as<uint32_t>(), b->d_tails.as<DevTail>(), b->d_cands.as<uint64_t>(),
+            b->cand_cap, b->d_cand_count.as<uint32_t>(), b->d_hits.as<unsigned long long>());
+  return rt::last_error_ok();
+}
+template<int LAYOUT>
+bool launch_phrase_terms(irs_hip_batch* b, rt::stream_t st) {
+  if (b->jt <= 2) return launch_phrase<LAYOUT, 2>(b, st);
+  if (b->jt <= 4) return launch_phrase<LAYOUT, 4>(b, st);
+  return launch_phrase<LAYOUT, int(kPhraseMaxTerms)>(b, st);
+}
+
 bool ensure_scratch(irs_hip_batch* b) {
   if (b->scratch_ready) return true;
+  if (b->phrase) b->tile = kPhraseTile;
   // 32-bit accumulators halve the LDS per doc: twice the tile at the same residency
   // the largest tile that still lets two workgroups share a CU's 160 KB of LDS
   // (AND / min-match batches also keep a match counter byte per doc)
@@ -281,6 +356,7 @@ bool ensure_scratch(irs_hip_batch* b) {
     b->max_tiles = std::max(b->max_tiles, dq.n_tiles);
   }
   b->stride_eff = std::max<uint32_t>(1, std::min<uint32_t>(b->stride, b->n_tiles / 2));
+  if (b->phrase) b->stride_eff = 1;  // no pilot: every match is a candidate
   if (const char* e = std::getenv("IRS_HIP_WG_THREADS")) {  // tuning knob
     const uint32_t t = uint32_t(std::atoi(e));
     if (t >= 256 && t <= 1024 && t % 64 == 0) b->wg_threads = t;
@@ -350,6 +426,17 @@ int irs_hip_segment_open(const irs_hip_segment_desc* d, irs_hip_segment** out) {
   // PostingsFormat: odd versions are the SSE (simd4) layouts (formats_10.cpp:283-313)
   if (version < 0 || version > 5) return IRS_HIP_ECORRUPT;
   if ((version & 1) != (d->layout == IRS_HIP_LAYOUT_SIMD4 ? 1 : 0)) return IRS_HIP_EINVAL;
+  size_t pos_hdr = 0;
+  if (d->pos_file) {
+    // positions need frequencies (IndexFeatures::POS implies FREQ); zero-based storage
+    // (PostingsFormat >= POSITIONS_ZEROBASED = 2, formats_10.cpp:297-304)
+    int32_t pos_version = -1;
+    pos_hdr = check_pos_header(d->pos_file, d->pos_file_len, &pos_version);
+    if (!pos_hdr) return IRS_HIP_ECORRUPT;
+    if (pos_version != version) return IRS_HIP_ECORRUPT;
+    if (!d->has_freq) return IRS_HIP_EINVAL;
+    if (version < 2) return IRS_HIP_EUNSUPPORTED;
+  }
   if (!device_usable(d->device)) return IRS_HIP_EHIP;
 
   irs_hip_segment* s = new (std::nothrow) irs_hip_segment;
@@ -432,9 +519,63 @@ int irs_hip_segment_open(const irs_hip_segment_desc* d, irs_hip_segment** out) {
     v.wand_count = d->wand_count;
     rc = d->layout == IRS_HIP_LAYOUT_SIMD4 ? build_directory<kSimd4>(s)
                                            : build_directory<kScalar>(s);
+    if (rc == IRS_HIP_OK && d->pos_file) {
+      std::vector<uint64_t> pos_end;
+      uint64_t rows = 0;
+      try {
+        s->pterms.resize(d->num_terms);
+        pos_end.resize(d->num_terms);
+      } catch (...) {
+        rc = IRS_HIP_ENOMEM;
+        break;
+      }
+      for (uint32_t i = 0; i < d->num_terms && rc == IRS_HIP_OK; ++i) {
+        const irs_hip_term_meta& m = d->terms[i];
+        DevPosTerm pt{};
+        if (m.docs_count) {
+          if (m.freq < m.docs_count || m.pos_start < pos_hdr || m.pos_start > d->pos_file_len)
+            rc = IRS_HIP_ECORRUPT;
+          pt.pos_start = m.pos_start;
+          pt.total = m.freq;
+          pt.nfull = m.freq / kBlock;
+          pt.tail_n = m.freq % kBlock;
+          pt.row = rows;
+          rows += pt.nfull;
+        }
+        s->pterms[i] = pt;
+        pos_end[i] = m.pos_end;
+      }
+      if (rc != IRS_HIP_OK) break;
+      if (!s->d_pos.alloc(d->pos_file_len + kPadBytes) ||
+          !s->d_pterms.alloc(std::max<size_t>(1, s->pterms.size()) * sizeof(DevPosTerm)) ||
+          !s->d_pblk_off.alloc((rows + 1) * 4) || !s->d_pblk_bits.alloc(rows + 1) ||
+          !s->d_blk_pos.alloc((blocks + 1) * 4) ||
+          !s->d_ptail.alloc((uint64_t(d->num_terms) + 1) * kBlock * 4)) {
+        rc = IRS_HIP_ENOMEM;
+        break;
+      }
+      if (!rt::h2d(s->d_pos.p, d->pos_file, d->pos_file_len, nullptr) ||
+          !rt::dmemset(s->d_pos.as<uint8_t>() + d->pos_file_len, 0, kPadBytes, nullptr) ||
+          !rt::h2d(s->d_pterms.p, s->pterms.data(), s->pterms.size() * sizeof(DevPosTerm),
+                   nullptr) ||
+          !rt::sync(nullptr)) {
+        rc = IRS_HIP_EHIP;
+        break;
+      }
+      v.pos = s->d_pos.as<uint8_t>();
+      v.pos_len = d->pos_file_len;
+      v.pterms = s->d_pterms.as<DevPosTerm>();
+      v.pblk_off = s->d_pblk_off.as<uint32_t>();
+      v.pblk_bits = s->d_pblk_bits.as<uint8_t>();
+      v.blk_pos = s->d_blk_pos.as<uint32_t>();
+      v.ptail = s->d_ptail.as<uint32_t>();
+      rc = d->layout == IRS_HIP_LAYOUT_SIMD4 ? build_positions<kSimd4>(s, pos_end)
+                                             : build_positions<kScalar>(s, pos_end);
+    }
     s->device_bytes = s->d_doc.n + s->d_norms.n + s->d_terms.n + s->d_blk_off.n +
                       s->d_blk_last.n + s->d_blk_bits.n + s->d_blk_aoff.n + s->d_pk.n +
-                      s->d_tail_docs.n + s->d_tail_freqs.n;
+                      s->d_tail_docs.n + s->d_tail_freqs.n + s->d_pos.n + s->d_pterms.n +
+                      s->d_pblk_off.n + s->d_pblk_bits.n + s->d_blk_pos.n + s->d_ptail.n;
   } while (false);
   if (rc != IRS_HIP_OK) {
     delete s;
@@ -477,6 +618,33 @@ int irs_hip_decode_term(irs_hip_segment* seg, uint32_t term, uint32_t* docs, uin
   }
   if (!rt::last_error_ok() || !rt::d2h(docs, dd.p, bytes, nullptr) ||
       (freqs && !rt::d2h(freqs, df.p, bytes, nullptr)) || !rt::sync(nullptr))
+    return IRS_HIP_EHIP;
+  return IRS_HIP_OK;
+}
+
+int irs_hip_decode_positions(irs_hip_segment* seg, uint32_t term, uint32_t* positions,
+                             uint64_t cap, uint64_t* count) {
+  if (!seg || !positions || !count || term >= seg->dev.num_terms) return IRS_HIP_EINVAL;
+  if (!seg->dev.pos) return IRS_HIP_EINVAL;  // the segment was opened without `.pos`
+  if (!rt::set_device(seg->device)) return IRS_HIP_EHIP;
+  const DevTerm& t = seg->terms[term];
+  const uint64_t total = seg->pterms[term].total;
+  *count = total;
+  if (t.docs_count == 0 || total == 0) return IRS_HIP_OK;
+  if (cap < total) return IRS_HIP_EINVAL;
+  DevBuf dp;
+  if (!dp.alloc(size_t(total) * 4)) return IRS_HIP_ENOMEM;
+  const uint32_t items = t.nblk + 1;
+  const uint32_t grid = (items + kWaves - 1) / kWaves;
+  if (seg->dev.layout == kSimd4) {
+    RT_LAUNCH((k_decode_positions<kSimd4>), grid, kThreads, 0, nullptr, seg->dev, term,
+              dp.as<uint32_t>());
+  } else {
+    RT_LAUNCH((k_decode_positions<kScalar>), grid, kThreads, 0, nullptr, seg->dev, term,
+              dp.as<uint32_t>());
+  }
+  if (!rt::last_error_ok() || !rt::d2h(positions, dp.p, size_t(total) * 4, nullptr) ||
+      !rt::sync(nullptr))
     return IRS_HIP_EHIP;
   return IRS_HIP_OK;
 }
@@ -575,12 +743,29 @@ int irs_hip_batch_create_multi(irs_hip_segment* const* segs, uint32_t n_segs,
       irs_hip_segment* seg = segs[q / nq_user];
       const irs_hip_term_scorer* terms = all_terms + size_t(q / nq_user) * n_entries;
       const irs_hip_query& in = queries[q % nq_user];
-      if ((in.op != IRS_HIP_OP_OR && in.op != IRS_HIP_OP_AND && in.op != IRS_HIP_OP_MINMATCH) ||
+      if ((in.op != IRS_HIP_OP_OR && in.op != IRS_HIP_OP_AND && in.op != IRS_HIP_OP_MINMATCH &&
+           in.op != IRS_HIP_OP_PHRASE) ||
           in.n_terms == 0 ||
           in.n_terms > IRS_HIP_MAX_TERMS || in.k == 0 || in.k > IRS_HIP_MAX_K ||
           uint64_t(in.first_term) + in.n_terms > n_entries) {
         rc = IRS_HIP_EINVAL;
         break;
+      }
+      const bool is_phrase = in.op == IRS_HIP_OP_PHRASE;
+      if (q == 0) b->phrase = is_phrase;
+      if (is_phrase != b->phrase) {  // a batch holds phrase queries only, or none
+        rc = IRS_HIP_EUNSUPPORTED;
+        break;
+      }
+      if (is_phrase) {
+        if (in.n_terms > IRS_HIP_MAX_PHRASE_TERMS || terms[in.first_term].phrase_offset != 0) {
+          rc = IRS_HIP_EINVAL;
+          break;
+        }
+        if (!seg->dev.pos) {  // FixedPhraseQuery needs FREQ | POS (phrase_query.cpp:63-66)
+          rc = IRS_HIP_EUNSUPPORTED;
+          break;
+        }
       }
       std::vector<DevQTerm> row;
       bool absent = false;
@@ -593,6 +778,7 @@ int irs_hip_batch_create_multi(irs_hip_segment* const* segs, uint32_t n_segs,
         qt.norm_const = ts.norm_const;
         qt.norm_length = ts.norm_length;
         qt.cache_id = kMaxCaches;
+        qt.pad0 = is_phrase ? ts.phrase_offset : 0u;
         if (ts.term != IRS_HIP_NO_TERM && ts.term >= seg->dev.num_terms) rc = IRS_HIP_EINVAL;
         if (!(ts.c0 >= 0.f) || !std::isfinite(ts.c0)) rc = IRS_HIP_EINVAL;
         if (rc != IRS_HIP_OK) break;
@@ -663,6 +849,16 @@ int irs_hip_batch_create_multi(irs_hip_segment* const* segs, uint32_t n_segs,
       } else if (in.op == IRS_HIP_OP_MINMATCH) {
         const uint32_t m = std::max<uint32_t>(1, in.min_match);
         need = (m > in.n_terms || m > row.size()) ? 0xFFu : m;
+      }
+      if (is_phrase) {
+        // no phrase state for a segment lacking one of the terms (phrase_filter.cpp:254-258)
+        need = absent ? 0xFFu : 1u;
+        // the phrase's scorer is one stats blob: every entry must carry the same values
+        for (const DevQTerm& qt : row)
+          if (qt.kind != row[0].kind || qt.c0 != row[0].c0 ||
+              qt.norm_const != row[0].norm_const || qt.norm_length != row[0].norm_length)
+            rc = IRS_HIP_EINVAL;
+        if (rc != IRS_HIP_OK) break;
       }
       if (need == 0xFFu) row.clear();
       dq.op = 0;
@@ -767,7 +963,7 @@ int irs_hip_batch_configure(irs_hip_batch* b, uint32_t tile_docs, uint32_t pilot
   if (cand_cap && cand_cap < b->k_max) return IRS_HIP_EINVAL;
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
   if (b->ran && !rt::sync(b->stream)) return IRS_HIP_EHIP;
-  if (tile_docs) b->tile = tile_docs;
+  if (tile_docs && !b->phrase) b->tile = tile_docs;  // phrase tiles are fixed
   if (pilot_stride) b->stride = pilot_stride;
   b->cand_cap = cand_cap;
   b->scratch_ready = false;
@@ -803,13 +999,17 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st) {
     ok = rt::last_error_ok();
   }
   ok = ok && mark(2 * IRS_HIP_K_PLAN + 1);
-  // 2. pilot: per-query score-bin threshold
+  // 2. pilot: per-query score-bin threshold (phrase batches have none: few docs match)
   ok = ok && mark(2 * IRS_HIP_K_PILOT);
-  ok = ok && (simd ? launch_pilot_acc<kSimd4>(b, st) : launch_pilot_acc<kScalar>(b, st));
+  if (!b->phrase)
+    ok = ok && (simd ? launch_pilot_acc<kSimd4>(b, st) : launch_pilot_acc<kScalar>(b, st));
   ok = ok && mark(2 * IRS_HIP_K_PILOT + 1);
   // 3. score every tile
   ok = ok && mark(2 * IRS_HIP_K_SCORE);
-  ok = ok && (simd ? launch_score_acc<kSimd4>(b, st) : launch_score_acc<kScalar>(b, st));
+  if (b->phrase)
+    ok = ok && (simd ? launch_phrase_terms<kSimd4>(b, st) : launch_phrase_terms<kScalar>(b, st));
+  else
+    ok = ok && (simd ? launch_score_acc<kSimd4>(b, st) : launch_score_acc<kScalar>(b, st));
   ok = ok && mark(2 * IRS_HIP_K_SCORE + 1);
   // 4. exact top-k
   ok = ok && mark(2 * IRS_HIP_K_SELECT);

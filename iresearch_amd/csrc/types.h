@@ -45,6 +45,16 @@ struct DevTerm {
   uint32_t last_doc;    // [dir kernel] last doc id of the list
 };
 
+// Where the positions of one term live in the staged `.pos` file (fields with POS).
+struct DevPosTerm {
+  uint64_t pos_start;   // term_meta::pos_start: absolute offset of the term's first pos block
+  uint64_t row;         // index of the term's first entry in the pos block directory
+  uint32_t nfull;       // full 128-position blocks: term_meta::freq / 128
+  uint32_t tail_n;      // vint-coded positions behind them: freq % 128
+  uint32_t total;       // term_meta::freq
+  uint32_t bytes;       // [pos dir kernel] encoded length of the term's positions
+};
+
 struct DevSegment {
   const uint8_t* doc;        // staged `.doc` bytes (+ kPadBytes zeros)
   uint64_t doc_len;
@@ -71,6 +81,15 @@ struct DevSegment {
   int32_t has_freq;
   int32_t layout;
   uint32_t wand_count;       // scorers the field was indexed with (wand data in front of short tails)
+  // positions (null unless the field has IndexFeatures::POS and `.pos` was staged)
+  const uint8_t* pos;        // staged `.pos` bytes (+ kPadBytes zeros)
+  uint64_t pos_len;
+  const DevPosTerm* pterms;  // [num_terms]
+  const uint32_t* pblk_off;  // pos block directory: byte offset relative to pos_start
+  const uint8_t* pblk_bits;  //   and bit width (0 = all-equal block)
+  const uint32_t* blk_pos;   // per doc-block row (+1 sentinel): positions of ALL earlier rows
+                             // (exclusive scan of the blocks' frequency sums, mod 2^32)
+  const uint32_t* ptail;     // decoded position-delta tails: [num_terms][kBlock]
 };
 
 struct DevQuery {
@@ -95,7 +114,8 @@ struct DevQTerm {
   float norm_const;
   float norm_length;
   uint32_t cache_id;    // < kMaxCaches: norm_cache slot in LDS; else compute on the fly
-  uint32_t pad0, pad1;
+  uint32_t pad0;        // phrase queries: the term's offset in the phrase
+  uint32_t pad1;
 };
 
 // What a tile workgroup needs to know about one term of one query, gathered by the plan

@@ -8,6 +8,7 @@ turns statistics into per-term score functions.
   irs::BM25::collect          core/search/bm25.cpp:366-410     -> BM25.collect
   irs::TFIDF::collect         core/search/tfidf.cpp:263-278    -> TFIDF.collect
   by_term::prepare            core/search/term_filter.cpp:92-129 -> prepare()
+  by_phrase (FixedPrepareCollect) core/search/phrase_filter.cpp:212-293 -> prepare()
   filter::prepared::execute   core/search/filter.hpp:52-78     -> SegmentReader.execute()
   utils/index-search.cpp:719-787 (heap over all segments)     -> Index.search()
 
@@ -24,7 +25,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import _lib
-from ._lib import (HIT, NO_TERM, OP_AND, OP_MINMATCH, OP_OR, QUERY, SCORE_BM1, SCORE_BM15, SCORE_BM25,
+from ._lib import (HIT, NO_TERM, OP_AND, OP_MINMATCH, OP_OR, OP_PHRASE, QUERY, SCORE_BM1, SCORE_BM15, SCORE_BM25,
                    SCORE_TFIDF, SCORE_TFIDF_NORM, TERM_META, TERM_SCORER, SegmentDesc)
 
 f32 = np.float32
@@ -114,6 +115,22 @@ class And:
     min_match: int = 0
 
 
+@dataclass
+class by_phrase:
+    """irs::by_phrase of plain terms (by_phrase_options::push_back<by_term_options>):
+    `terms` are term ordinals; `offsets[i]` = position of term i relative to the first
+    (default: consecutive words)."""
+    terms: list
+    offsets: list | None = None
+    boost: float = 1.0
+
+    def __post_init__(self):
+        if self.offsets is None:
+            self.offsets = list(range(len(self.terms)))
+        if len(self.offsets) != len(self.terms) or (self.offsets and self.offsets[0] != 0):
+            raise ValueError("offsets are relative to the first term")
+
+
 def _terms_of(flt):
     if isinstance(flt, by_term):
         return OP_OR, [flt]
@@ -129,6 +146,7 @@ class PreparedQuery:
     terms: list            # term ordinals
     scorers: list          # (kind, c0, norm_const, norm_length) per term
     min_match: int = 0
+    offsets: list | None = None   # OP_PHRASE: position of every term in the phrase
 
 
 # ------------------------------------------------------------------ segment --
@@ -138,7 +156,7 @@ class SegmentReader:
 
     def __init__(self, doc_file, metas, num_docs, layout, norms=None, norm_width=1,
                  docs_with_field=None, total_term_freq=0, device=0, has_freq=True, L=None,
-                 wand_count=0):
+                 wand_count=0, pos_file=None):
         self.L = L or _lib.lib()
         self.doc_file = np.ascontiguousarray(doc_file, np.uint8)
         self.metas = np.zeros(len(metas), TERM_META)
@@ -149,11 +167,14 @@ class SegmentReader:
         self.norm_width = norm_width
         self.docs_with_field = int(num_docs if docs_with_field is None else docs_with_field)
         self.total_term_freq = int(total_term_freq)
+        self.pos_file = None if pos_file is None else np.ascontiguousarray(pos_file, np.uint8)
         desc = SegmentDesc(
             device, layout, self.doc_file.ctypes.data, self.doc_file.size, num_docs,
             int(has_freq), None if self.norms is None else self.norms.ctypes.data, norm_width, 1,
             0 if self.norms is None else self.norms.size // norm_width,
-            self.metas.ctypes.data, len(self.metas), int(wand_count))
+            self.metas.ctypes.data, len(self.metas), int(wand_count),
+            None if self.pos_file is None else self.pos_file.ctypes.data,
+            0 if self.pos_file is None else self.pos_file.size)
         h = C.c_void_p()
         _lib.check(self.L, self.L.irs_hip_segment_open(C.byref(desc), C.byref(h)),
                    "irs_hip_segment_open")
@@ -163,7 +184,7 @@ class SegmentReader:
     def from_synth(cls, seg, device=0, L=None, has_freq=True):
         return cls(seg.doc_file, seg.metas, seg.num_docs, seg.layout, seg.norms, 1,
                    seg.docs_with_field, seg.total_term_freq, device, has_freq, L,
-                   getattr(seg, "wand_count", 0))
+                   getattr(seg, "wand_count", 0), getattr(seg, "pos_file", None))
 
     def close(self):
         if self.handle:
@@ -188,6 +209,16 @@ class SegmentReader:
             self.handle, term, docs.ctypes.data, None if freqs is None else freqs.ctypes.data,
             docs.size, C.byref(cnt)), "irs_hip_decode_term")
         return docs[:cnt.value], (None if freqs is None else freqs[:cnt.value])
+
+    def decode_positions(self, term: int):
+        """Every position of every doc of the term, doc after doc (term_meta::freq values)."""
+        n = int(self.metas[term]["freq"])
+        out = np.zeros(max(n, 1), np.uint32)
+        cnt = C.c_uint64()
+        _lib.check(self.L, self.L.irs_hip_decode_positions(
+            self.handle, term, out.ctypes.data, out.size, C.byref(cnt)),
+            "irs_hip_decode_positions")
+        return out[:cnt.value]
 
     def bit_union(self, terms, n_words: int, initial=None):
         """postings_reader::bit_union: (bitset as uint64 words, sum of docs_count)."""
@@ -231,10 +262,11 @@ class QueryBatch:
         at = 0
         for q, p in enumerate(prepared):
             self.queries[q] = (p.op, len(p.terms), at, self.k, p.min_match)
-            for t, (kind, c0, nc, nl) in zip(p.terms, p.scorers):
+            offs = p.offsets if p.offsets is not None else [0] * len(p.terms)
+            for t, (kind, c0, nc, nl), off in zip(p.terms, p.scorers, offs):
                 for s, sr in enumerate(self.segs):       # same scorer, the segment's own ordinal
                     present = t is not None and 0 <= t < len(sr.metas)
-                    self.terms[s, at] = (t if present else NO_TERM, kind, c0, nc, nl)
+                    self.terms[s, at] = (t if present else NO_TERM, kind, c0, nc, nl, off)
                 at += 1
         h = C.c_void_p()
         handles = (C.c_void_p * len(self.segs))(*[sr.handle for sr in self.segs])
@@ -328,6 +360,22 @@ def prepare(filters, scorer, segment_stats):
     ttf = sum(s.total_term_freq for s in segment_stats)
     out = []
     for flt in filters:
+        if isinstance(flt, by_phrase):
+            # FixedPrepareCollect (phrase_filter.cpp:212-293): term_stats.finish() of every
+            # phrase term lands in ONE stats blob — BM25::collect / TFIDF::collect do
+            # `idf +=` (bm25.cpp:381-383, tfidf.cpp:272-275), the norm constants are equal
+            idf = f32(0)
+            stats = None
+            for t in flt.terms:
+                dwt = sum(int(st.docs_count[t]) for st in segment_stats
+                          if 0 <= t < len(st.docs_count))
+                stats = scorer.collect(dwf, dwt, ttf)
+                idf = f32(idf + stats.idf)
+            one = scorer.term_scorer(TermStats(idf, stats.norm_const, stats.norm_length),
+                                     flt.boost)
+            out.append(PreparedQuery(OP_PHRASE, list(flt.terms), [one] * len(flt.terms), 0,
+                                     [int(o) for o in flt.offsets]))
+            continue
         op, subs = _terms_of(flt)
         scorers = []
         for s in subs:

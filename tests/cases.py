@@ -10,7 +10,7 @@ import pytest
 import oracle
 import parity
 from iresearch_amd import _lib, search, synth
-from iresearch_amd.search import BM25, TFIDF, And, Or, by_term
+from iresearch_amd.search import BM25, TFIDF, And, Or, by_phrase, by_term
 
 GOLDEN = __import__("pathlib").Path(__file__).parent / "golden"
 
@@ -628,6 +628,227 @@ def case_merge_ties(L, n_lists=5, nq=7, k=64, seed=11):
 
 
 # ------------------------------------------------------------------ errors --
+
+# --------------------------------------------------------------- positions --
+
+def _random_pos_list(rng, n, num_docs, max_tf, max_pos=400):
+    d = np.sort(rng.choice(np.arange(1, num_docs + 1), n, replace=False)).astype(np.uint32)
+    f = rng.integers(1, max_tf + 1, n).astype(np.uint32)
+    p = np.concatenate([np.sort(rng.choice(np.arange(1, max_pos), int(k), replace=False))
+                        for k in f]).astype(np.uint32)
+    return d, f, p
+
+
+def case_decode_positions(L, layout):
+    """irs_hip_decode_positions == the emitter's input == the oracle's position iterator
+    (position::next / refill / read_tail_block, formats_10.cpp:1515-1633): synthetic corpus
+    plus explicit lists hitting every framing case of the `.pos` stream."""
+    seg = synth.build_segment(20_000, 96, keep_postings=True, with_positions=True, layout=layout)
+    ver = C.c_int32()
+    assert oracle.lib().orc_check_pos_header(seg.pos_file.ctypes.data, seg.pos_file.size,
+                                             C.byref(ver)) > 0
+    sr = search.SegmentReader.from_synth(seg, L=L)
+    for r in (1, 2, 3, 9, 40, 95, 96):
+        got = sr.decode_positions(r - 1)
+        assert np.array_equal(got, seg.positions[r]), ("positions", layout, r)
+        assert np.array_equal(got, oracle.decode_positions(seg.doc_file, seg.pos_file,
+                                                           seg.meta(r), layout)), ("oracle", r)
+        # the skip() path of the reference (docs not drained) agrees on the drained ones
+        part = oracle.decode_positions(seg.doc_file, seg.pos_file, seg.meta(r), layout, stride=5)
+        keep = part != 0
+        assert np.array_equal(got[keep], part[keep])
+    sr.close()
+
+    rng = np.random.default_rng(5)
+    N = 3000
+    lists = [
+        _random_pos_list(rng, 1, N, 1),        # single doc, one position (nothing but a vint)
+        _random_pos_list(rng, 1, N, 300),      # single doc, possibly > 128 positions
+        _random_pos_list(rng, 64, N, 2),       # < 128 positions in all: tail only
+        _random_pos_list(rng, 128, N, 1),      # exactly one pos block, tail_start invalid
+        _random_pos_list(rng, 129, N, 3),
+        _random_pos_list(rng, 700, N, 6),
+        _random_pos_list(rng, 2500, N, 4),
+    ]
+    # total frequency exactly 128 over 64 docs; constant deltas -> ALL_EQUAL pos blocks
+    d = np.arange(1, 65, dtype=np.uint32)
+    lists.append((d, np.full(64, 2, np.uint32), np.tile(np.array([3, 6], np.uint32), 64)))
+    d = np.arange(1, 601, dtype=np.uint32)
+    lists.append((d, np.full(600, 3, np.uint32), np.tile(np.array([7, 14, 21], np.uint32), 600)))
+    # wide values: positions up to 2^31 (32-bit packed blocks)
+    d, f, _ = _random_pos_list(rng, 300, N, 2)
+    p = np.concatenate([np.cumsum(rng.integers(1, 2**30, int(k))) for k in f]).astype(np.uint32)
+    lists.append((d, f, p))
+    seg = synth.segment_from_lists(lists, N, layout)
+    sr = search.SegmentReader.from_synth(seg, L=L)
+    for t, (d, f, p) in enumerate(lists):
+        assert_decode(sr, seg, t, d, f)
+        got = sr.decode_positions(t)
+        assert np.array_equal(got, p), ("explicit positions", layout, t)
+        assert np.array_equal(got, oracle.decode_positions(seg.doc_file, seg.pos_file,
+                                                           seg.metas[t], layout)), t
+    # skip data of a POS field: pend_pos / pos_ptr of every level-0 entry (ReadState
+    # :1063-1080) are consistent with the frequencies
+    last, ptrs, pend, pptr = oracle.read_skip0_pos(seg.doc_file, seg.metas[6])
+    cum = np.cumsum(lists[6][1])
+    assert np.array_equal(pend, cum[127::128][:len(pend)] % 128)
+    assert (np.diff(pptr.astype(np.int64)) >= 0).all()
+    last_gpu, _ = sr.term_directory(6)
+    assert np.array_equal(last_gpu[:len(last)], last)
+    sr.close()
+
+
+def run_phrases(L, seg, phrases, scorer, k, sr=None, cap=0):
+    own = sr is None
+    sr = sr or search.SegmentReader.from_synth(seg, L=L)
+    prep = search.prepare(phrases, scorer, [parity.segment_stats(seg)])
+    b = sr.batch(prep, k)
+    if cap:
+        b.configure(0, 0, cap)
+    hits, counts, totals = b.run().results()
+    parity.check_phrase_segment(seg, phrases, scorer, k, hits, counts, totals)
+    reruns = b.reruns()
+    b.close()
+    if own:
+        sr.close()
+    return hits, counts, totals, reruns
+
+
+def case_phrase_queries(L, layout, num_docs=30_000):
+    """by_phrase with fixed offsets (FixedPhraseQuery::execute, phrase_query.cpp:44-111;
+    PhraseIterator + FixedPhraseFrequency, phrase_iterator.hpp:75-166, 540-626) against
+    the oracle's restatement: exact hit counts and phrase frequencies, scores <= 1e-5."""
+    seg = synth.build_segment(num_docs, 128, with_positions=True, layout=layout)
+    sr = search.SegmentReader.from_synth(seg, L=L)
+    phrases = [
+        by_phrase([0, 1]), by_phrase([2, 0]), by_phrase([0, 0]),         # "a a": one term twice
+        by_phrase([1, 4, 0]), by_phrase([0, 3], [0, 3]),                  # a gap of two words
+        by_phrase([9, 19]), by_phrase([0, 1, 2, 3]), by_phrase([5]),      # one word
+        by_phrase([0, 1, 0, 2, 1, 0, 3, 0], [0, 1, 2, 4, 5, 7, 8, 9]),    # the longest allowed
+        by_phrase([120, 127]),                                             # (almost) no match
+        by_phrase([0, 1], boost=2.5), by_phrase([1, 0, 1], [0, 2, 4]),
+        by_phrase([3, 10_000]),                                            # a term absent here
+    ]
+    for scorer in (BM25(), BM25(1.2, 0.0), BM25(0.0, 0.0), TFIDF(False), TFIDF(True)):
+        for k in (10, 1000):
+            run_phrases(L, seg, phrases, scorer, k, sr=sr)
+    # more matches than candidate slots: the buffer grows and the batch is re-run, exact
+    _, _, totals, reruns = run_phrases(L, seg, phrases[:3], BM25(), 16, sr=sr, cap=64)
+    assert reruns >= 1 and int(totals.max()) > 64
+    sr.close()
+
+
+def case_phrase_ragged(L, layout=synth.LAYOUT_SIMD4):
+    """Explicit lists: single-doc terms, lists shorter than a block, phrases that exist
+    only across block / tile borders, very frequent terms in one doc."""
+    N = 9000
+    rng = np.random.default_rng(3)
+    a = _random_pos_list(rng, 4000, N, 5, 60)
+    b = _random_pos_list(rng, 3500, N, 5, 60)
+    c = _random_pos_list(rng, 90, N, 3, 60)
+    one = (np.array([2049], np.uint32), np.array([3], np.uint32), np.array([5, 6, 9], np.uint32))
+    # a doc in which both terms occur 200 times, interleaved: "x y" matches 200 times
+    dd = np.array([7, 2048, 2049, 8999], np.uint32)
+    x = (dd, np.full(4, 200, np.uint32), np.tile(np.arange(1, 401, 2, dtype=np.uint32), 4))
+    y = (dd, np.full(4, 200, np.uint32), np.tile(np.arange(2, 402, 2, dtype=np.uint32), 4))
+    lists = [a, b, c, one, x, y]
+    seg = synth.segment_from_lists(lists, N, layout, norms=np.full(N, 255, np.uint8))
+    phrases = [by_phrase([0, 1]), by_phrase([1, 0]), by_phrase([0, 2]), by_phrase([2, 1, 0]),
+               by_phrase([3, 3]), by_phrase([0, 3]), by_phrase([4, 5]), by_phrase([5, 4]),
+               by_phrase([4, 5, 4]), by_phrase([4, 4], [0, 2]), by_phrase([3, 4], [0, 2])]
+    for scorer in (BM25(), TFIDF(True)):
+        for k in (3, 100):
+            run_phrases(L, seg, phrases, scorer, k)
+
+
+def case_phrase_multi_segment(L, sizes=(12_000, 5_000, 30_000), k=50):
+    """One batch over several segments of one device (irs_hip_batch_create_multi): every
+    segment's phrase results equal its own run and the oracle's multi-segment harness."""
+    segs, first = [], 0
+    for n in sizes:
+        segs.append(synth.build_segment(n, 64, first_doc=first, with_positions=True))
+        first += n
+    srs = [search.SegmentReader.from_synth(s, L=L) for s in segs]
+    phrases = [by_phrase([0, 1]), by_phrase([2, 1, 0]), by_phrase([7, 3]), by_phrase([0, 5], [0, 2])]
+    stats = [parity.segment_stats(s) for s in segs]
+    scorer = BM25()
+    prep = search.prepare(phrases, scorer, stats)
+    b = search.QueryBatch(srs, prep, k)
+    hits, counts, totals = b.run().results()
+    for i, s in enumerate(segs):
+        parity.check_phrase_segment(s, phrases, scorer, k, hits[i], counts[i], totals[i], segs)
+    merged = search.merge_topk_host([(hits[i], counts[i]) for i in range(len(segs))], k)
+    views = [parity.oracle_view(s) for s in segs]
+    osc = parity.oracle_scorer(scorer)
+    for q, ph in enumerate(phrases):
+        metas = np.stack([parity.metas_for(s, ph.terms) for s in segs])
+        oh, total = oracle.search_phrase(views, metas, ph.offsets, osc, k, ph.boost)
+        assert total == int(totals[:, q].sum())
+        assert len(merged[q]) == len(oh)
+        got = np.array([m[0] for m in merged[q]], np.float32)
+        want = np.sort(oh["score"])[::-1]
+        assert np.allclose(got, want, rtol=parity.REL_TOL, atol=0), ("merged scores", q)
+    b.close()
+    for sr in srs:
+        sr.close()
+
+
+def case_phrase_errors(L):
+    seg = synth.build_segment(5000, 32, with_positions=True)
+    plain = synth.build_segment(5000, 32)
+    stats = [parity.segment_stats(seg)]
+    sr = search.SegmentReader.from_synth(seg, L=L)
+    sr_plain = search.SegmentReader.from_synth(plain, L=L)
+    prep = search.prepare([by_phrase([0, 1])], BM25(), stats)
+    with pytest.raises(_lib.IrsHipError) as e:       # the field has no positions
+        sr_plain.batch(prep, 10)
+    assert e.value.status == _lib.EUNSUPPORTED
+    with pytest.raises(_lib.IrsHipError) as e:
+        sr_plain.decode_positions(0)
+    assert e.value.status == _lib.EINVAL
+    mixed = search.prepare([by_phrase([0, 1]), by_term(3)], BM25(), stats)
+    with pytest.raises(_lib.IrsHipError) as e:       # phrase and boolean queries do not mix
+        sr.batch(mixed, 10)
+    assert e.value.status == _lib.EUNSUPPORTED
+    long = search.prepare([by_phrase(list(range(_lib.MAX_PHRASE_TERMS + 1)))], BM25(), stats)
+    with pytest.raises(_lib.IrsHipError) as e:
+        sr.batch(long, 10)
+    assert e.value.status == _lib.EINVAL
+    bad = search.prepare([by_phrase([0, 1])], BM25(), stats)
+    bad[0].offsets = [1, 2]                           # not relative to the first term
+    with pytest.raises(_lib.IrsHipError) as e:
+        sr.batch(bad, 10)
+    assert e.value.status == _lib.EINVAL
+
+    def open_with(**kw):
+        args = dict(doc_file=seg.doc_file, metas=seg.metas, num_docs=seg.num_docs,
+                    layout=seg.layout, norms=seg.norms, norm_width=1,
+                    docs_with_field=seg.docs_with_field, total_term_freq=seg.total_term_freq,
+                    L=L, pos_file=seg.pos_file)
+        args.update(kw)
+        return search.SegmentReader(**args)
+
+    pbad = seg.pos_file.copy()
+    pbad[6] ^= 0xFF                                   # format name
+    with pytest.raises(_lib.IrsHipError) as e:
+        open_with(pos_file=pbad)
+    assert e.value.status == _lib.ECORRUPT
+    pbad = seg.pos_file.copy()
+    pbad[int(seg.metas[0]["pos_start"])] = 99         # pos block header: 99 bits
+    with pytest.raises(_lib.IrsHipError) as e:
+        open_with(pos_file=pbad)
+    assert e.value.status == _lib.ECORRUPT
+    metas = seg.metas.copy()
+    metas[0]["pos_end"] += 1                          # tail is not where the blocks end
+    with pytest.raises(_lib.IrsHipError) as e:
+        open_with(metas=metas)
+    assert e.value.status == _lib.ECORRUPT
+    with pytest.raises(_lib.IrsHipError) as e:       # positions without frequencies
+        open_with(has_freq=False)
+    assert e.value.status == _lib.EINVAL
+    sr.close()
+    sr_plain.close()
+
 
 def case_errors(L):
     seg = synth.build_segment(5000, 64)

@@ -26,7 +26,8 @@ def oracle_op(flt, op):
 def oracle_view(seg) -> oracle.SegmentView:
     return oracle.SegmentView(seg.doc_file, seg.norms, seg.layout, seg.num_docs,
                               seg.docs_with_field, seg.total_term_freq,
-                              getattr(seg, "norm_width", 1), getattr(seg, "wand_count", 0))
+                              getattr(seg, "norm_width", 1), getattr(seg, "wand_count", 0),
+                              getattr(seg, "pos_file", None))
 
 
 def segment_stats(seg) -> search.SegmentStats:
@@ -97,3 +98,40 @@ def oracle_topk(segs, filters, scorer, k):
         hits, total = oracle.search(views, metas, op, osc, k, [s.boost for s in subs])
         out.append((hits, total))
     return out
+
+
+
+def check_phrase_segment(seg, phrases, scorer, k, hits, counts, totals, all_segs=None):
+    """by_phrase results of the C ABI on `seg` vs the oracle's exhaustive phrase run
+    (phrase frequency per doc is exact; scores within REL_TOL)."""
+    all_segs = all_segs or [seg]
+    osc = oracle_scorer(scorer)
+    view = oracle_view(seg)
+    dwf = sum(s.docs_with_field for s in all_segs)
+    ttf = sum(s.total_term_freq for s in all_segs)
+    for q, ph in enumerate(phrases):
+        metas = metas_for(seg, ph.terms)
+        dwt = [sum(int(s.metas[t]["docs_count"]) if 0 <= t < len(s.metas) else 0
+                   for s in all_segs) for t in ph.terms]
+        scores, pf = oracle.score_all_phrase(view, metas, ph.offsets, osc, dwf, dwt, ttf, ph.boost)
+        matched = pf > 0
+        n_match = int(matched.sum())
+        assert int(totals[q]) == n_match, ("total hits", q, int(totals[q]), n_match)
+        n = int(counts[q])
+        assert n == min(k, n_match), ("count", q, n, k, n_match)
+        if n == 0:
+            continue
+        h = hits[q, :n]
+        docs = h["doc"].astype(np.int64)
+        assert len(set(docs.tolist())) == n, ("duplicate docs", q)
+        assert matched[docs].all(), ("doc without the phrase returned", q)
+        ref = scores[docs]
+        rel = np.abs(h["score"] - ref) / np.maximum(np.abs(ref), 1e-30)
+        assert rel.max() <= REL_TOL, ("score mismatch", q, float(rel.max()))
+        s, d = h["score"], h["doc"]
+        assert ((s[:-1] > s[1:]) | ((s[:-1] == s[1:]) & (d[:-1] < d[1:]))).all(), ("order", q)
+        ms = np.sort(scores[matched])[::-1]
+        thr = ms[n - 1]
+        must = np.nonzero(matched & (scores > thr * (1 + 2 * REL_TOL)))[0]
+        assert np.isin(must, docs).all(), ("missing doc above the k-th score", q)
+        assert (ref >= thr * (1 - 2 * REL_TOL)).all(), ("doc below the k-th score", q)

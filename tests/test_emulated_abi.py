@@ -92,5 +92,27 @@ def test_merge_ties(simlib):
     cases.case_merge_ties(simlib)
 
 
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_decode_positions(simlib, layout):
+    cases.case_decode_positions(simlib, layout)
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_phrase_queries(simlib, layout):
+    cases.case_phrase_queries(simlib, layout, 12_000)
+
+
+def test_phrase_ragged(simlib):
+    cases.case_phrase_ragged(simlib)
+
+
+def test_phrase_multi_segment(simlib):
+    cases.case_phrase_multi_segment(simlib)
+
+
+def test_phrase_errors(simlib):
+    cases.case_phrase_errors(simlib)
+
+
 def test_errors(simlib):
     cases.case_errors(simlib)
