@@ -793,6 +793,57 @@ def case_phrase_multi_segment(L, sizes=(12_000, 5_000, 30_000), k=50):
         sr.close()
 
 
+def phrase_golden_corpus():
+    """tests/golden/phrase_golden.json: the corpus tests/resources/phrase_sequential.json
+    and the doc sets tests/search/phrase_filter_tests.cpp asserts for its plain-term
+    phrases.  Field `phrase_anl`: text analyzer, locale C, no stopwords -> words at
+    positions 1, 2, ... (doc_generator.hpp:617-625)."""
+    import json
+    g = json.loads((GOLDEN / "phrase_golden.json").read_text())
+    names = [d["name"] for d in g["corpus"]]
+    toks = [d["phrase"].split() for d in g["corpus"]]
+    vocab = sorted({w for t in toks for w in t})
+    lists = []
+    for w in vocab:
+        d, f, p = [], [], []
+        for i, t in enumerate(toks):
+            pos = [j + 1 for j, x in enumerate(t) if x == w]
+            if pos:
+                d.append(i + 1)
+                f.append(len(pos))
+                p.extend(pos)
+        lists.append((np.array(d, np.uint32), np.array(f, np.uint32), np.array(p, np.uint32)))
+    norms = np.array([len(t) for t in toks], np.uint8)
+    return names, vocab, lists, norms, g["vectors"]
+
+
+def case_phrase_reference_vectors(L, layout=synth.LAYOUT_SIMD4):
+    """The reference's own phrase expectations, through the C ABI (and the oracle)."""
+    names, vocab, lists, norms, vectors = phrase_golden_corpus()
+    seg = synth.segment_from_lists(lists, len(names), layout, norms)
+    sr = search.SegmentReader.from_synth(seg, L=L)
+    view = parity.oracle_view(seg)
+    assert len(vectors) >= 7
+    for scorer in (BM25(), TFIDF(True)):
+        phrases, expect = [], []
+        for v in vectors:
+            if any(w not in vocab for w in v["words"]):
+                continue
+            phrases.append(by_phrase([vocab.index(w) for w in v["words"]], v["offsets"]))
+            expect.append(v["docs"])
+        hits, counts, totals, _ = run_phrases(L, seg, phrases, scorer, 64, sr=sr)
+        osc = parity.oracle_scorer(scorer)
+        for q, (ph, want) in enumerate(zip(phrases, expect)):
+            got = sorted(int(d) for d in hits[q, :counts[q]]["doc"])
+            assert [names[d - 1] for d in got] == want, ("golden docs", q, got, want)
+            assert int(totals[q]) == len(want)
+            oh, total = oracle.search_phrase([view], parity.metas_for(seg, ph.terms)[None, :],
+                                             ph.offsets, osc, 64)
+            assert total == len(want)
+            assert [names[d - 1] for d in sorted(int(x) for x in oh["doc"])] == want
+    sr.close()
+
+
 def case_phrase_errors(L):
     seg = synth.build_segment(5000, 32, with_positions=True)
     plain = synth.build_segment(5000, 32)

@@ -102,6 +102,11 @@ def test_phrase_queries(simlib, layout):
     cases.case_phrase_queries(simlib, layout, 12_000)
 
 
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_phrase_reference_vectors(simlib, layout):
+    cases.case_phrase_reference_vectors(simlib, layout)
+
+
 def test_phrase_ragged(simlib):
     cases.case_phrase_ragged(simlib)
 

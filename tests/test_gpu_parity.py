@@ -73,6 +73,34 @@ def test_bit_union(gpulib, layout):
     cases.case_bit_union(gpulib, layout, has_freq=False)
 
 
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_decode_positions(gpulib, layout):
+    cases.case_decode_positions(gpulib, layout)
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_phrase_queries(gpulib, layout):
+    cases.case_phrase_queries(gpulib, layout, 200_000)
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_phrase_reference_vectors(gpulib, layout):
+    cases.case_phrase_reference_vectors(gpulib, layout)
+
+
+def test_phrase_ragged(gpulib):
+    cases.case_phrase_ragged(gpulib)
+    cases.case_phrase_ragged(gpulib, synth.LAYOUT_SCALAR)
+
+
+def test_phrase_multi_segment(gpulib):
+    cases.case_phrase_multi_segment(gpulib, sizes=(120_000, 5_000, 300_000))
+
+
+def test_phrase_errors(gpulib):
+    cases.case_phrase_errors(gpulib)
+
+
 def test_reference_score_orders(gpulib):
     cases.case_reference_score_orders(gpulib)
 

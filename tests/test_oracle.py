@@ -161,3 +161,53 @@ def test_multi_segment_statistics_are_global():
     ties = len(np.unique(a["score"])) < 30
     if not ties:
         assert np.array_equal(np.sort(a["doc"]), docs_b)
+
+
+def test_positions_and_phrase_oracle():
+    """The restated position iterator reproduces the emitter's input (all framings),
+    the phrase iterator equals the set definition of a phrase match, its score is the
+    scorer at tf = phrase frequency with the terms' idf summed (float64 model), and the
+    doc sets the reference's phrase tests assert come out (tests/golden/phrase_golden.json)."""
+    import cases
+    seg = synth.build_segment(20_000, 48, keep_postings=True, with_positions=True)
+    view = parity.oracle_view(seg)
+    for r in (1, 5, 48):
+        for stride in (1, 4):
+            got = oracle.decode_positions(seg.doc_file, seg.pos_file, seg.meta(r), seg.layout,
+                                          stride=stride)
+            keep = got != 0
+            assert np.array_equal(got[keep], seg.positions[r][keep]) and keep.sum() > 0
+            assert stride > 1 or keep.all()
+    D, ttf = seg.docs_with_field, seg.total_term_freq
+    sc = oracle.Scorer(oracle.SCORER_BM25, 1.2, 0.75, 0)
+    for ranks, offs in (([1, 2], [0, 1]), ([3, 1, 2], [0, 1, 2]), ([1, 1], [0, 2]), ([7, 30], [0, 1])):
+        per = []
+        for r in ranks:
+            d, f = seg.postings[r]
+            o = np.concatenate([[0], np.cumsum(f)]).astype(np.int64)
+            per.append({int(d[i]): set(seg.positions[r][o[i]:o[i + 1]].tolist())
+                        for i in range(len(d))})
+        want = {}
+        for doc, p0 in per[0].items():
+            if all(doc in x for x in per[1:]):
+                c = sum(all((q + o) in per[i][doc] for i, o in enumerate(offs)) for q in p0)
+                if c:
+                    want[doc] = c
+        metas = np.array([seg.meta(r) for r in ranks])
+        dwt = [int(seg.meta(r)["docs_count"]) for r in ranks]
+        scores, pf = oracle.score_all_phrase(view, metas, offs, sc, D, dwt, ttf)
+        assert {int(d): int(pf[d]) for d in np.nonzero(pf)[0]} == want
+        idf = sum(math.log1p((D - n + 0.5) / (n + 0.5)) for n in dwt)
+        docs = np.array(sorted(want), np.int64)
+        tf = np.array([want[int(d)] for d in docs], np.float64)
+        dl = seg.norms[docs - 1].astype(np.float64)
+        exact = idf * 2.2 * tf / (tf + 1.2 * (0.25 + 0.75 * dl / (ttf / D)))
+        assert np.allclose(scores[docs], exact, rtol=3e-6)
+    names, vocab, lists, norms, vectors = cases.phrase_golden_corpus()
+    gseg = synth.segment_from_lists(lists, len(names), synth.LAYOUT_SCALAR, norms)
+    gview = parity.oracle_view(gseg)
+    for v in vectors:
+        terms = [vocab.index(w) for w in v["words"]]
+        hits, total = oracle.search_phrase([gview], parity.metas_for(gseg, terms)[None, :],
+                                           v["offsets"], sc, 64)
+        assert [names[d - 1] for d in sorted(int(x) for x in hits["doc"])] == v["docs"]

@@ -23,7 +23,10 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--configs", default="4096:16")
     ap.add_argument("--nocheck", action="store_true")
-    ap.add_argument("--op", default="or", choices=["or", "and", "mm"], help="Or / And / Or(min_match=terms-1)")
+    ap.add_argument("--op", default="or", choices=["or", "and", "mm", "phrase"],
+                    help="Or / And / Or(min_match=terms-1) / by_phrase of --terms consecutive words")
+    ap.add_argument("--lo-rank", type=int, default=16)
+    ap.add_argument("--hi-rank", type=int, default=4096)
     ap.add_argument("--terms", type=int, default=8)
     ap.add_argument("--layout", type=int, default=1, help="0 = scalar (1_5), 1 = simd4 (1_5simd)")
     ap.add_argument("--scorer", default="bm25", choices=["bm25", "tfidf", "bm15"])
@@ -32,12 +35,22 @@ def main():
     import torch
 
     from iresearch_amd import _lib, search, synth
-    from iresearch_amd.search import BM25, TFIDF, And, Or, by_term
+    from iresearch_amd.search import BM25, TFIDF, And, Or, by_phrase, by_term
     L = _lib.bind(ctypes.CDLL(args.lib)) if args.lib else _lib.lib()
-    seg = synth.build_segment(args.docs, 4096, layout=args.layout)
+    t0 = time.perf_counter()
+    seg = synth.build_segment(args.docs, 4096, layout=args.layout,
+                              with_positions=args.op == "phrase")
+    t1 = time.perf_counter()
     sr = search.SegmentReader.from_synth(seg, L=L)
-    ranks = synth.make_queries(args.queries, args.terms, 16, 4096, synth.SEED + 2)
-    if args.op == "and":
+    print("index built in %.1f s, staged in %.2f s (%.0f MB .doc, %.0f MB .pos, %.0f MB in HBM)" % (
+        t1 - t0, time.perf_counter() - t1, seg.doc_file.size / 1e6,
+        0 if seg.pos_file is None else seg.pos_file.size / 1e6, sr.device_bytes() / 1e6),
+        flush=True)
+    ranks = synth.make_queries(args.queries, args.terms, args.lo_rank, args.hi_rank,
+                               synth.SEED + 2)
+    if args.op == "phrase":
+        filters = [by_phrase([int(r) - 1 for r in row]) for row in ranks]
+    elif args.op == "and":
         filters = [And([by_term(int(r) - 1) for r in row]) for row in ranks]
     elif args.op == "mm":
         filters = [Or([by_term(int(r) - 1) for r in row], min_match=args.terms - 1) for row in ranks]
@@ -68,6 +81,8 @@ def main():
               "  score GB/s %.1f  same_hits=%s reruns=%d" % (tile, stride, dt * 1e3, args.queries / dt,
                                                               *avg, alg / avg[2] / 1e6, same,
                                                               b.reruns()), flush=True)
+        print("   hits/query: mean %.0f max %d" % (float(np.mean(totals)), int(np.max(totals))),
+              flush=True)
         b.close()
 
 
