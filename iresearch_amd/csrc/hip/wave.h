@@ -63,6 +63,13 @@ __device__ __forceinline__ uint32_t bcast(uint32_t v, int src_lane) {
   return __shfl(v, src_lane, 64);
 }
 __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+// LDS written by some lanes of this wavefront becomes readable by its other lanes
+// (DS operations of one wavefront execute in order; this stops the compiler reordering).
+__device__ __forceinline__ void sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // A value known to be identical in every lane -> SGPR, so that branches on it
 // are scalar branches instead of exec-mask juggling.

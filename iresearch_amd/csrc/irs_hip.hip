@@ -107,6 +107,8 @@ struct irs_hip_batch {
   uint32_t wg_threads = kDefaultWgThreads;  // threads per pilot/score workgroup
   bool any_and = false;
   bool phrase = false;  // a batch of by_phrase queries (k_phrase instead of k_pilot + k_score)
+  uint32_t n_phrase_wgs = 0;   // k_phrase workgroups: kPhraseWaves lead blocks each
+  DevBuf d_phrase_wgs;
   bool acc32 = true;   // 32-bit fixed-point accumulators are precise enough for every query
   bool scratch_ready = false;
   std::vector<DevQuery> queries;
@@ -317,16 +319,12 @@ bool launch_score_acc(irs_hip_batch* b, rt::stream_t st) {
 
 template<int LAYOUT, int MT>
 bool launch_phrase(irs_hip_batch* b, rt::stream_t st) {
-  const size_t smem = phrase_smem_bytes(b->jt);
-  auto kern = k_phrase<LAYOUT, MT>;
-  if (!big_smem(kern, smem)) return false;
-  const uint32_t cpq = (b->max_tiles + kPhraseChunk - 1) / kPhraseChunk;
-  const uint64_t grid = uint64_t(b->nq) * cpq;
-  if (grid > 0x7FFFFFFFull) return false;
-  RT_LAUNCH(kern, uint32_t(grid), kPhraseThreads, smem, st, b->d_segs.as<DevSegment>(),
-            b->d_queries.as<DevQuery>(), b->d_qterms.as<DevQTerm>(), b->jt, cpq,
-            b->d_first.as<uint32_t>(), b->d_tails.as<DevTail>(), b->d_cands.as<uint64_t>(),
-            b->cand_cap, b->d_cand_count.as<uint32_t>(), b->d_hits.as<unsigned long long>());
+  if (b->n_phrase_wgs == 0) return true;  // no query has all its terms in its segment
+  RT_LAUNCH((k_phrase<LAYOUT, MT>), b->n_phrase_wgs, kPhraseWaves * 64, 0, st,
+            b->d_segs.as<DevSegment>(), b->d_queries.as<DevQuery>(), b->d_qterms.as<DevQTerm>(),
+            b->jt, b->d_phrase_wgs.as<PhraseWg>(), b->d_tails.as<DevTail>(),
+            b->d_cands.as<uint64_t>(), b->cand_cap, b->d_cand_count.as<uint32_t>(),
+            b->d_hits.as<unsigned long long>());
   return rt::last_error_ok();
 }
 template<int LAYOUT>
@@ -338,7 +336,7 @@ bool launch_phrase_terms(irs_hip_batch* b, rt::stream_t st) {
 
 bool ensure_scratch(irs_hip_batch* b) {
   if (b->scratch_ready) return true;
-  if (b->phrase) b->tile = kPhraseTile;
+  if (b->phrase) b->tile = 0x40000000u;  // k_phrase is block driven: one "tile" = the segment
   // 32-bit accumulators halve the LDS per doc: twice the tile at the same residency
   // the largest tile that still lets two workgroups share a CU's 160 KB of LDS
   // (AND / min-match batches also keep a match counter byte per doc)
@@ -927,6 +925,39 @@ int irs_hip_batch_create_multi(irs_hip_segment* const* segs, uint32_t n_segs,
     }
   } catch (...) {
     rc = IRS_HIP_ENOMEM;
+  }
+  if (rc == IRS_HIP_OK && b->phrase) {
+    // k_phrase work list: the lead term of a unit is its rarest one; one wavefront per
+    // 128-posting block of it (+ one for its vint tail / single doc)
+    try {
+      std::vector<PhraseWg> wgs;
+      for (uint32_t u = 0; u < nq; ++u) {
+        const DevQuery& dq = b->queries[u];
+        if (!dq.n_terms) continue;
+        const irs_hip_segment* sg = b->segs[dq.seg];
+        uint32_t best = 0xFFFFFFFFu, items = 0;
+        for (uint32_t j = 0; j < dq.n_terms; ++j) {
+          const DevTerm& t = sg->terms[b->qterms[dq.first_term + j].term];
+          if (t.docs_count < best) {
+            best = t.docs_count;
+            items = t.nblk + ((t.docs_count == 1 || t.tail_n) ? 1u : 0u);
+          }
+        }
+        for (uint32_t it = 0; it < items; it += kPhraseWaves) wgs.push_back(PhraseWg{u, it});
+      }
+      if (wgs.size() > 0x7FFFFFFFull) {
+        rc = IRS_HIP_EUNSUPPORTED;
+      } else if (!wgs.empty()) {
+        b->n_phrase_wgs = uint32_t(wgs.size());
+        if (!b->d_phrase_wgs.alloc(wgs.size() * sizeof(PhraseWg)))
+          rc = IRS_HIP_ENOMEM;
+        else if (!rt::h2d(b->d_phrase_wgs.p, wgs.data(), wgs.size() * sizeof(PhraseWg), nullptr) ||
+                 !rt::sync(nullptr))
+          rc = IRS_HIP_EHIP;
+      }
+    } catch (...) {
+      rc = IRS_HIP_ENOMEM;
+    }
   }
   if (rc == IRS_HIP_OK) {
     if (b->jt == 0) b->jt = 1;

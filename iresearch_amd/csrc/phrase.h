@@ -13,18 +13,15 @@
 // one packed value is extracted by itself (both layouts).  P of a doc's first position
 // is the exclusive prefix sum of the frequencies in front of it: per 128-doc block that
 // sum is precomputed at open (DevSegment::blk_pos), inside the block one wavefront scan
-// gives the rest.  So a doc tile decodes every (term, block) exactly like k_score does,
-// records (P, tf) per doc slot in LDS, and only docs holding ALL phrase terms ever touch
-// the position stream.
+// gives the rest.  So the conjunction of the phrase's terms is formed from the doc blocks
+// alone (k_phrase below), with (P, tf) riding along, and only docs holding ALL phrase terms
+// ever touch the position stream.
 #pragma once
 #include "kernels.h"
 
 namespace irs_hip {
 
-constexpr uint32_t kPhraseTile = 2048;     // docs per LDS tile
 constexpr uint32_t kPhraseMaxTerms = 8;    // IRS_HIP_MAX_PHRASE_TERMS
-constexpr uint32_t kPhraseChunk = 8;       // tiles per workgroup
-constexpr uint32_t kPhraseThreads = 256;
 
 // Value j (0..127) of one packed block payload of `bits` (1..32) bits per value:
 // packed::at for the scalar layout (bit_packing.hpp), the same for simdcomp's 4-lane one.
@@ -220,159 +217,221 @@ __device__ __forceinline__ float phrase_score(const DevSegment& seg, const DevQT
   }
 }
 
-constexpr uint32_t phrase_smem_bytes(uint32_t m) {
-  return m * kPhraseTile * 8u + kPhraseTile * 2u;
+constexpr uint32_t kPhraseWaves = 4;  // wavefronts (= lead blocks) per workgroup
+
+// One workgroup of k_phrase: kPhraseWaves consecutive lead blocks of one unit.
+struct PhraseWg {
+  uint32_t unit;        // (segment, query) execution unit
+  uint32_t first_item;  // index of the workgroup's first lead block
+};
+
+// #{i < n : sorted[i] <= x}
+__device__ __forceinline__ uint32_t count_le(const uint32_t* sorted, uint32_t n, uint32_t x) {
+  uint32_t a = 0, b = n;
+  while (a < b) {
+    const uint32_t mid = (a + b) >> 1;
+    if (sorted[mid] <= x) a = mid + 1; else b = mid;
+  }
+  return a;
 }
 
-// One workgroup = kPhraseChunk consecutive doc tiles of one (segment, query) unit.
-// Per tile:
-//   1. every (term, block) reaching the tile is decoded by one wavefront; each posting
-//      inside the tile leaves (P, tf) in its doc slot of the term's LDS row;
-//   2. slots holding ALL terms (the conjunction PhraseIterator::next runs first) are
-//      compacted, and one thread per such doc merges the terms' position lists
-//      (FixedPhraseFrequency::NextPosition): phrase frequency = #{p in lead : p + off_i in
+// by_phrase, block driven.  The conjunction PhraseIterator::next runs first
+// (phrase_iterator.hpp:590-596) is bounded by its rarest member — the reason Conjunction
+// sorts its iterators by cost (conjunction.hpp:450-453) and lets the cheapest LEAD while
+// the others seek().  Here ONE WAVEFRONT owns one 128-posting block (or the vint tail)
+// of the lead term:
+//   1. it decodes the lead block: 128 ascending docs into LDS, (P, tf) of each into the
+//      lead's row;
+//   2. for every other term it finds the blocks that can hold one of those docs — what
+//      seek() does through the skip list (skip_list.hpp:208-249): binary search of the
+//      block directory for the first block reaching the lead block's first doc, then 64
+//      directory entries per step, a lane each, tested against the lead docs ("is any of
+//      them in (previous last, last]"); only the blocks that pass are decoded, and each
+//      decoded posting looks its doc up among the 128 lead docs (binary search in LDS):
+//      a hit leaves (P, tf) in the term's row;
+//   3. lead docs that every term reached are the conjunction's matches: one lane each
+//      merges the terms' position lists (FixedPhraseFrequency::NextPosition,
+//      phrase_iterator.hpp:109-151): phrase frequency = #{p in first term : p + off_i in
 //      term i for all i};
-//   3. matches are scored with tf = phrase frequency and appended to the unit's candidates
-//      (all of them: k_select picks the top k).
-// MT = compile-time bound of the phrase length (cursor state stays in registers).
+//   4. matches are scored with tf = phrase frequency and appended to the unit's
+//      candidates (all of them: k_select picks the top k).
+// No barrier after the prologue: wavefronts are independent.  MT = compile-time bound of
+// the phrase length (cursor state stays in registers).
 template<int LAYOUT, int MT>
-__global__ void __launch_bounds__(kPhraseThreads)
+__global__ void __launch_bounds__(kPhraseWaves * 64)
 k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms, uint32_t jt,
-         uint32_t cpq, const uint32_t* first, const DevTail* tails, uint64_t* cands,
-         uint32_t cand_cap, uint32_t* cand_count, unsigned long long* hits) {
-  RT_DYN_SMEM(smem);
+         const PhraseWg* wgs, const DevTail* tails, uint64_t* cands, uint32_t cand_cap,
+         uint32_t* cand_count, unsigned long long* hits) {
   __shared__ DevPosTerm s_pt[MT];
   __shared__ DevTail s_tl[MT];
   __shared__ uint32_t s_off[MT];
-  __shared__ uint32_t s_n;
+  __shared__ uint32_t s_docs[kPhraseWaves][kBlock];
+  __shared__ uint32_t s_pidx[kPhraseWaves][MT][kBlock];
+  __shared__ uint32_t s_tf[kPhraseWaves][MT][kBlock];
   const uint32_t tid = threadIdx.x;
   const unsigned lane = tid & 63u;
-  const uint32_t wv = tid >> 6, nw = blockDim.x >> 6;
-  const uint32_t unit = blockIdx.x / cpq, chunk = blockIdx.x % cpq;
+  const uint32_t wv = tid >> 6;
+  const PhraseWg wg = wgs[blockIdx.x];
+  const uint32_t unit = wg.unit;
   const DevQuery qd = queries[unit];
   const uint32_t m = qd.n_terms;
-  if (m == 0 || m > uint32_t(MT) || chunk * kPhraseChunk >= qd.n_tiles) return;  // uniform
   const DevSegment seg = segs[qd.seg];
-  uint32_t* s_pidx = reinterpret_cast<uint32_t*>(smem);        // [m][kPhraseTile]
-  uint32_t* s_tf = s_pidx + m * kPhraseTile;                   // [m][kPhraseTile]
-  uint16_t* s_list = reinterpret_cast<uint16_t*>(s_tf + m * kPhraseTile);  // [kPhraseTile]
-  if (tid < m) {
+  if (tid < m && tid < uint32_t(MT)) {
     s_tl[tid] = tails[uint64_t(unit) * jt + tid];
     s_pt[tid] = seg.pterms[s_tl[tid].term];
     s_off[tid] = qterms[qd.first_term + tid].pad0;  // desired offset in the phrase
   }
   const DevQTerm qt = qterms[qd.first_term];  // the phrase's scorer rides on its first term
   __syncthreads();
-  uint32_t my_hits = 0;
-  uint32_t tile_end = (chunk + 1u) * kPhraseChunk;
-  if (tile_end > qd.n_tiles) tile_end = qd.n_tiles;
-  for (uint32_t tile = chunk * kPhraseChunk; tile < tile_end; ++tile) {
-    const uint32_t lo = kDocMin + tile * kPhraseTile;
-    const uint32_t hi = lo + (kPhraseTile - 1u);
-    for (uint32_t i = tid; i < m * kPhraseTile; i += blockDim.x) s_tf[i] = 0u;
-    if (tid == 0) s_n = 0u;
-    __syncthreads();
-    // ---- 1. postings -> (P, tf) per doc slot
-    uint32_t c = 0;  // work item counter, the same in every wavefront
-    const uint32_t* row = first + qd.first_off + uint64_t(tile) * jt;
-    for (uint32_t i = 0; i < m; ++i) {
-      const DevTail tl = s_tl[i];
-      if (tl.nblk) {
-        const uint32_t b0 = row[i];
-        uint32_t b1 = row[jt + i];  // a block may straddle the tile's end
-        if (b1 > tl.nblk - 1u) b1 = tl.nblk - 1u;
-        for (uint32_t b = b0; b <= b1; ++b) {
-          if ((c++ % nw) != wv) continue;
-          const uint64_t e = tl.dir_off + b;
+  if (m == 0 || m > uint32_t(MT)) return;
+  uint32_t lead = 0, lead_n = 0xFFFFFFFFu;  // the term with the fewest postings leads
+  for (uint32_t i = 0; i < m; ++i) {
+    const uint32_t n = s_tl[i].nblk * kBlock + s_tl[i].n;
+    if (n < lead_n) { lead_n = n; lead = i; }
+  }
+  const DevTail ld = s_tl[lead];
+  const uint32_t item = wg.first_item + wv;
+  if (item >= ld.nblk + (ld.n ? 1u : 0u)) return;  // whole wavefront
+  uint32_t* docs = s_docs[wv];
+
+  // ---- 1. the lead block: entry index 2*lane + h (block) or lane + 64*h (tail)
+  uint32_t n = kBlock, e0, estep;
+  {
+    uint32_t d[2], f[2], p[2];
+    if (item < ld.nblk) {
+      const uint64_t e = ld.dir_off + item;
+      const uint32_t bits = seg.blk_bits[e];
+      const uint32_t base = item ? seg.blk_last[e - 1] : kDocMin;
+      decode_block<LAYOUT, true>(seg.doc + ld.doc_start + seg.blk_off[e], bits & 0xFFu,
+                                 bits >> 8, base, lane, d[0], d[1], f[0], f[1]);
+      const uint32_t incl = wave::inclusive_scan(f[0] + f[1]);
+      p[0] = seg.blk_pos[e] - seg.blk_pos[ld.dir_off] + incl - f[0] - f[1];
+      p[1] = p[0] + f[0];
+      e0 = 2u * lane;
+      estep = 1u;
+    } else {
+      n = ld.n;
+      // positions in front of the tail = all frequencies of the full blocks (0 for a
+      // list without blocks, whose dir_off has no rows of its own)
+      const uint32_t base = seg.blk_pos[ld.dir_off + ld.nblk] - seg.blk_pos[ld.dir_off];
+      tail_pidx(seg, ld.term, n, base, lane, d, f, p);
+      e0 = lane;
+      estep = 64u;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t idx = e0 + uint32_t(h) * estep;
+      docs[idx] = idx < n ? d[h] : 0xFFFFFFFFu;
+      for (uint32_t i = 0; i < m; ++i) {
+        s_pidx[wv][i][idx] = i == lead ? p[h] : 0u;
+        s_tf[wv][i][idx] = (i == lead && idx < n) ? f[h] : 0u;
+      }
+    }
+  }
+  wave::sync();
+  const uint32_t dlo = docs[0], dhi = docs[n - 1];
+
+  // a decoded posting of term i: is its doc one of the lead docs?
+  auto put = [&](uint32_t i, uint32_t doc, uint32_t f, uint32_t p) {
+    if (f == 0 || doc < dlo || doc > dhi) return;
+    const uint32_t c = count_le(docs, n, doc);
+    if (c && docs[c - 1] == doc) {
+      s_pidx[wv][i][c - 1] = p;
+      s_tf[wv][i][c - 1] = f;
+    }
+  };
+  // ---- 2. the other terms
+  for (uint32_t i = 0; i < m; ++i) {
+    if (i == lead) continue;
+    const DevTail tl = s_tl[i];
+    if (tl.nblk) {
+      const uint32_t* last = seg.blk_last + tl.dir_off;
+      uint32_t a = 0, b = tl.nblk;  // lower_bound(last, dlo): first block reaching dlo
+      while (a < b) {
+        const uint32_t mid = (a + b) >> 1;
+        if (last[mid] < dlo) a = mid + 1; else b = mid;
+      }
+      for (uint32_t b0 = a; b0 < tl.nblk; b0 += 64) {
+        const uint32_t bl = b0 + lane;
+        const bool valid = bl < tl.nblk;
+        const uint32_t lst = valid ? last[bl] : 0xFFFFFFFFu;
+        const uint32_t prv = (valid && bl) ? last[bl - 1] : 0u;  // block holds docs in (prv, lst]
+        const bool reach = valid && prv < dhi;
+        const bool want = reach && count_le(docs, n, lst) > count_le(docs, n, prv);
+        uint64_t mask = wave::ballot(want);
+        const bool more = wave::ballot(valid && !reach) == 0;  // no block started behind dhi yet
+        while (mask) {
+          const uint32_t k = uint32_t(__builtin_ctzll(mask));
+          mask &= mask - 1;
+          const uint64_t e = tl.dir_off + b0 + k;
           const uint32_t bits = seg.blk_bits[e];
-          const uint32_t base = b ? seg.blk_last[e - 1] : kDocMin;
+          const uint32_t base = (b0 + k) ? seg.blk_last[e - 1] : kDocMin;
           uint32_t d0, d1, f0, f1;
           decode_block<LAYOUT, true>(seg.doc + tl.doc_start + seg.blk_off[e], bits & 0xFFu,
                                      bits >> 8, base, lane, d0, d1, f0, f1);
           const uint32_t incl = wave::inclusive_scan(f0 + f1);
           const uint32_t p0 = seg.blk_pos[e] - seg.blk_pos[tl.dir_off] + incl - f0 - f1;
-          const uint32_t x0 = d0 - lo, x1 = d1 - lo;  // doc < lo wraps to a huge value
-          if (x0 < kPhraseTile) {
-            s_pidx[i * kPhraseTile + x0] = p0;
-            s_tf[i * kPhraseTile + x0] = f0;
-          }
-          if (x1 < kPhraseTile) {
-            s_pidx[i * kPhraseTile + x1] = p0 + f0;
-            s_tf[i * kPhraseTile + x1] = f1;
-          }
+          put(i, d0, f0, p0);
+          put(i, d1, f1, p0 + f0);
         }
-      }
-      if (tl.n && tl.first_doc <= hi && tl.last_doc >= lo) {  // vint tail / single doc
-        if ((c++ % nw) == wv) {
-          // positions in front of the tail = all frequencies of the full blocks
-          // (0 for a list without blocks, whose dir_off has no rows of its own)
-          const uint32_t base = seg.blk_pos[tl.dir_off + tl.nblk] - seg.blk_pos[tl.dir_off];
-          uint32_t d[2], f[2], p[2];
-          tail_pidx(seg, tl.term, tl.n, base, lane, d, f, p);
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const uint32_t x = d[h] - lo;
-            if (f[h] && x < kPhraseTile) {
-              s_pidx[i * kPhraseTile + x] = p[h];
-              s_tf[i * kPhraseTile + x] = f[h];
-            }
-          }
-        }
+        if (!more) break;
       }
     }
-    __syncthreads();
-    // ---- 2. conjunction: doc slots every term reached
-    for (uint32_t s = tid; s < kPhraseTile; s += blockDim.x) {
-      bool all = true;
-      for (uint32_t i = 0; i < m; ++i) all = all && s_tf[i * kPhraseTile + s] != 0u;
-      if (all) s_list[atomicAdd(&s_n, 1u)] = uint16_t(s);
+    if (tl.n && tl.first_doc <= dhi && tl.last_doc >= dlo) {  // vint tail / single doc
+      const uint32_t base = seg.blk_pos[tl.dir_off + tl.nblk] - seg.blk_pos[tl.dir_off];
+      uint32_t d[2], f[2], p[2];
+      tail_pidx(seg, tl.term, tl.n, base, lane, d, f, p);
+      put(i, d[0], f[0], p[0]);
+      put(i, d[1], f[1], p[1]);
     }
-    __syncthreads();
-    const uint32_t n_match = s_n;
-    for (uint32_t k = tid; k < n_match; k += blockDim.x) {
-      const uint32_t s = s_list[k];
-      uint32_t P[MT], T[MT], K[MT], V[MT];
+  }
+  wave::sync();
+
+  // ---- 3./4. lead docs every term reached: merge the position lists, score, emit
+  uint32_t my_hits = 0;
+  for (uint32_t s = lane; s < n; s += 64) {
+    uint32_t P[MT], T[MT], K[MT], V[MT];
+    bool all = true;
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const bool on = uint32_t(i) < m;
-        P[i] = on ? s_pidx[i * kPhraseTile + s] : 0u;
-        T[i] = on ? s_tf[i * kPhraseTile + s] : 0u;
-        K[i] = 0u;
-        V[i] = 0u;  // pos_limits::invalid()
-      }
-      // FixedPhraseFrequency::NextPosition (phrase_iterator.hpp:109-151).  Its
-      // lead.seek(sought - offset) only skips lead positions that cannot match; walking
-      // every lead position counts the same matches.
-      uint32_t pf = 0, lead = 0;
-      bool done = false;
-      for (uint32_t a = 0; a < T[0] && !done; ++a) {
-        lead += pos_delta<LAYOUT>(seg, s_pt[0], s_tl[0].term, P[0] + a);  // lead.next()
-        bool match = true;
+    for (int i = 0; i < MT; ++i) {
+      const bool on = uint32_t(i) < m;
+      P[i] = on ? s_pidx[wv][i][s] : 0u;
+      T[i] = on ? s_tf[wv][i][s] : 0u;
+      K[i] = 0u;
+      V[i] = 0u;  // pos_limits::invalid()
+      all = all && (!on || T[i] != 0u);
+    }
+    if (!all) continue;
+    // Walking every position of the first term counts the same matches as the
+    // reference's lead.seek(sought - offset), which only skips positions that cannot match.
+    uint32_t pf = 0, head = 0;
+    bool done = false;
+    for (uint32_t a = 0; a < T[0] && !done; ++a) {
+      head += pos_delta<LAYOUT>(seg, s_pt[0], s_tl[0].term, P[0] + a);  // lead.next()
+      bool match = true;
 #pragma unroll
-        for (int i = 1; i < MT; ++i) {
-          if (uint32_t(i) < m && match && !done) {
-            const uint32_t target = lead + s_off[i];
-            if (target < lead) { done = true; break; }  // !pos_limits::valid(term_position)
-            // position::seek(target) :1578-1604
-            while (V[i] < target && K[i] < T[i]) {
-              V[i] += pos_delta<LAYOUT>(seg, s_pt[i], s_tl[i].term, P[i] + K[i]);
-              ++K[i];
-            }
-            if (V[i] < target) done = true;           // exhausted: no later lead can match
-            else if (V[i] != target) match = false;   // sought too far from the lead
+      for (int i = 1; i < MT; ++i) {
+        if (uint32_t(i) < m && match && !done) {
+          const uint32_t target = head + s_off[i];
+          if (target < head) { done = true; break; }  // !pos_limits::valid(term_position)
+          // position::seek(target) :1578-1604
+          while (V[i] < target && K[i] < T[i]) {
+            V[i] += pos_delta<LAYOUT>(seg, s_pt[i], s_tl[i].term, P[i] + K[i]);
+            ++K[i];
           }
+          if (V[i] < target) done = true;           // exhausted: no later position can match
+          else if (V[i] != target) match = false;   // sought too far
         }
-        if (match && !done) ++pf;
       }
-      if (pf) {
-        const uint32_t doc = lo + s;
-        const float score = phrase_score(seg, qt, pf, doc);
-        const uint32_t slot = atomicAdd(&cand_count[unit], 1u);
-        if (slot < cand_cap) cands[uint64_t(unit) * cand_cap + slot] = make_key(score, doc);
-        ++my_hits;
-      }
+      if (match && !done) ++pf;
     }
-    __syncthreads();
+    if (pf) {
+      const uint32_t doc = docs[s];
+      const float score = phrase_score(seg, qt, pf, doc);
+      const uint32_t slot = atomicAdd(&cand_count[unit], 1u);
+      if (slot < cand_cap) cands[uint64_t(unit) * cand_cap + slot] = make_key(score, doc);
+      ++my_hits;
+    }
   }
   my_hits = wave::reduce_add(my_hits);
   if (lane == 0 && my_hits) atomicAdd(&hits[unit], static_cast<unsigned long long>(my_hits));

@@ -38,6 +38,8 @@ __device__ __forceinline__ uint32_t bcast(uint32_t v, int src_lane) {
   return __shfl(v, src_lane, 64);
 }
 __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+// wavefront-level rendezvous: every lane (fiber) arrives before any goes on
+__device__ __forceinline__ void sync() { (void)__ballot(1); }
 
 // LDS float accumulate without a returned value -> ds_add_f32
 __device__ __forceinline__ void lds_add(float* p, float v) { atomicAdd(p, v); }
