@@ -7,7 +7,7 @@ import pytest
 import cases
 import parity
 from iresearch_amd import search, synth
-from iresearch_amd.search import BM25, Or, by_term
+from iresearch_amd.search import BM25, TFIDF, And, Or, by_phrase, by_term
 
 pytestmark = pytest.mark.gpu
 LAYOUTS = [synth.LAYOUT_SIMD4, synth.LAYOUT_SCALAR]
@@ -154,6 +154,27 @@ def test_config3_or8_top1000_subset(gpulib):
     h1, c1, t1 = cases.run_and_check(gpulib, seg, filters, BM25(), 1000, sr=sr)
     h2, c2, t2 = cases.run_and_check(gpulib, seg, filters, BM25(), 1000, 8192, 4, sr=sr)
     assert np.array_equal(h1, h2) and np.array_equal(c1, c2) and np.array_equal(t1, t2)
+    sr.close()
+
+
+def test_config5_shape_and_phrase_tfidf(gpulib):
+    """BASELINE config 5 shape on one segment of one GPU: AND-of-2..4 and 2-word phrases
+    scored by TF-IDF without norms, on a field with positions (2 M docs), against the oracle.
+    (Block-max WAND pruning, the remaining part of config 5, is not built yet: results are
+    exhaustive, which is what pruning must reproduce.)"""
+    seg = synth.build_segment(2_000_000, 4096, with_positions=True)
+    sr = search.SegmentReader.from_synth(seg, L=gpulib)
+    ands = []
+    for n in (2, 3, 4):
+        for row in synth.make_queries(6, n, 16, 2048, synth.SEED + 5 + n):
+            ands.append(And([by_term(int(r) - 1) for r in row]))
+    cases.run_and_check(gpulib, seg, ands, TFIDF(False), 100, sr=sr)
+    phrases = [by_phrase([int(r) - 1 for r in row])
+               for row in synth.make_queries(24, 2, 4, 512, synth.SEED + 9)]
+    phrases += [by_phrase([int(r) - 1 for r in row])
+                for row in synth.make_queries(8, 3, 2, 64, synth.SEED + 10)]
+    _, _, totals, _ = cases.run_phrases(gpulib, seg, phrases, TFIDF(False), 100, sr=sr)
+    assert int(totals.sum()) > 0
     sr.close()
 
 
