@@ -449,11 +449,14 @@ int irs_hip_segment_open(const irs_hip_segment_desc* d, irs_hip_segment** out) {
       rc = IRS_HIP_ENOMEM;
       break;
     }
-    uint64_t blocks = 0;
+    uint64_t blocks = 0, tail_rows = 0;
     for (uint32_t i = 0; i < d->num_terms && rc == IRS_HIP_OK; ++i) {
       const irs_hip_term_meta& m = d->terms[i];
       DevTerm t{};
       t.docs_count = m.docs_count;
+      t.tail_row = uint32_t(tail_rows);
+      tail_rows += m.docs_count == 1 ? 1u : m.docs_count % kBlock;
+      if (tail_rows > 0xFFFFFF00ull) rc = IRS_HIP_EUNSUPPORTED;
       if (m.docs_count == 1) {
         t.single_doc = kDocMin + uint32_t(m.e_skip_start);  // formats_10.cpp:1887
         t.single_freq = m.freq;
@@ -478,8 +481,7 @@ int irs_hip_segment_open(const irs_hip_segment_desc* d, irs_hip_segment** out) {
         !s->d_terms.alloc(std::max<size_t>(1, s->terms.size()) * sizeof(DevTerm)) ||
         !s->d_blk_off.alloc((blocks + 1) * 4) || !s->d_blk_last.alloc((blocks + 1) * 4) ||
         !s->d_blk_bits.alloc((blocks + 1) * 2) || !s->d_blk_aoff.alloc((blocks + 1) * 4) ||
-        !s->d_tail_docs.alloc((uint64_t(d->num_terms) + 1) * kBlock * 4) ||
-        !s->d_tail_freqs.alloc((uint64_t(d->num_terms) + 1) * kBlock * 4) ||
+        !s->d_tail_docs.alloc((tail_rows + 1) * 4) || !s->d_tail_freqs.alloc((tail_rows + 1) * 4) ||
         !s->d_status.alloc(4)) {
       rc = IRS_HIP_ENOMEM;
       break;
@@ -519,7 +521,7 @@ int irs_hip_segment_open(const irs_hip_segment_desc* d, irs_hip_segment** out) {
                                            : build_directory<kScalar>(s);
     if (rc == IRS_HIP_OK && d->pos_file) {
       std::vector<uint64_t> pos_end;
-      uint64_t rows = 0;
+      uint64_t rows = 0, ptail_rows = 0;
       try {
         s->pterms.resize(d->num_terms);
         pos_end.resize(d->num_terms);
@@ -539,6 +541,9 @@ int irs_hip_segment_open(const irs_hip_segment_desc* d, irs_hip_segment** out) {
           pt.tail_n = m.freq % kBlock;
           pt.row = rows;
           rows += pt.nfull;
+          pt.tail_row = uint32_t(ptail_rows);
+          ptail_rows += pt.tail_n;
+          if (ptail_rows > 0xFFFFFF00ull) rc = IRS_HIP_EUNSUPPORTED;
         }
         s->pterms[i] = pt;
         pos_end[i] = m.pos_end;
@@ -548,7 +553,7 @@ int irs_hip_segment_open(const irs_hip_segment_desc* d, irs_hip_segment** out) {
           !s->d_pterms.alloc(std::max<size_t>(1, s->pterms.size()) * sizeof(DevPosTerm)) ||
           !s->d_pblk_off.alloc((rows + 1) * 4) || !s->d_pblk_bits.alloc(rows + 1) ||
           !s->d_blk_pos.alloc((blocks + 1) * 4) ||
-          !s->d_ptail.alloc((uint64_t(d->num_terms) + 1) * kBlock * 4)) {
+          !s->d_ptail.alloc((ptail_rows + 1) * 4)) {
         rc = IRS_HIP_ENOMEM;
         break;
       }

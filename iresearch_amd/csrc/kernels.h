@@ -60,8 +60,8 @@ k_build_directory(DevSegment seg, DevTerm* terms, uint32_t* blk_off,
   if (t.docs_count == 0) return;
   if (t.docs_count == 1) {  // single_doc_iterator, formats_10.cpp:1876-1890
     if (lane == 0) {
-      tail_docs[uint64_t(term) * kBlock] = t.single_doc;
-      tail_freqs[uint64_t(term) * kBlock] = t.single_freq;
+      tail_docs[t.tail_row] = t.single_doc;
+      tail_freqs[t.tail_row] = t.single_freq;
       terms[term].last_doc = t.single_doc;
       terms[term].tf_bound = t.single_freq;
       terms[term].tail_off = t.doc_start;
@@ -144,8 +144,8 @@ k_build_directory(DevSegment seg, DevTerm* terms, uint32_t* blk_off,
           doc += v;
         }
         // the decoded tail (read_tail_block, formats_10.cpp:1765-1792) is kept per term
-        tail_docs[uint64_t(term) * kBlock + i] = doc;
-        tail_freqs[uint64_t(term) * kBlock + i] = f;
+        tail_docs[t.tail_row + i] = doc;
+        tail_freqs[t.tail_row + i] = f;
       }
       if (cur > seg.doc_len) bad = true;
     }
@@ -412,7 +412,7 @@ k_plan(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms,
     if (threadIdx.x == 0) {
       tl->n = 0; tl->first_doc = 0; tl->last_doc = 0;
       tl->nblk = 0; tl->doc_start = 0; tl->dir_off = 0;
-      tl->term = 0; tl->pad = 0;
+      tl->term = 0; tl->tail_row = 0;
     }
     return;
   }
@@ -434,10 +434,10 @@ k_plan(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms,
     tl->doc_start = t.doc_start;
     tl->dir_off = t.dir_off;
     tl->term = term;
-    tl->pad = 0;
+    tl->tail_row = t.tail_row;
     // the tail's postings were decoded when the segment was opened
     tl->n = t.docs_count == 1 ? 1u : t.tail_n;
-    tl->first_doc = tl->n ? seg.tail_docs[uint64_t(term) * kBlock] : 0u;
+    tl->first_doc = tl->n ? seg.tail_docs[t.tail_row] : 0u;
     tl->last_doc = tl->n ? t.last_doc : 0u;
   }
 }
@@ -1054,8 +1054,8 @@ __device__ __forceinline__ void tile_accumulate(const DevSegment& seg, const Dev
       const float inv_one = 1.f / (qt.norm_const + qt.norm_length * 1.f);
       for (uint32_t i = lane; i < tn; i += 64)
         tile_apply<ACC, TILE, AND>(seg, sm, qt, inv_one,
-                                   seg.tail_docs[uint64_t(tl->term) * kBlock + i],
-                                   seg.tail_freqs[uint64_t(tl->term) * kBlock + i], lo, span,
+                                   seg.tail_docs[tl->tail_row + i],
+                                   seg.tail_freqs[tl->tail_row + i], lo, span,
                                    fx_mul);
     }
   }
@@ -1441,7 +1441,7 @@ k_score(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms,
           if ((tm >> j) & 1u) {
             const DevQTerm qt = sm.qts[j];
             const float inv_one = 1.f / (qt.norm_const + qt.norm_length * 1.f);
-            const uint64_t row = uint64_t(tails_q[j].term) * kBlock;
+            const uint32_t row = tails_q[j].tail_row;
             const uint32_t tn = tc[j].tail_n;
             for (uint32_t i = lane; i < tn; i += 64)
               tile_apply<ACC, TILE, AND>(seg, sm, qt, inv_one, tdocs[row + i], tfreqs[row + i], lo,

@@ -54,7 +54,7 @@ __device__ __forceinline__ uint32_t pos_delta(const DevSegment& seg, const DevPo
     }
     return packed_at<LAYOUT>(blk + 1, bits, idx & 127u);
   }
-  return seg.ptail[uint64_t(term) * kBlock + (idx - (pt.nfull << 7))];  // read_tail_block :1515
+  return seg.ptail[pt.tail_row + (idx - (pt.nfull << 7))];  // read_tail_block :1515
 }
 
 // ------------------------------------------------------------ open time --
@@ -116,7 +116,7 @@ k_pos_directory(DevSegment seg, DevPosTerm* pterms, uint32_t* pblk_off, uint8_t*
     for (uint32_t i = 0; i < pt.tail_n; ++i) {
       if (cur + 1 > seg.pos_len) { bad = true; break; }
       uint32_t len;
-      ptail[uint64_t(term) * kBlock + i] = vint_from(wave::load_u64(seg.pos + cur), &len);
+      ptail[pt.tail_row + i] = vint_from(wave::load_u64(seg.pos + cur), &len);
       cur += len;
     }
     if (cur > seg.pos_len) bad = true;
@@ -127,10 +127,9 @@ k_pos_directory(DevSegment seg, DevPosTerm* pterms, uint32_t* pblk_off, uint8_t*
 
 // (P, tf) of the tail postings this lane owns: entries `lane` and `lane + 64` of the
 // decoded tail (or the single doc).  base = positions in front of the tail.
-__device__ __forceinline__ void tail_pidx(const DevSegment& seg, uint32_t term, uint32_t n,
+__device__ __forceinline__ void tail_pidx(const DevSegment& seg, uint32_t row, uint32_t n,
                                           uint32_t base, unsigned lane, uint32_t (&doc)[2],
                                           uint32_t (&tf)[2], uint32_t (&pidx)[2]) {
-  const uint64_t row = uint64_t(term) * kBlock;
   tf[0] = lane < n ? seg.tail_freqs[row + lane] : 0u;
   tf[1] = lane + 64u < n ? seg.tail_freqs[row + lane + 64u] : 0u;
   doc[0] = lane < n ? seg.tail_docs[row + lane] : 0u;
@@ -164,7 +163,7 @@ k_decode_positions(DevSegment seg, uint32_t term, uint32_t* out) {
   } else if (item == t.nblk) {
     const uint32_t n = t.docs_count == 1 ? 1u : t.tail_n;
     const uint32_t base = seg.blk_pos[t.dir_off + t.nblk] - seg.blk_pos[t.dir_off];
-    tail_pidx(seg, term, n, base, lane, doc, tf, pidx);
+    tail_pidx(seg, t.tail_row, n, base, lane, doc, tf, pidx);
   }
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -314,7 +313,7 @@ k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms
       // positions in front of the tail = all frequencies of the full blocks (0 for a
       // list without blocks, whose dir_off has no rows of its own)
       const uint32_t base = seg.blk_pos[ld.dir_off + ld.nblk] - seg.blk_pos[ld.dir_off];
-      tail_pidx(seg, ld.term, n, base, lane, d, f, p);
+      tail_pidx(seg, ld.tail_row, n, base, lane, d, f, p);
       e0 = lane;
       estep = 64u;
     }
@@ -380,7 +379,7 @@ k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms
     if (tl.n && tl.first_doc <= dhi && tl.last_doc >= dlo) {  // vint tail / single doc
       const uint32_t base = seg.blk_pos[tl.dir_off + tl.nblk] - seg.blk_pos[tl.dir_off];
       uint32_t d[2], f[2], p[2];
-      tail_pidx(seg, tl.term, tl.n, base, lane, d, f, p);
+      tail_pidx(seg, tl.tail_row, tl.n, base, lane, d, f, p);
       put(i, d[0], f[0], p[0]);
       put(i, d[1], f[1], p[1]);
     }

@@ -43,6 +43,8 @@ struct DevTerm {
   uint32_t single_freq; // docs_count == 1: term_meta::freq
   uint32_t tf_bound;    // [dir kernel] upper bound of tf over the whole list
   uint32_t last_doc;    // [dir kernel] last doc id of the list
+  uint32_t tail_row;    // first entry of the term's decoded tail / single doc in tail_docs / tail_freqs
+  uint32_t pad;
 };
 
 // Where the positions of one term live in the staged `.pos` file (fields with POS).
@@ -53,6 +55,8 @@ struct DevPosTerm {
   uint32_t tail_n;      // vint-coded positions behind them: freq % 128
   uint32_t total;       // term_meta::freq
   uint32_t bytes;       // [pos dir kernel] encoded length of the term's positions
+  uint32_t tail_row;    // first entry of the term's decoded position tail in DevSegment::ptail
+  uint32_t pad;
 };
 
 struct DevSegment {
@@ -75,7 +79,8 @@ struct DevSegment {
   // headers leave all of them misaligned.  The hot decoder reads this copy.
   const uint8_t* pk;
   const uint32_t* blk_aoff;  // offset of the block in `pk`, in 16-byte units
-  // decoded vint tails / single docs: [num_terms][kBlock] absolute doc ids and frequencies
+  // decoded vint tails / single docs, term after term (DevTerm::tail_row): absolute doc ids
+  // and frequencies — at most 127 entries per term, 1 for a single-doc term
   const uint32_t* tail_docs;
   const uint32_t* tail_freqs;
   int32_t has_freq;
@@ -89,7 +94,7 @@ struct DevSegment {
   const uint8_t* pblk_bits;  //   and bit width (0 = all-equal block)
   const uint32_t* blk_pos;   // per doc-block row (+1 sentinel): positions of ALL earlier rows
                              // (exclusive scan of the blocks' frequency sums, mod 2^32)
-  const uint32_t* ptail;     // decoded position-delta tails: [num_terms][kBlock]
+  const uint32_t* ptail;     // decoded position-delta tails, term after term (DevPosTerm::tail_row)
 };
 
 struct DevQuery {
@@ -129,8 +134,8 @@ struct DevTail {
   uint32_t nblk;        // copy of DevTerm::nblk
   uint64_t doc_start;   // copy of DevTerm::doc_start
   uint64_t dir_off;     // copy of DevTerm::dir_off
-  uint32_t term;        // ordinal: row of the decoded-tail tables
-  uint32_t pad;
+  uint32_t term;        // ordinal in the term table
+  uint32_t tail_row;    // copy of DevTerm::tail_row
 };
 
 struct Hit {

@@ -697,6 +697,22 @@ def case_decode_positions(L, layout):
     assert np.array_equal(last_gpu[:len(last)], last)
     sr.close()
 
+    # a POS field indexed WITH a scorer: wand data sits in front of short tails and in every
+    # skip entry next to the POS fields (formats_10.cpp:511-518, 990-999)
+    norms = np.full(N, 255, np.uint8)
+    wseg = synth.segment_from_lists(lists[2:7], N, layout, norms, (synth.WAND_MIN_NORM,))
+    assert wseg.wand_count == 1 and wseg.doc_file.size > 0
+    wsr = search.SegmentReader.from_synth(wseg, L=L)
+    for t, (d, f, p) in enumerate(lists[2:7]):
+        dd, ff = wsr.decode_term(t)
+        assert np.array_equal(dd, d) and np.array_equal(ff, f)
+        assert np.array_equal(wsr.decode_positions(t), p), ("wand + positions", layout, t)
+        assert np.array_equal(p, oracle.decode_positions(wseg.doc_file, wseg.pos_file,
+                                                         wseg.metas[t], layout, wand_count=1))
+    l2, _, pend2, _ = oracle.read_skip0_pos(wseg.doc_file, wseg.metas[4], wand_count=1)
+    assert np.array_equal(l2, last) and np.array_equal(pend2, pend)
+    wsr.close()
+
 
 def run_phrases(L, seg, phrases, scorer, k, sr=None, cap=0):
     own = sr is None
