@@ -345,6 +345,7 @@ k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms
     const DevTail tl = s_tl[i];
     if (tl.nblk) {
       const uint32_t* last = seg.blk_last + tl.dir_off;
+      const uint32_t pos0 = seg.blk_pos[tl.dir_off];
       uint32_t a = 0, b = tl.nblk;  // lower_bound(last, dlo): first block reaching dlo
       while (a < b) {
         const uint32_t mid = (a + b) >> 1;
@@ -357,19 +358,28 @@ k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms
         const uint32_t prv = (valid && bl) ? last[bl - 1] : 0u;  // block holds docs in (prv, lst]
         const bool reach = valid && prv < dhi;
         const bool want = reach && count_le(docs, n, lst) > count_le(docs, n, prv);
+        // the directory words of the wanted blocks, one lane each (coalesced), handed to
+        // the whole wavefront by readlane when the block's turn comes
+        const uint64_t e_l = tl.dir_off + bl;
+        uint32_t bits_l = 0, off_l = 0, pos_l = 0;
+        if (want) {
+          bits_l = seg.blk_bits[e_l];
+          off_l = seg.blk_off[e_l];
+          pos_l = seg.blk_pos[e_l];
+        }
+        const uint32_t base_l = bl ? prv : kDocMin;
         uint64_t mask = wave::ballot(want);
         const bool more = wave::ballot(valid && !reach) == 0;  // no block started behind dhi yet
         while (mask) {
           const uint32_t k = uint32_t(__builtin_ctzll(mask));
           mask &= mask - 1;
-          const uint64_t e = tl.dir_off + b0 + k;
-          const uint32_t bits = seg.blk_bits[e];
-          const uint32_t base = (b0 + k) ? seg.blk_last[e - 1] : kDocMin;
+          const uint32_t bits = wave::read_lane(bits_l, k);
+          const uint32_t base = wave::read_lane(base_l, k);
           uint32_t d0, d1, f0, f1;
-          decode_block<LAYOUT, true>(seg.doc + tl.doc_start + seg.blk_off[e], bits & 0xFFu,
-                                     bits >> 8, base, lane, d0, d1, f0, f1);
+          decode_block<LAYOUT, true>(seg.doc + tl.doc_start + wave::read_lane(off_l, k),
+                                     bits & 0xFFu, bits >> 8, base, lane, d0, d1, f0, f1);
           const uint32_t incl = wave::inclusive_scan(f0 + f1);
-          const uint32_t p0 = seg.blk_pos[e] - seg.blk_pos[tl.dir_off] + incl - f0 - f1;
+          const uint32_t p0 = wave::read_lane(pos_l, k) - pos0 + incl - f0 - f1;
           put(i, d0, f0, p0);
           put(i, d1, f1, p0 + f0);
         }
