@@ -224,9 +224,9 @@ struct PhraseWg {
   uint32_t first_item;  // index of the workgroup's first lead block
 };
 
-// #{i < n : sorted[i] <= x}
-__device__ __forceinline__ uint32_t count_le(const uint32_t* sorted, uint32_t n, uint32_t x) {
-  uint32_t a = 0, b = n;
+// #{i < n : sorted[i] <= x}, knowing that it lies in [a, b]
+__device__ __forceinline__ uint32_t count_le(const uint32_t* sorted, uint32_t a, uint32_t b,
+                                             uint32_t x) {
   while (a < b) {
     const uint32_t mid = (a + b) >> 1;
     if (sorted[mid] <= x) a = mid + 1; else b = mid;
@@ -331,10 +331,11 @@ k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms
   const uint32_t dlo = docs[0], dhi = docs[n - 1];
 
   // a decoded posting of term i: is its doc one of the lead docs?
-  auto put = [&](uint32_t i, uint32_t doc, uint32_t f, uint32_t p) {
+  // (w0, w1] = ranks of the lead docs that can equal it: those inside its block's doc range
+  auto put = [&](uint32_t i, uint32_t doc, uint32_t f, uint32_t p, uint32_t w0, uint32_t w1) {
     if (f == 0 || doc < dlo || doc > dhi) return;
-    const uint32_t c = count_le(docs, n, doc);
-    if (c && docs[c - 1] == doc) {
+    const uint32_t c = count_le(docs, w0, w1, doc);
+    if (c > w0 && docs[c - 1] == doc) {
       s_pidx[wv][i][c - 1] = p;
       s_tf[wv][i][c - 1] = f;
     }
@@ -357,7 +358,9 @@ k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms
         const uint32_t lst = valid ? last[bl] : 0xFFFFFFFFu;
         const uint32_t prv = (valid && bl) ? last[bl - 1] : 0u;  // block holds docs in (prv, lst]
         const bool reach = valid && prv < dhi;
-        const bool want = reach && count_le(docs, n, lst) > count_le(docs, n, prv);
+        const uint32_t cp_l = reach ? count_le(docs, 0u, n, prv) : 0u;
+        const uint32_t cl_l = reach ? count_le(docs, cp_l, n, lst) : 0u;
+        const bool want = cl_l > cp_l;   // some lead doc lies in (prv, lst]
         // the directory words of the wanted blocks, one lane each (coalesced), handed to
         // the whole wavefront by readlane when the block's turn comes
         const uint64_t e_l = tl.dir_off + bl;
@@ -380,8 +383,9 @@ k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms
                                      bits & 0xFFu, bits >> 8, base, lane, d0, d1, f0, f1);
           const uint32_t incl = wave::inclusive_scan(f0 + f1);
           const uint32_t p0 = wave::read_lane(pos_l, k) - pos0 + incl - f0 - f1;
-          put(i, d0, f0, p0);
-          put(i, d1, f1, p0 + f0);
+          const uint32_t w0 = wave::read_lane(cp_l, k), w1 = wave::read_lane(cl_l, k);
+          put(i, d0, f0, p0, w0, w1);
+          put(i, d1, f1, p0 + f0, w0, w1);
         }
         if (!more) break;
       }
@@ -390,8 +394,8 @@ k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms
       const uint32_t base = seg.blk_pos[tl.dir_off + tl.nblk] - seg.blk_pos[tl.dir_off];
       uint32_t d[2], f[2], p[2];
       tail_pidx(seg, tl.tail_row, tl.n, base, lane, d, f, p);
-      put(i, d[0], f[0], p[0]);
-      put(i, d[1], f[1], p[1]);
+      put(i, d[0], f[0], p[0], 0u, n);
+      put(i, d[1], f[1], p[1], 0u, n);
     }
   }
   wave::sync();
