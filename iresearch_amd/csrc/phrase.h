@@ -39,6 +39,25 @@ __device__ __forceinline__ uint32_t packed_at(const uint8_t* payload, uint32_t b
   return uint32_t(wave::load_u64(payload + 4u * (bit >> 5)) >> (bit & 31u)) & mask;
 }
 
+// decode_block (decode.h) for a field with positions: absolute docs d0/d1 and frequencies
+// f0/f1 of postings 2*lane, 2*lane+1, and `before` = sum of the frequencies of the block's
+// postings in front of 2*lane (where this lane's positions start inside the block).  The two
+// prefix sums run as one interleaved chain.
+template<int LAYOUT>
+__device__ __forceinline__ void decode_block_pos(const uint8_t* blk, uint32_t dbits,
+                                                 uint32_t fbits, uint32_t base, unsigned lane,
+                                                 uint32_t& d0, uint32_t& d1, uint32_t& f0,
+                                                 uint32_t& f1, uint32_t& before) {
+  uint32_t x0, x1;
+  const uint32_t size = read_block_pair<LAYOUT>(blk, dbits, lane, x0, x1);
+  read_block_pair<LAYOUT>(blk + size, fbits, lane, f0, f1);
+  uint32_t dsum = x0 + x1, fsum = f0 + f1;
+  wave::inclusive_scan2(dsum, fsum);
+  d1 = base + dsum;
+  d0 = d1 - x1;
+  before = fsum - f0 - f1;
+}
+
 // Position delta number `idx` of a term (what position::next adds to value_, :1624-1626).
 template<int LAYOUT>
 __device__ __forceinline__ uint32_t pos_delta(const DevSegment& seg, const DevPosTerm& pt,
@@ -301,10 +320,10 @@ k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms
       const uint64_t e = ld.dir_off + item;
       const uint32_t bits = seg.blk_bits[e];
       const uint32_t base = item ? seg.blk_last[e - 1] : kDocMin;
-      decode_block<LAYOUT, true>(seg.doc + ld.doc_start + seg.blk_off[e], bits & 0xFFu,
-                                 bits >> 8, base, lane, d[0], d[1], f[0], f[1]);
-      const uint32_t incl = wave::inclusive_scan(f[0] + f[1]);
-      p[0] = seg.blk_pos[e] - seg.blk_pos[ld.dir_off] + incl - f[0] - f[1];
+      uint32_t before;
+      decode_block_pos<LAYOUT>(seg.doc + ld.doc_start + seg.blk_off[e], bits & 0xFFu, bits >> 8,
+                               base, lane, d[0], d[1], f[0], f[1], before);
+      p[0] = seg.blk_pos[e] - seg.blk_pos[ld.dir_off] + before;
       p[1] = p[0] + f[0];
       e0 = 2u * lane;
       estep = 1u;
@@ -378,11 +397,10 @@ k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms
           mask &= mask - 1;
           const uint32_t bits = wave::read_lane(bits_l, k);
           const uint32_t base = wave::read_lane(base_l, k);
-          uint32_t d0, d1, f0, f1;
-          decode_block<LAYOUT, true>(seg.doc + tl.doc_start + wave::read_lane(off_l, k),
-                                     bits & 0xFFu, bits >> 8, base, lane, d0, d1, f0, f1);
-          const uint32_t incl = wave::inclusive_scan(f0 + f1);
-          const uint32_t p0 = wave::read_lane(pos_l, k) - pos0 + incl - f0 - f1;
+          uint32_t d0, d1, f0, f1, before;
+          decode_block_pos<LAYOUT>(seg.doc + tl.doc_start + wave::read_lane(off_l, k),
+                                   bits & 0xFFu, bits >> 8, base, lane, d0, d1, f0, f1, before);
+          const uint32_t p0 = wave::read_lane(pos_l, k) - pos0 + before;
           const uint32_t w0 = wave::read_lane(cp_l, k), w1 = wave::read_lane(cl_l, k);
           put(i, d0, f0, p0, w0, w1);
           put(i, d1, f1, p0 + f0, w0, w1);
