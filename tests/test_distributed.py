@@ -20,16 +20,19 @@ DOCS = 12_000
 MAX_RANK = 128
 
 
-def _filters():
+def _filters(phrase=False):
     from iresearch_amd import synth
-    from iresearch_amd.search import And, Or, by_term
+    from iresearch_amd.search import And, Or, by_phrase, by_term
+    if phrase:
+        return [by_phrase([0, 1]), by_phrase([2, 0, 1]), by_phrase([5, 9]),
+                by_phrase([0, 3], [0, 2]), by_phrase([1, 1])]
     ranks = synth.make_queries(5, 8, 2, MAX_RANK)
     fl = [Or([by_term(int(r) - 1) for r in row]) for row in ranks]
     fl += [by_term(7), Or([by_term(3), by_term(99)]), And([by_term(1), by_term(20)])]
     return fl
 
 
-def _worker(rank, world, port, sim_path, out_dir):
+def _worker(rank, world, port, sim_path, out_dir, phrase=False):
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -39,7 +42,8 @@ def _worker(rank, world, port, sim_path, out_dir):
     from iresearch_amd.search import BM25
     L = _lib.bind(C.CDLL(sim_path))
     my = distributed.segments_of_rank(N_SEGS, rank, world)
-    segs = {s: synth.build_segment(DOCS, MAX_RANK, first_doc=s * DOCS) for s in my}
+    segs = {s: synth.build_segment(DOCS, MAX_RANK, first_doc=s * DOCS, with_positions=phrase)
+            for s in my}
     local = {s: (segs[s].docs_with_field, segs[s].total_term_freq,
                  np.asarray(segs[s].metas["docs_count"])) for s in my}
     gathered = [None] * world
@@ -48,7 +52,7 @@ def _worker(rank, world, port, sim_path, out_dir):
     for g in gathered:
         stats.update(g)
     seg_stats = [search.SegmentStats(*stats[s]) for s in range(N_SEGS)]
-    filters = _filters()
+    filters = _filters(phrase)
     prep = search.prepare(filters, BM25(), seg_stats)
     nq = len(filters)
     # the production flow (bench.py): ONE batch over the rank's segments, results written
@@ -106,6 +110,39 @@ def test_two_ranks_gloo_matches_oracle(simlib, tmp_path):
         key = list(zip(-got["score"].astype(np.float64), segs_of[q, :n], got["doc"]))
         assert key == sorted(key), q
         assert (segs_of[q, :n] < N_SEGS).all()
+
+
+def test_two_ranks_gloo_phrases_match_oracle(simlib, tmp_path):
+    """The same flow for a batch of by_phrase queries: statistics of every phrase term are
+    index-global, each rank runs one phrase batch over its segments, one all-gather, merge."""
+    port = 29500 + ((os.getpid() * 3 + 101) % 2000)
+    mp.spawn(_worker, args=(2, port, simlib._name, str(tmp_path), True), nprocs=2, join=True)
+    import oracle
+    import parity
+    from iresearch_amd import _lib, synth
+    from iresearch_amd.search import BM25
+    r0 = [np.load(tmp_path / ("%s_0.npy" % n)) for n in ("hits", "segs", "counts")]
+    r1 = [np.load(tmp_path / ("%s_1.npy" % n)) for n in ("hits", "segs", "counts")]
+    for a, b in zip(r0, r1):
+        assert np.array_equal(a, b)
+    hits = r0[0].view(_lib.HIT).reshape(r0[0].shape)
+    segs = [synth.build_segment(DOCS, MAX_RANK, first_doc=s * DOCS, with_positions=True)
+            for s in range(N_SEGS)]
+    views = [parity.oracle_view(s) for s in segs]
+    osc = parity.oracle_scorer(BM25())
+    some = 0
+    for q, ph in enumerate(_filters(True)):
+        metas = np.stack([parity.metas_for(s, ph.terms) for s in segs])
+        ohits, total = oracle.search_phrase(views, metas, ph.offsets, osc, K, ph.boost)
+        n = int(r0[2][q])
+        assert n == len(ohits), (q, n, len(ohits))
+        some += n
+        got = hits[q, :n]
+        want = np.sort(ohits["score"])[::-1]
+        assert np.allclose(got["score"], want, rtol=parity.REL_TOL, atol=0), q
+        key = list(zip(-got["score"].astype(np.float64), r0[1][q, :n], got["doc"]))
+        assert key == sorted(key), q
+    assert some > 0
 
 
 def test_bench_is_launchable_on_two_ranks(simlib):
