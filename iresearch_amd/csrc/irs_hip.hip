@@ -664,22 +664,37 @@ int irs_hip_bit_union(irs_hip_segment* seg, const uint32_t* terms, uint32_t n_te
   }
   if (count) *count = total;
   if (!n_terms) return IRS_HIP_OK;
-  DevBuf d_terms, d_set;
+  // work list: up to kUnionBlocks blocks of one term per workgroup (+ its tail)
+  std::vector<UnionWg> wgs;
+  try {
+    for (uint32_t i = 0; i < n_terms; ++i) {
+      if (terms[i] == IRS_HIP_NO_TERM) continue;
+      const DevTerm& t = seg->terms[terms[i]];
+      if (t.docs_count == 0) continue;
+      uint32_t b = 0;
+      do {
+        wgs.push_back(UnionWg{terms[i], b});
+        b += kUnionBlocks;
+      } while (b < t.nblk);
+    }
+  } catch (...) {
+    return IRS_HIP_ENOMEM;
+  }
+  if (wgs.empty()) return IRS_HIP_OK;
+  if (wgs.size() > 0x7FFFFFFFull) return IRS_HIP_EUNSUPPORTED;
+  DevBuf d_wgs, d_set;
   const size_t set_bytes = size_t(n_words) * 8;
-  if (!d_terms.alloc(size_t(n_terms) * 4) || !d_set.alloc(set_bytes)) return IRS_HIP_ENOMEM;
-  if (!rt::h2d(d_terms.p, terms, size_t(n_terms) * 4, nullptr) ||
+  if (!d_wgs.alloc(wgs.size() * sizeof(UnionWg)) || !d_set.alloc(set_bytes)) return IRS_HIP_ENOMEM;
+  if (!rt::h2d(d_wgs.p, wgs.data(), wgs.size() * sizeof(UnionWg), nullptr) ||
       !rt::h2d(d_set.p, set, set_bytes, nullptr))  // bits already set by the caller are kept
     return IRS_HIP_EHIP;
-  // enough slices to spread the longest lists over the chip, few enough that short
-  // ones do not drown in empty workgroups
-  const uint32_t slices = std::max<uint32_t>(1, std::min<uint32_t>(64, seg->cus * 8 / n_terms));
   const uint64_t n_bits = n_words * 64;
   if (seg->dev.layout == kSimd4) {
-    RT_LAUNCH((k_bit_union<kSimd4>), n_terms * slices, kThreads, 0, nullptr, seg->dev,
-              d_terms.as<uint32_t>(), slices, d_set.as<uint32_t>(), n_bits);
+    RT_LAUNCH((k_bit_union<kSimd4>), uint32_t(wgs.size()), kThreads, 0, nullptr, seg->dev,
+              d_wgs.as<UnionWg>(), d_set.as<uint32_t>(), n_bits);
   } else {
-    RT_LAUNCH((k_bit_union<kScalar>), n_terms * slices, kThreads, 0, nullptr, seg->dev,
-              d_terms.as<uint32_t>(), slices, d_set.as<uint32_t>(), n_bits);
+    RT_LAUNCH((k_bit_union<kScalar>), uint32_t(wgs.size()), kThreads, 0, nullptr, seg->dev,
+              d_wgs.as<UnionWg>(), d_set.as<uint32_t>(), n_bits);
   }
   if (!rt::last_error_ok() || !rt::d2h(set, d_set.p, set_bytes, nullptr) || !rt::sync(nullptr))
     return IRS_HIP_EHIP;

@@ -336,56 +336,41 @@ k_decode_term(DevSegment seg, uint32_t term, uint32_t* out_docs,
 
 // postings_reader::bit_union (formats_10.cpp:3716-3806): set bit `doc` of a doc
 // bitset for every posting of every given term; freq blocks are never touched
-// (the directory knows where each doc block starts).  grid = n_terms * slices:
-// wavefront (slice, w) of a term takes blocks slice*kWaves + w, then strides by
-// slices*kWaves; the wavefront that would take block `nblk` walks the vint tail.
+// (the directory knows where each doc block starts).  Work is cut by BLOCKS, not by
+// terms (posting lists are Zipf-distributed: the longest list of a prefix expansion can
+// hold most of the postings): one workgroup = up to kUnionBlocks consecutive blocks of
+// one term, a wavefront per block; the workgroup that owns a term's last blocks also
+// takes its decoded vint tail / single doc.
+constexpr uint32_t kUnionBlocks = 64;
+struct UnionWg {
+  uint32_t term;
+  uint32_t first_block;
+};
+
 template<int LAYOUT>
 __global__ void __launch_bounds__(kThreads)
-k_bit_union(DevSegment seg, const uint32_t* term_ids, uint32_t slices, uint32_t* set32,
-            uint64_t n_bits) {
+k_bit_union(DevSegment seg, const UnionWg* wgs, uint32_t* set32, uint64_t n_bits) {
   const unsigned lane = threadIdx.x & 63u;
-  const uint32_t slice = blockIdx.x % slices;
-  const uint32_t term = term_ids[blockIdx.x / slices];
-  if (term == kNoTerm) return;
-  const DevTerm t = seg.terms[term];
+  const UnionWg wg = wgs[blockIdx.x];
+  const DevTerm t = seg.terms[wg.term];
   auto mark = [&](uint32_t doc) {
     if (doc < n_bits) atomicOr(&set32[doc >> 5], 1u << (doc & 31u));
   };
-  const uint32_t first = slice * kWaves + (threadIdx.x >> 6);
-  if (t.docs_count == 0) return;
-  if (t.docs_count == 1) {  // formats_10.cpp:3797-3801
-    if (first == 0 && lane == 0) mark(t.single_doc);
-    return;
+  uint32_t end = wg.first_block + kUnionBlocks;
+  if (end > t.nblk) end = t.nblk;
+  for (uint32_t b = wg.first_block + (threadIdx.x >> 6); b < end; b += kWaves) {
+    const uint64_t e = t.dir_off + b;
+    const uint32_t base = b ? seg.blk_last[e - 1] : kDocMin;
+    uint32_t d0, d1, f0, f1;
+    decode_block<LAYOUT, false>(seg.doc + t.doc_start + seg.blk_off[e], seg.blk_bits[e] & 0xFFu,
+                                0, base, lane, d0, d1, f0, f1);
+    mark(d0);
+    mark(d1);
   }
-  const uint32_t stride = slices * kWaves;
-  for (uint32_t item = first; item <= t.nblk; item += stride) {
-    if (item < t.nblk) {
-      const uint64_t e = t.dir_off + item;
-      const uint32_t base = item ? seg.blk_last[e - 1] : kDocMin;
-      uint32_t d0, d1, f0, f1;
-      decode_block<LAYOUT, false>(seg.doc + t.doc_start + seg.blk_off[e],
-                                  seg.blk_bits[e] & 0xFFu, 0, base, lane, d0, d1, f0, f1);
-      mark(d0);
-      mark(d1);
-    } else if (lane == 0 && t.tail_n) {
-      const uint8_t* p = seg.doc + t.tail_off;
-      uint32_t doc = t.tail_base;
-      for (uint32_t i = 0; i < t.tail_n; ++i) {
-        uint32_t len;
-        const uint32_t v = vint_bytes(p, &len);
-        p += len;
-        if (seg.has_freq) {
-          doc += v >> 1;  // shift_unpack_32, store_utils.hpp:266-269
-          if (!(v & 1u)) {
-            vint_bytes(p, &len);
-            p += len;
-          }
-        } else {
-          doc += v;
-        }
-        mark(doc);
-      }
-    }
+  // the decoded tail (or the single doc, formats_10.cpp:3797-3801): at most 127 docs
+  if (end == t.nblk && threadIdx.x < kBlock) {
+    const uint32_t n = t.docs_count == 1 ? 1u : t.tail_n;
+    if (threadIdx.x < n) mark(seg.tail_docs[t.tail_row + threadIdx.x]);
   }
 }
 
