@@ -46,13 +46,20 @@ __device__ __forceinline__ uint32_t pk_units(uint32_t dbits, uint32_t fbits) {
 
 // One wavefront per term walks the term's full blocks front to back: header
 // byte -> payload size (bitpack::skip_block32, bitpack.hpp:60-69); the block's
-// last doc is base + sum(deltas).  Lane 0 then walks the vint tail
-// (formats_10.cpp:1765-1792) to find its end.  Nothing decoded is stored.
+// last doc is base + sum(deltas).  Lane 0 then decodes the vint tail
+// (formats_10.cpp:1765-1792) into the per-term tail tables.  The stream is staged through
+// LDS (kDirWindow bytes per refill and wavefront): the walk is a chain of dependent reads.
+constexpr uint32_t kDirWindow = 8192;
+struct alignas(16) DirLine {
+  uint64_t lo, hi;
+};
+
 template<int LAYOUT>
 __global__ void __launch_bounds__(kThreads)
 k_build_directory(DevSegment seg, DevTerm* terms, uint32_t* blk_off,
                   uint32_t* blk_last, uint16_t* blk_bits, uint32_t* blk_units,
                   uint32_t* tail_docs, uint32_t* tail_freqs, uint32_t* status) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[kWaves][kDirWindow];
   const unsigned lane = threadIdx.x & 63u;
   const uint32_t term = blockIdx.x * kWaves + (threadIdx.x >> 6);
   if (term >= seg.num_terms) return;
@@ -73,9 +80,27 @@ k_build_directory(DevSegment seg, DevTerm* terms, uint32_t* blk_off,
   uint32_t base = kDocMin;  // formats_10.cpp:636 / :2100-2105
   uint32_t tfb = 0;
   bool bad = false;
+  // The walk is a chain of dependent reads (header -> payload -> next header), so the
+  // stream is staged through LDS, kDirWindow bytes at a time: all 64 lanes copy, then the
+  // blocks inside the window are parsed at LDS latency.
+  uint8_t* win = s_win[threadIdx.x >> 6];
+  const uint64_t staged = seg.doc_len + kPadBytes;  // the device copy ends with zero padding
+  uint64_t win_lo = 0, win_hi = 0;
+  constexpr uint32_t kMaxPair = 2u * (1u + 16u * 32u) + 16u;  // doc block + freq block
   for (uint32_t b = 0; b < t.nblk; ++b) {
     if (cur + 2 > seg.doc_len) { bad = true; break; }
-    const uint8_t* blk = seg.doc + cur;
+    if (cur + kMaxPair > win_hi) {
+      wave::sync();  // every lane is done with the old window
+      win_lo = cur & ~uint64_t(15);
+      uint64_t bytes = staged - win_lo;
+      if (bytes > kDirWindow) bytes = kDirWindow;
+      bytes &= ~uint64_t(15);
+      for (uint32_t o = lane * 16u; o < bytes; o += 64u * 16u)
+        *reinterpret_cast<DirLine*>(win + o) = *reinterpret_cast<const DirLine*>(seg.doc + win_lo + o);
+      win_hi = win_lo + bytes;
+      wave::sync();
+    }
+    const uint8_t* blk = win + (cur - win_lo);
     const uint32_t dbits = blk[0];
     if (dbits > 32 || cur + 1 + 16ull * dbits > seg.doc_len) { bad = true; break; }
     uint32_t x0, x1;

@@ -98,50 +98,99 @@ k_freq_sums(DevSegment seg, uint32_t slices, uint32_t* sums) {
   }
 }
 
-// One wavefront per term; lane 0 walks the term's pos blocks (header byte -> size,
-// bitpack::skip_block32) and decodes the vint tail (read_tail_block :1515-1537).
+// One wavefront per term walks the term's pos blocks (header byte -> size,
+// bitpack::skip_block32) and decodes the vint tail (read_tail_block :1515-1537).  The walk
+// is a chain of dependent one-byte reads, so the stream is staged through LDS 8 KB at a
+// time (all 64 lanes copy, lane 0 walks the window at LDS latency): 0.29 s -> see DESIGN.md
+// for the 10 M-doc segment, whose longest term has 540 k pos blocks.
+constexpr uint32_t kWalkWindow = 8192;
+struct alignas(16) Bytes16 {
+  uint64_t lo, hi;
+};
+
 __global__ void __launch_bounds__(kThreads)
 k_pos_directory(DevSegment seg, DevPosTerm* pterms, uint32_t* pblk_off, uint8_t* pblk_bits,
                 uint32_t* ptail, const uint64_t* pos_end, uint32_t* status) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[kWaves][kWalkWindow];
   const unsigned lane = threadIdx.x & 63u;
-  const uint32_t term = blockIdx.x * kWaves + (threadIdx.x >> 6);
-  if (term >= seg.num_terms || lane != 0) return;
+  const uint32_t wv = threadIdx.x >> 6;
+  const uint32_t term = blockIdx.x * kWaves + wv;
+  if (term >= seg.num_terms) return;
   const DevPosTerm pt = pterms[term];
   if (pt.total == 0) return;
-  uint64_t cur = pt.pos_start;
-  bool bad = false;
-  for (uint32_t b = 0; b < pt.nfull; ++b) {
-    if (cur + 2 > seg.pos_len) { bad = true; break; }
-    const uint32_t bits = seg.pos[cur];
-    uint32_t size;
-    if (bits == 0) {
-      uint32_t len;
-      (void)vint_from(wave::load_u64(seg.pos + cur + 1), &len);
-      size = 1u + len;
-    } else {
-      size = 1u + 16u * bits;
+  uint8_t* win = s_win[wv];
+  const uint64_t staged = seg.pos_len + kPadBytes;  // the device copy ends with zero padding
+  uint64_t cur = pt.pos_start, win_lo = 0, win_hi = 0;
+  uint32_t b = 0;
+  uint32_t bad = 0;
+  // window [win_lo, win_hi) of the stream, starting at the 16-byte line holding `at`
+  auto refill = [&](uint64_t at) {
+    win_lo = at & ~uint64_t(15);
+    uint64_t bytes = staged - win_lo;
+    if (bytes > kWalkWindow) bytes = kWalkWindow;
+    bytes &= ~uint64_t(15);
+    for (uint32_t o = lane * 16u; o < bytes; o += 64u * 16u)
+      *reinterpret_cast<Bytes16*>(win + o) =
+        *reinterpret_cast<const Bytes16*>(seg.pos + win_lo + o);
+    win_hi = win_lo + bytes;
+    wave::sync();
+  };
+  while (b < pt.nfull && !bad) {
+    if (cur + 8 > seg.pos_len) { bad = 1; break; }
+    refill(cur);
+    if (lane == 0) {
+      // every block that starts with its header and a possible 5-byte vint inside the window
+      while (b < pt.nfull && cur + 6 <= win_hi) {
+        const uint32_t bits = win[cur - win_lo];
+        uint32_t size;
+        if (bits == 0) {
+          uint32_t len;
+          (void)vint_bytes(win + (cur + 1 - win_lo), &len);
+          size = 1u + len;
+        } else {
+          size = 1u + 16u * bits;
+        }
+        if (bits > 32 || cur + size > seg.pos_len || cur - pt.pos_start > 0xFFFFFFFFull) {
+          bad = 1;
+          break;
+        }
+        pblk_off[pt.row + b] = uint32_t(cur - pt.pos_start);
+        pblk_bits[pt.row + b] = uint8_t(bits);
+        cur += size;
+        ++b;
+      }
     }
-    if (bits > 32 || cur + size > seg.pos_len || cur - pt.pos_start > 0xFFFFFFFFull) {
-      bad = true;
-      break;
-    }
-    pblk_off[pt.row + b] = uint32_t(cur - pt.pos_start);
-    pblk_bits[pt.row + b] = uint8_t(bits);
-    cur += size;
+    b = wave::bcast(b, 0);
+    bad = wave::bcast(bad, 0);
+    const uint32_t lo = wave::bcast(uint32_t(cur), 0), hi = wave::bcast(uint32_t(cur >> 32), 0);
+    cur = (uint64_t(hi) << 32) | lo;
+    wave::sync();  // the window is rewritten next
   }
   // where the writer says the tail starts (EndTerm :719-722; reader :2270-2278)
-  if (!bad && pt.total > kBlock && pos_end[term] != cur - pt.pos_start) bad = true;
-  if (!bad) {
-    for (uint32_t i = 0; i < pt.tail_n; ++i) {
-      if (cur + 1 > seg.pos_len) { bad = true; break; }
-      uint32_t len;
-      ptail[pt.tail_row + i] = vint_from(wave::load_u64(seg.pos + cur), &len);
-      cur += len;
+  if (!bad && pt.total > kBlock && pos_end[term] != cur - pt.pos_start) bad = 1;
+  if (!bad && pt.tail_n) {
+    if (cur + 1 > seg.pos_len) {
+      bad = 1;
+    } else {
+      refill(cur);  // at most 127 vints of <= 5 bytes
+      if (lane == 0) {
+        for (uint32_t i = 0; i < pt.tail_n; ++i) {
+          if (cur + 1 > seg.pos_len) { bad = 1; break; }
+          uint32_t len;
+          ptail[pt.tail_row + i] = vint_bytes(win + (cur - win_lo), &len);
+          cur += len;
+        }
+        if (cur > seg.pos_len) bad = 1;
+      }
+      bad = wave::bcast(bad, 0);
+      const uint32_t lo = wave::bcast(uint32_t(cur), 0), hi = wave::bcast(uint32_t(cur >> 32), 0);
+      cur = (uint64_t(hi) << 32) | lo;
     }
-    if (cur > seg.pos_len) bad = true;
   }
-  pterms[term].bytes = uint32_t(cur - pt.pos_start);
-  if (bad) atomicOr(status, kStatusCorrupt);
+  if (lane == 0) {
+    pterms[term].bytes = uint32_t(cur - pt.pos_start);
+    if (bad) atomicOr(status, kStatusCorrupt);
+  }
 }
 
 // (P, tf) of the tail postings this lane owns: entries `lane` and `lane + 64` of the
