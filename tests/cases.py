@@ -830,7 +830,8 @@ def phrase_golden_corpus():
                 p.extend(pos)
         lists.append((np.array(d, np.uint32), np.array(f, np.uint32), np.array(p, np.uint32)))
     norms = np.array([len(t) for t in toks], np.uint8)
-    return names, vocab, lists, norms, g["vectors"]
+    return names, vocab, lists, norms, g["vectors"] + [dict(v, docs=sorted(v["ranked"]))
+                                                        for v in g.get("ranked", [])]
 
 
 def case_phrase_reference_vectors(L, layout=synth.LAYOUT_SIMD4):
@@ -843,7 +844,7 @@ def case_phrase_reference_vectors(L, layout=synth.LAYOUT_SIMD4):
     for scorer in (BM25(), TFIDF(True)):
         phrases, expect = [], []
         for v in vectors:
-            if any(w not in vocab for w in v["words"]):
+            if any(w not in vocab for w in v["words"]) or "ranked" in v:
                 continue
             phrases.append(by_phrase([vocab.index(w) for w in v["words"]], v["offsets"]))
             expect.append(v["docs"])
@@ -857,6 +858,19 @@ def case_phrase_reference_vectors(L, layout=synth.LAYOUT_SIMD4):
                                              ph.offsets, osc, 64)
             assert total == len(want)
             assert [names[d - 1] for d in sorted(int(x) for x in oh["doc"])] == want
+    # the score ORDER bm25_test.cpp / tfidf_test.cpp (test_phrase) assert for "jumps high"
+    ranked = [v for v in vectors if "ranked" in v]
+    assert len(ranked) == 2
+    for v in ranked:
+        scorer = BM25(1.2, 0.0) if v["scorer"] == "bm25_b0" else TFIDF(False)
+        ph = [by_phrase([vocab.index(w) for w in v["words"]], v["offsets"])]
+        hits, counts, _, _ = run_phrases(L, seg, ph, scorer, 64, sr=sr)
+        got = [names[int(d) - 1] for d in hits[0, :counts[0]]["doc"]]
+        assert got == v["ranked"], ("golden ranking", v["scorer"], got)
+        oh, _ = oracle.search_phrase([view], parity.metas_for(seg, ph[0].terms)[None, :],
+                                     ph[0].offsets, parity.oracle_scorer(scorer), 64)
+        key = sorted(zip(-oh["score"].astype(np.float64), oh["doc"].astype(np.int64)))
+        assert [names[d - 1] for _, d in key] == v["ranked"]
     sr.close()
 
 

@@ -77,8 +77,24 @@ def main():
         seen.add(key)
         vectors.append({"words": words, "offsets": offsets, "docs": order,
                         "freqs": wf if freqs else None})
-    OUT.write_text(json.dumps({"corpus": corpus, "vectors": vectors}, indent=1) + "\n")
-    print(len(vectors), "vectors ->", OUT)
+    # ranked vectors: test_phrase of bm25_test.cpp (BM25 with b = 0) and tfidf_test.cpp
+    # (TFIDF without norms) assert the ORDER of the docs of "jumps high" by score (a
+    # std::multimap<score, name, greater>: equal scores keep doc order)
+    ranked = []
+    for fname, scorer in (("search/bm25_test.cpp", "bm25_b0"), ("search/tfidf_test.cpp", "tfidf")):
+        text = (REF / fname).read_text()
+        at = text.find('// "jumps high" with order')
+        assert at > 0, fname
+        body = text[at:at + 1500]
+        words = re.findall(r'std::string_view\("([a-z]+)"\)', body[:600])
+        assert words == ["jumps", "high"], (fname, words)
+        exp = re.search(r"expected\{(.*?)\};", body, re.S).group(1)
+        order = re.findall(r'"([A-Z0-9]+)"', re.sub(r"//[^\n]*", "", exp))
+        assert order == ["O", "P", "Q", "R"], (fname, order)
+        ranked.append({"words": words, "offsets": [0, 1], "scorer": scorer, "ranked": order})
+    OUT.write_text(json.dumps({"corpus": corpus, "vectors": vectors, "ranked": ranked},
+                              indent=1) + "\n")
+    print(len(vectors), "doc-set vectors,", len(ranked), "ranked vectors ->", OUT)
 
 
 if __name__ == "__main__":
