@@ -14,7 +14,10 @@
  *   - scores: the ORDER of results is pinned by every ranking the reference's
  *     own tests assert on tests/resources/simple_sequential_order.json
  *     (bm25_test.cpp / tfidf_test.cpp, 16 vectors incl. two-segment ones:
- *     tests/cases.py REFERENCE_ORDERS); score MAGNITUDES are "parity unpinned" —
+ *     tests/cases.py REFERENCE_ORDERS); the DOC SETS of Or / And / min-match by the literal
+ *     lists and expectations of the reference's iterator tests
+ *     (tests/golden/boolean_golden.json), those of by_phrase and one phrase ranking by
+ *     tests/golden/phrase_golden.json; score MAGNITUDES are "parity unpinned" —
  *     those tests hold no float literals; the formulas are
  *     restated line by line and cross-checked in double precision.
  */

@@ -312,6 +312,33 @@ def case_reference_score_orders(L):
                 assert got == want, (name, terms, got, want)
 
 
+def case_boolean_reference_vectors(L, max_doc=2_000_000):
+    """tests/golden/boolean_golden.json: the literal posting lists and expected doc ids of
+    the reference's disjunction / conjunction / min-match iterator tests
+    (tests/search/boolean_filter_tests.cpp, `next` tests) through the C ABI and the oracle."""
+    import json
+    vectors = json.loads((GOLDEN / "boolean_golden.json").read_text())["vectors"]
+    assert len(vectors) >= 30
+    ran = 0
+    for v in vectors:
+        top = max(max(l) for l in v["lists"])
+        if top > max_doc:
+            continue
+        lists = [(np.array(l, np.uint32), np.ones(len(l), np.uint32)) for l in v["lists"]]
+        seg = synth.segment_from_lists(lists, top + 1, synth.LAYOUT_SIMD4, norms=False)
+        subs = [by_term(i) for i in range(len(lists))]
+        flt = {"or": Or(subs), "and": And(subs),
+               "minmatch": Or(subs, min_match=v["min_match"])}[v["op"]]
+        if v["op"] == "minmatch" and v["min_match"] == 1:
+            flt = Or(subs)
+        hits, counts, totals = run_and_check(L, seg, [flt], BM25(), 64)
+        got = sorted(int(d) for d in hits[0, :counts[0]]["doc"])
+        assert got == v["expected"], (v["test"], v["op"], v["min_match"], got, v["expected"])
+        assert int(totals[0]) == len(v["expected"])
+        ran += 1
+    assert ran >= 25
+
+
 def case_pilot_misled(L, k=600):
     """The pilot only sees every 16th doc tile.  Here every high-scoring doc sits in exactly
     the tiles query 0 samples, so the estimated threshold (which extrapolates the sample)

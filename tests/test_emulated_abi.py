@@ -72,6 +72,10 @@ def test_reference_score_orders(simlib):
     cases.case_reference_score_orders(simlib)
 
 
+def test_boolean_reference_vectors(simlib):
+    cases.case_boolean_reference_vectors(simlib)
+
+
 def test_many_items(simlib):
     cases.case_many_items(simlib, 40_000)
 

@@ -105,6 +105,10 @@ def test_reference_score_orders(gpulib):
     cases.case_reference_score_orders(gpulib)
 
 
+def test_boolean_reference_vectors(gpulib):
+    cases.case_boolean_reference_vectors(gpulib, max_doc=120_000_000)
+
+
 def test_many_items(gpulib):
     cases.case_many_items(gpulib, 300_000)
 
