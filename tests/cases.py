@@ -804,6 +804,32 @@ def case_phrase_ragged(L, layout=synth.LAYOUT_SIMD4):
             run_phrases(L, seg, phrases, scorer, k)
 
 
+def case_phrase_fuzz(L, iters=12, seed=1):
+    """Seeded differential run: random small segments (single-doc terms, short and long
+    lists, both layouts), random phrases of 1..5 terms — repeated terms, gaps, equal offsets —
+    random k and scorer, against the oracle's phrase iterator."""
+    rng = np.random.default_rng(seed)
+    for it in range(iters):
+        N = int(rng.integers(50, 6000))
+        nterms = int(rng.integers(2, 7))
+        lists = []
+        for _ in range(nterms):
+            n = 1 if rng.random() < 0.15 else int(rng.integers(1, min(N, 1500)))
+            maxtf = int(rng.integers(1, 9))
+            lists.append(_random_pos_list(rng, n, N, maxtf, int(rng.integers(maxtf + 2, 40))))
+        seg = synth.segment_from_lists(lists, N, int(rng.integers(0, 2)),
+                                       norms=rng.integers(40, 255, N).astype(np.uint8))
+        phrases = []
+        for _ in range(8):
+            m = int(rng.integers(1, 6))
+            offs = [0]
+            for _ in range(m - 1):
+                offs.append(offs[-1] + int(rng.integers(0, 4)))
+            phrases.append(by_phrase([int(rng.integers(0, nterms)) for _ in range(m)], offs))
+        scorer = [BM25(), TFIDF(True), BM25(1.2, 0.0)][it % 3]
+        run_phrases(L, seg, phrases, scorer, int(rng.integers(1, 50)))
+
+
 def case_phrase_multi_segment(L, sizes=(12_000, 5_000, 30_000), k=50):
     """One batch over several segments of one device (irs_hip_batch_create_multi): every
     segment's phrase results equal its own run and the oracle's multi-segment harness."""

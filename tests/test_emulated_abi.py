@@ -115,6 +115,10 @@ def test_phrase_ragged(simlib):
     cases.case_phrase_ragged(simlib)
 
 
+def test_phrase_fuzz(simlib):
+    cases.case_phrase_fuzz(simlib, iters=12, seed=1)
+
+
 def test_phrase_multi_segment(simlib):
     cases.case_phrase_multi_segment(simlib)
 

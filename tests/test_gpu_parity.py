@@ -93,6 +93,10 @@ def test_phrase_ragged(gpulib):
     cases.case_phrase_ragged(gpulib, synth.LAYOUT_SCALAR)
 
 
+def test_phrase_fuzz(gpulib):
+    cases.case_phrase_fuzz(gpulib, iters=60, seed=2)
+
+
 def test_phrase_multi_segment(gpulib):
     cases.case_phrase_multi_segment(gpulib, sizes=(120_000, 5_000, 300_000))
 
