@@ -39,6 +39,14 @@ inline void* dmalloc(size_t n) {
 inline void dfree(void* p) {
   if (p) (void)hipFree(p);
 }
+// page-locked host memory: device copies into it run at full PCIe speed
+inline void* hmalloc(size_t n) {
+  void* p = nullptr;
+  return ok(hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault)) ? p : nullptr;
+}
+inline void hfree(void* p) {
+  if (p) (void)hipHostFree(p);
+}
 inline bool h2d(void* d, const void* h, size_t n, stream_t s) {
   return n == 0 || ok(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s));
 }

@@ -107,6 +107,8 @@ struct irs_hip_batch {
   uint32_t wg_threads = kDefaultWgThreads;  // threads per pilot/score workgroup
   bool any_and = false;
   bool phrase = false;  // a batch of by_phrase queries (k_phrase instead of k_pilot + k_score)
+  void* h_pin = nullptr;       // page-locked staging for irs_hip_batch_results
+  size_t h_pin_bytes = 0;
   uint32_t n_phrase_wgs = 0;   // k_phrase workgroups: kPhraseWaves lead blocks each
   DevBuf d_phrase_wgs;
   bool acc32 = true;   // 32-bit fixed-point accumulators are precise enough for every query
@@ -1168,12 +1170,16 @@ int irs_hip_batch_results(irs_hip_batch* b, irs_hip_hit* hits, uint32_t k_stride
   if (!b || !hits || !counts || !b->ran || k_stride < b->k_max) return IRS_HIP_EINVAL;
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
   uint32_t status = 0;
-  std::vector<Hit> tmp;
-  try {
-    tmp.resize(size_t(b->nq) * b->k_max);
-  } catch (...) {
-    return IRS_HIP_ENOMEM;
+  // hits land in a page-locked buffer owned by the batch (a pageable destination would
+  // be staged by the runtime at a fraction of the PCIe rate), then go to the caller's layout
+  const size_t hit_bytes = size_t(b->nq) * b->k_max * sizeof(Hit);
+  if (b->h_pin_bytes < hit_bytes) {
+    rt::hfree(b->h_pin);
+    b->h_pin = rt::hmalloc(hit_bytes);
+    b->h_pin_bytes = b->h_pin ? hit_bytes : 0;
+    if (!b->h_pin) return IRS_HIP_ENOMEM;
   }
+  const Hit* tmp = static_cast<const Hit*>(b->h_pin);
   if (!rt::d2h(&status, b->d_status.p, 4, b->stream) || !rt::sync(b->stream))
     return IRS_HIP_EHIP;
   if (status & (kStatusOverflow | kStatusUnderflow)) {
@@ -1181,7 +1187,7 @@ int irs_hip_batch_results(irs_hip_batch* b, irs_hip_hit* hits, uint32_t k_stride
     if (rc != IRS_HIP_OK) return rc;
     status = 0;
   }
-  if (!rt::d2h(tmp.data(), b->d_out.p, tmp.size() * sizeof(Hit), b->stream) ||
+  if (!rt::d2h(b->h_pin, b->d_out.p, hit_bytes, b->stream) ||
       !rt::d2h(counts, b->d_out_count.p, size_t(b->nq) * 4, b->stream) ||
       (total_hits && !rt::d2h(total_hits, b->d_hits.p, size_t(b->nq) * 8, b->stream)) ||
       !rt::sync(b->stream))
@@ -1243,6 +1249,7 @@ void irs_hip_batch_destroy(irs_hip_batch* b) {
   if (b->ran) rt::sync(b->stream);
   if (b->events_ready)
     for (auto& e : b->ev) rt::event_destroy(e);
+  rt::hfree(b->h_pin);
   delete b;
 }
 

@@ -28,6 +28,8 @@ inline void* dmalloc(size_t n) {
   return p;
 }
 inline void dfree(void* p) { std::free(p); }
+inline void* hmalloc(size_t n) { return std::malloc(n ? n : 1); }
+inline void hfree(void* p) { std::free(p); }
 inline bool h2d(void* d, const void* h, size_t n, stream_t) {
   if (n) std::memcpy(d, h, n);
   return true;
