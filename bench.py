@@ -38,32 +38,55 @@ def log(*a):
         print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(seg, ranks, k, seconds_hint=15.0):
+def usable_cpus():
+    """CPUs this process can actually use: the affinity mask, capped by the container's CFS
+    quota (cgroup v2 cpu.max / v1 cpu.cfs_quota_us).  Running more threads than that only
+    gets them throttled."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
+def cpu_baseline(seg, ranks, k, seconds_hint=12.0):
     """Oracle (port of the index-search loop) on a bounded sample of the same
     queries.  Imports oracle/ here and only here."""
     import oracle
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import parity
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     view = parity.oracle_view(seg)
     sc = oracle.Scorer(oracle.SCORER_BM25, 1.2, 0.75, 0)
 
     def metas_of(rows):
         return np.stack([parity.metas_for(seg, [int(r) - 1 for r in row])[None] for row in rows])
 
-    # calibrate on a few queries, then size the sample for ~seconds_hint of wall time
-    probe = ranks[: min(len(ranks), max(2, cores))]
+    # calibrate on a few queries per thread, then size the sample (the bench queries, cycled
+    # if there are too few) for ~seconds_hint of wall time
+    probe = ranks[: min(len(ranks), max(8, 4 * cores))]
     t0 = time.perf_counter()
     oracle.search_batch([view], metas_of(probe), oracle.OP_OR, sc, k, cores)
     dt = max(time.perf_counter() - t0, 1e-6)
-    n = int(min(len(ranks), max(len(probe), len(probe) * seconds_hint / dt)))
-    sample = ranks[:n]
+    n = int(min(20000, max(len(probe), len(probe) * seconds_hint / dt)))
+    sample = ranks[np.arange(n) % len(ranks)]
     t0 = time.perf_counter()
     oracle.search_batch([view], metas_of(sample), oracle.OP_OR, sc, k, cores)
     dt = time.perf_counter() - t0
+    hw = os.cpu_count() or cores
     return {"value": round(n / dt, 3), "unit": "queries/s", "cores": cores, "kind": "port",
-            "sample": "first %d of the %d bench queries, %d threads popping one task queue "
-                      "(index-search --threads), %.1f s" % (n, len(ranks), cores, dt)}
+            "sample": "%d queries (the %d bench queries, cycled), %d threads popping one task "
+                      "queue (index-search --threads) = the CPUs this container may use "
+                      "(CFS quota) of %d hardware threads, %.1f s" % (n, len(ranks), cores, hw, dt)}
 
 
 def main():
