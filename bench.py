@@ -196,28 +196,37 @@ def main():
         batches[lead] = b
     sptr = None if sim else C_void(torch.cuda.current_stream(dev).cuda_stream)
     nq, k = args.queries, args.k
-    # every buffer of the exchange step is allocated once; each local segment's results
-    # are written straight into its slot of the send buffer
-    exchange = distributed.TopkExchange(L, local_rank, n_segments if multi else 1, rank, world,
-                                        nq, k, dev)
+    # every buffer of the exchange step is allocated once (twice: two sets alternate); each
+    # local segment's results are written straight into its slot of the send buffer
+    exchange = distributed.PipelinedExchange(L, local_rank, n_segments if multi else 1, rank,
+                                             world, nq, k, dev)
     # a multi-segment batch writes [segment][query][k] hits and [segment][query] counts: exactly
     # consecutive slots of the send buffer
-    slots = {lead: exchange.slot(my.index(lead)) for lead in batches}
+    slots = [{lead: exchange.slot(ph, my.index(lead)) for lead in batches} for ph in (0, 1)]
+    state = {"it": 0}
 
     def step():
         # every step ends with a checked, device-resident top-k: results_to_device reads the
         # batch status (4 bytes) and re-runs the batch if a threshold estimate or the
-        # candidate buffer fell short (irs_hip_batch_reruns counts those)
+        # candidate buffer fell short (irs_hip_batch_reruns counts those).  The all-gather
+        # (RCCL) of step i overlaps the kernels of step i+1; its GPU merge is enqueued behind them.
+        ph = state["it"] & 1
+        state["it"] += 1
         for s in batches:
             batches[s].run(sptr)
-        for s in batches:
-            batches[s].results_to_device(slots[s][0], slots[s][1], sptr)
         if multi:
-            return exchange.run(sptr)   # one all-gather (RCCL) + GPU merge
-        return exchange.send
+            exchange.finish(sptr)
+        for s in batches:
+            batches[s].results_to_device(slots[ph][s][0], slots[ph][s][1], sptr)
+        if multi:
+            exchange.start(ph)
+
+    def flush():
+        return exchange.finish(sptr) if multi else None
 
     for _ in range(args.warmup):
         step()
+    flush()
     sync()
     # sanity: results are retrievable (also triggers the overflow re-run path if needed)
     for s in batches:
@@ -232,6 +241,7 @@ def main():
         # per-kernel HIP-event timings of this step on rank 0 (waits for the stream)
         if rank == 0:
             score_ms.append(np.sum([batches[s].timings() for s in batches], axis=0))
+    flush()
     sync()
     if world > 1:
         dist.barrier()

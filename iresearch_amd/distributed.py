@@ -73,6 +73,19 @@ class TopkExchange:
         base = self.send.data_ptr()
         return base + 8 * i * self.nq * self.k, base + 8 * self.hit_words + 4 * i * self.nq
 
+    def gather(self, async_op: bool = False):
+        """The collective alone; with async_op the work handle (None on a single rank)."""
+        if self.world > 1:
+            return dist.all_gather_into_tensor(self.recv, self.send, async_op=async_op)
+        return None
+
+    def merge(self, stream=None):
+        _lib.check(self.L, self.L.irs_hip_merge_topk(
+            self.device_index, self._lists, self._counts, self._seg_ids.ctypes.data,
+            self.n_lists, self.nq, self.k, self.out_h.data_ptr(), self.out_s.data_ptr(),
+            self.out_c.data_ptr(), stream), "irs_hip_merge_topk")
+        return self.out_h, self.out_s, self.out_c
+
     def run(self, stream=None):
         if self.world > 1:
             dist.all_gather_into_tensor(self.recv, self.send)
@@ -81,6 +94,35 @@ class TopkExchange:
             self.n_lists, self.nq, self.k, self.out_h.data_ptr(), self.out_s.data_ptr(),
             self.out_c.data_ptr(), stream), "irs_hip_merge_topk")
         return self.out_h, self.out_s, self.out_c
+
+
+class PipelinedExchange:
+    """Two TopkExchange buffer sets used alternately, so that the all-gather of step i runs on
+    the collective's own stream (RCCL) WHILE the kernels of step i+1 execute; the merge of
+    step i is enqueued behind those kernels.  Per step:  run the batch (async) ->
+    finish() = merge of the previous step -> results_to_device into slot(phase, .) ->
+    start(phase).  After the last step: finish().  Every step still ends in a checked,
+    merged, device-resident top-k — one step later."""
+
+    def __init__(self, *args, **kw):
+        self.ex = [TopkExchange(*args, **kw), TopkExchange(*args, **kw)]
+        self.pending = None
+
+    def slot(self, phase: int, i: int):
+        return self.ex[phase].slot(i)
+
+    def start(self, phase: int):
+        assert self.pending is None
+        self.pending = (phase, self.ex[phase].gather(async_op=True))
+
+    def finish(self, stream=None):
+        if self.pending is None:
+            return None
+        phase, work = self.pending
+        self.pending = None
+        if work is not None:
+            work.wait()     # nccl: the current stream waits for the collective; gloo: the host
+        return self.ex[phase].merge(stream)
 
 
 def gather_merge(L, device_index: int, local_lists, n_segments: int, rank: int, world: int,

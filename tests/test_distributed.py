@@ -74,6 +74,19 @@ def _worker(rank, world, port, sim_path, out_dir, phrase=False):
         sb.close()
     oh2, osg2, oc2 = distributed.gather_merge(L, 0, lists, N_SEGS, rank, world, nq, K, "cpu")
     assert torch.equal(oh, oh2) and torch.equal(osg, osg2) and torch.equal(oc, oc2)
+    # ... and so must bench.py's pipelined form (the collective of step i is in flight while
+    # step i+1 runs; its merge comes one step later), on both buffer sets
+    px = distributed.PipelinedExchange(L, 0, N_SEGS, rank, world, nq, K, "cpu")
+    for it in range(3):
+        b.run()
+        prev = px.finish()
+        if it:
+            assert all(torch.equal(x, y) for x, y in zip(prev, (oh, osg, oc))), it
+        b.results_to_device(*px.slot(it & 1, 0))
+        px.start(it & 1)
+    last = px.finish()
+    assert all(torch.equal(x, y) for x, y in zip(last, (oh, osg, oc)))
+    assert px.finish() is None
     np.save(os.path.join(out_dir, "hits_%d.npy" % rank), oh.numpy())
     np.save(os.path.join(out_dir, "segs_%d.npy" % rank), osg.numpy())
     np.save(os.path.join(out_dir, "counts_%d.npy" % rank), oc.numpy())
