@@ -1,0 +1,385 @@
+// irs_hip.hpp — C++ host side above the C ABI (include/irs_hip.h), header only.
+//
+// Mirrors, for the hot path only, the interfaces an IResearch caller uses — same names,
+// argument meaning and error behaviour — so that code (and tests) written against the
+// reference read the same here:
+//   irs::BM25 / irs::TFIDF ::collect           core/search/bm25.cpp:366-410, tfidf.cpp:263-278
+//   irs::by_term / irs::Or / irs::And          core/search/term_filter.hpp, boolean_filter.hpp
+//   irs::by_phrase (plain terms)               core/search/phrase_filter.hpp:50-110
+//   filter::prepare  -> filter::prepared       core/search/term_filter.cpp:92-129,
+//                                              phrase_filter.cpp:212-293 (statistics over ALL segments)
+//   prepared::execute(segment) + harness loop  core/search/filter.hpp:52-78, utils/index-search.cpp:719-787
+//   exceptions instead of status codes         io_error / index_error / illegal_argument
+//                                              (core/error/error.hpp), as formats_10.cpp:3410-3415
+// Nothing per posting happens here: every posting is decoded and scored by libirs_hip.so on
+// the GPU.  The Python module iresearch_amd/search.py is the same layer for the test and
+// bench plumbing; both produce bit-identical scorer parameters.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <variant>
+#include <vector>
+
+#include "irs_hip.h"
+
+namespace irs_hip_host {
+
+// ---- errors: the reference throws, the C ABI returns codes ---------------------------------
+struct error : std::runtime_error {
+  int status;
+  error(int s, const std::string& what) : std::runtime_error(what), status(s) {}
+};
+struct illegal_argument : error { using error::error; };   // IRS_HIP_EINVAL
+struct index_error : error { using error::error; };        // IRS_HIP_ECORRUPT
+struct io_error : error { using error::error; };           // IRS_HIP_EHIP / ENOMEM / EOVERFLOW
+struct not_supported : error { using error::error; };      // IRS_HIP_EUNSUPPORTED
+
+inline void check(int rc, const char* what) {
+  if (rc == IRS_HIP_OK) return;
+  const std::string msg = std::string(what) + ": " + irs_hip_strerror(rc);
+  switch (rc) {
+    case IRS_HIP_EINVAL: throw illegal_argument(rc, msg);
+    case IRS_HIP_ECORRUPT: throw index_error(rc, msg);
+    case IRS_HIP_EUNSUPPORTED: throw not_supported(rc, msg);
+    default: throw io_error(rc, msg);
+  }
+}
+
+// ---- scorers ---------------------------------------------------------------------------------
+// The part of BM25Stats / TFIDF's idf that crosses the ABI (bm25.hpp:48-57).  `collect`
+// ACCUMULATES idf like the reference (`stats.idf += ...`, bm25.cpp:381-383): a phrase finishes
+// all of its terms into one blob (phrase_filter.cpp:281-287).
+struct TermStats {
+  float idf = 0.f;
+  float norm_const = 0.f;
+  float norm_length = 0.f;
+};
+
+class BM25 {
+ public:
+  explicit BM25(float k = 1.2f, float b = 0.75f) noexcept : k_{k}, b_{b} {}
+  float k() const noexcept { return k_; }
+  float b() const noexcept { return b_; }
+  bool IsBM1() const noexcept { return k_ == 0.f; }                // bm25.hpp:101
+  bool IsBM15() const noexcept { return !IsBM1() && b_ == 0.f; }   // bm25.hpp:103
+
+  void collect(TermStats& stats, uint64_t docs_with_field, uint64_t docs_with_term,
+               uint64_t total_term_freq) const {
+    stats.idf += static_cast<float>(
+      std::log1p((static_cast<double>(docs_with_field - docs_with_term) + 0.5) /
+                 (static_cast<double>(docs_with_term) + 0.5)));
+    if (k_ == 0.f || b_ == 0.f) {  // !NeedsNorm(), bm25.cpp:387-390
+      stats.norm_const = k_;
+      return;
+    }
+    const float kb = k_ * b_;
+    stats.norm_const = k_ - kb;
+    if (total_term_freq && docs_with_field) {
+      const float avg_dl =
+        static_cast<float>(total_term_freq) / static_cast<float>(docs_with_field);
+      stats.norm_length = kb / avg_dl;
+    } else {
+      stats.norm_length = kb;
+    }
+  }
+  irs_hip_term_scorer term_scorer(const TermStats& st, float boost) const noexcept {
+    irs_hip_term_scorer t{};
+    t.kind = IsBM1() ? IRS_HIP_SCORE_BM1 : IsBM15() ? IRS_HIP_SCORE_BM15 : IRS_HIP_SCORE_BM25;
+    t.c0 = boost * (k_ + 1.f) * st.idf;  // BM1Context, bm25.cpp:201
+    t.norm_const = st.norm_const;
+    t.norm_length = st.norm_length;
+    return t;
+  }
+
+ private:
+  float k_, b_;
+};
+
+class TFIDF {
+ public:
+  explicit TFIDF(bool normalize = false) noexcept : normalize_{normalize} {}
+  bool normalize() const noexcept { return normalize_; }
+  void collect(TermStats& stats, uint64_t docs_with_field, uint64_t docs_with_term,
+               uint64_t /*total_term_freq*/) const {
+    stats.idf += static_cast<float>(std::log1p((static_cast<double>(docs_with_field) + 1.0) /
+                                               (static_cast<double>(docs_with_term) + 1.0)));
+  }
+  irs_hip_term_scorer term_scorer(const TermStats& st, float boost) const noexcept {
+    irs_hip_term_scorer t{};
+    t.kind = normalize_ ? IRS_HIP_SCORE_TFIDF_NORM : IRS_HIP_SCORE_TFIDF;
+    t.c0 = boost * st.idf;  // TFIDFContext, tfidf.cpp:199
+    return t;
+  }
+
+ private:
+  bool normalize_;
+};
+
+// ---- filters ---------------------------------------------------------------------------------
+// Terms are ordinals of the segment's staged term table (the term dictionary walk is the
+// adapter's business: INTEGRATION.md).
+struct by_term {
+  uint32_t term = IRS_HIP_NO_TERM;
+  float boost = 1.f;
+};
+struct Or {
+  std::vector<by_term> subs;
+  uint32_t min_match_count = 1;  // irs::Or::min_match_count()
+};
+struct And {
+  std::vector<by_term> subs;
+};
+struct by_phrase {
+  std::vector<uint32_t> terms;
+  std::vector<uint32_t> offsets;  // relative to the first term; empty = consecutive words
+  float boost = 1.f;
+  // by_phrase_options::push_back<by_term_options>(offs): `offs` positions after the end
+  by_phrase& push_back(uint32_t term, uint32_t offs = 0) {
+    const uint32_t next = offsets.empty() ? 0u : offsets.back() + 1u;
+    terms.push_back(term);
+    offsets.push_back(next + offs);
+    return *this;
+  }
+};
+using filter = std::variant<by_term, Or, And, by_phrase>;
+
+// What by_term::prepare reads from one segment without touching postings.
+struct SegmentStats {
+  uint64_t docs_with_field = 0;
+  uint64_t total_term_freq = 0;
+  const irs_hip_term_meta* terms = nullptr;
+  uint32_t num_terms = 0;
+  uint64_t docs_count(uint32_t term) const noexcept {
+    return term < num_terms ? terms[term].docs_count : 0;
+  }
+};
+
+// filter::prepared: the op plus the (term, scorer values) entries of one query.
+struct PreparedQuery {
+  int32_t op = IRS_HIP_OP_OR;
+  uint32_t min_match = 0;
+  std::vector<irs_hip_term_scorer> terms;  // .term = the ordinal; same for every segment here
+};
+
+// filter::prepare for a list of filters against ALL segments (statistics are index-global:
+// D = sum docs_with_field, d = sum docs_count of the term, avgdl from the summed frequency).
+template<typename Scorer>
+std::vector<PreparedQuery> prepare(const std::vector<filter>& filters, const Scorer& scorer,
+                                   const std::vector<SegmentStats>& index) {
+  uint64_t dwf = 0, ttf = 0;
+  for (const auto& s : index) {
+    dwf += s.docs_with_field;
+    ttf += s.total_term_freq;
+  }
+  auto docs_with_term = [&](uint32_t term) {
+    uint64_t d = 0;
+    for (const auto& s : index) d += s.docs_count(term);
+    return d;
+  };
+  auto one = [&](const by_term& t) {
+    TermStats st;
+    scorer.collect(st, dwf, docs_with_term(t.term), ttf);
+    irs_hip_term_scorer e = scorer.term_scorer(st, t.boost);
+    e.term = t.term;
+    return e;
+  };
+  std::vector<PreparedQuery> out;
+  out.reserve(filters.size());
+  for (const filter& f : filters) {
+    PreparedQuery q;
+    if (const auto* t = std::get_if<by_term>(&f)) {
+      q.op = IRS_HIP_OP_OR;
+      q.terms.push_back(one(*t));
+    } else if (const auto* o = std::get_if<Or>(&f)) {
+      q.op = o->min_match_count > 1 ? IRS_HIP_OP_MINMATCH : IRS_HIP_OP_OR;
+      q.min_match = o->min_match_count > 1 ? o->min_match_count : 0;
+      for (const auto& t : o->subs) q.terms.push_back(one(t));
+    } else if (const auto* a = std::get_if<And>(&f)) {
+      q.op = IRS_HIP_OP_AND;
+      for (const auto& t : a->subs) q.terms.push_back(one(t));
+    } else {
+      const auto& p = std::get<by_phrase>(f);
+      if (!p.offsets.empty() && (p.offsets.size() != p.terms.size() || p.offsets[0] != 0))
+        throw illegal_argument(IRS_HIP_EINVAL, "by_phrase: offsets are relative to the first term");
+      q.op = IRS_HIP_OP_PHRASE;
+      TermStats st;  // ONE blob for the phrase (FixedPrepareCollect)
+      for (uint32_t t : p.terms) scorer.collect(st, dwf, docs_with_term(t), ttf);
+      irs_hip_term_scorer e = scorer.term_scorer(st, p.boost);
+      for (size_t i = 0; i < p.terms.size(); ++i) {
+        e.term = p.terms[i];
+        e.phrase_offset = p.offsets.empty() ? uint32_t(i) : p.offsets[i];
+        q.terms.push_back(e);
+      }
+    }
+    if (q.terms.empty()) throw illegal_argument(IRS_HIP_EINVAL, "empty filter");
+    out.push_back(std::move(q));
+  }
+  return out;
+}
+
+// ---- one segment on one GPU ------------------------------------------------------------------
+// irs::SubReader + postings_reader of one segment (postings_reader::prepare ... CountMappedMemory).
+class SegmentReader {
+ public:
+  explicit SegmentReader(const irs_hip_segment_desc& desc) : num_terms_{desc.num_terms} {
+    check(irs_hip_segment_open(&desc, &h_), "irs_hip_segment_open");
+  }
+  SegmentReader(const SegmentReader&) = delete;
+  SegmentReader& operator=(const SegmentReader&) = delete;
+  ~SegmentReader() { irs_hip_segment_close(h_); }
+  irs_hip_segment* handle() const noexcept { return h_; }
+  uint32_t num_terms() const noexcept { return num_terms_; }
+  uint64_t CountMappedMemory() const noexcept { return irs_hip_segment_device_bytes(h_); }
+
+  // postings_reader::iterator(...) drained: (docs, freqs) of one term
+  void postings(uint32_t term, std::vector<uint32_t>& docs, std::vector<uint32_t>* freqs,
+                uint32_t docs_count) const {
+    docs.resize(docs_count ? docs_count : 1);
+    if (freqs) freqs->resize(docs.size());
+    uint32_t n = 0;
+    check(irs_hip_decode_term(h_, term, docs.data(), freqs ? freqs->data() : nullptr,
+                              uint32_t(docs.size()), &n),
+          "irs_hip_decode_term");
+    docs.resize(n);
+    if (freqs) freqs->resize(n);
+  }
+  void positions(uint32_t term, std::vector<uint32_t>& out, uint64_t total_freq) const {
+    out.resize(total_freq ? total_freq : 1);
+    uint64_t n = 0;
+    check(irs_hip_decode_positions(h_, term, out.data(), out.size(), &n),
+          "irs_hip_decode_positions");
+    out.resize(n);
+  }
+  // postings_reader::bit_union: returns the sum of docs_count like the reference
+  uint64_t bit_union(const std::vector<uint32_t>& terms, std::vector<uint64_t>& set) const {
+    uint64_t count = 0;
+    check(irs_hip_bit_union(h_, terms.data(), uint32_t(terms.size()), set.data(), set.size(),
+                            &count),
+          "irs_hip_bit_union");
+    return count;
+  }
+
+ private:
+  irs_hip_segment* h_ = nullptr;
+  uint32_t num_terms_ = 0;
+};
+
+// ---- a batch of prepared queries on one or several segments of one device -------------------
+class QueryBatch {
+ public:
+  struct Results {
+    uint32_t n_segments = 0, n_queries = 0, k = 0;
+    std::vector<irs_hip_hit> hits;        // [segment][query][k]
+    std::vector<uint32_t> counts;         // [segment][query]
+    std::vector<uint64_t> total_hits;     // [segment][query]: index-search `hits=`
+    const irs_hip_hit* of(uint32_t seg, uint32_t q) const {
+      return hits.data() + (size_t(seg) * n_queries + q) * k;
+    }
+    uint32_t count(uint32_t seg, uint32_t q) const { return counts[size_t(seg) * n_queries + q]; }
+    uint64_t total(uint32_t seg, uint32_t q) const {
+      return total_hits[size_t(seg) * n_queries + q];
+    }
+  };
+
+  // A term a segment lacks (ordinal beyond its table) becomes IRS_HIP_NO_TERM there
+  // (TermQuery::execute: no state for the segment -> empty iterator, term_query.cpp:41-43).
+  // The device runs phrase queries and boolean queries as separate batches (different
+  // kernels); a caller mixes them freely, as with the reference: they are split here and the
+  // results stitched back in the caller's order.
+  QueryBatch(const std::vector<const SegmentReader*>& segments,
+             const std::vector<PreparedQuery>& prepared, uint32_t k)
+    : n_segments_{uint32_t(segments.size())}, n_queries_{uint32_t(prepared.size())}, k_{k} {
+    for (uint32_t q = 0; q < n_queries_; ++q)
+      part_[prepared[q].op == IRS_HIP_OP_PHRASE ? 1 : 0].index.push_back(q);
+    try {
+      for (Part& part : part_) {
+        if (part.index.empty()) continue;
+        std::vector<irs_hip_query> queries;
+        std::vector<irs_hip_term_scorer> entries;
+        for (uint32_t q : part.index) {
+          const PreparedQuery& p = prepared[q];
+          queries.push_back(irs_hip_query{p.op, uint32_t(p.terms.size()),
+                                          uint32_t(entries.size()), k, p.min_match});
+          entries.insert(entries.end(), p.terms.begin(), p.terms.end());
+        }
+        std::vector<irs_hip_term_scorer> all;
+        std::vector<irs_hip_segment*> handles;
+        for (const SegmentReader* s : segments) {
+          handles.push_back(s->handle());
+          for (irs_hip_term_scorer e : entries) {
+            if (e.term >= s->num_terms()) e.term = IRS_HIP_NO_TERM;
+            all.push_back(e);
+          }
+        }
+        check(irs_hip_batch_create_multi(handles.data(), n_segments_, queries.data(),
+                                         uint32_t(queries.size()), all.data(),
+                                         uint32_t(entries.size()), &part.h),
+              "irs_hip_batch_create_multi");
+      }
+    } catch (...) {
+      for (Part& part : part_) irs_hip_batch_destroy(part.h);
+      throw;
+    }
+  }
+  QueryBatch(const QueryBatch&) = delete;
+  QueryBatch& operator=(const QueryBatch&) = delete;
+  ~QueryBatch() {
+    for (Part& part : part_) irs_hip_batch_destroy(part.h);
+  }
+
+  QueryBatch& run(void* stream = nullptr) {
+    for (Part& part : part_)
+      if (part.h) check(irs_hip_batch_run(part.h, stream), "irs_hip_batch_run");
+    return *this;
+  }
+  Results results() {
+    Results r;
+    r.n_segments = n_segments_;
+    r.n_queries = n_queries_;
+    r.k = k_;
+    const size_t units = size_t(n_segments_) * n_queries_;
+    r.hits.resize(units * k_);
+    r.counts.resize(units);
+    r.total_hits.resize(units);
+    for (Part& part : part_) {
+      if (!part.h) continue;
+      const size_t nq = part.index.size(), pu = size_t(n_segments_) * nq;
+      std::vector<irs_hip_hit> hits(pu * k_);
+      std::vector<uint32_t> counts(pu);
+      std::vector<uint64_t> totals(pu);
+      check(irs_hip_batch_results(part.h, hits.data(), k_, counts.data(), totals.data()),
+            "irs_hip_batch_results");
+      for (uint32_t s = 0; s < n_segments_; ++s)
+        for (size_t i = 0; i < nq; ++i) {
+          const size_t from = s * nq + i, to = size_t(s) * n_queries_ + part.index[i];
+          std::copy_n(hits.begin() + from * k_, counts[from], r.hits.begin() + to * k_);
+          r.counts[to] = counts[from];
+          r.total_hits[to] = totals[from];
+        }
+    }
+    return r;
+  }
+  uint32_t reruns() const {
+    uint32_t total = 0;
+    for (const Part& part : part_) {
+      uint32_t n = 0;
+      if (part.h) check(irs_hip_batch_reruns(part.h, &n), "irs_hip_batch_reruns");
+      total += n;
+    }
+    return total;
+  }
+
+ private:
+  struct Part {  // [0] boolean queries, [1] phrase queries
+    irs_hip_batch* h = nullptr;
+    std::vector<uint32_t> index;  // position of each of its queries in the caller's list
+  };
+  Part part_[2];
+  uint32_t n_segments_, n_queries_, k_;
+};
+
+}  // namespace irs_hip_host

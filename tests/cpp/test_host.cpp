@@ -1,0 +1,236 @@
+// tests/cpp/test_host.cpp — TEST: the C++ host layer (iresearch_amd/cpp/irs_hip.hpp) above the
+// C ABI, written the way the reference's own search tests read (build an index, prepare
+// filters against it with a scorer, execute per segment, compare with expectations), checked
+// against the oracle's C API.  Linked against libirs_hip.so on a GPU box, or against the CPU
+// emulator build of the same sources (tests/sim) in the CPU tier.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "irs_hip.hpp"
+#include "oracle.h"
+#include "synth_index.h"
+
+using namespace irs_hip_host;
+
+#define REQUIRE(c)                                                          \
+  do {                                                                      \
+    if (!(c)) {                                                             \
+      std::fprintf(stderr, "%s:%d: REQUIRE(%s) failed\n", __FILE__, __LINE__, #c); \
+      return 1;                                                             \
+    }                                                                       \
+  } while (0)
+
+namespace {
+
+struct Segment {  // a synthetic segment and everything the two sides need of it
+  irs_synth_index* idx = nullptr;
+  const uint8_t *doc = nullptr, *pos = nullptr, *norms = nullptr;
+  uint64_t doc_len = 0, pos_len = 0, norm_count = 0;
+  const irs_hip_term_meta* metas = nullptr;
+  uint32_t num_terms = 0, num_docs = 0;
+  std::unique_ptr<SegmentReader> reader;
+
+  Segment(uint32_t docs, uint64_t first_doc, uint32_t max_rank) : num_docs{docs} {
+    irs_synth_params p{};
+    p.seed = 20260926;
+    p.first_doc = first_doc;
+    p.num_docs = docs;
+    p.vocab_log2 = 20;
+    p.max_rank = max_rank;
+    p.layout = IRS_SYNTH_LAYOUT_SIMD4;
+    p.mean_len = 100;
+    p.stddev_len = 30;
+    p.with_positions = 1;
+    if (irs_synth_build(&p, &idx) != 0) throw std::runtime_error("irs_synth_build");
+    doc = irs_synth_doc_bytes(idx, &doc_len);
+    pos = irs_synth_pos_bytes(idx, &pos_len);
+    norms = irs_synth_norms(idx, &norm_count);
+    static_assert(sizeof(irs_synth_term_meta) == sizeof(irs_hip_term_meta), "same layout");
+    static_assert(sizeof(orc_term_meta) == sizeof(irs_hip_term_meta), "same layout");
+    metas = reinterpret_cast<const irs_hip_term_meta*>(irs_synth_term_metas(idx, &num_terms));
+    reader = std::make_unique<SegmentReader>(desc());
+  }
+  ~Segment() {
+    reader.reset();
+    irs_synth_free(idx);
+  }
+  irs_hip_segment_desc desc() const {
+    irs_hip_segment_desc d{};
+    d.device = 0;
+    d.layout = IRS_HIP_LAYOUT_SIMD4;
+    d.doc_file = doc;
+    d.doc_file_len = doc_len;
+    d.num_docs = num_docs;
+    d.has_freq = 1;
+    d.norms = norms;
+    d.norm_width = 1;
+    d.norm_min_doc = 1;
+    d.norm_count = norm_count;
+    d.terms = metas;
+    d.num_terms = num_terms;
+    d.pos_file = pos;
+    d.pos_file_len = pos_len;
+    return d;
+  }
+  SegmentStats stats() const {
+    return SegmentStats{irs_synth_docs_with_field(idx), irs_synth_total_term_freq(idx), metas,
+                        num_terms};
+  }
+  orc_segment oracle_view() const {
+    orc_segment s{};
+    s.doc_file = doc;
+    s.doc_file_len = doc_len;
+    s.layout = ORC_LAYOUT_SIMD4;
+    s.num_docs = num_docs;
+    s.norms = norms;
+    s.norm_width = 1;
+    s.pos_file = pos;
+    s.pos_file_len = pos_len;
+    return s;
+  }
+};
+
+bool close_rel(float a, float b) { return std::fabs(a - b) <= 1e-5f * std::fabs(b); }
+
+}  // namespace
+
+int main() {
+  constexpr uint32_t kMaxRank = 128, kTop = 50;
+  Segment a(20000, 0, kMaxRank), b(9000, 20000, kMaxRank);
+  const Segment* segs[2] = {&a, &b};
+
+  // filters, as a caller of the reference would write them
+  std::vector<filter> filters;
+  uint32_t ranks[4 * 8];
+  REQUIRE(irs_synth_queries(20260928, 4, 8, 2, kMaxRank, ranks) == 0);
+  for (int q = 0; q < 4; ++q) {
+    Or f;
+    for (int t = 0; t < 8; ++t) f.subs.push_back(by_term{ranks[q * 8 + t] - 1});
+    filters.push_back(f);
+  }
+  filters.push_back(by_term{7});
+  filters.push_back(And{{by_term{1}, by_term{20}, by_term{3, 2.5f}}});
+  filters.push_back(Or{{by_term{2}, by_term{9}, by_term{30}, by_term{5}}, 2});
+  filters.push_back(by_phrase{}.push_back(0).push_back(1));
+  filters.push_back(by_phrase{}.push_back(2).push_back(0, 1).push_back(1));  // a gap of one word
+  filters.push_back(by_term{kMaxRank + 500});                                  // no such term
+
+  const BM25 scorer;  // k = 1.2, b = 0.75
+  const auto prepared = prepare(filters, scorer, {a.stats(), b.stats()});
+  QueryBatch batch({a.reader.get(), b.reader.get()}, prepared, kTop);
+  const auto res = batch.run().results();
+  REQUIRE(res.n_segments == 2 && res.n_queries == filters.size());
+
+  // the oracle's harness loop over both segments (utils/index-search.cpp:719-787)
+  const orc_segment views[2] = {a.oracle_view(), b.oracle_view()};
+  const uint64_t dwf[2] = {a.stats().docs_with_field, b.stats().docs_with_field};
+  const uint64_t ttf[2] = {a.stats().total_term_freq, b.stats().total_term_freq};
+  const orc_scorer osc{ORC_SCORER_BM25, scorer.k(), scorer.b(), 0};
+  for (size_t q = 0; q < filters.size(); ++q) {
+    const PreparedQuery& p = prepared[q];
+    const uint32_t n = uint32_t(p.terms.size());
+    std::vector<orc_term_meta> metas(2 * n);
+    std::vector<float> boosts(n, 1.f);
+    std::vector<uint32_t> offsets(n);
+    for (uint32_t s = 0; s < 2; ++s)
+      for (uint32_t t = 0; t < n; ++t) {
+        const uint32_t term = p.terms[t].term;
+        if (term < segs[s]->num_terms)
+          std::memcpy(&metas[s * n + t], &segs[s]->metas[term], sizeof(orc_term_meta));
+        offsets[t] = p.terms[t].phrase_offset;
+      }
+    std::vector<orc_hit> want(kTop);
+    uint64_t want_total = 0;
+    int64_t got_n;
+    if (p.op == IRS_HIP_OP_PHRASE) {
+      got_n = orc_search_phrase(views, 2, metas.data(), n, offsets.data(), &osc,
+                                std::get<by_phrase>(filters[q]).boost, dwf, ttf, kTop, want.data(),
+                                &want_total);
+    } else {
+      if (const auto* f = std::get_if<And>(&filters[q]))
+        for (uint32_t t = 0; t < n; ++t) boosts[t] = f->subs[t].boost;
+      const int32_t op = p.op == IRS_HIP_OP_MINMATCH ? (ORC_OP_MINMATCH | int32_t(p.min_match << 8))
+                                                     : p.op;
+      got_n = orc_search(views, 2, metas.data(), n, op, &osc, boosts.data(), dwf, ttf, kTop,
+                         want.data(), &want_total);
+    }
+    REQUIRE(got_n >= 0);
+    want.resize(size_t(got_n));
+    // merge the two per-segment lists the way the harness heap would see them
+    std::vector<irs_hip_hit> mine;
+    for (uint32_t s = 0; s < 2; ++s)
+      mine.insert(mine.end(), res.of(s, uint32_t(q)), res.of(s, uint32_t(q)) + res.count(s, uint32_t(q)));
+    std::sort(mine.begin(), mine.end(),
+              [](const irs_hip_hit& x, const irs_hip_hit& y) { return x.score > y.score; });
+    if (mine.size() > kTop) mine.resize(kTop);
+    REQUIRE(res.total(0, uint32_t(q)) + res.total(1, uint32_t(q)) == want_total);
+    REQUIRE(mine.size() == want.size());
+    std::sort(want.begin(), want.end(),
+              [](const orc_hit& x, const orc_hit& y) { return x.score > y.score; });
+    for (size_t i = 0; i < want.size(); ++i) REQUIRE(close_rel(mine[i].score, want[i].score));
+  }
+  REQUIRE(batch.reruns() == 0);
+
+  // postings / positions / bit_union of one term against the oracle's iterators
+  {
+    const uint32_t term = 11;
+    std::vector<uint32_t> docs, freqs, pos;
+    a.reader->postings(term, docs, &freqs, a.metas[term].docs_count);
+    std::vector<uint32_t> odocs(docs.size()), ofreqs(docs.size());
+    REQUIRE(orc_decode_term(a.doc, a.doc_len, ORC_LAYOUT_SIMD4,
+                            reinterpret_cast<const orc_term_meta*>(&a.metas[term]), odocs.data(),
+                            ofreqs.data(), odocs.size()) == int64_t(docs.size()));
+    REQUIRE(docs == odocs && freqs == ofreqs);
+    a.reader->positions(term, pos, a.metas[term].freq);
+    std::vector<uint32_t> opos(pos.size());
+    REQUIRE(orc_decode_positions(a.doc, a.doc_len, a.pos, a.pos_len, ORC_LAYOUT_SIMD4, 0,
+                                 reinterpret_cast<const orc_term_meta*>(&a.metas[term]), 1,
+                                 opos.data(), opos.size()) == int64_t(pos.size()));
+    REQUIRE(pos == opos);
+    std::vector<uint64_t> set((a.num_docs + 64) / 64, 0), oset(set.size(), 0);
+    const std::vector<uint32_t> terms{3, 11, 90};
+    orc_term_meta om[3];
+    for (int i = 0; i < 3; ++i) std::memcpy(&om[i], &a.metas[terms[i]], sizeof om[i]);
+    const uint64_t cnt = a.reader->bit_union(terms, set);
+    REQUIRE(int64_t(cnt) == orc_bit_union(a.doc, a.doc_len, ORC_LAYOUT_SIMD4, 1, om, 3, oset.data(),
+                                          oset.size()));
+    REQUIRE(set == oset);
+  }
+
+  // error behaviour: exceptions where the reference throws
+  {
+    bool threw = false;
+    try {
+      QueryBatch bad({a.reader.get()}, prepared, 0);  // top-0
+    } catch (const illegal_argument&) {
+      threw = true;
+    }
+    REQUIRE(threw);
+    std::vector<uint8_t> corrupt(a.doc, a.doc + a.doc_len);
+    corrupt[0] ^= 0xFF;  // format magic
+    irs_hip_segment_desc d = a.desc();
+    d.doc_file = corrupt.data();
+    threw = false;
+    try {
+      SegmentReader r(d);
+    } catch (const index_error&) {
+      threw = true;
+    }
+    REQUIRE(threw);
+    d = a.desc();
+    d.device = 99;  // no such device
+    threw = false;
+    try {
+      SegmentReader r(d);
+    } catch (const io_error&) {
+      threw = true;
+    }
+    REQUIRE(threw);
+  }
+  std::printf("test_host OK: %zu queries over 2 segments, %zu phrase\n", filters.size(), size_t(2));
+  return 0;
+}

@@ -1,0 +1,44 @@
+"""The C++ host layer above the C ABI (iresearch_amd/cpp/irs_hip.hpp): tests/cpp/test_host.cpp
+is compiled with g++ and run — against the CPU emulator build of the product sources here,
+against libirs_hip.so on a GPU box.  The program itself checks every result against the
+oracle's C API."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _build_and_run(tmp_path, abi_lib: Path, extra=()):
+    import oracle
+    from iresearch_amd import _build
+    synth = _build.build_synth()
+    orc = oracle.build()
+    exe = tmp_path / "test_host"
+    cmd = ["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-Wall",
+           "-I", str(ROOT / "include"), "-I", str(ROOT / "iresearch_amd" / "cpp"),
+           "-I", str(ROOT / "iresearch_amd" / "index"), "-I", str(ROOT / "oracle"),
+           str(ROOT / "tests" / "cpp" / "test_host.cpp"), "-o", str(exe),
+           str(abi_lib), str(synth), str(orc), "-pthread",
+           "-Wl,-rpath," + str(abi_lib.parent), "-Wl,-rpath," + str(Path(synth).parent),
+           "-Wl,-rpath," + str(Path(orc).parent), *extra]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, (run.stdout + run.stderr)[-3000:]
+    assert "test_host OK" in run.stdout
+
+
+def test_cpp_host_layer_on_the_emulator(simlib, tmp_path):
+    _build_and_run(tmp_path, Path(simlib._name))
+
+
+@pytest.mark.gpu
+def test_cpp_host_layer_on_the_gpu(gpulib, tmp_path):
+    from iresearch_amd import _build
+    rocm = "/opt/rocm/lib"
+    _build_and_run(tmp_path, Path(_build.HIP_LIB),
+                   ["-Wl,-rpath," + rocm, "-Wl,-rpath-link," + rocm, "-Wl,--allow-shlib-undefined"])
