@@ -255,9 +255,9 @@ int irs_hip_batch_configure(irs_hip_batch* batch, uint32_t tile_docs,
  * When enabled, every run() brackets each kernel launch with events;
  * timings() waits for the stream and returns the durations (ms) of the last run. */
 enum {
-  IRS_HIP_K_PLAN = 0,   /* block-range planning + tail decode       */
+  IRS_HIP_K_PLAN = 0,   /* block-range planning per (query, term)    */
   IRS_HIP_K_PILOT = 1,  /* pilot tiles -> per-query score threshold */
-  IRS_HIP_K_SCORE = 2,  /* decode + score + accumulate + candidates */
+  IRS_HIP_K_SCORE = 2,  /* decode + score + accumulate + candidates (phrase batches: k_phrase) */
   IRS_HIP_K_SELECT = 3, /* exact top-k of the candidates            */
   IRS_HIP_K_COUNT = 4
 };
