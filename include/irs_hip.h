@@ -78,8 +78,9 @@ typedef struct irs_hip_segment_desc {
                              * lists' tails (formats_10.cpp:686-688, skipped as :2298-2301)
                              * and inside the skip data (never read here). 0..16. */
   const uint8_t* pos_file;  /* whole `.pos` file of a field with IndexFeatures::POS (and no
-                             * offsets / payloads), formats 1_3+ (zero-based position storage,
-                             * formats_10.cpp:297-304) — what postings_reader::prepare opens
+                             * offsets / payloads); zero-based (formats 1_3+) or one-based
+                             * (1_0..1_2) position storage is told from the file's version
+                             * (formats_10.cpp:283-304) — what postings_reader::prepare opens
                              * as pos_in_ (:3369-3381); NULL: no positions, no phrase queries */
   uint64_t pos_file_len;
 } irs_hip_segment_desc;

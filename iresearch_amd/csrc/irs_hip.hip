@@ -428,14 +428,12 @@ int irs_hip_segment_open(const irs_hip_segment_desc* d, irs_hip_segment** out) {
   if ((version & 1) != (d->layout == IRS_HIP_LAYOUT_SIMD4 ? 1 : 0)) return IRS_HIP_EINVAL;
   size_t pos_hdr = 0;
   if (d->pos_file) {
-    // positions need frequencies (IndexFeatures::POS implies FREQ); zero-based storage
-    // (PostingsFormat >= POSITIONS_ZEROBASED = 2, formats_10.cpp:297-304)
+    // positions need frequencies (IndexFeatures::POS implies FREQ)
     int32_t pos_version = -1;
     pos_hdr = check_pos_header(d->pos_file, d->pos_file_len, &pos_version);
     if (!pos_hdr) return IRS_HIP_ECORRUPT;
     if (pos_version != version) return IRS_HIP_ECORRUPT;
     if (!d->has_freq) return IRS_HIP_EINVAL;
-    if (version < 2) return IRS_HIP_EUNSUPPORTED;
   }
   if (!device_usable(d->device)) return IRS_HIP_EHIP;
 
@@ -574,6 +572,8 @@ int irs_hip_segment_open(const irs_hip_segment_desc* d, irs_hip_segment** out) {
       v.pblk_bits = s->d_pblk_bits.as<uint8_t>();
       v.blk_pos = s->d_blk_pos.as<uint32_t>();
       v.ptail = s->d_ptail.as<uint32_t>();
+      // PostingsFormat < POSITIONS_ZEROBASED (formats_10.cpp:283-304): one-based storage
+      v.pos_base = version < 2 ? 1u : 0u;
       rc = d->layout == IRS_HIP_LAYOUT_SIMD4 ? build_positions<kSimd4>(s, pos_end)
                                              : build_positions<kScalar>(s, pos_end);
     }

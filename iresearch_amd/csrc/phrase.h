@@ -235,7 +235,7 @@ k_decode_positions(DevSegment seg, uint32_t term, uint32_t* out) {
   }
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    uint32_t v = 0;  // pos_limits::invalid(): zero-based storage, first delta is the position
+    uint32_t v = seg.pos_base;  // pos_limits::invalid() (+ pos_limits::min() in the one-based formats)
     for (uint32_t k = 0; k < tf[h]; ++k) {
       v += pos_delta<LAYOUT>(seg, pt, term, pidx[h] + k);
       out[pidx[h] + k] = v;
@@ -478,13 +478,13 @@ k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms
       P[i] = on ? s_pidx[wv][i][s] : 0u;
       T[i] = on ? s_tf[wv][i][s] : 0u;
       K[i] = 0u;
-      V[i] = 0u;  // pos_limits::invalid()
+      V[i] = seg.pos_base;  // pos_limits::invalid() (+ min() before the first delta, one-based)
       all = all && (!on || T[i] != 0u);
     }
     if (!all) continue;
     // Walking every position of the first term counts the same matches as the
     // reference's lead.seek(sought - offset), which only skips positions that cannot match.
-    uint32_t pf = 0, head = 0;
+    uint32_t pf = 0, head = seg.pos_base;
     bool done = false;
     for (uint32_t a = 0; a < T[0] && !done; ++a) {
       head += pos_delta<LAYOUT>(seg, s_pt[0], s_tl[0].term, P[0] + a);  // lead.next()
@@ -495,7 +495,8 @@ k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms
           const uint32_t target = head + s_off[i];
           if (target < head) { done = true; break; }  // !pos_limits::valid(term_position)
           // position::seek(target) :1578-1604
-          while (V[i] < target && K[i] < T[i]) {
+          // (value_ is invalid until the first position is read: K[i] == 0)
+          while ((K[i] == 0u || V[i] < target) && K[i] < T[i]) {
             V[i] += pos_delta<LAYOUT>(seg, s_pt[i], s_tl[i].term, P[i] + K[i]);
             ++K[i];
           }

@@ -95,6 +95,9 @@ struct DevSegment {
   const uint32_t* blk_pos;   // per doc-block row (+1 sentinel): positions of ALL earlier rows
                              // (exclusive scan of the blocks' frequency sums, mod 2^32)
   const uint32_t* ptail;     // decoded position-delta tails, term after term (DevPosTerm::tail_row)
+  uint32_t pos_base;         // what a doc's first delta is relative to: 0 (formats 1_3+, zero-based
+                             // storage) or pos_limits::min() = 1 (1_0..1_2, formats_10.cpp:1623-1625)
+  uint32_t pos_pad;
 };
 
 struct DevQuery {

@@ -179,7 +179,8 @@ void wand_write(uint32_t kind, const WandEntry& e, Bytes& o) {
 void encode_term(const uint32_t* docs, const uint32_t* freqs, uint32_t count,
                  uint32_t segment_docs, uint32_t layout, Bytes& o,
                  irs_synth_term_meta& meta, const WandSpec* wand = nullptr,
-                 const uint32_t* positions = nullptr, Bytes* pos = nullptr) {
+                 const uint32_t* positions = nullptr, Bytes* pos = nullptr,
+                 bool one_based = false) {
   const size_t start = o.size();
   meta = irs_synth_term_meta{};
   meta.pos_end = UINT64_MAX;
@@ -286,7 +287,9 @@ void encode_term(const uint32_t* docs, const uint32_t* freqs, uint32_t count,
       n = 0;
     }
     if (has_pos) {
-      uint32_t pos_last = 0;  // FormatTraits::pos_min() of the zero-based formats (:883, :4196)
+      // FormatTraits::pos_min() (:883): 0 in the zero-based formats 1_3+ (:4196), pos_limits::min()
+      // in 1_0..1_2 (:4161), whose reader adds it back before the first delta (:1623-1625)
+      uint32_t pos_last = one_based ? 1u : 0u;
       for (uint32_t k = 0; k < freqs[i]; ++k) {  // AddPosition :894-913
         const uint32_t p = positions[pos_at++];
         pos_buf[pos_n++] = p - pos_last;
@@ -361,13 +364,15 @@ uint32_t crc32c(const uint8_t* p, size_t n) {
 constexpr char kDocFormatName[] = "iresearch_10_postings_documents";  // :325
 constexpr char kPosFormatName[] = "iresearch_10_postings_positions";  // :328
 
-void make_header(Bytes& o, uint32_t layout, const char* name = kDocFormatName) {
+void make_header(Bytes& o, uint32_t layout, const char* name = kDocFormatName,
+                 bool one_based = false) {
   const size_t len = std::strlen(name);
   put_be32(o, 0x3fd76c17u);  // kFormatMagic format_utils.hpp:36
   put_vint(o, uint32_t(len));
   o.insert(o.end(), name, name + len);
   // PostingsFormat::WAND_SSE (5) / WAND (4) — formats_10.cpp:305-311
-  put_be32(o, layout == IRS_SYNTH_LAYOUT_SIMD4 ? 5u : 4u);
+  // ... or POSITIONS_ONEBASED_SSE (1) / POSITIONS_ONEBASED (0), formats 1_2simd / 1_0 (:283-296)
+  put_be32(o, (one_based ? 0u : 4u) + (layout == IRS_SYNTH_LAYOUT_SIMD4 ? 1u : 0u));
 }
 
 // ---------------------------------------------------------------- corpus --
@@ -525,6 +530,22 @@ int64_t irs_synth_wrap_doc_file(const uint8_t* body, uint64_t body_len,
   return int64_t(o.size());
 }
 
+int64_t irs_synth_wrap_file(const uint8_t* body, uint64_t body_len, uint32_t layout,
+                            uint32_t is_pos, uint32_t one_based, uint8_t* out, uint64_t out_cap,
+                            uint64_t* body_offset) {
+  Bytes o;
+  make_header(o, layout, is_pos ? kPosFormatName : kDocFormatName, one_based != 0);
+  const uint64_t hdr = o.size();
+  o.insert(o.end(), body, body + body_len);
+  put_be32(o, uint32_t(-int32_t(0x3fd76c17)));
+  put_be32(o, 0);
+  put_be64(o, crc32c(o.data(), o.size()));
+  if (o.size() > out_cap) return -2;
+  std::memcpy(out, o.data(), o.size());
+  if (body_offset) *body_offset = hdr;
+  return int64_t(o.size());
+}
+
 int64_t irs_synth_wrap_pos_file(const uint8_t* body, uint64_t body_len,
                                 uint32_t layout, uint8_t* out,
                                 uint64_t out_cap, uint64_t* body_offset) {
@@ -548,6 +569,19 @@ int64_t irs_synth_encode_term_pos(const uint32_t* docs, const uint32_t* freqs,
                                   uint32_t wand_count, uint8_t* out, uint64_t out_cap,
                                   uint8_t* pos_out, uint64_t pos_cap, uint64_t* pos_len,
                                   irs_synth_term_meta* meta) {
+  return irs_synth_encode_term_pos_v(docs, freqs, positions, count, segment_docs, layout, norms,
+                                     wand_kinds, wand_count, 0, out, out_cap, pos_out, pos_cap,
+                                     pos_len, meta);
+}
+
+int64_t irs_synth_encode_term_pos_v(const uint32_t* docs, const uint32_t* freqs,
+                                    const uint32_t* positions, uint32_t count,
+                                    uint32_t segment_docs, uint32_t layout,
+                                    const uint8_t* norms, const uint32_t* wand_kinds,
+                                    uint32_t wand_count, uint32_t one_based, uint8_t* out,
+                                    uint64_t out_cap, uint8_t* pos_out, uint64_t pos_cap,
+                                    uint64_t* pos_len, irs_synth_term_meta* meta) {
+  if (one_based && wand_count) return -1;  // the one-based formats predate wand data
   if (!meta || !freqs || !positions || !pos_len || (count && !docs) || wand_count > 8 ||
       (wand_count && !wand_kinds))
     return -1;
@@ -572,7 +606,7 @@ int64_t irs_synth_encode_term_pos(const uint32_t* docs, const uint32_t* freqs,
   const WandSpec spec{norms, wand_count, wand_kinds};
   Bytes o, po;
   encode_term(docs, freqs, count, segment_docs, layout, o, *meta,
-              wand_count ? &spec : nullptr, positions, &po);
+              wand_count ? &spec : nullptr, positions, &po, one_based != 0);
   if (o.size() > out_cap || po.size() > pos_cap) return -2;
   if (!o.empty()) std::memcpy(out, o.data(), o.size());
   if (!po.empty()) std::memcpy(pos_out, po.data(), po.size());
@@ -584,7 +618,8 @@ int irs_synth_build(const irs_synth_params* p, irs_synth_index** out) {
   if (!p || !out || p->num_docs == 0 || p->max_rank == 0 ||
       p->vocab_log2 == 0 || p->vocab_log2 > 24 ||
       p->max_rank > (1u << p->vocab_log2) || p->num_docs >= 0x7FFFFFF0u ||
-      p->wand_count > 8 || p->wand_kind > IRS_SYNTH_WAND_DIV_NORM)
+      p->wand_count > 8 || p->wand_kind > IRS_SYNTH_WAND_DIV_NORM ||
+      (p->one_based_positions && p->wand_count))
     return -1;
   auto idx = std::make_unique<irs_synth_index>();
   const uint32_t N = p->num_docs;
@@ -691,7 +726,7 @@ int irs_synth_build(const irs_synth_params* p, irs_synth_index** out) {
           encode_term(d.data(), f.data(), uint32_t(total), N, p->layout,
                       term_bytes[r], idx->metas[r], wand.count ? &wand : nullptr,
                       p->with_positions ? ps.data() : nullptr,
-                      p->with_positions ? &term_pos[r] : nullptr);
+                      p->with_positions ? &term_pos[r] : nullptr, p->one_based_positions != 0);
           if (p->keep_postings) {
             idx->docs[r] = d;
             idx->freqs[r] = f;
@@ -705,7 +740,7 @@ int irs_synth_build(const irs_synth_params* p, irs_synth_index** out) {
 
   // ---- assemble the `.doc` image -----------------------------------------
   Bytes& file = idx->doc_file;
-  make_header(file, p->layout);
+  make_header(file, p->layout, kDocFormatName, p->one_based_positions != 0);
   uint64_t total = file.size();
   for (uint32_t r = 0; r < R; ++r) {
     idx->metas[r].doc_start += total;  // encode_term left it at 0
@@ -722,7 +757,7 @@ int irs_synth_build(const irs_synth_params* p, irs_synth_index** out) {
 
   if (p->with_positions) {  // the `.pos` image, same framing (:544-547)
     Bytes& pf = idx->pos_file;
-    make_header(pf, p->layout, kPosFormatName);
+    make_header(pf, p->layout, kPosFormatName, p->one_based_positions != 0);
     uint64_t at = pf.size();
     for (uint32_t r = 0; r < R; ++r) {
       idx->metas[r].pos_start += at;

@@ -60,7 +60,8 @@ typedef struct irs_synth_params {
   uint32_t wand_kind;     /* IRS_SYNTH_WAND_* of every one of them           */
   uint32_t with_positions;/* field has IndexFeatures::POS: also emit the `.pos` stream
                              (position of a token = its 1-based index in the doc)   */
-  uint32_t reserved;
+  uint32_t one_based_positions; /* write formats 1_0 / 1_2simd (PostingsFormat 0 / 1): the first
+                             position of a doc is stored relative to pos_limits::min() = 1 */
 } irs_synth_params;
 
 typedef struct irs_synth_index irs_synth_index;
@@ -121,6 +122,18 @@ int64_t irs_synth_encode_term_pos(const uint32_t* docs, const uint32_t* freqs,
                                   uint32_t wand_count, uint8_t* out, uint64_t out_cap,
                                   uint8_t* pos_out, uint64_t pos_cap, uint64_t* pos_len,
                                   irs_synth_term_meta* meta);
+/* ... with one_based != 0: the formats before 1_3 (one-based position storage, no wand data) */
+int64_t irs_synth_encode_term_pos_v(const uint32_t* docs, const uint32_t* freqs,
+                                    const uint32_t* positions, uint32_t count,
+                                    uint32_t segment_docs, uint32_t layout,
+                                    const uint8_t* norms, const uint32_t* wand_kinds,
+                                    uint32_t wand_count, uint32_t one_based, uint8_t* out,
+                                    uint64_t out_cap, uint8_t* pos_out, uint64_t pos_cap,
+                                    uint64_t* pos_len, irs_synth_term_meta* meta);
+/* header + body + footer of a `.doc` (is_pos == 0) or `.pos` file of either format family */
+int64_t irs_synth_wrap_file(const uint8_t* body, uint64_t body_len, uint32_t layout,
+                            uint32_t is_pos, uint32_t one_based, uint8_t* out, uint64_t out_cap,
+                            uint64_t* body_offset);
 int64_t irs_synth_wrap_pos_file(const uint8_t* body, uint64_t body_len,
                                 uint32_t layout, uint8_t* out,
                                 uint64_t out_cap, uint64_t* body_offset);

@@ -30,7 +30,7 @@ class _Params(C.Structure):
         ("vocab_log2", C.c_uint32), ("max_rank", C.c_uint32), ("layout", C.c_uint32),
         ("mean_len", C.c_uint32), ("stddev_len", C.c_uint32), ("threads", C.c_uint32),
         ("keep_postings", C.c_uint32), ("wand_count", C.c_uint32), ("wand_kind", C.c_uint32),
-        ("with_positions", C.c_uint32), ("reserved", C.c_uint32),
+        ("with_positions", C.c_uint32), ("one_based_positions", C.c_uint32),
     ]
 
 
@@ -66,6 +66,15 @@ def lib():
                                                 C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p,
                                                 C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]
         L.irs_synth_encode_term_pos.restype = C.c_int64
+        L.irs_synth_encode_term_pos_v.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                                  C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                                  C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64,
+                                                  C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                                  C.c_void_p]
+        L.irs_synth_encode_term_pos_v.restype = C.c_int64
+        L.irs_synth_wrap_file.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                          C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.irs_synth_wrap_file.restype = C.c_int64
         L.irs_synth_wrap_pos_file.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
                                               C.c_uint64, C.POINTER(C.c_uint64)]
         L.irs_synth_wrap_pos_file.restype = C.c_int64
@@ -107,6 +116,7 @@ class SynthSegment:
     wand_count: int = 0           # scorers the field was indexed with (wand data in `.doc`)
     pos_file: np.ndarray | None = None   # uint8, the whole `.pos` image (field with POS)
     positions: dict | None = None        # rank -> u32[Σ freqs] positions, doc after doc, when kept
+    pos_one_based: bool = False          # formats 1_0..1_2: one-based position storage
 
     def meta(self, rank: int) -> np.void:
         return self.metas[rank - 1]
@@ -116,11 +126,12 @@ def build_segment(num_docs: int, max_rank: int = 4096, *, layout: int = LAYOUT_S
                   seed: int = SEED, first_doc: int = 0, vocab_log2: int = 20,
                   mean_len: int = 100, stddev_len: int = 30, threads: int = 0,
                   keep_postings: bool = False, wand_count: int = 0,
-                  wand_kind: int = WAND_MIN_NORM, with_positions: bool = False) -> SynthSegment:
+                  wand_kind: int = WAND_MIN_NORM, with_positions: bool = False,
+                  one_based_positions: bool = False) -> SynthSegment:
     L = lib()
     p = _Params(seed, first_doc, num_docs, vocab_log2, max_rank, layout, mean_len,
                 stddev_len, threads, int(keep_postings), wand_count, wand_kind,
-                int(with_positions), 0)
+                int(with_positions), int(one_based_positions))
     h = C.c_void_p()
     rc = L.irs_synth_build(C.byref(p), C.byref(h))
     if rc != 0:
@@ -158,13 +169,13 @@ def build_segment(num_docs: int, max_rank: int = 4096, *, layout: int = LAYOUT_S
                     postings[r] = (np.zeros(0, np.uint32), np.zeros(0, np.uint32))
         return SynthSegment(doc_file, norms, metas, L.irs_synth_docs_with_field(h),
                             L.irs_synth_total_term_freq(h), layout, num_docs, postings,
-                            wand_count, pos_file, positions)
+                            wand_count, pos_file, positions, bool(one_based_positions))
     finally:
         L.irs_synth_free(h)
 
 
 def encode_term_pos(docs, freqs, positions, segment_docs: int, layout: int = LAYOUT_SIMD4,
-                    norms=None, wand_kinds=()):
+                    norms=None, wand_kinds=(), one_based: bool = False):
     """postings_writer::write for one list of a field with POS -> (doc bytes, pos bytes, meta);
     positions = Σ freqs values, doc after doc (ascending and >= 1 within a doc)."""
     docs = np.ascontiguousarray(docs, dtype=np.uint32)
@@ -179,12 +190,12 @@ def encode_term_pos(docs, freqs, positions, segment_docs: int, layout: int = LAY
     plen = C.c_uint64()
     meta = np.zeros(1, TERM_META)
     nrm = None if norms is None else np.ascontiguousarray(norms, np.uint8)
-    n = lib().irs_synth_encode_term_pos(docs.ctypes.data, freqs.ctypes.data,
-                                        positions.ctypes.data, len(docs), segment_docs, layout,
-                                        None if nrm is None else nrm.ctypes.data,
-                                        kinds.ctypes.data if kinds.size else None, kinds.size,
-                                        out.ctypes.data, cap, pout.ctypes.data, pcap,
-                                        C.byref(plen), meta.ctypes.data)
+    n = lib().irs_synth_encode_term_pos_v(docs.ctypes.data, freqs.ctypes.data,
+                                          positions.ctypes.data, len(docs), segment_docs, layout,
+                                          None if nrm is None else nrm.ctypes.data,
+                                          kinds.ctypes.data if kinds.size else None, kinds.size,
+                                          int(one_based), out.ctypes.data, cap, pout.ctypes.data,
+                                          pcap, C.byref(plen), meta.ctypes.data)
     if n < 0:
         raise ValueError("irs_synth_encode_term_pos failed: %d" % n)
     return out[:n].copy(), pout[:plen.value].copy(), meta[0]
@@ -217,7 +228,7 @@ def encode_term(docs, freqs, segment_docs: int, layout: int = LAYOUT_SIMD4, norm
 
 
 def segment_from_lists(lists, num_docs: int, layout: int = LAYOUT_SIMD4, norms=None,
-                       wand_kinds=()):
+                       wand_kinds=(), one_based: bool = False):
     """Build a `.doc` image from explicit [(docs, freqs), ...] posting lists."""
     if len(wand_kinds) and (norms is None or norms is False) and \
             any(k != WAND_MAX_FREQ for k in wand_kinds):
@@ -231,7 +242,7 @@ def segment_from_lists(lists, num_docs: int, layout: int = LAYOUT_SIMD4, norms=N
         wn = norms if len(wand_kinds) and norms is not None and norms is not False else None
         if with_pos:
             b, pb, m = encode_term_pos(entry[0], entry[1], entry[2], num_docs, layout, wn,
-                                       wand_kinds)
+                                       wand_kinds, one_based)
             metas[i] = m
             metas[i]["pos_start"] = poff
             poff += len(pb)
@@ -248,27 +259,28 @@ def segment_from_lists(lists, num_docs: int, layout: int = LAYOUT_SIMD4, norms=N
         pbody = np.concatenate(pbody) if pbody else np.zeros(0, np.uint8)
         pout = np.zeros(len(pbody) + 128, np.uint8)
         phdr = C.c_uint64()
-        pn = lib().irs_synth_wrap_pos_file(pbody.ctypes.data, len(pbody), layout,
-                                           pout.ctypes.data, len(pout), C.byref(phdr))
+        pn = lib().irs_synth_wrap_file(pbody.ctypes.data, len(pbody), layout, 1, int(one_based),
+                                       pout.ctypes.data, len(pout), C.byref(phdr))
         if pn < 0:
             raise ValueError("irs_synth_wrap_pos_file failed")
         metas["pos_start"] += phdr.value
         pos_file = pout[:pn].copy()
     out = np.zeros(len(body) + 128, np.uint8)
     hdr = C.c_uint64()
-    n = lib().irs_synth_wrap_doc_file(body.ctypes.data, len(body), layout, out.ctypes.data,
-                                      len(out), C.byref(hdr))
+    n = lib().irs_synth_wrap_file(body.ctypes.data, len(body), layout, 0, int(one_based),
+                                  out.ctypes.data, len(out), C.byref(hdr))
     if n < 0:
         raise ValueError("irs_synth_wrap_doc_file failed")
     metas["doc_start"] += hdr.value
     if norms is False:  # no Norm2 column at all
         return SynthSegment(out[:n].copy(), None, metas, num_docs, num_docs, layout, num_docs,
-                            None, len(wand_kinds), pos_file)
+                            None, len(wand_kinds), pos_file, None, bool(one_based))
     if norms is None:
         norms = np.ones(num_docs, np.uint8)
     ttf = int(np.asarray(norms, dtype=np.uint64).sum())
     return SynthSegment(out[:n].copy(), np.ascontiguousarray(norms, np.uint8), metas,
-                        num_docs, ttf, layout, num_docs, None, len(wand_kinds), pos_file)
+                        num_docs, ttf, layout, num_docs, None, len(wand_kinds), pos_file, None,
+                        bool(one_based))
 
 
 def make_queries(n_queries: int, n_terms: int, lo_rank: int = 16, hi_rank: int = 4096,

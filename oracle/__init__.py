@@ -29,7 +29,8 @@ HIT = np.dtype([("score", "<f4"), ("doc", "<u4"), ("segment", "<u4")])
 class Segment(C.Structure):
     _fields_ = [("doc_file", C.c_void_p), ("doc_file_len", C.c_uint64), ("layout", C.c_int32),
                 ("num_docs", C.c_uint32), ("norms", C.c_void_p), ("norm_width", C.c_uint32),
-                ("wand_count", C.c_uint32), ("pos_file", C.c_void_p), ("pos_file_len", C.c_uint64)]
+                ("wand_count", C.c_uint32), ("pos_file", C.c_void_p), ("pos_file_len", C.c_uint64),
+                ("pos_one_based", C.c_int32)]
 
 
 class Scorer(C.Structure):
@@ -98,8 +99,9 @@ def lib():
         L.orc_read_skip0_pos.argtypes = [vp, u64, u32, C.c_int, vp, vp, vp, u64, C.POINTER(u32),
                                          vp, vp, vp, vp]
         L.orc_read_skip0_pos.restype = C.c_int64
-        L.orc_decode_positions.argtypes = [vp, u64, vp, u64, C.c_int, u32, vp, u32, vp, u64]
-        L.orc_decode_positions.restype = C.c_int64
+        L.orc_decode_positions_v.argtypes = [vp, u64, vp, u64, C.c_int, u32, C.c_int, vp, u32, vp,
+                                             u64]
+        L.orc_decode_positions_v.restype = C.c_int64
         L.orc_check_pos_header.argtypes = [vp, u64, C.POINTER(i32)]
         L.orc_check_pos_header.restype = C.c_int64
         L.orc_search_phrase.argtypes = [vp, u32, vp, u32, vp, C.POINTER(Scorer), C.c_float, vp, vp,
@@ -167,7 +169,7 @@ def decode_term(doc_file: np.ndarray, meta, layout: int, want_freq: bool = True,
 
 
 def decode_positions(doc_file: np.ndarray, pos_file: np.ndarray, meta, layout: int,
-                     wand_count: int = 0, stride: int = 1) -> np.ndarray:
+                     wand_count: int = 0, stride: int = 1, one_based: bool = False) -> np.ndarray:
     """All positions of one term, doc after doc (Σ freq values); stride > 1 drains every
     stride-th doc only (the rest goes through position::skip and reads as 0)."""
     m = np.zeros(1, TERM_META)
@@ -175,9 +177,9 @@ def decode_positions(doc_file: np.ndarray, pos_file: np.ndarray, meta, layout: i
         m[0][k] = meta[k]
     n = int(m[0]["freq"])
     out = np.zeros(n, np.uint32)
-    got = lib().orc_decode_positions(doc_file.ctypes.data, doc_file.size, pos_file.ctypes.data,
-                                     pos_file.size, layout, wand_count, m.ctypes.data, stride,
-                                     out.ctypes.data, n)
+    got = lib().orc_decode_positions_v(doc_file.ctypes.data, doc_file.size, pos_file.ctypes.data,
+                                       pos_file.size, layout, wand_count, int(one_based),
+                                       m.ctypes.data, stride, out.ctypes.data, n)
     if got != n:
         raise ValueError("orc_decode_positions: %d != %d" % (got, n))
     return out
@@ -249,20 +251,22 @@ class SegmentView:
     """Keeps the numpy buffers of one segment alive next to the C struct."""
 
     def __init__(self, doc_file, norms, layout, num_docs, docs_with_field, total_term_freq,
-                 norm_width=1, wand_count=0, pos_file=None):
+                 norm_width=1, wand_count=0, pos_file=None, pos_one_based=False):
         self.doc_file = np.ascontiguousarray(doc_file, np.uint8)
         self.norms = None if norms is None else np.ascontiguousarray(norms, np.uint8)
         self.layout, self.num_docs, self.norm_width = layout, num_docs, norm_width
         self.docs_with_field, self.total_term_freq = docs_with_field, total_term_freq
         self.wand_count = wand_count
         self.pos_file = None if pos_file is None else np.ascontiguousarray(pos_file, np.uint8)
+        self.pos_one_based = bool(pos_one_based)
 
     def struct(self) -> Segment:
         return Segment(self.doc_file.ctypes.data, self.doc_file.size, self.layout, self.num_docs,
                        None if self.norms is None else self.norms.ctypes.data, self.norm_width,
                        self.wand_count,
                        None if self.pos_file is None else self.pos_file.ctypes.data,
-                       0 if self.pos_file is None else self.pos_file.size)
+                       0 if self.pos_file is None else self.pos_file.size,
+                       int(self.pos_one_based))
 
 
 def _metas_array(metas) -> np.ndarray:

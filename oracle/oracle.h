@@ -100,6 +100,12 @@ int64_t orc_decode_positions(const uint8_t* doc_file, uint64_t len, const uint8_
                              uint64_t pos_len, int layout, uint32_t wand_count,
                              const orc_term_meta* meta, uint32_t stride, uint32_t* out,
                              uint64_t cap);
+/* one_based != 0: formats 1_0..1_2 (PostingsFormat < POSITIONS_ZEROBASED): the reader adds
+ * pos_limits::min() back before a doc's first delta (formats_10.cpp:1589-1591, 1623-1625) */
+int64_t orc_decode_positions_v(const uint8_t* doc_file, uint64_t len, const uint8_t* pos_file,
+                               uint64_t pos_len, int layout, uint32_t wand_count, int one_based,
+                               const orc_term_meta* meta, uint32_t stride, uint32_t* out,
+                               uint64_t cap);
 int64_t orc_check_pos_header(const uint8_t* pos_file, uint64_t len, int32_t* version);
 /* postings_reader::bit_union (formats_10.cpp:3716-3806): ORs bit `doc` into `set`
  * for every posting of every term; returns the sum of docs_count. */
@@ -147,6 +153,7 @@ typedef struct orc_segment {
   uint32_t wand_count;  /* scorers the field was indexed with (wand data to skip) */
   const uint8_t* pos_file; /* `.pos` image of a field with POS, or NULL */
   uint64_t pos_file_len;
+  int32_t pos_one_based;   /* formats 1_0..1_2 */
 } orc_segment;
 
 typedef struct orc_scorer {

@@ -58,10 +58,11 @@ typedef struct {
   uint32_t tail_length;
   uint32_t buf_pos;     /* ORC_BLOCK = buffer consumed */
   uint32_t value;       /* 0 = pos_limits::invalid(), UINT32_MAX = eof */
+  int one_based;        /* IteratorTraits::one_based_position_storage(): formats 1_0..1_2 */
 } orc_pos_iterator;
 
 void orc_pos_prepare(orc_pos_iterator* p, const uint8_t* pos_file, uint64_t len, int layout,
-                     const orc_term_meta* m);
+                     const orc_term_meta* m, int one_based);
 void orc_pos_notify(orc_pos_iterator* p, uint32_t n); /* + clear(): doc iterator moved on */
 int orc_pos_next(orc_pos_iterator* p, uint32_t freq);
 uint32_t orc_pos_seek(orc_pos_iterator* p, uint32_t freq, uint32_t target);

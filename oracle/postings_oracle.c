@@ -560,8 +560,9 @@ uint32_t orc_it_seek(orc_doc_iterator* it, uint32_t target) {
 /* position_impl::prepare(const DocState&) :1472-1491 with the tail location
  * doc_iterator::prepare computes (:2270-2285; single_doc_iterator :1896-1913) */
 void orc_pos_prepare(orc_pos_iterator* p, const uint8_t* pos_file, uint64_t len, int layout,
-                     const orc_term_meta* m) {
+                     const orc_term_meta* m, int one_based) {
   memset(p, 0, sizeof *p);
+  p->one_based = one_based;
   p->file = pos_file;
   p->layout = layout;
   p->in.end = pos_file + len;
@@ -628,6 +629,7 @@ int orc_pos_next(orc_pos_iterator* p, uint32_t freq) {
     pos_refill(p);
     p->buf_pos = 0;
   }
+  if (p->one_based) p->value += (p->value == 0); /* :1623-1625 */
   p->value += p->pos_deltas[p->buf_pos];
   ++p->buf_pos;
   --p->pend_pos;
@@ -645,6 +647,7 @@ uint32_t orc_pos_seek(orc_pos_iterator* p, uint32_t freq, uint32_t target) {
       pos_refill(p);
       p->buf_pos = 0;
     }
+    if (p->one_based) p->value += (p->value == 0); /* :1589-1591 */
     p->value += p->pos_deltas[p->buf_pos];
     ++p->buf_pos;
     --p->pend_pos;
@@ -660,13 +663,21 @@ int64_t orc_decode_positions(const uint8_t* doc_file, uint64_t len, const uint8_
                              uint64_t pos_len, int layout, uint32_t wand_count,
                              const orc_term_meta* meta, uint32_t stride, uint32_t* out,
                              uint64_t cap) {
+  return orc_decode_positions_v(doc_file, len, pos_file, pos_len, layout, wand_count, 0, meta,
+                                stride, out, cap);
+}
+
+int64_t orc_decode_positions_v(const uint8_t* doc_file, uint64_t len, const uint8_t* pos_file,
+                               uint64_t pos_len, int layout, uint32_t wand_count, int one_based,
+                               const orc_term_meta* meta, uint32_t stride, uint32_t* out,
+                               uint64_t cap) {
   orc_doc_iterator it;
   orc_pos_iterator pos;
   uint64_t n = 0, d = 0;
   if (meta->docs_count == 0) return 0;
   if (!stride) stride = 1;
   orc_it_prepare_wand(&it, doc_file, len, layout, meta, 1, wand_count);
-  orc_pos_prepare(&pos, pos_file, pos_len, layout, meta);
+  orc_pos_prepare(&pos, pos_file, pos_len, layout, meta, one_based);
   while (orc_it_next(&it)) {
     uint32_t k;
     orc_pos_notify(&pos, it.freq);

@@ -397,7 +397,8 @@ void execute_phrase(const orc_segment& seg, const orc_term_meta* metas, uint32_t
     PSub& s = subs[t];
     orc_it_prepare_wand(&s.it, seg.doc_file, seg.doc_file_len, seg.layout, &metas[t], 1,
                         seg.wand_count);
-    orc_pos_prepare(&s.pos, seg.pos_file, seg.pos_file_len, seg.layout, &metas[t]);
+    orc_pos_prepare(&s.pos, seg.pos_file, seg.pos_file_len, seg.layout, &metas[t],
+                    seg.pos_one_based);
     s.offset = offsets[t];
     s.cost = metas[t].docs_count;
   }

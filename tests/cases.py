@@ -724,6 +724,19 @@ def case_decode_positions(L, layout):
     assert np.array_equal(last_gpu[:len(last)], last)
     sr.close()
 
+    # formats 1_0 / 1_2simd (PostingsFormat 0 / 1): one-based position storage — the first delta
+    # of a doc is relative to pos_limits::min() and the reader adds it back (:1589-1591, 1623-1625)
+    oseg = synth.segment_from_lists(lists, N, layout, one_based=True)
+    assert oseg.doc_file[4 + 1 + 31 + 3] == layout    # version 0 (scalar) / 1 (simd4)
+    osr = search.SegmentReader.from_synth(oseg, L=L)
+    for t, (d, f, p) in enumerate(lists):
+        assert np.array_equal(osr.decode_positions(t), p), ("one-based positions", layout, t)
+        assert np.array_equal(p, oracle.decode_positions(oseg.doc_file, oseg.pos_file, oseg.metas[t],
+                                                         layout, one_based=True))
+        zp = oracle.decode_positions(oseg.doc_file, oseg.pos_file, oseg.metas[t], layout)
+        assert not np.array_equal(zp, p)             # read as zero-based it is off by one
+    osr.close()
+
     # a POS field indexed WITH a scorer: wand data sits in front of short tails and in every
     # skip entry next to the POS fields (formats_10.cpp:511-518, 990-999)
     norms = np.full(N, 255, np.uint8)
@@ -781,7 +794,7 @@ def case_phrase_queries(L, layout, num_docs=30_000):
     sr.close()
 
 
-def case_phrase_ragged(L, layout=synth.LAYOUT_SIMD4):
+def case_phrase_ragged(L, layout=synth.LAYOUT_SIMD4, one_based=False):
     """Explicit lists: single-doc terms, lists shorter than a block, phrases that exist
     only across block / tile borders, very frequent terms in one doc."""
     N = 9000
@@ -795,7 +808,8 @@ def case_phrase_ragged(L, layout=synth.LAYOUT_SIMD4):
     x = (dd, np.full(4, 200, np.uint32), np.tile(np.arange(1, 401, 2, dtype=np.uint32), 4))
     y = (dd, np.full(4, 200, np.uint32), np.tile(np.arange(2, 402, 2, dtype=np.uint32), 4))
     lists = [a, b, c, one, x, y]
-    seg = synth.segment_from_lists(lists, N, layout, norms=np.full(N, 255, np.uint8))
+    seg = synth.segment_from_lists(lists, N, layout, norms=np.full(N, 255, np.uint8),
+                                   one_based=one_based)
     phrases = [by_phrase([0, 1]), by_phrase([1, 0]), by_phrase([0, 2]), by_phrase([2, 1, 0]),
                by_phrase([3, 3]), by_phrase([0, 3]), by_phrase([4, 5]), by_phrase([5, 4]),
                by_phrase([4, 5, 4]), by_phrase([4, 4], [0, 2]), by_phrase([3, 4], [0, 2])]

@@ -113,6 +113,7 @@ def test_phrase_reference_vectors(simlib, layout):
 
 def test_phrase_ragged(simlib):
     cases.case_phrase_ragged(simlib)
+    cases.case_phrase_ragged(simlib, synth.LAYOUT_SCALAR, one_based=True)
 
 
 def test_phrase_fuzz(simlib):

@@ -91,6 +91,7 @@ def test_phrase_reference_vectors(gpulib, layout):
 def test_phrase_ragged(gpulib):
     cases.case_phrase_ragged(gpulib)
     cases.case_phrase_ragged(gpulib, synth.LAYOUT_SCALAR)
+    cases.case_phrase_ragged(gpulib, synth.LAYOUT_SIMD4, one_based=True)
 
 
 def test_phrase_fuzz(gpulib):
