@@ -25,6 +25,8 @@ extern "C" {
 #define IRS_HIP_MAX_K 4096u      /* largest top-k                         */
 #define IRS_HIP_MAX_PHRASE_TERMS 8u /* terms of one by_phrase query       */
 #define IRS_HIP_NO_TERM 0xFFFFFFFFu
+#define IRS_HIP_POS_OFFSETS 1u
+#define IRS_HIP_POS_PAYLOADS 2u
 
 /* Errors replace the reference's exceptions (io_error / index_error,
  * formats_10.cpp:158-160, 3410-3415): never thrown across this boundary. */
@@ -83,6 +85,12 @@ typedef struct irs_hip_segment_desc {
                              * (formats_10.cpp:283-304) — what postings_reader::prepare opens
                              * as pos_in_ (:3369-3381); NULL: no positions, no phrase queries */
   uint64_t pos_file_len;
+  uint32_t pos_features;    /* what else the field stores per position: IRS_HIP_POS_OFFSETS
+                             * (IndexFeatures::OFFS), IRS_HIP_POS_PAYLOADS (IndexFeatures::PAY).
+                             * Both change the vint tail of `.pos` (formats_10.cpp:728-760) and
+                             * are answered with IRS_HIP_EUNSUPPORTED for now instead of being
+                             * mis-read; 0 = positions only */
+  uint32_t reserved0;
 } irs_hip_segment_desc;
 
 typedef struct irs_hip_segment irs_hip_segment; /* opaque, immutable after open */

@@ -43,6 +43,7 @@ class SegmentDesc(C.Structure):
         ("norms", C.c_void_p), ("norm_width", C.c_uint32), ("norm_min_doc", C.c_uint32),
         ("norm_count", C.c_uint64), ("terms", C.c_void_p), ("num_terms", C.c_uint32),
         ("wand_count", C.c_uint32), ("pos_file", C.c_void_p), ("pos_file_len", C.c_uint64),
+        ("pos_features", C.c_uint32), ("reserved0", C.c_uint32),
     ]
 
 

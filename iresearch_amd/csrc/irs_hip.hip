@@ -434,6 +434,8 @@ int irs_hip_segment_open(const irs_hip_segment_desc* d, irs_hip_segment** out) {
     if (!pos_hdr) return IRS_HIP_ECORRUPT;
     if (pos_version != version) return IRS_HIP_ECORRUPT;
     if (!d->has_freq) return IRS_HIP_EINVAL;
+    if (d->pos_features & ~(IRS_HIP_POS_OFFSETS | IRS_HIP_POS_PAYLOADS)) return IRS_HIP_EINVAL;
+    if (d->pos_features) return IRS_HIP_EUNSUPPORTED;  // the `.pos` tail interleaves them
   }
   if (!device_usable(d->device)) return IRS_HIP_EHIP;
 

@@ -994,6 +994,9 @@ def case_phrase_errors(L):
     with pytest.raises(_lib.IrsHipError) as e:       # positions without frequencies
         open_with(has_freq=False)
     assert e.value.status == _lib.EINVAL
+    with pytest.raises(_lib.IrsHipError) as e:       # offsets / payloads change the `.pos` tail
+        open_with(pos_features=1)
+    assert e.value.status == _lib.EUNSUPPORTED
     sr.close()
     sr_plain.close()
 
