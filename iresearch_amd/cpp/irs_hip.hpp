@@ -382,4 +382,42 @@ class QueryBatch {
   uint32_t n_segments_, n_queries_, k_;
 };
 
+// ---- the harness: one heap over all segments (utils/index-search.cpp:719-787) ---------------
+struct ScoredDoc {
+  float score;
+  uint32_t segment;  // ordinal in the list the batch was created with
+  uint32_t doc;      // segment-local id, as index-search prints it (:807)
+};
+
+// Global top-k of every query from the per-segment top-k lists, ordered (score desc,
+// segment asc, doc asc) — the order tests/search/wand_test.cpp:72-86 fixes.  (Host-side
+// counterpart of irs_hip_merge_topk, which does the same on device-resident lists.)
+inline std::vector<std::vector<ScoredDoc>> merge(const QueryBatch::Results& r) {
+  std::vector<std::vector<ScoredDoc>> out(r.n_queries);
+  for (uint32_t q = 0; q < r.n_queries; ++q) {
+    auto& v = out[q];
+    for (uint32_t s = 0; s < r.n_segments; ++s) {
+      const irs_hip_hit* h = r.of(s, q);
+      for (uint32_t i = 0; i < r.count(s, q); ++i) v.push_back(ScoredDoc{h[i].score, s, h[i].doc});
+    }
+    std::sort(v.begin(), v.end(), [](const ScoredDoc& x, const ScoredDoc& y) {
+      if (x.score != y.score) return x.score > y.score;
+      if (x.segment != y.segment) return x.segment < y.segment;
+      return x.doc < y.doc;
+    });
+    if (v.size() > r.k) v.resize(r.k);
+  }
+  return out;
+}
+
+// filter.prepare(index) -> execute on every segment -> one top-k per query.
+template<typename Scorer>
+std::vector<std::vector<ScoredDoc>> search(const std::vector<const SegmentReader*>& segments,
+                                           const std::vector<SegmentStats>& index,
+                                           const std::vector<filter>& filters,
+                                           const Scorer& scorer, uint32_t k) {
+  QueryBatch batch(segments, prepare(filters, scorer, index), k);
+  return merge(batch.run().results());
+}
+
 }  // namespace irs_hip_host

@@ -124,6 +124,7 @@ int main() {
   QueryBatch batch({a.reader.get(), b.reader.get()}, prepared, kTop);
   const auto res = batch.run().results();
   REQUIRE(res.n_segments == 2 && res.n_queries == filters.size());
+  const auto top = merge(res);  // the harness heap over both segments
 
   // the oracle's harness loop over both segments (utils/index-search.cpp:719-787)
   const orc_segment views[2] = {a.oracle_view(), b.oracle_view()};
@@ -160,13 +161,7 @@ int main() {
     }
     REQUIRE(got_n >= 0);
     want.resize(size_t(got_n));
-    // merge the two per-segment lists the way the harness heap would see them
-    std::vector<irs_hip_hit> mine;
-    for (uint32_t s = 0; s < 2; ++s)
-      mine.insert(mine.end(), res.of(s, uint32_t(q)), res.of(s, uint32_t(q)) + res.count(s, uint32_t(q)));
-    std::sort(mine.begin(), mine.end(),
-              [](const irs_hip_hit& x, const irs_hip_hit& y) { return x.score > y.score; });
-    if (mine.size() > kTop) mine.resize(kTop);
+    const std::vector<ScoredDoc>& mine = top[q];
     REQUIRE(res.total(0, uint32_t(q)) + res.total(1, uint32_t(q)) == want_total);
     REQUIRE(mine.size() == want.size());
     std::sort(want.begin(), want.end(),
@@ -174,6 +169,18 @@ int main() {
     for (size_t i = 0; i < want.size(); ++i) REQUIRE(close_rel(mine[i].score, want[i].score));
   }
   REQUIRE(batch.reruns() == 0);
+  // the one-call form gives the same lists
+  {
+    const auto again = search({a.reader.get(), b.reader.get()}, {a.stats(), b.stats()}, filters,
+                              scorer, kTop);
+    REQUIRE(again.size() == top.size());
+    for (size_t q = 0; q < top.size(); ++q) {
+      REQUIRE(again[q].size() == top[q].size());
+      for (size_t i = 0; i < top[q].size(); ++i)
+        REQUIRE(again[q][i].score == top[q][i].score && again[q][i].doc == top[q][i].doc &&
+                again[q][i].segment == top[q][i].segment);
+    }
+  }
 
   // postings / positions / bit_union of one term against the oracle's iterators
   {
