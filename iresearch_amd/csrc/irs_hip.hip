@@ -355,6 +355,23 @@ bool ensure_scratch(irs_hip_batch* b) {
     b->n_tiles = std::min(b->n_tiles, dq.n_tiles);
     b->max_tiles = std::max(b->max_tiles, dq.n_tiles);
   }
+  {  // k_score's queue order: heaviest units first within every chunk round
+    std::vector<std::pair<uint64_t, uint32_t>> work(b->nq);
+    for (uint32_t u = 0; u < b->nq; ++u) {
+      const DevQuery& dq = b->queries[u];
+      uint64_t w = 0;
+      for (uint32_t j = 0; j < dq.n_terms; ++j)
+        w += b->segs[dq.seg]->terms[b->qterms[dq.first_term + j].term].docs_count;
+      work[u] = {w, u};
+    }
+    // ... segment by segment: the workgroups resident at one time should keep reading the same
+    // doc range (shared in L2), so units of one segment stay together
+    std::stable_sort(work.begin(), work.end(), [&](const auto& x, const auto& y) {
+      const uint32_t sx = b->queries[x.second].seg, sy = b->queries[y.second].seg;
+      return sx != sy ? sx < sy : x.first > y.first;
+    });
+    for (uint32_t i = 0; i < b->nq; ++i) b->queries[i].run_unit = work[i].second;
+  }
   b->stride_eff = std::max<uint32_t>(1, std::min<uint32_t>(b->stride, b->n_tiles / 2));
   if (b->phrase) b->stride_eff = 1;  // no pilot: every match is a candidate
   if (const char* e = std::getenv("IRS_HIP_WG_THREADS")) {  // tuning knob

@@ -1273,7 +1273,7 @@ k_score(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms,
 
     // chunk-major ids: every unit's first chunk, then every unit's second, ... so the short
     // last chunks of the units are handed out at the very end (smaller tail)
-    const uint32_t q = chunk % n_queries;
+    const uint32_t q = wave::uniform(queries[chunk % n_queries].run_unit);
     const uint32_t tile0 = (chunk / n_queries) * kChunkTiles;
     const DevQuery qd = queries[q];
     const DevSegment seg = segs[qd.seg];

@@ -113,6 +113,11 @@ struct DevQuery {
   uint32_t seg;         // index into the batch's DevSegment array
   uint32_t n_tiles;     // doc tiles of that segment
   uint64_t first_off;   // start of the unit's [n_tiles + 1][jt] slice of the plan table
+  // work-queue order of k_score (NOT a property of this unit): slot i of the array names the
+  // unit that runs i-th within every chunk round — units sorted by decreasing work, so the
+  // last workgroups to finish hold the lightest chunks (longest-processing-time first)
+  uint32_t run_unit;
+  uint32_t pad;
 };
 
 struct DevQTerm {
