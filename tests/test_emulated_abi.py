@@ -34,6 +34,14 @@ def test_queries_all_scorers(simlib, layout):
     cases.case_queries_all_scorers(simlib, 30_000, 256, layout)
 
 
+def test_queries_k_extremes(simlib):
+    from iresearch_amd import _lib
+    seg = synth.build_segment(20_000, 128, with_positions=True)
+    for k in (1, _lib.MAX_K):
+        cases.run_and_check(simlib, seg, cases.standard_filters(128), cases.BM25(), k)
+        cases.run_phrases(simlib, seg, [cases.by_phrase([0, 1])], cases.BM25(), k)
+
+
 def test_queries_tiles_and_strides(simlib):
     cases.case_queries_tiles_and_strides(simlib, 40_000, 256)
 

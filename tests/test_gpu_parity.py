@@ -39,6 +39,17 @@ def test_queries_all_scorers(gpulib, layout):
     cases.case_queries_all_scorers(gpulib, 300_000, 1024, layout)
 
 
+def test_queries_k_extremes(gpulib):
+    """top-1 and top-IRS_HIP_MAX_K, boolean and phrase queries."""
+    from iresearch_amd import _lib
+    seg = synth.build_segment(400_000, 1024, with_positions=True)
+    sr = search.SegmentReader.from_synth(seg, L=gpulib)
+    for k in (1, _lib.MAX_K):
+        cases.run_and_check(gpulib, seg, cases.standard_filters(1024), BM25(), k, sr=sr)
+        cases.run_phrases(gpulib, seg, [by_phrase([0, 1]), by_phrase([5, 2, 0])], BM25(), k, sr=sr)
+    sr.close()
+
+
 def test_queries_tiles_and_strides(gpulib):
     cases.case_queries_tiles_and_strides(gpulib, 200_000, 512)
 
