@@ -39,6 +39,38 @@ def test_queries_all_scorers(gpulib, layout):
     cases.case_queries_all_scorers(gpulib, 300_000, 1024, layout)
 
 
+def test_two_host_threads_share_a_segment(gpulib):
+    """The threading contract of include/irs_hip.h: a segment is immutable after open and
+    shared by threads; every thread owns its batches (index-search --threads)."""
+    import threading
+    seg = synth.build_segment(300_000, 512)
+    sr = search.SegmentReader.from_synth(seg, L=gpulib)
+    filters = cases.standard_filters(512)
+    prep = search.prepare(filters, BM25(), [parity.segment_stats(seg)])
+    ref = sr.batch(prep, 100).run().results()
+    out, errs = {}, []
+
+    def work(i):
+        try:
+            for _ in range(4):
+                b = sr.batch(prep, 100)
+                out[i] = b.run().results()
+                b.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for i in range(4):
+        for a, b in zip(out[i], ref):
+            assert np.array_equal(a, b)
+    sr.close()
+
+
 def test_queries_k_extremes(gpulib):
     """top-1 and top-IRS_HIP_MAX_K, boolean and phrase queries."""
     from iresearch_amd import _lib
