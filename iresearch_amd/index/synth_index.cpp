@@ -619,7 +619,7 @@ int irs_synth_build(const irs_synth_params* p, irs_synth_index** out) {
       p->vocab_log2 == 0 || p->vocab_log2 > 24 ||
       p->max_rank > (1u << p->vocab_log2) || p->num_docs >= 0x7FFFFFF0u ||
       p->wand_count > 8 || p->wand_kind > IRS_SYNTH_WAND_DIV_NORM ||
-      (p->one_based_positions && p->wand_count))
+      (p->one_based_positions && p->wand_count) || p->topic_percent > 100)
     return -1;
   auto idx = std::make_unique<irs_synth_index>();
   const uint32_t N = p->num_docs;
@@ -655,7 +655,16 @@ int irs_synth_build(const irs_synth_params* p, irs_synth_index** out) {
           local_ttf += len;
           uint32_t m = 0;
           for (uint32_t i = 0; i < len; ++i) {
-            const uint32_t r = zipf.sample(token_hash(p->seed, g, i));
+            const uint64_t h = token_hash(p->seed, g, i);
+            uint32_t r;
+            if (p->topic_docs && mix64(h ^ 0x7091C5ull) % 100u < p->topic_percent) {
+              // one of the topic's own ranks (clustered corpus)
+              const uint64_t topic = g / p->topic_docs;
+              const uint64_t slot = mix64(h ^ 0x51A7ull) % std::max<uint32_t>(1, p->topic_terms);
+              r = 1u + uint32_t(mix64(p->seed ^ mix64(topic * 0x9E3779B97F4A7C15ull + slot)) % R);
+            } else {
+              r = zipf.sample(h);
+            }
             if (r) ranks[m++] = (r << 8) | (i + 1);
           }
           std::sort(ranks, ranks + m);

@@ -62,6 +62,15 @@ typedef struct irs_synth_params {
                              (position of a token = its 1-based index in the doc)   */
   uint32_t one_based_positions; /* write formats 1_0 / 1_2simd (PostingsFormat 0 / 1): the first
                              position of a doc is stored relative to pos_limits::min() = 1 */
+  /* Optional CLUSTERED corpus (0 = off: the i.i.d. benchmark corpus, byte for byte): docs come
+     in runs of `topic_docs` consecutive ids sharing a topic; a token is drawn from the topic's
+     own `topic_terms` ranks (uniform among them, the ranks chosen by hashing the topic id)
+     with probability topic_percent / 100, from the global Zipf distribution otherwise.  Posting
+     lists of such a corpus are bursty, which is what block-max pruning feeds on. */
+  uint32_t topic_docs;
+  uint32_t topic_percent;
+  uint32_t topic_terms;
+  uint32_t reserved1;
 } irs_synth_params;
 
 typedef struct irs_synth_index irs_synth_index;

@@ -31,6 +31,8 @@ class _Params(C.Structure):
         ("mean_len", C.c_uint32), ("stddev_len", C.c_uint32), ("threads", C.c_uint32),
         ("keep_postings", C.c_uint32), ("wand_count", C.c_uint32), ("wand_kind", C.c_uint32),
         ("with_positions", C.c_uint32), ("one_based_positions", C.c_uint32),
+        ("topic_docs", C.c_uint32), ("topic_percent", C.c_uint32), ("topic_terms", C.c_uint32),
+        ("reserved1", C.c_uint32),
     ]
 
 
@@ -127,11 +129,13 @@ def build_segment(num_docs: int, max_rank: int = 4096, *, layout: int = LAYOUT_S
                   mean_len: int = 100, stddev_len: int = 30, threads: int = 0,
                   keep_postings: bool = False, wand_count: int = 0,
                   wand_kind: int = WAND_MIN_NORM, with_positions: bool = False,
-                  one_based_positions: bool = False) -> SynthSegment:
+                  one_based_positions: bool = False, topic_docs: int = 0,
+                  topic_percent: int = 0, topic_terms: int = 16) -> SynthSegment:
     L = lib()
     p = _Params(seed, first_doc, num_docs, vocab_log2, max_rank, layout, mean_len,
                 stddev_len, threads, int(keep_postings), wand_count, wand_kind,
-                int(with_positions), int(one_based_positions))
+                int(with_positions), int(one_based_positions), int(topic_docs),
+                int(topic_percent), int(topic_terms), 0)
     h = C.c_void_p()
     rc = L.irs_synth_build(C.byref(p), C.byref(h))
     if rc != 0:

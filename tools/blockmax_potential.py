@@ -25,6 +25,10 @@ def main():
     ap.add_argument("--queries", type=int, default=32)
     ap.add_argument("--terms", type=int, default=8)
     ap.add_argument("--k", type=int, default=1000)
+    ap.add_argument("--topic-docs", type=int, default=0,
+                    help="clustered corpus: docs per topic run (0 = the i.i.d. benchmark corpus)")
+    ap.add_argument("--topic-percent", type=int, default=30)
+    ap.add_argument("--topic-terms", type=int, default=16)
     args = ap.parse_args()
     import oracle
     import parity
@@ -32,13 +36,15 @@ def main():
     from iresearch_amd.search import BM25, Or, by_term
 
     seg = synth.build_segment(args.docs, 4096, keep_postings=True, wand_count=1,
-                              wand_kind=synth.WAND_MIN_NORM)
+                              wand_kind=synth.WAND_MIN_NORM, topic_docs=args.topic_docs,
+                              topic_percent=args.topic_percent, topic_terms=args.topic_terms)
     view = parity.oracle_view(seg)
     st = [parity.segment_stats(seg)]
     ranks = synth.make_queries(args.queries, args.terms, 16, 4096, synth.SEED + 2)
     scorer = BM25()
     osc = parity.oracle_scorer(scorer)
     total_post = skippable_post = 0
+    present_dead_post = present_skip_post = 0
     for row in ranks:
         terms = [int(r) - 1 for r in row]
         flt = Or([by_term(t) for t in terms])
@@ -63,6 +69,13 @@ def main():
                     lo = int(last[b]) + 1
         bound = ub.sum(axis=0)
         dead = bound <= theta          # docs no scorer could lift above the threshold
+        # presence-based bound (what WAND's pivoting amounts to): only the terms that CONTAIN
+        # the doc contribute their block-max
+        pres = np.zeros(seg.num_docs + 2, np.float32)
+        for j, t in enumerate(terms):
+            d, _ = seg.postings[t + 1]
+            pres[d] += ub[j, d]
+        pdead = pres <= theta
         for j, t in enumerate(terms):
             d, _ = seg.postings[t + 1]
             total_post += len(d)
@@ -72,9 +85,21 @@ def main():
             if nb:
                 blk_dead = dd[:nb * 128].reshape(nb, 128).all(axis=1)
                 skippable_post += int(blk_dead.sum()) * 128
-    print("docs %d, %d OR-%d queries, k=%d: %.2f %% of the postings sit in blocks that a perfect "
-          "block-max test could skip" % (args.docs, args.queries, args.terms, args.k,
-                                         100.0 * skippable_post / max(total_post, 1)))
+            pd = pdead[d]
+            present_dead_post += int(pd.sum())
+            if nb:
+                present_skip_post += int(pd[:nb * 128].reshape(nb, 128).all(axis=1).sum()) * 128
+    corpus = ("clustered (runs of %d docs, %d %% of the tokens from %d topic terms)" %
+              (args.topic_docs, args.topic_percent, args.topic_terms)) if args.topic_docs \
+        else "i.i.d. benchmark corpus"
+    print("%s, docs %d, %d OR-%d queries, k=%d: %.2f %% of the postings sit in blocks that a "
+          "perfect block-max test could skip" % (corpus, args.docs, args.queries, args.terms,
+                                                  args.k, 100.0 * skippable_post / max(total_post, 1)))
+    print("  presence-based bound (sum of the block-maxes of the terms that contain the doc — "
+          "what WAND's pivot sees): %.1f %% of the postings belong to docs that cannot reach the "
+          "threshold (no full scoring needed), %.2f %% sit in blocks made of such docs only "
+          "(no decode needed)" % (100.0 * present_dead_post / max(total_post, 1),
+                                  100.0 * present_skip_post / max(total_post, 1)))
 
 
 if __name__ == "__main__":
