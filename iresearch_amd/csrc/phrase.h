@@ -432,11 +432,12 @@ k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms
         // the directory words of the wanted blocks, one lane each (coalesced), handed to
         // the whole wavefront by readlane when the block's turn comes
         const uint64_t e_l = tl.dir_off + bl;
-        uint32_t bits_l = 0, off_l = 0, pos_l = 0;
+        uint32_t bits_l = 0, off_l = 0, pos_l = 0, aoff_l = 0;
         if (want) {
           bits_l = seg.blk_bits[e_l];
           off_l = seg.blk_off[e_l];
           pos_l = seg.blk_pos[e_l];
+          aoff_l = seg.blk_aoff[e_l];
         }
         const uint32_t base_l = bl ? prv : kDocMin;
         uint64_t mask = wave::ballot(want);
@@ -447,8 +448,26 @@ k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms
           const uint32_t bits = wave::read_lane(bits_l, k);
           const uint32_t base = wave::read_lane(base_l, k);
           uint32_t d0, d1, f0, f1, before;
-          decode_block_pos<LAYOUT>(seg.doc + tl.doc_start + wave::read_lane(off_l, k),
-                                   bits & 0xFFu, bits >> 8, base, lane, d0, d1, f0, f1, before);
+          const uint32_t dbits = bits & 0xFFu, fbits = bits >> 8;
+          if (pk_units(dbits, fbits)) {
+            // both parts 1..31-bit packed: the 16-byte aligned copy in the packed image,
+            // one funnel shift + one bit-field extract per value (as k_score's hot loop)
+            const uint8_t* pl = seg.pk + (uint64_t(wave::read_lane(aoff_l, k)) << 4);
+            uint64_t da, db, fa, fb;
+            raw_load_packed<LAYOUT>(pl, dbits, lane, da, db);
+            raw_load_packed<LAYOUT>(pl + 16u * dbits, fbits, lane, fa, fb);
+            uint32_t x0, x1;
+            extract_fast<LAYOUT>(da, db, dbits, lane, x0, x1);
+            extract_fast<LAYOUT>(fa, fb, fbits, lane, f0, f1);
+            uint32_t dsum = x0 + x1, fsum = f0 + f1;
+            wave::inclusive_scan2(dsum, fsum);
+            d1 = base + dsum;
+            d0 = d1 - x1;
+            before = fsum - f0 - f1;
+          } else {
+            decode_block_pos<LAYOUT>(seg.doc + tl.doc_start + wave::read_lane(off_l, k), dbits,
+                                     fbits, base, lane, d0, d1, f0, f1, before);
+          }
           const uint32_t p0 = wave::read_lane(pos_l, k) - pos0 + before;
           const uint32_t w0 = wave::read_lane(cp_l, k), w1 = wave::read_lane(cl_l, k);
           put(i, d0, f0, p0, w0, w1);
