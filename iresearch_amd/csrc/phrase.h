@@ -58,6 +58,27 @@ __device__ __forceinline__ void decode_block_pos(const uint8_t* blk, uint32_t db
   before = fsum - f0 - f1;
 }
 
+// The same from the packed-payload image (both parts 1..31-bit packed, pk_units() != 0):
+// 16-byte aligned payloads, one funnel shift + one bit-field extract per value, as k_score's
+// hot loop reads them.
+template<int LAYOUT>
+__device__ __forceinline__ void decode_packed_pos(const uint8_t* pl, uint32_t dbits,
+                                                  uint32_t fbits, uint32_t base, unsigned lane,
+                                                  uint32_t& d0, uint32_t& d1, uint32_t& f0,
+                                                  uint32_t& f1, uint32_t& before) {
+  uint64_t da, db, fa, fb;
+  raw_load_packed<LAYOUT>(pl, dbits, lane, da, db);
+  raw_load_packed<LAYOUT>(pl + 16u * dbits, fbits, lane, fa, fb);
+  uint32_t x0, x1;
+  extract_fast<LAYOUT>(da, db, dbits, lane, x0, x1);
+  extract_fast<LAYOUT>(fa, fb, fbits, lane, f0, f1);
+  uint32_t dsum = x0 + x1, fsum = f0 + f1;
+  wave::inclusive_scan2(dsum, fsum);
+  d1 = base + dsum;
+  d0 = d1 - x1;
+  before = fsum - f0 - f1;
+}
+
 // Position delta number `idx` of a term (what position::next adds to value_, :1624-1626).
 template<int LAYOUT>
 __device__ __forceinline__ uint32_t pos_delta(const DevSegment& seg, const DevPosTerm& pt,
@@ -370,8 +391,13 @@ k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms
       const uint32_t bits = seg.blk_bits[e];
       const uint32_t base = item ? seg.blk_last[e - 1] : kDocMin;
       uint32_t before;
-      decode_block_pos<LAYOUT>(seg.doc + ld.doc_start + seg.blk_off[e], bits & 0xFFu, bits >> 8,
-                               base, lane, d[0], d[1], f[0], f[1], before);
+      if (pk_units(bits & 0xFFu, bits >> 8)) {
+        decode_packed_pos<LAYOUT>(seg.pk + (uint64_t(seg.blk_aoff[e]) << 4), bits & 0xFFu,
+                                  bits >> 8, base, lane, d[0], d[1], f[0], f[1], before);
+      } else {
+        decode_block_pos<LAYOUT>(seg.doc + ld.doc_start + seg.blk_off[e], bits & 0xFFu, bits >> 8,
+                                 base, lane, d[0], d[1], f[0], f[1], before);
+      }
       p[0] = seg.blk_pos[e] - seg.blk_pos[ld.dir_off] + before;
       p[1] = p[0] + f[0];
       e0 = 2u * lane;
@@ -452,18 +478,8 @@ k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms
           if (pk_units(dbits, fbits)) {
             // both parts 1..31-bit packed: the 16-byte aligned copy in the packed image,
             // one funnel shift + one bit-field extract per value (as k_score's hot loop)
-            const uint8_t* pl = seg.pk + (uint64_t(wave::read_lane(aoff_l, k)) << 4);
-            uint64_t da, db, fa, fb;
-            raw_load_packed<LAYOUT>(pl, dbits, lane, da, db);
-            raw_load_packed<LAYOUT>(pl + 16u * dbits, fbits, lane, fa, fb);
-            uint32_t x0, x1;
-            extract_fast<LAYOUT>(da, db, dbits, lane, x0, x1);
-            extract_fast<LAYOUT>(fa, fb, fbits, lane, f0, f1);
-            uint32_t dsum = x0 + x1, fsum = f0 + f1;
-            wave::inclusive_scan2(dsum, fsum);
-            d1 = base + dsum;
-            d0 = d1 - x1;
-            before = fsum - f0 - f1;
+            decode_packed_pos<LAYOUT>(seg.pk + (uint64_t(wave::read_lane(aoff_l, k)) << 4), dbits,
+                                      fbits, base, lane, d0, d1, f0, f1, before);
           } else {
             decode_block_pos<LAYOUT>(seg.doc + tl.doc_start + wave::read_lane(off_l, k), dbits,
                                      fbits, base, lane, d0, d1, f0, f1, before);
