@@ -120,6 +120,11 @@ __device__ __forceinline__ uint32_t opaque(uint32_t v) {
   return v;
 }
 
+__device__ __forceinline__ uint64_t opaque64(uint64_t v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
+
 // A register whose content does not matter (no instruction is emitted).
 __device__ __forceinline__ uint64_t undef64() {
   uint64_t v;
@@ -166,6 +171,30 @@ __device__ __forceinline__ void lds_add(const unsigned char*, uint32_t off, unsi
 
 // LDS float accumulate without a returned value -> ds_add_f32
 __device__ __forceinline__ void lds_add(float* p, float v) { atomicAdd(p, v); }
+
+// ---- loads that are NOT flat ---------------------------------------------------
+// A pointer read out of a struct in memory is a generic pointer: the compiler emits
+// FLAT loads for it, which count on BOTH vmcnt and lgkmcnt — every wait for an LDS
+// result then also drains the global loads in flight.  The hot paths therefore go
+// through explicit address spaces:
+//   sload<T>(a)      a record at a wave-uniform ADDRESS (an integer: a pointer would let the
+//                    compiler trace it back to a global-memory kernel argument and fall back
+//                    to vector loads) that nobody writes during the kernel -> constant
+//                    address space -> s_load_dwordxN into SGPRs
+//   gload_u64(b, o)  8 bytes at (wave-uniform 64-bit base) + (per-lane 32-bit offset)
+//                    -> global_load_dwordx2 v, v_off, s[base] (saddr form, vmcnt only)
+#define IRS_CONST __attribute__((address_space(4)))
+#define IRS_GLOBAL __attribute__((address_space(1)))
+template<typename T>
+__device__ __forceinline__ T sload(uint64_t addr) {
+  T v;
+  __builtin_memcpy(&v, (const IRS_CONST T*)addr, sizeof(T));
+  return v;
+}
+__device__ __forceinline__ uint64_t gload_u64(uint64_t base, uint32_t off) {
+  typedef uint64_t __attribute__((aligned(4))) u64a4;
+  return *(const IRS_GLOBAL u64a4*)((const IRS_GLOBAL uint8_t*)base + off);
+}
 
 // Unaligned little-endian loads from the byte-granular `.doc` stream.
 __device__ __forceinline__ uint64_t load_u64(const uint8_t* p) {

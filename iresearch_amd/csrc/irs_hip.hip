@@ -13,6 +13,7 @@
 #include "gpu_rt.h"
 #include "kernels.h"
 #include "phrase.h"
+#include "score.h"
 
 using namespace irs_hip;
 
@@ -117,6 +118,13 @@ struct irs_hip_batch {
   std::vector<DevQTerm> qterms;
   DevBuf d_segs, d_queries, d_qterms, d_first, d_tails, d_bstar, d_cands, d_cand_count, d_hits,
     d_out, d_out_count, d_status, d_work;
+  // work-item lists of the doc tiles (score.h): per-tile item offsets (+ scan scratch) and
+  // the 32-byte records themselves
+  DevBuf d_tile_off, d_scan_parts, d_items, d_score_args;
+  ScoreArgs score_args{};
+  uint32_t total_tiles = 0;    // doc tiles of all units
+  uint32_t score_threads = 0;  // threads per k_pilot / k_score workgroup (power of two x 64)
+  uint32_t nw_log2 = 3;        // log2(wavefronts per such workgroup)
   uint64_t alg_bytes = 0, postings = 0;
   bool profile = false;
   bool events_ready = false;
@@ -245,10 +253,10 @@ bool launch_pilot(irs_hip_batch* b, rt::stream_t st) {
   const size_t smem = tile_smem_bytes<ACC, TILE, AND>() + kBins * sizeof(uint32_t);
   auto kern = k_pilot<ACC, LAYOUT, TILE, AND>;
   if (!big_smem(kern, smem)) return false;
-  RT_LAUNCH(kern, b->nq, b->wg_threads, smem, st, b->d_segs.as<DevSegment>(),
-            b->d_queries.as<DevQuery>(), b->d_qterms.as<DevQTerm>(), b->jt, b->stride_eff,
-            b->d_first.as<uint32_t>(), b->d_tails.as<DevTail>(), b->d_bstar.as<uint32_t>(),
-            b->estimate ? kPilotMargin : 0u);
+  RT_LAUNCH(kern, b->nq, b->score_threads, smem, st, b->d_segs.as<DevSegment>(),
+            b->d_queries.as<DevQuery>(), b->d_qterms.as<DevQTerm>(), b->stride_eff,
+            b->nw_log2, b->d_tile_off.as<uint32_t>(), reinterpret_cast<uint64_t>(b->d_items.p),
+            b->d_bstar.as<uint32_t>(), b->estimate ? kPilotMargin : 0u);
   return rt::last_error_ok();
 }
 
@@ -257,27 +265,53 @@ bool launch_score(irs_hip_batch* b, rt::stream_t st) {
   const size_t smem = score_smem_bytes<ACC, TILE, AND>();
   auto kern = k_score<ACC, LAYOUT, TILE, AND>;
   if (!big_smem(kern, smem)) return false;
-  // k_score stages 16 norm bytes per thread per tile
-  const uint32_t threads = std::max<uint32_t>(b->wg_threads, uint32_t(TILE) / (TILE > 8192 ? 24u : 16u));
   // persistent grid: as many workgroups as stay resident on the chip at once
-  const uint32_t waves = threads / 64;
+  const uint32_t waves = b->score_threads / 64;
   uint32_t per_cu = uint32_t((160u * 1024u) / smem);
-#ifdef IRS_SCORE_WAVES_PER_EU
-  per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 4u * IRS_SCORE_WAVES_PER_EU / waves));
-#else
   per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 16u / waves));  // 128 VGPRs: 4 waves/SIMD
-#endif
   const uint32_t cpq = (b->max_tiles + kChunkTiles - 1) / kChunkTiles;  // chunk ids per unit
   const uint64_t chunks = uint64_t(b->nq) * cpq;
   if (chunks > 0xFFFF0000ull) return false;
   const uint32_t grid = uint32_t(std::min<uint64_t>(chunks, uint64_t(b->seg->cus) * per_cu));
-  if (!rt::dmemset(b->d_work.p, 0, 4, st)) return false;
-  RT_LAUNCH(kern, grid, threads, smem, st, b->d_segs.as<DevSegment>(),
-            b->d_queries.as<DevQuery>(), b->d_qterms.as<DevQTerm>(), b->jt, cpq, b->nq,
-            b->d_first.as<uint32_t>(), b->d_tails.as<DevTail>(), b->d_bstar.as<uint32_t>(),
-            b->d_cands.as<uint64_t>(), b->cand_cap, b->d_cand_count.as<uint32_t>(),
-            b->d_hits.as<unsigned long long>(), b->d_work.as<uint32_t>());
+  ScoreArgs& a = b->score_args;   // read by the kernel from device memory (score.h)
+  a.segs = b->d_segs.as<DevSegment>();
+  a.queries = b->d_queries.as<DevQuery>();
+  a.qterms = b->d_qterms.as<DevQTerm>();
+  a.tile_off = b->d_tile_off.as<uint32_t>();
+  a.items = reinterpret_cast<uint64_t>(b->d_items.p);
+  a.bstar = b->d_bstar.as<uint32_t>();
+  a.cands = b->d_cands.as<uint64_t>();
+  a.cand_count = b->d_cand_count.as<uint32_t>();
+  a.hits = b->d_hits.as<unsigned long long>();
+  a.work_counter = b->d_work.as<uint32_t>();
+  a.cpq = cpq;
+  a.n_units = b->nq;
+  a.nw_log2 = b->nw_log2;
+  a.cand_cap = b->cand_cap;
+  if (!rt::dmemset(b->d_work.p, 0, 4, st) ||
+      !rt::h2d(b->d_score_args.p, &a, sizeof a, st))
+    return false;
+  RT_LAUNCH(kern, grid, b->score_threads, smem, st, reinterpret_cast<uint64_t>(b->d_score_args.p));
   return rt::last_error_ok();
+}
+
+// LDS byte offset of the table rows in the tile kernels' layout (what k_items_fill writes
+// into the work items' `tab` field)
+template<typename ACC, int TILE>
+uint32_t caches_off_and(const irs_hip_batch* b) {
+  return b->any_and ? TileOff<ACC, TILE, true>::caches : TileOff<ACC, TILE, false>::caches;
+}
+template<typename ACC>
+uint32_t caches_off_tile(const irs_hip_batch* b) {
+  switch (b->tile) {
+    case 12288: return caches_off_and<ACC, 12288>(b);
+    case 8192: return caches_off_and<ACC, 8192>(b);
+    case 6144: return caches_off_and<ACC, 6144>(b);
+    default: return caches_off_and<ACC, 4096>(b);
+  }
+}
+uint32_t caches_off(const irs_hip_batch* b) {
+  return b->acc32 ? caches_off_tile<uint32_t>(b) : caches_off_tile<unsigned long long>(b);
 }
 
 template<typename ACC, int LAYOUT, int TILE>
@@ -319,6 +353,28 @@ bool launch_score_acc(irs_hip_batch* b, rt::stream_t st) {
                   : launch_score_tile<unsigned long long, LAYOUT>(b, st);
 }
 
+// Work-item lists of every (unit, doc tile): count -> exclusive scan (all on the device, no
+// host round trip: the buffer is sized by an upper bound) -> fill.
+bool launch_items(irs_hip_batch* b, rt::stream_t st) {
+  uint32_t* off = b->d_tile_off.as<uint32_t>();
+  const uint64_t n = uint64_t(b->total_tiles) + 1;   // [total_tiles] = 0 -> the grand total
+  if (!rt::dmemset(off + b->total_tiles, 0, 4, st)) return false;
+  const uint32_t tb = (b->max_tiles + kThreads - 1) / kThreads;
+  RT_LAUNCH(k_items_count, b->nq * tb, kThreads, 0, st, b->d_queries.as<DevQuery>(), b->jt,
+            b->tile, tb, b->d_first.as<uint32_t>(), b->d_tails.as<DevTail>(), off);
+  const uint32_t parts = uint32_t((n + kScanChunk - 1) / kScanChunk);
+  uint64_t* totals = b->d_scan_parts.as<uint64_t>();
+  RT_LAUNCH(k_scan_totals, parts, kThreads, 0, st, off, n, totals);
+  RT_LAUNCH(k_scan_parts, 1, 64, 0, st, totals, parts);
+  RT_LAUNCH(k_scan_apply, parts, kThreads, 0, st, off, n, totals);
+  const uint32_t tb4 = (b->max_tiles + kWaves - 1) / kWaves;
+  RT_LAUNCH(k_items_fill, b->nq * tb4, kThreads, 0, st, b->d_segs.as<DevSegment>(),
+            b->d_queries.as<DevQuery>(), b->d_qterms.as<DevQTerm>(), b->jt, b->tile, tb4,
+            b->nw_log2, caches_off(b), b->d_first.as<uint32_t>(), b->d_tails.as<DevTail>(), off,
+            b->total_tiles, b->d_items.as<ItemG>());
+  return rt::last_error_ok();
+}
+
 template<int LAYOUT, int MT>
 bool launch_phrase(irs_hip_batch* b, rt::stream_t st) {
   if (b->n_phrase_wgs == 0) return true;  // no query has all its terms in its segment
@@ -343,8 +399,10 @@ bool ensure_scratch(irs_hip_batch* b) {
   // the largest tile that still lets two workgroups share a CU's 160 KB of LDS
   // (AND / min-match batches also keep a match counter byte per doc)
   if (b->tile == 0) b->tile = b->acc32 ? (b->any_and ? 8192 : 12288) : 6144;
-  // per unit: tiles of its segment and its slice of the plan table
-  uint64_t first_words = 0;
+  // per unit: tiles of its segment, its slice of the plan table and of the per-tile tables;
+  // upper bound of its work items: every block once + one more per tile border it may
+  // straddle + the decoded tail
+  uint64_t first_words = 0, tiles = 0, item_bound = kItemSlack;
   b->n_tiles = 0xFFFFFFFFu;
   b->max_tiles = 0;
   for (uint32_t u = 0; u < b->nq; ++u) {
@@ -352,9 +410,19 @@ bool ensure_scratch(irs_hip_batch* b) {
     dq.n_tiles = (b->segs[dq.seg]->dev.num_docs + b->tile - 1) / b->tile;
     dq.first_off = first_words;
     first_words += uint64_t(dq.n_tiles + 1) * b->jt;
+    if (tiles + dq.n_tiles > 0xFFFFFF00ull) return false;
+    dq.tile_base = uint32_t(tiles);
+    tiles += dq.n_tiles;
     b->n_tiles = std::min(b->n_tiles, dq.n_tiles);
     b->max_tiles = std::max(b->max_tiles, dq.n_tiles);
+    if (!b->phrase) {
+      for (uint32_t j = 0; j < dq.n_terms; ++j)
+        item_bound += uint64_t(b->segs[dq.seg]->terms[b->qterms[dq.first_term + j].term].nblk) +
+                      dq.n_tiles + 1;
+    }
   }
+  if (item_bound > 0xFFFFFF00ull) return false;
+  b->total_tiles = uint32_t(tiles);
   {  // k_score's queue order: heaviest units first within every chunk round
     std::vector<std::pair<uint64_t, uint32_t>> work(b->nq);
     for (uint32_t u = 0; u < b->nq; ++u) {
@@ -376,7 +444,16 @@ bool ensure_scratch(irs_hip_batch* b) {
   if (b->phrase) b->stride_eff = 1;  // no pilot: every match is a candidate
   if (const char* e = std::getenv("IRS_HIP_WG_THREADS")) {  // tuning knob
     const uint32_t t = uint32_t(std::atoi(e));
-    if (t >= 256 && t <= 1024 && t % 64 == 0) b->wg_threads = t;
+    if (t == 256 || t == 512 || t == 1024) b->wg_threads = t;
+  }
+  // k_pilot / k_score stage TILE norm bytes per tile, NormStage<TILE>::kPieces x 8 per thread
+  {
+    const uint32_t pieces = (b->tile + 4095u) / 4096u;
+    uint32_t need = b->phrase ? 0u : (b->tile + 8u * pieces - 1u) / (8u * pieces);
+    b->score_threads = b->wg_threads;
+    while (b->score_threads < need) b->score_threads *= 2;
+    b->nw_log2 = 0;
+    while ((64u << b->nw_log2) < b->score_threads) ++b->nw_log2;
   }
   if (b->cand_cap == 0) b->cand_cap = default_cand_cap(b);
   const uint64_t rows = uint64_t(b->nq) * b->jt;
@@ -393,6 +470,14 @@ bool ensure_scratch(irs_hip_batch* b) {
       !b->d_out_count.alloc(b->nq * sizeof(uint32_t)) || !b->d_status.alloc(4) ||
       !b->d_work.alloc(4))
     return false;
+  if (!b->phrase) {
+    const uint64_t parts = (tiles + 1 + kScanChunk - 1) / kScanChunk;
+    if (!b->d_tile_off.alloc((tiles + 1) * sizeof(uint32_t)) ||
+        !b->d_scan_parts.alloc((parts + 1) * sizeof(uint64_t)) ||
+        !b->d_items.alloc(item_bound * sizeof(ItemG)) ||
+        !b->d_score_args.alloc(sizeof(ScoreArgs)))
+      return false;
+  }
   b->scratch_ready = true;
   return true;
 }
@@ -1070,6 +1155,7 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st) {
               b->d_first.as<uint32_t>(), b->d_tails.as<DevTail>());
     ok = rt::last_error_ok();
   }
+  if (ok && !b->phrase) ok = launch_items(b, st);
   ok = ok && mark(2 * IRS_HIP_K_PLAN + 1);
   // 2. pilot: per-query score-bin threshold (phrase batches have none: few docs match)
   ok = ok && mark(2 * IRS_HIP_K_PILOT);

@@ -58,7 +58,7 @@ __device__ __forceinline__ void decode_block_pos(const uint8_t* blk, uint32_t db
   before = fsum - f0 - f1;
 }
 
-// The same from the packed-payload image (both parts 1..31-bit packed, pk_units() != 0):
+// The same from the packed-payload image (both parts 1..31-bit packed, pk_both()):
 // 16-byte aligned payloads, one funnel shift + one bit-field extract per value, as k_score's
 // hot loop reads them.
 template<int LAYOUT>
@@ -391,7 +391,7 @@ k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms
       const uint32_t bits = seg.blk_bits[e];
       const uint32_t base = item ? seg.blk_last[e - 1] : kDocMin;
       uint32_t before;
-      if (pk_units(bits & 0xFFu, bits >> 8)) {
+      if (pk_both(bits & 0xFFu, bits >> 8)) {
         decode_packed_pos<LAYOUT>(seg.pk + (uint64_t(seg.blk_aoff[e]) << 4), bits & 0xFFu,
                                   bits >> 8, base, lane, d[0], d[1], f[0], f[1], before);
       } else {
@@ -475,7 +475,7 @@ k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms
           const uint32_t base = wave::read_lane(base_l, k);
           uint32_t d0, d1, f0, f1, before;
           const uint32_t dbits = bits & 0xFFu, fbits = bits >> 8;
-          if (pk_units(dbits, fbits)) {
+          if (pk_both(dbits, fbits)) {
             // both parts 1..31-bit packed: the 16-byte aligned copy in the packed image,
             // one funnel shift + one bit-field extract per value (as k_score's hot loop)
             decode_packed_pos<LAYOUT>(seg.pk + (uint64_t(wave::read_lane(aoff_l, k)) << 4), dbits,

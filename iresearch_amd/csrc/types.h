@@ -117,7 +117,8 @@ struct DevQuery {
   // unit that runs i-th within every chunk round — units sorted by decreasing work, so the
   // last workgroups to finish hold the lightest chunks (longest-processing-time first)
   uint32_t run_unit;
-  uint32_t pad;
+  uint32_t tile_base;   // index of the unit's first doc tile in the batch-wide per-tile tables
+                        // (DevQuery n_tiles summed over the units in front of it)
 };
 
 struct DevQTerm {

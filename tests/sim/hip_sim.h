@@ -302,6 +302,17 @@ inline unsigned long long __ballot(int pred) {
   return m;
 }
 
+inline unsigned __float_as_uint(float f) {
+  unsigned u;
+  std::memcpy(&u, &f, 4);
+  return u;
+}
+inline float __uint_as_float(unsigned u) {
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+
 // ---- atomics (global memory is shared between OS threads) --------------------
 inline unsigned atomicAdd(unsigned* p, unsigned v) {
   return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);

@@ -56,6 +56,15 @@ __device__ __forceinline__ uint32_t load_u32(const uint8_t* p) {
   return v;
 }
 
+// scalar / saddr-global loads of hip/wave.h: plain reads here
+template<typename T>
+__device__ __forceinline__ T sload(uint64_t addr) { return *reinterpret_cast<const T*>(addr); }
+__device__ __forceinline__ uint64_t gload_u64(uint64_t base, uint32_t off) {
+  uint64_t v;
+  __builtin_memcpy(&v, reinterpret_cast<const uint8_t*>(base) + off, 8);
+  return v;
+}
+
 // wave-uniform value -> scalar register on the GPU; identity here
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return v; }
 __device__ __forceinline__ float uniform_f(float v) { return v; }
@@ -72,6 +81,8 @@ __device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t s)
 __device__ __forceinline__ uint32_t bfe(uint32_t x, uint32_t bits) { return x & ((1u << bits) - 1u); }
 __device__ __forceinline__ uint64_t undef64() { return 0; }
 __device__ __forceinline__ uint32_t opaque(uint32_t v) { return v; }
+__device__ __forceinline__ uint64_t opaque64(uint64_t v) { return v; }
+
 // LDS "by absolute address" (hip/wave.h): here simply base + offset
 __device__ __forceinline__ bool lds_is_at_zero(const unsigned char*) { return true; }
 __device__ __forceinline__ uint32_t lds_u8(const unsigned char* base, uint32_t off) { return base[off]; }
