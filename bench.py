@@ -58,12 +58,14 @@ def usable_cpus():
     return max(1, n)
 
 
-def cpu_baseline(seg, ranks, k, seconds_hint=12.0):
-    """Oracle (port of the index-search loop) on a bounded sample of the same
-    queries.  Imports oracle/ here and only here."""
+def cpu_baseline(seg, ranks, k, seconds_hint=10.0):
+    """Oracle (port of the index-search loop) on a bounded sample of the same queries, built
+    -O3 -march=native on this host, timed with ONE thread and with as many
+    threads as this container may use.  Imports oracle/ here and only here."""
     import oracle
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import parity
+    native = oracle.use_native()
     cores = usable_cpus()
     view = parity.oracle_view(seg)
     sc = oracle.Scorer(oracle.SCORER_BM25, 1.2, 0.75, 0)
@@ -71,22 +73,30 @@ def cpu_baseline(seg, ranks, k, seconds_hint=12.0):
     def metas_of(rows):
         return np.stack([parity.metas_for(seg, [int(r) - 1 for r in row])[None] for row in rows])
 
-    # calibrate on a few queries per thread, then size the sample (the bench queries, cycled
-    # if there are too few) for ~seconds_hint of wall time
-    probe = ranks[: min(len(ranks), max(8, 4 * cores))]
-    t0 = time.perf_counter()
-    oracle.search_batch([view], metas_of(probe), oracle.OP_OR, sc, k, cores)
-    dt = max(time.perf_counter() - t0, 1e-6)
-    n = int(min(20000, max(len(probe), len(probe) * seconds_hint / dt)))
-    sample = ranks[np.arange(n) % len(ranks)]
-    t0 = time.perf_counter()
-    oracle.search_batch([view], metas_of(sample), oracle.OP_OR, sc, k, cores)
-    dt = time.perf_counter() - t0
+    def timed(threads, hint):
+        # calibrate on a few queries per thread, then size the sample (the bench queries,
+        # cycled if there are too few) for ~hint seconds of wall time
+        probe = ranks[: min(len(ranks), max(4, 4 * threads))]
+        t0 = time.perf_counter()
+        oracle.search_batch([view], metas_of(probe), oracle.OP_OR, sc, k, threads)
+        dt = max(time.perf_counter() - t0, 1e-6)
+        n = int(min(20000, max(len(probe), len(probe) * hint / dt)))
+        sample = ranks[np.arange(n) % len(ranks)]
+        t0 = time.perf_counter()
+        oracle.search_batch([view], metas_of(sample), oracle.OP_OR, sc, k, threads)
+        dt = time.perf_counter() - t0
+        return n / dt, n, dt
+
+    q1, n1, dt1 = timed(1, 0.6 * seconds_hint)
+    qt, nt, dtt = timed(cores, seconds_hint)
     hw = os.cpu_count() or cores
-    return {"value": round(n / dt, 3), "unit": "queries/s", "cores": cores, "kind": "port",
-            "sample": "%d queries (the %d bench queries, cycled), %d threads popping one task "
-                      "queue (index-search --threads) = the CPUs this container may use "
-                      "(CFS quota) of %d hardware threads, %.1f s" % (n, len(ranks), cores, hw, dt)}
+    return {"value": round(qt, 3), "value_1thread": round(q1, 3), "unit": "queries/s",
+            "cores": cores, "kind": "port",
+            "flags": "-O3 -march=native" if native else "-O2 (native build failed)",
+            "sample": "%d queries on %d threads in %.1f s, %d queries on 1 thread in %.1f s (the %d "
+                      "bench queries, cycled); threads pop one task queue (index-search "
+                      "--threads); %d = the CPUs this container may use (CFS quota) of %d "
+                      "hardware threads" % (nt, cores, dtt, n1, dt1, len(ranks), cores, hw)}
 
 
 def main():
@@ -102,6 +112,9 @@ def main():
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--stride", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--query-sets", type=int, default=4,
+                    help="distinct query batches of the same distribution the steps rotate over "
+                         "(set 0 is BASELINE config 3's; no step replays the previous one)")
     ap.add_argument("--per-segment-batches", action="store_true",
                     help="one batch per local segment instead of one batch over all of them (A/B)")
     ap.add_argument("--force-segments", action="store_true",
@@ -176,24 +189,32 @@ def main():
         (time.perf_counter() - t0, sum(r.device_bytes() for r in readers.values()) / 1e6))
 
     # ---- queries: prepared once (statistics are index-global) ---------------
-    ranks = synth.make_queries(args.queries, args.terms, 16, 4096, synth.SEED + 2)
-    filters = [Or([by_term(int(r) - 1) for r in row]) for row in ranks]
-    prepared = search.prepare(filters, BM25(), seg_stats)
-    # ONE batch per rank over all of its segments (irs_hip_batch_create_multi): every kernel is
-    # launched once for all (segment, query) pairs.  --per-segment-batches: one batch per
-    # segment, back to back (A/B).
-    batches = {}
+    # query set 0 = BASELINE config 3 (seed + 2); further sets: same distribution, other seeds
+    n_sets = max(1, args.query_sets)
+    rank_sets = [synth.make_queries(args.queries, args.terms, 16, 4096,
+                                    synth.SEED + 2 + (10 + i if i else 0)) for i in range(n_sets)]
+    ranks = rank_sets[0]
+    # ONE batch per rank (and query set) over all of its segments (irs_hip_batch_create_multi):
+    # every kernel is launched once for all (segment, query) pairs.  --per-segment-batches: one
+    # batch per segment, back to back (A/B).
     if len(my) > 1 and not args.per_segment_batches:
         groups = {my[0]: list(my)}
     else:
         groups = {s: [s] for s in my}
-    for lead, members in groups.items():
-        b = search.QueryBatch([readers[s] for s in members], prepared, args.k) \
-            if len(members) > 1 else readers[lead].batch(prepared, args.k)
-        if args.tile or args.stride:
-            b.configure(args.tile, args.stride, 0)
-        b.profile(True)
-        batches[lead] = b
+    batch_sets = []
+    for rk in rank_sets:
+        filters = [Or([by_term(int(r) - 1) for r in row]) for row in rk]
+        prepared = search.prepare(filters, BM25(), seg_stats)
+        batches = {}
+        for lead, members in groups.items():
+            b = search.QueryBatch([readers[s] for s in members], prepared, args.k) \
+                if len(members) > 1 else readers[lead].batch(prepared, args.k)
+            if args.tile or args.stride:
+                b.configure(args.tile, args.stride, 0)
+            b.profile(True)
+            batches[lead] = b
+        batch_sets.append(batches)
+    batches = batch_sets[0]
     sptr = None if sim else C_void(torch.cuda.current_stream(dev).cuda_stream)
     nq, k = args.queries, args.k
     # every buffer of the exchange step is allocated once (twice: two sets alternate); each
@@ -205,32 +226,51 @@ def main():
     slots = [{lead: exchange.slot(ph, my.index(lead)) for lead in batches} for ph in (0, 1)]
     state = {"it": 0}
 
-    def step():
+    def step(host_results=False):
         # every step ends with a checked, device-resident top-k: results_to_device reads the
         # batch status (4 bytes) and re-runs the batch if a threshold estimate or the
         # candidate buffer fell short (irs_hip_batch_reruns counts those).  The all-gather
         # (RCCL) of step i overlaps the kernels of step i+1; its GPU merge is enqueued behind them.
+        # Steps rotate over the query sets.  host_results: the hits also go to host memory
+        # (irs_hip_batch_results), where the reference's harness ends (index-search.cpp:782-807).
         ph = state["it"] & 1
+        cur = batch_sets[state["it"] % n_sets]
         state["it"] += 1
-        for s in batches:
-            batches[s].run(sptr)
+        state["cur"] = cur
+        for s in cur:
+            cur[s].run(sptr)
         if multi:
             exchange.finish(sptr)
-        for s in batches:
-            batches[s].results_to_device(slots[ph][s][0], slots[ph][s][1], sptr)
+        for s in cur:
+            if host_results:
+                cur[s].results()
+            cur[s].results_to_device(slots[ph][s][0], slots[ph][s][1], sptr)
         if multi:
             exchange.start(ph)
 
     def flush():
         return exchange.finish(sptr) if multi else None
 
+    # first execution of every batch (a fresh query set): timed apart, outside the steps —
+    # includes whatever re-run a misled threshold estimate costs
+    first_ms = []
+    for _ in range(n_sets):
+        sync()
+        t0 = time.perf_counter()
+        step()
+        flush()
+        sync()
+        first_ms.append(1e3 * (time.perf_counter() - t0))
+    state["it"] = 0
+    reruns_before = sum(b[s].reruns() for b in batch_sets for s in b)
     for _ in range(args.warmup):
         step()
     flush()
     sync()
-    # sanity: results are retrievable (also triggers the overflow re-run path if needed)
+    # sanity: results are retrievable
     for s in batches:
         batches[s].results()
+    reruns_warm = sum(b[s].reruns() for b in batch_sets for s in b)
     score_ms = []
     if world > 1:
         dist.barrier()
@@ -240,20 +280,35 @@ def main():
         step()
         # per-kernel HIP-event timings of this step on rank 0 (waits for the stream)
         if rank == 0:
-            score_ms.append(np.sum([batches[s].timings() for s in batches], axis=0))
+            cur = state["cur"]
+            score_ms.append(np.sum([cur[s].timings() for s in cur], axis=0))
     flush()
     sync()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    reruns_timed = sum(b[s].reruns() for b in batch_sets for s in b) - reruns_warm
+    # the same steps with the hits copied to host memory in every step (not `value`)
+    host_elapsed = None
+    if world == 1 and not sim:
+        n_host = max(2, min(args.steps, 8))
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n_host):
+            step(host_results=True)
+        flush()
+        sync()
+        host_elapsed = (time.perf_counter() - t0) / n_host
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    reruns = sum(batches[s].reruns() for s in batches)
-    alg_bytes = sum(batches[s].work()[0] for s in batches)
-    postings = sum(batches[s].work()[1] for s in batches)
+    reruns = sum(b[s].reruns() for b in batch_sets for s in b)
+    # per step, averaged over the query sets the steps rotated over
+    used = [batch_sets[i % n_sets] for i in range(args.steps)]
+    alg_bytes = sum(b[s].work()[0] for b in used for s in b) / len(used)
+    postings = sum(b[s].work()[1] for b in used for s in b) / len(used)
     rank0_alg_bytes = alg_bytes
     if world > 1:
         t = torch.tensor([alg_bytes, postings], dtype=torch.float64, device=dev)
@@ -271,7 +326,7 @@ def main():
             achieved = rank0_alg_bytes / (avg[_lib.K_SCORE] * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": "k_score", "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": None if multi else measured_traffic(1),
+                    "traffic": None if multi else measured_traffic(),
                     "algorithmic_bytes_per_launch": int(rank0_alg_bytes / len(batches)),
                     "launches_per_step": len(batches),
                     "avg_launch_ms": round(float(avg[_lib.K_SCORE]), 4),
@@ -281,21 +336,24 @@ def main():
             "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "value_with_results_on_host": None if host_elapsed is None else round(nq / host_elapsed, 2),
             "dtype": "u32+f32", "data": "synthetic" if not sim else "synthetic (EMULATOR DRY RUN)",
             "config": {
                 "workload": "OR-of-%d terms BM25 top-%d, %d-doc Zipfian index, %d segment(s), "
                             "%d queries/step" % (args.terms, k, args.docs, n_segments, nq),
                 "segments": n_segments, "queries_per_step": nq, "layout": "1_5simd",
                 "postings_per_step": int(postings), "algorithmic_bytes_per_step": int(alg_bytes),
-                "reruns_rank0": int(reruns),
+                "query_sets": n_sets, "first_run_ms_per_set": [round(x, 3) for x in first_ms],
+                "reruns_rank0": int(reruns), "reruns_in_timed_steps": int(reruns_timed),
                 "parallelism": ("%d segments over %d GPU(s) + RCCL all-gather of per-segment "
                                 "top-k + GPU merge" % (n_segments, world)) if multi
                                else "1 segment on 1 GPU"},
             "roofline": roof,
         }
     if rank == 0 and not multi and not args.no_cpu:
-        for b in batches.values():
-            b.close()
+        for bs in batch_sets:
+            for b in bs.values():
+                b.close()
         out["cpu_baseline"] = cpu_baseline(segs[0], ranks, k)
     elif rank == 0:
         out["cpu_baseline"] = None
@@ -306,16 +364,30 @@ def main():
         dist.destroy_process_group()
 
 
-def measured_traffic(n_launches):
+def kernel_sources_sha():
+    """What a traffic measurement is valid for: the kernel sources it was taken with."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "iresearch_amd", "csrc")
+    for n in sorted(os.listdir(d)) + sorted("hip/" + x for x in os.listdir(os.path.join(d, "hip"))):
+        p = os.path.join(d, n)
+        if os.path.isfile(p) and n.endswith((".h", ".hip")):
+            h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic():
     """HBM bytes per k_score launch from rocprofv3 PMC passes of this same command
-    (FETCH_SIZE and WRITE_SIZE in their own --pmc runs), committed under profiles/."""
+    (FETCH_SIZE and WRITE_SIZE in their own --pmc runs, tools/summarize_prof.py), committed
+    under profiles/ — reported only while the kernel sources are the ones it was measured
+    with; null otherwise (a stale figure is worse than none)."""
     path = os.path.join(ROOT, "profiles", "traffic_latest.json")
     try:
         with open(path) as f:
             t = json.load(f)
-        return t if n_launches == 1 else None
-    except OSError:
+    except (OSError, ValueError):
         return None
+    return t if t.get("kernel_sources_sha") == kernel_sources_sha() else None
 
 
 def C_void(v):

@@ -83,6 +83,7 @@ struct irs_hip_segment {
   DevSegment dev{};
   DevBuf d_doc, d_norms, d_terms, d_blk_off, d_blk_last, d_blk_bits, d_status;
   DevBuf d_blk_aoff, d_pk;     // packed-payload image (DevSegment::pk) and its offsets
+  DevBuf d_blk_dir;            // BlkDir per block
   DevBuf d_tail_docs, d_tail_freqs;  // decoded vint tails, [num_terms][128]
   // positions (fields with POS): `.pos` bytes, per-term records, pos block directory,
   // positions in front of every doc block, decoded position tails
@@ -160,6 +161,11 @@ int build_packed_image(irs_hip_segment* s) {
   const uint64_t n = s->total_blocks;
   uint64_t total_units = 0;  // offsets are u32 units of 16 bytes (64 GB)
   if (const int rc = scan_exclusive(s->d_blk_aoff.as<uint32_t>(), n, &total_units)) return rc;
+  if (n) {
+    RT_LAUNCH(k_dir_aoff, uint32_t((n + kThreads - 1) / kThreads), kThreads, 0, nullptr,
+              s->d_blk_aoff.as<uint32_t>(), n, s->d_blk_dir.as<BlkDir>());
+    if (!rt::last_error_ok()) return IRS_HIP_EHIP;
+  }
   const uint64_t bytes = total_units * 16;
   if (!s->d_pk.alloc(bytes + kPadBytes)) return IRS_HIP_ENOMEM;
   if (!rt::dmemset(s->d_pk.as<uint8_t>() + bytes, 0, kPadBytes, nullptr)) return IRS_HIP_EHIP;
@@ -182,8 +188,9 @@ int build_directory(irs_hip_segment* s) {
     RT_LAUNCH((k_build_directory<LAYOUT>), grid, kThreads, 0, nullptr, s->dev,
               s->d_terms.as<DevTerm>(), s->d_blk_off.as<uint32_t>(),
               s->d_blk_last.as<uint32_t>(), s->d_blk_bits.as<uint16_t>(),
-              s->d_blk_aoff.as<uint32_t>(), s->d_tail_docs.as<uint32_t>(),
-              s->d_tail_freqs.as<uint32_t>(), s->d_status.as<uint32_t>());
+              s->d_blk_aoff.as<uint32_t>(), s->d_blk_dir.as<BlkDir>(),
+              s->d_tail_docs.as<uint32_t>(), s->d_tail_freqs.as<uint32_t>(),
+              s->d_status.as<uint32_t>());
   }
   if (!rt::last_error_ok()) return IRS_HIP_EHIP;
   uint32_t status = 0;
@@ -223,6 +230,10 @@ int build_positions(irs_hip_segment* s, const std::vector<uint64_t>& pos_end) {
     return IRS_HIP_EHIP;
   const uint32_t grid = (s->dev.num_terms + kWaves - 1) / kWaves;
   if (grid) {
+    // a term_meta::freq that disagrees with the decoded frequencies would send the position
+    // kernels past their buffers: refuse the segment (IRS_HIP_ECORRUPT)
+    RT_LAUNCH(k_check_freq_totals, (s->dev.num_terms + kThreads - 1) / kThreads, kThreads, 0,
+              nullptr, s->dev, s->d_pterms.as<DevPosTerm>(), s->d_status.as<uint32_t>());
     RT_LAUNCH(k_pos_directory, grid, kThreads, 0, nullptr, s->dev, s->d_pterms.as<DevPosTerm>(),
               s->d_pblk_off.as<uint32_t>(), s->d_pblk_bits.as<uint8_t>(),
               s->d_ptail.as<uint32_t>(), d_pos_end.as<uint64_t>(), s->d_status.as<uint32_t>());
@@ -484,6 +495,19 @@ bool ensure_scratch(irs_hip_batch* b) {
 
 }  // namespace
 
+// Runs one entry point's body; exceptions (std::bad_alloc out of a std::vector, anything
+// else) become status codes: the ABI promises that nothing is thrown across it.
+template<typename F>
+int guarded(F&& f) noexcept {
+  try {
+    return f();
+  } catch (const std::bad_alloc&) {
+    return IRS_HIP_ENOMEM;
+  } catch (...) {
+    return IRS_HIP_EHIP;
+  }
+}
+
 extern "C" {
 
 uint32_t irs_hip_abi_version(void) { return IRS_HIP_ABI_VERSION; }
@@ -501,14 +525,14 @@ const char* irs_hip_strerror(int status) {
   }
 }
 
-int irs_hip_device_arch(int32_t device, char* buf, size_t cap) {
+static int device_arch_impl(int32_t device, char* buf, size_t cap) {
   if (!buf || !cap) return IRS_HIP_EINVAL;
   if (device < 0 || device >= rt::device_count() || !rt::device_arch(device, buf, cap))
     return IRS_HIP_EHIP;
   return IRS_HIP_OK;
 }
 
-int irs_hip_segment_open(const irs_hip_segment_desc* d, irs_hip_segment** out) {
+static int segment_open_impl(const irs_hip_segment_desc* d, irs_hip_segment** out) {
   if (!d || !out) return IRS_HIP_EINVAL;
   *out = nullptr;
   if (!d->doc_file || !d->num_docs || d->num_docs > 0x7FFF0000u ||
@@ -585,6 +609,7 @@ int irs_hip_segment_open(const irs_hip_segment_desc* d, irs_hip_segment** out) {
         !s->d_terms.alloc(std::max<size_t>(1, s->terms.size()) * sizeof(DevTerm)) ||
         !s->d_blk_off.alloc((blocks + 1) * 4) || !s->d_blk_last.alloc((blocks + 1) * 4) ||
         !s->d_blk_bits.alloc((blocks + 1) * 2) || !s->d_blk_aoff.alloc((blocks + 1) * 4) ||
+        !s->d_blk_dir.alloc((blocks + 1) * sizeof(BlkDir)) ||
         !s->d_tail_docs.alloc((tail_rows + 1) * 4) || !s->d_tail_freqs.alloc((tail_rows + 1) * 4) ||
         !s->d_status.alloc(4)) {
       rc = IRS_HIP_ENOMEM;
@@ -615,6 +640,7 @@ int irs_hip_segment_open(const irs_hip_segment_desc* d, irs_hip_segment** out) {
     v.blk_last = s->d_blk_last.as<uint32_t>();
     v.blk_bits = s->d_blk_bits.as<uint16_t>();
     v.blk_aoff = s->d_blk_aoff.as<uint32_t>();
+    v.blk_dir = s->d_blk_dir.as<BlkDir>();
     v.tail_docs = s->d_tail_docs.as<uint32_t>();
     v.tail_freqs = s->d_tail_freqs.as<uint32_t>();
     v.pk = nullptr;  // set by build_packed_image
@@ -682,7 +708,7 @@ int irs_hip_segment_open(const irs_hip_segment_desc* d, irs_hip_segment** out) {
                                              : build_positions<kScalar>(s, pos_end);
     }
     s->device_bytes = s->d_doc.n + s->d_norms.n + s->d_terms.n + s->d_blk_off.n +
-                      s->d_blk_last.n + s->d_blk_bits.n + s->d_blk_aoff.n + s->d_pk.n +
+                      s->d_blk_last.n + s->d_blk_bits.n + s->d_blk_aoff.n + s->d_blk_dir.n + s->d_pk.n +
                       s->d_tail_docs.n + s->d_tail_freqs.n + s->d_pos.n + s->d_pterms.n +
                       s->d_pblk_off.n + s->d_pblk_bits.n + s->d_blk_pos.n + s->d_ptail.n;
   } while (false);
@@ -704,7 +730,7 @@ uint64_t irs_hip_segment_device_bytes(const irs_hip_segment* seg) {
   return seg ? seg->device_bytes : 0;
 }
 
-int irs_hip_decode_term(irs_hip_segment* seg, uint32_t term, uint32_t* docs, uint32_t* freqs,
+static int decode_term_impl(irs_hip_segment* seg, uint32_t term, uint32_t* docs, uint32_t* freqs,
                         uint32_t cap, uint32_t* count) {
   if (!seg || !docs || !count || term >= seg->dev.num_terms) return IRS_HIP_EINVAL;
   if (freqs && !seg->dev.has_freq) return IRS_HIP_EINVAL;
@@ -731,7 +757,7 @@ int irs_hip_decode_term(irs_hip_segment* seg, uint32_t term, uint32_t* docs, uin
   return IRS_HIP_OK;
 }
 
-int irs_hip_decode_positions(irs_hip_segment* seg, uint32_t term, uint32_t* positions,
+static int decode_positions_impl(irs_hip_segment* seg, uint32_t term, uint32_t* positions,
                              uint64_t cap, uint64_t* count) {
   if (!seg || !positions || !count || term >= seg->dev.num_terms) return IRS_HIP_EINVAL;
   if (!seg->dev.pos) return IRS_HIP_EINVAL;  // the segment was opened without `.pos`
@@ -758,7 +784,7 @@ int irs_hip_decode_positions(irs_hip_segment* seg, uint32_t term, uint32_t* posi
   return IRS_HIP_OK;
 }
 
-int irs_hip_bit_union(irs_hip_segment* seg, const uint32_t* terms, uint32_t n_terms,
+static int bit_union_impl(irs_hip_segment* seg, const uint32_t* terms, uint32_t n_terms,
                       uint64_t* set, uint64_t n_words, uint64_t* count) {
   if (!seg || (!terms && n_terms) || !set || !n_words) return IRS_HIP_EINVAL;
   if (!rt::set_device(seg->device)) return IRS_HIP_EHIP;
@@ -807,7 +833,7 @@ int irs_hip_bit_union(irs_hip_segment* seg, const uint32_t* terms, uint32_t n_te
   return IRS_HIP_OK;
 }
 
-int irs_hip_term_directory(irs_hip_segment* seg, uint32_t term, uint32_t* last_docs,
+static int term_directory_impl(irs_hip_segment* seg, uint32_t term, uint32_t* last_docs,
                            uint64_t* offsets, uint32_t cap, uint32_t* count) {
   if (!seg || !count || term >= seg->dev.num_terms) return IRS_HIP_EINVAL;
   if (!rt::set_device(seg->device)) return IRS_HIP_EHIP;
@@ -828,13 +854,13 @@ int irs_hip_term_directory(irs_hip_segment* seg, uint32_t term, uint32_t* last_d
 
 // ----------------------------------------------------------------- batch --
 
-int irs_hip_batch_create(irs_hip_segment* seg, const irs_hip_query* queries, uint32_t nq,
+static int batch_create_impl(irs_hip_segment* seg, const irs_hip_query* queries, uint32_t nq,
                          const irs_hip_term_scorer* terms, uint32_t n_entries,
                          irs_hip_batch** out) {
   return irs_hip_batch_create_multi(&seg, 1, queries, nq, terms, n_entries, out);
 }
 
-int irs_hip_batch_create_multi(irs_hip_segment* const* segs, uint32_t n_segs,
+static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs,
                                const irs_hip_query* queries, uint32_t nq_user,
                                const irs_hip_term_scorer* all_terms, uint32_t n_entries,
                                irs_hip_batch** out) {
@@ -1111,7 +1137,7 @@ int irs_hip_batch_create_multi(irs_hip_segment* const* segs, uint32_t n_segs,
   return IRS_HIP_OK;
 }
 
-int irs_hip_batch_configure(irs_hip_batch* b, uint32_t tile_docs, uint32_t pilot_stride,
+static int batch_configure_impl(irs_hip_batch* b, uint32_t tile_docs, uint32_t pilot_stride,
                             uint32_t cand_cap) {
   if (!b) return IRS_HIP_EINVAL;
   if (tile_docs && tile_docs != 4096 && tile_docs != 6144 && tile_docs != 8192 &&
@@ -1127,7 +1153,7 @@ int irs_hip_batch_configure(irs_hip_batch* b, uint32_t tile_docs, uint32_t pilot
   return IRS_HIP_OK;
 }
 
-int irs_hip_batch_profile(irs_hip_batch* b, int enable) {
+static int batch_profile_impl(irs_hip_batch* b, int enable) {
   if (!b) return IRS_HIP_EINVAL;
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
   if (enable && !b->events_ready) {
@@ -1190,7 +1216,7 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st) {
   return ok ? IRS_HIP_OK : IRS_HIP_EHIP;
 }
 
-int irs_hip_batch_run(irs_hip_batch* b, void* stream) {
+static int batch_run_impl(irs_hip_batch* b, void* stream) {
   if (!b) return IRS_HIP_EINVAL;
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
   return run_impl(b, static_cast<rt::stream_t>(stream));
@@ -1249,7 +1275,7 @@ static int recover_overflow(irs_hip_batch* b) {
   return IRS_HIP_EOVERFLOW;
 }
 
-int irs_hip_batch_timings(irs_hip_batch* b, float ms[IRS_HIP_K_COUNT]) {
+static int batch_timings_impl(irs_hip_batch* b, float ms[IRS_HIP_K_COUNT]) {
   if (!b || !ms || !b->profile || !b->ran) return IRS_HIP_EINVAL;
   if (!rt::set_device(b->seg->device) || !rt::sync(b->stream)) return IRS_HIP_EHIP;
   for (int i = 0; i < IRS_HIP_K_COUNT; ++i)
@@ -1257,20 +1283,20 @@ int irs_hip_batch_timings(irs_hip_batch* b, float ms[IRS_HIP_K_COUNT]) {
   return IRS_HIP_OK;
 }
 
-int irs_hip_batch_reruns(irs_hip_batch* b, uint32_t* count) {
+static int batch_reruns_impl(irs_hip_batch* b, uint32_t* count) {
   if (!b || !count) return IRS_HIP_EINVAL;
   *count = b->reruns;
   return IRS_HIP_OK;
 }
 
-int irs_hip_batch_work(irs_hip_batch* b, uint64_t* algorithmic_bytes, uint64_t* postings) {
+static int batch_work_impl(irs_hip_batch* b, uint64_t* algorithmic_bytes, uint64_t* postings) {
   if (!b) return IRS_HIP_EINVAL;
   if (algorithmic_bytes) *algorithmic_bytes = b->alg_bytes;
   if (postings) *postings = b->postings;
   return IRS_HIP_OK;
 }
 
-int irs_hip_batch_results(irs_hip_batch* b, irs_hip_hit* hits, uint32_t k_stride,
+static int batch_results_impl(irs_hip_batch* b, irs_hip_hit* hits, uint32_t k_stride,
                           uint32_t* counts, uint64_t* total_hits) {
   if (!b || !hits || !counts || !b->ran || k_stride < b->k_max) return IRS_HIP_EINVAL;
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
@@ -1323,7 +1349,7 @@ static int verify_run(irs_hip_batch* b) {
   return IRS_HIP_OK;
 }
 
-int irs_hip_batch_device_results(irs_hip_batch* b, void** d_hits, void** d_counts,
+static int batch_device_results_impl(irs_hip_batch* b, void** d_hits, void** d_counts,
                                  uint32_t* k_max) {
   if (!b || !b->ran) return IRS_HIP_EINVAL;
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
@@ -1335,7 +1361,7 @@ int irs_hip_batch_device_results(irs_hip_batch* b, void** d_hits, void** d_count
   return IRS_HIP_OK;
 }
 
-int irs_hip_batch_results_to_device(irs_hip_batch* b, void* d_hits, void* d_counts,
+static int batch_results_to_device_impl(irs_hip_batch* b, void* d_hits, void* d_counts,
                                     void* stream) {
   if (!b || !b->ran || !d_hits || !d_counts) return IRS_HIP_EINVAL;
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
@@ -1358,7 +1384,7 @@ void irs_hip_batch_destroy(irs_hip_batch* b) {
   delete b;
 }
 
-int irs_hip_query_batch(irs_hip_segment* seg, const irs_hip_query* queries, uint32_t nq,
+static int query_batch_impl(irs_hip_segment* seg, const irs_hip_query* queries, uint32_t nq,
                         const irs_hip_term_scorer* terms, uint32_t n_entries,
                         irs_hip_hit* hits, uint32_t k_stride, uint32_t* counts,
                         uint64_t* total_hits) {
@@ -1371,7 +1397,7 @@ int irs_hip_query_batch(irs_hip_segment* seg, const irs_hip_query* queries, uint
   return rc;
 }
 
-int irs_hip_merge_topk(int32_t device, const void* const* d_lists, const void* const* d_counts,
+static int merge_topk_impl(int32_t device, const void* const* d_lists, const void* const* d_counts,
                        const uint32_t* seg_ids, uint32_t n_lists, uint32_t n_queries,
                        uint32_t k, void* d_out, void* d_out_seg, void* d_out_counts,
                        void* stream) {
@@ -1392,6 +1418,66 @@ int irs_hip_merge_topk(int32_t device, const void* const* d_lists, const void* c
             n_lists, k, static_cast<Hit*>(d_out), static_cast<uint32_t*>(d_out_seg),
             static_cast<uint32_t*>(d_out_counts));
   return rt::last_error_ok() ? IRS_HIP_OK : IRS_HIP_EHIP;
+}
+
+
+// ---- the exported entry points: nothing C++ leaves this library (status codes only) ----
+int irs_hip_device_arch(int32_t device, char* buf, size_t cap) {
+  return guarded([&] { return device_arch_impl(device, buf, cap); });
+}
+int irs_hip_segment_open(const irs_hip_segment_desc* d, irs_hip_segment** out) {
+  return guarded([&] { return segment_open_impl(d, out); });
+}
+int irs_hip_decode_term(irs_hip_segment* seg, uint32_t term, uint32_t* docs, uint32_t* freqs, uint32_t cap, uint32_t* count) {
+  return guarded([&] { return decode_term_impl(seg, term, docs, freqs, cap, count); });
+}
+int irs_hip_decode_positions(irs_hip_segment* seg, uint32_t term, uint32_t* positions, uint64_t cap, uint64_t* count) {
+  return guarded([&] { return decode_positions_impl(seg, term, positions, cap, count); });
+}
+int irs_hip_bit_union(irs_hip_segment* seg, const uint32_t* terms, uint32_t n_terms, uint64_t* set, uint64_t n_words, uint64_t* count) {
+  return guarded([&] { return bit_union_impl(seg, terms, n_terms, set, n_words, count); });
+}
+int irs_hip_term_directory(irs_hip_segment* seg, uint32_t term, uint32_t* last_docs, uint64_t* offsets, uint32_t cap, uint32_t* count) {
+  return guarded([&] { return term_directory_impl(seg, term, last_docs, offsets, cap, count); });
+}
+int irs_hip_batch_create(irs_hip_segment* seg, const irs_hip_query* queries, uint32_t nq, const irs_hip_term_scorer* terms, uint32_t n_entries, irs_hip_batch** out) {
+  return guarded([&] { return batch_create_impl(seg, queries, nq, terms, n_entries, out); });
+}
+int irs_hip_batch_create_multi(irs_hip_segment* const* segs, uint32_t n_segs, const irs_hip_query* queries, uint32_t nq_user, const irs_hip_term_scorer* all_terms, uint32_t n_entries, irs_hip_batch** out) {
+  return guarded([&] { return batch_create_multi_impl(segs, n_segs, queries, nq_user, all_terms, n_entries, out); });
+}
+int irs_hip_batch_configure(irs_hip_batch* b, uint32_t tile_docs, uint32_t pilot_stride, uint32_t cand_cap) {
+  return guarded([&] { return batch_configure_impl(b, tile_docs, pilot_stride, cand_cap); });
+}
+int irs_hip_batch_profile(irs_hip_batch* b, int enable) {
+  return guarded([&] { return batch_profile_impl(b, enable); });
+}
+int irs_hip_batch_run(irs_hip_batch* b, void* stream) {
+  return guarded([&] { return batch_run_impl(b, stream); });
+}
+int irs_hip_batch_timings(irs_hip_batch* b, float ms[IRS_HIP_K_COUNT]) {
+  return guarded([&] { return batch_timings_impl(b, ms); });
+}
+int irs_hip_batch_reruns(irs_hip_batch* b, uint32_t* count) {
+  return guarded([&] { return batch_reruns_impl(b, count); });
+}
+int irs_hip_batch_work(irs_hip_batch* b, uint64_t* algorithmic_bytes, uint64_t* postings) {
+  return guarded([&] { return batch_work_impl(b, algorithmic_bytes, postings); });
+}
+int irs_hip_batch_results(irs_hip_batch* b, irs_hip_hit* hits, uint32_t k_stride, uint32_t* counts, uint64_t* total_hits) {
+  return guarded([&] { return batch_results_impl(b, hits, k_stride, counts, total_hits); });
+}
+int irs_hip_batch_device_results(irs_hip_batch* b, void** d_hits, void** d_counts, uint32_t* k_max) {
+  return guarded([&] { return batch_device_results_impl(b, d_hits, d_counts, k_max); });
+}
+int irs_hip_batch_results_to_device(irs_hip_batch* b, void* d_hits, void* d_counts, void* stream) {
+  return guarded([&] { return batch_results_to_device_impl(b, d_hits, d_counts, stream); });
+}
+int irs_hip_query_batch(irs_hip_segment* seg, const irs_hip_query* queries, uint32_t nq, const irs_hip_term_scorer* terms, uint32_t n_entries, irs_hip_hit* hits, uint32_t k_stride, uint32_t* counts, uint64_t* total_hits) {
+  return guarded([&] { return query_batch_impl(seg, queries, nq, terms, n_entries, hits, k_stride, counts, total_hits); });
+}
+int irs_hip_merge_topk(int32_t device, const void* const* d_lists, const void* const* d_counts, const uint32_t* seg_ids, uint32_t n_lists, uint32_t n_queries, uint32_t k, void* d_out, void* d_out_seg, void* d_out_counts, void* stream) {
+  return guarded([&] { return merge_topk_impl(device, d_lists, d_counts, seg_ids, n_lists, n_queries, k, d_out, d_out_seg, d_out_counts, stream); });
 }
 
 }  // extern "C"

@@ -54,7 +54,7 @@ struct alignas(16) DirLine {
 template<int LAYOUT>
 __global__ void __launch_bounds__(kThreads)
 k_build_directory(DevSegment seg, DevTerm* terms, uint32_t* blk_off,
-                  uint32_t* blk_last, uint16_t* blk_bits, uint32_t* blk_units,
+                  uint32_t* blk_last, uint16_t* blk_bits, uint32_t* blk_units, BlkDir* blk_dir,
                   uint32_t* tail_docs, uint32_t* tail_freqs, uint32_t* status) {
   __shared__ __attribute__((aligned(16))) uint8_t s_win[kWaves][kDirWindow];
   const unsigned lane = threadIdx.x & 63u;
@@ -103,6 +103,9 @@ k_build_directory(DevSegment seg, DevTerm* terms, uint32_t* blk_off,
     uint32_t x0, x1;
     uint32_t size = read_block_pair<LAYOUT>(blk, dbits, lane, x0, x1);
     const uint32_t last = base + wave::reduce_add(x0 + x1);
+    // doc ids ascend and stay inside the segment (a doc block of valid data ends at least
+    // 127 docs behind the previous one)
+    if (last <= base || last > seg.num_docs) { bad = true; break; }
     uint32_t fbits = 0;
     if (seg.has_freq) {
       if (cur + size + 2 > seg.doc_len) { bad = true; break; }
@@ -125,6 +128,12 @@ k_build_directory(DevSegment seg, DevTerm* terms, uint32_t* blk_off,
       blk_last[t.dir_off + b] = last;
       blk_bits[t.dir_off + b] = uint16_t(dbits | (fbits << 8));
       blk_units[t.dir_off + b] = pk_units(dbits, fbits);
+      BlkDir d;
+      d.off = uint32_t(cur - t.doc_start);
+      d.prev_last = base;
+      d.aoff = 0;   // k_dir_aoff fills it in once the image offsets are known
+      d.bits = dbits | (fbits << 8);
+      blk_dir[t.dir_off + b] = d;
     }
     cur += size;
     base = last;
@@ -245,6 +254,13 @@ k_scan_apply(uint32_t* v, uint64_t n, const uint64_t* totals) {
     if (at + e < n) v[at + e] = uint32_t(off);   // the host checked the grand total fits
     off += x[e];
   }
+}
+
+// BlkDir::aoff <- blk_aoff (after the exclusive scan turned block sizes into offsets)
+__global__ void __launch_bounds__(kThreads)
+k_dir_aoff(const uint32_t* blk_aoff, uint64_t n, BlkDir* blk_dir) {
+  const uint64_t i = uint64_t(blockIdx.x) * kThreads + threadIdx.x;
+  if (i < n) blk_dir[i].aoff = blk_aoff[i];
 }
 
 // Copies the payloads of the decodable blocks into the packed-payload image.

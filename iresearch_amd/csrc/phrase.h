@@ -119,6 +119,21 @@ k_freq_sums(DevSegment seg, uint32_t slices, uint32_t* sums) {
   }
 }
 
+// term_meta::freq (what sizes the position buffers and the pos block directory) must be
+// what the `.doc` stream really holds: the frequencies of the term's full blocks (blk_pos
+// differences) plus those of its decoded tail.  One thread per term.
+__global__ void __launch_bounds__(kThreads)
+k_check_freq_totals(DevSegment seg, const DevPosTerm* pterms, uint32_t* status) {
+  const uint32_t term = blockIdx.x * kThreads + threadIdx.x;
+  if (term >= seg.num_terms) return;
+  const DevTerm t = seg.terms[term];
+  if (t.docs_count == 0) return;
+  uint32_t sum = seg.blk_pos[t.dir_off + t.nblk] - seg.blk_pos[t.dir_off];
+  const uint32_t n = t.docs_count == 1 ? 1u : t.tail_n;
+  for (uint32_t i = 0; i < n; ++i) sum += seg.tail_freqs[t.tail_row + i];
+  if (sum != pterms[term].total) atomicOr(status, kStatusCorrupt);
+}
+
 // One wavefront per term walks the term's pos blocks (header byte -> size,
 // bitpack::skip_block32) and decodes the vint tail (read_tail_block :1515-1537).  The walk
 // is a chain of dependent one-byte reads, so the stream is staged through LDS 8 KB at a

@@ -40,6 +40,7 @@ enum : uint32_t {
   kItemSqrt = 1u << 10,     // square-root score form (TF-IDF family), else reciprocal form
   kItemPair = 1u << 11,     // even item of a wavefront: it and the next one run as a fused pair
   kItemSolo = 1u << 12,     // even item of a wavefront: there is no next one
+  kItemTable = 1u << 13,    // score = cs * T[tf][norm]: every tf of the block has a table row
   kItemFreqShift = 16,      // aux bits 16..31: added to every extracted frequency — the value
                             // of an ALL-EQUAL freq block (fbits == 0 extracts zeros), else 0
 };
@@ -87,6 +88,18 @@ struct alignas(8) ItemCalc {    // bytes 8..31 of an ItemG: all the decode + sco
 //     TF-IDF              tab[n] = 1                               (tfidf.cpp:185-187)
 //     TF-IDF with norms   tab[n] = 1/sqrt(n), [0] = 0              (tfidf.cpp:251-253)
 // Rows that ignore the norm are constant, so whatever byte the norm stage reads is fine.
+//
+// Most blocks only hold small frequencies (the bit width of the freq part says so), and for
+// those the whole per-posting expression is tabulated as well: a table slot is R rows
+//   row 0        tab[n]                      (above; general frequencies: one v_rcp / v_sqrt)
+//   row r >= 1   T_r[n] = 1 - 1/(1 + r*tab[n])   resp.   sqrt(r) * tab[n]
+// so that a posting with tf < R costs one table read and one multiply-add: score = c0 * T_tf[norm].
+// R = kTableRows / (slots rounded up to a power of two): 16 rows with one slot (the usual
+// case: one (norm_const, norm_length) per query), 8 with two, 4 with three or four.
+constexpr uint32_t kTableRows = 16;   // 256-entry rows of floats in LDS: 16 KB
+__host__ __device__ __forceinline__ uint32_t table_rows(uint32_t n_caches) {
+  return n_caches <= 1u ? 16u : (n_caches <= 2u ? 8u : 4u);
+}
 __host__ __device__ __forceinline__ bool table_kind(int32_t kind) {
   return kind == kBM25Tiny || kind == kBM25One || kind == kBM15 || kind == kTfidf ||
          kind == kTfidfTiny;
@@ -111,9 +124,10 @@ struct TileSmemT {
                      // + one private dummy slot per lane
   uint32_t* cnt;     // [(TILE + 64)/4] per-doc match counters, 1 byte each (AND only; + dummies)
   uint8_t* lnorm;    // [TILE] Norm2 bytes of the tile
-  float* caches;     // [kMaxCaches][256] table rows (BM25Stats::norm_cache and friends)
+  float* caches;     // [kTableRows][256] table rows (BM25Stats::norm_cache and friends)
   DevQTerm* qts;     // [kMaxTerms] the query's term scorers (generic path)
-  uint32_t* slow;    // [4] what else the generic path needs: fx_mul (float bits), num_docs
+  uint32_t* slow;    // [4] what else the generic path needs: fx_mul (float bits), num_docs,
+                     // rows per table slot
 };
 
 // Byte offsets of the tile arrays inside the workgroup's LDS block (== carve() below);
@@ -124,7 +138,7 @@ struct TileOff {
   static constexpr uint32_t cnt = uint32_t(sizeof(ACC)) * (TILE + 64);
   static constexpr uint32_t lnorm = cnt + (AND ? TILE + 64 : 0);
   static constexpr uint32_t caches = lnorm + TILE;
-  static constexpr uint32_t qts = caches + 4u * 256u * kMaxCaches;
+  static constexpr uint32_t qts = caches + 4u * 256u * kTableRows;
   static constexpr uint32_t slow = qts + uint32_t(sizeof(DevQTerm)) * kMaxTerms;
   static constexpr uint32_t end = slow + 16u;
 };
@@ -143,15 +157,19 @@ __device__ __forceinline__ TileSmemT<ACC> carve(unsigned char* smem, unsigned ch
   return sm;
 }
 
-// One thread per table entry: the row of slot c comes from the first term using it.
+// One thread per table entry: the rows of slot c come from the first term using it.
 template<typename SM>
 __device__ __forceinline__ void build_tables(const SM& sm, uint32_t n_caches, uint32_t n_terms) {
-  for (uint32_t e = threadIdx.x; e < n_caches * 256u; e += blockDim.x) {
-    const uint32_t c = e >> 8, n = e & 255u;
+  const uint32_t rows = table_rows(n_caches);
+  for (uint32_t e = threadIdx.x; e < n_caches * rows * 256u; e += blockDim.x) {
+    const uint32_t c = (e >> 8) / rows, r = (e >> 8) % rows, n = e & 255u;
     float v = 0.f;
     for (uint32_t j = 0; j < n_terms; ++j) {
       if (sm.qts[j].cache_id == c) {
-        v = table_value(sm.qts[j].kind, sm.qts[j].norm_const, sm.qts[j].norm_length, n);
+        const float t = table_value(sm.qts[j].kind, sm.qts[j].norm_const, sm.qts[j].norm_length, n);
+        if (r == 0) v = t;
+        else if (sqrt_kind(sm.qts[j].kind)) v = sqrtf(static_cast<float>(r)) * t;
+        else v = 1.f - 1.f / (1.f + static_cast<float>(r) * t);
         break;
       }
     }
@@ -197,7 +215,7 @@ __device__ __forceinline__ float score_posting(const DevSegment& seg, const DevQ
       const uint32_t n = sm.lnorm[idx];
       float inv;
       if (qt.cache_id < kMaxCaches) {
-        inv = sm.caches[qt.cache_id * 256u + n];
+        inv = sm.caches[qt.cache_id * sm.slow[2] * 256u + n];
       } else {
         inv = n ? 1.f / (qt.norm_const + qt.norm_length * static_cast<float>(n)) : 0.f;
       }
@@ -304,6 +322,56 @@ __device__ __forceinline__ void tile_post(const TileSmemT<ACC>& sm, const float 
 // `bits` bits that starts `skip16` 16-byte units behind `addr` (0: the doc part; dbits: the
 // freq part right behind it).  saddr global loads: `addr` is wave-uniform.  No branch on the
 // bit width; reads at most 24 bytes past the part.
+// The same for postings whose frequencies all have a table row (kItemTable): score =
+// cs * T_tf[norm] — `tab[k]` is the offset of row 0 of the term's slot (all-equal freq
+// blocks: of the row of their one frequency, and the extracted freq is 0).  The `+ 1.0` of
+// the multiply-add keeps every contribution non-zero ("accumulator != 0" == "matched")
+// without a separate OR; it costs at most the one unit per posting the truncation may lose
+// anyway.
+template<typename ACC, int TILE, bool AND, int N>
+__device__ __forceinline__ void tile_post_table(const TileSmemT<ACC>& sm, const float (&cs)[N],
+                                                const uint32_t (&tab)[N],
+                                                const uint32_t (&raw)[N],
+                                                const uint32_t (&freq)[N], unsigned lane) {
+  using Off = TileOff<ACC, TILE, AND>;
+  const unsigned char* base = reinterpret_cast<const unsigned char*>(sm.acc);  // LDS offset 0
+  uint32_t idx[N], nb[N];
+  float t[N];
+  ACC fx[N];
+  const uint32_t dummy = uint32_t(TILE) + lane;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    idx[k] = raw[k] < dummy ? raw[k] : dummy;
+    nb[k] = wave::lds_u8(base, Off::lnorm + idx[k]);
+  }
+  // row of each posting's frequency: computed while the norm bytes are on their way
+  uint32_t row[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) row[k] = (freq[k] << 10) + tab[k];   // v_lshl_add_u32
+  wave::keep_all(row);
+  wave::keep_all(nb);
+#pragma unroll
+  for (int k = 0; k < N; ++k) t[k] = wave::lds_f32(base, (nb[k] << 2) + row[k]);   // v_lshl_add_u32
+  wave::keep_all_f(t);
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    if (sizeof(ACC) == 4) {
+      float scaled = wave::fma(cs[k], t[k], 1.f);
+      wave::keep_f(scaled);
+      fx[k] = static_cast<ACC>(static_cast<uint32_t>(scaled));
+    } else {
+      float scaled = cs[k] * t[k];
+      wave::keep_f(scaled);
+      fx[k] = fixed_from_scaled<ACC>(scaled);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    wave::lds_add(base, Off::acc + idx[k] * uint32_t(sizeof(ACC)), fx[k]);
+    if (AND) wave::lds_add(base, Off::cnt + (idx[k] & ~3u), 1u << (8u * (idx[k] & 3u)));
+  }
+}
+
 // `m` receives the bit offset of the lane's first value in its stream (simd4: lane stream
 // l = 2*(lane & 1), value row lane >> 1; scalar: value 2*lane): the extraction shifts by its
 // low 5 bits, so it rides along with the payload words instead of being multiplied again.
@@ -459,8 +527,13 @@ __device__ __forceinline__ void fast_item(const TileSmemT<ACC>& sm, const ItemCa
   const float css[2] = {I.cs, I.cs};
   const uint32_t tabs2[2] = {I.tab, I.tab};
   const uint32_t raw2[2] = {d1 - x1, d1};
-  const uint32_t freqs2[2] = {f0 + fadd, f1 + fadd};
-  tile_post<ACC, TILE, AND, 2>(sm, css, tabs2, raw2, freqs2, lane, (I.aux & kItemSqrt) != 0u);
+  if (I.aux & kItemTable) {
+    const uint32_t freqs2[2] = {f0, f1};
+    tile_post_table<ACC, TILE, AND, 2>(sm, css, tabs2, raw2, freqs2, lane);
+  } else {
+    const uint32_t freqs2[2] = {f0 + fadd, f1 + fadd};
+    tile_post<ACC, TILE, AND, 2>(sm, css, tabs2, raw2, freqs2, lane, (I.aux & kItemSqrt) != 0u);
+  }
 }
 
 // hot path, two items fused: 4 postings per lane in flight, two independent DPP scan
@@ -481,8 +554,13 @@ __device__ __forceinline__ void fast_pair(const TileSmemT<ACC>& sm, const ItemPa
   const float css[4] = {c.a.cs, c.a.cs, c.b.cs, c.b.cs};
   const uint32_t tabs4[4] = {c.a.tab, c.a.tab, c.b.tab, c.b.tab};
   const uint32_t raw4[4] = {ad1 - ax1, ad1, bd1 - bx1, bd1};
-  const uint32_t freqs4[4] = {af0 + fa_add, af1 + fa_add, bf0 + fb_add, bf1 + fb_add};
-  tile_post<ACC, TILE, AND, 4>(sm, css, tabs4, raw4, freqs4, lane, (c.a.aux & kItemSqrt) != 0u);
+  if (c.a.aux & kItemTable) {   // (a fused pair is two table items or two general ones)
+    const uint32_t freqs4[4] = {af0, af1, bf0, bf1};
+    tile_post_table<ACC, TILE, AND, 4>(sm, css, tabs4, raw4, freqs4, lane);
+  } else {
+    const uint32_t freqs4[4] = {af0 + fa_add, af1 + fa_add, bf0 + fb_add, bf1 + fb_add};
+    tile_post<ACC, TILE, AND, 4>(sm, css, tabs4, raw4, freqs4, lane, (c.a.aux & kItemSqrt) != 0u);
+  }
 }
 
 // One pair of the hot loop.  Generic items are only noted (`slow` collects their flags) and
@@ -624,52 +702,58 @@ k_items_fill(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qt
   const uint32_t a = n >> nw_log2, r = n & (nw - 1u);
   const uint64_t pk = reinterpret_cast<uint64_t>(seg.pk);
 
-  // term slot and directory row of block item g; whether it takes the straight-line path
-  auto locate = [&](uint32_t g, uint32_t& j, uint64_t& e, uint32_t& b) {
+  // term slot and directory row of block item g
+  auto locate = [&](uint32_t g, uint32_t& j, uint64_t& e) {
     j = 0;
     for (uint32_t t = 1; t < qd.n_terms; ++t) j += s_pre[wv][t] <= g ? 1u : 0u;
-    b = s_b0[wv][j] + (g - s_pre[wv][j]);
-    e = tl[j].dir_off + b;
+    e = tl[j].dir_off + s_b0[wv][j] + (g - s_pre[wv][j]);
   };
   // the value of an ALL-EQUAL freq block: vint behind the doc part and the 0 header byte
-  auto freq_const = [&](uint32_t j, uint64_t e, uint32_t dbits) {
+  auto freq_const = [&](uint32_t j, const BlkDir& d) {
     uint32_t len;
-    return vint_from(wave::load_u64(seg.doc + tl[j].doc_start + seg.blk_off[e] + 2u + 16u * dbits),
+    return vint_from(wave::load_u64(seg.doc + tl[j].doc_start + d.off + 2u + 16u * (d.bits & 0xFFu)),
                      &len);
   };
   // straight-line path: a scorer of the table family, the block in the packed image, and an
-  // all-equal frequency that fits the record's 16 bits
-  auto fast_of = [&](uint32_t j, uint64_t e, uint32_t bits16, uint32_t& fadd) {
-    fadd = 0;
-    if (!(table_kind(qts[j].kind) && qts[j].cache_id < kMaxCaches &&
-          pk_units(bits16 & 0xFFu, bits16 >> 8) != 0u))
-      return false;
-    if ((bits16 >> 8) == 0u) {
-      fadd = freq_const(j, e, bits16 & 0xFFu);
-      if (fadd > 0xFFFFu) return false;
+  // all-equal frequency that fits the record's 16 bits.  cls: 0 = generic, 1 = straight-line
+  // with general frequencies, 2 = every frequency of the block has a table row; bit 2: the
+  // square-root form (only tells general items apart)
+  const uint32_t rows = table_rows(qd.n_caches);
+  auto classify = [&](uint32_t j, const BlkDir& d, uint32_t& fconst) {
+    fconst = 0;
+    const uint32_t dbits = d.bits & 0xFFu, fbits = d.bits >> 8;
+    if (!(table_kind(qts[j].kind) && qts[j].cache_id < kMaxCaches && pk_units(dbits, fbits) != 0u))
+      return 0u;
+    if (fbits == 0u) {
+      fconst = freq_const(j, d);
+      if (fconst > 0xFFFFu) return 0u;
+      return fconst < rows ? 2u : (sqrt_kind(qts[j].kind) ? 5u : 1u);
     }
-    return true;
+    return (1u << fbits) <= rows ? 2u : (sqrt_kind(qts[j].kind) ? 5u : 1u);
   };
-  for (uint32_t g = lane; g < n; g += 64) {
-    ItemG I;
-    bool fast = false, sq = false;
+  for (uint32_t g0 = 0; g0 < n; g0 += 64) {   // (whole wavefront: shuffles inside)
+    const uint32_t g = g0 + lane;
+    ItemG I{};
+    uint32_t cls = 0;
     if (g < n_blocks) {
-      uint32_t j, b;
+      uint32_t j, fconst;
       uint64_t e;
-      locate(g, j, e, b);
-      const uint32_t bits16 = seg.blk_bits[e];
-      uint32_t fadd;
-      fast = fast_of(j, e, bits16, fadd);
-      sq = sqrt_kind(qts[j].kind);
-      I.addr = fast ? pk + (uint64_t(seg.blk_aoff[e]) << 4)
-                    : reinterpret_cast<uint64_t>(seg.doc) + tl[j].doc_start + seg.blk_off[e];
-      I.dbits = bits16 & 0xFFu;
-      I.fbits = bits16 >> 8;
-      I.base = (b ? seg.blk_last[e - 1] : kDocMin) - lo;
+      locate(g, j, e);
+      const BlkDir d = seg.blk_dir[e];
+      cls = classify(j, d, fconst);
+      const bool fast = cls != 0u;
+      const uint32_t slot = qts[j].cache_id < kMaxCaches ? qts[j].cache_id : 0u;
+      I.addr = fast ? pk + (uint64_t(d.aoff) << 4)
+                    : reinterpret_cast<uint64_t>(seg.doc) + tl[j].doc_start + d.off;
+      I.dbits = d.bits & 0xFFu;
+      I.fbits = d.bits >> 8;
+      I.base = d.prev_last - lo;
       I.cs = qts[j].c0 * qd.fx_mul;
-      I.tab = caches_off + (qts[j].cache_id < kMaxCaches ? qts[j].cache_id : 0u) * 1024u;
-      I.aux = j | (fast ? 0u : kItemSlow) | (sq ? kItemSqrt : 0u) | (fadd << kItemFreqShift);
-    } else {
+      // table items: an all-equal frequency selects its row right here
+      I.tab = caches_off + (slot * rows + (cls == 2u ? fconst : 0u)) * 1024u;
+      I.aux = j | (fast ? 0u : kItemSlow) | (sqrt_kind(qts[j].kind) ? kItemSqrt : 0u) |
+              (cls == 2u ? kItemTable : fconst << kItemFreqShift);
+    } else if (g < n) {
       // the (g - n_blocks)-th term whose tail reaches into the tile
       uint64_t m = tail_mask;
       for (uint32_t s = g - n_blocks; s; --s) m &= m - 1;
@@ -682,21 +766,27 @@ k_items_fill(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qt
       I.tab = tl[j].tail_row;
       I.aux = j | kItemSlow | kItemTail;
     }
-    const uint32_t w = g & (nw - 1u), i = g >> nw_log2;
-    const uint32_t n_w = a + (w < r ? 1u : 0u);
-    if (!(i & 1u)) {
-      if (i + 1u == n_w) {
-        I.aux |= kItemSolo;
-      } else if (fast && g + nw < n_blocks) {   // the wavefront's next item: g + nw
-        uint32_t j2, b2;
+    // class of the wavefront's next item, g + nw: computed by lane + nw, or — for the last
+    // nw lanes — looked up directly
+    uint32_t next_cls = __shfl_down(cls, nw, 64);
+    if (lane + nw >= 64u) {
+      next_cls = 0;
+      if (g + nw < n_blocks) {
+        uint32_t j2, fconst2;
         uint64_t e2;
-        locate(g + nw, j2, e2, b2);
-        uint32_t fadd2;
-        if (fast_of(j2, e2, seg.blk_bits[e2], fadd2) && sqrt_kind(qts[j2].kind) == sq)
-          I.aux |= kItemPair;
+        locate(g + nw, j2, e2);
+        next_cls = classify(j2, seg.blk_dir[e2], fconst2);
       }
     }
-    items[off0 + w * a + (w < r ? w : r) + i] = I;
+    if (g < n) {
+      const uint32_t w = g & (nw - 1u), i = g >> nw_log2;
+      const uint32_t n_w = a + (w < r ? 1u : 0u);
+      if (!(i & 1u)) {
+        if (i + 1u == n_w) I.aux |= kItemSolo;
+        else if (cls && g + nw < n_blocks && next_cls == cls) I.aux |= kItemPair;
+      }
+      items[off0 + w * a + (w < r ? w : r) + i] = I;
+    }
   }
   if (ut + 1u == total_tiles && lane < kItemSlack) {   // readable slack behind the last list
     ItemG I;
@@ -803,6 +893,7 @@ k_pilot(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms,
   if (tid == 0) {
     sm.slow[0] = __float_as_uint(qd.fx_mul);
     sm.slow[1] = seg.num_docs;
+    sm.slow[2] = table_rows(qd.n_caches);
   }
   __syncthreads();
   build_tables(sm, qd.n_caches, qd.n_terms);
@@ -988,6 +1079,7 @@ k_score(uint64_t args /*address of a ScoreArgs*/) {
     if (tid == 0) {
       sm.slow[0] = __float_as_uint(qd.fx_mul);
       sm.slow[1] = seg.num_docs;
+      sm.slow[2] = table_rows(qd.n_caches);
     }
     NormStage<TILE> nrm;
     nrm.load(norms1, norm_count, tile0);

@@ -59,6 +59,16 @@ struct DevPosTerm {
   uint32_t pad;
 };
 
+// One entry of the block directory as the work-item builder reads it: everything about a
+// block in ONE 16-byte load (the separate arrays below stay for the binary searches and the
+// position kernels).
+struct alignas(16) BlkDir {
+  uint32_t off;        // byte offset of the block relative to the term's doc_start
+  uint32_t prev_last;  // last doc of the preceding block of the term (kDocMin for its first)
+  uint32_t aoff;       // offset of the block in the packed-payload image, 16-byte units
+  uint32_t bits;       // doc bits | freq bits << 8
+};
+
 struct DevSegment {
   const uint8_t* doc;        // staged `.doc` bytes (+ kPadBytes zeros)
   uint64_t doc_len;
@@ -79,6 +89,7 @@ struct DevSegment {
   // headers leave all of them misaligned.  The hot decoder reads this copy.
   const uint8_t* pk;
   const uint32_t* blk_aoff;  // offset of the block in `pk`, in 16-byte units
+  const BlkDir* blk_dir;     // the same facts per block, gathered
   // decoded vint tails / single docs, term after term (DevTerm::tail_row): absolute doc ids
   // and frequencies — at most 127 entries per term, 1 for a single-doc term
   const uint32_t* tail_docs;

@@ -57,10 +57,34 @@ def build(force: bool = False):
     return lib
 
 
-def lib():
+def build_native():
+    """The same sources built the way SURVEY.md §8d states the CPU baseline: -O3
+    -march=native (bench.py's `cpu_baseline` leg only; compiled where it runs, since
+    "native" of the build container need not exist on the GPU box).  None if that fails."""
+    lib = HERE / "liboracle_native.so"
+    try:
+        subprocess.run(["make", "-C", str(HERE), "-B", "liboracle_native.so"], check=True,
+                       capture_output=True)
+    except (OSError, subprocess.CalledProcessError):
+        return None
+    return lib if lib.exists() else None
+
+
+def use_native() -> bool:
+    """Switches every call of this module to the -O3 -march=native build (bench only)."""
+    global _lib
+    so = build_native()
+    if so is None:
+        return False
+    _lib = None
+    lib(so)
+    return True
+
+
+def lib(path=None):
     global _lib
     if _lib is None:
-        L = C.CDLL(str(build()))
+        L = C.CDLL(str(path or build()))
         vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
         for n in ("orc_pack_scalar", "orc_unpack_scalar", "orc_pack_simd4", "orc_unpack_simd4"):
             getattr(L, n).argtypes = [vp, u32, vp]

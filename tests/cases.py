@@ -99,6 +99,73 @@ def case_decode_edge_blocks(L, layout):
     sr.close()
 
 
+def _doc_file(version, body: bytes) -> np.ndarray:
+    """Header + postings + footer of a `.doc` file (format_utils.cpp:57-67; big-endian ints)."""
+    name = b"iresearch_10_postings_documents"
+    hdr = (0x3fd76c17).to_bytes(4, "big") + bytes([len(name)]) + name + version.to_bytes(4, "big")
+    ftr = ((-0x3fd76c17) & 0xFFFFFFFF).to_bytes(4, "big") + (0).to_bytes(4, "big") + (0).to_bytes(8, "big")
+    return np.frombuffer(hdr + body + ftr, np.uint8).copy(), len(hdr)
+
+
+def case_decode_reference_packed(L, layout):
+    """`.doc` blocks assembled BY HAND from words the reference's own compiled packers
+    produced (tests/golden/codec_golden.npz: packed::pack_block / simdpackwithoutmask on the
+    literal vector of tests/utils/bit_packing_tests.cpp:102-114 and on random data, bits
+    1..32) and decoded through the C ABI: no emitter and no oracle in the loop — the
+    expectation is the packers' INPUT."""
+    from iresearch_amd._lib import TERM_META
+    g = np.load(GOLDEN / "codec_golden.npz")
+    lay = "simd4" if layout == synth.LAYOUT_SIMD4 else "scalar"
+
+    def values(kind, bits):
+        if kind == "lit":
+            mask = np.uint32(0xFFFFFFFF if bits == 32 else (1 << bits) - 1)
+            return g["literal"] & mask
+        return g["random_b%d" % bits]
+
+    def block(kind, bits):
+        return bytes([bits]) + g["%s_%s_b%d" % (lay, kind, bits)].astype("<u4").tobytes()
+
+    body = b""
+    terms = []   # (doc_start relative to the body, [(doc kind, dbits, freq kind, fbits), ...])
+    for kind in ("lit", "rnd"):
+        for b in range(1, 33):
+            # every width as a freq block; doc deltas up to 23 bits (128 of them stay < 2^31)
+            terms.append((len(body), [(kind, min(b, 23), kind, b)]))
+            body += block(kind, min(b, 23)) + block(kind, b)
+    # a list of 8 blocks: the base carries over from block to block
+    blocks = [("rnd" if i & 1 else "lit", 9 + i, "lit" if i & 1 else "rnd", 1 + 4 * i) for i in range(8)]
+    terms.append((len(body), blocks))
+    for dk, db, fk, fb in blocks:
+        body += block(dk, db) + block(fk, fb)
+    doc_file, hdr = _doc_file(5 if layout == synth.LAYOUT_SIMD4 else 4, body)
+    metas = np.zeros(len(terms), TERM_META)
+    want = []
+    for t, (off, blks) in enumerate(terms):
+        docs, freqs, base = [], [], 1   # doc_limits::min(), formats_10.cpp:636
+        for dk, db, fk, fb in blks:
+            d = base + np.cumsum(values(dk, db).astype(np.uint64))
+            base = int(d[-1])
+            docs.append(d)
+            freqs.append(values(fk, fb))
+        docs = np.concatenate(docs)
+        assert docs[-1] < 2**31
+        want.append((docs.astype(np.uint32), np.concatenate(freqs)))
+        metas[t]["docs_count"] = docs.size
+        metas[t]["freq"] = min(int(np.concatenate(freqs).astype(np.uint64).sum()), 0xFFFFFFFF)
+        metas[t]["doc_start"] = hdr + off
+        metas[t]["e_skip_start"] = 0   # the block directory never reads the skip data
+    num_docs = max(int(w[0][-1]) for w in want)
+    sr = search.SegmentReader(doc_file, metas, num_docs, layout, L=L)
+    for t, (d, f) in enumerate(want):
+        got_d, got_f = sr.decode_term(t)
+        assert np.array_equal(got_d, d), ("docs", t)
+        assert np.array_equal(got_f, f), ("freqs", t)
+        last, offs = sr.term_directory(t)
+        assert np.array_equal(last, d[127::128]), ("directory", t)
+    sr.close()
+
+
 def case_decode_synth(L, layout, num_docs, max_rank, step=1):
     seg = synth.build_segment(num_docs, max_rank, layout=layout, keep_postings=True)
     sr = search.SegmentReader.from_synth(seg, L=L)
@@ -991,6 +1058,14 @@ def case_phrase_errors(L):
     with pytest.raises(_lib.IrsHipError) as e:
         open_with(metas=metas)
     assert e.value.status == _lib.ECORRUPT
+    # term_meta::freq disagrees with the frequencies in `.doc` (by a whole pos block, so that
+    # only the totals check can tell): the position kernels would run past their buffers
+    for t in (0, len(seg.metas) - 1):
+        metas = seg.metas.copy()
+        metas[t]["freq"] += 128
+        with pytest.raises(_lib.IrsHipError) as e:
+            open_with(metas=metas)
+        assert e.value.status == _lib.ECORRUPT, t
     with pytest.raises(_lib.IrsHipError) as e:       # positions without frequencies
         open_with(has_freq=False)
     assert e.value.status == _lib.EINVAL
@@ -1025,6 +1100,9 @@ def case_errors(L):
     with pytest.raises(_lib.IrsHipError) as e:
         open_with(doc_file=bad)
     assert e.value.status == _lib.ECORRUPT
+    with pytest.raises(_lib.IrsHipError) as e:       # doc ids run past the segment
+        open_with(num_docs=seg.num_docs // 2)
+    assert e.value.status in (_lib.ECORRUPT, _lib.EUNSUPPORTED)
     metas = seg.metas.copy()
     metas[3]["doc_start"] = seg.doc_file.size + 5
     with pytest.raises(_lib.IrsHipError) as e:

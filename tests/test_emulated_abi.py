@@ -15,6 +15,11 @@ def test_decode_reference_lists(simlib, layout):
 
 
 @pytest.mark.parametrize("layout", LAYOUTS)
+def test_decode_reference_packed(simlib, layout):
+    cases.case_decode_reference_packed(simlib, layout)
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
 def test_decode_sizes(simlib, layout):
     cases.case_decode_sizes(simlib, layout)
 

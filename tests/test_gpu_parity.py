@@ -19,6 +19,11 @@ def test_decode_reference_lists(gpulib, layout):
 
 
 @pytest.mark.parametrize("layout", LAYOUTS)
+def test_decode_reference_packed(gpulib, layout):
+    cases.case_decode_reference_packed(gpulib, layout)
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
 def test_decode_sizes(gpulib, layout):
     cases.case_decode_sizes(gpulib, layout, sizes=(1, 2, 117, 127, 128, 129, 255, 256, 319, 1024,
                                                    10_000, 32_768))

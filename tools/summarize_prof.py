@@ -13,6 +13,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
 def main():
@@ -47,6 +48,7 @@ def main():
                 # coalesced streams; our loads are 8 B/lane (uncalibrated width) so both bounds are given
                 "fetch_bytes_x2_correction": 2 * fetch_kb * 1024,
                 "bytes": 2 * fetch_kb * 1024 + write_kb * 1024,
+                "kernel_sources_sha": __import__("bench").kernel_sources_sha(),
                 "unit": "bytes per launch",
             }
             json.dump(t, open(os.path.join(out, "traffic_latest.json"), "w"), indent=1)
