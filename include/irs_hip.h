@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define IRS_HIP_ABI_VERSION 2
+#define IRS_HIP_ABI_VERSION 3
 #define IRS_HIP_BLOCK_SIZE 128u  /* postings per block, formats_10.cpp:90 */
 #define IRS_HIP_MAX_TERMS 16u    /* terms per boolean query               */
 #define IRS_HIP_MAX_K 4096u      /* largest top-k                         */
@@ -142,7 +142,8 @@ int irs_hip_term_directory(irs_hip_segment* seg, uint32_t term,
 
 typedef enum irs_hip_op {
   IRS_HIP_OP_OR = 0, /* irs::Or / by_term: disjunction.hpp MakeDisjunction :1411-1467 */
-  IRS_HIP_OP_AND = 1, /* irs::And: conjunction.hpp MakeConjunction :436-490           */
+  IRS_HIP_OP_AND = 1, /* irs::And: conjunction.hpp MakeConjunction :436-490 — executed block
+                         by block of the rarest term (Conjunction::converge :207-223)    */
   IRS_HIP_OP_MINMATCH = 2, /* irs::Or with min_match_count: MinMatchQuery::execute
                              (boolean_query.cpp:212-247) -> min_match_iterator =
                              block_disjunction<kMinMatch> (disjunction.hpp:1378-1383)   */
@@ -259,6 +260,24 @@ int irs_hip_query_batch(irs_hip_segment* seg, const irs_hip_query* queries,
  * depend on any of them. */
 int irs_hip_batch_configure(irs_hip_batch* batch, uint32_t tile_docs,
                             uint32_t pilot_stride, uint32_t cand_cap);
+
+/* ExecutionContext::wand (filter.hpp:52-78; utils/index-search --search-mode wand): lets the
+ * batch SKIP posting blocks that cannot reach the top k.  The bound of a block is the query
+ * term's own score function on the block's (max freq, min norm) — what the wanderator
+ * evaluates per skip entry (formats_10.cpp:2498-2528, wand_writer.hpp:302-342) — summed over
+ * the terms of a conjunction for the blocks overlapping one doc range (BlockConjunction,
+ * conjunction.hpp:380-426); the threshold is the pilot pass's lower bound of the k-th score.
+ * The top k (docs, scores, order) is the one the exhaustive run returns
+ * (tests/search/wand_test.cpp:231-241); total_hits only counts the docs that were evaluated,
+ * as with the reference's wand mode.  The per-block (max freq, min norm) are derived from the
+ * postings on first use (every block gets them, also the last one of a list, for which the
+ * skip data has no entry) and kept with the segment.  Applies to IRS_HIP_OP_AND queries and
+ * to whole doc tiles of OR queries.  Call before the batch's first run. */
+int irs_hip_batch_set_wand(irs_hip_batch* batch, int enable);
+/* The block-max data of one term, for inspection/tests (computed as for set_wand): largest
+ * frequency and smallest non-zero norm of every full 128-doc block. */
+int irs_hip_term_blockmax(irs_hip_segment* seg, uint32_t term, uint32_t* max_freqs,
+                          uint32_t* min_norms, uint32_t cap, uint32_t* count);
 
 /* Kernel timing with HIP events recorded on the batch's own stream.
  * When enabled, every run() brackets each kernel launch with events;

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -14,6 +15,7 @@
 #include "kernels.h"
 #include "phrase.h"
 #include "score.h"
+#include "conj.h"
 
 using namespace irs_hip;
 
@@ -93,6 +95,10 @@ struct irs_hip_segment {
   uint64_t total_blocks = 0;
   uint64_t device_bytes = 0;
   uint32_t cus = 1;  // compute units of the device (persistent grid sizing)
+  // block-max data (WAND), built on first use: the one thing that changes after open
+  std::mutex wand_mutex;
+  bool wand_ready = false;
+  DevBuf d_blk_maxf, d_blk_minn;
 };
 
 struct irs_hip_batch {
@@ -107,7 +113,13 @@ struct irs_hip_batch {
   uint32_t max_tiles = 0;   // ... with the most (chunk ids per unit)
   uint32_t stride_eff = 1;  // pilot stride actually used (>= 2 pilot tiles per segment when possible)
   uint32_t wg_threads = kDefaultWgThreads;  // threads per pilot/score workgroup
-  bool any_and = false;
+  bool any_and = false;    // some unit counts matches per doc in the tile kernels (min-match)
+  bool wand = false;       // irs_hip_batch_set_wand
+  // units by the kernels that execute them: doc tiles (Or, min-match) / lead blocks (And)
+  std::vector<uint32_t> tile_units, conj_units;
+  std::vector<uint32_t> conj_items;   // lead items of every conj unit
+  uint32_t n_conj_wgs = 0;
+  DevBuf d_tile_units, d_conj_units, d_conj_items, d_conj_wgs, d_conj_hist;
   bool phrase = false;  // a batch of by_phrase queries (k_phrase instead of k_pilot + k_score)
   void* h_pin = nullptr;       // page-locked staging for irs_hip_batch_results
   size_t h_pin_bytes = 0;
@@ -121,7 +133,7 @@ struct irs_hip_batch {
     d_out, d_out_count, d_status, d_work;
   // work-item lists of the doc tiles (score.h): per-tile item offsets (+ scan scratch) and
   // the 32-byte records themselves
-  DevBuf d_tile_off, d_scan_parts, d_items, d_score_args;
+  DevBuf d_tile_off, d_scan_parts, d_items, d_score_args, d_tile_ub;
   ScoreArgs score_args{};
   uint32_t total_tiles = 0;    // doc tiles of all units
   uint32_t score_threads = 0;  // threads per k_pilot / k_score workgroup (power of two x 64)
@@ -264,7 +276,8 @@ bool launch_pilot(irs_hip_batch* b, rt::stream_t st) {
   const size_t smem = tile_smem_bytes<ACC, TILE, AND>() + kBins * sizeof(uint32_t);
   auto kern = k_pilot<ACC, LAYOUT, TILE, AND>;
   if (!big_smem(kern, smem)) return false;
-  RT_LAUNCH(kern, b->nq, b->score_threads, smem, st, b->d_segs.as<DevSegment>(),
+  RT_LAUNCH(kern, uint32_t(b->tile_units.size()), b->score_threads, smem, st,
+            b->d_tile_units.as<uint32_t>(), b->d_segs.as<DevSegment>(),
             b->d_queries.as<DevQuery>(), b->d_qterms.as<DevQTerm>(), b->stride_eff,
             b->nw_log2, b->d_tile_off.as<uint32_t>(), reinterpret_cast<uint64_t>(b->d_items.p),
             b->d_bstar.as<uint32_t>(), b->estimate ? kPilotMargin : 0u);
@@ -281,7 +294,8 @@ bool launch_score(irs_hip_batch* b, rt::stream_t st) {
   uint32_t per_cu = uint32_t((160u * 1024u) / smem);
   per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 16u / waves));  // 128 VGPRs: 4 waves/SIMD
   const uint32_t cpq = (b->max_tiles + kChunkTiles - 1) / kChunkTiles;  // chunk ids per unit
-  const uint64_t chunks = uint64_t(b->nq) * cpq;
+  const uint32_t n_units = uint32_t(b->tile_units.size());
+  const uint64_t chunks = uint64_t(n_units) * cpq;
   if (chunks > 0xFFFF0000ull) return false;
   const uint32_t grid = uint32_t(std::min<uint64_t>(chunks, uint64_t(b->seg->cus) * per_cu));
   ScoreArgs& a = b->score_args;   // read by the kernel from device memory (score.h)
@@ -295,8 +309,9 @@ bool launch_score(irs_hip_batch* b, rt::stream_t st) {
   a.cand_count = b->d_cand_count.as<uint32_t>();
   a.hits = b->d_hits.as<unsigned long long>();
   a.work_counter = b->d_work.as<uint32_t>();
+  a.tile_ub = b->wand ? b->d_tile_ub.as<float>() : nullptr;
   a.cpq = cpq;
-  a.n_units = b->nq;
+  a.n_units = n_units;
   a.nw_log2 = b->nw_log2;
   a.cand_cap = b->cand_cap;
   if (!rt::dmemset(b->d_work.p, 0, 4, st) ||
@@ -364,6 +379,35 @@ bool launch_score_acc(irs_hip_batch* b, rt::stream_t st) {
                   : launch_score_tile<unsigned long long, LAYOUT>(b, st);
 }
 
+// Conjunctions: [pilot pass over every P-th lead block -> threshold bins] -> full pass.
+template<int LAYOUT>
+bool launch_conj(irs_hip_batch* b, rt::stream_t st) {
+  if (b->n_conj_wgs == 0) return true;
+  ConjArgs a{};
+  a.segs = b->d_segs.as<DevSegment>();
+  a.queries = b->d_queries.as<DevQuery>();
+  a.qterms = b->d_qterms.as<DevQTerm>();
+  a.wgs = b->d_conj_wgs.as<PhraseWg>();
+  a.tails = b->d_tails.as<DevTail>();
+  a.bstar = b->d_bstar.as<uint32_t>();
+  a.cands = b->d_cands.as<uint64_t>();
+  a.cand_count = b->d_cand_count.as<uint32_t>();
+  a.hits = b->d_hits.as<unsigned long long>();
+  a.hist = b->d_conj_hist.as<uint32_t>();
+  a.jt = b->jt;
+  a.cand_cap = b->cand_cap;
+  a.pilot_stride = b->stride_eff == 1 ? 1u : b->stride;
+  a.wand = b->wand ? 1u : 0u;
+  if (!rt::dmemset(b->d_conj_hist.p, 0, b->d_conj_hist.n, st)) return false;
+  RT_LAUNCH((k_conj<LAYOUT>), b->n_conj_wgs, kConjWaves * 64, 0, st, a, 1u);
+  RT_LAUNCH(k_conj_threshold, uint32_t(b->conj_units.size()), 64, 0, st,
+            b->d_queries.as<DevQuery>(), b->d_conj_units.as<uint32_t>(),
+            b->d_conj_items.as<uint32_t>(), b->d_conj_hist.as<uint32_t>(), a.pilot_stride,
+            b->estimate ? kPilotMargin : 0u, b->d_bstar.as<uint32_t>());
+  RT_LAUNCH((k_conj<LAYOUT>), b->n_conj_wgs, kConjWaves * 64, 0, st, a, 0u);
+  return rt::last_error_ok();
+}
+
 // Work-item lists of every (unit, doc tile): count -> exclusive scan (all on the device, no
 // host round trip: the buffer is sized by an upper bound) -> fill.
 bool launch_items(irs_hip_batch* b, rt::stream_t st) {
@@ -378,11 +422,10 @@ bool launch_items(irs_hip_batch* b, rt::stream_t st) {
   RT_LAUNCH(k_scan_totals, parts, kThreads, 0, st, off, n, totals);
   RT_LAUNCH(k_scan_parts, 1, 64, 0, st, totals, parts);
   RT_LAUNCH(k_scan_apply, parts, kThreads, 0, st, off, n, totals);
-  const uint32_t tb4 = (b->max_tiles + kWaves - 1) / kWaves;
-  RT_LAUNCH(k_items_fill, b->nq * tb4, kThreads, 0, st, b->d_segs.as<DevSegment>(),
-            b->d_queries.as<DevQuery>(), b->d_qterms.as<DevQTerm>(), b->jt, b->tile, tb4,
+  RT_LAUNCH(k_items_fill, b->nq * tb, kThreads, 0, st, b->d_segs.as<DevSegment>(),
+            b->d_queries.as<DevQuery>(), b->d_qterms.as<DevQTerm>(), b->jt, b->tile, tb,
             b->nw_log2, caches_off(b), b->d_first.as<uint32_t>(), b->d_tails.as<DevTail>(), off,
-            b->total_tiles, b->d_items.as<ItemG>());
+            b->total_tiles, b->d_items.as<ItemG>(), b->wand ? b->d_tile_ub.as<float>() : nullptr);
   return rt::last_error_ok();
 }
 
@@ -403,6 +446,31 @@ bool launch_phrase_terms(irs_hip_batch* b, rt::stream_t st) {
   return launch_phrase<LAYOUT, int(kPhraseMaxTerms)>(b, st);
 }
 
+// Block-max data of a segment (conj.h k_block_max), built once, on first use.
+int prepare_blockmax(irs_hip_segment* s) {
+  std::lock_guard<std::mutex> lock(s->wand_mutex);
+  if (s->wand_ready) return IRS_HIP_OK;
+  const uint64_t n = s->total_blocks;
+  if (!s->d_blk_maxf.alloc((n + 1) * 4) || !s->d_blk_minn.alloc((n + 1) * 4)) return IRS_HIP_ENOMEM;
+  if (n && s->dev.num_terms) {
+    const uint32_t slices =
+        std::max<uint32_t>(1, std::min<uint32_t>(64, s->cus * 8 / s->dev.num_terms));
+    if (s->dev.layout == kSimd4) {
+      RT_LAUNCH((k_block_max<kSimd4>), s->dev.num_terms * slices, kThreads, 0, nullptr, s->dev,
+                slices, s->d_blk_maxf.as<uint32_t>(), s->d_blk_minn.as<uint32_t>());
+    } else {
+      RT_LAUNCH((k_block_max<kScalar>), s->dev.num_terms * slices, kThreads, 0, nullptr, s->dev,
+                slices, s->d_blk_maxf.as<uint32_t>(), s->d_blk_minn.as<uint32_t>());
+    }
+    if (!rt::last_error_ok() || !rt::sync(nullptr)) return IRS_HIP_EHIP;
+  }
+  s->dev.blk_maxf = s->d_blk_maxf.as<uint32_t>();
+  s->dev.blk_minn = s->d_blk_minn.as<uint32_t>();
+  s->device_bytes += s->d_blk_maxf.n + s->d_blk_minn.n;
+  s->wand_ready = true;
+  return IRS_HIP_OK;
+}
+
 bool ensure_scratch(irs_hip_batch* b) {
   if (b->scratch_ready) return true;
   if (b->phrase) b->tile = 0x40000000u;  // k_phrase is block driven: one "tile" = the segment
@@ -418,15 +486,17 @@ bool ensure_scratch(irs_hip_batch* b) {
   b->max_tiles = 0;
   for (uint32_t u = 0; u < b->nq; ++u) {
     DevQuery& dq = b->queries[u];
-    dq.n_tiles = (b->segs[dq.seg]->dev.num_docs + b->tile - 1) / b->tile;
+    const bool tiled = !b->phrase && (dq.op & 0xFF) != 2;   // conjunctions are block driven
+    dq.n_tiles = tiled ? (b->segs[dq.seg]->dev.num_docs + b->tile - 1) / b->tile : 0u;
+    if (b->phrase) dq.n_tiles = 1;
     dq.first_off = first_words;
     first_words += uint64_t(dq.n_tiles + 1) * b->jt;
     if (tiles + dq.n_tiles > 0xFFFFFF00ull) return false;
     dq.tile_base = uint32_t(tiles);
     tiles += dq.n_tiles;
-    b->n_tiles = std::min(b->n_tiles, dq.n_tiles);
+    if (tiled) b->n_tiles = std::min(b->n_tiles, dq.n_tiles);
     b->max_tiles = std::max(b->max_tiles, dq.n_tiles);
-    if (!b->phrase) {
+    if (tiled) {
       for (uint32_t j = 0; j < dq.n_terms; ++j)
         item_bound += uint64_t(b->segs[dq.seg]->terms[b->qterms[dq.first_term + j].term].nblk) +
                       dq.n_tiles + 1;
@@ -434,14 +504,15 @@ bool ensure_scratch(irs_hip_batch* b) {
   }
   if (item_bound > 0xFFFFFF00ull) return false;
   b->total_tiles = uint32_t(tiles);
-  {  // k_score's queue order: heaviest units first within every chunk round
-    std::vector<std::pair<uint64_t, uint32_t>> work(b->nq);
-    for (uint32_t u = 0; u < b->nq; ++u) {
+  if (b->n_tiles == 0xFFFFFFFFu) b->n_tiles = 0;
+  {  // k_score's queue order over the tiled units: heaviest first within every chunk round
+    std::vector<std::pair<uint64_t, uint32_t>> work;
+    for (uint32_t u : b->tile_units) {
       const DevQuery& dq = b->queries[u];
       uint64_t w = 0;
       for (uint32_t j = 0; j < dq.n_terms; ++j)
         w += b->segs[dq.seg]->terms[b->qterms[dq.first_term + j].term].docs_count;
-      work[u] = {w, u};
+      work.push_back({w, u});
     }
     // ... segment by segment: the workgroups resident at one time should keep reading the same
     // doc range (shared in L2), so units of one segment stay together
@@ -449,9 +520,11 @@ bool ensure_scratch(irs_hip_batch* b) {
       const uint32_t sx = b->queries[x.second].seg, sy = b->queries[y.second].seg;
       return sx != sy ? sx < sy : x.first > y.first;
     });
-    for (uint32_t i = 0; i < b->nq; ++i) b->queries[i].run_unit = work[i].second;
+    for (uint32_t i = 0; i < work.size(); ++i) b->queries[i].run_unit = work[i].second;
   }
-  b->stride_eff = std::max<uint32_t>(1, std::min<uint32_t>(b->stride, b->n_tiles / 2));
+  b->stride_eff = b->tile_units.empty()
+                      ? b->stride
+                      : std::max<uint32_t>(1, std::min<uint32_t>(b->stride, b->n_tiles / 2));
   if (b->phrase) b->stride_eff = 1;  // no pilot: every match is a candidate
   if (const char* e = std::getenv("IRS_HIP_WG_THREADS")) {  // tuning knob
     const uint32_t t = uint32_t(std::atoi(e));
@@ -481,12 +554,13 @@ bool ensure_scratch(irs_hip_batch* b) {
       !b->d_out_count.alloc(b->nq * sizeof(uint32_t)) || !b->d_status.alloc(4) ||
       !b->d_work.alloc(4))
     return false;
-  if (!b->phrase) {
+  if (!b->phrase && !b->tile_units.empty()) {
     const uint64_t parts = (tiles + 1 + kScanChunk - 1) / kScanChunk;
     if (!b->d_tile_off.alloc((tiles + 1) * sizeof(uint32_t)) ||
         !b->d_scan_parts.alloc((parts + 1) * sizeof(uint64_t)) ||
         !b->d_items.alloc(item_bound * sizeof(ItemG)) ||
-        !b->d_score_args.alloc(sizeof(ScoreArgs)))
+        !b->d_score_args.alloc(sizeof(ScoreArgs)) ||
+        !b->d_tile_ub.alloc((tiles + 1) * sizeof(float)))
       return false;
   }
   b->scratch_ready = true;
@@ -1011,17 +1085,23 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
         if (rc != IRS_HIP_OK) break;
       }
       if (need == 0xFFu) row.clear();
+      // low byte of op: 0 = disjunction in doc tiles, 1 = doc tiles with per-doc match
+      // counters (min-match), 2 = conjunction, block by block of its rarest term (conj.h)
       dq.op = 0;
-      if (need > 1 && !row.empty()) {
-        dq.op = int32_t(1u | (need << 8));
-        b->any_and = true;
+      if (need > 1 && !row.empty() && !is_phrase) {
         if (need == row.size()) {
-          // MakeConjunction sorts by cost (conjunction.hpp:450-453); sums are order-free here
+          // MakeConjunction sorts by cost (conjunction.hpp:450-453): the cheapest leads, and
+          // the scores are summed in that order
           std::stable_sort(row.begin(), row.end(), [&](const DevQTerm& x, const DevQTerm& y) {
             return seg->terms[x.term].docs_count < seg->terms[y.term].docs_count;
           });
+          dq.op = int32_t(2u | (need << 8));
+        } else {
+          dq.op = int32_t(1u | (need << 8));
+          b->any_and = true;
         }
       }
+      if (!is_phrase) ((dq.op & 0xFF) == 2 ? b->conj_units : b->tile_units).push_back(q);
       // table slots (kernels.h "table_kind"): one per distinct (kind, norm_const, norm_length)
       uint32_t n_caches = 0;
       float cnc[kMaxCaches], cnl[kMaxCaches];
@@ -1111,6 +1191,47 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
       rc = IRS_HIP_ENOMEM;
     }
   }
+  if (rc == IRS_HIP_OK && !b->conj_units.empty()) {
+    // k_conj work list: the lead term of a unit is its first one (sorted by cost above); one
+    // wavefront per 128-posting block of it (+ one for its vint tail / single doc)
+    try {
+      std::vector<PhraseWg> wgs;
+      for (uint32_t u : b->conj_units) {
+        const DevQuery& dq = b->queries[u];
+        uint32_t items = 0;
+        if (dq.n_terms) {
+          const DevTerm& t = b->segs[dq.seg]->terms[b->qterms[dq.first_term].term];
+          items = t.nblk + ((t.docs_count == 1 || t.tail_n) ? 1u : 0u);
+        }
+        b->conj_items.push_back(items);
+        for (uint32_t it = 0; it < items; it += kConjWaves) wgs.push_back(PhraseWg{u, it});
+      }
+      if (wgs.size() > 0x7FFFFFFFull) {
+        rc = IRS_HIP_EUNSUPPORTED;
+      } else {
+        b->n_conj_wgs = uint32_t(wgs.size());
+        if (!b->d_conj_wgs.alloc(std::max<size_t>(1, wgs.size()) * sizeof(PhraseWg)) ||
+            !b->d_conj_units.alloc(b->conj_units.size() * 4) ||
+            !b->d_conj_items.alloc(b->conj_items.size() * 4) ||
+            !b->d_conj_hist.alloc(uint64_t(nq) * kBins * 4))
+          rc = IRS_HIP_ENOMEM;
+        else if (!rt::h2d(b->d_conj_wgs.p, wgs.data(), wgs.size() * sizeof(PhraseWg), nullptr) ||
+                 !rt::h2d(b->d_conj_units.p, b->conj_units.data(), b->conj_units.size() * 4, nullptr) ||
+                 !rt::h2d(b->d_conj_items.p, b->conj_items.data(), b->conj_items.size() * 4, nullptr) ||
+                 !rt::sync(nullptr))
+          rc = IRS_HIP_EHIP;
+      }
+    } catch (...) {
+      rc = IRS_HIP_ENOMEM;
+    }
+  }
+  if (rc == IRS_HIP_OK && !b->tile_units.empty()) {
+    if (!b->d_tile_units.alloc(b->tile_units.size() * 4))
+      rc = IRS_HIP_ENOMEM;
+    else if (!rt::h2d(b->d_tile_units.p, b->tile_units.data(), b->tile_units.size() * 4, nullptr) ||
+             !rt::sync(nullptr))
+      rc = IRS_HIP_EHIP;
+  }
   if (rc == IRS_HIP_OK) {
     if (b->jt == 0) b->jt = 1;
     if (b->qterms.empty()) b->qterms.push_back(DevQTerm{});
@@ -1153,6 +1274,39 @@ static int batch_configure_impl(irs_hip_batch* b, uint32_t tile_docs, uint32_t p
   return IRS_HIP_OK;
 }
 
+static int batch_set_wand_impl(irs_hip_batch* b, int enable) {
+  if (!b) return IRS_HIP_EINVAL;
+  if (b->ran) return IRS_HIP_EINVAL;   // before the first run: the segment records are uploaded once
+  if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
+  b->wand = enable != 0;
+  if (!b->wand) return IRS_HIP_OK;
+  std::vector<DevSegment> dsegs;
+  for (irs_hip_segment* sg : b->segs) {
+    if (const int rc = prepare_blockmax(sg)) return rc;
+    dsegs.push_back(sg->dev);
+  }
+  if (!rt::h2d(b->d_segs.p, dsegs.data(), dsegs.size() * sizeof(DevSegment), nullptr) ||
+      !rt::sync(nullptr))
+    return IRS_HIP_EHIP;
+  return IRS_HIP_OK;
+}
+
+static int term_blockmax_impl(irs_hip_segment* seg, uint32_t term, uint32_t* max_freqs,
+                              uint32_t* min_norms, uint32_t cap, uint32_t* count) {
+  if (!seg || !count || term >= seg->dev.num_terms) return IRS_HIP_EINVAL;
+  if (!rt::set_device(seg->device)) return IRS_HIP_EHIP;
+  const DevTerm& t = seg->terms[term];
+  *count = t.nblk;
+  if (!t.nblk) return IRS_HIP_OK;
+  if (cap < t.nblk || !max_freqs || !min_norms) return IRS_HIP_EINVAL;
+  if (const int rc = prepare_blockmax(seg)) return rc;
+  if (!rt::d2h(max_freqs, seg->d_blk_maxf.as<uint32_t>() + t.dir_off, size_t(t.nblk) * 4, nullptr) ||
+      !rt::d2h(min_norms, seg->d_blk_minn.as<uint32_t>() + t.dir_off, size_t(t.nblk) * 4, nullptr) ||
+      !rt::sync(nullptr))
+    return IRS_HIP_EHIP;
+  return IRS_HIP_OK;
+}
+
 static int batch_profile_impl(irs_hip_batch* b, int enable) {
   if (!b) return IRS_HIP_EINVAL;
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
@@ -1172,7 +1326,8 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st) {
   auto mark = [&](int i) { return !b->profile || rt::event_record(b->ev[i], st); };
   bool ok = rt::dmemset(b->d_cand_count.p, 0, b->d_cand_count.n, st) &&
             rt::dmemset(b->d_hits.p, 0, b->d_hits.n, st) &&
-            rt::dmemset(b->d_status.p, 0, 4, st);
+            rt::dmemset(b->d_status.p, 0, 4, st) &&
+            rt::dmemset(b->d_bstar.p, 0, b->d_bstar.n, st);
   // 1. plan: tile -> first block tables, tail decode
   ok = ok && mark(2 * IRS_HIP_K_PLAN);
   if (ok) {
@@ -1181,19 +1336,21 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st) {
               b->d_first.as<uint32_t>(), b->d_tails.as<DevTail>());
     ok = rt::last_error_ok();
   }
-  if (ok && !b->phrase) ok = launch_items(b, st);
+  const bool tiles = !b->phrase && !b->tile_units.empty();
+  if (ok && tiles) ok = launch_items(b, st);
   ok = ok && mark(2 * IRS_HIP_K_PLAN + 1);
   // 2. pilot: per-query score-bin threshold (phrase batches have none: few docs match)
   ok = ok && mark(2 * IRS_HIP_K_PILOT);
-  if (!b->phrase)
+  if (tiles)
     ok = ok && (simd ? launch_pilot_acc<kSimd4>(b, st) : launch_pilot_acc<kScalar>(b, st));
   ok = ok && mark(2 * IRS_HIP_K_PILOT + 1);
-  // 3. score every tile
+  // 3. score every tile / every lead block
   ok = ok && mark(2 * IRS_HIP_K_SCORE);
   if (b->phrase)
     ok = ok && (simd ? launch_phrase_terms<kSimd4>(b, st) : launch_phrase_terms<kScalar>(b, st));
-  else
+  else if (tiles)
     ok = ok && (simd ? launch_score_acc<kSimd4>(b, st) : launch_score_acc<kScalar>(b, st));
+  if (!b->phrase) ok = ok && (simd ? launch_conj<kSimd4>(b, st) : launch_conj<kScalar>(b, st));
   ok = ok && mark(2 * IRS_HIP_K_SCORE + 1);
   // 4. exact top-k
   ok = ok && mark(2 * IRS_HIP_K_SELECT);
@@ -1451,6 +1608,13 @@ int irs_hip_batch_configure(irs_hip_batch* b, uint32_t tile_docs, uint32_t pilot
 }
 int irs_hip_batch_profile(irs_hip_batch* b, int enable) {
   return guarded([&] { return batch_profile_impl(b, enable); });
+}
+int irs_hip_batch_set_wand(irs_hip_batch* b, int enable) {
+  return guarded([&] { return batch_set_wand_impl(b, enable); });
+}
+int irs_hip_term_blockmax(irs_hip_segment* seg, uint32_t term, uint32_t* max_freqs,
+                          uint32_t* min_norms, uint32_t cap, uint32_t* count) {
+  return guarded([&] { return term_blockmax_impl(seg, term, max_freqs, min_norms, cap, count); });
 }
 int irs_hip_batch_run(irs_hip_batch* b, void* stream) {
   return guarded([&] { return batch_run_impl(b, stream); });

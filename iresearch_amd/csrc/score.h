@@ -456,20 +456,16 @@ __device__ __forceinline__ WaveList wave_list(uint64_t items, uint32_t off0, uin
   return l;
 }
 
-// The pipeline state a wavefront carries into a tile: the records (compute parts) of its
-// first two item pairs, their payload words (requested, maybe not landed), the address parts
-// of the third pair.
+// The pipeline state a wavefront carries into a tile: the payload words of its first two
+// item pairs (requested, maybe not landed) and the address parts of the third pair.
 struct ItemPipe {
-  ItemPair c0, c1;
   PairRegs p0, p1;
   ItemAddr la, lb;
 };
-// Head of a list, step 1: scalar loads of the first two pairs' records.  (Reads up to 4
+// Head of a list, step 1: scalar loads of the first two pairs' address parts.  (Reads up to 4
 // records from the list's start whatever its length: always readable, see kItemSlack.)
-__device__ __forceinline__ void pipe_begin(const WaveList& l, ItemPipe& s, ItemAddr (&h)[4]) {
+__device__ __forceinline__ void pipe_begin(const WaveList& l, ItemAddr (&h)[4]) {
   if (l.n) {
-    load_pair(l.p, s.c0);
-    load_pair(l.p + 2 * sizeof(ItemG), s.c1);
     load_addrs(l.p, h[0], h[1]);
     load_addrs(l.p + 2 * sizeof(ItemG), h[2], h[3]);
   }
@@ -583,13 +579,13 @@ __device__ __forceinline__ void pair_compute(const TileSmemT<ACC>& sm, const Ite
 }
 
 // All items of this wavefront in one tile: decode + score + accumulate.  In flight at any
-// time: the payload words of the next pair (requested one step ago) and the scalar loads for
-// the pair after it.  One step = compute pair i out of registers, then request the payload of
-// pair i+2 into the registers just freed, then fetch the records of pair i+2 (compute part,
-// into the record registers just freed) and of pair i+3 (address part).  The scalar loads go
-// LAST in a step: scalar loads return out of order, so the first wait for any LDS or scalar
-// result drains all of them — placed here they have the next step's whole decode (the
-// extraction and the prefix sums, no waits) to land.  Unrolled by two so that the two
+// time: the payload words of the next pair (requested one step ago) and the scalar load of the
+// address parts of the pair after it.  One step = fetch the pair's records (a scalar-cache
+// hit: their cache line came in with the address parts two steps ago), compute the pair out
+// of registers, then request the payload of pair i+2 into the registers just freed and the
+// address parts of pair i+3.  Those scalar loads go LAST in a step: scalar loads return out
+// of order, so the first wait for any LDS or scalar result drains all of them — placed here
+// they have the next step's whole decode to land.  Unrolled by two so that the two payload
 // register sets simply alternate (no moves).
 // In: `s` as left by pipe_begin + pipe_issue for THIS list.  The look-ahead reads run up to
 // 7 records past the list's end: those are records of other lists or the slack records
@@ -600,22 +596,27 @@ template<typename ACC, int LAYOUT, int TILE, bool AND>
 __device__ __forceinline__ uint32_t items_run(const TileSmemT<ACC>& sm, const WaveList& l,
                                               ItemPipe& s, unsigned lane) {
   uint32_t slow = 0;
-  for (uint32_t i = 0; i < l.n;) {
-    pair_compute<ACC, LAYOUT, TILE, AND>(sm, s.c0, s.p0, slow, lane);
-    if (i + 4 < l.n) {
+  // p = address of the pair computed next, left = items from there on (one running pointer:
+  // every record address below is p + a constant, i.e. an immediate of the scalar load)
+  uint64_t p = l.p;
+  ItemPair c;
+  for (uint32_t left = l.n; left;) {
+    load_pair(p, c);
+    pair_compute<ACC, LAYOUT, TILE, AND>(sm, c, s.p0, slow, lane);
+    if (left > 4) {
       pair_issue<LAYOUT>(s.la, s.lb, lane, s.p0);
-      load_pair(l.p + (i + 4) * sizeof(ItemG), s.c0);
-      load_addrs(l.p + (i + 6) * sizeof(ItemG), s.la, s.lb);
+      load_addrs(p + 6 * sizeof(ItemG), s.la, s.lb);
     }
-    i += 2;
-    if (i >= l.n) break;
-    pair_compute<ACC, LAYOUT, TILE, AND>(sm, s.c1, s.p1, slow, lane);
-    if (i + 4 < l.n) {
+    if (left <= 2) break;
+    load_pair(p + 2 * sizeof(ItemG), c);
+    pair_compute<ACC, LAYOUT, TILE, AND>(sm, c, s.p1, slow, lane);
+    if (left > 6) {
       pair_issue<LAYOUT>(s.la, s.lb, lane, s.p1);
-      load_pair(l.p + (i + 4) * sizeof(ItemG), s.c1);
-      load_addrs(l.p + (i + 6) * sizeof(ItemG), s.la, s.lb);
+      load_addrs(p + 8 * sizeof(ItemG), s.la, s.lb);
     }
-    i += 2;
+    if (left <= 4) break;
+    left -= 4;
+    p += 4 * sizeof(ItemG);
   }
   return slow;
 }
@@ -630,6 +631,44 @@ __device__ __forceinline__ void items_slow(const DevSegment& seg, const TileSmem
     const ItemCalc I = wave::sload<ItemCalc>(at + 8u);
     if (I.aux & kItemSlow) slow_item<ACC, LAYOUT, TILE, AND>(seg, sm, I, at, tile, lane);
   }
+}
+
+// The score function a term scorer compiles to, on explicit values — used on (tf, the doc's
+// norm) for postings and on (max freq, min norm) for block bounds, exactly as the wanderator
+// runs the one ScoreFunction on its WandSource (formats_10.cpp:2498-2503).  The reference's
+// float expressions: bm25.cpp:281-282, 313, 348-359; tfidf.cpp:185-187, 251-253.
+__device__ __forceinline__ float score_value(const DevQTerm& qt, uint32_t freq, uint32_t norm) {
+  const float tf = static_cast<float>(freq);
+  switch (qt.kind) {
+    case kBM1:
+      return qt.c0;
+    case kBM15:
+      return qt.c0 - qt.c0 / (1.f + tf / qt.norm_const);
+    case kBM25Tiny: {
+      const float inv = norm ? 1.f / (qt.norm_const + qt.norm_length * static_cast<float>(norm)) : 0.f;
+      return qt.c0 - qt.c0 / (1.f + tf * inv);
+    }
+    case kBM25One: {
+      const float inv = 1.f / (qt.norm_const + qt.norm_length);
+      return qt.c0 - qt.c0 / (1.f + tf * inv);
+    }
+    case kBM25Wide: {
+      const float c1 = qt.norm_const + qt.norm_length * static_cast<float>(norm);
+      return qt.c0 - qt.c0 * c1 / (c1 + tf);
+    }
+    case kTfidf:
+      return sqrtf(tf) * qt.c0;
+    default: {  // kTfidfTiny, kTfidfWide
+      const float r = norm ? 1.f / sqrtf(static_cast<float>(norm)) : 0.f;
+      return sqrtf(tf) * qt.c0 * r;
+    }
+  }
+}
+// what no posting of the term can exceed (BM25 family: the supremum over tf; TF-IDF: at the
+// term's largest frequency, DevTerm::tf_bound)
+__device__ __forceinline__ float term_bound(const DevQTerm& qt, uint32_t tf_bound) {
+  return sqrt_kind(qt.kind) || qt.kind == kTfidfWide
+             ? sqrtf(static_cast<float>(tf_bound)) * qt.c0 : qt.c0;
 }
 
 // -------------------------------------------------------- item list build --
@@ -658,67 +697,68 @@ k_items_count(const DevQuery* queries, uint32_t jt, uint32_t tile_docs, uint32_t
   tile_cnt[qd.tile_base + tile] = n;
 }
 
-// One wavefront per (unit, doc tile) writes the tile's work items: everything the scoring
-// loop would otherwise derive per block — where the payload lives, the bit widths out of the
+// One THREAD per (unit, doc tile) writes the tile's work items: everything the scoring loop
+// would otherwise derive per block — where the payload lives, the bit widths out of the
 // block directory, the preceding block's last doc relative to the tile, the term's scaled c0
-// and table row — goes into the record once.  grid = n_units * tb, tb = ceil(max tiles / kWaves).
+// and table row — goes into the record once.  (A thread per tile, not a wavefront: the
+// per-tile set-up is then paid by one lane instead of 64, and the directory reads of the 64
+// tiles a wavefront handles are all in flight together — 1.35 ms -> see DESIGN.md.)
+// grid = n_units * tb, tb = ceil(max tiles / kThreads).
 __global__ void __launch_bounds__(kThreads)
 k_items_fill(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms,
              uint32_t jt, uint32_t tile_docs, uint32_t tb, uint32_t nw_log2,
              uint32_t caches_off, const uint32_t* first, const DevTail* tails,
-             const uint32_t* tile_off, uint32_t total_tiles, ItemG* items) {
-  __shared__ uint32_t s_pre[kWaves][kMaxTerms + 1];  // exclusive prefix sums of the block counts
-  __shared__ uint32_t s_b0[kWaves][kMaxTerms];
-  const unsigned lane = threadIdx.x & 63u;
-  const uint32_t wv = threadIdx.x >> 6;
+             const uint32_t* tile_off, uint32_t total_tiles, ItemG* items,
+             float* tile_ub /*WAND: upper bound of any doc's score in the tile; else null*/) {
   const uint32_t unit = blockIdx.x / tb;
-  const uint32_t tile = (blockIdx.x % tb) * kWaves + wv;
+  const uint32_t tile = (blockIdx.x % tb) * kThreads + threadIdx.x;
   const DevQuery qd = queries[unit];
-  if (tile >= qd.n_tiles) return;   // whole wavefront
+  if (tile >= qd.n_tiles) return;
   const DevSegment& seg = segs[qd.seg];
   const uint32_t* f0 = first + qd.first_off + uint64_t(tile) * jt;
   const DevTail* tl = tails + uint64_t(unit) * jt;
   const DevQTerm* qts = qterms + qd.first_term;
   const uint32_t lo = kDocMin + tile * tile_docs;
-  uint32_t nb = 0, b0 = 0;
-  bool tail_here = false;
-  if (lane < qd.n_terms) {
-    b0 = f0[lane];
-    uint32_t b1 = f0[jt + lane] + 1u;
-    b1 = b1 < tl[lane].nblk ? b1 : tl[lane].nblk;
-    nb = b1 > b0 ? b1 - b0 : 0u;
-    tail_here = tl[lane].n && tl[lane].first_doc < lo + tile_docs && tl[lane].last_doc >= lo;
-  }
-  const uint32_t incl = wave::inclusive_scan(nb);
-  if (lane <= kMaxTerms) s_pre[wv][lane] = incl - nb;   // lanes >= n_terms hold the total
-  if (lane < kMaxTerms) s_b0[wv][lane] = b0;
-  const uint64_t tail_mask = wave::ballot(tail_here);
-  wave::sync();
-  const uint32_t n_blocks = s_pre[wv][kMaxTerms];
-  const uint32_t n = n_blocks + uint32_t(__builtin_popcountll(tail_mask));
   const uint32_t ut = qd.tile_base + tile;
-  const uint32_t off0 = tile_off[ut];
+  const uint32_t off0 = tile_off[ut], n = tile_off[ut + 1] - off0;
   const uint32_t nw = 1u << nw_log2;
   const uint32_t a = n >> nw_log2, r = n & (nw - 1u);
   const uint64_t pk = reinterpret_cast<uint64_t>(seg.pk);
+  const BlkDir* dir = seg.blk_dir;
+  const uint8_t* doc = seg.doc;
+  const uint32_t rows = table_rows(qd.n_caches);
 
-  // term slot and directory row of block item g
-  auto locate = [&](uint32_t g, uint32_t& j, uint64_t& e) {
-    j = 0;
-    for (uint32_t t = 1; t < qd.n_terms; ++t) j += s_pre[wv][t] <= g ? 1u : 0u;
-    e = tl[j].dir_off + s_b0[wv][j] + (g - s_pre[wv][j]);
+  // a position in the tile's sequence of block items: block b of term slot j
+  struct Cursor {
+    uint32_t j, b, b_end;
+    bool valid;
+  };
+  auto enter = [&](Cursor& c) {   // first term slot at or behind c.j with a block in the tile
+    for (; c.j < qd.n_terms; ++c.j) {
+      c.b = f0[c.j];
+      uint32_t b1 = f0[jt + c.j] + 1u;
+      b1 = b1 < tl[c.j].nblk ? b1 : tl[c.j].nblk;
+      c.b_end = b1;
+      if (c.b < c.b_end) return;
+    }
+    c.valid = false;
+  };
+  auto advance = [&](Cursor& c) {
+    if (!c.valid) return;
+    if (++c.b >= c.b_end) {
+      ++c.j;
+      enter(c);
+    }
   };
   // the value of an ALL-EQUAL freq block: vint behind the doc part and the 0 header byte
   auto freq_const = [&](uint32_t j, const BlkDir& d) {
     uint32_t len;
-    return vint_from(wave::load_u64(seg.doc + tl[j].doc_start + d.off + 2u + 16u * (d.bits & 0xFFu)),
-                     &len);
+    return vint_from(wave::load_u64(doc + tl[j].doc_start + d.off + 2u + 16u * (d.bits & 0xFFu)), &len);
   };
   // straight-line path: a scorer of the table family, the block in the packed image, and an
   // all-equal frequency that fits the record's 16 bits.  cls: 0 = generic, 1 = straight-line
   // with general frequencies, 2 = every frequency of the block has a table row; bit 2: the
   // square-root form (only tells general items apart)
-  const uint32_t rows = table_rows(qd.n_caches);
   auto classify = [&](uint32_t j, const BlkDir& d, uint32_t& fconst) {
     fconst = 0;
     const uint32_t dbits = d.bits & 0xFFu, fbits = d.bits >> 8;
@@ -731,64 +771,80 @@ k_items_fill(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qt
     }
     return (1u << fbits) <= rows ? 2u : (sqrt_kind(qts[j].kind) ? 5u : 1u);
   };
-  for (uint32_t g0 = 0; g0 < n; g0 += 64) {   // (whole wavefront: shuffles inside)
-    const uint32_t g = g0 + lane;
-    ItemG I{};
-    uint32_t cls = 0;
-    if (g < n_blocks) {
-      uint32_t j, fconst;
-      uint64_t e;
-      locate(g, j, e);
-      const BlkDir d = seg.blk_dir[e];
-      cls = classify(j, d, fconst);
-      const bool fast = cls != 0u;
-      const uint32_t slot = qts[j].cache_id < kMaxCaches ? qts[j].cache_id : 0u;
-      I.addr = fast ? pk + (uint64_t(d.aoff) << 4)
-                    : reinterpret_cast<uint64_t>(seg.doc) + tl[j].doc_start + d.off;
-      I.dbits = d.bits & 0xFFu;
-      I.fbits = d.bits >> 8;
-      I.base = d.prev_last - lo;
-      I.cs = qts[j].c0 * qd.fx_mul;
-      // table items: an all-equal frequency selects its row right here
-      I.tab = caches_off + (slot * rows + (cls == 2u ? fconst : 0u)) * 1024u;
-      I.aux = j | (fast ? 0u : kItemSlow) | (sqrt_kind(qts[j].kind) ? kItemSqrt : 0u) |
-              (cls == 2u ? kItemTable : fconst << kItemFreqShift);
-    } else if (g < n) {
-      // the (g - n_blocks)-th term whose tail reaches into the tile
-      uint64_t m = tail_mask;
-      for (uint32_t s = g - n_blocks; s; --s) m &= m - 1;
-      const uint32_t j = uint32_t(__builtin_ctzll(m));
-      I.addr = pk;   // readable; never used
-      I.dbits = 1;
-      I.fbits = 1;
-      I.base = tl[j].n;
-      I.cs = 0.f;
-      I.tab = tl[j].tail_row;
-      I.aux = j | kItemSlow | kItemTail;
+  // where item g of the tile goes: wavefront g % nw, its i-th item; each wavefront's share
+  // is contiguous.  Even items of a wavefront carry the pairing flags.
+  auto place = [&](uint32_t g, ItemG& I, uint32_t cls, uint32_t next_cls) {
+    const uint32_t w = g & (nw - 1u), i = g >> nw_log2;
+    const uint32_t n_w = a + (w < r ? 1u : 0u);
+    if (!(i & 1u)) {
+      if (i + 1u == n_w) I.aux |= kItemSolo;
+      else if (cls && next_cls == cls) I.aux |= kItemPair;
     }
-    // class of the wavefront's next item, g + nw: computed by lane + nw, or — for the last
-    // nw lanes — looked up directly
-    uint32_t next_cls = __shfl_down(cls, nw, 64);
-    if (lane + nw >= 64u) {
-      next_cls = 0;
-      if (g + nw < n_blocks) {
-        uint32_t j2, fconst2;
-        uint64_t e2;
-        locate(g + nw, j2, e2);
-        next_cls = classify(j2, seg.blk_dir[e2], fconst2);
+    items[off0 + w * a + (w < r ? w : r) + i] = I;
+  };
+
+  Cursor cur{0, 0, 0, true};
+  enter(cur);
+  Cursor ahead = cur;   // the wavefront's next item: nw items further on
+  for (uint32_t k = 0; k < nw; ++k) advance(ahead);
+  uint32_t g = 0;
+  // WAND: bound of the tile = sum over the terms of their largest block-max score in it
+  // (the min lambda of block_disjunction sums the sub-iterators' bounds, disjunction.hpp:1133-1167)
+  float bound = 0.f, term_ub = 0.f;
+  uint32_t bound_j = 0;
+  for (; cur.valid; ++g) {
+    const uint32_t j = cur.j;
+    if (tile_ub) {
+      if (j != bound_j) {
+        bound += term_ub;
+        term_ub = 0.f;
+        bound_j = j;
       }
+      const uint64_t e = tl[j].dir_off + cur.b;
+      const float ub = score_value(qts[j], seg.blk_maxf[e], seg.blk_minn[e]);
+      term_ub = ub > term_ub ? ub : term_ub;
     }
-    if (g < n) {
-      const uint32_t w = g & (nw - 1u), i = g >> nw_log2;
-      const uint32_t n_w = a + (w < r ? 1u : 0u);
-      if (!(i & 1u)) {
-        if (i + 1u == n_w) I.aux |= kItemSolo;
-        else if (cls && g + nw < n_blocks && next_cls == cls) I.aux |= kItemPair;
-      }
-      items[off0 + w * a + (w < r ? w : r) + i] = I;
+    const BlkDir d = dir[tl[j].dir_off + cur.b];
+    uint32_t fconst, cls = classify(j, d, fconst), next_cls = 0;
+    if (ahead.valid) {
+      uint32_t fc2;
+      next_cls = classify(ahead.j, dir[tl[ahead.j].dir_off + ahead.b], fc2);
     }
+    const bool fast = cls != 0u;
+    const uint32_t slot = qts[j].cache_id < kMaxCaches ? qts[j].cache_id : 0u;
+    ItemG I;
+    I.addr = fast ? pk + (uint64_t(d.aoff) << 4)
+                  : reinterpret_cast<uint64_t>(doc) + tl[j].doc_start + d.off;
+    I.dbits = d.bits & 0xFFu;
+    I.fbits = d.bits >> 8;
+    I.base = d.prev_last - lo;
+    I.cs = qts[j].c0 * qd.fx_mul;
+    // table items: an all-equal frequency selects its row right here
+    I.tab = caches_off + (slot * rows + (cls == 2u ? fconst : 0u)) * 1024u;
+    I.aux = j | (fast ? 0u : kItemSlow) | (sqrt_kind(qts[j].kind) ? kItemSqrt : 0u) |
+            (cls == 2u ? kItemTable : fconst << kItemFreqShift);
+    place(g, I, cls, next_cls);
+    advance(cur);
+    advance(ahead);
   }
-  if (ut + 1u == total_tiles && lane < kItemSlack) {   // readable slack behind the last list
+  // one item per term whose decoded tail reaches into the tile
+  for (uint32_t j = 0; j < qd.n_terms; ++j) {
+    if (!(tl[j].n && tl[j].first_doc < lo + tile_docs && tl[j].last_doc >= lo)) continue;
+    ItemG I;
+    I.addr = pk;   // readable; never used
+    I.dbits = 1;
+    I.fbits = 1;
+    I.base = tl[j].n;
+    I.cs = 0.f;
+    I.tab = tl[j].tail_row;
+    I.aux = j | kItemSlow | kItemTail;
+    place(g++, I, 0u, 0u);
+    // (a decoded tail has no block-max entry: the term's global bound; counted on top of the
+    // term's blocks in the tile, which only loosens the bound)
+    if (tile_ub) bound += term_bound(qts[j], seg.terms[tl[j].term].tf_bound);
+  }
+  if (tile_ub) tile_ub[ut] = (bound + term_ub) * (1.f + 1e-6f);
+  if (ut + 1u == total_tiles) {   // readable slack behind the last list
     ItemG I;
     I.addr = pk;
     I.dbits = 1;
@@ -797,7 +853,7 @@ k_items_fill(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qt
     I.cs = 0.f;
     I.tab = caches_off;
     I.aux = kItemSlow | kItemTail | kItemSolo;
-    items[off0 + n + lane] = I;
+    for (uint32_t k = 0; k < kItemSlack; ++k) items[off0 + n + k] = I;
   }
 }
 
@@ -866,8 +922,8 @@ constexpr uint32_t kPilotMinSample = 48;
 
 template<typename ACC, int LAYOUT, int TILE, bool AND>
 __global__ void __launch_bounds__(kTileThreadsMax)
-k_pilot(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms,
-        uint32_t stride, uint32_t nw_log2, const uint32_t* tile_off,
+k_pilot(const uint32_t* units, const DevSegment* segs, const DevQuery* queries,
+        const DevQTerm* qterms, uint32_t stride, uint32_t nw_log2, const uint32_t* tile_off,
         uint64_t items /*address of the ItemG records*/, uint32_t* bstar, uint32_t margin) {
   RT_DYN_SMEM(smem);
   if (!wave::lds_is_at_zero(smem)) __builtin_trap();  // the tile arrays are addressed absolutely
@@ -877,7 +933,7 @@ k_pilot(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms,
   const uint32_t tid = threadIdx.x;
   const unsigned lane = tid & 63u;
   const uint32_t wv = wave::uniform(tid >> 6);
-  const uint32_t q = blockIdx.x;
+  const uint32_t q = units[blockIdx.x];   // the units executed as doc tiles
   const DevQuery qd = queries[q];
   const DevSegment& seg = segs[qd.seg];   // (read field by field: the generic path is cold)
   const bool tiny = seg.norms && seg.norm_width == 1;
@@ -905,7 +961,7 @@ k_pilot(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms,
                                  wave::uniform(tile_off[ut + 1]), wv, nw_log2);
     ItemPipe s;
     ItemAddr head[4];
-    pipe_begin(l, s, head);
+    pipe_begin(l, head);
     pipe_issue<LAYOUT>(l, s, head, lane);
     nrm.store(sm.lnorm);
     __syncthreads();   // norms (and, first time round, tables and cleared accumulators) are in place
@@ -992,6 +1048,7 @@ template<typename ACC, int TILE, bool AND>
 constexpr uint32_t score_smem_bytes() {
   return tile_smem_bytes<ACC, TILE, AND>()
          + 4u * (kChunkTiles + 2)                          // item offsets of the chunk's tiles
+         + 4u * kChunkTiles                                // WAND: which of them are skipped
          + 8u * 2u * kScoreCands                           // candidate staging x2
          + 4u * kVWords;
 }
@@ -1010,6 +1067,7 @@ struct ScoreArgs {
   uint32_t* cand_count;
   unsigned long long* hits;
   uint32_t* work_counter;
+  const float* tile_ub;         // WAND: per-tile score bounds (k_items_fill), else null
   uint32_t cpq;                 // chunk ids per unit
   uint32_t n_units;
   uint32_t nw_log2;
@@ -1027,6 +1085,8 @@ k_score(uint64_t args /*address of a ScoreArgs*/) {
   const TileSmemT<ACC> sm = carve<ACC, TILE, AND>(smem, &rest);
   uint32_t* toff = reinterpret_cast<uint32_t*>(rest);       // [kChunkTiles + 2]
   rest += 4u * (kChunkTiles + 2);
+  uint32_t* tdead = reinterpret_cast<uint32_t*>(rest);      // [kChunkTiles]
+  rest += 4u * kChunkTiles;
   uint64_t* lcand = reinterpret_cast<uint64_t*>(rest);      // [2][kScoreCands]
   rest += 8u * 2u * kScoreCands;
   uint32_t* vars = reinterpret_cast<uint32_t*>(rest);
@@ -1076,6 +1136,12 @@ k_score(uint64_t args /*address of a ScoreArgs*/) {
     // ---- chunk prologue: everything that is per query / per chunk ----------
     if (tid < qd.n_terms) sm.qts[tid] = IRS_ARG(qterms)[qd.first_term + tid];
     if (tid <= ntile) toff[tid] = IRS_ARG(tile_off)[qd.tile_base + tile0 + tid];
+    if (tid < ntile) {
+      // WAND: no doc of the tile can reach the threshold bin -> the tile is skipped (its work
+      // items are not even read)
+      const float* ub = IRS_ARG(tile_ub);
+      tdead[tid] = (ub && bs && score_bin(ub[qd.tile_base + tile0 + tid], qd.bin_scale) < bs) ? 1u : 0u;
+    }
     if (tid == 0) {
       sm.slow[0] = __float_as_uint(qd.fx_mul);
       sm.slow[1] = seg.num_docs;
@@ -1090,9 +1156,10 @@ k_score(uint64_t args /*address of a ScoreArgs*/) {
     // ---- prime the pipeline: this wavefront's items of tile 0, norms of tiles 0 and 1
     WaveList l = wave_list(IRS_ARG(items), wave::uniform(toff[0]), wave::uniform(toff[1]), wv,
                            nw_log2);
+    if (wave::uniform(tdead[0])) l.n = 0;
     ItemPipe s;
     ItemAddr head[4];
-    pipe_begin(l, s, head);
+    pipe_begin(l, head);
     nrm.store(sm.lnorm);
     pipe_issue<LAYOUT>(l, s, head, lane);
     if (1 < ntile) nrm.load(norms1, norm_count, tile0 + 1);
@@ -1107,7 +1174,8 @@ k_score(uint64_t args /*address of a ScoreArgs*/) {
       if (has_next) {   // records of the head of this wavefront's list of tile u+1
         l = wave_list(IRS_ARG(items), wave::uniform(toff[u + 1]), wave::uniform(toff[u + 2]), wv,
                       nw_log2);
-        pipe_begin(l, s, head);
+        if (wave::uniform(tdead[u + 1])) l.n = 0;
+        pipe_begin(l, head);
       }
       __syncthreads();  // B1: every accumulation of tile u has landed
 
@@ -1134,7 +1202,7 @@ k_score(uint64_t args /*address of a ScoreArgs*/) {
           }
         }
       };
-      {
+      if (!wave::uniform(tdead[u])) {   // (a skipped tile accumulated nothing)
         const bool is_and = AND && (qd.op & 0xFF) == 1;  // op = 1 | required matches << 8
         const uint32_t need = uint32_t(qd.op >> 8);
         // eight accumulators per lane per step: two 4-wide LDS reads in flight, two wide clears

@@ -90,6 +90,11 @@ struct DevSegment {
   const uint8_t* pk;
   const uint32_t* blk_aoff;  // offset of the block in `pk`, in 16-byte units
   const BlkDir* blk_dir;     // the same facts per block, gathered
+  // block-max data (null until a WAND batch asks for it): largest frequency and smallest
+  // non-zero norm of every full block — what FreqNormProducer stores per skip entry
+  // (wand_writer.hpp:170-209)
+  const uint32_t* blk_maxf;
+  const uint32_t* blk_minn;
   // decoded vint tails / single docs, term after term (DevTerm::tail_row): absolute doc ids
   // and frequencies — at most 127 entries per term, 1 for a single-doc term
   const uint32_t* tail_docs;

@@ -241,6 +241,18 @@ class SegmentReader:
             "irs_hip_term_directory")
         return last[:cnt.value], offs[:cnt.value]
 
+    def term_blockmax(self, term: int):
+        """Per full block of the term: (largest frequency, smallest non-zero norm) — the
+        block-max data WAND batches prune with."""
+        nb = int(self.metas[term]["docs_count"]) // 128
+        mf = np.zeros(max(nb, 1), np.uint32)
+        mn = np.zeros(max(nb, 1), np.uint32)
+        cnt = C.c_uint32()
+        _lib.check(self.L, self.L.irs_hip_term_blockmax(
+            self.handle, term, mf.ctypes.data, mn.ctypes.data, mf.size, C.byref(cnt)),
+            "irs_hip_term_blockmax")
+        return mf[:cnt.value], mn[:cnt.value]
+
     def batch(self, prepared, k: int):
         return QueryBatch(self, prepared, k)
 
@@ -279,6 +291,12 @@ class QueryBatch:
     def configure(self, tile_docs=0, pilot_stride=0, cand_cap=0):
         _lib.check(self.L, self.L.irs_hip_batch_configure(self.handle, tile_docs, pilot_stride,
                                                           cand_cap), "irs_hip_batch_configure")
+        return self
+
+    def set_wand(self, enable=True):
+        """ExecutionContext::wand (index-search --search-mode wand): block-max pruning."""
+        _lib.check(self.L, self.L.irs_hip_batch_set_wand(self.handle, int(enable)),
+                   "irs_hip_batch_set_wand")
         return self
 
     def profile(self, enable=True):

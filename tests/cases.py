@@ -30,6 +30,49 @@ def assert_decode(sr, seg, term, docs, freqs):
     assert np.array_equal(d2, d) and f2 is None
 
 
+def case_wand_equals_exhaustive(L, num_docs=60_000, max_rank=256, layout=synth.LAYOUT_SIMD4,
+                                ks=(10, 100)):
+    """The reference's differential rule for WAND (tests/search/wand_test.cpp:231-241): the
+    top k of a run that may skip blocks is the top k of the exhaustive run — same docs, same
+    scores, same order — for term / And / Or queries under BM25, BM15, BM11 and TF-IDF, on
+    the default corpus and on a clustered one (bursty posting lists, where whole blocks and
+    tiles really are skipped).  Total hits may only shrink."""
+    scorers = [BM25(), BM25(1.2, 0.0), BM25(1.2, 1.0), TFIDF(False), TFIDF(True)]
+    pruned = 0
+    for clustered in (False, True):
+        kw = dict(topic_docs=2048, topic_percent=85, topic_terms=12) if clustered else {}
+        seg = synth.build_segment(num_docs, max_rank, layout=layout, **kw)
+        sr = search.SegmentReader.from_synth(seg, L=L)
+        stats = [parity.segment_stats(seg)]
+        rng = np.random.default_rng(11 + clustered)
+        filters = [by_term(int(t)) for t in rng.integers(0, max_rank, 4)]
+        filters += [And([by_term(int(t)) for t in rng.choice(max_rank // 4, 2, replace=False)])
+                    for _ in range(6)]
+        filters += [And([by_term(int(t)) for t in rng.choice(max_rank // 2, 3, replace=False)])
+                    for _ in range(4)]
+        filters += [Or([by_term(int(t)) for t in rng.choice(max_rank, 3, replace=False)])
+                    for _ in range(4)]
+        for scorer in scorers:
+            prep = search.prepare(filters, scorer, stats)
+            for k in ks:
+                ex = sr.batch(prep, k)
+                h0, c0, t0 = ex.run().results()
+                ex.close()
+                wb = sr.batch(prep, k).set_wand(True)
+                h1, c1, t1 = wb.run().results()
+                wb.close()
+                assert np.array_equal(c0, c1), (clustered, type(scorer).__name__, k)
+                for q in range(len(filters)):
+                    n = int(c0[q])
+                    assert np.array_equal(h0[q, :n], h1[q, :n]), (clustered, q, k)
+                assert (t1 <= t0).all()
+                pruned += int((t0 - t1).sum())
+            # and the exhaustive run is the oracle's
+            parity.check_single_segment(seg, filters, scorer, ks[-1], h0, c0, t0)
+        sr.close()
+    assert pruned > 0, "no block or tile was ever skipped: the pruning path went untested"
+
+
 # ------------------------------------------------------------------ decode --
 
 def case_decode_reference_lists(L, layout):
@@ -513,6 +556,18 @@ def case_wand_data(L, layout):
                 assert mf[b] == f[blk].max(), (t, b)
                 if kinds[0] == synth.WAND_MIN_NORM:
                     assert nm[b] == max(int(norms[d[blk] - 1].min()), int(f[blk].max())), (t, b)
+            # the block-max data the GPU prunes with == what the index's own wand data says
+            # (FreqNormProducer stores max(min norm, max freq), wand_writer.hpp:198-209); the
+            # GPU also has it for a list's last full block, which has no skip entry
+            gmf, gmn = sr.term_blockmax(t)
+            assert len(gmf) == len(d) // 128
+            for b in range(len(gmf)):
+                blk = slice(128 * b, 128 * b + 128)
+                assert gmf[b] == f[blk].max() and gmn[b] == norms[d[blk] - 1].min(), (t, b)
+                if b < len(sl):
+                    assert gmf[b] == mf[b], (t, b)
+                    if kinds[0] == synth.WAND_MIN_NORM:
+                        assert max(int(gmn[b]), int(gmf[b])) == nm[b], (t, b)
         n_words = (n_docs + 64) // 64
         terms = list(range(len(lists)))
         got, cnt = sr.bit_union(terms, n_words)

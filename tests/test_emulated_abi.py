@@ -141,5 +141,9 @@ def test_phrase_errors(simlib):
     cases.case_phrase_errors(simlib)
 
 
+def test_wand_equals_exhaustive(simlib):
+    cases.case_wand_equals_exhaustive(simlib)
+
+
 def test_errors(simlib):
     cases.case_errors(simlib)

@@ -183,6 +183,10 @@ def test_merge_ties(gpulib):
     cases.case_merge_ties(gpulib, n_lists=8, nq=5, k=1000, seed=5)
 
 
+def test_wand_equals_exhaustive(gpulib):
+    cases.case_wand_equals_exhaustive(gpulib, num_docs=400_000, max_rank=512, ks=(10, 1000))
+
+
 def test_errors(gpulib):
     cases.case_errors(gpulib)
 

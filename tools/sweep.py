@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--layout", type=int, default=1, help="0 = scalar (1_5), 1 = simd4 (1_5simd)")
     ap.add_argument("--scorer", default="bm25", choices=["bm25", "tfidf", "bm15"])
     ap.add_argument("--lib", default=None, help="alternative build of libirs_hip.so (A/B runs)")
+    ap.add_argument("--wand", action="store_true", help="also time the batch with block-max pruning")
+    ap.add_argument("--clustered", action="store_true", help="bursty posting lists (topic docs)")
     args = ap.parse_args()
     import torch
 
@@ -38,8 +40,9 @@ def main():
     from iresearch_amd.search import BM25, TFIDF, And, Or, by_phrase, by_term
     L = _lib.bind(ctypes.CDLL(args.lib)) if args.lib else _lib.lib()
     t0 = time.perf_counter()
+    kw = dict(topic_docs=4096, topic_percent=85, topic_terms=12) if args.clustered else {}
     seg = synth.build_segment(args.docs, 4096, layout=args.layout,
-                              with_positions=args.op == "phrase")
+                              with_positions=args.op == "phrase", **kw)
     t1 = time.perf_counter()
     sr = search.SegmentReader.from_synth(seg, L=L)
     print("index built in %.1f s, staged in %.2f s (%.0f MB .doc, %.0f MB .pos, %.0f MB in HBM)" % (
@@ -84,6 +87,22 @@ def main():
         print("   hits/query: mean %.0f max %d" % (float(np.mean(totals)), int(np.max(totals))),
               flush=True)
         b.close()
+        if args.wand:
+            b = sr.batch(prep, args.k).configure(tile, stride, 0).set_wand(True).profile(True)
+            b.run()
+            whits, wcounts, wtotals = b.results()
+            ms = []
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                b.run()
+                ms.append(b.timings())
+            dt = (time.perf_counter() - t0) / args.steps
+            avg = np.mean(ms, axis=0)
+            print("   WAND: step %.2f ms  plan %.2f pilot %.2f score %.2f select %.2f  same top-k=%s  "
+                  "docs evaluated %.1f%% of the exhaustive run's hits" % (
+                      dt * 1e3, *avg, bool(np.array_equal(whits, hits)),
+                      100.0 * float(np.sum(wtotals)) / max(1.0, float(np.sum(totals)))), flush=True)
+            b.close()
 
 
 if __name__ == "__main__":
