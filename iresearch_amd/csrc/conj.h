@@ -97,6 +97,41 @@ __device__ __forceinline__ void decode_dir_block(const DevSegment& seg, uint64_t
 }
 
 constexpr uint32_t kConjWaves = 4;  // wavefronts (= lead blocks) per workgroup
+constexpr uint32_t kConjHash = 256;   // slots of the lead-doc hash table (128 keys: half full)
+
+// Where the other terms start for every lead item: the binary search of a term's block
+// directory for the first block reaching the lead item's first doc — SkipReader::Seek
+// (skip_list.hpp:208-249) — done once per (lead item, term) by ONE THREAD of a pre-pass
+// (inside k_conj a wavefront would walk the same dependent chain 64 lanes wide).
+// One thread per lead item of every conjunction; seek[(item_base + item) * (jt - 1) + i - 1].
+__global__ void __launch_bounds__(kThreads)
+k_conj_seek(const DevSegment* segs, const DevQuery* queries, const DevTail* tails, uint32_t jt,
+            const uint32_t* conj_units, const uint32_t* item_base /*[n_conj + 1]*/,
+            uint32_t n_conj, uint32_t* seek) {
+  const uint32_t t = blockIdx.x * kThreads + threadIdx.x;
+  if (t >= item_base[n_conj]) return;
+  uint32_t lo = 0, hi = n_conj;   // the unit whose items hold t: last c with item_base[c] <= t
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (item_base[mid] <= t) lo = mid; else hi = mid;
+  }
+  const uint32_t unit = conj_units[lo], item = t - item_base[lo];
+  const DevQuery qd = queries[unit];
+  const DevSegment& seg = segs[qd.seg];
+  const DevTail* tl = tails + uint64_t(unit) * jt;
+  const DevTail ld = tl[0];
+  const uint32_t r_lo = item < ld.nblk ? (item ? seg.blk_last[ld.dir_off + item - 1] + 1u : kDocMin)
+                                       : ld.first_doc;
+  for (uint32_t i = 1; i < qd.n_terms; ++i) {
+    const uint32_t* last = seg.blk_last + tl[i].dir_off;
+    uint32_t a = 0, b = tl[i].nblk;  // lower_bound(last, r_lo)
+    while (a < b) {
+      const uint32_t mid = (a + b) >> 1;
+      if (last[mid] < r_lo) a = mid + 1; else b = mid;
+    }
+    seek[uint64_t(t) * (jt - 1u) + (i - 1u)] = a;
+  }
+}
 
 struct ConjArgs {
   const DevSegment* segs;
@@ -105,6 +140,8 @@ struct ConjArgs {
   const PhraseWg* wgs;          // {unit, first lead item} per workgroup
   const DevTail* tails;         // [unit][jt] (k_plan)
   const uint32_t* bstar;        // threshold bin per unit (0 = none)
+  const uint32_t* seek;         // k_conj_seek
+  const uint32_t* unit_items;   // [nq] first row of the unit's lead items in `seek` (conj units)
   uint64_t* cands;
   uint32_t* cand_count;
   unsigned long long* hits;
@@ -115,6 +152,10 @@ struct ConjArgs {
   uint32_t wand;                // prune lead blocks by block-max bounds
 };
 
+__device__ __forceinline__ uint32_t conj_hash(uint32_t doc) {
+  return (doc * 0x9E3779B1u) >> 24;   // top 8 bits of a Fibonacci hash: kConjHash slots
+}
+
 template<int LAYOUT>
 __global__ void __launch_bounds__(kConjWaves * 64)
 k_conj(ConjArgs A, uint32_t pilot) {
@@ -123,7 +164,10 @@ k_conj(ConjArgs A, uint32_t pilot) {
   __shared__ uint32_t s_docs[kConjWaves][kBlock];
   __shared__ float s_score[kConjWaves][kBlock];
   __shared__ uint32_t s_norm[kConjWaves][kBlock];
-  __shared__ uint32_t s_cnt[kConjWaves][kBlock];   // terms that reached the doc so far
+  __shared__ uint32_t s_cnt[kConjWaves][kBlock];    // terms that reached the doc so far
+  __shared__ uint32_t s_alive[kConjWaves][kBlock + 1];  // docs alive among the first c
+  __shared__ uint32_t s_hkey[kConjWaves][kConjHash];    // lead doc -> its index (open addressing)
+  __shared__ uint32_t s_hval[kConjWaves][kConjHash];
   const uint32_t tid = threadIdx.x;
   const unsigned lane = tid & 63u;
   const uint32_t wv = tid >> 6;
@@ -151,6 +195,10 @@ k_conj(ConjArgs A, uint32_t pilot) {
   float* score = s_score[wv];
   uint32_t* nrm = s_norm[wv];
   uint32_t* cnt = s_cnt[wv];
+  uint32_t* alive = s_alive[wv];
+  uint32_t* hkey = s_hkey[wv];
+  uint32_t* hval = s_hval[wv];
+  const uint32_t* seek = A.seek + uint64_t(A.unit_items[unit] + item) * (A.jt - 1u);
 
   // ---- doc range of the lead block (from the directory: nothing decoded yet)
   uint32_t r_lo, r_hi;   // the lead block's docs lie in [r_lo, r_hi]
@@ -176,19 +224,11 @@ k_conj(ConjArgs A, uint32_t pilot) {
       } else if (i == 0) {
         ub = term_bound(qt, seg.terms[tl.term].tf_bound);
       } else {
-        // blocks of term i overlapping [r_lo, r_hi]: rows [a, z)
-        const uint32_t* last = seg.blk_last + tl.dir_off;
-        uint32_t a = 0, b = tl.nblk;
-        while (a < b) {
-          const uint32_t mid = (a + b) >> 1;
-          if (last[mid] < r_lo) a = mid + 1; else b = mid;
-        }
-        uint32_t z = a, zb = tl.nblk;   // first block whose predecessor ends at or behind r_hi
-        while (z < zb) {
-          const uint32_t mid = (z + zb) >> 1;
-          if (last[mid] < r_hi) z = mid + 1; else zb = mid;
-        }
-        z = z < tl.nblk ? z + 1u : tl.nblk;
+        // blocks of term i overlapping [r_lo, r_hi]: rows [a, z): from the seek table (the next
+        // lead item starts behind r_hi, so its first row bounds this item's last one)
+        const uint32_t a = seek[i - 1u];
+        uint32_t z = item + 1u < n_items ? seek[(A.jt - 1u) + i - 1u] + 1u : tl.nblk;
+        z = z < tl.nblk ? z : tl.nblk;
         for (uint32_t k = a + lane; k < z; k += 64) {
           const float s = score_value(qt, seg.blk_maxf[tl.dir_off + k], seg.blk_minn[tl.dir_off + k]);
           ub = s > ub ? s : ub;
@@ -213,6 +253,8 @@ k_conj(ConjArgs A, uint32_t pilot) {
 
   // ---- 1. the lead block: entry index 2*lane + h (block) or lane + 64*h (tail)
   uint32_t n = kBlock;
+  for (uint32_t h = lane; h < kConjHash; h += 64) hkey[h] = 0xFFFFFFFFu;
+  wave::sync();
   {
     const DevQTerm qt = s_qt[0];
     uint32_t d[2], f[2], e0, estep;
@@ -242,6 +284,11 @@ k_conj(ConjArgs A, uint32_t pilot) {
       nrm[idx] = nv;
       score[idx] = on ? score_value(qt, f[h], nv) : 0.f;
       cnt[idx] = on ? 1u : 0u;
+      if (on) {   // doc -> idx: linear probing, at most half of the slots are ever taken
+        uint32_t s = conj_hash(d[h]);
+        while (atomicCAS(&hkey[s], 0xFFFFFFFFu, d[h]) != 0xFFFFFFFFu) s = (s + 1u) & (kConjHash - 1u);
+        hval[s] = idx;
+      }
     }
   }
   wave::sync();
@@ -251,24 +298,38 @@ k_conj(ConjArgs A, uint32_t pilot) {
   for (uint32_t i = 1; i < m; ++i) {
     const DevTail tl = s_tl[i];
     const DevQTerm qt = s_qt[i];
+    // alive[c] = docs among the first c that every earlier term reached
+    {
+      const uint32_t a0 = (2u * lane < n && cnt[2u * lane] == i) ? 1u : 0u;
+      const uint32_t a1 = (2u * lane + 1u < n && cnt[2u * lane + 1u] == i) ? 1u : 0u;
+      const uint32_t incl = wave::inclusive_scan(a0 + a1);
+      if (lane == 0) alive[0] = 0u;
+      alive[2u * lane + 1u] = incl - a1;
+      alive[2u * lane + 2u] = incl;
+      wave::sync();
+      if (alive[kBlock] == 0u) return;   // no doc reached by every term so far: the block is done
+    }
     // a decoded posting of term i: is its doc one of the lead docs still alive?
-    // (w0, w1] = ranks of the lead docs that can equal it: those inside its block's doc range
-    auto put = [&](uint32_t doc, uint32_t f, uint32_t w0, uint32_t w1) {
+    auto put = [&](uint32_t doc, uint32_t f) {
       if (f == 0 || doc < dlo || doc > dhi) return;
-      const uint32_t c = count_le(docs, w0, w1, doc);
-      if (c > w0 && docs[c - 1] == doc && cnt[c - 1] == i) {
-        score[c - 1] += score_value(qt, f, nrm[c - 1]);
-        cnt[c - 1] = i + 1u;
+      uint32_t s = conj_hash(doc);
+      for (;;) {
+        const uint32_t k = hkey[s];
+        if (k == doc) {
+          const uint32_t c = hval[s];
+          if (cnt[c] == i) {
+            score[c] += score_value(qt, f, nrm[c]);
+            cnt[c] = i + 1u;
+          }
+          return;
+        }
+        if (k == 0xFFFFFFFFu) return;
+        s = (s + 1u) & (kConjHash - 1u);
       }
     };
     if (tl.nblk) {
       const uint32_t* last = seg.blk_last + tl.dir_off;
-      uint32_t a = 0, b = tl.nblk;  // lower_bound(last, dlo): first block reaching dlo
-      while (a < b) {
-        const uint32_t mid = (a + b) >> 1;
-        if (last[mid] < dlo) a = mid + 1; else b = mid;
-      }
-      for (uint32_t b0 = a; b0 < tl.nblk; b0 += 64) {
+      for (uint32_t b0 = seek[i - 1u]; b0 < tl.nblk; b0 += 64) {
         const uint32_t bl = b0 + lane;
         const bool valid = bl < tl.nblk;
         const uint32_t lst = valid ? last[bl] : 0xFFFFFFFFu;
@@ -277,11 +338,9 @@ k_conj(ConjArgs A, uint32_t pilot) {
         const uint32_t cp_l = reach ? count_le(docs, 0u, n, prv) : 0u;
         const uint32_t cl_l = reach ? count_le(docs, cp_l, n, lst) : 0u;
         // some lead doc that every earlier term reached lies in (prv, lst]
-        bool want = false;
-        for (uint32_t c = cp_l; c < cl_l && !want; ++c) want = cnt[c] == i;
+        const bool want = alive[cl_l] > alive[cp_l];
         BlkDir d{};
         if (want) d = seg.blk_dir[tl.dir_off + bl];
-        const uint32_t base_l = bl ? prv : kDocMin;
         uint64_t mask = wave::ballot(want);
         const bool more = wave::ballot(valid && !reach) == 0;  // no block started behind dhi yet
         while (mask) {
@@ -290,11 +349,9 @@ k_conj(ConjArgs A, uint32_t pilot) {
           uint32_t d0, d1, f0, f1;
           decode_dir_block<LAYOUT>(seg, tl.doc_start, wave::read_lane(d.bits, k),
                                    wave::read_lane(d.off, k), wave::read_lane(d.aoff, k),
-                                   wave::read_lane(base_l, k), lane, d0, d1, f0, f1);
-          const uint32_t w0 = wave::read_lane(cp_l, k), w1 = wave::read_lane(cl_l, k);
-          put(d0, f0, w0, w1);
-          put(d1, f1, w0, w1);
-          wave::sync();
+                                   wave::read_lane(d.prev_last, k), lane, d0, d1, f0, f1);
+          put(d0, f0);
+          put(d1, f1);
         }
         if (!more) break;
       }
@@ -304,13 +361,10 @@ k_conj(ConjArgs A, uint32_t pilot) {
       const uint32_t t1 = lane + 64u < tl.n ? seg.tail_docs[tl.tail_row + lane + 64u] : 0u;
       const uint32_t g0 = lane < tl.n ? seg.tail_freqs[tl.tail_row + lane] : 0u;
       const uint32_t g1 = lane + 64u < tl.n ? seg.tail_freqs[tl.tail_row + lane + 64u] : 0u;
-      put(t0, g0, 0u, n);
-      put(t1, g1, 0u, n);
+      put(t0, g0);
+      put(t1, g1);
     }
     wave::sync();
-    // no doc reached by every term so far: the block is done
-    const bool alive = (lane < n && cnt[lane] == i + 1u) || (lane + 64u < n && cnt[lane + 64u] == i + 1u);
-    if (wave::ballot(alive) == 0) return;
   }
 
   // ---- 3. docs every term reached

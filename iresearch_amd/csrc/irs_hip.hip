@@ -120,6 +120,8 @@ struct irs_hip_batch {
   std::vector<uint32_t> conj_items;   // lead items of every conj unit
   uint32_t n_conj_wgs = 0;
   DevBuf d_tile_units, d_conj_units, d_conj_items, d_conj_wgs, d_conj_hist;
+  DevBuf d_conj_item_base, d_conj_unit_items, d_conj_seek;   // k_conj_seek
+  uint32_t conj_total_items = 0;
   bool phrase = false;  // a batch of by_phrase queries (k_phrase instead of k_pilot + k_score)
   void* h_pin = nullptr;       // page-locked staging for irs_hip_batch_results
   size_t h_pin_bytes = 0;
@@ -394,11 +396,17 @@ bool launch_conj(irs_hip_batch* b, rt::stream_t st) {
   a.cand_count = b->d_cand_count.as<uint32_t>();
   a.hits = b->d_hits.as<unsigned long long>();
   a.hist = b->d_conj_hist.as<uint32_t>();
+  a.seek = b->d_conj_seek.as<uint32_t>();
+  a.unit_items = b->d_conj_unit_items.as<uint32_t>();
   a.jt = b->jt;
   a.cand_cap = b->cand_cap;
   a.pilot_stride = b->stride_eff == 1 ? 1u : b->stride;
   a.wand = b->wand ? 1u : 0u;
   if (!rt::dmemset(b->d_conj_hist.p, 0, b->d_conj_hist.n, st)) return false;
+  RT_LAUNCH(k_conj_seek, (b->conj_total_items + kThreads - 1) / kThreads, kThreads, 0, st,
+            b->d_segs.as<DevSegment>(), b->d_queries.as<DevQuery>(), b->d_tails.as<DevTail>(),
+            b->jt, b->d_conj_units.as<uint32_t>(), b->d_conj_item_base.as<uint32_t>(),
+            uint32_t(b->conj_units.size()), b->d_conj_seek.as<uint32_t>());
   RT_LAUNCH((k_conj<LAYOUT>), b->n_conj_wgs, kConjWaves * 64, 0, st, a, 1u);
   RT_LAUNCH(k_conj_threshold, uint32_t(b->conj_units.size()), 64, 0, st,
             b->d_queries.as<DevQuery>(), b->d_conj_units.as<uint32_t>(),
@@ -422,8 +430,9 @@ bool launch_items(irs_hip_batch* b, rt::stream_t st) {
   RT_LAUNCH(k_scan_totals, parts, kThreads, 0, st, off, n, totals);
   RT_LAUNCH(k_scan_parts, 1, 64, 0, st, totals, parts);
   RT_LAUNCH(k_scan_apply, parts, kThreads, 0, st, off, n, totals);
-  RT_LAUNCH(k_items_fill, b->nq * tb, kThreads, 0, st, b->d_segs.as<DevSegment>(),
-            b->d_queries.as<DevQuery>(), b->d_qterms.as<DevQTerm>(), b->jt, b->tile, tb,
+  const uint32_t tb4 = (b->max_tiles + kWaves - 1) / kWaves;
+  RT_LAUNCH(k_items_fill, b->nq * tb4, kThreads, 0, st, b->d_segs.as<DevSegment>(),
+            b->d_queries.as<DevQuery>(), b->d_qterms.as<DevQTerm>(), b->jt, b->tile, tb4,
             b->nw_log2, caches_off(b), b->d_first.as<uint32_t>(), b->d_tails.as<DevTail>(), off,
             b->total_tiles, b->d_items.as<ItemG>(), b->wand ? b->d_tile_ub.as<float>() : nullptr);
   return rt::last_error_ok();
@@ -1210,6 +1219,28 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
         rc = IRS_HIP_EUNSUPPORTED;
       } else {
         b->n_conj_wgs = uint32_t(wgs.size());
+        // rows of the seek table: the lead items of the conj units, unit after unit
+        std::vector<uint32_t> item_base(b->conj_units.size() + 1, 0), unit_items(nq, 0);
+        uint64_t total = 0;
+        for (size_t c = 0; c < b->conj_units.size(); ++c) {
+          item_base[c] = uint32_t(total);
+          unit_items[b->conj_units[c]] = uint32_t(total);
+          total += b->conj_items[c];
+        }
+        if (total > 0x7FFFFFFFull) rc = IRS_HIP_EUNSUPPORTED;
+        item_base[b->conj_units.size()] = uint32_t(total);
+        b->conj_total_items = uint32_t(total);
+        if (rc == IRS_HIP_OK &&
+            (!b->d_conj_item_base.alloc(item_base.size() * 4) ||
+             !b->d_conj_unit_items.alloc(unit_items.size() * 4) ||
+             !b->d_conj_seek.alloc((total + 2) * uint64_t(kMaxTerms) * 4)))
+          rc = IRS_HIP_ENOMEM;
+        if (rc == IRS_HIP_OK &&
+            (!rt::h2d(b->d_conj_item_base.p, item_base.data(), item_base.size() * 4, nullptr) ||
+             !rt::h2d(b->d_conj_unit_items.p, unit_items.data(), unit_items.size() * 4, nullptr)))
+          rc = IRS_HIP_EHIP;
+        if (rc != IRS_HIP_OK) {
+        } else
         if (!b->d_conj_wgs.alloc(std::max<size_t>(1, wgs.size()) * sizeof(PhraseWg)) ||
             !b->d_conj_units.alloc(b->conj_units.size() * 4) ||
             !b->d_conj_items.alloc(b->conj_items.size() * 4) ||

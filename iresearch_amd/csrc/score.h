@@ -697,68 +697,70 @@ k_items_count(const DevQuery* queries, uint32_t jt, uint32_t tile_docs, uint32_t
   tile_cnt[qd.tile_base + tile] = n;
 }
 
-// One THREAD per (unit, doc tile) writes the tile's work items: everything the scoring loop
-// would otherwise derive per block — where the payload lives, the bit widths out of the
+// One wavefront per (unit, doc tile) writes the tile's work items: everything the scoring
+// loop would otherwise derive per block — where the payload lives, the bit widths out of the
 // block directory, the preceding block's last doc relative to the tile, the term's scaled c0
-// and table row — goes into the record once.  (A thread per tile, not a wavefront: the
-// per-tile set-up is then paid by one lane instead of 64, and the directory reads of the 64
-// tiles a wavefront handles are all in flight together — 1.35 ms -> see DESIGN.md.)
-// grid = n_units * tb, tb = ceil(max tiles / kThreads).
+// and table row — goes into the record once.  grid = n_units * tb, tb = ceil(max tiles / kWaves).
 __global__ void __launch_bounds__(kThreads)
 k_items_fill(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms,
              uint32_t jt, uint32_t tile_docs, uint32_t tb, uint32_t nw_log2,
              uint32_t caches_off, const uint32_t* first, const DevTail* tails,
              const uint32_t* tile_off, uint32_t total_tiles, ItemG* items,
              float* tile_ub /*WAND: upper bound of any doc's score in the tile; else null*/) {
+  __shared__ uint32_t s_pre[kWaves][kMaxTerms + 1];  // exclusive prefix sums of the block counts
+  __shared__ uint32_t s_b0[kWaves][kMaxTerms];
+  __shared__ uint32_t s_ub[kWaves][kMaxTerms];       // WAND: per term, largest block-max score (float bits)
+  const unsigned lane = threadIdx.x & 63u;
+  const uint32_t wv = threadIdx.x >> 6;
   const uint32_t unit = blockIdx.x / tb;
-  const uint32_t tile = (blockIdx.x % tb) * kThreads + threadIdx.x;
+  const uint32_t tile = (blockIdx.x % tb) * kWaves + wv;
   const DevQuery qd = queries[unit];
-  if (tile >= qd.n_tiles) return;
+  if (tile >= qd.n_tiles) return;   // whole wavefront
   const DevSegment& seg = segs[qd.seg];
   const uint32_t* f0 = first + qd.first_off + uint64_t(tile) * jt;
   const DevTail* tl = tails + uint64_t(unit) * jt;
   const DevQTerm* qts = qterms + qd.first_term;
   const uint32_t lo = kDocMin + tile * tile_docs;
+  uint32_t nb = 0, b0 = 0;
+  bool tail_here = false;
+  if (lane < qd.n_terms) {
+    b0 = f0[lane];
+    uint32_t b1 = f0[jt + lane] + 1u;
+    b1 = b1 < tl[lane].nblk ? b1 : tl[lane].nblk;
+    nb = b1 > b0 ? b1 - b0 : 0u;
+    tail_here = tl[lane].n && tl[lane].first_doc < lo + tile_docs && tl[lane].last_doc >= lo;
+  }
+  const uint32_t incl = wave::inclusive_scan(nb);
+  if (lane <= kMaxTerms) s_pre[wv][lane] = incl - nb;   // lanes >= n_terms hold the total
+  if (lane < kMaxTerms) s_b0[wv][lane] = b0;
+  if (lane < kMaxTerms) s_ub[wv][lane] = 0u;
+  const uint64_t tail_mask = wave::ballot(tail_here);
+  wave::sync();
+  const uint32_t n_blocks = s_pre[wv][kMaxTerms];
+  const uint32_t n = n_blocks + uint32_t(__builtin_popcountll(tail_mask));
   const uint32_t ut = qd.tile_base + tile;
-  const uint32_t off0 = tile_off[ut], n = tile_off[ut + 1] - off0;
+  const uint32_t off0 = tile_off[ut];
   const uint32_t nw = 1u << nw_log2;
   const uint32_t a = n >> nw_log2, r = n & (nw - 1u);
   const uint64_t pk = reinterpret_cast<uint64_t>(seg.pk);
-  const BlkDir* dir = seg.blk_dir;
-  const uint8_t* doc = seg.doc;
-  const uint32_t rows = table_rows(qd.n_caches);
 
-  // a position in the tile's sequence of block items: block b of term slot j
-  struct Cursor {
-    uint32_t j, b, b_end;
-    bool valid;
-  };
-  auto enter = [&](Cursor& c) {   // first term slot at or behind c.j with a block in the tile
-    for (; c.j < qd.n_terms; ++c.j) {
-      c.b = f0[c.j];
-      uint32_t b1 = f0[jt + c.j] + 1u;
-      b1 = b1 < tl[c.j].nblk ? b1 : tl[c.j].nblk;
-      c.b_end = b1;
-      if (c.b < c.b_end) return;
-    }
-    c.valid = false;
-  };
-  auto advance = [&](Cursor& c) {
-    if (!c.valid) return;
-    if (++c.b >= c.b_end) {
-      ++c.j;
-      enter(c);
-    }
+  // term slot and directory row of block item g
+  auto locate = [&](uint32_t g, uint32_t& j, uint64_t& e) {
+    j = 0;
+    for (uint32_t t = 1; t < qd.n_terms; ++t) j += s_pre[wv][t] <= g ? 1u : 0u;
+    e = tl[j].dir_off + s_b0[wv][j] + (g - s_pre[wv][j]);
   };
   // the value of an ALL-EQUAL freq block: vint behind the doc part and the 0 header byte
   auto freq_const = [&](uint32_t j, const BlkDir& d) {
     uint32_t len;
-    return vint_from(wave::load_u64(doc + tl[j].doc_start + d.off + 2u + 16u * (d.bits & 0xFFu)), &len);
+    return vint_from(wave::load_u64(seg.doc + tl[j].doc_start + d.off + 2u + 16u * (d.bits & 0xFFu)),
+                     &len);
   };
   // straight-line path: a scorer of the table family, the block in the packed image, and an
   // all-equal frequency that fits the record's 16 bits.  cls: 0 = generic, 1 = straight-line
   // with general frequencies, 2 = every frequency of the block has a table row; bit 2: the
   // square-root form (only tells general items apart)
+  const uint32_t rows = table_rows(qd.n_caches);
   auto classify = [&](uint32_t j, const BlkDir& d, uint32_t& fconst) {
     fconst = 0;
     const uint32_t dbits = d.bits & 0xFFu, fbits = d.bits >> 8;
@@ -771,80 +773,81 @@ k_items_fill(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qt
     }
     return (1u << fbits) <= rows ? 2u : (sqrt_kind(qts[j].kind) ? 5u : 1u);
   };
-  // where item g of the tile goes: wavefront g % nw, its i-th item; each wavefront's share
-  // is contiguous.  Even items of a wavefront carry the pairing flags.
-  auto place = [&](uint32_t g, ItemG& I, uint32_t cls, uint32_t next_cls) {
-    const uint32_t w = g & (nw - 1u), i = g >> nw_log2;
-    const uint32_t n_w = a + (w < r ? 1u : 0u);
-    if (!(i & 1u)) {
-      if (i + 1u == n_w) I.aux |= kItemSolo;
-      else if (cls && next_cls == cls) I.aux |= kItemPair;
+  for (uint32_t g0 = 0; g0 < n; g0 += 64) {   // (whole wavefront: shuffles inside)
+    const uint32_t g = g0 + lane;
+    ItemG I{};
+    uint32_t cls = 0;
+    if (g < n_blocks) {
+      uint32_t j, fconst;
+      uint64_t e;
+      locate(g, j, e);
+      const BlkDir d = seg.blk_dir[e];
+      if (tile_ub)   // positive floats order like their bit patterns
+        atomicMax(&s_ub[wv][j], __float_as_uint(score_value(qts[j], seg.blk_maxf[e], seg.blk_minn[e])));
+      cls = classify(j, d, fconst);
+      const bool fast = cls != 0u;
+      const uint32_t slot = qts[j].cache_id < kMaxCaches ? qts[j].cache_id : 0u;
+      I.addr = fast ? pk + (uint64_t(d.aoff) << 4)
+                    : reinterpret_cast<uint64_t>(seg.doc) + tl[j].doc_start + d.off;
+      I.dbits = d.bits & 0xFFu;
+      I.fbits = d.bits >> 8;
+      I.base = d.prev_last - lo;
+      I.cs = qts[j].c0 * qd.fx_mul;
+      // table items: an all-equal frequency selects its row right here
+      I.tab = caches_off + (slot * rows + (cls == 2u ? fconst : 0u)) * 1024u;
+      I.aux = j | (fast ? 0u : kItemSlow) | (sqrt_kind(qts[j].kind) ? kItemSqrt : 0u) |
+              (cls == 2u ? kItemTable : fconst << kItemFreqShift);
+    } else if (g < n) {
+      // the (g - n_blocks)-th term whose tail reaches into the tile
+      uint64_t m = tail_mask;
+      for (uint32_t s = g - n_blocks; s; --s) m &= m - 1;
+      const uint32_t j = uint32_t(__builtin_ctzll(m));
+      I.addr = pk;   // readable; never used
+      I.dbits = 1;
+      I.fbits = 1;
+      I.base = tl[j].n;
+      I.cs = 0.f;
+      I.tab = tl[j].tail_row;
+      I.aux = j | kItemSlow | kItemTail;
     }
-    items[off0 + w * a + (w < r ? w : r) + i] = I;
-  };
-
-  Cursor cur{0, 0, 0, true};
-  enter(cur);
-  Cursor ahead = cur;   // the wavefront's next item: nw items further on
-  for (uint32_t k = 0; k < nw; ++k) advance(ahead);
-  uint32_t g = 0;
-  // WAND: bound of the tile = sum over the terms of their largest block-max score in it
-  // (the min lambda of block_disjunction sums the sub-iterators' bounds, disjunction.hpp:1133-1167)
-  float bound = 0.f, term_ub = 0.f;
-  uint32_t bound_j = 0;
-  for (; cur.valid; ++g) {
-    const uint32_t j = cur.j;
-    if (tile_ub) {
-      if (j != bound_j) {
-        bound += term_ub;
-        term_ub = 0.f;
-        bound_j = j;
+    // class of the wavefront's next item, g + nw: computed by lane + nw, or — for the last
+    // nw lanes — looked up directly
+    uint32_t next_cls = __shfl_down(cls, nw, 64);
+    if (lane + nw >= 64u) {
+      next_cls = 0;
+      if (g + nw < n_blocks) {
+        uint32_t j2, fconst2;
+        uint64_t e2;
+        locate(g + nw, j2, e2);
+        next_cls = classify(j2, seg.blk_dir[e2], fconst2);
       }
-      const uint64_t e = tl[j].dir_off + cur.b;
-      const float ub = score_value(qts[j], seg.blk_maxf[e], seg.blk_minn[e]);
-      term_ub = ub > term_ub ? ub : term_ub;
     }
-    const BlkDir d = dir[tl[j].dir_off + cur.b];
-    uint32_t fconst, cls = classify(j, d, fconst), next_cls = 0;
-    if (ahead.valid) {
-      uint32_t fc2;
-      next_cls = classify(ahead.j, dir[tl[ahead.j].dir_off + ahead.b], fc2);
+    if (g < n) {
+      const uint32_t w = g & (nw - 1u), i = g >> nw_log2;
+      const uint32_t n_w = a + (w < r ? 1u : 0u);
+      if (!(i & 1u)) {
+        if (i + 1u == n_w) I.aux |= kItemSolo;
+        else if (cls && g + nw < n_blocks && next_cls == cls) I.aux |= kItemPair;
+      }
+      items[off0 + w * a + (w < r ? w : r) + i] = I;
     }
-    const bool fast = cls != 0u;
-    const uint32_t slot = qts[j].cache_id < kMaxCaches ? qts[j].cache_id : 0u;
-    ItemG I;
-    I.addr = fast ? pk + (uint64_t(d.aoff) << 4)
-                  : reinterpret_cast<uint64_t>(doc) + tl[j].doc_start + d.off;
-    I.dbits = d.bits & 0xFFu;
-    I.fbits = d.bits >> 8;
-    I.base = d.prev_last - lo;
-    I.cs = qts[j].c0 * qd.fx_mul;
-    // table items: an all-equal frequency selects its row right here
-    I.tab = caches_off + (slot * rows + (cls == 2u ? fconst : 0u)) * 1024u;
-    I.aux = j | (fast ? 0u : kItemSlow) | (sqrt_kind(qts[j].kind) ? kItemSqrt : 0u) |
-            (cls == 2u ? kItemTable : fconst << kItemFreqShift);
-    place(g, I, cls, next_cls);
-    advance(cur);
-    advance(ahead);
   }
-  // one item per term whose decoded tail reaches into the tile
-  for (uint32_t j = 0; j < qd.n_terms; ++j) {
-    if (!(tl[j].n && tl[j].first_doc < lo + tile_docs && tl[j].last_doc >= lo)) continue;
-    ItemG I;
-    I.addr = pk;   // readable; never used
-    I.dbits = 1;
-    I.fbits = 1;
-    I.base = tl[j].n;
-    I.cs = 0.f;
-    I.tab = tl[j].tail_row;
-    I.aux = j | kItemSlow | kItemTail;
-    place(g++, I, 0u, 0u);
-    // (a decoded tail has no block-max entry: the term's global bound; counted on top of the
-    // term's blocks in the tile, which only loosens the bound)
-    if (tile_ub) bound += term_bound(qts[j], seg.terms[tl[j].term].tf_bound);
+  if (tile_ub) {
+    // WAND: bound of the tile = sum over the terms of their largest block-max score in it
+    // (the min lambda of block_disjunction sums the sub-iterators' bounds,
+    // disjunction.hpp:1133-1167); a decoded tail has no block-max entry: the term's global
+    // bound, counted on top of its blocks (which only loosens the bound)
+    wave::sync();
+    float ub = 0.f;
+    if (lane < qd.n_terms) {
+      ub = __uint_as_float(s_ub[wv][lane]);
+      if (tail_here) ub += term_bound(qts[lane], seg.terms[tl[lane].term].tf_bound);
+    }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) ub += __shfl_xor(ub, sft, 64);
+    if (lane == 0) tile_ub[ut] = ub * (1.f + 1e-6f);
   }
-  if (tile_ub) tile_ub[ut] = (bound + term_ub) * (1.f + 1e-6f);
-  if (ut + 1u == total_tiles) {   // readable slack behind the last list
+  if (ut + 1u == total_tiles && lane < kItemSlack) {   // readable slack behind the last list
     ItemG I;
     I.addr = pk;
     I.dbits = 1;
@@ -853,7 +856,7 @@ k_items_fill(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qt
     I.cs = 0.f;
     I.tab = caches_off;
     I.aux = kItemSlow | kItemTail | kItemSolo;
-    for (uint32_t k = 0; k < kItemSlack; ++k) items[off0 + n + k] = I;
+    items[off0 + n + lane] = I;
   }
 }
 

@@ -350,6 +350,10 @@ inline unsigned atomicMax(unsigned* p, unsigned v) {
   }
   return old;
 }
+inline unsigned atomicCAS(unsigned* p, unsigned expected, unsigned desired) {
+  __atomic_compare_exchange_n(p, &expected, desired, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
+  return expected;
+}
 inline unsigned atomicOr(unsigned* p, unsigned v) {
   return __atomic_fetch_or(p, v, __ATOMIC_RELAXED);
 }

@@ -218,18 +218,25 @@ def test_config3_or8_top1000_subset(gpulib):
     sr.close()
 
 
-def test_config5_shape_and_phrase_tfidf(gpulib):
-    """BASELINE config 5 shape on one segment of one GPU: AND-of-2..4 and 2-word phrases
-    scored by TF-IDF without norms, on a field with positions (2 M docs), against the oracle.
-    (Block-max WAND pruning, the remaining part of config 5, is not built yet: results are
-    exhaustive, which is what pruning must reproduce.)"""
-    seg = synth.build_segment(2_000_000, 4096, with_positions=True)
+def test_config5_and_phrase_tfidf_wand(gpulib):
+    """BASELINE config 5 at its per-GPU size: one 6.25 M-doc segment of the 50 M-doc index
+    (50 M docs over 8 GPUs) with positions; AND-of-2..4 and 2/3-word phrases scored by TF-IDF
+    without norms (MaxFreq wand data, tfidf.cpp:364-386), against the oracle; and the same AND
+    batch with block-max WAND pruning must return the exhaustive top k."""
+    seg = synth.build_segment(6_250_000, 4096, with_positions=True)
     sr = search.SegmentReader.from_synth(seg, L=gpulib)
     ands = []
     for n in (2, 3, 4):
         for row in synth.make_queries(6, n, 16, 2048, synth.SEED + 5 + n):
             ands.append(And([by_term(int(r) - 1) for r in row]))
-    cases.run_and_check(gpulib, seg, ands, TFIDF(False), 100, sr=sr)
+    h0, c0, t0 = cases.run_and_check(gpulib, seg, ands, TFIDF(False), 100, sr=sr)
+    prep = search.prepare(ands, TFIDF(False), [parity.segment_stats(seg)])
+    wb = sr.batch(prep, 100).set_wand(True)
+    h1, c1, t1 = wb.run().results()
+    wb.close()
+    assert np.array_equal(c0, c1) and (t1 <= t0).all()
+    for q in range(len(ands)):
+        assert np.array_equal(h0[q, :int(c0[q])], h1[q, :int(c0[q])]), q
     phrases = [by_phrase([int(r) - 1 for r in row])
                for row in synth.make_queries(24, 2, 4, 512, synth.SEED + 9)]
     phrases += [by_phrase([int(r) - 1 for r in row])
@@ -248,7 +255,7 @@ def test_config3_full_size_properties(gpulib):
       * bitwise the same answer for another tile size / pilot stride;
       * the index cut into 8 segments (private doc ids, global statistics) and merged on the
         device gives the same top-k as the single segment, doc ids mapped back;
-      * full oracle parity for the first queries."""
+      * full oracle parity for the first 24 queries."""
     import ctypes
 
     import torch
@@ -280,7 +287,7 @@ def test_config3_full_size_properties(gpulib):
     h2, c2, t2 = b2.run().results()
     b2.close()
     assert np.array_equal(hits, h2) and np.array_equal(counts, c2) and np.array_equal(totals, t2)
-    parity.check_single_segment(seg, filters[:6], BM25(), k, hits[:6], counts[:6], totals[:6])
+    parity.check_single_segment(seg, filters[:24], BM25(), k, hits[:24], counts[:24], totals[:24])
     sr.close()
 
     per = n_docs // n_segs

@@ -34,6 +34,8 @@ cases.case_wide_norms(L, 2)
 cases.case_pilot_misled(L)
 cases.case_merge_ties(L)
 cases.case_boolean_reference_vectors(L)
+cases.case_wand_equals_exhaustive(L, num_docs=30_000, max_rank=128, ks=(10,))
+cases.case_decode_reference_packed(L, 1)
 cases.case_errors(L)
 cases.case_phrase_errors(L)
 print("asan emulator run: clean")
