@@ -112,6 +112,10 @@ def main():
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--stride", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--config", type=int, default=3, choices=[3, 5],
+                    help="3 (default, with --gpus > 1: config 4): OR-of-8 BM25 top-1000 on 10 M docs; "
+                         "5: AND-of-2..4 + 2-word by_phrase, TF-IDF, block-max WAND, on --docs "
+                         "(default 50 M) docs in 8 segments with positions, 8 / N per GPU")
     ap.add_argument("--query-sets", type=int, default=4,
                     help="distinct query batches of the same distribution the steps rotate over "
                          "(set 0 is BASELINE config 3's; no step replays the previous one)")
@@ -120,6 +124,8 @@ def main():
     ap.add_argument("--force-segments", action="store_true",
                     help="use the multi-segment path (merge kernel) even on one GPU")
     args = ap.parse_args()
+    if args.config == 5:
+        return main_config5(args)
 
     import torch
     import torch.distributed as dist
@@ -358,6 +364,149 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_config5(args):
+    """BASELINE config 5: AND-of-2..4 + 2-word by_phrase, TF-IDF (no norms => MaxFreq wand data,
+    tfidf.cpp:364-386), block-max WAND, a 50 M-doc index with positions in 8 segments, 8 / N per
+    GPU.  A step = one batch of --queries AND queries + one batch of --queries phrase queries
+    over the rank's segments; the per-segment top-k lists are exchanged and merged as in config 4.
+    Reports A(q) (exhaustive algorithmic bytes) AND the bytes the kernels really decoded."""
+    import torch
+    import torch.distributed as dist
+
+    from iresearch_amd import _lib, distributed, search, synth
+    from iresearch_amd.search import TFIDF, And, by_phrase, by_term
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    L = _lib.lib()
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    docs = args.docs if args.docs != 10_000_000 else 50_000_000
+    n_segments = args.segments
+    my = distributed.segments_of_rank(n_segments, rank, world)
+    per = docs // n_segments
+    t0 = time.perf_counter()
+    segs = {s: synth.build_segment(per if s < n_segments - 1 else docs - per * (n_segments - 1),
+                                   4096, first_doc=s * per, with_positions=True) for s in my}
+    log("built %d segment(s) with positions in %.1f s" % (len(my), time.perf_counter() - t0))
+    local_stats = {s: (segs[s].docs_with_field, segs[s].total_term_freq,
+                       np.asarray(segs[s].metas["docs_count"])) for s in my}
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, local_stats)
+        all_stats = {}
+        for g in gathered:
+            all_stats.update(g)
+    else:
+        all_stats = local_stats
+    seg_stats = [search.SegmentStats(*all_stats[s]) for s in range(n_segments)]
+    readers = [search.SegmentReader.from_synth(segs[s], device=local_rank, L=L) for s in my]
+    log("staged: %.1f MB resident on rank 0" % (sum(r.device_bytes() for r in readers) / 1e6))
+    nq, k = args.queries, args.k if args.k != 1000 else 100
+    ands = []
+    for n_terms in (2, 3, 4):
+        for row in synth.make_queries((nq + 2) // 3, n_terms, 16, 4096, synth.SEED + 5 + n_terms):
+            ands.append(And([by_term(int(r) - 1) for r in row]))
+    ands = ands[:nq]
+    phrases = [by_phrase([int(r) - 1 for r in row])
+               for row in synth.make_queries(nq, 2, 16, 4096, synth.SEED + 9)]
+    sc = TFIDF(False)
+    bat = {}
+    for name, fl in (("and", ands), ("phrase", phrases)):
+        prep = search.prepare(fl, sc, seg_stats)
+        b = search.QueryBatch(readers, prep, k) if len(readers) > 1 else readers[0].batch(prep, k)
+        if name == "and":
+            b.set_wand(True)
+        b.profile(True)
+        bat[name] = b
+    sptr = C_void(torch.cuda.current_stream(dev).cuda_stream)
+    ex = {name: distributed.PipelinedExchange(L, local_rank, n_segments, rank, world, nq, k, dev)
+          for name in bat}
+    it = {"n": 0}
+
+    def step():
+        ph = it["n"] & 1
+        it["n"] += 1
+        for name, b in bat.items():
+            b.run(sptr)
+        for name, b in bat.items():
+            ex[name].finish(sptr)
+            hp, cp = ex[name].slot(ph, 0)
+            b.results_to_device(hp, cp, sptr)
+            ex[name].start(ph)
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    for e in ex.values():
+        e.finish(sptr)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kms = []
+    for _ in range(args.steps):
+        step()
+        if rank == 0:
+            kms.append({n: b.timings() for n, b in bat.items()})
+    for e in ex.values():
+        e.finish(sptr)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    alg = {n: b.work() for n, b in bat.items()}
+    touched = {n: b.touched() for n, b in bat.items()}
+    vals = [alg["and"][0], alg["phrase"][0], touched["and"][0], touched["phrase"][0],
+            touched["phrase"][1]]
+    if world > 1:
+        t = torch.tensor(vals, dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        vals = [float(x) for x in t.tolist()]
+    if rank == 0:
+        ms = {n: float(np.mean([x[n][_lib.K_SCORE] for x in kms])) for n in bat}
+        rank0_touched = touched["and"][0] + touched["phrase"][0]
+        out = {
+            "metric": "queries/sec AND + by_phrase (positions), block-max WAND, TF-IDF, 50M-doc index @N GPU",
+            "value": round(args.steps * 2 * nq / elapsed, 2), "unit": "queries/s", "n_gpus": world,
+            "steps": args.steps, "warmup": max(1, args.warmup),
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u32+f32", "data": "synthetic",
+            "config": {
+                "workload": "config 5: %d AND-of-2..4 + %d 2-word by_phrase queries/step, TF-IDF, "
+                            "top-%d, %d-doc Zipfian index with positions, %d segments, WAND on the "
+                            "AND batch" % (nq, nq, k, docs, n_segments),
+                "segments": n_segments, "queries_per_step": 2 * nq,
+                "algorithmic_bytes_per_step": {"and": int(vals[0]), "phrase_doc_side": int(vals[1])},
+                "bytes_touched_per_step": {"and_doc_and_norm": int(vals[2]),
+                                           "phrase_doc": int(vals[3]),
+                                           "phrase_positions_read": int(vals[4])},
+                "parallelism": "%d segments over %d GPU(s), all-gather of per-segment top-k + GPU merge"
+                               % (n_segments, world)},
+            "roofline": {"bound": "hbm", "kernel": "k_conj + k_phrase (rank 0)",
+                         "achieved": round(rank0_touched / ((ms["and"] + ms["phrase"]) * 1e-3) / 1e9, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(rank0_touched / ((ms["and"] + ms["phrase"]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                         "traffic": None, "kernel_ms": {"k_conj": round(ms["and"], 4),
+                                                        "k_phrase": round(ms["phrase"], 4)},
+                         "note": "achieved = bytes actually decoded / kernel time (block-driven "
+                                 "kernels touch less than A(q))"},
+            "cpu_baseline": None,
+        }
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -27,6 +27,8 @@ extern "C" {
 #define IRS_HIP_NO_TERM 0xFFFFFFFFu
 #define IRS_HIP_POS_OFFSETS 1u
 #define IRS_HIP_POS_PAYLOADS 2u
+#define IRS_HIP_NORM2 0u
+#define IRS_HIP_NORM_LEGACY 1u
 
 /* Errors replace the reference's exceptions (io_error / index_error,
  * formats_10.cpp:158-160, 3410-3415): never thrown across this boundary. */
@@ -90,7 +92,12 @@ typedef struct irs_hip_segment_desc {
                              * Both change the vint tail of `.pos` (formats_10.cpp:728-760) and
                              * are answered with IRS_HIP_EUNSUPPORTED for now instead of being
                              * mis-read; 0 = positions only */
-  uint32_t reserved0;
+  uint32_t norm_kind;       /* IRS_HIP_NORM2 (0): `norms` are Norm2 values, big-endian integers of
+                             * norm_width bytes (norm.hpp:128-251) — the field length in tokens.
+                             * IRS_HIP_NORM_LEGACY (1): the legacy `Norm` feature (norm.hpp:46-70):
+                             * one little-endian float per doc, 1/sqrt(length) (norm_width 4; the
+                             * adapter decodes the sparse zvfloat column into this dense array,
+                             * Norm::DEFAULT() = 1 for docs without a value) */
 } irs_hip_segment_desc;
 
 typedef struct irs_hip_segment irs_hip_segment; /* opaque, immutable after open */
@@ -161,7 +168,8 @@ typedef enum irs_hip_op {
 
 /* Which ScoreFunction Scorer::prepare_scorer would have built. */
 typedef enum irs_hip_scorer_kind {
-  IRS_HIP_SCORE_BM25 = 0,      /* bm25.cpp:321-364; norm path by segment norm_width (:466-476);
+  IRS_HIP_SCORE_BM25 = 0,      /* bm25.cpp:321-364; norm path by segment norm_width (:466-476),
+                                  legacy Norm column => :333-337, 242-249;
                                   no norm column => norm == 1 (:487-489)               */
   IRS_HIP_SCORE_BM15 = 1,      /* bm25.cpp:288-319 (b == 0)                            */
   IRS_HIP_SCORE_BM1 = 2,       /* bm25.cpp:262-286 (k == 0): constant                  */
@@ -296,6 +304,11 @@ int irs_hip_batch_timings(irs_hip_batch* batch, float ms[IRS_HIP_K_COUNT]);
  * posting (norm_width) + 8*k result bytes; and the number of postings. */
 int irs_hip_batch_work(irs_hip_batch* batch, uint64_t* algorithmic_bytes,
                        uint64_t* postings);
+/* What the last run of a conjunction / phrase batch really read, next to the algorithmic
+ * bytes above ("report both A(q) and bytes actually touched"): encoded bytes of
+ * the `.doc` blocks it decoded plus the norm bytes it read, and the number of positions it
+ * read from `.pos`.  (Doc-tile batches read every block of every term: A(q).) */
+int irs_hip_batch_touched(irs_hip_batch* batch, uint64_t* doc_bytes, uint64_t* positions);
 /* How many times fetching results had to re-execute the batch so far: the pilot's
  * estimated threshold left fewer than k candidates for some query (re-run with the
  * provable threshold), or the candidate buffer overflowed (exact re-run, then a

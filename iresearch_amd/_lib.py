@@ -43,7 +43,7 @@ class SegmentDesc(C.Structure):
         ("norms", C.c_void_p), ("norm_width", C.c_uint32), ("norm_min_doc", C.c_uint32),
         ("norm_count", C.c_uint64), ("terms", C.c_void_p), ("num_terms", C.c_uint32),
         ("wand_count", C.c_uint32), ("pos_file", C.c_void_p), ("pos_file_len", C.c_uint64),
-        ("pos_features", C.c_uint32), ("reserved0", C.c_uint32),
+        ("pos_features", C.c_uint32), ("norm_kind", C.c_uint32),
     ]
 
 
@@ -63,7 +63,7 @@ SYMBOLS = (
     "irs_hip_batch_results_to_device", "irs_hip_batch_destroy",
     "irs_hip_query_batch", "irs_hip_batch_configure", "irs_hip_batch_profile",
     "irs_hip_batch_timings", "irs_hip_batch_work", "irs_hip_batch_reruns", "irs_hip_merge_topk",
-    "irs_hip_batch_set_wand", "irs_hip_term_blockmax",
+    "irs_hip_batch_set_wand", "irs_hip_term_blockmax", "irs_hip_batch_touched",
 )
 
 
@@ -113,6 +113,7 @@ def bind(L: C.CDLL) -> C.CDLL:
     L.irs_hip_batch_set_wand.argtypes, L.irs_hip_batch_set_wand.restype = [vp, C.c_int], C.c_int
     L.irs_hip_term_blockmax.argtypes = [vp, u32, vp, vp, u32, P(u32)]
     L.irs_hip_term_blockmax.restype = C.c_int
+    L.irs_hip_batch_touched.argtypes, L.irs_hip_batch_touched.restype = [vp, P(u64), P(u64)], C.c_int
     return L
 
 

@@ -54,7 +54,7 @@ k_block_max(DevSegment seg, uint32_t slices, uint32_t* blk_maxf, uint32_t* blk_m
                                base, lane, d0, d1, f0, f1);
     uint32_t mf = f0 > f1 ? f0 : f1;
     uint32_t mn = 0xFFFFFFFFu;
-    if (seg.norms) {
+    if (seg.norms && !seg.norm_legacy) {
       const uint32_t n0 = seg.norm_width == 1 ? seg.norms[d0 - seg.norm_min_doc] : norm_global(seg, d0);
       const uint32_t n1 = seg.norm_width == 1 ? seg.norms[d1 - seg.norm_min_doc] : norm_global(seg, d1);
       if (n0) mn = n0;
@@ -97,7 +97,6 @@ __device__ __forceinline__ void decode_dir_block(const DevSegment& seg, uint64_t
 }
 
 constexpr uint32_t kConjWaves = 4;  // wavefronts (= lead blocks) per workgroup
-constexpr uint32_t kConjHash = 256;   // slots of the lead-doc hash table (128 keys: half full)
 
 // Where the other terms start for every lead item: the binary search of a term's block
 // directory for the first block reaching the lead item's first doc — SkipReader::Seek
@@ -137,7 +136,9 @@ struct ConjArgs {
   const DevSegment* segs;
   const DevQuery* queries;
   const DevQTerm* qterms;
-  const PhraseWg* wgs;          // {unit, first lead item} per workgroup
+  const PhraseWg* wgs;          // {unit, first lead item} per workgroup; pilot pass: {unit, lead
+                                // item} per WAVEFRONT (the sampled items only)
+  uint32_t n_pilot;             // entries of the pilot list
   const DevTail* tails;         // [unit][jt] (k_plan)
   const uint32_t* bstar;        // threshold bin per unit (0 = none)
   const uint32_t* seek;         // k_conj_seek
@@ -145,6 +146,7 @@ struct ConjArgs {
   uint64_t* cands;
   uint32_t* cand_count;
   unsigned long long* hits;
+  unsigned long long* touched;  // [2]: `.doc` + norm bytes actually decoded / read (full pass)
   uint32_t* hist;               // [unit][kBins], pilot pass only
   uint32_t jt;
   uint32_t cand_cap;
@@ -152,52 +154,54 @@ struct ConjArgs {
   uint32_t wand;                // prune lead blocks by block-max bounds
 };
 
-__device__ __forceinline__ uint32_t conj_hash(uint32_t doc) {
-  return (doc * 0x9E3779B1u) >> 24;   // top 8 bits of a Fibonacci hash: kConjHash slots
-}
-
 template<int LAYOUT>
 __global__ void __launch_bounds__(kConjWaves * 64)
 k_conj(ConjArgs A, uint32_t pilot) {
-  __shared__ DevTail s_tl[kMaxTerms];
-  __shared__ DevQTerm s_qt[kMaxTerms];
+  __shared__ DevTail s_tl[kConjWaves * kMaxTerms];
+  __shared__ DevQTerm s_qt[kConjWaves * kMaxTerms];
   __shared__ uint32_t s_docs[kConjWaves][kBlock];
   __shared__ float s_score[kConjWaves][kBlock];
   __shared__ uint32_t s_norm[kConjWaves][kBlock];
   __shared__ uint32_t s_cnt[kConjWaves][kBlock];    // terms that reached the doc so far
   __shared__ uint32_t s_alive[kConjWaves][kBlock + 1];  // docs alive among the first c
-  __shared__ uint32_t s_hkey[kConjWaves][kConjHash];    // lead doc -> its index (open addressing)
-  __shared__ uint32_t s_hval[kConjWaves][kConjHash];
   const uint32_t tid = threadIdx.x;
   const unsigned lane = tid & 63u;
   const uint32_t wv = tid >> 6;
-  const PhraseWg wg = A.wgs[blockIdx.x];
-  const uint32_t unit = wg.unit;
+  // full pass: a workgroup = kConjWaves consecutive lead items of one unit; pilot pass: every
+  // wavefront has its own (unit, item) entry (wavefronts of a workgroup may belong to
+  // different units: the per-unit records are then read per wavefront, not staged)
+  uint32_t unit, item;
+  if (pilot) {
+    const uint32_t e = blockIdx.x * kConjWaves + wv;
+    const PhraseWg w = A.wgs[e < A.n_pilot ? e : A.n_pilot - 1u];
+    unit = w.unit;
+    item = e < A.n_pilot ? w.first_item : 0xFFFFFFFFu;
+  } else {
+    const PhraseWg w = A.wgs[blockIdx.x];
+    unit = w.unit;
+    item = w.first_item + wv;
+  }
   const DevQuery qd = A.queries[unit];
   const uint32_t m = qd.n_terms;
   const DevSegment seg = A.segs[qd.seg];
-  if (tid < m) {
-    s_tl[tid] = A.tails[uint64_t(unit) * A.jt + tid];
-    s_qt[tid] = A.qterms[qd.first_term + tid];
+  // (the term records of this wavefront's unit, in its own LDS rows)
+  DevTail* w_tl = s_tl + wv * kMaxTerms;
+  DevQTerm* w_qt = s_qt + wv * kMaxTerms;
+  if (lane < m) {
+    w_tl[lane] = A.tails[uint64_t(unit) * A.jt + lane];
+    w_qt[lane] = A.qterms[qd.first_term + lane];
   }
-  __syncthreads();
+  wave::sync();
   if (m == 0) return;
-  const DevTail ld = s_tl[0];   // the host sorted the terms by cost: the cheapest leads
+  const DevTail ld = w_tl[0];   // the host sorted the terms by cost: the cheapest leads
   const uint32_t n_items = ld.nblk + (ld.n ? 1u : 0u);
-  const uint32_t item = wg.first_item + wv;
   if (item >= n_items) return;  // whole wavefront
-  if (pilot) {
-    const uint32_t phase = (unit * 7u) % A.pilot_stride;
-    if (item % A.pilot_stride != phase) return;
-  }
   const uint32_t bs = pilot ? 0u : A.bstar[unit];
   uint32_t* docs = s_docs[wv];
   float* score = s_score[wv];
   uint32_t* nrm = s_norm[wv];
   uint32_t* cnt = s_cnt[wv];
   uint32_t* alive = s_alive[wv];
-  uint32_t* hkey = s_hkey[wv];
-  uint32_t* hval = s_hval[wv];
   const uint32_t* seek = A.seek + uint64_t(A.unit_items[unit] + item) * (A.jt - 1u);
 
   // ---- doc range of the lead block (from the directory: nothing decoded yet)
@@ -216,11 +220,11 @@ k_conj(ConjArgs A, uint32_t pilot) {
   if (A.wand && bs) {
     float bound = 0.f;
     for (uint32_t i = 0; i < m; ++i) {
-      const DevTail tl = s_tl[i];
-      const DevQTerm qt = s_qt[i];
+      const DevTail tl = w_tl[i];
+      const DevQTerm qt = w_qt[i];
       float ub = 0.f;
       if (i == 0 && item < ld.nblk) {
-        ub = score_value(qt, seg.blk_maxf[ld.dir_off + item], seg.blk_minn[ld.dir_off + item]);
+        ub = block_bound(qt, seg.blk_maxf[ld.dir_off + item], seg.blk_minn[ld.dir_off + item]);
       } else if (i == 0) {
         ub = term_bound(qt, seg.terms[tl.term].tf_bound);
       } else {
@@ -230,7 +234,7 @@ k_conj(ConjArgs A, uint32_t pilot) {
         uint32_t z = item + 1u < n_items ? seek[(A.jt - 1u) + i - 1u] + 1u : tl.nblk;
         z = z < tl.nblk ? z : tl.nblk;
         for (uint32_t k = a + lane; k < z; k += 64) {
-          const float s = score_value(qt, seg.blk_maxf[tl.dir_off + k], seg.blk_minn[tl.dir_off + k]);
+          const float s = block_bound(qt, seg.blk_maxf[tl.dir_off + k], seg.blk_minn[tl.dir_off + k]);
           ub = s > ub ? s : ub;
         }
         // the decoded tail (no block-max entry): the term's global bound
@@ -253,15 +257,19 @@ k_conj(ConjArgs A, uint32_t pilot) {
 
   // ---- 1. the lead block: entry index 2*lane + h (block) or lane + 64*h (tail)
   uint32_t n = kBlock;
-  for (uint32_t h = lane; h < kConjHash; h += 64) hkey[h] = 0xFFFFFFFFu;
-  wave::sync();
+  uint32_t bytes = 0;   // (wave-uniform) encoded bytes of the blocks this wavefront decodes
+  auto block_bytes = [](uint32_t bits) {   // header bytes + payloads (all-equal: ~1 byte of vint)
+    const uint32_t db = bits & 0xFFu, fb = bits >> 8;
+    return 2u + (db ? 16u * db : 1u) + (fb ? 16u * fb : 1u);
+  };
   {
-    const DevQTerm qt = s_qt[0];
+    const DevQTerm qt = w_qt[0];
     uint32_t d[2], f[2], e0, estep;
     if (item < ld.nblk) {
       const uint64_t e = ld.dir_off + item;
       decode_dir_block<LAYOUT>(seg, ld.doc_start, seg.blk_bits[e], seg.blk_off[e], seg.blk_aoff[e],
                                lead_base, lane, d[0], d[1], f[0], f[1]);
+      bytes += block_bytes(seg.blk_bits[e]);
       e0 = 2u * lane;
       estep = 1u;
     } else {
@@ -277,18 +285,11 @@ k_conj(ConjArgs A, uint32_t pilot) {
     for (int h = 0; h < 2; ++h) {
       const uint32_t idx = e0 + uint32_t(h) * estep;
       const bool on = idx < n;
-      uint32_t nv = 1u;
-      if (on && seg.norms)
-        nv = seg.norm_width == 1 ? seg.norms[d[h] - seg.norm_min_doc] : norm_global(seg, d[h]);
+      const uint32_t nv = on ? norm_value(seg, d[h]) : 1u;
       docs[idx] = on ? d[h] : 0xFFFFFFFFu;
       nrm[idx] = nv;
       score[idx] = on ? score_value(qt, f[h], nv) : 0.f;
       cnt[idx] = on ? 1u : 0u;
-      if (on) {   // doc -> idx: linear probing, at most half of the slots are ever taken
-        uint32_t s = conj_hash(d[h]);
-        while (atomicCAS(&hkey[s], 0xFFFFFFFFu, d[h]) != 0xFFFFFFFFu) s = (s + 1u) & (kConjHash - 1u);
-        hval[s] = idx;
-      }
     }
   }
   wave::sync();
@@ -296,8 +297,8 @@ k_conj(ConjArgs A, uint32_t pilot) {
 
   // ---- 2. the other terms, cheapest first
   for (uint32_t i = 1; i < m; ++i) {
-    const DevTail tl = s_tl[i];
-    const DevQTerm qt = s_qt[i];
+    const DevTail tl = w_tl[i];
+    const DevQTerm qt = w_qt[i];
     // alive[c] = docs among the first c that every earlier term reached
     {
       const uint32_t a0 = (2u * lane < n && cnt[2u * lane] == i) ? 1u : 0u;
@@ -307,24 +308,21 @@ k_conj(ConjArgs A, uint32_t pilot) {
       alive[2u * lane + 1u] = incl - a1;
       alive[2u * lane + 2u] = incl;
       wave::sync();
-      if (alive[kBlock] == 0u) return;   // no doc reached by every term so far: the block is done
+      if (alive[kBlock] == 0u) {   // no doc reached by every term so far: the block is done
+        if (!pilot && lane == 0) atomicAdd(&A.touched[0], static_cast<unsigned long long>(bytes));
+        return;
+      }
     }
     // a decoded posting of term i: is its doc one of the lead docs still alive?
-    auto put = [&](uint32_t doc, uint32_t f) {
+    // (w0, w1] = ranks of the lead docs that can equal it: those inside its block's doc range
+    // (a binary search all lanes finish together; a hash table was tried and lost to the
+    // longest probe sequence among the 64 lanes)
+    auto put = [&](uint32_t doc, uint32_t f, uint32_t w0, uint32_t w1) {
       if (f == 0 || doc < dlo || doc > dhi) return;
-      uint32_t s = conj_hash(doc);
-      for (;;) {
-        const uint32_t k = hkey[s];
-        if (k == doc) {
-          const uint32_t c = hval[s];
-          if (cnt[c] == i) {
-            score[c] += score_value(qt, f, nrm[c]);
-            cnt[c] = i + 1u;
-          }
-          return;
-        }
-        if (k == 0xFFFFFFFFu) return;
-        s = (s + 1u) & (kConjHash - 1u);
+      const uint32_t c = count_le(docs, w0, w1, doc);
+      if (c > w0 && docs[c - 1] == doc && cnt[c - 1] == i) {
+        score[c - 1] += score_value(qt, f, nrm[c - 1]);
+        cnt[c - 1] = i + 1u;
       }
     };
     if (tl.nblk) {
@@ -350,8 +348,10 @@ k_conj(ConjArgs A, uint32_t pilot) {
           decode_dir_block<LAYOUT>(seg, tl.doc_start, wave::read_lane(d.bits, k),
                                    wave::read_lane(d.off, k), wave::read_lane(d.aoff, k),
                                    wave::read_lane(d.prev_last, k), lane, d0, d1, f0, f1);
-          put(d0, f0);
-          put(d1, f1);
+          bytes += block_bytes(wave::read_lane(d.bits, k));
+          const uint32_t w0 = wave::read_lane(cp_l, k), w1 = wave::read_lane(cl_l, k);
+          put(d0, f0, w0, w1);
+          put(d1, f1, w0, w1);
         }
         if (!more) break;
       }
@@ -361,13 +361,18 @@ k_conj(ConjArgs A, uint32_t pilot) {
       const uint32_t t1 = lane + 64u < tl.n ? seg.tail_docs[tl.tail_row + lane + 64u] : 0u;
       const uint32_t g0 = lane < tl.n ? seg.tail_freqs[tl.tail_row + lane] : 0u;
       const uint32_t g1 = lane + 64u < tl.n ? seg.tail_freqs[tl.tail_row + lane + 64u] : 0u;
-      put(t0, g0);
-      put(t1, g1);
+      put(t0, g0, 0u, n);
+      put(t1, g1, 0u, n);
     }
     wave::sync();
   }
 
   // ---- 3. docs every term reached
+  if (!pilot && lane == 0) {
+    // + the norm of every lead doc, where the scorer reads one
+    const uint32_t nb = needs_norm(w_qt[0].kind) ? n * seg.norm_width : 0u;
+    atomicAdd(&A.touched[0], static_cast<unsigned long long>(bytes + nb));
+  }
   uint32_t my_hits = 0;
   for (uint32_t s = lane; s < n; s += 64) {
     if (cnt[s] != m) continue;

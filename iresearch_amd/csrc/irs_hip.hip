@@ -122,6 +122,8 @@ struct irs_hip_batch {
   DevBuf d_tile_units, d_conj_units, d_conj_items, d_conj_wgs, d_conj_hist;
   DevBuf d_conj_item_base, d_conj_unit_items, d_conj_seek;   // k_conj_seek
   uint32_t conj_total_items = 0;
+  DevBuf d_conj_pilot;             // the lead items the pilot pass samples, {unit, item} each
+  uint32_t n_conj_pilot = 0, conj_pilot_stride = 0;
   bool phrase = false;  // a batch of by_phrase queries (k_phrase instead of k_pilot + k_score)
   void* h_pin = nullptr;       // page-locked staging for irs_hip_batch_results
   size_t h_pin_bytes = 0;
@@ -136,6 +138,7 @@ struct irs_hip_batch {
   // work-item lists of the doc tiles (score.h): per-tile item offsets (+ scan scratch) and
   // the 32-byte records themselves
   DevBuf d_tile_off, d_scan_parts, d_items, d_score_args, d_tile_ub;
+  DevBuf d_touched;   // [2] u64: bytes decoded / positions read by the block-driven kernels
   ScoreArgs score_args{};
   uint32_t total_tiles = 0;    // doc tiles of all units
   uint32_t score_threads = 0;  // threads per k_pilot / k_score workgroup (power of two x 64)
@@ -396,18 +399,41 @@ bool launch_conj(irs_hip_batch* b, rt::stream_t st) {
   a.cand_count = b->d_cand_count.as<uint32_t>();
   a.hits = b->d_hits.as<unsigned long long>();
   a.hist = b->d_conj_hist.as<uint32_t>();
+  a.touched = b->d_touched.as<unsigned long long>();
   a.seek = b->d_conj_seek.as<uint32_t>();
   a.unit_items = b->d_conj_unit_items.as<uint32_t>();
   a.jt = b->jt;
   a.cand_cap = b->cand_cap;
   a.pilot_stride = b->stride_eff == 1 ? 1u : b->stride;
   a.wand = b->wand ? 1u : 0u;
+  if (b->conj_pilot_stride != a.pilot_stride) {
+    // the pilot pass's own work list: lead items {phase, phase + P, ...} of every unit
+    std::vector<PhraseWg> pl;
+    for (size_t c = 0; c < b->conj_units.size(); ++c) {
+      const uint32_t u = b->conj_units[c];
+      for (uint32_t it = (u * 7u) % a.pilot_stride; it < b->conj_items[c]; it += a.pilot_stride)
+        pl.push_back(PhraseWg{u, it});
+    }
+    if (!b->d_conj_pilot.alloc(std::max<size_t>(1, pl.size()) * sizeof(PhraseWg)) ||
+        !rt::sync(st) ||
+        !rt::h2d(b->d_conj_pilot.p, pl.data(), pl.size() * sizeof(PhraseWg), nullptr) ||
+        !rt::sync(nullptr))
+      return false;
+    b->n_conj_pilot = uint32_t(pl.size());
+    b->conj_pilot_stride = a.pilot_stride;
+  }
   if (!rt::dmemset(b->d_conj_hist.p, 0, b->d_conj_hist.n, st)) return false;
   RT_LAUNCH(k_conj_seek, (b->conj_total_items + kThreads - 1) / kThreads, kThreads, 0, st,
             b->d_segs.as<DevSegment>(), b->d_queries.as<DevQuery>(), b->d_tails.as<DevTail>(),
             b->jt, b->d_conj_units.as<uint32_t>(), b->d_conj_item_base.as<uint32_t>(),
             uint32_t(b->conj_units.size()), b->d_conj_seek.as<uint32_t>());
-  RT_LAUNCH((k_conj<LAYOUT>), b->n_conj_wgs, kConjWaves * 64, 0, st, a, 1u);
+  if (b->n_conj_pilot) {
+    ConjArgs p = a;
+    p.wgs = b->d_conj_pilot.as<PhraseWg>();
+    p.n_pilot = b->n_conj_pilot;
+    RT_LAUNCH((k_conj<LAYOUT>), (b->n_conj_pilot + kConjWaves - 1) / kConjWaves, kConjWaves * 64, 0,
+              st, p, 1u);
+  }
   RT_LAUNCH(k_conj_threshold, uint32_t(b->conj_units.size()), 64, 0, st,
             b->d_queries.as<DevQuery>(), b->d_conj_units.as<uint32_t>(),
             b->d_conj_items.as<uint32_t>(), b->d_conj_hist.as<uint32_t>(), a.pilot_stride,
@@ -445,7 +471,7 @@ bool launch_phrase(irs_hip_batch* b, rt::stream_t st) {
             b->d_segs.as<DevSegment>(), b->d_queries.as<DevQuery>(), b->d_qterms.as<DevQTerm>(),
             b->jt, b->d_phrase_wgs.as<PhraseWg>(), b->d_tails.as<DevTail>(),
             b->d_cands.as<uint64_t>(), b->cand_cap, b->d_cand_count.as<uint32_t>(),
-            b->d_hits.as<unsigned long long>());
+            b->d_hits.as<unsigned long long>(), b->d_touched.as<unsigned long long>());
   return rt::last_error_ok();
 }
 template<int LAYOUT>
@@ -561,7 +587,7 @@ bool ensure_scratch(irs_hip_batch* b) {
       !b->d_hits.alloc(b->nq * sizeof(uint64_t)) ||
       !b->d_out.alloc(uint64_t(b->nq) * b->k_max * sizeof(Hit)) ||
       !b->d_out_count.alloc(b->nq * sizeof(uint32_t)) || !b->d_status.alloc(4) ||
-      !b->d_work.alloc(4))
+      !b->d_work.alloc(4) || !b->d_touched.alloc(16))
     return false;
   if (!b->phrase && !b->tile_units.empty()) {
     const uint64_t parts = (tiles + 1 + kScanChunk - 1) / kScanChunk;
@@ -622,8 +648,10 @@ static int segment_open_impl(const irs_hip_segment_desc* d, irs_hip_segment** ou
       (d->layout != IRS_HIP_LAYOUT_SCALAR && d->layout != IRS_HIP_LAYOUT_SIMD4) ||
       (d->num_terms && !d->terms) || d->wand_count > 16)
     return IRS_HIP_EINVAL;
+  if (d->norm_kind != IRS_HIP_NORM2 && d->norm_kind != IRS_HIP_NORM_LEGACY) return IRS_HIP_EINVAL;
   if (d->norms) {
     if (d->norm_width != 1 && d->norm_width != 2 && d->norm_width != 4) return IRS_HIP_EINVAL;
+    if (d->norm_kind == IRS_HIP_NORM_LEGACY && d->norm_width != 4) return IRS_HIP_EINVAL;
     // dense column covering every doc (columnstore2.cpp:650-789); sparse columns
     // are not on the benchmark path
     if (d->norm_min_doc != kDocMin || d->norm_count < d->num_docs) return IRS_HIP_EUNSUPPORTED;
@@ -716,6 +744,7 @@ static int segment_open_impl(const irs_hip_segment_desc* d, irs_hip_segment** ou
     v.norm_width = d->norms ? d->norm_width : 0;
     v.norm_min_doc = d->norms ? d->norm_min_doc : kDocMin;
     v.norm_count = d->norms ? d->norm_count : 0;
+    v.norm_legacy = (d->norms && d->norm_kind == IRS_HIP_NORM_LEGACY) ? 1u : 0u;
     v.terms = s->d_terms.as<DevTerm>();
     v.num_terms = d->num_terms;
     v.num_docs = d->num_docs;
@@ -1015,12 +1044,15 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
         if (ts.term != IRS_HIP_NO_TERM && ts.term >= seg->dev.num_terms) rc = IRS_HIP_EINVAL;
         if (!(ts.c0 >= 0.f) || !std::isfinite(ts.c0)) rc = IRS_HIP_EINVAL;
         if (rc != IRS_HIP_OK) break;
-        // a zero score would be indistinguishable from "no match" in the accumulators
-        if (ts.c0 == 0.f) rc = IRS_HIP_EUNSUPPORTED;
+        // (a zero boost is legal: every posting then scores 0 — the fixed-point accumulators
+        // still mark the doc as matched, and sums below kMaxTerms units come back as 0)
         const bool norms = seg->dev.norms != nullptr;
+        const bool legacy = norms && seg->dev.norm_legacy;
         switch (ts.kind) {
           case IRS_HIP_SCORE_BM25:
-            qt.kind = norms ? (seg->dev.norm_width == 1 ? kBM25Tiny : kBM25Wide) : kBM25One;
+            qt.kind = !norms ? kBM25One
+                      : legacy ? kBM25Legacy
+                               : (seg->dev.norm_width == 1 ? kBM25Tiny : kBM25Wide);
             if (!(ts.norm_const + ts.norm_length > 0.f)) rc = IRS_HIP_EINVAL;
             break;
           case IRS_HIP_SCORE_BM15:
@@ -1030,7 +1062,9 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
           case IRS_HIP_SCORE_BM1: qt.kind = kBM1; break;
           case IRS_HIP_SCORE_TFIDF: qt.kind = kTfidf; break;
           case IRS_HIP_SCORE_TFIDF_NORM:
-            qt.kind = norms ? (seg->dev.norm_width == 1 ? kTfidfTiny : kTfidfWide) : kTfidf;
+            qt.kind = !norms ? kTfidf
+                      : legacy ? kTfidfLegacy
+                               : (seg->dev.norm_width == 1 ? kTfidfTiny : kTfidfWide);
             break;
           default: rc = IRS_HIP_EINVAL;
         }
@@ -1057,12 +1091,13 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
           }
           min_score = std::min(min_score, smin);
         }
-        const bool tfidf = qt.kind == kTfidf || qt.kind == kTfidfTiny || qt.kind == kTfidfWide;
+        const bool tfidf = qt.kind == kTfidf || qt.kind == kTfidfTiny || qt.kind == kTfidfWide ||
+                           qt.kind == kTfidfLegacy;
         upper += tfidf ? double(qt.c0) * std::sqrt(double(t.tf_bound)) : double(qt.c0);
         b->postings += t.docs_count;
         b->alg_bytes += uint64_t(t.blocks_bytes) + t.tail_bytes;
         if (qt.kind == kBM25Tiny || qt.kind == kBM25Wide || qt.kind == kTfidfTiny ||
-            qt.kind == kTfidfWide)
+            qt.kind == kTfidfWide || qt.kind == kBM25Legacy || qt.kind == kTfidfLegacy)
           b->alg_bytes += uint64_t(t.docs_count) * seg->dev.norm_width;
         row.push_back(qt);
       }
@@ -1134,6 +1169,7 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
       dq.n_terms = uint32_t(row.size());
       dq.first_term = uint32_t(b->qterms.size());
       upper *= 1.0 + 1e-6;
+      if (!row.empty() && upper == 0.0) upper = 1.0;   // every boost is 0: all scores are 0
       if (!row.empty() && !(upper > 0.0 && std::isfinite(upper))) {
         rc = IRS_HIP_EUNSUPPORTED;
         break;
@@ -1338,6 +1374,16 @@ static int term_blockmax_impl(irs_hip_segment* seg, uint32_t term, uint32_t* max
   return IRS_HIP_OK;
 }
 
+static int batch_touched_impl(irs_hip_batch* b, uint64_t* doc_bytes, uint64_t* positions) {
+  if (!b || !b->ran) return IRS_HIP_EINVAL;
+  if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
+  uint64_t v[2] = {0, 0};
+  if (!rt::d2h(v, b->d_touched.p, 16, b->stream) || !rt::sync(b->stream)) return IRS_HIP_EHIP;
+  if (doc_bytes) *doc_bytes = v[0];
+  if (positions) *positions = v[1];
+  return IRS_HIP_OK;
+}
+
 static int batch_profile_impl(irs_hip_batch* b, int enable) {
   if (!b) return IRS_HIP_EINVAL;
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
@@ -1358,7 +1404,8 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st) {
   bool ok = rt::dmemset(b->d_cand_count.p, 0, b->d_cand_count.n, st) &&
             rt::dmemset(b->d_hits.p, 0, b->d_hits.n, st) &&
             rt::dmemset(b->d_status.p, 0, 4, st) &&
-            rt::dmemset(b->d_bstar.p, 0, b->d_bstar.n, st);
+            rt::dmemset(b->d_bstar.p, 0, b->d_bstar.n, st) &&
+            rt::dmemset(b->d_touched.p, 0, 16, st);
   // 1. plan: tile -> first block tables, tail decode
   ok = ok && mark(2 * IRS_HIP_K_PLAN);
   if (ok) {
@@ -1646,6 +1693,9 @@ int irs_hip_batch_set_wand(irs_hip_batch* b, int enable) {
 int irs_hip_term_blockmax(irs_hip_segment* seg, uint32_t term, uint32_t* max_freqs,
                           uint32_t* min_norms, uint32_t cap, uint32_t* count) {
   return guarded([&] { return term_blockmax_impl(seg, term, max_freqs, min_norms, cap, count); });
+}
+int irs_hip_batch_touched(irs_hip_batch* b, uint64_t* doc_bytes, uint64_t* positions) {
+  return guarded([&] { return batch_touched_impl(b, doc_bytes, positions); });
 }
 int irs_hip_batch_run(irs_hip_batch* b, void* stream) {
   return guarded([&] { return batch_run_impl(b, stream); });

@@ -467,6 +467,13 @@ k_plan(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms,
 
 // ------------------------------------------------- shared decode helpers --
 
+// legacy `Norm` column (norm.hpp:57-69): one float per doc, 1/sqrt(|doc|)
+__device__ __forceinline__ float norm_legacy(const DevSegment& seg, uint32_t doc) {
+  float v;
+  __builtin_memcpy(&v, seg.norms + 4ull * (doc - seg.norm_min_doc), 4);
+  return v;
+}
+
 __device__ __forceinline__ uint32_t norm_global(const DevSegment& seg, uint32_t doc) {
   // dense fixed-length column, big-endian values (columnstore2.cpp:736-740, norm.hpp:170-182)
   const uint8_t* p = seg.norms + uint64_t(seg.norm_width) * (doc - seg.norm_min_doc);

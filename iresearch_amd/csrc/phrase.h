@@ -17,7 +17,7 @@
 // alone (k_phrase below), with (P, tf) riding along, and only docs holding ALL phrase terms
 // ever touch the position stream.
 #pragma once
-#include "kernels.h"
+#include "score.h"
 
 namespace irs_hip {
 
@@ -281,45 +281,6 @@ k_decode_positions(DevSegment seg, uint32_t term, uint32_t* out) {
 
 // ------------------------------------------------------------ query time --
 
-// The score function the phrase iterator compiles (CompileScore with the phrase's
-// aggregated stats; tf = phrase frequency): the reference's float expressions,
-// bm25.cpp:281-282, 313, 348-359, tfidf.cpp:185-187, 251-253.
-__device__ __forceinline__ float phrase_score(const DevSegment& seg, const DevQTerm& qt,
-                                              uint32_t freq, uint32_t doc) {
-  const float tf = static_cast<float>(freq);
-  switch (qt.kind) {
-    case kBM1:
-      return qt.c0;
-    case kBM15:
-      return qt.c0 - qt.c0 / (1.f + tf / qt.norm_const);
-    case kBM25Tiny: {
-      const uint32_t n = seg.norms[doc - seg.norm_min_doc];
-      const float inv = n ? 1.f / (qt.norm_const + qt.norm_length * static_cast<float>(n)) : 0.f;
-      return qt.c0 - qt.c0 / (1.f + tf * inv);
-    }
-    case kBM25One: {
-      const float inv = 1.f / (qt.norm_const + qt.norm_length);
-      return qt.c0 - qt.c0 / (1.f + tf * inv);
-    }
-    case kBM25Wide: {
-      const float c1 = qt.norm_const + qt.norm_length * static_cast<float>(norm_global(seg, doc));
-      return qt.c0 - qt.c0 * c1 / (c1 + tf);
-    }
-    case kTfidf:
-      return sqrtf(tf) * qt.c0;
-    case kTfidfTiny: {
-      const uint32_t n = seg.norms[doc - seg.norm_min_doc];
-      const float r = n ? 1.f / sqrtf(static_cast<float>(n)) : 0.f;
-      return sqrtf(tf) * qt.c0 * r;
-    }
-    default: {  // kTfidfWide
-      const uint32_t n = norm_global(seg, doc);
-      const float r = n ? 1.f / sqrtf(static_cast<float>(n)) : 0.f;
-      return sqrtf(tf) * qt.c0 * r;
-    }
-  }
-}
-
 constexpr uint32_t kPhraseWaves = 4;  // wavefronts (= lead blocks) per workgroup
 
 // One workgroup of k_phrase: kPhraseWaves consecutive lead blocks of one unit.
@@ -364,7 +325,8 @@ template<int LAYOUT, int MT>
 __global__ void __launch_bounds__(kPhraseWaves * 64)
 k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms, uint32_t jt,
          const PhraseWg* wgs, const DevTail* tails, uint64_t* cands, uint32_t cand_cap,
-         uint32_t* cand_count, unsigned long long* hits) {
+         uint32_t* cand_count, unsigned long long* hits,
+         unsigned long long* touched /*[2]: `.doc` bytes decoded, positions read*/) {
   __shared__ DevPosTerm s_pt[MT];
   __shared__ DevTail s_tl[MT];
   __shared__ uint32_t s_off[MT];
@@ -399,11 +361,17 @@ k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms
 
   // ---- 1. the lead block: entry index 2*lane + h (block) or lane + 64*h (tail)
   uint32_t n = kBlock, e0, estep;
+  uint32_t bytes = 0;   // (wave-uniform) encoded bytes of the doc blocks this wavefront decodes
+  auto block_bytes = [](uint32_t bits) {
+    const uint32_t db = bits & 0xFFu, fb = bits >> 8;
+    return 2u + (db ? 16u * db : 1u) + (fb ? 16u * fb : 1u);
+  };
   {
     uint32_t d[2], f[2], p[2];
     if (item < ld.nblk) {
       const uint64_t e = ld.dir_off + item;
       const uint32_t bits = seg.blk_bits[e];
+      bytes += block_bytes(bits);
       const uint32_t base = item ? seg.blk_last[e - 1] : kDocMin;
       uint32_t before;
       if (pk_both(bits & 0xFFu, bits >> 8)) {
@@ -487,6 +455,7 @@ k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms
           const uint32_t k = uint32_t(__builtin_ctzll(mask));
           mask &= mask - 1;
           const uint32_t bits = wave::read_lane(bits_l, k);
+          bytes += block_bytes(bits);
           const uint32_t base = wave::read_lane(base_l, k);
           uint32_t d0, d1, f0, f1, before;
           const uint32_t dbits = bits & 0xFFu, fbits = bits >> 8;
@@ -518,7 +487,7 @@ k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms
   wave::sync();
 
   // ---- 3./4. lead docs every term reached: merge the position lists, score, emit
-  uint32_t my_hits = 0;
+  uint32_t my_hits = 0, my_pos = 0;
   for (uint32_t s = lane; s < n; s += 64) {
     uint32_t P[MT], T[MT], K[MT], V[MT];
     bool all = true;
@@ -538,6 +507,7 @@ k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms
     bool done = false;
     for (uint32_t a = 0; a < T[0] && !done; ++a) {
       head += pos_delta<LAYOUT>(seg, s_pt[0], s_tl[0].term, P[0] + a);  // lead.next()
+      ++my_pos;
       bool match = true;
 #pragma unroll
       for (int i = 1; i < MT; ++i) {
@@ -549,6 +519,7 @@ k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms
           while ((K[i] == 0u || V[i] < target) && K[i] < T[i]) {
             V[i] += pos_delta<LAYOUT>(seg, s_pt[i], s_tl[i].term, P[i] + K[i]);
             ++K[i];
+            ++my_pos;
           }
           if (V[i] < target) done = true;           // exhausted: no later position can match
           else if (V[i] != target) match = false;   // sought too far
@@ -558,14 +529,19 @@ k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms
     }
     if (pf) {
       const uint32_t doc = docs[s];
-      const float score = phrase_score(seg, qt, pf, doc);
+      const float score = score_value(qt, pf, norm_value(seg, doc));
       const uint32_t slot = atomicAdd(&cand_count[unit], 1u);
       if (slot < cand_cap) cands[uint64_t(unit) * cand_cap + slot] = make_key(score, doc);
       ++my_hits;
     }
   }
   my_hits = wave::reduce_add(my_hits);
-  if (lane == 0 && my_hits) atomicAdd(&hits[unit], static_cast<unsigned long long>(my_hits));
+  my_pos = wave::reduce_add(my_pos);
+  if (lane == 0) {
+    if (my_hits) atomicAdd(&hits[unit], static_cast<unsigned long long>(my_hits));
+    atomicAdd(&touched[0], static_cast<unsigned long long>(bytes));
+    if (my_pos) atomicAdd(&touched[1], static_cast<unsigned long long>(my_pos));
+  }
 }
 
 }  // namespace irs_hip

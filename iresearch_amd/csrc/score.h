@@ -235,11 +235,17 @@ __device__ __forceinline__ float score_posting(const DevSegment& seg, const DevQ
       const float r = n ? 1.f / sqrtf(static_cast<float>(n)) : 0.f;
       return sqrtf(tf) * qt.c0 * r;
     }
-    default: {  // kTfidfWide
+    case kTfidfWide: {
       const uint32_t n = norm_global(seg, doc);
       const float r = n ? 1.f / sqrtf(static_cast<float>(n)) : 0.f;
       return sqrtf(tf) * qt.c0 * r;
     }
+    case kBM25Legacy: {   // BM25NormAdapter<kNorm>: 1/stored; tf = kSQRT(freq)  bm25.cpp:242-249, 333-337
+      const float c1 = qt.norm_const + qt.norm_length * (1.f / norm_legacy(seg, doc));
+      return qt.c0 - qt.c0 * c1 / (c1 + sqrtf(tf));
+    }
+    default:              // kTfidfLegacy: the stored value as it is  tfidf.cpp:214-219
+      return sqrtf(tf) * qt.c0 * norm_legacy(seg, doc);
   }
 }
 
@@ -636,7 +642,8 @@ __device__ __forceinline__ void items_slow(const DevSegment& seg, const TileSmem
 // The score function a term scorer compiles to, on explicit values — used on (tf, the doc's
 // norm) for postings and on (max freq, min norm) for block bounds, exactly as the wanderator
 // runs the one ScoreFunction on its WandSource (formats_10.cpp:2498-2503).  The reference's
-// float expressions: bm25.cpp:281-282, 313, 348-359; tfidf.cpp:185-187, 251-253.
+// float expressions: bm25.cpp:281-282, 313, 348-359; tfidf.cpp:185-187, 251-253.  `norm`: the
+// Norm2 value; for the legacy `Norm` kinds the bits of the stored float.
 __device__ __forceinline__ float score_value(const DevQTerm& qt, uint32_t freq, uint32_t norm) {
   const float tf = static_cast<float>(freq);
   switch (qt.kind) {
@@ -658,16 +665,39 @@ __device__ __forceinline__ float score_value(const DevQTerm& qt, uint32_t freq, 
     }
     case kTfidf:
       return sqrtf(tf) * qt.c0;
+    case kBM25Legacy: {
+      const float c1 = qt.norm_const + qt.norm_length * (1.f / __uint_as_float(norm));
+      return qt.c0 - qt.c0 * c1 / (c1 + sqrtf(tf));
+    }
+    case kTfidfLegacy:
+      return sqrtf(tf) * qt.c0 * __uint_as_float(norm);
     default: {  // kTfidfTiny, kTfidfWide
       const float r = norm ? 1.f / sqrtf(static_cast<float>(norm)) : 0.f;
       return sqrtf(tf) * qt.c0 * r;
     }
   }
 }
+__device__ __forceinline__ bool needs_norm(int32_t kind) {
+  return kind == kBM25Tiny || kind == kBM25Wide || kind == kTfidfTiny || kind == kTfidfWide ||
+         kind == kBM25Legacy || kind == kTfidfLegacy;
+}
+// The norm value score_value() wants for `doc` (1 without a column: bm25.cpp:487-489).
+__device__ __forceinline__ uint32_t norm_value(const DevSegment& seg, uint32_t doc) {
+  if (!seg.norms) return 1u;
+  if (seg.norm_legacy) return __float_as_uint(norm_legacy(seg, doc));
+  return seg.norm_width == 1 ? seg.norms[doc - seg.norm_min_doc] : norm_global(seg, doc);
+}
+// Bound of a block from its (max freq, min norm); the legacy kinds have no block-max norms:
+// their bound over any norm (stored values are <= 1).
+__device__ __forceinline__ float block_bound(const DevQTerm& qt, uint32_t maxf, uint32_t minn) {
+  if (qt.kind == kBM25Legacy) return qt.c0;
+  if (qt.kind == kTfidfLegacy) return sqrtf(static_cast<float>(maxf)) * qt.c0;
+  return score_value(qt, maxf, minn);
+}
 // what no posting of the term can exceed (BM25 family: the supremum over tf; TF-IDF: at the
 // term's largest frequency, DevTerm::tf_bound)
 __device__ __forceinline__ float term_bound(const DevQTerm& qt, uint32_t tf_bound) {
-  return sqrt_kind(qt.kind) || qt.kind == kTfidfWide
+  return sqrt_kind(qt.kind) || qt.kind == kTfidfWide || qt.kind == kTfidfLegacy
              ? sqrtf(static_cast<float>(tf_bound)) * qt.c0 : qt.c0;
 }
 
@@ -783,7 +813,7 @@ k_items_fill(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qt
       locate(g, j, e);
       const BlkDir d = seg.blk_dir[e];
       if (tile_ub)   // positive floats order like their bit patterns
-        atomicMax(&s_ub[wv][j], __float_as_uint(score_value(qts[j], seg.blk_maxf[e], seg.blk_minn[e])));
+        atomicMax(&s_ub[wv][j], __float_as_uint(block_bound(qts[j], seg.blk_maxf[e], seg.blk_minn[e])));
       cls = classify(j, d, fconst);
       const bool fast = cls != 0u;
       const uint32_t slot = qts[j].cache_id < kMaxCaches ? qts[j].cache_id : 0u;
@@ -1192,7 +1222,8 @@ k_score(uint64_t args /*address of a ScoreArgs*/) {
       uint64_t* lc = lcand + (u & 1u) * kScoreCands;
       uint32_t* ncand = vars + kVNc0 + (u % 3u);
       auto candidate = [&](uint32_t i, ACC a) {   // rare
-        const float v = from_fixed<ACC>(a, qd.fx_inv);
+        // (a sum of at most kMaxTerms units is what postings of zero-boost terms leave: score 0)
+        const float v = a <= ACC(kMaxTerms) ? 0.f : from_fixed<ACC>(a, qd.fx_inv);
         if (score_bin(v, qd.bin_scale) >= bs) {
           const uint64_t key = make_key(v, kDocMin + tile * uint32_t(TILE) + i);
           const uint32_t slot = atomicAdd(ncand, 1u);

@@ -26,6 +26,9 @@ enum Kind : int32_t {
   kTfidf = 5,
   kTfidfTiny = 6,  // * kRSQRT.get<false>(norm)
   kTfidfWide = 7,  // * kRSQRT.get<true>(norm)
+  // legacy `Norm` feature (norm.hpp:46-70): the column holds 1/sqrt(|doc|) as float
+  kBM25Legacy = 8,   // tf = sqrt(freq), norm = 1/stored: c0 - c0*c1/(c1 + tf)   bm25.cpp:333-359, 242-249
+  kTfidfLegacy = 9,  // sqrt(freq) * idf * stored                              tfidf.cpp:214-219, 253
 };
 
 // One term of the segment's term table, as staged on the device.
@@ -75,7 +78,7 @@ struct DevSegment {
   const uint8_t* norms;      // Norm2 column bytes, may be null
   uint32_t norm_width;
   uint32_t norm_min_doc;
-  uint64_t norm_count;
+  uint64_t norm_count;      // (norm_legacy below: the values are little-endian floats, width 4)
   const DevTerm* terms;
   uint32_t num_terms;
   uint32_t num_docs;
@@ -113,7 +116,7 @@ struct DevSegment {
   const uint32_t* ptail;     // decoded position-delta tails, term after term (DevPosTerm::tail_row)
   uint32_t pos_base;         // what a doc's first delta is relative to: 0 (formats 1_3+, zero-based
                              // storage) or pos_limits::min() = 1 (1_0..1_2, formats_10.cpp:1623-1625)
-  uint32_t pos_pad;
+  uint32_t norm_legacy;      // the norm column is the legacy `Norm` feature: float 1/sqrt(|doc|)
 };
 
 struct DevQuery {

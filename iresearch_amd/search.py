@@ -156,7 +156,7 @@ class SegmentReader:
 
     def __init__(self, doc_file, metas, num_docs, layout, norms=None, norm_width=1,
                  docs_with_field=None, total_term_freq=0, device=0, has_freq=True, L=None,
-                 wand_count=0, pos_file=None, pos_features=0):
+                 wand_count=0, pos_file=None, pos_features=0, norm_kind=0):
         self.L = L or _lib.lib()
         self.doc_file = np.ascontiguousarray(doc_file, np.uint8)
         self.metas = np.zeros(len(metas), TERM_META)
@@ -174,7 +174,7 @@ class SegmentReader:
             0 if self.norms is None else self.norms.size // norm_width,
             self.metas.ctypes.data, len(self.metas), int(wand_count),
             None if self.pos_file is None else self.pos_file.ctypes.data,
-            0 if self.pos_file is None else self.pos_file.size, int(pos_features), 0)
+            0 if self.pos_file is None else self.pos_file.size, int(pos_features), int(norm_kind))
         h = C.c_void_p()
         _lib.check(self.L, self.L.irs_hip_segment_open(C.byref(desc), C.byref(h)),
                    "irs_hip_segment_open")
@@ -318,6 +318,13 @@ class QueryBatch:
         _lib.check(self.L, self.L.irs_hip_batch_reruns(self.handle, C.byref(n)),
                    "irs_hip_batch_reruns")
         return n.value
+
+    def touched(self):
+        """(`.doc` + norm bytes decoded, positions read) by the last run (And / by_phrase)."""
+        a, p = C.c_uint64(), C.c_uint64()
+        _lib.check(self.L, self.L.irs_hip_batch_touched(self.handle, C.byref(a), C.byref(p)),
+                   "irs_hip_batch_touched")
+        return a.value, p.value
 
     def work(self):
         a, p = C.c_uint64(), C.c_uint64()

@@ -43,6 +43,8 @@ class BM25Stats(C.Structure):
                 ("norm_cache", C.c_float * 256)]
 
 
+NORM_LEGACY_F32 = 0x104  # orc_segment.norm_width: legacy `Norm` floats (oracle.h)
+
 _lib = None
 _ref = None
 

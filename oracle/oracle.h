@@ -143,13 +143,15 @@ enum {
 enum { ORC_OP_OR = 0, ORC_OP_AND = 1, ORC_OP_MINMATCH = 2 /* + (min_match << 8) */,
        ORC_OP_PHRASE = 3 /* orc_search_phrase / orc_score_all_phrase only */ };
 
+#define ORC_NORM_LEGACY_F32 0x104u
 typedef struct orc_segment {
   const uint8_t* doc_file;
   uint64_t doc_file_len;
   int32_t layout;
   uint32_t num_docs;
   const uint8_t* norms; /* dense Norm2 column, big-endian, doc 1 first; NULL = none */
-  uint32_t norm_width;  /* 1, 2 or 4 bytes */
+  uint32_t norm_width;  /* 1, 2 or 4 bytes; ORC_NORM_LEGACY_F32: the legacy `Norm` feature,
+                           little-endian floats 1/sqrt(len) (norm.hpp:46-70) */
   uint32_t wand_count;  /* scorers the field was indexed with (wand data to skip) */
   const uint8_t* pos_file; /* `.pos` image of a field with POS, or NULL */
   uint64_t pos_file_len;

@@ -35,6 +35,8 @@ enum Kind {
   kTfidf,       // tfidf.cpp:251      no norms
   kTfidfTiny,   // tfidf.cpp:253 with kRSQRT.get<false>
   kTfidfWide,   // tfidf.cpp:253 with kRSQRT.get<true>
+  kBM25Legacy,  // bm25.cpp:333-337 + BM25NormAdapter<kNorm> :242-249 (legacy `Norm`: float 1/sqrt(len))
+  kTfidfLegacy, // tfidf.cpp:214-219 TFIDFNormAdapter<kNorm>: the stored float as it is
 };
 
 struct TermScorer {
@@ -60,6 +62,14 @@ inline uint32_t read_norm(const TermScorer& s, uint32_t doc) {
       return (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) |
              (uint32_t(p[2]) << 8) | p[3];
   }
+}
+
+inline float read_legacy_norm(const TermScorer& s, uint32_t doc) {
+  // Norm::MakeReader (norm.hpp:57-69): the float the writer stored for the doc, 1/sqrt(len);
+  // here a dense little-endian float array, doc 1 first
+  float v;
+  std::memcpy(&v, s.norms + size_t(4) * (doc - 1), 4);
+  return v;
 }
 
 inline float rsqrt_cached(uint32_t i) {
@@ -100,6 +110,13 @@ inline float score_posting(const TermScorer& s, uint32_t freq, uint32_t doc) {
     case kTfidfWide:
       return std::sqrt(static_cast<float>(freq)) * s.c0 *
              rsqrt_cached(read_norm(s, doc));
+    case kBM25Legacy: {
+      const float tf = std::sqrt(static_cast<float>(freq));  // kSQRT.get<true>, bm25.cpp:336
+      const float c1 = s.norm_const + s.norm_length * (1.f / read_legacy_norm(s, doc));
+      return s.c0 - s.c0 * c1 / (c1 + tf);
+    }
+    case kTfidfLegacy:
+      return std::sqrt(static_cast<float>(freq)) * s.c0 * read_legacy_norm(s, doc);
   }
   return 0.f;
 }
@@ -122,9 +139,11 @@ Kind pick_kind(const orc_scorer& s, const orc_segment& seg) {
     if (s.k == 0.f) return kBM1;   // IsBM1  bm25.cpp:447
     if (s.b == 0.f) return kBM15;  // IsBM15 bm25.cpp:451
     if (!seg.norms) return kBM25NoNorm;
+    if (seg.norm_width == ORC_NORM_LEGACY_F32) return kBM25Legacy;  // :478-483
     return seg.norm_width == 1 ? kBM25Tiny : kBM25Wide;  // :466-476
   }
   if (!s.with_norms || !seg.norms) return kTfidf;
+  if (seg.norm_width == ORC_NORM_LEGACY_F32) return kTfidfLegacy;
   return seg.norm_width == 1 ? kTfidfTiny : kTfidfWide;
 }
 

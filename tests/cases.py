@@ -508,6 +508,51 @@ def case_wide_norms(L, width):
     sr.close()
 
 
+def case_legacy_norms(L):
+    """The legacy `Norm` feature (norm.hpp:46-70: float 1/sqrt(|doc|) per doc): BM25 takes
+    tf = sqrt(freq) and norm = 1/stored through c0 - c0*c1/(c1 + tf) (bm25.cpp:333-359,
+    242-249), TF-IDF multiplies by the stored value (tfidf.cpp:214-219) — boolean queries,
+    conjunctions (incl. WAND) and phrases."""
+    seg = synth.build_segment(20_000, 128, with_positions=True)
+    lengths = seg.norms.astype(np.float32)
+    seg.norms = np.frombuffer((np.float32(1.0) / np.sqrt(lengths)).astype("<f4").tobytes(),
+                              np.uint8).copy()
+    seg.norm_width = oracle.NORM_LEGACY_F32   # what parity.oracle_view hands to the oracle
+    sr = search.SegmentReader(seg.doc_file, seg.metas, seg.num_docs, seg.layout, seg.norms, 4,
+                              seg.docs_with_field, seg.total_term_freq, L=L,
+                              pos_file=seg.pos_file, norm_kind=1)
+    filters = standard_filters(128, n_or8=2)
+    for scorer in (BM25(), TFIDF(True)):
+        h0, c0, t0 = run_and_check(L, seg, filters, scorer, 50, sr=sr)
+        wb = sr.batch(search.prepare(filters, scorer, [parity.segment_stats(seg)]), 50).set_wand(True)
+        h1, c1, t1 = wb.run().results()
+        wb.close()
+        assert np.array_equal(c0, c1)
+        for q in range(len(filters)):
+            assert np.array_equal(h0[q, :int(c0[q])], h1[q, :int(c0[q])]), q
+        run_phrases(L, seg, [by_phrase([0, 1]), by_phrase([3, 9, 0])], scorer, 20, sr=sr)
+    sr.close()
+
+
+def case_zero_boost(L):
+    """A boost of 0 is legal (by_term::boost, filter.hpp): the term still matches, its
+    postings score 0 — alone (every score is 0, ranked by doc id) and next to boosted terms."""
+    seg = synth.build_segment(20_000, 128)
+    sr = search.SegmentReader.from_synth(seg, L=L)
+    filters = [by_term(5, boost=0.0),
+               Or([by_term(3, boost=0.0), by_term(40), by_term(77, boost=0.0)]),
+               And([by_term(2, boost=0.0), by_term(9)]),
+               Or([by_term(1), by_term(6, boost=0.0), by_term(30)], min_match=2),
+               Or([by_term(8, boost=0.0), by_term(21, boost=0.0)])]
+    for scorer in (BM25(), TFIDF(False)):
+        hits, counts, totals = run_and_check(L, seg, filters, scorer, 30, sr=sr)
+        assert (hits[0, :int(counts[0])]["score"] == 0).all()
+        assert (hits[4, :int(counts[4])]["score"] == 0).all()
+        d = hits[0, :int(counts[0])]["doc"]
+        assert (d[:-1] < d[1:]).all()
+    sr.close()
+
+
 def case_decode_without_freq(L, layout):
     """Iterator requested without IndexFeatures::FREQ on a FREQ field: freq blocks are
     skipped (formats_10.cpp:1746-1750) — docs must be identical."""
@@ -1177,10 +1222,6 @@ def case_errors(L):
     with pytest.raises(_lib.IrsHipError) as e:
         sr.batch(search.prepare(many, BM25(), [parity.segment_stats(seg)]), 10)
     assert e.value.status == _lib.EINVAL
-    zero = search.prepare([by_term(1, boost=0.0)], BM25(), [parity.segment_stats(seg)])
-    with pytest.raises(_lib.IrsHipError) as e:
-        sr.batch(zero, 10)
-    assert e.value.status == _lib.EUNSUPPORTED
     # candidate buffer too small -> exact re-run (full histogram, then a grown
     # buffer), never a silently wrong top-k
     fl = [Or([by_term(0), by_term(1), by_term(2)]), by_term(5)]

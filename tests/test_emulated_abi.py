@@ -141,6 +141,14 @@ def test_phrase_errors(simlib):
     cases.case_phrase_errors(simlib)
 
 
+def test_legacy_norms(simlib):
+    cases.case_legacy_norms(simlib)
+
+
+def test_zero_boost(simlib):
+    cases.case_zero_boost(simlib)
+
+
 def test_wand_equals_exhaustive(simlib):
     cases.case_wand_equals_exhaustive(simlib)
 

@@ -183,6 +183,14 @@ def test_merge_ties(gpulib):
     cases.case_merge_ties(gpulib, n_lists=8, nq=5, k=1000, seed=5)
 
 
+def test_legacy_norms(gpulib):
+    cases.case_legacy_norms(gpulib)
+
+
+def test_zero_boost(gpulib):
+    cases.case_zero_boost(gpulib)
+
+
 def test_wand_equals_exhaustive(gpulib):
     cases.case_wand_equals_exhaustive(gpulib, num_docs=400_000, max_rank=512, ks=(10, 1000))
 
