@@ -225,8 +225,16 @@ def main():
     nq, k = args.queries, args.k
     # every buffer of the exchange step is allocated once (twice: two sets alternate); each
     # local segment's results are written straight into its slot of the send buffer
+    # the collective goes through the library's own RCCL communicator (irs_hip_comm_*); torch
+    # only carries its 128-byte id to the other ranks
+    comm = None
+    if world > 1:
+        try:
+            comm = distributed.Communicator(L, local_rank, rank, world)
+        except Exception as e:  # noqa: BLE001  (torch.distributed remains the way out)
+            log("irs_hip_comm unavailable (%s): all-gather through torch.distributed" % e)
     exchange = distributed.PipelinedExchange(L, local_rank, n_segments if multi else 1, rank,
-                                             world, nq, k, dev)
+                                             world, nq, k, dev, comm=comm)
     # a multi-segment batch writes [segment][query][k] hits and [segment][query] counts: exactly
     # consecutive slots of the send buffer
     slots = [{lead: exchange.slot(ph, my.index(lead)) for lead in batches} for ph in (0, 1)]
@@ -353,7 +361,10 @@ def main():
                 "reruns_rank0": int(reruns), "reruns_in_timed_steps": int(reruns_timed),
                 "parallelism": ("%d segments over %d GPU(s) + RCCL all-gather of per-segment "
                                 "top-k + GPU merge" % (n_segments, world)) if multi
-                               else "1 segment on 1 GPU"},
+                               else "1 segment on 1 GPU",
+                "collective": None if world == 1 else
+                              ("irs_hip_topk_allgather (RCCL behind the C ABI)" if comm is not None
+                               else "torch.distributed all_gather_into_tensor")},
             "roofline": roof,
         }
     if rank == 0 and not multi and not args.no_cpu:

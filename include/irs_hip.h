@@ -327,6 +327,25 @@ int irs_hip_merge_topk(int32_t device, const void* const* d_lists,
                        void* d_out, void* d_out_seg, void* d_out_counts,
                        void* stream);
 
+/* ---- the collective of the multi-GPU exchange --------------------------
+ * One process per GPU.  The per-segment top-k lists of a step — [n_queries][k] hits and
+ * [n_queries] counts per local segment, written by irs_hip_batch_results_to_device straight
+ * into one send buffer — are exchanged with ONE all-gather over RCCL (xGMI); every rank then
+ * merges them with irs_hip_merge_topk.  What the harness loop `for (auto& segment : reader)`
+ * into one heap (utils/index-search.cpp:719-779) becomes when the segments live on different
+ * GPUs.  irs_hip_comm_unique_id: on one rank; the caller distributes the 128 bytes to the
+ * others by whatever it has (MPI, a file, a socket), exactly as with ncclUniqueId. */
+typedef struct irs_hip_comm irs_hip_comm;
+#define IRS_HIP_COMM_ID_BYTES 128u
+int irs_hip_comm_unique_id(uint8_t id[IRS_HIP_COMM_ID_BYTES]);
+int irs_hip_comm_init_rank(int32_t device, const uint8_t id[IRS_HIP_COMM_ID_BYTES], int32_t n_ranks,
+                           int32_t rank, irs_hip_comm** out);
+void irs_hip_comm_destroy(irs_hip_comm* comm);
+/* d_send: bytes_per_rank bytes on the device; d_recv: n_ranks * bytes_per_rank, rank r's block
+ * at r * bytes_per_rank.  Asynchronous on `stream` (a hipStream_t). */
+int irs_hip_topk_allgather(irs_hip_comm* comm, const void* d_send, void* d_recv,
+                           uint64_t bytes_per_rank, void* stream);
+
 const char* irs_hip_strerror(int status);
 uint32_t irs_hip_abi_version(void);
 /* Name of the device the library would use, e.g. "gfx950"; EHIP when none. */

@@ -64,6 +64,8 @@ SYMBOLS = (
     "irs_hip_query_batch", "irs_hip_batch_configure", "irs_hip_batch_profile",
     "irs_hip_batch_timings", "irs_hip_batch_work", "irs_hip_batch_reruns", "irs_hip_merge_topk",
     "irs_hip_batch_set_wand", "irs_hip_term_blockmax", "irs_hip_batch_touched",
+    "irs_hip_comm_unique_id", "irs_hip_comm_init_rank", "irs_hip_comm_destroy",
+    "irs_hip_topk_allgather",
 )
 
 
@@ -114,6 +116,12 @@ def bind(L: C.CDLL) -> C.CDLL:
     L.irs_hip_term_blockmax.argtypes = [vp, u32, vp, vp, u32, P(u32)]
     L.irs_hip_term_blockmax.restype = C.c_int
     L.irs_hip_batch_touched.argtypes, L.irs_hip_batch_touched.restype = [vp, P(u64), P(u64)], C.c_int
+    L.irs_hip_comm_unique_id.argtypes, L.irs_hip_comm_unique_id.restype = [vp], C.c_int
+    L.irs_hip_comm_init_rank.argtypes = [i32, vp, i32, i32, P(vp)]
+    L.irs_hip_comm_init_rank.restype = C.c_int
+    L.irs_hip_comm_destroy.argtypes, L.irs_hip_comm_destroy.restype = [vp], None
+    L.irs_hip_topk_allgather.argtypes = [vp, vp, vp, u64, vp]
+    L.irs_hip_topk_allgather.restype = C.c_int
     return L
 
 

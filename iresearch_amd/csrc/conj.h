@@ -146,7 +146,8 @@ struct ConjArgs {
   uint64_t* cands;
   uint32_t* cand_count;
   unsigned long long* hits;
-  unsigned long long* touched;  // [2]: `.doc` + norm bytes actually decoded / read (full pass)
+  unsigned long long* touched;  // [unit][2]: `.doc` + norm bytes actually decoded / read (full
+                                // pass; per unit: one hot address would serialise the atomics)
   uint32_t* hist;               // [unit][kBins], pilot pass only
   uint32_t jt;
   uint32_t cand_cap;
@@ -309,7 +310,7 @@ k_conj(ConjArgs A, uint32_t pilot) {
       alive[2u * lane + 2u] = incl;
       wave::sync();
       if (alive[kBlock] == 0u) {   // no doc reached by every term so far: the block is done
-        if (!pilot && lane == 0) atomicAdd(&A.touched[0], static_cast<unsigned long long>(bytes));
+        if (!pilot && lane == 0) atomicAdd(&A.touched[2u * unit], static_cast<unsigned long long>(bytes));
         return;
       }
     }
@@ -371,7 +372,7 @@ k_conj(ConjArgs A, uint32_t pilot) {
   if (!pilot && lane == 0) {
     // + the norm of every lead doc, where the scorer reads one
     const uint32_t nb = needs_norm(w_qt[0].kind) ? n * seg.norm_width : 0u;
-    atomicAdd(&A.touched[0], static_cast<unsigned long long>(bytes + nb));
+    atomicAdd(&A.touched[2u * unit], static_cast<unsigned long long>(bytes + nb));
   }
   uint32_t my_hits = 0;
   for (uint32_t s = lane; s < n; s += 64) {

@@ -3,6 +3,7 @@
 // kernels on a CPU fiber emulator for the CPU-only test tier; the product is
 // only ever built against THIS file.)
 #pragma once
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
@@ -68,12 +69,69 @@ inline bool allow_dynamic_smem(const void* fn, size_t bytes) {
   return ok(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
 }
 
+inline bool event_sync(event_t e) { return ok(hipEventSynchronize(e)); }
 inline bool event_create(event_t* e) { return ok(hipEventCreate(e)); }
 inline void event_destroy(event_t e) { (void)hipEventDestroy(e); }
 inline bool event_record(event_t e, stream_t s) { return ok(hipEventRecord(e, s)); }
 inline bool event_elapsed(float* ms, event_t a, event_t b) {
   return ok(hipEventElapsedTime(ms, a, b));
 }
+
+// ---- RCCL (the collective of the multi-GPU top-k exchange) -----------------------------
+// Bound at first use with dlopen: a process that never creates a communicator never loads
+// librccl.  Only the four entry points the exchange needs.
+namespace comm {
+
+constexpr size_t kIdBytes = 128;   // NCCL_UNIQUE_ID_BYTES
+struct UniqueId {
+  char internal[kIdBytes];
+};
+using handle_t = void*;            // ncclComm_t
+
+struct Api {
+  int (*get_unique_id)(UniqueId*) = nullptr;
+  int (*init_rank)(handle_t*, int, UniqueId, int) = nullptr;
+  int (*all_gather)(const void*, void*, size_t, int /*ncclDataType_t*/, handle_t, hipStream_t) = nullptr;
+  int (*destroy)(handle_t) = nullptr;
+  bool ok = false;
+};
+inline const Api& api() {   // one dlopen per process, at first use
+  static const Api a = [] {
+    Api x;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return x;
+    x.get_unique_id = reinterpret_cast<decltype(x.get_unique_id)>(dlsym(h, "ncclGetUniqueId"));
+    x.init_rank = reinterpret_cast<decltype(x.init_rank)>(dlsym(h, "ncclCommInitRank"));
+    x.all_gather = reinterpret_cast<decltype(x.all_gather)>(dlsym(h, "ncclAllGather"));
+    x.destroy = reinterpret_cast<decltype(x.destroy)>(dlsym(h, "ncclCommDestroy"));
+    x.ok = x.get_unique_id && x.init_rank && x.all_gather && x.destroy;
+    return x;
+  }();
+  return a;
+}
+
+inline bool unique_id(void* id128) {
+  const Api& a = api();
+  return a.ok && a.get_unique_id(static_cast<UniqueId*>(id128)) == 0;
+}
+inline bool init_rank(handle_t* out, int nranks, const void* id128, int rank) {
+  const Api& a = api();
+  if (!a.ok) return false;
+  UniqueId id;
+  std::memcpy(&id, id128, kIdBytes);
+  return a.init_rank(out, nranks, id, rank) == 0;
+}
+inline bool all_gather(handle_t c, const void* send, void* recv, size_t bytes, stream_t s) {
+  const Api& a = api();
+  return a.ok && a.all_gather(send, recv, bytes, 0 /*ncclInt8*/, c, s) == 0;
+}
+inline void destroy(handle_t c) {
+  const Api& a = api();
+  if (a.ok && c) (void)a.destroy(c);
+}
+
+}  // namespace comm
 
 }  // namespace rt
 

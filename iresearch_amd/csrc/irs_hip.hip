@@ -101,6 +101,12 @@ struct irs_hip_segment {
   DevBuf d_blk_maxf, d_blk_minn;
 };
 
+struct irs_hip_comm {
+  int device = 0;
+  int n_ranks = 1, rank = 0;
+  rt::comm::handle_t h = nullptr;
+};
+
 struct irs_hip_batch {
   irs_hip_segment* seg = nullptr;          // segs[0]: device, CU count
   std::vector<irs_hip_segment*> segs;      // a batch spans one or more segments of one device
@@ -138,7 +144,7 @@ struct irs_hip_batch {
   // work-item lists of the doc tiles (score.h): per-tile item offsets (+ scan scratch) and
   // the 32-byte records themselves
   DevBuf d_tile_off, d_scan_parts, d_items, d_score_args, d_tile_ub;
-  DevBuf d_touched;   // [2] u64: bytes decoded / positions read by the block-driven kernels
+  DevBuf d_touched;   // [unit][2] u64: bytes decoded / positions read by the block-driven kernels
   ScoreArgs score_args{};
   uint32_t total_tiles = 0;    // doc tiles of all units
   uint32_t score_threads = 0;  // threads per k_pilot / k_score workgroup (power of two x 64)
@@ -587,7 +593,7 @@ bool ensure_scratch(irs_hip_batch* b) {
       !b->d_hits.alloc(b->nq * sizeof(uint64_t)) ||
       !b->d_out.alloc(uint64_t(b->nq) * b->k_max * sizeof(Hit)) ||
       !b->d_out_count.alloc(b->nq * sizeof(uint32_t)) || !b->d_status.alloc(4) ||
-      !b->d_work.alloc(4) || !b->d_touched.alloc(16))
+      !b->d_work.alloc(4) || !b->d_touched.alloc(uint64_t(b->nq) * 16))
     return false;
   if (!b->phrase && !b->tile_units.empty()) {
     const uint64_t parts = (tiles + 1 + kScanChunk - 1) / kScanChunk;
@@ -1374,13 +1380,51 @@ static int term_blockmax_impl(irs_hip_segment* seg, uint32_t term, uint32_t* max
   return IRS_HIP_OK;
 }
 
+static int comm_unique_id_impl(uint8_t* id) {
+  if (!id) return IRS_HIP_EINVAL;
+  return rt::comm::unique_id(id) ? IRS_HIP_OK : IRS_HIP_EHIP;
+}
+
+static int comm_init_rank_impl(int32_t device, const uint8_t* id, int32_t n_ranks, int32_t rank,
+                               irs_hip_comm** out) {
+  if (!id || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks) return IRS_HIP_EINVAL;
+  *out = nullptr;
+  if (!device_usable(device)) return IRS_HIP_EHIP;
+  irs_hip_comm* c = new (std::nothrow) irs_hip_comm;
+  if (!c) return IRS_HIP_ENOMEM;
+  c->device = device;
+  c->n_ranks = n_ranks;
+  c->rank = rank;
+  if (!rt::comm::init_rank(&c->h, n_ranks, id, rank)) {
+    delete c;
+    return IRS_HIP_EHIP;
+  }
+  *out = c;
+  return IRS_HIP_OK;
+}
+
+static int topk_allgather_impl(irs_hip_comm* c, const void* d_send, void* d_recv,
+                               uint64_t bytes_per_rank, void* stream) {
+  if (!c || !d_send || !d_recv || !bytes_per_rank) return IRS_HIP_EINVAL;
+  if (!rt::set_device(c->device)) return IRS_HIP_EHIP;
+  return rt::comm::all_gather(c->h, d_send, d_recv, bytes_per_rank,
+                              static_cast<rt::stream_t>(stream))
+             ? IRS_HIP_OK : IRS_HIP_EHIP;
+}
+
 static int batch_touched_impl(irs_hip_batch* b, uint64_t* doc_bytes, uint64_t* positions) {
   if (!b || !b->ran) return IRS_HIP_EINVAL;
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
-  uint64_t v[2] = {0, 0};
-  if (!rt::d2h(v, b->d_touched.p, 16, b->stream) || !rt::sync(b->stream)) return IRS_HIP_EHIP;
-  if (doc_bytes) *doc_bytes = v[0];
-  if (positions) *positions = v[1];
+  std::vector<uint64_t> v(size_t(b->nq) * 2);
+  if (!rt::d2h(v.data(), b->d_touched.p, v.size() * 8, b->stream) || !rt::sync(b->stream))
+    return IRS_HIP_EHIP;
+  uint64_t bytes = 0, pos = 0;
+  for (uint32_t u = 0; u < b->nq; ++u) {
+    bytes += v[2 * u];
+    pos += v[2 * u + 1];
+  }
+  if (doc_bytes) *doc_bytes = bytes;
+  if (positions) *positions = pos;
   return IRS_HIP_OK;
 }
 
@@ -1405,7 +1449,7 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st) {
             rt::dmemset(b->d_hits.p, 0, b->d_hits.n, st) &&
             rt::dmemset(b->d_status.p, 0, 4, st) &&
             rt::dmemset(b->d_bstar.p, 0, b->d_bstar.n, st) &&
-            rt::dmemset(b->d_touched.p, 0, 16, st);
+            rt::dmemset(b->d_touched.p, 0, b->d_touched.n, st);
   // 1. plan: tile -> first block tables, tail decode
   ok = ok && mark(2 * IRS_HIP_K_PLAN);
   if (ok) {
@@ -1693,6 +1737,23 @@ int irs_hip_batch_set_wand(irs_hip_batch* b, int enable) {
 int irs_hip_term_blockmax(irs_hip_segment* seg, uint32_t term, uint32_t* max_freqs,
                           uint32_t* min_norms, uint32_t cap, uint32_t* count) {
   return guarded([&] { return term_blockmax_impl(seg, term, max_freqs, min_norms, cap, count); });
+}
+int irs_hip_comm_unique_id(uint8_t id[IRS_HIP_COMM_ID_BYTES]) {
+  return guarded([&] { return comm_unique_id_impl(id); });
+}
+int irs_hip_comm_init_rank(int32_t device, const uint8_t id[IRS_HIP_COMM_ID_BYTES], int32_t n_ranks,
+                           int32_t rank, irs_hip_comm** out) {
+  return guarded([&] { return comm_init_rank_impl(device, id, n_ranks, rank, out); });
+}
+void irs_hip_comm_destroy(irs_hip_comm* c) {
+  if (!c) return;
+  rt::set_device(c->device);
+  rt::comm::destroy(c->h);
+  delete c;
+}
+int irs_hip_topk_allgather(irs_hip_comm* c, const void* d_send, void* d_recv,
+                           uint64_t bytes_per_rank, void* stream) {
+  return guarded([&] { return topk_allgather_impl(c, d_send, d_recv, bytes_per_rank, stream); });
 }
 int irs_hip_batch_touched(irs_hip_batch* b, uint64_t* doc_bytes, uint64_t* positions) {
   return guarded([&] { return batch_touched_impl(b, doc_bytes, positions); });

@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(kPhraseWaves * 64)
 k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms, uint32_t jt,
          const PhraseWg* wgs, const DevTail* tails, uint64_t* cands, uint32_t cand_cap,
          uint32_t* cand_count, unsigned long long* hits,
-         unsigned long long* touched /*[2]: `.doc` bytes decoded, positions read*/) {
+         unsigned long long* touched /*[unit][2]: `.doc` bytes decoded, positions read*/) {
   __shared__ DevPosTerm s_pt[MT];
   __shared__ DevTail s_tl[MT];
   __shared__ uint32_t s_off[MT];
@@ -539,8 +539,8 @@ k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms
   my_pos = wave::reduce_add(my_pos);
   if (lane == 0) {
     if (my_hits) atomicAdd(&hits[unit], static_cast<unsigned long long>(my_hits));
-    atomicAdd(&touched[0], static_cast<unsigned long long>(bytes));
-    if (my_pos) atomicAdd(&touched[1], static_cast<unsigned long long>(my_pos));
+    atomicAdd(&touched[2u * unit], static_cast<unsigned long long>(bytes));
+    if (my_pos) atomicAdd(&touched[2u * unit + 1u], static_cast<unsigned long long>(my_pos));
   }
 }
 

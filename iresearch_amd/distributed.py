@@ -33,6 +33,53 @@ def _ptr_array(ptrs):
     return (C.c_void_p * len(ptrs))(*ptrs)
 
 
+class Communicator:
+    """irs_hip_comm: the RCCL communicator behind the C ABI (include/irs_hip.h) — the data path
+    of the exchange does not go through torch.distributed.  The 128-byte id is made on rank 0
+    and handed to the other ranks by `broadcast` (any callable: here torch.distributed's object
+    broadcast, in a C++ host MPI or a file)."""
+
+    def __init__(self, L, device_index: int, rank: int, world: int, broadcast=None):
+        self.L, self.rank, self.world = L, rank, world
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            _lib.check(L, L.irs_hip_comm_unique_id(ident), "irs_hip_comm_unique_id")
+        if world > 1:
+            if broadcast is None:
+                def broadcast(b):
+                    box = [b]
+                    dist.broadcast_object_list(box, src=0)
+                    return box[0]
+            raw = broadcast(bytes(ident) if rank == 0 else None)
+            ident = (C.c_uint8 * 128).from_buffer_copy(raw)
+        h = C.c_void_p()
+        _lib.check(L, L.irs_hip_comm_init_rank(device_index, ident, world, rank, C.byref(h)),
+                   "irs_hip_comm_init_rank")
+        self.handle = h
+
+    def all_gather(self, d_send: int, d_recv: int, bytes_per_rank: int, stream=None):
+        _lib.check(self.L, self.L.irs_hip_topk_allgather(self.handle, d_send, d_recv,
+                                                         bytes_per_rank, stream),
+                   "irs_hip_topk_allgather")
+
+    def close(self):
+        if self.handle:
+            self.L.irs_hip_comm_destroy(self.handle)
+            self.handle = None
+
+
+class _CommWork:
+    """What `gather(async_op=True)` returns on the C-ABI path: wait() makes the current stream
+    wait for the collective (like the work handle of torch.distributed)."""
+
+    def __init__(self, done):
+        self.done = done
+
+    def wait(self):
+        if self.done is not None:
+            torch.cuda.current_stream().wait_event(self.done)
+
+
 class TopkExchange:
     """The one exchange step of the path, with every buffer allocated once.
 
@@ -44,9 +91,14 @@ class TopkExchange:
     """
 
     def __init__(self, L, device_index: int, n_segments: int, rank: int, world: int, nq: int,
-                 k: int, tensor_device):
+                 k: int, tensor_device, comm: "Communicator | None" = None):
         self.L, self.device_index, self.nq, self.k = L, device_index, nq, k
         self.world, self.rank = world, rank
+        # comm: the collective goes through irs_hip_topk_allgather (RCCL called from the
+        # library, on its own stream) instead of torch.distributed
+        self.comm = comm
+        self.on_gpu = torch.device(tensor_device).type == "cuda"
+        self.comm_stream = torch.cuda.Stream(device=tensor_device) if (comm and self.on_gpu) else None
         self.per = per = (n_segments + world - 1) // world
         self.n_lists = min(n_segments, world * per)
         self.hit_words = per * nq * k
@@ -75,8 +127,23 @@ class TopkExchange:
 
     def gather(self, async_op: bool = False):
         """The collective alone; with async_op the work handle (None on a single rank)."""
-        if self.world > 1:
+        if self.world <= 1:
+            return None
+        if self.comm is None:
             return dist.all_gather_into_tensor(self.recv, self.send, async_op=async_op)
+        nbytes = self.send.numel() * 8
+        if not self.on_gpu:   # emulator tier: host buffers, no streams
+            self.comm.all_gather(self.send.data_ptr(), self.recv.data_ptr(), nbytes)
+            return _CommWork(None) if async_op else None
+        cur = torch.cuda.current_stream()
+        self.comm_stream.wait_stream(cur)            # the send buffer is complete
+        self.comm.all_gather(self.send.data_ptr(), self.recv.data_ptr(), nbytes,
+                             C.c_void_p(self.comm_stream.cuda_stream))
+        done = torch.cuda.Event()
+        done.record(self.comm_stream)
+        if async_op:
+            return _CommWork(done)
+        cur.wait_event(done)
         return None
 
     def merge(self, stream=None):
@@ -87,8 +154,7 @@ class TopkExchange:
         return self.out_h, self.out_s, self.out_c
 
     def run(self, stream=None):
-        if self.world > 1:
-            dist.all_gather_into_tensor(self.recv, self.send)
+        self.gather()
         _lib.check(self.L, self.L.irs_hip_merge_topk(
             self.device_index, self._lists, self._counts, self._seg_ids.ctypes.data,
             self.n_lists, self.nq, self.k, self.out_h.data_ptr(), self.out_s.data_ptr(),

@@ -1,7 +1,13 @@
 // tests/sim/gpu_rt.h — TEST INFRASTRUCTURE ONLY: the rt:: surface of
 // iresearch_amd/csrc/hip/gpu_rt.h on top of the CPU fiber emulator.
 #pragma once
+#include <atomic>
 #include <chrono>
+#include <cstdio>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <cstddef>
 #include <cstdint>
 #include <cstdlib>
@@ -50,6 +56,7 @@ inline bool sync(stream_t) { return true; }
 inline bool last_error_ok() { return true; }
 inline bool allow_dynamic_smem(const void*, size_t bytes) { return bytes <= sim::kMaxSmem; }
 
+inline bool event_sync(event_t) { return true; }
 inline bool event_create(event_t* e) {
   *e = 0;
   return true;
@@ -68,6 +75,112 @@ inline bool event_elapsed(float* ms, event_t a, event_t b) {
   *ms = float(b - a);
   return true;
 }
+
+// ---- communicator of the CPU test tier: ranks are PROCESSES sharing one file under /dev/shm
+// (header with a generation barrier, then one slot per rank).  Semantics of the RCCL calls
+// of hip/gpu_rt.h, nothing of their performance.
+namespace comm {
+
+constexpr size_t kIdBytes = 128;
+using handle_t = void*;
+constexpr size_t kSlotBytes = 8u << 20;   // largest per-rank message of the tests
+
+struct Shared {
+  std::atomic<uint32_t> arrived;
+  std::atomic<uint32_t> generation;
+  uint32_t nranks;
+  uint32_t pad;
+};
+struct Comm {
+  Shared* sh = nullptr;
+  unsigned char* slots = nullptr;
+  size_t map_bytes = 0;
+  int nranks = 0, rank = 0;
+  char path[160];
+};
+
+inline bool shm_map(const char* path, size_t bytes, bool create, void** out) {
+  int fd = -1;
+  if (create) {
+    fd = ::open(path, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0 || ::ftruncate(fd, off_t(bytes)) != 0) return false;   // (new file: zero-filled)
+  } else {
+    for (int tries = 0; tries < 20000 && fd < 0; ++tries) {   // up to ~20 s
+      fd = ::open(path, O_RDWR);
+      struct stat st;
+      if (fd >= 0 && (::fstat(fd, &st) != 0 || size_t(st.st_size) < bytes)) {
+        ::close(fd);
+        fd = -1;
+      }
+      if (fd < 0) ::usleep(1000);
+    }
+    if (fd < 0) return false;
+  }
+  void* m = ::mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  ::close(fd);
+  if (m == MAP_FAILED) return false;
+  *out = m;
+  return true;
+}
+
+inline bool unique_id(void* id128) {
+  std::memset(id128, 0, kIdBytes);
+  static std::atomic<unsigned> counter{0};
+  std::snprintf(static_cast<char*>(id128), kIdBytes, "/dev/shm/irs_sim_comm_%ld_%u_%ld",
+                long(::getpid()), counter.fetch_add(1),
+                long(std::chrono::steady_clock::now().time_since_epoch().count() & 0xFFFFFF));
+  return true;
+}
+inline void barrier(Comm* c) {
+  const uint32_t gen = c->sh->generation.load();
+  if (c->sh->arrived.fetch_add(1) + 1 == uint32_t(c->nranks)) {
+    c->sh->arrived.store(0);
+    c->sh->generation.fetch_add(1);
+  } else {
+    while (c->sh->generation.load() == gen) ::usleep(50);
+  }
+}
+inline bool init_rank(handle_t* out, int nranks, const void* id128, int rank) {
+  if (nranks < 1 || rank < 0 || rank >= nranks) return false;
+  Comm* c = new Comm;
+  c->nranks = nranks;
+  c->rank = rank;
+  std::memcpy(c->path, id128, kIdBytes);
+  c->path[kIdBytes - 1] = 0;
+  c->map_bytes = 4096 + size_t(nranks) * kSlotBytes;
+  void* m = nullptr;
+  // rank 0 creates (and zero-fills) the file, the others wait for it to appear
+  if (!shm_map(c->path, c->map_bytes, rank == 0, &m)) {
+    delete c;
+    return false;
+  }
+  c->sh = static_cast<Shared*>(m);
+  c->slots = static_cast<unsigned char*>(m) + 4096;
+  if (rank == 0) c->sh->nranks = uint32_t(nranks);
+  barrier(c);
+  *out = c;
+  return true;
+}
+inline bool all_gather(handle_t h, const void* send, void* recv, size_t bytes, stream_t) {
+  Comm* c = static_cast<Comm*>(h);
+  if (bytes > kSlotBytes) return false;
+  std::memcpy(c->slots + size_t(c->rank) * kSlotBytes, send, bytes);
+  barrier(c);
+  for (int r = 0; r < c->nranks; ++r)
+    std::memcpy(static_cast<unsigned char*>(recv) + size_t(r) * bytes, c->slots + size_t(r) * kSlotBytes, bytes);
+  barrier(c);
+  return true;
+}
+inline void destroy(handle_t h) {
+  Comm* c = static_cast<Comm*>(h);
+  if (!c) return;
+  barrier(c);   // nobody still reads the slots
+  ::munmap(c->sh, c->map_bytes);
+  if (c->rank == 0) ::unlink(c->path);
+  delete c;
+}
+
+}  // namespace comm
 
 }  // namespace rt
 

@@ -87,6 +87,21 @@ def _worker(rank, world, port, sim_path, out_dir, phrase=False):
     last = px.finish()
     assert all(torch.equal(x, y) for x, y in zip(last, (oh, osg, oc)))
     assert px.finish() is None
+    # ... and with the collective behind the C ABI (irs_hip_comm_* / irs_hip_topk_allgather:
+    # RCCL on the GPU, a shared-memory stand-in in this emulator build) instead of
+    # torch.distributed: same answer, one-shot and pipelined
+    comm = distributed.Communicator(L, 0, rank, world)
+    ex2 = distributed.TopkExchange(L, 0, N_SEGS, rank, world, nq, K, "cpu", comm=comm)
+    b.results_to_device(*ex2.slot(0))
+    assert all(torch.equal(x, y) for x, y in zip(ex2.run(), (oh, osg, oc)))
+    px2 = distributed.PipelinedExchange(L, 0, N_SEGS, rank, world, nq, K, "cpu", comm=comm)
+    for it in range(2):
+        b.run()
+        px2.finish()
+        b.results_to_device(*px2.slot(it & 1, 0))
+        px2.start(it & 1)
+    assert all(torch.equal(x, y) for x, y in zip(px2.finish(), (oh, osg, oc)))
+    comm.close()
     np.save(os.path.join(out_dir, "hits_%d.npy" % rank), oh.numpy())
     np.save(os.path.join(out_dir, "segs_%d.npy" % rank), osg.numpy())
     np.save(os.path.join(out_dir, "counts_%d.npy" % rank), oc.numpy())

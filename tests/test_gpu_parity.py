@@ -340,3 +340,20 @@ def test_config3_full_size_properties(gpulib):
         bb.close()
     for r in readers:
         r.close()
+
+
+def test_rccl_behind_the_c_abi(gpulib):
+    """irs_hip_comm_* / irs_hip_topk_allgather on the real GPU: librccl is bound at first use,
+    a one-rank communicator is created from a fresh id and the all-gather moves the send
+    buffer (multi-rank runs need several GPUs: the 2-rank flow is covered on the CPU tier)."""
+    import torch
+
+    from iresearch_amd import distributed
+    comm = distributed.Communicator(gpulib, 0, 0, 1)
+    send = torch.arange(1 << 16, dtype=torch.int64, device="cuda")
+    recv = torch.zeros_like(send)
+    comm.all_gather(send.data_ptr(), recv.data_ptr(), send.numel() * 8)
+    torch.cuda.synchronize()
+    assert torch.equal(send, recv)
+    comm.close()
+

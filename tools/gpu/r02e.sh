@@ -1,0 +1,10 @@
+set -x
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/r02e_gputests.log 2>&1; echo "gputests rc=$?"
+tail -5 gpurun_out/r02e_gputests.log
+( timeout 200 python tools/sweep.py --op and --terms 3 --configs 8192:64 --nocheck --wand 2>&1 | tail -4
+  timeout 200 python tools/sweep.py --op and --terms 2 --configs 8192:64 --nocheck 2>&1 | tail -3 ) > gpurun_out/r02e_sweep.txt 2>&1
+cat gpurun_out/r02e_sweep.txt
+timeout 900 python bench.py --config 5 --steps 5 --warmup 2 > gpurun_out/r02e_bench_c5.json 2> gpurun_out/r02e_bench_c5.err; echo "c5 rc=$?"
+cat gpurun_out/r02e_bench_c5.json; tail -3 gpurun_out/r02e_bench_c5.err
