@@ -481,7 +481,13 @@ def main_config5(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     alg = {n: b.work() for n, b in bat.items()}
-    touched = {n: b.touched() for n, b in bat.items()}
+    # what the kernels really decoded: one extra, untimed run with the counters on
+    touched = {}
+    for n, b in bat.items():
+        b.profile(3)
+        b.run(sptr)
+        b.results()
+        touched[n] = b.touched()
     vals = [alg["and"][0], alg["phrase"][0], touched["and"][0], touched["phrase"][0],
             touched["phrase"][1]]
     if world > 1:

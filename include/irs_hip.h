@@ -297,6 +297,8 @@ enum {
   IRS_HIP_K_SELECT = 3, /* exact top-k of the candidates            */
   IRS_HIP_K_COUNT = 4
 };
+/* enable: bit 0 = time the kernels (below); bit 1 = let the block-driven kernels count what
+ * they decode (irs_hip_batch_touched) — a diagnostic run: the counting costs atomics. */
 int irs_hip_batch_profile(irs_hip_batch* batch, int enable);
 int irs_hip_batch_timings(irs_hip_batch* batch, float ms[IRS_HIP_K_COUNT]);
 /* Work accounting for the roofline: algorithmic bytes A(q)
@@ -307,7 +309,8 @@ int irs_hip_batch_work(irs_hip_batch* batch, uint64_t* algorithmic_bytes,
 /* What the last run of a conjunction / phrase batch really read, next to the algorithmic
  * bytes above ("report both A(q) and bytes actually touched"): encoded bytes of
  * the `.doc` blocks it decoded plus the norm bytes it read, and the number of positions it
- * read from `.pos`.  (Doc-tile batches read every block of every term: A(q).) */
+ * read from `.pos`.  (Doc-tile batches read every block of every term: A(q).)  Needs
+ * irs_hip_batch_profile(batch, 2 | ...) before the run. */
 int irs_hip_batch_touched(irs_hip_batch* batch, uint64_t* doc_bytes, uint64_t* positions);
 /* How many times fetching results had to re-execute the batch so far: the pilot's
  * estimated threshold left fewer than k candidates for some query (re-run with the
@@ -335,6 +338,14 @@ int irs_hip_merge_topk(int32_t device, const void* const* d_lists,
  * into one heap (utils/index-search.cpp:719-779) becomes when the segments live on different
  * GPUs.  irs_hip_comm_unique_id: on one rank; the caller distributes the 128 bytes to the
  * others by whatever it has (MPI, a file, a socket), exactly as with ncclUniqueId. */
+/* Device buffers for a host that drives the exchange without a HIP toolchain of its own (the
+ * C++ layer iresearch_amd/cpp/irs_hip.hpp): plain hipMalloc / hipMemcpy / hipStreamSynchronize. */
+int irs_hip_device_alloc(int32_t device, uint64_t bytes, void** d_out);
+void irs_hip_device_free(int32_t device, void* d_ptr);
+int irs_hip_device_upload(int32_t device, void* d_dst, const void* h_src, uint64_t bytes);
+int irs_hip_device_download(int32_t device, void* h_dst, const void* d_src, uint64_t bytes);
+int irs_hip_device_sync(int32_t device, void* stream);
+
 typedef struct irs_hip_comm irs_hip_comm;
 #define IRS_HIP_COMM_ID_BYTES 128u
 int irs_hip_comm_unique_id(uint8_t id[IRS_HIP_COMM_ID_BYTES]);

@@ -65,7 +65,8 @@ SYMBOLS = (
     "irs_hip_batch_timings", "irs_hip_batch_work", "irs_hip_batch_reruns", "irs_hip_merge_topk",
     "irs_hip_batch_set_wand", "irs_hip_term_blockmax", "irs_hip_batch_touched",
     "irs_hip_comm_unique_id", "irs_hip_comm_init_rank", "irs_hip_comm_destroy",
-    "irs_hip_topk_allgather",
+    "irs_hip_topk_allgather", "irs_hip_device_alloc", "irs_hip_device_free",
+    "irs_hip_device_upload", "irs_hip_device_download", "irs_hip_device_sync",
 )
 
 

@@ -17,6 +17,7 @@
 #pragma once
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdint>
 #include <stdexcept>
@@ -331,6 +332,12 @@ class QueryBatch {
     for (Part& part : part_) irs_hip_batch_destroy(part.h);
   }
 
+  // ExecutionContext::wand (index-search --search-mode wand): block-max pruning; before run()
+  QueryBatch& set_wand(bool enable) {
+    for (Part& part : part_)
+      if (part.h) check(irs_hip_batch_set_wand(part.h, enable ? 1 : 0), "irs_hip_batch_set_wand");
+    return *this;
+  }
   QueryBatch& run(void* stream = nullptr) {
     for (Part& part : part_)
       if (part.h) check(irs_hip_batch_run(part.h, stream), "irs_hip_batch_run");
@@ -362,6 +369,12 @@ class QueryBatch {
         }
     }
     return r;
+  }
+  // the one device batch of a list of queries that are all boolean or all by_phrase
+  // (what search_sharded hands to irs_hip_batch_results_to_device)
+  irs_hip_batch* single_part() const {
+    if (part_[0].h && part_[1].h) throw not_supported(IRS_HIP_EUNSUPPORTED, "mixed boolean / phrase batch");
+    return part_[0].h ? part_[0].h : part_[1].h;
   }
   uint32_t reruns() const {
     uint32_t total = 0;
@@ -418,6 +431,116 @@ std::vector<std::vector<ScoredDoc>> search(const std::vector<const SegmentReader
                                            const Scorer& scorer, uint32_t k) {
   QueryBatch batch(segments, prepare(filters, scorer, index), k);
   return merge(batch.run().results());
+}
+
+// ---- several GPUs: one process per GPU, segments sharded, ONE all-gather per batch -----------
+// (what the harness loop over `reader`'s segments becomes when the segments
+// live on different devices)
+class DeviceBuffer {
+ public:
+  DeviceBuffer(int32_t device, uint64_t bytes) : device_{device}, bytes_{bytes} {
+    check(irs_hip_device_alloc(device, bytes ? bytes : 1, &p_), "irs_hip_device_alloc");
+  }
+  DeviceBuffer(const DeviceBuffer&) = delete;
+  DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+  ~DeviceBuffer() { irs_hip_device_free(device_, p_); }
+  void* get() const noexcept { return p_; }
+  char* at(uint64_t off) const noexcept { return static_cast<char*>(p_) + off; }
+  uint64_t bytes() const noexcept { return bytes_; }
+
+ private:
+  int32_t device_;
+  uint64_t bytes_;
+  void* p_ = nullptr;
+};
+
+class Communicator {
+ public:
+  using Id = std::array<uint8_t, IRS_HIP_COMM_ID_BYTES>;
+  // on ONE rank; the caller carries the bytes to the others (MPI_Bcast, a file, a socket)
+  static Id unique_id() {
+    Id id{};
+    check(irs_hip_comm_unique_id(id.data()), "irs_hip_comm_unique_id");
+    return id;
+  }
+  Communicator(int32_t device, const Id& id, int n_ranks, int rank)
+    : device_{device}, n_ranks_{n_ranks}, rank_{rank} {
+    check(irs_hip_comm_init_rank(device, id.data(), n_ranks, rank, &h_), "irs_hip_comm_init_rank");
+  }
+  Communicator(const Communicator&) = delete;
+  Communicator& operator=(const Communicator&) = delete;
+  ~Communicator() { irs_hip_comm_destroy(h_); }
+  int n_ranks() const noexcept { return n_ranks_; }
+  int rank() const noexcept { return rank_; }
+  int32_t device() const noexcept { return device_; }
+  void all_gather(const void* d_send, void* d_recv, uint64_t bytes_per_rank, void* stream = nullptr) {
+    check(irs_hip_topk_allgather(h_, d_send, d_recv, bytes_per_rank, stream), "irs_hip_topk_allgather");
+  }
+
+ private:
+  int32_t device_;
+  int n_ranks_, rank_;
+  irs_hip_comm* h_ = nullptr;
+};
+
+// Every rank calls this with ITS segments (`first_segment` = global ordinal of the first one;
+// ranks hold consecutive blocks of `per_rank` segments, the last block may be short) and the
+// statistics of ALL segments of the index (they are index-global: term_filter.cpp:102-125).
+// Returns, on every rank, the global top-k per query: ScoredDoc::segment is the GLOBAL ordinal.
+// The queries must be all boolean or all by_phrase.
+template<typename Scorer>
+std::vector<std::vector<ScoredDoc>> search_sharded(Communicator& comm,
+                                                   const std::vector<const SegmentReader*>& mine,
+                                                   uint32_t per_rank, uint32_t n_segments,
+                                                   const std::vector<SegmentStats>& index,
+                                                   const std::vector<filter>& filters,
+                                                   const Scorer& scorer, uint32_t k, bool wand = false) {
+  const uint32_t nq = uint32_t(filters.size());
+  const int32_t dev = comm.device();
+  if (mine.size() > per_rank) throw illegal_argument(IRS_HIP_EINVAL, "more local segments than per_rank");
+  QueryBatch batch(mine.empty() ? std::vector<const SegmentReader*>{} : mine,
+                   prepare(filters, scorer, index), k);
+  // one block per rank: per_rank hit tables [nq][k], then per_rank count tables [nq] (padded
+  // to 8 bytes) — irs_hip_batch_results_to_device writes the local lists straight into it
+  const uint64_t hit_bytes = uint64_t(per_rank) * nq * k * sizeof(irs_hip_hit);
+  const uint64_t cnt_bytes = (uint64_t(per_rank) * nq * 4 + 7) & ~uint64_t(7);
+  const uint64_t block = hit_bytes + cnt_bytes;
+  DeviceBuffer send(dev, block), recv(dev, block * uint64_t(comm.n_ranks()));
+  {
+    std::vector<char> zero(block, 0);   // slots of segments this rank does not have: count 0
+    check(irs_hip_device_upload(dev, send.get(), zero.data(), block), "irs_hip_device_upload");
+  }
+  if (!mine.empty()) {
+    if (wand) batch.set_wand(true);
+    batch.run();
+    check(irs_hip_batch_results_to_device(batch.single_part(), send.at(0), send.at(hit_bytes), nullptr),
+          "irs_hip_batch_results_to_device");
+  }
+  check(irs_hip_device_sync(dev, nullptr), "irs_hip_device_sync");
+  comm.all_gather(send.get(), recv.get(), block);
+  std::vector<const void*> lists, counts;
+  std::vector<uint32_t> ids;
+  for (uint32_t s = 0; s < n_segments; ++s) {
+    const uint32_t r = s / per_rank, j = s % per_rank;
+    lists.push_back(recv.at(block * r + uint64_t(j) * nq * k * sizeof(irs_hip_hit)));
+    counts.push_back(recv.at(block * r + hit_bytes + uint64_t(j) * nq * 4));
+    ids.push_back(s);
+  }
+  DeviceBuffer out_h(dev, uint64_t(nq) * k * sizeof(irs_hip_hit)), out_s(dev, uint64_t(nq) * k * 4),
+    out_c(dev, uint64_t(nq) * 4);
+  check(irs_hip_merge_topk(dev, lists.data(), counts.data(), ids.data(), n_segments, nq, k,
+                           out_h.get(), out_s.get(), out_c.get(), nullptr),
+        "irs_hip_merge_topk");
+  std::vector<irs_hip_hit> h(size_t(nq) * k);
+  std::vector<uint32_t> sg(size_t(nq) * k), c(nq);
+  check(irs_hip_device_download(dev, h.data(), out_h.get(), h.size() * sizeof(irs_hip_hit)), "download");
+  check(irs_hip_device_download(dev, sg.data(), out_s.get(), sg.size() * 4), "download");
+  check(irs_hip_device_download(dev, c.data(), out_c.get(), c.size() * 4), "download");
+  std::vector<std::vector<ScoredDoc>> out(nq);
+  for (uint32_t q = 0; q < nq; ++q)
+    for (uint32_t i = 0; i < c[q]; ++i)
+      out[q].push_back(ScoredDoc{h[size_t(q) * k + i].score, sg[size_t(q) * k + i], h[size_t(q) * k + i].doc});
+  return out;
 }
 
 }  // namespace irs_hip_host

@@ -147,7 +147,8 @@ struct ConjArgs {
   uint32_t* cand_count;
   unsigned long long* hits;
   unsigned long long* touched;  // [unit][2]: `.doc` + norm bytes actually decoded / read (full
-                                // pass; per unit: one hot address would serialise the atomics)
+                                // pass; per unit: one hot address would serialise the atomics);
+                                // null unless the batch counts (irs_hip_batch_profile bit 1)
   uint32_t* hist;               // [unit][kBins], pilot pass only
   uint32_t jt;
   uint32_t cand_cap;
@@ -155,8 +156,13 @@ struct ConjArgs {
   uint32_t wand;                // prune lead blocks by block-max bounds
 };
 
+#ifndef IRS_CONJ_WAVES_PER_EU   // tuning experiment: force a register budget (8 -> 64 VGPRs)
+#define IRS_CONJ_ATTR
+#else
+#define IRS_CONJ_ATTR __attribute__((amdgpu_waves_per_eu(IRS_CONJ_WAVES_PER_EU, IRS_CONJ_WAVES_PER_EU)))
+#endif
 template<int LAYOUT>
-__global__ void __launch_bounds__(kConjWaves * 64)
+__global__ void __launch_bounds__(kConjWaves * 64) IRS_CONJ_ATTR
 k_conj(ConjArgs A, uint32_t pilot) {
   __shared__ DevTail s_tl[kConjWaves * kMaxTerms];
   __shared__ DevQTerm s_qt[kConjWaves * kMaxTerms];
@@ -310,7 +316,8 @@ k_conj(ConjArgs A, uint32_t pilot) {
       alive[2u * lane + 2u] = incl;
       wave::sync();
       if (alive[kBlock] == 0u) {   // no doc reached by every term so far: the block is done
-        if (!pilot && lane == 0) atomicAdd(&A.touched[2u * unit], static_cast<unsigned long long>(bytes));
+        if (!pilot && A.touched && lane == 0)
+          atomicAdd(&A.touched[2u * unit], static_cast<unsigned long long>(bytes));
         return;
       }
     }
@@ -369,7 +376,7 @@ k_conj(ConjArgs A, uint32_t pilot) {
   }
 
   // ---- 3. docs every term reached
-  if (!pilot && lane == 0) {
+  if (!pilot && A.touched && lane == 0) {
     // + the norm of every lead doc, where the scorer reads one
     const uint32_t nb = needs_norm(w_qt[0].kind) ? n * seg.norm_width : 0u;
     atomicAdd(&A.touched[2u * unit], static_cast<unsigned long long>(bytes + nb));

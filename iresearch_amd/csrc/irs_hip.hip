@@ -151,6 +151,7 @@ struct irs_hip_batch {
   uint32_t nw_log2 = 3;        // log2(wavefronts per such workgroup)
   uint64_t alg_bytes = 0, postings = 0;
   bool profile = false;
+  bool count_touched = false;   // irs_hip_batch_profile bit 1: the kernels count what they decode
   bool events_ready = false;
   rt::event_t ev[2 * IRS_HIP_K_COUNT];
   rt::stream_t stream = nullptr;
@@ -405,7 +406,7 @@ bool launch_conj(irs_hip_batch* b, rt::stream_t st) {
   a.cand_count = b->d_cand_count.as<uint32_t>();
   a.hits = b->d_hits.as<unsigned long long>();
   a.hist = b->d_conj_hist.as<uint32_t>();
-  a.touched = b->d_touched.as<unsigned long long>();
+  a.touched = b->count_touched ? b->d_touched.as<unsigned long long>() : nullptr;
   a.seek = b->d_conj_seek.as<uint32_t>();
   a.unit_items = b->d_conj_unit_items.as<uint32_t>();
   a.jt = b->jt;
@@ -477,7 +478,8 @@ bool launch_phrase(irs_hip_batch* b, rt::stream_t st) {
             b->d_segs.as<DevSegment>(), b->d_queries.as<DevQuery>(), b->d_qterms.as<DevQTerm>(),
             b->jt, b->d_phrase_wgs.as<PhraseWg>(), b->d_tails.as<DevTail>(),
             b->d_cands.as<uint64_t>(), b->cand_cap, b->d_cand_count.as<uint32_t>(),
-            b->d_hits.as<unsigned long long>(), b->d_touched.as<unsigned long long>());
+            b->d_hits.as<unsigned long long>(),
+            b->count_touched ? b->d_touched.as<unsigned long long>() : nullptr);
   return rt::last_error_ok();
 }
 template<int LAYOUT>
@@ -1413,7 +1415,7 @@ static int topk_allgather_impl(irs_hip_comm* c, const void* d_send, void* d_recv
 }
 
 static int batch_touched_impl(irs_hip_batch* b, uint64_t* doc_bytes, uint64_t* positions) {
-  if (!b || !b->ran) return IRS_HIP_EINVAL;
+  if (!b || !b->ran || !b->count_touched) return IRS_HIP_EINVAL;
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
   std::vector<uint64_t> v(size_t(b->nq) * 2);
   if (!rt::d2h(v.data(), b->d_touched.p, v.size() * 8, b->stream) || !rt::sync(b->stream))
@@ -1431,12 +1433,13 @@ static int batch_touched_impl(irs_hip_batch* b, uint64_t* doc_bytes, uint64_t* p
 static int batch_profile_impl(irs_hip_batch* b, int enable) {
   if (!b) return IRS_HIP_EINVAL;
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
-  if (enable && !b->events_ready) {
+  if ((enable & 1) && !b->events_ready) {
     for (auto& e : b->ev)
       if (!rt::event_create(&e)) return IRS_HIP_EHIP;
     b->events_ready = true;
   }
-  b->profile = enable != 0;
+  b->profile = (enable & 1) != 0;
+  b->count_touched = (enable & 2) != 0;
   return IRS_HIP_OK;
 }
 
@@ -1737,6 +1740,38 @@ int irs_hip_batch_set_wand(irs_hip_batch* b, int enable) {
 int irs_hip_term_blockmax(irs_hip_segment* seg, uint32_t term, uint32_t* max_freqs,
                           uint32_t* min_norms, uint32_t cap, uint32_t* count) {
   return guarded([&] { return term_blockmax_impl(seg, term, max_freqs, min_norms, cap, count); });
+}
+int irs_hip_device_alloc(int32_t device, uint64_t bytes, void** d_out) {
+  return guarded([&] {
+    if (!d_out) return int(IRS_HIP_EINVAL);
+    *d_out = nullptr;
+    if (!device_usable(device)) return int(IRS_HIP_EHIP);
+    *d_out = rt::dmalloc(bytes);
+    return int(*d_out ? IRS_HIP_OK : IRS_HIP_ENOMEM);
+  });
+}
+void irs_hip_device_free(int32_t device, void* d_ptr) {
+  if (rt::set_device(device)) rt::dfree(d_ptr);
+}
+int irs_hip_device_upload(int32_t device, void* d_dst, const void* h_src, uint64_t bytes) {
+  return guarded([&] {
+    if ((!d_dst || !h_src) && bytes) return int(IRS_HIP_EINVAL);
+    if (!rt::set_device(device)) return int(IRS_HIP_EHIP);
+    return int(rt::h2d(d_dst, h_src, bytes, nullptr) && rt::sync(nullptr) ? IRS_HIP_OK : IRS_HIP_EHIP);
+  });
+}
+int irs_hip_device_download(int32_t device, void* h_dst, const void* d_src, uint64_t bytes) {
+  return guarded([&] {
+    if ((!h_dst || !d_src) && bytes) return int(IRS_HIP_EINVAL);
+    if (!rt::set_device(device)) return int(IRS_HIP_EHIP);
+    return int(rt::d2h(h_dst, d_src, bytes, nullptr) && rt::sync(nullptr) ? IRS_HIP_OK : IRS_HIP_EHIP);
+  });
+}
+int irs_hip_device_sync(int32_t device, void* stream) {
+  return guarded([&] {
+    if (!rt::set_device(device)) return int(IRS_HIP_EHIP);
+    return int(rt::sync(static_cast<rt::stream_t>(stream)) ? IRS_HIP_OK : IRS_HIP_EHIP);
+  });
 }
 int irs_hip_comm_unique_id(uint8_t id[IRS_HIP_COMM_ID_BYTES]) {
   return guarded([&] { return comm_unique_id_impl(id); });

@@ -536,11 +536,13 @@ k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms
     }
   }
   my_hits = wave::reduce_add(my_hits);
-  my_pos = wave::reduce_add(my_pos);
-  if (lane == 0) {
-    if (my_hits) atomicAdd(&hits[unit], static_cast<unsigned long long>(my_hits));
-    atomicAdd(&touched[2u * unit], static_cast<unsigned long long>(bytes));
-    if (my_pos) atomicAdd(&touched[2u * unit + 1u], static_cast<unsigned long long>(my_pos));
+  if (lane == 0 && my_hits) atomicAdd(&hits[unit], static_cast<unsigned long long>(my_hits));
+  if (touched) {   // (only when the batch counts: irs_hip_batch_profile bit 1)
+    my_pos = wave::reduce_add(my_pos);
+    if (lane == 0) {
+      atomicAdd(&touched[2u * unit], static_cast<unsigned long long>(bytes));
+      if (my_pos) atomicAdd(&touched[2u * unit + 1u], static_cast<unsigned long long>(my_pos));
+    }
   }
 }
 

@@ -300,6 +300,7 @@ class QueryBatch:
         return self
 
     def profile(self, enable=True):
+        """True / 1: kernel timings; 2: count what the block-driven kernels decode; 3: both."""
         _lib.check(self.L, self.L.irs_hip_batch_profile(self.handle, int(enable)),
                    "irs_hip_batch_profile")
         return self

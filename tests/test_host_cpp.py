@@ -32,6 +32,31 @@ def _build_and_run(tmp_path, abi_lib: Path, extra=()):
     assert "test_host OK" in run.stdout
 
 
+def test_cpp_sharded_search_two_processes(simlib, tmp_path):
+    """search_sharded of the C++ host layer as TWO processes (one per rank) on the emulator
+    build: segments sharded, the all-gather through irs_hip_comm_* / irs_hip_topk_allgather
+    (a shared-memory stand-in for RCCL here), merge on every rank — against the one-process
+    search() over all segments."""
+    from iresearch_amd import _build
+    abi_lib, synth = Path(simlib._name), _build.build_synth()
+    exe = tmp_path / "test_sharded"
+    cmd = ["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-Wall",
+           "-I", str(ROOT / "include"), "-I", str(ROOT / "iresearch_amd" / "cpp"),
+           "-I", str(ROOT / "iresearch_amd" / "index"),
+           str(ROOT / "tests" / "cpp" / "test_sharded.cpp"), "-o", str(exe),
+           str(abi_lib), str(synth), "-pthread",
+           "-Wl,-rpath," + str(abi_lib.parent), "-Wl,-rpath," + str(Path(synth).parent)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    id_file = tmp_path / "comm_id"
+    procs = [subprocess.Popen([str(exe), "2", str(r), str(id_file)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in (0, 1)]
+    for r, p in enumerate(procs):
+        text, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, text[-3000:]
+        assert "test_sharded OK: rank %d" % r in text
+
+
 def test_cpp_host_layer_on_the_emulator(simlib, tmp_path):
     _build_and_run(tmp_path, Path(simlib._name))
 
