@@ -433,6 +433,122 @@ std::vector<std::vector<ScoredDoc>> search(const std::vector<const SegmentReader
   return merge(batch.run().results());
 }
 
+// ---- adapter groundwork: what a postings_reader built on this library does on the HOST --------
+// before anything reaches the GPU: validate the files, decode the term
+// dictionary's term_meta entries, read the Norm2 column header.
+namespace format10 {
+
+constexpr int32_t kFormatMagic = 0x3fd76c17;                 // format_utils.hpp:36
+constexpr uint32_t kFooterLen = 2 * 4 + 8;                   // format_utils.hpp:38
+constexpr const char* kDocFormatName = "iresearch_10_postings_documents";   // formats_10.cpp:325-326
+constexpr const char* kPosFormatName = "iresearch_10_postings_positions";   // :327-328
+constexpr uint32_t kBlockSize = IRS_HIP_BLOCK_SIZE;
+
+inline uint32_t be32(const uint8_t* p) {
+  return (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | p[3];
+}
+inline uint64_t be64(const uint8_t* p) { return (uint64_t(be32(p)) << 32) | be32(p + 4); }
+
+// bytes_io<T>::vread (bytes_utils.hpp:176-206): LEB128, least significant group first
+template<typename T>
+inline T vread(const uint8_t*& p) {
+  T v = 0;
+  for (unsigned shift = 0;; shift += 7) {
+    const uint8_t b = *p++;
+    v |= T(b & 0x7Fu) << shift;
+    if (!(b & 0x80u) || shift + 7 >= sizeof(T) * 8 + 6) break;
+  }
+  return v;
+}
+
+// CRC-32C (Castagnoli), bit-reflected, as absl::ExtendCrc32c from 0 (utils/crc.hpp:31-54)
+inline uint32_t crc32c(const uint8_t* p, size_t n) {
+  static const std::array<uint32_t, 256> table = [] {
+    std::array<uint32_t, 256> t{};
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1u) ? 0x82F63B78u : 0u);
+      t[i] = c;
+    }
+    return t;
+  }();
+  uint32_t c = 0xFFFFFFFFu;
+  for (size_t i = 0; i < n; ++i) c = table[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
+  return c ^ 0xFFFFFFFFu;
+}
+
+// format_utils::check_header (format_utils.cpp:74-105): magic, format name, version range.
+// Returns the version; *header_len = where the postings start.
+inline int32_t check_header(const uint8_t* f, uint64_t len, const char* format, int32_t min_ver,
+                            int32_t max_ver, size_t* header_len = nullptr) {
+  const size_t nlen = std::char_traits<char>::length(format);
+  const size_t expected = 4 + 1 + nlen + 4;   // header_length(): name sizes < 128 take one vint byte
+  if (len < expected) throw index_error(IRS_HIP_ECORRUPT, "While checking header, error: file too short");
+  if (int32_t(be32(f)) != kFormatMagic)
+    throw index_error(IRS_HIP_ECORRUPT, "While checking header, error: invalid magic");
+  if (f[4] != nlen || std::char_traits<char>::compare(reinterpret_cast<const char*>(f + 5), format, nlen))
+    throw index_error(IRS_HIP_ECORRUPT, "While checking header, error: format mismatch");
+  const int32_t ver = int32_t(be32(f + 5 + nlen));
+  if (ver < min_ver || ver > max_ver)
+    throw index_error(IRS_HIP_ECORRUPT, "While checking header, error: invalid version");
+  if (header_len) *header_len = expected;
+  return ver;
+}
+
+// validate_footer + check_footer (format_utils.cpp:32-53, format_utils.hpp:44-69): footer magic,
+// algorithm id 0 and — with `verify_checksum` — the CRC-32C of everything in front of it.
+inline void check_footer(const uint8_t* f, uint64_t len, bool verify_checksum = true) {
+  if (len < kFooterLen) throw index_error(IRS_HIP_ECORRUPT, "While validating footer, error: invalid position");
+  const uint8_t* t = f + len - kFooterLen;
+  if (int32_t(be32(t)) != -kFormatMagic)
+    throw index_error(IRS_HIP_ECORRUPT, "While validating footer, error: invalid magic number");
+  if (be32(t + 4) != 0)
+    throw index_error(IRS_HIP_ECORRUPT, "While validating footer, error: invalid algorithm");
+  if (verify_checksum && be64(t + 8) != crc32c(f, len - 8))
+    throw index_error(IRS_HIP_ECORRUPT, "While validating footer, error: checksum mismatch");
+}
+
+// postings_reader_base::decode (formats_10.cpp:3421-3456): one term_meta entry of a term
+// dictionary block, delta-coded against the previous entry of the block (`state` carries it:
+// doc_start / pos_start / pay_start accumulate; a block's first entry starts from zeros).
+// Returns the bytes consumed.
+inline size_t decode_term_meta(const uint8_t* in, bool has_freq, bool has_pos, bool has_pay_or_offs,
+                               irs_hip_term_meta& state) {
+  const uint8_t* p = in;
+  state.docs_count = vread<uint32_t>(p);
+  if (has_freq) state.freq = state.docs_count + vread<uint32_t>(p);
+  state.doc_start += vread<uint64_t>(p);
+  if (has_freq && state.freq && has_pos) {
+    state.pos_start += vread<uint64_t>(p);
+    state.pos_end = state.freq > kBlockSize ? vread<uint64_t>(p) : ~uint64_t(0);   // address_limits::invalid()
+    if (has_pay_or_offs) state.pay_start += vread<uint64_t>(p);
+  }
+  if (state.docs_count == 1) {
+    state.e_skip_start = vread<uint32_t>(p);     // e_single_doc (the union's other member)
+  } else if (state.docs_count > kBlockSize) {
+    state.e_skip_start = vread<uint64_t>(p);
+  }
+  return size_t(p - in);
+}
+
+// Norm2Header::Read (norm.cpp:117-146; layout :107-115): version byte, bytes per value,
+// min and max field length (big-endian).
+struct Norm2Header {
+  uint32_t num_bytes = 0, min = 0, max = 0;
+  // Norm2ReaderContext::max_num_bytes: 1 selects the norm_cache BM25 variant (bm25.cpp:466-470)
+  uint32_t max_num_bytes() const { return max <= 0xFFu ? 1u : (max <= 0xFFFFu ? 2u : 4u); }
+};
+inline bool read_norm2_header(const uint8_t* payload, size_t size, Norm2Header& out) {
+  if (size != 10 || payload[0] != 0) return false;             // ByteSize(), Norm2Version::kMin
+  if (payload[1] != 1 && payload[1] != 2 && payload[1] != 4) return false;   // CheckNumBytes
+  out.num_bytes = payload[1];
+  out.min = be32(payload + 2);
+  out.max = be32(payload + 6);
+  return true;
+}
+
+}  // namespace format10
+
 // ---- several GPUs: one process per GPU, segments sharded, ONE all-gather per batch -----------
 // (what the harness loop over `reader`'s segments becomes when the segments
 // live on different devices)

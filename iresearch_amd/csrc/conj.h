@@ -27,6 +27,7 @@
 // The same kernel run over every P-th lead block with `pilot` set histograms the scores of
 // the matches instead (k_conj_threshold turns the histogram into the threshold bin).
 #pragma once
+#include "gpu_rt.h"
 #include "phrase.h"
 #include "score.h"
 
@@ -156,11 +157,9 @@ struct ConjArgs {
   uint32_t wand;                // prune lead blocks by block-max bounds
 };
 
-#ifndef IRS_CONJ_WAVES_PER_EU   // tuning experiment: force a register budget (8 -> 64 VGPRs)
-#define IRS_CONJ_ATTR
-#else
-#define IRS_CONJ_ATTR __attribute__((amdgpu_waves_per_eu(IRS_CONJ_WAVES_PER_EU, IRS_CONJ_WAVES_PER_EU)))
-#endif
+// 8 wavefronts per SIMD (a 64-VGPR budget, a few spilled values): the kernel waits on chains
+// of dependent loads, so resident wavefronts count for more than registers (AND-3: 6.8 -> 6.0 ms)
+#define IRS_CONJ_ATTR RT_WAVES_PER_SIMD(8)
 template<int LAYOUT>
 __global__ void __launch_bounds__(kConjWaves * 64) IRS_CONJ_ATTR
 k_conj(ConjArgs A, uint32_t pilot) {

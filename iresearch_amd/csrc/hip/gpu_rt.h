@@ -139,6 +139,9 @@ inline void destroy(handle_t c) {
 #define RT_LAUNCH(kernel, grid, block, shmem, stream, ...) \
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (shmem), (stream), __VA_ARGS__)
 
+// A kernel compiled for exactly n resident wavefronts per SIMD (its register budget follows).
+#define RT_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+
 // Dynamic LDS carve base, 16-byte aligned (cdna guide G17).
 #define RT_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 

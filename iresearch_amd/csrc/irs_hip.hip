@@ -391,6 +391,8 @@ bool launch_score_acc(irs_hip_batch* b, rt::stream_t st) {
                   : launch_score_tile<unsigned long long, LAYOUT>(b, st);
 }
 
+bool ensure_pilot_list(irs_hip_batch* b, uint32_t stride, rt::stream_t st);
+
 // Conjunctions: [pilot pass over every P-th lead block -> threshold bins] -> full pass.
 template<int LAYOUT>
 bool launch_conj(irs_hip_batch* b, rt::stream_t st) {
@@ -413,22 +415,7 @@ bool launch_conj(irs_hip_batch* b, rt::stream_t st) {
   a.cand_cap = b->cand_cap;
   a.pilot_stride = b->stride_eff == 1 ? 1u : b->stride;
   a.wand = b->wand ? 1u : 0u;
-  if (b->conj_pilot_stride != a.pilot_stride) {
-    // the pilot pass's own work list: lead items {phase, phase + P, ...} of every unit
-    std::vector<PhraseWg> pl;
-    for (size_t c = 0; c < b->conj_units.size(); ++c) {
-      const uint32_t u = b->conj_units[c];
-      for (uint32_t it = (u * 7u) % a.pilot_stride; it < b->conj_items[c]; it += a.pilot_stride)
-        pl.push_back(PhraseWg{u, it});
-    }
-    if (!b->d_conj_pilot.alloc(std::max<size_t>(1, pl.size()) * sizeof(PhraseWg)) ||
-        !rt::sync(st) ||
-        !rt::h2d(b->d_conj_pilot.p, pl.data(), pl.size() * sizeof(PhraseWg), nullptr) ||
-        !rt::sync(nullptr))
-      return false;
-    b->n_conj_pilot = uint32_t(pl.size());
-    b->conj_pilot_stride = a.pilot_stride;
-  }
+  if (!ensure_pilot_list(b, a.pilot_stride, st)) return false;
   if (!rt::dmemset(b->d_conj_hist.p, 0, b->d_conj_hist.n, st)) return false;
   RT_LAUNCH(k_conj_seek, (b->conj_total_items + kThreads - 1) / kThreads, kThreads, 0, st,
             b->d_segs.as<DevSegment>(), b->d_queries.as<DevQuery>(), b->d_tails.as<DevTail>(),
@@ -471,15 +458,51 @@ bool launch_items(irs_hip_batch* b, rt::stream_t st) {
   return rt::last_error_ok();
 }
 
+// The pilot pass's work list of a block-driven batch (And / by_phrase): lead items
+// {phase, phase + P, ...} of every unit in conj_units.
+bool ensure_pilot_list(irs_hip_batch* b, uint32_t stride, rt::stream_t st) {
+  if (b->conj_pilot_stride == stride) return true;
+  std::vector<PhraseWg> pl;
+  for (size_t c = 0; c < b->conj_units.size(); ++c) {
+    const uint32_t u = b->conj_units[c];
+    for (uint32_t it = (u * 7u) % stride; it < b->conj_items[c]; it += stride)
+      pl.push_back(PhraseWg{u, it});
+  }
+  if (!b->d_conj_pilot.alloc(std::max<size_t>(1, pl.size()) * sizeof(PhraseWg)) || !rt::sync(st) ||
+      !rt::h2d(b->d_conj_pilot.p, pl.data(), pl.size() * sizeof(PhraseWg), nullptr) ||
+      !rt::sync(nullptr))
+    return false;
+  b->n_conj_pilot = uint32_t(pl.size());
+  b->conj_pilot_stride = stride;
+  return true;
+}
+
+// by_phrase: pilot pass over every P-th lead block -> threshold bins -> full pass.
 template<int LAYOUT, int MT>
 bool launch_phrase(irs_hip_batch* b, rt::stream_t st) {
   if (b->n_phrase_wgs == 0) return true;  // no query has all its terms in its segment
+  const uint32_t stride = b->stride_eff == 1 ? 1u : b->stride;
+  if (!ensure_pilot_list(b, stride, st) || !rt::dmemset(b->d_conj_hist.p, 0, b->d_conj_hist.n, st))
+    return false;
+  unsigned long long* touched = b->count_touched ? b->d_touched.as<unsigned long long>() : nullptr;
+  if (b->n_conj_pilot) {
+    RT_LAUNCH((k_phrase<LAYOUT, MT>), b->n_conj_pilot, 64, 0, st, b->d_segs.as<DevSegment>(),
+              b->d_queries.as<DevQuery>(), b->d_qterms.as<DevQTerm>(), b->jt,
+              b->d_conj_pilot.as<PhraseWg>(), b->d_tails.as<DevTail>(), b->d_cands.as<uint64_t>(),
+              b->cand_cap, b->d_cand_count.as<uint32_t>(), b->d_hits.as<unsigned long long>(),
+              static_cast<unsigned long long*>(nullptr), b->d_bstar.as<uint32_t>(),
+              b->d_conj_hist.as<uint32_t>(), 1u);
+  }
+  RT_LAUNCH(k_conj_threshold, uint32_t(b->conj_units.size()), 64, 0, st,
+            b->d_queries.as<DevQuery>(), b->d_conj_units.as<uint32_t>(),
+            b->d_conj_items.as<uint32_t>(), b->d_conj_hist.as<uint32_t>(), stride,
+            b->estimate ? kPilotMargin : 0u, b->d_bstar.as<uint32_t>());
   RT_LAUNCH((k_phrase<LAYOUT, MT>), b->n_phrase_wgs, kPhraseWaves * 64, 0, st,
             b->d_segs.as<DevSegment>(), b->d_queries.as<DevQuery>(), b->d_qterms.as<DevQTerm>(),
             b->jt, b->d_phrase_wgs.as<PhraseWg>(), b->d_tails.as<DevTail>(),
             b->d_cands.as<uint64_t>(), b->cand_cap, b->d_cand_count.as<uint32_t>(),
-            b->d_hits.as<unsigned long long>(),
-            b->count_touched ? b->d_touched.as<unsigned long long>() : nullptr);
+            b->d_hits.as<unsigned long long>(), touched, b->d_bstar.as<uint32_t>(),
+            b->d_conj_hist.as<uint32_t>(), 0u);
   return rt::last_error_ok();
 }
 template<int LAYOUT>
@@ -568,7 +591,6 @@ bool ensure_scratch(irs_hip_batch* b) {
   b->stride_eff = b->tile_units.empty()
                       ? b->stride
                       : std::max<uint32_t>(1, std::min<uint32_t>(b->stride, b->n_tiles / 2));
-  if (b->phrase) b->stride_eff = 1;  // no pilot: every match is a candidate
   if (const char* e = std::getenv("IRS_HIP_WG_THREADS")) {  // tuning knob
     const uint32_t t = uint32_t(std::atoi(e));
     if (t == 256 || t == 512 || t == 1024) b->wg_threads = t;
@@ -1229,13 +1251,22 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
           }
         }
         for (uint32_t it = 0; it < items; it += kPhraseWaves) wgs.push_back(PhraseWg{u, it});
+        // (the lists of the pilot pass: same bookkeeping as for conjunctions)
+        b->conj_units.push_back(u);
+        b->conj_items.push_back(items);
       }
       if (wgs.size() > 0x7FFFFFFFull) {
         rc = IRS_HIP_EUNSUPPORTED;
       } else if (!wgs.empty()) {
         b->n_phrase_wgs = uint32_t(wgs.size());
-        if (!b->d_phrase_wgs.alloc(wgs.size() * sizeof(PhraseWg)))
+        if (!b->d_phrase_wgs.alloc(wgs.size() * sizeof(PhraseWg)) ||
+            !b->d_conj_units.alloc(b->conj_units.size() * 4) ||
+            !b->d_conj_items.alloc(b->conj_items.size() * 4) ||
+            !b->d_conj_hist.alloc(uint64_t(nq) * kBins * 4))
           rc = IRS_HIP_ENOMEM;
+        else if (!rt::h2d(b->d_conj_units.p, b->conj_units.data(), b->conj_units.size() * 4, nullptr) ||
+                 !rt::h2d(b->d_conj_items.p, b->conj_items.data(), b->conj_items.size() * 4, nullptr))
+          rc = IRS_HIP_EHIP;
         else if (!rt::h2d(b->d_phrase_wgs.p, wgs.data(), wgs.size() * sizeof(PhraseWg), nullptr) ||
                  !rt::sync(nullptr))
           rc = IRS_HIP_EHIP;
@@ -1244,7 +1275,7 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
       rc = IRS_HIP_ENOMEM;
     }
   }
-  if (rc == IRS_HIP_OK && !b->conj_units.empty()) {
+  if (rc == IRS_HIP_OK && !b->phrase && !b->conj_units.empty()) {
     // k_conj work list: the lead term of a unit is its first one (sorted by cost above); one
     // wavefront per 128-posting block of it (+ one for its vint tail / single doc)
     try {

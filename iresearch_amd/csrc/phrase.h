@@ -326,7 +326,10 @@ __global__ void __launch_bounds__(kPhraseWaves * 64)
 k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms, uint32_t jt,
          const PhraseWg* wgs, const DevTail* tails, uint64_t* cands, uint32_t cand_cap,
          uint32_t* cand_count, unsigned long long* hits,
-         unsigned long long* touched /*[unit][2]: `.doc` bytes decoded, positions read*/) {
+         unsigned long long* touched /*[unit][2]: `.doc` bytes decoded, positions read*/,
+         const uint32_t* bstar /*threshold bin per unit*/, uint32_t* hist /*[unit][kBins]*/,
+         uint32_t pilot /*1: histogram the scores of the sampled lead items (launched one
+                          wavefront per workgroup over the pilot list), no candidates*/) {
   __shared__ DevPosTerm s_pt[MT];
   __shared__ DevTail s_tl[MT];
   __shared__ uint32_t s_off[MT];
@@ -347,6 +350,7 @@ k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms
     s_off[tid] = qterms[qd.first_term + tid].pad0;  // desired offset in the phrase
   }
   const DevQTerm qt = qterms[qd.first_term];  // the phrase's scorer rides on its first term
+  const uint32_t bs = pilot ? 0u : bstar[unit];
   __syncthreads();
   if (m == 0 || m > uint32_t(MT)) return;
   uint32_t lead = 0, lead_n = 0xFFFFFFFFu;  // the term with the fewest postings leads
@@ -530,11 +534,17 @@ k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms
     if (pf) {
       const uint32_t doc = docs[s];
       const float score = score_value(qt, pf, norm_value(seg, doc));
-      const uint32_t slot = atomicAdd(&cand_count[unit], 1u);
-      if (slot < cand_cap) cands[uint64_t(unit) * cand_cap + slot] = make_key(score, doc);
+      const uint32_t bin = score_bin(score, qd.bin_scale);
+      if (pilot) {
+        atomicAdd(&hist[uint64_t(unit) * kBins + bin], 1u);
+      } else if (bin >= bs) {   // below the pilot's threshold bin: cannot be among the top k
+        const uint32_t slot = atomicAdd(&cand_count[unit], 1u);
+        if (slot < cand_cap) cands[uint64_t(unit) * cand_cap + slot] = make_key(score, doc);
+      }
       ++my_hits;
     }
   }
+  if (pilot) return;
   my_hits = wave::reduce_add(my_hits);
   if (lane == 0 && my_hits) atomicAdd(&hits[unit], static_cast<unsigned long long>(my_hits));
   if (touched) {   // (only when the batch counts: irs_hip_batch_profile bit 1)

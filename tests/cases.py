@@ -508,6 +508,45 @@ def case_wide_norms(L, width):
     sr.close()
 
 
+def case_full_vocabulary(L, num_docs=30_000, max_rank=1 << 16, n_queries=24, report=None):
+    """The shape a real term dictionary has: the whole vocabulary indexed, so that most terms
+    are short lists — a vint tail only (df < 128), a single doc (df == 1, nothing in `.doc`),
+    or absent in this segment (df == 0) — next to the few long ones.  Disjunctions and
+    conjunctions over such terms against the oracle; decode of a spread of them."""
+    import time
+    t0 = time.perf_counter()
+    seg = synth.build_segment(num_docs, max_rank, keep_postings=False)
+    t1 = time.perf_counter()
+    sr = search.SegmentReader.from_synth(seg, L=L)
+    t_open = time.perf_counter() - t1
+    dc = np.asarray(seg.metas["docs_count"])
+    short = np.nonzero((dc > 1) & (dc < 128))[0]
+    single = np.nonzero(dc == 1)[0]
+    absent = np.nonzero(dc == 0)[0]
+    assert len(short) > max_rank // 2 and len(single) > 0
+    rng = np.random.default_rng(3)
+    for t in list(rng.choice(short, 20)) + list(rng.choice(single, 5)):
+        d, f = sr.decode_term(int(t))
+        od, of = oracle.decode_term(seg.doc_file, seg.metas[int(t)], seg.layout)
+        assert np.array_equal(d, od) and np.array_equal(f, of), t
+    filters = []
+    for q in range(n_queries):
+        terms = list(rng.choice(short, 6)) + list(rng.choice(single, 1))
+        if len(absent):
+            terms.append(rng.choice(absent))
+        filters.append(Or([by_term(int(t)) for t in terms]))
+    filters += [Or([by_term(int(t)) for t in rng.choice(short, 3)] + [by_term(1)]),
+                And([by_term(int(rng.choice(short))), by_term(2)]),
+                And([by_term(int(rng.choice(single))), by_term(0)])]
+    t2 = time.perf_counter()
+    run_and_check(L, seg, filters, BM25(), 50, sr=sr)
+    if report is not None:
+        report.update(terms=len(dc), short=len(short), single=len(single), absent=len(absent),
+                      build_s=t1 - t0, open_s=t_open, query_and_check_s=time.perf_counter() - t2,
+                      device_mb=sr.device_bytes() / 1e6)
+    sr.close()
+
+
 def case_legacy_norms(L):
     """The legacy `Norm` feature (norm.hpp:46-70: float 1/sqrt(|doc|) per doc): BM25 takes
     tf = sqrt(freq) and norm = 1/stored through c0 - c0*c1/(c1 + tf) (bm25.cpp:333-359,
@@ -921,13 +960,13 @@ def case_decode_positions(L, layout):
     wsr.close()
 
 
-def run_phrases(L, seg, phrases, scorer, k, sr=None, cap=0):
+def run_phrases(L, seg, phrases, scorer, k, sr=None, cap=0, stride=0):
     own = sr is None
     sr = sr or search.SegmentReader.from_synth(seg, L=L)
     prep = search.prepare(phrases, scorer, [parity.segment_stats(seg)])
     b = sr.batch(prep, k)
-    if cap:
-        b.configure(0, 0, cap)
+    if cap or stride:
+        b.configure(0, stride, cap)
     hits, counts, totals = b.run().results()
     parity.check_phrase_segment(seg, phrases, scorer, k, hits, counts, totals)
     reruns = b.reruns()
@@ -955,6 +994,12 @@ def case_phrase_queries(L, layout, num_docs=30_000):
     for scorer in (BM25(), BM25(1.2, 0.0), BM25(0.0, 0.0), TFIDF(False), TFIDF(True)):
         for k in (10, 1000):
             run_phrases(L, seg, phrases, scorer, k, sr=sr)
+    # a pilot pass over every 2nd / every lead block picks a threshold bin: frequent phrases
+    # then only append the matches that can still make the top k — same results
+    h0, c0, t0, _ = run_phrases(L, seg, phrases, BM25(), 10, sr=sr)
+    for stride in (2, 1):
+        h1, c1, t1, _ = run_phrases(L, seg, phrases, BM25(), 10, sr=sr, stride=stride)
+        assert np.array_equal(h0, h1) and np.array_equal(c0, c1) and np.array_equal(t0, t1), stride
     # more matches than candidate slots: the buffer grows and the batch is re-run, exact
     _, _, totals, reruns = run_phrases(L, seg, phrases[:3], BM25(), 16, sr=sr, cap=64)
     assert reruns >= 1 and int(totals.max()) > 64

@@ -208,6 +208,72 @@ int main() {
     REQUIRE(set == oset);
   }
 
+  // adapter groundwork (format10::): the files' headers and footers, the term dictionary's
+  // term_meta entries (encoded here the way postings_writer_base::encode does,
+  // formats_10.cpp:576-604), the Norm2 column header (norm.cpp:107-115)
+  {
+    size_t hdr = 0;
+    REQUIRE(format10::check_header(a.doc, a.doc_len, format10::kDocFormatName, 0, 5, &hdr) == 5);
+    REQUIRE(hdr < a.metas[0].doc_start + 1);
+    REQUIRE(format10::check_header(a.pos, a.pos_len, format10::kPosFormatName, 0, 5) == 5);
+    format10::check_footer(a.doc, a.doc_len);
+    format10::check_footer(a.pos, a.pos_len);
+    std::vector<uint8_t> bad(a.doc, a.doc + a.doc_len);
+    bad[bad.size() / 2] ^= 1;   // a flipped bit in the postings: the checksum catches it
+    bool threw = false;
+    try {
+      format10::check_footer(bad.data(), bad.size());
+    } catch (const index_error&) {
+      threw = true;
+    }
+    REQUIRE(threw);
+    auto vwrite = [](std::vector<uint8_t>& o, uint64_t v) {
+      while (v >= 0x80) {
+        o.push_back(uint8_t(v) | 0x80);
+        v >>= 7;
+      }
+      o.push_back(uint8_t(v));
+    };
+    std::vector<uint8_t> dict;
+    irs_hip_term_meta last{};
+    for (uint32_t t = 0; t < a.num_terms; ++t) {
+      const irs_hip_term_meta& m = a.metas[t];
+      vwrite(dict, m.docs_count);
+      if (m.freq) vwrite(dict, m.freq - m.docs_count);
+      vwrite(dict, m.doc_start - last.doc_start);
+      vwrite(dict, m.pos_start - last.pos_start);             // the field has positions
+      if (m.pos_end != ~uint64_t(0)) vwrite(dict, m.pos_end);
+      if (m.docs_count == 1) vwrite(dict, uint32_t(m.e_skip_start));
+      else if (m.docs_count > 128) vwrite(dict, m.e_skip_start);
+      last = m;
+    }
+    const uint8_t* p = dict.data();
+    irs_hip_term_meta state{};
+    for (uint32_t t = 0; t < a.num_terms; ++t) {
+      if (a.metas[t].docs_count == 0) {   // (the emitter keeps a row for unseen ranks; a real
+        // dictionary simply has no entry)
+        irs_hip_term_meta skip = state;
+        p += format10::decode_term_meta(p, true, true, false, skip);
+        continue;
+      }
+      p += format10::decode_term_meta(p, true, true, false, state);
+      const irs_hip_term_meta& m = a.metas[t];
+      REQUIRE(state.docs_count == m.docs_count && state.freq == m.freq);
+      REQUIRE(state.doc_start == m.doc_start && state.pos_start == m.pos_start);
+      REQUIRE(m.freq <= 128 || state.pos_end == m.pos_end);
+      REQUIRE((m.docs_count != 1 && m.docs_count <= 128) || state.e_skip_start == m.e_skip_start);
+    }
+    REQUIRE(p == dict.data() + dict.size());
+    const uint8_t n2[10] = {0, 1, 0, 0, 0, 3, 0, 0, 0, 0xF0};
+    format10::Norm2Header nh;
+    REQUIRE(format10::read_norm2_header(n2, sizeof n2, nh));
+    REQUIRE(nh.num_bytes == 1 && nh.min == 3 && nh.max == 0xF0 && nh.max_num_bytes() == 1);
+    const uint8_t n4[10] = {0, 4, 0, 0, 0, 1, 0, 1, 0x86, 0xA0};
+    REQUIRE(format10::read_norm2_header(n4, sizeof n4, nh) && nh.num_bytes == 4 && nh.max_num_bytes() == 4);
+    const uint8_t nbad[10] = {0, 3, 0, 0, 0, 1, 0, 0, 0, 2};
+    REQUIRE(!format10::read_norm2_header(nbad, sizeof nbad, nh));
+  }
+
   // error behaviour: exceptions where the reference throws
   {
     bool threw = false;

@@ -198,4 +198,6 @@ inline void launch_kernel(unsigned grid, unsigned block, size_t shmem, K kernel,
                        __VA_ARGS__);                                             \
   } while (0)
 
+#define RT_WAVES_PER_SIMD(n)
+
 #define RT_DYN_SMEM(name) unsigned char* name = sim::dyn_smem()

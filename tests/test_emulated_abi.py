@@ -141,6 +141,10 @@ def test_phrase_errors(simlib):
     cases.case_phrase_errors(simlib)
 
 
+def test_full_vocabulary(simlib):
+    cases.case_full_vocabulary(simlib)
+
+
 def test_legacy_norms(simlib):
     cases.case_legacy_norms(simlib)
 

@@ -183,6 +183,15 @@ def test_merge_ties(gpulib):
     cases.case_merge_ties(gpulib, n_lists=8, nq=5, k=1000, seed=5)
 
 
+def test_full_vocabulary_million_terms(gpulib):
+    """A segment with the WHOLE vocabulary indexed (2^20 terms, ~890 k of them tail-only, ~100 k
+    single-doc): open, then disjunctions / conjunctions over short lists, against the oracle."""
+    rep = {}
+    cases.case_full_vocabulary(gpulib, num_docs=300_000, max_rank=1 << 20, n_queries=200, report=rep)
+    print("full vocabulary:", rep)
+    assert rep["terms"] == 1 << 20 and rep["short"] > 800_000
+
+
 def test_legacy_norms(gpulib):
     cases.case_legacy_norms(gpulib)
 
