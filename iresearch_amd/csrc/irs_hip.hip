@@ -164,7 +164,7 @@ namespace {
 // exclusive prefix sum in place -> one copy pass.  Everything on the device.
 // In-place exclusive prefix sum of n u32 values on the device; *total = their sum, which
 // must fit 32 bits (the scanned values are offsets kept as u32).
-int scan_exclusive(uint32_t* d_values, uint64_t n, uint64_t* total) {
+int scan_exclusive(uint32_t* d_values, uint64_t n, uint64_t* total, bool may_wrap = false) {
   *total = 0;
   if (!n) return IRS_HIP_OK;
   const uint32_t parts = uint32_t((n + kScanChunk - 1) / kScanChunk);
@@ -175,7 +175,8 @@ int scan_exclusive(uint32_t* d_values, uint64_t n, uint64_t* total) {
   if (!rt::last_error_ok() || !rt::d2h(total, totals.as<uint64_t>() + parts, 8, nullptr) ||
       !rt::sync(nullptr))
     return IRS_HIP_EHIP;
-  if (*total > 0xFFFFFFFFull) return IRS_HIP_EUNSUPPORTED;
+  // (offsets kept as u32; sums that are only ever used as DIFFERENCES may wrap mod 2^32)
+  if (*total > 0xFFFFFFFFull && !may_wrap) return IRS_HIP_EUNSUPPORTED;
   RT_LAUNCH(k_scan_apply, parts, kThreads, 0, nullptr, d_values, n, totals.as<uint64_t>());
   if (!rt::last_error_ok() || !rt::sync(nullptr)) return IRS_HIP_EHIP;
   return IRS_HIP_OK;
@@ -244,7 +245,8 @@ int build_positions(irs_hip_segment* s, const std::vector<uint64_t>& pos_end) {
     if (!rt::last_error_ok() || !rt::sync(nullptr)) return IRS_HIP_EHIP;
   }
   uint64_t total = 0;
-  if (const int rc = scan_exclusive(s->d_blk_pos.as<uint32_t>(), n, &total)) return rc;
+  // (position numbers are per term: differences of blk_pos, every term's total < 2^32)
+  if (const int rc = scan_exclusive(s->d_blk_pos.as<uint32_t>(), n, &total, true)) return rc;
   const uint32_t total32 = uint32_t(total);  // sentinel row: everything in front of "row n"
   if (!rt::h2d(s->d_blk_pos.as<uint32_t>() + n, &total32, 4, nullptr)) return IRS_HIP_EHIP;
   DevBuf d_pos_end;
@@ -413,7 +415,7 @@ bool launch_conj(irs_hip_batch* b, rt::stream_t st) {
   a.unit_items = b->d_conj_unit_items.as<uint32_t>();
   a.jt = b->jt;
   a.cand_cap = b->cand_cap;
-  a.pilot_stride = b->stride_eff == 1 ? 1u : b->stride;
+  a.pilot_stride = b->stride_eff;
   a.wand = b->wand ? 1u : 0u;
   if (!ensure_pilot_list(b, a.pilot_stride, st)) return false;
   if (!rt::dmemset(b->d_conj_hist.p, 0, b->d_conj_hist.n, st)) return false;
@@ -481,7 +483,7 @@ bool ensure_pilot_list(irs_hip_batch* b, uint32_t stride, rt::stream_t st) {
 template<int LAYOUT, int MT>
 bool launch_phrase(irs_hip_batch* b, rt::stream_t st) {
   if (b->n_phrase_wgs == 0) return true;  // no query has all its terms in its segment
-  const uint32_t stride = b->stride_eff == 1 ? 1u : b->stride;
+  const uint32_t stride = b->stride_eff;
   if (!ensure_pilot_list(b, stride, st) || !rt::dmemset(b->d_conj_hist.p, 0, b->d_conj_hist.n, st))
     return false;
   unsigned long long* touched = b->count_touched ? b->d_touched.as<unsigned long long>() : nullptr;
@@ -1145,7 +1147,13 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
       if (in.op == IRS_HIP_OP_AND) {
         need = absent ? 0xFFu : uint32_t(row.size());
       } else if (in.op == IRS_HIP_OP_MINMATCH) {
-        const uint32_t m = std::max<uint32_t>(1, in.min_match);
+        // Or::prepare turns min_match_count == 0 into the all-docs filter
+        // (boolean_filter.cpp:213): not a posting-list query, not on this path
+        if (in.min_match == 0) {
+          rc = IRS_HIP_EUNSUPPORTED;
+          break;
+        }
+        const uint32_t m = in.min_match;
         need = (m > in.n_terms || m > row.size()) ? 0xFFu : m;
       }
       if (is_phrase) {
@@ -1548,6 +1556,9 @@ static int recover(irs_hip_batch* b, uint32_t status) {
   ++b->reruns;
   if (status & kStatusUnderflow) {
     b->estimate = false;
+    // the sound threshold admits about k * (pilot stride) candidates per unit: a denser pilot
+    // keeps the candidate buffer of a large batch (units x cap x 8 bytes) in bounds
+    b->stride_eff = std::min<uint32_t>(b->stride_eff, 16);
     const uint32_t cap = default_cand_cap(b);  // the sound threshold admits more candidates
     if (cap > b->cand_cap) {
       if (!b->d_cands.alloc(uint64_t(b->nq) * cap * sizeof(uint64_t))) return IRS_HIP_ENOMEM;
