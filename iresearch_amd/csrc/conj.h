@@ -14,16 +14,19 @@
 //      largest block-max score among its blocks overlapping the lead block's doc range; a
 //      bound below the threshold bin (from the pilot pass) skips the lead block — nothing is
 //      decoded;
-//   1. the lead block is decoded: 128 ascending docs, their scores and norms into LDS;
+//   1. the lead block is decoded: 128 ascending docs and their frequencies into LDS;
 //   2. for every other term, cheapest first: binary search of the block directory for the
 //      first block reaching the lead block's first doc, then 64 directory entries per step, a
 //      lane each, tested against the docs still alive ("is any of them in (previous last,
 //      last]"); only blocks that pass are decoded, and each decoded posting looks its doc up
-//      among the lead docs (binary search in LDS): a hit adds the term's score.  A term that
-//      leaves no doc alive ends the block;
-//   3. docs every term reached are the conjunction: score = the per-term scores summed in
-//      cost order (the order the reference's Conjunction sums them); docs at or above the
-//      threshold bin become candidates for k_select.
+//      among the lead docs (binary search in LDS): a hit leaves the term's frequency in the
+//      term's row.  A term that leaves no doc alive ends the block;
+//   3. docs every term reached are the conjunction.  Only THEY are scored — as the reference
+//      scores a doc after converge() has accepted it (conjunction.hpp:176-187): their norm is
+//      read, the per-term scores are summed in cost order (the order the reference's
+//      Conjunction sums them); docs at or above the threshold bin become candidates for
+//      k_select.  (Frequencies are kept for kConjRows terms at a time: a longer conjunction
+//      scores the docs still alive every kConjRows terms.)
 // The same kernel run over every P-th lead block with `pilot` set histograms the scores of
 // the matches instead (k_conj_threshold turns the histogram into the threshold bin).
 #pragma once
@@ -98,16 +101,34 @@ __device__ __forceinline__ void decode_dir_block(const DevSegment& seg, uint64_t
 }
 
 constexpr uint32_t kConjWaves = 4;  // wavefronts (= lead blocks) per workgroup
+constexpr uint32_t kConjRows = 4;   // frequency rows per wavefront (terms scored per flush)
+constexpr uint32_t kConjWords = 128;  // 32-bit words of a wavefront's doc-range bitmaps
 
-// Where the other terms start for every lead item: the binary search of a term's block
-// directory for the first block reaching the lead item's first doc — SkipReader::Seek
-// (skip_list.hpp:208-249) — done once per (lead item, term) by ONE THREAD of a pre-pass
-// (inside k_conj a wavefront would walk the same dependent chain 64 lanes wide).
-// One thread per lead item of every conjunction; seek[(item_base + item) * (jt - 1) + i - 1].
+// One lead item (a 128-posting block of the conjunction's rarest term, or its decoded vint
+// tail), everything its wavefront needs to start decoding — written by the pre-pass so that
+// the wavefront's first load is this record (one scalar load) instead of a chain of dependent
+// ones (unit -> query -> term record -> directory words).
+struct alignas(32) ConjItem {
+  uint32_t unit;
+  uint32_t item;    // block index in the lead's list; == its nblk: the vint tail
+  uint32_t base;    // doc the block's first delta is relative to (formats_10.cpp:636)
+  uint32_t r_lo;    // the item's docs lie in [r_lo, r_hi] (from the directory)
+  uint32_t r_hi;
+  uint32_t aoff;    // block in the packed-payload image, 16-byte units
+  uint32_t bits;    // header bytes: dbits | fbits << 8
+  uint32_t off;     // block in `.doc`, relative to the term's doc_start
+};
+static_assert(sizeof(ConjItem) == 32, "one s_load_dwordx8 per lead item");
+
+// Pre-pass, one thread per lead item of every conjunction: the item's record, and where the
+// other terms start for it — the binary search of a term's block directory for the first
+// block reaching the lead item's first doc, SkipReader::Seek (skip_list.hpp:208-249), done
+// once per (lead item, term) by ONE THREAD (inside k_conj a wavefront would walk the same
+// dependent chain 64 lanes wide).  seek[(item_base + item) * (jt - 1) + i - 1].
 __global__ void __launch_bounds__(kThreads)
 k_conj_seek(const DevSegment* segs, const DevQuery* queries, const DevTail* tails, uint32_t jt,
             const uint32_t* conj_units, const uint32_t* item_base /*[n_conj + 1]*/,
-            uint32_t n_conj, uint32_t* seek) {
+            uint32_t n_conj, uint32_t* seek, ConjItem* recs) {
   const uint32_t t = blockIdx.x * kThreads + threadIdx.x;
   if (t >= item_base[n_conj]) return;
   uint32_t lo = 0, hi = n_conj;   // the unit whose items hold t: last c with item_base[c] <= t
@@ -120,14 +141,28 @@ k_conj_seek(const DevSegment* segs, const DevQuery* queries, const DevTail* tail
   const DevSegment& seg = segs[qd.seg];
   const DevTail* tl = tails + uint64_t(unit) * jt;
   const DevTail ld = tl[0];
-  const uint32_t r_lo = item < ld.nblk ? (item ? seg.blk_last[ld.dir_off + item - 1] + 1u : kDocMin)
-                                       : ld.first_doc;
+  ConjItem r{};
+  r.unit = unit;
+  r.item = item;
+  if (item < ld.nblk) {
+    const uint64_t e = ld.dir_off + item;
+    r.base = item ? seg.blk_last[e - 1] : kDocMin;
+    r.r_lo = item ? r.base + 1u : kDocMin;
+    r.r_hi = seg.blk_last[e];
+    r.aoff = seg.blk_aoff[e];
+    r.bits = seg.blk_bits[e];
+    r.off = seg.blk_off[e];
+  } else {
+    r.r_lo = ld.first_doc;
+    r.r_hi = ld.last_doc;
+  }
+  recs[t] = r;
   for (uint32_t i = 1; i < qd.n_terms; ++i) {
     const uint32_t* last = seg.blk_last + tl[i].dir_off;
     uint32_t a = 0, b = tl[i].nblk;  // lower_bound(last, r_lo)
     while (a < b) {
       const uint32_t mid = (a + b) >> 1;
-      if (last[mid] < r_lo) a = mid + 1; else b = mid;
+      if (last[mid] < r.r_lo) a = mid + 1; else b = mid;
     }
     seek[uint64_t(t) * (jt - 1u) + (i - 1u)] = a;
   }
@@ -137,13 +172,14 @@ struct ConjArgs {
   const DevSegment* segs;
   const DevQuery* queries;
   const DevQTerm* qterms;
-  const PhraseWg* wgs;          // {unit, first lead item} per workgroup; pilot pass: {unit, lead
-                                // item} per WAVEFRONT (the sampled items only)
+  const PhraseWg* wgs;          // pilot pass: {unit, lead item} per wavefront (the sampled items)
   uint32_t n_pilot;             // entries of the pilot list
+  uint32_t n_items;             // full pass: lead items of all conjunctions (= records)
   const DevTail* tails;         // [unit][jt] (k_plan)
   const uint32_t* bstar;        // threshold bin per unit (0 = none)
   const uint32_t* seek;         // k_conj_seek
-  const uint32_t* unit_items;   // [nq] first row of the unit's lead items in `seek` (conj units)
+  const ConjItem* recs;         // k_conj_seek
+  const uint32_t* unit_items;   // [nq] first record of the unit's lead items (conj units)
   uint64_t* cands;
   uint32_t* cand_count;
   unsigned long long* hits;
@@ -157,77 +193,69 @@ struct ConjArgs {
   uint32_t wand;                // prune lead blocks by block-max bounds
 };
 
-// 8 wavefronts per SIMD (a 64-VGPR budget, a few spilled values): the kernel waits on chains
-// of dependent loads, so resident wavefronts count for more than registers (AND-3: 6.8 -> 6.0 ms)
+// LDS of one wavefront.  The lead block's docs are mirrored in a bitmap over its doc range
+// [dlo, dhi], one bit per 2^s docs (s = 0 whenever the range is below 32 * kConjWords docs —
+// every lead dense enough to matter): "is this doc one of the lead docs still alive" is one
+// word read and a bit test for a decoded posting, and "does this block hold such a doc" two
+// prefix-count reads for a directory entry, where a search of the sorted docs would walk seven
+// dependent reads.
+struct ConjWave {
+  uint32_t docs[kBlock];
+  float score[kBlock];
+  uint32_t fr[kConjRows][kBlock];       // frequencies of the current terms
+  uint32_t bm[3][kConjWords + 4];       // bitmaps: [0] the lead docs, [1] / [2] alternately the
+                                        // docs the current term reached (= alive for the next)
+  uint8_t lpre[kConjWords + 4];         // lead-bitmap bits in the words before word w
+  uint8_t apre[kConjWords + 4];         // the same for the alive bitmap of the current term
+  uint8_t cnt[kBlock];                  // terms that reached the doc so far
+};
+
+// 8 wavefronts per SIMD (a 64-VGPR budget): the kernel is a chain of short dependent steps,
+// resident wavefronts count for more than registers
 #define IRS_CONJ_ATTR RT_WAVES_PER_SIMD(8)
 template<int LAYOUT>
 __global__ void __launch_bounds__(kConjWaves * 64) IRS_CONJ_ATTR
 k_conj(ConjArgs A, uint32_t pilot) {
-  __shared__ DevTail s_tl[kConjWaves * kMaxTerms];
-  __shared__ DevQTerm s_qt[kConjWaves * kMaxTerms];
-  __shared__ uint32_t s_docs[kConjWaves][kBlock];
-  __shared__ float s_score[kConjWaves][kBlock];
-  __shared__ uint32_t s_norm[kConjWaves][kBlock];
-  __shared__ uint32_t s_cnt[kConjWaves][kBlock];    // terms that reached the doc so far
-  __shared__ uint32_t s_alive[kConjWaves][kBlock + 1];  // docs alive among the first c
+  __shared__ ConjWave s_wave[kConjWaves];
   const uint32_t tid = threadIdx.x;
   const unsigned lane = tid & 63u;
-  const uint32_t wv = tid >> 6;
-  // full pass: a workgroup = kConjWaves consecutive lead items of one unit; pilot pass: every
-  // wavefront has its own (unit, item) entry (wavefronts of a workgroup may belong to
-  // different units: the per-unit records are then read per wavefront, not staged)
-  uint32_t unit, item;
+  const uint32_t wv = wave::uniform(tid >> 6);
+  // one lead item per wavefront: record e (pilot pass: the sampled items' records)
+  uint32_t e = blockIdx.x * kConjWaves + wv;
   if (pilot) {
-    const uint32_t e = blockIdx.x * kConjWaves + wv;
-    const PhraseWg w = A.wgs[e < A.n_pilot ? e : A.n_pilot - 1u];
-    unit = w.unit;
-    item = e < A.n_pilot ? w.first_item : 0xFFFFFFFFu;
-  } else {
-    const PhraseWg w = A.wgs[blockIdx.x];
-    unit = w.unit;
-    item = w.first_item + wv;
+    if (e >= A.n_pilot) return;
+    const PhraseWg w = A.wgs[e];
+    e = wave::uniform(A.unit_items[w.unit] + w.first_item);
+  } else if (e >= A.n_items) {
+    return;
   }
-  const DevQuery qd = A.queries[unit];
+  // (wave-uniform records are read with scalar loads, at the point of use)
+  const ConjItem R = wave::sload<ConjItem>(reinterpret_cast<uint64_t>(A.recs) + uint64_t(e) * sizeof(ConjItem));
+  const uint32_t unit = R.unit, item = R.item;
+  const DevQuery qd = wave::sload<DevQuery>(reinterpret_cast<uint64_t>(A.queries) + uint64_t(unit) * sizeof(DevQuery));
   const uint32_t m = qd.n_terms;
-  const DevSegment seg = A.segs[qd.seg];
-  // (the term records of this wavefront's unit, in its own LDS rows)
-  DevTail* w_tl = s_tl + wv * kMaxTerms;
-  DevQTerm* w_qt = s_qt + wv * kMaxTerms;
-  if (lane < m) {
-    w_tl[lane] = A.tails[uint64_t(unit) * A.jt + lane];
-    w_qt[lane] = A.qterms[qd.first_term + lane];
-  }
-  wave::sync();
   if (m == 0) return;
-  const DevTail ld = w_tl[0];   // the host sorted the terms by cost: the cheapest leads
+  const DevSegment& seg = A.segs[qd.seg];   // (read field by field)
+  const uint64_t tl_at = reinterpret_cast<uint64_t>(A.tails) + uint64_t(unit) * A.jt * sizeof(DevTail);
+  const uint64_t qt_at = reinterpret_cast<uint64_t>(A.qterms) + uint64_t(qd.first_term) * sizeof(DevQTerm);
+  auto term_tail = [&](uint32_t i) { return wave::sload<DevTail>(tl_at + i * sizeof(DevTail)); };
+  auto term_q = [&](uint32_t i) { return wave::sload<DevQTerm>(qt_at + i * sizeof(DevQTerm)); };
+  const DevTail ld = term_tail(0);   // the host sorted the terms by cost: the cheapest leads
   const uint32_t n_items = ld.nblk + (ld.n ? 1u : 0u);
-  if (item >= n_items) return;  // whole wavefront
   const uint32_t bs = pilot ? 0u : A.bstar[unit];
-  uint32_t* docs = s_docs[wv];
-  float* score = s_score[wv];
-  uint32_t* nrm = s_norm[wv];
-  uint32_t* cnt = s_cnt[wv];
-  uint32_t* alive = s_alive[wv];
-  const uint32_t* seek = A.seek + uint64_t(A.unit_items[unit] + item) * (A.jt - 1u);
-
-  // ---- doc range of the lead block (from the directory: nothing decoded yet)
-  uint32_t r_lo, r_hi;   // the lead block's docs lie in [r_lo, r_hi]
-  uint32_t lead_base = kDocMin;   // what its first delta is relative to (formats_10.cpp:636)
-  if (item < ld.nblk) {
-    r_hi = seg.blk_last[ld.dir_off + item];
-    if (item) lead_base = seg.blk_last[ld.dir_off + item - 1];
-    r_lo = item ? lead_base + 1u : kDocMin;
-  } else {
-    r_lo = ld.first_doc;
-    r_hi = ld.last_doc;
-  }
+  ConjWave& W = s_wave[wv];
+  uint32_t* docs = W.docs;
+  float* score = W.score;
+  uint8_t* cnt = W.cnt;
+  const uint32_t* seek = A.seek + uint64_t(e) * (A.jt - 1u);
+  const uint32_t r_lo = R.r_lo, r_hi = R.r_hi;   // the lead block's docs lie in [r_lo, r_hi]
 
   // ---- 0. block-max bound of every doc of this lead block (WandContext: ExecutionContext::wand)
   if (A.wand && bs) {
     float bound = 0.f;
     for (uint32_t i = 0; i < m; ++i) {
-      const DevTail tl = w_tl[i];
-      const DevQTerm qt = w_qt[i];
+      const DevTail tl = term_tail(i);
+      const DevQTerm qt = term_q(i);
       float ub = 0.f;
       if (i == 0 && item < ld.nblk) {
         ub = block_bound(qt, seg.blk_maxf[ld.dir_off + item], seg.blk_minn[ld.dir_off + item]);
@@ -240,17 +268,17 @@ k_conj(ConjArgs A, uint32_t pilot) {
         uint32_t z = item + 1u < n_items ? seek[(A.jt - 1u) + i - 1u] + 1u : tl.nblk;
         z = z < tl.nblk ? z : tl.nblk;
         for (uint32_t k = a + lane; k < z; k += 64) {
-          const float s = block_bound(qt, seg.blk_maxf[tl.dir_off + k], seg.blk_minn[tl.dir_off + k]);
-          ub = s > ub ? s : ub;
+          const float sc = block_bound(qt, seg.blk_maxf[tl.dir_off + k], seg.blk_minn[tl.dir_off + k]);
+          ub = sc > ub ? sc : ub;
         }
         // the decoded tail (no block-max entry): the term's global bound
         if (tl.n && tl.first_doc <= r_hi && tl.last_doc >= r_lo) {
-          const float s = term_bound(qt, seg.terms[tl.term].tf_bound);
-          ub = s > ub ? s : ub;
+          const float sc = term_bound(qt, seg.terms[tl.term].tf_bound);
+          ub = sc > ub ? sc : ub;
         }
 #pragma unroll
-        for (int s = 32; s > 0; s >>= 1) {
-          const float o = __shfl_xor(ub, s, 64);
+        for (int sh = 32; sh > 0; sh >>= 1) {
+          const float o = __shfl_xor(ub, sh, 64);
           ub = o > ub ? o : ub;
         }
       }
@@ -268,97 +296,176 @@ k_conj(ConjArgs A, uint32_t pilot) {
     const uint32_t db = bits & 0xFFu, fb = bits >> 8;
     return 2u + (db ? 16u * db : 1u) + (fb ? 16u * fb : 1u);
   };
+  uint32_t ld_d[2], ld_e[2];   // this lane's two lead docs and their entry indices
   {
-    const DevQTerm qt = w_qt[0];
-    uint32_t d[2], f[2], e0, estep;
+    uint32_t f[2], estep;
     if (item < ld.nblk) {
-      const uint64_t e = ld.dir_off + item;
-      decode_dir_block<LAYOUT>(seg, ld.doc_start, seg.blk_bits[e], seg.blk_off[e], seg.blk_aoff[e],
-                               lead_base, lane, d[0], d[1], f[0], f[1]);
-      bytes += block_bytes(seg.blk_bits[e]);
-      e0 = 2u * lane;
+      decode_dir_block<LAYOUT>(seg, ld.doc_start, R.bits, R.off, R.aoff, R.base, lane, ld_d[0],
+                               ld_d[1], f[0], f[1]);
+      bytes += block_bytes(R.bits);
+      ld_e[0] = 2u * lane;
       estep = 1u;
     } else {
       n = ld.n;
-      d[0] = lane < n ? seg.tail_docs[ld.tail_row + lane] : 0u;
-      d[1] = lane + 64u < n ? seg.tail_docs[ld.tail_row + lane + 64u] : 0u;
+      ld_d[0] = lane < n ? seg.tail_docs[ld.tail_row + lane] : 0u;
+      ld_d[1] = lane + 64u < n ? seg.tail_docs[ld.tail_row + lane + 64u] : 0u;
       f[0] = lane < n ? seg.tail_freqs[ld.tail_row + lane] : 0u;
       f[1] = lane + 64u < n ? seg.tail_freqs[ld.tail_row + lane + 64u] : 0u;
-      e0 = lane;
+      ld_e[0] = lane;
       estep = 64u;
     }
+    ld_e[1] = ld_e[0] + estep;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const uint32_t idx = e0 + uint32_t(h) * estep;
-      const bool on = idx < n;
-      const uint32_t nv = on ? norm_value(seg, d[h]) : 1u;
-      docs[idx] = on ? d[h] : 0xFFFFFFFFu;
-      nrm[idx] = nv;
-      score[idx] = on ? score_value(qt, f[h], nv) : 0.f;
-      cnt[idx] = on ? 1u : 0u;
+      const bool on = ld_e[h] < n;
+      docs[ld_e[h]] = on ? ld_d[h] : 0xFFFFFFFFu;
+      W.fr[0][ld_e[h]] = f[h];
+      score[ld_e[h]] = 0.f;
+      cnt[ld_e[h]] = on ? 1u : 0u;
+    }
+    // (words 2*lane, 2*lane+1 of the three bitmaps; the 4 slack words stay zero from here)
+    if (lane < (kConjWords + 4u) / 2u) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        W.bm[k][2u * lane] = 0u;
+        W.bm[k][2u * lane + 1u] = 0u;
+      }
+    }
+  }
+  // the docs every one of the terms [g0, g1) reached (and every earlier one) get those terms'
+  // scores: norm read here, once per flush, for these docs only
+  const bool with_norm = needs_norm(term_q(0).kind);
+  auto flush = [&](uint32_t g0, uint32_t g1) {
+    uint32_t scored = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t sl = lane + 64u * uint32_t(h);
+      const bool on = sl < n && cnt[sl] == g1;
+      scored += uint32_t(__builtin_popcountll(wave::ballot(on)));
+      if (on) {
+        const uint32_t nv = norm_value(seg, docs[sl]);
+        float v = score[sl];
+        for (uint32_t j = g0; j < g1; ++j) v += score_value(term_q(j), W.fr[j - g0][sl], nv);
+        score[sl] = v;
+      }
+    }
+    if (with_norm) bytes += scored * seg.norm_width;
+  };
+  wave::sync();
+  const uint32_t dlo = wave::uniform(docs[0]), dhi = wave::uniform(docs[n - 1]);
+  // bucket of a doc: (doc - dlo) >> s, below 32 * kConjWords
+  const uint32_t span = dhi - dlo;
+  const uint32_t s = span < 32u * kConjWords ? 0u
+                     : 32u - uint32_t(__builtin_clz(span)) - (5u + uint32_t(__builtin_ctz(kConjWords)));
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (ld_e[h] < n) {
+      const uint32_t bk = (ld_d[h] - dlo) >> s;
+      atomicOr(&W.bm[0][bk >> 5], 1u << (bk & 31u));
     }
   }
   wave::sync();
-  const uint32_t dlo = docs[0], dhi = docs[n - 1];
+  // bits in the words before word w (lane: words 2*lane, 2*lane+1; [kConjWords] = all)
+  auto prefix = [&](const uint32_t* bmap, uint8_t* pre) {
+    uint32_t p0 = 0, p1 = 0;
+    if (lane < kConjWords / 2u) {
+      p0 = uint32_t(__builtin_popcount(bmap[2u * lane]));
+      p1 = uint32_t(__builtin_popcount(bmap[2u * lane + 1u]));
+    }
+    const uint32_t incl = wave::inclusive_scan(p0 + p1);
+    if (lane < kConjWords / 2u) {
+      pre[2u * lane] = uint8_t(incl - p0 - p1);
+      pre[2u * lane + 1u] = uint8_t(incl - p1);
+    }
+    if (lane == kConjWords / 2u - 1u) pre[kConjWords] = uint8_t(incl);
+    wave::sync();
+    return wave::read_lane(incl, 63);
+  };
+  prefix(W.bm[0], W.lpre);
 
   // ---- 2. the other terms, cheapest first
   for (uint32_t i = 1; i < m; ++i) {
-    const DevTail tl = w_tl[i];
-    const DevQTerm qt = w_qt[i];
-    // alive[c] = docs among the first c that every earlier term reached
-    {
-      const uint32_t a0 = (2u * lane < n && cnt[2u * lane] == i) ? 1u : 0u;
-      const uint32_t a1 = (2u * lane + 1u < n && cnt[2u * lane + 1u] == i) ? 1u : 0u;
-      const uint32_t incl = wave::inclusive_scan(a0 + a1);
-      if (lane == 0) alive[0] = 0u;
-      alive[2u * lane + 1u] = incl - a1;
-      alive[2u * lane + 2u] = incl;
+    const DevTail tl = term_tail(i);
+    uint32_t* row = W.fr[i % kConjRows];
+    if (i % kConjRows == 0) {   // the rows are full: score what is still alive, reuse them
+      flush(i - kConjRows, i);
       wave::sync();
-      if (alive[kBlock] == 0u) {   // no doc reached by every term so far: the block is done
+    }
+    // alive = the docs every earlier term reached: the lead bitmap, then what the previous
+    // term marked; `mark` collects what this term reaches
+    const uint32_t mk = 1u + ((i - 1u) & 1u);
+    const uint32_t* alive = i == 1u ? W.bm[0] : W.bm[3u - mk];
+    uint32_t* mark = W.bm[mk];
+    const uint8_t* apre = W.lpre;
+    if (i > 1u) {
+      if (lane < kConjWords / 2u) {
+        mark[2u * lane] = 0u;
+        mark[2u * lane + 1u] = 0u;
+      }
+      apre = W.apre;
+      if (prefix(alive, W.apre) == 0u) {   // no doc reached by every term so far: done
         if (!pilot && A.touched && lane == 0)
           atomicAdd(&A.touched[2u * unit], static_cast<unsigned long long>(bytes));
         return;
       }
     }
+    // alive bits in the buckets below x, 0 <= x <= 32 * kConjWords
+    auto alive_below = [&](uint32_t x) {
+      return uint32_t(apre[x >> 5]) + uint32_t(__builtin_popcount(alive[x >> 5] & ((1u << (x & 31u)) - 1u)));
+    };
     // a decoded posting of term i: is its doc one of the lead docs still alive?
-    // (w0, w1] = ranks of the lead docs that can equal it: those inside its block's doc range
-    // (a binary search all lanes finish together; a hash table was tried and lost to the
-    // longest probe sequence among the 64 lanes)
-    auto put = [&](uint32_t doc, uint32_t f, uint32_t w0, uint32_t w1) {
-      if (f == 0 || doc < dlo || doc > dhi) return;
-      const uint32_t c = count_le(docs, w0, w1, doc);
-      if (c > w0 && docs[c - 1] == doc && cnt[c - 1] == i) {
-        score[c - 1] += score_value(qt, f, nrm[c - 1]);
-        cnt[c - 1] = i + 1u;
+    auto put = [&](uint32_t doc, uint32_t f) {
+      const uint32_t x = doc - dlo;
+      if (f == 0 || x > span) return;
+      const uint32_t bk = x >> s;
+      if (!((alive[bk >> 5] >> (bk & 31u)) & 1u)) return;
+      uint32_t c;   // the doc's entry index + 1
+      if (s == 0) {   // (wave-uniform) one doc per bit: the rank of the bit among the lead's
+        c = 1u + uint32_t(W.lpre[bk >> 5]) +
+            uint32_t(__builtin_popcount(W.bm[0][bk >> 5] & ((1u << (bk & 31u)) - 1u)));
+      } else {        // a bit stands for 2^s docs: look the doc up among the sorted lead docs
+        c = count_le(docs, 0u, n, doc);
+        if (c == 0u || docs[c - 1u] != doc || cnt[c - 1u] != i) return;
       }
+      row[c - 1u] = f;
+      cnt[c - 1u] = uint8_t(i + 1u);
+      atomicOr(&mark[bk >> 5], 1u << (bk & 31u));
     };
     if (tl.nblk) {
       const uint32_t* last = seg.blk_last + tl.dir_off;
-      for (uint32_t b0 = seek[i - 1u]; b0 < tl.nblk; b0 += 64) {
+      const uint32_t b_first = seek[i - 1u];
+      uint32_t carry = b_first ? last[b_first - 1u] : 0u;   // last doc of the block before
+      for (uint32_t b0 = b_first; b0 < tl.nblk; b0 += 64) {
         const uint32_t bl = b0 + lane;
         const bool valid = bl < tl.nblk;
         const uint32_t lst = valid ? last[bl] : 0xFFFFFFFFu;
-        const uint32_t prv = (valid && bl) ? last[bl - 1] : 0u;  // block holds docs in (prv, lst]
-        const bool reach = valid && prv < dhi;
-        const uint32_t cp_l = reach ? count_le(docs, 0u, n, prv) : 0u;
-        const uint32_t cl_l = reach ? count_le(docs, cp_l, n, lst) : 0u;
-        // some lead doc that every earlier term reached lies in (prv, lst]
-        const bool want = alive[cl_l] > alive[cp_l];
+        // the block holds docs in (prv, lst], prv = the preceding block's lst
+        uint32_t prv = uint32_t(__shfl_up(lst, 1, 64));
+        if (lane == 0) prv = carry;
+        carry = wave::read_lane(lst, 63);
+        const bool reach = valid && prv < dhi && lst >= dlo;
+        // some doc every earlier term reached lies in a bucket touching (prv, lst]
+        bool want = false;
+        if (reach) {
+          const uint32_t x0 = prv + 1u > dlo ? prv + 1u - dlo : 0u;
+          const uint32_t x1 = (lst < dhi ? lst : dhi) - dlo;
+          want = alive_below((x1 >> s) + 1u) > alive_below(x0 >> s);
+        }
         BlkDir d{};
         if (want) d = seg.blk_dir[tl.dir_off + bl];
         uint64_t mask = wave::ballot(want);
-        const bool more = wave::ballot(valid && !reach) == 0;  // no block started behind dhi yet
+        const bool more = wave::ballot(valid && prv >= dhi) == 0;  // no block started behind dhi yet
         while (mask) {
           const uint32_t k = uint32_t(__builtin_ctzll(mask));
           mask &= mask - 1;
           uint32_t d0, d1, f0, f1;
-          decode_dir_block<LAYOUT>(seg, tl.doc_start, wave::read_lane(d.bits, k),
-                                   wave::read_lane(d.off, k), wave::read_lane(d.aoff, k),
-                                   wave::read_lane(d.prev_last, k), lane, d0, d1, f0, f1);
-          bytes += block_bytes(wave::read_lane(d.bits, k));
-          const uint32_t w0 = wave::read_lane(cp_l, k), w1 = wave::read_lane(cl_l, k);
-          put(d0, f0, w0, w1);
-          put(d1, f1, w0, w1);
+          const uint32_t kbits = wave::read_lane(d.bits, k);
+          decode_dir_block<LAYOUT>(seg, tl.doc_start, kbits, wave::read_lane(d.off, k),
+                                   wave::read_lane(d.aoff, k), wave::read_lane(d.prev_last, k),
+                                   lane, d0, d1, f0, f1);
+          bytes += block_bytes(kbits);
+          put(d0, f0);
+          put(d1, f1);
         }
         if (!more) break;
       }
@@ -368,29 +475,28 @@ k_conj(ConjArgs A, uint32_t pilot) {
       const uint32_t t1 = lane + 64u < tl.n ? seg.tail_docs[tl.tail_row + lane + 64u] : 0u;
       const uint32_t g0 = lane < tl.n ? seg.tail_freqs[tl.tail_row + lane] : 0u;
       const uint32_t g1 = lane + 64u < tl.n ? seg.tail_freqs[tl.tail_row + lane + 64u] : 0u;
-      put(t0, g0, 0u, n);
-      put(t1, g1, 0u, n);
+      put(t0, g0);
+      put(t1, g1);
     }
     wave::sync();
   }
 
   // ---- 3. docs every term reached
-  if (!pilot && A.touched && lane == 0) {
-    // + the norm of every lead doc, where the scorer reads one
-    const uint32_t nb = needs_norm(w_qt[0].kind) ? n * seg.norm_width : 0u;
-    atomicAdd(&A.touched[2u * unit], static_cast<unsigned long long>(bytes + nb));
-  }
+  flush(((m - 1u) / kConjRows) * kConjRows, m);
+  wave::sync();
+  if (!pilot && A.touched && lane == 0)
+    atomicAdd(&A.touched[2u * unit], static_cast<unsigned long long>(bytes));
   uint32_t my_hits = 0;
-  for (uint32_t s = lane; s < n; s += 64) {
-    if (cnt[s] != m) continue;
+  for (uint32_t sl = lane; sl < n; sl += 64) {
+    if (cnt[sl] != m) continue;
     ++my_hits;
-    const float v = score[s];
+    const float v = score[sl];
     const uint32_t bin = score_bin(v, qd.bin_scale);
     if (pilot) {
       atomicAdd(&A.hist[uint64_t(unit) * kBins + bin], 1u);
     } else if (bin >= bs) {
       const uint32_t slot = atomicAdd(&A.cand_count[unit], 1u);
-      if (slot < A.cand_cap) A.cands[uint64_t(unit) * A.cand_cap + slot] = make_key(v, docs[s]);
+      if (slot < A.cand_cap) A.cands[uint64_t(unit) * A.cand_cap + slot] = make_key(v, docs[sl]);
     }
   }
   if (!pilot) {

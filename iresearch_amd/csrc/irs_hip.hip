@@ -125,8 +125,8 @@ struct irs_hip_batch {
   std::vector<uint32_t> tile_units, conj_units;
   std::vector<uint32_t> conj_items;   // lead items of every conj unit
   uint32_t n_conj_wgs = 0;
-  DevBuf d_tile_units, d_conj_units, d_conj_items, d_conj_wgs, d_conj_hist;
-  DevBuf d_conj_item_base, d_conj_unit_items, d_conj_seek;   // k_conj_seek
+  DevBuf d_tile_units, d_conj_units, d_conj_items, d_conj_hist;
+  DevBuf d_conj_item_base, d_conj_unit_items, d_conj_seek, d_conj_recs;   // k_conj_seek
   uint32_t conj_total_items = 0;
   DevBuf d_conj_pilot;             // the lead items the pilot pass samples, {unit, item} each
   uint32_t n_conj_pilot = 0, conj_pilot_stride = 0;
@@ -403,7 +403,8 @@ bool launch_conj(irs_hip_batch* b, rt::stream_t st) {
   a.segs = b->d_segs.as<DevSegment>();
   a.queries = b->d_queries.as<DevQuery>();
   a.qterms = b->d_qterms.as<DevQTerm>();
-  a.wgs = b->d_conj_wgs.as<PhraseWg>();
+  a.wgs = nullptr;
+  a.n_items = b->conj_total_items;
   a.tails = b->d_tails.as<DevTail>();
   a.bstar = b->d_bstar.as<uint32_t>();
   a.cands = b->d_cands.as<uint64_t>();
@@ -412,6 +413,7 @@ bool launch_conj(irs_hip_batch* b, rt::stream_t st) {
   a.hist = b->d_conj_hist.as<uint32_t>();
   a.touched = b->count_touched ? b->d_touched.as<unsigned long long>() : nullptr;
   a.seek = b->d_conj_seek.as<uint32_t>();
+  a.recs = b->d_conj_recs.as<ConjItem>();
   a.unit_items = b->d_conj_unit_items.as<uint32_t>();
   a.jt = b->jt;
   a.cand_cap = b->cand_cap;
@@ -422,7 +424,8 @@ bool launch_conj(irs_hip_batch* b, rt::stream_t st) {
   RT_LAUNCH(k_conj_seek, (b->conj_total_items + kThreads - 1) / kThreads, kThreads, 0, st,
             b->d_segs.as<DevSegment>(), b->d_queries.as<DevQuery>(), b->d_tails.as<DevTail>(),
             b->jt, b->d_conj_units.as<uint32_t>(), b->d_conj_item_base.as<uint32_t>(),
-            uint32_t(b->conj_units.size()), b->d_conj_seek.as<uint32_t>());
+            uint32_t(b->conj_units.size()), b->d_conj_seek.as<uint32_t>(),
+            b->d_conj_recs.as<ConjItem>());
   if (b->n_conj_pilot) {
     ConjArgs p = a;
     p.wgs = b->d_conj_pilot.as<PhraseWg>();
@@ -434,7 +437,8 @@ bool launch_conj(irs_hip_batch* b, rt::stream_t st) {
             b->d_queries.as<DevQuery>(), b->d_conj_units.as<uint32_t>(),
             b->d_conj_items.as<uint32_t>(), b->d_conj_hist.as<uint32_t>(), a.pilot_stride,
             b->estimate ? kPilotMargin : 0u, b->d_bstar.as<uint32_t>());
-  RT_LAUNCH((k_conj<LAYOUT>), b->n_conj_wgs, kConjWaves * 64, 0, st, a, 0u);
+  RT_LAUNCH((k_conj<LAYOUT>), (b->conj_total_items + kConjWaves - 1) / kConjWaves, kConjWaves * 64,
+            0, st, a, 0u);
   return rt::last_error_ok();
 }
 
@@ -1284,10 +1288,10 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
     }
   }
   if (rc == IRS_HIP_OK && !b->phrase && !b->conj_units.empty()) {
-    // k_conj work list: the lead term of a unit is its first one (sorted by cost above); one
-    // wavefront per 128-posting block of it (+ one for its vint tail / single doc)
+    // k_conj work: the lead term of a unit is its first one (sorted by cost above); one
+    // wavefront per 128-posting block of it (+ one for its vint tail / single doc), its record
+    // and the other terms' start blocks written by k_conj_seek every run
     try {
-      std::vector<PhraseWg> wgs;
       for (uint32_t u : b->conj_units) {
         const DevQuery& dq = b->queries[u];
         uint32_t items = 0;
@@ -1296,12 +1300,8 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
           items = t.nblk + ((t.docs_count == 1 || t.tail_n) ? 1u : 0u);
         }
         b->conj_items.push_back(items);
-        for (uint32_t it = 0; it < items; it += kConjWaves) wgs.push_back(PhraseWg{u, it});
       }
-      if (wgs.size() > 0x7FFFFFFFull) {
-        rc = IRS_HIP_EUNSUPPORTED;
-      } else {
-        b->n_conj_wgs = uint32_t(wgs.size());
+      {
         // rows of the seek table: the lead items of the conj units, unit after unit
         std::vector<uint32_t> item_base(b->conj_units.size() + 1, 0), unit_items(nq, 0);
         uint64_t total = 0;
@@ -1313,10 +1313,12 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
         if (total > 0x7FFFFFFFull) rc = IRS_HIP_EUNSUPPORTED;
         item_base[b->conj_units.size()] = uint32_t(total);
         b->conj_total_items = uint32_t(total);
+        b->n_conj_wgs = uint32_t((total + kConjWaves - 1) / kConjWaves);
         if (rc == IRS_HIP_OK &&
             (!b->d_conj_item_base.alloc(item_base.size() * 4) ||
              !b->d_conj_unit_items.alloc(unit_items.size() * 4) ||
-             !b->d_conj_seek.alloc((total + 2) * uint64_t(kMaxTerms) * 4)))
+             !b->d_conj_seek.alloc((total + 2) * uint64_t(kMaxTerms) * 4) ||
+             !b->d_conj_recs.alloc((total + 1) * sizeof(ConjItem))))
           rc = IRS_HIP_ENOMEM;
         if (rc == IRS_HIP_OK &&
             (!rt::h2d(b->d_conj_item_base.p, item_base.data(), item_base.size() * 4, nullptr) ||
@@ -1324,13 +1326,11 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
           rc = IRS_HIP_EHIP;
         if (rc != IRS_HIP_OK) {
         } else
-        if (!b->d_conj_wgs.alloc(std::max<size_t>(1, wgs.size()) * sizeof(PhraseWg)) ||
-            !b->d_conj_units.alloc(b->conj_units.size() * 4) ||
+        if (!b->d_conj_units.alloc(b->conj_units.size() * 4) ||
             !b->d_conj_items.alloc(b->conj_items.size() * 4) ||
             !b->d_conj_hist.alloc(uint64_t(nq) * kBins * 4))
           rc = IRS_HIP_ENOMEM;
-        else if (!rt::h2d(b->d_conj_wgs.p, wgs.data(), wgs.size() * sizeof(PhraseWg), nullptr) ||
-                 !rt::h2d(b->d_conj_units.p, b->conj_units.data(), b->conj_units.size() * 4, nullptr) ||
+        else if (!rt::h2d(b->d_conj_units.p, b->conj_units.data(), b->conj_units.size() * 4, nullptr) ||
                  !rt::h2d(b->d_conj_items.p, b->conj_items.data(), b->conj_items.size() * 4, nullptr) ||
                  !rt::sync(nullptr))
           rc = IRS_HIP_EHIP;

@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--lib", default=None, help="alternative build of libirs_hip.so (A/B runs)")
     ap.add_argument("--wand", action="store_true", help="also time the batch with block-max pruning")
     ap.add_argument("--clustered", action="store_true", help="bursty posting lists (topic docs)")
+    ap.add_argument("--touched", action="store_true",
+                    help="And / by_phrase: one more run that counts the bytes actually decoded")
     args = ap.parse_args()
     import torch
 
@@ -86,6 +88,12 @@ def main():
                                                               b.reruns()), flush=True)
         print("   hits/query: mean %.0f max %d" % (float(np.mean(totals)), int(np.max(totals))),
               flush=True)
+        if args.touched:
+            b.profile(3).run()
+            td, tp = b.touched()
+            print("   touched: %.1f MB .doc + norms (%.1f%% of the terms' %.1f MB), %.1f MB positions; "
+                  "%.1f GB/s of touched bytes" % (td / 1e6, 100.0 * td / max(1, alg), alg / 1e6,
+                                                  tp / 1e6, (td + tp) / avg[2] / 1e6), flush=True)
         b.close()
         if args.wand:
             b = sr.batch(prep, args.k).configure(tile, stride, 0).set_wand(True).profile(True)
