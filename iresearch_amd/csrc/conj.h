@@ -429,7 +429,7 @@ k_conj(ConjArgs A, uint32_t pilot) {
       }
       row[c - 1u] = f;
       cnt[c - 1u] = uint8_t(i + 1u);
-      atomicOr(&mark[bk >> 5], 1u << (bk & 31u));
+      if (i + 1u < m) atomicOr(&mark[bk >> 5], 1u << (bk & 31u));   // (alive for the next term)
     };
     if (tl.nblk) {
       const uint32_t* last = seg.blk_last + tl.dir_off;
@@ -481,28 +481,48 @@ k_conj(ConjArgs A, uint32_t pilot) {
     wave::sync();
   }
 
-  // ---- 3. docs every term reached
-  flush(((m - 1u) / kConjRows) * kConjRows, m);
+  // ---- 3. docs every term reached: compacted (usually one pass of the wavefront), the terms
+  // not yet scored added, straight into the histogram (pilot) / the candidate list
+  const uint32_t g0 = ((m - 1u) / kConjRows) * kConjRows;
+  const bool h0 = lane < n && cnt[lane] == m, h1 = lane + 64u < n && cnt[lane + 64u] == m;
+  const uint64_t m0 = wave::ballot(h0), m1 = wave::ballot(h1);
+  const uint64_t below = (1ull << lane) - 1ull;
+  const uint32_t c0 = uint32_t(__builtin_popcountll(m0));
+  const uint32_t total = c0 + uint32_t(__builtin_popcountll(m1));
+  uint8_t* list = W.apre;   // (the alive prefix counts have served)
+  if (h0) list[__builtin_popcountll(m0 & below)] = uint8_t(lane);
+  if (h1) list[c0 + uint32_t(__builtin_popcountll(m1 & below))] = uint8_t(lane + 64u);
   wave::sync();
+  if (with_norm) bytes += total * seg.norm_width;
   if (!pilot && A.touched && lane == 0)
     atomicAdd(&A.touched[2u * unit], static_cast<unsigned long long>(bytes));
-  uint32_t my_hits = 0;
-  for (uint32_t sl = lane; sl < n; sl += 64) {
-    if (cnt[sl] != m) continue;
-    ++my_hits;
-    const float v = score[sl];
-    const uint32_t bin = score_bin(v, qd.bin_scale);
-    if (pilot) {
-      atomicAdd(&A.hist[uint64_t(unit) * kBins + bin], 1u);
-    } else if (bin >= bs) {
-      const uint32_t slot = atomicAdd(&A.cand_count[unit], 1u);
-      if (slot < A.cand_cap) A.cands[uint64_t(unit) * A.cand_cap + slot] = make_key(v, docs[sl]);
+  for (uint32_t p0 = 0; p0 < total; p0 += 64) {
+    const bool on = p0 + lane < total;
+    bool cand = false;
+    float v = 0.f;
+    uint32_t doc = 0;
+    if (on) {
+      const uint32_t sl = list[p0 + lane];
+      doc = docs[sl];
+      const uint32_t nv = norm_value(seg, doc);
+      v = score[sl];
+      for (uint32_t j = g0; j < m; ++j) v += score_value(term_q(j), W.fr[j - g0][sl], nv);
+      const uint32_t bin = score_bin(v, qd.bin_scale);
+      if (pilot) atomicAdd(&A.hist[uint64_t(unit) * kBins + bin], 1u);
+      else cand = bin >= bs;
+    }
+    // one reservation per wavefront for all its candidates of this pass
+    const uint64_t cm = wave::ballot(cand);
+    if (cm) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&A.cand_count[unit], uint32_t(__builtin_popcountll(cm)));
+      base = wave::read_lane(base, 0);
+      const uint32_t slot = base + uint32_t(__builtin_popcountll(cm & below));
+      if (cand && slot < A.cand_cap) A.cands[uint64_t(unit) * A.cand_cap + slot] = make_key(v, doc);
     }
   }
-  if (!pilot) {
-    my_hits = wave::reduce_add(my_hits);
-    if (lane == 0 && my_hits) atomicAdd(&A.hits[unit], static_cast<unsigned long long>(my_hits));
-  }
+  if (!pilot && lane == 0 && total)
+    atomicAdd(&A.hits[unit], static_cast<unsigned long long>(total));
 }
 
 // Threshold bin of a unit from the pilot histogram (the rule of k_pilot): one wavefront per unit.
