@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define IRS_HIP_ABI_VERSION 3
+#define IRS_HIP_ABI_VERSION 4
 #define IRS_HIP_BLOCK_SIZE 128u  /* postings per block, formats_10.cpp:90 */
 #define IRS_HIP_MAX_TERMS 16u    /* terms per boolean query               */
 #define IRS_HIP_MAX_K 4096u      /* largest top-k                         */
@@ -190,12 +190,25 @@ typedef struct irs_hip_term_scorer {
                              :279-284; 0 for the first); ignored by the other ops          */
 } irs_hip_term_scorer;
 
+/* boolean_filter::merge_type() — irs::ScoreMergeType (scorer.hpp:224-236) of an Or / And:
+ * how the scores of the sub-queries on one doc combine.  The mergers are the reference's
+ * (scorer.hpp:390-423), including what kMin does in a disjunction: it merges with the 0 of
+ * every sub-query that is not on the doc, so an Or of two scores min(a, b) where both match
+ * and 0 elsewhere, and an Or of three or more (block_disjunction's zeroed score buffer,
+ * disjunction.hpp:1308-1351) scores 0 everywhere.  kNoop (no scores) is not offered. */
+typedef enum irs_hip_merge {
+  IRS_HIP_MERGE_SUM = 0,
+  IRS_HIP_MERGE_MAX = 1,
+  IRS_HIP_MERGE_MIN = 2
+} irs_hip_merge;
+
 typedef struct irs_hip_query {
   int32_t op;          /* irs_hip_op                                   */
   uint32_t n_terms;    /* 1..IRS_HIP_MAX_TERMS (PHRASE: ..IRS_HIP_MAX_PHRASE_TERMS) */
   uint32_t first_term; /* index of the first entry in the `terms` array */
   uint32_t k;          /* top-k, 1..IRS_HIP_MAX_K (index-search --topN) */
   uint32_t min_match;  /* IRS_HIP_OP_MINMATCH: Or::min_match_count(); else ignored */
+  uint32_t merge;      /* irs_hip_merge (OR / AND / MINMATCH); PHRASE: IRS_HIP_MERGE_SUM */
 } irs_hip_query;
 
 /* (score, segment-local doc) exactly as utils/index-search.cpp:745-787 keeps. */

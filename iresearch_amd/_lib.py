@@ -30,10 +30,10 @@ TERM_SCORER = np.dtype(
     [("term", "<u4"), ("kind", "<i4"), ("c0", "<f4"), ("norm_const", "<f4"),
      ("norm_length", "<f4"), ("phrase_offset", "<u4")], align=True)
 QUERY = np.dtype([("op", "<i4"), ("n_terms", "<u4"), ("first_term", "<u4"), ("k", "<u4"),
-                  ("min_match", "<u4")], align=True)
+                  ("min_match", "<u4"), ("merge", "<u4")], align=True)
 HIT = np.dtype([("score", "<f4"), ("doc", "<u4")], align=True)
 assert TERM_META.itemsize == 48 and TERM_SCORER.itemsize == 24
-assert QUERY.itemsize == 20 and HIT.itemsize == 8
+assert QUERY.itemsize == 24 and HIT.itemsize == 8
 
 
 class SegmentDesc(C.Structure):

@@ -130,9 +130,11 @@ struct by_term {
 struct Or {
   std::vector<by_term> subs;
   uint32_t min_match_count = 1;  // irs::Or::min_match_count()
+  irs_hip_merge merge_type = IRS_HIP_MERGE_SUM;  // boolean_filter::merge_type()
 };
 struct And {
   std::vector<by_term> subs;
+  irs_hip_merge merge_type = IRS_HIP_MERGE_SUM;
 };
 struct by_phrase {
   std::vector<uint32_t> terms;
@@ -163,6 +165,7 @@ struct SegmentStats {
 struct PreparedQuery {
   int32_t op = IRS_HIP_OP_OR;
   uint32_t min_match = 0;
+  uint32_t merge = IRS_HIP_MERGE_SUM;
   std::vector<irs_hip_term_scorer> terms;  // .term = the ordinal; same for every segment here
 };
 
@@ -198,9 +201,11 @@ std::vector<PreparedQuery> prepare(const std::vector<filter>& filters, const Sco
     } else if (const auto* o = std::get_if<Or>(&f)) {
       q.op = o->min_match_count > 1 ? IRS_HIP_OP_MINMATCH : IRS_HIP_OP_OR;
       q.min_match = o->min_match_count > 1 ? o->min_match_count : 0;
+      q.merge = o->merge_type;
       for (const auto& t : o->subs) q.terms.push_back(one(t));
     } else if (const auto* a = std::get_if<And>(&f)) {
       q.op = IRS_HIP_OP_AND;
+      q.merge = a->merge_type;
       for (const auto& t : a->subs) q.terms.push_back(one(t));
     } else {
       const auto& p = std::get<by_phrase>(f);
@@ -304,7 +309,7 @@ class QueryBatch {
         for (uint32_t q : part.index) {
           const PreparedQuery& p = prepared[q];
           queries.push_back(irs_hip_query{p.op, uint32_t(p.terms.size()),
-                                          uint32_t(entries.size()), k, p.min_match});
+                                          uint32_t(entries.size()), k, p.min_match, p.merge});
           entries.insert(entries.end(), p.terms.begin(), p.terms.end());
         }
         std::vector<irs_hip_term_scorer> all;

@@ -100,6 +100,15 @@ __device__ __forceinline__ void decode_dir_block(const DevSegment& seg, uint64_t
   }
 }
 
+// Conjunction::Score2 / ScoreN (conjunction.hpp:105-126): the first sub-score, then the
+// filter's merger over the others (SumMerger / MaxMerger / MinMerger, scorer.hpp:390-423).
+__device__ __forceinline__ float merge_scores(uint32_t merge, bool first, float acc, float s) {
+  if (first) return acc + s;   // (acc is 0: the same float the reference starts from)
+  if (merge == kScoreMax) return acc < s ? s : acc;
+  if (merge == kScoreMin) return s < acc ? s : acc;
+  return acc + s;
+}
+
 constexpr uint32_t kConjWaves = 4;  // wavefronts (= lead blocks) per workgroup
 constexpr uint32_t kConjRows = 4;   // frequency rows per wavefront (terms scored per flush)
 constexpr uint32_t kConjWords = 128;  // 32-bit words of a wavefront's doc-range bitmaps
@@ -235,6 +244,7 @@ k_conj(ConjArgs A, uint32_t pilot) {
   const DevQuery qd = wave::sload<DevQuery>(reinterpret_cast<uint64_t>(A.queries) + uint64_t(unit) * sizeof(DevQuery));
   const uint32_t m = qd.n_terms;
   if (m == 0) return;
+  const uint32_t mrg = query_merge(qd.op);
   const DevSegment& seg = A.segs[qd.seg];   // (read field by field)
   const uint64_t tl_at = reinterpret_cast<uint64_t>(A.tails) + uint64_t(unit) * A.jt * sizeof(DevTail);
   const uint64_t qt_at = reinterpret_cast<uint64_t>(A.qterms) + uint64_t(qd.first_term) * sizeof(DevQTerm);
@@ -345,7 +355,8 @@ k_conj(ConjArgs A, uint32_t pilot) {
       if (on) {
         const uint32_t nv = norm_value(seg, docs[sl]);
         float v = score[sl];
-        for (uint32_t j = g0; j < g1; ++j) v += score_value(term_q(j), W.fr[j - g0][sl], nv);
+        for (uint32_t j = g0; j < g1; ++j)
+          v = merge_scores(mrg, j == 0u, v, score_value(term_q(j), W.fr[j - g0][sl], nv));
         score[sl] = v;
       }
     }
@@ -506,7 +517,8 @@ k_conj(ConjArgs A, uint32_t pilot) {
       doc = docs[sl];
       const uint32_t nv = norm_value(seg, doc);
       v = score[sl];
-      for (uint32_t j = g0; j < m; ++j) v += score_value(term_q(j), W.fr[j - g0][sl], nv);
+      for (uint32_t j = g0; j < m; ++j)
+        v = merge_scores(mrg, j == 0u, v, score_value(term_q(j), W.fr[j - g0][sl], nv));
       const uint32_t bin = score_bin(v, qd.bin_scale);
       if (pilot) atomicAdd(&A.hist[uint64_t(unit) * kBins + bin], 1u);
       else cand = bin >= bs;

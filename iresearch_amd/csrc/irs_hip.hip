@@ -1043,7 +1043,8 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
       const irs_hip_query& in = queries[q % nq_user];
       if ((in.op != IRS_HIP_OP_OR && in.op != IRS_HIP_OP_AND && in.op != IRS_HIP_OP_MINMATCH &&
            in.op != IRS_HIP_OP_PHRASE) ||
-          in.n_terms == 0 ||
+          in.n_terms == 0 || in.merge > IRS_HIP_MERGE_MIN ||
+          (in.op == IRS_HIP_OP_PHRASE && in.merge != IRS_HIP_MERGE_SUM) ||
           in.n_terms > IRS_HIP_MAX_TERMS || in.k == 0 || in.k > IRS_HIP_MAX_K ||
           uint64_t(in.first_term) + in.n_terms > n_entries) {
         rc = IRS_HIP_EINVAL;
@@ -1187,6 +1188,25 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
           b->any_and = true;
         }
       }
+      // The filter's ScoreMergeType (boolean_filter.hpp:39-43).  One sub-iterator: its score as
+      // it is (MakeDisjunction :1422-1426, MakeConjunction :444).  kMin in a disjunction merges
+      // with the 0 of every sub-iterator that is not on the doc (basic_disjunction,
+      // disjunction.hpp:338-351) resp. with the zeroed score buffer (block_disjunction
+      // :1308-1351): two sub-iterators -> min where both match, else 0; more (or the
+      // min-match block disjunction) -> 0 for every doc.
+      uint32_t merge = row.size() > 1 ? in.merge : uint32_t(IRS_HIP_MERGE_SUM);
+      if (merge == IRS_HIP_MERGE_MIN && (dq.op & 0xFF) != 2) {
+        if ((dq.op & 0xFF) == 0 && row.size() == 2) {
+          dq.op |= int32_t(1u << 18);
+          b->any_and = true;   // (the per-doc match counters tell "both")
+        } else {
+          for (DevQTerm& qt : row) qt.c0 = 0.f;
+          upper = 0.0;
+          min_score = 0.0;
+          merge = IRS_HIP_MERGE_SUM;
+        }
+      }
+      dq.op |= int32_t(merge << 16);
       if (!is_phrase) ((dq.op & 0xFF) == 2 ? b->conj_units : b->tile_units).push_back(q);
       // table slots (kernels.h "table_kind"): one per distinct (kind, norm_const, norm_length)
       uint32_t n_caches = 0;

@@ -199,6 +199,21 @@ __device__ __forceinline__ float from_fixed(ACC a, float fx_inv) {
   return static_cast<float>(a) * fx_inv;
 }
 
+// DevQuery::op: bits 0..7 how the unit runs (0 doc tiles, 1 doc tiles with match counters,
+// 2 block-driven conjunction), 8..15 the matches a doc needs, 16..17 the boolean filter's
+// ScoreMergeType (scorer.hpp:224-236: 0 sum, 1 max, 2 min), bit 18: a kMin disjunction of two
+// sub-iterators — a doc only one of them holds scores 0 (disjunction.hpp:338-351).
+enum : uint32_t { kScoreSum = 0, kScoreMax = 1, kScoreMin = 2 };
+__host__ __device__ __forceinline__ uint32_t query_merge(int32_t op) { return (uint32_t(op) >> 16) & 3u; }
+__host__ __device__ __forceinline__ uint32_t query_need(int32_t op) { return (uint32_t(op) >> 8) & 0xFFu; }
+__host__ __device__ __forceinline__ bool query_min_both(int32_t op) { return (uint32_t(op) >> 18) & 1u; }
+// Max/Min merged accumulators hold max(fixed) resp. max(~fixed) (0 = untouched either way);
+// back to the fixed-point score:
+template<typename ACC>
+__device__ __forceinline__ ACC merged_fixed(ACC a, uint32_t merge) {
+  return merge == kScoreMin ? ACC(~a) : a;
+}
+
 // Score of one posting — the reference's float expressions, evaluated in the
 // same order with no FMA contraction (bm25.cpp:313, 353, 359; tfidf.cpp:185-187, 251-253).
 template<typename SM>
@@ -257,7 +272,10 @@ __device__ __forceinline__ void tile_apply(const DevSegment& seg, const TileSmem
                                            float fx_mul) {
   if (idx < span) {
     const float s = score_posting(seg, qt, inv_one, sm, freq, lo + idx, idx);
-    atomicAdd(&sm.acc[idx], fixed_from_scaled<ACC>(s * fx_mul));
+    const ACC fx = fixed_from_scaled<ACC>(s * fx_mul);
+    const uint32_t merge = sm.slow[3];   // MaxMerger / MinMerger, scorer.hpp:399-423
+    if (merge == kScoreSum) atomicAdd(&sm.acc[idx], fx);
+    else atomicMax(&sm.acc[idx], merge == kScoreMin ? ACC(~fx) : fx);
     if (AND) atomicAdd(&sm.cnt[idx >> 2], 1u << (8u * (idx & 3u)));
   }
 }
@@ -796,6 +814,7 @@ k_items_fill(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qt
     const uint32_t dbits = d.bits & 0xFFu, fbits = d.bits >> 8;
     if (!(table_kind(qts[j].kind) && qts[j].cache_id < kMaxCaches && pk_units(dbits, fbits) != 0u))
       return 0u;
+    if (query_merge(qd.op)) return 0u;   // Max/Min merged scores: the generic path's atomic max
     if (fbits == 0u) {
       fconst = freq_const(j, d);
       if (fconst > 0xFFFFu) return 0u;
@@ -983,6 +1002,7 @@ k_pilot(const uint32_t* units, const DevSegment* segs, const DevQuery* queries,
     sm.slow[0] = __float_as_uint(qd.fx_mul);
     sm.slow[1] = seg.num_docs;
     sm.slow[2] = table_rows(qd.n_caches);
+    sm.slow[3] = query_merge(qd.op);
   }
   __syncthreads();
   build_tables(sm, qd.n_caches, qd.n_terms);
@@ -1005,9 +1025,14 @@ k_pilot(const uint32_t* units, const DevSegment* segs, const DevQuery* queries,
       const ACC a = sm.acc[i];
       sm.acc[i] = ACC(0);
       bool m = a != ACC(0);
+      const uint32_t c = AND ? (sm.cnt[i >> 2] >> (8u * (i & 3u))) & 0xFFu : 0u;
       if (AND && (qd.op & 0xFF) == 1)  // AND / min-match: op = 1 | required matches << 8
-        m = ((sm.cnt[i >> 2] >> (8u * (i & 3u))) & 0xFFu) >= uint32_t(qd.op >> 8);
-      if (m) atomicAdd(&hist[score_bin(from_fixed<ACC>(a, qd.fx_inv), qd.bin_scale)], 1u);
+        m = c >= query_need(qd.op);
+      if (m) {
+        ACC f = merged_fixed<ACC>(a, query_merge(qd.op));
+        if (AND && query_min_both(qd.op) && c < 2u) f = ACC(0);
+        atomicAdd(&hist[score_bin(from_fixed<ACC>(f, qd.fx_inv), qd.bin_scale)], 1u);
+      }
     }
     __syncthreads();
     if (AND) {
@@ -1179,6 +1204,7 @@ k_score(uint64_t args /*address of a ScoreArgs*/) {
       sm.slow[0] = __float_as_uint(qd.fx_mul);
       sm.slow[1] = seg.num_docs;
       sm.slow[2] = table_rows(qd.n_caches);
+      sm.slow[3] = query_merge(qd.op);
     }
     NormStage<TILE> nrm;
     nrm.load(norms1, norm_count, tile0);
@@ -1223,7 +1249,8 @@ k_score(uint64_t args /*address of a ScoreArgs*/) {
       uint32_t* ncand = vars + kVNc0 + (u % 3u);
       auto candidate = [&](uint32_t i, ACC a) {   // rare
         // (a sum of at most kMaxTerms units is what postings of zero-boost terms leave: score 0)
-        const float v = a <= ACC(kMaxTerms) ? 0.f : from_fixed<ACC>(a, qd.fx_inv);
+        const ACC f = merged_fixed<ACC>(a, query_merge(qd.op));
+        const float v = f <= ACC(kMaxTerms) ? 0.f : from_fixed<ACC>(f, qd.fx_inv);
         if (score_bin(v, qd.bin_scale) >= bs) {
           const uint64_t key = make_key(v, kDocMin + tile * uint32_t(TILE) + i);
           const uint32_t slot = atomicAdd(ncand, 1u);
@@ -1238,7 +1265,8 @@ k_score(uint64_t args /*address of a ScoreArgs*/) {
       };
       if (!wave::uniform(tdead[u])) {   // (a skipped tile accumulated nothing)
         const bool is_and = AND && (qd.op & 0xFF) == 1;  // op = 1 | required matches << 8
-        const uint32_t need = uint32_t(qd.op >> 8);
+        const uint32_t need = query_need(qd.op);
+        const bool min_both = AND && query_min_both(qd.op);
         // eight accumulators per lane per step: two 4-wide LDS reads in flight, two wide clears
         const uint32_t step = blockDim.x * 4u;
         for (uint32_t i = tid * 4u; i < uint32_t(TILE); i += 2u * step) {
@@ -1275,6 +1303,15 @@ k_score(uint64_t args /*address of a ScoreArgs*/) {
             for (int e = 0; e < 8; ++e) {
               const uint32_t c = ((e < 4 ? cw0 : cw1) >> (8u * (uint32_t(e) & 3u))) & 0xFFu;
               a[e] = c >= need ? a[e] : ACC(0);
+            }
+          }
+          if (AND && min_both) {
+            // a kMin disjunction of two: a doc only one of them holds scores 0 (as the
+            // complement of the smallest fixed-point value: still "matched")
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const uint32_t c = ((e < 4 ? cw0 : cw1) >> (8u * (uint32_t(e) & 3u))) & 0xFFu;
+              a[e] = (a[e] != ACC(0) && c < 2u) ? ACC(~ACC(1)) : a[e];
             }
           }
           ACC top = a[0];

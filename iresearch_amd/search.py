@@ -97,11 +97,17 @@ class by_term:
     boost: float = 1.0
 
 
+# irs::ScoreMergeType (scorer.hpp:224-236) of a boolean filter: boolean_filter::merge_type()
+MERGE_SUM, MERGE_MAX, MERGE_MIN = 0, 1, 2
+
+
 @dataclass
 class Or:
-    """irs::Or; min_match > 1 is Or::min_match_count() (boolean_filter.hpp)."""
+    """irs::Or; min_match > 1 is Or::min_match_count() (boolean_filter.hpp); `merge` its
+    merge_type()."""
     subs: list
     min_match: int = 1
+    merge: int = MERGE_SUM
 
     @property
     def op(self):
@@ -113,6 +119,7 @@ class And:
     subs: list
     op: int = OP_AND
     min_match: int = 0
+    merge: int = MERGE_SUM
 
 
 @dataclass
@@ -147,6 +154,7 @@ class PreparedQuery:
     scorers: list          # (kind, c0, norm_const, norm_length) per term
     min_match: int = 0
     offsets: list | None = None   # OP_PHRASE: position of every term in the phrase
+    merge: int = MERGE_SUM
 
 
 # ------------------------------------------------------------------ segment --
@@ -273,7 +281,7 @@ class QueryBatch:
         self.terms = np.zeros((len(self.segs), max(n_entries, 1)), TERM_SCORER)
         at = 0
         for q, p in enumerate(prepared):
-            self.queries[q] = (p.op, len(p.terms), at, self.k, p.min_match)
+            self.queries[q] = (p.op, len(p.terms), at, self.k, p.min_match, p.merge)
             offs = p.offsets if p.offsets is not None else [0] * len(p.terms)
             for t, (kind, c0, nc, nl), off in zip(p.terms, p.scorers, offs):
                 for s, sr in enumerate(self.segs):       # same scorer, the segment's own ordinal
@@ -412,7 +420,8 @@ def prepare(filters, scorer, segment_stats):
             stats = scorer.collect(dwf, dwt, ttf)
             scorers.append(scorer.term_scorer(stats, s.boost))
         out.append(PreparedQuery(op, [s.term for s in subs], scorers,
-                                 int(getattr(flt, "min_match", 0))))
+                                 int(getattr(flt, "min_match", 0)),
+                                 merge=int(getattr(flt, "merge", MERGE_SUM))))
     return out
 
 

@@ -142,6 +142,8 @@ enum {
 };
 enum { ORC_OP_OR = 0, ORC_OP_AND = 1, ORC_OP_MINMATCH = 2 /* + (min_match << 8) */,
        ORC_OP_PHRASE = 3 /* orc_search_phrase / orc_score_all_phrase only */ };
+/* ScoreMergeType of the boolean filter (scorer.hpp:224-236), in bits 24..25 of `op` */
+enum { ORC_MERGE_SUM = 0, ORC_MERGE_MAX = 1, ORC_MERGE_MIN = 2 };
 
 #define ORC_NORM_LEGACY_F32 0x104u
 typedef struct orc_segment {

@@ -165,10 +165,26 @@ void make_term_scorer(const orc_scorer& s, const orc_segment& seg,
 // ---------------------------------------------------------------------------
 // Iterators. `emit(doc, score)` plays the role of the harness loop body.
 
+// SumMerger / MaxMerger / MinMerger — scorer.hpp:390-423.  `dst` is whatever the caller
+// started from: the first sub-score in a conjunction (conjunction.hpp:105-126), 0 for a
+// sub-iterator that is not on the doc in basic_disjunction (score_iterator_impl,
+// disjunction.hpp:338-351) and the zeroed score buffer in block_disjunction (:1308-1351) —
+// so a kMin disjunction scores 0 unless it has exactly two sub-iterators and both match
+// ("probably can work strange with Max/MinMerger", scorer.hpp:387-388).
+inline void merge_score(int merge, float& dst, float src) {
+  if (merge == ORC_MERGE_MAX) {
+    if (dst < src) dst = src;
+  } else if (merge == ORC_MERGE_MIN) {
+    if (src < dst) dst = src;
+  } else {
+    dst += src;
+  }
+}
+
 // basic_disjunction — disjunction.hpp:233-253 (next), 302-310 (score),
 // 338-351 (score_iterator_impl)
 template<typename Emit>
-void run_or2(Sub& lhs, Sub& rhs, Emit&& emit) {
+void run_or2(Sub& lhs, Sub& rhs, int merge, Emit&& emit) {
   uint32_t doc = 0;
   auto next_impl = [&](Sub& s) {
     const uint32_t v = s.it.doc;
@@ -185,7 +201,7 @@ void run_or2(Sub& lhs, Sub& rhs, Emit&& emit) {
     if (doc == kEof) return;
     float res = lhs.it.doc == doc ? lhs.score() : 0.f;
     const float tmp = rhs.it.doc == doc ? rhs.score() : 0.f;
-    res += tmp;  // SumMerger scorer.hpp:392-397
+    merge_score(merge, res, tmp);  // merger(res, merger.temp()) :303
     emit(doc, res);
   }
 }
@@ -195,7 +211,7 @@ void run_or2(Sub& lhs, Sub& rhs, Emit&& emit) {
 // per-slot match counters (min_match_buffer :56-78), docs below min_match are
 // skipped in next() (:963-970), buffers are reset on every refill round (:1255-1259).
 template<typename Emit>
-void run_block_or(std::vector<Sub>& itrs, Emit&& emit, uint32_t min_match = 1) {
+void run_block_or(std::vector<Sub>& itrs, int merge, Emit&& emit, uint32_t min_match = 1) {
   constexpr uint32_t kWindow = 512;  // kBlockSize * kNumBlocks :1087-1092
   uint64_t mask[8];
   float score_buf[kWindow];
@@ -240,7 +256,7 @@ void run_block_or(std::vector<Sub>& itrs, Emit&& emit, uint32_t min_match = 1) {
             }
             const uint32_t offset = value - doc_base;
             mask[offset / 64] |= uint64_t(1) << (offset % 64);
-            score_buf[offset] += s.score();  // SumMerger
+            merge_score(merge, score_buf[offset], s.score());  // :1334-1336
             if (mm) {
               empty &= (++match_count[offset] < min_match);  // match_buf_.inc :1341
             } else {
@@ -278,7 +294,7 @@ void run_block_or(std::vector<Sub>& itrs, Emit&& emit, uint32_t min_match = 1) {
 
 // Conjunction — conjunction.hpp:191-223 (next/converge), 105-126 (Score2/N)
 template<typename Emit>
-void run_and(std::vector<Sub>& itrs, Emit&& emit) {
+void run_and(std::vector<Sub>& itrs, int merge, Emit&& emit) {
   Sub& front = itrs.front();
   for (;;) {
     if (!orc_it_next(&front.it)) return;
@@ -293,7 +309,7 @@ void run_and(std::vector<Sub>& itrs, Emit&& emit) {
       }
     }
     float res = itrs[0].score();
-    for (size_t i = 1; i < itrs.size(); ++i) res += itrs[i].score();
+    for (size_t i = 1; i < itrs.size(); ++i) merge_score(merge, res, itrs[i].score());
     emit(target, res);
   }
 }
@@ -303,7 +319,9 @@ template<typename Emit>
 void execute_segment(const orc_segment& seg, const orc_term_meta* metas,
                      uint32_t n_terms, int32_t op, const orc_scorer& scorer,
                      const float* boosts, const TermStats* stats, Emit&& emit) {
-  // op = ORC_OP_OR | ORC_OP_AND | ORC_OP_MINMATCH + (min_match << 8)
+  // op = ORC_OP_OR | ORC_OP_AND | ORC_OP_MINMATCH + (min_match << 8), + (ORC_MERGE_* << 24)
+  const int merge = (op >> 24) & 3;   // boolean_filter::merge_type(), boolean_filter.hpp:39-43
+  op &= 0xFFFFFF;
   uint32_t min_match = 1;
   if ((op & 0xFF) == ORC_OP_MINMATCH) {
     // MinMatchQuery::execute — boolean_query.cpp:212-247
@@ -335,7 +353,7 @@ void execute_segment(const orc_segment& seg, const orc_term_meta* metas,
     if (min_match == itrs.size()) {
       op = ORC_OP_AND;  // pure conjunction :1491-1494
     } else {
-      run_block_or(itrs, emit, min_match);
+      run_block_or(itrs, merge, emit, min_match);
       return;
     }
   }
@@ -347,11 +365,11 @@ void execute_segment(const orc_segment& seg, const orc_term_meta* metas,
   if (op == ORC_OP_AND) {
     std::sort(itrs.begin(), itrs.end(),  // MakeConjunction :450-453
               [](const Sub& a, const Sub& b) { return a.cost < b.cost; });
-    run_and(itrs, emit);
+    run_and(itrs, merge, emit);
   } else if (itrs.size() == 2) {
-    run_or2(itrs[0], itrs[1], emit);  // MakeDisjunction :1433-1440
+    run_or2(itrs[0], itrs[1], merge, emit);  // MakeDisjunction :1433-1440
   } else {
-    run_block_or(itrs, emit);  // :1465
+    run_block_or(itrs, merge, emit);  // :1465
   }
 }
 

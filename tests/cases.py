@@ -592,6 +592,44 @@ def case_zero_boost(L):
     sr.close()
 
 
+def case_merge_types(L):
+    """boolean_filter::merge_type() = kMax / kMin (scorer.hpp:399-423): Or, And and min-match,
+    with the reference's own kMin-in-a-disjunction behaviour (min of two where both match and 0
+    elsewhere; 0 everywhere for three or more: the zeroed score buffer), every scorer family,
+    both accumulator widths, dense and sparse terms (wide doc ranges in the conjunction)."""
+    from iresearch_amd.search import MERGE_MAX, MERGE_MIN
+    seg = synth.build_segment(60_000, 512)
+    sr = search.SegmentReader.from_synth(seg, L=L)
+    t = by_term
+    filters = []
+    for mg in (MERGE_MAX, MERGE_MIN):
+        filters += [Or([t(3), t(40), t(77), t(200)], merge=mg),
+                    Or([t(5), t(9)], merge=mg),
+                    Or([t(2, 3.0), t(30, 0.5)], merge=mg),
+                    And([t(1), t(6), t(30)], merge=mg),
+                    And([t(4), t(300)], merge=mg),
+                    And([t(0), t(2), t(3), t(5), t(7), t(11)], merge=mg),
+                    Or([t(1), t(6), t(30), t(12)], min_match=2, merge=mg),
+                    Or([t(1), t(6), t(30)], min_match=3, merge=mg),
+                    Or([t(7), t(10 ** 6)], merge=mg),        # one side absent: a single iterator
+                    Or([t(8)], merge=mg)]
+    for scorer in (BM25(), TFIDF(True), BM25(1.2, 0.0)):
+        hits, counts, totals = run_and_check(L, seg, filters, scorer, 50, sr=sr)
+        n = len(filters) // 2
+        # kMin, Or of four: every score is 0
+        assert (hits[n, :int(counts[n])]["score"] == 0).all() and counts[n] == 50
+        # kMin, Or of two: some docs hold both terms (score > 0), the others score 0
+        s = hits[n + 1, :int(counts[n + 1])]["score"]
+        assert s[0] > 0
+    import os
+    os.environ["IRS_HIP_ACC"] = "64"
+    try:
+        run_and_check(L, seg, filters, BM25(), 50, sr=sr)
+    finally:
+        del os.environ["IRS_HIP_ACC"]
+    sr.close()
+
+
 def case_decode_without_freq(L, layout):
     """Iterator requested without IndexFeatures::FREQ on a FREQ field: freq blocks are
     skipped (formats_10.cpp:1746-1750) — docs must be identical."""

@@ -18,9 +18,11 @@ def oracle_scorer(scorer) -> oracle.Scorer:
 
 
 def oracle_op(flt, op):
-    """Or with min_match > 1 -> ORC_OP_MINMATCH | (min_match << 8)."""
+    """Or with min_match > 1 -> ORC_OP_MINMATCH | (min_match << 8); the filter's merge type
+    in bits 24..25 (ORC_MERGE_*)."""
     mm = int(getattr(flt, "min_match", 0) or 0)
-    return oracle.OP_MINMATCH | (mm << 8) if op == oracle.OP_MINMATCH else op
+    op = oracle.OP_MINMATCH | (mm << 8) if op == oracle.OP_MINMATCH else op
+    return op | (int(getattr(flt, "merge", 0) or 0) << 24)
 
 
 def oracle_view(seg) -> oracle.SegmentView:

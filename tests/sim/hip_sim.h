@@ -350,6 +350,13 @@ inline unsigned atomicMax(unsigned* p, unsigned v) {
   }
   return old;
 }
+inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v) {
+  unsigned long long old = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (v > old &&
+         !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+  }
+  return old;
+}
 inline unsigned atomicCAS(unsigned* p, unsigned expected, unsigned desired) {
   __atomic_compare_exchange_n(p, &expected, desired, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
   return expected;

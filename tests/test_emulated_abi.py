@@ -153,6 +153,10 @@ def test_zero_boost(simlib):
     cases.case_zero_boost(simlib)
 
 
+def test_max_and_min_score_merging(simlib):
+    cases.case_merge_types(simlib)
+
+
 def test_wand_equals_exhaustive(simlib):
     cases.case_wand_equals_exhaustive(simlib)
 
