@@ -1596,18 +1596,23 @@ static int recover(irs_hip_batch* b, uint32_t status) {
 static int recover_overflow(irs_hip_batch* b) {
   constexpr uint64_t kMaxCandBytes = 16ull << 30;
   for (int attempt = 0; attempt < 3; ++attempt) {
-    if (b->stride_eff != 1) {
-      b->stride_eff = 1;
-    } else {
-      std::vector<uint32_t> cc(b->nq);
-      if (!rt::d2h(cc.data(), b->d_cand_count.p, size_t(b->nq) * 4, b->stream) ||
-          !rt::sync(b->stream))
-        return IRS_HIP_EHIP;
-      const uint64_t need = uint64_t(*std::max_element(cc.begin(), cc.end())) + 1024;
-      if (need <= b->cand_cap || need * b->nq * sizeof(uint64_t) > kMaxCandBytes)
-        return IRS_HIP_EOVERFLOW;
+    // the failed run counted every candidate it met, also those it could not store: with the
+    // same threshold a buffer of that size holds them all.  Growing it is the cheap way out;
+    // only when that is not affordable, a full histogram pass (stride 1: the tightest sound
+    // threshold) comes first — it costs as much as the scoring pass itself.
+    std::vector<uint32_t> cc(b->nq);
+    if (!rt::d2h(cc.data(), b->d_cand_count.p, size_t(b->nq) * 4, b->stream) ||
+        !rt::sync(b->stream))
+      return IRS_HIP_EHIP;
+    const uint64_t need = uint64_t(*std::max_element(cc.begin(), cc.end())) + 1024;
+    const bool affordable = need * b->nq * sizeof(uint64_t) <= kMaxCandBytes;
+    if (need > b->cand_cap && affordable) {
       if (!b->d_cands.alloc(need * b->nq * sizeof(uint64_t))) return IRS_HIP_ENOMEM;
       b->cand_cap = uint32_t(need);
+    } else if (b->stride_eff != 1) {
+      b->stride_eff = 1;
+    } else {
+      return IRS_HIP_EOVERFLOW;
     }
     int rc = run_impl(b, b->stream);
     if (rc != IRS_HIP_OK) return rc;
