@@ -111,96 +111,6 @@ __device__ __forceinline__ float merge_scores(uint32_t merge, bool first, float 
 
 constexpr uint32_t kConjWaves = 4;  // wavefronts (= lead blocks) per workgroup
 constexpr uint32_t kConjRows = 4;   // frequency rows per wavefront (terms scored per flush)
-constexpr uint32_t kConjWords = 128;  // 32-bit words of a wavefront's doc-range bitmaps
-
-// One lead item (a 128-posting block of the conjunction's rarest term, or its decoded vint
-// tail), everything its wavefront needs to start decoding — written by the pre-pass so that
-// the wavefront's first load is this record (one scalar load) instead of a chain of dependent
-// ones (unit -> query -> term record -> directory words).
-struct alignas(32) ConjItem {
-  uint32_t unit;
-  uint32_t item;    // block index in the lead's list; == its nblk: the vint tail
-  uint32_t base;    // doc the block's first delta is relative to (formats_10.cpp:636)
-  uint32_t r_lo;    // the item's docs lie in [r_lo, r_hi] (from the directory)
-  uint32_t r_hi;
-  uint32_t aoff;    // block in the packed-payload image, 16-byte units
-  uint32_t bits;    // header bytes: dbits | fbits << 8
-  uint32_t off;     // block in `.doc`, relative to the term's doc_start
-};
-static_assert(sizeof(ConjItem) == 32, "one s_load_dwordx8 per lead item");
-
-// Pre-pass, one thread per lead item of every conjunction: the item's record, and where the
-// other terms start for it — the binary search of a term's block directory for the first
-// block reaching the lead item's first doc, SkipReader::Seek (skip_list.hpp:208-249), done
-// once per (lead item, term) by ONE THREAD (inside k_conj a wavefront would walk the same
-// dependent chain 64 lanes wide).  seek[(item_base + item) * (jt - 1) + i - 1].
-__global__ void __launch_bounds__(kThreads)
-k_conj_seek(const DevSegment* segs, const DevQuery* queries, const DevTail* tails, uint32_t jt,
-            const uint32_t* conj_units, const uint32_t* item_base /*[n_conj + 1]*/,
-            uint32_t n_conj, uint32_t* seek, ConjItem* recs) {
-  const uint32_t t = blockIdx.x * kThreads + threadIdx.x;
-  if (t >= item_base[n_conj]) return;
-  uint32_t lo = 0, hi = n_conj;   // the unit whose items hold t: last c with item_base[c] <= t
-  while (hi - lo > 1) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (item_base[mid] <= t) lo = mid; else hi = mid;
-  }
-  const uint32_t unit = conj_units[lo], item = t - item_base[lo];
-  const DevQuery qd = queries[unit];
-  const DevSegment& seg = segs[qd.seg];
-  const DevTail* tl = tails + uint64_t(unit) * jt;
-  const DevTail ld = tl[0];
-  ConjItem r{};
-  r.unit = unit;
-  r.item = item;
-  if (item < ld.nblk) {
-    const uint64_t e = ld.dir_off + item;
-    r.base = item ? seg.blk_last[e - 1] : kDocMin;
-    r.r_lo = item ? r.base + 1u : kDocMin;
-    r.r_hi = seg.blk_last[e];
-    r.aoff = seg.blk_aoff[e];
-    r.bits = seg.blk_bits[e];
-    r.off = seg.blk_off[e];
-  } else {
-    r.r_lo = ld.first_doc;
-    r.r_hi = ld.last_doc;
-  }
-  recs[t] = r;
-  for (uint32_t i = 1; i < qd.n_terms; ++i) {
-    const uint32_t* last = seg.blk_last + tl[i].dir_off;
-    uint32_t a = 0, b = tl[i].nblk;  // lower_bound(last, r_lo)
-    while (a < b) {
-      const uint32_t mid = (a + b) >> 1;
-      if (last[mid] < r.r_lo) a = mid + 1; else b = mid;
-    }
-    seek[uint64_t(t) * (jt - 1u) + (i - 1u)] = a;
-  }
-}
-
-struct ConjArgs {
-  const DevSegment* segs;
-  const DevQuery* queries;
-  const DevQTerm* qterms;
-  const PhraseWg* wgs;          // pilot pass: {unit, lead item} per wavefront (the sampled items)
-  uint32_t n_pilot;             // entries of the pilot list
-  uint32_t n_items;             // full pass: lead items of all conjunctions (= records)
-  const DevTail* tails;         // [unit][jt] (k_plan)
-  const uint32_t* bstar;        // threshold bin per unit (0 = none)
-  const uint32_t* seek;         // k_conj_seek
-  const ConjItem* recs;         // k_conj_seek
-  const uint32_t* unit_items;   // [nq] first record of the unit's lead items (conj units)
-  uint64_t* cands;
-  uint32_t* cand_count;
-  unsigned long long* hits;
-  unsigned long long* touched;  // [unit][2]: `.doc` + norm bytes actually decoded / read (full
-                                // pass; per unit: one hot address would serialise the atomics);
-                                // null unless the batch counts (irs_hip_batch_profile bit 1)
-  uint32_t* hist;               // [unit][kBins], pilot pass only
-  uint32_t jt;
-  uint32_t cand_cap;
-  uint32_t pilot_stride;        // pilot pass: lead items {phase, phase + P, ...}
-  uint32_t wand;                // prune lead blocks by block-max bounds
-};
 
 // LDS of one wavefront.  The lead block's docs are mirrored in a bitmap over its doc range
 // [dlo, dhi], one bit per 2^s docs (s = 0 whenever the range is below 32 * kConjWords docs —

@@ -127,6 +127,7 @@ struct irs_hip_batch {
   uint32_t n_conj_wgs = 0;
   DevBuf d_tile_units, d_conj_units, d_conj_items, d_conj_hist;
   DevBuf d_conj_item_base, d_conj_unit_items, d_conj_seek, d_conj_recs;   // k_conj_seek
+  DevBuf d_lead_of;   // by_phrase: slot of every unit's lead term
   uint32_t conj_total_items = 0;
   DevBuf d_conj_pilot;             // the lead items the pilot pass samples, {unit, item} each
   uint32_t n_conj_pilot = 0, conj_pilot_stride = 0;
@@ -134,7 +135,6 @@ struct irs_hip_batch {
   void* h_pin = nullptr;       // page-locked staging for irs_hip_batch_results
   size_t h_pin_bytes = 0;
   uint32_t n_phrase_wgs = 0;   // k_phrase workgroups: kPhraseWaves lead blocks each
-  DevBuf d_phrase_wgs;
   bool acc32 = true;   // 32-bit fixed-point accumulators are precise enough for every query
   bool scratch_ready = false;
   std::vector<DevQuery> queries;
@@ -424,8 +424,8 @@ bool launch_conj(irs_hip_batch* b, rt::stream_t st) {
   RT_LAUNCH(k_conj_seek, (b->conj_total_items + kThreads - 1) / kThreads, kThreads, 0, st,
             b->d_segs.as<DevSegment>(), b->d_queries.as<DevQuery>(), b->d_tails.as<DevTail>(),
             b->jt, b->d_conj_units.as<uint32_t>(), b->d_conj_item_base.as<uint32_t>(),
-            uint32_t(b->conj_units.size()), b->d_conj_seek.as<uint32_t>(),
-            b->d_conj_recs.as<ConjItem>());
+            uint32_t(b->conj_units.size()), static_cast<const uint32_t*>(nullptr),
+            b->d_conj_seek.as<uint32_t>(), b->d_conj_recs.as<ConjItem>());
   if (b->n_conj_pilot) {
     ConjArgs p = a;
     p.wgs = b->d_conj_pilot.as<PhraseWg>();
@@ -483,32 +483,52 @@ bool ensure_pilot_list(irs_hip_batch* b, uint32_t stride, rt::stream_t st) {
   return true;
 }
 
-// by_phrase: pilot pass over every P-th lead block -> threshold bins -> full pass.
+// by_phrase: lead-item records + start blocks -> pilot pass over every P-th lead block ->
+// threshold bins -> full pass.
 template<int LAYOUT, int MT>
 bool launch_phrase(irs_hip_batch* b, rt::stream_t st) {
   if (b->n_phrase_wgs == 0) return true;  // no query has all its terms in its segment
   const uint32_t stride = b->stride_eff;
   if (!ensure_pilot_list(b, stride, st) || !rt::dmemset(b->d_conj_hist.p, 0, b->d_conj_hist.n, st))
     return false;
-  unsigned long long* touched = b->count_touched ? b->d_touched.as<unsigned long long>() : nullptr;
+  ConjArgs a{};
+  a.segs = b->d_segs.as<DevSegment>();
+  a.queries = b->d_queries.as<DevQuery>();
+  a.qterms = b->d_qterms.as<DevQTerm>();
+  a.wgs = nullptr;
+  a.n_items = b->conj_total_items;
+  a.tails = b->d_tails.as<DevTail>();
+  a.bstar = b->d_bstar.as<uint32_t>();
+  a.cands = b->d_cands.as<uint64_t>();
+  a.cand_count = b->d_cand_count.as<uint32_t>();
+  a.hits = b->d_hits.as<unsigned long long>();
+  a.hist = b->d_conj_hist.as<uint32_t>();
+  a.touched = b->count_touched ? b->d_touched.as<unsigned long long>() : nullptr;
+  a.seek = b->d_conj_seek.as<uint32_t>();
+  a.recs = b->d_conj_recs.as<ConjItem>();
+  a.unit_items = b->d_conj_unit_items.as<uint32_t>();
+  a.lead_of = b->d_lead_of.as<uint32_t>();
+  a.jt = b->jt;
+  a.cand_cap = b->cand_cap;
+  a.pilot_stride = stride;
+  RT_LAUNCH(k_conj_seek, (b->conj_total_items + kThreads - 1) / kThreads, kThreads, 0, st,
+            b->d_segs.as<DevSegment>(), b->d_queries.as<DevQuery>(), b->d_tails.as<DevTail>(),
+            b->jt, b->d_conj_units.as<uint32_t>(), b->d_conj_item_base.as<uint32_t>(),
+            uint32_t(b->conj_units.size()), b->d_lead_of.as<uint32_t>(),
+            b->d_conj_seek.as<uint32_t>(), b->d_conj_recs.as<ConjItem>());
   if (b->n_conj_pilot) {
-    RT_LAUNCH((k_phrase<LAYOUT, MT>), b->n_conj_pilot, 64, 0, st, b->d_segs.as<DevSegment>(),
-              b->d_queries.as<DevQuery>(), b->d_qterms.as<DevQTerm>(), b->jt,
-              b->d_conj_pilot.as<PhraseWg>(), b->d_tails.as<DevTail>(), b->d_cands.as<uint64_t>(),
-              b->cand_cap, b->d_cand_count.as<uint32_t>(), b->d_hits.as<unsigned long long>(),
-              static_cast<unsigned long long*>(nullptr), b->d_bstar.as<uint32_t>(),
-              b->d_conj_hist.as<uint32_t>(), 1u);
+    ConjArgs p = a;
+    p.wgs = b->d_conj_pilot.as<PhraseWg>();
+    p.n_pilot = b->n_conj_pilot;
+    p.touched = nullptr;
+    RT_LAUNCH((k_phrase<LAYOUT, MT>), (b->n_conj_pilot + kPhraseWaves - 1) / kPhraseWaves,
+              kPhraseWaves * 64, 0, st, p, 1u);
   }
   RT_LAUNCH(k_conj_threshold, uint32_t(b->conj_units.size()), 64, 0, st,
             b->d_queries.as<DevQuery>(), b->d_conj_units.as<uint32_t>(),
             b->d_conj_items.as<uint32_t>(), b->d_conj_hist.as<uint32_t>(), stride,
             b->estimate ? kPilotMargin : 0u, b->d_bstar.as<uint32_t>());
-  RT_LAUNCH((k_phrase<LAYOUT, MT>), b->n_phrase_wgs, kPhraseWaves * 64, 0, st,
-            b->d_segs.as<DevSegment>(), b->d_queries.as<DevQuery>(), b->d_qterms.as<DevQTerm>(),
-            b->jt, b->d_phrase_wgs.as<PhraseWg>(), b->d_tails.as<DevTail>(),
-            b->d_cands.as<uint64_t>(), b->cand_cap, b->d_cand_count.as<uint32_t>(),
-            b->d_hits.as<unsigned long long>(), touched, b->d_bstar.as<uint32_t>(),
-            b->d_conj_hist.as<uint32_t>(), 0u);
+  RT_LAUNCH((k_phrase<LAYOUT, MT>), b->n_phrase_wgs, kPhraseWaves * 64, 0, st, a, 0u);
   return rt::last_error_ok();
 }
 template<int LAYOUT>
@@ -1266,10 +1286,11 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
     rc = IRS_HIP_ENOMEM;
   }
   if (rc == IRS_HIP_OK && b->phrase) {
-    // k_phrase work list: the lead term of a unit is its rarest one; one wavefront per
-    // 128-posting block of it (+ one for its vint tail / single doc)
+    // k_phrase work: the lead term of a unit is its rarest one; one wavefront per
+    // 128-posting block of it (+ one for its vint tail / single doc); records and start
+    // blocks of the other terms written by k_conj_seek every run
     try {
-      std::vector<PhraseWg> wgs;
+      std::vector<uint32_t> lead_of(nq, 0);
       for (uint32_t u = 0; u < nq; ++u) {
         const DevQuery& dq = b->queries[u];
         if (!dq.n_terms) continue;
@@ -1280,26 +1301,40 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
           if (t.docs_count < best) {
             best = t.docs_count;
             items = t.nblk + ((t.docs_count == 1 || t.tail_n) ? 1u : 0u);
+            lead_of[u] = j;
           }
         }
-        for (uint32_t it = 0; it < items; it += kPhraseWaves) wgs.push_back(PhraseWg{u, it});
         // (the lists of the pilot pass: same bookkeeping as for conjunctions)
         b->conj_units.push_back(u);
         b->conj_items.push_back(items);
       }
-      if (wgs.size() > 0x7FFFFFFFull) {
+      std::vector<uint32_t> item_base(b->conj_units.size() + 1, 0), unit_items(nq, 0);
+      uint64_t total = 0;
+      for (size_t c = 0; c < b->conj_units.size(); ++c) {
+        item_base[c] = uint32_t(total);
+        unit_items[b->conj_units[c]] = uint32_t(total);
+        total += b->conj_items[c];
+      }
+      item_base[b->conj_units.size()] = uint32_t(total);
+      if (total > 0x7FFFFFFFull) {
         rc = IRS_HIP_EUNSUPPORTED;
-      } else if (!wgs.empty()) {
-        b->n_phrase_wgs = uint32_t(wgs.size());
-        if (!b->d_phrase_wgs.alloc(wgs.size() * sizeof(PhraseWg)) ||
-            !b->d_conj_units.alloc(b->conj_units.size() * 4) ||
+      } else if (total) {
+        b->conj_total_items = uint32_t(total);
+        b->n_phrase_wgs = uint32_t((total + kPhraseWaves - 1) / kPhraseWaves);
+        if (!b->d_conj_units.alloc(b->conj_units.size() * 4) ||
             !b->d_conj_items.alloc(b->conj_items.size() * 4) ||
+            !b->d_conj_item_base.alloc(item_base.size() * 4) ||
+            !b->d_conj_unit_items.alloc(unit_items.size() * 4) ||
+            !b->d_lead_of.alloc(lead_of.size() * 4) ||
+            !b->d_conj_seek.alloc((total + 2) * uint64_t(kMaxTerms) * 4) ||
+            !b->d_conj_recs.alloc((total + 1) * sizeof(ConjItem)) ||
             !b->d_conj_hist.alloc(uint64_t(nq) * kBins * 4))
           rc = IRS_HIP_ENOMEM;
         else if (!rt::h2d(b->d_conj_units.p, b->conj_units.data(), b->conj_units.size() * 4, nullptr) ||
-                 !rt::h2d(b->d_conj_items.p, b->conj_items.data(), b->conj_items.size() * 4, nullptr))
-          rc = IRS_HIP_EHIP;
-        else if (!rt::h2d(b->d_phrase_wgs.p, wgs.data(), wgs.size() * sizeof(PhraseWg), nullptr) ||
+                 !rt::h2d(b->d_conj_items.p, b->conj_items.data(), b->conj_items.size() * 4, nullptr) ||
+                 !rt::h2d(b->d_conj_item_base.p, item_base.data(), item_base.size() * 4, nullptr) ||
+                 !rt::h2d(b->d_conj_unit_items.p, unit_items.data(), unit_items.size() * 4, nullptr) ||
+                 !rt::h2d(b->d_lead_of.p, lead_of.data(), lead_of.size() * 4, nullptr) ||
                  !rt::sync(nullptr))
           rc = IRS_HIP_EHIP;
       }

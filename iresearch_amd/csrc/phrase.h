@@ -282,11 +282,12 @@ k_decode_positions(DevSegment seg, uint32_t term, uint32_t* out) {
 // ------------------------------------------------------------ query time --
 
 constexpr uint32_t kPhraseWaves = 4;  // wavefronts (= lead blocks) per workgroup
+constexpr uint32_t kConjWords = 128;  // 32-bit words of a wavefront's doc-range bitmaps
 
-// One workgroup of k_phrase: kPhraseWaves consecutive lead blocks of one unit.
+// One entry of a pilot list: a sampled lead item of a unit.
 struct PhraseWg {
   uint32_t unit;        // (segment, query) execution unit
-  uint32_t first_item;  // index of the workgroup's first lead block
+  uint32_t first_item;  // index of the lead item
 };
 
 // #{i < n : sorted[i] <= x}, knowing that it lies in [a, b]
@@ -299,183 +300,356 @@ __device__ __forceinline__ uint32_t count_le(const uint32_t* sorted, uint32_t a,
   return a;
 }
 
+// ---- block-driven execution (irs::And in conj.h, by_phrase below): shared pieces
+
+// One lead item (a 128-posting block of the conjunction's rarest term, or its decoded vint
+// tail), everything its wavefront needs to start decoding — written by the pre-pass so that
+// the wavefront's first load is this record (one scalar load) instead of a chain of dependent
+// ones (unit -> query -> term record -> directory words).
+struct alignas(32) ConjItem {
+  uint32_t unit;
+  uint32_t item;    // block index in the lead's list; == its nblk: the vint tail
+  uint32_t base;    // doc the block's first delta is relative to (formats_10.cpp:636)
+  uint32_t r_lo;    // the item's docs lie in [r_lo, r_hi] (from the directory)
+  uint32_t r_hi;
+  uint32_t aoff;    // block in the packed-payload image, 16-byte units
+  uint32_t bits;    // header bytes: dbits | fbits << 8
+  uint32_t off;     // block in `.doc`, relative to the term's doc_start
+};
+static_assert(sizeof(ConjItem) == 32, "one s_load_dwordx8 per lead item");
+
+// Pre-pass, one thread per lead item of every conjunction: the item's record, and where the
+// other terms start for it — the binary search of a term's block directory for the first
+// block reaching the lead item's first doc, SkipReader::Seek (skip_list.hpp:208-249), done
+// once per (lead item, term) by ONE THREAD (inside k_conj a wavefront would walk the same
+// dependent chain 64 lanes wide).  seek[(item_base + item) * (jt - 1) + slot of term i among the non-lead terms].
+__global__ void __launch_bounds__(kThreads)
+k_conj_seek(const DevSegment* segs, const DevQuery* queries, const DevTail* tails, uint32_t jt,
+            const uint32_t* conj_units, const uint32_t* item_base /*[n_conj + 1]*/,
+            uint32_t n_conj, const uint32_t* lead_of /*[unit] slot of the lead term; null: 0*/,
+            uint32_t* seek, ConjItem* recs) {
+  const uint32_t t = blockIdx.x * kThreads + threadIdx.x;
+  if (t >= item_base[n_conj]) return;
+  uint32_t lo = 0, hi = n_conj;   // the unit whose items hold t: last c with item_base[c] <= t
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (item_base[mid] <= t) lo = mid; else hi = mid;
+  }
+  const uint32_t unit = conj_units[lo], item = t - item_base[lo];
+  const DevQuery qd = queries[unit];
+  const DevSegment& seg = segs[qd.seg];
+  const DevTail* tl = tails + uint64_t(unit) * jt;
+  const uint32_t lead = lead_of ? lead_of[unit] : 0u;
+  const DevTail ld = tl[lead];
+  ConjItem r{};
+  r.unit = unit;
+  r.item = item;
+  if (item < ld.nblk) {
+    const uint64_t e = ld.dir_off + item;
+    r.base = item ? seg.blk_last[e - 1] : kDocMin;
+    r.r_lo = item ? r.base + 1u : kDocMin;
+    r.r_hi = seg.blk_last[e];
+    r.aoff = seg.blk_aoff[e];
+    r.bits = seg.blk_bits[e];
+    r.off = seg.blk_off[e];
+  } else {
+    r.r_lo = ld.first_doc;
+    r.r_hi = ld.last_doc;
+  }
+  recs[t] = r;
+  for (uint32_t i = 0; i < qd.n_terms; ++i) {   // row: the other terms in slot order
+    if (i == lead) continue;
+    const uint32_t* last = seg.blk_last + tl[i].dir_off;
+    uint32_t a = 0, b = tl[i].nblk;  // lower_bound(last, r_lo)
+    while (a < b) {
+      const uint32_t mid = (a + b) >> 1;
+      if (last[mid] < r.r_lo) a = mid + 1; else b = mid;
+    }
+    seek[uint64_t(t) * (jt - 1u) + (i < lead ? i : i - 1u)] = a;
+  }
+}
+
+struct ConjArgs {
+  const DevSegment* segs;
+  const DevQuery* queries;
+  const DevQTerm* qterms;
+  const PhraseWg* wgs;          // pilot pass: {unit, lead item} per wavefront (the sampled items)
+  uint32_t n_pilot;             // entries of the pilot list
+  uint32_t n_items;             // full pass: lead items of all conjunctions (= records)
+  const DevTail* tails;         // [unit][jt] (k_plan)
+  const uint32_t* bstar;        // threshold bin per unit (0 = none)
+  const uint32_t* seek;         // k_conj_seek
+  const ConjItem* recs;         // k_conj_seek
+  const uint32_t* unit_items;   // [nq] first record of the unit's lead items (conj units)
+  const uint32_t* lead_of;      // [nq] by_phrase: slot of the unit's lead (rarest) term
+  uint64_t* cands;
+  uint32_t* cand_count;
+  unsigned long long* hits;
+  unsigned long long* touched;  // [unit][2]: `.doc` + norm bytes actually decoded / read (full
+                                // pass; per unit: one hot address would serialise the atomics);
+                                // null unless the batch counts (irs_hip_batch_profile bit 1)
+  uint32_t* hist;               // [unit][kBins], pilot pass only
+  uint32_t jt;
+  uint32_t cand_cap;
+  uint32_t pilot_stride;        // pilot pass: lead items {phase, phase + P, ...}
+  uint32_t wand;                // prune lead blocks by block-max bounds
+};
+
+
 // by_phrase, block driven.  The conjunction PhraseIterator::next runs first
 // (phrase_iterator.hpp:590-596) is bounded by its rarest member — the reason Conjunction
 // sorts its iterators by cost (conjunction.hpp:450-453) and lets the cheapest LEAD while
 // the others seek().  Here ONE WAVEFRONT owns one 128-posting block (or the vint tail)
-// of the lead term:
-//   1. it decodes the lead block: 128 ascending docs into LDS, (P, tf) of each into the
-//      lead's row;
-//   2. for every other term it finds the blocks that can hold one of those docs — what
-//      seek() does through the skip list (skip_list.hpp:208-249): binary search of the
-//      block directory for the first block reaching the lead block's first doc, then 64
-//      directory entries per step, a lane each, tested against the lead docs ("is any of
-//      them in (previous last, last]"); only the blocks that pass are decoded, and each
-//      decoded posting looks its doc up among the 128 lead docs (binary search in LDS):
-//      a hit leaves (P, tf) in the term's row;
-//   3. lead docs that every term reached are the conjunction's matches: one lane each
+// of the lead term (its record and the other terms' start blocks come from k_conj_seek):
+//   1. it decodes the lead block: 128 ascending docs into LDS and into a bitmap over the
+//      block's doc range (conj.h: ConjWave), (P, tf) of each into the lead's row;
+//   2. for every other term it finds the blocks that can hold one of the docs every term
+//      so far reached — what seek() does through the skip list (skip_list.hpp:208-249): 64
+//      directory entries per step, a lane each, tested against the alive bitmap ("is any of
+//      them in (previous last, last]": two prefix-count reads); only the blocks that pass are
+//      decoded, and each decoded posting tests its doc's bit: a hit leaves (P, tf) in the
+//      term's row at the doc's rank and marks the doc alive for the next term;
+//   3. docs that every term reached are the conjunction's matches: compacted, one lane each
 //      merges the terms' position lists (FixedPhraseFrequency::NextPosition,
 //      phrase_iterator.hpp:109-151): phrase frequency = #{p in first term : p + off_i in
 //      term i for all i};
-//   4. matches are scored with tf = phrase frequency and appended to the unit's
-//      candidates (all of them: k_select picks the top k).
-// No barrier after the prologue: wavefronts are independent.  MT = compile-time bound of
-// the phrase length (cursor state stays in registers).
+//   4. matches are scored with tf = phrase frequency; those at or above the unit's threshold
+//      bin (pilot pass: histogrammed instead) are appended to its candidates, one reservation
+//      per wavefront.
+// Wavefronts are independent (no workgroup barrier).  MT = compile-time bound of the phrase
+// length (cursor state stays in registers).
+template<int MT>
+struct PhraseWave {
+  uint32_t docs[kBlock];
+  uint32_t pidx[MT][kBlock];          // first position number of the doc in term i's list
+  uint32_t tf[MT][kBlock];            // its frequency there (0: the term has not reached the doc)
+  uint32_t bm[3][kConjWords + 4];     // bitmaps over [dlo, dhi]: lead docs, alive / marked
+  uint8_t lpre[kConjWords + 4];       // lead-bitmap bits in the words before word w
+  uint8_t apre[kConjWords + 4];       // the same for the alive bitmap of the current term
+  DevPosTerm pt[MT];                  // the merge stage's per-term records
+  uint32_t term[MT];
+  uint32_t off[MT];
+};
+
 template<int LAYOUT, int MT>
 __global__ void __launch_bounds__(kPhraseWaves * 64)
-k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms, uint32_t jt,
-         const PhraseWg* wgs, const DevTail* tails, uint64_t* cands, uint32_t cand_cap,
-         uint32_t* cand_count, unsigned long long* hits,
-         unsigned long long* touched /*[unit][2]: `.doc` bytes decoded, positions read*/,
-         const uint32_t* bstar /*threshold bin per unit*/, uint32_t* hist /*[unit][kBins]*/,
-         uint32_t pilot /*1: histogram the scores of the sampled lead items (launched one
-                          wavefront per workgroup over the pilot list), no candidates*/) {
-  __shared__ DevPosTerm s_pt[MT];
-  __shared__ DevTail s_tl[MT];
-  __shared__ uint32_t s_off[MT];
-  __shared__ uint32_t s_docs[kPhraseWaves][kBlock];
-  __shared__ uint32_t s_pidx[kPhraseWaves][MT][kBlock];
-  __shared__ uint32_t s_tf[kPhraseWaves][MT][kBlock];
+k_phrase(ConjArgs A, uint32_t pilot /*1: histogram the scores of the sampled lead items, no
+                                       candidates*/) {
+  __shared__ PhraseWave<MT> s_wave[kPhraseWaves];
   const uint32_t tid = threadIdx.x;
   const unsigned lane = tid & 63u;
-  const uint32_t wv = tid >> 6;
-  const PhraseWg wg = wgs[blockIdx.x];
-  const uint32_t unit = wg.unit;
-  const DevQuery qd = queries[unit];
+  const uint32_t wv = wave::uniform(tid >> 6);
+  uint32_t e = blockIdx.x * kPhraseWaves + wv;
+  if (pilot) {
+    if (e >= A.n_pilot) return;
+    const PhraseWg w = A.wgs[e];
+    e = wave::uniform(A.unit_items[w.unit] + w.first_item);
+  } else if (e >= A.n_items) {
+    return;
+  }
+  const ConjItem R = wave::sload<ConjItem>(reinterpret_cast<uint64_t>(A.recs) + uint64_t(e) * sizeof(ConjItem));
+  const uint32_t unit = R.unit, item = R.item;
+  const DevQuery qd = wave::sload<DevQuery>(reinterpret_cast<uint64_t>(A.queries) + uint64_t(unit) * sizeof(DevQuery));
   const uint32_t m = qd.n_terms;
-  const DevSegment seg = segs[qd.seg];
-  if (tid < m && tid < uint32_t(MT)) {
-    s_tl[tid] = tails[uint64_t(unit) * jt + tid];
-    s_pt[tid] = seg.pterms[s_tl[tid].term];
-    s_off[tid] = qterms[qd.first_term + tid].pad0;  // desired offset in the phrase
-  }
-  const DevQTerm qt = qterms[qd.first_term];  // the phrase's scorer rides on its first term
-  const uint32_t bs = pilot ? 0u : bstar[unit];
-  __syncthreads();
   if (m == 0 || m > uint32_t(MT)) return;
-  uint32_t lead = 0, lead_n = 0xFFFFFFFFu;  // the term with the fewest postings leads
-  for (uint32_t i = 0; i < m; ++i) {
-    const uint32_t n = s_tl[i].nblk * kBlock + s_tl[i].n;
-    if (n < lead_n) { lead_n = n; lead = i; }
+  const DevSegment& seg = A.segs[qd.seg];   // (read field by field)
+  const uint64_t tl_at = reinterpret_cast<uint64_t>(A.tails) + uint64_t(unit) * A.jt * sizeof(DevTail);
+  auto term_tail = [&](uint32_t i) { return wave::sload<DevTail>(tl_at + i * sizeof(DevTail)); };
+  const uint32_t lead = A.lead_of[unit];   // the term with the fewest postings leads
+  const DevTail ld = term_tail(lead);
+  const DevQTerm qt = A.qterms[qd.first_term];  // the phrase's scorer rides on its first term
+  const uint32_t bs = pilot ? 0u : A.bstar[unit];
+  PhraseWave<MT>& W = s_wave[wv];
+  uint32_t* docs = W.docs;
+  const uint32_t* seek = A.seek + uint64_t(e) * (A.jt - 1u);
+  if (lane < m) {   // what the position merges read, a lane per term
+    const DevTail t = A.tails[uint64_t(unit) * A.jt + lane];
+    W.pt[lane] = seg.pterms[t.term];
+    W.term[lane] = t.term;
+    W.off[lane] = A.qterms[qd.first_term + lane].pad0;  // desired offset in the phrase
   }
-  const DevTail ld = s_tl[lead];
-  const uint32_t item = wg.first_item + wv;
-  if (item >= ld.nblk + (ld.n ? 1u : 0u)) return;  // whole wavefront
-  uint32_t* docs = s_docs[wv];
 
   // ---- 1. the lead block: entry index 2*lane + h (block) or lane + 64*h (tail)
-  uint32_t n = kBlock, e0, estep;
+  uint32_t n = kBlock;
   uint32_t bytes = 0;   // (wave-uniform) encoded bytes of the doc blocks this wavefront decodes
   auto block_bytes = [](uint32_t bits) {
     const uint32_t db = bits & 0xFFu, fb = bits >> 8;
     return 2u + (db ? 16u * db : 1u) + (fb ? 16u * fb : 1u);
   };
+  uint32_t ld_d[2], ld_e[2];
   {
-    uint32_t d[2], f[2], p[2];
+    uint32_t f[2], p[2], estep;
     if (item < ld.nblk) {
-      const uint64_t e = ld.dir_off + item;
-      const uint32_t bits = seg.blk_bits[e];
-      bytes += block_bytes(bits);
-      const uint32_t base = item ? seg.blk_last[e - 1] : kDocMin;
+      const uint64_t eb = ld.dir_off + item;
+      bytes += block_bytes(R.bits);
       uint32_t before;
-      if (pk_both(bits & 0xFFu, bits >> 8)) {
-        decode_packed_pos<LAYOUT>(seg.pk + (uint64_t(seg.blk_aoff[e]) << 4), bits & 0xFFu,
-                                  bits >> 8, base, lane, d[0], d[1], f[0], f[1], before);
+      if (pk_both(R.bits & 0xFFu, R.bits >> 8)) {
+        decode_packed_pos<LAYOUT>(seg.pk + (uint64_t(R.aoff) << 4), R.bits & 0xFFu, R.bits >> 8,
+                                  R.base, lane, ld_d[0], ld_d[1], f[0], f[1], before);
       } else {
-        decode_block_pos<LAYOUT>(seg.doc + ld.doc_start + seg.blk_off[e], bits & 0xFFu, bits >> 8,
-                                 base, lane, d[0], d[1], f[0], f[1], before);
+        decode_block_pos<LAYOUT>(seg.doc + ld.doc_start + R.off, R.bits & 0xFFu, R.bits >> 8,
+                                 R.base, lane, ld_d[0], ld_d[1], f[0], f[1], before);
       }
-      p[0] = seg.blk_pos[e] - seg.blk_pos[ld.dir_off] + before;
+      p[0] = seg.blk_pos[eb] - seg.blk_pos[ld.dir_off] + before;
       p[1] = p[0] + f[0];
-      e0 = 2u * lane;
+      ld_e[0] = 2u * lane;
       estep = 1u;
     } else {
       n = ld.n;
       // positions in front of the tail = all frequencies of the full blocks (0 for a
       // list without blocks, whose dir_off has no rows of its own)
       const uint32_t base = seg.blk_pos[ld.dir_off + ld.nblk] - seg.blk_pos[ld.dir_off];
-      tail_pidx(seg, ld.tail_row, n, base, lane, d, f, p);
-      e0 = lane;
+      tail_pidx(seg, ld.tail_row, n, base, lane, ld_d, f, p);
+      ld_e[0] = lane;
       estep = 64u;
     }
+    ld_e[1] = ld_e[0] + estep;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const uint32_t idx = e0 + uint32_t(h) * estep;
-      docs[idx] = idx < n ? d[h] : 0xFFFFFFFFu;
+      const uint32_t idx = ld_e[h];
+      docs[idx] = idx < n ? ld_d[h] : 0xFFFFFFFFu;
       for (uint32_t i = 0; i < m; ++i) {
-        s_pidx[wv][i][idx] = i == lead ? p[h] : 0u;
-        s_tf[wv][i][idx] = (i == lead && idx < n) ? f[h] : 0u;
+        W.pidx[i][idx] = i == lead ? p[h] : 0u;
+        W.tf[i][idx] = (i == lead && idx < n) ? f[h] : 0u;
+      }
+    }
+    if (lane < (kConjWords + 4u) / 2u) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        W.bm[k][2u * lane] = 0u;
+        W.bm[k][2u * lane + 1u] = 0u;
       }
     }
   }
   wave::sync();
-  const uint32_t dlo = docs[0], dhi = docs[n - 1];
-
-  // a decoded posting of term i: is its doc one of the lead docs?
-  // (w0, w1] = ranks of the lead docs that can equal it: those inside its block's doc range
-  auto put = [&](uint32_t i, uint32_t doc, uint32_t f, uint32_t p, uint32_t w0, uint32_t w1) {
-    if (f == 0 || doc < dlo || doc > dhi) return;
-    const uint32_t c = count_le(docs, w0, w1, doc);
-    if (c > w0 && docs[c - 1] == doc) {
-      s_pidx[wv][i][c - 1] = p;
-      s_tf[wv][i][c - 1] = f;
+  const uint32_t dlo = wave::uniform(docs[0]), dhi = wave::uniform(docs[n - 1]);
+  // bucket of a doc: (doc - dlo) >> s, below 32 * kConjWords (s = 0: one doc per bit)
+  const uint32_t span = dhi - dlo;
+  const uint32_t s = span < 32u * kConjWords ? 0u
+                     : 32u - uint32_t(__builtin_clz(span)) - (5u + uint32_t(__builtin_ctz(kConjWords)));
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (ld_e[h] < n) {
+      const uint32_t bk = (ld_d[h] - dlo) >> s;
+      atomicOr(&W.bm[0][bk >> 5], 1u << (bk & 31u));
     }
+  }
+  wave::sync();
+  // bits in the words before word w (lane: words 2*lane, 2*lane+1; [kConjWords] = all)
+  auto prefix = [&](const uint32_t* bmap, uint8_t* pre) {
+    uint32_t p0 = 0, p1 = 0;
+    if (lane < kConjWords / 2u) {
+      p0 = uint32_t(__builtin_popcount(bmap[2u * lane]));
+      p1 = uint32_t(__builtin_popcount(bmap[2u * lane + 1u]));
+    }
+    const uint32_t incl = wave::inclusive_scan(p0 + p1);
+    if (lane < kConjWords / 2u) {
+      pre[2u * lane] = uint8_t(incl - p0 - p1);
+      pre[2u * lane + 1u] = uint8_t(incl - p1);
+    }
+    if (lane == kConjWords / 2u - 1u) pre[kConjWords] = uint8_t(incl);
+    wave::sync();
+    return wave::read_lane(incl, 63);
   };
+  prefix(W.bm[0], W.lpre);
+
   // ---- 2. the other terms
+  uint32_t step = 0;   // terms done so far (the lead aside)
   for (uint32_t i = 0; i < m; ++i) {
     if (i == lead) continue;
-    const DevTail tl = s_tl[i];
+    const DevTail tl = term_tail(i);
+    // alive = docs every term so far reached: the lead bitmap, then what the previous term
+    // marked; `mark` collects what this term reaches
+    const uint32_t mk = 1u + (step & 1u);
+    const uint32_t* alive = step == 0u ? W.bm[0] : W.bm[3u - mk];
+    uint32_t* mark = W.bm[mk];
+    const uint8_t* apre = W.lpre;
+    if (step > 0u) {
+      if (lane < kConjWords / 2u) {
+        mark[2u * lane] = 0u;
+        mark[2u * lane + 1u] = 0u;
+      }
+      apre = W.apre;
+      if (prefix(alive, W.apre) == 0u) {   // no doc reached by every term so far: done
+        if (!pilot && A.touched && lane == 0)
+          atomicAdd(&A.touched[2u * unit], static_cast<unsigned long long>(bytes));
+        return;
+      }
+    }
+    ++step;
+    auto alive_below = [&](uint32_t x) {
+      return uint32_t(apre[x >> 5]) + uint32_t(__builtin_popcount(alive[x >> 5] & ((1u << (x & 31u)) - 1u)));
+    };
+    // a decoded posting of term i: is its doc one of the lead docs still alive?
+    auto put = [&](uint32_t doc, uint32_t f, uint32_t p) {
+      const uint32_t x = doc - dlo;
+      if (f == 0 || x > span) return;
+      const uint32_t bk = x >> s;
+      if (!((alive[bk >> 5] >> (bk & 31u)) & 1u)) return;
+      uint32_t c;   // the doc's entry index + 1
+      if (s == 0) {
+        c = 1u + uint32_t(W.lpre[bk >> 5]) +
+            uint32_t(__builtin_popcount(W.bm[0][bk >> 5] & ((1u << (bk & 31u)) - 1u)));
+      } else {
+        c = count_le(docs, 0u, n, doc);
+        if (c == 0u || docs[c - 1u] != doc) return;
+        // (alive at bucket granularity: every earlier term must have reached THIS doc)
+        for (uint32_t j = 0; j < i; ++j)
+          if (W.tf[j][c - 1u] == 0u) return;
+      }
+      W.pidx[i][c - 1u] = p;
+      W.tf[i][c - 1u] = f;
+      atomicOr(&mark[bk >> 5], 1u << (bk & 31u));
+    };
     if (tl.nblk) {
       const uint32_t* last = seg.blk_last + tl.dir_off;
       const uint32_t pos0 = seg.blk_pos[tl.dir_off];
-      uint32_t a = 0, b = tl.nblk;  // lower_bound(last, dlo): first block reaching dlo
-      while (a < b) {
-        const uint32_t mid = (a + b) >> 1;
-        if (last[mid] < dlo) a = mid + 1; else b = mid;
-      }
-      for (uint32_t b0 = a; b0 < tl.nblk; b0 += 64) {
+      const uint32_t b_first = seek[i < lead ? i : i - 1u];
+      uint32_t carry = b_first ? last[b_first - 1u] : 0u;   // last doc of the block before
+      for (uint32_t b0 = b_first; b0 < tl.nblk; b0 += 64) {
         const uint32_t bl = b0 + lane;
         const bool valid = bl < tl.nblk;
         const uint32_t lst = valid ? last[bl] : 0xFFFFFFFFu;
-        const uint32_t prv = (valid && bl) ? last[bl - 1] : 0u;  // block holds docs in (prv, lst]
-        const bool reach = valid && prv < dhi;
-        const uint32_t cp_l = reach ? count_le(docs, 0u, n, prv) : 0u;
-        const uint32_t cl_l = reach ? count_le(docs, cp_l, n, lst) : 0u;
-        const bool want = cl_l > cp_l;   // some lead doc lies in (prv, lst]
-        // the directory words of the wanted blocks, one lane each (coalesced), handed to
-        // the whole wavefront by readlane when the block's turn comes
-        const uint64_t e_l = tl.dir_off + bl;
-        uint32_t bits_l = 0, off_l = 0, pos_l = 0, aoff_l = 0;
-        if (want) {
-          bits_l = seg.blk_bits[e_l];
-          off_l = seg.blk_off[e_l];
-          pos_l = seg.blk_pos[e_l];
-          aoff_l = seg.blk_aoff[e_l];
+        uint32_t prv = uint32_t(__shfl_up(lst, 1, 64));   // the block holds docs in (prv, lst]
+        if (lane == 0) prv = carry;
+        carry = wave::read_lane(lst, 63);
+        const bool reach = valid && prv < dhi && lst >= dlo;
+        bool want = false;
+        if (reach) {
+          const uint32_t x0 = prv + 1u > dlo ? prv + 1u - dlo : 0u;
+          const uint32_t x1 = (lst < dhi ? lst : dhi) - dlo;
+          want = alive_below((x1 >> s) + 1u) > alive_below(x0 >> s);
         }
-        const uint32_t base_l = bl ? prv : kDocMin;
+        // the directory words of the wanted blocks, one lane each, handed to the whole
+        // wavefront by readlane when the block's turn comes
+        BlkDir d{};
+        uint32_t pos_l = 0;
+        if (want) {
+          d = seg.blk_dir[tl.dir_off + bl];
+          pos_l = seg.blk_pos[tl.dir_off + bl];
+        }
         uint64_t mask = wave::ballot(want);
-        const bool more = wave::ballot(valid && !reach) == 0;  // no block started behind dhi yet
+        const bool more = wave::ballot(valid && prv >= dhi) == 0;  // no block started behind dhi yet
         while (mask) {
           const uint32_t k = uint32_t(__builtin_ctzll(mask));
           mask &= mask - 1;
-          const uint32_t bits = wave::read_lane(bits_l, k);
+          const uint32_t bits = wave::read_lane(d.bits, k);
           bytes += block_bytes(bits);
-          const uint32_t base = wave::read_lane(base_l, k);
+          const uint32_t base = wave::read_lane(d.prev_last, k);
           uint32_t d0, d1, f0, f1, before;
           const uint32_t dbits = bits & 0xFFu, fbits = bits >> 8;
           if (pk_both(dbits, fbits)) {
             // both parts 1..31-bit packed: the 16-byte aligned copy in the packed image,
             // one funnel shift + one bit-field extract per value (as k_score's hot loop)
-            decode_packed_pos<LAYOUT>(seg.pk + (uint64_t(wave::read_lane(aoff_l, k)) << 4), dbits,
+            decode_packed_pos<LAYOUT>(seg.pk + (uint64_t(wave::read_lane(d.aoff, k)) << 4), dbits,
                                       fbits, base, lane, d0, d1, f0, f1, before);
           } else {
-            decode_block_pos<LAYOUT>(seg.doc + tl.doc_start + wave::read_lane(off_l, k), dbits,
+            decode_block_pos<LAYOUT>(seg.doc + tl.doc_start + wave::read_lane(d.off, k), dbits,
                                      fbits, base, lane, d0, d1, f0, f1, before);
           }
           const uint32_t p0 = wave::read_lane(pos_l, k) - pos0 + before;
-          const uint32_t w0 = wave::read_lane(cp_l, k), w1 = wave::read_lane(cl_l, k);
-          put(i, d0, f0, p0, w0, w1);
-          put(i, d1, f1, p0 + f0, w0, w1);
+          put(d0, f0, p0);
+          put(d1, f1, p0 + f0);
         }
         if (!more) break;
       }
@@ -484,74 +658,107 @@ k_phrase(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms
       const uint32_t base = seg.blk_pos[tl.dir_off + tl.nblk] - seg.blk_pos[tl.dir_off];
       uint32_t d[2], f[2], p[2];
       tail_pidx(seg, tl.tail_row, tl.n, base, lane, d, f, p);
-      put(i, d[0], f[0], p[0], 0u, n);
-      put(i, d[1], f[1], p[1], 0u, n);
+      put(d[0], f[0], p[0]);
+      put(d[1], f[1], p[1]);
     }
+    wave::sync();
   }
-  wave::sync();
 
-  // ---- 3./4. lead docs every term reached: merge the position lists, score, emit
+  // ---- 3./4. lead docs every term reached, compacted: merge the position lists, score, emit
+  bool h01[2];
+  uint64_t m01[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t sl = lane + 64u * uint32_t(h);
+    bool all = sl < n;
+    for (uint32_t i = 0; i < m; ++i) all = all && W.tf[i][sl < n ? sl : 0u] != 0u;
+    h01[h] = all;
+    m01[h] = wave::ballot(all);
+  }
+  const uint64_t below = (1ull << lane) - 1ull;
+  const uint32_t c0 = uint32_t(__builtin_popcountll(m01[0]));
+  const uint32_t total = c0 + uint32_t(__builtin_popcountll(m01[1]));
+  uint8_t* list = W.apre;   // (the alive prefix counts have served)
+  if (h01[0]) list[__builtin_popcountll(m01[0] & below)] = uint8_t(lane);
+  if (h01[1]) list[c0 + uint32_t(__builtin_popcountll(m01[1] & below))] = uint8_t(lane + 64u);
+  wave::sync();
   uint32_t my_hits = 0, my_pos = 0;
-  for (uint32_t s = lane; s < n; s += 64) {
-    uint32_t P[MT], T[MT], K[MT], V[MT];
-    bool all = true;
+  // (the fields the position merges read, in registers: through the reference every
+  // pos_delta of the serial merge loops would load them again)
+  DevSegment ps{};
+  ps.pos = seg.pos;
+  ps.pblk_off = seg.pblk_off;
+  ps.pblk_bits = seg.pblk_bits;
+  ps.ptail = seg.ptail;
+  ps.pos_base = seg.pos_base;
+  for (uint32_t q0 = 0; q0 < total; q0 += 64) {
+    bool cand = false;
+    float score = 0.f;
+    uint32_t doc = 0;
+    if (q0 + lane < total) {
+      const uint32_t sl = list[q0 + lane];
+      uint32_t P[MT], T[MT], K[MT], V[MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const bool on = uint32_t(i) < m;
-      P[i] = on ? s_pidx[wv][i][s] : 0u;
-      T[i] = on ? s_tf[wv][i][s] : 0u;
-      K[i] = 0u;
-      V[i] = seg.pos_base;  // pos_limits::invalid() (+ min() before the first delta, one-based)
-      all = all && (!on || T[i] != 0u);
-    }
-    if (!all) continue;
-    // Walking every position of the first term counts the same matches as the
-    // reference's lead.seek(sought - offset), which only skips positions that cannot match.
-    uint32_t pf = 0, head = seg.pos_base;
-    bool done = false;
-    for (uint32_t a = 0; a < T[0] && !done; ++a) {
-      head += pos_delta<LAYOUT>(seg, s_pt[0], s_tl[0].term, P[0] + a);  // lead.next()
-      ++my_pos;
-      bool match = true;
+      for (int i = 0; i < MT; ++i) {
+        const bool on = uint32_t(i) < m;
+        P[i] = on ? W.pidx[i][sl] : 0u;
+        T[i] = on ? W.tf[i][sl] : 0u;
+        K[i] = 0u;
+        V[i] = ps.pos_base;  // pos_limits::invalid() (+ min() before the first delta, one-based)
+      }
+      // Walking every position of the first term counts the same matches as the
+      // reference's lead.seek(sought - offset), which only skips positions that cannot match.
+      uint32_t pf = 0, head = ps.pos_base;
+      bool done = false;
+      for (uint32_t a = 0; a < T[0] && !done; ++a) {
+        head += pos_delta<LAYOUT>(ps, W.pt[0], W.term[0], P[0] + a);  // lead.next()
+        ++my_pos;
+        bool match = true;
 #pragma unroll
-      for (int i = 1; i < MT; ++i) {
-        if (uint32_t(i) < m && match && !done) {
-          const uint32_t target = head + s_off[i];
-          if (target < head) { done = true; break; }  // !pos_limits::valid(term_position)
-          // position::seek(target) :1578-1604
-          // (value_ is invalid until the first position is read: K[i] == 0)
-          while ((K[i] == 0u || V[i] < target) && K[i] < T[i]) {
-            V[i] += pos_delta<LAYOUT>(seg, s_pt[i], s_tl[i].term, P[i] + K[i]);
-            ++K[i];
-            ++my_pos;
+        for (int i = 1; i < MT; ++i) {
+          if (uint32_t(i) < m && match && !done) {
+            const uint32_t target = head + W.off[i];
+            if (target < head) { done = true; break; }  // !pos_limits::valid(term_position)
+            // position::seek(target) :1578-1604
+            // (value_ is invalid until the first position is read: K[i] == 0)
+            while ((K[i] == 0u || V[i] < target) && K[i] < T[i]) {
+              V[i] += pos_delta<LAYOUT>(ps, W.pt[i], W.term[i], P[i] + K[i]);
+              ++K[i];
+              ++my_pos;
+            }
+            if (V[i] < target) done = true;           // exhausted: no later position can match
+            else if (V[i] != target) match = false;   // sought too far
           }
-          if (V[i] < target) done = true;           // exhausted: no later position can match
-          else if (V[i] != target) match = false;   // sought too far
         }
+        if (match && !done) ++pf;
       }
-      if (match && !done) ++pf;
+      if (pf) {
+        doc = docs[sl];
+        score = score_value(qt, pf, norm_value(seg, doc));
+        const uint32_t bin = score_bin(score, qd.bin_scale);
+        if (pilot) atomicAdd(&A.hist[uint64_t(unit) * kBins + bin], 1u);
+        else cand = bin >= bs;   // below the pilot's threshold bin: cannot be among the top k
+        ++my_hits;
+      }
     }
-    if (pf) {
-      const uint32_t doc = docs[s];
-      const float score = score_value(qt, pf, norm_value(seg, doc));
-      const uint32_t bin = score_bin(score, qd.bin_scale);
-      if (pilot) {
-        atomicAdd(&hist[uint64_t(unit) * kBins + bin], 1u);
-      } else if (bin >= bs) {   // below the pilot's threshold bin: cannot be among the top k
-        const uint32_t slot = atomicAdd(&cand_count[unit], 1u);
-        if (slot < cand_cap) cands[uint64_t(unit) * cand_cap + slot] = make_key(score, doc);
-      }
-      ++my_hits;
+    // one reservation per wavefront for all its candidates of this pass
+    const uint64_t cm = wave::ballot(cand);
+    if (cm) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&A.cand_count[unit], uint32_t(__builtin_popcountll(cm)));
+      base = wave::read_lane(base, 0);
+      const uint32_t slot = base + uint32_t(__builtin_popcountll(cm & below));
+      if (cand && slot < A.cand_cap) A.cands[uint64_t(unit) * A.cand_cap + slot] = make_key(score, doc);
     }
   }
   if (pilot) return;
   my_hits = wave::reduce_add(my_hits);
-  if (lane == 0 && my_hits) atomicAdd(&hits[unit], static_cast<unsigned long long>(my_hits));
-  if (touched) {   // (only when the batch counts: irs_hip_batch_profile bit 1)
+  if (lane == 0 && my_hits) atomicAdd(&A.hits[unit], static_cast<unsigned long long>(my_hits));
+  if (A.touched) {   // (only when the batch counts: irs_hip_batch_profile bit 1)
     my_pos = wave::reduce_add(my_pos);
     if (lane == 0) {
-      atomicAdd(&touched[2u * unit], static_cast<unsigned long long>(bytes));
-      if (my_pos) atomicAdd(&touched[2u * unit + 1u], static_cast<unsigned long long>(my_pos));
+      atomicAdd(&A.touched[2u * unit], static_cast<unsigned long long>(bytes));
+      if (my_pos) atomicAdd(&A.touched[2u * unit + 1u], static_cast<unsigned long long>(my_pos));
     }
   }
 }
