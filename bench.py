@@ -240,29 +240,50 @@ def main():
     slots = [{lead: exchange.slot(ph, my.index(lead)) for lead in batches} for ph in (0, 1)]
     state = {"it": 0}
 
-    def step(host_results=False):
-        # every step ends with a checked, device-resident top-k: results_to_device reads the
-        # batch status (4 bytes) and re-runs the batch if a threshold estimate or the
-        # candidate buffer fell short (irs_hip_batch_reruns counts those).  The all-gather
-        # (RCCL) of step i overlaps the kernels of step i+1; its GPU merge is enqueued behind them.
-        # Steps rotate over the query sets.  host_results: the hits also go to host memory
-        # (irs_hip_batch_results), where the reference's harness ends (index-search.cpp:782-807).
-        ph = state["it"] & 1
-        cur = batch_sets[state["it"] % n_sets]
-        state["it"] += 1
-        state["cur"] = cur
-        for s in cur:
-            cur[s].run(sptr)
+    def deliver(prev):
+        # a finished step: checked (irs_hip_batch_results_to_device waits for THAT batch's own
+        # event and reads its status word from page-locked memory; it re-runs the batch if a
+        # threshold estimate or the candidate buffer fell short — irs_hip_batch_reruns counts
+        # those), its per-segment top-k copied into the exchange slots, the all-gather started.
+        cur, ph, host_results = prev
         if multi:
             exchange.finish(sptr)
         for s in cur:
             if host_results:
                 cur[s].results()
             cur[s].results_to_device(slots[ph][s][0], slots[ph][s][1], sptr)
+        if rank == 0 and state.get("collect") is not None:
+            # per-kernel HIP-event timings of that step (the batch's own events: no stream sync)
+            state["collect"].append(np.sum([cur[s].timings() for s in cur], axis=0))
         if multi:
             exchange.start(ph)
 
+    def step(host_results=False):
+        # Steps rotate over the query sets and are software-pipelined one deep: the kernels of
+        # step i are enqueued FIRST, then step i-1 is verified and delivered — the host waits
+        # on step i-1's event while the GPU already runs step i, so there is no per-step
+        # host/device round trip on the critical path.  Every step still ends (one step later;
+        # flush() for the last) with a checked, device-resident top-k.  host_results: the hits
+        # also go to host memory (irs_hip_batch_results), where the reference's harness ends
+        # (index-search.cpp:782-807) — that variant is not pipelined.
+        ph = state["it"] & 1
+        cur = batch_sets[state["it"] % n_sets]
+        state["it"] += 1
+        state["cur"] = cur
+        prev = state.get("prev")
+        if prev is not None and (prev[0] is cur or host_results or prev[2]):
+            deliver(prev)     # the same batch again (one query set): its results go out first
+            prev = None
+        for s in cur:
+            cur[s].run(sptr)
+        if prev is not None:
+            deliver(prev)
+        state["prev"] = (cur, ph, host_results)
+
     def flush():
+        prev = state.pop("prev", None)
+        if prev is not None:
+            deliver(prev)
         return exchange.finish(sptr) if multi else None
 
     # first execution of every batch (a fresh query set): timed apart, outside the steps —
@@ -290,13 +311,11 @@ def main():
         dist.barrier()
     sync()
     t0 = time.perf_counter()
+    state["collect"] = score_ms
     for _ in range(args.steps):
         step()
-        # per-kernel HIP-event timings of this step on rank 0 (waits for the stream)
-        if rank == 0:
-            cur = state["cur"]
-            score_ms.append(np.sum([cur[s].timings() for s in cur], axis=0))
     flush()
+    state["collect"] = None
     sync()
     if world > 1:
         dist.barrier()

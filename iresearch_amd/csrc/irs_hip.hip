@@ -154,6 +154,11 @@ struct irs_hip_batch {
   bool count_touched = false;   // irs_hip_batch_profile bit 1: the kernels count what they decode
   bool events_ready = false;
   rt::event_t ev[2 * IRS_HIP_K_COUNT];
+  // what verify_run waits for: the batch's OWN last run (not whatever else the caller has
+  // queued on the stream since), and the status word that run left in page-locked memory
+  rt::event_t ev_done{};
+  bool ev_done_ready = false;
+  uint32_t* h_status = nullptr;
   rt::stream_t stream = nullptr;
   bool ran = false;
 };
@@ -1588,6 +1593,13 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st) {
     }
   }
   ok = ok && mark(2 * IRS_HIP_K_SELECT + 1);
+  // the status word follows the kernels into page-locked memory; the event marks this run
+  if (ok && !b->h_status) {
+    b->h_status = static_cast<uint32_t*>(rt::hmalloc(sizeof(uint32_t)));
+    ok = b->h_status != nullptr;
+  }
+  if (ok && !b->ev_done_ready) ok = b->ev_done_ready = rt::event_create(&b->ev_done);
+  ok = ok && rt::d2h(b->h_status, b->d_status.p, 4, st) && rt::event_record(b->ev_done, st);
   b->ran = true;
   return ok ? IRS_HIP_OK : IRS_HIP_EHIP;
 }
@@ -1661,7 +1673,9 @@ static int recover_overflow(irs_hip_batch* b) {
 
 static int batch_timings_impl(irs_hip_batch* b, float ms[IRS_HIP_K_COUNT]) {
   if (!b || !ms || !b->profile || !b->ran) return IRS_HIP_EINVAL;
-  if (!rt::set_device(b->seg->device) || !rt::sync(b->stream)) return IRS_HIP_EHIP;
+  // (the batch's own last run: later work on the stream is not waited for)
+  if (!rt::set_device(b->seg->device) || !b->ev_done_ready || !rt::event_sync(b->ev_done))
+    return IRS_HIP_EHIP;
   for (int i = 0; i < IRS_HIP_K_COUNT; ++i)
     if (!rt::event_elapsed(&ms[i], b->ev[2 * i], b->ev[2 * i + 1])) return IRS_HIP_EHIP;
   return IRS_HIP_OK;
@@ -1721,10 +1735,11 @@ static int batch_results_impl(irs_hip_batch* b, irs_hip_hit* hits, uint32_t k_st
 // Waits for the batch, reads its status word and re-executes it when the candidate
 // buffer or the threshold estimate fell short.  Afterwards d_out / d_out_count hold the
 // exact top-k.
+// Waits for the batch's own last run (its event: work the caller queued behind it on the same
+// stream — the next batch's kernels, say — keeps running) and reads the status it left.
 static int verify_run(irs_hip_batch* b) {
-  uint32_t status = 0;
-  if (!rt::d2h(&status, b->d_status.p, 4, b->stream) || !rt::sync(b->stream))
-    return IRS_HIP_EHIP;
+  if (!b->ev_done_ready || !b->h_status || !rt::event_sync(b->ev_done)) return IRS_HIP_EHIP;
+  const uint32_t status = *b->h_status;
   if (status & (kStatusOverflow | kStatusUnderflow)) {
     const int rc = recover(b, status);
     if (rc != IRS_HIP_OK) return rc;
@@ -1764,6 +1779,8 @@ void irs_hip_batch_destroy(irs_hip_batch* b) {
   if (b->ran) rt::sync(b->stream);
   if (b->events_ready)
     for (auto& e : b->ev) rt::event_destroy(e);
+  if (b->ev_done_ready) rt::event_destroy(b->ev_done);
+  rt::hfree(b->h_status);
   rt::hfree(b->h_pin);
   delete b;
 }
