@@ -114,6 +114,23 @@ __device__ __forceinline__ void keep_all_f(float (&v)[4]) {
   asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
 }
 
+// acc += number of non-zero values among a..d: v_min_u32(1, x) pairs folded by v_add3_u32 in
+// one block (two temporaries) — written out because the optimiser turns min(x, 1) back into
+// compare + add-with-carry, which costs a VCC round trip with wait states per value on gfx950.
+__device__ __forceinline__ void count_nonzero4(uint32_t& acc, uint32_t a, uint32_t b, uint32_t c,
+                                               uint32_t d) {
+  uint32_t t0, t1;
+  asm("v_min_u32 %1, 1, %3\n\tv_min_u32 %2, 1, %4\n\tv_add3_u32 %0, %0, %1, %2\n\t"
+      "v_min_u32 %1, 1, %5\n\tv_min_u32 %2, 1, %6\n\tv_add3_u32 %0, %0, %1, %2"
+      : "+v"(acc), "=&v"(t0), "=&v"(t1)
+      : "v"(a), "v"(b), "v"(c), "v"(d));
+}
+__device__ __forceinline__ void count_nonzero4(uint32_t& acc, unsigned long long a,
+                                               unsigned long long b, unsigned long long c,
+                                               unsigned long long d) {
+  acc += (a != 0) + (b != 0) + (c != 0) + (d != 0);
+}
+
 // A wave-uniform value the optimiser may not reason about (stays in an SGPR).
 __device__ __forceinline__ uint32_t opaque(uint32_t v) {
   asm volatile("" : "+s"(v));

@@ -1267,11 +1267,11 @@ k_score(uint64_t args /*address of a ScoreArgs*/) {
         const bool is_and = AND && (qd.op & 0xFF) == 1;  // op = 1 | required matches << 8
         const uint32_t need = query_need(qd.op);
         const bool min_both = AND && query_min_both(qd.op);
-        // eight accumulators per lane per step: two 4-wide LDS reads in flight, two wide clears
+        // eight accumulators per lane per step: two 4-wide LDS reads in flight, two wide clears.
+        // `two`: the step's second group of four exists (always, when the tile is a whole
+        // number of double steps — the usual geometry: the test then costs nothing).
         const uint32_t step = blockDim.x * 4u;
-        for (uint32_t i = tid * 4u; i < uint32_t(TILE); i += 2u * step) {
-          const bool two = i + step < uint32_t(TILE);  // same for the whole workgroup
-          const uint32_t i2 = two ? i + step : i;
+        auto eight = [&](uint32_t i, uint32_t i2, bool two) {
           ACC a[8];
 #pragma unroll
           for (int e = 0; e < 4; ++e) a[e] = sm.acc[i + e];
@@ -1316,10 +1316,10 @@ k_score(uint64_t args /*address of a ScoreArgs*/) {
           }
           ACC top = a[0];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            my_hits += a[e] != ACC(0) ? 1u : 0u;   // per lane; summed once per chunk
-            top = a[e] > top ? a[e] : top;
-          }
+          for (int e = 0; e < 8; ++e) top = a[e] > top ? a[e] : top;
+          // matching docs, per lane (summed once per chunk)
+          wave::count_nonzero4(my_hits, a[0], a[1], a[2], a[3]);
+          wave::count_nonzero4(my_hits, a[4], a[5], a[6], a[7]);
           if (top >= thr) {  // rare: one copy of the candidate code, per-lane loop
             uint32_t cm = 0;
 #pragma unroll
@@ -1332,6 +1332,14 @@ k_score(uint64_t args /*address of a ScoreArgs*/) {
               for (int f = 1; f < 8; ++f) x = e == uint32_t(f) ? a[f] : x;
               candidate((e < 4u ? i : i2 - 4u) + e, x);
             }
+          }
+        };
+        if (uint32_t(TILE) % (2u * step) == 0u) {   // (wave-uniform)
+          for (uint32_t i = tid * 4u; i < uint32_t(TILE); i += 2u * step) eight(i, i + step, true);
+        } else {
+          for (uint32_t i = tid * 4u; i < uint32_t(TILE); i += 2u * step) {
+            const bool two = i + step < uint32_t(TILE);  // same for the whole workgroup
+            eight(i, two ? i + step : i, two);
           }
         }
       }

@@ -80,6 +80,10 @@ __device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t s)
 }
 __device__ __forceinline__ uint32_t bfe(uint32_t x, uint32_t bits) { return x & ((1u << bits) - 1u); }
 __device__ __forceinline__ uint64_t undef64() { return 0; }
+template<typename T>
+__device__ __forceinline__ void count_nonzero4(uint32_t& acc, T a, T b, T c, T d) {
+  acc += uint32_t(a != 0) + uint32_t(b != 0) + uint32_t(c != 0) + uint32_t(d != 0);
+}
 __device__ __forceinline__ uint32_t opaque(uint32_t v) { return v; }
 __device__ __forceinline__ uint64_t opaque64(uint64_t v) { return v; }
 
