@@ -295,6 +295,16 @@ int irs_hip_batch_configure(irs_hip_batch* batch, uint32_t tile_docs,
  * skip data has no entry) and kept with the segment.  Applies to IRS_HIP_OP_AND queries and
  * to whole doc tiles of OR queries.  Call before the batch's first run. */
 int irs_hip_batch_set_wand(irs_hip_batch* batch, int enable);
+
+/* irs::score::Min (score_function.hpp:42-142): the threshold the harness pushes into the
+ * iterator once its heap is full — the k-th best score so far, carried over from the segments
+ * it executed before (utils/index-search.cpp:737, 756, 777).  min_scores: [n_queries] floats
+ * >= 0 (0 = none), or NULL to clear.  A doc scoring below min_scores[q] is not competitive: the
+ * batch may drop it (pruning then starts from that bound instead of from the pilot pass's
+ * estimate alone), so a query returns the docs at or above its threshold, at most k of them,
+ * in the usual order — possibly fewer than k; total_hits still counts every match.  May be
+ * called between runs. */
+int irs_hip_batch_set_min_scores(irs_hip_batch* batch, const float* min_scores);
 /* The block-max data of one term, for inspection/tests (computed as for set_wand): largest
  * frequency and smallest non-zero norm of every full 128-doc block. */
 int irs_hip_term_blockmax(irs_hip_segment* seg, uint32_t term, uint32_t* max_freqs,

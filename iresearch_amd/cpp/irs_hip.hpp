@@ -343,6 +343,18 @@ class QueryBatch {
       if (part.h) check(irs_hip_batch_set_wand(part.h, enable ? 1 : 0), "irs_hip_batch_set_wand");
     return *this;
   }
+  // irs::score::Min per query: the k-th best score the caller's heap holds so far (empty: none)
+  QueryBatch& set_min_scores(const std::vector<float>& min_scores) {
+    for (Part& part : part_) {
+      if (!part.h) continue;
+      std::vector<float> m(part.index.size());
+      for (size_t i = 0; i < part.index.size(); ++i)
+        m[i] = min_scores.empty() ? 0.f : min_scores.at(part.index[i]);
+      check(irs_hip_batch_set_min_scores(part.h, min_scores.empty() ? nullptr : m.data()),
+            "irs_hip_batch_set_min_scores");
+    }
+    return *this;
+  }
   QueryBatch& run(void* stream = nullptr) {
     for (Part& part : part_)
       if (part.h) check(irs_hip_batch_run(part.h, stream), "irs_hip_batch_run");

@@ -451,7 +451,8 @@ k_conj(ConjArgs A, uint32_t pilot) {
 // `items[unit]` = lead items of the unit.
 __global__ void __launch_bounds__(64)
 k_conj_threshold(const DevQuery* queries, const uint32_t* conj_units, const uint32_t* n_items,
-                 const uint32_t* hist, uint32_t stride, uint32_t margin, uint32_t* bstar) {
+                 const uint32_t* hist, uint32_t stride, uint32_t margin, uint32_t* bstar,
+                 const uint32_t* min_bin /*[unit] bin of the caller's score::Min; null: none*/) {
   const unsigned lane = threadIdx.x;
   const uint32_t unit = conj_units[blockIdx.x];
   const DevQuery qd = queries[unit];
@@ -481,7 +482,7 @@ k_conj_threshold(const DevQuery* queries, const uint32_t* conj_units, const uint
       if (cum >= need) { result = c * (kBins / 64) + uint32_t(i); break; }
     }
   }
-  if (lane == 0) bstar[unit] = result;
+  if (lane == 0) bstar[unit] = (min_bin && min_bin[unit] > result) ? min_bin[unit] : result;
 }
 
 }  // namespace irs_hip

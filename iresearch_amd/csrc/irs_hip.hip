@@ -128,6 +128,8 @@ struct irs_hip_batch {
   DevBuf d_tile_units, d_conj_units, d_conj_items, d_conj_hist;
   DevBuf d_conj_item_base, d_conj_unit_items, d_conj_seek, d_conj_recs;   // k_conj_seek
   DevBuf d_lead_of;   // by_phrase: slot of every unit's lead term
+  DevBuf d_min_bin;   // [unit] score bin of the caller's irs::score::Min (irs_hip_batch_set_min_scores)
+  bool has_min = false;
   uint32_t conj_total_items = 0;
   DevBuf d_conj_pilot;             // the lead items the pilot pass samples, {unit, item} each
   uint32_t n_conj_pilot = 0, conj_pilot_stride = 0;
@@ -284,6 +286,10 @@ bool big_smem(K kernel, size_t bytes) {
 
 // Candidate slots per query.  An estimated threshold aims at kPilotMargin * k
 // candidates; the sound one admits about k * (pilot stride).
+static const uint32_t* min_bins(const irs_hip_batch* b) {
+  return b->has_min ? b->d_min_bin.as<uint32_t>() : nullptr;
+}
+
 static uint32_t default_cand_cap(const irs_hip_batch* b) {
   const uint64_t per_k = b->estimate ? 16ull : 4ull * b->stride_eff;
   return uint32_t(std::min<uint64_t>(std::max<uint64_t>(per_k * b->k_max, 16384), 262144));
@@ -299,7 +305,7 @@ bool launch_pilot(irs_hip_batch* b, rt::stream_t st) {
             b->d_tile_units.as<uint32_t>(), b->d_segs.as<DevSegment>(),
             b->d_queries.as<DevQuery>(), b->d_qterms.as<DevQTerm>(), b->stride_eff,
             b->nw_log2, b->d_tile_off.as<uint32_t>(), reinterpret_cast<uint64_t>(b->d_items.p),
-            b->d_bstar.as<uint32_t>(), b->estimate ? kPilotMargin : 0u);
+            b->d_bstar.as<uint32_t>(), b->estimate ? kPilotMargin : 0u, min_bins(b));
   return rt::last_error_ok();
 }
 
@@ -441,7 +447,7 @@ bool launch_conj(irs_hip_batch* b, rt::stream_t st) {
   RT_LAUNCH(k_conj_threshold, uint32_t(b->conj_units.size()), 64, 0, st,
             b->d_queries.as<DevQuery>(), b->d_conj_units.as<uint32_t>(),
             b->d_conj_items.as<uint32_t>(), b->d_conj_hist.as<uint32_t>(), a.pilot_stride,
-            b->estimate ? kPilotMargin : 0u, b->d_bstar.as<uint32_t>());
+            b->estimate ? kPilotMargin : 0u, b->d_bstar.as<uint32_t>(), min_bins(b));
   RT_LAUNCH((k_conj<LAYOUT>), (b->conj_total_items + kConjWaves - 1) / kConjWaves, kConjWaves * 64,
             0, st, a, 0u);
   return rt::last_error_ok();
@@ -532,7 +538,7 @@ bool launch_phrase(irs_hip_batch* b, rt::stream_t st) {
   RT_LAUNCH(k_conj_threshold, uint32_t(b->conj_units.size()), 64, 0, st,
             b->d_queries.as<DevQuery>(), b->d_conj_units.as<uint32_t>(),
             b->d_conj_items.as<uint32_t>(), b->d_conj_hist.as<uint32_t>(), stride,
-            b->estimate ? kPilotMargin : 0u, b->d_bstar.as<uint32_t>());
+            b->estimate ? kPilotMargin : 0u, b->d_bstar.as<uint32_t>(), min_bins(b));
   RT_LAUNCH((k_phrase<LAYOUT, MT>), b->n_phrase_wgs, kPhraseWaves * 64, 0, st, a, 0u);
   return rt::last_error_ok();
 }
@@ -1465,6 +1471,30 @@ static int batch_set_wand_impl(irs_hip_batch* b, int enable) {
   return IRS_HIP_OK;
 }
 
+static int batch_set_min_scores_impl(irs_hip_batch* b, const float* min_scores) {
+  if (!b) return IRS_HIP_EINVAL;
+  if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
+  if (!min_scores) {
+    b->has_min = false;
+    return IRS_HIP_OK;
+  }
+  const uint32_t nq_user = b->nq / uint32_t(b->segs.size());
+  std::vector<uint32_t> bins(b->nq, 0u);
+  for (uint32_t u = 0; u < b->nq; ++u) {
+    const float m = min_scores[u % nq_user];
+    if (!(m >= 0.f)) return IRS_HIP_EINVAL;   // (also NaN)
+    // the bin score_bin() puts a score of m into: docs at or above m land in it or higher
+    const float x = std::fmin(m * b->queries[u].bin_scale, float(kBins - 1));
+    bins[u] = uint32_t(x);
+  }
+  if (b->ran && !rt::sync(b->stream)) return IRS_HIP_EHIP;
+  if (!b->d_min_bin.alloc(bins.size() * 4) ||
+      !rt::h2d(b->d_min_bin.p, bins.data(), bins.size() * 4, nullptr) || !rt::sync(nullptr))
+    return IRS_HIP_EHIP;
+  b->has_min = true;
+  return IRS_HIP_OK;
+}
+
 static int term_blockmax_impl(irs_hip_segment* seg, uint32_t term, uint32_t* max_freqs,
                               uint32_t* min_norms, uint32_t cap, uint32_t* count) {
   if (!seg || !count || term >= seg->dev.num_terms) return IRS_HIP_EINVAL;
@@ -1588,7 +1618,8 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st) {
       RT_LAUNCH(k_select, b->nq, kThreads, smem, st, b->d_queries.as<DevQuery>(),
                 b->d_cands.as<uint64_t>(), b->cand_cap, b->d_cand_count.as<uint32_t>(),
                 b->d_hits.as<unsigned long long>(), b->d_out.as<Hit>(), b->k_max,
-                b->d_out_count.as<uint32_t>(), b->d_status.as<uint32_t>(), stage_cap, sort_cap);
+                b->d_out_count.as<uint32_t>(), b->d_status.as<uint32_t>(), stage_cap, sort_cap,
+                b->d_bstar.as<uint32_t>(), min_bins(b));
       ok = rt::last_error_ok();
     }
   }
@@ -1855,6 +1886,9 @@ int irs_hip_batch_profile(irs_hip_batch* b, int enable) {
 }
 int irs_hip_batch_set_wand(irs_hip_batch* b, int enable) {
   return guarded([&] { return batch_set_wand_impl(b, enable); });
+}
+int irs_hip_batch_set_min_scores(irs_hip_batch* b, const float* min_scores) {
+  return guarded([&] { return batch_set_min_scores_impl(b, min_scores); });
 }
 int irs_hip_term_blockmax(irs_hip_segment* seg, uint32_t term, uint32_t* max_freqs,
                           uint32_t* min_norms, uint32_t cap, uint32_t* count) {

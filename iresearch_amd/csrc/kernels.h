@@ -556,7 +556,8 @@ constexpr uint32_t kSelectStage = 8192;
 __global__ void __launch_bounds__(kThreads)
 k_select(const DevQuery* queries, const uint64_t* cands, uint32_t cand_cap,
          const uint32_t* cand_count, const unsigned long long* hits, Hit* out, uint32_t k_max,
-         uint32_t* out_count, uint32_t* status, uint32_t stage_cap, uint32_t sort_cap) {
+         uint32_t* out_count, uint32_t* status, uint32_t stage_cap, uint32_t sort_cap,
+         const uint32_t* bstar, const uint32_t* min_bin /*null: no caller thresholds*/) {
   RT_DYN_SMEM(smem);
   uint64_t* keys = reinterpret_cast<uint64_t*>(smem);         // [sort_cap]
   uint64_t* stage = keys + sort_cap;                          // [stage_cap]
@@ -573,8 +574,10 @@ k_select(const DevQuery* queries, const uint64_t* cands, uint32_t cand_cap,
     if (tid == 0) atomicOr(status, kStatusOverflow);
     n = cand_cap;
   }
-  // an estimated threshold (k_pilot) cut off docs that belong to the top k
-  if (n < qd.k && hits[q] > n && tid == 0) atomicOr(status, kStatusUnderflow);
+  // an estimated threshold (k_pilot) cut off docs that belong to the top k — unless the
+  // threshold in force is the caller's own (irs::score::Min): fewer than k docs reach it
+  const bool callers = min_bin && min_bin[q] != 0u && bstar[q] == min_bin[q];
+  if (n < qd.k && hits[q] > n && !callers && tid == 0) atomicOr(status, kStatusUnderflow);
   const uint64_t* src = cands + uint64_t(q) * cand_cap;
   const uint32_t kk = qd.k < n ? qd.k : n;
   const bool staged = n <= stage_cap;

@@ -976,7 +976,8 @@ template<typename ACC, int LAYOUT, int TILE, bool AND>
 __global__ void __launch_bounds__(kTileThreadsMax)
 k_pilot(const uint32_t* units, const DevSegment* segs, const DevQuery* queries,
         const DevQTerm* qterms, uint32_t stride, uint32_t nw_log2, const uint32_t* tile_off,
-        uint64_t items /*address of the ItemG records*/, uint32_t* bstar, uint32_t margin) {
+        uint64_t items /*address of the ItemG records*/, uint32_t* bstar, uint32_t margin,
+        const uint32_t* min_bin /*[unit] bin of the caller's score::Min; null: none*/) {
   RT_DYN_SMEM(smem);
   if (!wave::lds_is_at_zero(smem)) __builtin_trap();  // the tile arrays are addressed absolutely
   unsigned char* rest;
@@ -1067,7 +1068,8 @@ k_pilot(const uint32_t* units, const DevSegment* segs, const DevQuery* queries,
         if (cum >= need) { result = c * (kBins / 64) + uint32_t(i); break; }
       }
     }
-    if (lane == 0) bstar[q] = result;
+    // (+ the caller's own lower bound — irs::score::Min — whichever is higher)
+    if (lane == 0) bstar[q] = (min_bin && min_bin[q] > result) ? min_bin[q] : result;
   }
 }
 

@@ -307,6 +307,18 @@ class QueryBatch:
                    "irs_hip_batch_set_wand")
         return self
 
+    def set_min_scores(self, min_scores):
+        """irs::score::Min per query (the harness heap's k-th score so far); None clears."""
+        if min_scores is None:
+            ptr = None
+        else:
+            arr = np.ascontiguousarray(min_scores, np.float32)
+            assert arr.shape == (self.nq_user,)
+            ptr = arr.ctypes.data
+        _lib.check(self.L, self.L.irs_hip_batch_set_min_scores(self.handle, ptr),
+                   "irs_hip_batch_set_min_scores")
+        return self
+
     def profile(self, enable=True):
         """True / 1: kernel timings; 2: count what the block-driven kernels decode; 3: both."""
         _lib.check(self.L, self.L.irs_hip_batch_profile(self.handle, int(enable)),

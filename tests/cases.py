@@ -630,6 +630,45 @@ def case_merge_types(L):
     sr.close()
 
 
+def case_min_score_pushdown(L):
+    """irs::score::Min (score_function.hpp:42-142; the harness pushes its heap's k-th score,
+    index-search.cpp:737-777): with the k-th score of a first run as threshold the same top-k
+    comes back; with the score of rank 10 at least those 10, all of them a prefix of the first
+    list, and never a doc below the threshold's bin; hit counts are unchanged.  Or, And, phrase."""
+    seg = synth.build_segment(50_000, 256, with_positions=True)
+    sr = search.SegmentReader.from_synth(seg, L=L)
+    st = [parity.segment_stats(seg)]
+    sets = [[Or([by_term(t) for t in (3, 17, 40, 99)]), Or([by_term(1), by_term(5)]),
+             And([by_term(2), by_term(9)]), And([by_term(0), by_term(4), by_term(30)]),
+             by_term(12)],
+            [by_phrase([1, 2]), by_phrase([0, 3])]]
+    k = 40
+    for filters in sets:
+        prep = search.prepare(filters, BM25(), st)
+        b = sr.batch(prep, k)
+        h0, c0, t0 = (x.copy() for x in b.run().results())
+        assert (c0 >= 12).all()
+        kth = np.array([h0[q, c0[q] - 1]["score"] for q in range(len(filters))], np.float32)
+        h1, c1, t1 = (x.copy() for x in b.set_min_scores(kth).run().results())
+        assert np.array_equal(c0, c1) and np.array_equal(t0, t1) and np.array_equal(h0, h1)
+        tenth = np.array([h0[q, 9]["score"] for q in range(len(filters))], np.float32)
+        h2, c2, t2 = (x.copy() for x in b.set_min_scores(tenth).run().results())
+        assert np.array_equal(t0, t2) and b.reruns() == 0
+        for q in range(len(filters)):
+            n = int(c2[q])
+            assert 10 <= n <= c0[q]
+            assert np.array_equal(h2[q, :n], h0[q, :n])
+        # a threshold nothing reaches: no hits returned, the matches still counted
+        h3, c3, t3 = b.set_min_scores(np.full(len(filters), 1e30, np.float32)).run().results()
+        assert np.array_equal(t0, t3)
+        top_bin_docs = c3   # (only docs in the highest score bin may remain)
+        assert (top_bin_docs <= c0).all()
+        h4, c4, t4 = b.set_min_scores(None).run().results()
+        assert np.array_equal(h0, h4) and np.array_equal(c0, c4)
+        b.close()
+    sr.close()
+
+
 def case_decode_without_freq(L, layout):
     """Iterator requested without IndexFeatures::FREQ on a FREQ field: freq blocks are
     skipped (formats_10.cpp:1746-1750) — docs must be identical."""

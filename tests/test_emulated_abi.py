@@ -157,6 +157,10 @@ def test_max_and_min_score_merging(simlib):
     cases.case_merge_types(simlib)
 
 
+def test_min_score_pushdown(simlib):
+    cases.case_min_score_pushdown(simlib)
+
+
 def test_wand_equals_exhaustive(simlib):
     cases.case_wand_equals_exhaustive(simlib)
 

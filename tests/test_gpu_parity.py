@@ -204,6 +204,10 @@ def test_max_and_min_score_merging(gpulib):
     cases.case_merge_types(gpulib)
 
 
+def test_min_score_pushdown(gpulib):
+    cases.case_min_score_pushdown(gpulib)
+
+
 def test_wand_equals_exhaustive(gpulib):
     cases.case_wand_equals_exhaustive(gpulib, num_docs=400_000, max_rank=512, ks=(10, 1000))
 
