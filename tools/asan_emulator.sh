@@ -38,5 +38,10 @@ cases.case_wand_equals_exhaustive(L, num_docs=30_000, max_rank=128, ks=(10,))
 cases.case_decode_reference_packed(L, 1)
 cases.case_errors(L)
 cases.case_phrase_errors(L)
+cases.case_merge_types(L)
+cases.case_min_score_pushdown(L)
+cases.case_many_items(L, 20_000)
+cases.case_zero_boost(L)
+cases.case_legacy_norms(L)
 print("asan emulator run: clean")
 PY
