@@ -414,13 +414,24 @@ def main_config5(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    L = _lib.lib()
+    sim = os.environ.get("IRS_BENCH_SIM")   # control-flow dry run on the emulator (see main())
+    if sim:
+        import ctypes
+        dev = torch.device("cpu")
+        L = _lib.bind(ctypes.CDLL(sim))
+        local_rank = 0
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        L = _lib.lib()
+    sync = (lambda: None) if sim else torch.cuda.synchronize
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if sim:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     docs = args.docs if args.docs != 10_000_000 else 50_000_000
     n_segments = args.segments
     my = distributed.segments_of_rank(n_segments, rank, world)
@@ -459,7 +470,7 @@ def main_config5(args):
             b.set_wand(True)
         b.profile(True)
         bat[name] = b
-    sptr = C_void(torch.cuda.current_stream(dev).cuda_stream)
+    sptr = None if sim else C_void(torch.cuda.current_stream(dev).cuda_stream)
     ex = {name: distributed.PipelinedExchange(L, local_rank, n_segments, rank, world, nq, k, dev)
           for name in bat}
     it = {"n": 0}
@@ -479,10 +490,10 @@ def main_config5(args):
         step()
     for e in ex.values():
         e.finish(sptr)
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     kms = []
     for _ in range(args.steps):
@@ -491,7 +502,7 @@ def main_config5(args):
             kms.append({n: b.timings() for n, b in bat.items()})
     for e in ex.values():
         e.finish(sptr)
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -521,7 +532,8 @@ def main_config5(args):
             "value": round(args.steps * 2 * nq / elapsed, 2), "unit": "queries/s", "n_gpus": world,
             "steps": args.steps, "warmup": max(1, args.warmup),
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "u32+f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "u32+f32",
+            "data": "synthetic" if not sim else "synthetic (EMULATOR DRY RUN)",
             "config": {
                 "workload": "config 5: %d AND-of-2..4 + %d 2-word by_phrase queries/step, TF-IDF, "
                             "top-%d, %d-doc Zipfian index with positions, %d segments, WAND on the "

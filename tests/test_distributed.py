@@ -198,3 +198,29 @@ def test_bench_is_launchable_on_two_ranks(simlib):
     assert d["config"]["segments"] == 4 and d["config"]["reruns_rank0"] == 0
     assert d["roofline"]["launches_per_step"] == 1       # ONE batch over rank 0's 2 segments
     assert d["cpu_baseline"] is None
+
+
+def test_bench_config5_is_launchable_on_two_ranks(simlib):
+    """`bench.py --config 5` (AND + by_phrase, TF-IDF, block-max WAND, segments with positions
+    sharded over ranks) under the driver's launch line, emulator dry run: two batches per rank
+    and step, two exchanges, ONE JSON line with the bytes actually decoded."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29500 + ((os.getpid() * 11 + 17) % 2000)
+    env = dict(os.environ, IRS_BENCH_SIM=simlib._name, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--config", "5", "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--docs", "40000", "--queries", "6", "--k", "20", "--segments", "4"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0
+    assert d["config"]["segments"] == 4 and d["config"]["queries_per_step"] == 12
+    t = d["config"]["bytes_touched_per_step"]
+    a = d["config"]["algorithmic_bytes_per_step"]
+    assert 0 < t["and_doc_and_norm"] <= a["and"] and t["phrase_doc"] > 0
