@@ -710,6 +710,46 @@ k_phrase(ConjArgs A, uint32_t pilot /*1: histogram the scores of the sampled lea
       // reference's lead.seek(sought - offset), which only skips positions that cannot match.
       uint32_t pf = 0, head = ps.pos_base;
       bool done = false;
+      if (MT == 2 && m == 2u) {
+        // Two terms: ONE loop that reads one position per trip, of whichever list is behind
+        // (the term's records selected per lane).  The nested form below costs a wavefront the
+        // SUM over lead positions of the LONGEST seek among its 64 docs; this one the longest
+        // tf_a + tf_b — what very frequent phrases (thousands of matching docs per block of
+        // the lead) are bound by: 43 -> 36 ms per 1000 such queries.  (Keeping two deltas of
+        // either list in flight was tried and is slower: the loop is bound by the instructions
+        // of a random-access position read, not by its latency.)
+        const DevPosTerm pa = W.pt[0], pb = W.pt[1];
+        const uint32_t off = W.off[1];
+        uint32_t ka = 0, kb = 0, va = ps.pos_base, vb = ps.pos_base;
+        for (;;) {
+          bool adv_a;
+          if (ka == 0u) {
+            adv_a = true;                       // lead.next()
+          } else if (kb == 0u || vb < va + off) {
+            adv_a = false;                      // position::seek(target) :1578-1604
+          } else {
+            pf += vb == va + off ? 1u : 0u;     // reached the target, or sought too far
+            adv_a = true;
+          }
+          if (adv_a ? ka == T[0] : kb == T[1]) break;   // exhausted: no later position can match
+          DevPosTerm pt;
+          pt.pos_start = adv_a ? pa.pos_start : pb.pos_start;
+          pt.row = adv_a ? pa.row : pb.row;
+          pt.nfull = adv_a ? pa.nfull : pb.nfull;
+          pt.tail_row = adv_a ? pa.tail_row : pb.tail_row;
+          const uint32_t d = pos_delta<LAYOUT>(ps, pt, 0u, adv_a ? P[0] + ka : P[1] + kb);
+          ++my_pos;
+          if (adv_a) {
+            va += d;
+            ++ka;
+            if (va + off < va) break;           // !pos_limits::valid(term_position)
+          } else {
+            vb += d;
+            ++kb;
+          }
+        }
+        done = true;
+      }
       for (uint32_t a = 0; a < T[0] && !done; ++a) {
         head += pos_delta<LAYOUT>(ps, W.pt[0], W.term[0], P[0] + a);  // lead.next()
         ++my_pos;
