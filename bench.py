@@ -228,11 +228,8 @@ def main():
     # the collective goes through the library's own RCCL communicator (irs_hip_comm_*); torch
     # only carries its 128-byte id to the other ranks
     comm = None
-    if world > 1:
-        try:
-            comm = distributed.Communicator(L, local_rank, rank, world)
-        except Exception as e:  # noqa: BLE001  (torch.distributed remains the way out)
-            log("irs_hip_comm unavailable (%s): all-gather through torch.distributed" % e)
+    if world > 1:   # (on every rank or on none; torch.distributed remains the way out)
+        comm = distributed.agreed_communicator(L, local_rank, rank, world, dev, log)
     exchange = distributed.PipelinedExchange(L, local_rank, n_segments if multi else 1, rank,
                                              world, nq, k, dev, comm=comm)
     # a multi-segment batch writes [segment][query][k] hits and [segment][query] counts: exactly

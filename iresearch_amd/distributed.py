@@ -42,7 +42,7 @@ class Communicator:
     def __init__(self, L, device_index: int, rank: int, world: int, broadcast=None):
         self.L, self.rank, self.world = L, rank, world
         ident = (C.c_uint8 * 128)()
-        if rank == 0:
+        if rank == 0 and (broadcast is None or world == 1):
             _lib.check(L, L.irs_hip_comm_unique_id(ident), "irs_hip_comm_unique_id")
         if world > 1:
             if broadcast is None:
@@ -50,6 +50,7 @@ class Communicator:
                     box = [b]
                     dist.broadcast_object_list(box, src=0)
                     return box[0]
+            # (a caller-supplied `broadcast` returns the id on every rank, rank 0 included)
             raw = broadcast(bytes(ident) if rank == 0 else None)
             ident = (C.c_uint8 * 128).from_buffer_copy(raw)
         h = C.c_void_p()
@@ -66,6 +67,66 @@ class Communicator:
         if self.handle:
             self.L.irs_hip_comm_destroy(self.handle)
             self.handle = None
+
+
+def agreed_communicator(L, device_index: int, rank: int, world: int, device, log=None):
+    """Communicator on EVERY rank or on none: a rank that cannot bind RCCL (or whose
+    ncclCommInitRank fails) must not leave the others waiting in a collective it never joins.
+    Each step is followed by an all-reduce(MIN) of the ranks' success flags over
+    torch.distributed; on any failure every rank drops its communicator and the caller falls
+    back to torch.distributed's all-gather.  Returns the communicator or None."""
+    def all_ok(ok: bool) -> bool:
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    why = None
+    ident = (C.c_uint8 * 128)()
+    try:   # capability probe on every rank (rank 0's id is the one that counts)
+        _lib.check(L, L.irs_hip_comm_unique_id(ident), "irs_hip_comm_unique_id")
+        ok = True
+    except Exception as e:  # noqa: BLE001
+        ok, why = False, e
+    if not all_ok(ok):
+        if log:
+            log("irs_hip_comm unavailable on some rank (%s): all-gather through torch.distributed" % why)
+        return None
+    box = [bytes(ident) if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    comm = None
+    try:
+        comm = Communicator(L, device_index, rank, world, broadcast=lambda _b: box[0])
+        ok = True
+    except Exception as e:  # noqa: BLE001
+        ok, why = False, e
+    if not all_ok(ok):
+        if comm is not None:
+            comm.close()
+        if log:
+            log("irs_hip_comm_init_rank failed on some rank (%s): all-gather through torch.distributed" % why)
+        return None
+    # one small all-gather with known contents before anything depends on it
+    try:
+        n = 256
+        send = torch.full((n,), rank + 1, dtype=torch.int32, device=device)
+        recv = torch.zeros((world * n,), dtype=torch.int32, device=device)
+        stream = None
+        if device.type == "cuda":
+            stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        comm.all_gather(send.data_ptr(), recv.data_ptr(), 4 * n, stream)
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+        want = torch.arange(1, world + 1, dtype=torch.int32, device=device).repeat_interleave(n)
+        ok = bool(torch.equal(recv, want))
+        why = "self-test all-gather returned wrong data"
+    except Exception as e:  # noqa: BLE001
+        ok, why = False, e
+    if not all_ok(ok):
+        comm.close()
+        if log:
+            log("irs_hip_topk_allgather self-test failed on some rank (%s): torch.distributed" % why)
+        return None
+    return comm
 
 
 class _CommWork:
