@@ -309,6 +309,14 @@ int irs_hip_batch_set_min_scores(irs_hip_batch* batch, const float* min_scores);
  * frequency and smallest non-zero norm of every full 128-doc block. */
 int irs_hip_term_blockmax(irs_hip_segment* seg, uint32_t term, uint32_t* max_freqs,
                           uint32_t* min_norms, uint32_t cap, uint32_t* count);
+/* Where the block-max pairs of a segment come from: blocks whose pair was READ from the index's
+ * own wand data — the payload of scorer 0 in the level-0 skip entries (FreqNormSource::Read,
+ * wand_writer.hpp:318-334), present when the field was indexed with scorers
+ * (irs_hip_segment_desc.wand_count > 0) — out of all full blocks; the others (every block of an
+ * index written without wand data, the last block of every list, the norm where the payload
+ * only carries a frequency) are derived from the postings.  A field with positions must have
+ * been opened with its `.pos` for the entries to be read (they carry position fields). */
+int irs_hip_segment_wand_source(irs_hip_segment* seg, uint64_t* from_index, uint64_t* total);
 
 /* Kernel timing with HIP events recorded on the batch's own stream.
  * When enabled, every run() brackets each kernel launch with events;

@@ -77,6 +77,92 @@ k_block_max(DevSegment seg, uint32_t slices, uint32_t* blk_maxf, uint32_t* blk_m
   }
 }
 
+// The index's OWN block-max data, where the field was indexed with scorers: one thread per term
+// walks level 0 of the term's skip list (SkipWriter layout: per level a vlong length + bytes,
+// level 0 last; formats_10.cpp:501-533, 1063-1080) and takes, for every entry, the payload of
+// scorer 0 — FreqNormSource::Read (wand_writer.hpp:318-334): vint(max freq) [+ vint(norm -
+// freq)] — as the block's (max freq, min norm), overwriting what k_block_max derived from the
+// postings.  The index stores max(min norm, max freq) as the norm (FreqNormProducer,
+// wand_writer.hpp:198-209; a valid bound because a doc's norm is never below its frequency);
+// the last block of a list has no entry and keeps the derived pair.  `taken` counts the
+// entries read.
+__global__ void __launch_bounds__(kThreads)
+k_wand_skip0(DevSegment seg, const uint64_t* skip_at /*[term] absolute offset of the skip data,
+             0 = the list has none*/, uint32_t has_pos, uint32_t* blk_maxf, uint32_t* blk_minn,
+             unsigned long long* taken, uint32_t* status) {
+  const uint32_t term = blockIdx.x * kThreads + threadIdx.x;
+  if (term >= seg.num_terms) return;
+  const DevTerm t = seg.terms[term];
+  const uint64_t at = skip_at[term];
+  if (!at || !t.nblk) return;
+  const uint8_t* p = seg.doc + at;
+  const uint8_t* end = seg.doc + seg.doc_len;   // (the staged copy is zero padded behind it)
+  bool bad = false;
+  auto vlong = [&]() {
+    uint64_t v = 0;
+    for (uint32_t sh = 0; sh < 64 && p < end; sh += 7) {
+      const uint8_t b = *p++;
+      v |= uint64_t(b & 0x7Fu) << sh;
+      if (!(b & 0x80u)) return v;
+    }
+    bad = true;
+    return v;
+  };
+  auto sizes = [&](uint32_t& first) {   // one size byte per scorer (CommonSkipWandData :1962-1979)
+    uint64_t total = 0;
+    first = 0;
+    for (uint32_t w = 0; w < seg.wand_count && p < end; ++w) {
+      if (w == 0) first = *p;
+      total += *p++;
+    }
+    return total;
+  };
+  uint32_t s0;
+  p += sizes(s0);                              // the root entry in front of the level count
+  const uint32_t levels = uint32_t(vlong());
+  if (!levels || bad) return;
+  for (uint32_t l = levels; l-- > 1 && !bad;) {   // levels n..1
+    const uint64_t len = vlong();
+    if (!len || uint64_t(end - p) < len) bad = true; else p += len;
+  }
+  uint64_t len0 = bad ? 0 : vlong();
+  if (bad || !len0 || uint64_t(end - p) < len0) {
+    atomicOr(status, kStatusCorrupt);
+    return;
+  }
+  const uint8_t* stop = p + len0;
+  uint32_t n = 0;
+  while (p < stop && n < t.nblk && !bad) {
+    // last doc of the block: must be the directory's — anything else means the entries are
+    // framed differently from what this walk assumes (the caller then keeps the derived pairs)
+    if (uint32_t(vlong()) != seg.blk_last[t.dir_off + n]) {
+      atomicOr(status, kStatusWandFraming);
+      return;
+    }
+    (void)vlong();   // delta of the next block's pointer
+    if (has_pos) {   // pend_pos, delta of the `.pos` pointer (ReadState :1063-1080)
+      (void)vlong();
+      (void)vlong();
+    }
+    const uint64_t total = sizes(s0);
+    if (uint64_t(end - p) < total) { bad = true; break; }
+    if (s0) {
+      const uint8_t* payload = p;
+      const uint32_t f = uint32_t(vlong());
+      // (no more bytes: norm == freq — what a frequency-only payload means to a scorer that
+      // wants a norm, "compatibility between BM25 in the index and TFIDF in the query")
+      const uint32_t nrm = uint32_t(p - payload) != s0 ? f + uint32_t(vlong()) : f;
+      blk_maxf[t.dir_off + n] = f;
+      blk_minn[t.dir_off + n] = nrm;
+      p = payload;
+    }
+    p += total;
+    ++n;
+  }
+  if (bad) atomicOr(status, kStatusCorrupt);
+  else if (n) atomicAdd(taken, static_cast<unsigned long long>(n));
+}
+
 // Doc block `e` of a term, from the packed image when both parts live there (one funnel
 // shift + one bit-field extract per value), else from `.doc` (any framing).
 template<int LAYOUT>

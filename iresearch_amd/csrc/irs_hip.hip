@@ -99,6 +99,9 @@ struct irs_hip_segment {
   std::mutex wand_mutex;
   bool wand_ready = false;
   DevBuf d_blk_maxf, d_blk_minn;
+  std::vector<uint64_t> skip_at;   // per term: absolute offset of its skip data (0: none)
+  bool has_pos = false;
+  uint64_t wand_from_index = 0;    // blocks whose (max freq, min norm) came from the index's wand data
 };
 
 struct irs_hip_comm {
@@ -550,22 +553,52 @@ bool launch_phrase_terms(irs_hip_batch* b, rt::stream_t st) {
 }
 
 // Block-max data of a segment (conj.h k_block_max), built once, on first use.
+static bool launch_block_max(irs_hip_segment* s) {
+  const uint32_t slices =
+      std::max<uint32_t>(1, std::min<uint32_t>(64, s->cus * 8 / s->dev.num_terms));
+  if (s->dev.layout == kSimd4) {
+    RT_LAUNCH((k_block_max<kSimd4>), s->dev.num_terms * slices, kThreads, 0, nullptr, s->dev,
+              slices, s->d_blk_maxf.as<uint32_t>(), s->d_blk_minn.as<uint32_t>());
+  } else {
+    RT_LAUNCH((k_block_max<kScalar>), s->dev.num_terms * slices, kThreads, 0, nullptr, s->dev,
+              slices, s->d_blk_maxf.as<uint32_t>(), s->d_blk_minn.as<uint32_t>());
+  }
+  return rt::last_error_ok() && rt::sync(nullptr);
+}
+
 int prepare_blockmax(irs_hip_segment* s) {
   std::lock_guard<std::mutex> lock(s->wand_mutex);
   if (s->wand_ready) return IRS_HIP_OK;
   const uint64_t n = s->total_blocks;
   if (!s->d_blk_maxf.alloc((n + 1) * 4) || !s->d_blk_minn.alloc((n + 1) * 4)) return IRS_HIP_ENOMEM;
   if (n && s->dev.num_terms) {
-    const uint32_t slices =
-        std::max<uint32_t>(1, std::min<uint32_t>(64, s->cus * 8 / s->dev.num_terms));
-    if (s->dev.layout == kSimd4) {
-      RT_LAUNCH((k_block_max<kSimd4>), s->dev.num_terms * slices, kThreads, 0, nullptr, s->dev,
-                slices, s->d_blk_maxf.as<uint32_t>(), s->d_blk_minn.as<uint32_t>());
-    } else {
-      RT_LAUNCH((k_block_max<kScalar>), s->dev.num_terms * slices, kThreads, 0, nullptr, s->dev,
-                slices, s->d_blk_maxf.as<uint32_t>(), s->d_blk_minn.as<uint32_t>());
+    // derived from the postings: every block of every index gets a pair
+    if (!launch_block_max(s)) return IRS_HIP_EHIP;
+    // a field indexed with scorers carries the pairs itself (skip level 0): those are used
+    if (!s->skip_at.empty()) {
+      DevBuf d_at, d_taken;
+      if (!d_at.alloc(s->skip_at.size() * 8) || !d_taken.alloc(8)) return IRS_HIP_ENOMEM;
+      uint32_t status = 0;
+      unsigned long long taken = 0;
+      if (!rt::h2d(d_at.p, s->skip_at.data(), s->skip_at.size() * 8, nullptr) ||
+          !rt::dmemset(d_taken.p, 0, 8, nullptr) || !rt::dmemset(s->d_status.p, 0, 4, nullptr))
+        return IRS_HIP_EHIP;
+      RT_LAUNCH(k_wand_skip0, (s->dev.num_terms + kThreads - 1) / kThreads, kThreads, 0, nullptr,
+                s->dev, d_at.as<uint64_t>(), s->has_pos ? 1u : 0u, s->d_blk_maxf.as<uint32_t>(),
+                s->d_blk_minn.as<uint32_t>(), d_taken.as<unsigned long long>(),
+                s->d_status.as<uint32_t>());
+      if (!rt::last_error_ok() || !rt::d2h(&status, s->d_status.p, 4, nullptr) ||
+          !rt::d2h(&taken, d_taken.p, 8, nullptr) || !rt::sync(nullptr))
+        return IRS_HIP_EHIP;
+      if (status & kStatusCorrupt) return IRS_HIP_ECORRUPT;
+      if (status & kStatusWandFraming) {
+        // entries that do not line up with the block directory (e.g. a field with positions
+        // opened without its `.pos`): nothing of the walk is trusted, the derived pairs stand
+        if (!launch_block_max(s)) return IRS_HIP_EHIP;
+        taken = 0;
+      }
+      s->wand_from_index = taken;
     }
-    if (!rt::last_error_ok() || !rt::sync(nullptr)) return IRS_HIP_EHIP;
   }
   s->dev.blk_maxf = s->d_blk_maxf.as<uint32_t>();
   s->dev.blk_minn = s->d_blk_minn.as<uint32_t>();
@@ -776,11 +809,17 @@ static int segment_open_impl(const irs_hip_segment_desc* d, irs_hip_segment** ou
         blocks += t.nblk;
         // block offsets are kept as u32 relative to doc_start
         if (m.docs_count > kBlock && m.e_skip_start > 0xFFFFFFFFull) rc = IRS_HIP_EUNSUPPORTED;
+        if (m.docs_count > kBlock && d->wand_count) {
+          if (s->skip_at.empty()) s->skip_at.assign(d->num_terms, 0);
+          s->skip_at[i] = m.doc_start + m.e_skip_start;
+          if (s->skip_at[i] >= d->doc_file_len) rc = IRS_HIP_ECORRUPT;
+        }
       }
       s->terms[i] = t;
     }
     if (rc != IRS_HIP_OK) break;
     s->total_blocks = blocks;
+    s->has_pos = d->pos_file != nullptr;
     const uint64_t norm_bytes = d->norms ? uint64_t(d->norm_width) * d->norm_count : 0;
     if (!s->d_doc.alloc(d->doc_file_len + kPadBytes) ||
         (d->norms && !s->d_norms.alloc(norm_bytes + kPadBytes)) ||
@@ -1511,6 +1550,15 @@ static int term_blockmax_impl(irs_hip_segment* seg, uint32_t term, uint32_t* max
   return IRS_HIP_OK;
 }
 
+static int segment_wand_source_impl(irs_hip_segment* seg, uint64_t* from_index, uint64_t* total) {
+  if (!seg) return IRS_HIP_EINVAL;
+  if (!rt::set_device(seg->device)) return IRS_HIP_EHIP;
+  if (const int rc = prepare_blockmax(seg)) return rc;
+  if (from_index) *from_index = seg->wand_from_index;
+  if (total) *total = seg->total_blocks;
+  return IRS_HIP_OK;
+}
+
 static int comm_unique_id_impl(uint8_t* id) {
   if (!id) return IRS_HIP_EINVAL;
   return rt::comm::unique_id(id) ? IRS_HIP_OK : IRS_HIP_EHIP;
@@ -1893,6 +1941,9 @@ int irs_hip_batch_set_min_scores(irs_hip_batch* b, const float* min_scores) {
 int irs_hip_term_blockmax(irs_hip_segment* seg, uint32_t term, uint32_t* max_freqs,
                           uint32_t* min_norms, uint32_t cap, uint32_t* count) {
   return guarded([&] { return term_blockmax_impl(seg, term, max_freqs, min_norms, cap, count); });
+}
+int irs_hip_segment_wand_source(irs_hip_segment* seg, uint64_t* from_index, uint64_t* total) {
+  return guarded([&] { return segment_wand_source_impl(seg, from_index, total); });
 }
 int irs_hip_device_alloc(int32_t device, uint64_t bytes, void** d_out) {
   return guarded([&] {

@@ -26,6 +26,7 @@ enum : uint32_t {
   kStatusCorrupt = 1u,   // malformed block header / out-of-bounds offset
   kStatusOverflow = 2u,  // candidate buffer exhausted
   kStatusUnderflow = 4u, // an estimated threshold left fewer than k candidates
+  kStatusWandFraming = 8u, // k_wand_skip0: skip entries do not line up with the block directory
 };
 
 // ------------------------------------------------------------- directory --

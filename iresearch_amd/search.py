@@ -249,6 +249,13 @@ class SegmentReader:
             "irs_hip_term_directory")
         return last[:cnt.value], offs[:cnt.value]
 
+    def wand_source(self):
+        """(blocks whose (max freq, min norm) was read from the index's own wand data, all blocks)."""
+        a, b = C.c_uint64(), C.c_uint64()
+        _lib.check(self.L, self.L.irs_hip_segment_wand_source(self.handle, C.byref(a), C.byref(b)),
+                   "irs_hip_segment_wand_source")
+        return a.value, b.value
+
     def term_blockmax(self, term: int):
         """Per full block of the term: (largest frequency, smallest non-zero norm) — the
         block-max data WAND batches prune with."""

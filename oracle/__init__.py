@@ -244,9 +244,11 @@ def bit_union(doc_file: np.ndarray, metas, layout: int, has_freq: bool, n_words:
     return bits, int(n)
 
 
-def read_skip0(doc_file: np.ndarray, meta, wand_count: int = 0, with_wand: bool = False):
+def read_skip0(doc_file: np.ndarray, meta, wand_count: int = 0, with_wand: bool = False,
+               has_pos: bool = False):
     """Level-0 skip entries: (last docs, next block pointers, #levels) and, with_wand, the
-    (max freq, norm) payload of scorer 0 in every entry."""
+    (max freq, norm) payload of scorer 0 in every entry.  has_pos: the field stores positions
+    (the entries then also carry pend_pos and the `.pos` pointer)."""
     m = np.zeros(1, TERM_META)
     for k in TERM_META.names:
         m[0][k] = meta[k]
@@ -256,9 +258,10 @@ def read_skip0(doc_file: np.ndarray, meta, wand_count: int = 0, with_wand: bool 
     mf = np.zeros(cap, np.uint32)
     nm = np.zeros(cap, np.uint32)
     lv = C.c_uint32()
-    n = lib().orc_read_skip0_wand(doc_file.ctypes.data, doc_file.size, wand_count,
-                                  m.ctypes.data, last.ctypes.data, ptrs.ctypes.data, cap,
-                                  C.byref(lv), mf.ctypes.data, nm.ctypes.data)
+    n = lib().orc_read_skip0_pos(doc_file.ctypes.data, doc_file.size, wand_count,
+                                 1 if has_pos else 0, m.ctypes.data, last.ctypes.data,
+                                 ptrs.ctypes.data, cap, C.byref(lv), mf.ctypes.data,
+                                 nm.ctypes.data, None, None)
     if n < 0:
         raise ValueError("orc_read_skip0 failed: %d" % n)
     if with_wand:

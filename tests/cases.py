@@ -39,10 +39,13 @@ def case_wand_equals_exhaustive(L, num_docs=60_000, max_rank=256, layout=synth.L
     tiles really are skipped).  Total hits may only shrink."""
     scorers = [BM25(), BM25(1.2, 0.0), BM25(1.2, 1.0), TFIDF(False), TFIDF(True)]
     pruned = 0
-    for clustered in (False, True):
+    for clustered, wand_count in ((False, 0), (True, 0), (True, 1)):
+        # (wand_count 1: the field was indexed with a scorer — the bounds then come from the
+        # index's own wand data, k_wand_skip0, instead of being derived from the postings)
         kw = dict(topic_docs=2048, topic_percent=85, topic_terms=12) if clustered else {}
-        seg = synth.build_segment(num_docs, max_rank, layout=layout, **kw)
+        seg = synth.build_segment(num_docs, max_rank, layout=layout, wand_count=wand_count, **kw)
         sr = search.SegmentReader.from_synth(seg, L=L)
+        assert (sr.wand_source()[0] > 0) == (wand_count > 0)
         stats = [parity.segment_stats(seg)]
         rng = np.random.default_rng(11 + clustered)
         filters = [by_term(int(t)) for t in rng.integers(0, max_rank, 4)]
@@ -724,11 +727,17 @@ def case_wand_data(L, layout):
             assert len(gmf) == len(d) // 128
             for b in range(len(gmf)):
                 blk = slice(128 * b, 128 * b + 128)
-                assert gmf[b] == f[blk].max() and gmn[b] == norms[d[blk] - 1].min(), (t, b)
-                if b < len(sl):
-                    assert gmf[b] == mf[b], (t, b)
-                    if kinds[0] == synth.WAND_MIN_NORM:
-                        assert max(int(gmn[b]), int(gmf[b])) == nm[b], (t, b)
+                assert gmf[b] == f[blk].max(), (t, b)
+                if b < len(sl):      # read from the index's skip entry (k_wand_skip0); a
+                    # frequency-only payload reads as norm == freq (FreqNormSource::Read)
+                    assert gmf[b] == mf[b] and gmn[b] == nm[b], (t, b)
+                else:                # no skip entry for a list's last block: derived (k_block_max)
+                    assert gmn[b] == norms[d[blk] - 1].min(), (t, b)
+        # where the pairs came from: one skip entry per full block but the last of every list
+        from_index, total = sr.wand_source()
+        assert total == sum(len(d) // 128 for d, _ in lists)
+        assert from_index == sum(max(len(d) // 128 - (1 if len(d) % 128 == 0 else 0), 0)
+                                 for d, _ in lists if len(d) > 128), (from_index, total)
         n_words = (n_docs + 64) // 64
         terms = list(range(len(lists)))
         got, cnt = sr.bit_union(terms, n_words)
@@ -742,12 +751,29 @@ def case_wand_data(L, layout):
         h0, c0, t0 = run_and_check(L, plain, filters, BM25(), 50)
         assert np.array_equal(h0, h1) and np.array_equal(c0, c1) and np.array_equal(t0, t1)
         sr.close()
+    # an index written without scorers has no pairs of its own: all derived
+    sr = search.SegmentReader.from_synth(plain, L=L)
+    assert sr.wand_source()[0] == 0
+    sr.close()
     # the whole-corpus builder writes the same framing
     a = synth.build_segment(6_000, 64, layout=layout, keep_postings=True, wand_count=2)
     sr = search.SegmentReader.from_synth(a, L=L)
     for r in (1, 7, 30, 64):
         gd, gf = sr.decode_term(r - 1)
         assert np.array_equal(gd, a.postings[r][0]) and np.array_equal(gf, a.postings[r][1])
+    assert sr.wand_source()[0] > 0
+    sr.close()
+    # ... and with positions the skip entries also carry the `.pos` fields (ReadState :1063-1080):
+    # the pairs read from them are the oracle's
+    p = synth.build_segment(20_000, 32, layout=layout, wand_count=1, with_positions=True)
+    sr = search.SegmentReader.from_synth(p, L=L)
+    from_index, total = sr.wand_source()
+    assert 0 < from_index <= total
+    for t in (0, 3, 17):
+        sl, sp, levels, mf, nm = oracle.read_skip0(p.doc_file, p.metas[t], 1, True, has_pos=True)
+        gmf, gmn = sr.term_blockmax(t)
+        assert len(sl) > 0
+        assert np.array_equal(gmf[:len(sl)], mf) and np.array_equal(gmn[:len(sl)], nm), t
     sr.close()
 
 
