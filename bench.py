@@ -434,8 +434,12 @@ def main_config5(args):
     my = distributed.segments_of_rank(n_segments, rank, world)
     per = docs // n_segments
     t0 = time.perf_counter()
+    # the field is indexed WITH its scorer, as a WAND-enabled IResearch index is: TF-IDF without
+    # norms asks for MaxFreq wand data (tfidf.cpp:364-386) — the block-max pairs the pruning uses
+    # are then read from the index's own skip entries (k_wand_skip0)
     segs = {s: synth.build_segment(per if s < n_segments - 1 else docs - per * (n_segments - 1),
-                                   4096, first_doc=s * per, with_positions=True) for s in my}
+                                   4096, first_doc=s * per, with_positions=True, wand_count=1,
+                                   wand_kind=synth.WAND_MAX_FREQ) for s in my}
     log("built %d segment(s) with positions in %.1f s" % (len(my), time.perf_counter() - t0))
     local_stats = {s: (segs[s].docs_with_field, segs[s].total_term_freq,
                        np.asarray(segs[s].metas["docs_count"])) for s in my}
