@@ -119,6 +119,11 @@ def main():
     ap.add_argument("--query-sets", type=int, default=4,
                     help="distinct query batches of the same distribution the steps rotate over "
                          "(set 0 is BASELINE config 3's; no step replays the previous one)")
+    ap.add_argument("--plan-ahead", action="store_true",
+                    help="experiment: queue the planning stage of the next step's batch on a "
+                         "second stream (irs_hip_batch_plan). Measured SLOWER: the planner streams "
+                         "2.4 GB through L2 while k_score lives on cross-query L2 reuse "
+                         "(20.4 vs 13.1 ms per step)")
     ap.add_argument("--per-segment-batches", action="store_true",
                     help="one batch per local segment instead of one batch over all of them (A/B)")
     ap.add_argument("--force-segments", action="store_true",
@@ -222,6 +227,8 @@ def main():
         batch_sets.append(batches)
     batches = batch_sets[0]
     sptr = None if sim else C_void(torch.cuda.current_stream(dev).cuda_stream)
+    plan_stream = torch.cuda.Stream(device=dev) if (args.plan_ahead and not sim) else None
+    plan_ptr = None if plan_stream is None else C_void(plan_stream.cuda_stream)
     nq, k = args.queries, args.k
     # every buffer of the exchange step is allocated once (twice: two sets alternate); each
     # local segment's results are written straight into its slot of the send buffer
@@ -273,6 +280,12 @@ def main():
             prev = None
         for s in cur:
             cur[s].run(sptr)
+        # --plan-ahead (off by default, see its help): the planning stage of the NEXT step's
+        # batch on a second stream, overlapping this step's scoring kernels
+        nxt = batch_sets[state["it"] % n_sets]
+        if plan_ptr is not None and nxt is not cur and not host_results:
+            for s in nxt:
+                nxt[s].plan(plan_ptr)
         if prev is not None:
             deliver(prev)
         state["prev"] = (cur, ph, host_results)

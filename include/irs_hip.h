@@ -252,6 +252,13 @@ int irs_hip_batch_create_multi(irs_hip_segment* const* segs, uint32_t n_segs,
                                const irs_hip_term_scorer* terms, uint32_t n_term_entries,
                                irs_hip_batch** out);
 int irs_hip_batch_run(irs_hip_batch* batch, void* stream);
+/* Optional: queue the PLANNING stage of the batch's next run (tile tables, work items: what
+ * building the iterator tree is to filter::prepared::execute) on `stream` now; the next
+ * irs_hip_batch_run then only waits for it (an event) and starts with scoring.  The stage reads
+ * and writes nothing another batch's run touches, so with two streams a caller overlaps the
+ * planning of batch i+1 with the scoring kernels of batch i.  Without this call run() plans
+ * inline, as before. */
+int irs_hip_batch_plan(irs_hip_batch* batch, void* stream);
 int irs_hip_batch_results(irs_hip_batch* batch, irs_hip_hit* hits,
                           uint32_t k_stride, uint32_t* counts,
                           uint64_t* total_hits);

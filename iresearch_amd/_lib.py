@@ -63,7 +63,8 @@ SYMBOLS = (
     "irs_hip_batch_results_to_device", "irs_hip_batch_destroy",
     "irs_hip_query_batch", "irs_hip_batch_configure", "irs_hip_batch_profile",
     "irs_hip_batch_timings", "irs_hip_batch_work", "irs_hip_batch_reruns", "irs_hip_merge_topk",
-    "irs_hip_batch_set_wand", "irs_hip_batch_set_min_scores", "irs_hip_term_blockmax",
+    "irs_hip_batch_plan", "irs_hip_batch_set_wand", "irs_hip_batch_set_min_scores",
+    "irs_hip_term_blockmax",
     "irs_hip_segment_wand_source",
     "irs_hip_batch_touched",
     "irs_hip_comm_unique_id", "irs_hip_comm_init_rank", "irs_hip_comm_destroy",
@@ -116,6 +117,7 @@ def bind(L: C.CDLL) -> C.CDLL:
     L.irs_hip_merge_topk.argtypes = [i32, vp, vp, vp, u32, u32, u32, vp, vp, vp, vp]
     L.irs_hip_merge_topk.restype = C.c_int
     L.irs_hip_batch_set_wand.argtypes, L.irs_hip_batch_set_wand.restype = [vp, C.c_int], C.c_int
+    L.irs_hip_batch_plan.argtypes, L.irs_hip_batch_plan.restype = [vp, vp], C.c_int
     L.irs_hip_segment_wand_source.argtypes = [vp, P(u64), P(u64)]
     L.irs_hip_segment_wand_source.restype = C.c_int
     L.irs_hip_batch_set_min_scores.argtypes = [vp, vp]

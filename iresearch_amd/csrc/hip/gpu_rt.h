@@ -73,6 +73,8 @@ inline bool event_sync(event_t e) { return ok(hipEventSynchronize(e)); }
 inline bool event_create(event_t* e) { return ok(hipEventCreate(e)); }
 inline void event_destroy(event_t e) { (void)hipEventDestroy(e); }
 inline bool event_record(event_t e, stream_t s) { return ok(hipEventRecord(e, s)); }
+// work queued on `s` from here on starts after `e`
+inline bool stream_wait(stream_t s, event_t e) { return ok(hipStreamWaitEvent(s, e, 0)); }
 inline bool event_elapsed(float* ms, event_t a, event_t b) {
   return ok(hipEventElapsedTime(ms, a, b));
 }

@@ -163,6 +163,10 @@ struct irs_hip_batch {
   // queued on the stream since), and the status word that run left in page-locked memory
   rt::event_t ev_done{};
   bool ev_done_ready = false;
+  // irs_hip_batch_plan: the planning stage of the NEXT run was queued ahead (on another stream)
+  rt::event_t ev_planned{};
+  bool ev_planned_ready = false;
+  bool planned = false;
   uint32_t* h_status = nullptr;
   rt::stream_t stream = nullptr;
   bool ran = false;
@@ -1620,6 +1624,36 @@ static int batch_profile_impl(irs_hip_batch* b, int enable) {
   return IRS_HIP_OK;
 }
 
+// The planning stage of a run: tile -> first block tables, per-term records, the work items of
+// the tile kernels.  A pure function of (batch, segments): it touches nothing a run of ANOTHER
+// batch reads, so a caller may queue it ahead on a second stream (irs_hip_batch_plan).
+static bool plan_stage(irs_hip_batch* b, rt::stream_t st) {
+  auto mark = [&](int i) { return !b->profile || rt::event_record(b->ev[i], st); };
+  bool ok = mark(2 * IRS_HIP_K_PLAN);
+  if (ok) {
+    RT_LAUNCH(k_plan, b->nq * b->jt, kThreads, 0, st, b->d_segs.as<DevSegment>(),
+              b->d_queries.as<DevQuery>(), b->d_qterms.as<DevQTerm>(), b->jt, b->tile,
+              b->d_first.as<uint32_t>(), b->d_tails.as<DevTail>());
+    ok = rt::last_error_ok();
+  }
+  if (ok && !b->phrase && !b->tile_units.empty()) ok = launch_items(b, st);
+  return ok && mark(2 * IRS_HIP_K_PLAN + 1);
+}
+
+static int batch_plan_impl(irs_hip_batch* b, void* stream) {
+  if (!b) return IRS_HIP_EINVAL;
+  if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
+  if (!ensure_scratch(b)) return IRS_HIP_ENOMEM;
+  rt::stream_t st = static_cast<rt::stream_t>(stream);
+  bool ok = true;
+  if (!b->ev_planned_ready) ok = b->ev_planned_ready = rt::event_create(&b->ev_planned);
+  // (the tables are rewritten: the batch's own previous run must be through with them)
+  if (ok && b->ev_done_ready && b->ran) ok = rt::stream_wait(st, b->ev_done);
+  ok = ok && plan_stage(b, st) && rt::event_record(b->ev_planned, st);
+  b->planned = ok;
+  return ok ? IRS_HIP_OK : IRS_HIP_EHIP;
+}
+
 static int run_impl(irs_hip_batch* b, rt::stream_t st) {
   if (!ensure_scratch(b)) return IRS_HIP_ENOMEM;
   b->stream = st;
@@ -1630,17 +1664,14 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st) {
             rt::dmemset(b->d_status.p, 0, 4, st) &&
             rt::dmemset(b->d_bstar.p, 0, b->d_bstar.n, st) &&
             rt::dmemset(b->d_touched.p, 0, b->d_touched.n, st);
-  // 1. plan: tile -> first block tables, tail decode
-  ok = ok && mark(2 * IRS_HIP_K_PLAN);
-  if (ok) {
-    RT_LAUNCH(k_plan, b->nq * b->jt, kThreads, 0, st, b->d_segs.as<DevSegment>(),
-              b->d_queries.as<DevQuery>(), b->d_qterms.as<DevQTerm>(), b->jt, b->tile,
-              b->d_first.as<uint32_t>(), b->d_tails.as<DevTail>());
-    ok = rt::last_error_ok();
-  }
+  // 1. plan (already queued by irs_hip_batch_plan: wait for it instead)
   const bool tiles = !b->phrase && !b->tile_units.empty();
-  if (ok && tiles) ok = launch_items(b, st);
-  ok = ok && mark(2 * IRS_HIP_K_PLAN + 1);
+  if (b->planned) {
+    ok = ok && rt::stream_wait(st, b->ev_planned);
+    b->planned = false;
+  } else {
+    ok = ok && plan_stage(b, st);
+  }
   // 2. pilot: per-query score-bin threshold (phrase batches have none: few docs match)
   ok = ok && mark(2 * IRS_HIP_K_PILOT);
   if (tiles)
@@ -1859,6 +1890,7 @@ void irs_hip_batch_destroy(irs_hip_batch* b) {
   if (b->events_ready)
     for (auto& e : b->ev) rt::event_destroy(e);
   if (b->ev_done_ready) rt::event_destroy(b->ev_done);
+  if (b->ev_planned_ready) rt::event_destroy(b->ev_planned);
   rt::hfree(b->h_status);
   rt::hfree(b->h_pin);
   delete b;
@@ -1996,6 +2028,9 @@ int irs_hip_topk_allgather(irs_hip_comm* c, const void* d_send, void* d_recv,
 }
 int irs_hip_batch_touched(irs_hip_batch* b, uint64_t* doc_bytes, uint64_t* positions) {
   return guarded([&] { return batch_touched_impl(b, doc_bytes, positions); });
+}
+int irs_hip_batch_plan(irs_hip_batch* b, void* stream) {
+  return guarded([&] { return batch_plan_impl(b, stream); });
 }
 int irs_hip_batch_run(irs_hip_batch* b, void* stream) {
   return guarded([&] { return batch_run_impl(b, stream); });

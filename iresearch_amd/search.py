@@ -332,6 +332,11 @@ class QueryBatch:
                    "irs_hip_batch_profile")
         return self
 
+    def plan(self, stream=None):
+        """Queue the planning stage of the next run on `stream` (irs_hip_batch_plan)."""
+        _lib.check(self.L, self.L.irs_hip_batch_plan(self.handle, stream), "irs_hip_batch_plan")
+        return self
+
     def run(self, stream=None):
         _lib.check(self.L, self.L.irs_hip_batch_run(self.handle, stream), "irs_hip_batch_run")
         return self

@@ -633,6 +633,30 @@ def case_merge_types(L):
     sr.close()
 
 
+def case_plan_ahead(L):
+    """irs_hip_batch_plan: a run whose planning stage was queued ahead returns exactly what a
+    plain run returns — tile batches, conjunctions, phrases, repeated and interleaved with
+    plain runs."""
+    seg = synth.build_segment(40_000, 128, with_positions=True)
+    sr = search.SegmentReader.from_synth(seg, L=L)
+    st = [parity.segment_stats(seg)]
+    for filters in ([Or([by_term(t) for t in (3, 17, 40, 99)]), by_term(5),
+                     And([by_term(2), by_term(9)]), Or([by_term(1), by_term(6), by_term(30)], min_match=2)],
+                    [by_phrase([1, 2]), by_phrase([0, 3, 5])]):
+        prep = search.prepare(filters, BM25(), st)
+        b = sr.batch(prep, 25)
+        ref = [x.copy() for x in b.run().results()]
+        for _ in range(2):
+            got = b.plan().run().results()
+            assert all(np.array_equal(a, g) for a, g in zip(ref, got))
+        got = b.run().results()
+        assert all(np.array_equal(a, g) for a, g in zip(ref, got))
+        got = b.plan().plan().run().results()     # planning twice is harmless
+        assert all(np.array_equal(a, g) for a, g in zip(ref, got))
+        b.close()
+    sr.close()
+
+
 def case_min_score_pushdown(L):
     """irs::score::Min (score_function.hpp:42-142; the harness pushes its heap's k-th score,
     index-search.cpp:737-777): with the k-th score of a first run as threshold the same top-k

@@ -71,6 +71,7 @@ inline bool event_record(event_t& e, stream_t) {
   e = now_ms();
   return true;
 }
+inline bool stream_wait(stream_t, const event_t&) { return true; }   // (everything is synchronous)
 inline bool event_elapsed(float* ms, event_t a, event_t b) {
   *ms = float(b - a);
   return true;

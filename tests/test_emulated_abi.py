@@ -161,6 +161,10 @@ def test_min_score_pushdown(simlib):
     cases.case_min_score_pushdown(simlib)
 
 
+def test_plan_ahead(simlib):
+    cases.case_plan_ahead(simlib)
+
+
 def test_wand_equals_exhaustive(simlib):
     cases.case_wand_equals_exhaustive(simlib)
 
