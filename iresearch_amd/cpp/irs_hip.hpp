@@ -355,6 +355,12 @@ class QueryBatch {
     }
     return *this;
   }
+  // queue the planning stage of the next run() on `stream` (irs_hip_batch_plan)
+  QueryBatch& plan(void* stream = nullptr) {
+    for (Part& part : part_)
+      if (part.h) check(irs_hip_batch_plan(part.h, stream), "irs_hip_batch_plan");
+    return *this;
+  }
   QueryBatch& run(void* stream = nullptr) {
     for (Part& part : part_)
       if (part.h) check(irs_hip_batch_run(part.h, stream), "irs_hip_batch_run");
