@@ -367,9 +367,13 @@ def main():
             ms = np.array(score_ms)                    # [steps][K_COUNT]
             avg = ms.mean(axis=0)
             achieved = rank0_alg_bytes / (avg[_lib.K_SCORE] * 1e-3) / 1e9
+            tr = measured_traffic()
             roof = {"bound": "hbm", "kernel": "k_score", "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": None if multi else measured_traffic(),
+                    # HBM bytes per k_score launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, separate
+                    # rocprofv3 passes of this command at these kernel sources), else null
+                    "traffic": None if (multi or tr is None) else int(tr["bytes"]),
+                    "traffic_detail": None if multi else tr,
                     "algorithmic_bytes_per_launch": int(rank0_alg_bytes / len(batches)),
                     "launches_per_step": len(batches),
                     "avg_launch_ms": round(float(avg[_lib.K_SCORE]), 4),
