@@ -97,6 +97,32 @@ __device__ __forceinline__ uint32_t pos_delta(const DevSegment& seg, const DevPo
   return seg.ptail[pt.tail_row + (idx - (pt.nfull << 7))];  // read_tail_block :1515
 }
 
+// A position list read front to back: the block a delta lives in (its payload address and bit
+// width: two dependent directory reads) is looked up once per 128 positions, not per position.
+struct PosCursor {
+  uint64_t payload;   // address of the current block's packed payload / of its all-equal value
+  uint32_t blk;       // index of the current block (0xFFFFFFFF: none yet)
+  uint32_t bits;      // its bit width (0: all-equal)
+};
+template<int LAYOUT>
+__device__ __forceinline__ uint32_t pos_delta_cached(const DevSegment& seg, const DevPosTerm& pt,
+                                                     PosCursor& c, uint32_t idx) {
+  const uint32_t b = idx >> 7;
+  if (b >= pt.nfull) return seg.ptail[pt.tail_row + (idx - (pt.nfull << 7))];  // read_tail_block :1515
+  if (b != c.blk) {
+    const uint64_t e = pt.row + b;
+    c.blk = b;
+    c.bits = seg.pblk_bits[e];
+    c.payload = reinterpret_cast<uint64_t>(seg.pos + pt.pos_start + seg.pblk_off[e] + 1);
+  }
+  const uint8_t* pl = reinterpret_cast<const uint8_t*>(c.payload);
+  if (c.bits == 0) {  // ALL_EQUAL (bitpack.hpp:159)
+    uint32_t len;
+    return vint_from(wave::load_u64(pl), &len);
+  }
+  return packed_at<LAYOUT>(pl, c.bits, idx & 127u);
+}
+
 // ------------------------------------------------------------ open time --
 
 // Sum of the frequencies of every full doc block (-> exclusive scan -> blk_pos).
@@ -721,6 +747,7 @@ k_phrase(ConjArgs A, uint32_t pilot /*1: histogram the scores of the sampled lea
         const DevPosTerm pa = W.pt[0], pb = W.pt[1];
         const uint32_t off = W.off[1];
         uint32_t ka = 0, kb = 0, va = ps.pos_base, vb = ps.pos_base;
+        PosCursor ca{0, 0xFFFFFFFFu, 0}, cb{0, 0xFFFFFFFFu, 0};
         for (;;) {
           bool adv_a;
           if (ka == 0u) {
@@ -737,13 +764,16 @@ k_phrase(ConjArgs A, uint32_t pilot /*1: histogram the scores of the sampled lea
           pt.row = adv_a ? pa.row : pb.row;
           pt.nfull = adv_a ? pa.nfull : pb.nfull;
           pt.tail_row = adv_a ? pa.tail_row : pb.tail_row;
-          const uint32_t d = pos_delta<LAYOUT>(ps, pt, 0u, adv_a ? P[0] + ka : P[1] + kb);
+          PosCursor cur = adv_a ? ca : cb;
+          const uint32_t d = pos_delta_cached<LAYOUT>(ps, pt, cur, adv_a ? P[0] + ka : P[1] + kb);
           ++my_pos;
           if (adv_a) {
+            ca = cur;
             va += d;
             ++ka;
             if (va + off < va) break;           // !pos_limits::valid(term_position)
           } else {
+            cb = cur;
             vb += d;
             ++kb;
           }
