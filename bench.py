@@ -99,6 +99,50 @@ def cpu_baseline(seg, ranks, k, seconds_hint=10.0):
                       "hardware threads" % (nt, cores, dtt, n1, dt1, len(ranks), cores, hw)}
 
 
+def cpu_baseline_config5(segs, ands, phrases, scorer, k, seconds_hint=12.0):
+    """Config 5 on the host: the oracle's restatement of the index-search loop over ALL segments
+    (one heap per query, as the harness keeps it) on a bounded, interleaved sample of the same
+    AND and by_phrase queries; the container's CPUs pop one task queue (index-search --threads).
+    Imports oracle/ here and only here."""
+    import concurrent.futures as cf
+
+    import oracle
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import parity
+    native = oracle.use_native()
+    cores = usable_cpus()
+    views = [parity.oracle_view(sg) for sg in segs]
+    osc = parity.oracle_scorer(scorer)
+
+    def run_and(flt):
+        terms = [t.term for t in flt.subs]
+        metas = np.stack([parity.metas_for(sg, terms) for sg in segs])
+        oracle.search(views, metas, oracle.OP_AND, osc, k, [t.boost for t in flt.subs])
+
+    def run_phrase(ph):
+        metas = np.stack([parity.metas_for(sg, ph.terms) for sg in segs])
+        oracle.search_phrase(views, metas, ph.offsets, osc, k, ph.boost)
+
+    tasks = []
+    for a, ph in zip(ands, phrases):
+        tasks += [(run_and, a), (run_phrase, ph)]
+
+    def timed(threads, n):
+        t0 = time.perf_counter()
+        with cf.ThreadPoolExecutor(threads) as ex:
+            list(ex.map(lambda t: t[0](t[1]), tasks[:n]))
+        return time.perf_counter() - t0
+
+    probe = min(len(tasks), 2 * cores)
+    dt = max(timed(cores, probe), 1e-6)
+    n = int(min(len(tasks), max(probe, probe * seconds_hint / dt)))
+    dt = timed(cores, n)
+    return {"value": round(n / dt, 3), "unit": "queries/s", "cores": cores, "kind": "port",
+            "flags": "-O3 -march=native" if native else "-O2 (native build failed)",
+            "sample": "%d queries (AND and by_phrase alternating, the bench's own) over %d segments "
+                      "on %d threads in %.1f s" % (n, len(segs), cores, dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -573,6 +617,11 @@ def main_config5(args):
                                  "kernels touch less than A(q))"},
             "cpu_baseline": None,
         }
+        if world == 1 and not sim and not args.no_cpu:
+            for b in bat.values():
+                b.close()
+            out["cpu_baseline"] = cpu_baseline_config5([segs[s] for s in range(n_segments)], ands,
+                                                       phrases, sc, k)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
