@@ -758,6 +758,11 @@ k_items_fill(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qt
   __shared__ uint32_t s_pre[kWaves][kMaxTerms + 1];  // exclusive prefix sums of the block counts
   __shared__ uint32_t s_b0[kWaves][kMaxTerms];
   __shared__ uint32_t s_ub[kWaves][kMaxTerms];       // WAND: per term, largest block-max score (float bits)
+  // per-term values every item of the term needs (read per lane with a lane-varying term
+  // slot: from LDS, not as gathers from the query / term records in global memory)
+  __shared__ uint64_t s_dir[kWaves][kMaxTerms];      // DevTail::dir_off
+  __shared__ float s_cs[kWaves][kMaxTerms];          // c0 * fixed-point scale
+  __shared__ uint32_t s_tf[kWaves][kMaxTerms];       // table slot | table_kind << 8 | sqrt_kind << 9
   const unsigned lane = threadIdx.x & 63u;
   const uint32_t wv = threadIdx.x >> 6;
   const uint32_t unit = blockIdx.x / tb;
@@ -777,6 +782,12 @@ k_items_fill(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qt
     b1 = b1 < tl[lane].nblk ? b1 : tl[lane].nblk;
     nb = b1 > b0 ? b1 - b0 : 0u;
     tail_here = tl[lane].n && tl[lane].first_doc < lo + tile_docs && tl[lane].last_doc >= lo;
+    const DevQTerm qt = qts[lane];
+    s_dir[wv][lane] = tl[lane].dir_off;
+    s_cs[wv][lane] = qt.c0 * qd.fx_mul;
+    s_tf[wv][lane] = (qt.cache_id < kMaxCaches ? qt.cache_id : 0u) |
+                     ((table_kind(qt.kind) && qt.cache_id < kMaxCaches) ? 0x100u : 0u) |
+                     (sqrt_kind(qt.kind) ? 0x200u : 0u);
   }
   const uint32_t incl = wave::inclusive_scan(nb);
   if (lane <= kMaxTerms) s_pre[wv][lane] = incl - nb;   // lanes >= n_terms hold the total
@@ -796,7 +807,7 @@ k_items_fill(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qt
   auto locate = [&](uint32_t g, uint32_t& j, uint64_t& e) {
     j = 0;
     for (uint32_t t = 1; t < qd.n_terms; ++t) j += s_pre[wv][t] <= g ? 1u : 0u;
-    e = tl[j].dir_off + s_b0[wv][j] + (g - s_pre[wv][j]);
+    e = s_dir[wv][j] + s_b0[wv][j] + (g - s_pre[wv][j]);
   };
   // the value of an ALL-EQUAL freq block: vint behind the doc part and the 0 header byte
   auto freq_const = [&](uint32_t j, const BlkDir& d) {
@@ -812,15 +823,16 @@ k_items_fill(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qt
   auto classify = [&](uint32_t j, const BlkDir& d, uint32_t& fconst) {
     fconst = 0;
     const uint32_t dbits = d.bits & 0xFFu, fbits = d.bits >> 8;
-    if (!(table_kind(qts[j].kind) && qts[j].cache_id < kMaxCaches && pk_units(dbits, fbits) != 0u))
-      return 0u;
+    const uint32_t tf = s_tf[wv][j];
+    if (!((tf & 0x100u) && pk_units(dbits, fbits) != 0u)) return 0u;
     if (query_merge(qd.op)) return 0u;   // Max/Min merged scores: the generic path's atomic max
+    const uint32_t general = (tf & 0x200u) ? 5u : 1u;
     if (fbits == 0u) {
       fconst = freq_const(j, d);
       if (fconst > 0xFFFFu) return 0u;
-      return fconst < rows ? 2u : (sqrt_kind(qts[j].kind) ? 5u : 1u);
+      return fconst < rows ? 2u : general;
     }
-    return (1u << fbits) <= rows ? 2u : (sqrt_kind(qts[j].kind) ? 5u : 1u);
+    return (1u << fbits) <= rows ? 2u : general;
   };
   for (uint32_t g0 = 0; g0 < n; g0 += 64) {   // (whole wavefront: shuffles inside)
     const uint32_t g = g0 + lane;
@@ -835,16 +847,17 @@ k_items_fill(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qt
         atomicMax(&s_ub[wv][j], __float_as_uint(block_bound(qts[j], seg.blk_maxf[e], seg.blk_minn[e])));
       cls = classify(j, d, fconst);
       const bool fast = cls != 0u;
-      const uint32_t slot = qts[j].cache_id < kMaxCaches ? qts[j].cache_id : 0u;
+      const uint32_t tf = s_tf[wv][j];
+      const uint32_t slot = tf & 0xFFu;
       I.addr = fast ? pk + (uint64_t(d.aoff) << 4)
                     : reinterpret_cast<uint64_t>(seg.doc) + tl[j].doc_start + d.off;
       I.dbits = d.bits & 0xFFu;
       I.fbits = d.bits >> 8;
       I.base = d.prev_last - lo;
-      I.cs = qts[j].c0 * qd.fx_mul;
+      I.cs = s_cs[wv][j];
       // table items: an all-equal frequency selects its row right here
       I.tab = caches_off + (slot * rows + (cls == 2u ? fconst : 0u)) * 1024u;
-      I.aux = j | (fast ? 0u : kItemSlow) | (sqrt_kind(qts[j].kind) ? kItemSqrt : 0u) |
+      I.aux = j | (fast ? 0u : kItemSlow) | ((tf & 0x200u) ? kItemSqrt : 0u) |
               (cls == 2u ? kItemTable : fconst << kItemFreqShift);
     } else if (g < n) {
       // the (g - n_blocks)-th term whose tail reaches into the tile
