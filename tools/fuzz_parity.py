@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Randomised differential run of the C ABI against the oracle (test infrastructure: imports
+oracle/ through tests/parity.py).  Every round builds a fresh segment (random size, vocabulary,
+layout, clustering, wand data, positions), a batch of random Or / And / min-match / by_term
+filters with random boosts and merge types (or by_phrase filters), a random scorer and k, and
+checks the results as the parity tests do; the same batch is then re-run with block-max pruning
+(top-k must not change) and with the k-th score pushed down as irs::score::Min.
+
+  python tools/fuzz_parity.py --seconds 120            # on the GPU (libirs_hip.so)
+  python tools/fuzz_parity.py --sim --seconds 60       # on the CPU emulator
+"""
+import argparse
+import ctypes
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=60)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--sim", action="store_true")
+    ap.add_argument("--max-docs", type=int, default=400_000)
+    args = ap.parse_args()
+    import parity
+    from iresearch_amd import _lib, search, synth
+    from iresearch_amd.search import (BM25, MERGE_MAX, MERGE_MIN, MERGE_SUM, TFIDF, And, Or,
+                                      by_phrase, by_term)
+    if args.sim:
+        L = _lib.bind(ctypes.CDLL(os.path.join(ROOT, "tests", "sim", "libirs_hip_sim.so")))
+        args.max_docs = min(args.max_docs, 40_000)
+    else:
+        L = _lib.lib()
+    rng = np.random.default_rng(args.seed)
+    t_end = time.time() + args.seconds
+    rounds = queries = 0
+    while time.time() < t_end:
+        docs = int(rng.integers(2_000, args.max_docs))
+        max_rank = int(rng.choice([32, 128, 512, 2048]))
+        layout = int(rng.integers(0, 2))
+        clustered = bool(rng.integers(0, 2))
+        wand_count = int(rng.integers(0, 2))
+        positions = bool(rng.integers(0, 3) == 0)
+        kw = dict(topic_docs=int(rng.choice([512, 2048, 8192])), topic_percent=85,
+                  topic_terms=12) if clustered else {}
+        seg = synth.build_segment(docs, max_rank, layout=layout, wand_count=wand_count,
+                                  with_positions=positions, seed=int(rng.integers(1, 1 << 30)), **kw)
+        sr = search.SegmentReader.from_synth(seg, L=L)
+        st = [parity.segment_stats(seg)]
+        scorer = [BM25(), BM25(1.2, 0.0), BM25(0.0, 0.0), BM25(2.0, 1.0), TFIDF(False),
+                  TFIDF(True)][int(rng.integers(0, 6))]
+        k = int(rng.choice([1, 10, 100, 1000]))
+
+        def term():
+            # mostly frequent ranks (Zipf), sometimes rare or absent ones
+            r = int(rng.integers(0, 4))
+            hi = [8, 64, max_rank, max_rank + 40][r]
+            return by_term(int(rng.integers(0, hi)), float(rng.choice([1.0, 1.0, 0.5, 2.5, 0.0])))
+
+        def merge():
+            return int(rng.choice([MERGE_SUM, MERGE_SUM, MERGE_MAX, MERGE_MIN]))
+
+        if positions and rng.integers(0, 2):
+            filters = [by_phrase([int(t) for t in rng.integers(0, min(max_rank, 48), int(rng.integers(1, 5)))])
+                       for _ in range(12)]
+            prep = search.prepare(filters, scorer, st)
+            b = sr.batch(prep, k)
+            hits, counts, totals = (x.copy() for x in b.run().results())
+            parity.check_phrase_segment(seg, filters, scorer, k, hits, counts, totals)
+        else:
+            filters = []
+            for _ in range(16):
+                n = int(rng.integers(1, 9))
+                subs = [term() for _ in range(n)]
+                kind = int(rng.integers(0, 4))
+                if kind == 0 or n == 1:
+                    filters.append(Or(subs, merge=merge()))
+                elif kind == 1:
+                    filters.append(And(subs[:int(rng.integers(2, 6))] if n > 2 else subs, merge=merge()))
+                elif kind == 2:
+                    filters.append(Or(subs, min_match=int(rng.integers(2, n + 1)), merge=merge()))
+                else:
+                    filters.append(subs[0])
+            prep = search.prepare(filters, scorer, st)
+            b = sr.batch(prep, k)
+            hits, counts, totals = (x.copy() for x in b.run().results())
+            parity.check_single_segment(seg, filters, scorer, k, hits, counts, totals)
+            # block-max pruning: the same top-k
+            wb = sr.batch(prep, k).set_wand(True)
+            wh, wc, wt = wb.run().results()
+            assert np.array_equal(counts, wc), "wand: counts"
+            for q in range(len(filters)):
+                assert np.array_equal(hits[q, :counts[q]], wh[q, :counts[q]]), ("wand: top-k", q)
+            assert (wt <= totals).all()
+            wb.close()
+        # irs::score::Min = the k-th score: the same top-k again
+        kth = np.array([hits[q, counts[q] - 1]["score"] if counts[q] else 0.0
+                        for q in range(len(filters))], np.float32)
+        h2, c2, t2 = b.set_min_scores(kth).run().results()
+        assert np.array_equal(c2, counts) and np.array_equal(t2, totals), "min score: counts"
+        for q in range(len(filters)):
+            assert np.array_equal(h2[q, :counts[q]], hits[q, :counts[q]]), ("min score: top-k", q)
+        b.close()
+        sr.close()
+        rounds += 1
+        queries += len(filters)
+    print("fuzz ok: %d rounds, %d queries, seed %d" % (rounds, queries, args.seed))
+
+
+if __name__ == "__main__":
+    main()
