@@ -298,6 +298,7 @@ k_conj(ConjArgs A, uint32_t pilot) {
   // ---- 1. the lead block: entry index 2*lane + h (block) or lane + 64*h (tail)
   uint32_t n = kBlock;
   uint32_t bytes = 0;   // (wave-uniform) encoded bytes of the blocks this wavefront decodes
+  const bool counting = !pilot && A.touched != nullptr;   // (irs_hip_batch_profile bit 1)
   auto block_bytes = [](uint32_t bits) {   // header bytes + payloads (all-equal: ~1 byte of vint)
     const uint32_t db = bits & 0xFFu, fb = bits >> 8;
     return 2u + (db ? 16u * db : 1u) + (fb ? 16u * fb : 1u);
@@ -308,7 +309,7 @@ k_conj(ConjArgs A, uint32_t pilot) {
     if (item < ld.nblk) {
       decode_dir_block<LAYOUT>(seg, ld.doc_start, R.bits, R.off, R.aoff, R.base, lane, ld_d[0],
                                ld_d[1], f[0], f[1]);
-      bytes += block_bytes(R.bits);
+      if (counting) bytes += block_bytes(R.bits);
       ld_e[0] = 2u * lane;
       estep = 1u;
     } else {
@@ -347,7 +348,7 @@ k_conj(ConjArgs A, uint32_t pilot) {
     for (int h = 0; h < 2; ++h) {
       const uint32_t sl = lane + 64u * uint32_t(h);
       const bool on = sl < n && cnt[sl] == g1;
-      scored += uint32_t(__builtin_popcountll(wave::ballot(on)));
+      if (counting) scored += uint32_t(__builtin_popcountll(wave::ballot(on)));
       if (on) {
         const uint32_t nv = norm_value(seg, docs[sl]);
         float v = score[sl];
@@ -470,7 +471,7 @@ k_conj(ConjArgs A, uint32_t pilot) {
           decode_dir_block<LAYOUT>(seg, tl.doc_start, kbits, wave::read_lane(d.off, k),
                                    wave::read_lane(d.aoff, k), wave::read_lane(d.prev_last, k),
                                    lane, d0, d1, f0, f1);
-          bytes += block_bytes(kbits);
+          if (counting) bytes += block_bytes(kbits);
           put(d0, f0);
           put(d1, f1);
         }
@@ -500,8 +501,8 @@ k_conj(ConjArgs A, uint32_t pilot) {
   if (h0) list[__builtin_popcountll(m0 & below)] = uint8_t(lane);
   if (h1) list[c0 + uint32_t(__builtin_popcountll(m1 & below))] = uint8_t(lane + 64u);
   wave::sync();
-  if (with_norm) bytes += total * seg.norm_width;
-  if (!pilot && A.touched && lane == 0)
+  if (counting && with_norm) bytes += total * seg.norm_width;
+  if (counting && lane == 0)
     atomicAdd(&A.touched[2u * unit], static_cast<unsigned long long>(bytes));
   for (uint32_t p0 = 0; p0 < total; p0 += 64) {
     const bool on = p0 + lane < total;

@@ -498,6 +498,7 @@ k_phrase(ConjArgs A, uint32_t pilot /*1: histogram the scores of the sampled lea
   // ---- 1. the lead block: entry index 2*lane + h (block) or lane + 64*h (tail)
   uint32_t n = kBlock;
   uint32_t bytes = 0;   // (wave-uniform) encoded bytes of the doc blocks this wavefront decodes
+  const bool counting = !pilot && A.touched != nullptr;   // (irs_hip_batch_profile bit 1)
   auto block_bytes = [](uint32_t bits) {
     const uint32_t db = bits & 0xFFu, fb = bits >> 8;
     return 2u + (db ? 16u * db : 1u) + (fb ? 16u * fb : 1u);
@@ -507,7 +508,7 @@ k_phrase(ConjArgs A, uint32_t pilot /*1: histogram the scores of the sampled lea
     uint32_t f[2], p[2], estep;
     if (item < ld.nblk) {
       const uint64_t eb = ld.dir_off + item;
-      bytes += block_bytes(R.bits);
+      if (counting) bytes += block_bytes(R.bits);
       uint32_t before;
       if (pk_both(R.bits & 0xFFu, R.bits >> 8)) {
         decode_packed_pos<LAYOUT>(seg.pk + (uint64_t(R.aoff) << 4), R.bits & 0xFFu, R.bits >> 8,
@@ -660,7 +661,7 @@ k_phrase(ConjArgs A, uint32_t pilot /*1: histogram the scores of the sampled lea
           const uint32_t k = uint32_t(__builtin_ctzll(mask));
           mask &= mask - 1;
           const uint32_t bits = wave::read_lane(d.bits, k);
-          bytes += block_bytes(bits);
+          if (counting) bytes += block_bytes(bits);
           const uint32_t base = wave::read_lane(d.prev_last, k);
           uint32_t d0, d1, f0, f1, before;
           const uint32_t dbits = bits & 0xFFu, fbits = bits >> 8;
