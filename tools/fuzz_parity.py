@@ -100,6 +100,23 @@ def main():
                 assert np.array_equal(hits[q, :counts[q]], wh[q, :counts[q]]), ("wand: top-k", q)
             assert (wt <= totals).all()
             wb.close()
+            # every third round: the same filters over several segments in ONE batch
+            # (irs_hip_batch_create_multi; statistics over all of them) — per segment the oracle's
+            if rounds % 3 == 0:
+                extra = [synth.build_segment(int(rng.integers(1_000, max(2_000, docs // 2))), max_rank,
+                                             layout=layout, first_doc=docs * (i + 1),
+                                             seed=int(rng.integers(1, 1 << 30)))
+                         for i in range(int(rng.integers(1, 3)))]
+                msegs = [seg] + extra
+                readers = [sr] + [search.SegmentReader.from_synth(x, L=L) for x in extra]
+                mprep = search.prepare(filters, scorer, [parity.segment_stats(x) for x in msegs])
+                mb = search.QueryBatch(readers, mprep, k)
+                mh, mc, mt = mb.run().results()
+                for i, x in enumerate(msegs):
+                    parity.check_single_segment(x, filters, scorer, k, mh[i], mc[i], mt[i], msegs)
+                mb.close()
+                for r in readers[1:]:
+                    r.close()
         # irs::score::Min = the k-th score: the same top-k again
         kth = np.array([hits[q, counts[q] - 1]["score"] if counts[q] else 0.0
                         for q in range(len(filters))], np.float32)
