@@ -118,6 +118,14 @@ int main() {
   filters.push_back(by_phrase{}.push_back(0).push_back(1));
   filters.push_back(by_phrase{}.push_back(2).push_back(0, 1).push_back(1));  // a gap of one word
   filters.push_back(by_term{kMaxRank + 500});                                  // no such term
+  {  // boolean_filter::merge_type(): kMax on a disjunction, kMin on a conjunction
+    Or mx{{by_term{4}, by_term{11}, by_term{40}}};
+    mx.merge_type = IRS_HIP_MERGE_MAX;
+    filters.push_back(mx);
+    And mn{{by_term{1}, by_term{6}}};
+    mn.merge_type = IRS_HIP_MERGE_MIN;
+    filters.push_back(mn);
+  }
 
   const BM25 scorer;  // k = 1.2, b = 0.75
   const auto prepared = prepare(filters, scorer, {a.stats(), b.stats()});
@@ -154,8 +162,9 @@ int main() {
     } else {
       if (const auto* f = std::get_if<And>(&filters[q]))
         for (uint32_t t = 0; t < n; ++t) boosts[t] = f->subs[t].boost;
-      const int32_t op = p.op == IRS_HIP_OP_MINMATCH ? (ORC_OP_MINMATCH | int32_t(p.min_match << 8))
-                                                     : p.op;
+      const int32_t op = (p.op == IRS_HIP_OP_MINMATCH ? (ORC_OP_MINMATCH | int32_t(p.min_match << 8))
+                                                      : p.op) |
+                         int32_t(p.merge << 24);   // ORC_MERGE_* == IRS_HIP_MERGE_*
       got_n = orc_search(views, 2, metas.data(), n, op, &osc, boosts.data(), dwf, ttf, kTop,
                          want.data(), &want_total);
     }
@@ -169,6 +178,25 @@ int main() {
     for (size_t i = 0; i < want.size(); ++i) REQUIRE(close_rel(mine[i].score, want[i].score));
   }
   REQUIRE(batch.reruns() == 0);
+  {
+    // planning queued ahead (irs_hip_batch_plan) changes nothing; irs::score::Min at every
+    // query's k-th score gives the same lists again
+    const auto planned = merge(batch.plan().run().results());
+    std::vector<float> kth(filters.size(), 0.f);
+    for (size_t q = 0; q < top.size(); ++q) {
+      REQUIRE(planned[q].size() == top[q].size());
+      for (size_t i = 0; i < top[q].size(); ++i)
+        REQUIRE(planned[q][i].score == top[q][i].score && planned[q][i].doc == top[q][i].doc);
+      if (!top[q].empty()) kth[q] = top[q].back().score;
+    }
+    const auto pushed = merge(batch.set_min_scores(kth).run().results());
+    for (size_t q = 0; q < top.size(); ++q) {
+      REQUIRE(pushed[q].size() == top[q].size());
+      for (size_t i = 0; i < top[q].size(); ++i)
+        REQUIRE(pushed[q][i].score == top[q][i].score && pushed[q][i].doc == top[q][i].doc);
+    }
+    batch.set_min_scores({});
+  }
   // the one-call form gives the same lists
   {
     const auto again = search({a.reader.get(), b.reader.get()}, {a.stats(), b.stats()}, filters,
