@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define IRS_HIP_ABI_VERSION 4
+#define IRS_HIP_ABI_VERSION 5
 #define IRS_HIP_BLOCK_SIZE 128u  /* postings per block, formats_10.cpp:90 */
 #define IRS_HIP_MAX_TERMS 16u    /* terms per boolean query               */
 #define IRS_HIP_MAX_K 4096u      /* largest top-k                         */
@@ -289,6 +289,23 @@ int irs_hip_query_batch(irs_hip_segment* seg, const irs_hip_query* queries,
 int irs_hip_batch_configure(irs_hip_batch* batch, uint32_t tile_docs,
                             uint32_t pilot_stride, uint32_t cand_cap);
 
+/* How the doc-tile units of a batch (Or / by_term / min-match) execute — a tuning / test knob,
+ * results are the same within one fixed-point unit per posting either way:
+ *   IRS_HIP_PATH_ITEMS   every query decodes the blocks of its own terms (work items);
+ *   IRS_HIP_PATH_JOINED  every DISTINCT (segment, term) of the batch is decoded once per run
+ *                        into a stream of (doc, tf, norm) entries which the queries then only
+ *                        accumulate — what block_disjunction::refill (disjunction.hpp:1240-1351)
+ *                        does per query, shared by the queries of a batch.  Only for plain
+ *                        disjunctions with table-family scorers (BM25 / BM15 / TF-IDF over 1-byte
+ *                        norms or none), sum merge, frequencies < 64, no block-max pruning;
+ *                        a batch that does not qualify runs as ITEMS whatever was asked;
+ *   IRS_HIP_PATH_AUTO    (default) JOINED where it applies.
+ * Call before the batch's first run (or after a configure). */
+enum { IRS_HIP_PATH_AUTO = 0, IRS_HIP_PATH_ITEMS = 1, IRS_HIP_PATH_JOINED = 2 };
+int irs_hip_batch_set_path(irs_hip_batch* batch, int path);
+/* Which one the batch's last run used (IRS_HIP_PATH_ITEMS / IRS_HIP_PATH_JOINED). */
+int irs_hip_batch_path(irs_hip_batch* batch, int* path);
+
 /* ExecutionContext::wand (filter.hpp:52-78; utils/index-search --search-mode wand): lets the
  * batch SKIP posting blocks that cannot reach the top k.  The bound of a block is the query
  * term's own score function on the block's (max freq, min norm) — what the wanderator
@@ -329,7 +346,8 @@ int irs_hip_segment_wand_source(irs_hip_segment* seg, uint64_t* from_index, uint
  * When enabled, every run() brackets each kernel launch with events;
  * timings() waits for the stream and returns the durations (ms) of the last run. */
 enum {
-  IRS_HIP_K_PLAN = 0,   /* block-range planning per (query, term)    */
+  IRS_HIP_K_PLAN = 0,   /* block-range planning per (query, term) + work items; joined path:
+                           the decode + norm join of the batch's distinct terms (k_join) */
   IRS_HIP_K_PILOT = 1,  /* pilot tiles -> per-query score threshold */
   IRS_HIP_K_SCORE = 2,  /* decode + score + accumulate + candidates (phrase batches: k_phrase) */
   IRS_HIP_K_SELECT = 3, /* exact top-k of the candidates            */

@@ -19,6 +19,7 @@ LAYOUT_SCALAR, LAYOUT_SIMD4 = 0, 1
 OP_OR, OP_AND, OP_MINMATCH, OP_PHRASE = 0, 1, 2, 3
 SCORE_BM25, SCORE_BM15, SCORE_BM1, SCORE_TFIDF, SCORE_TFIDF_NORM = 0, 1, 2, 3, 4
 NO_TERM = 0xFFFFFFFF
+PATH_AUTO, PATH_ITEMS, PATH_JOINED = 0, 1, 2
 MAX_TERMS, MAX_K, MAX_PHRASE_TERMS = 16, 4096, 8
 K_PLAN, K_PILOT, K_SCORE, K_SELECT, K_COUNT = 0, 1, 2, 3, 4
 KERNEL_NAMES = ("k_plan", "k_pilot", "k_score", "k_select")
@@ -64,6 +65,7 @@ SYMBOLS = (
     "irs_hip_query_batch", "irs_hip_batch_configure", "irs_hip_batch_profile",
     "irs_hip_batch_timings", "irs_hip_batch_work", "irs_hip_batch_reruns", "irs_hip_merge_topk",
     "irs_hip_batch_plan", "irs_hip_batch_set_wand", "irs_hip_batch_set_min_scores",
+    "irs_hip_batch_set_path", "irs_hip_batch_path",
     "irs_hip_term_blockmax",
     "irs_hip_segment_wand_source",
     "irs_hip_batch_touched",
@@ -118,6 +120,8 @@ def bind(L: C.CDLL) -> C.CDLL:
     L.irs_hip_merge_topk.restype = C.c_int
     L.irs_hip_batch_set_wand.argtypes, L.irs_hip_batch_set_wand.restype = [vp, C.c_int], C.c_int
     L.irs_hip_batch_plan.argtypes, L.irs_hip_batch_plan.restype = [vp, vp], C.c_int
+    L.irs_hip_batch_set_path.argtypes, L.irs_hip_batch_set_path.restype = [vp, C.c_int], C.c_int
+    L.irs_hip_batch_path.argtypes, L.irs_hip_batch_path.restype = [vp, P(C.c_int)], C.c_int
     L.irs_hip_segment_wand_source.argtypes = [vp, P(u64), P(u64)]
     L.irs_hip_segment_wand_source.restype = C.c_int
     L.irs_hip_batch_set_min_scores.argtypes = [vp, vp]

@@ -186,6 +186,17 @@ __device__ __forceinline__ void lds_add(const unsigned char*, uint32_t off, unsi
                          __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// 16 bytes of LDS at a 16-byte aligned offset: ds_read_b128 / ds_write_b128
+__device__ __forceinline__ void lds_read4(const unsigned char*, uint32_t off, uint32_t (&v)[4]) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 x = *(const IRS_LDS u32x4*)(uintptr_t)off;
+  v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+}
+__device__ __forceinline__ void lds_zero4(unsigned char*, uint32_t off) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  *(IRS_LDS u32x4*)(uintptr_t)off = u32x4{0u, 0u, 0u, 0u};
+}
+
 // LDS float accumulate without a returned value -> ds_add_f32
 __device__ __forceinline__ void lds_add(float* p, float v) { atomicAdd(p, v); }
 
@@ -211,6 +222,11 @@ __device__ __forceinline__ T sload(uint64_t addr) {
 __device__ __forceinline__ uint64_t gload_u64(uint64_t base, uint32_t off) {
   typedef uint64_t __attribute__((aligned(4))) u64a4;
   return *(const IRS_GLOBAL u64a4*)((const IRS_GLOBAL uint8_t*)base + off);
+}
+
+// 4 bytes at (wave-uniform 64-bit base) + (per-lane 32-bit offset): global_load_dword, saddr form
+__device__ __forceinline__ uint32_t gload_u32(uint64_t base, uint32_t off) {
+  return *(const IRS_GLOBAL uint32_t*)((const IRS_GLOBAL uint8_t*)base + off);
 }
 
 // Unaligned little-endian loads from the byte-granular `.doc` stream.

@@ -16,6 +16,7 @@
 #include "phrase.h"
 #include "score.h"
 #include "conj.h"
+#include "join.h"
 
 using namespace irs_hip;
 
@@ -125,7 +126,10 @@ struct irs_hip_batch {
   bool any_and = false;    // some unit counts matches per doc in the tile kernels (min-match)
   bool wand = false;       // irs_hip_batch_set_wand
   // units by the kernels that execute them: doc tiles (Or, min-match) / lead blocks (And)
-  std::vector<uint32_t> tile_units, conj_units;
+  // (all_tile_units: every doc-tile unit, fixed at create; ensure_scratch deals them to
+  // join_units — plain disjunctions run as joined posting streams, join.h — and tile_units —
+  // the rest, score.h's work items)
+  std::vector<uint32_t> all_tile_units, tile_units, join_units, conj_units;
   std::vector<uint32_t> conj_items;   // lead items of every conj unit
   uint32_t n_conj_wgs = 0;
   DevBuf d_tile_units, d_conj_units, d_conj_items, d_conj_hist;
@@ -155,6 +159,17 @@ struct irs_hip_batch {
   uint32_t score_threads = 0;  // threads per k_pilot / k_score workgroup (power of two x 64)
   uint32_t nw_log2 = 3;        // log2(wavefronts per such workgroup)
   uint64_t alg_bytes = 0, postings = 0;
+  // joined posting streams (join.h): every distinct (segment, term) of the batch decoded once
+  // per run.  path_pref: irs_hip_batch_set_path (0 auto, 1 work items, 2 joined streams).
+  int path_pref = 0;
+  bool joined = false;
+  DevBuf d_streams, d_join_wgs, d_jterms, d_entries, d_bounds, d_join_args, d_join_units,
+    d_join_order;
+  uint32_t join_max_tiles = 0;
+  uint32_t n_streams = 0, n_join_wgs = 0;
+  uint32_t join_threads = 512, join_nw_log2 = 3;   // threads per k_join_pilot / k_join_score workgroup
+  uint64_t join_entries = 0;
+  JoinArgs join_args{};
   bool profile = false;
   bool count_touched = false;   // irs_hip_batch_profile bit 1: the kernels count what they decode
   bool events_ready = false;
@@ -611,9 +626,209 @@ int prepare_blockmax(irs_hip_segment* s) {
   return IRS_HIP_OK;
 }
 
+// ---- joined posting streams (join.h) ----------------------------------------------------
+// Can the batch's doc-tile units run as joined streams?  (Anything else keeps score.h's work
+// items: per-doc match counters, Max / Min merged scores, scorers outside the table family,
+// 64-bit accumulators, a frequency that does not fit an entry, block-max pruning.)
+bool join_allowed(const irs_hip_batch* b) {   // batch level
+  if (b->path_pref == IRS_HIP_PATH_ITEMS) return false;
+  if (const char* e = std::getenv("IRS_HIP_JOIN")) {   // tuning / test knob
+    if (std::atoi(e) == 0 && b->path_pref != IRS_HIP_PATH_JOINED) return false;
+  }
+  return !b->phrase && b->acc32 && !b->wand;
+}
+bool unit_counts_matches(const DevQuery& dq) {   // min-match / the kMin disjunction of two
+  return (dq.op & 0xFF) == 1 || query_min_both(dq.op);
+}
+bool unit_joinable(const irs_hip_batch* b, uint32_t u) {
+  const DevQuery& dq = b->queries[u];
+  if ((dq.op & 0xFF) != 0 || query_min_both(dq.op) || query_merge(dq.op) != kScoreSum) return false;
+  const irs_hip_segment* sg = b->segs[dq.seg];
+  for (uint32_t j = 0; j < dq.n_terms; ++j) {
+    const DevQTerm& qt = b->qterms[dq.first_term + j];
+    if (!table_kind(qt.kind) || qt.cache_id >= kMaxCaches) return false;
+    if (sg->terms[qt.term].tf_bound > kJoinTfMax) return false;
+  }
+  return true;
+}
+
+// The batch's distinct (segment, term) streams, k_join's work list and the per-(unit, term)
+// records of k_join_score.  Static per batch: built once, the kernels refill the entries and
+// boundaries in every run.
+bool build_streams(irs_hip_batch* b) {
+  std::vector<StreamRec> streams;
+  std::vector<JoinWg> wgs;
+  std::vector<JoinTerm> jterms(b->qterms.size());
+  std::vector<uint64_t> key_of;   // sorted (segment << 32 | term) -> stream
+  {
+    for (uint32_t u : b->join_units) {
+      const DevQuery& dq = b->queries[u];
+      for (uint32_t j = 0; j < dq.n_terms; ++j)
+        key_of.push_back((uint64_t(dq.seg) << 32) | b->qterms[dq.first_term + j].term);
+    }
+    std::sort(key_of.begin(), key_of.end());
+    key_of.erase(std::unique(key_of.begin(), key_of.end()), key_of.end());
+  }
+  uint64_t entries = 0, bounds = 0;
+  std::vector<uint64_t> ent_off, bnd_off;
+  for (const uint64_t key : key_of) {
+    const uint32_t sgi = uint32_t(key >> 32), term = uint32_t(key);
+    const irs_hip_segment* sg = b->segs[sgi];
+    const DevTerm& t = sg->terms[term];
+    StreamRec r{};
+    r.seg = sgi;
+    r.term = term;
+    r.n = t.docs_count;
+    ent_off.push_back(entries);
+    bnd_off.push_back(bounds);
+    const uint32_t n_tiles = (sg->dev.num_docs + kJoinTile - 1) / kJoinTile;
+    const uint32_t nb = t.nblk + ((t.docs_count == 1 || t.tail_n) ? 1u : 0u);
+    for (uint32_t first = 0; first < nb; first += kJoinBlocks)
+      wgs.push_back(JoinWg{uint32_t(streams.size()), first});
+    entries += t.docs_count;
+    bounds += uint64_t(n_tiles) + 1;
+    streams.push_back(r);
+  }
+  if (wgs.size() > 0x7FFFFFFFull) return false;
+  if (!b->d_entries.alloc((entries + kJoinSlack) * 4) || !b->d_bounds.alloc((bounds + 1) * 4) ||
+      !b->d_streams.alloc(std::max<size_t>(1, streams.size()) * sizeof(StreamRec)) ||
+      !b->d_join_wgs.alloc(std::max<size_t>(1, wgs.size()) * sizeof(JoinWg)) ||
+      !b->d_jterms.alloc(jterms.size() * sizeof(JoinTerm)) ||
+      !b->d_join_args.alloc(sizeof(JoinArgs)) ||
+      !b->d_join_units.alloc(b->join_units.size() * 4) ||
+      !b->d_join_order.alloc(b->join_units.size() * 4))
+    return false;
+  // k_join_score's queue order: heaviest units first within every chunk round, segment by
+  // segment (as for k_score)
+  std::vector<uint32_t> order;
+  {
+    std::vector<std::pair<uint64_t, uint32_t>> work;
+    for (uint32_t u : b->join_units) {
+      const DevQuery& dq = b->queries[u];
+      uint64_t w = 0;
+      for (uint32_t j = 0; j < dq.n_terms; ++j)
+        w += b->segs[dq.seg]->terms[b->qterms[dq.first_term + j].term].docs_count;
+      work.push_back({w, u});
+    }
+    std::stable_sort(work.begin(), work.end(), [&](const auto& x, const auto& y) {
+      const uint32_t sx = b->queries[x.second].seg, sy = b->queries[y.second].seg;
+      return sx != sy ? sx < sy : x.first > y.first;
+    });
+    for (const auto& w : work) order.push_back(w.second);
+  }
+  for (size_t i = 0; i < streams.size(); ++i) {
+    streams[i].entries = reinterpret_cast<uint64_t>(b->d_entries.as<uint32_t>() + ent_off[i]);
+    streams[i].bounds = reinterpret_cast<uint64_t>(b->d_bounds.as<uint32_t>() + bnd_off[i]);
+  }
+  for (uint32_t u : b->join_units) {
+    const DevQuery& dq = b->queries[u];
+    const uint32_t rows = table_rows(dq.n_caches);
+    for (uint32_t j = 0; j < dq.n_terms; ++j) {
+      const DevQTerm& qt = b->qterms[dq.first_term + j];
+      const uint64_t key = (uint64_t(dq.seg) << 32) | qt.term;
+      const size_t sid = size_t(std::lower_bound(key_of.begin(), key_of.end(), key) - key_of.begin());
+      JoinTerm& jt = jterms[dq.first_term + j];
+      jt.entries = streams[sid].entries;
+      jt.bounds = streams[sid].bounds;
+      jt.cs = qt.c0 * dq.fx_mul;
+      jt.mode = (qt.cache_id * rows * 1024u) |
+                (qt.pad1 >= rows ? kJoinGeneral : 0u) |
+                (sqrt_kind(qt.kind) ? kJoinSqrt : 0u);
+    }
+  }
+  // (the slack behind the last stream is only ever read by masked-off look-ahead: zero it once)
+  if (!rt::dmemset(b->d_entries.as<uint32_t>() + entries, 0, kJoinSlack * 4, nullptr) ||
+      !rt::h2d(b->d_streams.p, streams.data(), streams.size() * sizeof(StreamRec), nullptr) ||
+      !rt::h2d(b->d_join_wgs.p, wgs.data(), wgs.size() * sizeof(JoinWg), nullptr) ||
+      !rt::h2d(b->d_jterms.p, jterms.data(), jterms.size() * sizeof(JoinTerm), nullptr) ||
+      !rt::h2d(b->d_join_units.p, b->join_units.data(), b->join_units.size() * 4, nullptr) ||
+      !rt::h2d(b->d_join_order.p, order.data(), order.size() * 4, nullptr) ||
+      !rt::sync(nullptr))
+    return false;
+  b->n_streams = uint32_t(streams.size());
+  b->n_join_wgs = uint32_t(wgs.size());
+  b->join_entries = entries;
+  return true;
+}
+
+bool launch_join(irs_hip_batch* b, rt::stream_t st) {
+  if (!b->n_join_wgs) return true;
+  if (b->seg->dev.layout == kSimd4) {
+    RT_LAUNCH((k_join<kSimd4>), b->n_join_wgs, kThreads, 0, st, b->d_segs.as<DevSegment>(),
+              b->d_streams.as<StreamRec>(), b->d_join_wgs.as<JoinWg>());
+  } else {
+    RT_LAUNCH((k_join<kScalar>), b->n_join_wgs, kThreads, 0, st, b->d_segs.as<DevSegment>(),
+              b->d_streams.as<StreamRec>(), b->d_join_wgs.as<JoinWg>());
+  }
+  return rt::last_error_ok();
+}
+
+bool launch_join_pilot(irs_hip_batch* b, rt::stream_t st) {
+  const size_t smem = JoinOff::end + kBins * sizeof(uint32_t);
+  if (!big_smem(k_join_pilot, smem)) return false;
+  RT_LAUNCH(k_join_pilot, uint32_t(b->join_units.size()), b->join_threads, smem, st,
+            b->d_join_units.as<uint32_t>(), b->d_queries.as<DevQuery>(),
+            b->d_qterms.as<DevQTerm>(), b->d_jterms.as<JoinTerm>(), b->stride_eff,
+            b->join_nw_log2, b->d_bstar.as<uint32_t>(), b->estimate ? kPilotMargin : 0u,
+            min_bins(b));
+  return rt::last_error_ok();
+}
+
+bool launch_join_score(irs_hip_batch* b, rt::stream_t st) {
+  const size_t smem = JoinOff::end;
+  if (!big_smem(k_join_score, smem)) return false;
+  const uint32_t waves = b->join_threads / 64;
+  uint32_t per_cu = uint32_t((160u * 1024u) / smem);
+  per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 32u / waves));
+  const uint32_t cpq = (b->join_max_tiles + kJoinChunkTiles - 1) / kJoinChunkTiles;
+  const uint32_t n_units = uint32_t(b->join_units.size());
+  const uint64_t chunks = uint64_t(n_units) * cpq;
+  if (chunks > 0xFFFF0000ull) return false;
+  const uint32_t grid = uint32_t(std::min<uint64_t>(chunks, uint64_t(b->seg->cus) * per_cu));
+  JoinArgs& a = b->join_args;   // read by the kernel from device memory
+  a.queries = b->d_queries.as<DevQuery>();
+  a.qterms = b->d_qterms.as<DevQTerm>();
+  a.jterms = b->d_jterms.as<JoinTerm>();
+  a.bstar = b->d_bstar.as<uint32_t>();
+  a.cands = b->d_cands.as<uint64_t>();
+  a.cand_count = b->d_cand_count.as<uint32_t>();
+  a.hits = b->d_hits.as<unsigned long long>();
+  a.order = b->d_join_order.as<uint32_t>();
+  a.work_counter = b->d_work.as<uint32_t>() + 1;   // ([0] is k_score's)
+  a.cpq = cpq;
+  a.n_units = n_units;
+  a.nw_log2 = b->join_nw_log2;
+  a.cand_cap = b->cand_cap;
+  if (!rt::dmemset(b->d_work.as<uint32_t>() + 1, 0, 4, st) ||
+      !rt::h2d(b->d_join_args.p, &a, sizeof a, st))
+    return false;
+  RT_LAUNCH(k_join_score, grid, b->join_threads, smem, st, b->d_join_args.as<JoinArgs>());
+  return rt::last_error_ok();
+}
+
 bool ensure_scratch(irs_hip_batch* b) {
   if (b->scratch_ready) return true;
   if (b->phrase) b->tile = 0x40000000u;  // k_phrase is block driven: one "tile" = the segment
+  // 32-bit accumulators halve the LDS per doc: twice the tile at the same residency
+  // the largest tile that still lets two workgroups share a CU's 160 KB of LDS
+  // (AND / min-match batches also keep a match counter byte per doc)
+  // doc-tile units: plain disjunctions run as joined posting streams (join.h), the others as
+  // work items (score.h)
+  {
+    const bool allow = join_allowed(b);
+    b->tile_units.clear();
+    b->join_units.clear();
+    b->any_and = false;
+    for (uint32_t u : b->all_tile_units) {
+      if (allow && unit_joinable(b, u)) {
+        b->join_units.push_back(u);
+      } else {
+        b->tile_units.push_back(u);
+        b->any_and = b->any_and || unit_counts_matches(b->queries[u]);
+      }
+    }
+    b->joined = !b->join_units.empty();
+  }
   // 32-bit accumulators halve the LDS per doc: twice the tile at the same residency
   // the largest tile that still lets two workgroups share a CU's 160 KB of LDS
   // (AND / min-match batches also keep a match counter byte per doc)
@@ -624,17 +839,27 @@ bool ensure_scratch(irs_hip_batch* b) {
   uint64_t first_words = 0, tiles = 0, item_bound = kItemSlack;
   b->n_tiles = 0xFFFFFFFFu;
   b->max_tiles = 0;
+  b->join_max_tiles = 0;
+  std::vector<uint8_t> is_join(b->nq, 0);
+  for (uint32_t u : b->join_units) is_join[u] = 1;
   for (uint32_t u = 0; u < b->nq; ++u) {
     DevQuery& dq = b->queries[u];
     const bool tiled = !b->phrase && (dq.op & 0xFF) != 2;   // conjunctions are block driven
-    dq.n_tiles = tiled ? (b->segs[dq.seg]->dev.num_docs + b->tile - 1) / b->tile : 0u;
+    const uint32_t tile_docs = is_join[u] ? kJoinTile : b->tile;   // (streams are cut at kJoinTile)
+    dq.n_tiles = tiled ? (b->segs[dq.seg]->dev.num_docs + tile_docs - 1) / tile_docs : 0u;
     if (b->phrase) dq.n_tiles = 1;
+    if (tiled) b->n_tiles = std::min(b->n_tiles, dq.n_tiles);
+    if (is_join[u]) {   // no plan table, no work items (k_plan / k_items_* skip the unit)
+      dq.first_off = kNoPlan;
+      dq.tile_base = 0;
+      b->join_max_tiles = std::max(b->join_max_tiles, dq.n_tiles);
+      continue;
+    }
     dq.first_off = first_words;
     first_words += uint64_t(dq.n_tiles + 1) * b->jt;
     if (tiles + dq.n_tiles > 0xFFFFFF00ull) return false;
     dq.tile_base = uint32_t(tiles);
     tiles += dq.n_tiles;
-    if (tiled) b->n_tiles = std::min(b->n_tiles, dq.n_tiles);
     b->max_tiles = std::max(b->max_tiles, dq.n_tiles);
     if (tiled) {
       for (uint32_t j = 0; j < dq.n_terms; ++j)
@@ -662,7 +887,7 @@ bool ensure_scratch(irs_hip_batch* b) {
     });
     for (uint32_t i = 0; i < work.size(); ++i) b->queries[i].run_unit = work[i].second;
   }
-  b->stride_eff = b->tile_units.empty()
+  b->stride_eff = b->all_tile_units.empty()
                       ? b->stride
                       : std::max<uint32_t>(1, std::min<uint32_t>(b->stride, b->n_tiles / 2));
   if (const char* e = std::getenv("IRS_HIP_WG_THREADS")) {  // tuning knob
@@ -678,6 +903,12 @@ bool ensure_scratch(irs_hip_batch* b) {
     b->nw_log2 = 0;
     while ((64u << b->nw_log2) < b->score_threads) ++b->nw_log2;
   }
+  if (const char* e = std::getenv("IRS_HIP_JOIN_THREADS")) {  // tuning knob
+    const uint32_t t = uint32_t(std::atoi(e));
+    if (t == 256 || t == 512 || t == 1024) b->join_threads = t;
+  }
+  b->join_nw_log2 = 0;
+  while ((64u << b->join_nw_log2) < b->join_threads) ++b->join_nw_log2;
   if (b->cand_cap == 0) b->cand_cap = default_cand_cap(b);
   const uint64_t rows = uint64_t(b->nq) * b->jt;
   if (!rt::h2d(b->d_queries.p, b->queries.data(), b->queries.size() * sizeof(DevQuery), nullptr) ||
@@ -691,8 +922,15 @@ bool ensure_scratch(irs_hip_batch* b) {
       !b->d_hits.alloc(b->nq * sizeof(uint64_t)) ||
       !b->d_out.alloc(uint64_t(b->nq) * b->k_max * sizeof(Hit)) ||
       !b->d_out_count.alloc(b->nq * sizeof(uint32_t)) || !b->d_status.alloc(4) ||
-      !b->d_work.alloc(4) || !b->d_touched.alloc(uint64_t(b->nq) * 16))
+      !b->d_work.alloc(8) || !b->d_touched.alloc(uint64_t(b->nq) * 16))
     return false;
+  if (b->joined && !build_streams(b)) return false;
+  if (!b->tile_units.empty()) {
+    if (!b->d_tile_units.alloc(b->tile_units.size() * 4) ||
+        !rt::h2d(b->d_tile_units.p, b->tile_units.data(), b->tile_units.size() * 4, nullptr) ||
+        !rt::sync(nullptr))
+      return false;
+  }
   if (!b->phrase && !b->tile_units.empty()) {
     const uint64_t parts = (tiles + 1 + kScanChunk - 1) / kScanChunk;
     if (!b->d_tile_off.alloc((tiles + 1) * sizeof(uint32_t)) ||
@@ -1187,6 +1425,7 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
           continue;
         }
         const DevTerm& t = seg->terms[qt.term];
+        qt.pad1 = t.tf_bound;
         {
           // smallest score one posting of this term can have (tf = 1, longest doc)
           const double c0 = qt.c0, nc = qt.norm_const, nl = qt.norm_length;
@@ -1281,7 +1520,7 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
         }
       }
       dq.op |= int32_t(merge << 16);
-      if (!is_phrase) ((dq.op & 0xFF) == 2 ? b->conj_units : b->tile_units).push_back(q);
+      if (!is_phrase) ((dq.op & 0xFF) == 2 ? b->conj_units : b->all_tile_units).push_back(q);
       // table slots (kernels.h "table_kind"): one per distinct (kind, norm_const, norm_length)
       uint32_t n_caches = 0;
       float cnc[kMaxCaches], cnl[kMaxCaches];
@@ -1448,13 +1687,6 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
       rc = IRS_HIP_ENOMEM;
     }
   }
-  if (rc == IRS_HIP_OK && !b->tile_units.empty()) {
-    if (!b->d_tile_units.alloc(b->tile_units.size() * 4))
-      rc = IRS_HIP_ENOMEM;
-    else if (!rt::h2d(b->d_tile_units.p, b->tile_units.data(), b->tile_units.size() * 4, nullptr) ||
-             !rt::sync(nullptr))
-      rc = IRS_HIP_EHIP;
-  }
   if (rc == IRS_HIP_OK) {
     if (b->jt == 0) b->jt = 1;
     if (b->qterms.empty()) b->qterms.push_back(DevQTerm{});
@@ -1494,6 +1726,23 @@ static int batch_configure_impl(irs_hip_batch* b, uint32_t tile_docs, uint32_t p
   if (pilot_stride) b->stride = pilot_stride;
   b->cand_cap = cand_cap;
   b->scratch_ready = false;
+  b->planned = false;   // a plan queued ahead used the old geometry: run() plans inline
+  return IRS_HIP_OK;
+}
+
+static int batch_set_path_impl(irs_hip_batch* b, int path) {
+  if (!b || path < IRS_HIP_PATH_AUTO || path > IRS_HIP_PATH_JOINED) return IRS_HIP_EINVAL;
+  if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
+  if (b->ran && !rt::sync(b->stream)) return IRS_HIP_EHIP;
+  b->path_pref = path;
+  b->scratch_ready = false;
+  b->planned = false;   // (a plan queued ahead was made for the other path)
+  return IRS_HIP_OK;
+}
+
+static int batch_path_impl(irs_hip_batch* b, int* path) {
+  if (!b || !path) return IRS_HIP_EINVAL;
+  *path = b->joined ? IRS_HIP_PATH_JOINED : IRS_HIP_PATH_ITEMS;
   return IRS_HIP_OK;
 }
 
@@ -1502,6 +1751,9 @@ static int batch_set_wand_impl(irs_hip_batch* b, int enable) {
   if (b->ran) return IRS_HIP_EINVAL;   // before the first run: the segment records are uploaded once
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
   b->wand = enable != 0;
+  // a plan queued ahead (irs_hip_batch_plan) was made without the tile bounds: run() re-plans
+  b->planned = false;
+  b->scratch_ready = false;   // (which path the batch takes depends on it)
   if (!b->wand) return IRS_HIP_OK;
   std::vector<DevSegment> dsegs;
   for (irs_hip_segment* sg : b->segs) {
@@ -1630,12 +1882,14 @@ static int batch_profile_impl(irs_hip_batch* b, int enable) {
 static bool plan_stage(irs_hip_batch* b, rt::stream_t st) {
   auto mark = [&](int i) { return !b->profile || rt::event_record(b->ev[i], st); };
   bool ok = mark(2 * IRS_HIP_K_PLAN);
-  if (ok) {
+  // (a joined batch without conjunctions needs none of k_plan's tables)
+  if (ok && (b->phrase || !b->tile_units.empty() || !b->conj_units.empty())) {
     RT_LAUNCH(k_plan, b->nq * b->jt, kThreads, 0, st, b->d_segs.as<DevSegment>(),
               b->d_queries.as<DevQuery>(), b->d_qterms.as<DevQTerm>(), b->jt, b->tile,
               b->d_first.as<uint32_t>(), b->d_tails.as<DevTail>());
     ok = rt::last_error_ok();
   }
+  if (ok && b->joined) ok = launch_join(b, st);
   if (ok && !b->phrase && !b->tile_units.empty()) ok = launch_items(b, st);
   return ok && mark(2 * IRS_HIP_K_PLAN + 1);
 }
@@ -1674,6 +1928,7 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st) {
   }
   // 2. pilot: per-query score-bin threshold (phrase batches have none: few docs match)
   ok = ok && mark(2 * IRS_HIP_K_PILOT);
+  if (b->joined) ok = ok && launch_join_pilot(b, st);
   if (tiles)
     ok = ok && (simd ? launch_pilot_acc<kSimd4>(b, st) : launch_pilot_acc<kScalar>(b, st));
   ok = ok && mark(2 * IRS_HIP_K_PILOT + 1);
@@ -1683,6 +1938,7 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st) {
     ok = ok && (simd ? launch_phrase_terms<kSimd4>(b, st) : launch_phrase_terms<kScalar>(b, st));
   else if (tiles)
     ok = ok && (simd ? launch_score_acc<kSimd4>(b, st) : launch_score_acc<kScalar>(b, st));
+  if (b->joined) ok = ok && launch_join_score(b, st);
   if (!b->phrase) ok = ok && (simd ? launch_conj<kSimd4>(b, st) : launch_conj<kScalar>(b, st));
   ok = ok && mark(2 * IRS_HIP_K_SCORE + 1);
   // 4. exact top-k
@@ -1963,6 +2219,12 @@ int irs_hip_batch_configure(irs_hip_batch* b, uint32_t tile_docs, uint32_t pilot
 }
 int irs_hip_batch_profile(irs_hip_batch* b, int enable) {
   return guarded([&] { return batch_profile_impl(b, enable); });
+}
+int irs_hip_batch_set_path(irs_hip_batch* b, int path) {
+  return guarded([&] { return batch_set_path_impl(b, path); });
+}
+int irs_hip_batch_path(irs_hip_batch* b, int* path) {
+  return guarded([&] { return batch_path_impl(b, path); });
 }
 int irs_hip_batch_set_wand(irs_hip_batch* b, int enable) {
   return guarded([&] { return batch_set_wand_impl(b, enable); });

@@ -1,0 +1,583 @@
+// join.h — disjunctions over JOINED POSTING STREAMS: every distinct (segment, term) of a
+// batch is decoded ONCE per run, whatever the number of queries that use it.
+//
+//   k_join        decode + norm join: one 4-byte entry per posting
+//                    [ (doc - tile's first doc) * 4 : 16 | tf : 6 | norm : 8 | 00 ]
+//                 in posting order, plus the entry index at which every doc tile starts
+//   k_join_pilot  scores every P-th doc tile, derives a per-query score-bin threshold
+//   k_join_score  accumulates the streams of a query's terms tile by tile in LDS, emits the
+//                 candidates above the threshold, counts hits
+//
+// Replaces, like score.h, block_disjunction::refill (disjunction.hpp:1240-1351) and
+// basic_disjunction (:204-358) — and it is literally the pipeline BASELINE.json's north_star
+// names: a decode kernel (bit-exact doc ids and frequencies, wavefront prefix sum) followed by
+// the candidate / score-accumulation kernel.  Why a second organisation next to score.h's work
+// items: PMC showed k_score bound by instruction issue with ~70 wave-instructions per 64
+// postings, 24 of them the decode itself and the rest per-(query, tile, block) bookkeeping,
+// while the queries of a batch share their frequent terms (log-uniform ranks: a top-octave
+// term is used by ~60 of 1000 queries).  An entry is query independent — the score of a
+// posting is c0 * T[tf][norm] with a table that only depends on the scorer — so a query's
+// posting costs: one coalesced 4-byte load, one table read, one multiply-add, one LDS add.
+//
+// The score arithmetic is score.h's (same tables, same fixed point): results differ from the
+// work-item path by at most one fixed-point unit per posting, where the two classify a
+// posting differently (table row vs. general expression).
+//
+// Eligibility (anything else runs on score.h's kernels): plain disjunctions (no per-doc match
+// counters), sum merge, scorers of the table family over 1-byte norms or none, 32-bit
+// accumulators, every term's frequencies below 64, no block-max pruning.
+#pragma once
+#include "score.h"
+
+namespace irs_hip {
+
+constexpr uint32_t kJoinTile = 12288;     // docs per accumulator tile (48 KB of u32 in LDS)
+constexpr uint32_t kJoinTfMax = 63;       // entry layout: 6 bits of tf
+constexpr uint32_t kJoinBlocks = 16;      // blocks per k_join workgroup
+constexpr uint32_t kJoinChunkTiles = 16;  // consecutive tiles of one unit per work-queue item
+constexpr uint32_t kJoinCands = 256;      // candidate staging slots per chunk (x2 buffers)
+constexpr uint32_t kJoinSlack = 1024;     // readable entries behind the last stream
+
+enum : uint32_t {
+  kJoinGeneral = 1u << 30,   // JoinTerm::mode: some tf of the term has no table row
+  kJoinSqrt = 1u << 31,      //   square-root score form (TF-IDF family)
+  kJoinTabMask = 0xFFFFu,    //   LDS byte offset of the term's table slot inside the tables
+};
+
+// One distinct (segment, term) of a batch: where its entries and tile boundaries live.
+struct alignas(16) StreamRec {
+  uint64_t entries;   // device address of the first entry (u32 each, posting order)
+  uint64_t bounds;    // device address of bounds[0 .. n_tiles]: entry index of the first
+                      // posting with doc >= tile's first doc; bounds[n_tiles] = n
+  uint32_t seg, term;
+  uint32_t n;         // postings
+  uint32_t pad;
+};
+struct JoinWg {       // k_join work: kJoinBlocks blocks (the tail counts as one) of a stream
+  uint32_t stream;
+  uint32_t first;
+};
+// Per (unit, term slot), parallel to DevQTerm: all k_join_score needs in one 32-byte record.
+struct alignas(16) JoinTerm {
+  uint64_t entries;
+  uint64_t bounds;
+  float cs;          // c0 * the unit's fixed-point scale
+  uint32_t mode;     // table slot offset | kJoinGeneral | kJoinSqrt
+  uint32_t pad[2];
+};
+static_assert(sizeof(JoinTerm) == 32, "JoinTerm");
+
+__host__ __device__ __forceinline__ uint32_t join_entry(uint32_t idx, uint32_t tf, uint32_t norm) {
+  return (idx << 18) | ((tf & kJoinTfMax) << 10) | ((norm & 0xFFu) << 2);
+}
+
+// ------------------------------------------------------------------ join --
+
+// One workgroup = kJoinBlocks consecutive blocks of one stream, a wavefront per block: decode
+// (decode.h: bit-exact doc ids + frequencies), read the doc's norm byte, write the entries
+// (coalesced: posting i is entry i), and note where doc tiles begin.
+template<int LAYOUT>
+__global__ void __launch_bounds__(kThreads)
+k_join(const DevSegment* segs, const StreamRec* streams, const JoinWg* wgs) {
+  const unsigned lane = threadIdx.x & 63u;
+  const uint32_t wv = threadIdx.x >> 6;
+  const JoinWg wg = wgs[blockIdx.x];
+  const StreamRec S = streams[wg.stream];
+  const DevSegment& seg = segs[S.seg];
+  const DevTerm t = seg.terms[S.term];
+  uint32_t* ent = reinterpret_cast<uint32_t*>(S.entries);
+  uint32_t* bnd = reinterpret_cast<uint32_t*>(S.bounds);
+  const uint32_t n_tiles = (seg.num_docs + kJoinTile - 1u) / kJoinTile;
+  const uint32_t tail_n = t.docs_count == 1u ? 1u : t.tail_n;
+  const uint32_t nb = t.nblk + (tail_n ? 1u : 0u);
+  const bool tiny = seg.norms && seg.norm_width == 1u && !seg.norm_legacy;
+  uint32_t end = wg.first + kJoinBlocks;
+  if (end > nb) end = nb;
+  for (uint32_t b = wg.first + wv; b < end; b += kWaves) {   // (b is wave-uniform)
+    uint32_t d0 = 0, d1 = 0, f0 = 0, f1 = 0, prev = 0;
+    bool v0 = true, v1 = true;
+    if (b < t.nblk) {
+      const BlkDir d = seg.blk_dir[t.dir_off + b];
+      decode_block<LAYOUT, true>(seg.doc + t.doc_start + d.off, d.bits & 0xFFu, d.bits >> 8,
+                                 d.prev_last, lane, d0, d1, f0, f1);
+      prev = b ? d.prev_last : 0u;   // (0: this is the list's first posting)
+    } else {
+      // the vint tail / single doc, decoded when the segment was opened
+      const uint32_t i0 = 2u * lane;
+      v0 = i0 < tail_n;
+      v1 = i0 + 1u < tail_n;
+      if (v0) { d0 = seg.tail_docs[t.tail_row + i0]; f0 = seg.tail_freqs[t.tail_row + i0]; }
+      if (v1) { d1 = seg.tail_docs[t.tail_row + i0 + 1u]; f1 = seg.tail_freqs[t.tail_row + i0 + 1u]; }
+      prev = t.nblk ? t.tail_base : 0u;
+    }
+    const uint32_t p0 = kBlock * b + 2u * lane;
+    const uint32_t t0 = v0 ? (d0 - kDocMin) / kJoinTile : 0u;
+    const uint32_t t1 = v1 ? (d1 - kDocMin) / kJoinTile : t0;
+    const uint32_t n0 = (v0 && tiny) ? seg.norms[d0 - seg.norm_min_doc] : 0u;
+    const uint32_t n1 = (v1 && tiny) ? seg.norms[d1 - seg.norm_min_doc] : 0u;
+    const uint32_t e0 = join_entry((d0 - kDocMin) - t0 * kJoinTile, f0, n0);
+    const uint32_t e1 = join_entry((d1 - kDocMin) - t1 * kJoinTile, f1, n1);
+    if (v1) {
+      uint64_t both = (uint64_t(e1) << 32) | e0;
+      __builtin_memcpy(ent + p0, &both, 8);
+    } else if (v0) {
+      ent[p0] = e0;
+    }
+    // tile boundaries: posting p opens every tile in (tile of posting p - 1, tile of p]
+    const uint32_t up = __shfl_up(t1, 1, 64);
+    int32_t tp = lane ? int32_t(up) : (prev ? int32_t((prev - kDocMin) / kJoinTile) : -1);
+    if (v0) {
+      for (int32_t u = tp + 1; u <= int32_t(t0); ++u) bnd[u] = p0;
+    }
+    if (v1) {
+      for (uint32_t u = t0 + 1u; u <= t1; ++u) bnd[u] = p0 + 1u;
+    }
+    if (b + 1u == nb) {   // behind the list's last posting: every remaining tile is empty
+      const uint32_t last_tile = (t.last_doc - kDocMin) / kJoinTile;
+      for (uint32_t u = last_tile + 1u + lane; u <= n_tiles; u += 64u) bnd[u] = S.n;
+    }
+  }
+}
+
+// ----------------------------------------------------------------- score --
+
+// LDS layout of k_join_pilot / k_join_score (byte offsets; the hot path addresses them
+// absolutely, wave::lds_*)
+struct JoinOff {
+  static constexpr uint32_t acc = 0;                                   // [kJoinTile] u32
+  static constexpr uint32_t caches = 4u * kJoinTile;                   // [kTableRows][256] f32
+  static constexpr uint32_t qts = caches + 4u * 256u * kTableRows;     // DevQTerm[kMaxTerms]
+  static constexpr uint32_t jts = qts + uint32_t(sizeof(DevQTerm)) * kMaxTerms;   // JoinTerm[kMaxTerms]
+  static constexpr uint32_t rng = jts + uint32_t(sizeof(JoinTerm)) * kMaxTerms;   // [chunk tiles + 1][kMaxTerms] u32
+  static constexpr uint32_t sig = rng + 4u * (kJoinChunkTiles + 1u) * kMaxTerms;  // [2][16] u32
+  static constexpr uint32_t cand = sig + 4u * 2u * 16u;                // [2][kJoinCands] u64
+  static constexpr uint32_t vars = cand + 8u * 2u * kJoinCands;        // [16] u32
+  static constexpr uint32_t end = vars + 64u;
+};
+static_assert(JoinOff::cand % 8u == 0u, "candidate keys are 8-byte aligned");
+static_assert(JoinOff::caches + 4u * 256u * kTableRows <= 65536u, "table offsets fit the DS immediate");
+
+struct JoinSm {   // what build_tables() wants to see
+  DevQTerm* qts;
+  float* caches;
+};
+
+// The per-lane view of a query: lane j holds term j (zeros beyond the query's terms).
+struct JoinLane {
+  uint32_t ent_lo, ent_hi;
+  float cs;
+  uint32_t mode;
+};
+
+// Fixed-point contribution of one entry.  TABLE: every frequency of the term has a table row,
+// score = cs * T_tf[norm] (the entry's low 16 bits ARE the offset of T_tf[norm] inside the
+// slot); else row 0 and the general expression (score.h tile_post).
+template<bool TABLE>
+__device__ __forceinline__ void join_post4(const unsigned char* lds, const uint32_t (&e)[4],
+                                           float cs, uint32_t tabofs, bool sqrt_form) {
+  uint32_t at[4];
+  float t[4];
+  uint32_t fx[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    at[k] = TABLE ? ((e[k] & 0xFFFFu) | tabofs) : ((e[k] & 0x3FCu) | tabofs);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) t[k] = wave::lds_f32(lds, JoinOff::caches + at[k]);
+  wave::keep_all_f(t);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (TABLE) {
+      fx[k] = static_cast<uint32_t>(wave::fma(cs, t[k], 1.f));
+    } else {
+      const float tf = static_cast<float>((e[k] >> 10) & kJoinTfMax);
+      float scaled = sqrt_form ? wave::fast_sqrt(tf) * cs * t[k]
+                               : wave::fma(-cs, wave::fast_rcp(wave::fma(tf, t[k], 1.f)), cs);
+      wave::keep_f(scaled);
+      fx[k] = static_cast<uint32_t>(scaled) | 1u;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) wave::lds_add(lds, JoinOff::acc + (e[k] >> 16), fx[k]);
+}
+template<bool TABLE>
+__device__ __forceinline__ void join_post1(const unsigned char* lds, uint32_t e, float cs,
+                                           uint32_t tabofs, bool sqrt_form) {
+  uint32_t fx;
+  if (TABLE) {
+    const float t = wave::lds_f32(lds, JoinOff::caches + ((e & 0xFFFFu) | tabofs));
+    fx = static_cast<uint32_t>(wave::fma(cs, t, 1.f));
+  } else {
+    const float t = wave::lds_f32(lds, JoinOff::caches + ((e & 0x3FCu) | tabofs));
+    const float tf = static_cast<float>((e >> 10) & kJoinTfMax);
+    const float scaled = sqrt_form ? wave::fast_sqrt(tf) * cs * t
+                                   : wave::fma(-cs, wave::fast_rcp(wave::fma(tf, t, 1.f)), cs);
+    fx = static_cast<uint32_t>(scaled) | 1u;
+  }
+  wave::lds_add(lds, JoinOff::acc + (e >> 16), fx);
+}
+
+// `count` consecutive entries from address `base` (wave-uniform): 256 per step, a dword per
+// lane and load (coalesced, saddr form); the last step masks the lanes past the end.
+template<bool TABLE>
+__device__ __forceinline__ void join_run(const unsigned char* lds, uint64_t base, uint32_t count,
+                                         float cs, uint32_t tabofs, bool sqrt_form, unsigned lane) {
+  const uint32_t off = lane * 4u;
+  while (count >= 256u) {
+    uint32_t e[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e[k] = wave::gload_u32(base, off + 256u * uint32_t(k));
+    wave::keep_all(e);
+    join_post4<TABLE>(lds, e, cs, tabofs, sqrt_form);
+    base += 1024u;
+    count -= 256u;
+  }
+  for (uint32_t k = 0; k * 64u < count; ++k) {   // (wave-uniform trip count)
+    if (k * 64u + lane < count) {
+      const uint32_t e = wave::gload_u32(base, off + 256u * k);
+      join_post1<TABLE>(lds, e, cs, tabofs, sqrt_form);
+    }
+  }
+}
+
+// This wavefront's share of one tile: the entries of all terms are cut into slabs of 64 (per
+// term: its range in the tile is contiguous, the last slab partial); the tile's slabs are
+// numbered term after term and wavefront w of nw takes slabs [S*w/nw, S*(w+1)/nw) — a
+// contiguous run that touches one or two terms.  Lane j: a = first entry of term j in the
+// tile, n = its entries there.
+__device__ __forceinline__ void join_tile(const unsigned char* lds, const JoinLane& T, uint32_t a,
+                                          uint32_t n, uint32_t wv, uint32_t nw_log2,
+                                          unsigned lane) {
+  const uint32_t slabs = (n + 63u) >> 6;
+  const uint32_t P = wave::inclusive_scan(slabs);
+  const uint32_t S = wave::read_lane(P, 63u);
+  const uint32_t lo = (S * wv) >> nw_log2, hi = (S * (wv + 1u)) >> nw_log2;
+  if (lo == hi) return;
+  uint32_t s = lo;
+  uint32_t j = wave::uniform(uint32_t(__builtin_ctzll(wave::ballot(P > lo))));
+  while (s < hi) {
+    const uint32_t Pj = wave::read_lane(P, j);
+    const uint32_t end = Pj < hi ? Pj : hi;
+    if (end > s) {   // (a term without entries here has Pj == P[j-1] <= s)
+      const uint32_t first = (s - (Pj - wave::read_lane(slabs, j))) << 6;
+      const uint32_t left = wave::read_lane(n, j) - first;
+      const uint32_t want = (end - s) << 6;
+      const uint32_t cnt = left < want ? left : want;
+      const uint64_t base = ((uint64_t(wave::read_lane(T.ent_hi, j)) << 32) | wave::read_lane(T.ent_lo, j)) +
+                            4ull * (uint64_t(wave::read_lane(a, j)) + first);
+      const float cs = wave::read_lane_f(T.cs, j);
+      const uint32_t mode = wave::read_lane(T.mode, j);
+      if (mode & kJoinGeneral)
+        join_run<false>(lds, base, cnt, cs, mode & kJoinTabMask, (mode & kJoinSqrt) != 0u, lane);
+      else
+        join_run<true>(lds, base, cnt, cs, mode & kJoinTabMask, false, lane);
+      s = end;
+    }
+    ++j;
+  }
+}
+
+// Chunk / pilot prologue, whole workgroup: the query's term scorers and stream records to
+// LDS; the score tables are rebuilt only when the scorer parameters differ from what the
+// previous query of this workgroup left there (the queries of a batch normally share them).
+// Ends with every thread seeing all of it.
+__device__ __forceinline__ void join_prologue(unsigned char* smem, const DevQuery& qd,
+                                              const DevQTerm* qterms, const JoinTerm* jterms) {
+  DevQTerm* qts = reinterpret_cast<DevQTerm*>(smem + JoinOff::qts);
+  JoinTerm* jts = reinterpret_cast<JoinTerm*>(smem + JoinOff::jts);
+  uint32_t* sig = reinterpret_cast<uint32_t*>(smem + JoinOff::sig);   // [0]: in force, [16]: wanted
+  const uint32_t tid = threadIdx.x;
+  if (tid < kMaxTerms) {
+    DevQTerm qt{};
+    JoinTerm jt{};
+    if (tid < qd.n_terms) {
+      qt = qterms[qd.first_term + tid];
+      jt = jterms[qd.first_term + tid];
+      if (qt.cache_id < kMaxCaches) {   // (same values from every term of the slot)
+        sig[16u + 1u + 3u * qt.cache_id] = uint32_t(qt.kind);
+        sig[16u + 2u + 3u * qt.cache_id] = __float_as_uint(qt.norm_const);
+        sig[16u + 3u + 3u * qt.cache_id] = __float_as_uint(qt.norm_length);
+      }
+    }
+    qts[tid] = qt;
+    jts[tid] = jt;
+  }
+  if (tid == 0) sig[16u] = qd.n_caches;
+  __syncthreads();
+  bool same = sig[0] == sig[16u];
+  for (uint32_t c = 0; c < 3u * qd.n_caches; ++c) same = same && sig[1u + c] == sig[17u + c];
+  if (!same) {   // (the same for every thread)
+    JoinSm sm;
+    sm.qts = qts;
+    sm.caches = reinterpret_cast<float*>(smem + JoinOff::caches);
+    build_tables(sm, qd.n_caches, qd.n_terms);
+    __syncthreads();   // everyone has compared before the signature changes
+    if (tid < 1u + 3u * kMaxCaches) sig[tid] = sig[16u + tid];
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ JoinLane join_lane(const unsigned char* smem, unsigned lane) {
+  JoinLane T{};
+  if (lane < kMaxTerms) {
+    const JoinTerm jt = reinterpret_cast<const JoinTerm*>(smem + JoinOff::jts)[lane];
+    T.ent_lo = uint32_t(jt.entries);
+    T.ent_hi = uint32_t(jt.entries >> 32);
+    T.cs = jt.cs;
+    T.mode = jt.mode;
+  }
+  return T;
+}
+
+struct JoinArgs {
+  const DevQuery* queries;
+  const DevQTerm* qterms;
+  const JoinTerm* jterms;
+  const uint32_t* bstar;
+  uint64_t* cands;
+  uint32_t* cand_count;
+  unsigned long long* hits;
+  const uint32_t* order;  // work-queue order: slot i names the unit that runs i-th in a chunk round
+  uint32_t* work_counter;
+  uint32_t cpq;          // chunk ids per unit
+  uint32_t n_units;
+  uint32_t nw_log2;
+  uint32_t cand_cap;
+};
+
+// One workgroup per unit scores the tiles {phase, phase + P, ...} and picks the threshold bin
+// (score.h k_pilot: same histogram, same rule).
+__global__ void __launch_bounds__(kTileThreadsMax)
+k_join_pilot(const uint32_t* units, const DevQuery* queries, const DevQTerm* qterms,
+             const JoinTerm* jterms, uint32_t stride, uint32_t nw_log2, uint32_t* bstar,
+             uint32_t margin, const uint32_t* min_bin) {
+  RT_DYN_SMEM(smem);
+  if (!wave::lds_is_at_zero(smem)) __builtin_trap();
+  uint32_t* acc = reinterpret_cast<uint32_t*>(smem + JoinOff::acc);
+  uint32_t* hist = reinterpret_cast<uint32_t*>(smem + JoinOff::end);   // [kBins]
+  uint32_t* sig = reinterpret_cast<uint32_t*>(smem + JoinOff::sig);
+  const uint32_t tid = threadIdx.x;
+  const unsigned lane = tid & 63u;
+  const uint32_t wv = wave::uniform(tid >> 6);
+  const uint32_t q = units[blockIdx.x];
+  const DevQuery qd = queries[q];
+  const uint32_t n_tiles = qd.n_tiles;
+  for (uint32_t i = tid; i < kBins; i += blockDim.x) hist[i] = 0u;
+  for (uint32_t i = tid; i < kJoinTile; i += blockDim.x) acc[i] = 0u;
+  if (tid == 0) sig[0] = 0xFFFFFFFFu;
+  __syncthreads();
+  join_prologue(smem, qd, qterms, jterms);
+  const JoinLane T = join_lane(smem, lane);
+  const JoinTerm* jts = reinterpret_cast<const JoinTerm*>(smem + JoinOff::jts);
+  const uint32_t* bnd = lane < qd.n_terms ? reinterpret_cast<const uint32_t*>(jts[lane < kMaxTerms ? lane : 0].bounds) : nullptr;
+  for (uint32_t tile = (q * 7u) % stride; tile < n_tiles; tile += stride) {
+    uint32_t a = 0, n = 0;
+    if (bnd) {
+      a = bnd[tile];
+      n = bnd[tile + 1u] - a;
+    }
+    join_tile(smem, T, a, n, wv, nw_log2, lane);
+    __syncthreads();
+    for (uint32_t i = tid; i < kJoinTile; i += blockDim.x) {
+      const uint32_t f = acc[i];
+      if (f) {
+        acc[i] = 0u;
+        const float v = f <= kMaxTerms ? 0.f : from_fixed<uint32_t>(f, qd.fx_inv);
+        atomicAdd(&hist[score_bin(v, qd.bin_scale)], 1u);
+      }
+    }
+    __syncthreads();
+  }
+  uint32_t need = qd.k;
+  if (margin) {
+    const uint32_t phase = (q * 7u) % stride;
+    const uint32_t sampled = phase < n_tiles ? (n_tiles - phase + stride - 1) / stride : 0u;
+    const uint64_t est = (uint64_t(margin) * qd.k * sampled + n_tiles - 1) / (n_tiles ? n_tiles : 1u);
+    const uint32_t lo = est < kPilotMinSample ? kPilotMinSample : uint32_t(est < 0xFFFFFFFFull ? est : 0xFFFFFFFFull);
+    need = lo < qd.k ? lo : qd.k;
+  }
+  if (tid < 64) {   // suffix search: lane L owns the 8 bins of chunk 63-L (k_pilot)
+    const uint32_t chunk = 63u - lane;
+    uint32_t s = 0;
+    for (uint32_t i = 0; i < kBins / 64; ++i) s += hist[chunk * (kBins / 64) + i];
+    const uint32_t incl = wave::inclusive_scan(s);
+    const uint64_t reach = wave::ballot(incl >= need);
+    uint32_t result = 0;
+    if (reach) {
+      const int src = __builtin_ctzll(reach);
+      const uint32_t above = wave::bcast(incl - s, src);
+      const uint32_t c = 63u - uint32_t(src);
+      uint32_t cum = above;
+      for (int i = int(kBins / 64) - 1; i >= 0; --i) {
+        cum += hist[c * (kBins / 64) + uint32_t(i)];
+        if (cum >= need) { result = c * (kBins / 64) + uint32_t(i); break; }
+      }
+    }
+    if (lane == 0) bstar[q] = (min_bin && min_bin[q] > result) ? min_bin[q] : result;
+  }
+}
+
+// Persistent workgroups pulling chunks of kJoinChunkTiles consecutive tiles of one unit
+// (chunk-major ids, heaviest units first: score.h k_score).  Per tile: every wavefront
+// accumulates its share of the tile's entries; barrier; every thread reads + clears its
+// accumulators, counts matches, stages the candidates at or above the threshold bin; barrier.
+// Candidates are staged per chunk; their global slots are reserved by one returning atomic
+// whose latency hides behind the next chunk.
+enum : uint32_t {   // LDS scratch words
+  kJChunk = 0,      // next chunk id
+  kJNc = 2,         // kJNc + (parity): candidates staged by the current / previous chunk
+  kJPendQ = 4,      // previous chunk: unit, reserved base, count
+  kJPendBase = 5,
+  kJPendN = 6,
+};
+
+__global__ void __launch_bounds__(kTileThreadsMax)
+k_join_score(const JoinArgs* __restrict__ args) {
+  RT_DYN_SMEM(smem);
+  if (!wave::lds_is_at_zero(smem)) __builtin_trap();
+  uint32_t* acc = reinterpret_cast<uint32_t*>(smem + JoinOff::acc);
+  uint32_t* rng = reinterpret_cast<uint32_t*>(smem + JoinOff::rng);
+  uint32_t* sig = reinterpret_cast<uint32_t*>(smem + JoinOff::sig);
+  uint64_t* lcand = reinterpret_cast<uint64_t*>(smem + JoinOff::cand);
+  uint32_t* vars = reinterpret_cast<uint32_t*>(smem + JoinOff::vars);
+  const uint32_t tid = threadIdx.x;
+  const unsigned lane = tid & 63u;
+  const uint32_t wv = wave::uniform(tid >> 6);
+  const uint32_t n_units = args->n_units;
+  const uint32_t total_chunks = n_units * args->cpq;
+  const uint32_t nw_log2 = args->nw_log2;
+  const uint32_t cap = args->cand_cap;
+
+  for (uint32_t i = tid; i < kJoinTile; i += blockDim.x) acc[i] = 0u;
+  if (tid < 16u) vars[tid] = 0u;
+  if (tid == 0) {
+    sig[0] = 0xFFFFFFFFu;
+    vars[kJChunk] = atomicAdd(args->work_counter, 1u);
+  }
+  __syncthreads();
+  uint32_t chunk = wave::uniform(vars[kJChunk]);
+  uint32_t parity = 0;
+  // thread 0: the previous chunk's reservation (a returning atomic in flight)
+  uint32_t pend_q = 0, pend_n = 0, pend_base = 0;
+  __syncthreads();
+
+  while (chunk < total_chunks) {
+    uint32_t next_chunk = 0;
+    if (tid == 0) next_chunk = atomicAdd(args->work_counter, 1u);
+    const uint32_t q = wave::uniform(args->order[chunk % n_units]);
+    const uint32_t tile0 = (chunk / n_units) * kJoinChunkTiles;
+    const DevQuery qd = args->queries[q];
+    const uint32_t n_tiles = qd.n_tiles;
+    const uint32_t ntile = tile0 >= n_tiles ? 0u
+                           : ((n_tiles - tile0) < kJoinChunkTiles ? (n_tiles - tile0) : kJoinChunkTiles);
+    const uint32_t bs = args->bstar[q];
+    uint32_t my_hits = 0;
+    uint64_t* lc = lcand + parity * kJoinCands;
+    uint32_t* ncand = vars + kJNc + parity;
+    if (ntile) {
+      // tile boundaries of the chunk, every term: rng[i][j] = bounds_j[tile0 + i]
+      for (uint32_t e = tid; e < (ntile + 1u) * kMaxTerms; e += blockDim.x) {
+        const uint32_t i = e / kMaxTerms, j = e % kMaxTerms;
+        uint32_t v = 0;
+        if (j < qd.n_terms)
+          v = reinterpret_cast<const uint32_t*>(args->jterms[qd.first_term + j].bounds)[tile0 + i];
+        rng[e] = v;
+      }
+      join_prologue(smem, qd, args->qterms, args->jterms);   // (its barriers publish rng too)
+      const JoinLane T = join_lane(smem, lane);
+      const uint32_t thr = bin_threshold<uint32_t>(bs, qd);
+      for (uint32_t u = 0; u < ntile; ++u) {
+        uint32_t a = 0, n = 0;
+        if (lane < kMaxTerms) {
+          a = rng[u * kMaxTerms + lane];
+          n = rng[(u + 1u) * kMaxTerms + lane] - a;
+        }
+        join_tile(smem, T, a, n, wv, nw_log2, lane);
+        __syncthreads();   // B1: every accumulation of tile u has landed
+        const uint32_t doc0 = kDocMin + (tile0 + u) * kJoinTile;
+        auto candidate = [&](uint32_t i, uint32_t f) {   // rare
+          const float v = f <= kMaxTerms ? 0.f : from_fixed<uint32_t>(f, qd.fx_inv);
+          if (score_bin(v, qd.bin_scale) >= bs) {
+            const uint64_t key = make_key(v, doc0 + i);
+            const uint32_t slot = atomicAdd(ncand, 1u);
+            if (slot < kJoinCands) {
+              lc[slot] = key;
+            } else {   // rarer: more candidates in one chunk than staging slots
+              const uint32_t g = atomicAdd(&args->cand_count[q], 1u);
+              if (g < cap) args->cands[uint64_t(q) * cap + g] = key;
+            }
+          }
+        };
+        for (uint32_t i = tid * 4u; i < kJoinTile; i += blockDim.x * 4u) {
+          uint32_t v[4];
+          wave::lds_read4(smem, JoinOff::acc + i * 4u, v);
+          wave::lds_zero4(smem, JoinOff::acc + i * 4u);
+          wave::count_nonzero4(my_hits, v[0], v[1], v[2], v[3]);
+          uint32_t top = v[0] > v[1] ? v[0] : v[1];
+          const uint32_t top2 = v[2] > v[3] ? v[2] : v[3];
+          top = top > top2 ? top : top2;
+          if (top >= thr) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (v[e] >= thr) candidate(i + uint32_t(e), v[e]);
+          }
+        }
+        __syncthreads();   // B2: accumulators are clear again
+      }
+    }
+    // ---- chunk hand-over: flush the PREVIOUS chunk's staged candidates (their reservation
+    // has had a whole chunk to come back), reserve slots for this chunk's, publish hits
+    if (tid == 0) {
+      vars[kJPendQ] = pend_q;
+      vars[kJPendBase] = pend_base;
+      vars[kJPendN] = pend_n;
+      vars[kJChunk] = next_chunk;
+    }
+    my_hits = wave::reduce_add(my_hits);
+    if (lane == 0 && my_hits)
+      atomicAdd(&args->hits[q], static_cast<unsigned long long>(my_hits));
+    __syncthreads();
+    {
+      const uint32_t pn = vars[kJPendN];
+      if (pn) {
+        const uint32_t pq = vars[kJPendQ], gbase = vars[kJPendBase];
+        const uint64_t* pl = lcand + (parity ^ 1u) * kJoinCands;
+        uint64_t* out = args->cands + uint64_t(pq) * cap;
+        for (uint32_t i = tid; i < pn; i += blockDim.x) {
+          const uint32_t g = gbase + i;
+          if (g < cap) out[g] = pl[i];
+        }
+      }
+    }
+    chunk = wave::uniform(vars[kJChunk]);
+    if (tid == 0) {
+      const uint32_t raw = *ncand;
+      pend_n = raw < kJoinCands ? raw : kJoinCands;
+      pend_q = q;
+      pend_base = pend_n ? atomicAdd(&args->cand_count[q], pend_n) : 0u;
+    }
+    __syncthreads();   // everyone has read the hand-over words and the previous staging buffer
+    parity ^= 1u;
+    if (tid == 0) vars[kJNc + parity] = 0u;   // (the buffer flushed above becomes the next chunk's)
+  }
+  // the last chunk's candidates
+  if (tid == 0) {
+    vars[kJPendQ] = pend_q;
+    vars[kJPendBase] = pend_base;
+    vars[kJPendN] = pend_n;
+  }
+  __syncthreads();
+  {
+    const uint32_t pn = vars[kJPendN];
+    if (pn) {
+      const uint32_t pq = vars[kJPendQ], gbase = vars[kJPendBase];
+      const uint64_t* pl = lcand + (parity ^ 1u) * kJoinCands;
+      uint64_t* out = args->cands + uint64_t(pq) * cap;
+      for (uint32_t i = tid; i < pn; i += blockDim.x) {
+        const uint32_t g = gbase + i;
+        if (g < cap) out[g] = pl[i];
+      }
+    }
+  }
+}
+
+}  // namespace irs_hip

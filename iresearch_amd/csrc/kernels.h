@@ -425,6 +425,7 @@ k_plan(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qterms,
        uint32_t* first /*per unit: [n_tiles+1][jt]*/, DevTail* tails /*[unit][jt]*/) {
   const uint32_t q = blockIdx.x / jt, j = blockIdx.x % jt;   // q: (segment, query) unit
   const DevQuery qd = queries[q];
+  if (qd.first_off == kNoPlan) return;   // joined posting streams: no plan tables
   const DevSegment seg = segs[qd.seg];
   const uint32_t n_tiles = qd.n_tiles;
   DevTail* tl = tails + (uint64_t(q) * jt + j);

@@ -264,15 +264,40 @@ __device__ __forceinline__ float score_posting(const DevSegment& seg, const DevQ
   }
 }
 
-// generic scorer (every kind), used off the hot path; idx = doc - lo (wraps for doc < lo)
+// generic scorer (every kind), used off the hot path; idx = doc - lo (wraps for doc < lo).
+// Scorers of the table family use the ARITHMETIC OF THE STRAIGHT-LINE PATH (tile_post /
+// tile_post_table: table row or v_rcp / v_sqrt form, chosen per TERM by its largest
+// frequency, DevQTerm::pad1), so that a posting contributes the same fixed-point value
+// whichever path decodes it — a block of the packed image, an odd framing, the vint tail — and
+// the same as on the joined posting streams of join.h: results are bit-identical across them.
 template<typename ACC, int TILE, bool AND>
 __device__ __forceinline__ void tile_apply(const DevSegment& seg, const TileSmemT<ACC>& sm,
                                            const DevQTerm& qt, float inv_one, uint32_t idx,
                                            uint32_t freq, uint32_t lo, uint32_t span,
                                            float fx_mul) {
   if (idx < span) {
-    const float s = score_posting(seg, qt, inv_one, sm, freq, lo + idx, idx);
-    const ACC fx = fixed_from_scaled<ACC>(s * fx_mul);
+    ACC fx;
+    if (table_kind(qt.kind) && qt.cache_id < kMaxCaches) {
+      const uint32_t rows = sm.slow[2];
+      const float* slot = sm.caches + qt.cache_id * rows * 256u;
+      const uint32_t n = sm.lnorm[idx];
+      const float cs = qt.c0 * fx_mul;
+      if (qt.pad1 < rows) {
+        const float t = slot[freq * 256u + n];
+        if (sizeof(ACC) == 4) fx = static_cast<ACC>(static_cast<uint32_t>(wave::fma(cs, t, 1.f)));
+        else fx = fixed_from_scaled<ACC>(cs * t);
+      } else {
+        const float inv = slot[n];
+        const float tf = static_cast<float>(freq);
+        const float scaled = sqrt_kind(qt.kind)
+                                 ? wave::fast_sqrt(tf) * cs * inv
+                                 : wave::fma(-cs, wave::fast_rcp(wave::fma(tf, inv, 1.f)), cs);
+        fx = fixed_from_scaled<ACC>(scaled);
+      }
+    } else {
+      const float s = score_posting(seg, qt, inv_one, sm, freq, lo + idx, idx);
+      fx = fixed_from_scaled<ACC>(s * fx_mul);
+    }
     const uint32_t merge = sm.slow[3];   // MaxMerger / MinMerger, scorer.hpp:399-423
     if (merge == kScoreSum) atomicAdd(&sm.acc[idx], fx);
     else atomicMax(&sm.acc[idx], merge == kScoreMin ? ACC(~fx) : fx);
@@ -730,7 +755,7 @@ k_items_count(const DevQuery* queries, uint32_t jt, uint32_t tile_docs, uint32_t
   const uint32_t unit = blockIdx.x / tb;
   const uint32_t tile = (blockIdx.x % tb) * kThreads + threadIdx.x;
   const DevQuery qd = queries[unit];
-  if (tile >= qd.n_tiles) return;
+  if (tile >= qd.n_tiles || qd.first_off == kNoPlan) return;
   const uint32_t* f0 = first + qd.first_off + uint64_t(tile) * jt;
   const DevTail* tl = tails + uint64_t(unit) * jt;
   const uint32_t lo = kDocMin + tile * tile_docs;
@@ -763,12 +788,13 @@ k_items_fill(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qt
   __shared__ uint64_t s_dir[kWaves][kMaxTerms];      // DevTail::dir_off
   __shared__ float s_cs[kWaves][kMaxTerms];          // c0 * fixed-point scale
   __shared__ uint32_t s_tf[kWaves][kMaxTerms];       // table slot | table_kind << 8 | sqrt_kind << 9
+                                                     // | (every tf of the term has a table row) << 10
   const unsigned lane = threadIdx.x & 63u;
   const uint32_t wv = threadIdx.x >> 6;
   const uint32_t unit = blockIdx.x / tb;
   const uint32_t tile = (blockIdx.x % tb) * kWaves + wv;
   const DevQuery qd = queries[unit];
-  if (tile >= qd.n_tiles) return;   // whole wavefront
+  if (tile >= qd.n_tiles || qd.first_off == kNoPlan) return;   // whole wavefront
   const DevSegment& seg = segs[qd.seg];
   const uint32_t* f0 = first + qd.first_off + uint64_t(tile) * jt;
   const DevTail* tl = tails + uint64_t(unit) * jt;
@@ -787,7 +813,8 @@ k_items_fill(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qt
     s_cs[wv][lane] = qt.c0 * qd.fx_mul;
     s_tf[wv][lane] = (qt.cache_id < kMaxCaches ? qt.cache_id : 0u) |
                      ((table_kind(qt.kind) && qt.cache_id < kMaxCaches) ? 0x100u : 0u) |
-                     (sqrt_kind(qt.kind) ? 0x200u : 0u);
+                     (sqrt_kind(qt.kind) ? 0x200u : 0u) |
+                     (qt.pad1 < table_rows(qd.n_caches) ? 0x400u : 0u);
   }
   const uint32_t incl = wave::inclusive_scan(nb);
   if (lane <= kMaxTerms) s_pre[wv][lane] = incl - nb;   // lanes >= n_terms hold the total
@@ -817,7 +844,8 @@ k_items_fill(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qt
   };
   // straight-line path: a scorer of the table family, the block in the packed image, and an
   // all-equal frequency that fits the record's 16 bits.  cls: 0 = generic, 1 = straight-line
-  // with general frequencies, 2 = every frequency of the block has a table row; bit 2: the
+  // with general frequencies, 2 = every frequency of the TERM has a table row (per term, not
+  // per block: the generic path and join.h make the same choice, see tile_apply); bit 2: the
   // square-root form (only tells general items apart)
   const uint32_t rows = table_rows(qd.n_caches);
   auto classify = [&](uint32_t j, const BlkDir& d, uint32_t& fconst) {
@@ -826,13 +854,12 @@ k_items_fill(const DevSegment* segs, const DevQuery* queries, const DevQTerm* qt
     const uint32_t tf = s_tf[wv][j];
     if (!((tf & 0x100u) && pk_units(dbits, fbits) != 0u)) return 0u;
     if (query_merge(qd.op)) return 0u;   // Max/Min merged scores: the generic path's atomic max
-    const uint32_t general = (tf & 0x200u) ? 5u : 1u;
+    const uint32_t cls = (tf & 0x400u) ? 2u : ((tf & 0x200u) ? 5u : 1u);
     if (fbits == 0u) {
       fconst = freq_const(j, d);
       if (fconst > 0xFFFFu) return 0u;
-      return fconst < rows ? 2u : general;
     }
-    return (1u << fbits) <= rows ? 2u : general;
+    return cls;
   };
   for (uint32_t g0 = 0; g0 < n; g0 += 64) {   // (whole wavefront: shuffles inside)
     const uint32_t g = g0 + lane;

@@ -11,7 +11,8 @@ constexpr uint32_t kMaxTerms = 16;     // IRS_HIP_MAX_TERMS
 constexpr uint32_t kMaxK = 4096;       // IRS_HIP_MAX_K
 constexpr uint32_t kBins = 512;        // score histogram bins (pilot threshold)
 constexpr uint32_t kMaxCaches = 4;     // distinct (norm_const, norm_length) per query in LDS
-constexpr uint32_t kPadBytes = 64;     // zero padding after the staged `.doc` bytes
+constexpr uint32_t kPadBytes = 64;
+constexpr uint64_t kNoPlan = ~uint64_t(0);  // DevQuery::first_off of a unit without plan tables     // zero padding after the staged `.doc` bytes
 
 enum Layout : int32_t { kScalar = 0, kSimd4 = 1 };
 
@@ -132,6 +133,7 @@ struct DevQuery {
   uint32_t seg;         // index into the batch's DevSegment array
   uint32_t n_tiles;     // doc tiles of that segment
   uint64_t first_off;   // start of the unit's [n_tiles + 1][jt] slice of the plan table
+                        // (kNoPlan: the unit runs on joined posting streams, join.h)
   // work-queue order of k_score (NOT a property of this unit): slot i of the array names the
   // unit that runs i-th within every chunk round — units sorted by decreasing work, so the
   // last workgroups to finish hold the lightest chunks (longest-processing-time first)
@@ -148,7 +150,8 @@ struct DevQTerm {
   float norm_length;
   uint32_t cache_id;    // < kMaxCaches: norm_cache slot in LDS; else compute on the fly
   uint32_t pad0;        // phrase queries: the term's offset in the phrase
-  uint32_t pad1;
+  uint32_t pad1;        // the term's largest frequency (DevTerm::tf_bound): below the rows of a
+                        // table slot, every posting of the term scores through its table row
 };
 
 // What a tile workgroup needs to know about one term of one query, gathered by the plan

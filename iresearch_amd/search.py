@@ -308,6 +308,18 @@ class QueryBatch:
                                                           cand_cap), "irs_hip_batch_configure")
         return self
 
+    def set_path(self, path):
+        """PATH_AUTO / PATH_ITEMS / PATH_JOINED (irs_hip_batch_set_path)."""
+        _lib.check(self.L, self.L.irs_hip_batch_set_path(self.handle, int(path)),
+                   "irs_hip_batch_set_path")
+        return self
+
+    def path(self):
+        """Which path the last run took (PATH_ITEMS / PATH_JOINED)."""
+        v = C.c_int(0)
+        _lib.check(self.L, self.L.irs_hip_batch_path(self.handle, C.byref(v)), "irs_hip_batch_path")
+        return int(v.value)
+
     def set_wand(self, enable=True):
         """ExecutionContext::wand (index-search --search-mode wand): block-max pruning."""
         _lib.check(self.L, self.L.irs_hip_batch_set_wand(self.handle, int(enable)),

@@ -58,7 +58,8 @@ def case_wand_equals_exhaustive(L, num_docs=60_000, max_rank=256, layout=synth.L
         for scorer in scorers:
             prep = search.prepare(filters, scorer, stats)
             for k in ks:
-                ex = sr.batch(prep, k)
+                # (block-max pruning runs on the work-item path: like with like, bit for bit)
+                ex = sr.batch(prep, k).set_path(_lib.PATH_ITEMS)
                 h0, c0, t0 = ex.run().results()
                 ex.close()
                 wb = sr.batch(prep, k).set_wand(True)
@@ -227,13 +228,15 @@ def case_decode_synth(L, layout, num_docs, max_rank, step=1):
 
 # ----------------------------------------------------------------- queries --
 
-def run_and_check(L, seg, filters, scorer, k, tile=0, stride=0, cap=0, sr=None):
+def run_and_check(L, seg, filters, scorer, k, tile=0, stride=0, cap=0, sr=None, path=None):
     own = sr is None
     sr = sr or search.SegmentReader.from_synth(seg, L=L)
     prep = search.prepare(filters, scorer, [parity.segment_stats(seg)])
     b = sr.batch(prep, k)
     if tile or stride or cap:
         b.configure(tile, stride, cap)
+    if path is not None:
+        b.set_path(path)
     hits, counts, totals = b.run().results()
     parity.check_single_segment(seg, filters, scorer, k, hits, counts, totals)
     b.close()
@@ -452,33 +455,71 @@ def case_boolean_reference_vectors(L, max_doc=2_000_000):
     assert ran >= 25
 
 
-def case_pilot_misled(L, k=600):
+def case_pilot_misled(L, k=600, joined=False):
     """The pilot only sees every 16th doc tile.  Here every high-scoring doc sits in exactly
     the tiles query 0 samples, so the estimated threshold (which extrapolates the sample)
     is far too high; k_select must notice (fewer than k candidates although more docs
-    matched) and the batch must re-run with the sound threshold."""
-    tile, stride, n_tiles = 4096, 16, 64
+    matched) and the batch must re-run with the sound threshold.  Both organisations of the
+    doc tiles: work items (4096-doc tiles here) and joined posting streams (12288)."""
+    tile, stride, n_tiles = (12288 if joined else 4096), 16, 64
+    path = _lib.PATH_JOINED if joined else _lib.PATH_ITEMS
     n_docs = tile * n_tiles
     rng = np.random.default_rng(21)
     sampled = [t for t in range(n_tiles) if t % stride == 0]      # phase of query 0 is 0
     hot = np.concatenate([1 + t * tile + np.sort(rng.choice(tile, 500, replace=False))
                           for t in sampled]).astype(np.uint32)
-    hot_f = rng.integers(1, 200, hot.size).astype(np.uint32)      # spread over many score bins
+    # spread over many score bins (a joined stream holds frequencies below 64)
+    hot_f = rng.integers(1, 64 if joined else 200, hot.size).astype(np.uint32)
     cold = np.sort(rng.choice(n_docs, 3000, replace=False)).astype(np.uint32) + 1
     lists = [(hot, hot_f), (cold, np.ones(cold.size, np.uint32))]
     seg, sr = open_lists(L, lists, n_docs, synth.LAYOUT_SIMD4, norms=False)
     filters = [by_term(0), Or([by_term(0), by_term(1)]), by_term(1)]
     for scorer in (TFIDF(False), BM25(1.2, 0.0)):
-        run_and_check(L, seg, filters, scorer, k, tile, stride, sr=sr)
+        run_and_check(L, seg, filters, scorer, k, 0 if joined else tile, stride, sr=sr, path=path)
     # the fallback really is what produced those results
     prep = search.prepare(filters, TFIDF(False), [parity.segment_stats(seg)])
-    b = sr.batch(prep, k).configure(tile, stride, 0)
+    b = sr.batch(prep, k).configure(0 if joined else tile, stride, 0).set_path(path)
     assert b.reruns() == 0
     b.run().results()
     assert b.reruns() == 1
+    assert b.path() == path
     b.run().results()            # the batch stays in sound mode: no further re-run
     assert b.reruns() == 1
     b.close()
+    sr.close()
+
+
+def case_paths_agree(L, num_docs=70_000, max_rank=256, layout=synth.LAYOUT_SIMD4):
+    """The two organisations of a disjunction batch — every query decoding its own blocks (work
+    items) and the batch decoding every distinct term once (joined posting streams) — return
+    the same docs, scores and hit counts, bit for bit (a posting's fixed-point contribution is
+    computed by the same arithmetic wherever it is decoded).  Each one is also checked against
+    the oracle.  Mixed batches: the And /
+    min-match / kMax queries stay on their own kernels while the plain disjunctions join."""
+    seg = synth.build_segment(num_docs, max_rank, layout=layout)
+    sr = search.SegmentReader.from_synth(seg, L=L)
+    ranks = synth.make_queries(6, 8, 2, max_rank, synth.SEED + 5)
+    pure = [Or([by_term(int(r) - 1) for r in row]) for row in ranks]
+    pure += [by_term(3), by_term(max_rank - 1), Or([by_term(1), by_term(2, 3.0)]),
+             Or([by_term(0), by_term(10 * max_rank)])]
+    mixed = pure + standard_filters(max_rank, n_or8=1)
+    for scorer in (BM25(), BM25(1.2, 0.0), TFIDF(True), TFIDF(False)):
+        for filters, k in ((pure, 1000), (mixed, 40)):
+            got = {}
+            for path in (_lib.PATH_ITEMS, _lib.PATH_JOINED, _lib.PATH_AUTO):
+                prep = search.prepare(filters, scorer, [parity.segment_stats(seg)])
+                b = sr.batch(prep, k).set_path(path)
+                h, c, t = b.run().results()
+                assert b.path() == (_lib.PATH_ITEMS if path == _lib.PATH_ITEMS else _lib.PATH_JOINED)
+                parity.check_single_segment(seg, filters, scorer, k, h, c, t)
+                got[path] = (h.copy(), c.copy(), t.copy())
+                b.close()
+            hi, ci, ti = got[_lib.PATH_ITEMS]
+            hj, cj, tj = got[_lib.PATH_JOINED]
+            assert np.array_equal(ci, cj) and np.array_equal(ti, tj)
+            assert np.array_equal(got[_lib.PATH_AUTO][0], hj)
+            # bit for bit: a posting contributes the same fixed-point value on either path
+            assert np.array_equal(hi, hj)
     sr.close()
 
 

@@ -101,6 +101,17 @@ __device__ __forceinline__ void lds_add(const unsigned char* base, uint32_t off,
 __device__ __forceinline__ void lds_add(const unsigned char* base, uint32_t off, unsigned long long v) {
   atomicAdd(reinterpret_cast<unsigned long long*>(const_cast<unsigned char*>(base) + off), v);
 }
+__device__ __forceinline__ void lds_read4(const unsigned char* base, uint32_t off, uint32_t (&v)[4]) {
+  __builtin_memcpy(v, base + off, 16);
+}
+__device__ __forceinline__ void lds_zero4(unsigned char* base, uint32_t off) {
+  __builtin_memset(base + off, 0, 16);
+}
+__device__ __forceinline__ uint32_t gload_u32(uint64_t base, uint32_t off) {
+  uint32_t v;
+  __builtin_memcpy(&v, reinterpret_cast<const uint8_t*>(base) + off, 4);
+  return v;
+}
 template<int N> __device__ __forceinline__ void keep_all(uint32_t (&)[N]) {}
 template<int N> __device__ __forceinline__ void keep_all_f(float (&)[N]) {}
 __device__ __forceinline__ void keep(uint32_t&) {}

@@ -93,8 +93,14 @@ def test_many_items(simlib):
     cases.case_many_items(simlib, 40_000)
 
 
-def test_pilot_misled(simlib):
-    cases.case_pilot_misled(simlib)
+@pytest.mark.parametrize("joined", [False, True])
+def test_pilot_misled(simlib, joined):
+    cases.case_pilot_misled(simlib, joined=joined)
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+def test_paths_agree(simlib, layout):
+    cases.case_paths_agree(simlib, layout=layout)
 
 
 def test_multi_segment(simlib):

@@ -166,8 +166,14 @@ def test_many_items(gpulib):
     cases.case_many_items(gpulib, 300_000)
 
 
-def test_pilot_misled(gpulib):
-    cases.case_pilot_misled(gpulib)
+@pytest.mark.parametrize("joined", [False, True])
+def test_pilot_misled(gpulib, joined):
+    cases.case_pilot_misled(gpulib, joined=joined)
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+def test_paths_agree(gpulib, layout):
+    cases.case_paths_agree(gpulib, layout=layout)
 
 
 def test_multi_segment(gpulib):
