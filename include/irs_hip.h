@@ -29,6 +29,12 @@ extern "C" {
 #define IRS_HIP_POS_PAYLOADS 2u
 #define IRS_HIP_NORM2 0u
 #define IRS_HIP_NORM_LEGACY 1u
+/* irs::Scorer::WandType (scorer.hpp:196-201) of the scorer a field's wand data was written by */
+#define IRS_HIP_WAND_NONE 0u      /* unknown / no wand data                               */
+#define IRS_HIP_WAND_DIV_NORM 1u  /* TFIDF with norms, BM11: (freq, norm) of the doc with the
+                                     largest freq / norm (wand_writer.hpp:181-186)         */
+#define IRS_HIP_WAND_MAX_FREQ 2u  /* BM15, TFIDF without norms: the largest frequency      */
+#define IRS_HIP_WAND_MIN_NORM 3u  /* BM25: largest frequency, smallest norm                */
 
 /* Errors replace the reference's exceptions (io_error / index_error,
  * formats_10.cpp:158-160, 3410-3415): never thrown across this boundary. */
@@ -98,6 +104,13 @@ typedef struct irs_hip_segment_desc {
                              * one little-endian float per doc, 1/sqrt(length) (norm_width 4; the
                              * adapter decodes the sparse zvfloat column into this dense array,
                              * Norm::DEFAULT() = 1 for docs without a value) */
+  uint32_t wand_type;       /* IRS_HIP_WAND_*: what scorer 0 of the field's wand data wrote
+                             * (Scorer::wand_type of the scorer the field was indexed with).  Only
+                             * MAX_FREQ and MIN_NORM pairs bound every score function
+                             * (Scorer::compatible, scorer.cpp:31-64: a DivNorm index is refused
+                             * for MaxFreq / MinNorm queries) — those are read from the index;
+                             * with DIV_NORM or NONE the per-block (max freq, min norm) pairs
+                             * are derived from the postings, which is always sound. */
 } irs_hip_segment_desc;
 
 typedef struct irs_hip_segment irs_hip_segment; /* opaque, immutable after open */

@@ -20,6 +20,7 @@ OP_OR, OP_AND, OP_MINMATCH, OP_PHRASE = 0, 1, 2, 3
 SCORE_BM25, SCORE_BM15, SCORE_BM1, SCORE_TFIDF, SCORE_TFIDF_NORM = 0, 1, 2, 3, 4
 NO_TERM = 0xFFFFFFFF
 PATH_AUTO, PATH_ITEMS, PATH_JOINED = 0, 1, 2
+WAND_NONE, WAND_DIV_NORM, WAND_MAX_FREQ, WAND_MIN_NORM = 0, 1, 2, 3   # Scorer::WandType
 MAX_TERMS, MAX_K, MAX_PHRASE_TERMS = 16, 4096, 8
 K_PLAN, K_PILOT, K_SCORE, K_SELECT, K_COUNT = 0, 1, 2, 3, 4
 KERNEL_NAMES = ("k_plan", "k_pilot", "k_score", "k_select")
@@ -44,7 +45,7 @@ class SegmentDesc(C.Structure):
         ("norms", C.c_void_p), ("norm_width", C.c_uint32), ("norm_min_doc", C.c_uint32),
         ("norm_count", C.c_uint64), ("terms", C.c_void_p), ("num_terms", C.c_uint32),
         ("wand_count", C.c_uint32), ("pos_file", C.c_void_p), ("pos_file_len", C.c_uint64),
-        ("pos_features", C.c_uint32), ("norm_kind", C.c_uint32),
+        ("pos_features", C.c_uint32), ("norm_kind", C.c_uint32), ("wand_type", C.c_uint32),
     ]
 
 

@@ -5,6 +5,8 @@
 #include <cstdint>
 
 #define IRS_WAVE 64
+// register budget of a kernel: at least N wavefronts per SIMD (512 / N VGPRs each)
+#define IRS_WAVES_PER_SIMD(N) __attribute__((amdgpu_waves_per_eu(N)))
 
 namespace wave {
 

@@ -103,6 +103,7 @@ struct irs_hip_segment {
   std::vector<uint64_t> skip_at;   // per term: absolute offset of its skip data (0: none)
   bool has_pos = false;
   uint64_t wand_from_index = 0;    // blocks whose (max freq, min norm) came from the index's wand data
+  uint32_t wand_type = 0;          // IRS_HIP_WAND_* of the scorer that wrote the wand data
 };
 
 struct irs_hip_comm {
@@ -593,8 +594,12 @@ int prepare_blockmax(irs_hip_segment* s) {
   if (n && s->dev.num_terms) {
     // derived from the postings: every block of every index gets a pair
     if (!launch_block_max(s)) return IRS_HIP_EHIP;
-    // a field indexed with scorers carries the pairs itself (skip level 0): those are used
-    if (!s->skip_at.empty()) {
+    // a field indexed with scorers carries the pairs itself (skip level 0): those are used —
+    // when they bound EVERY score function: a MaxFreq or MinNorm payload.  A DivNorm payload
+    // is the (freq, norm) of the doc with the largest ratio, no bound for BM25 or a MaxFreq
+    // scorer (the reference refuses the combination: Scorer::compatible, scorer.cpp:46-49)
+    if (!s->skip_at.empty() &&
+        (s->wand_type == IRS_HIP_WAND_MAX_FREQ || s->wand_type == IRS_HIP_WAND_MIN_NORM)) {
       DevBuf d_at, d_taken;
       if (!d_at.alloc(s->skip_at.size() * 8) || !d_taken.alloc(8)) return IRS_HIP_ENOMEM;
       uint32_t status = 0;

@@ -142,21 +142,27 @@ k_join(const DevSegment* segs, const StreamRec* streams, const JoinWg* wgs) {
 // ----------------------------------------------------------------- score --
 
 // LDS layout of k_join_pilot / k_join_score (byte offsets; the hot path addresses them
-// absolutely, wave::lds_*)
+// absolutely, wave::lds_*).  The dummy words sit right behind the accumulators so that their
+// offsets fit the 16 address bits of an entry: a lane without a posting adds to its own dummy.
 struct JoinOff {
   static constexpr uint32_t acc = 0;                                   // [kJoinTile] u32
-  static constexpr uint32_t caches = 4u * kJoinTile;                   // [kTableRows][256] f32
-  static constexpr uint32_t qts = caches + 4u * 256u * kTableRows;     // DevQTerm[kMaxTerms]
+  static constexpr uint32_t dummy = 4u * kJoinTile;                    // [64] u32
+  static constexpr uint32_t qts = dummy + 256u;                        // DevQTerm[kMaxTerms]
   static constexpr uint32_t jts = qts + uint32_t(sizeof(DevQTerm)) * kMaxTerms;   // JoinTerm[kMaxTerms]
   static constexpr uint32_t rng = jts + uint32_t(sizeof(JoinTerm)) * kMaxTerms;   // [chunk tiles + 1][kMaxTerms] u32
   static constexpr uint32_t sig = rng + 4u * (kJoinChunkTiles + 1u) * kMaxTerms;  // [2][16] u32
   static constexpr uint32_t cand = sig + 4u * 2u * 16u;                // [2][kJoinCands] u64
   static constexpr uint32_t vars = cand + 8u * 2u * kJoinCands;        // [16] u32
-  static constexpr uint32_t end = vars + 64u;
+  static constexpr uint32_t caches = vars + 64u;                       // [kTableRows][256] f32
+  static constexpr uint32_t end = caches + 4u * 256u * kTableRows;
 };
 static_assert(JoinOff::cand % 8u == 0u, "candidate keys are 8-byte aligned");
-static_assert(JoinOff::caches + 4u * 256u * kTableRows <= 65536u, "table offsets fit the DS immediate");
+static_assert(JoinOff::caches % 16u == 0u && JoinOff::caches <= 65535u, "the table base is a DS immediate");
+static_assert(JoinOff::dummy + 256u <= 65536u, "dummy offsets fit an entry's 16 address bits");
 
+struct alignas(16) JoinQuad {   // 16 bytes moved at once
+  uint32_t x, y, z, w;
+};
 struct JoinSm {   // what build_tables() wants to see
   DevQTerm* qts;
   float* caches;
@@ -169,29 +175,39 @@ struct JoinLane {
   uint32_t mode;
 };
 
-// Fixed-point contribution of one entry.  TABLE: every frequency of the term has a table row,
-// score = cs * T_tf[norm] (the entry's low 16 bits ARE the offset of T_tf[norm] inside the
-// slot); else row 0 and the general expression (score.h tile_post).
-template<bool TABLE>
-__device__ __forceinline__ void join_post4(const unsigned char* lds, const uint32_t (&e)[4],
-                                           float cs, uint32_t tabofs, bool sqrt_form) {
-  uint32_t at[4];
+enum : int { kJTable = 0, kJRcp = 1, kJSqrt = 2 };
+__device__ __forceinline__ int join_form(uint32_t mode) {
+  return !(mode & kJoinGeneral) ? kJTable : ((mode & kJoinSqrt) ? kJSqrt : kJRcp);
+}
+// the entry a lane without a posting carries: its own dummy accumulator, table offset 0
+__device__ __forceinline__ uint32_t join_dummy(unsigned lane) {
+  return (JoinOff::dummy + 4u * lane) << 16;
+}
+
+// Four entries per lane: table reads back to back, then the multiply-adds, then the LDS adds.
+// FORM kJTable: every frequency of the term has a table row, score = cs * T_tf[norm] — the
+// entry's low 16 bits ARE the offset of T_tf[norm] inside the slot; else row 0 and the general
+// expression (score.h tile_post: v_rcp / v_sqrt form).
+template<int FORM>
+__device__ __forceinline__ void join_post4(const unsigned char* lds, uint32_t e0, uint32_t e1,
+                                           uint32_t e2, uint32_t e3, float cs, uint32_t tabofs) {
+  const uint32_t e[4] = {e0, e1, e2, e3};
   float t[4];
   uint32_t fx[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
-    at[k] = TABLE ? ((e[k] & 0xFFFFu) | tabofs) : ((e[k] & 0x3FCu) | tabofs);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) t[k] = wave::lds_f32(lds, JoinOff::caches + at[k]);
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t at = (FORM == kJTable) ? ((e[k] & 0xFFFFu) | tabofs) : ((e[k] & 0x3FCu) | tabofs);
+    t[k] = wave::lds_f32(lds, JoinOff::caches + at);
+  }
   wave::keep_all_f(t);
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    if (TABLE) {
+    if (FORM == kJTable) {
       fx[k] = static_cast<uint32_t>(wave::fma(cs, t[k], 1.f));
     } else {
       const float tf = static_cast<float>((e[k] >> 10) & kJoinTfMax);
-      float scaled = sqrt_form ? wave::fast_sqrt(tf) * cs * t[k]
-                               : wave::fma(-cs, wave::fast_rcp(wave::fma(tf, t[k], 1.f)), cs);
+      float scaled = (FORM == kJSqrt) ? wave::fast_sqrt(tf) * cs * t[k]
+                                      : wave::fma(-cs, wave::fast_rcp(wave::fma(tf, t[k], 1.f)), cs);
       wave::keep_f(scaled);
       fx[k] = static_cast<uint32_t>(scaled) | 1u;
     }
@@ -199,77 +215,126 @@ __device__ __forceinline__ void join_post4(const unsigned char* lds, const uint3
 #pragma unroll
   for (int k = 0; k < 4; ++k) wave::lds_add(lds, JoinOff::acc + (e[k] >> 16), fx[k]);
 }
-template<bool TABLE>
-__device__ __forceinline__ void join_post1(const unsigned char* lds, uint32_t e, float cs,
-                                           uint32_t tabofs, bool sqrt_form) {
-  uint32_t fx;
-  if (TABLE) {
-    const float t = wave::lds_f32(lds, JoinOff::caches + ((e & 0xFFFFu) | tabofs));
-    fx = static_cast<uint32_t>(wave::fma(cs, t, 1.f));
-  } else {
-    const float t = wave::lds_f32(lds, JoinOff::caches + ((e & 0x3FCu) | tabofs));
-    const float tf = static_cast<float>((e >> 10) & kJoinTfMax);
-    const float scaled = sqrt_form ? wave::fast_sqrt(tf) * cs * t
-                                   : wave::fma(-cs, wave::fast_rcp(wave::fma(tf, t, 1.f)), cs);
-    fx = static_cast<uint32_t>(scaled) | 1u;
-  }
-  wave::lds_add(lds, JoinOff::acc + (e >> 16), fx);
+__device__ __forceinline__ void join_post4_any(const unsigned char* lds, uint32_t e0, uint32_t e1,
+                                               uint32_t e2, uint32_t e3, float cs, uint32_t mode) {
+  const uint32_t tabofs = mode & kJoinTabMask;
+  const int form = join_form(mode);   // (wave-uniform)
+  if (form == kJTable) join_post4<kJTable>(lds, e0, e1, e2, e3, cs, tabofs);
+  else if (form == kJRcp) join_post4<kJRcp>(lds, e0, e1, e2, e3, cs, tabofs);
+  else join_post4<kJSqrt>(lds, e0, e1, e2, e3, cs, tabofs);
 }
 
-// `count` consecutive entries from address `base` (wave-uniform): 256 per step, a dword per
-// lane and load (coalesced, saddr form); the last step masks the lanes past the end.
-template<bool TABLE>
+// Slabs [0, 4) of `count` (> 0) entries at `base`: a dword per lane and slab (coalesced); lanes
+// past the end keep their dummy entry, so whatever consumes the four values needs no mask.
+__device__ __forceinline__ void join_load4(uint64_t base, uint32_t count, unsigned lane,
+                                           uint32_t& e0, uint32_t& e1, uint32_t& e2, uint32_t& e3) {
+  const uint32_t off = lane * 4u;
+  e0 = e1 = e2 = e3 = join_dummy(lane);
+  if (lane < count) e0 = wave::gload_u32(base, off);
+  if (lane + 64u < count) e1 = wave::gload_u32(base, off + 256u);
+  if (lane + 128u < count) e2 = wave::gload_u32(base, off + 512u);
+  if (lane + 192u < count) e3 = wave::gload_u32(base, off + 768u);
+}
+
+// `count` consecutive entries from address `base` (wave-uniform), 256 per step.
+template<int FORM>
 __device__ __forceinline__ void join_run(const unsigned char* lds, uint64_t base, uint32_t count,
-                                         float cs, uint32_t tabofs, bool sqrt_form, unsigned lane) {
+                                         float cs, uint32_t tabofs, unsigned lane) {
   const uint32_t off = lane * 4u;
   while (count >= 256u) {
     uint32_t e[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) e[k] = wave::gload_u32(base, off + 256u * uint32_t(k));
     wave::keep_all(e);
-    join_post4<TABLE>(lds, e, cs, tabofs, sqrt_form);
+    join_post4<FORM>(lds, e[0], e[1], e[2], e[3], cs, tabofs);
     base += 1024u;
     count -= 256u;
   }
-  for (uint32_t k = 0; k * 64u < count; ++k) {   // (wave-uniform trip count)
-    if (k * 64u + lane < count) {
-      const uint32_t e = wave::gload_u32(base, off + 256u * k);
-      join_post1<TABLE>(lds, e, cs, tabofs, sqrt_form);
-    }
+  if (count) {
+    uint32_t e0, e1, e2, e3;
+    join_load4(base, count, lane, e0, e1, e2, e3);
+    join_post4<FORM>(lds, e0, e1, e2, e3, cs, tabofs);
   }
 }
 
-// This wavefront's share of one tile: the entries of all terms are cut into slabs of 64 (per
+// A wavefront's share of one tile.  The entries of all terms are cut into slabs of 64 (per
 // term: its range in the tile is contiguous, the last slab partial); the tile's slabs are
 // numbered term after term and wavefront w of nw takes slabs [S*w/nw, S*(w+1)/nw) — a
-// contiguous run that touches one or two terms.  Lane j: a = first entry of term j in the
-// tile, n = its entries there.
-__device__ __forceinline__ void join_tile(const unsigned char* lds, const JoinLane& T, uint32_t a,
-                                          uint32_t n, uint32_t wv, uint32_t nw_log2,
-                                          unsigned lane) {
-  const uint32_t slabs = (n + 63u) >> 6;
-  const uint32_t P = wave::inclusive_scan(slabs);
-  const uint32_t S = wave::read_lane(P, 63u);
-  const uint32_t lo = (S * wv) >> nw_log2, hi = (S * (wv + 1u)) >> nw_log2;
-  if (lo == hi) return;
-  uint32_t s = lo;
-  uint32_t j = wave::uniform(uint32_t(__builtin_ctzll(wave::ballot(P > lo))));
+// contiguous run that touches one or two terms.  begin() works that out and REQUESTS the first
+// kJoinPre slabs of the run's first term (the loads then fly behind the previous tile's barrier
+// and epilogue); finish() consumes them and streams whatever is left.
+constexpr int kJoinPre = 8;   // 4 or 8
+struct JoinRun {
+  uint32_t a, n, slabs, P;   // lane j = term j: first entry in the tile, entries, slabs, prefix
+  uint32_t s, hi, j;         // (uniform) next slab of the run, its end, the term slab s is in
+  uint32_t pre;              // (uniform) slabs requested by begin(): 0, 1..4 (e[0..3]) or 5..8
+  float cs;                  // (uniform) of the requested term
+  uint32_t mode;
+  uint32_t e[8];
+};
+
+__device__ __forceinline__ void join_begin(JoinRun& r, const JoinLane& T, uint32_t a, uint32_t n,
+                                           uint32_t wv, uint32_t nw_log2, unsigned lane) {
+  r.a = a;
+  r.n = n;
+  r.slabs = (n + 63u) >> 6;
+  r.P = wave::inclusive_scan(r.slabs);
+  const uint32_t S = wave::read_lane(r.P, 63u);
+  const uint32_t lo = (S * wv) >> nw_log2;
+  r.hi = (S * (wv + 1u)) >> nw_log2;
+  r.s = lo;
+  r.pre = 0;
+  r.j = 0;
+  r.cs = 0.f;
+  r.mode = 0;
+  if (lo == r.hi) return;
+  const uint32_t j = wave::uniform(uint32_t(__builtin_ctzll(wave::ballot(r.P > lo))));
+  r.j = j;
+  const uint32_t Pj = wave::read_lane(r.P, j);
+  const uint32_t end = Pj < r.hi ? Pj : r.hi;
+  const uint32_t first = (lo - (Pj - wave::read_lane(r.slabs, j))) << 6;
+  const uint32_t left = wave::read_lane(n, j) - first;
+  uint32_t take = end - lo;
+  if (take > uint32_t(kJoinPre)) take = uint32_t(kJoinPre);
+  const uint32_t want = take << 6;
+  const uint32_t cnt = left < want ? left : want;
+  const uint64_t base = ((uint64_t(wave::read_lane(T.ent_hi, j)) << 32) | wave::read_lane(T.ent_lo, j)) +
+                        4ull * (uint64_t(wave::read_lane(a, j)) + first);
+  r.cs = wave::read_lane_f(T.cs, j);
+  r.mode = wave::read_lane(T.mode, j);
+  r.pre = take;
+  r.s = lo + take;
+  join_load4(base, cnt, lane, r.e[0], r.e[1], r.e[2], r.e[3]);
+  if (kJoinPre > 4 && take > 4u)
+    join_load4(base + 1024u, cnt - 256u, lane, r.e[4], r.e[5], r.e[6], r.e[7]);
+}
+
+__device__ __forceinline__ void join_finish(const unsigned char* lds, JoinRun& r, const JoinLane& T,
+                                            unsigned lane) {
+  // (the run's scalars crossed a barrier and a loop back edge inside a struct: the compiler no
+  // longer knows they are wave-uniform and would predicate everything below lane by lane)
+  const uint32_t pre = wave::uniform(r.pre), mode0 = wave::uniform(r.mode), hi = wave::uniform(r.hi);
+  const float cs0 = wave::uniform_f(r.cs);
+  if (pre) join_post4_any(lds, r.e[0], r.e[1], r.e[2], r.e[3], cs0, mode0);
+  if (kJoinPre > 4 && pre > 4u) join_post4_any(lds, r.e[4], r.e[5], r.e[6], r.e[7], cs0, mode0);
+  uint32_t s = wave::uniform(r.s), j = wave::uniform(r.j);
   while (s < hi) {
-    const uint32_t Pj = wave::read_lane(P, j);
+    const uint32_t Pj = wave::read_lane(r.P, j);
     const uint32_t end = Pj < hi ? Pj : hi;
     if (end > s) {   // (a term without entries here has Pj == P[j-1] <= s)
-      const uint32_t first = (s - (Pj - wave::read_lane(slabs, j))) << 6;
-      const uint32_t left = wave::read_lane(n, j) - first;
+      const uint32_t first = (s - (Pj - wave::read_lane(r.slabs, j))) << 6;
+      const uint32_t left = wave::read_lane(r.n, j) - first;
       const uint32_t want = (end - s) << 6;
       const uint32_t cnt = left < want ? left : want;
       const uint64_t base = ((uint64_t(wave::read_lane(T.ent_hi, j)) << 32) | wave::read_lane(T.ent_lo, j)) +
-                            4ull * (uint64_t(wave::read_lane(a, j)) + first);
+                            4ull * (uint64_t(wave::read_lane(r.a, j)) + first);
       const float cs = wave::read_lane_f(T.cs, j);
       const uint32_t mode = wave::read_lane(T.mode, j);
-      if (mode & kJoinGeneral)
-        join_run<false>(lds, base, cnt, cs, mode & kJoinTabMask, (mode & kJoinSqrt) != 0u, lane);
-      else
-        join_run<true>(lds, base, cnt, cs, mode & kJoinTabMask, false, lane);
+      const uint32_t tabofs = mode & kJoinTabMask;
+      const int form = join_form(mode);
+      if (form == kJTable) join_run<kJTable>(lds, base, cnt, cs, tabofs, lane);
+      else if (form == kJRcp) join_run<kJRcp>(lds, base, cnt, cs, tabofs, lane);
+      else join_run<kJSqrt>(lds, base, cnt, cs, tabofs, lane);
       s = end;
     }
     ++j;
@@ -283,23 +348,26 @@ __device__ __forceinline__ void join_tile(const unsigned char* lds, const JoinLa
 __device__ __forceinline__ void join_prologue(unsigned char* smem, const DevQuery& qd,
                                               const DevQTerm* qterms, const JoinTerm* jterms) {
   DevQTerm* qts = reinterpret_cast<DevQTerm*>(smem + JoinOff::qts);
-  JoinTerm* jts = reinterpret_cast<JoinTerm*>(smem + JoinOff::jts);
+  JoinQuad* jts = reinterpret_cast<JoinQuad*>(smem + JoinOff::jts);
   uint32_t* sig = reinterpret_cast<uint32_t*>(smem + JoinOff::sig);   // [0]: in force, [16]: wanted
   const uint32_t tid = threadIdx.x;
-  if (tid < kMaxTerms) {
-    DevQTerm qt{};
-    JoinTerm jt{};
-    if (tid < qd.n_terms) {
-      qt = qterms[qd.first_term + tid];
-      jt = jterms[qd.first_term + tid];
-      if (qt.cache_id < kMaxCaches) {   // (same values from every term of the slot)
-        sig[16u + 1u + 3u * qt.cache_id] = uint32_t(qt.kind);
-        sig[16u + 2u + 3u * qt.cache_id] = __float_as_uint(qt.norm_const);
-        sig[16u + 3u + 3u * qt.cache_id] = __float_as_uint(qt.norm_length);
-      }
-    }
+  if (tid < qd.n_terms) {
+    const DevQTerm qt = qterms[qd.first_term + tid];
     qts[tid] = qt;
-    jts[tid] = jt;
+    if (qt.cache_id < kMaxCaches) {   // (same values from every term of the slot)
+      sig[16u + 1u + 3u * qt.cache_id] = uint32_t(qt.kind);
+      sig[16u + 2u + 3u * qt.cache_id] = __float_as_uint(qt.norm_const);
+      sig[16u + 3u + 3u * qt.cache_id] = __float_as_uint(qt.norm_length);
+    }
+  }
+  if (tid < 2u * kMaxTerms) {   // a JoinTerm = two 16-byte halves
+    const uint32_t j = tid >> 1;
+    uint32_t x = 0, y = 0, z = 0, w = 0;   // (field by field: an aggregate temporary would live in scratch)
+    if (j < qd.n_terms) {
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(jterms + qd.first_term) + 4u * tid;
+      x = src[0]; y = src[1]; z = src[2]; w = src[3];
+    }
+    jts[tid].x = x; jts[tid].y = y; jts[tid].z = z; jts[tid].w = w;
   }
   if (tid == 0) sig[16u] = qd.n_caches;
   __syncthreads();
@@ -319,11 +387,12 @@ __device__ __forceinline__ void join_prologue(unsigned char* smem, const DevQuer
 __device__ __forceinline__ JoinLane join_lane(const unsigned char* smem, unsigned lane) {
   JoinLane T{};
   if (lane < kMaxTerms) {
-    const JoinTerm jt = reinterpret_cast<const JoinTerm*>(smem + JoinOff::jts)[lane];
-    T.ent_lo = uint32_t(jt.entries);
-    T.ent_hi = uint32_t(jt.entries >> 32);
-    T.cs = jt.cs;
-    T.mode = jt.mode;
+    const JoinQuad lo = reinterpret_cast<const JoinQuad*>(smem + JoinOff::jts)[2u * lane];
+    const JoinQuad hi = reinterpret_cast<const JoinQuad*>(smem + JoinOff::jts)[2u * lane + 1u];
+    T.ent_lo = lo.x;   // JoinTerm::entries
+    T.ent_hi = lo.y;
+    T.cs = __uint_as_float(hi.x);
+    T.mode = hi.y;
   }
   return T;
 }
@@ -367,15 +436,18 @@ k_join_pilot(const uint32_t* units, const DevQuery* queries, const DevQTerm* qte
   __syncthreads();
   join_prologue(smem, qd, qterms, jterms);
   const JoinLane T = join_lane(smem, lane);
-  const JoinTerm* jts = reinterpret_cast<const JoinTerm*>(smem + JoinOff::jts);
-  const uint32_t* bnd = lane < qd.n_terms ? reinterpret_cast<const uint32_t*>(jts[lane < kMaxTerms ? lane : 0].bounds) : nullptr;
+  const uint32_t* bnd = nullptr;
+  if (lane < qd.n_terms)
+    bnd = reinterpret_cast<const uint32_t*>(reinterpret_cast<const JoinTerm*>(smem + JoinOff::jts)[lane].bounds);
   for (uint32_t tile = (q * 7u) % stride; tile < n_tiles; tile += stride) {
     uint32_t a = 0, n = 0;
     if (bnd) {
       a = bnd[tile];
       n = bnd[tile + 1u] - a;
     }
-    join_tile(smem, T, a, n, wv, nw_log2, lane);
+    JoinRun r;
+    join_begin(r, T, a, n, wv, nw_log2, lane);
+    join_finish(smem, r, T, lane);
     __syncthreads();
     for (uint32_t i = tid; i < kJoinTile; i += blockDim.x) {
       const uint32_t f = acc[i];
@@ -417,9 +489,13 @@ k_join_pilot(const uint32_t* units, const DevQuery* queries, const DevQTerm* qte
 }
 
 // Persistent workgroups pulling chunks of kJoinChunkTiles consecutive tiles of one unit
-// (chunk-major ids, heaviest units first: score.h k_score).  Per tile: every wavefront
-// accumulates its share of the tile's entries; barrier; every thread reads + clears its
-// accumulators, counts matches, stages the candidates at or above the threshold bin; barrier.
+// (chunk-major ids, heaviest units first: score.h k_score).  Per tile and wavefront:
+//   finish(u)     consume the requested entries of tile u, stream the rest of its share
+//   begin(u + 1)  work out the share of tile u+1, request its first entries
+//   barrier B1    every accumulation of tile u has landed
+//   epilogue      every thread reads + clears its accumulators, counts matches, stages the
+//                 candidates at or above the threshold bin (the requests fly behind it)
+//   barrier B2    accumulators are clear again
 // Candidates are staged per chunk; their global slots are reserved by one returning atomic
 // whose latency hides behind the next chunk.
 enum : uint32_t {   // LDS scratch words
@@ -430,7 +506,7 @@ enum : uint32_t {   // LDS scratch words
   kJPendN = 6,
 };
 
-__global__ void __launch_bounds__(kTileThreadsMax)
+__global__ void __launch_bounds__(kTileThreadsMax) IRS_WAVES_PER_SIMD(8)
 k_join_score(const JoinArgs* __restrict__ args) {
   RT_DYN_SMEM(smem);
   if (!wave::lds_is_at_zero(smem)) __builtin_trap();
@@ -447,7 +523,7 @@ k_join_score(const JoinArgs* __restrict__ args) {
   const uint32_t nw_log2 = args->nw_log2;
   const uint32_t cap = args->cand_cap;
 
-  for (uint32_t i = tid; i < kJoinTile; i += blockDim.x) acc[i] = 0u;
+  for (uint32_t i = tid; i < kJoinTile + 64u; i += blockDim.x) acc[i] = 0u;   // (+ the dummies)
   if (tid < 16u) vars[tid] = 0u;
   if (tid == 0) {
     sig[0] = 0xFFFFFFFFu;
@@ -482,16 +558,30 @@ k_join_score(const JoinArgs* __restrict__ args) {
           v = reinterpret_cast<const uint32_t*>(args->jterms[qd.first_term + j].bounds)[tile0 + i];
         rng[e] = v;
       }
-      join_prologue(smem, qd, args->qterms, args->jterms);   // (its barriers publish rng too)
+      join_prologue(smem, qd, args->qterms, args->jterms);   // (its barrier publishes rng too)
       const JoinLane T = join_lane(smem, lane);
       const uint32_t thr = bin_threshold<uint32_t>(bs, qd);
-      for (uint32_t u = 0; u < ntile; ++u) {
-        uint32_t a = 0, n = 0;
+      auto range = [&](uint32_t u, uint32_t& a, uint32_t& n) {
+        a = 0;
+        n = 0;
         if (lane < kMaxTerms) {
           a = rng[u * kMaxTerms + lane];
           n = rng[(u + 1u) * kMaxTerms + lane] - a;
         }
-        join_tile(smem, T, a, n, wv, nw_log2, lane);
+      };
+      JoinRun r;
+      {
+        uint32_t a, n;
+        range(0, a, n);
+        join_begin(r, T, a, n, wv, nw_log2, lane);
+      }
+      for (uint32_t u = 0; u < ntile; ++u) {
+        join_finish(smem, r, T, lane);
+        if (u + 1u < ntile) {
+          uint32_t a, n;
+          range(u + 1u, a, n);
+          join_begin(r, T, a, n, wv, nw_log2, lane);
+        }
         __syncthreads();   // B1: every accumulation of tile u has landed
         const uint32_t doc0 = kDocMin + (tile0 + u) * kJoinTile;
         auto candidate = [&](uint32_t i, uint32_t f) {   // rare
@@ -515,10 +605,15 @@ k_join_score(const JoinArgs* __restrict__ args) {
           uint32_t top = v[0] > v[1] ? v[0] : v[1];
           const uint32_t top2 = v[2] > v[3] ? v[2] : v[3];
           top = top > top2 ? top : top2;
-          if (top >= thr) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (v[e] >= thr) candidate(i + uint32_t(e), v[e]);
+          if (top >= thr) {   // rare: one copy of the candidate code, per-lane loop
+            uint32_t cm = (v[0] >= thr ? 1u : 0u) | (v[1] >= thr ? 2u : 0u) |
+                          (v[2] >= thr ? 4u : 0u) | (v[3] >= thr ? 8u : 0u);
+            while (cm) {
+              const uint32_t e = uint32_t(__builtin_ctz(cm));
+              cm &= cm - 1u;
+              const uint32_t x = e == 0u ? v[0] : (e == 1u ? v[1] : (e == 2u ? v[2] : v[3]));
+              candidate(i + e, x);
+            }
           }
         }
         __syncthreads();   // B2: accumulators are clear again

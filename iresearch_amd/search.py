@@ -164,7 +164,7 @@ class SegmentReader:
 
     def __init__(self, doc_file, metas, num_docs, layout, norms=None, norm_width=1,
                  docs_with_field=None, total_term_freq=0, device=0, has_freq=True, L=None,
-                 wand_count=0, pos_file=None, pos_features=0, norm_kind=0):
+                 wand_count=0, pos_file=None, pos_features=0, norm_kind=0, wand_type=0):
         self.L = L or _lib.lib()
         self.doc_file = np.ascontiguousarray(doc_file, np.uint8)
         self.metas = np.zeros(len(metas), TERM_META)
@@ -182,7 +182,8 @@ class SegmentReader:
             0 if self.norms is None else self.norms.size // norm_width,
             self.metas.ctypes.data, len(self.metas), int(wand_count),
             None if self.pos_file is None else self.pos_file.ctypes.data,
-            0 if self.pos_file is None else self.pos_file.size, int(pos_features), int(norm_kind))
+            0 if self.pos_file is None else self.pos_file.size, int(pos_features), int(norm_kind),
+            int(wand_type))
         h = C.c_void_p()
         _lib.check(self.L, self.L.irs_hip_segment_open(C.byref(desc), C.byref(h)),
                    "irs_hip_segment_open")
@@ -192,7 +193,8 @@ class SegmentReader:
     def from_synth(cls, seg, device=0, L=None, has_freq=True):
         return cls(seg.doc_file, seg.metas, seg.num_docs, seg.layout, seg.norms, 1,
                    seg.docs_with_field, seg.total_term_freq, device, has_freq, L,
-                   getattr(seg, "wand_count", 0), getattr(seg, "pos_file", None))
+                   getattr(seg, "wand_count", 0), getattr(seg, "pos_file", None),
+                   wand_type=getattr(seg, "wand_type", 0))
 
     def close(self):
         if self.handle:

@@ -119,6 +119,7 @@ class SynthSegment:
     pos_file: np.ndarray | None = None   # uint8, the whole `.pos` image (field with POS)
     positions: dict | None = None        # rank -> u32[Σ freqs] positions, doc after doc, when kept
     pos_one_based: bool = False          # formats 1_0..1_2: one-based position storage
+    wand_type: int = 0                   # Scorer::WandType of the scorer that wrote the wand data
 
     def meta(self, rank: int) -> np.void:
         return self.metas[rank - 1]
@@ -173,7 +174,10 @@ def build_segment(num_docs: int, max_rank: int = 4096, *, layout: int = LAYOUT_S
                     postings[r] = (np.zeros(0, np.uint32), np.zeros(0, np.uint32))
         return SynthSegment(doc_file, norms, metas, L.irs_synth_docs_with_field(h),
                             L.irs_synth_total_term_freq(h), layout, num_docs, postings,
-                            wand_count, pos_file, positions, bool(one_based_positions))
+                            wand_count, pos_file, positions, bool(one_based_positions),
+                            # WAND_* (the writer's tags) -> Scorer::WandType (scorer.hpp:196-201)
+                            {WAND_MAX_FREQ: 2, WAND_MIN_NORM: 3, WAND_DIV_NORM: 1}[wand_kind]
+                            if wand_count else 0)
     finally:
         L.irs_synth_free(h)
 

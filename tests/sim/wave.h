@@ -6,6 +6,7 @@
 #include <cstdint>
 
 #define IRS_WAVE 64
+#define IRS_WAVES_PER_SIMD(N)
 
 namespace wave {
 
