@@ -78,6 +78,9 @@ __device__ __forceinline__ void sync() {
 __device__ __forceinline__ uint32_t uniform(uint32_t v) {
   return uint32_t(__builtin_amdgcn_readfirstlane(int(v)));
 }
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
+  return (uint64_t(uniform(uint32_t(v >> 32))) << 32) | uniform(uint32_t(v));
+}
 __device__ __forceinline__ float uniform_f(float v) {
   return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
@@ -194,9 +197,36 @@ __device__ __forceinline__ void lds_read4(const unsigned char*, uint32_t off, ui
   const u32x4 x = *(const IRS_LDS u32x4*)(uintptr_t)off;
   v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
 }
-__device__ __forceinline__ void lds_zero4(unsigned char*, uint32_t off) {
+// Read 16 bytes of LDS and leave zeros behind, in ONE pass of the LDS pipeline
+// (ds_wrxchg2_rtn_b64: an atomic exchange of two adjacent 8-byte words) instead of a 16-byte
+// read followed by a 16-byte write.  take4x2: two of them in flight behind one wait.
+__device__ __forceinline__ void lds_take4(unsigned char*, uint32_t off, uint32_t (&v)[4]) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  *(IRS_LDS u32x4*)(uintptr_t)off = u32x4{0u, 0u, 0u, 0u};
+  u32x4 x;
+  uint64_t z = 0;
+  asm volatile("ds_wrxchg2_rtn_b64 %0, %1, %2, %2 offset1:1\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(x) : "v"(off), "v"(z) : "memory");
+  v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+}
+__device__ __forceinline__ void lds_take4x2(unsigned char*, uint32_t off0, uint32_t off1,
+                                            uint32_t (&a)[4], uint32_t (&b)[4]) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 x, y;
+  uint64_t z = 0;
+  asm volatile("ds_wrxchg2_rtn_b64 %0, %2, %4, %4 offset1:1\n\t"
+               "ds_wrxchg2_rtn_b64 %1, %3, %4, %4 offset1:1\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&v"(x), "=&v"(y) : "v"(off0), "v"(off1), "v"(z) : "memory");
+  a[0] = x[0]; a[1] = x[1]; a[2] = x[2]; a[3] = x[3];
+  b[0] = y[0]; b[1] = y[1]; b[2] = y[2]; b[3] = y[3];
+}
+// (ds_write2_b64 from ONE zeroed register pair: a ds_write_b128 would pin four zero registers
+// for the whole kernel)
+__device__ __forceinline__ void lds_zero4(unsigned char*, uint32_t off) {
+  uint64_t z = 0;
+  asm volatile("" : "+v"(z));
+  *(IRS_LDS uint64_t*)(uintptr_t)off = z;
+  *(IRS_LDS uint64_t*)(uintptr_t)(off + 8u) = z;
 }
 
 // LDS float accumulate without a returned value -> ds_add_f32

@@ -34,7 +34,7 @@ namespace irs_hip {
 constexpr uint32_t kJoinTile = 12288;     // docs per accumulator tile (48 KB of u32 in LDS)
 constexpr uint32_t kJoinTfMax = 63;       // entry layout: 6 bits of tf
 constexpr uint32_t kJoinBlocks = 16;      // blocks per k_join workgroup
-constexpr uint32_t kJoinChunkTiles = 16;  // consecutive tiles of one unit per work-queue item
+constexpr uint32_t kJoinChunkTiles = 32;  // consecutive tiles of one unit per work-queue item
 constexpr uint32_t kJoinCands = 256;      // candidate staging slots per chunk (x2 buffers)
 constexpr uint32_t kJoinSlack = 1024;     // readable entries behind the last stream
 
@@ -150,7 +150,8 @@ struct JoinOff {
   static constexpr uint32_t qts = dummy + 256u;                        // DevQTerm[kMaxTerms]
   static constexpr uint32_t jts = qts + uint32_t(sizeof(DevQTerm)) * kMaxTerms;   // JoinTerm[kMaxTerms]
   static constexpr uint32_t rng = jts + uint32_t(sizeof(JoinTerm)) * kMaxTerms;   // [chunk tiles + 1][kMaxTerms] u32
-  static constexpr uint32_t sig = rng + 4u * (kJoinChunkTiles + 1u) * kMaxTerms;  // [2][16] u32
+  static constexpr uint32_t cum = rng + 4u * (kJoinChunkTiles + 1u) * kMaxTerms;  // [chunk tiles][kMaxTerms] u32
+  static constexpr uint32_t sig = cum + 4u * kJoinChunkTiles * kMaxTerms;         // [2][16] u32
   static constexpr uint32_t cand = sig + 4u * 2u * 16u;                // [2][kJoinCands] u64
   static constexpr uint32_t vars = cand + 8u * 2u * kJoinCands;        // [16] u32
   static constexpr uint32_t caches = vars + 64u;                       // [kTableRows][256] f32
@@ -184,24 +185,24 @@ __device__ __forceinline__ uint32_t join_dummy(unsigned lane) {
   return (JoinOff::dummy + 4u * lane) << 16;
 }
 
-// Four entries per lane: table reads back to back, then the multiply-adds, then the LDS adds.
-// FORM kJTable: every frequency of the term has a table row, score = cs * T_tf[norm] — the
-// entry's low 16 bits ARE the offset of T_tf[norm] inside the slot; else row 0 and the general
-// expression (score.h tile_post: v_rcp / v_sqrt form).
-template<int FORM>
-__device__ __forceinline__ void join_post4(const unsigned char* lds, uint32_t e0, uint32_t e1,
-                                           uint32_t e2, uint32_t e3, float cs, uint32_t tabofs) {
-  const uint32_t e[4] = {e0, e1, e2, e3};
-  float t[4];
-  uint32_t fx[4];
+// N entries per lane (N slabs of 64): table reads back to back, then the multiply-adds, then
+// the LDS adds.  FORM kJTable: every frequency of the term has a table row, score =
+// cs * T_tf[norm] — the entry's low 16 bits ARE the offset of T_tf[norm] inside the slot; else
+// row 0 and the general expression (score.h tile_post: v_rcp / v_sqrt form).
+template<int FORM, int N>
+__device__ __forceinline__ void join_post(const unsigned char* lds, const uint32_t (&e)[4],
+                                          float cs, uint32_t tabofs) {
+  float t[N];
+  uint32_t fx[N];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < N; ++k) {
     const uint32_t at = (FORM == kJTable) ? ((e[k] & 0xFFFFu) | tabofs) : ((e[k] & 0x3FCu) | tabofs);
     t[k] = wave::lds_f32(lds, JoinOff::caches + at);
   }
-  wave::keep_all_f(t);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < N; ++k) wave::keep_f(t[k]);
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
     if (FORM == kJTable) {
       fx[k] = static_cast<uint32_t>(wave::fma(cs, t[k], 1.f));
     } else {
@@ -213,27 +214,46 @@ __device__ __forceinline__ void join_post4(const unsigned char* lds, uint32_t e0
     }
   }
 #pragma unroll
-  for (int k = 0; k < 4; ++k) wave::lds_add(lds, JoinOff::acc + (e[k] >> 16), fx[k]);
+  for (int k = 0; k < N; ++k) wave::lds_add(lds, JoinOff::acc + (e[k] >> 16), fx[k]);
 }
-__device__ __forceinline__ void join_post4_any(const unsigned char* lds, uint32_t e0, uint32_t e1,
-                                               uint32_t e2, uint32_t e3, float cs, uint32_t mode) {
-  const uint32_t tabofs = mode & kJoinTabMask;
-  const int form = join_form(mode);   // (wave-uniform)
-  if (form == kJTable) join_post4<kJTable>(lds, e0, e1, e2, e3, cs, tabofs);
-  else if (form == kJRcp) join_post4<kJRcp>(lds, e0, e1, e2, e3, cs, tabofs);
-  else join_post4<kJSqrt>(lds, e0, e1, e2, e3, cs, tabofs);
+// `slabs` (1..4, wave-uniform) of them
+template<int FORM>
+__device__ __forceinline__ void join_post_n(const unsigned char* lds, const uint32_t (&e)[4],
+                                            uint32_t slabs, float cs, uint32_t tabofs) {
+  if (slabs >= 4u) join_post<FORM, 4>(lds, e, cs, tabofs);
+  else if (slabs == 3u) join_post<FORM, 3>(lds, e, cs, tabofs);
+  else if (slabs == 2u) join_post<FORM, 2>(lds, e, cs, tabofs);
+  else join_post<FORM, 1>(lds, e, cs, tabofs);
+}
+template<bool SIMPLE>
+__device__ __forceinline__ void join_post_any(const unsigned char* lds, const uint32_t (&e)[4],
+                                              uint32_t slabs, float cs, uint32_t mode) {
+  if (SIMPLE) {
+    join_post_n<kJTable>(lds, e, slabs, cs, 0u);
+  } else {
+    const uint32_t tabofs = mode & kJoinTabMask;
+    const int form = join_form(mode);   // (wave-uniform)
+    if (form == kJTable) join_post_n<kJTable>(lds, e, slabs, cs, tabofs);
+    else if (form == kJRcp) join_post_n<kJRcp>(lds, e, slabs, cs, tabofs);
+    else join_post_n<kJSqrt>(lds, e, slabs, cs, tabofs);
+  }
 }
 
-// Slabs [0, 4) of `count` (> 0) entries at `base`: a dword per lane and slab (coalesced); lanes
-// past the end keep their dummy entry, so whatever consumes the four values needs no mask.
-__device__ __forceinline__ void join_load4(uint64_t base, uint32_t count, unsigned lane,
-                                           uint32_t& e0, uint32_t& e1, uint32_t& e2, uint32_t& e3) {
+// The first ceil(count / 64) <= 4 slabs of `count` (> 0) entries at `base`: a dword per lane and
+// slab (coalesced); lanes past the end keep their dummy entry, so whatever consumes the values
+// needs no mask; slabs past the end are not loaded at all.
+__device__ __forceinline__ void join_load(uint64_t base, uint32_t count, unsigned lane,
+                                          uint32_t (&e)[4]) {
   const uint32_t off = lane * 4u;
-  e0 = e1 = e2 = e3 = join_dummy(lane);
-  if (lane < count) e0 = wave::gload_u32(base, off);
-  if (lane + 64u < count) e1 = wave::gload_u32(base, off + 256u);
-  if (lane + 128u < count) e2 = wave::gload_u32(base, off + 512u);
-  if (lane + 192u < count) e3 = wave::gload_u32(base, off + 768u);
+  e[0] = e[1] = e[2] = e[3] = join_dummy(lane);
+  if (lane < count) e[0] = wave::gload_u32(base, off);
+  if (count > 64u) {   // (wave-uniform)
+    if (lane + 64u < count) e[1] = wave::gload_u32(base, off + 256u);
+    if (count > 128u) {
+      if (lane + 128u < count) e[2] = wave::gload_u32(base, off + 512u);
+      if (count > 192u && lane + 192u < count) e[3] = wave::gload_u32(base, off + 768u);
+    }
+  }
 }
 
 // `count` consecutive entries from address `base` (wave-uniform), 256 per step.
@@ -246,98 +266,123 @@ __device__ __forceinline__ void join_run(const unsigned char* lds, uint64_t base
 #pragma unroll
     for (int k = 0; k < 4; ++k) e[k] = wave::gload_u32(base, off + 256u * uint32_t(k));
     wave::keep_all(e);
-    join_post4<FORM>(lds, e[0], e[1], e[2], e[3], cs, tabofs);
+    join_post<FORM, 4>(lds, e, cs, tabofs);
     base += 1024u;
     count -= 256u;
   }
   if (count) {
-    uint32_t e0, e1, e2, e3;
-    join_load4(base, count, lane, e0, e1, e2, e3);
-    join_post4<FORM>(lds, e0, e1, e2, e3, cs, tabofs);
+    uint32_t e[4];
+    join_load(base, count, lane, e);
+    join_post_n<FORM>(lds, e, (count + 63u) >> 6, cs, tabofs);
   }
 }
 
-// A wavefront's share of one tile.  The entries of all terms are cut into slabs of 64 (per
-// term: its range in the tile is contiguous, the last slab partial); the tile's slabs are
-// numbered term after term and wavefront w of nw takes slabs [S*w/nw, S*(w+1)/nw) — a
-// contiguous run that touches one or two terms.  begin() works that out and REQUESTS the first
-// kJoinPre slabs of the run's first term (the loads then fly behind the previous tile's barrier
-// and epilogue); finish() consumes them and streams whatever is left.
-constexpr int kJoinPre = 8;   // 4 or 8
+// A wavefront's share of one tile.  The entries of the query's terms in the tile, term after
+// term, are one sequence of N entries; wavefront w of nw takes [N*w/nw, N*(w+1)/nw) — a
+// contiguous piece that touches one or two terms, rarely more.  begin() intersects that piece
+// with every term's range (lane j = term j) and REQUESTS the first kJoinPre * 64 entries of the
+// first term it touches — the loads then fly behind the previous tile's barrier and epilogue;
+// finish() consumes them and streams whatever is left.  SIMPLE: every term of the query scores
+// through table slot 0 (one scorer, small frequencies — the usual batch): no per-term form.
+constexpr uint32_t kJoinPre = 256;   // entries begin() requests: four loads, always
 struct JoinRun {
-  uint32_t a, n, slabs, P;   // lane j = term j: first entry in the tile, entries, slabs, prefix
-  uint32_t s, hi, j;         // (uniform) next slab of the run, its end, the term slab s is in
-  uint32_t pre;              // (uniform) slabs requested by begin(): 0, 1..4 (e[0..3]) or 5..8
-  float cs;                  // (uniform) of the requested term
+  uint32_t a_lo, a_hi;   // lane j = term j: address of the first entry this wavefront takes
+  uint32_t cnt;          //   and how many (0: none)
+  uint64_t mask;         // (uniform) terms with cnt > 0 that are still to do
+  uint64_t rest;         // (uniform) what begin() left of its term: address,
+  uint32_t left;         //   entries
+  uint32_t pre;          // (uniform) entries requested by begin(): 0 .. kJoinPre
+  float cs;              // (uniform) of that term
   uint32_t mode;
-  uint32_t e[8];
+  uint32_t e[4];         // the requested slabs, RAW: lanes past `pre` hold some other entry
 };
 
+// a = first entry of term j in the tile (index into its stream), n = its entries there,
+// c = inclusive prefix sum of n over the terms (lanes beyond the query's terms: n = 0).
+// Always issues exactly four loads (to `safe`, any readable address, when the share is empty;
+// lanes past the end re-read the share's last entry): two runs are in flight at a time — the
+// next tile's and the one after — and only a FIXED number of younger loads lets the wait for
+// the older run's data leave the younger one's in flight (s_waitcnt vmcnt(4)).
+template<bool SIMPLE>
 __device__ __forceinline__ void join_begin(JoinRun& r, const JoinLane& T, uint32_t a, uint32_t n,
-                                           uint32_t wv, uint32_t nw_log2, unsigned lane) {
-  r.a = a;
-  r.n = n;
-  r.slabs = (n + 63u) >> 6;
-  r.P = wave::inclusive_scan(r.slabs);
-  const uint32_t S = wave::read_lane(r.P, 63u);
-  const uint32_t lo = (S * wv) >> nw_log2;
-  r.hi = (S * (wv + 1u)) >> nw_log2;
-  r.s = lo;
-  r.pre = 0;
-  r.j = 0;
+                                           uint32_t c, uint32_t wv, uint32_t nw_log2,
+                                           uint64_t safe, unsigned lane) {
+  const uint32_t N = wave::read_lane(c, kMaxTerms - 1u);
+  const uint32_t lo = (N * wv) >> nw_log2, hi = (N * (wv + 1u)) >> nw_log2;
+  const uint32_t first = c - n;                      // the term's position in the sequence
+  const uint32_t st = lo > first ? lo : first;
+  const uint32_t en = hi < c ? hi : c;
+  r.cnt = en > st ? en - st : 0u;
+  const uint64_t addr = ((uint64_t(T.ent_hi) << 32) | T.ent_lo) + 4ull * (uint64_t(a) + (st - first));
+  r.a_lo = uint32_t(addr);
+  r.a_hi = uint32_t(addr >> 32);
+  uint64_t mask = wave::ballot(r.cnt != 0u);
+  uint64_t base = safe;
+  uint32_t take = 0;
+  r.left = 0;
+  r.rest = 0;
   r.cs = 0.f;
   r.mode = 0;
-  if (lo == r.hi) return;
-  const uint32_t j = wave::uniform(uint32_t(__builtin_ctzll(wave::ballot(r.P > lo))));
-  r.j = j;
-  const uint32_t Pj = wave::read_lane(r.P, j);
-  const uint32_t end = Pj < r.hi ? Pj : r.hi;
-  const uint32_t first = (lo - (Pj - wave::read_lane(r.slabs, j))) << 6;
-  const uint32_t left = wave::read_lane(n, j) - first;
-  uint32_t take = end - lo;
-  if (take > uint32_t(kJoinPre)) take = uint32_t(kJoinPre);
-  const uint32_t want = take << 6;
-  const uint32_t cnt = left < want ? left : want;
-  const uint64_t base = ((uint64_t(wave::read_lane(T.ent_hi, j)) << 32) | wave::read_lane(T.ent_lo, j)) +
-                        4ull * (uint64_t(wave::read_lane(a, j)) + first);
-  r.cs = wave::read_lane_f(T.cs, j);
-  r.mode = wave::read_lane(T.mode, j);
+  if (mask) {
+    const uint32_t j = uint32_t(__builtin_ctzll(mask));
+    mask &= mask - 1ull;
+    base = (uint64_t(wave::read_lane(r.a_hi, j)) << 32) | wave::read_lane(r.a_lo, j);
+    const uint32_t cnt = wave::read_lane(r.cnt, j);
+    r.cs = wave::read_lane_f(T.cs, j);
+    if (!SIMPLE) r.mode = wave::read_lane(T.mode, j);
+    take = cnt < kJoinPre ? cnt : kJoinPre;
+    r.left = cnt - take;
+    r.rest = base + 4ull * take;
+  }
   r.pre = take;
-  r.s = lo + take;
-  join_load4(base, cnt, lane, r.e[0], r.e[1], r.e[2], r.e[3]);
-  if (kJoinPre > 4 && take > 4u)
-    join_load4(base + 1024u, cnt - 256u, lane, r.e[4], r.e[5], r.e[6], r.e[7]);
+  r.mask = mask;
+  const uint32_t last = take ? (take - 1u) * 4u : 0u;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t off = lane * 4u + 256u * uint32_t(k);
+    r.e[k] = wave::gload_u32(base, off < last ? off : last);
+  }
 }
 
+template<bool SIMPLE>
+__device__ __forceinline__ void join_some(const unsigned char* lds, uint64_t base, uint32_t cnt,
+                                          float cs, uint32_t mode, unsigned lane) {
+  if (SIMPLE) {
+    join_run<kJTable>(lds, base, cnt, cs, 0u, lane);
+  } else {
+    const uint32_t tabofs = mode & kJoinTabMask;
+    const int form = join_form(mode);
+    if (form == kJTable) join_run<kJTable>(lds, base, cnt, cs, tabofs, lane);
+    else if (form == kJRcp) join_run<kJRcp>(lds, base, cnt, cs, tabofs, lane);
+    else join_run<kJSqrt>(lds, base, cnt, cs, tabofs, lane);
+  }
+}
+
+template<bool SIMPLE>
 __device__ __forceinline__ void join_finish(const unsigned char* lds, JoinRun& r, const JoinLane& T,
                                             unsigned lane) {
   // (the run's scalars crossed a barrier and a loop back edge inside a struct: the compiler no
   // longer knows they are wave-uniform and would predicate everything below lane by lane)
-  const uint32_t pre = wave::uniform(r.pre), mode0 = wave::uniform(r.mode), hi = wave::uniform(r.hi);
+  const uint32_t pre = wave::uniform(r.pre);
+  if (!pre) return;   // (nothing requested: nothing at all)
+  const uint32_t mode0 = SIMPLE ? 0u : wave::uniform(r.mode);
   const float cs0 = wave::uniform_f(r.cs);
-  if (pre) join_post4_any(lds, r.e[0], r.e[1], r.e[2], r.e[3], cs0, mode0);
-  if (kJoinPre > 4 && pre > 4u) join_post4_any(lds, r.e[4], r.e[5], r.e[6], r.e[7], cs0, mode0);
-  uint32_t s = wave::uniform(r.s), j = wave::uniform(r.j);
-  while (s < hi) {
-    const uint32_t Pj = wave::read_lane(r.P, j);
-    const uint32_t end = Pj < hi ? Pj : hi;
-    if (end > s) {   // (a term without entries here has Pj == P[j-1] <= s)
-      const uint32_t first = (s - (Pj - wave::read_lane(r.slabs, j))) << 6;
-      const uint32_t left = wave::read_lane(r.n, j) - first;
-      const uint32_t want = (end - s) << 6;
-      const uint32_t cnt = left < want ? left : want;
-      const uint64_t base = ((uint64_t(wave::read_lane(T.ent_hi, j)) << 32) | wave::read_lane(T.ent_lo, j)) +
-                            4ull * (uint64_t(wave::read_lane(r.a, j)) + first);
-      const float cs = wave::read_lane_f(T.cs, j);
-      const uint32_t mode = wave::read_lane(T.mode, j);
-      const uint32_t tabofs = mode & kJoinTabMask;
-      const int form = join_form(mode);
-      if (form == kJTable) join_run<kJTable>(lds, base, cnt, cs, tabofs, lane);
-      else if (form == kJRcp) join_run<kJRcp>(lds, base, cnt, cs, tabofs, lane);
-      else join_run<kJSqrt>(lds, base, cnt, cs, tabofs, lane);
-      s = end;
-    }
-    ++j;
+  {
+    const uint32_t dummy = join_dummy(lane);
+    uint32_t e[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e[k] = lane + 64u * uint32_t(k) < pre ? r.e[k] : dummy;
+    join_post_any<SIMPLE>(lds, e, (pre + 63u) >> 6, cs0, mode0);
+  }
+  const uint32_t left = wave::uniform(r.left);
+  if (left) join_some<SIMPLE>(lds, wave::uniform64(r.rest), left, cs0, mode0, lane);
+  uint64_t mask = wave::uniform64(r.mask);
+  while (mask) {
+    const uint32_t j = uint32_t(__builtin_ctzll(mask));
+    mask &= mask - 1ull;
+    const uint64_t base = (uint64_t(wave::read_lane(r.a_hi, j)) << 32) | wave::read_lane(r.a_lo, j);
+    join_some<SIMPLE>(lds, base, wave::read_lane(r.cnt, j), wave::read_lane_f(T.cs, j),
+                      SIMPLE ? 0u : wave::read_lane(T.mode, j), lane);
   }
 }
 
@@ -446,8 +491,9 @@ k_join_pilot(const uint32_t* units, const DevQuery* queries, const DevQTerm* qte
       n = bnd[tile + 1u] - a;
     }
     JoinRun r;
-    join_begin(r, T, a, n, wv, nw_log2, lane);
-    join_finish(smem, r, T, lane);
+    join_begin<false>(r, T, a, n, wave::inclusive_scan(n), wv, nw_log2,
+                      reinterpret_cast<uint64_t>(jterms), lane);
+    join_finish<false>(smem, r, T, lane);
     __syncthreads();
     for (uint32_t i = tid; i < kJoinTile; i += blockDim.x) {
       const uint32_t f = acc[i];
@@ -488,6 +534,102 @@ k_join_pilot(const uint32_t* units, const DevQuery* queries, const DevQTerm* qte
   }
 }
 
+// The tiles of one chunk (k_join_score); everything per query / per chunk arrives in `ctx`.
+struct JoinTileCtx {
+  const JoinArgs* args;
+  uint32_t q, bs, thr, cap;
+  float fx_inv, bin_scale;
+  uint64_t* lc;        // this chunk's candidate staging buffer
+  uint32_t* ncand;     // ... and its fill count
+};
+
+template<bool SIMPLE>
+__device__ __forceinline__ void join_tiles(unsigned char* smem, const JoinTileCtx& ctx,
+                                           const JoinLane& T, uint32_t tile0, uint32_t ntile,
+                                           uint32_t wv, uint32_t nw_log2, uint32_t& my_hits) {
+  const uint32_t* rng = reinterpret_cast<const uint32_t*>(smem + JoinOff::rng);
+  const uint32_t* cum = reinterpret_cast<const uint32_t*>(smem + JoinOff::cum);
+  const uint32_t tid = threadIdx.x;
+  const unsigned lane = tid & 63u;
+  const uint64_t safe = reinterpret_cast<uint64_t>(ctx.args->jterms);
+  auto begin = [&](uint32_t u, JoinRun& r) {   // (u >= ntile: an empty share, four loads all the same)
+    uint32_t a = 0, n = 0, c = 0;
+    if (lane < kMaxTerms && u < ntile) {
+      a = rng[u * kMaxTerms + lane];
+      n = rng[(u + 1u) * kMaxTerms + lane] - a;
+      c = cum[u * kMaxTerms + lane];
+    }
+    join_begin<SIMPLE>(r, T, a, n, c, wv, nw_log2, safe, lane);
+  };
+  // two runs in flight: while tile u is being accumulated, the entries of tiles u+1 AND u+2
+  // are on their way (a request then has a whole tile's time to come back from HBM, not just
+  // an epilogue's); the loop is unrolled by two so that the two register sets simply alternate
+  JoinRun r0, r1;
+  begin(0, r0);
+  begin(1, r1);
+  // barrier B1 + epilogue + barrier B2 of tile u
+  auto end_tile = [&](uint32_t u) {
+    __syncthreads();   // B1: every accumulation of tile u has landed
+    const uint32_t doc0 = kDocMin + (tile0 + u) * kJoinTile;
+    auto candidate = [&](uint32_t i, uint32_t f) {   // rare
+      const float v = f <= kMaxTerms ? 0.f : from_fixed<uint32_t>(f, ctx.fx_inv);
+      if (score_bin(v, ctx.bin_scale) >= ctx.bs) {
+        const uint64_t key = make_key(v, doc0 + i);
+        const uint32_t slot = atomicAdd(ctx.ncand, 1u);
+        if (slot < kJoinCands) {
+          ctx.lc[slot] = key;
+        } else {   // rarer: more candidates in one chunk than staging slots
+          const uint32_t g = atomicAdd(&ctx.args->cand_count[ctx.q], 1u);
+          if (g < ctx.cap) ctx.args->cands[uint64_t(ctx.q) * ctx.cap + g] = key;
+        }
+      }
+    };
+    // four accumulators per lane read AND cleared by one LDS exchange; two in flight where the
+    // geometry allows
+    auto four = [&](uint32_t i, const uint32_t (&v)[4]) {
+      wave::count_nonzero4(my_hits, v[0], v[1], v[2], v[3]);
+      uint32_t top = v[0] > v[1] ? v[0] : v[1];
+      const uint32_t top2 = v[2] > v[3] ? v[2] : v[3];
+      top = top > top2 ? top : top2;
+      if (top >= ctx.thr) {   // rare: one copy of the candidate code, per-lane loop
+        uint32_t cm = (v[0] >= ctx.thr ? 1u : 0u) | (v[1] >= ctx.thr ? 2u : 0u) |
+                      (v[2] >= ctx.thr ? 4u : 0u) | (v[3] >= ctx.thr ? 8u : 0u);
+        while (cm) {
+          const uint32_t e = uint32_t(__builtin_ctz(cm));
+          cm &= cm - 1u;
+          const uint32_t x = e == 0u ? v[0] : (e == 1u ? v[1] : (e == 2u ? v[2] : v[3]));
+          candidate(i + e, x);
+        }
+      }
+    };
+    const uint32_t step = blockDim.x * 4u;
+    uint32_t i = tid * 4u;
+    for (; i + step < kJoinTile; i += 2u * step) {
+      uint32_t v0[4], v1[4];
+      wave::lds_take4x2(smem, JoinOff::acc + i * 4u, JoinOff::acc + (i + step) * 4u, v0, v1);
+      four(i, v0);
+      four(i + step, v1);
+    }
+    if (i < kJoinTile) {
+      uint32_t v0[4];
+      wave::lds_take4(smem, JoinOff::acc + i * 4u, v0);
+      four(i, v0);
+    }
+    __syncthreads();   // B2: accumulators are clear again
+  };
+  // straight-line pairs of tiles (the compiler's wait-count bookkeeping only sees the fixed
+  // distance between a run's loads and its use when no branch separates the two register
+  // sets); an odd tile count ends with an empty share, whose begin / finish do nothing
+  for (uint32_t u = 0; u < ntile; u += 2u) {
+    join_finish<SIMPLE>(smem, r0, T, lane);
+    begin(u + 2u, r0);
+    end_tile(u);
+    join_finish<SIMPLE>(smem, r1, T, lane);
+    begin(u + 3u, r1);
+    if (u + 1u < ntile) end_tile(u + 1u);
+  }
+}
+
 // Persistent workgroups pulling chunks of kJoinChunkTiles consecutive tiles of one unit
 // (chunk-major ids, heaviest units first: score.h k_score).  Per tile and wavefront:
 //   finish(u)     consume the requested entries of tile u, stream the rest of its share
@@ -512,6 +654,7 @@ k_join_score(const JoinArgs* __restrict__ args) {
   if (!wave::lds_is_at_zero(smem)) __builtin_trap();
   uint32_t* acc = reinterpret_cast<uint32_t*>(smem + JoinOff::acc);
   uint32_t* rng = reinterpret_cast<uint32_t*>(smem + JoinOff::rng);
+  uint32_t* cum = reinterpret_cast<uint32_t*>(smem + JoinOff::cum);
   uint32_t* sig = reinterpret_cast<uint32_t*>(smem + JoinOff::sig);
   uint64_t* lcand = reinterpret_cast<uint64_t*>(smem + JoinOff::cand);
   uint32_t* vars = reinterpret_cast<uint32_t*>(smem + JoinOff::vars);
@@ -559,65 +702,30 @@ k_join_score(const JoinArgs* __restrict__ args) {
         rng[e] = v;
       }
       join_prologue(smem, qd, args->qterms, args->jterms);   // (its barrier publishes rng too)
+      // per tile: the inclusive prefix of the terms' entry counts (what join_begin splits)
+      for (uint32_t e = tid; e < ntile * kMaxTerms; e += blockDim.x) {
+        const uint32_t i = e / kMaxTerms, j = e % kMaxTerms;
+        uint32_t c = 0;
+        for (uint32_t t = 0; t <= j; ++t)
+          c += rng[(i + 1u) * kMaxTerms + t] - rng[i * kMaxTerms + t];
+        cum[e] = c;
+      }
+      __syncthreads();
       const JoinLane T = join_lane(smem, lane);
-      const uint32_t thr = bin_threshold<uint32_t>(bs, qd);
-      auto range = [&](uint32_t u, uint32_t& a, uint32_t& n) {
-        a = 0;
-        n = 0;
-        if (lane < kMaxTerms) {
-          a = rng[u * kMaxTerms + lane];
-          n = rng[(u + 1u) * kMaxTerms + lane] - a;
-        }
-      };
-      JoinRun r;
-      {
-        uint32_t a, n;
-        range(0, a, n);
-        join_begin(r, T, a, n, wv, nw_log2, lane);
-      }
-      for (uint32_t u = 0; u < ntile; ++u) {
-        join_finish(smem, r, T, lane);
-        if (u + 1u < ntile) {
-          uint32_t a, n;
-          range(u + 1u, a, n);
-          join_begin(r, T, a, n, wv, nw_log2, lane);
-        }
-        __syncthreads();   // B1: every accumulation of tile u has landed
-        const uint32_t doc0 = kDocMin + (tile0 + u) * kJoinTile;
-        auto candidate = [&](uint32_t i, uint32_t f) {   // rare
-          const float v = f <= kMaxTerms ? 0.f : from_fixed<uint32_t>(f, qd.fx_inv);
-          if (score_bin(v, qd.bin_scale) >= bs) {
-            const uint64_t key = make_key(v, doc0 + i);
-            const uint32_t slot = atomicAdd(ncand, 1u);
-            if (slot < kJoinCands) {
-              lc[slot] = key;
-            } else {   // rarer: more candidates in one chunk than staging slots
-              const uint32_t g = atomicAdd(&args->cand_count[q], 1u);
-              if (g < cap) args->cands[uint64_t(q) * cap + g] = key;
-            }
-          }
-        };
-        for (uint32_t i = tid * 4u; i < kJoinTile; i += blockDim.x * 4u) {
-          uint32_t v[4];
-          wave::lds_read4(smem, JoinOff::acc + i * 4u, v);
-          wave::lds_zero4(smem, JoinOff::acc + i * 4u);
-          wave::count_nonzero4(my_hits, v[0], v[1], v[2], v[3]);
-          uint32_t top = v[0] > v[1] ? v[0] : v[1];
-          const uint32_t top2 = v[2] > v[3] ? v[2] : v[3];
-          top = top > top2 ? top : top2;
-          if (top >= thr) {   // rare: one copy of the candidate code, per-lane loop
-            uint32_t cm = (v[0] >= thr ? 1u : 0u) | (v[1] >= thr ? 2u : 0u) |
-                          (v[2] >= thr ? 4u : 0u) | (v[3] >= thr ? 8u : 0u);
-            while (cm) {
-              const uint32_t e = uint32_t(__builtin_ctz(cm));
-              cm &= cm - 1u;
-              const uint32_t x = e == 0u ? v[0] : (e == 1u ? v[1] : (e == 2u ? v[2] : v[3]));
-              candidate(i + e, x);
-            }
-          }
-        }
-        __syncthreads();   // B2: accumulators are clear again
-      }
+      // every term through table slot 0?  (wave-uniform, the same in every wavefront)
+      const bool simple = wave::ballot(T.mode != 0u) == 0ull;
+      JoinTileCtx ctx;
+      ctx.args = args;
+      ctx.q = q;
+      ctx.bs = bs;
+      ctx.thr = bin_threshold<uint32_t>(bs, qd);
+      ctx.fx_inv = qd.fx_inv;
+      ctx.bin_scale = qd.bin_scale;
+      ctx.cap = cap;
+      ctx.lc = lc;
+      ctx.ncand = ncand;
+      if (simple) join_tiles<true>(smem, ctx, T, tile0, ntile, wv, nw_log2, my_hits);
+      else join_tiles<false>(smem, ctx, T, tile0, ntile, wv, nw_log2, my_hits);
     }
     // ---- chunk hand-over: flush the PREVIOUS chunk's staged candidates (their reservation
     // has had a whole chunk to come back), reserve slots for this chunk's, publish hits

@@ -69,6 +69,7 @@ __device__ __forceinline__ uint64_t gload_u64(uint64_t base, uint32_t off) {
 // wave-uniform value -> scalar register on the GPU; identity here
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return v; }
 __device__ __forceinline__ float uniform_f(float v) { return v; }
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) { return v; }
 __device__ __forceinline__ void inclusive_scan2(uint32_t& a, uint32_t& b) {
   a = inclusive_scan(a);
   b = inclusive_scan(b);
@@ -107,6 +108,15 @@ __device__ __forceinline__ void lds_read4(const unsigned char* base, uint32_t of
 }
 __device__ __forceinline__ void lds_zero4(unsigned char* base, uint32_t off) {
   __builtin_memset(base + off, 0, 16);
+}
+__device__ __forceinline__ void lds_take4(unsigned char* base, uint32_t off, uint32_t (&v)[4]) {
+  __builtin_memcpy(v, base + off, 16);
+  __builtin_memset(base + off, 0, 16);
+}
+__device__ __forceinline__ void lds_take4x2(unsigned char* base, uint32_t off0, uint32_t off1,
+                                            uint32_t (&a)[4], uint32_t (&b)[4]) {
+  lds_take4(base, off0, a);
+  lds_take4(base, off1, b);
 }
 __device__ __forceinline__ uint32_t gload_u32(uint64_t base, uint32_t off) {
   uint32_t v;
