@@ -338,8 +338,9 @@ int irs_hip_batch_set_wand(irs_hip_batch* batch, int enable);
  * it executed before (utils/index-search.cpp:737, 756, 777).  min_scores: [n_queries] floats
  * >= 0 (0 = none), or NULL to clear.  A doc scoring below min_scores[q] is not competitive: the
  * batch may drop it (pruning then starts from that bound instead of from the pilot pass's
- * estimate alone), so a query returns the docs at or above its threshold, at most k of them,
- * in the usual order — possibly fewer than k; total_hits still counts every match.  May be
+ * estimate alone), so a query returns exactly the docs scoring at or above its threshold,
+ * at most k of them, in the usual order — possibly fewer than k (the kernels drop by score bin,
+ * the final selection by the score itself); total_hits still counts every match.  May be
  * called between runs. */
 int irs_hip_batch_set_min_scores(irs_hip_batch* batch, const float* min_scores);
 /* The block-max data of one term, for inspection/tests (computed as for set_wand): largest

@@ -24,6 +24,7 @@ WAND_NONE, WAND_DIV_NORM, WAND_MAX_FREQ, WAND_MIN_NORM = 0, 1, 2, 3   # Scorer::
 MAX_TERMS, MAX_K, MAX_PHRASE_TERMS = 16, 4096, 8
 K_PLAN, K_PILOT, K_SCORE, K_SELECT, K_COUNT = 0, 1, 2, 3, 4
 KERNEL_NAMES = ("k_plan", "k_pilot", "k_score", "k_select")
+KERNEL_NAMES_JOINED = ("k_join", "k_join_pilot", "k_join_score", "k_select")
 
 TERM_META = np.dtype(
     [("docs_count", "<u4"), ("freq", "<u4"), ("doc_start", "<u8"), ("pos_start", "<u8"),

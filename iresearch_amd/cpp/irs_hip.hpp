@@ -20,6 +20,7 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <variant>
@@ -622,11 +623,14 @@ class Communicator {
   irs_hip_comm* h_ = nullptr;
 };
 
-// Every rank calls this with ITS segments (`first_segment` = global ordinal of the first one;
-// ranks hold consecutive blocks of `per_rank` segments, the last block may be short) and the
-// statistics of ALL segments of the index (they are index-global: term_filter.cpp:102-125).
-// Returns, on every rank, the global top-k per query: ScoredDoc::segment is the GLOBAL ordinal.
-// The queries must be all boolean or all by_phrase.
+// Every rank calls this with ITS segments (ranks hold consecutive blocks of `per_rank` segments
+// of the index's `n_segments`; the last block may be short, a rank may hold none — 5 segments on
+// 8 ranks) and the statistics of ALL segments of the index (they are index-global:
+// term_filter.cpp:102-125).  Returns, on every rank, the global top-k per query:
+// ScoredDoc::segment is the GLOBAL ordinal.  The queries must be all boolean or all by_phrase.
+// Every rank reaches the collective whatever happens locally: a rank whose own execution
+// fails sends a failure mark with its (empty) block and all ranks throw AFTER the all-gather —
+// nobody is left waiting in it.
 template<typename Scorer>
 std::vector<std::vector<ScoredDoc>> search_sharded(Communicator& comm,
                                                    const std::vector<const SegmentReader*>& mine,
@@ -637,26 +641,42 @@ std::vector<std::vector<ScoredDoc>> search_sharded(Communicator& comm,
   const uint32_t nq = uint32_t(filters.size());
   const int32_t dev = comm.device();
   if (mine.size() > per_rank) throw illegal_argument(IRS_HIP_EINVAL, "more local segments than per_rank");
-  QueryBatch batch(mine.empty() ? std::vector<const SegmentReader*>{} : mine,
-                   prepare(filters, scorer, index), k);
   // one block per rank: per_rank hit tables [nq][k], then per_rank count tables [nq] (padded
-  // to 8 bytes) — irs_hip_batch_results_to_device writes the local lists straight into it
+  // to 8 bytes) — irs_hip_batch_results_to_device writes the local lists straight into it —
+  // then 8 bytes of status (0 = this rank's part is good)
   const uint64_t hit_bytes = uint64_t(per_rank) * nq * k * sizeof(irs_hip_hit);
   const uint64_t cnt_bytes = (uint64_t(per_rank) * nq * 4 + 7) & ~uint64_t(7);
-  const uint64_t block = hit_bytes + cnt_bytes;
+  const uint64_t block = hit_bytes + cnt_bytes + 8;
   DeviceBuffer send(dev, block), recv(dev, block * uint64_t(comm.n_ranks()));
-  {
-    std::vector<char> zero(block, 0);   // slots of segments this rank does not have: count 0
+  std::vector<char> zero(block, 0);   // slots of segments this rank does not have: count 0
+  check(irs_hip_device_upload(dev, send.get(), zero.data(), block), "irs_hip_device_upload");
+  std::string local_error;
+  try {
+    if (!mine.empty()) {   // (a rank without segments has no batch to build)
+      QueryBatch batch(mine, prepare(filters, scorer, index), k);
+      if (wand) batch.set_wand(true);
+      batch.run();
+      check(irs_hip_batch_results_to_device(batch.single_part(), send.at(0), send.at(hit_bytes), nullptr),
+            "irs_hip_batch_results_to_device");
+      check(irs_hip_device_sync(dev, nullptr), "irs_hip_device_sync");
+    }
+  } catch (const std::exception& e) {
+    local_error = e.what();
+    const uint64_t failed = 1;     // the block goes out empty, marked
+    std::memcpy(zero.data() + hit_bytes + cnt_bytes, &failed, 8);
     check(irs_hip_device_upload(dev, send.get(), zero.data(), block), "irs_hip_device_upload");
-  }
-  if (!mine.empty()) {
-    if (wand) batch.set_wand(true);
-    batch.run();
-    check(irs_hip_batch_results_to_device(batch.single_part(), send.at(0), send.at(hit_bytes), nullptr),
-          "irs_hip_batch_results_to_device");
   }
   check(irs_hip_device_sync(dev, nullptr), "irs_hip_device_sync");
   comm.all_gather(send.get(), recv.get(), block);
+  for (int r = 0; r < comm.n_ranks(); ++r) {
+    uint64_t st = 0;
+    check(irs_hip_device_download(dev, &st, recv.at(block * uint64_t(r) + hit_bytes + cnt_bytes), 8),
+          "irs_hip_device_download");
+    if (st) {
+      throw error(IRS_HIP_EHIP, r == comm.rank() ? "search_sharded: " + local_error
+                                                 : "search_sharded: rank " + std::to_string(r) + " failed");
+    }
+  }
   std::vector<const void*> lists, counts;
   std::vector<uint32_t> ids;
   for (uint32_t s = 0; s < n_segments; ++s) {

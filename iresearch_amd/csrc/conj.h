@@ -292,7 +292,12 @@ k_conj(ConjArgs A, uint32_t pilot) {
     }
     // every doc of the block scores <= bound: below the threshold bin none can be a candidate
     // (wanderator: skip_scores_[level] <= threshold_, formats_10.cpp:2521-2528)
-    if (score_bin(bound, qd.bin_scale) < bs) return;
+    if (score_bin(bound, qd.bin_scale) < bs) {
+      // (k_select: with blocks skipped, "fewer than k candidates" no longer shows in the hit
+      // count — an estimated threshold that was too high must still be noticed)
+      if (lane == 0 && A.pruned) A.pruned[unit] = 1u;
+      return;
+    }
   }
 
   // ---- 1. the lead block: entry index 2*lane + h (block) or lane + 64*h (tail)

@@ -137,6 +137,7 @@ struct irs_hip_batch {
   DevBuf d_conj_item_base, d_conj_unit_items, d_conj_seek, d_conj_recs;   // k_conj_seek
   DevBuf d_lead_of;   // by_phrase: slot of every unit's lead term
   DevBuf d_min_bin;   // [unit] score bin of the caller's irs::score::Min (irs_hip_batch_set_min_scores)
+  DevBuf d_min_score; // [unit] ... and the score itself (k_select's exact filter)
   bool has_min = false;
   uint32_t conj_total_items = 0;
   DevBuf d_conj_pilot;             // the lead items the pilot pass samples, {unit, item} each
@@ -154,6 +155,7 @@ struct irs_hip_batch {
   // work-item lists of the doc tiles (score.h): per-tile item offsets (+ scan scratch) and
   // the 32-byte records themselves
   DevBuf d_tile_off, d_scan_parts, d_items, d_score_args, d_tile_ub;
+  DevBuf d_pruned;    // [unit] u32: block-max pruning skipped something of the unit in this run
   DevBuf d_touched;   // [unit][2] u64: bytes decoded / positions read by the block-driven kernels
   ScoreArgs score_args{};
   uint32_t total_tiles = 0;    // doc tiles of all units
@@ -168,7 +170,7 @@ struct irs_hip_batch {
     d_join_order;
   uint32_t join_max_tiles = 0;
   uint32_t n_streams = 0, n_join_wgs = 0;
-  uint32_t join_threads = 512, join_nw_log2 = 3;   // threads per k_join_pilot / k_join_score workgroup
+  uint32_t join_threads = 1024, join_nw_log2 = 4;   // threads per k_join_pilot / k_join_score workgroup
   uint64_t join_entries = 0;
   JoinArgs join_args{};
   bool profile = false;
@@ -358,6 +360,7 @@ bool launch_score(irs_hip_batch* b, rt::stream_t st) {
   a.hits = b->d_hits.as<unsigned long long>();
   a.work_counter = b->d_work.as<uint32_t>();
   a.tile_ub = b->wand ? b->d_tile_ub.as<float>() : nullptr;
+  a.pruned = b->d_pruned.as<uint32_t>();
   a.cpq = cpq;
   a.n_units = n_units;
   a.nw_log2 = b->nw_log2;
@@ -453,6 +456,7 @@ bool launch_conj(irs_hip_batch* b, rt::stream_t st) {
   a.cand_cap = b->cand_cap;
   a.pilot_stride = b->stride_eff;
   a.wand = b->wand ? 1u : 0u;
+  a.pruned = b->d_pruned.as<uint32_t>();
   if (!ensure_pilot_list(b, a.pilot_stride, st)) return false;
   if (!rt::dmemset(b->d_conj_hist.p, 0, b->d_conj_hist.n, st)) return false;
   RT_LAUNCH(k_conj_seek, (b->conj_total_items + kThreads - 1) / kThreads, kThreads, 0, st,
@@ -943,7 +947,8 @@ bool ensure_scratch(irs_hip_batch* b) {
       !b->d_hits.alloc(b->nq * sizeof(uint64_t)) ||
       !b->d_out.alloc(uint64_t(b->nq) * b->k_max * sizeof(Hit)) ||
       !b->d_out_count.alloc(b->nq * sizeof(uint32_t)) || !b->d_status.alloc(4) ||
-      !b->d_work.alloc(8) || !b->d_touched.alloc(uint64_t(b->nq) * 16))
+      !b->d_work.alloc(8) || !b->d_touched.alloc(uint64_t(b->nq) * 16) ||
+      !b->d_pruned.alloc(uint64_t(b->nq) * 4))
     return false;
   if (b->joined && !build_streams(b)) return false;
   if (!b->tile_units.empty()) {
@@ -1009,7 +1014,7 @@ static int segment_open_impl(const irs_hip_segment_desc* d, irs_hip_segment** ou
   *out = nullptr;
   if (!d->doc_file || !d->num_docs || d->num_docs > 0x7FFF0000u ||
       (d->layout != IRS_HIP_LAYOUT_SCALAR && d->layout != IRS_HIP_LAYOUT_SIMD4) ||
-      (d->num_terms && !d->terms) || d->wand_count > 16)
+      (d->num_terms && !d->terms) || d->wand_count > 16 || d->wand_type > IRS_HIP_WAND_MIN_NORM)
     return IRS_HIP_EINVAL;
   if (d->norm_kind != IRS_HIP_NORM2 && d->norm_kind != IRS_HIP_NORM_LEGACY) return IRS_HIP_EINVAL;
   if (d->norms) {
@@ -1083,6 +1088,7 @@ static int segment_open_impl(const irs_hip_segment_desc* d, irs_hip_segment** ou
     if (rc != IRS_HIP_OK) break;
     s->total_blocks = blocks;
     s->has_pos = d->pos_file != nullptr;
+    s->wand_type = d->wand_type;
     const uint64_t norm_bytes = d->norms ? uint64_t(d->norm_width) * d->norm_count : 0;
     if (!s->d_doc.alloc(d->doc_file_len + kPadBytes) ||
         (d->norms && !s->d_norms.alloc(norm_bytes + kPadBytes)) ||
@@ -1796,16 +1802,19 @@ static int batch_set_min_scores_impl(irs_hip_batch* b, const float* min_scores) 
   }
   const uint32_t nq_user = b->nq / uint32_t(b->segs.size());
   std::vector<uint32_t> bins(b->nq, 0u);
+  std::vector<float> mins(b->nq, 0.f);
   for (uint32_t u = 0; u < b->nq; ++u) {
     const float m = min_scores[u % nq_user];
     if (!(m >= 0.f)) return IRS_HIP_EINVAL;   // (also NaN)
+    mins[u] = m;
     // the bin score_bin() puts a score of m into: docs at or above m land in it or higher
     const float x = std::fmin(m * b->queries[u].bin_scale, float(kBins - 1));
     bins[u] = uint32_t(x);
   }
   if (b->ran && !rt::sync(b->stream)) return IRS_HIP_EHIP;
-  if (!b->d_min_bin.alloc(bins.size() * 4) ||
-      !rt::h2d(b->d_min_bin.p, bins.data(), bins.size() * 4, nullptr) || !rt::sync(nullptr))
+  if (!b->d_min_bin.alloc(bins.size() * 4) || !b->d_min_score.alloc(mins.size() * 4) ||
+      !rt::h2d(b->d_min_bin.p, bins.data(), bins.size() * 4, nullptr) ||
+      !rt::h2d(b->d_min_score.p, mins.data(), mins.size() * 4, nullptr) || !rt::sync(nullptr))
     return IRS_HIP_EHIP;
   b->has_min = true;
   return IRS_HIP_OK;
@@ -1938,7 +1947,8 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st) {
             rt::dmemset(b->d_hits.p, 0, b->d_hits.n, st) &&
             rt::dmemset(b->d_status.p, 0, 4, st) &&
             rt::dmemset(b->d_bstar.p, 0, b->d_bstar.n, st) &&
-            rt::dmemset(b->d_touched.p, 0, b->d_touched.n, st);
+            rt::dmemset(b->d_touched.p, 0, b->d_touched.n, st) &&
+            rt::dmemset(b->d_pruned.p, 0, b->d_pruned.n, st);
   // 1. plan (already queued by irs_hip_batch_plan: wait for it instead)
   const bool tiles = !b->phrase && !b->tile_units.empty();
   if (b->planned) {
@@ -1975,7 +1985,8 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st) {
                 b->d_cands.as<uint64_t>(), b->cand_cap, b->d_cand_count.as<uint32_t>(),
                 b->d_hits.as<unsigned long long>(), b->d_out.as<Hit>(), b->k_max,
                 b->d_out_count.as<uint32_t>(), b->d_status.as<uint32_t>(), stage_cap, sort_cap,
-                b->d_bstar.as<uint32_t>(), min_bins(b));
+                b->d_bstar.as<uint32_t>(), min_bins(b), b->d_pruned.as<uint32_t>(),
+                b->has_min ? b->d_min_score.as<float>() : static_cast<const float*>(nullptr));
       ok = rt::last_error_ok();
     }
   }

@@ -73,9 +73,41 @@ __host__ __device__ __forceinline__ uint32_t join_entry(uint32_t idx, uint32_t t
 
 // ------------------------------------------------------------------ join --
 
-// One workgroup = kJoinBlocks consecutive blocks of one stream, a wavefront per block: decode
-// (decode.h: bit-exact doc ids + frequencies), read the doc's norm byte, write the entries
-// (coalesced: posting i is entry i), and note where doc tiles begin.
+// One workgroup = kJoinBlocks consecutive blocks of one stream; a wavefront owns every 4th of
+// them and keeps all of its blocks IN FLIGHT TOGETHER: the directory records, then every
+// block's payload words, then every block's norm bytes — three memory round trips per
+// wavefront instead of three per block (the kernel is latency bound: a block is 100 VALU
+// instructions behind 3 dependent loads).  Decode as decode.h (bit-exact doc ids +
+// frequencies); entries are written coalesced (posting i is entry i).
+constexpr uint32_t kJoinPerWave = kJoinBlocks / kWaves;
+
+// entries + tile boundaries of the two postings a lane holds of one block
+__device__ __forceinline__ void join_emit(uint32_t* ent, uint32_t* bnd, uint32_t b, unsigned lane,
+                                          uint32_t d0, uint32_t d1, uint32_t f0, uint32_t f1,
+                                          uint32_t n0, uint32_t n1, bool v0, bool v1,
+                                          uint32_t prev /*0: the list's first posting*/) {
+  const uint32_t p0 = kBlock * b + 2u * lane;
+  const uint32_t t0 = v0 ? (d0 - kDocMin) / kJoinTile : 0u;
+  const uint32_t t1 = v1 ? (d1 - kDocMin) / kJoinTile : t0;
+  const uint32_t e0 = join_entry((d0 - kDocMin) - t0 * kJoinTile, f0, n0);
+  const uint32_t e1 = join_entry((d1 - kDocMin) - t1 * kJoinTile, f1, n1);
+  if (v1) {
+    uint64_t both = (uint64_t(e1) << 32) | e0;
+    __builtin_memcpy(ent + p0, &both, 8);
+  } else if (v0) {
+    ent[p0] = e0;
+  }
+  // tile boundaries: posting p opens every tile in (tile of posting p - 1, tile of p]
+  const uint32_t up = __shfl_up(t1, 1, 64);
+  const int32_t tp = lane ? int32_t(up) : (prev ? int32_t((prev - kDocMin) / kJoinTile) : -1);
+  if (v0) {
+    for (int32_t u = tp + 1; u <= int32_t(t0); ++u) bnd[u] = p0;
+  }
+  if (v1) {
+    for (uint32_t u = t0 + 1u; u <= t1; ++u) bnd[u] = p0 + 1u;
+  }
+}
+
 template<int LAYOUT>
 __global__ void __launch_bounds__(kThreads)
 k_join(const DevSegment* segs, const StreamRec* streams, const JoinWg* wgs) {
@@ -91,51 +123,82 @@ k_join(const DevSegment* segs, const StreamRec* streams, const JoinWg* wgs) {
   const uint32_t tail_n = t.docs_count == 1u ? 1u : t.tail_n;
   const uint32_t nb = t.nblk + (tail_n ? 1u : 0u);
   const bool tiny = seg.norms && seg.norm_width == 1u && !seg.norm_legacy;
+  const uint8_t* norms = seg.norms - seg.norm_min_doc;   // (indexed by doc id)
   uint32_t end = wg.first + kJoinBlocks;
   if (end > nb) end = nb;
-  for (uint32_t b = wg.first + wv; b < end; b += kWaves) {   // (b is wave-uniform)
-    uint32_t d0 = 0, d1 = 0, f0 = 0, f1 = 0, prev = 0;
-    bool v0 = true, v1 = true;
-    if (b < t.nblk) {
-      const BlkDir d = seg.blk_dir[t.dir_off + b];
-      decode_block<LAYOUT, true>(seg.doc + t.doc_start + d.off, d.bits & 0xFFu, d.bits >> 8,
-                                 d.prev_last, lane, d0, d1, f0, f1);
-      prev = b ? d.prev_last : 0u;   // (0: this is the list's first posting)
-    } else {
-      // the vint tail / single doc, decoded when the segment was opened
-      const uint32_t i0 = 2u * lane;
-      v0 = i0 < tail_n;
-      v1 = i0 + 1u < tail_n;
-      if (v0) { d0 = seg.tail_docs[t.tail_row + i0]; f0 = seg.tail_freqs[t.tail_row + i0]; }
-      if (v1) { d1 = seg.tail_docs[t.tail_row + i0 + 1u]; f1 = seg.tail_freqs[t.tail_row + i0 + 1u]; }
-      prev = t.nblk ? t.tail_base : 0u;
+  // this wavefront's blocks: b_i = first + wv + kWaves * i  (all wave-uniform)
+  BlkDir dir[kJoinPerWave];
+  RawPair rd[kJoinPerWave], rf[kJoinPerWave];
+  bool full[kJoinPerWave], plain[kJoinPerWave];
+#pragma unroll
+  for (uint32_t i = 0; i < kJoinPerWave; ++i) {
+    const uint32_t b = wg.first + wv + kWaves * i;
+    full[i] = b < end && b < t.nblk;
+    dir[i] = BlkDir{0u, 0u, 0u, 0u};
+    if (full[i]) dir[i] = seg.blk_dir[t.dir_off + b];
+  }
+#pragma unroll
+  for (uint32_t i = 0; i < kJoinPerWave; ++i) {
+    const uint32_t dbits = dir[i].bits & 0xFFu, fbits = dir[i].bits >> 8;
+    // (an all-equal doc part is a vint of unknown length: that block decodes by itself below)
+    plain[i] = full[i] && dbits != 0u;
+    if (plain[i]) {
+      const uint8_t* blk = seg.doc + t.doc_start + dir[i].off;
+      rd[i] = raw_load<LAYOUT>(blk + 1, dbits, lane);
+      rf[i] = raw_load<LAYOUT>(blk + 1u + 16u * dbits + 1u, fbits, lane);
     }
-    const uint32_t p0 = kBlock * b + 2u * lane;
-    const uint32_t t0 = v0 ? (d0 - kDocMin) / kJoinTile : 0u;
-    const uint32_t t1 = v1 ? (d1 - kDocMin) / kJoinTile : t0;
-    const uint32_t n0 = (v0 && tiny) ? seg.norms[d0 - seg.norm_min_doc] : 0u;
-    const uint32_t n1 = (v1 && tiny) ? seg.norms[d1 - seg.norm_min_doc] : 0u;
-    const uint32_t e0 = join_entry((d0 - kDocMin) - t0 * kJoinTile, f0, n0);
-    const uint32_t e1 = join_entry((d1 - kDocMin) - t1 * kJoinTile, f1, n1);
-    if (v1) {
-      uint64_t both = (uint64_t(e1) << 32) | e0;
-      __builtin_memcpy(ent + p0, &both, 8);
-    } else if (v0) {
-      ent[p0] = e0;
+  }
+  uint32_t d0[kJoinPerWave], d1[kJoinPerWave], f0[kJoinPerWave], f1[kJoinPerWave];
+#pragma unroll
+  for (uint32_t i = 0; i < kJoinPerWave; ++i) {
+    d0[i] = d1[i] = kDocMin;
+    f0[i] = f1[i] = 0;
+    if (plain[i]) {
+      const uint32_t dbits = dir[i].bits & 0xFFu, fbits = dir[i].bits >> 8;
+      uint32_t x0, x1;
+      raw_extract<LAYOUT>(rd[i], dbits, lane, x0, x1);
+      d1[i] = dir[i].prev_last + wave::inclusive_scan(x0 + x1);
+      d0[i] = d1[i] - x1;
+      if (fbits == 0u) {   // all-equal frequencies: the vint behind the header byte
+        uint32_t len;
+        f0[i] = f1[i] = vint_from(rf[i].a, &len);
+      } else {
+        raw_extract<LAYOUT>(rf[i], fbits, lane, f0[i], f1[i]);
+      }
+    } else if (full[i]) {
+      decode_block<LAYOUT, true>(seg.doc + t.doc_start + dir[i].off, 0u, dir[i].bits >> 8,
+                                 dir[i].prev_last, lane, d0[i], d1[i], f0[i], f1[i]);
     }
-    // tile boundaries: posting p opens every tile in (tile of posting p - 1, tile of p]
-    const uint32_t up = __shfl_up(t1, 1, 64);
-    int32_t tp = lane ? int32_t(up) : (prev ? int32_t((prev - kDocMin) / kJoinTile) : -1);
-    if (v0) {
-      for (int32_t u = tp + 1; u <= int32_t(t0); ++u) bnd[u] = p0;
-    }
-    if (v1) {
-      for (uint32_t u = t0 + 1u; u <= t1; ++u) bnd[u] = p0 + 1u;
-    }
-    if (b + 1u == nb) {   // behind the list's last posting: every remaining tile is empty
-      const uint32_t last_tile = (t.last_doc - kDocMin) / kJoinTile;
-      for (uint32_t u = last_tile + 1u + lane; u <= n_tiles; u += 64u) bnd[u] = S.n;
-    }
+  }
+  uint32_t n0[kJoinPerWave], n1[kJoinPerWave];
+#pragma unroll
+  for (uint32_t i = 0; i < kJoinPerWave; ++i) {
+    n0[i] = (full[i] && tiny) ? norms[d0[i]] : 0u;
+    n1[i] = (full[i] && tiny) ? norms[d1[i]] : 0u;
+  }
+#pragma unroll
+  for (uint32_t i = 0; i < kJoinPerWave; ++i) {
+    const uint32_t b = wg.first + wv + kWaves * i;
+    if (full[i])
+      join_emit(ent, bnd, b, lane, d0[i], d1[i], f0[i], f1[i], n0[i], n1[i], true, true,
+                b ? dir[i].prev_last : 0u);
+  }
+  // the vint tail / single doc, decoded when the segment was opened: the list's last "block"
+  const uint32_t bt = t.nblk;
+  if (tail_n && bt >= wg.first && bt < end && ((bt - wg.first) % kWaves) == wv) {
+    const uint32_t i0 = 2u * lane;
+    const bool v0 = i0 < tail_n, v1 = i0 + 1u < tail_n;
+    uint32_t td0 = kDocMin, td1 = kDocMin, tf0 = 0, tf1 = 0;
+    if (v0) { td0 = seg.tail_docs[t.tail_row + i0]; tf0 = seg.tail_freqs[t.tail_row + i0]; }
+    if (v1) { td1 = seg.tail_docs[t.tail_row + i0 + 1u]; tf1 = seg.tail_freqs[t.tail_row + i0 + 1u]; }
+    const uint32_t tn0 = (v0 && tiny) ? norms[td0] : 0u;
+    const uint32_t tn1 = (v1 && tiny) ? norms[td1] : 0u;
+    join_emit(ent, bnd, bt, lane, td0, td1, tf0, tf1, tn0, tn1, v0, v1, t.nblk ? t.tail_base : 0u);
+  }
+  // behind the list's last posting every remaining tile is empty: whoever holds the last block
+  if (nb && nb - 1u >= wg.first && nb - 1u < end && ((nb - 1u - wg.first) % kWaves) == wv) {
+    const uint32_t last_tile = (t.last_doc - kDocMin) / kJoinTile;
+    for (uint32_t u = last_tile + 1u + lane; u <= n_tiles; u += 64u) bnd[u] = S.n;
   }
 }
 

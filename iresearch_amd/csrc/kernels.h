@@ -559,7 +559,9 @@ __global__ void __launch_bounds__(kThreads)
 k_select(const DevQuery* queries, const uint64_t* cands, uint32_t cand_cap,
          const uint32_t* cand_count, const unsigned long long* hits, Hit* out, uint32_t k_max,
          uint32_t* out_count, uint32_t* status, uint32_t stage_cap, uint32_t sort_cap,
-         const uint32_t* bstar, const uint32_t* min_bin /*null: no caller thresholds*/) {
+         const uint32_t* bstar, const uint32_t* min_bin /*null: no caller thresholds*/,
+         const uint32_t* pruned /*[unit] != 0: block-max pruning skipped blocks or tiles*/,
+         const float* min_score /*[unit] the caller's irs::score::Min, null: none*/) {
   RT_DYN_SMEM(smem);
   uint64_t* keys = reinterpret_cast<uint64_t*>(smem);         // [sort_cap]
   uint64_t* stage = keys + sort_cap;                          // [stage_cap]
@@ -579,7 +581,10 @@ k_select(const DevQuery* queries, const uint64_t* cands, uint32_t cand_cap,
   // an estimated threshold (k_pilot) cut off docs that belong to the top k — unless the
   // threshold in force is the caller's own (irs::score::Min): fewer than k docs reach it
   const bool callers = min_bin && min_bin[q] != 0u && bstar[q] == min_bin[q];
-  if (n < qd.k && hits[q] > n && !callers && tid == 0) atomicOr(status, kStatusUnderflow);
+  // (hits only counts evaluated docs: where pruning skipped some, "fewer than k" alone says
+  // the threshold was too high — unless nothing more exists, which a sound re-run then shows)
+  if (n < qd.k && (hits[q] > n || pruned[q]) && !callers && tid == 0)
+    atomicOr(status, kStatusUnderflow);
   const uint64_t* src = cands + uint64_t(q) * cand_cap;
   const uint32_t kk = qd.k < n ? qd.k : n;
   const bool staged = n <= stage_cap;
@@ -640,9 +645,22 @@ k_select(const DevQuery* queries, const uint64_t* cands, uint32_t cand_cap,
   __syncthreads();
   for (uint32_t i = m + tid; i < p2; i += blockDim.x) keys[i] = 0;
   bitonic_desc(keys, p2);
-  for (uint32_t i = tid; i < kk; i += blockDim.x)
+  // the caller's own threshold is exact: the kernels filtered by score BIN, the few docs that
+  // share the threshold's bin but score below it go here (sorted: they are a suffix)
+  uint32_t keep = kk;
+  if (min_score && min_score[q] > 0.f) {
+    if (tid == 0) sh_n = 0;
+    __syncthreads();
+    const float m = min_score[q];
+    uint32_t mine = 0;
+    for (uint32_t i = tid; i < kk; i += blockDim.x) mine += key_hit(keys[i]).score >= m ? 1u : 0u;
+    if (mine) atomicAdd(&sh_n, mine);
+    __syncthreads();
+    keep = sh_n;
+  }
+  for (uint32_t i = tid; i < keep; i += blockDim.x)
     out[uint64_t(q) * k_max + i] = key_hit(keys[i]);
-  if (tid == 0) out_count[q] = kk;
+  if (tid == 0) out_count[q] = keep;
 }
 
 // ----------------------------------------------------------------- merge --

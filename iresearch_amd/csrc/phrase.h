@@ -419,6 +419,7 @@ struct ConjArgs {
   uint32_t cand_cap;
   uint32_t pilot_stride;        // pilot pass: lead items {phase, phase + P, ...}
   uint32_t wand;                // prune lead blocks by block-max bounds
+  uint32_t* pruned;             // [unit] set when a lead block was skipped (k_select's underflow check)
 };
 
 

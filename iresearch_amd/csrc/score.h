@@ -1168,6 +1168,7 @@ struct ScoreArgs {
   unsigned long long* hits;
   uint32_t* work_counter;
   const float* tile_ub;         // WAND: per-tile score bounds (k_items_fill), else null
+  uint32_t* pruned;             // [unit] set when a tile was skipped (k_select's underflow check)
   uint32_t cpq;                 // chunk ids per unit
   uint32_t n_units;
   uint32_t nw_log2;
@@ -1240,7 +1241,9 @@ k_score(uint64_t args /*address of a ScoreArgs*/) {
       // WAND: no doc of the tile can reach the threshold bin -> the tile is skipped (its work
       // items are not even read)
       const float* ub = IRS_ARG(tile_ub);
-      tdead[tid] = (ub && bs && score_bin(ub[qd.tile_base + tile0 + tid], qd.bin_scale) < bs) ? 1u : 0u;
+      const bool dead = ub && bs && score_bin(ub[qd.tile_base + tile0 + tid], qd.bin_scale) < bs;
+      tdead[tid] = dead ? 1u : 0u;
+      if (dead) IRS_ARG(pruned)[q] = 1u;
     }
     if (tid == 0) {
       sm.slow[0] = __float_as_uint(qd.fx_mul);

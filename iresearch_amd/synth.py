@@ -280,15 +280,18 @@ def segment_from_lists(lists, num_docs: int, layout: int = LAYOUT_SIMD4, norms=N
     if n < 0:
         raise ValueError("irs_synth_wrap_doc_file failed")
     metas["doc_start"] += hdr.value
+    # Scorer::WandType (scorer.hpp:196-201) of the scorer that wrote slot 0 of the wand data
+    wand_type = {WAND_MAX_FREQ: 2, WAND_MIN_NORM: 3, WAND_DIV_NORM: 1}[wand_kinds[0]] \
+        if len(wand_kinds) else 0
     if norms is False:  # no Norm2 column at all
         return SynthSegment(out[:n].copy(), None, metas, num_docs, num_docs, layout, num_docs,
-                            None, len(wand_kinds), pos_file, None, bool(one_based))
+                            None, len(wand_kinds), pos_file, None, bool(one_based), wand_type)
     if norms is None:
         norms = np.ones(num_docs, np.uint8)
     ttf = int(np.asarray(norms, dtype=np.uint64).sum())
     return SynthSegment(out[:n].copy(), np.ascontiguousarray(norms, np.uint8), metas,
                         num_docs, ttf, layout, num_docs, None, len(wand_kinds), pos_file, None,
-                        bool(one_based))
+                        bool(one_based), wand_type)
 
 
 def make_queries(n_queries: int, n_terms: int, lo_rank: int = 16, hi_rank: int = 4096,

@@ -146,6 +146,49 @@ def case_decode_edge_blocks(L, layout):
     sr.close()
 
 
+def case_join_edge_blocks(L, layout):
+    """The joined-stream path (k_join: every list decoded once per batch) over awkward lists:
+    all-equal doc and freq blocks, every doc bit width a 200 k-doc segment allows, exactly 128 /
+    129 / 256 postings, tail-only and single-doc lists, lists that start late, end early or
+    jump over several 12288-doc tiles, the largest frequency an entry holds (63: no table row)
+    — each list alone and all of them in one Or, against the oracle and bit for bit against the
+    work-item path."""
+    n_docs = 200_000
+    rng = np.random.default_rng(77)
+    lists = []
+    lists.append((np.arange(2, 2 + 300, dtype=np.uint32), np.full(300, 3, np.uint32)))   # all-equal
+    lists.append((np.arange(1, 1 + 256, dtype=np.uint32), np.ones(256, np.uint32)))
+    for bits in (1, 2, 3, 5, 8, 10):
+        n = 128 * 3 + bits
+        gaps = rng.integers(1, 1 << bits, n, dtype=np.int64)
+        gaps[7] = (1 << bits) - 1 if bits > 1 else 1
+        d = (50 + np.cumsum(gaps)).astype(np.uint32)
+        lists.append((d, rng.integers(1, 1 << min(bits, 6), n).astype(np.uint32)))
+    for n in (1, 5, 127, 128, 129, 256, 257):
+        d = np.sort(rng.choice(np.arange(1, n_docs + 1), n, replace=False)).astype(np.uint32)
+        lists.append((d, rng.integers(1, 64, n).astype(np.uint32)))      # up to 63: general form
+    late = np.sort(rng.choice(np.arange(5 * 12288 + 100, 7 * 12288), 300, replace=False))
+    lists.append((late.astype(np.uint32), rng.integers(1, 4, 300).astype(np.uint32)))   # starts late, ends early
+    jump = np.concatenate([np.arange(10, 138), [3 * 12288 + 5], 9 * 12288 + np.arange(1, 200), [n_docs]])
+    lists.append((jump.astype(np.uint32), np.ones(jump.size, np.uint32)))               # jumps over tiles
+    lists.append((np.array([n_docs], np.uint32), np.array([63], np.uint32)))            # last doc only
+    lists.append((np.array([12288], np.uint32), np.array([2], np.uint32)))              # a tile's last doc
+    lists.append((np.array([12289], np.uint32), np.array([2], np.uint32)))              # a tile's first doc
+    norms = rng.integers(1, 256, n_docs).astype(np.uint8)
+    seg, sr = open_lists(L, lists, n_docs, layout, norms)
+    nt = len(lists)
+    filters = [by_term(t) for t in range(nt)]
+    filters += [Or([by_term(t) for t in range(0, nt, 2)][:16]), Or([by_term(t) for t in range(1, nt, 2)][:16]),
+                Or([by_term(8), by_term(nt + 3), by_term(12)])]
+    for scorer in (BM25(), TFIDF(True), BM25(1.2, 0.0)):
+        for k in (3, 500):
+            hj = run_and_check(L, seg, filters, scorer, k, sr=sr, path=_lib.PATH_JOINED)
+            hi = run_and_check(L, seg, filters, scorer, k, sr=sr, path=_lib.PATH_ITEMS)
+            for x, y in zip(hj, hi):
+                assert np.array_equal(x, y)
+    sr.close()
+
+
 def _doc_file(version, body: bytes) -> np.ndarray:
     """Header + postings + footer of a `.doc` file (format_utils.cpp:57-67; big-endian ints)."""
     name = b"iresearch_10_postings_documents"
@@ -702,7 +745,7 @@ def case_min_score_pushdown(L):
     """irs::score::Min (score_function.hpp:42-142; the harness pushes its heap's k-th score,
     index-search.cpp:737-777): with the k-th score of a first run as threshold the same top-k
     comes back; with the score of rank 10 at least those 10, all of them a prefix of the first
-    list, and never a doc below the threshold's bin; hit counts are unchanged.  Or, And, phrase."""
+    list, and never a doc below the threshold; hit counts are unchanged.  Or, And, phrase."""
     seg = synth.build_segment(50_000, 256, with_positions=True)
     sr = search.SegmentReader.from_synth(seg, L=L)
     st = [parity.segment_stats(seg)]
@@ -724,13 +767,12 @@ def case_min_score_pushdown(L):
         assert np.array_equal(t0, t2) and b.reruns() == 0
         for q in range(len(filters)):
             n = int(c2[q])
-            assert 10 <= n <= c0[q]
+            # exactly the docs at or above the threshold (ties with the 10th included)
+            assert n == int((h0[q, :int(c0[q])]["score"] >= tenth[q]).sum()) >= 10
             assert np.array_equal(h2[q, :n], h0[q, :n])
         # a threshold nothing reaches: no hits returned, the matches still counted
         h3, c3, t3 = b.set_min_scores(np.full(len(filters), 1e30, np.float32)).run().results()
-        assert np.array_equal(t0, t3)
-        top_bin_docs = c3   # (only docs in the highest score bin may remain)
-        assert (top_bin_docs <= c0).all()
+        assert np.array_equal(t0, t3) and (c3 == 0).all()
         h4, c4, t4 = b.set_min_scores(None).run().results()
         assert np.array_equal(h0, h4) and np.array_equal(c0, c4)
         b.close()
@@ -819,6 +861,33 @@ def case_wand_data(L, layout):
     # an index written without scorers has no pairs of its own: all derived
     sr = search.SegmentReader.from_synth(plain, L=L)
     assert sr.wand_source()[0] == 0
+    sr.close()
+    # scorer 0 was a DivNorm producer (TFIDF with norms, BM11): its pair is the (freq, norm) of
+    # the doc with the largest freq / norm — no bound for BM25 or a MaxFreq scorer (the
+    # reference refuses the combination, Scorer::compatible scorer.cpp:46-49).  The index's
+    # pairs must NOT be taken; pruning with the derived ones returns the exhaustive top k.
+    seg = synth.segment_from_lists(lists, n_docs, layout, norms,
+                                   wand_kinds=[synth.WAND_DIV_NORM, synth.WAND_MIN_NORM])
+    assert seg.wand_type == _lib.WAND_DIV_NORM
+    sr = search.SegmentReader.from_synth(seg, L=L)
+    assert sr.wand_source()[0] == 0
+    for t, (d, f) in enumerate(lists):
+        gmf, gmn = sr.term_blockmax(t)
+        for b in range(len(gmf)):
+            blk = slice(128 * b, 128 * b + 128)
+            assert gmf[b] == f[blk].max() and gmn[b] == norms[d[blk] - 1].min(), (t, b)
+    filters = [by_term(9), Or([by_term(8), by_term(9)]), And([by_term(8), by_term(9)]),
+               And([by_term(7), by_term(9), by_term(8)])]
+    for scorer in (BM25(), TFIDF(False), BM25(1.2, 0.0)):
+        prep = search.prepare(filters, scorer, [parity.segment_stats(seg)])
+        ex = sr.batch(prep, 10).set_path(_lib.PATH_ITEMS)
+        h0, c0, t0 = ex.run().results()
+        ex.close()
+        wb = sr.batch(prep, 10).set_wand(True)
+        h1, c1, t1 = wb.run().results()
+        wb.close()
+        assert np.array_equal(c0, c1) and np.array_equal(h0, h1)
+        parity.check_single_segment(seg, filters, scorer, 10, h0, c0, t0)
     sr.close()
     # the whole-corpus builder writes the same framing
     a = synth.build_segment(6_000, 64, layout=layout, keep_postings=True, wand_count=2)

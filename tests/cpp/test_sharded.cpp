@@ -139,6 +139,20 @@ int main(int argc, char** argv) {
               sharded_wand[q][i].segment == want[q][i].segment);
     }
   }
+  // a rank WITHOUT segments (3 per rank: rank 0 holds all three, rank 1 none) builds no batch and
+  // still takes part in the exchange
+  {
+    std::vector<const SegmentReader*> lot;
+    if (rank == 0) lot = all;
+    const auto lopsided = search_sharded(comm, lot, kSegs, kSegs, index, filters, scorer, kTop);
+    REQUIRE(lopsided.size() == want.size());
+    for (size_t q = 0; q < want.size(); ++q) {
+      REQUIRE(lopsided[q].size() == want[q].size());
+      for (size_t i = 0; i < want[q].size(); ++i)
+        REQUIRE(lopsided[q][i].score == want[q][i].score && lopsided[q][i].doc == want[q][i].doc &&
+                lopsided[q][i].segment == want[q][i].segment);
+    }
+  }
   std::printf("test_sharded OK: rank %d of %d, %zu queries over %u segments\n", rank, n_ranks,
               filters.size(), kSegs);
   return 0;

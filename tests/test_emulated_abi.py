@@ -99,6 +99,11 @@ def test_pilot_misled(simlib, joined):
 
 
 @pytest.mark.parametrize("layout", [0, 1])
+def test_join_edge_blocks(simlib, layout):
+    cases.case_join_edge_blocks(simlib, layout)
+
+
+@pytest.mark.parametrize("layout", [0, 1])
 def test_paths_agree(simlib, layout):
     cases.case_paths_agree(simlib, layout=layout)
 

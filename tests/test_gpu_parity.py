@@ -172,6 +172,11 @@ def test_pilot_misled(gpulib, joined):
 
 
 @pytest.mark.parametrize("layout", [0, 1])
+def test_join_edge_blocks(gpulib, layout):
+    cases.case_join_edge_blocks(gpulib, layout)
+
+
+@pytest.mark.parametrize("layout", [0, 1])
 def test_paths_agree(gpulib, layout):
     cases.case_paths_agree(gpulib, layout=layout)
 

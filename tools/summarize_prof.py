@@ -28,7 +28,7 @@ def main():
             agg = collections.defaultdict(lambda: collections.defaultdict(float))
             launches = collections.defaultdict(set)
             for r in csv.DictReader(open(f)):
-                k = r["Kernel_Name"].split("(")[0].replace("void irs_hip::", "")
+                k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("irs_hip::", "")
                 agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
                 launches[k].add(r["Dispatch_Id"])
             for k, v in agg.items():
@@ -37,10 +37,16 @@ def main():
                 for c, x in v.items():
                     summary[k][c + "_per_launch"] = x / n
     json.dump(summary, open(os.path.join(out, "%s_pmc.json" % tag), "w"), indent=1, sort_keys=True)
-    for k, v in summary.items():
-        if k.startswith("k_score") and "FETCH_SIZE_per_launch" in v:
-            fetch_kb = v["FETCH_SIZE_per_launch"]
-            write_kb = v.get("WRITE_SIZE_per_launch", 0.0)
+    # the kernels the roofline prices (bench.py): the work-item path's k_score, or the joined
+    # path's two stages k_join + k_join_score (the pilot kernels are apart)
+    staged = [k for k in summary if (k.startswith("k_join<") or k == "k_join_score")
+              and "FETCH_SIZE_per_launch" in summary[k]]
+    scored = [k for k in summary if k.startswith("k_score") and "FETCH_SIZE_per_launch" in summary[k]]
+    for group in ([staged] if len(staged) == 2 else [[k] for k in scored]):
+        if group:
+            k = " + ".join(sorted(group))
+            fetch_kb = sum(summary[g]["FETCH_SIZE_per_launch"] for g in group)
+            write_kb = sum(summary[g].get("WRITE_SIZE_per_launch", 0.0) for g in group)
             t = {
                 "kernel": k, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), %s" % tag,
                 "fetch_bytes_raw": fetch_kb * 1024, "write_bytes": write_kb * 1024,
