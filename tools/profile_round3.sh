@@ -1,0 +1,30 @@
+#!/bin/bash
+# Run on the GPU box (gpurun -- 'bash tools/profile_round3.sh r03a'): the evidence behind the
+# round-3 numbers.  Kernel statistics and counters are separate rocprofv3 runs (PMC passes are
+# never combined with tracing).  Outputs land in gpurun_out/<tag>_*; `tools/collect_round3.sh
+# <tag>` turns them into the committed files under profiles/.
+TAG=${1:-r03a}
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out
+mkdir -p $O
+# headline bench (with the cpu baseline) without a profiler, then under --kernel-trace --stats
+python $R/bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_plain.json 2> $O/${TAG}_bench_plain.err
+rocprofv3 --kernel-trace --stats -d $O/${TAG}_stats -o $TAG --output-format csv -- \
+  python $R/bench.py --steps 5 --warmup 1 --no-cpu > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
+i=0
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
+           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM" \
+           "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+           "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
+  i=$((i+1))
+  rocprofv3 --pmc $grp -d $O/${TAG}_pmc_$i -o p --output-format csv -- \
+    python $R/bench.py --steps 2 --warmup 1 --no-cpu > $O/${TAG}_pmc_$i.log 2>&1
+done
+if [ "$2" = "full" ]; then
+  rocprofv3 --kernel-trace --stats -d $O/${TAG}_stats_seg -o ${TAG}seg --output-format csv -- \
+    python $R/bench.py --steps 3 --warmup 1 --force-segments --no-cpu > $O/${TAG}_bench_seg.json 2> $O/${TAG}_bench_seg.err
+  rocprofv3 --kernel-trace --stats -d $O/${TAG}_stats_c5 -o ${TAG}c5 --output-format csv -- \
+    python $R/bench.py --config 5 --steps 3 --warmup 1 > $O/${TAG}_bench_c5.json 2> $O/${TAG}_bench_c5.err
+fi
+cat $O/${TAG}_bench_plain.json
