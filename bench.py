@@ -465,7 +465,9 @@ def main():
                                else "1 segment on 1 GPU",
                 "collective": None if world == 1 else
                               ("irs_hip_topk_allgather (RCCL behind the C ABI)" if comm is not None
-                               else "torch.distributed all_gather_into_tensor")},
+                               else "torch.distributed all_gather_into_tensor"),
+                "rccl_library": None if comm is None else comm.library(),
+                "ranks_seen": None if comm is None else comm.ranks_seen},
             "roofline": roof,
         }
     if rank == 0 and not multi and not args.no_cpu:
@@ -557,7 +559,13 @@ def main_config5(args):
         b.profile(True)
         bat[name] = b
     sptr = None if sim else C_void(torch.cuda.current_stream(dev).cuda_stream)
-    ex = {name: distributed.PipelinedExchange(L, local_rank, n_segments, rank, world, nq, k, dev)
+    # the collective goes through the library's own RCCL communicator (irs_hip_comm_*), as in
+    # the headline config; one communicator serves both exchanges
+    comm = None
+    if world > 1:
+        comm = distributed.agreed_communicator(L, local_rank, rank, world, dev, log)
+    ex = {name: distributed.PipelinedExchange(L, local_rank, n_segments, rank, world, nq, k, dev,
+                                              comm=comm)
           for name in bat}
     it = {"n": 0}
 
@@ -630,7 +638,12 @@ def main_config5(args):
                                            "phrase_doc": int(vals[3]),
                                            "phrase_positions_read": int(vals[4])},
                 "parallelism": "%d segments over %d GPU(s), all-gather of per-segment top-k + GPU merge"
-                               % (n_segments, world)},
+                               % (n_segments, world),
+                "collective": None if world == 1 else
+                              ("irs_hip_topk_allgather (RCCL behind the C ABI)" if comm is not None
+                               else "torch.distributed all_gather_into_tensor"),
+                "rccl_library": None if comm is None else comm.library(),
+                "ranks_seen": None if comm is None else comm.ranks_seen},
             "roofline": {"bound": "hbm", "kernel": "k_conj + k_phrase (rank 0)",
                          "achieved": round(rank0_touched / ((ms["and"] + ms["phrase"]) * 1e-3) / 1e9, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",

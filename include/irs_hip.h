@@ -422,6 +422,11 @@ int irs_hip_comm_unique_id(uint8_t id[IRS_HIP_COMM_ID_BYTES]);
 int irs_hip_comm_init_rank(int32_t device, const uint8_t id[IRS_HIP_COMM_ID_BYTES], int32_t n_ranks,
                            int32_t rank, irs_hip_comm** out);
 void irs_hip_comm_destroy(irs_hip_comm* comm);
+/* Which RCCL the collective runs on (diagnostics): the library's path, prefixed "mapped:" when
+ * the process had it loaded already — a host that also uses torch.distributed has torch's
+ * bundled librccl.so mapped, and the communicator then binds THAT copy instead of loading a
+ * second RCCL next to it.  EHIP when no RCCL could be bound. */
+int irs_hip_comm_library(char* buf, size_t cap);
 /* d_send: bytes_per_rank bytes on the device; d_recv: n_ranks * bytes_per_rank, rank r's block
  * at r * bytes_per_rank.  Asynchronous on `stream` (a hipStream_t). */
 int irs_hip_topk_allgather(irs_hip_comm* comm, const void* d_send, void* d_recv,

@@ -72,6 +72,7 @@ SYMBOLS = (
     "irs_hip_segment_wand_source",
     "irs_hip_batch_touched",
     "irs_hip_comm_unique_id", "irs_hip_comm_init_rank", "irs_hip_comm_destroy",
+    "irs_hip_comm_library",
     "irs_hip_topk_allgather", "irs_hip_device_alloc", "irs_hip_device_free",
     "irs_hip_device_upload", "irs_hip_device_download", "irs_hip_device_sync",
 )
@@ -135,6 +136,7 @@ def bind(L: C.CDLL) -> C.CDLL:
     L.irs_hip_comm_init_rank.argtypes = [i32, vp, i32, i32, P(vp)]
     L.irs_hip_comm_init_rank.restype = C.c_int
     L.irs_hip_comm_destroy.argtypes, L.irs_hip_comm_destroy.restype = [vp], None
+    L.irs_hip_comm_library.argtypes, L.irs_hip_comm_library.restype = [C.c_char_p, C.c_size_t], C.c_int
     L.irs_hip_topk_allgather.argtypes = [vp, vp, vp, u64, vp]
     L.irs_hip_topk_allgather.restype = C.c_int
     return L

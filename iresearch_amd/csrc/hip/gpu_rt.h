@@ -4,6 +4,8 @@
 // only ever built against THIS file.)
 #pragma once
 #include <dlfcn.h>
+#include <link.h>
+#include <cstdio>
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
@@ -91,17 +93,42 @@ struct UniqueId {
 using handle_t = void*;            // ncclComm_t
 
 struct Api {
+  char path[512] = {0};   // the library the entry points were bound from ("" = none)
+  bool preloaded = false; // ... which the process had mapped already (e.g. torch's bundled one)
   int (*get_unique_id)(UniqueId*) = nullptr;
   int (*init_rank)(handle_t*, int, UniqueId, int) = nullptr;
   int (*all_gather)(const void*, void*, size_t, int /*ncclDataType_t*/, handle_t, hipStream_t) = nullptr;
   int (*destroy)(handle_t) = nullptr;
   bool ok = false;
 };
-inline const Api& api() {   // one dlopen per process, at first use
+// An RCCL this process has mapped already — a host that also runs torch.distributed has torch's
+// bundled torch/lib/librccl.so in its address space; a second copy next to it would mean two
+// sets of RCCL globals (bootstrap threads, topology caches, IPC handle tables) in one process.
+inline int find_mapped_rccl(struct dl_phdr_info* info, size_t, void* out) {
+  const char* name = info->dlpi_name;
+  if (name && std::strstr(name, "librccl.so")) {
+    std::snprintf(static_cast<char*>(out), 512, "%s", name);
+    return 1;
+  }
+  return 0;
+}
+inline const Api& api() {   // bound once per process, at first use
   static const Api a = [] {
     Api x;
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    void* h = nullptr;
+    char mapped[512] = {0};
+    if (dl_iterate_phdr(find_mapped_rccl, mapped) && mapped[0]) {
+      h = dlopen(mapped, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);   // (only takes a reference)
+      if (h) {
+        x.preloaded = true;
+        std::snprintf(x.path, sizeof x.path, "%s", mapped);
+      }
+    }
+    for (const char* name : {"librccl.so.1", "librccl.so"}) {
+      if (h) break;
+      h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (h) std::snprintf(x.path, sizeof x.path, "%s", name);
+    }
     if (!h) return x;
     x.get_unique_id = reinterpret_cast<decltype(x.get_unique_id)>(dlsym(h, "ncclGetUniqueId"));
     x.init_rank = reinterpret_cast<decltype(x.init_rank)>(dlsym(h, "ncclCommInitRank"));
@@ -131,6 +158,14 @@ inline bool all_gather(handle_t c, const void* send, void* recv, size_t bytes, s
 inline void destroy(handle_t c) {
   const Api& a = api();
   if (a.ok && c) (void)a.destroy(c);
+}
+// which library the collective runs on: its path, prefixed "mapped:" when the process had it
+// loaded before this library asked (diagnostics: bench.py prints it)
+inline bool library(char* buf, size_t cap) {
+  const Api& a = api();
+  if (!a.ok) return false;
+  std::snprintf(buf, cap, "%s%s", a.preloaded ? "mapped:" : "", a.path);
+  return true;
 }
 
 }  // namespace comm

@@ -2310,6 +2310,12 @@ int irs_hip_comm_init_rank(int32_t device, const uint8_t id[IRS_HIP_COMM_ID_BYTE
                            int32_t rank, irs_hip_comm** out) {
   return guarded([&] { return comm_init_rank_impl(device, id, n_ranks, rank, out); });
 }
+int irs_hip_comm_library(char* buf, size_t cap) {
+  return guarded([&] {
+    if (!buf || !cap) return int(IRS_HIP_EINVAL);
+    return rt::comm::library(buf, cap) ? int(IRS_HIP_OK) : int(IRS_HIP_EHIP);
+  });
+}
 void irs_hip_comm_destroy(irs_hip_comm* c) {
   if (!c) return;
   rt::set_device(c->device);

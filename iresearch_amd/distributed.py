@@ -57,6 +57,14 @@ class Communicator:
         _lib.check(L, L.irs_hip_comm_init_rank(device_index, ident, world, rank, C.byref(h)),
                    "irs_hip_comm_init_rank")
         self.handle = h
+        self.ranks_seen = None   # set by agreed_communicator's self-test all-gather
+
+    def library(self) -> str:
+        """Which RCCL the communicator runs on ("mapped:<path>": the copy the process — torch —
+        had loaded already)."""
+        buf = C.create_string_buffer(600)
+        _lib.check(self.L, self.L.irs_hip_comm_library(buf, len(buf)), "irs_hip_comm_library")
+        return buf.value.decode()
 
     def all_gather(self, d_send: int, d_recv: int, bytes_per_rank: int, stream=None):
         _lib.check(self.L, self.L.irs_hip_topk_allgather(self.handle, d_send, d_recv,
@@ -119,6 +127,8 @@ def agreed_communicator(L, device_index: int, rank: int, world: int, device, log
         want = torch.arange(1, world + 1, dtype=torch.int32, device=device).repeat_interleave(n)
         ok = bool(torch.equal(recv, want))
         why = "self-test all-gather returned wrong data"
+        # what the self-test saw: how many distinct ranks' blocks arrived (bench.py reports it)
+        comm.ranks_seen = int(torch.unique(recv).numel())
     except Exception as e:  # noqa: BLE001
         ok, why = False, e
     if not all_ok(ok):

@@ -172,6 +172,10 @@ inline bool all_gather(handle_t h, const void* send, void* recv, size_t bytes, s
   barrier(c);
   return true;
 }
+inline bool library(char* buf, size_t cap) {
+  std::snprintf(buf, cap, "shared-memory stand-in (tests/sim)");
+  return true;
+}
 inline void destroy(handle_t h) {
   Comm* c = static_cast<Comm*>(h);
   if (!c) return;

@@ -198,6 +198,9 @@ def test_bench_is_launchable_on_two_ranks(simlib):
     assert d["config"]["segments"] == 4 and d["config"]["reruns_rank0"] == 0
     assert d["roofline"]["launches_per_step"] == 1       # ONE batch over rank 0's 2 segments
     assert d["cpu_baseline"] is None
+    # the exchange went through the C ABI's communicator and its self-test saw both ranks
+    assert d["config"]["collective"].startswith("irs_hip_topk_allgather")
+    assert d["config"]["ranks_seen"] == 2 and d["config"]["rccl_library"]
 
 
 def test_bench_config5_is_launchable_on_two_ranks(simlib):
@@ -224,3 +227,5 @@ def test_bench_config5_is_launchable_on_two_ranks(simlib):
     t = d["config"]["bytes_touched_per_step"]
     a = d["config"]["algorithmic_bytes_per_step"]
     assert 0 < t["and_doc_and_norm"] <= a["and"] and t["phrase_doc"] > 0
+    assert d["config"]["collective"].startswith("irs_hip_topk_allgather")
+    assert d["config"]["ranks_seen"] == 2 and d["config"]["rccl_library"]
