@@ -14,7 +14,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 REPO = ROOT.parent
 
-SYNTH_SRC = [ROOT / "index" / "synth_index.cpp"]
+SYNTH_SRC = [ROOT / "index" / "synth_index.cpp", ROOT / "index" / "synth_dict.cpp"]
 SYNTH_HDR = [ROOT / "index" / "synth_index.h"]
 SYNTH_LIB = ROOT / "index" / "libirs_synth.so"
 

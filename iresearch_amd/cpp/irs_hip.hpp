@@ -571,6 +571,341 @@ inline bool read_norm2_header(const uint8_t* payload, size_t size, Norm2Header& 
   return true;
 }
 
+
+// ---- the term dictionary (`.tm`), walked WITHOUT the term index ------------------------------
+// What the reference's term iterator yields — (term bytes, term_meta) for every term of a
+// field (term_reader::iterator + next(), formats_burst_trie.cpp:3196-3297; the cookie holds the
+// version10::term_meta, :802-826) — recovered from the blocks of `.tm` alone.  The term index
+// (`.ti`, an FST) only exists to seek; the blocks link to each other:
+//   block  = vint (entries << 1 | last block of its group)
+//            vlong (suffix bytes << 1 | leaf), the suffixes, vlong stats bytes, the stats
+//            (block_iterator::load :1765-1825, written by field_writer::WriteBlock :1023-1112)
+//   suffix = vint length (leaf) or (length << 1 | is-block), the bytes and, for a block entry,
+//            vlong (this block's start - the sub-block's start)   (read_entry_nonleaf :1827-1848)
+//   stats  = one postings_writer::encode record per TERM entry, delta-coded from zeros at the
+//            block's first (decode_term_meta above)
+// A term = the prefix its block's group stands for + the suffix.  Blocks are written children
+// first, so every sub-block reference points backwards; the blocks of one prefix that was too
+// large for one block ("floor" blocks) follow each other and only the first is referenced —
+// the "last of its group" bit says where a group ends.  Hence: parse all blocks front to back,
+// form the groups, and hand prefixes down from the unreferenced (root) group of each field.
+struct DictTerm {
+  std::string term;
+  irs_hip_term_meta meta;
+};
+
+inline std::vector<DictTerm> walk_term_dictionary(const uint8_t* tm, uint64_t len, bool has_freq,
+                                                  bool has_pos, bool has_pay_or_offs) {
+  size_t hl = 0;
+  const int32_t version = check_header(tm, len, "block_tree_terms_dict", 0, 3, &hl);
+  check_footer(tm, len);
+  const uint8_t* p = tm + hl;
+  const uint8_t* const end = tm + len - kFooterLen;
+  auto need = [&](uint64_t n) {
+    if (uint64_t(end - p) < n) throw index_error(IRS_HIP_ECORRUPT, "term dictionary: truncated");
+  };
+  if (version > 0) {   // irs::encrypt (encryption.cpp:37-45): the cipher header, empty = none
+    need(5);
+    const uint32_t enc = vread<uint32_t>(p);
+    if (enc) throw not_supported(IRS_HIP_EUNSUPPORTED, "term dictionary: encrypted segment");
+  }
+  {                    // postings_reader_base::prepare (formats_10.cpp:3404-3416)
+    size_t h2 = 0;
+    check_header(p, uint64_t(end - p), "iresearch_10_postings_terms", 0, 0, &h2);
+    p += h2;
+    need(5);
+    if (vread<uint32_t>(p) != kBlockSize)
+      throw index_error(IRS_HIP_ECORRUPT, "term dictionary: invalid postings block size");
+  }
+  struct Ent {
+    uint32_t suffix_at, suffix_len;   // into the file
+    bool is_block;
+    uint64_t child;                   // is_block: file offset of the sub-block
+    irs_hip_term_meta meta;           // term
+  };
+  struct Block {
+    uint64_t start;
+    bool last;
+    std::vector<Ent> ents;
+  };
+  std::vector<Block> blocks;
+  while (p < end) {
+    Block b;
+    b.start = uint64_t(p - tm);
+    need(2);
+    const uint32_t head = vread<uint32_t>(p);
+    b.last = (head & 1u) != 0;
+    const uint32_t n = head >> 1;
+    need(1);
+    const uint64_t sz = vread<uint64_t>(p);
+    const bool leaf = (sz & 1u) != 0;
+    const uint64_t suffix_bytes = sz >> 1;
+    need(suffix_bytes);
+    const uint8_t* sp = p;
+    const uint8_t* const send = p + suffix_bytes;
+    p = send;
+    need(1);
+    const uint64_t stats_bytes = vread<uint64_t>(p);
+    need(stats_bytes);
+    const uint8_t* st = p;
+    const uint8_t* const stend = p + stats_bytes;
+    p = stend;
+    irs_hip_term_meta state{};   // (a block's first record is coded against zeros)
+    state.pos_end = ~uint64_t(0);
+    for (uint32_t i = 0; i < n; ++i) {
+      if (sp >= send) throw index_error(IRS_HIP_ECORRUPT, "term dictionary: suffix block overrun");
+      Ent e{};
+      uint32_t v = vread<uint32_t>(sp);
+      e.is_block = !leaf && (v & 1u);
+      e.suffix_len = leaf ? v : (v >> 1);
+      e.suffix_at = uint32_t(sp - tm);
+      if (uint64_t(send - sp) < e.suffix_len)
+        throw index_error(IRS_HIP_ECORRUPT, "term dictionary: suffix block overrun");
+      sp += e.suffix_len;
+      if (e.is_block) {
+        const uint64_t back = vread<uint64_t>(sp);
+        if (back == 0 || back > b.start)
+          throw index_error(IRS_HIP_ECORRUPT, "term dictionary: sub-block pointer out of range");
+        e.child = b.start - back;
+      } else {
+        if (st >= stend) throw index_error(IRS_HIP_ECORRUPT, "term dictionary: stats block overrun");
+        st += decode_term_meta(st, has_freq, has_pos, has_pay_or_offs, state);
+        e.meta = state;
+      }
+      b.ents.push_back(e);
+    }
+    if (sp != send || st != stend)
+      throw index_error(IRS_HIP_ECORRUPT, "term dictionary: block sizes do not add up");
+    blocks.push_back(std::move(b));
+  }
+  // groups of floor blocks; who references which group
+  std::vector<size_t> group_first;            // index of the first block of every group
+  std::vector<size_t> group_of(blocks.size());
+  for (size_t i = 0; i < blocks.size();) {
+    group_first.push_back(i);
+    size_t j = i;
+    for (;; ++j) {
+      if (j >= blocks.size()) throw index_error(IRS_HIP_ECORRUPT, "term dictionary: open block group");
+      group_of[j] = group_first.size() - 1;
+      if (blocks[j].last) break;
+    }
+    i = j + 1;
+  }
+  std::vector<char> referenced(group_first.size(), 0);
+  auto group_at = [&](uint64_t start) -> size_t {
+    size_t lo = 0, hi = group_first.size();
+    while (lo < hi) {   // groups ascend by start
+      const size_t mid = (lo + hi) / 2;
+      if (blocks[group_first[mid]].start < start) lo = mid + 1; else hi = mid;
+    }
+    if (lo == group_first.size() || blocks[group_first[lo]].start != start)
+      throw index_error(IRS_HIP_ECORRUPT, "term dictionary: sub-block pointer hits no block");
+    return lo;
+  };
+  for (const Block& b : blocks)
+    for (const Ent& e : b.ents)
+      if (e.is_block) referenced[group_at(e.child)] = 1;
+  std::vector<DictTerm> out;
+  // depth first from every root group (one per field, in field order)
+  struct Todo {
+    size_t group;
+    std::string prefix;
+  };
+  for (size_t g = 0; g < group_first.size(); ++g) {
+    if (referenced[g]) continue;
+    std::vector<Todo> todo{{g, std::string()}};
+    while (!todo.empty()) {
+      Todo t = std::move(todo.back());
+      todo.pop_back();
+      for (size_t bi = group_first[t.group];; ++bi) {
+        for (const Ent& e : blocks[bi].ents) {
+          std::string full = t.prefix;
+          full.append(reinterpret_cast<const char*>(tm + e.suffix_at), e.suffix_len);
+          if (e.is_block) todo.push_back(Todo{group_at(e.child), std::move(full)});
+          else out.push_back(DictTerm{std::move(full), e.meta});
+        }
+        if (blocks[bi].last) break;
+      }
+    }
+  }
+  std::sort(out.begin(), out.end(), [](const DictTerm& a, const DictTerm& b) { return a.term < b.term; });
+  return out;
+}
+
+// ---- columnstore2: the fixed-length column a Norm2 feature lives in ---------------------------
+// reader::prepare_index (columnstore2.cpp:1746-1830): per column — in name order — the
+// compression id, the column header (read_header :79-88), the payload (for Norm2: its
+// Norm2Header, norm.hpp:83-125), the name unless anonymous, the bitmap index of a column that
+// lacks docs, then what its type needs: fixed_length_column (:792-1011) the value length and
+// one data offset per 65536-doc block, dense_fixed_length_column (:650-789) the value length
+// and ONE offset — value of doc d at data + len * (d - header.min) (:736-740).  The feature
+// columns of a field are anonymous; field_meta::features maps the feature to the column id.
+struct FixedColumn {
+  uint32_t id = 0, min_doc = 0, docs_count = 0;
+  uint32_t value_bytes = 0;
+  std::vector<uint8_t> payload;
+  std::vector<uint8_t> values;   // dense: value of doc d at value_bytes * (d - min_doc)
+};
+
+inline FixedColumn read_fixed_column(const uint8_t* csi, uint64_t csi_len, const uint8_t* csd,
+                                     uint64_t csd_len, uint32_t column_id) {
+  size_t hl = 0;
+  check_header(csi, csi_len, "iresearch_11_columnstore_index", 0, 0, &hl);
+  check_footer(csi, csi_len);
+  size_t dl = 0;
+  check_header(csd, csd_len, "iresearch_11_columnstore_data", 0, 0, &dl);
+  check_footer(csd, csd_len, /*verify_checksum=*/false);   // (the reader only validates the data footer)
+  const uint8_t* p = csi + hl;
+  const uint8_t* const end = csi + csi_len - kFooterLen;
+  auto need = [&](uint64_t n) {
+    if (uint64_t(end - p) < n) throw index_error(IRS_HIP_ECORRUPT, "columnstore index: truncated");
+  };
+  auto skip_string = [&](const uint8_t** at = nullptr) -> uint32_t {
+    need(1);
+    const uint32_t n = vread<uint32_t>(p);
+    need(n);
+    if (at) *at = p;
+    p += n;
+    return n;
+  };
+  constexpr uint32_t kColumnBlock = 1u << 16;   // column::kBlockSize = sparse_bitmap_writer::kBlockSize
+  need(1);
+  const uint32_t count = vread<uint32_t>(p);
+  for (uint32_t c = 0; c < count; ++c) {
+    const uint8_t* comp = nullptr;
+    const uint32_t comp_len = skip_string(&comp);
+    need(24);
+    const uint64_t docs_index = be64(p);
+    const uint32_t id = be32(p + 8), min_doc = be32(p + 12), docs = be32(p + 16);
+    const uint32_t type = (uint32_t(p[20]) << 8) | p[21], props = (uint32_t(p[22]) << 8) | p[23];
+    p += 24;
+    if (id >= count) throw index_error(IRS_HIP_ECORRUPT, "columnstore index: invalid ordinal position");
+    const uint8_t* payload = nullptr;
+    const uint32_t payload_len = skip_string(&payload);
+    if (!(props & 2u)) skip_string();                       // ColumnProperty::kNoName
+    if (docs_index) {                                       // read_bitmap_index (:109-133)
+      need(4);
+      const uint32_t nb = be32(p);
+      p += 4;
+      if (nb > 0xFFFFu) throw index_error(IRS_HIP_ECORRUPT, "columnstore index: invalid number of blocks");
+      if (nb > 2) {
+        need(uint64_t(nb) * 8);
+        p += uint64_t(nb) * 8;
+      }
+    }
+    const uint32_t nblocks = (docs + kColumnBlock - 1) / kColumnBlock;
+    const bool mine = id == column_id;
+    if (mine && (type != 2 && type != 3))
+      throw not_supported(IRS_HIP_EUNSUPPORTED, "columnstore: the column is not a fixed-length column");
+    if (mine && (props & 1u))
+      throw not_supported(IRS_HIP_EUNSUPPORTED, "columnstore: encrypted column");
+    if (mine && docs_index)
+      throw not_supported(IRS_HIP_EUNSUPPORTED, "columnstore: the column lacks docs (not dense)");
+    if (mine && !(comp_len == 28 && !std::memcmp(comp, "iresearch::compression::none", 28)))
+      throw not_supported(IRS_HIP_EUNSUPPORTED, "columnstore: compressed column");
+    switch (type) {
+      case 0:   // kSparse: addr, avg, bits, data, last_size per block (write_blocks_sparse :135-145)
+        need(uint64_t(nblocks) * 33);
+        p += uint64_t(nblocks) * 33;
+        break;
+      case 1:   // kMask: nothing
+        break;
+      case 2:   // kFixed: value length, one data offset per block
+      case 3: { // kDenseFixed: value length, ONE offset
+        need(8);
+        const uint64_t len = be64(p);
+        p += 8;
+        const uint32_t offsets = type == 3 ? 1u : nblocks;
+        need(uint64_t(offsets) * 8);
+        if (mine) {
+          if (len != 1 && len != 2 && len != 4)
+            throw not_supported(IRS_HIP_EUNSUPPORTED, "columnstore: value length is not 1, 2 or 4");
+          FixedColumn col;
+          col.id = id;
+          col.min_doc = min_doc;
+          col.docs_count = docs;
+          col.value_bytes = uint32_t(len);
+          col.payload.assign(payload, payload + payload_len);
+          col.values.resize(uint64_t(docs) * len);
+          for (uint32_t b = 0; b < nblocks; ++b) {
+            const uint64_t at = type == 3 ? be64(p) + uint64_t(b) * kColumnBlock * len : be64(p + 8ull * b);
+            const uint64_t n = std::min<uint64_t>(kColumnBlock, docs - uint64_t(b) * kColumnBlock) * len;
+            if (at < dl || at + n > csd_len - kFooterLen)
+              throw index_error(IRS_HIP_ECORRUPT, "columnstore: block outside the data file");
+            std::memcpy(col.values.data() + uint64_t(b) * kColumnBlock * len, csd + at, n);
+          }
+          return col;
+        }
+        p += uint64_t(offsets) * 8;
+        break;
+      }
+      default:
+        throw index_error(IRS_HIP_ECORRUPT, "columnstore index: invalid column type");
+    }
+  }
+  throw index_error(IRS_HIP_ECORRUPT, "columnstore: no column with that id");
+}
+
+// The files of one field of one segment, as they lie on disk -> a SegmentReader: the term
+// dictionary walk yields the term table (terms ascending: ordinal i = i-th term), the
+// columnstore the dense Norm2 column (norm_column < 0: the field has no norms) — the host half
+// of a real-index ingestion adapter: what `irs_hip_segment_open` needs, from
+// nothing but file bytes.  `terms_out` receives the term bytes per ordinal.
+struct FieldFiles {
+  const uint8_t* doc = nullptr;  uint64_t doc_len = 0;
+  const uint8_t* pos = nullptr;  uint64_t pos_len = 0;     // null: no positions
+  const uint8_t* tm = nullptr;   uint64_t tm_len = 0;      // term dictionary
+  const uint8_t* csi = nullptr;  uint64_t csi_len = 0;     // columnstore index + data
+  const uint8_t* csd = nullptr;  uint64_t csd_len = 0;
+  int64_t norm_column = -1;      // field_meta::features[Norm2]
+  uint32_t num_docs = 0;
+  int32_t layout = IRS_HIP_LAYOUT_SIMD4;
+  bool has_freq = true;
+  uint32_t wand_count = 0, wand_type = IRS_HIP_WAND_NONE;
+};
+struct OpenedField {
+  std::vector<std::string> terms;            // ordinal -> term bytes
+  std::vector<irs_hip_term_meta> metas;
+  FixedColumn norms;
+  Norm2Header norm_header;
+  uint64_t total_term_freq = 0;
+};
+inline irs_hip_segment_desc describe_field(const FieldFiles& f, int32_t device, OpenedField& o) {
+  const auto dict = walk_term_dictionary(f.tm, f.tm_len, f.has_freq, f.pos != nullptr, false);
+  o.terms.clear();
+  o.metas.clear();
+  o.total_term_freq = 0;
+  for (const DictTerm& t : dict) {
+    o.terms.push_back(t.term);
+    o.metas.push_back(t.meta);
+    o.total_term_freq += t.meta.freq;
+  }
+  irs_hip_segment_desc d{};
+  d.device = device;
+  d.layout = f.layout;
+  d.doc_file = f.doc;
+  d.doc_file_len = f.doc_len;
+  d.num_docs = f.num_docs;
+  d.has_freq = f.has_freq ? 1u : 0u;
+  if (f.norm_column >= 0) {
+    o.norms = read_fixed_column(f.csi, f.csi_len, f.csd, f.csd_len, uint32_t(f.norm_column));
+    if (!read_norm2_header(o.norms.payload.data(), o.norms.payload.size(), o.norm_header) ||
+        o.norm_header.num_bytes != o.norms.value_bytes)
+      throw index_error(IRS_HIP_ECORRUPT, "norm column: invalid Norm2 header");
+    d.norms = o.norms.values.data();
+    d.norm_width = o.norms.value_bytes;
+    d.norm_min_doc = o.norms.min_doc;
+    d.norm_count = o.norms.docs_count;
+  }
+  d.terms = o.metas.data();
+  d.num_terms = uint32_t(o.metas.size());
+  d.wand_count = f.wand_count;
+  d.wand_type = f.wand_type;
+  d.pos_file = f.pos;
+  d.pos_file_len = f.pos_len;
+  return d;
+}
+
 }  // namespace format10
 
 // ---- several GPUs: one process per GPU, segments sharded, ONE all-gather per batch -----------

@@ -163,6 +163,31 @@ uint32_t irs_synth_doc_length(uint64_t seed, uint64_t global_doc,
 int irs_synth_queries(uint64_t seed, uint32_t n_queries, uint32_t n_terms,
                       uint32_t lo_rank, uint32_t hi_rank, uint32_t* ranks_out);
 
+/* ---- the other files of a segment the hot path is fed from (synth_dict.cpp) --------------- */
+/* postings_writer::encode (formats_10.cpp:576-604) of n consecutive terms of ONE dictionary
+ * block: the delta state starts from zeros.  Returns bytes written, <0 on error. */
+int64_t irs_synth_term_meta_stream(const irs_synth_term_meta* metas, uint32_t n, uint32_t has_freq,
+                                   uint32_t has_pos, uint32_t has_pay, uint8_t* out,
+                                   uint64_t out_cap);
+/* The `.tm` term dictionary of one field: `n` terms (bytes concatenated in `terms`, lengths in
+ * `term_lens`, ascending) with their metas, as field_writer lays blocks out
+ * (formats_burst_trie.cpp:1023-1196; min_block / max_block = 25 / 48 in the reference).
+ * *root_start = file offset of the field's root block (what the term index would hold). */
+int64_t irs_synth_term_dictionary(const uint8_t* terms, const uint32_t* term_lens,
+                                  const irs_synth_term_meta* metas, uint32_t n,
+                                  uint32_t has_freq, uint32_t has_pos, uint32_t has_pay,
+                                  uint32_t min_block, uint32_t max_block, uint8_t* out,
+                                  uint64_t out_cap, uint64_t* root_start);
+/* columnstore2 `.csd` + `.csi` holding ONE anonymous fixed-length column (values of
+ * `value_bytes` bytes for docs min_doc .. min_doc + n_docs - 1, `payload` = the feature's
+ * header, e.g. a Norm2Header) — written block by block (kFixed, a fresh segment) or in one
+ * piece (dense_fixed, a consolidated one) — followed by `lead_columns` named mask columns. */
+int64_t irs_synth_columnstore(const uint8_t* values, uint32_t value_bytes, uint32_t n_docs,
+                              uint32_t min_doc, const uint8_t* payload, uint32_t payload_len,
+                              uint32_t dense_fixed, uint32_t lead_columns, uint8_t* csd_out,
+                              uint64_t csd_cap, uint64_t* csd_len, uint8_t* csi_out,
+                              uint64_t csi_cap, uint64_t* csi_len, uint32_t* column_id);
+
 #ifdef __cplusplus
 }
 #endif

@@ -95,6 +95,20 @@ def lib():
         L.irs_synth_queries.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                         C.c_uint32, C.c_void_p]
         L.irs_synth_queries.restype = C.c_int
+        L.irs_synth_term_meta_stream.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                 C.c_uint32, C.c_void_p, C.c_uint64]
+        L.irs_synth_term_meta_stream.restype = C.c_int64
+        L.irs_synth_term_dictionary.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                                C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                C.c_uint32, C.c_void_p, C.c_uint64,
+                                                C.POINTER(C.c_uint64)]
+        L.irs_synth_term_dictionary.restype = C.c_int64
+        L.irs_synth_columnstore.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                            C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                            C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                            C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                            C.POINTER(C.c_uint32)]
+        L.irs_synth_columnstore.restype = C.c_int64
         _lib = L
     return _lib
 
@@ -305,3 +319,65 @@ def make_queries(n_queries: int, n_terms: int, lo_rank: int = 16, hi_rank: int =
 
 def doc_length(global_doc: int, seed: int = SEED, mean_len: int = 100, stddev_len: int = 30):
     return lib().irs_synth_doc_length(seed, global_doc, mean_len, stddev_len)
+
+
+# -------------------------------------------- term dictionary / columnstore files --
+
+def term_meta_stream(metas, has_freq=True, has_pos=False, has_pay=False) -> np.ndarray:
+    """The stats records of ONE dictionary block (postings_writer::encode, formats_10.cpp:576-604)."""
+    m = np.ascontiguousarray(metas, TERM_META)
+    out = np.zeros(64 * len(m) + 64, np.uint8)
+    n = lib().irs_synth_term_meta_stream(m.ctypes.data, len(m), int(has_freq), int(has_pos),
+                                         int(has_pay), out.ctypes.data, out.size)
+    if n < 0:
+        raise ValueError("irs_synth_term_meta_stream failed: %d" % n)
+    return out[:n].copy()
+
+
+def term_bytes_of(ordinal: int) -> bytes:
+    """The synthetic term of ordinal i (rank i + 1): its 4-byte big-endian number — ascending
+    bytewise like the ordinals, with long shared prefixes (a deep block tree)."""
+    return int(ordinal).to_bytes(4, "big")
+
+
+def term_dictionary(terms, metas, has_freq=True, has_pos=False, has_pay=False, min_block=25,
+                    max_block=48):
+    """`.tm` of one field (field_writer, formats_burst_trie.cpp:1023-1196) -> (bytes, root_start)."""
+    m = np.ascontiguousarray(metas, TERM_META)
+    assert len(terms) == len(m)
+    blob = np.frombuffer(b"".join(terms), np.uint8) if terms else np.zeros(0, np.uint8)
+    blob = np.ascontiguousarray(blob)
+    lens = np.array([len(t) for t in terms], np.uint32)
+    out = np.zeros(blob.size + 64 * len(m) + 4096, np.uint8)
+    root = C.c_uint64()
+    n = lib().irs_synth_term_dictionary(blob.ctypes.data if blob.size else None,
+                                        lens.ctypes.data if lens.size else None,
+                                        m.ctypes.data if len(m) else None, len(m), int(has_freq),
+                                        int(has_pos), int(has_pay), min_block, max_block,
+                                        out.ctypes.data, out.size, C.byref(root))
+    if n < 0:
+        raise ValueError("irs_synth_term_dictionary failed: %d" % n)
+    return out[:n].copy(), int(root.value)
+
+
+def norm2_header(width: int, lo: int, hi: int) -> bytes:
+    """Norm2Header::Write (norm.cpp:107-115): version 0, bytes per value, min and max length."""
+    return bytes([0, width]) + int(lo).to_bytes(4, "big") + int(hi).to_bytes(4, "big")
+
+
+def columnstore(values, width: int, min_doc: int = 1, payload: bytes = b"", dense_fixed=False,
+                lead_columns: int = 2):
+    """columnstore2 `.csd` / `.csi` with one anonymous fixed-length column -> (csd, csi, id)."""
+    v = np.ascontiguousarray(values, np.uint8)
+    n_docs = v.size // width
+    csd = np.zeros(v.size + 4096 + 8 * (n_docs // 65536 + 2), np.uint8)
+    csi = np.zeros(4096 + 8 * (n_docs // 65536 + 2) + 64 * lead_columns, np.uint8)
+    pl = np.frombuffer(payload, np.uint8).copy() if payload else np.zeros(1, np.uint8)
+    dl, il, cid = C.c_uint64(), C.c_uint64(), C.c_uint32()
+    rc = lib().irs_synth_columnstore(v.ctypes.data, width, n_docs, min_doc, pl.ctypes.data,
+                                     len(payload), int(dense_fixed), lead_columns,
+                                     csd.ctypes.data, csd.size, C.byref(dl), csi.ctypes.data,
+                                     csi.size, C.byref(il), C.byref(cid))
+    if rc != 0:
+        raise ValueError("irs_synth_columnstore failed: %d" % rc)
+    return csd[:dl.value].copy(), csi[:il.value].copy(), int(cid.value)

@@ -50,8 +50,8 @@ _ref = None
 
 
 def build(force: bool = False):
-    deps = [HERE / n for n in ("postings_oracle.c", "search_oracle.cpp", "oracle.h",
-                               "oracle_internal.h")]
+    deps = [HERE / n for n in ("postings_oracle.c", "search_oracle.cpp", "dict_oracle.cpp",
+                               "oracle.h", "oracle_internal.h")]
     lib = HERE / "liboracle.so"
     if force or not lib.exists() or any(d.stat().st_mtime > lib.stat().st_mtime for d in deps):
         subprocess.run(["make", "-C", str(HERE), "liboracle.so"], check=True,
@@ -136,6 +136,16 @@ def lib(path=None):
         L.orc_score_all_phrase.argtypes = [C.POINTER(Segment), vp, u32, vp, C.POINTER(Scorer),
                                            C.c_float, u64, vp, u64, vp, vp]
         L.orc_score_all_phrase.restype = C.c_int64
+        L.orc_encode_term_meta.argtypes = [vp, vp, C.c_int, C.c_int, vp, u64]
+        L.orc_encode_term_meta.restype = C.c_int64
+        L.orc_decode_term_meta.argtypes = [vp, u64, C.c_int, C.c_int, C.c_int, vp]
+        L.orc_decode_term_meta.restype = C.c_int64
+        L.orc_walk_term_dictionary.argtypes = [vp, u64, u64, C.c_int, C.c_int, C.c_int,
+                                               C.POINTER(u32), C.POINTER(u64), vp, vp, vp]
+        L.orc_walk_term_dictionary.restype = C.c_int
+        L.orc_read_fixed_column.argtypes = [vp, u64, vp, u64, u32, C.POINTER(u32), C.POINTER(u32),
+                                            C.POINTER(u32), vp, u32, C.POINTER(u32), vp, u64]
+        L.orc_read_fixed_column.restype = C.c_int
         _lib = L
     return _lib
 
@@ -396,3 +406,80 @@ def score_all_phrase(segment: SegmentView, metas, offsets, scorer: Scorer, docs_
     if n < 0:
         raise ValueError("orc_score_all_phrase failed")
     return scores, pf
+
+
+# ---------------------------------------------- term dictionary / columnstore --
+
+def encode_term_metas(metas, has_pos: bool = False, has_pay: bool = False) -> np.ndarray:
+    """postings_writer::encode of consecutive terms of ONE dictionary block (oracle's writer
+    twin: formats_10.cpp:576-604)."""
+    m = _metas_array(metas)
+    last = np.zeros(1, m.dtype)
+    out = np.zeros(64 * len(m) + 64, np.uint8)
+    at = 0
+    for i in range(len(m)):
+        n = lib().orc_encode_term_meta(m[i:i + 1].ctypes.data, last.ctypes.data, int(has_pos),
+                                       int(has_pay), out[at:].ctypes.data, out.size - at)
+        assert n > 0
+        at += n
+    return out[:at].copy()
+
+
+def decode_term_metas(stream, n: int, has_freq: bool = True, has_pos: bool = False,
+                      has_pay: bool = False) -> np.ndarray:
+    """postings_reader::decode of `n` consecutive records of one block (formats_10.cpp:3421-3456)."""
+    buf = np.ascontiguousarray(stream, np.uint8)
+    out = np.zeros(n, TERM_META)
+    state = np.zeros(1, out.dtype)
+    state["pos_end"] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    at = 0
+    for i in range(n):
+        used = lib().orc_decode_term_meta(buf[at:].ctypes.data, buf.size - at, int(has_freq),
+                                          int(has_pos), int(has_pay), state.ctypes.data)
+        assert used > 0, (i, used)
+        at += used
+        out[i] = state[0]
+    assert at == buf.size, (at, buf.size)
+    return out
+
+
+def walk_term_dictionary(tm, root_start: int, has_freq=True, has_pos=False, has_pay=False):
+    """The reference term iterator's walk of `.tm` from the root block -> (terms, metas)."""
+    buf = np.ascontiguousarray(tm, np.uint8)
+    n, nbytes = C.c_uint32(), C.c_uint64()
+    rc = lib().orc_walk_term_dictionary(buf.ctypes.data, buf.size, root_start, int(has_freq),
+                                        int(has_pos), int(has_pay), C.byref(n), C.byref(nbytes),
+                                        None, None, None)
+    if rc != 0:
+        raise ValueError("orc_walk_term_dictionary failed: %d" % rc)
+    lens = np.zeros(max(n.value, 1), np.uint32)
+    blob = np.zeros(max(nbytes.value, 1), np.uint8)
+    metas = np.zeros(max(n.value, 1), TERM_META)
+    rc = lib().orc_walk_term_dictionary(buf.ctypes.data, buf.size, root_start, int(has_freq),
+                                        int(has_pos), int(has_pay), C.byref(n), C.byref(nbytes),
+                                        lens.ctypes.data, blob.ctypes.data, metas.ctypes.data)
+    assert rc == 0
+    terms, at = [], 0
+    for i in range(n.value):
+        terms.append(bytes(blob[at:at + lens[i]]))
+        at += int(lens[i])
+    return terms, metas[:n.value]
+
+
+def read_fixed_column(csi, csd, column_id: int):
+    """columnstore2 reader: (value_bytes, min_doc, payload bytes, values[docs * value_bytes])."""
+    a = np.ascontiguousarray(csi, np.uint8)
+    d = np.ascontiguousarray(csd, np.uint8)
+    vb, mn, docs, pl = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+    payload = np.zeros(64, np.uint8)
+    rc = lib().orc_read_fixed_column(a.ctypes.data, a.size, d.ctypes.data, d.size, column_id,
+                                     C.byref(vb), C.byref(mn), C.byref(docs), payload.ctypes.data,
+                                     payload.size, C.byref(pl), None, 0)
+    if rc != 0:
+        raise ValueError("orc_read_fixed_column failed: %d" % rc)
+    values = np.zeros(docs.value * vb.value, np.uint8)
+    rc = lib().orc_read_fixed_column(a.ctypes.data, a.size, d.ctypes.data, d.size, column_id,
+                                     C.byref(vb), C.byref(mn), C.byref(docs), payload.ctypes.data,
+                                     payload.size, C.byref(pl), values.ctypes.data, values.size)
+    assert rc == 0
+    return vb.value, mn.value, bytes(payload[:pl.value]), values

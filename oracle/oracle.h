@@ -226,6 +226,28 @@ int64_t orc_score_all_phrase(const orc_segment* seg, const orc_term_meta* metas,
                              const uint64_t* docs_with_term, uint64_t total_term_freq,
                              float* scores, uint32_t* phrase_freq);
 
+/* ---- term dictionary + columnstore readers ------------------------ */
+/* postings_writer_base::encode (formats_10.cpp:576-604): one term's stats, delta-coded against
+ * `last` (zeroed at the start of a dictionary block), which is updated.  Returns bytes, <0. */
+int64_t orc_encode_term_meta(const orc_term_meta* meta, orc_term_meta* last, int has_pos,
+                             int has_pay, uint8_t* out, uint64_t cap);
+/* postings_reader_base::decode (formats_10.cpp:3421-3456): `state` carries the previous term of
+ * the block.  Returns bytes consumed, <0 on truncation. */
+int64_t orc_decode_term_meta(const uint8_t* in, uint64_t len, int has_freq, int has_pos,
+                             int has_pay, orc_term_meta* state);
+/* The term iterator's walk of `.tm` from the field's root block (what the term index hands
+ * out): formats_burst_trie.cpp block_iterator / term_iterator.  See dict_oracle.cpp. */
+int orc_walk_term_dictionary(const uint8_t* tm, uint64_t len, uint64_t root_start, int has_freq,
+                             int has_pos, int has_pay, uint32_t* n_terms, uint64_t* term_bytes,
+                             uint32_t* term_lens, uint8_t* terms, orc_term_meta* metas);
+/* columnstore2 reader: the fixed-length column `column_id` (columnstore2.cpp:1746-1830,
+ * 650-789, 792-1011). */
+int orc_read_fixed_column(const uint8_t* csi, uint64_t csi_len, const uint8_t* csd,
+                          uint64_t csd_len, uint32_t column_id, uint32_t* value_bytes,
+                          uint32_t* min_doc, uint32_t* docs_count, uint8_t* payload,
+                          uint32_t payload_cap, uint32_t* payload_len, uint8_t* values,
+                          uint64_t values_cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -237,8 +237,8 @@ int main() {
   }
 
   // adapter groundwork (format10::): the files' headers and footers, the term dictionary's
-  // term_meta entries (encoded here the way postings_writer_base::encode does,
-  // formats_10.cpp:576-604), the Norm2 column header (norm.cpp:107-115)
+  // term_meta entries, the Norm2 column header (norm.cpp:107-115); tests/cpp/test_files.cpp
+  // opens a whole segment from file bytes
   {
     size_t hdr = 0;
     REQUIRE(format10::check_header(a.doc, a.doc_len, format10::kDocFormatName, 0, 5, &hdr) == 5);
@@ -255,37 +255,45 @@ int main() {
       threw = true;
     }
     REQUIRE(threw);
-    auto vwrite = [](std::vector<uint8_t>& o, uint64_t v) {
-      while (v >= 0x80) {
-        o.push_back(uint8_t(v) | 0x80);
-        v >>= 7;
+    // the stats records of one dictionary block: written by the emitter from the writer
+    // (synth_dict.cpp <- postings_writer_base::encode, formats_10.cpp:576-604), read back by
+    // format10::decode_term_meta AND by the oracle's twin of the reader (dict_oracle.cpp <-
+    // postings_reader_base::decode :3421-3456); the oracle's own encoder must produce the
+    // same bytes.  (A real dictionary has no entry for a term without docs.)
+    std::vector<irs_synth_term_meta> present;
+    for (uint32_t t = 0; t < a.num_terms; ++t)
+      if (a.metas[t].docs_count)
+        present.push_back(reinterpret_cast<const irs_synth_term_meta&>(a.metas[t]));
+    std::vector<uint8_t> dict(64 * present.size() + 64);
+    const int64_t dict_len = irs_synth_term_meta_stream(present.data(), uint32_t(present.size()), 1, 1, 0,
+                                                        dict.data(), dict.size());
+    REQUIRE(dict_len > 0);
+    dict.resize(size_t(dict_len));
+    {
+      std::vector<uint8_t> again(dict.size() + 64);
+      orc_term_meta last;
+      std::memset(&last, 0, sizeof last);
+      size_t at = 0;
+      for (const auto& m : present) {
+        const int64_t n = orc_encode_term_meta(reinterpret_cast<const orc_term_meta*>(&m), &last, 1, 0,
+                                               again.data() + at, again.size() - at);
+        REQUIRE(n > 0);
+        at += size_t(n);
       }
-      o.push_back(uint8_t(v));
-    };
-    std::vector<uint8_t> dict;
-    irs_hip_term_meta last{};
-    for (uint32_t t = 0; t < a.num_terms; ++t) {
-      const irs_hip_term_meta& m = a.metas[t];
-      vwrite(dict, m.docs_count);
-      if (m.freq) vwrite(dict, m.freq - m.docs_count);
-      vwrite(dict, m.doc_start - last.doc_start);
-      vwrite(dict, m.pos_start - last.pos_start);             // the field has positions
-      if (m.pos_end != ~uint64_t(0)) vwrite(dict, m.pos_end);
-      if (m.docs_count == 1) vwrite(dict, uint32_t(m.e_skip_start));
-      else if (m.docs_count > 128) vwrite(dict, m.e_skip_start);
-      last = m;
+      REQUIRE(at == dict.size() && !std::memcmp(again.data(), dict.data(), at));
     }
     const uint8_t* p = dict.data();
     irs_hip_term_meta state{};
-    for (uint32_t t = 0; t < a.num_terms; ++t) {
-      if (a.metas[t].docs_count == 0) {   // (the emitter keeps a row for unseen ranks; a real
-        // dictionary simply has no entry)
-        irs_hip_term_meta skip = state;
-        p += format10::decode_term_meta(p, true, true, false, skip);
-        continue;
-      }
-      p += format10::decode_term_meta(p, true, true, false, state);
-      const irs_hip_term_meta& m = a.metas[t];
+    orc_term_meta ostate;
+    std::memset(&ostate, 0, sizeof ostate);
+    ostate.pos_end = ~uint64_t(0);
+    state.pos_end = ~uint64_t(0);
+    for (const auto& m : present) {
+      const int64_t used = orc_decode_term_meta(p, uint64_t(dict.data() + dict.size() - p), 1, 1, 0, &ostate);
+      REQUIRE(used > 0);
+      REQUIRE(format10::decode_term_meta(p, true, true, false, state) == size_t(used));
+      p += used;
+      REQUIRE(!std::memcmp(&state, &ostate, sizeof state));
       REQUIRE(state.docs_count == m.docs_count && state.freq == m.freq);
       REQUIRE(state.doc_start == m.doc_start && state.pos_start == m.pos_start);
       REQUIRE(m.freq <= 128 || state.pos_end == m.pos_end);

@@ -12,24 +12,24 @@ import pytest
 ROOT = Path(__file__).resolve().parents[1]
 
 
-def _build_and_run(tmp_path, abi_lib: Path, extra=()):
+def _build_and_run(tmp_path, abi_lib: Path, extra=(), source="test_host", args=()):
     import oracle
     from iresearch_amd import _build
     synth = _build.build_synth()
     orc = oracle.build()
-    exe = tmp_path / "test_host"
+    exe = tmp_path / source
     cmd = ["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-Wall",
            "-I", str(ROOT / "include"), "-I", str(ROOT / "iresearch_amd" / "cpp"),
            "-I", str(ROOT / "iresearch_amd" / "index"), "-I", str(ROOT / "oracle"),
-           str(ROOT / "tests" / "cpp" / "test_host.cpp"), "-o", str(exe),
+           str(ROOT / "tests" / "cpp" / (source + ".cpp")), "-o", str(exe),
            str(abi_lib), str(synth), str(orc), "-pthread",
            "-Wl,-rpath," + str(abi_lib.parent), "-Wl,-rpath," + str(Path(synth).parent),
            "-Wl,-rpath," + str(Path(orc).parent), *extra]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
-    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    run = subprocess.run([str(exe), *args], capture_output=True, text=True, timeout=900)
     assert run.returncode == 0, (run.stdout + run.stderr)[-3000:]
-    assert "test_host OK" in run.stdout
+    assert source + " OK" in run.stdout
 
 
 def test_cpp_sharded_search_two_processes(simlib, tmp_path):
@@ -59,6 +59,24 @@ def test_cpp_sharded_search_two_processes(simlib, tmp_path):
 
 def test_cpp_host_layer_on_the_emulator(simlib, tmp_path):
     _build_and_run(tmp_path, Path(simlib._name))
+
+
+@pytest.mark.parametrize("positions", [0, 1])
+def test_cpp_segment_from_file_bytes_on_the_emulator(simlib, tmp_path, positions):
+    """a segment opened from `.doc` (+ `.pos`), the term dictionary and
+    the columnstore files only (tests/cpp/test_files.cpp), then BASELINE config 2 on it."""
+    _build_and_run(tmp_path, Path(simlib._name), source="test_files",
+                   args=["60000", str(positions)])
+
+
+@pytest.mark.gpu
+def test_cpp_segment_from_file_bytes_on_the_gpu(gpulib, tmp_path):
+    """... at config 2's own size: OR-of-2 BM25 top-100 on a 1 M-doc segment read from files."""
+    from iresearch_amd import _build
+    rocm = "/opt/rocm/lib"
+    _build_and_run(tmp_path, Path(_build.HIP_LIB),
+                   ["-Wl,-rpath," + rocm, "-Wl,-rpath-link," + rocm, "-Wl,--allow-shlib-undefined"],
+                   source="test_files", args=["1000000", "0"])
 
 
 @pytest.mark.gpu

@@ -211,3 +211,91 @@ def test_positions_and_phrase_oracle():
         hits, total = oracle.search_phrase([gview], parity.metas_for(gseg, terms)[None, :],
                                            v["offsets"], sc, 64)
         assert [names[d - 1] for d in sorted(int(x) for x in hits["doc"])] == v["docs"]
+
+
+def test_term_meta_codec_writer_and_reader_twins():
+    """SURVEY §8 a7: postings_writer::encode / postings_reader::decode of the term dictionary's
+    stats records (formats_10.cpp:576-604, 3421-3456).  Two independent restatements of the
+    WRITER (the emitter iresearch_amd/index/synth_dict.cpp and the oracle's orc_encode_term_meta)
+    must produce the same bytes, and the oracle's restatement of the READER must give the metas
+    back — for fields with and without positions / frequencies and the framing cases: a single
+    doc (e_single_doc), exactly 128 docs (no skip pointer), 129 (skip pointer), pos_end present
+    only when the term has more than 128 positions."""
+    from iresearch_amd import synth
+    rng = np.random.default_rng(9)
+    n_docs = 5000
+
+    def lst(n, tf_hi):
+        d = np.sort(rng.choice(np.arange(1, n_docs + 1), n, replace=False)).astype(np.uint32)
+        return d, rng.integers(1, tf_hi + 1, n).astype(np.uint32)
+
+    # (docs, max tf): single doc with tf 1 / tf 200 (pos_end only for the second), 127/128/129
+    # docs with tf == 1 (128 positions: no pos_end; 129: pos_end), long lists
+    shapes = [(1, 1), (1, 200), (5, 1), (127, 1), (128, 1), (129, 1), (128, 3), (300, 2), (2000, 4)]
+    plain = [lst(n, hi) for n, hi in shapes]
+    with_pos = []
+    for d, f in plain:
+        pos = np.concatenate([np.sort(rng.choice(np.arange(1, 400), int(x), replace=False)) for x in f])
+        with_pos.append((d, f, pos.astype(np.uint32)))
+    for lists, has_pos in ((plain, False), (with_pos, True)):
+        seg = synth.segment_from_lists(lists, n_docs, synth.LAYOUT_SIMD4)
+        metas = seg.metas
+        assert (metas["docs_count"] == [n for n, _ in shapes]).all()
+        if has_pos:   # pos_end: set exactly where the reader will look for it
+            for m in metas:
+                assert (int(m["pos_end"]) != 0xFFFFFFFFFFFFFFFF) == (int(m["freq"]) > 128)
+        stream = synth.term_meta_stream(metas, has_freq=True, has_pos=has_pos)
+        assert np.array_equal(stream, oracle.encode_term_metas(metas, has_pos=has_pos))
+        back = oracle.decode_term_metas(stream, len(metas), has_freq=True, has_pos=has_pos)
+        for got, want in zip(back, metas):
+            assert got["docs_count"] == want["docs_count"] and got["freq"] == want["freq"]
+            assert got["doc_start"] == want["doc_start"]
+            if has_pos:
+                assert got["pos_start"] == want["pos_start"]
+                assert got["pos_end"] == want["pos_end"]
+            if want["docs_count"] == 1:
+                assert int(got["e_skip_start"]) & 0xFFFFFFFF == int(want["e_skip_start"]) & 0xFFFFFFFF
+            elif want["docs_count"] > 128:
+                assert got["e_skip_start"] == want["e_skip_start"]
+    # a field without frequencies: freq stays 0, no "freq - docs_count" record
+    nofreq = np.zeros(3, synth.TERM_META)
+    nofreq["docs_count"] = [1, 128, 500]
+    nofreq["doc_start"] = [40, 40, 400]
+    nofreq["e_skip_start"] = [7, 0, 333]
+    nofreq["pos_end"] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    stream = synth.term_meta_stream(nofreq, has_freq=False)
+    assert np.array_equal(stream, oracle.encode_term_metas(nofreq))
+    back = oracle.decode_term_metas(stream, 3, has_freq=False)
+    assert (back["docs_count"] == nofreq["docs_count"]).all() and (back["freq"] == 0).all()
+    assert (back["doc_start"] == nofreq["doc_start"]).all()
+    assert int(back[0]["e_skip_start"]) == 7 and int(back[2]["e_skip_start"]) == 333
+
+
+def test_term_dictionary_and_columnstore_files():
+    """the emitter's `.tm` (blocks written the way field_writer does) read by the
+    oracle's restatement of the reference iterator, and its columnstore2 pair read by the
+    oracle's column reader — nested blocks, floor blocks, 1/2/4-byte values, a column written
+    block by block (fresh segment) and in one piece (consolidated)."""
+    from iresearch_amd import synth
+    seg = synth.build_segment(30_000, 2048)
+    keep = [i for i in range(len(seg.metas)) if seg.metas[i]["docs_count"]]
+    terms = [synth.term_bytes_of(i) for i in keep]
+    tm, root = synth.term_dictionary(terms, seg.metas[keep])
+    got_terms, got_metas = oracle.walk_term_dictionary(tm, root)
+    assert got_terms == terms
+    for g, w in zip(got_metas, seg.metas[keep]):
+        assert g["docs_count"] == w["docs_count"] and g["freq"] == w["freq"]
+        assert g["doc_start"] == w["doc_start"]
+    with pytest.raises(ValueError):
+        oracle.walk_term_dictionary(tm[:len(tm) // 2], root)
+    rng = np.random.default_rng(4)
+    for width in (1, 2, 4):
+        n = 70_000 if width == 1 else 66_000     # more than one 65536-doc block
+        vals = rng.integers(0, 256, n * width).astype(np.uint8)
+        hdr = synth.norm2_header(width, 1, 200)
+        for dense in (False, True):
+            csd, csi, cid = synth.columnstore(vals, width, min_doc=1, payload=hdr, dense_fixed=dense)
+            vb, mn, payload, values = oracle.read_fixed_column(csi, csd, cid)
+            assert (vb, mn, payload) == (width, 1, hdr) and np.array_equal(values, vals)
+        with pytest.raises(ValueError):
+            oracle.read_fixed_column(csi, csd, cid + 1)   # a mask column: not a fixed-length one
