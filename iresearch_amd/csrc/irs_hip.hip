@@ -805,7 +805,10 @@ bool launch_join_score(irs_hip_batch* b, rt::stream_t st) {
   const uint32_t waves = b->join_threads / 64;
   uint32_t per_cu = uint32_t((160u * 1024u) / smem);
   per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 32u / waves));
-  const uint32_t cpq = (b->join_max_tiles + kJoinChunkTiles - 1) / kJoinChunkTiles;
+  // chunks of up to kJoinChunkTiles tiles, the unit's tiles cut evenly (102 tiles: 4 x 26, not
+  // 3 x 32 + 6 — a short last chunk pays the whole per-chunk prologue for a few tiles)
+  const uint32_t cpq = std::max<uint32_t>(1, (b->join_max_tiles + kJoinChunkTiles - 1) / kJoinChunkTiles);
+  const uint32_t chunk_tiles = std::max<uint32_t>(1, (b->join_max_tiles + cpq - 1) / cpq);
   const uint32_t n_units = uint32_t(b->join_units.size());
   const uint64_t chunks = uint64_t(n_units) * cpq;
   if (chunks > 0xFFFF0000ull) return false;
@@ -824,6 +827,7 @@ bool launch_join_score(irs_hip_batch* b, rt::stream_t st) {
   a.n_units = n_units;
   a.nw_log2 = b->join_nw_log2;
   a.cand_cap = b->cand_cap;
+  a.chunk_tiles = chunk_tiles;
   if (!rt::dmemset(b->d_work.as<uint32_t>() + 1, 0, 4, st) ||
       !rt::h2d(b->d_join_args.p, &a, sizeof a, st))
     return false;

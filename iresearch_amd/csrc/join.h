@@ -519,6 +519,7 @@ struct JoinArgs {
   uint32_t n_units;
   uint32_t nw_log2;
   uint32_t cand_cap;
+  uint32_t chunk_tiles;  // tiles per chunk, <= kJoinChunkTiles: the units' tiles cut evenly
 };
 
 // One workgroup per unit scores the tiles {phase, phase + P, ...} and picks the threshold bin
@@ -746,11 +747,12 @@ k_join_score(const JoinArgs* __restrict__ args) {
     uint32_t next_chunk = 0;
     if (tid == 0) next_chunk = atomicAdd(args->work_counter, 1u);
     const uint32_t q = wave::uniform(args->order[chunk % n_units]);
-    const uint32_t tile0 = (chunk / n_units) * kJoinChunkTiles;
+    const uint32_t per_chunk = args->chunk_tiles;
+    const uint32_t tile0 = (chunk / n_units) * per_chunk;
     const DevQuery qd = args->queries[q];
     const uint32_t n_tiles = qd.n_tiles;
     const uint32_t ntile = tile0 >= n_tiles ? 0u
-                           : ((n_tiles - tile0) < kJoinChunkTiles ? (n_tiles - tile0) : kJoinChunkTiles);
+                           : ((n_tiles - tile0) < per_chunk ? (n_tiles - tile0) : per_chunk);
     const uint32_t bs = args->bstar[q];
     uint32_t my_hits = 0;
     uint64_t* lc = lcand + parity * kJoinCands;
