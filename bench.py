@@ -153,6 +153,10 @@ def main():
     ap.add_argument("--terms", type=int, default=8)
     ap.add_argument("--k", type=int, default=1000)
     ap.add_argument("--segments", type=int, default=8, help="segments of the index when --gpus > 1")
+    ap.add_argument("--max-rank", type=int, default=4096,
+                    help="term ranks that get posting lists (the queries draw from [16, 4096] "
+                         "whatever this is; 1048576 = the corpus's whole vocabulary: term tables, "
+                         "block directory and open time at a real dictionary's size)")
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--stride", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -224,7 +228,7 @@ def main():
     segs = {}
     for s in my:
         n = per if s < n_segments - 1 else args.docs - per * (n_segments - 1)
-        segs[s] = synth.build_segment(n, 4096, first_doc=s * per)
+        segs[s] = synth.build_segment(n, args.max_rank, first_doc=s * per)
     log("built %d segment(s) in %.1f s" % (len(my), time.perf_counter() - t0))
     local_stats = {s: (segs[s].docs_with_field, segs[s].total_term_freq,
                        np.asarray(segs[s].metas["docs_count"])) for s in my}
@@ -453,6 +457,7 @@ def main():
                 "workload": "OR-of-%d terms BM25 top-%d, %d-doc Zipfian index, %d segment(s), "
                             "%d queries/step" % (args.terms, k, args.docs, n_segments, nq),
                 "segments": n_segments, "queries_per_step": nq, "layout": "1_5simd",
+                "indexed_ranks": args.max_rank,
                 "path": "joined posting streams (k_join once per distinct term of the batch, "
                         "k_join_score per query)" if all(b.path() == _lib.PATH_JOINED
                                                          for b in batches.values())

@@ -717,6 +717,50 @@ def case_merge_types(L):
     sr.close()
 
 
+def case_accumulator_switch(L):
+    """32-bit fixed-point accumulators are used while U / (smallest possible posting score)
+    <= 1000 for every query of the batch, 64-bit ones beyond (irs_hip.hip batch_create).  Batches
+    sitting just below and just above that switch, on the docs that make the bound tight — the
+    longest docs (norm 255), tf = 1, matched by the LOW-boost term only — must both stay within
+    1e-5 of the oracle for every returned doc, the smallest scores included (k takes every
+    match)."""
+    n_docs = 6000
+    rng = np.random.default_rng(31)
+    norms = np.full(n_docs, 255, np.uint8)
+    norms[::7] = 40
+    da = np.sort(rng.choice(np.arange(1, n_docs + 1), 1500, replace=False)).astype(np.uint32)
+    db = np.sort(rng.choice(np.arange(1, n_docs + 1), 700, replace=False)).astype(np.uint32)
+    dc = np.sort(rng.choice(np.arange(1, n_docs + 1), 300, replace=False)).astype(np.uint32)
+    lists = [(da, np.ones(da.size, np.uint32)),
+             (db, rng.integers(1, 6, db.size).astype(np.uint32)),
+             (dc, rng.integers(1, 30, dc.size).astype(np.uint32))]
+    seg, sr = open_lists(L, lists, n_docs, synth.LAYOUT_SIMD4, norms)
+    stats = [parity.segment_stats(seg)]
+    scorer = BM25()
+    # U / min-score as batch_create computes it, for an Or of (term 0, boost 1) and (term 1, boost B)
+    c0 = [p.scorers[0][1] for p in search.prepare([by_term(0), by_term(1), by_term(2)], scorer, stats)]
+    nc, nl = search.prepare([by_term(0)], scorer, stats)[0].scorers[0][2:4]
+    smin = c0[0] - c0[0] / (1.0 + 1.0 / (nc + nl * 255.0))
+
+    def boost_for(ratio):   # (the batch's widest query: terms 0, 1 at boost B, 2 at B / 2)
+        return (ratio * smin - c0[0]) / (c0[1] + c0[2] / 2.0)
+    for ratio, want_joined in ((900.0, True), (990.0, True), (1010.0, False), (1500.0, False)):
+        B = boost_for(ratio)
+        filters = [Or([by_term(0), by_term(1, B)]), Or([by_term(0), by_term(1, B), by_term(2, B / 2)]),
+                   Or([by_term(1, B), by_term(0)])]
+        prep = search.prepare(filters, scorer, stats)
+        b = sr.batch(prep, 4096)
+        hits, counts, totals = b.run().results()
+        # (which side of the switch the batch fell on shows in the path it could take)
+        assert (b.path() == _lib.PATH_JOINED) == want_joined, (ratio, b.path())
+        parity.check_single_segment(seg, filters, scorer, 4096, hits, counts, totals)
+        assert counts[0] == totals[0] == np.union1d(da, db).size     # every match returned
+        lo = hits[0, int(counts[0]) - 1]
+        assert lo["score"] > 0 and lo["score"] <= smin * (1 + 1e-4)  # ... down to the smallest one
+        b.close()
+    sr.close()
+
+
 def case_plan_ahead(L):
     """irs_hip_batch_plan: a run whose planning stage was queued ahead returns exactly what a
     plain run returns — tile batches, conjunctions, phrases, repeated and interleaved with

@@ -98,6 +98,10 @@ def test_pilot_misled(simlib, joined):
     cases.case_pilot_misled(simlib, joined=joined)
 
 
+def test_accumulator_switch(simlib):
+    cases.case_accumulator_switch(simlib)
+
+
 @pytest.mark.parametrize("layout", [0, 1])
 def test_join_edge_blocks(simlib, layout):
     cases.case_join_edge_blocks(simlib, layout)

@@ -171,6 +171,10 @@ def test_pilot_misled(gpulib, joined):
     cases.case_pilot_misled(gpulib, joined=joined)
 
 
+def test_accumulator_switch(gpulib):
+    cases.case_accumulator_switch(gpulib)
+
+
 @pytest.mark.parametrize("layout", [0, 1])
 def test_join_edge_blocks(gpulib, layout):
     cases.case_join_edge_blocks(gpulib, layout)
