@@ -130,7 +130,10 @@ struct irs_hip_batch {
   // (all_tile_units: every doc-tile unit, fixed at create; ensure_scratch deals them to
   // join_units — plain disjunctions run as joined posting streams, join.h — and tile_units —
   // the rest, score.h's work items)
-  std::vector<uint32_t> all_tile_units, tile_units, join_units, conj_units;
+  // (all_conj_units: every conjunction, fixed at create; ensure_scratch deals them to
+  // join_units — accumulators with match counts, join.h — and conj_units — block driven, conj.h)
+  std::vector<uint32_t> all_tile_units, tile_units, join_units, conj_units, all_conj_units;
+  std::vector<uint8_t> count_precise;   // [unit] match counts may share its 32-bit accumulators
   std::vector<uint32_t> conj_items;   // lead items of every conj unit
   uint32_t n_conj_wgs = 0;
   DevBuf d_tile_units, d_conj_units, d_conj_items, d_conj_hist;
@@ -646,12 +649,44 @@ bool join_allowed(const irs_hip_batch* b) {   // batch level
   }
   return !b->phrase && b->acc32 && !b->wand;
 }
+bool join_counts_allowed() {   // tuning / test knob
+  const char* e = std::getenv("IRS_HIP_JOIN_COUNTS");
+  return !e || std::atoi(e) != 0;
+}
+// Conjunction as joined streams (every entry of every term walked, ~1 unit of time each) or
+// block driven (per lead block: its decode + a seek and a block decode in every other term,
+// ~kJoinAndBlockCost units each)?
+constexpr uint64_t kJoinAndBlockCost = 700;
+bool join_and_pays(const irs_hip_batch* b, const DevQuery& dq) {
+  if (b->path_pref == IRS_HIP_PATH_JOINED) return true;   // (forced: wherever it is possible)
+  if (const char* e = std::getenv("IRS_HIP_JOIN_AND")) {   // tuning / test knob: 0 never, 1 always
+    return std::atoi(e) != 0;
+  }
+  const irs_hip_segment* sg = b->segs[dq.seg];
+  uint64_t sum = 0, lead = ~0ull;
+  for (uint32_t j = 0; j < dq.n_terms; ++j) {
+    const uint64_t df = sg->terms[b->qterms[dq.first_term + j].term].docs_count;
+    sum += df;
+    lead = std::min(lead, df);
+  }
+  const uint64_t lead_blocks = lead / kBlock + 1;
+  return sum + uint64_t(sg->dev.num_docs / kJoinTile + 1) * 2000ull <=
+         lead_blocks * dq.n_terms * kJoinAndBlockCost;
+}
 bool unit_counts_matches(const DevQuery& dq) {   // min-match / the kMin disjunction of two
   return (dq.op & 0xFF) == 1 || query_min_both(dq.op);
 }
 bool unit_joinable(const irs_hip_batch* b, uint32_t u) {
   const DevQuery& dq = b->queries[u];
-  if ((dq.op & 0xFF) != 0 || query_min_both(dq.op) || query_merge(dq.op) != kScoreSum) return false;
+  if (query_min_both(dq.op) || query_merge(dq.op) != kScoreSum) return false;
+  if ((dq.op & 0xFF) != 0) {
+    // min-match / conjunction: the match count rides in the accumulator's low bits (join.h
+    // COUNT) where that costs no precision that matters
+    if (!dq.n_terms || !b->count_precise[u] || !join_counts_allowed()) return false;
+    // a conjunction whose rarest term is far rarer than the rest is cheaper block driven
+    // (conj.h decodes only the blocks the lead term's docs fall into)
+    if ((dq.op & 0xFF) == 2 && !join_and_pays(b, dq)) return false;
+  }
   const irs_hip_segment* sg = b->segs[dq.seg];
   for (uint32_t j = 0; j < dq.n_terms; ++j) {
     const DevQTerm& qt = b->qterms[dq.first_term + j];
@@ -835,6 +870,62 @@ bool launch_join_score(irs_hip_batch* b, rt::stream_t st) {
   return rt::last_error_ok();
 }
 
+
+// k_conj work of the batch's block-driven conjunctions (conj_units): the lead term of a unit is
+// its first one (sorted by cost at create); one wavefront per 128-posting block of it (+ one for
+// its vint tail / single doc), its record and the other terms' start blocks written by
+// k_conj_seek every run.  Rebuilt whenever ensure_scratch deals the conjunctions anew.
+int build_conj_work(irs_hip_batch* b) {
+  const uint32_t nq = b->nq;
+  int rc = IRS_HIP_OK;
+  b->conj_items.clear();
+  b->conj_total_items = 0;
+  b->n_conj_wgs = 0;
+  b->n_conj_pilot = 0;
+  b->conj_pilot_stride = 0;
+  if (b->conj_units.empty()) return rc;
+  try {
+    for (uint32_t u : b->conj_units) {
+      const DevQuery& dq = b->queries[u];
+      uint32_t items = 0;
+      if (dq.n_terms) {
+        const DevTerm& t = b->segs[dq.seg]->terms[b->qterms[dq.first_term].term];
+        items = t.nblk + ((t.docs_count == 1 || t.tail_n) ? 1u : 0u);
+      }
+      b->conj_items.push_back(items);
+    }
+    // rows of the seek table: the lead items of the conj units, unit after unit
+    std::vector<uint32_t> item_base(b->conj_units.size() + 1, 0), unit_items(nq, 0);
+    uint64_t total = 0;
+    for (size_t c = 0; c < b->conj_units.size(); ++c) {
+      item_base[c] = uint32_t(total);
+      unit_items[b->conj_units[c]] = uint32_t(total);
+      total += b->conj_items[c];
+    }
+    if (total > 0x7FFFFFFFull) return IRS_HIP_EUNSUPPORTED;
+    item_base[b->conj_units.size()] = uint32_t(total);
+    b->conj_total_items = uint32_t(total);
+    b->n_conj_wgs = uint32_t((total + kConjWaves - 1) / kConjWaves);
+    if (!b->d_conj_item_base.alloc(item_base.size() * 4) ||
+        !b->d_conj_unit_items.alloc(unit_items.size() * 4) ||
+        !b->d_conj_seek.alloc((total + 2) * uint64_t(kMaxTerms) * 4) ||
+        !b->d_conj_recs.alloc((total + 1) * sizeof(ConjItem)) ||
+        !b->d_conj_units.alloc(b->conj_units.size() * 4) ||
+        !b->d_conj_items.alloc(b->conj_items.size() * 4) ||
+        !b->d_conj_hist.alloc(uint64_t(nq) * kBins * 4))
+      return IRS_HIP_ENOMEM;
+    if (!rt::h2d(b->d_conj_item_base.p, item_base.data(), item_base.size() * 4, nullptr) ||
+        !rt::h2d(b->d_conj_unit_items.p, unit_items.data(), unit_items.size() * 4, nullptr) ||
+        !rt::h2d(b->d_conj_units.p, b->conj_units.data(), b->conj_units.size() * 4, nullptr) ||
+        !rt::h2d(b->d_conj_items.p, b->conj_items.data(), b->conj_items.size() * 4, nullptr) ||
+        !rt::sync(nullptr))
+      return IRS_HIP_EHIP;
+  } catch (...) {
+    rc = IRS_HIP_ENOMEM;
+  }
+  return rc;
+}
+
 bool ensure_scratch(irs_hip_batch* b) {
   if (b->scratch_ready) return true;
   if (b->phrase) b->tile = 0x40000000u;  // k_phrase is block driven: one "tile" = the segment
@@ -856,6 +947,14 @@ bool ensure_scratch(irs_hip_batch* b) {
         b->any_and = b->any_and || unit_counts_matches(b->queries[u]);
       }
     }
+    if (!b->phrase) {   // (a phrase batch's conj_units are its phrases, fixed at create)
+      b->conj_units.clear();
+      for (uint32_t u : b->all_conj_units) {
+        if (allow && unit_joinable(b, u)) b->join_units.push_back(u);
+        else b->conj_units.push_back(u);
+      }
+      if (build_conj_work(b) != IRS_HIP_OK) return false;
+    }
     b->joined = !b->join_units.empty();
   }
   // 32-bit accumulators halve the LDS per doc: twice the tile at the same residency
@@ -873,7 +972,8 @@ bool ensure_scratch(irs_hip_batch* b) {
   for (uint32_t u : b->join_units) is_join[u] = 1;
   for (uint32_t u = 0; u < b->nq; ++u) {
     DevQuery& dq = b->queries[u];
-    const bool tiled = !b->phrase && (dq.op & 0xFF) != 2;   // conjunctions are block driven
+    // (conjunctions are block driven unless they run as joined streams)
+    const bool tiled = !b->phrase && ((dq.op & 0xFF) != 2 || is_join[u]);
     const uint32_t tile_docs = is_join[u] ? kJoinTile : b->tile;   // (streams are cut at kJoinTile)
     dq.n_tiles = tiled ? (b->segs[dq.seg]->dev.num_docs + tile_docs - 1) / tile_docs : 0u;
     if (b->phrase) dq.n_tiles = 1;
@@ -916,7 +1016,7 @@ bool ensure_scratch(irs_hip_batch* b) {
     });
     for (uint32_t i = 0; i < work.size(); ++i) b->queries[i].run_unit = work[i].second;
   }
-  b->stride_eff = b->all_tile_units.empty()
+  b->stride_eff = (b->tile_units.empty() && b->join_units.empty())
                       ? b->stride
                       : std::max<uint32_t>(1, std::min<uint32_t>(b->stride, b->n_tiles / 2));
   if (const char* e = std::getenv("IRS_HIP_WG_THREADS")) {  // tuning knob
@@ -1376,6 +1476,7 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
   try {
     b->segs.assign(segs, segs + n_segs);
     b->queries.resize(nq);
+    b->count_precise.assign(nq, 0);
     b->qterms.reserve(size_t(n_entries) * n_segs);
     std::vector<int> exps;
     exps.reserve(nq);
@@ -1412,6 +1513,7 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
       std::vector<DevQTerm> row;
       bool absent = false;
       double upper = 0.0, min_score = 1e300;
+      std::vector<double> smins;   // per present term: the smallest score of one posting
       for (uint32_t j = 0; j < in.n_terms; ++j) {
         const irs_hip_term_scorer& ts = terms[in.first_term + j];
         DevQTerm qt{};
@@ -1471,6 +1573,7 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
             default: smin = 0.0;  // wide norms: unbounded below
           }
           min_score = std::min(min_score, smin);
+          smins.push_back(smin);
         }
         const bool tfidf = qt.kind == kTfidf || qt.kind == kTfidfTiny || qt.kind == kTfidfWide ||
                            qt.kind == kTfidfLegacy;
@@ -1516,6 +1619,16 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
         if (rc != IRS_HIP_OK) break;
       }
       if (need == 0xFFu) row.clear();
+      // A doc that exists matches at least `need` terms: c matched postings score at least
+      // c times the mean of the `need` smallest per-term minima — the score below which no
+      // posting of a matching doc falls ON AVERAGE, which is what bounds the relative error of
+      // a fixed-point sum that loses a constant per posting
+      if (need > 1 && need != 0xFFu && !smins.empty() && !is_phrase) {
+        std::sort(smins.begin(), smins.end());
+        double sm = 0.0;
+        for (uint32_t i = 0; i < need && i < smins.size(); ++i) sm += smins[i];
+        min_score = sm / double(need);
+      }
       // low byte of op: 0 = disjunction in doc tiles, 1 = doc tiles with per-doc match
       // counters (min-match), 2 = conjunction, block by block of its rarest term (conj.h)
       dq.op = 0;
@@ -1551,7 +1664,12 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
         }
       }
       dq.op |= int32_t(merge << 16);
-      if (!is_phrase) ((dq.op & 0xFF) == 2 ? b->conj_units : b->all_tile_units).push_back(q);
+      if (!is_phrase) ((dq.op & 0xFF) == 2 ? b->all_conj_units : b->all_tile_units).push_back(q);
+      // match counts in the low bits of a 32-bit accumulator (join.h COUNT) round every posting
+      // to 16 fixed-point units (+-8): relative to any doc's score that is at most
+      // 8 * upper / (2^29 * min_score) — allowed while it stays below 2e-6
+      b->count_precise[q] = row.size() <= kJoinCountTerms && min_score > 0.0 && upper > 0.0 &&
+                            upper / min_score <= 125.0;
       // table slots (kernels.h "table_kind"): one per distinct (kind, norm_const, norm_length)
       uint32_t n_caches = 0;
       float cnc[kMaxCaches], cnl[kMaxCaches];
@@ -1659,58 +1777,6 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
                  !rt::h2d(b->d_conj_item_base.p, item_base.data(), item_base.size() * 4, nullptr) ||
                  !rt::h2d(b->d_conj_unit_items.p, unit_items.data(), unit_items.size() * 4, nullptr) ||
                  !rt::h2d(b->d_lead_of.p, lead_of.data(), lead_of.size() * 4, nullptr) ||
-                 !rt::sync(nullptr))
-          rc = IRS_HIP_EHIP;
-      }
-    } catch (...) {
-      rc = IRS_HIP_ENOMEM;
-    }
-  }
-  if (rc == IRS_HIP_OK && !b->phrase && !b->conj_units.empty()) {
-    // k_conj work: the lead term of a unit is its first one (sorted by cost above); one
-    // wavefront per 128-posting block of it (+ one for its vint tail / single doc), its record
-    // and the other terms' start blocks written by k_conj_seek every run
-    try {
-      for (uint32_t u : b->conj_units) {
-        const DevQuery& dq = b->queries[u];
-        uint32_t items = 0;
-        if (dq.n_terms) {
-          const DevTerm& t = b->segs[dq.seg]->terms[b->qterms[dq.first_term].term];
-          items = t.nblk + ((t.docs_count == 1 || t.tail_n) ? 1u : 0u);
-        }
-        b->conj_items.push_back(items);
-      }
-      {
-        // rows of the seek table: the lead items of the conj units, unit after unit
-        std::vector<uint32_t> item_base(b->conj_units.size() + 1, 0), unit_items(nq, 0);
-        uint64_t total = 0;
-        for (size_t c = 0; c < b->conj_units.size(); ++c) {
-          item_base[c] = uint32_t(total);
-          unit_items[b->conj_units[c]] = uint32_t(total);
-          total += b->conj_items[c];
-        }
-        if (total > 0x7FFFFFFFull) rc = IRS_HIP_EUNSUPPORTED;
-        item_base[b->conj_units.size()] = uint32_t(total);
-        b->conj_total_items = uint32_t(total);
-        b->n_conj_wgs = uint32_t((total + kConjWaves - 1) / kConjWaves);
-        if (rc == IRS_HIP_OK &&
-            (!b->d_conj_item_base.alloc(item_base.size() * 4) ||
-             !b->d_conj_unit_items.alloc(unit_items.size() * 4) ||
-             !b->d_conj_seek.alloc((total + 2) * uint64_t(kMaxTerms) * 4) ||
-             !b->d_conj_recs.alloc((total + 1) * sizeof(ConjItem))))
-          rc = IRS_HIP_ENOMEM;
-        if (rc == IRS_HIP_OK &&
-            (!rt::h2d(b->d_conj_item_base.p, item_base.data(), item_base.size() * 4, nullptr) ||
-             !rt::h2d(b->d_conj_unit_items.p, unit_items.data(), unit_items.size() * 4, nullptr)))
-          rc = IRS_HIP_EHIP;
-        if (rc != IRS_HIP_OK) {
-        } else
-        if (!b->d_conj_units.alloc(b->conj_units.size() * 4) ||
-            !b->d_conj_items.alloc(b->conj_items.size() * 4) ||
-            !b->d_conj_hist.alloc(uint64_t(nq) * kBins * 4))
-          rc = IRS_HIP_ENOMEM;
-        else if (!rt::h2d(b->d_conj_units.p, b->conj_units.data(), b->conj_units.size() * 4, nullptr) ||
-                 !rt::h2d(b->d_conj_items.p, b->conj_items.data(), b->conj_items.size() * 4, nullptr) ||
                  !rt::sync(nullptr))
           rc = IRS_HIP_EHIP;
       }

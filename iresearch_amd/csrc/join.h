@@ -23,9 +23,12 @@
 // work-item path by at most one fixed-point unit per posting, where the two classify a
 // posting differently (table row vs. general expression).
 //
-// Eligibility (anything else runs on score.h's kernels): plain disjunctions (no per-doc match
-// counters), sum merge, scorers of the table family over 1-byte norms or none, 32-bit
-// accumulators, every term's frequencies below 64, no block-max pruning.
+// Eligibility (anything else runs on score.h's / conj.h's kernels): sum merge, scorers of the
+// table family over 1-byte norms or none, 32-bit accumulators, every term's frequencies below
+// 64, no block-max pruning.  Conjunctions and min-match disjunctions of at most 15 terms join
+// too where the rounding of their match-counting accumulators (join_post COUNT) stays below
+// the parity tolerance and — conjunctions — where walking every entry of every term beats
+// decoding only the blocks the rarest term's docs fall into (irs_hip.hip unit_joinable).
 #pragma once
 #include "score.h"
 
@@ -37,6 +40,11 @@ constexpr uint32_t kJoinBlocks = 16;      // blocks per k_join workgroup
 constexpr uint32_t kJoinChunkTiles = 32;  // consecutive tiles of one unit per work-queue item
 constexpr uint32_t kJoinCands = 256;      // candidate staging slots per chunk (x2 buffers)
 constexpr uint32_t kJoinSlack = 1024;     // readable entries behind the last stream
+// units that need per-doc match counts (conjunctions, min-match): the low 4 bits of an
+// accumulator count matches (so at most 15 terms), contributions are rounded to multiples of 16
+constexpr uint32_t kJoinCountMask = 15u;
+constexpr uint32_t kJoinCountTerms = 15u;
+constexpr float kJoinCountRound = 8.f;
 
 enum : uint32_t {
   kJoinGeneral = 1u << 30,   // JoinTerm::mode: some tf of the term has no table row
@@ -252,7 +260,12 @@ __device__ __forceinline__ uint32_t join_dummy(unsigned lane) {
 // the LDS adds.  FORM kJTable: every frequency of the term has a table row, score =
 // cs * T_tf[norm] — the entry's low 16 bits ARE the offset of T_tf[norm] inside the slot; else
 // row 0 and the general expression (score.h tile_post: v_rcp / v_sqrt form).
-template<int FORM, int N>
+//
+// COUNT (conjunctions, min-match): the low kJoinCountBits bits of an accumulator count the
+// terms that hold the doc — every contribution is rounded to a multiple of 16 units and carries
+// a 1 there (one v_and_or_b32 more per slab: no second LDS access, no counter array); the unit's
+// eligibility bounds the rounding error (irs_hip.hip unit_joinable).
+template<int FORM, int N, bool COUNT>
 __device__ __forceinline__ void join_post(const unsigned char* lds, const uint32_t (&e)[4],
                                           float cs, uint32_t tabofs) {
   float t[N];
@@ -267,38 +280,43 @@ __device__ __forceinline__ void join_post(const unsigned char* lds, const uint32
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     if (FORM == kJTable) {
-      fx[k] = static_cast<uint32_t>(wave::fma(cs, t[k], 1.f));
+      fx[k] = static_cast<uint32_t>(wave::fma(cs, t[k], COUNT ? kJoinCountRound : 1.f));
+      if (COUNT) fx[k] = (fx[k] & ~kJoinCountMask) | 1u;
     } else {
       const float tf = static_cast<float>((e[k] >> 10) & kJoinTfMax);
       float scaled = (FORM == kJSqrt) ? wave::fast_sqrt(tf) * cs * t[k]
                                       : wave::fma(-cs, wave::fast_rcp(wave::fma(tf, t[k], 1.f)), cs);
       wave::keep_f(scaled);
-      fx[k] = static_cast<uint32_t>(scaled) | 1u;
+      fx[k] = COUNT ? ((static_cast<uint32_t>(scaled + kJoinCountRound) & ~kJoinCountMask) | 1u)
+                    : (static_cast<uint32_t>(scaled) | 1u);
     }
   }
 #pragma unroll
   for (int k = 0; k < N; ++k) wave::lds_add(lds, JoinOff::acc + (e[k] >> 16), fx[k]);
 }
 // `slabs` (1..4, wave-uniform) of them
-template<int FORM>
+template<int FORM, bool COUNT>
 __device__ __forceinline__ void join_post_n(const unsigned char* lds, const uint32_t (&e)[4],
                                             uint32_t slabs, float cs, uint32_t tabofs) {
-  if (slabs >= 4u) join_post<FORM, 4>(lds, e, cs, tabofs);
-  else if (slabs == 3u) join_post<FORM, 3>(lds, e, cs, tabofs);
-  else if (slabs == 2u) join_post<FORM, 2>(lds, e, cs, tabofs);
-  else join_post<FORM, 1>(lds, e, cs, tabofs);
+  if (slabs >= 4u) join_post<FORM, 4, COUNT>(lds, e, cs, tabofs);
+  else if (slabs == 3u) join_post<FORM, 3, COUNT>(lds, e, cs, tabofs);
+  else if (slabs == 2u) join_post<FORM, 2, COUNT>(lds, e, cs, tabofs);
+  else join_post<FORM, 1, COUNT>(lds, e, cs, tabofs);
 }
-template<bool SIMPLE>
+// M: kJSimple | kJCount (template mode bits of the tile loop)
+enum : int { kJSimple = 1, kJCount = 2 };
+template<int M>
 __device__ __forceinline__ void join_post_any(const unsigned char* lds, const uint32_t (&e)[4],
                                               uint32_t slabs, float cs, uint32_t mode) {
-  if (SIMPLE) {
-    join_post_n<kJTable>(lds, e, slabs, cs, 0u);
+  constexpr bool COUNT = (M & kJCount) != 0;
+  if (M & kJSimple) {
+    join_post_n<kJTable, COUNT>(lds, e, slabs, cs, 0u);
   } else {
     const uint32_t tabofs = mode & kJoinTabMask;
     const int form = join_form(mode);   // (wave-uniform)
-    if (form == kJTable) join_post_n<kJTable>(lds, e, slabs, cs, tabofs);
-    else if (form == kJRcp) join_post_n<kJRcp>(lds, e, slabs, cs, tabofs);
-    else join_post_n<kJSqrt>(lds, e, slabs, cs, tabofs);
+    if (form == kJTable) join_post_n<kJTable, COUNT>(lds, e, slabs, cs, tabofs);
+    else if (form == kJRcp) join_post_n<kJRcp, COUNT>(lds, e, slabs, cs, tabofs);
+    else join_post_n<kJSqrt, COUNT>(lds, e, slabs, cs, tabofs);
   }
 }
 
@@ -320,7 +338,7 @@ __device__ __forceinline__ void join_load(uint64_t base, uint32_t count, unsigne
 }
 
 // `count` consecutive entries from address `base` (wave-uniform), 256 per step.
-template<int FORM>
+template<int FORM, bool COUNT>
 __device__ __forceinline__ void join_run(const unsigned char* lds, uint64_t base, uint32_t count,
                                          float cs, uint32_t tabofs, unsigned lane) {
   const uint32_t off = lane * 4u;
@@ -329,14 +347,14 @@ __device__ __forceinline__ void join_run(const unsigned char* lds, uint64_t base
 #pragma unroll
     for (int k = 0; k < 4; ++k) e[k] = wave::gload_u32(base, off + 256u * uint32_t(k));
     wave::keep_all(e);
-    join_post<FORM, 4>(lds, e, cs, tabofs);
+    join_post<FORM, 4, COUNT>(lds, e, cs, tabofs);
     base += 1024u;
     count -= 256u;
   }
   if (count) {
     uint32_t e[4];
     join_load(base, count, lane, e);
-    join_post_n<FORM>(lds, e, (count + 63u) >> 6, cs, tabofs);
+    join_post_n<FORM, COUNT>(lds, e, (count + 63u) >> 6, cs, tabofs);
   }
 }
 
@@ -366,7 +384,7 @@ struct JoinRun {
 // lanes past the end re-read the share's last entry): two runs are in flight at a time — the
 // next tile's and the one after — and only a FIXED number of younger loads lets the wait for
 // the older run's data leave the younger one's in flight (s_waitcnt vmcnt(4)).
-template<bool SIMPLE>
+template<int M>
 __device__ __forceinline__ void join_begin(JoinRun& r, const JoinLane& T, uint32_t a, uint32_t n,
                                            uint32_t c, uint32_t wv, uint32_t nw_log2,
                                            uint64_t safe, unsigned lane) {
@@ -392,7 +410,7 @@ __device__ __forceinline__ void join_begin(JoinRun& r, const JoinLane& T, uint32
     base = (uint64_t(wave::read_lane(r.a_hi, j)) << 32) | wave::read_lane(r.a_lo, j);
     const uint32_t cnt = wave::read_lane(r.cnt, j);
     r.cs = wave::read_lane_f(T.cs, j);
-    if (!SIMPLE) r.mode = wave::read_lane(T.mode, j);
+    if (!(M & kJSimple)) r.mode = wave::read_lane(T.mode, j);
     take = cnt < kJoinPre ? cnt : kJoinPre;
     r.left = cnt - take;
     r.rest = base + 4ull * take;
@@ -407,27 +425,29 @@ __device__ __forceinline__ void join_begin(JoinRun& r, const JoinLane& T, uint32
   }
 }
 
-template<bool SIMPLE>
+template<int M>
 __device__ __forceinline__ void join_some(const unsigned char* lds, uint64_t base, uint32_t cnt,
                                           float cs, uint32_t mode, unsigned lane) {
-  if (SIMPLE) {
-    join_run<kJTable>(lds, base, cnt, cs, 0u, lane);
+  constexpr bool COUNT = (M & kJCount) != 0;
+  if (M & kJSimple) {
+    join_run<kJTable, COUNT>(lds, base, cnt, cs, 0u, lane);
   } else {
     const uint32_t tabofs = mode & kJoinTabMask;
     const int form = join_form(mode);
-    if (form == kJTable) join_run<kJTable>(lds, base, cnt, cs, tabofs, lane);
-    else if (form == kJRcp) join_run<kJRcp>(lds, base, cnt, cs, tabofs, lane);
-    else join_run<kJSqrt>(lds, base, cnt, cs, tabofs, lane);
+    if (form == kJTable) join_run<kJTable, COUNT>(lds, base, cnt, cs, tabofs, lane);
+    else if (form == kJRcp) join_run<kJRcp, COUNT>(lds, base, cnt, cs, tabofs, lane);
+    else join_run<kJSqrt, COUNT>(lds, base, cnt, cs, tabofs, lane);
   }
 }
 
-template<bool SIMPLE>
+template<int M>
 __device__ __forceinline__ void join_finish(const unsigned char* lds, JoinRun& r, const JoinLane& T,
                                             unsigned lane) {
   // (the run's scalars crossed a barrier and a loop back edge inside a struct: the compiler no
   // longer knows they are wave-uniform and would predicate everything below lane by lane)
   const uint32_t pre = wave::uniform(r.pre);
   if (!pre) return;   // (nothing requested: nothing at all)
+  constexpr bool SIMPLE = (M & kJSimple) != 0;
   const uint32_t mode0 = SIMPLE ? 0u : wave::uniform(r.mode);
   const float cs0 = wave::uniform_f(r.cs);
   {
@@ -435,16 +455,16 @@ __device__ __forceinline__ void join_finish(const unsigned char* lds, JoinRun& r
     uint32_t e[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) e[k] = lane + 64u * uint32_t(k) < pre ? r.e[k] : dummy;
-    join_post_any<SIMPLE>(lds, e, (pre + 63u) >> 6, cs0, mode0);
+    join_post_any<M>(lds, e, (pre + 63u) >> 6, cs0, mode0);
   }
   const uint32_t left = wave::uniform(r.left);
-  if (left) join_some<SIMPLE>(lds, wave::uniform64(r.rest), left, cs0, mode0, lane);
+  if (left) join_some<M>(lds, wave::uniform64(r.rest), left, cs0, mode0, lane);
   uint64_t mask = wave::uniform64(r.mask);
   while (mask) {
     const uint32_t j = uint32_t(__builtin_ctzll(mask));
     mask &= mask - 1ull;
     const uint64_t base = (uint64_t(wave::read_lane(r.a_hi, j)) << 32) | wave::read_lane(r.a_lo, j);
-    join_some<SIMPLE>(lds, base, wave::read_lane(r.cnt, j), wave::read_lane_f(T.cs, j),
+    join_some<M>(lds, base, wave::read_lane(r.cnt, j), wave::read_lane_f(T.cs, j),
                       SIMPLE ? 0u : wave::read_lane(T.mode, j), lane);
   }
 }
@@ -539,6 +559,7 @@ k_join_pilot(const uint32_t* units, const DevQuery* queries, const DevQTerm* qte
   const uint32_t q = units[blockIdx.x];
   const DevQuery qd = queries[q];
   const uint32_t n_tiles = qd.n_tiles;
+  const uint32_t need_matches = query_need(qd.op);   // (> 1: conjunction / min-match)
   for (uint32_t i = tid; i < kBins; i += blockDim.x) hist[i] = 0u;
   for (uint32_t i = tid; i < kJoinTile; i += blockDim.x) acc[i] = 0u;
   if (tid == 0) sig[0] = 0xFFFFFFFFu;
@@ -555,16 +576,27 @@ k_join_pilot(const uint32_t* units, const DevQuery* queries, const DevQTerm* qte
       n = bnd[tile + 1u] - a;
     }
     JoinRun r;
-    join_begin<false>(r, T, a, n, wave::inclusive_scan(n), wv, nw_log2,
-                      reinterpret_cast<uint64_t>(jterms), lane);
-    join_finish<false>(smem, r, T, lane);
+    if (need_matches > 1u) {
+      join_begin<kJCount>(r, T, a, n, wave::inclusive_scan(n), wv, nw_log2,
+                          reinterpret_cast<uint64_t>(jterms), lane);
+      join_finish<kJCount>(smem, r, T, lane);
+    } else {
+      join_begin<0>(r, T, a, n, wave::inclusive_scan(n), wv, nw_log2,
+                    reinterpret_cast<uint64_t>(jterms), lane);
+      join_finish<0>(smem, r, T, lane);
+    }
     __syncthreads();
     for (uint32_t i = tid; i < kJoinTile; i += blockDim.x) {
       const uint32_t f = acc[i];
       if (f) {
         acc[i] = 0u;
-        const float v = f <= kMaxTerms ? 0.f : from_fixed<uint32_t>(f, qd.fx_inv);
-        atomicAdd(&hist[score_bin(v, qd.bin_scale)], 1u);
+        if (need_matches > 1u) {
+          if ((f & kJoinCountMask) >= need_matches)
+            atomicAdd(&hist[score_bin(from_fixed<uint32_t>(f & ~kJoinCountMask, qd.fx_inv), qd.bin_scale)], 1u);
+        } else {
+          const float v = f <= kMaxTerms ? 0.f : from_fixed<uint32_t>(f, qd.fx_inv);
+          atomicAdd(&hist[score_bin(v, qd.bin_scale)], 1u);
+        }
       }
     }
     __syncthreads();
@@ -602,12 +634,13 @@ k_join_pilot(const uint32_t* units, const DevQuery* queries, const DevQTerm* qte
 struct JoinTileCtx {
   const JoinArgs* args;
   uint32_t q, bs, thr, cap;
+  uint32_t need;       // matches a doc needs (units with match counts)
   float fx_inv, bin_scale;
   uint64_t* lc;        // this chunk's candidate staging buffer
   uint32_t* ncand;     // ... and its fill count
 };
 
-template<bool SIMPLE>
+template<int M>
 __device__ __forceinline__ void join_tiles(unsigned char* smem, const JoinTileCtx& ctx,
                                            const JoinLane& T, uint32_t tile0, uint32_t ntile,
                                            uint32_t wv, uint32_t nw_log2, uint32_t& my_hits) {
@@ -616,6 +649,7 @@ __device__ __forceinline__ void join_tiles(unsigned char* smem, const JoinTileCt
   const uint32_t tid = threadIdx.x;
   const unsigned lane = tid & 63u;
   const uint64_t safe = reinterpret_cast<uint64_t>(ctx.args->jterms);
+  constexpr bool COUNT = (M & kJCount) != 0;
   auto begin = [&](uint32_t u, JoinRun& r) {   // (u >= ntile: an empty share, four loads all the same)
     uint32_t a = 0, n = 0, c = 0;
     if (lane < kMaxTerms && u < ntile) {
@@ -623,7 +657,7 @@ __device__ __forceinline__ void join_tiles(unsigned char* smem, const JoinTileCt
       n = rng[(u + 1u) * kMaxTerms + lane] - a;
       c = cum[u * kMaxTerms + lane];
     }
-    join_begin<SIMPLE>(r, T, a, n, c, wv, nw_log2, safe, lane);
+    join_begin<M>(r, T, a, n, c, wv, nw_log2, safe, lane);
   };
   // two runs in flight: while tile u is being accumulated, the entries of tiles u+1 AND u+2
   // are on their way (a request then has a whole tile's time to come back from HBM, not just
@@ -636,7 +670,8 @@ __device__ __forceinline__ void join_tiles(unsigned char* smem, const JoinTileCt
     __syncthreads();   // B1: every accumulation of tile u has landed
     const uint32_t doc0 = kDocMin + (tile0 + u) * kJoinTile;
     auto candidate = [&](uint32_t i, uint32_t f) {   // rare
-      const float v = f <= kMaxTerms ? 0.f : from_fixed<uint32_t>(f, ctx.fx_inv);
+      const float v = COUNT ? from_fixed<uint32_t>(f & ~kJoinCountMask, ctx.fx_inv)
+                            : (f <= kMaxTerms ? 0.f : from_fixed<uint32_t>(f, ctx.fx_inv));
       if (score_bin(v, ctx.bin_scale) >= ctx.bs) {
         const uint64_t key = make_key(v, doc0 + i);
         const uint32_t slot = atomicAdd(ctx.ncand, 1u);
@@ -650,8 +685,18 @@ __device__ __forceinline__ void join_tiles(unsigned char* smem, const JoinTileCt
     };
     // four accumulators per lane read AND cleared by one LDS exchange; two in flight where the
     // geometry allows
-    auto four = [&](uint32_t i, const uint32_t (&v)[4]) {
-      wave::count_nonzero4(my_hits, v[0], v[1], v[2], v[3]);
+    auto four = [&](uint32_t i, const uint32_t (&w)[4]) {
+      uint32_t v[4] = {w[0], w[1], w[2], w[3]};
+      if (COUNT) {   // only docs held by enough terms exist
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const bool m = (v[k] & kJoinCountMask) >= ctx.need;
+          my_hits += m ? 1u : 0u;
+          v[k] = m ? v[k] : 0u;
+        }
+      } else {
+        wave::count_nonzero4(my_hits, v[0], v[1], v[2], v[3]);
+      }
       uint32_t top = v[0] > v[1] ? v[0] : v[1];
       const uint32_t top2 = v[2] > v[3] ? v[2] : v[3];
       top = top > top2 ? top : top2;
@@ -685,10 +730,10 @@ __device__ __forceinline__ void join_tiles(unsigned char* smem, const JoinTileCt
   // distance between a run's loads and its use when no branch separates the two register
   // sets); an odd tile count ends with an empty share, whose begin / finish do nothing
   for (uint32_t u = 0; u < ntile; u += 2u) {
-    join_finish<SIMPLE>(smem, r0, T, lane);
+    join_finish<M>(smem, r0, T, lane);
     begin(u + 2u, r0);
     end_tile(u);
-    join_finish<SIMPLE>(smem, r1, T, lane);
+    join_finish<M>(smem, r1, T, lane);
     begin(u + 3u, r1);
     if (u + 1u < ntile) end_tile(u + 1u);
   }
@@ -789,8 +834,14 @@ k_join_score(const JoinArgs* __restrict__ args) {
       ctx.cap = cap;
       ctx.lc = lc;
       ctx.ncand = ncand;
-      if (simple) join_tiles<true>(smem, ctx, T, tile0, ntile, wv, nw_log2, my_hits);
-      else join_tiles<false>(smem, ctx, T, tile0, ntile, wv, nw_log2, my_hits);
+      ctx.need = query_need(qd.op);
+      if (ctx.need > 1u) {   // conjunction / min-match: accumulators carry match counts
+        if (simple) join_tiles<kJSimple | kJCount>(smem, ctx, T, tile0, ntile, wv, nw_log2, my_hits);
+        else join_tiles<kJCount>(smem, ctx, T, tile0, ntile, wv, nw_log2, my_hits);
+      } else {
+        if (simple) join_tiles<kJSimple>(smem, ctx, T, tile0, ntile, wv, nw_log2, my_hits);
+        else join_tiles<0>(smem, ctx, T, tile0, ntile, wv, nw_log2, my_hits);
+      }
     }
     // ---- chunk hand-over: flush the PREVIOUS chunk's staged candidates (their reservation
     // has had a whole chunk to come back), reserve slots for this chunk's, publish hits

@@ -5,6 +5,7 @@
 // Rank 0 makes the communicator id and leaves it in the id file (what MPI_Bcast would carry);
 // every rank checks the sharded result against the single-process search() over all segments.
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -135,7 +136,11 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < want[q].size(); ++i) {
       REQUIRE(sharded[q][i].score == want[q][i].score && sharded[q][i].doc == want[q][i].doc &&
               sharded[q][i].segment == want[q][i].segment);
-      REQUIRE(sharded_wand[q][i].score == want[q][i].score && sharded_wand[q][i].doc == want[q][i].doc &&
+      // (block-max pruning runs on the work-item / block-driven kernels; without it the And and
+      // the min-match query take the joined streams, whose match counts round each posting's
+      // fixed-point contribution: same docs, scores within the parity tolerance)
+      REQUIRE(std::fabs(sharded_wand[q][i].score - want[q][i].score) <= 1e-5f * want[q][i].score &&
+              sharded_wand[q][i].doc == want[q][i].doc &&
               sharded_wand[q][i].segment == want[q][i].segment);
     }
   }

@@ -112,6 +112,10 @@ def test_paths_agree(simlib, layout):
     cases.case_paths_agree(simlib, layout=layout)
 
 
+def test_join_counts(simlib):
+    cases.case_join_counts(simlib)
+
+
 def test_multi_segment(simlib):
     cases.case_multi_segment(simlib, 45_000, 256)
 

@@ -185,6 +185,10 @@ def test_paths_agree(gpulib, layout):
     cases.case_paths_agree(gpulib, layout=layout)
 
 
+def test_join_counts(gpulib):
+    cases.case_join_counts(gpulib, num_docs=900_000, max_rank=1024)
+
+
 def test_multi_segment(gpulib):
     cases.case_multi_segment(gpulib, 600_000, 1024, n_segs=4, k=1000)
 

@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--lib", default=None, help="alternative build of libirs_hip.so (A/B runs)")
     ap.add_argument("--wand", action="store_true", help="also time the batch with block-max pruning")
     ap.add_argument("--clustered", action="store_true", help="bursty posting lists (topic docs)")
+    ap.add_argument("--path", default="auto", choices=["auto", "items", "joined"],
+                    help="irs_hip_batch_set_path: work items / block-driven kernels, or joined streams "
+                         "wherever a unit can take them")
     ap.add_argument("--touched", action="store_true",
                     help="And / by_phrase: one more run that counts the bytes actually decoded")
     args = ap.parse_args()
@@ -68,9 +71,11 @@ def main():
     ref = None
     for cfg in args.configs.split(","):
         tile, stride = (int(x) for x in cfg.split(":"))
-        b = sr.batch(prep, args.k).configure(tile, stride, 0).profile(True)
+        path = {"auto": _lib.PATH_AUTO, "items": _lib.PATH_ITEMS, "joined": _lib.PATH_JOINED}[args.path]
+        b = sr.batch(prep, args.k).configure(tile, stride, 0).set_path(path).profile(True)
         b.run()
         hits, counts, totals = b.results()
+        print("   path: %s" % ("joined" if b.path() == _lib.PATH_JOINED else "items"), flush=True)
         if ref is None:
             ref = hits.copy()
         same = bool(np.array_equal(ref, hits))
