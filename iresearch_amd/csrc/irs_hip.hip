@@ -175,7 +175,8 @@ struct irs_hip_batch {
   uint32_t n_streams = 0, n_join_wgs = 0;
   uint32_t join_threads = 1024, join_nw_log2 = 4;   // threads per k_join_pilot / k_join_score workgroup
   uint64_t join_entries = 0;
-  JoinArgs join_args{};
+  JoinArgs join_args[2]{};   // plain disjunctions / units with match counts
+  uint32_t n_join_plain = 0; // join_units in d_join_order: the plain ones first
   bool profile = false;
   bool count_touched = false;   // irs_hip_batch_profile bit 1: the kernels count what they decode
   bool events_ready = false;
@@ -653,15 +654,14 @@ bool join_counts_allowed() {   // tuning / test knob
   const char* e = std::getenv("IRS_HIP_JOIN_COUNTS");
   return !e || std::atoi(e) != 0;
 }
-// Conjunction as joined streams (every entry of every term walked, ~1 unit of time each) or
-// block driven (per lead block: its decode + a seek and a block decode in every other term,
-// ~kJoinAndBlockCost units each)?
-constexpr uint64_t kJoinAndBlockCost = 700;
-bool join_and_pays(const irs_hip_batch* b, const DevQuery& dq) {
-  if (b->path_pref == IRS_HIP_PATH_JOINED) return true;   // (forced: wherever it is possible)
-  if (const char* e = std::getenv("IRS_HIP_JOIN_AND")) {   // tuning / test knob: 0 never, 1 always
-    return std::atoi(e) != 0;
-  }
+// Conjunction as joined streams or block driven?  Measured on 10 M docs (tools/sweep.py --op and,
+// GPU time summed over the chip, picoseconds): joined = 4200 per doc tile of the unit (barriers,
+// epilogue: the part that does not depend on the postings) + 1.5 per posting of its terms
+// (k_join_score 0.3 + a share of k_join's decode); block driven = 2300 + 400 x terms per
+// 128-posting block of the rarest term: its decode plus a seek and a block decode in every other
+// term.  The conjunctions of two frequent terms are the ones that join.
+// Returns the picoseconds saved by joining (<= 0: block driven is cheaper).
+int64_t join_and_saving(const irs_hip_batch* b, const DevQuery& dq) {
   const irs_hip_segment* sg = b->segs[dq.seg];
   uint64_t sum = 0, lead = ~0ull;
   for (uint32_t j = 0; j < dq.n_terms; ++j) {
@@ -669,9 +669,18 @@ bool join_and_pays(const irs_hip_batch* b, const DevQuery& dq) {
     sum += df;
     lead = std::min(lead, df);
   }
+  const uint64_t tiles = sg->dev.num_docs / kJoinTile + 1;
   const uint64_t lead_blocks = lead / kBlock + 1;
-  return sum + uint64_t(sg->dev.num_docs / kJoinTile + 1) * 2000ull <=
-         lead_blocks * dq.n_terms * kJoinAndBlockCost;
+  return int64_t(lead_blocks * (2300ull + 400ull * dq.n_terms)) -
+         int64_t(4200ull * tiles + (3ull * sum) / 2);
+}
+// ... and the launches of the joined kernels themselves (k_join, the pilot, one more score
+// kernel) only pay when the conjunctions that would join save more than that together
+constexpr int64_t kJoinAndLaunchCost = 500000000;   // 0.5 ms
+int join_and_forced(const irs_hip_batch* b) {   // -1: decide by cost
+  if (b->path_pref == IRS_HIP_PATH_JOINED) return 1;   // (forced: wherever it is possible)
+  if (const char* e = std::getenv("IRS_HIP_JOIN_AND")) return std::atoi(e) != 0;   // tuning / test knob
+  return -1;
 }
 bool unit_counts_matches(const DevQuery& dq) {   // min-match / the kMin disjunction of two
   return (dq.op & 0xFF) == 1 || query_min_both(dq.op);
@@ -683,9 +692,6 @@ bool unit_joinable(const irs_hip_batch* b, uint32_t u) {
     // min-match / conjunction: the match count rides in the accumulator's low bits (join.h
     // COUNT) where that costs no precision that matters
     if (!dq.n_terms || !b->count_precise[u] || !join_counts_allowed()) return false;
-    // a conjunction whose rarest term is far rarer than the rest is cheaper block driven
-    // (conj.h decodes only the blocks the lead term's docs fall into)
-    if ((dq.op & 0xFF) == 2 && !join_and_pays(b, dq)) return false;
   }
   const irs_hip_segment* sg = b->segs[dq.seg];
   for (uint32_t j = 0; j < dq.n_terms; ++j) {
@@ -754,7 +760,7 @@ bool build_streams(irs_hip_batch* b) {
       !b->d_streams.alloc(std::max<size_t>(1, streams.size()) * sizeof(StreamRec)) ||
       !b->d_join_wgs.alloc(std::max<size_t>(1, wgs.size()) * sizeof(JoinWg)) ||
       !b->d_jterms.alloc(jterms.size() * sizeof(JoinTerm)) ||
-      !b->d_join_args.alloc(sizeof(JoinArgs)) ||
+      !b->d_join_args.alloc(2 * sizeof(JoinArgs)) ||
       !b->d_join_units.alloc(b->join_units.size() * 4) ||
       !b->d_join_order.alloc(b->join_units.size() * 4))
     return false;
@@ -774,7 +780,15 @@ bool build_streams(irs_hip_batch* b) {
       const uint32_t sx = b->queries[x.second].seg, sy = b->queries[y.second].seg;
       return sx != sy ? sx < sy : x.first > y.first;
     });
-    for (const auto& w : work) order.push_back(w.second);
+    // the plain disjunctions first, then the units with match counts (a launch each)
+    std::stable_partition(work.begin(), work.end(), [&](const auto& x) {
+      return query_need(b->queries[x.second].op) <= 1u;
+    });
+    b->n_join_plain = 0;
+    for (const auto& w : work) {
+      order.push_back(w.second);
+      if (query_need(b->queries[w.second].op) <= 1u) ++b->n_join_plain;
+    }
   }
   for (size_t i = 0; i < streams.size(); ++i) {
     streams[i].entries = reinterpret_cast<uint64_t>(b->d_entries.as<uint32_t>() + ent_off[i]);
@@ -836,7 +850,7 @@ bool launch_join_pilot(irs_hip_batch* b, rt::stream_t st) {
 
 bool launch_join_score(irs_hip_batch* b, rt::stream_t st) {
   const size_t smem = JoinOff::end;
-  if (!big_smem(k_join_score, smem)) return false;
+  if (!big_smem(k_join_score<false>, smem) || !big_smem(k_join_score<true>, smem)) return false;
   const uint32_t waves = b->join_threads / 64;
   uint32_t per_cu = uint32_t((160u * 1024u) / smem);
   per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 32u / waves));
@@ -844,29 +858,39 @@ bool launch_join_score(irs_hip_batch* b, rt::stream_t st) {
   // 3 x 32 + 6 — a short last chunk pays the whole per-chunk prologue for a few tiles)
   const uint32_t cpq = std::max<uint32_t>(1, (b->join_max_tiles + kJoinChunkTiles - 1) / kJoinChunkTiles);
   const uint32_t chunk_tiles = std::max<uint32_t>(1, (b->join_max_tiles + cpq - 1) / cpq);
-  const uint32_t n_units = uint32_t(b->join_units.size());
-  const uint64_t chunks = uint64_t(n_units) * cpq;
-  if (chunks > 0xFFFF0000ull) return false;
-  const uint32_t grid = uint32_t(std::min<uint64_t>(chunks, uint64_t(b->seg->cus) * per_cu));
-  JoinArgs& a = b->join_args;   // read by the kernel from device memory
-  a.queries = b->d_queries.as<DevQuery>();
-  a.qterms = b->d_qterms.as<DevQTerm>();
-  a.jterms = b->d_jterms.as<JoinTerm>();
-  a.bstar = b->d_bstar.as<uint32_t>();
-  a.cands = b->d_cands.as<uint64_t>();
-  a.cand_count = b->d_cand_count.as<uint32_t>();
-  a.hits = b->d_hits.as<unsigned long long>();
-  a.order = b->d_join_order.as<uint32_t>();
-  a.work_counter = b->d_work.as<uint32_t>() + 1;   // ([0] is k_score's)
-  a.cpq = cpq;
-  a.n_units = n_units;
-  a.nw_log2 = b->join_nw_log2;
-  a.cand_cap = b->cand_cap;
-  a.chunk_tiles = chunk_tiles;
-  if (!rt::dmemset(b->d_work.as<uint32_t>() + 1, 0, 4, st) ||
-      !rt::h2d(b->d_join_args.p, &a, sizeof a, st))
-    return false;
-  RT_LAUNCH(k_join_score, grid, b->join_threads, smem, st, b->d_join_args.as<JoinArgs>());
+  const uint32_t n_all = uint32_t(b->join_units.size());
+  if (!rt::dmemset(b->d_work.as<uint32_t>() + 1, 0, 8, st)) return false;
+  // two launches: the plain disjunctions, then the units whose accumulators count matches
+  for (uint32_t part = 0; part < 2; ++part) {
+    const uint32_t first = part ? b->n_join_plain : 0u;
+    const uint32_t n_units = part ? n_all - b->n_join_plain : b->n_join_plain;
+    if (!n_units) continue;
+    const uint64_t chunks = uint64_t(n_units) * cpq;
+    if (chunks > 0xFFFF0000ull) return false;
+    const uint32_t grid = uint32_t(std::min<uint64_t>(chunks, uint64_t(b->seg->cus) * per_cu));
+    JoinArgs& a = b->join_args[part];   // read by the kernel from device memory
+    a.queries = b->d_queries.as<DevQuery>();
+    a.qterms = b->d_qterms.as<DevQTerm>();
+    a.jterms = b->d_jterms.as<JoinTerm>();
+    a.bstar = b->d_bstar.as<uint32_t>();
+    a.cands = b->d_cands.as<uint64_t>();
+    a.cand_count = b->d_cand_count.as<uint32_t>();
+    a.hits = b->d_hits.as<unsigned long long>();
+    a.order = b->d_join_order.as<uint32_t>() + first;
+    a.work_counter = b->d_work.as<uint32_t>() + 1 + part;   // ([0] is k_score's)
+    a.cpq = cpq;
+    a.n_units = n_units;
+    a.nw_log2 = b->join_nw_log2;
+    a.cand_cap = b->cand_cap;
+    a.chunk_tiles = chunk_tiles;
+    JoinArgs* d_args = b->d_join_args.as<JoinArgs>() + part;
+    if (!rt::h2d(d_args, &a, sizeof a, st)) return false;
+    if (part) {
+      RT_LAUNCH(k_join_score<true>, grid, b->join_threads, smem, st, d_args);
+    } else {
+      RT_LAUNCH(k_join_score<false>, grid, b->join_threads, smem, st, d_args);
+    }
+  }
   return rt::last_error_ok();
 }
 
@@ -948,10 +972,29 @@ bool ensure_scratch(irs_hip_batch* b) {
       }
     }
     if (!b->phrase) {   // (a phrase batch's conj_units are its phrases, fixed at create)
+      // a conjunction whose rarest term is far rarer than the rest is cheaper block driven
+      // (conj.h decodes only the blocks the lead term's docs fall into): join_and_saving
       b->conj_units.clear();
+      const int forced = join_and_forced(b);
+      std::vector<uint32_t> joining;
+      int64_t saved = 0;
       for (uint32_t u : b->all_conj_units) {
-        if (allow && unit_joinable(b, u)) b->join_units.push_back(u);
-        else b->conj_units.push_back(u);
+        const int64_t s = (allow && forced != 0 && unit_joinable(b, u))
+                              ? (forced == 1 ? 1 : join_and_saving(b, b->queries[u])) : 0;
+        if (s > 0) {
+          joining.push_back(u);
+          saved += s;
+        }
+      }
+      if (forced != 1 && saved < kJoinAndLaunchCost) joining.clear();
+      size_t at = 0;
+      for (uint32_t u : b->all_conj_units) {
+        if (at < joining.size() && joining[at] == u) {
+          b->join_units.push_back(u);
+          ++at;
+        } else {
+          b->conj_units.push_back(u);
+        }
       }
       if (build_conj_work(b) != IRS_HIP_OK) return false;
     }
@@ -1051,7 +1094,7 @@ bool ensure_scratch(irs_hip_batch* b) {
       !b->d_hits.alloc(b->nq * sizeof(uint64_t)) ||
       !b->d_out.alloc(uint64_t(b->nq) * b->k_max * sizeof(Hit)) ||
       !b->d_out_count.alloc(b->nq * sizeof(uint32_t)) || !b->d_status.alloc(4) ||
-      !b->d_work.alloc(8) || !b->d_touched.alloc(uint64_t(b->nq) * 16) ||
+      !b->d_work.alloc(16) || !b->d_touched.alloc(uint64_t(b->nq) * 16) ||
       !b->d_pruned.alloc(uint64_t(b->nq) * 4))
     return false;
   if (b->joined && !build_streams(b)) return false;

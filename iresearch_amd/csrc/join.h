@@ -757,6 +757,9 @@ enum : uint32_t {   // LDS scratch words
   kJPendN = 6,
 };
 
+// COUNT: the launch's units are conjunctions / min-match disjunctions (accumulators with match
+// counts); a kernel of its own, so that the plain disjunctions' code stays as small as it is.
+template<bool COUNT>
 __global__ void __launch_bounds__(kTileThreadsMax) IRS_WAVES_PER_SIMD(8)
 k_join_score(const JoinArgs* __restrict__ args) {
   RT_DYN_SMEM(smem);
@@ -835,7 +838,7 @@ k_join_score(const JoinArgs* __restrict__ args) {
       ctx.lc = lc;
       ctx.ncand = ncand;
       ctx.need = query_need(qd.op);
-      if (ctx.need > 1u) {   // conjunction / min-match: accumulators carry match counts
+      if (COUNT) {   // conjunction / min-match: accumulators carry match counts
         if (simple) join_tiles<kJSimple | kJCount>(smem, ctx, T, tile0, ntile, wv, nw_log2, my_hits);
         else join_tiles<kJCount>(smem, ctx, T, tile0, ntile, wv, nw_log2, my_hits);
       } else {

@@ -560,15 +560,15 @@ def case_paths_agree(L, num_docs=70_000, max_rank=256, layout=synth.LAYOUT_SIMD4
             hi, ci, ti = got[_lib.PATH_ITEMS]
             hj, cj, tj = got[_lib.PATH_JOINED]
             assert np.array_equal(ci, cj) and np.array_equal(ti, tj)
-            assert np.array_equal(got[_lib.PATH_AUTO][0], hj)
             # bit for bit: a posting contributes the same fixed-point value on either path —
             # except where the joined path keeps match counts in its accumulators' low bits
-            # (And / min-match: contributions rounded to 16 fixed-point units; both runs were
-            # checked against the oracle above)
+            # (And / min-match: contributions rounded to 16 fixed-point units; which of them join
+            # without being forced is a cost decision; every run was checked against the oracle)
             for qi, f in enumerate(filters):
                 counting = isinstance(f, And) or (isinstance(f, Or) and getattr(f, "min_match", 1) > 1)
                 if not counting:
                     assert np.array_equal(hi[qi], hj[qi]), qi
+                    assert np.array_equal(got[_lib.PATH_AUTO][0][qi], hj[qi]), qi
     sr.close()
 
 

@@ -39,7 +39,7 @@ def main():
     json.dump(summary, open(os.path.join(out, "%s_pmc.json" % tag), "w"), indent=1, sort_keys=True)
     # the kernels the roofline prices (bench.py): the work-item path's k_score, or the joined
     # path's two stages k_join + k_join_score (the pilot kernels are apart)
-    staged = [k for k in summary if (k.startswith("k_join<") or k == "k_join_score")
+    staged = [k for k in summary if (k.startswith("k_join<") or k.startswith("k_join_score"))
               and "FETCH_SIZE_per_launch" in summary[k]]
     scored = [k for k in summary if k.startswith("k_score") and "FETCH_SIZE_per_launch" in summary[k]]
     for group in ([staged] if len(staged) == 2 else [[k] for k in scored]):
