@@ -172,6 +172,8 @@ def main():
                          "second stream (irs_hip_batch_plan). Measured SLOWER: the planner streams "
                          "2.4 GB through L2 while k_score lives on cross-query L2 reuse "
                          "(20.4 vs 13.1 ms per step)")
+    ap.add_argument("--no-shared-threshold", action="store_true",
+                    help="A/B: every (segment, query) unit of a rank's batch keeps its own threshold")
     ap.add_argument("--per-segment-batches", action="store_true",
                     help="one batch per local segment instead of one batch over all of them (A/B)")
     ap.add_argument("--force-segments", action="store_true",
@@ -270,6 +272,10 @@ def main():
                 if len(members) > 1 else readers[lead].batch(prepared, args.k)
             if args.tile or args.stride:
                 b.configure(args.tile, args.stride, 0)
+            if len(members) > 1 and not args.no_shared_threshold:
+                # the per-segment lists are merged (all-gather + k_merge_topk): the segments of
+                # a rank look for a query's k best docs TOGETHER (irs_hip_batch_set_shared_threshold)
+                b.set_shared_threshold(True)
             b.profile(True)
             batches[lead] = b
         batch_sets.append(batches)

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define IRS_HIP_ABI_VERSION 5
+#define IRS_HIP_ABI_VERSION 6
 #define IRS_HIP_BLOCK_SIZE 128u  /* postings per block, formats_10.cpp:90 */
 #define IRS_HIP_MAX_TERMS 16u    /* terms per boolean query               */
 #define IRS_HIP_MAX_K 4096u      /* largest top-k                         */
@@ -318,6 +318,19 @@ enum { IRS_HIP_PATH_AUTO = 0, IRS_HIP_PATH_ITEMS = 1, IRS_HIP_PATH_JOINED = 2 };
 int irs_hip_batch_set_path(irs_hip_batch* batch, int path);
 /* Which one the batch's last run used (IRS_HIP_PATH_ITEMS / IRS_HIP_PATH_JOINED). */
 int irs_hip_batch_path(irs_hip_batch* batch, int* path);
+
+/* A batch over several segments (irs_hip_batch_create_multi) whose per-segment lists the caller
+ * MERGES into one top k per query — what the harness does with its segments
+ * (index-search.cpp:719-787) and what irs_hip_merge_topk does here: with `enable` the units of a
+ * query share ONE score threshold, chosen so that the segments TOGETHER yield the k best docs
+ * (plus the usual margin) instead of every segment its own k.  A segment's list then holds every
+ * doc of it at or above the shared threshold — possibly fewer than k although more matched — and
+ * the merged top k is exactly what it is without the option; total_hits are unchanged.  The
+ * candidate volume, which is what small segments spend their time on, drops by the number of
+ * segments.  Applies to units on joined posting streams whose scorers bound the score alike in
+ * every segment (BM25 family); other units keep their own thresholds.  Off by default; call
+ * before the batch's first run (or after a configure). */
+int irs_hip_batch_set_shared_threshold(irs_hip_batch* batch, int enable);
 
 /* ExecutionContext::wand (filter.hpp:52-78; utils/index-search --search-mode wand): lets the
  * batch SKIP posting blocks that cannot reach the top k.  The bound of a block is the query

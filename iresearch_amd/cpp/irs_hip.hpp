@@ -344,6 +344,15 @@ class QueryBatch {
       if (part.h) check(irs_hip_batch_set_wand(part.h, enable ? 1 : 0), "irs_hip_batch_set_wand");
     return *this;
   }
+  // the per-segment lists will be MERGED (search(), search_sharded()): one threshold per query
+  // for all of its segments here (irs_hip_batch_set_shared_threshold); before run()
+  QueryBatch& set_shared_threshold(bool enable) {
+    for (Part& part : part_)
+      if (part.h)
+        check(irs_hip_batch_set_shared_threshold(part.h, enable ? 1 : 0),
+              "irs_hip_batch_set_shared_threshold");
+    return *this;
+  }
   // irs::score::Min per query: the k-th best score the caller's heap holds so far (empty: none)
   QueryBatch& set_min_scores(const std::vector<float>& min_scores) {
     for (Part& part : part_) {
@@ -454,6 +463,7 @@ std::vector<std::vector<ScoredDoc>> search(const std::vector<const SegmentReader
                                            const std::vector<filter>& filters,
                                            const Scorer& scorer, uint32_t k) {
   QueryBatch batch(segments, prepare(filters, scorer, index), k);
+  batch.set_shared_threshold(true);   // (merged right here: one threshold per query)
   return merge(batch.run().results());
 }
 
@@ -990,6 +1000,7 @@ std::vector<std::vector<ScoredDoc>> search_sharded(Communicator& comm,
     if (!mine.empty()) {   // (a rank without segments has no batch to build)
       QueryBatch batch(mine, prepare(filters, scorer, index), k);
       if (wand) batch.set_wand(true);
+      batch.set_shared_threshold(true);   // (the lists are merged below: one threshold per query)
       batch.run();
       check(irs_hip_batch_results_to_device(batch.single_part(), send.at(0), send.at(hit_bytes), nullptr),
             "irs_hip_batch_results_to_device");

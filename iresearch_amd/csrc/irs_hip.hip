@@ -175,6 +175,12 @@ struct irs_hip_batch {
   uint32_t n_streams = 0, n_join_wgs = 0;
   uint32_t join_threads = 1024, join_nw_log2 = 4;   // threads per k_join_pilot / k_join_score workgroup
   uint64_t join_entries = 0;
+  // one threshold per query for its units on the batch's segments (irs_hip_batch_set_shared_threshold)
+  bool shared_threshold = false;
+  uint32_t n_groups = 0;       // groups in force this run (0: none)
+  DevBuf d_group_of;           // [unit] group + 1, 0: a threshold of its own
+  DevBuf d_group_members;      // [nq_user][n_segs] unit or 0xFFFFFFFF
+  DevBuf d_group_hist;         // [nq_user][kBins + 2]
   JoinArgs join_args[2]{};   // plain disjunctions / units with match counts
   uint32_t n_join_plain = 0; // join_units in d_join_order: the plain ones first
   bool profile = false;
@@ -837,14 +843,69 @@ bool launch_join(irs_hip_batch* b, rt::stream_t st) {
   return rt::last_error_ok();
 }
 
+// Groups of a batch over several segments (irs_hip_batch_set_shared_threshold): the units of one
+// query — where every one of them runs on joined streams and they bin scores alike (the bins
+// span [0, upper bound of the query's score]: equal for scorers whose bound does not depend on the
+// segment's frequencies).  Anything else keeps a threshold per unit.
+bool build_groups(irs_hip_batch* b) {
+  b->n_groups = 0;
+  const uint32_t n_segs = uint32_t(b->segs.size());
+  if (!b->shared_threshold || n_segs < 2 || n_segs > 64 || b->join_units.empty()) return true;
+  const uint32_t nq_user = b->nq_user;
+  std::vector<uint8_t> is_join(b->nq, 0);
+  for (uint32_t u : b->join_units) is_join[u] = 1;
+  std::vector<uint32_t> group_of(b->nq, 0), members(size_t(nq_user) * n_segs, 0xFFFFFFFFu);
+  uint32_t grouped = 0;
+  for (uint32_t g = 0; g < nq_user; ++g) {
+    bool ok = true;
+    uint32_t live = 0;
+    for (uint32_t sgi = 0; sgi < n_segs && ok; ++sgi) {
+      const uint32_t u = sgi * nq_user + g;
+      const DevQuery& dq = b->queries[u];
+      if (!dq.n_terms) continue;   // (nothing of the query in this segment)
+      ok = is_join[u] != 0;
+      for (uint32_t s2 = 0; s2 < sgi && ok; ++s2) {
+        const DevQuery& other = b->queries[s2 * nq_user + g];
+        if (other.n_terms) ok = other.bin_scale == dq.bin_scale && other.k == dq.k;
+      }
+      ++live;
+    }
+    if (!ok || live < 2) continue;
+    for (uint32_t sgi = 0; sgi < n_segs; ++sgi) {
+      const uint32_t u = sgi * nq_user + g;
+      if (!b->queries[u].n_terms) continue;
+      group_of[u] = g + 1;
+      members[size_t(g) * n_segs + sgi] = u;
+    }
+    ++grouped;
+  }
+  if (!grouped) return true;
+  if (!b->d_group_of.alloc(group_of.size() * 4) || !b->d_group_members.alloc(members.size() * 4) ||
+      !b->d_group_hist.alloc(uint64_t(nq_user) * (kBins + 2) * 4) ||
+      !rt::h2d(b->d_group_of.p, group_of.data(), group_of.size() * 4, nullptr) ||
+      !rt::h2d(b->d_group_members.p, members.data(), members.size() * 4, nullptr) ||
+      !rt::sync(nullptr))
+    return false;
+  b->n_groups = nq_user;
+  return true;
+}
+
 bool launch_join_pilot(irs_hip_batch* b, rt::stream_t st) {
   const size_t smem = JoinOff::end + kBins * sizeof(uint32_t);
   if (!big_smem(k_join_pilot, smem)) return false;
+  if (b->n_groups && !rt::dmemset(b->d_group_hist.p, 0, b->d_group_hist.n, st)) return false;
   RT_LAUNCH(k_join_pilot, uint32_t(b->join_units.size()), b->join_threads, smem, st,
             b->d_join_units.as<uint32_t>(), b->d_queries.as<DevQuery>(),
             b->d_qterms.as<DevQTerm>(), b->d_jterms.as<JoinTerm>(), b->stride_eff,
             b->join_nw_log2, b->d_bstar.as<uint32_t>(), b->estimate ? kPilotMargin : 0u,
-            min_bins(b));
+            min_bins(b), b->n_groups ? b->d_group_of.as<uint32_t>() : nullptr,
+            b->d_group_hist.as<uint32_t>());
+  if (b->n_groups) {
+    RT_LAUNCH(k_group_threshold, b->n_groups, 64, 0, st, b->d_queries.as<DevQuery>(),
+              b->d_group_members.as<uint32_t>(), uint32_t(b->segs.size()),
+              b->d_group_hist.as<uint32_t>(), b->estimate ? kPilotMargin : 0u, min_bins(b),
+              b->d_bstar.as<uint32_t>());
+  }
   return rt::last_error_ok();
 }
 
@@ -1098,6 +1159,7 @@ bool ensure_scratch(irs_hip_batch* b) {
       !b->d_pruned.alloc(uint64_t(b->nq) * 4))
     return false;
   if (b->joined && !build_streams(b)) return false;
+  if (!build_groups(b)) return false;
   if (!b->tile_units.empty()) {
     if (!b->d_tile_units.alloc(b->tile_units.size() * 4) ||
         !rt::h2d(b->d_tile_units.p, b->tile_units.data(), b->tile_units.size() * 4, nullptr) ||
@@ -1880,6 +1942,16 @@ static int batch_set_path_impl(irs_hip_batch* b, int path) {
   return IRS_HIP_OK;
 }
 
+static int batch_set_shared_threshold_impl(irs_hip_batch* b, int enable) {
+  if (!b) return IRS_HIP_EINVAL;
+  if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
+  if (b->ran && !rt::sync(b->stream)) return IRS_HIP_EHIP;
+  b->shared_threshold = enable != 0;
+  b->scratch_ready = false;
+  b->planned = false;
+  return IRS_HIP_OK;
+}
+
 static int batch_path_impl(irs_hip_batch* b, int* path) {
   if (!b || !path) return IRS_HIP_EINVAL;
   *path = b->joined ? IRS_HIP_PATH_JOINED : IRS_HIP_PATH_ITEMS;
@@ -2099,7 +2171,14 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st) {
                 b->d_hits.as<unsigned long long>(), b->d_out.as<Hit>(), b->k_max,
                 b->d_out_count.as<uint32_t>(), b->d_status.as<uint32_t>(), stage_cap, sort_cap,
                 b->d_bstar.as<uint32_t>(), min_bins(b), b->d_pruned.as<uint32_t>(),
-                b->has_min ? b->d_min_score.as<float>() : static_cast<const float*>(nullptr));
+                b->has_min ? b->d_min_score.as<float>() : static_cast<const float*>(nullptr),
+                b->n_groups ? b->d_group_of.as<uint32_t>() : static_cast<const uint32_t*>(nullptr));
+      if (b->n_groups) {
+        RT_LAUNCH(k_group_check, (b->n_groups + 63u) / 64u, 64, 0, st, b->d_queries.as<DevQuery>(),
+                  b->d_group_members.as<uint32_t>(), uint32_t(b->segs.size()), b->n_groups,
+                  b->d_out_count.as<uint32_t>(), b->d_hits.as<unsigned long long>(),
+                  b->d_bstar.as<uint32_t>(), min_bins(b), b->d_status.as<uint32_t>());
+      }
       ok = rt::last_error_ok();
     }
   }
@@ -2367,6 +2446,9 @@ int irs_hip_batch_profile(irs_hip_batch* b, int enable) {
 }
 int irs_hip_batch_set_path(irs_hip_batch* b, int path) {
   return guarded([&] { return batch_set_path_impl(b, path); });
+}
+int irs_hip_batch_set_shared_threshold(irs_hip_batch* b, int enable) {
+  return guarded([&] { return batch_set_shared_threshold_impl(b, enable); });
 }
 int irs_hip_batch_path(irs_hip_batch* b, int* path) {
   return guarded([&] { return batch_path_impl(b, path); });

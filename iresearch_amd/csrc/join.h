@@ -547,7 +547,9 @@ struct JoinArgs {
 __global__ void __launch_bounds__(kTileThreadsMax)
 k_join_pilot(const uint32_t* units, const DevQuery* queries, const DevQTerm* qterms,
              const JoinTerm* jterms, uint32_t stride, uint32_t nw_log2, uint32_t* bstar,
-             uint32_t margin, const uint32_t* min_bin) {
+             uint32_t margin, const uint32_t* min_bin,
+             const uint32_t* group_of /*[unit] group + 1, 0: a threshold of its own; null: all*/,
+             uint32_t* group_hist /*[group][kBins + 2]: bins, sampled tiles, tiles*/) {
   RT_DYN_SMEM(smem);
   if (!wave::lds_is_at_zero(smem)) __builtin_trap();
   uint32_t* acc = reinterpret_cast<uint32_t*>(smem + JoinOff::acc);
@@ -601,6 +603,19 @@ k_join_pilot(const uint32_t* units, const DevQuery* queries, const DevQTerm* qte
     }
     __syncthreads();
   }
+  if (group_of && group_of[q]) {
+    // one threshold for the units of a group (the same query on several segments,
+    // k_group_threshold): this unit only contributes its sample
+    uint32_t* gh = group_hist + uint64_t(group_of[q] - 1u) * (kBins + 2u);
+    for (uint32_t i = tid; i < kBins; i += blockDim.x)
+      if (hist[i]) atomicAdd(&gh[i], hist[i]);
+    if (tid == 0) {
+      const uint32_t phase = (q * 7u) % stride;
+      atomicAdd(&gh[kBins], phase < n_tiles ? (n_tiles - phase + stride - 1) / stride : 0u);
+      atomicAdd(&gh[kBins + 1u], n_tiles);
+    }
+    return;
+  }
   uint32_t need = qd.k;
   if (margin) {
     const uint32_t phase = (q * 7u) % stride;
@@ -628,6 +643,77 @@ k_join_pilot(const uint32_t* units, const DevQuery* queries, const DevQTerm* qte
     }
     if (lane == 0) bstar[q] = (min_bin && min_bin[q] > result) ? min_bin[q] : result;
   }
+}
+
+// A group = one query on the several segments of a batch whose results the caller merges: ONE
+// threshold bin for the group, picked from the summed pilot histograms with the rule of
+// k_join_pilot (an expected margin * k candidates in the whole group instead of in every
+// segment — the candidates are what a small segment's tiles spend their time on).  One wavefront
+// per group; members[g * n_segs + s] = unit or 0xFFFFFFFF.
+__global__ void __launch_bounds__(64)
+k_group_threshold(const DevQuery* queries, const uint32_t* members, uint32_t n_segs,
+                  const uint32_t* group_hist, uint32_t margin, const uint32_t* min_bin,
+                  uint32_t* bstar) {
+  const unsigned lane = threadIdx.x;
+  const uint32_t g = blockIdx.x;
+  const uint32_t* hist = group_hist + uint64_t(g) * (kBins + 2u);
+  uint32_t first = 0xFFFFFFFFu;
+  for (uint32_t s = 0; s < n_segs; ++s) {
+    const uint32_t u = members[uint64_t(g) * n_segs + s];
+    if (u != 0xFFFFFFFFu && first == 0xFFFFFFFFu) first = u;
+  }
+  if (first == 0xFFFFFFFFu) return;
+  const uint32_t k = queries[first].k;
+  const uint32_t sampled = hist[kBins], n_tiles = hist[kBins + 1u];
+  uint32_t need = k;
+  if (margin) {
+    const uint64_t est = (uint64_t(margin) * k * sampled + n_tiles - 1) / (n_tiles ? n_tiles : 1u);
+    const uint32_t lo = est < kPilotMinSample ? kPilotMinSample : uint32_t(est < 0xFFFFFFFFull ? est : 0xFFFFFFFFull);
+    need = lo < k ? lo : k;
+  }
+  const uint32_t chunk = 63u - lane;   // suffix search: lane L owns the 8 bins of chunk 63-L
+  uint32_t sum = 0;
+  for (uint32_t i = 0; i < kBins / 64; ++i) sum += hist[chunk * (kBins / 64) + i];
+  const uint32_t incl = wave::inclusive_scan(sum);
+  const uint64_t reach = wave::ballot(incl >= need);
+  uint32_t result = 0;
+  if (reach) {
+    const int src = __builtin_ctzll(reach);
+    const uint32_t above = wave::bcast(incl - sum, src);
+    const uint32_t c = 63u - uint32_t(src);
+    uint32_t cum = above;
+    for (int i = int(kBins / 64) - 1; i >= 0; --i) {
+      cum += hist[c * (kBins / 64) + uint32_t(i)];
+      if (cum >= need) { result = c * (kBins / 64) + uint32_t(i); break; }
+    }
+  }
+  if (lane < n_segs) {
+    const uint32_t u = members[uint64_t(g) * n_segs + lane];
+    if (u != 0xFFFFFFFFu) bstar[u] = (min_bin && min_bin[u] > result) ? min_bin[u] : result;
+  }
+}
+
+// ... and its soundness check behind k_select: the group's lists together hold min(k, docs that
+// matched) entries, or the (estimated) threshold was too high — kStatusUnderflow, the host re-runs
+// the batch with the sound threshold (what k_select checks per unit for ungrouped units).
+__global__ void __launch_bounds__(64)
+k_group_check(const DevQuery* queries, const uint32_t* members, uint32_t n_segs, uint32_t n_groups,
+              const uint32_t* out_count, const unsigned long long* hits, const uint32_t* bstar,
+              const uint32_t* min_bin, uint32_t* status) {
+  const uint32_t g = blockIdx.x * 64u + threadIdx.x;
+  if (g >= n_groups) return;
+  unsigned long long got = 0, matched = 0;
+  uint32_t k = 0;
+  bool callers = false;
+  for (uint32_t s = 0; s < n_segs; ++s) {
+    const uint32_t u = members[uint64_t(g) * n_segs + s];
+    if (u == 0xFFFFFFFFu) continue;
+    k = queries[u].k;
+    got += out_count[u];
+    matched += hits[u];
+    callers = callers || (min_bin && min_bin[u] != 0u && bstar[u] == min_bin[u]);
+  }
+  if (got < k && matched > got && !callers) atomicOr(status, kStatusUnderflow);
 }
 
 // The tiles of one chunk (k_join_score); everything per query / per chunk arrives in `ctx`.

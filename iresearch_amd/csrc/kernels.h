@@ -561,7 +561,9 @@ k_select(const DevQuery* queries, const uint64_t* cands, uint32_t cand_cap,
          uint32_t* out_count, uint32_t* status, uint32_t stage_cap, uint32_t sort_cap,
          const uint32_t* bstar, const uint32_t* min_bin /*null: no caller thresholds*/,
          const uint32_t* pruned /*[unit] != 0: block-max pruning skipped blocks or tiles*/,
-         const float* min_score /*[unit] the caller's irs::score::Min, null: none*/) {
+         const float* min_score /*[unit] the caller's irs::score::Min, null: none*/,
+         const uint32_t* group_of /*[unit] != 0: the unit shares its threshold with a group —
+                                    "fewer than k" is checked for the group (k_group_check)*/) {
   RT_DYN_SMEM(smem);
   uint64_t* keys = reinterpret_cast<uint64_t*>(smem);         // [sort_cap]
   uint64_t* stage = keys + sort_cap;                          // [stage_cap]
@@ -583,7 +585,8 @@ k_select(const DevQuery* queries, const uint64_t* cands, uint32_t cand_cap,
   const bool callers = min_bin && min_bin[q] != 0u && bstar[q] == min_bin[q];
   // (hits only counts evaluated docs: where pruning skipped some, "fewer than k" alone says
   // the threshold was too high — unless nothing more exists, which a sound re-run then shows)
-  if (n < qd.k && (hits[q] > n || pruned[q]) && !callers && tid == 0)
+  const bool grouped = group_of && group_of[q] != 0u;
+  if (n < qd.k && (hits[q] > n || pruned[q]) && !callers && !grouped && tid == 0)
     atomicOr(status, kStatusUnderflow);
   const uint64_t* src = cands + uint64_t(q) * cand_cap;
   const uint32_t kk = qd.k < n ? qd.k : n;

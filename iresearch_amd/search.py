@@ -310,6 +310,13 @@ class QueryBatch:
                                                           cand_cap), "irs_hip_batch_configure")
         return self
 
+    def set_shared_threshold(self, enable=True):
+        """One threshold per query for its units on the batch's segments
+        (irs_hip_batch_set_shared_threshold): for callers that merge the per-segment lists."""
+        _lib.check(self.L, self.L.irs_hip_batch_set_shared_threshold(self.handle, int(bool(enable))),
+                   "irs_hip_batch_set_shared_threshold")
+        return self
+
     def set_path(self, path):
         """PATH_AUTO / PATH_ITEMS / PATH_JOINED (irs_hip_batch_set_path)."""
         _lib.check(self.L, self.L.irs_hip_batch_set_path(self.handle, int(path)),

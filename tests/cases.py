@@ -1140,6 +1140,91 @@ def case_multi_segment_batch(L, sizes=(30_000, 9_000, 140_000), max_rank=256, k=
         r.close()
 
 
+def case_shared_threshold(L, sizes=(70_000, 30_000, 140_000, 50_000), max_rank=256):
+    """irs_hip_batch_set_shared_threshold: the units of a query on the batch's segments share one
+    threshold.  The MERGED top k is bit for bit what the batch gives without the option (and what
+    the oracle's heap over all segments holds), total hits are unchanged, a segment's list is a
+    prefix of its own top k — and shorter wherever the segment holds fewer of the k best docs."""
+    first = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    segs = [synth.build_segment(int(n), max_rank, first_doc=int(f)) for n, f in zip(sizes, first)]
+    segs[1].metas[max_rank - 1]["docs_count"] = 0   # a term missing from one segment
+    readers = [search.SegmentReader.from_synth(s, L=L) for s in segs]
+    ranks = synth.make_queries(6, 8, 12, max_rank, synth.SEED + 9)
+    filters = [Or([by_term(int(r) - 1) for r in row]) for row in ranks]
+    filters += [by_term(max_rank - 1), Or([by_term(20), by_term(max_rank - 1, 2.0)]),
+                Or([by_term(12), by_term(13), by_term(14)], min_match=2),
+                And([by_term(12), by_term(13)])]
+    # (a TF-IDF score bound depends on the segment's largest frequencies: its units form groups
+    # only where those agree)
+    for scorer, grouped in ((BM25(), True), (BM25(1.2, 0.0), True), (TFIDF(True), False)):
+        prep = search.prepare(filters, scorer, [parity.segment_stats(s) for s in segs])
+        for k in (10, 300):
+            plain = search.QueryBatch(readers, prep, k)
+            ph, pc, pt = plain.run().results()
+            shared = search.QueryBatch(readers, prep, k).set_shared_threshold(True)
+            sh, sc, st = shared.run().results()
+            assert shared.reruns() == 0
+            assert np.array_equal(pt, st)
+            assert np.all(sc <= pc)
+            for i in range(len(segs)):
+                for q in range(len(filters)):
+                    n = int(sc[i, q])
+                    assert np.array_equal(sh[i, q, :n], ph[i, q, :n]), (i, q)
+            if grouped and k == 300:   # the segments share the work of finding k docs
+                assert int(sc[:, :6].sum()) < int(pc[:, :6].sum())
+            mp = search.merge_topk_host([(ph[i], pc[i]) for i in range(len(segs))], k)
+            ms = search.merge_topk_host([(sh[i], sc[i]) for i in range(len(segs))], k)
+            assert mp == ms
+            ref = parity.oracle_topk(segs, filters, scorer, k)
+            for q, (rows, (ohits, total)) in enumerate(zip(ms, ref)):
+                assert len(rows) == len(ohits), q
+                if rows:
+                    a = np.array([r[0] for r in rows], np.float32)
+                    assert np.allclose(a, np.sort(ohits["score"])[::-1], rtol=parity.REL_TOL, atol=0), q
+            plain.close()
+            shared.close()
+    for r in readers:
+        r.close()
+
+
+def case_shared_threshold_misled(L, k=400):
+    """... and when the pilot sample misleads the shared threshold (the sampled tiles of every
+    segment hold far better docs than the rest) the group check behind k_select notices that the
+    segments together returned fewer than k docs although more matched: one re-run with the
+    sound threshold, as for a single segment (case_pilot_misled)."""
+    tile, stride, n_tiles = 12288, 16, 64
+    n_docs = tile * n_tiles
+    segs, readers = [], []
+    for si in range(2):
+        rng = np.random.default_rng(31 + si)
+        phase = ((si * 3 + 0) * 7) % stride     # of unit (segment si, query 0): k_join_pilot
+        sampled = [t for t in range(n_tiles) if t % stride == phase]
+        hot = np.concatenate([1 + t * tile + np.sort(rng.choice(tile, 400, replace=False))
+                              for t in sampled]).astype(np.uint32)
+        hot_f = rng.integers(1, 64, hot.size).astype(np.uint32)
+        cold = np.sort(rng.choice(n_docs, 3000, replace=False)).astype(np.uint32) + 1
+        seg, sr = open_lists(L, [(hot, hot_f), (cold, np.ones(cold.size, np.uint32))], n_docs,
+                             synth.LAYOUT_SIMD4, norms=False)
+        segs.append(seg)
+        readers.append(sr)
+    filters = [by_term(0), Or([by_term(0), by_term(1)]), by_term(1)]
+    scorer = BM25(1.2, 0.0)
+    prep = search.prepare(filters, scorer, [parity.segment_stats(s) for s in segs])
+    b = search.QueryBatch(readers, prep, k).configure(0, stride, 0).set_shared_threshold(True)
+    assert b.reruns() == 0
+    h, c, t = b.run().results()
+    assert b.reruns() == 1 and b.path() == _lib.PATH_JOINED
+    merged = search.merge_topk_host([(h[i], c[i]) for i in range(2)], k)
+    ref = parity.oracle_topk(segs, filters, scorer, k)
+    for q, (rows, (ohits, total)) in enumerate(zip(merged, ref)):
+        assert len(rows) == len(ohits), q
+        a = np.array([r[0] for r in rows], np.float32)
+        assert np.allclose(a, np.sort(ohits["score"])[::-1], rtol=parity.REL_TOL, atol=0), q
+    b.close()
+    for r in readers:
+        r.close()
+
+
 def case_merge_ties(L, n_lists=5, nq=7, k=64, seed=11):
     """irs_hip_merge_topk alone: few distinct scores (heavy ties across segments), ragged
     counts including empty lists, segment ids not in list order.  Expected order:

@@ -116,6 +116,11 @@ def test_join_counts(simlib):
     cases.case_join_counts(simlib)
 
 
+def test_shared_threshold(simlib):
+    cases.case_shared_threshold(simlib)
+    cases.case_shared_threshold_misled(simlib)
+
+
 def test_multi_segment(simlib):
     cases.case_multi_segment(simlib, 45_000, 256)
 

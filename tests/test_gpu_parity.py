@@ -189,6 +189,11 @@ def test_join_counts(gpulib):
     cases.case_join_counts(gpulib, num_docs=900_000, max_rank=1024)
 
 
+def test_shared_threshold(gpulib):
+    cases.case_shared_threshold(gpulib)
+    cases.case_shared_threshold_misled(gpulib)
+
+
 def test_multi_segment(gpulib):
     cases.case_multi_segment(gpulib, 600_000, 1024, n_segs=4, k=1000)
 
