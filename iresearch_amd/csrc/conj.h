@@ -535,8 +535,20 @@ k_conj(ConjArgs A, uint32_t pilot) {
       if (cand && slot < A.cand_cap) A.cands[uint64_t(unit) * A.cand_cap + slot] = make_key(v, doc);
     }
   }
-  if (!pilot && lane == 0 && total)
-    atomicAdd(&A.hits[unit], static_cast<unsigned long long>(total));
+  if (!pilot && lane == 0 && total) A.item_hits[e] = total;
+}
+
+// hits of a block-driven unit = sum over its lead items (ConjArgs::item_hits): one wavefront per unit.
+__global__ void __launch_bounds__(64)
+k_conj_hits(const uint32_t* conj_units, const uint32_t* item_base, const uint32_t* item_hits,
+            unsigned long long* hits) {
+  const unsigned lane = threadIdx.x;
+  const uint32_t c = blockIdx.x;
+  unsigned long long sum = 0;
+  for (uint32_t i = item_base[c] + lane; i < item_base[c + 1u]; i += 64u) sum += item_hits[i];
+  // (24-bit pieces: 64 of them cannot overflow the 32-bit wavefront sum)
+  const uint32_t lo = wave::reduce_add(uint32_t(sum) & 0xFFFFFFu), hi = wave::reduce_add(uint32_t(sum >> 24));
+  if (lane == 0) hits[conj_units[c]] = (static_cast<unsigned long long>(hi) << 24) + lo;
 }
 
 // Threshold bin of a unit from the pilot histogram (the rule of k_pilot): one wavefront per unit.

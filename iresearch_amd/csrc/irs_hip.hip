@@ -138,6 +138,7 @@ struct irs_hip_batch {
   uint32_t n_conj_wgs = 0;
   DevBuf d_tile_units, d_conj_units, d_conj_items, d_conj_hist;
   DevBuf d_conj_item_base, d_conj_unit_items, d_conj_seek, d_conj_recs;   // k_conj_seek
+  DevBuf d_conj_item_hits;   // [lead item] matches (ConjArgs::item_hits, k_conj_hits)
   DevBuf d_lead_of;   // by_phrase: slot of every unit's lead term
   DevBuf d_min_bin;   // [unit] score bin of the caller's irs::score::Min (irs_hip_batch_set_min_scores)
   DevBuf d_min_score; // [unit] ... and the score itself (k_select's exact filter)
@@ -467,8 +468,11 @@ bool launch_conj(irs_hip_batch* b, rt::stream_t st) {
   a.pilot_stride = b->stride_eff;
   a.wand = b->wand ? 1u : 0u;
   a.pruned = b->d_pruned.as<uint32_t>();
+  a.item_hits = b->d_conj_item_hits.as<uint32_t>();
   if (!ensure_pilot_list(b, a.pilot_stride, st)) return false;
-  if (!rt::dmemset(b->d_conj_hist.p, 0, b->d_conj_hist.n, st)) return false;
+  if (!rt::dmemset(b->d_conj_hist.p, 0, b->d_conj_hist.n, st) ||
+      !rt::dmemset(b->d_conj_item_hits.p, 0, b->d_conj_item_hits.n, st))
+    return false;
   RT_LAUNCH(k_conj_seek, (b->conj_total_items + kThreads - 1) / kThreads, kThreads, 0, st,
             b->d_segs.as<DevSegment>(), b->d_queries.as<DevQuery>(), b->d_tails.as<DevTail>(),
             b->jt, b->d_conj_units.as<uint32_t>(), b->d_conj_item_base.as<uint32_t>(),
@@ -487,6 +491,9 @@ bool launch_conj(irs_hip_batch* b, rt::stream_t st) {
             b->estimate ? kPilotMargin : 0u, b->d_bstar.as<uint32_t>(), min_bins(b));
   RT_LAUNCH((k_conj<LAYOUT>), (b->conj_total_items + kConjWaves - 1) / kConjWaves, kConjWaves * 64,
             0, st, a, 0u);
+  RT_LAUNCH(k_conj_hits, uint32_t(b->conj_units.size()), 64, 0, st, b->d_conj_units.as<uint32_t>(),
+            b->d_conj_item_base.as<uint32_t>(), b->d_conj_item_hits.as<uint32_t>(),
+            b->d_hits.as<unsigned long long>());
   return rt::last_error_ok();
 }
 
@@ -556,9 +563,11 @@ bool launch_phrase(irs_hip_batch* b, rt::stream_t st) {
   a.recs = b->d_conj_recs.as<ConjItem>();
   a.unit_items = b->d_conj_unit_items.as<uint32_t>();
   a.lead_of = b->d_lead_of.as<uint32_t>();
+  a.item_hits = b->d_conj_item_hits.as<uint32_t>();
   a.jt = b->jt;
   a.cand_cap = b->cand_cap;
   a.pilot_stride = stride;
+  if (!rt::dmemset(b->d_conj_item_hits.p, 0, b->d_conj_item_hits.n, st)) return false;
   RT_LAUNCH(k_conj_seek, (b->conj_total_items + kThreads - 1) / kThreads, kThreads, 0, st,
             b->d_segs.as<DevSegment>(), b->d_queries.as<DevQuery>(), b->d_tails.as<DevTail>(),
             b->jt, b->d_conj_units.as<uint32_t>(), b->d_conj_item_base.as<uint32_t>(),
@@ -577,6 +586,9 @@ bool launch_phrase(irs_hip_batch* b, rt::stream_t st) {
             b->d_conj_items.as<uint32_t>(), b->d_conj_hist.as<uint32_t>(), stride,
             b->estimate ? kPilotMargin : 0u, b->d_bstar.as<uint32_t>(), min_bins(b));
   RT_LAUNCH((k_phrase<LAYOUT, MT>), b->n_phrase_wgs, kPhraseWaves * 64, 0, st, a, 0u);
+  RT_LAUNCH(k_conj_hits, uint32_t(b->conj_units.size()), 64, 0, st, b->d_conj_units.as<uint32_t>(),
+            b->d_conj_item_base.as<uint32_t>(), b->d_conj_item_hits.as<uint32_t>(),
+            b->d_hits.as<unsigned long long>());
   return rt::last_error_ok();
 }
 template<int LAYOUT>
@@ -995,6 +1007,7 @@ int build_conj_work(irs_hip_batch* b) {
         !b->d_conj_unit_items.alloc(unit_items.size() * 4) ||
         !b->d_conj_seek.alloc((total + 2) * uint64_t(kMaxTerms) * 4) ||
         !b->d_conj_recs.alloc((total + 1) * sizeof(ConjItem)) ||
+        !b->d_conj_item_hits.alloc((total + 1) * 4) ||
         !b->d_conj_units.alloc(b->conj_units.size() * 4) ||
         !b->d_conj_items.alloc(b->conj_items.size() * 4) ||
         !b->d_conj_hist.alloc(uint64_t(nq) * kBins * 4))
@@ -1875,6 +1888,7 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
             !b->d_lead_of.alloc(lead_of.size() * 4) ||
             !b->d_conj_seek.alloc((total + 2) * uint64_t(kMaxTerms) * 4) ||
             !b->d_conj_recs.alloc((total + 1) * sizeof(ConjItem)) ||
+            !b->d_conj_item_hits.alloc((total + 1) * 4) ||
             !b->d_conj_hist.alloc(uint64_t(nq) * kBins * 4))
           rc = IRS_HIP_ENOMEM;
         else if (!rt::h2d(b->d_conj_units.p, b->conj_units.data(), b->conj_units.size() * 4, nullptr) ||
