@@ -43,5 +43,11 @@ cases.case_min_score_pushdown(L)
 cases.case_many_items(L, 20_000)
 cases.case_zero_boost(L)
 cases.case_legacy_norms(L)
+cases.case_paths_agree(L, num_docs=40_000, max_rank=128)
+cases.case_join_edge_blocks(L, 1)
+cases.case_join_counts(L, num_docs=40_000, max_rank=128)
+cases.case_accumulator_switch(L)
+cases.case_shared_threshold(L, sizes=(30_000, 13_000, 40_000), max_rank=128)
+cases.case_shared_threshold_misled(L)
 print("asan emulator run: clean")
 PY
