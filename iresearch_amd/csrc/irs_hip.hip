@@ -184,6 +184,9 @@ struct irs_hip_batch {
   DevBuf d_group_hist;         // [nq_user][kBins + 2]
   JoinArgs join_args[2]{};   // plain disjunctions / units with match counts
   uint32_t n_join_plain = 0; // join_units in d_join_order: the plain ones first
+  uint32_t join_first[2][kJoinQueues + 1]{};   // [launch] the queues' first slots in d_join_order
+  DevBuf d_join_ctr;                           // [launch][kJoinQueues] work counters
+  uint32_t join_ctr_init[2][kJoinQueues]{};
   bool profile = false;
   bool count_touched = false;   // irs_hip_batch_profile bit 1: the kernels count what they decode
   bool events_ready = false;
@@ -782,30 +785,44 @@ bool build_streams(irs_hip_batch* b) {
       !b->d_join_units.alloc(b->join_units.size() * 4) ||
       !b->d_join_order.alloc(b->join_units.size() * 4))
     return false;
-  // k_join_score's queue order: heaviest units first within every chunk round, segment by
-  // segment (as for k_score)
+  // k_join_score's queues (JoinArgs): per launch — the plain disjunctions, then the units with
+  // match counts — the units sorted by (segment, heaviest term) and cut into kJoinQueues runs of
+  // about equal work, one queue per XCD: the workgroups that share an L2 work on units that share
+  // their longest stream (and the same doc range: chunk-major within a queue).
   std::vector<uint32_t> order;
   {
-    std::vector<std::pair<uint64_t, uint32_t>> work;
-    for (uint32_t u : b->join_units) {
-      const DevQuery& dq = b->queries[u];
-      uint64_t w = 0;
-      for (uint32_t j = 0; j < dq.n_terms; ++j)
-        w += b->segs[dq.seg]->terms[b->qterms[dq.first_term + j].term].docs_count;
-      work.push_back({w, u});
-    }
-    std::stable_sort(work.begin(), work.end(), [&](const auto& x, const auto& y) {
-      const uint32_t sx = b->queries[x.second].seg, sy = b->queries[y.second].seg;
-      return sx != sy ? sx < sy : x.first > y.first;
-    });
-    // the plain disjunctions first, then the units with match counts (a launch each)
-    std::stable_partition(work.begin(), work.end(), [&](const auto& x) {
-      return query_need(b->queries[x.second].op) <= 1u;
-    });
+    struct Item { uint64_t work; uint64_t key; uint32_t unit; };
     b->n_join_plain = 0;
-    for (const auto& w : work) {
-      order.push_back(w.second);
-      if (query_need(b->queries[w.second].op) <= 1u) ++b->n_join_plain;
+    for (uint32_t part = 0; part < 2; ++part) {
+      std::vector<Item> items;
+      for (uint32_t u : b->join_units) {
+        const DevQuery& dq = b->queries[u];
+        if ((query_need(dq.op) > 1u) != (part == 1u)) continue;
+        uint64_t w = 0, top = 0, top_term = 0;
+        for (uint32_t j = 0; j < dq.n_terms; ++j) {
+          const uint32_t term = b->qterms[dq.first_term + j].term;
+          const uint64_t df = b->segs[dq.seg]->terms[term].docs_count;
+          w += df;
+          if (df > top) { top = df; top_term = term; }
+        }
+        items.push_back({w, (uint64_t(dq.seg) << 32) | top_term, u});
+      }
+      if (part == 0) b->n_join_plain = uint32_t(items.size());
+      std::stable_sort(items.begin(), items.end(),
+                       [](const Item& x, const Item& y) { return x.key < y.key; });
+      uint64_t total = 0;
+      for (const Item& it : items) total += it.work + 1;
+      uint32_t (&first)[kJoinQueues + 1] = b->join_first[part];
+      size_t at = 0;
+      uint64_t done = 0;
+      for (uint32_t g = 0; g < kJoinQueues; ++g) {
+        first[g] = uint32_t(order.size());
+        const uint64_t goal = total * (g + 1) / kJoinQueues;
+        const size_t from = at;
+        while (at < items.size() && (done < goal || g + 1 == kJoinQueues)) done += items[at++].work + 1;
+        for (size_t i = from; i < at; ++i) order.push_back(items[i].unit);
+      }
+      first[kJoinQueues] = uint32_t(order.size());
     }
   }
   for (size_t i = 0; i < streams.size(); ++i) {
@@ -932,10 +949,9 @@ bool launch_join_score(irs_hip_batch* b, rt::stream_t st) {
   const uint32_t cpq = std::max<uint32_t>(1, (b->join_max_tiles + kJoinChunkTiles - 1) / kJoinChunkTiles);
   const uint32_t chunk_tiles = std::max<uint32_t>(1, (b->join_max_tiles + cpq - 1) / cpq);
   const uint32_t n_all = uint32_t(b->join_units.size());
-  if (!rt::dmemset(b->d_work.as<uint32_t>() + 1, 0, 8, st)) return false;
+  if (!b->d_join_ctr.p && !b->d_join_ctr.alloc(sizeof b->join_ctr_init)) return false;
   // two launches: the plain disjunctions, then the units whose accumulators count matches
   for (uint32_t part = 0; part < 2; ++part) {
-    const uint32_t first = part ? b->n_join_plain : 0u;
     const uint32_t n_units = part ? n_all - b->n_join_plain : b->n_join_plain;
     if (!n_units) continue;
     const uint64_t chunks = uint64_t(n_units) * cpq;
@@ -949,15 +965,26 @@ bool launch_join_score(irs_hip_batch* b, rt::stream_t st) {
     a.cands = b->d_cands.as<uint64_t>();
     a.cand_count = b->d_cand_count.as<uint32_t>();
     a.hits = b->d_hits.as<unsigned long long>();
-    a.order = b->d_join_order.as<uint32_t>() + first;
-    a.work_counter = b->d_work.as<uint32_t>() + 1 + part;   // ([0] is k_score's)
+    a.order = b->d_join_order.as<uint32_t>();
+    a.work_counter = b->d_join_ctr.as<uint32_t>() + part * kJoinQueues;
+    uint32_t base = 0;
+    for (uint32_t g = 0; g <= kJoinQueues; ++g) {
+      a.first[g] = b->join_first[part][g];
+      a.base[g] = base;
+      if (g < kJoinQueues) {
+        b->join_ctr_init[part][g] = base;
+        base += (b->join_first[part][g + 1] - b->join_first[part][g]) * cpq;
+      }
+    }
     a.cpq = cpq;
     a.n_units = n_units;
     a.nw_log2 = b->join_nw_log2;
     a.cand_cap = b->cand_cap;
     a.chunk_tiles = chunk_tiles;
     JoinArgs* d_args = b->d_join_args.as<JoinArgs>() + part;
-    if (!rt::h2d(d_args, &a, sizeof a, st)) return false;
+    if (!rt::h2d(d_args, &a, sizeof a, st) ||
+        !rt::h2d(a.work_counter, b->join_ctr_init[part], sizeof b->join_ctr_init[part], st))
+      return false;
     if (part) {
       RT_LAUNCH(k_join_score<true>, grid, b->join_threads, smem, st, d_args);
     } else {

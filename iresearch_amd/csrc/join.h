@@ -40,6 +40,7 @@ constexpr uint32_t kJoinBlocks = 16;      // blocks per k_join workgroup
 constexpr uint32_t kJoinChunkTiles = 32;  // consecutive tiles of one unit per work-queue item
 constexpr uint32_t kJoinCands = 256;      // candidate staging slots per chunk (x2 buffers)
 constexpr uint32_t kJoinSlack = 1024;     // readable entries behind the last stream
+constexpr uint32_t kJoinQueues = 8;       // work queues of k_join_score: one per XCD
 // units that need per-doc match counts (conjunctions, min-match): the low 4 bits of an
 // accumulator count matches (so at most 15 terms), contributions are rounded to multiples of 16
 constexpr uint32_t kJoinCountMask = 15u;
@@ -534,7 +535,15 @@ struct JoinArgs {
   uint32_t* cand_count;
   unsigned long long* hits;
   const uint32_t* order;  // work-queue order: slot i names the unit that runs i-th in a chunk round
+  // One work queue per XCD: the units are dealt to kJoinQueues groups of alike units (sorted by
+  // their heaviest term), a workgroup pulls from the queue of the XCD it runs on (blockIdx % 8:
+  // how the hardware deals workgroups today — a placement assumption that only speed depends on)
+  // and moves on to the other queues when that one is empty.  The workgroups that share an L2
+  // then read the same streams at the same time.  Chunk ids: queue g owns [base[g], base[g+1]),
+  // chunk-major over its units order[first[g] .. first[g+1]); work_counter[g] starts at base[g].
   uint32_t* work_counter;
+  uint32_t base[kJoinQueues + 1];
+  uint32_t first[kJoinQueues + 1];
   uint32_t cpq;          // chunk ids per unit
   uint32_t n_units;
   uint32_t nw_log2;
@@ -835,7 +844,26 @@ __device__ __forceinline__ void join_tiles(unsigned char* smem, const JoinTileCt
 //   barrier B2    accumulators are clear again
 // Candidates are staged per chunk; their global slots are reserved by one returning atomic
 // whose latency hides behind the next chunk.
+// The next chunk id for a workgroup that last worked on queue g0 (thread 0 only): its own
+// queue's, else the first other queue that still has one; total (= base[kJoinQueues]): none.
+__device__ __forceinline__ uint32_t join_pull(const JoinArgs* a, uint32_t g0, uint32_t first_raw,
+                                              uint32_t& g_out) {
+  g_out = g0;
+  if (first_raw < a->base[g0 + 1u]) return first_raw;
+  for (uint32_t k = 1; k < kJoinQueues; ++k) {
+    const uint32_t g = (g0 + k) % kJoinQueues;
+    if (a->base[g + 1u] == a->base[g]) continue;
+    const uint32_t raw = atomicAdd(&a->work_counter[g], 1u);
+    if (raw < a->base[g + 1u]) {
+      g_out = g;
+      return raw;
+    }
+  }
+  return a->base[kJoinQueues];
+}
+
 enum : uint32_t {   // LDS scratch words
+  kJGroup = 1,      // the queue the next chunk id came from
   kJChunk = 0,      // next chunk id
   kJNc = 2,         // kJNc + (parity): candidates staged by the current / previous chunk
   kJPendQ = 4,      // previous chunk: unit, reserved base, count
@@ -859,30 +887,36 @@ k_join_score(const JoinArgs* __restrict__ args) {
   const uint32_t tid = threadIdx.x;
   const unsigned lane = tid & 63u;
   const uint32_t wv = wave::uniform(tid >> 6);
-  const uint32_t n_units = args->n_units;
-  const uint32_t total_chunks = n_units * args->cpq;
+  const uint32_t total_chunks = args->base[kJoinQueues];
   const uint32_t nw_log2 = args->nw_log2;
   const uint32_t cap = args->cand_cap;
 
   for (uint32_t i = tid; i < kJoinTile + 64u; i += blockDim.x) acc[i] = 0u;   // (+ the dummies)
   if (tid < 16u) vars[tid] = 0u;
+  __syncthreads();
   if (tid == 0) {
     sig[0] = 0xFFFFFFFFu;
-    vars[kJChunk] = atomicAdd(args->work_counter, 1u);
+    const uint32_t g0 = blockIdx.x % kJoinQueues;
+    uint32_t g = g0;
+    vars[kJChunk] = join_pull(args, g0, atomicAdd(&args->work_counter[g0], 1u), g);
+    vars[kJGroup] = g;
   }
   __syncthreads();
   uint32_t chunk = wave::uniform(vars[kJChunk]);
+  uint32_t group = wave::uniform(vars[kJGroup]);
   uint32_t parity = 0;
   // thread 0: the previous chunk's reservation (a returning atomic in flight)
   uint32_t pend_q = 0, pend_n = 0, pend_base = 0;
   __syncthreads();
 
   while (chunk < total_chunks) {
-    uint32_t next_chunk = 0;
-    if (tid == 0) next_chunk = atomicAdd(args->work_counter, 1u);
-    const uint32_t q = wave::uniform(args->order[chunk % n_units]);
+    uint32_t next_raw = 0;   // (a returning atomic in flight until the hand-over)
+    if (tid == 0) next_raw = atomicAdd(&args->work_counter[group], 1u);
+    const uint32_t n_units = args->first[group + 1u] - args->first[group];
+    const uint32_t local = chunk - args->base[group];
+    const uint32_t q = wave::uniform(args->order[args->first[group] + local % n_units]);
     const uint32_t per_chunk = args->chunk_tiles;
-    const uint32_t tile0 = (chunk / n_units) * per_chunk;
+    const uint32_t tile0 = (local / n_units) * per_chunk;
     const DevQuery qd = args->queries[q];
     const uint32_t n_tiles = qd.n_tiles;
     const uint32_t ntile = tile0 >= n_tiles ? 0u
@@ -938,7 +972,9 @@ k_join_score(const JoinArgs* __restrict__ args) {
       vars[kJPendQ] = pend_q;
       vars[kJPendBase] = pend_base;
       vars[kJPendN] = pend_n;
-      vars[kJChunk] = next_chunk;
+      uint32_t g = group;
+      vars[kJChunk] = join_pull(args, group, next_raw, g);
+      vars[kJGroup] = g;
     }
     my_hits = wave::reduce_add(my_hits);
     if (lane == 0 && my_hits)
@@ -957,6 +993,7 @@ k_join_score(const JoinArgs* __restrict__ args) {
       }
     }
     chunk = wave::uniform(vars[kJChunk]);
+    group = wave::uniform(vars[kJGroup]);
     if (tid == 0) {
       const uint32_t raw = *ncand;
       pend_n = raw < kJoinCands ? raw : kJoinCands;
