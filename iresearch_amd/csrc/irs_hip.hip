@@ -727,8 +727,9 @@ bool unit_joinable(const irs_hip_batch* b, uint32_t u) {
 // records of k_join_score.  Static per batch: built once, the kernels refill the entries and
 // boundaries in every run.
 bool build_streams(irs_hip_batch* b) {
+  struct WgRef { uint32_t stream, first; };   // a k_join workgroup before its record is made
   std::vector<StreamRec> streams;
-  std::vector<JoinWg> wgs;
+  std::vector<WgRef> wgs;
   std::vector<JoinTerm> jterms(b->qterms.size());
   std::vector<uint64_t> key_of;   // sorted (segment << 32 | term) -> stream
   {
@@ -755,7 +756,7 @@ bool build_streams(irs_hip_batch* b) {
     const uint32_t n_tiles = (sg->dev.num_docs + kJoinTile - 1) / kJoinTile;
     const uint32_t nb = t.nblk + ((t.docs_count == 1 || t.tail_n) ? 1u : 0u);
     for (uint32_t first = 0; first < nb; first += kJoinBlocks)
-      wgs.push_back(JoinWg{uint32_t(streams.size()), first});
+      wgs.push_back(WgRef{uint32_t(streams.size()), first});
     entries += t.docs_count;
     bounds += uint64_t(n_tiles) + 1;
     streams.push_back(r);
@@ -766,9 +767,9 @@ bool build_streams(irs_hip_batch* b) {
   // Ordered by where in the doc space a workgroup's blocks lie — estimated as its position
   // inside its list — the ones in flight share a doc range, i.e. norm cache lines.
   {
-    std::vector<std::pair<float, JoinWg>> keyed;
+    std::vector<std::pair<float, WgRef>> keyed;
     keyed.reserve(wgs.size());
-    for (const JoinWg& w : wgs) {
+    for (const WgRef& w : wgs) {
       const DevTerm& t = b->segs[streams[w.stream].seg]->terms[streams[w.stream].term];
       const uint32_t nb = t.nblk + ((t.docs_count == 1 || t.tail_n) ? 1u : 0u);
       keyed.push_back({float(streams[w.stream].seg) + (float(w.first) + 0.5f * kJoinBlocks) / float(nb + kJoinBlocks), w});
@@ -829,6 +830,31 @@ bool build_streams(irs_hip_batch* b) {
     streams[i].entries = reinterpret_cast<uint64_t>(b->d_entries.as<uint32_t>() + ent_off[i]);
     streams[i].bounds = reinterpret_cast<uint64_t>(b->d_bounds.as<uint32_t>() + bnd_off[i]);
   }
+  // the workgroups' records (JoinWg: everything k_join reads before its first payload byte)
+  std::vector<JoinWg> wg_recs(wgs.size());
+  for (size_t i = 0; i < wgs.size(); ++i) {
+    const StreamRec& sr = streams[wgs[i].stream];
+    const irs_hip_segment* sg = b->segs[sr.seg];
+    const DevSegment& ds = sg->dev;
+    const DevTerm& t = sg->terms[sr.term];
+    JoinWg& w = wg_recs[i];
+    w.entries = sr.entries;
+    w.bounds = sr.bounds;
+    w.doc = reinterpret_cast<uint64_t>(ds.doc) + t.doc_start;
+    w.dir = reinterpret_cast<uint64_t>(ds.blk_dir + t.dir_off);
+    w.norms = (ds.norms && ds.norm_width == 1u && !ds.norm_legacy)
+                  ? reinterpret_cast<uint64_t>(ds.norms) - ds.norm_min_doc : 0ull;
+    w.tail_docs = reinterpret_cast<uint64_t>(ds.tail_docs + t.tail_row);
+    w.tail_freqs = reinterpret_cast<uint64_t>(ds.tail_freqs + t.tail_row);
+    w.first = wgs[i].first;
+    w.nblk = t.nblk;
+    w.tail_n = t.docs_count == 1u ? 1u : t.tail_n;
+    w.tail_base = t.nblk ? t.tail_base : 0u;
+    w.last_doc = t.last_doc;
+    w.n_tiles = (ds.num_docs + kJoinTile - 1) / kJoinTile;
+    w.n = sr.n;
+    w.pad = 0;
+  }
   for (uint32_t u : b->join_units) {
     const DevQuery& dq = b->queries[u];
     const uint32_t rows = table_rows(dq.n_caches);
@@ -848,7 +874,7 @@ bool build_streams(irs_hip_batch* b) {
   // (the slack behind the last stream is only ever read by masked-off look-ahead: zero it once)
   if (!rt::dmemset(b->d_entries.as<uint32_t>() + entries, 0, kJoinSlack * 4, nullptr) ||
       !rt::h2d(b->d_streams.p, streams.data(), streams.size() * sizeof(StreamRec), nullptr) ||
-      !rt::h2d(b->d_join_wgs.p, wgs.data(), wgs.size() * sizeof(JoinWg), nullptr) ||
+      !rt::h2d(b->d_join_wgs.p, wg_recs.data(), wg_recs.size() * sizeof(JoinWg), nullptr) ||
       !rt::h2d(b->d_jterms.p, jterms.data(), jterms.size() * sizeof(JoinTerm), nullptr) ||
       !rt::h2d(b->d_join_units.p, b->join_units.data(), b->join_units.size() * 4, nullptr) ||
       !rt::h2d(b->d_join_order.p, order.data(), order.size() * 4, nullptr) ||
@@ -863,11 +889,9 @@ bool build_streams(irs_hip_batch* b) {
 bool launch_join(irs_hip_batch* b, rt::stream_t st) {
   if (!b->n_join_wgs) return true;
   if (b->seg->dev.layout == kSimd4) {
-    RT_LAUNCH((k_join<kSimd4>), b->n_join_wgs, kThreads, 0, st, b->d_segs.as<DevSegment>(),
-              b->d_streams.as<StreamRec>(), b->d_join_wgs.as<JoinWg>());
+    RT_LAUNCH((k_join<kSimd4>), b->n_join_wgs, kThreads, 0, st, b->d_join_wgs.as<JoinWg>());
   } else {
-    RT_LAUNCH((k_join<kScalar>), b->n_join_wgs, kThreads, 0, st, b->d_segs.as<DevSegment>(),
-              b->d_streams.as<StreamRec>(), b->d_join_wgs.as<JoinWg>());
+    RT_LAUNCH((k_join<kScalar>), b->n_join_wgs, kThreads, 0, st, b->d_join_wgs.as<JoinWg>());
   }
   return rt::last_error_ok();
 }

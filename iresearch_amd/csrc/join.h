@@ -36,7 +36,7 @@ namespace irs_hip {
 
 constexpr uint32_t kJoinTile = 12288;     // docs per accumulator tile (48 KB of u32 in LDS)
 constexpr uint32_t kJoinTfMax = 63;       // entry layout: 6 bits of tf
-constexpr uint32_t kJoinBlocks = 16;      // blocks per k_join workgroup
+constexpr uint32_t kJoinBlocks = 64;      // blocks per k_join workgroup
 constexpr uint32_t kJoinChunkTiles = 32;  // consecutive tiles of one unit per work-queue item
 constexpr uint32_t kJoinCands = 256;      // candidate staging slots per chunk (x2 buffers)
 constexpr uint32_t kJoinSlack = 1024;     // readable entries behind the last stream
@@ -62,10 +62,26 @@ struct alignas(16) StreamRec {
   uint32_t n;         // postings
   uint32_t pad;
 };
-struct JoinWg {       // k_join work: kJoinBlocks blocks (the tail counts as one) of a stream
-  uint32_t stream;
-  uint32_t first;
+// k_join work: kJoinBlocks blocks (the tail counts as one) of a stream, and EVERYTHING the
+// workgroup needs to know about it in one record, read by a scalar load: the kernel used to walk
+// work item -> stream -> segment -> term -> directory (five dependent loads, ~4 us) before its
+// first payload byte, for 16 blocks of work — it was bound by that chain, not by bytes.
+struct alignas(16) JoinWg {
+  uint64_t entries, bounds;   // of the stream (StreamRec)
+  uint64_t doc;               // the term's first posting byte: DevSegment::doc + DevTerm::doc_start
+  uint64_t dir;               // its first directory record: DevSegment::blk_dir + DevTerm::dir_off
+  uint64_t norms;             // the 1-byte Norm2 column indexed by doc id (0: none / another kind)
+  uint64_t tail_docs, tail_freqs;   // the decoded tail / single doc (+ DevTerm::tail_row)
+  uint32_t first;             // the workgroup's first block
+  uint32_t nblk;              // full blocks of the list
+  uint32_t tail_n;            // postings of the decoded tail (1 for a single-doc term)
+  uint32_t tail_base;         // last doc in front of the tail (0: the list has no full block)
+  uint32_t last_doc;          // of the list
+  uint32_t n_tiles;           // doc tiles of the segment
+  uint32_t n;                 // postings of the list
+  uint32_t pad;
 };
+static_assert(sizeof(JoinWg) == 96, "JoinWg");
 // Per (unit, term slot), parallel to DevQTerm: all k_join_score needs in one 32-byte record.
 struct alignas(16) JoinTerm {
   uint64_t entries;
@@ -82,13 +98,15 @@ __host__ __device__ __forceinline__ uint32_t join_entry(uint32_t idx, uint32_t t
 
 // ------------------------------------------------------------------ join --
 
-// One workgroup = kJoinBlocks consecutive blocks of one stream; a wavefront owns every 4th of
-// them and keeps all of its blocks IN FLIGHT TOGETHER: the directory records, then every
-// block's payload words, then every block's norm bytes — three memory round trips per
-// wavefront instead of three per block (the kernel is latency bound: a block is 100 VALU
-// instructions behind 3 dependent loads).  Decode as decode.h (bit-exact doc ids +
+// One workgroup = kJoinBlocks consecutive blocks of one stream, in rounds of kWaves x
+// kJoinPerWave: a wavefront owns every 4th block of a round and keeps its blocks of the round IN
+// FLIGHT TOGETHER — the directory records, then every block's payload words, then every
+// block's norm bytes: three memory round trips per round instead of three per block (a block is
+// 100 VALU instructions behind 3 dependent loads).  Decode as decode.h (bit-exact doc ids +
 // frequencies); entries are written coalesced (posting i is entry i).
-constexpr uint32_t kJoinPerWave = kJoinBlocks / kWaves;
+constexpr uint32_t kJoinPerWave = 4;
+constexpr uint32_t kJoinRounds = kJoinBlocks / (kWaves * kJoinPerWave);
+static_assert(kJoinRounds * kWaves * kJoinPerWave == kJoinBlocks, "k_join rounds");
 
 // entries + tile boundaries of the two postings a lane holds of one block
 __device__ __forceinline__ void join_emit(uint32_t* ent, uint32_t* bnd, uint32_t b, unsigned lane,
@@ -119,95 +137,95 @@ __device__ __forceinline__ void join_emit(uint32_t* ent, uint32_t* bnd, uint32_t
 
 template<int LAYOUT>
 __global__ void __launch_bounds__(kThreads)
-k_join(const DevSegment* segs, const StreamRec* streams, const JoinWg* wgs) {
+k_join(const JoinWg* wgs) {
   const unsigned lane = threadIdx.x & 63u;
-  const uint32_t wv = threadIdx.x >> 6;
-  const JoinWg wg = wgs[blockIdx.x];
-  const StreamRec S = streams[wg.stream];
-  const DevSegment& seg = segs[S.seg];
-  const DevTerm t = seg.terms[S.term];
-  uint32_t* ent = reinterpret_cast<uint32_t*>(S.entries);
-  uint32_t* bnd = reinterpret_cast<uint32_t*>(S.bounds);
-  const uint32_t n_tiles = (seg.num_docs + kJoinTile - 1u) / kJoinTile;
-  const uint32_t tail_n = t.docs_count == 1u ? 1u : t.tail_n;
-  const uint32_t nb = t.nblk + (tail_n ? 1u : 0u);
-  const bool tiny = seg.norms && seg.norm_width == 1u && !seg.norm_legacy;
-  const uint8_t* norms = seg.norms - seg.norm_min_doc;   // (indexed by doc id)
-  uint32_t end = wg.first + kJoinBlocks;
+  const uint32_t wv = wave::uniform(threadIdx.x >> 6);
+  const JoinWg W = wave::sload<JoinWg>(reinterpret_cast<uint64_t>(wgs) + uint64_t(blockIdx.x) * sizeof(JoinWg));
+  uint32_t* ent = reinterpret_cast<uint32_t*>(W.entries);
+  uint32_t* bnd = reinterpret_cast<uint32_t*>(W.bounds);
+  const uint8_t* doc = reinterpret_cast<const uint8_t*>(W.doc);
+  const uint8_t* norms = reinterpret_cast<const uint8_t*>(W.norms);   // (indexed by doc id)
+  const bool tiny = W.norms != 0;
+  const uint32_t nb = W.nblk + (W.tail_n ? 1u : 0u);
+  uint32_t end = W.first + kJoinBlocks;
   if (end > nb) end = nb;
-  // this wavefront's blocks: b_i = first + wv + kWaves * i  (all wave-uniform)
-  BlkDir dir[kJoinPerWave];
-  RawPair rd[kJoinPerWave], rf[kJoinPerWave];
-  bool full[kJoinPerWave], plain[kJoinPerWave];
+  for (uint32_t r0 = W.first; r0 < end; r0 += kWaves * kJoinPerWave) {
+    // this wavefront's blocks of the round: b_i = r0 + wv + kWaves * i  (all wave-uniform)
+    BlkDir dir[kJoinPerWave];
+    RawPair rd[kJoinPerWave], rf[kJoinPerWave];
+    bool full[kJoinPerWave], plain[kJoinPerWave];
 #pragma unroll
-  for (uint32_t i = 0; i < kJoinPerWave; ++i) {
-    const uint32_t b = wg.first + wv + kWaves * i;
-    full[i] = b < end && b < t.nblk;
-    dir[i] = BlkDir{0u, 0u, 0u, 0u};
-    if (full[i]) dir[i] = seg.blk_dir[t.dir_off + b];
-  }
-#pragma unroll
-  for (uint32_t i = 0; i < kJoinPerWave; ++i) {
-    const uint32_t dbits = dir[i].bits & 0xFFu, fbits = dir[i].bits >> 8;
-    // (an all-equal doc part is a vint of unknown length: that block decodes by itself below)
-    plain[i] = full[i] && dbits != 0u;
-    if (plain[i]) {
-      const uint8_t* blk = seg.doc + t.doc_start + dir[i].off;
-      rd[i] = raw_load<LAYOUT>(blk + 1, dbits, lane);
-      rf[i] = raw_load<LAYOUT>(blk + 1u + 16u * dbits + 1u, fbits, lane);
+    for (uint32_t i = 0; i < kJoinPerWave; ++i) {
+      const uint32_t b = r0 + wv + kWaves * i;
+      full[i] = b < end && b < W.nblk;
+      dir[i] = BlkDir{0u, 0u, 0u, 0u};
+      if (full[i]) dir[i] = wave::sload<BlkDir>(W.dir + uint64_t(b) * sizeof(BlkDir));
     }
-  }
-  uint32_t d0[kJoinPerWave], d1[kJoinPerWave], f0[kJoinPerWave], f1[kJoinPerWave];
 #pragma unroll
-  for (uint32_t i = 0; i < kJoinPerWave; ++i) {
-    d0[i] = d1[i] = kDocMin;
-    f0[i] = f1[i] = 0;
-    if (plain[i]) {
+    for (uint32_t i = 0; i < kJoinPerWave; ++i) {
       const uint32_t dbits = dir[i].bits & 0xFFu, fbits = dir[i].bits >> 8;
-      uint32_t x0, x1;
-      raw_extract<LAYOUT>(rd[i], dbits, lane, x0, x1);
-      d1[i] = dir[i].prev_last + wave::inclusive_scan(x0 + x1);
-      d0[i] = d1[i] - x1;
-      if (fbits == 0u) {   // all-equal frequencies: the vint behind the header byte
-        uint32_t len;
-        f0[i] = f1[i] = vint_from(rf[i].a, &len);
-      } else {
-        raw_extract<LAYOUT>(rf[i], fbits, lane, f0[i], f1[i]);
+      // (an all-equal doc part is a vint of unknown length: that block decodes by itself below)
+      plain[i] = full[i] && dbits != 0u;
+      if (plain[i]) {
+        const uint8_t* blk = doc + dir[i].off;
+        rd[i] = raw_load<LAYOUT>(blk + 1, dbits, lane);
+        rf[i] = raw_load<LAYOUT>(blk + 1u + 16u * dbits + 1u, fbits, lane);
       }
-    } else if (full[i]) {
-      decode_block<LAYOUT, true>(seg.doc + t.doc_start + dir[i].off, 0u, dir[i].bits >> 8,
-                                 dir[i].prev_last, lane, d0[i], d1[i], f0[i], f1[i]);
     }
-  }
-  uint32_t n0[kJoinPerWave], n1[kJoinPerWave];
+    uint32_t d0[kJoinPerWave], d1[kJoinPerWave], f0[kJoinPerWave], f1[kJoinPerWave];
 #pragma unroll
-  for (uint32_t i = 0; i < kJoinPerWave; ++i) {
-    n0[i] = (full[i] && tiny) ? norms[d0[i]] : 0u;
-    n1[i] = (full[i] && tiny) ? norms[d1[i]] : 0u;
-  }
+    for (uint32_t i = 0; i < kJoinPerWave; ++i) {
+      d0[i] = d1[i] = kDocMin;
+      f0[i] = f1[i] = 0;
+      if (plain[i]) {
+        const uint32_t dbits = dir[i].bits & 0xFFu, fbits = dir[i].bits >> 8;
+        uint32_t x0, x1;
+        raw_extract<LAYOUT>(rd[i], dbits, lane, x0, x1);
+        d1[i] = dir[i].prev_last + wave::inclusive_scan(x0 + x1);
+        d0[i] = d1[i] - x1;
+        if (fbits == 0u) {   // all-equal frequencies: the vint behind the header byte
+          uint32_t len;
+          f0[i] = f1[i] = vint_from(rf[i].a, &len);
+        } else {
+          raw_extract<LAYOUT>(rf[i], fbits, lane, f0[i], f1[i]);
+        }
+      } else if (full[i]) {
+        decode_block<LAYOUT, true>(doc + dir[i].off, 0u, dir[i].bits >> 8, dir[i].prev_last, lane,
+                                   d0[i], d1[i], f0[i], f1[i]);
+      }
+    }
+    uint32_t n0[kJoinPerWave], n1[kJoinPerWave];
 #pragma unroll
-  for (uint32_t i = 0; i < kJoinPerWave; ++i) {
-    const uint32_t b = wg.first + wv + kWaves * i;
-    if (full[i])
-      join_emit(ent, bnd, b, lane, d0[i], d1[i], f0[i], f1[i], n0[i], n1[i], true, true,
-                b ? dir[i].prev_last : 0u);
+    for (uint32_t i = 0; i < kJoinPerWave; ++i) {
+      n0[i] = (full[i] && tiny) ? norms[d0[i]] : 0u;
+      n1[i] = (full[i] && tiny) ? norms[d1[i]] : 0u;
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < kJoinPerWave; ++i) {
+      const uint32_t b = r0 + wv + kWaves * i;
+      if (full[i])
+        join_emit(ent, bnd, b, lane, d0[i], d1[i], f0[i], f1[i], n0[i], n1[i], true, true,
+                  b ? dir[i].prev_last : 0u);
+    }
   }
   // the vint tail / single doc, decoded when the segment was opened: the list's last "block"
-  const uint32_t bt = t.nblk;
-  if (tail_n && bt >= wg.first && bt < end && ((bt - wg.first) % kWaves) == wv) {
+  const uint32_t bt = W.nblk;
+  if (W.tail_n && bt >= W.first && bt < end && ((bt - W.first) % kWaves) == wv) {
+    const uint32_t* tdocs = reinterpret_cast<const uint32_t*>(W.tail_docs);
+    const uint32_t* tfreqs = reinterpret_cast<const uint32_t*>(W.tail_freqs);
     const uint32_t i0 = 2u * lane;
-    const bool v0 = i0 < tail_n, v1 = i0 + 1u < tail_n;
+    const bool v0 = i0 < W.tail_n, v1 = i0 + 1u < W.tail_n;
     uint32_t td0 = kDocMin, td1 = kDocMin, tf0 = 0, tf1 = 0;
-    if (v0) { td0 = seg.tail_docs[t.tail_row + i0]; tf0 = seg.tail_freqs[t.tail_row + i0]; }
-    if (v1) { td1 = seg.tail_docs[t.tail_row + i0 + 1u]; tf1 = seg.tail_freqs[t.tail_row + i0 + 1u]; }
+    if (v0) { td0 = tdocs[i0]; tf0 = tfreqs[i0]; }
+    if (v1) { td1 = tdocs[i0 + 1u]; tf1 = tfreqs[i0 + 1u]; }
     const uint32_t tn0 = (v0 && tiny) ? norms[td0] : 0u;
     const uint32_t tn1 = (v1 && tiny) ? norms[td1] : 0u;
-    join_emit(ent, bnd, bt, lane, td0, td1, tf0, tf1, tn0, tn1, v0, v1, t.nblk ? t.tail_base : 0u);
+    join_emit(ent, bnd, bt, lane, td0, td1, tf0, tf1, tn0, tn1, v0, v1, W.tail_base);
   }
   // behind the list's last posting every remaining tile is empty: whoever holds the last block
-  if (nb && nb - 1u >= wg.first && nb - 1u < end && ((nb - 1u - wg.first) % kWaves) == wv) {
-    const uint32_t last_tile = (t.last_doc - kDocMin) / kJoinTile;
-    for (uint32_t u = last_tile + 1u + lane; u <= n_tiles; u += 64u) bnd[u] = S.n;
+  if (nb && nb - 1u >= W.first && nb - 1u < end && ((nb - 1u - W.first) % kWaves) == wv) {
+    const uint32_t last_tile = (W.last_doc - kDocMin) / kJoinTile;
+    for (uint32_t u = last_tile + 1u + lane; u <= W.n_tiles; u += 64u) bnd[u] = W.n;
   }
 }
 
