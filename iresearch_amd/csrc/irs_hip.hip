@@ -99,6 +99,10 @@ struct irs_hip_segment {
   // block-max data (WAND), built on first use: the one thing that changes after open
   std::mutex wand_mutex;
   bool wand_ready = false;
+  // the norm byte of every posting in posting order (k_posting_norms), built on the segment's
+  // first joined batch; 1-byte Norm2 columns only
+  DevBuf d_pnorm, d_tail_norms;
+  bool pnorm_ready = false;
   DevBuf d_blk_maxf, d_blk_minn;
   std::vector<uint64_t> skip_at;   // per term: absolute offset of its skip data (0: none)
   bool has_pos = false;
@@ -615,6 +619,35 @@ static bool launch_block_max(irs_hip_segment* s) {
   return rt::last_error_ok() && rt::sync(nullptr);
 }
 
+int prepare_posting_norms(irs_hip_segment* s) {
+  std::lock_guard<std::mutex> lock(s->wand_mutex);
+  if (s->pnorm_ready) return IRS_HIP_OK;
+  const DevSegment& d = s->dev;
+  if (d.norms && d.norm_width == 1u && !d.norm_legacy) {
+    const uint64_t rows = s->total_blocks, tails = s->d_tail_docs.n / 4;
+    if (!s->d_pnorm.alloc((rows + 1) * kBlock) || !s->d_tail_norms.alloc(tails + 1))
+      return IRS_HIP_ENOMEM;
+    if (rows && d.num_terms) {
+      const uint32_t slices = std::max<uint32_t>(1, std::min<uint32_t>(64, s->cus * 8 / d.num_terms));
+      if (d.layout == kSimd4) {
+        RT_LAUNCH((k_posting_norms<kSimd4>), d.num_terms * slices, kThreads, 0, nullptr, d, slices,
+                  s->d_pnorm.as<uint8_t>());
+      } else {
+        RT_LAUNCH((k_posting_norms<kScalar>), d.num_terms * slices, kThreads, 0, nullptr, d, slices,
+                  s->d_pnorm.as<uint8_t>());
+      }
+    }
+    if (tails) {
+      RT_LAUNCH(k_tail_norms, uint32_t((tails + kThreads - 1) / kThreads), kThreads, 0, nullptr, d,
+                tails, s->d_tail_norms.as<uint8_t>());
+    }
+    if (!rt::last_error_ok() || !rt::sync(nullptr)) return IRS_HIP_EHIP;
+    s->device_bytes += s->d_pnorm.n + s->d_tail_norms.n;
+  }
+  s->pnorm_ready = true;
+  return IRS_HIP_OK;
+}
+
 int prepare_blockmax(irs_hip_segment* s) {
   std::lock_guard<std::mutex> lock(s->wand_mutex);
   if (s->wand_ready) return IRS_HIP_OK;
@@ -830,6 +863,8 @@ bool build_streams(irs_hip_batch* b) {
     streams[i].entries = reinterpret_cast<uint64_t>(b->d_entries.as<uint32_t>() + ent_off[i]);
     streams[i].bounds = reinterpret_cast<uint64_t>(b->d_bounds.as<uint32_t>() + bnd_off[i]);
   }
+  for (irs_hip_segment* sg : b->segs)
+    if (prepare_posting_norms(sg) != IRS_HIP_OK) return false;
   // the workgroups' records (JoinWg: everything k_join reads before its first payload byte)
   std::vector<JoinWg> wg_recs(wgs.size());
   for (size_t i = 0; i < wgs.size(); ++i) {
@@ -842,8 +877,9 @@ bool build_streams(irs_hip_batch* b) {
     w.bounds = sr.bounds;
     w.doc = reinterpret_cast<uint64_t>(ds.doc) + t.doc_start;
     w.dir = reinterpret_cast<uint64_t>(ds.blk_dir + t.dir_off);
-    w.norms = (ds.norms && ds.norm_width == 1u && !ds.norm_legacy)
-                  ? reinterpret_cast<uint64_t>(ds.norms) - ds.norm_min_doc : 0ull;
+    const bool tiny = sg->d_pnorm.p != nullptr;
+    w.pnorm = tiny ? reinterpret_cast<uint64_t>(sg->d_pnorm.as<uint8_t>() + t.dir_off * kBlock) : 0ull;
+    w.tail_norms = tiny ? reinterpret_cast<uint64_t>(sg->d_tail_norms.as<uint8_t>() + t.tail_row) : 0ull;
     w.tail_docs = reinterpret_cast<uint64_t>(ds.tail_docs + t.tail_row);
     w.tail_freqs = reinterpret_cast<uint64_t>(ds.tail_freqs + t.tail_row);
     w.first = wgs[i].first;
@@ -853,7 +889,7 @@ bool build_streams(irs_hip_batch* b) {
     w.last_doc = t.last_doc;
     w.n_tiles = (ds.num_docs + kJoinTile - 1) / kJoinTile;
     w.n = sr.n;
-    w.pad = 0;
+    w.pad[0] = w.pad[1] = w.pad[2] = 0;
   }
   for (uint32_t u : b->join_units) {
     const DevQuery& dq = b->queries[u];
