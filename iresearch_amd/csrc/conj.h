@@ -345,8 +345,16 @@ k_conj(ConjArgs A, uint32_t pilot) {
     }
   }
   // the docs every one of the terms [g0, g1) reached (and every earlier one) get those terms'
-  // scores: norm read here, once per flush, for these docs only
+  // scores: norm read here, once per flush, for these docs only — they are postings of the lead
+  // block: from the posting-order copy of the column where the segment has one (consecutive
+  // bytes instead of a gather by doc id)
   const bool with_norm = needs_norm(term_q(0).kind);
+  const uint8_t* lead_norms = nullptr;
+  if (seg.pnorm)
+    lead_norms = item < ld.nblk ? seg.pnorm + (ld.dir_off + item) * kBlock : seg.tail_norms + ld.tail_row;
+  auto lead_norm = [&](uint32_t sl, uint32_t doc) {
+    return lead_norms ? uint32_t(lead_norms[sl]) : norm_value(seg, doc);
+  };
   auto flush = [&](uint32_t g0, uint32_t g1) {
     uint32_t scored = 0;
 #pragma unroll
@@ -355,7 +363,7 @@ k_conj(ConjArgs A, uint32_t pilot) {
       const bool on = sl < n && cnt[sl] == g1;
       if (counting) scored += uint32_t(__builtin_popcountll(wave::ballot(on)));
       if (on) {
-        const uint32_t nv = norm_value(seg, docs[sl]);
+        const uint32_t nv = lead_norm(sl, docs[sl]);
         float v = score[sl];
         for (uint32_t j = g0; j < g1; ++j)
           v = merge_scores(mrg, j == 0u, v, score_value(term_q(j), W.fr[j - g0][sl], nv));
@@ -517,7 +525,7 @@ k_conj(ConjArgs A, uint32_t pilot) {
     if (on) {
       const uint32_t sl = list[p0 + lane];
       doc = docs[sl];
-      const uint32_t nv = norm_value(seg, doc);
+      const uint32_t nv = lead_norm(sl, doc);
       v = score[sl];
       for (uint32_t j = g0; j < m; ++j)
         v = merge_scores(mrg, j == 0u, v, score_value(term_q(j), W.fr[j - g0][sl], nv));

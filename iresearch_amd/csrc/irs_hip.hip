@@ -643,6 +643,8 @@ int prepare_posting_norms(irs_hip_segment* s) {
     }
     if (!rt::last_error_ok() || !rt::sync(nullptr)) return IRS_HIP_EHIP;
     s->device_bytes += s->d_pnorm.n + s->d_tail_norms.n;
+    s->dev.pnorm = s->d_pnorm.as<uint8_t>();
+    s->dev.tail_norms = s->d_tail_norms.as<uint8_t>();
   }
   s->pnorm_ready = true;
   return IRS_HIP_OK;
@@ -1989,6 +1991,11 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
     } catch (...) {
       rc = IRS_HIP_ENOMEM;
     }
+  }
+  // (the block-driven kernels read the norms of a lead block's docs from the posting-order copy)
+  if (rc == IRS_HIP_OK && (b->phrase || !b->all_conj_units.empty())) {
+    for (irs_hip_segment* sg : b->segs)
+      if (rc == IRS_HIP_OK) rc = prepare_posting_norms(sg);
   }
   if (rc == IRS_HIP_OK) {
     if (b->jt == 0) b->jt = 1;

@@ -811,7 +811,11 @@ k_phrase(ConjArgs A, uint32_t pilot /*1: histogram the scores of the sampled lea
       }
       if (pf) {
         doc = docs[sl];
-        score = score_value(qt, pf, norm_value(seg, doc));
+        // (a posting of the lead block: its norm from the posting-order copy of the column)
+        const uint32_t nv = !seg.pnorm ? norm_value(seg, doc)
+                            : (item < ld.nblk ? seg.pnorm[(ld.dir_off + item) * kBlock + sl]
+                                              : seg.tail_norms[ld.tail_row + sl]);
+        score = score_value(qt, pf, nv);
         const uint32_t bin = score_bin(score, qd.bin_scale);
         if (pilot) atomicAdd(&A.hist[uint64_t(unit) * kBins + bin], 1u);
         else cand = bin >= bs;   // below the pilot's threshold bin: cannot be among the top k

@@ -118,6 +118,10 @@ struct DevSegment {
   uint32_t pos_base;         // what a doc's first delta is relative to: 0 (formats 1_3+, zero-based
                              // storage) or pos_limits::min() = 1 (1_0..1_2, formats_10.cpp:1623-1625)
   uint32_t norm_legacy;      // the norm column is the legacy `Norm` feature: float 1/sqrt(|doc|)
+  // the 1-byte Norm2 column once more, in POSTING order (null until a batch asks for it:
+  // prepare_posting_norms): 128 bytes per directory row, and per entry of tail_docs
+  const uint8_t* pnorm;
+  const uint8_t* tail_norms;
 };
 
 struct DevQuery {
