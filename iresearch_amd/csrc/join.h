@@ -637,40 +637,83 @@ k_join_pilot(const uint32_t* units, const DevQuery* queries, const DevQTerm* qte
   __syncthreads();
   join_prologue(smem, qd, qterms, jterms);
   const JoinLane T = join_lane(smem, lane);
-  const uint32_t* bnd = nullptr;
-  if (lane < qd.n_terms)
-    bnd = reinterpret_cast<const uint32_t*>(reinterpret_cast<const JoinTerm*>(smem + JoinOff::jts)[lane].bounds);
-  for (uint32_t tile = (q * 7u) % stride; tile < n_tiles; tile += stride) {
-    uint32_t a = 0, n = 0;
-    if (bnd) {
-      a = bnd[tile];
-      n = bnd[tile + 1u] - a;
-    }
-    JoinRun r;
+  // The sampled tiles in passes of kJoinChunkTiles: their boundaries first (one batch of loads
+  // into LDS: first entry and entry count per term), then tile after tile with the NEXT tile's
+  // first entries requested before this tile's barrier — they fly behind its epilogue, which
+  // reads and clears the accumulators with LDS exchanges (as k_join_score's).
+  uint32_t* row_a = reinterpret_cast<uint32_t*>(smem + JoinOff::rng);   // [pass tile][kMaxTerms]
+  uint32_t* row_n = reinterpret_cast<uint32_t*>(smem + JoinOff::cum);
+  const uint32_t first_tile = (q * 7u) % stride;
+  const uint32_t sampled_tiles = first_tile < n_tiles ? (n_tiles - first_tile + stride - 1) / stride : 0u;
+  const uint64_t safe = reinterpret_cast<uint64_t>(jterms);
+  auto histogram = [&](uint32_t f) {
+    if (!f) return;
     if (need_matches > 1u) {
-      join_begin<kJCount>(r, T, a, n, wave::inclusive_scan(n), wv, nw_log2,
-                          reinterpret_cast<uint64_t>(jterms), lane);
-      join_finish<kJCount>(smem, r, T, lane);
+      if ((f & kJoinCountMask) >= need_matches)
+        atomicAdd(&hist[score_bin(from_fixed<uint32_t>(f & ~kJoinCountMask, qd.fx_inv), qd.bin_scale)], 1u);
     } else {
-      join_begin<0>(r, T, a, n, wave::inclusive_scan(n), wv, nw_log2,
-                    reinterpret_cast<uint64_t>(jterms), lane);
-      join_finish<0>(smem, r, T, lane);
+      const float v = f <= kMaxTerms ? 0.f : from_fixed<uint32_t>(f, qd.fx_inv);
+      atomicAdd(&hist[score_bin(v, qd.bin_scale)], 1u);
+    }
+  };
+  for (uint32_t s0 = 0; s0 < sampled_tiles; s0 += kJoinChunkTiles) {
+    const uint32_t ns = sampled_tiles - s0 < kJoinChunkTiles ? sampled_tiles - s0 : kJoinChunkTiles;
+    __syncthreads();   // (the previous pass is through with the rows)
+    for (uint32_t e = tid; e < ns * kMaxTerms; e += blockDim.x) {
+      const uint32_t i = e / kMaxTerms, j = e % kMaxTerms;
+      uint32_t a = 0, n = 0;
+      if (j < qd.n_terms) {
+        const uint32_t* bnd = reinterpret_cast<const uint32_t*>(
+            reinterpret_cast<const JoinTerm*>(smem + JoinOff::jts)[j].bounds);
+        const uint32_t tile = first_tile + (s0 + i) * stride;
+        a = bnd[tile];
+        n = bnd[tile + 1u] - a;
+      }
+      row_a[e] = a;
+      row_n[e] = n;
     }
     __syncthreads();
-    for (uint32_t i = tid; i < kJoinTile; i += blockDim.x) {
-      const uint32_t f = acc[i];
-      if (f) {
-        acc[i] = 0u;
-        if (need_matches > 1u) {
-          if ((f & kJoinCountMask) >= need_matches)
-            atomicAdd(&hist[score_bin(from_fixed<uint32_t>(f & ~kJoinCountMask, qd.fx_inv), qd.bin_scale)], 1u);
-        } else {
-          const float v = f <= kMaxTerms ? 0.f : from_fixed<uint32_t>(f, qd.fx_inv);
-          atomicAdd(&hist[score_bin(v, qd.bin_scale)], 1u);
+    auto begin = [&](uint32_t i, JoinRun& r) {   // (i >= ns: an empty share)
+      uint32_t a = 0, n = 0;
+      if (lane < kMaxTerms && i < ns) {
+        a = row_a[i * kMaxTerms + lane];
+        n = row_n[i * kMaxTerms + lane];
+      }
+      if (need_matches > 1u)
+        join_begin<kJCount>(r, T, a, n, wave::inclusive_scan(n), wv, nw_log2, safe, lane);
+      else
+        join_begin<0>(r, T, a, n, wave::inclusive_scan(n), wv, nw_log2, safe, lane);
+    };
+    auto finish = [&](JoinRun& r) {
+      if (need_matches > 1u) join_finish<kJCount>(smem, r, T, lane);
+      else join_finish<0>(smem, r, T, lane);
+    };
+    auto end_tile = [&]() {
+      __syncthreads();
+      for (uint32_t i = tid * 4u; i < kJoinTile; i += blockDim.x * 4u) {
+        uint32_t v[4];
+        wave::lds_take4(smem, JoinOff::acc + i * 4u, v);
+        if (v[0] | v[1] | v[2] | v[3]) {
+          histogram(v[0]);
+          histogram(v[1]);
+          histogram(v[2]);
+          histogram(v[3]);
         }
       }
+      __syncthreads();
+    };
+    JoinRun r0, r1;
+    begin(0, r0);
+    for (uint32_t i = 0; i < ns; i += 2u) {
+      finish(r0);
+      begin(i + 1u, r1);
+      end_tile();
+      if (i + 1u < ns) {
+        finish(r1);
+        begin(i + 2u, r0);
+        end_tile();
+      }
     }
-    __syncthreads();
   }
   if (group_of && group_of[q]) {
     // one threshold for the units of a group (the same query on several segments,
