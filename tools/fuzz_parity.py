@@ -92,12 +92,19 @@ def main():
             b = sr.batch(prep, k)
             hits, counts, totals = (x.copy() for x in b.run().results())
             parity.check_single_segment(seg, filters, scorer, k, hits, counts, totals)
-            # block-max pruning: the same top-k
+            # the other execution path (work items / block-driven kernels): checked against the
+            # oracle like the first run (which took the joined streams wherever it could)
+            ib = sr.batch(prep, k).set_path(_lib.PATH_ITEMS)
+            ih, ic, it = (x.copy() for x in ib.run().results())
+            parity.check_single_segment(seg, filters, scorer, k, ih, ic, it)
+            assert np.array_equal(ic, counts) and np.array_equal(it, totals), "paths: counts"
+            ib.close()
+            # block-max pruning (runs on that path): the same top-k, bit for bit
             wb = sr.batch(prep, k).set_wand(True)
             wh, wc, wt = wb.run().results()
-            assert np.array_equal(counts, wc), "wand: counts"
+            assert np.array_equal(ic, wc), "wand: counts"
             for q in range(len(filters)):
-                assert np.array_equal(hits[q, :counts[q]], wh[q, :counts[q]]), ("wand: top-k", q)
+                assert np.array_equal(ih[q, :ic[q]], wh[q, :ic[q]]), ("wand: top-k", q)
             assert (wt <= totals).all()
             wb.close()
             # every third round: the same filters over several segments in ONE batch
@@ -111,10 +118,18 @@ def main():
                 readers = [sr] + [search.SegmentReader.from_synth(x, L=L) for x in extra]
                 mprep = search.prepare(filters, scorer, [parity.segment_stats(x) for x in msegs])
                 mb = search.QueryBatch(readers, mprep, k)
-                mh, mc, mt = mb.run().results()
+                mh, mc, mt = (x.copy() for x in mb.run().results())
                 for i, x in enumerate(msegs):
                     parity.check_single_segment(x, filters, scorer, k, mh[i], mc[i], mt[i], msegs)
                 mb.close()
+                # one threshold per query for all segments: the merged top k must not change
+                sb = search.QueryBatch(readers, mprep, k).set_shared_threshold(True)
+                sh, sc, stot = sb.run().results()
+                assert np.array_equal(stot, mt) and (sc <= mc).all(), "shared threshold: counts"
+                plain = search.merge_topk_host([(mh[i], mc[i]) for i in range(len(msegs))], k)
+                shared = search.merge_topk_host([(sh[i], sc[i]) for i in range(len(msegs))], k)
+                assert plain == shared, "shared threshold: merged top-k"
+                sb.close()
                 for r in readers[1:]:
                     r.close()
         # irs::score::Min = the k-th score: the same top-k again
