@@ -904,9 +904,11 @@ bool build_streams(irs_hip_batch* b) {
       jt.entries = streams[sid].entries;
       jt.bounds = streams[sid].bounds;
       jt.cs = qt.c0 * dq.fx_mul;
+      // (the form only matters for a term with frequencies beyond the table's rows: a TF-IDF
+      // batch whose terms all fit the tables runs the table-only loop like a BM25 one)
+      const bool general = qt.pad1 >= rows;
       jt.mode = (qt.cache_id * rows * 1024u) |
-                (qt.pad1 >= rows ? kJoinGeneral : 0u) |
-                (sqrt_kind(qt.kind) ? kJoinSqrt : 0u);
+                (general ? kJoinGeneral | (sqrt_kind(qt.kind) ? kJoinSqrt : 0u) : 0u);
     }
   }
   // (the slack behind the last stream is only ever read by masked-off look-ahead: zero it once)
