@@ -164,14 +164,10 @@ def main():
                     help="3 (default, with --gpus > 1: config 4): OR-of-8 BM25 top-1000 on 10 M docs; "
                          "5: AND-of-2..4 + 2-word by_phrase, TF-IDF, block-max WAND, on --docs "
                          "(default 50 M) docs in 8 segments with positions, 8 / N per GPU")
-    ap.add_argument("--query-sets", type=int, default=4,
-                    help="distinct query batches of the same distribution the steps rotate over "
-                         "(set 0 is BASELINE config 3's; no step replays the previous one)")
-    ap.add_argument("--plan-ahead", action="store_true",
-                    help="experiment: queue the planning stage of the next step's batch on a "
-                         "second stream (irs_hip_batch_plan). Measured SLOWER: the planner streams "
-                         "2.4 GB through L2 while k_score lives on cross-query L2 reuse "
-                         "(20.4 vs 13.1 ms per step)")
+    ap.add_argument("--query-sets", type=int, default=0,
+                    help="0 (default): every step executes a batch of queries that never ran before "
+                         "(created, run and destroyed inside the step); N > 0: the old protocol — N "
+                         "persistent batches of the same distribution replayed in rotation (A/B)")
     ap.add_argument("--no-shared-threshold", action="store_true",
                     help="A/B: every (segment, query) unit of a rank's batch keeps its own threshold")
     ap.add_argument("--per-segment-batches", action="store_true",
@@ -249,27 +245,39 @@ def main():
     log("staged to HBM in %.1f s (%.1f MB resident on rank 0)" %
         (time.perf_counter() - t0, sum(r.device_bytes() for r in readers.values()) / 1e6))
 
-    # ---- queries: prepared once (statistics are index-global) ---------------
-    # query set 0 = BASELINE config 3 (seed + 2); further sets: same distribution, other seeds
-    n_sets = max(1, args.query_sets)
+    # ---- queries ---------------------------------------------------------------
+    # A step executes a batch of queries THAT HAS NEVER RUN: new term rows (their own seed; set 0
+    # = BASELINE config 3, seed + 2), prepared (index-global statistics -> scorer constants,
+    # by_term::prepare + BM25::collect), turned into a batch (irs_hip_batch_create_multi: the
+    # per-query records, the batch's distinct posting streams, the work lists of the kernels),
+    # run, checked, delivered, destroyed — all inside the step, as the reference's harness builds
+    # and prepares the filter and constructs the iterators inside its timers
+    # (index-search.cpp:694-722).  Only the random term rows themselves are drawn ahead.
+    # --query-sets N > 0: the round-1..3 protocol (N persistent batches replayed in rotation).
+    replay = args.query_sets > 0
+    n_probe = 3            # isolated (unpipelined) fresh batches, timed one by one
+    n_host = 0 if (world > 1 or sim) else max(2, min(args.steps, 8))
+    n_rows = max(1, args.query_sets) if replay else min(64, n_probe + args.warmup + args.steps + n_host)
     rank_sets = [synth.make_queries(args.queries, args.terms, 16, 4096,
-                                    synth.SEED + 2 + (10 + i if i else 0)) for i in range(n_sets)]
+                                    synth.SEED + 2 + (10 + i if i else 0)) for i in range(n_rows)]
     ranks = rank_sets[0]
-    # ONE batch per rank (and query set) over all of its segments (irs_hip_batch_create_multi):
-    # every kernel is launched once for all (segment, query) pairs.  --per-segment-batches: one
-    # batch per segment, back to back (A/B).
+    scorer = BM25()
+    # ONE batch per rank over all of its segments (irs_hip_batch_create_multi): every kernel is
+    # launched once for all (segment, query) pairs.  --per-segment-batches: one batch per
+    # segment, back to back (A/B).
     if len(my) > 1 and not args.per_segment_batches:
         groups = {my[0]: list(my)}
     else:
         groups = {s: [s] for s in my}
-    batch_sets = []
-    for rk in rank_sets:
-        filters = [Or([by_term(int(r) - 1) for r in row]) for row in rk]
-        prepared = search.prepare(filters, BM25(), seg_stats)
-        batches = {}
+    nq, k = args.queries, args.k
+
+    def make_batches(i):
+        rows = rank_sets[i % n_rows].astype(np.int64) - 1      # rank r is term ordinal r - 1
+        out = {}
         for lead, members in groups.items():
-            b = search.QueryBatch([readers[s] for s in members], prepared, args.k) \
-                if len(members) > 1 else readers[lead].batch(prepared, args.k)
+            rs = [readers[s] for s in members]
+            arrays = search.prepare_disjunctions(rows, scorer, seg_stats, rs, k)
+            b = search.QueryBatch(rs if len(members) > 1 else rs[0], arrays)
             if args.tile or args.stride:
                 b.configure(args.tile, args.stride, 0)
             if len(members) > 1 and not args.no_shared_threshold:
@@ -277,13 +285,11 @@ def main():
                 # a rank look for a query's k best docs TOGETHER (irs_hip_batch_set_shared_threshold)
                 b.set_shared_threshold(True)
             b.profile(True)
-            batches[lead] = b
-        batch_sets.append(batches)
-    batches = batch_sets[0]
+            out[lead] = b
+        return out
+
+    batch_sets = [make_batches(i) for i in range(n_rows)] if replay else None
     sptr = None if sim else C_void(torch.cuda.current_stream(dev).cuda_stream)
-    plan_stream = torch.cuda.Stream(device=dev) if (args.plan_ahead and not sim) else None
-    plan_ptr = None if plan_stream is None else C_void(plan_stream.cuda_stream)
-    nq, k = args.queries, args.k
     # every buffer of the exchange step is allocated once (twice: two sets alternate); each
     # local segment's results are written straight into its slot of the send buffer
     # the collective goes through the library's own RCCL communicator (irs_hip_comm_*); torch
@@ -295,8 +301,8 @@ def main():
                                              world, nq, k, dev, comm=comm)
     # a multi-segment batch writes [segment][query][k] hits and [segment][query] counts: exactly
     # consecutive slots of the send buffer
-    slots = [{lead: exchange.slot(ph, my.index(lead)) for lead in batches} for ph in (0, 1)]
-    state = {"it": 0}
+    slots = [{lead: exchange.slot(ph, my.index(lead)) for lead in groups} for ph in (0, 1)]
+    state = {"it": 0, "work": [], "joined": True, "reruns": 0, "retire": []}
 
     def deliver(prev):
         # a finished step: checked (irs_hip_batch_results_to_device waits for THAT batch's own
@@ -313,33 +319,37 @@ def main():
         if rank == 0 and state.get("collect") is not None:
             # per-kernel HIP-event timings of that step (the batch's own events: no stream sync)
             state["collect"].append(np.sum([cur[s].timings() for s in cur], axis=0))
+            state["work"].append(np.sum([cur[s].work() for s in cur], axis=0))
+        state["joined"] = state["joined"] and all(b.path() == _lib.PATH_JOINED for b in cur.values())
         if multi:
             exchange.start(ph)
+        if not replay:
+            # a delivered batch is destroyed one step LATER: its result copies were queued behind
+            # the next step's kernels, and irs_hip_batch_destroy waits for them (its buffers go
+            # back to the library's pool) — by then they are through
+            for b in state["retire"]:
+                state["reruns"] += b.reruns()
+                b.close()
+            state["retire"] = list(cur.values())
 
     def step(host_results=False):
-        # Steps rotate over the query sets and are software-pipelined one deep: the kernels of
-        # step i are enqueued FIRST, then step i-1 is verified and delivered — the host waits
-        # on step i-1's event while the GPU already runs step i, so there is no per-step
-        # host/device round trip on the critical path.  Every step still ends (one step later;
-        # flush() for the last) with a checked, device-resident top-k.  host_results: the hits
-        # also go to host memory (irs_hip_batch_results), where the reference's harness ends
+        # Steps are software-pipelined one deep: the batch of step i is prepared, created and
+        # its kernels enqueued FIRST, then step i-1 is verified and delivered — the host builds
+        # step i while the GPU still runs step i-1, and waits on step i-1's event while the GPU
+        # already runs step i: no per-step host/device round trip on the critical path.  Every
+        # step still ends (one step later; flush() for the last) with a checked,
+        # device-resident top-k.  host_results: the hits also go to host memory
+        # (irs_hip_batch_results), where the reference's harness ends
         # (index-search.cpp:782-807) — that variant is not pipelined.
         ph = state["it"] & 1
-        cur = batch_sets[state["it"] % n_sets]
+        cur = batch_sets[state["it"] % n_rows] if replay else make_batches(state["it"])
         state["it"] += 1
-        state["cur"] = cur
         prev = state.get("prev")
         if prev is not None and (prev[0] is cur or host_results or prev[2]):
-            deliver(prev)     # the same batch again (one query set): its results go out first
+            deliver(prev)     # the same batch again (replay of one set): its results go out first
             prev = None
         for s in cur:
             cur[s].run(sptr)
-        # --plan-ahead (off by default, see its help): the planning stage of the NEXT step's
-        # batch on a second stream, overlapping this step's scoring kernels
-        nxt = batch_sets[state["it"] % n_sets]
-        if plan_ptr is not None and nxt is not cur and not host_results:
-            for s in nxt:
-                nxt[s].plan(plan_ptr)
         if prev is not None:
             deliver(prev)
         state["prev"] = (cur, ph, host_results)
@@ -348,34 +358,45 @@ def main():
         prev = state.pop("prev", None)
         if prev is not None:
             deliver(prev)
-        return exchange.finish(sptr) if multi else None
+        out = exchange.finish(sptr) if multi else None
+        if not replay:
+            sync()
+            for b in state["retire"]:
+                state["reruns"] += b.reruns()
+                b.close()
+            state["retire"] = []
+        return out
 
-    # first execution of every batch (a fresh query set): timed apart, outside the steps —
-    # includes whatever re-run a misled threshold estimate costs
+    def total_reruns():
+        if replay:
+            return sum(b[s].reruns() for b in batch_sets for s in b)
+        return state["reruns"]
+
+    # isolated executions of never-seen batches (no pipelining: host preparation + kernels +
+    # verification in sequence), timed one by one — includes whatever re-run a misled threshold
+    # estimate costs; the first also pays the allocations the pool keeps from then on
     first_ms = []
-    for _ in range(n_sets):
+    for _ in range(n_rows if replay else n_probe):
         sync()
         t0 = time.perf_counter()
         step()
         flush()
         sync()
         first_ms.append(1e3 * (time.perf_counter() - t0))
-    state["it"] = 0
-    reruns_before = sum(b[s].reruns() for b in batch_sets for s in b)
+    if replay:
+        state["it"] = 0
     for _ in range(args.warmup):
         step()
     flush()
     sync()
-    # sanity: results are retrievable
-    for s in batches:
-        batches[s].results()
-    reruns_warm = sum(b[s].reruns() for b in batch_sets for s in b)
+    reruns_warm = total_reruns()
     score_ms = []
     if world > 1:
         dist.barrier()
     sync()
     t0 = time.perf_counter()
     state["collect"] = score_ms
+    state["work"] = []
     for _ in range(args.steps):
         step()
     flush()
@@ -384,11 +405,10 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    reruns_timed = sum(b[s].reruns() for b in batch_sets for s in b) - reruns_warm
+    reruns_timed = total_reruns() - reruns_warm
     # the same steps with the hits copied to host memory in every step (not `value`)
     host_elapsed = None
-    if world == 1 and not sim:
-        n_host = max(2, min(args.steps, 8))
+    if n_host:
         sync()
         t0 = time.perf_counter()
         for _ in range(n_host):
@@ -401,11 +421,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    reruns = sum(b[s].reruns() for b in batch_sets for s in b)
-    # per step, averaged over the query sets the steps rotated over
-    used = [batch_sets[i % n_sets] for i in range(args.steps)]
-    alg_bytes = sum(b[s].work()[0] for b in used for s in b) / len(used)
-    postings = sum(b[s].work()[1] for b in used for s in b) / len(used)
+    reruns = total_reruns()
+    # per step, averaged over the timed steps (rank 0 collected them; the other ranks' shares
+    # are summed below)
+    if rank == 0 and state["work"]:
+        alg_bytes, postings = [float(x) for x in np.mean(np.array(state["work"], dtype=np.float64), axis=0)]
+    else:
+        wb = batch_sets[0] if replay else make_batches(0)
+        alg_bytes, postings = [float(x) for x in np.sum([wb[s].work() for s in wb], axis=0)]
+        if not replay:
+            for b in wb.values():
+                b.close()
+    batches = groups
+    joined = state["joined"]
     rank0_alg_bytes = alg_bytes
     if world > 1:
         t = torch.tensor([alg_bytes, postings], dtype=torch.float64, device=dev)
@@ -419,7 +447,6 @@ def main():
         if score_ms:
             ms = np.array(score_ms)                    # [steps][K_COUNT]
             avg = ms.mean(axis=0)
-            joined = all(b.path() == _lib.PATH_JOINED for b in batches.values())
             tr = measured_traffic()
             if joined:
                 # joined posting streams: the algorithmic bytes of a step flow through TWO
@@ -429,21 +456,20 @@ def main():
                 # k_join_score alone, the dominant kernel, is given next to it.
                 stage_ms = float(avg[_lib.K_PLAN] + avg[_lib.K_SCORE])
                 achieved = rank0_alg_bytes / (stage_ms * 1e-3) / 1e9
-                alone = rank0_alg_bytes / (float(avg[_lib.K_SCORE]) * 1e-3) / 1e9
                 names = _lib.KERNEL_NAMES_JOINED
                 kernel = "k_join + k_join_score"
             else:
                 # k_score on rank 0: its algorithmic bytes / its summed launch time per step
                 stage_ms = float(avg[_lib.K_SCORE])
-                achieved = alone = rank0_alg_bytes / (stage_ms * 1e-3) / 1e9
+                achieved = rank0_alg_bytes / (stage_ms * 1e-3) / 1e9
                 names = _lib.KERNEL_NAMES
                 kernel = "k_score"
             roof = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                    # (no fraction of its own for the larger of the two kernels: the algorithmic
+                    # bytes are consumed by the decode stage, not by it)
                     "dominant_kernel": {"name": "k_join_score" if joined else "k_score",
-                                        "avg_launch_ms": round(float(avg[_lib.K_SCORE]), 4),
-                                        "achieved": round(alone, 2),
-                                        "frac": round(alone / HBM_PEAK_GBS, 5)},
+                                        "avg_launch_ms": round(float(avg[_lib.K_SCORE]), 4)},
                     # HBM-side bytes per step of those kernels (PMC: 2 x FETCH_SIZE + WRITE_SIZE,
                     # separate rocprofv3 passes of this command at these kernel sources), else null
                     "traffic": None if (multi or tr is None) else int(tr["bytes"]),
@@ -465,11 +491,15 @@ def main():
                 "segments": n_segments, "queries_per_step": nq, "layout": "1_5simd",
                 "indexed_ranks": args.max_rank,
                 "path": "joined posting streams (k_join once per distinct term of the batch, "
-                        "k_join_score per query)" if all(b.path() == _lib.PATH_JOINED
-                                                         for b in batches.values())
+                        "k_join_score per query)" if joined
                         else "work items (every query decodes its own blocks)",
                 "postings_per_step": int(postings), "algorithmic_bytes_per_step": int(alg_bytes),
-                "query_sets": n_sets, "first_run_ms_per_set": [round(x, 3) for x in first_ms],
+                "batches": ("%d persistent batches replayed in rotation (--query-sets)" % n_rows) if replay
+                           else "every step prepares, creates, runs and destroys a batch of queries "
+                                "that never ran before (%d distinct query sets)" % n_rows,
+                "query_sets": n_rows,
+                # isolated (unpipelined) never-seen batches: host preparation + kernels + check
+                "first_run_ms_per_set": [round(x, 3) for x in first_ms],
                 "reruns_rank0": int(reruns), "reruns_in_timed_steps": int(reruns_timed),
                 "parallelism": ("%d segments over %d GPU(s) + RCCL all-gather of per-segment "
                                 "top-k + GPU merge" % (n_segments, world)) if multi
@@ -482,7 +512,7 @@ def main():
             "roofline": roof,
         }
     if rank == 0 and not multi and not args.no_cpu:
-        for bs in batch_sets:
+        for bs in (batch_sets or []):
             for b in bs.values():
                 b.close()
         out["cpu_baseline"] = cpu_baseline(segs[0], ranks, k)
@@ -553,22 +583,35 @@ def main_config5(args):
     readers = [search.SegmentReader.from_synth(segs[s], device=local_rank, L=L) for s in my]
     log("staged: %.1f MB resident on rank 0" % (sum(r.device_bytes() for r in readers) / 1e6))
     nq, k = args.queries, args.k if args.k != 1000 else 100
-    ands = []
-    for n_terms in (2, 3, 4):
-        for row in synth.make_queries((nq + 2) // 3, n_terms, 16, 4096, synth.SEED + 5 + n_terms):
-            ands.append(And([by_term(int(r) - 1) for r in row]))
-    ands = ands[:nq]
-    phrases = [by_phrase([int(r) - 1 for r in row])
-               for row in synth.make_queries(nq, 2, 16, 4096, synth.SEED + 9)]
     sc = TFIDF(False)
-    bat = {}
-    for name, fl in (("and", ands), ("phrase", phrases)):
-        prep = search.prepare(fl, sc, seg_stats)
-        b = search.QueryBatch(readers, prep, k) if len(readers) > 1 else readers[0].batch(prep, k)
-        if name == "and":
-            b.set_wand(True)
-        b.profile(True)
-        bat[name] = b
+    # Query sets (set 0 = the configuration's own seeds): a step creates its two batches anew
+    # from the prepared arrays of the next set, runs them and destroys them — no batch object
+    # is executed twice (the filters' statistics are collected ahead, once per set).
+    n_sets = max(1, min(4, args.query_sets if args.query_sets > 0 else 4))
+    sets = []
+    for i in range(n_sets):
+        ands_i = []
+        for n_terms in (2, 3, 4):
+            for row in synth.make_queries((nq + 2) // 3, n_terms, 16, 4096,
+                                          synth.SEED + 5 + n_terms + 100 * i):
+                ands_i.append(And([by_term(int(r) - 1) for r in row]))
+        ands_i = ands_i[:nq]
+        phrases_i = [by_phrase([int(r) - 1 for r in row])
+                     for row in synth.make_queries(nq, 2, 16, 4096, synth.SEED + 9 + 100 * i)]
+        arrays = {name: search.QueryArrays.from_prepared(readers, search.prepare(fl, sc, seg_stats), k)
+                  for name, fl in (("and", ands_i), ("phrase", phrases_i))}
+        sets.append((ands_i, phrases_i, arrays))
+    ands, phrases = sets[0][0], sets[0][1]
+
+    def make_batches(i):
+        out = {}
+        for name, arrays in sets[i % n_sets][2].items():
+            b = search.QueryBatch(readers if len(readers) > 1 else readers[0], arrays)
+            if name == "and":
+                b.set_wand(True)
+            b.profile(True)
+            out[name] = b
+        return out
     sptr = None if sim else C_void(torch.cuda.current_stream(dev).cuda_stream)
     # the collective goes through the library's own RCCL communicator (irs_hip_comm_*), as in
     # the headline config; one communicator serves both exchanges
@@ -577,11 +620,13 @@ def main_config5(args):
         comm = distributed.agreed_communicator(L, local_rank, rank, world, dev, log)
     ex = {name: distributed.PipelinedExchange(L, local_rank, n_segments, rank, world, nq, k, dev,
                                               comm=comm)
-          for name in bat}
-    it = {"n": 0}
+          for name in ("and", "phrase")}
+    it = {"n": 0, "retire": []}
+    kms = None
 
     def step():
         ph = it["n"] & 1
+        bat = make_batches(it["n"])
         it["n"] += 1
         for name, b in bat.items():
             b.run(sptr)
@@ -590,6 +635,12 @@ def main_config5(args):
             hp, cp = ex[name].slot(ph, 0)
             b.results_to_device(hp, cp, sptr)
             ex[name].start(ph)
+        if rank == 0 and kms is not None:
+            kms.append({n: b.timings() for n, b in bat.items()})
+        # (destroyed one step later: irs_hip_batch_destroy waits for the copies just queued)
+        for b in it["retire"]:
+            b.close()
+        it["retire"] = list(bat.values())
 
     for _ in range(max(1, args.warmup)):
         step()
@@ -603,18 +654,20 @@ def main_config5(args):
     kms = []
     for _ in range(args.steps):
         step()
-        if rank == 0:
-            kms.append({n: b.timings() for n, b in bat.items()})
     for e in ex.values():
         e.finish(sptr)
     sync()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    for b in it["retire"]:
+        b.close()
+    it["retire"] = []
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    bat = make_batches(0)
     alg = {n: b.work() for n, b in bat.items()}
     # what the kernels really decoded: one extra, untimed run with the counters on
     touched = {}

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define IRS_HIP_ABI_VERSION 6
+#define IRS_HIP_ABI_VERSION 7
 #define IRS_HIP_BLOCK_SIZE 128u  /* postings per block, formats_10.cpp:90 */
 #define IRS_HIP_MAX_TERMS 16u    /* terms per boolean query               */
 #define IRS_HIP_MAX_K 4096u      /* largest top-k                         */
@@ -428,6 +428,12 @@ void irs_hip_device_free(int32_t device, void* d_ptr);
 int irs_hip_device_upload(int32_t device, void* d_dst, const void* h_src, uint64_t bytes);
 int irs_hip_device_download(int32_t device, void* h_dst, const void* d_src, uint64_t bytes);
 int irs_hip_device_sync(int32_t device, void* stream);
+/* The library recycles the device and page-locked memory of destroyed batches and closed
+ * segments (hipMalloc / hipFree / hipHostMalloc cost more than a batch's kernels, and hipFree
+ * synchronises the device): up to 64 GB per device stay with the library (IRS_HIP_POOL_MB
+ * overrides).  This hands all of it back to the runtime — postings_reader::CountMappedMemory's
+ * counterpart for callers that watch their memory (formats.hpp:190). */
+int irs_hip_device_trim(int32_t device);
 
 typedef struct irs_hip_comm irs_hip_comm;
 #define IRS_HIP_COMM_ID_BYTES 128u

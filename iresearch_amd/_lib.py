@@ -75,6 +75,7 @@ SYMBOLS = (
     "irs_hip_comm_library",
     "irs_hip_topk_allgather", "irs_hip_device_alloc", "irs_hip_device_free",
     "irs_hip_device_upload", "irs_hip_device_download", "irs_hip_device_sync",
+    "irs_hip_device_trim",
 )
 
 
@@ -141,6 +142,7 @@ def bind(L: C.CDLL) -> C.CDLL:
     L.irs_hip_comm_library.argtypes, L.irs_hip_comm_library.restype = [C.c_char_p, C.c_size_t], C.c_int
     L.irs_hip_topk_allgather.argtypes = [vp, vp, vp, u64, vp]
     L.irs_hip_topk_allgather.restype = C.c_int
+    L.irs_hip_device_trim.argtypes, L.irs_hip_device_trim.restype = [i32], C.c_int
     return L
 
 

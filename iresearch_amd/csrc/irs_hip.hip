@@ -4,9 +4,11 @@
 #include "irs_hip.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -26,26 +28,165 @@ constexpr uint32_t kDefaultStride = 64;
 constexpr uint32_t kPilotMargin = 3;   // estimated threshold: aim at margin * k candidates
 constexpr uint32_t kDefaultWgThreads = 512;  // 8 wavefronts share one tile (measured best)
 
-struct DevBuf {  // owning device allocation
+// Freed device / page-locked memory is kept per device and handed out again (size classes of
+// 1/8 of a power of two): hipMalloc, hipFree and hipHostMalloc cost 0.1 - 1 ms apiece and hipFree
+// synchronises the device — a batch that is created, run once and destroyed (the normal life of
+// a batch) would spend more time in the allocator than in its kernels.  Whoever returns a block
+// has made sure no queued work still touches it (irs_hip_batch_destroy waits for the batch's own
+// events).  irs_hip_device_trim() gives everything back to the runtime.
+namespace pool {
+constexpr int kMaxDevices = 16;
+struct Bin {
+  std::mutex m;
+  std::multimap<size_t, void*> blocks;   // capacity -> block
+  size_t cached = 0;
+};
+inline Bin& bin(int device, bool pinned) {
+  static Bin bins[2][kMaxDevices];
+  return bins[pinned ? 1 : 0][device >= 0 && device < kMaxDevices ? device : 0];
+}
+inline size_t size_class(size_t n) {
+  size_t step = 4096;
+  while (step * 16 <= n) step <<= 1;   // step = 2^floor(log2 n) / 8 for n >= 64 KB
+  return (std::max<size_t>(n, 1) + step - 1) / step * step;
+}
+inline size_t cap_bytes() {
+  if (const char* e = std::getenv("IRS_HIP_POOL_MB")) return size_t(std::atoll(e)) << 20;
+  return rt::pool_cap_bytes();
+}
+inline void release_all(int device, bool pinned) {
+  Bin& b = bin(device, pinned);
+  std::lock_guard<std::mutex> lock(b.m);
+  for (auto& kv : b.blocks) pinned ? rt::hfree(kv.second) : rt::dfree(kv.second);
+  b.blocks.clear();
+  b.cached = 0;
+}
+// `*cap` = the block's capacity (what give() wants back)
+inline void* take(int device, bool pinned, size_t bytes, size_t* cap) {
+  const size_t want = size_class(bytes);
+  Bin& b = bin(device, pinned);
+  {
+    std::lock_guard<std::mutex> lock(b.m);
+    auto it = b.blocks.lower_bound(want);
+    if (it != b.blocks.end() && it->first <= want + want / 4) {
+      void* p = it->second;
+      *cap = it->first;
+      b.cached -= it->first;
+      b.blocks.erase(it);
+      rt::poison(p, *cap);
+      return p;
+    }
+  }
+  void* p = pinned ? rt::hmalloc(want) : rt::dmalloc(want);
+  if (!p) {   // out of memory with blocks of other sizes lying around: give them back first
+    release_all(device, pinned);
+    p = pinned ? rt::hmalloc(want) : rt::dmalloc(want);
+  }
+  *cap = p ? want : 0;
+  return p;
+}
+inline void give(int device, bool pinned, void* p, size_t cap) {
+  if (!p) return;
+  Bin& b = bin(device, pinned);
+  {
+    std::lock_guard<std::mutex> lock(b.m);
+    if (b.cached + cap <= cap_bytes()) {
+      b.blocks.emplace(cap, p);
+      b.cached += cap;
+      return;
+    }
+  }
+  pinned ? rt::hfree(p) : rt::dfree(p);
+}
+}  // namespace pool
+
+template<bool PINNED>
+struct PoolBuf {  // owning allocation out of the pool of the device that was current at alloc()
   void* p = nullptr;
-  size_t n = 0;
-  DevBuf() = default;
-  DevBuf(const DevBuf&) = delete;
-  DevBuf& operator=(const DevBuf&) = delete;
-  ~DevBuf() { rt::dfree(p); }
+  size_t n = 0;     // bytes asked for
+  size_t cap = 0;   // the block's capacity
+  int device = 0;
+  PoolBuf() = default;
+  PoolBuf(const PoolBuf&) = delete;
+  PoolBuf& operator=(const PoolBuf&) = delete;
+  PoolBuf(PoolBuf&& o) noexcept : p(o.p), n(o.n), cap(o.cap), device(o.device) {
+    o.p = nullptr;
+    o.n = o.cap = 0;
+  }
+  ~PoolBuf() { release(); }
   bool alloc(size_t bytes) {
-    rt::dfree(p);
-    p = rt::dmalloc(bytes);
+    if (p && bytes <= cap && pool::size_class(bytes) == cap) {   // the same block would come back
+      n = bytes;
+      return true;
+    }
+    release();
+    device = rt::current_device();
+    p = pool::take(device, PINNED, bytes, &cap);
     n = p ? bytes : 0;
     return p != nullptr;
   }
   void release() {
-    rt::dfree(p);
+    pool::give(device, PINNED, p, cap);
     p = nullptr;
-    n = 0;
+    n = cap = 0;
   }
   template<typename T>
   T* as() const { return static_cast<T*>(p); }
+};
+using DevBuf = PoolBuf<false>;
+using PinBuf = PoolBuf<true>;
+
+// Host -> device uploads of a batch: the bytes are built in (or copied into) page-locked memory
+// and go out with asynchronous copies on the stream of the batch's next run — no copy from
+// pageable memory (the runtime stages those synchronously), no stream synchronisation, so a
+// caller's host thread prepares batch i + 1 while the device still executes batch i.
+struct Stager {
+  struct Piece { void* dst; const void* src; size_t n; };
+  std::vector<PinBuf> chunks;
+  size_t used = 0;   // of chunks.back()
+  std::vector<Piece> pending;
+  // n bytes of page-locked memory that will be copied to `dst`: the caller fills them before
+  // the next flush()
+  void* put(void* dst, size_t n) {
+    if (!n) return nullptr;
+    const size_t need = (n + 63) & ~size_t(63);
+    if (chunks.empty() || used + need > chunks.back().n) {
+      PinBuf c;
+      if (!c.alloc(std::max<size_t>(need, size_t(1) << 20))) return nullptr;
+      chunks.push_back(std::move(c));
+      used = 0;
+    }
+    void* at = chunks.back().as<uint8_t>() + used;
+    used += need;
+    pending.push_back(Piece{dst, at, n});
+    return at;
+  }
+  bool copy(void* dst, const void* src, size_t n) {
+    if (!n) return true;
+    void* at = put(dst, n);
+    if (!at) return false;
+    std::memcpy(at, src, n);
+    return true;
+  }
+  bool flush(rt::stream_t st) {
+    bool ok = true;
+    for (const Piece& p : pending) ok = ok && rt::h2d(p.dst, p.src, p.n, st);
+    pending.clear();
+    return ok;
+  }
+};
+
+// IRS_HIP_TRACE=1: host-side stage times on stderr (what a batch costs before its first kernel)
+struct HostTrace {
+  const char* what;
+  std::chrono::steady_clock::time_point t0;
+  explicit HostTrace(const char* w) : what(w), t0(std::chrono::steady_clock::now()) {}
+  ~HostTrace() {
+    static const bool on = std::getenv("IRS_HIP_TRACE") != nullptr;
+    if (on)
+      std::fprintf(stderr, "[irs_hip] %s: %.1f us\n", what,
+                   std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+  }
 };
 
 bool device_usable(int device) {
@@ -151,8 +292,7 @@ struct irs_hip_batch {
   DevBuf d_conj_pilot;             // the lead items the pilot pass samples, {unit, item} each
   uint32_t n_conj_pilot = 0, conj_pilot_stride = 0;
   bool phrase = false;  // a batch of by_phrase queries (k_phrase instead of k_pilot + k_score)
-  void* h_pin = nullptr;       // page-locked staging for irs_hip_batch_results
-  size_t h_pin_bytes = 0;
+  PinBuf h_pin;                // page-locked staging for irs_hip_batch_results
   uint32_t n_phrase_wgs = 0;   // k_phrase workgroups: kPhraseWaves lead blocks each
   bool acc32 = true;   // 32-bit fixed-point accumulators are precise enough for every query
   bool scratch_ready = false;
@@ -165,7 +305,8 @@ struct irs_hip_batch {
   DevBuf d_tile_off, d_scan_parts, d_items, d_score_args, d_tile_ub;
   DevBuf d_pruned;    // [unit] u32: block-max pruning skipped something of the unit in this run
   DevBuf d_touched;   // [unit][2] u64: bytes decoded / positions read by the block-driven kernels
-  ScoreArgs score_args{};
+  ScoreArgs score_args{}, score_args_sent{};
+  bool score_args_valid = false;
   uint32_t total_tiles = 0;    // doc tiles of all units
   uint32_t score_threads = 0;  // threads per k_pilot / k_score workgroup (power of two x 64)
   uint32_t nw_log2 = 3;        // log2(wavefronts per such workgroup)
@@ -187,6 +328,8 @@ struct irs_hip_batch {
   DevBuf d_group_members;      // [nq_user][n_segs] unit or 0xFFFFFFFF
   DevBuf d_group_hist;         // [nq_user][kBins + 2]
   JoinArgs join_args[2]{};   // plain disjunctions / units with match counts
+  JoinArgs join_args_sent[2]{};   // ... as the device last got them
+  bool join_args_valid[2] = {false, false};
   uint32_t n_join_plain = 0; // join_units in d_join_order: the plain ones first
   uint32_t join_first[2][kJoinQueues + 1]{};   // [launch] the queues' first slots in d_join_order
   DevBuf d_join_ctr;                           // [launch][kJoinQueues] work counters
@@ -204,8 +347,16 @@ struct irs_hip_batch {
   bool ev_planned_ready = false;
   bool planned = false;
   uint32_t* h_status = nullptr;
+  PinBuf h_status_buf;
   rt::stream_t stream = nullptr;
   bool ran = false;
+  // host -> device tables of the batch: built in page-locked memory, sent with the next run
+  Stager up;
+  bool slack_zeroed = false;   // the readable slack behind d_entries
+  // the last copy OUT of the batch's buffers queued by irs_hip_batch_results_to_device (destroy
+  // waits for it and for ev_done — never for the stream, which may hold other batches' work)
+  rt::event_t ev_used{};
+  bool ev_used_ready = false, ev_used_pending = false;
 };
 
 namespace {
@@ -383,9 +534,13 @@ bool launch_score(irs_hip_batch* b, rt::stream_t st) {
   a.n_units = n_units;
   a.nw_log2 = b->nw_log2;
   a.cand_cap = b->cand_cap;
-  if (!rt::dmemset(b->d_work.p, 0, 4, st) ||
-      !rt::h2d(b->d_score_args.p, &a, sizeof a, st))
-    return false;
+  // (the arguments only change with the batch's geometry or a regrown candidate buffer)
+  if (std::memcmp(&a, &b->score_args_sent, sizeof a) != 0 || !b->score_args_valid) {
+    if (!b->up.copy(b->d_score_args.p, &a, sizeof a) || !b->up.flush(st)) return false;
+    std::memcpy(&b->score_args_sent, &a, sizeof a);
+    b->score_args_valid = true;
+  }
+  if (!rt::dmemset(b->d_work.p, 0, 4, st)) return false;
   RT_LAUNCH(kern, grid, b->score_threads, smem, st, reinterpret_cast<uint64_t>(b->d_score_args.p));
   return rt::last_error_ok();
 }
@@ -536,9 +691,10 @@ bool ensure_pilot_list(irs_hip_batch* b, uint32_t stride, rt::stream_t st) {
     for (uint32_t it = (u * 7u) % stride; it < b->conj_items[c]; it += stride)
       pl.push_back(PhraseWg{u, it});
   }
-  if (!b->d_conj_pilot.alloc(std::max<size_t>(1, pl.size()) * sizeof(PhraseWg)) || !rt::sync(st) ||
-      !rt::h2d(b->d_conj_pilot.p, pl.data(), pl.size() * sizeof(PhraseWg), nullptr) ||
-      !rt::sync(nullptr))
+  // (the list being replaced may still be read by a run in flight: recoveries come here)
+  if ((b->d_conj_pilot.p && !rt::sync(st)) ||
+      !b->d_conj_pilot.alloc(std::max<size_t>(1, pl.size()) * sizeof(PhraseWg)) ||
+      !b->up.copy(b->d_conj_pilot.p, pl.data(), pl.size() * sizeof(PhraseWg)) || !b->up.flush(st))
     return false;
   b->n_conj_pilot = uint32_t(pl.size());
   b->conj_pilot_stride = stride;
@@ -802,16 +958,22 @@ bool build_streams(irs_hip_batch* b) {
   // Ordered by where in the doc space a workgroup's blocks lie — estimated as its position
   // inside its list — the ones in flight share a doc range, i.e. norm cache lines.
   {
-    std::vector<std::pair<float, WgRef>> keyed;
-    keyed.reserve(wgs.size());
-    for (const WgRef& w : wgs) {
-      const DevTerm& t = b->segs[streams[w.stream].seg]->terms[streams[w.stream].term];
+    // (a counting sort over 1024 positions per segment: this runs once per batch on the host,
+    // in front of the batch's first kernel)
+    constexpr uint32_t kPos = 1024;
+    std::vector<uint32_t> key(wgs.size()), start(b->segs.size() * kPos + 1, 0);
+    for (size_t i = 0; i < wgs.size(); ++i) {
+      const StreamRec& sr = streams[wgs[i].stream];
+      const DevTerm& t = b->segs[sr.seg]->terms[sr.term];
       const uint32_t nb = t.nblk + ((t.docs_count == 1 || t.tail_n) ? 1u : 0u);
-      keyed.push_back({float(streams[w.stream].seg) + (float(w.first) + 0.5f * kJoinBlocks) / float(nb + kJoinBlocks), w});
+      const uint64_t at = (uint64_t(2u * wgs[i].first + kJoinBlocks) * kPos) / (2ull * (nb + kJoinBlocks));
+      key[i] = sr.seg * kPos + uint32_t(std::min<uint64_t>(at, kPos - 1));
+      ++start[key[i] + 1];
     }
-    std::stable_sort(keyed.begin(), keyed.end(),
-                     [](const auto& x, const auto& y) { return x.first < y.first; });
-    for (size_t i = 0; i < wgs.size(); ++i) wgs[i] = keyed[i].second;
+    for (size_t k = 1; k < start.size(); ++k) start[k] += start[k - 1];
+    std::vector<WgRef> sorted(wgs.size());
+    for (size_t i = 0; i < wgs.size(); ++i) sorted[start[key[i]]++] = wgs[i];
+    wgs.swap(sorted);
   }
   if (!b->d_entries.alloc((entries + kJoinSlack) * 4) || !b->d_bounds.alloc((bounds + 1) * 4) ||
       !b->d_streams.alloc(std::max<size_t>(1, streams.size()) * sizeof(StreamRec)) ||
@@ -868,7 +1030,8 @@ bool build_streams(irs_hip_batch* b) {
   for (irs_hip_segment* sg : b->segs)
     if (prepare_posting_norms(sg) != IRS_HIP_OK) return false;
   // the workgroups' records (JoinWg: everything k_join reads before its first payload byte)
-  std::vector<JoinWg> wg_recs(wgs.size());
+  JoinWg* wg_recs = static_cast<JoinWg*>(b->up.put(b->d_join_wgs.p, wgs.size() * sizeof(JoinWg)));
+  if (!wg_recs && !wgs.empty()) return false;
   for (size_t i = 0; i < wgs.size(); ++i) {
     const StreamRec& sr = streams[wgs[i].stream];
     const irs_hip_segment* sg = b->segs[sr.seg];
@@ -912,13 +1075,11 @@ bool build_streams(irs_hip_batch* b) {
     }
   }
   // (the slack behind the last stream is only ever read by masked-off look-ahead: zero it once)
-  if (!rt::dmemset(b->d_entries.as<uint32_t>() + entries, 0, kJoinSlack * 4, nullptr) ||
-      !rt::h2d(b->d_streams.p, streams.data(), streams.size() * sizeof(StreamRec), nullptr) ||
-      !rt::h2d(b->d_join_wgs.p, wg_recs.data(), wg_recs.size() * sizeof(JoinWg), nullptr) ||
-      !rt::h2d(b->d_jterms.p, jterms.data(), jterms.size() * sizeof(JoinTerm), nullptr) ||
-      !rt::h2d(b->d_join_units.p, b->join_units.data(), b->join_units.size() * 4, nullptr) ||
-      !rt::h2d(b->d_join_order.p, order.data(), order.size() * 4, nullptr) ||
-      !rt::sync(nullptr))
+  b->slack_zeroed = false;   // (run_impl zeroes it on the run's stream)
+  if (!b->up.copy(b->d_streams.p, streams.data(), streams.size() * sizeof(StreamRec)) ||
+      !b->up.copy(b->d_jterms.p, jterms.data(), jterms.size() * sizeof(JoinTerm)) ||
+      !b->up.copy(b->d_join_units.p, b->join_units.data(), b->join_units.size() * 4) ||
+      !b->up.copy(b->d_join_order.p, order.data(), order.size() * 4))
     return false;
   b->n_streams = uint32_t(streams.size());
   b->n_join_wgs = uint32_t(wgs.size());
@@ -975,9 +1136,8 @@ bool build_groups(irs_hip_batch* b) {
   if (!grouped) return true;
   if (!b->d_group_of.alloc(group_of.size() * 4) || !b->d_group_members.alloc(members.size() * 4) ||
       !b->d_group_hist.alloc(uint64_t(nq_user) * (kBins + 2) * 4) ||
-      !rt::h2d(b->d_group_of.p, group_of.data(), group_of.size() * 4, nullptr) ||
-      !rt::h2d(b->d_group_members.p, members.data(), members.size() * 4, nullptr) ||
-      !rt::sync(nullptr))
+      !b->up.copy(b->d_group_of.p, group_of.data(), group_of.size() * 4) ||
+      !b->up.copy(b->d_group_members.p, members.data(), members.size() * 4))
     return false;
   b->n_groups = nq_user;
   return true;
@@ -1013,7 +1173,8 @@ bool launch_join_score(irs_hip_batch* b, rt::stream_t st) {
   const uint32_t cpq = std::max<uint32_t>(1, (b->join_max_tiles + kJoinChunkTiles - 1) / kJoinChunkTiles);
   const uint32_t chunk_tiles = std::max<uint32_t>(1, (b->join_max_tiles + cpq - 1) / cpq);
   const uint32_t n_all = uint32_t(b->join_units.size());
-  if (!b->d_join_ctr.p && !b->d_join_ctr.alloc(sizeof b->join_ctr_init)) return false;
+  // [0]: the live counters, [1]: their start values (copied over [0] on the device every run)
+  if (!b->d_join_ctr.p && !b->d_join_ctr.alloc(2 * sizeof b->join_ctr_init)) return false;
   // two launches: the plain disjunctions, then the units whose accumulators count matches
   for (uint32_t part = 0; part < 2; ++part) {
     const uint32_t n_units = part ? n_all - b->n_join_plain : b->n_join_plain;
@@ -1046,9 +1207,16 @@ bool launch_join_score(irs_hip_batch* b, rt::stream_t st) {
     a.cand_cap = b->cand_cap;
     a.chunk_tiles = chunk_tiles;
     JoinArgs* d_args = b->d_join_args.as<JoinArgs>() + part;
-    if (!rt::h2d(d_args, &a, sizeof a, st) ||
-        !rt::h2d(a.work_counter, b->join_ctr_init[part], sizeof b->join_ctr_init[part], st))
-      return false;
+    uint32_t* d_init = a.work_counter + 2 * kJoinQueues;
+    if (!b->join_args_valid[part] || std::memcmp(&a, &b->join_args_sent[part], sizeof a) != 0) {
+      if (!b->up.copy(d_args, &a, sizeof a) ||
+          !b->up.copy(d_init, b->join_ctr_init[part], sizeof b->join_ctr_init[part]) ||
+          !b->up.flush(st))
+        return false;
+      std::memcpy(&b->join_args_sent[part], &a, sizeof a);
+      b->join_args_valid[part] = true;
+    }
+    if (!rt::d2d(a.work_counter, d_init, sizeof b->join_ctr_init[part], st)) return false;
     if (part) {
       RT_LAUNCH(k_join_score<true>, grid, b->join_threads, smem, st, d_args);
     } else {
@@ -1103,12 +1271,11 @@ int build_conj_work(irs_hip_batch* b) {
         !b->d_conj_items.alloc(b->conj_items.size() * 4) ||
         !b->d_conj_hist.alloc(uint64_t(nq) * kBins * 4))
       return IRS_HIP_ENOMEM;
-    if (!rt::h2d(b->d_conj_item_base.p, item_base.data(), item_base.size() * 4, nullptr) ||
-        !rt::h2d(b->d_conj_unit_items.p, unit_items.data(), unit_items.size() * 4, nullptr) ||
-        !rt::h2d(b->d_conj_units.p, b->conj_units.data(), b->conj_units.size() * 4, nullptr) ||
-        !rt::h2d(b->d_conj_items.p, b->conj_items.data(), b->conj_items.size() * 4, nullptr) ||
-        !rt::sync(nullptr))
-      return IRS_HIP_EHIP;
+    if (!b->up.copy(b->d_conj_item_base.p, item_base.data(), item_base.size() * 4) ||
+        !b->up.copy(b->d_conj_unit_items.p, unit_items.data(), unit_items.size() * 4) ||
+        !b->up.copy(b->d_conj_units.p, b->conj_units.data(), b->conj_units.size() * 4) ||
+        !b->up.copy(b->d_conj_items.p, b->conj_items.data(), b->conj_items.size() * 4))
+      return IRS_HIP_ENOMEM;
   } catch (...) {
     rc = IRS_HIP_ENOMEM;
   }
@@ -1117,6 +1284,8 @@ int build_conj_work(irs_hip_batch* b) {
 
 bool ensure_scratch(irs_hip_batch* b) {
   if (b->scratch_ready) return true;
+  HostTrace trace("ensure_scratch (units dealt, streams, work lists)");
+  b->join_args_valid[0] = b->join_args_valid[1] = b->score_args_valid = false;
   if (b->phrase) b->tile = 0x40000000u;  // k_phrase is block driven: one "tile" = the segment
   // 32-bit accumulators halve the LDS per doc: twice the tile at the same residency
   // the largest tile that still lets two workgroups share a CU's 160 KB of LDS
@@ -1248,8 +1417,7 @@ bool ensure_scratch(irs_hip_batch* b) {
   while ((64u << b->join_nw_log2) < b->join_threads) ++b->join_nw_log2;
   if (b->cand_cap == 0) b->cand_cap = default_cand_cap(b);
   const uint64_t rows = uint64_t(b->nq) * b->jt;
-  if (!rt::h2d(b->d_queries.p, b->queries.data(), b->queries.size() * sizeof(DevQuery), nullptr) ||
-      !rt::sync(nullptr))
+  if (!b->up.copy(b->d_queries.p, b->queries.data(), b->queries.size() * sizeof(DevQuery)))
     return false;
   if (!b->d_first.alloc(std::max<uint64_t>(first_words, 1) * sizeof(uint32_t)) ||
       !b->d_tails.alloc(rows * sizeof(DevTail)) ||
@@ -1266,8 +1434,7 @@ bool ensure_scratch(irs_hip_batch* b) {
   if (!build_groups(b)) return false;
   if (!b->tile_units.empty()) {
     if (!b->d_tile_units.alloc(b->tile_units.size() * 4) ||
-        !rt::h2d(b->d_tile_units.p, b->tile_units.data(), b->tile_units.size() * 4, nullptr) ||
-        !rt::sync(nullptr))
+        !b->up.copy(b->d_tile_units.p, b->tile_units.data(), b->tile_units.size() * 4))
       return false;
   }
   if (!b->phrase && !b->tile_units.empty()) {
@@ -1665,6 +1832,7 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
                                const irs_hip_term_scorer* all_terms, uint32_t n_entries,
                                irs_hip_batch** out) {
   if (!segs || !n_segs || !queries || !all_terms || !out || !nq_user) return IRS_HIP_EINVAL;
+  HostTrace trace("batch_create (query records)");
   *out = nullptr;
   if (uint64_t(n_segs) * nq_user > 0x7FFFFFFFull) return IRS_HIP_EINVAL;
   for (uint32_t s = 0; s < n_segs; ++s) {
@@ -1982,13 +2150,12 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
             !b->d_conj_item_hits.alloc((total + 1) * 4) ||
             !b->d_conj_hist.alloc(uint64_t(nq) * kBins * 4))
           rc = IRS_HIP_ENOMEM;
-        else if (!rt::h2d(b->d_conj_units.p, b->conj_units.data(), b->conj_units.size() * 4, nullptr) ||
-                 !rt::h2d(b->d_conj_items.p, b->conj_items.data(), b->conj_items.size() * 4, nullptr) ||
-                 !rt::h2d(b->d_conj_item_base.p, item_base.data(), item_base.size() * 4, nullptr) ||
-                 !rt::h2d(b->d_conj_unit_items.p, unit_items.data(), unit_items.size() * 4, nullptr) ||
-                 !rt::h2d(b->d_lead_of.p, lead_of.data(), lead_of.size() * 4, nullptr) ||
-                 !rt::sync(nullptr))
-          rc = IRS_HIP_EHIP;
+        else if (!b->up.copy(b->d_conj_units.p, b->conj_units.data(), b->conj_units.size() * 4) ||
+                 !b->up.copy(b->d_conj_items.p, b->conj_items.data(), b->conj_items.size() * 4) ||
+                 !b->up.copy(b->d_conj_item_base.p, item_base.data(), item_base.size() * 4) ||
+                 !b->up.copy(b->d_conj_unit_items.p, unit_items.data(), unit_items.size() * 4) ||
+                 !b->up.copy(b->d_lead_of.p, lead_of.data(), lead_of.size() * 4))
+          rc = IRS_HIP_ENOMEM;
       }
     } catch (...) {
       rc = IRS_HIP_ENOMEM;
@@ -2008,13 +2175,10 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
         !b->d_qterms.alloc(b->qterms.size() * sizeof(DevQTerm)) ||
         !b->d_segs.alloc(dsegs.size() * sizeof(DevSegment))) {
       rc = IRS_HIP_ENOMEM;
-    } else if (!rt::h2d(b->d_segs.p, dsegs.data(), dsegs.size() * sizeof(DevSegment), nullptr) ||
-               !rt::h2d(b->d_queries.p, b->queries.data(), b->queries.size() * sizeof(DevQuery),
-                        nullptr) ||
-               !rt::h2d(b->d_qterms.p, b->qterms.data(), b->qterms.size() * sizeof(DevQTerm),
-                        nullptr) ||
-               !rt::sync(nullptr)) {
-      rc = IRS_HIP_EHIP;
+    } else if (!b->up.copy(b->d_segs.p, dsegs.data(), dsegs.size() * sizeof(DevSegment)) ||
+               !b->up.copy(b->d_qterms.p, b->qterms.data(), b->qterms.size() * sizeof(DevQTerm))) {
+      // (d_queries goes out from ensure_scratch, once the units' tile geometry is in)
+      rc = IRS_HIP_ENOMEM;
     }
   }
   if (rc != IRS_HIP_OK) {
@@ -2082,9 +2246,8 @@ static int batch_set_wand_impl(irs_hip_batch* b, int enable) {
     if (const int rc = prepare_blockmax(sg)) return rc;
     dsegs.push_back(sg->dev);
   }
-  if (!rt::h2d(b->d_segs.p, dsegs.data(), dsegs.size() * sizeof(DevSegment), nullptr) ||
-      !rt::sync(nullptr))
-    return IRS_HIP_EHIP;
+  if (!b->up.copy(b->d_segs.p, dsegs.data(), dsegs.size() * sizeof(DevSegment)))
+    return IRS_HIP_ENOMEM;
   return IRS_HIP_OK;
 }
 
@@ -2108,9 +2271,9 @@ static int batch_set_min_scores_impl(irs_hip_batch* b, const float* min_scores) 
   }
   if (b->ran && !rt::sync(b->stream)) return IRS_HIP_EHIP;
   if (!b->d_min_bin.alloc(bins.size() * 4) || !b->d_min_score.alloc(mins.size() * 4) ||
-      !rt::h2d(b->d_min_bin.p, bins.data(), bins.size() * 4, nullptr) ||
-      !rt::h2d(b->d_min_score.p, mins.data(), mins.size() * 4, nullptr) || !rt::sync(nullptr))
-    return IRS_HIP_EHIP;
+      !b->up.copy(b->d_min_bin.p, bins.data(), bins.size() * 4) ||
+      !b->up.copy(b->d_min_score.p, mins.data(), mins.size() * 4))
+    return IRS_HIP_ENOMEM;
   b->has_min = true;
   return IRS_HIP_OK;
 }
@@ -2228,17 +2391,25 @@ static int batch_plan_impl(irs_hip_batch* b, void* stream) {
   if (!b->ev_planned_ready) ok = b->ev_planned_ready = rt::event_create(&b->ev_planned);
   // (the tables are rewritten: the batch's own previous run must be through with them)
   if (ok && b->ev_done_ready && b->ran) ok = rt::stream_wait(st, b->ev_done);
-  ok = ok && plan_stage(b, st) && rt::event_record(b->ev_planned, st);
+  ok = ok && b->up.flush(st) && plan_stage(b, st) && rt::event_record(b->ev_planned, st);
   b->planned = ok;
   return ok ? IRS_HIP_OK : IRS_HIP_EHIP;
 }
 
 static int run_impl(irs_hip_batch* b, rt::stream_t st) {
+  HostTrace trace("batch_run (scratch + uploads + launches queued)");
   if (!ensure_scratch(b)) return IRS_HIP_ENOMEM;
   b->stream = st;
   const bool simd = b->seg->dev.layout == kSimd4;
   auto mark = [&](int i) { return !b->profile || rt::event_record(b->ev[i], st); };
-  bool ok = rt::dmemset(b->d_cand_count.p, 0, b->d_cand_count.n, st) &&
+  // the batch's tables (built in page-locked memory since create) go out on this stream
+  bool ok = b->up.flush(st);
+  if (ok && b->joined && !b->slack_zeroed) {
+    // (the slack behind the last stream is only ever read by masked-off look-ahead: zero it once)
+    ok = rt::dmemset(b->d_entries.as<uint32_t>() + b->join_entries, 0, kJoinSlack * 4, st);
+    b->slack_zeroed = ok;
+  }
+  ok = ok && rt::dmemset(b->d_cand_count.p, 0, b->d_cand_count.n, st) &&
             rt::dmemset(b->d_hits.p, 0, b->d_hits.n, st) &&
             rt::dmemset(b->d_status.p, 0, 4, st) &&
             rt::dmemset(b->d_bstar.p, 0, b->d_bstar.n, st) &&
@@ -2295,8 +2466,8 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st) {
   ok = ok && mark(2 * IRS_HIP_K_SELECT + 1);
   // the status word follows the kernels into page-locked memory; the event marks this run
   if (ok && !b->h_status) {
-    b->h_status = static_cast<uint32_t*>(rt::hmalloc(sizeof(uint32_t)));
-    ok = b->h_status != nullptr;
+    ok = b->h_status_buf.alloc(64);
+    b->h_status = b->h_status_buf.as<uint32_t>();
   }
   if (ok && !b->ev_done_ready) ok = b->ev_done_ready = rt::event_create(&b->ev_done);
   ok = ok && rt::d2h(b->h_status, b->d_status.p, 4, st) && rt::event_record(b->ev_done, st);
@@ -2402,13 +2573,8 @@ static int batch_results_impl(irs_hip_batch* b, irs_hip_hit* hits, uint32_t k_st
   // hits land in a page-locked buffer owned by the batch (a pageable destination would
   // be staged by the runtime at a fraction of the PCIe rate), then go to the caller's layout
   const size_t hit_bytes = size_t(b->nq) * b->k_max * sizeof(Hit);
-  if (b->h_pin_bytes < hit_bytes) {
-    rt::hfree(b->h_pin);
-    b->h_pin = rt::hmalloc(hit_bytes);
-    b->h_pin_bytes = b->h_pin ? hit_bytes : 0;
-    if (!b->h_pin) return IRS_HIP_ENOMEM;
-  }
-  const Hit* tmp = static_cast<const Hit*>(b->h_pin);
+  if (b->h_pin.n < hit_bytes && !b->h_pin.alloc(hit_bytes)) return IRS_HIP_ENOMEM;
+  const Hit* tmp = b->h_pin.as<Hit>();
   if (!rt::d2h(&status, b->d_status.p, 4, b->stream) || !rt::sync(b->stream))
     return IRS_HIP_EHIP;
   if (status & (kStatusOverflow | kStatusUnderflow)) {
@@ -2416,7 +2582,7 @@ static int batch_results_impl(irs_hip_batch* b, irs_hip_hit* hits, uint32_t k_st
     if (rc != IRS_HIP_OK) return rc;
     status = 0;
   }
-  if (!rt::d2h(b->h_pin, b->d_out.p, hit_bytes, b->stream) ||
+  if (!rt::d2h(b->h_pin.p, b->d_out.p, hit_bytes, b->stream) ||
       !rt::d2h(counts, b->d_out_count.p, size_t(b->nq) * 4, b->stream) ||
       (total_hits && !rt::d2h(total_hits, b->d_hits.p, size_t(b->nq) * 8, b->stream)) ||
       !rt::sync(b->stream))
@@ -2470,19 +2636,29 @@ static int batch_results_to_device_impl(irs_hip_batch* b, void* d_hits, void* d_
   if (!rt::d2d(d_hits, b->d_out.p, size_t(b->nq) * b->k_max * sizeof(Hit), st) ||
       !rt::d2d(d_counts, b->d_out_count.p, size_t(b->nq) * 4, st))
     return IRS_HIP_EHIP;
+  // (destroy must not hand d_out back to the pool while these copies are queued)
+  if (!b->ev_used_ready) b->ev_used_ready = rt::event_create(&b->ev_used);
+  if (!b->ev_used_ready || !rt::event_record(b->ev_used, st)) return IRS_HIP_EHIP;
+  b->ev_used_pending = true;
   return IRS_HIP_OK;
 }
 
 void irs_hip_batch_destroy(irs_hip_batch* b) {
   if (!b) return;
   rt::set_device(b->seg->device);
-  if (b->ran) rt::sync(b->stream);
+  // Its buffers go back to the pool: every piece of queued work that touches them must be
+  // through — the batch's own last run (ev_done), a plan queued ahead, copies out of d_out.
+  // Not the whole stream: the caller may have queued the NEXT batch behind this one.
+  bool waited = true;
+  if (b->ran) waited = b->ev_done_ready && rt::event_sync(b->ev_done);
+  if (b->planned) waited = waited && b->ev_planned_ready && rt::event_sync(b->ev_planned);
+  if (b->ev_used_pending) waited = waited && rt::event_sync(b->ev_used);
+  if (!waited && b->ran) rt::sync(b->stream);
   if (b->events_ready)
     for (auto& e : b->ev) rt::event_destroy(e);
   if (b->ev_done_ready) rt::event_destroy(b->ev_done);
   if (b->ev_planned_ready) rt::event_destroy(b->ev_planned);
-  rt::hfree(b->h_status);
-  rt::hfree(b->h_pin);
+  if (b->ev_used_ready) rt::event_destroy(b->ev_used);
   delete b;
 }
 
@@ -2600,6 +2776,14 @@ int irs_hip_device_download(int32_t device, void* h_dst, const void* d_src, uint
     if ((!h_dst || !d_src) && bytes) return int(IRS_HIP_EINVAL);
     if (!rt::set_device(device)) return int(IRS_HIP_EHIP);
     return int(rt::d2h(h_dst, d_src, bytes, nullptr) && rt::sync(nullptr) ? IRS_HIP_OK : IRS_HIP_EHIP);
+  });
+}
+int irs_hip_device_trim(int32_t device) {
+  return guarded([&] {
+    if (device < 0 || device >= rt::device_count() || !rt::set_device(device)) return int(IRS_HIP_EHIP);
+    pool::release_all(device, false);
+    pool::release_all(device, true);
+    return int(IRS_HIP_OK);
   });
 }
 int irs_hip_device_sync(int32_t device, void* stream) {

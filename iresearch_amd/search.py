@@ -274,29 +274,89 @@ class SegmentReader:
         return QueryBatch(self, prepared, k)
 
 
+class QueryArrays:
+    """The C arrays irs_hip_batch_create_multi takes for a list of prepared queries on a list
+    of segments: irs_hip_query[nq] and irs_hip_term_scorer[n_segs][n_entries] (every segment
+    gets the same scorer constants and its own term ordinals).  Building them is the host half
+    of filter::prepare; creating a batch from them is one C call."""
+
+    def __init__(self, n_segs, queries, terms, k):
+        self.n_segs, self.queries, self.terms, self.k = int(n_segs), queries, terms, int(k)
+
+    @classmethod
+    def from_prepared(cls, segs, prepared, k):
+        n_entries = sum(len(p.terms) for p in prepared)
+        queries = np.zeros(len(prepared), QUERY)
+        terms = np.zeros((len(segs), max(n_entries, 1)), TERM_SCORER)
+        at = 0
+        for q, p in enumerate(prepared):
+            queries[q] = (p.op, len(p.terms), at, int(k), p.min_match, p.merge)
+            offs = p.offsets if p.offsets is not None else [0] * len(p.terms)
+            for t, (kind, c0, nc, nl), off in zip(p.terms, p.scorers, offs):
+                for s, sr in enumerate(segs):       # same scorer, the segment's own ordinal
+                    present = t is not None and 0 <= t < len(sr.metas)
+                    terms[s, at] = (t if present else NO_TERM, kind, c0, nc, nl, off)
+                at += 1
+        return cls(len(segs), queries, terms, k)
+
+
+def prepare_disjunctions(term_rows, scorer, segment_stats, segs, k, boost=1.0):
+    """prepare() + QueryArrays.from_prepared for the common case — every row of `term_rows`
+    (int array [nq][n_terms] of term ordinals) is an Or of by_term filters with one boost —
+    with the statistics of ALL terms computed at once (numpy), value for value what
+    BM25.collect / TFIDF.collect / term_scorer compute one term at a time (the test suite
+    compares the two).  This is the per-batch host work of a serving loop."""
+    rows = np.ascontiguousarray(term_rows, np.int64)
+    nq, nt = rows.shape
+    flat = rows.reshape(-1)
+    dwf = sum(s.docs_with_field for s in segment_stats)
+    ttf = sum(s.total_term_freq for s in segment_stats)
+    dwt = np.zeros(flat.size, np.float64)
+    for st in segment_stats:
+        dc = np.asarray(st.docs_count)
+        ok = (flat >= 0) & (flat < len(dc))
+        dwt[ok] += dc[flat[ok]]
+    if isinstance(scorer, BM25):
+        idf = np.log1p((float(dwf) - dwt + 0.5) / (dwt + 0.5)).astype(np.float32)
+        c0 = (f32(f32(boost) * f32(scorer.k + f32(1))) * idf).astype(np.float32)
+        probe = scorer.collect(dwf, 1, ttf)
+        kind = scorer.term_scorer(probe)[0]
+        nc, nl = probe.norm_const, probe.norm_length
+    else:
+        idf = np.log1p((dwf + 1.0) / (dwt + 1.0)).astype(np.float32)
+        c0 = (f32(boost) * idf).astype(np.float32)
+        kind, nc, nl = scorer.term_scorer(TermStats(f32(1)))[0], f32(0), f32(0)
+    queries = np.zeros(nq, QUERY)
+    queries["op"], queries["n_terms"], queries["k"] = OP_OR, nt, int(k)
+    queries["first_term"] = np.arange(nq, dtype=np.uint32) * nt
+    queries["min_match"], queries["merge"] = 1, MERGE_SUM
+    terms = np.zeros((len(segs), max(flat.size, 1)), TERM_SCORER)
+    for s, sr in enumerate(segs):
+        present = (flat >= 0) & (flat < len(sr.metas))
+        terms["term"][s, :flat.size] = np.where(present, flat, NO_TERM).astype(np.uint32)
+    terms["kind"][:, :flat.size] = kind
+    terms["c0"][:, :flat.size] = c0
+    terms["norm_const"][:, :flat.size] = nc
+    terms["norm_length"][:, :flat.size] = nl
+    return QueryArrays(len(segs), queries, terms, k)
+
+
 class QueryBatch:
     """A batch of prepared queries on one segment — or on several segments of one device
     at once (irs_hip_batch_create_multi): then every result array gets a leading segment
-    axis, [n_segs][nq]..., in the order the readers were given."""
+    axis, [n_segs][nq]..., in the order the readers were given.  `prepared`: a list of
+    PreparedQuery, or the QueryArrays made from one."""
 
-    def __init__(self, seg, prepared, k: int):
+    def __init__(self, seg, prepared, k: int | None = None):
         self.segs = list(seg) if isinstance(seg, (list, tuple)) else [seg]
         self.multi = isinstance(seg, (list, tuple))
-        self.seg, self.L, self.k = self.segs[0], self.segs[0].L, int(k)
-        self.nq_user = len(prepared)
+        arrays = prepared if isinstance(prepared, QueryArrays) else \
+            QueryArrays.from_prepared(self.segs, prepared, k)
+        assert arrays.n_segs == len(self.segs)
+        self.seg, self.L, self.k = self.segs[0], self.segs[0].L, arrays.k
+        self.nq_user = len(arrays.queries)
         self.nq = self.nq_user * len(self.segs)          # execution units
-        n_entries = sum(len(p.terms) for p in prepared)
-        self.queries = np.zeros(self.nq_user, QUERY)
-        self.terms = np.zeros((len(self.segs), max(n_entries, 1)), TERM_SCORER)
-        at = 0
-        for q, p in enumerate(prepared):
-            self.queries[q] = (p.op, len(p.terms), at, self.k, p.min_match, p.merge)
-            offs = p.offsets if p.offsets is not None else [0] * len(p.terms)
-            for t, (kind, c0, nc, nl), off in zip(p.terms, p.scorers, offs):
-                for s, sr in enumerate(self.segs):       # same scorer, the segment's own ordinal
-                    present = t is not None and 0 <= t < len(sr.metas)
-                    self.terms[s, at] = (t if present else NO_TERM, kind, c0, nc, nl, off)
-                at += 1
+        self.queries, self.terms = arrays.queries, arrays.terms
         h = C.c_void_p()
         handles = (C.c_void_p * len(self.segs))(*[sr.handle for sr in self.segs])
         _lib.check(self.L, self.L.irs_hip_batch_create_multi(

@@ -22,6 +22,9 @@ using event_t = double;
 
 inline int device_count() { return 1; }
 inline bool set_device(int dev) { return dev == 0; }
+inline int current_device() { return 0; }
+inline size_t pool_cap_bytes() { return size_t(256) << 20; }
+inline void poison(void* p, size_t n) { std::memset(p, 0xCD, n); }   // recycled memory is not zero either
 inline bool device_arch(int, char* buf, size_t cap) {
   std::strncpy(buf, "gfx950-sim", cap);
   if (cap) buf[cap - 1] = 0;
