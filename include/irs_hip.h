@@ -302,19 +302,27 @@ int irs_hip_query_batch(irs_hip_segment* seg, const irs_hip_query* queries,
 int irs_hip_batch_configure(irs_hip_batch* batch, uint32_t tile_docs,
                             uint32_t pilot_stride, uint32_t cand_cap);
 
-/* How the doc-tile units of a batch (Or / by_term / min-match) execute — a tuning / test knob,
- * results are the same within one fixed-point unit per posting either way:
+/* How the doc-tile units of a batch (Or / by_term / min-match, conjunctions that qualify)
+ * execute — a tuning / test knob; the hits of plain disjunctions are BIT-IDENTICAL on every path
+ * (units with match counts — conjunctions, min-match — differ by the rounding of their counting
+ * accumulators when they join, within the parity tolerance):
  *   IRS_HIP_PATH_ITEMS   every query decodes the blocks of its own terms (work items);
  *   IRS_HIP_PATH_JOINED  every DISTINCT (segment, term) of the batch is decoded once per run
- *                        into a stream of (doc, tf, norm) entries which the queries then only
- *                        accumulate — what block_disjunction::refill (disjunction.hpp:1240-1351)
- *                        does per query, shared by the queries of a batch.  Only for plain
- *                        disjunctions with table-family scorers (BM25 / BM15 / TF-IDF over 1-byte
- *                        norms or none), sum merge, frequencies < 64, no block-max pruning;
- *                        a batch that does not qualify runs as ITEMS whatever was asked;
+ *                        into streams of entries which the queries then only accumulate — what
+ *                        block_disjunction::refill (disjunction.hpp:1240-1351) does per query,
+ *                        shared by the queries of a batch.  Plain disjunctions run in two passes:
+ *                        packed 16-bit accumulators over (doc, approximate score) entries find
+ *                        the docs that can reach the top k, those are re-scored exactly from
+ *                        (doc, tf, norm) entries (fast.h).  For sum-merged units with table-family
+ *                        scorers (BM25 / BM15 / TF-IDF over 1-byte norms or none), frequencies
+ *                        < 64, no block-max pruning; units that do not qualify run as ITEMS
+ *                        whatever was asked;
+ *   IRS_HIP_PATH_JOINED_EXACT  JOINED with the one-pass exact accumulation for plain
+ *                        disjunctions as well (round 3's kernel: A/B and parity tests);
  *   IRS_HIP_PATH_AUTO    (default) JOINED where it applies.
  * Call before the batch's first run (or after a configure). */
-enum { IRS_HIP_PATH_AUTO = 0, IRS_HIP_PATH_ITEMS = 1, IRS_HIP_PATH_JOINED = 2 };
+enum { IRS_HIP_PATH_AUTO = 0, IRS_HIP_PATH_ITEMS = 1, IRS_HIP_PATH_JOINED = 2,
+       IRS_HIP_PATH_JOINED_EXACT = 3 };
 int irs_hip_batch_set_path(irs_hip_batch* batch, int path);
 /* Which one the batch's last run used (IRS_HIP_PATH_ITEMS / IRS_HIP_PATH_JOINED). */
 int irs_hip_batch_path(irs_hip_batch* batch, int* path);

@@ -19,7 +19,7 @@ LAYOUT_SCALAR, LAYOUT_SIMD4 = 0, 1
 OP_OR, OP_AND, OP_MINMATCH, OP_PHRASE = 0, 1, 2, 3
 SCORE_BM25, SCORE_BM15, SCORE_BM1, SCORE_TFIDF, SCORE_TFIDF_NORM = 0, 1, 2, 3, 4
 NO_TERM = 0xFFFFFFFF
-PATH_AUTO, PATH_ITEMS, PATH_JOINED = 0, 1, 2
+PATH_AUTO, PATH_ITEMS, PATH_JOINED, PATH_JOINED_EXACT = 0, 1, 2, 3
 WAND_NONE, WAND_DIV_NORM, WAND_MAX_FREQ, WAND_MIN_NORM = 0, 1, 2, 3   # Scorer::WandType
 MAX_TERMS, MAX_K, MAX_PHRASE_TERMS = 16, 4096, 8
 K_PLAN, K_PILOT, K_SCORE, K_SELECT, K_COUNT = 0, 1, 2, 3, 4

@@ -104,6 +104,39 @@ __device__ __forceinline__ uint32_t bfe(uint32_t x, uint32_t bits) {
   return __builtin_amdgcn_ubfe(x, 0u, bits);
 }
 
+// high 32 bits of a 32 x 32 bit product (v_mul_hi_u32)
+__device__ __forceinline__ uint32_t mul_hi(uint32_t a, uint32_t b) { return __umulhi(a, b); }
+// Two 16-bit halves of a word at once (VOP3P v_pk_*_u16): the packed first-pass accumulators of
+// fast.h hold two docs per word.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+  u16x2 x, y;
+  __builtin_memcpy(&x, &a, 4);
+  __builtin_memcpy(&y, &b, 4);
+  const u16x2 r = __builtin_elementwise_min(x, y);
+  uint32_t o;
+  __builtin_memcpy(&o, &r, 4);
+  return o;
+}
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+  u16x2 x, y;
+  __builtin_memcpy(&x, &a, 4);
+  __builtin_memcpy(&y, &b, 4);
+  const u16x2 r = __builtin_elementwise_max(x, y);
+  uint32_t o;
+  __builtin_memcpy(&o, &r, 4);
+  return o;
+}
+__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {
+  u16x2 x, y;
+  __builtin_memcpy(&x, &a, 4);
+  __builtin_memcpy(&y, &b, 4);
+  const u16x2 r = x + y;
+  uint32_t o;
+  __builtin_memcpy(&o, &r, 4);
+  return o;
+}
+
 // Optimisation barrier: the value must exist in a VGPR at this program point.
 __device__ __forceinline__ void keep(uint32_t& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void keep_f(float& v) { asm volatile("" : "+v"(v)); }

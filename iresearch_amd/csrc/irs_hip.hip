@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -19,6 +20,7 @@
 #include "score.h"
 #include "conj.h"
 #include "join.h"
+#include "fast.h"
 
 using namespace irs_hip;
 
@@ -317,6 +319,13 @@ struct irs_hip_batch {
   bool joined = false;
   DevBuf d_streams, d_join_wgs, d_jterms, d_entries, d_bounds, d_join_args, d_join_units,
     d_join_order;
+  // fast.h: plain disjunctions in two passes — fast entries next to the exact ones (same
+  // offsets), the first pass's approximate candidates, the kernels' argument records
+  bool fast16 = false;
+  DevBuf d_fast, d_acands, d_acand_count, d_fast_args, d_rescore_args;
+  FastArgs fast_args{}, fast_args_sent{};
+  RescoreArgs rescore_args{}, rescore_args_sent{};
+  bool fast_args_valid = false, rescore_args_valid = false;
   uint32_t join_max_tiles = 0;
   uint32_t n_streams = 0, n_join_wgs = 0;
   uint32_t join_threads = 1024, join_nw_log2 = 4;   // threads per k_join_pilot / k_join_score workgroup
@@ -858,9 +867,17 @@ int prepare_blockmax(irs_hip_segment* s) {
 bool join_allowed(const irs_hip_batch* b) {   // batch level
   if (b->path_pref == IRS_HIP_PATH_ITEMS) return false;
   if (const char* e = std::getenv("IRS_HIP_JOIN")) {   // tuning / test knob
-    if (std::atoi(e) == 0 && b->path_pref != IRS_HIP_PATH_JOINED) return false;
+    if (std::atoi(e) == 0 && b->path_pref != IRS_HIP_PATH_JOINED &&
+        b->path_pref != IRS_HIP_PATH_JOINED_EXACT)
+      return false;
   }
   return !b->phrase && b->acc32 && !b->wand;
+}
+// plain disjunctions of a joined batch in two passes (fast.h)?
+bool fast16_allowed(const irs_hip_batch* b) {
+  if (b->path_pref == IRS_HIP_PATH_JOINED_EXACT) return false;
+  if (const char* e = std::getenv("IRS_HIP_FAST16")) return std::atoi(e) != 0;   // tuning / test knob
+  return true;
 }
 bool join_counts_allowed() {   // tuning / test knob
   const char* e = std::getenv("IRS_HIP_JOIN_COUNTS");
@@ -890,7 +907,8 @@ int64_t join_and_saving(const irs_hip_batch* b, const DevQuery& dq) {
 // kernel) only pay when the conjunctions that would join save more than that together
 constexpr int64_t kJoinAndLaunchCost = 500000000;   // 0.5 ms
 int join_and_forced(const irs_hip_batch* b) {   // -1: decide by cost
-  if (b->path_pref == IRS_HIP_PATH_JOINED) return 1;   // (forced: wherever it is possible)
+  if (b->path_pref == IRS_HIP_PATH_JOINED || b->path_pref == IRS_HIP_PATH_JOINED_EXACT)
+    return 1;   // (forced: wherever it is possible)
   if (const char* e = std::getenv("IRS_HIP_JOIN_AND")) return std::atoi(e) != 0;   // tuning / test knob
   return -1;
 }
@@ -919,40 +937,74 @@ bool unit_joinable(const irs_hip_batch* b, uint32_t u) {
 // boundaries in every run.
 bool build_streams(irs_hip_batch* b) {
   struct WgRef { uint32_t stream, first; };   // a k_join workgroup before its record is made
+  std::unique_ptr<HostTrace> tr(new HostTrace("  streams: distinct terms"));
+  auto lap = [&](const char* what) { tr.reset(); tr.reset(new HostTrace(what)); };
   std::vector<StreamRec> streams;
   std::vector<WgRef> wgs;
   std::vector<JoinTerm> jterms(b->qterms.size());
-  std::vector<uint64_t> key_of;   // sorted (segment << 32 | term) -> stream
+  // A stream = a distinct (segment, term, scorer signature) of the joined units: the signature
+  // — (kind, norm_const, norm_length), normally ONE per batch — is what k_join evaluates a
+  // stream's fast entries with (fast.h).  stream_of[unit term] by an open-addressing table: the
+  // streams come out in first-use order.
+  struct Sig { int32_t kind; float nc, nl; };
+  std::vector<Sig> sigs;
+  std::vector<uint32_t> stream_of(b->qterms.size(), 0xFFFFFFFFu);
+  std::vector<uint8_t> stream_fast, stream_sig;
   {
+    size_t slots = 64;
+    size_t n_keys = 0;
+    for (uint32_t u : b->join_units) n_keys += b->queries[u].n_terms;
+    while (slots < 2 * n_keys + 2) slots <<= 1;
+    std::vector<uint64_t> hkey(slots, ~0ull);
+    std::vector<uint32_t> hval(slots, 0);
     for (uint32_t u : b->join_units) {
       const DevQuery& dq = b->queries[u];
-      for (uint32_t j = 0; j < dq.n_terms; ++j)
-        key_of.push_back((uint64_t(dq.seg) << 32) | b->qterms[dq.first_term + j].term);
+      const bool fast = b->fast16 && query_need(dq.op) <= 1u;
+      for (uint32_t j = 0; j < dq.n_terms; ++j) {
+        const DevQTerm& qt = b->qterms[dq.first_term + j];
+        uint32_t sg_id = 0;
+        for (; sg_id < sigs.size(); ++sg_id)
+          if (sigs[sg_id].kind == qt.kind && sigs[sg_id].nc == qt.norm_const && sigs[sg_id].nl == qt.norm_length) break;
+        if (sg_id == sigs.size()) {
+          if (sigs.size() >= 255) return false;
+          sigs.push_back(Sig{qt.kind, qt.norm_const, qt.norm_length});
+        }
+        if (dq.seg >= (1u << 24)) return false;
+        const uint64_t key = (uint64_t(sg_id) << 56) | (uint64_t(dq.seg) << 32) | qt.term;
+        size_t h = size_t((key * 0x9E3779B97F4A7C15ull) >> 32) & (slots - 1);
+        while (hkey[h] != ~0ull && hkey[h] != key) h = (h + 1) & (slots - 1);
+        if (hkey[h] == ~0ull) {
+          hkey[h] = key;
+          hval[h] = uint32_t(streams.size());
+          StreamRec r{};
+          r.seg = dq.seg;
+          r.term = qt.term;
+          r.n = b->segs[dq.seg]->terms[qt.term].docs_count;
+          streams.push_back(r);
+          stream_fast.push_back(0);
+          stream_sig.push_back(uint8_t(sg_id));
+        }
+        stream_of[dq.first_term + j] = hval[h];
+        if (fast) stream_fast[hval[h]] = 1;
+      }
     }
-    std::sort(key_of.begin(), key_of.end());
-    key_of.erase(std::unique(key_of.begin(), key_of.end()), key_of.end());
   }
   uint64_t entries = 0, bounds = 0;
   std::vector<uint64_t> ent_off, bnd_off;
-  for (const uint64_t key : key_of) {
-    const uint32_t sgi = uint32_t(key >> 32), term = uint32_t(key);
-    const irs_hip_segment* sg = b->segs[sgi];
-    const DevTerm& t = sg->terms[term];
-    StreamRec r{};
-    r.seg = sgi;
-    r.term = term;
-    r.n = t.docs_count;
+  for (size_t si = 0; si < streams.size(); ++si) {
+    const irs_hip_segment* sg = b->segs[streams[si].seg];
+    const DevTerm& t = sg->terms[streams[si].term];
     ent_off.push_back(entries);
     bnd_off.push_back(bounds);
     const uint32_t n_tiles = (sg->dev.num_docs + kJoinTile - 1) / kJoinTile;
     const uint32_t nb = t.nblk + ((t.docs_count == 1 || t.tail_n) ? 1u : 0u);
     for (uint32_t first = 0; first < nb; first += kJoinBlocks)
-      wgs.push_back(WgRef{uint32_t(streams.size()), first});
+      wgs.push_back(WgRef{uint32_t(si), first});
     entries += t.docs_count;
     bounds += uint64_t(n_tiles) + 1;
-    streams.push_back(r);
   }
   if (wgs.size() > 0x7FFFFFFFull) return false;
+  lap("  streams: work list order");
   // k_join reads a norm byte per posting: launched term after term, the workgroups in flight
   // would touch the whole norm column at once (10 MB at 10 M docs against 4 MB of L2 per XCD).
   // Ordered by where in the doc space a workgroup's blocks lie — estimated as its position
@@ -975,6 +1027,9 @@ bool build_streams(irs_hip_batch* b) {
     for (size_t i = 0; i < wgs.size(); ++i) sorted[start[key[i]]++] = wgs[i];
     wgs.swap(sorted);
   }
+  lap("  streams: buffers");
+  if (b->fast16 && !b->d_fast.alloc((entries + kJoinSlack) * 4)) return false;
+  if (!b->fast16) b->d_fast.release();
   if (!b->d_entries.alloc((entries + kJoinSlack) * 4) || !b->d_bounds.alloc((bounds + 1) * 4) ||
       !b->d_streams.alloc(std::max<size_t>(1, streams.size()) * sizeof(StreamRec)) ||
       !b->d_join_wgs.alloc(std::max<size_t>(1, wgs.size()) * sizeof(JoinWg)) ||
@@ -987,6 +1042,7 @@ bool build_streams(irs_hip_batch* b) {
   // match counts — the units sorted by (segment, heaviest term) and cut into kJoinQueues runs of
   // about equal work, one queue per XCD: the workgroups that share an L2 work on units that share
   // their longest stream (and the same doc range: chunk-major within a queue).
+  lap("  streams: queue order");
   std::vector<uint32_t> order;
   {
     struct Item { uint64_t work; uint64_t key; uint32_t unit; };
@@ -1029,6 +1085,7 @@ bool build_streams(irs_hip_batch* b) {
   }
   for (irs_hip_segment* sg : b->segs)
     if (prepare_posting_norms(sg) != IRS_HIP_OK) return false;
+  lap("  streams: k_join records");
   // the workgroups' records (JoinWg: everything k_join reads before its first payload byte)
   JoinWg* wg_recs = static_cast<JoinWg*>(b->up.put(b->d_join_wgs.p, wgs.size() * sizeof(JoinWg)));
   if (!wg_recs && !wgs.empty()) return false;
@@ -1054,16 +1111,30 @@ bool build_streams(irs_hip_batch* b) {
     w.last_doc = t.last_doc;
     w.n_tiles = (ds.num_docs + kJoinTile - 1) / kJoinTile;
     w.n = sr.n;
-    w.pad[0] = w.pad[1] = w.pad[2] = 0;
+    const Sig& sig = sigs[stream_sig[wgs[i].stream]];
+    w.fast_kind = uint32_t(sig.kind & 0xFF) | (stream_fast[wgs[i].stream] ? 0x100u : 0u);
+    std::memcpy(&w.fast_nc, &sig.nc, 4);
+    std::memcpy(&w.fast_nl, &sig.nl, 4);
   }
+  lap("  streams: per-term records");
   for (uint32_t u : b->join_units) {
-    const DevQuery& dq = b->queries[u];
+    DevQuery& dq = b->queries[u];
     const uint32_t rows = table_rows(dq.n_caches);
+    // fast.h: the unit's 16-bit scale — every doc's approximate sum (each posting at most its
+    // term's csq + 1) stays below 2^15
+    double u16 = 0.0;
     for (uint32_t j = 0; j < dq.n_terms; ++j) {
       const DevQTerm& qt = b->qterms[dq.first_term + j];
-      const uint64_t key = (uint64_t(dq.seg) << 32) | qt.term;
-      const size_t sid = size_t(std::lower_bound(key_of.begin(), key_of.end(), key) - key_of.begin());
+      u16 += double(qt.c0) * double(fast_tn(qt.kind));
+    }
+    const double s16 = u16 > 0.0 ? double(kFastMaxSum - 2u * dq.n_terms) / (u16 * (1.0 + 1e-6)) : 0.0;
+    dq.s16 = float(s16);
+    for (uint32_t j = 0; j < dq.n_terms; ++j) {
+      const DevQTerm& qt = b->qterms[dq.first_term + j];
+      const size_t sid = stream_of[dq.first_term + j];
       JoinTerm& jt = jterms[dq.first_term + j];
+      jt.pad[0] = uint32_t(double(qt.c0) * double(fast_tn(qt.kind)) * s16);
+      jt.pad[1] = 0;
       jt.entries = streams[sid].entries;
       jt.bounds = streams[sid].bounds;
       jt.cs = qt.c0 * dq.fx_mul;
@@ -1087,12 +1158,17 @@ bool build_streams(irs_hip_batch* b) {
   return true;
 }
 
+// a stream's fast entries live at the same offset of d_fast as its exact entries of d_entries
+int64_t fast_delta(const irs_hip_batch* b) {
+  return b->fast16 ? int64_t(reinterpret_cast<intptr_t>(b->d_fast.p) - reinterpret_cast<intptr_t>(b->d_entries.p)) : 0;
+}
+
 bool launch_join(irs_hip_batch* b, rt::stream_t st) {
   if (!b->n_join_wgs) return true;
   if (b->seg->dev.layout == kSimd4) {
-    RT_LAUNCH((k_join<kSimd4>), b->n_join_wgs, kThreads, 0, st, b->d_join_wgs.as<JoinWg>());
+    RT_LAUNCH((k_join<kSimd4>), b->n_join_wgs, kThreads, 0, st, b->d_join_wgs.as<JoinWg>(), fast_delta(b));
   } else {
-    RT_LAUNCH((k_join<kScalar>), b->n_join_wgs, kThreads, 0, st, b->d_join_wgs.as<JoinWg>());
+    RT_LAUNCH((k_join<kScalar>), b->n_join_wgs, kThreads, 0, st, b->d_join_wgs.as<JoinWg>(), fast_delta(b));
   }
   return rt::last_error_ok();
 }
@@ -1178,7 +1254,7 @@ bool launch_join_score(irs_hip_batch* b, rt::stream_t st) {
   // two launches: the plain disjunctions, then the units whose accumulators count matches
   for (uint32_t part = 0; part < 2; ++part) {
     const uint32_t n_units = part ? n_all - b->n_join_plain : b->n_join_plain;
-    if (!n_units) continue;
+    if (!n_units || (part == 0 && b->fast16)) continue;   // (fast.h runs the plain disjunctions)
     const uint64_t chunks = uint64_t(n_units) * cpq;
     if (chunks > 0xFFFF0000ull) return false;
     const uint32_t grid = uint32_t(std::min<uint64_t>(chunks, uint64_t(b->seg->cus) * per_cu));
@@ -1226,6 +1302,80 @@ bool launch_join_score(irs_hip_batch* b, rt::stream_t st) {
   return rt::last_error_ok();
 }
 
+
+// fast.h: the plain disjunctions of a joined batch — packed first pass, exact re-score
+bool launch_join_fast(irs_hip_batch* b, rt::stream_t st) {
+  const uint32_t n_units = b->n_join_plain;
+  if (!b->fast16 || !n_units) return true;
+  const size_t smem = FastOff::end;
+  if (!big_smem(k_join_fast, smem) || !big_smem(k_join_rescore, kRescoreSmem)) return false;
+  const uint32_t waves = b->join_threads / 64;
+  uint32_t per_cu = uint32_t((160u * 1024u) / smem);
+  per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 32u / waves));
+  const uint32_t tiles = (b->join_max_tiles + 1u) / 2u;   // packed tiles: two join.h tiles each
+  const uint32_t cpq = std::max<uint32_t>(1, (tiles + kFastChunkTiles - 1) / kFastChunkTiles);
+  const uint32_t chunk_tiles = std::max<uint32_t>(1, (tiles + cpq - 1) / cpq);
+  const uint64_t chunks = uint64_t(n_units) * cpq;
+  if (chunks > 0xFFFF0000ull) return false;
+  const uint32_t grid = uint32_t(std::min<uint64_t>(chunks, uint64_t(b->seg->cus) * per_cu));
+  if (!b->d_join_ctr.p && !b->d_join_ctr.alloc(2 * sizeof b->join_ctr_init)) return false;
+  FastArgs& a = b->fast_args;
+  a.queries = b->d_queries.as<DevQuery>();
+  a.jterms = b->d_jterms.as<JoinTerm>();
+  a.fast_delta = fast_delta(b);
+  a.bstar = b->d_bstar.as<uint32_t>();
+  a.cands = b->d_acands.as<uint64_t>();
+  a.cand_count = b->d_acand_count.as<uint32_t>();
+  a.hits = b->d_hits.as<unsigned long long>();
+  a.order = b->d_join_order.as<uint32_t>();
+  a.work_counter = b->d_join_ctr.as<uint32_t>();   // (the plain launch's counters: part 0)
+  uint32_t base = 0;
+  for (uint32_t g = 0; g <= kJoinQueues; ++g) {
+    a.first[g] = b->join_first[0][g];
+    a.base[g] = base;
+    if (g < kJoinQueues) {
+      b->join_ctr_init[0][g] = base;
+      base += (b->join_first[0][g + 1] - b->join_first[0][g]) * cpq;
+    }
+  }
+  a.cpq = cpq;
+  a.n_units = n_units;
+  a.nw_log2 = b->join_nw_log2;
+  a.cand_cap = b->cand_cap;
+  a.chunk_tiles = chunk_tiles;
+  uint32_t* d_init = a.work_counter + 2 * kJoinQueues;
+  if (!b->fast_args_valid || std::memcmp(&a, &b->fast_args_sent, sizeof a) != 0) {
+    if (!b->up.copy(b->d_fast_args.p, &a, sizeof a) ||
+        !b->up.copy(d_init, b->join_ctr_init[0], sizeof b->join_ctr_init[0]) || !b->up.flush(st))
+      return false;
+    std::memcpy(&b->fast_args_sent, &a, sizeof a);
+    b->fast_args_valid = true;
+  }
+  RescoreArgs& r = b->rescore_args;
+  r.units = b->d_join_order.as<uint32_t>();   // (the plain units come first in the queue order)
+  r.queries = b->d_queries.as<DevQuery>();
+  r.qterms = b->d_qterms.as<DevQTerm>();
+  r.jterms = b->d_jterms.as<JoinTerm>();
+  r.bstar = b->d_bstar.as<uint32_t>();
+  r.acands = b->d_acands.as<uint64_t>();
+  r.acand_count = b->d_acand_count.as<uint32_t>();
+  r.cands = b->d_cands.as<uint64_t>();
+  r.cand_count = b->d_cand_count.as<uint32_t>();
+  r.cand_cap = b->cand_cap;
+  if (!b->rescore_args_valid || std::memcmp(&r, &b->rescore_args_sent, sizeof r) != 0) {
+    if (!b->up.copy(b->d_rescore_args.p, &r, sizeof r) || !b->up.flush(st)) return false;
+    std::memcpy(&b->rescore_args_sent, &r, sizeof r);
+    b->rescore_args_valid = true;
+  }
+  if (!rt::d2d(a.work_counter, d_init, sizeof b->join_ctr_init[0], st) ||
+      !rt::dmemset(b->d_acand_count.p, 0, b->d_acand_count.n, st))
+    return false;
+  static const bool trace = std::getenv("IRS_HIP_TRACE") != nullptr;
+  if (trace) std::fprintf(stderr, "[irs_hip] k_join_fast: %u units, %u chunks of %u tiles, grid %u\n", n_units, unsigned(chunks), chunk_tiles, grid);
+  RT_LAUNCH(k_join_fast, grid, b->join_threads, smem, st, b->d_fast_args.as<FastArgs>());
+  RT_LAUNCH(k_join_rescore, n_units, kTileThreadsMax, kRescoreSmem, st, b->d_rescore_args.as<RescoreArgs>());
+  return rt::last_error_ok();
+}
 
 // k_conj work of the batch's block-driven conjunctions (conj_units): the lead term of a unit is
 // its first one (sorted by cost at create); one wavefront per 128-posting block of it (+ one for
@@ -1286,6 +1436,7 @@ bool ensure_scratch(irs_hip_batch* b) {
   if (b->scratch_ready) return true;
   HostTrace trace("ensure_scratch (units dealt, streams, work lists)");
   b->join_args_valid[0] = b->join_args_valid[1] = b->score_args_valid = false;
+  b->fast_args_valid = b->rescore_args_valid = false;
   if (b->phrase) b->tile = 0x40000000u;  // k_phrase is block driven: one "tile" = the segment
   // 32-bit accumulators halve the LDS per doc: twice the tile at the same residency
   // the largest tile that still lets two workgroups share a CU's 160 KB of LDS
@@ -1333,6 +1484,9 @@ bool ensure_scratch(irs_hip_batch* b) {
       if (build_conj_work(b) != IRS_HIP_OK) return false;
     }
     b->joined = !b->join_units.empty();
+    b->fast16 = false;
+    if (b->joined && fast16_allowed(b))
+      for (uint32_t u : b->join_units) b->fast16 = b->fast16 || query_need(b->queries[u].op) <= 1u;
   }
   // 32-bit accumulators halve the LDS per doc: twice the tile at the same residency
   // the largest tile that still lets two workgroups share a CU's 160 KB of LDS
@@ -1417,8 +1571,6 @@ bool ensure_scratch(irs_hip_batch* b) {
   while ((64u << b->join_nw_log2) < b->join_threads) ++b->join_nw_log2;
   if (b->cand_cap == 0) b->cand_cap = default_cand_cap(b);
   const uint64_t rows = uint64_t(b->nq) * b->jt;
-  if (!b->up.copy(b->d_queries.p, b->queries.data(), b->queries.size() * sizeof(DevQuery)))
-    return false;
   if (!b->d_first.alloc(std::max<uint64_t>(first_words, 1) * sizeof(uint32_t)) ||
       !b->d_tails.alloc(rows * sizeof(DevTail)) ||
       !b->d_bstar.alloc(b->nq * sizeof(uint32_t)) ||
@@ -1429,6 +1581,11 @@ bool ensure_scratch(irs_hip_batch* b) {
       !b->d_out_count.alloc(b->nq * sizeof(uint32_t)) || !b->d_status.alloc(4) ||
       !b->d_work.alloc(16) || !b->d_touched.alloc(uint64_t(b->nq) * 16) ||
       !b->d_pruned.alloc(uint64_t(b->nq) * 4))
+    return false;
+  if (b->fast16 &&
+      (!b->d_acands.alloc(uint64_t(b->nq) * b->cand_cap * sizeof(uint64_t)) ||
+       !b->d_acand_count.alloc(b->nq * sizeof(uint32_t)) || !b->d_fast_args.alloc(sizeof(FastArgs)) ||
+       !b->d_rescore_args.alloc(sizeof(RescoreArgs))))
     return false;
   if (b->joined && !build_streams(b)) return false;
   if (!build_groups(b)) return false;
@@ -1446,6 +1603,9 @@ bool ensure_scratch(irs_hip_batch* b) {
         !b->d_tile_ub.alloc((tiles + 1) * sizeof(float)))
       return false;
   }
+  // (the unit records last: dealing the units and building the streams filled fields in)
+  if (!b->up.copy(b->d_queries.p, b->queries.data(), b->queries.size() * sizeof(DevQuery)))
+    return false;
   b->scratch_ready = true;
   return true;
 }
@@ -2207,7 +2367,7 @@ static int batch_configure_impl(irs_hip_batch* b, uint32_t tile_docs, uint32_t p
 }
 
 static int batch_set_path_impl(irs_hip_batch* b, int path) {
-  if (!b || path < IRS_HIP_PATH_AUTO || path > IRS_HIP_PATH_JOINED) return IRS_HIP_EINVAL;
+  if (!b || path < IRS_HIP_PATH_AUTO || path > IRS_HIP_PATH_JOINED_EXACT) return IRS_HIP_EINVAL;
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
   if (b->ran && !rt::sync(b->stream)) return IRS_HIP_EHIP;
   b->path_pref = path;
@@ -2435,7 +2595,7 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st) {
     ok = ok && (simd ? launch_phrase_terms<kSimd4>(b, st) : launch_phrase_terms<kScalar>(b, st));
   else if (tiles)
     ok = ok && (simd ? launch_score_acc<kSimd4>(b, st) : launch_score_acc<kScalar>(b, st));
-  if (b->joined) ok = ok && launch_join_score(b, st);
+  if (b->joined) ok = ok && launch_join_fast(b, st) && launch_join_score(b, st);
   if (!b->phrase) ok = ok && (simd ? launch_conj<kSimd4>(b, st) : launch_conj<kScalar>(b, st));
   ok = ok && mark(2 * IRS_HIP_K_SCORE + 1);
   // 4. exact top-k
@@ -2499,7 +2659,9 @@ static int recover(irs_hip_batch* b, uint32_t status) {
     b->stride_eff = std::min<uint32_t>(b->stride_eff, 16);
     const uint32_t cap = default_cand_cap(b);  // the sound threshold admits more candidates
     if (cap > b->cand_cap) {
-      if (!b->d_cands.alloc(uint64_t(b->nq) * cap * sizeof(uint64_t))) return IRS_HIP_ENOMEM;
+      if (!b->d_cands.alloc(uint64_t(b->nq) * cap * sizeof(uint64_t)) ||
+          (b->fast16 && !b->d_acands.alloc(uint64_t(b->nq) * cap * sizeof(uint64_t))))
+        return IRS_HIP_ENOMEM;
       b->cand_cap = cap;
     }
     const int rc = run_impl(b, b->stream);
@@ -2525,7 +2687,9 @@ static int recover_overflow(irs_hip_batch* b) {
     const uint64_t need = uint64_t(*std::max_element(cc.begin(), cc.end())) + 1024;
     const bool affordable = need * b->nq * sizeof(uint64_t) <= kMaxCandBytes;
     if (need > b->cand_cap && affordable) {
-      if (!b->d_cands.alloc(need * b->nq * sizeof(uint64_t))) return IRS_HIP_ENOMEM;
+      if (!b->d_cands.alloc(need * b->nq * sizeof(uint64_t)) ||
+          (b->fast16 && !b->d_acands.alloc(need * b->nq * sizeof(uint64_t))))
+        return IRS_HIP_ENOMEM;
       b->cand_cap = uint32_t(need);
     } else if (b->stride_eff != 1) {
       b->stride_eff = 1;

@@ -81,7 +81,9 @@ struct alignas(16) JoinWg {
   uint32_t last_doc;          // of the list
   uint32_t n_tiles;           // doc tiles of the segment
   uint32_t n;                 // postings of the list
-  uint32_t pad[3];
+  // fast.h: the stream also gets FAST entries (bit 8) evaluated with this scorer: Kind (low byte),
+  // norm_const, norm_length (float bits)
+  uint32_t fast_kind, fast_nc, fast_nl;
 };
 static_assert(sizeof(JoinWg) == 112, "JoinWg");
 // Per (unit, term slot), parallel to DevQTerm: all k_join_score needs in one 32-byte record.
@@ -98,6 +100,29 @@ __host__ __device__ __forceinline__ uint32_t join_entry(uint32_t idx, uint32_t t
   return (idx << 18) | ((tf & kJoinTfMax) << 10) | ((norm & 0xFFu) << 2);
 }
 
+// ---- the query-independent factor of a posting, as k_join evaluates it ---------------------
+// T(tf, norm) of score.h's tables (row tf of a slot: 1 - 1/(1 + tf * tab[norm]) resp.
+// sqrt(tf) * tab[norm]) through v_rcp / v_sqrt instead of a table: the fast entry only has to
+// be within a 16-bit unit.  Tn: what T stays below (1 for the BM25 family; sqrt(64) for TF-IDF,
+// whose frequencies are < 64 in a joined stream).
+__host__ __device__ __forceinline__ float fast_tn(int32_t kind) { return sqrt_kind(kind) ? 8.f : 1.f; }
+__device__ __forceinline__ uint32_t fast_unit(int32_t kind, float nc, float nl, uint32_t tf, uint32_t norm) {
+  const float f = static_cast<float>(tf);
+  float t = 0.f;   // T / Tn
+  switch (kind) {   // (wave-uniform)
+    case kBM25Tiny: t = norm ? f * wave::fast_rcp(f + wave::fma(nl, static_cast<float>(norm), nc)) : 0.f; break;
+    case kBM25One: t = f * wave::fast_rcp(f + (nc + nl)); break;
+    case kBM15: t = f * wave::fast_rcp(f + nc); break;
+    case kTfidf: t = wave::fast_sqrt(f) * 0.125f; break;
+    default: t = norm ? wave::fast_sqrt(f * wave::fast_rcp(static_cast<float>(norm))) * 0.125f : 0.f;   // kTfidfTiny
+  }
+  const uint32_t u = static_cast<uint32_t>(t * 65536.f);
+  return u < 65535u ? u : 65535u;
+}
+__host__ __device__ __forceinline__ uint32_t fast_entry(uint32_t idx_in_half_tile, uint32_t unit16) {
+  return (unit16 << 16) | (idx_in_half_tile << 2);
+}
+
 // ------------------------------------------------------------------ join --
 
 // One workgroup = kJoinBlocks consecutive blocks of one stream, in rounds of kWaves x
@@ -111,10 +136,16 @@ constexpr uint32_t kJoinRounds = kJoinBlocks / (kWaves * kJoinPerWave);
 static_assert(kJoinRounds * kWaves * kJoinPerWave == kJoinBlocks, "k_join rounds");
 
 // entries + tile boundaries of the two postings a lane holds of one block
+struct JoinFast {   // (wave-uniform) where a stream's fast entries go and how they are scored
+  uint32_t* ent;    // null: the stream has none
+  int32_t kind;
+  float nc, nl;
+};
 __device__ __forceinline__ void join_emit(uint32_t* ent, uint32_t* bnd, uint32_t b, unsigned lane,
                                           uint32_t d0, uint32_t d1, uint32_t f0, uint32_t f1,
                                           uint32_t n0, uint32_t n1, bool v0, bool v1,
-                                          uint32_t prev /*0: the list's first posting*/) {
+                                          uint32_t prev /*0: the list's first posting*/,
+                                          const JoinFast& F) {
   const uint32_t p0 = kBlock * b + 2u * lane;
   const uint32_t t0 = v0 ? (d0 - kDocMin) / kJoinTile : 0u;
   const uint32_t t1 = v1 ? (d1 - kDocMin) / kJoinTile : t0;
@@ -125,6 +156,16 @@ __device__ __forceinline__ void join_emit(uint32_t* ent, uint32_t* bnd, uint32_t
     __builtin_memcpy(ent + p0, &both, 8);
   } else if (v0) {
     ent[p0] = e0;
+  }
+  if (F.ent) {   // (wave-uniform) fast.h: the same postings once more, scored
+    const uint32_t g0 = fast_entry((d0 - kDocMin) - t0 * kJoinTile, fast_unit(F.kind, F.nc, F.nl, f0, n0));
+    const uint32_t g1 = fast_entry((d1 - kDocMin) - t1 * kJoinTile, fast_unit(F.kind, F.nc, F.nl, f1, n1));
+    if (v1) {
+      uint64_t both = (uint64_t(g1) << 32) | g0;
+      __builtin_memcpy(F.ent + p0, &both, 8);
+    } else if (v0) {
+      F.ent[p0] = g0;
+    }
   }
   // tile boundaries: posting p opens every tile in (tile of posting p - 1, tile of p]
   const uint32_t up = __shfl_up(t1, 1, 64);
@@ -139,11 +180,16 @@ __device__ __forceinline__ void join_emit(uint32_t* ent, uint32_t* bnd, uint32_t
 
 template<int LAYOUT>
 __global__ void __launch_bounds__(kThreads)
-k_join(const JoinWg* wgs) {
+k_join(const JoinWg* wgs, int64_t fast_delta) {
   const unsigned lane = threadIdx.x & 63u;
   const uint32_t wv = wave::uniform(threadIdx.x >> 6);
   const JoinWg W = wave::sload<JoinWg>(reinterpret_cast<uint64_t>(wgs) + uint64_t(blockIdx.x) * sizeof(JoinWg));
   uint32_t* ent = reinterpret_cast<uint32_t*>(W.entries);
+  JoinFast F;
+  F.ent = (W.fast_kind & 0x100u) ? reinterpret_cast<uint32_t*>(W.entries + uint64_t(fast_delta)) : nullptr;
+  F.kind = int32_t(W.fast_kind & 0xFFu);
+  F.nc = __uint_as_float(W.fast_nc);
+  F.nl = __uint_as_float(W.fast_nl);
   uint32_t* bnd = reinterpret_cast<uint32_t*>(W.bounds);
   const uint8_t* doc = reinterpret_cast<const uint8_t*>(W.doc);
   const bool tiny = W.pnorm != 0;
@@ -214,7 +260,7 @@ k_join(const JoinWg* wgs) {
       const uint32_t b = r0 + wv + kWaves * i;
       if (full[i])
         join_emit(ent, bnd, b, lane, d0[i], d1[i], f0[i], f1[i], n0[i], n1[i], true, true,
-                  b ? dir[i].prev_last : 0u);
+                  b ? dir[i].prev_last : 0u, F);
     }
   }
   // the vint tail / single doc, decoded when the segment was opened: the list's last "block"
@@ -230,7 +276,7 @@ k_join(const JoinWg* wgs) {
     const uint8_t* tnorms = reinterpret_cast<const uint8_t*>(W.tail_norms);
     const uint32_t tn0 = (v0 && tiny) ? tnorms[i0] : 0u;
     const uint32_t tn1 = (v1 && tiny) ? tnorms[i0 + 1u] : 0u;
-    join_emit(ent, bnd, bt, lane, td0, td1, tf0, tf1, tn0, tn1, v0, v1, W.tail_base);
+    join_emit(ent, bnd, bt, lane, td0, td1, tf0, tf1, tn0, tn1, v0, v1, W.tail_base, F);
   }
   // behind the list's last posting every remaining tile is empty: whoever holds the last block
   if (nb && nb - 1u >= W.first && nb - 1u < end && ((nb - 1u - W.first) % kWaves) == wv) {

@@ -536,7 +536,9 @@ def case_paths_agree(L, num_docs=70_000, max_rank=256, layout=synth.LAYOUT_SIMD4
     """The two organisations of a disjunction batch — every query decoding its own blocks (work
     items) and the batch decoding every distinct term once (joined posting streams) — return
     the same docs, scores and hit counts, bit for bit (a posting's fixed-point contribution is
-    computed by the same arithmetic wherever it is decoded).  Each one is also checked against
+    computed by the same arithmetic wherever it is decoded) — and so do the two forms of the
+    joined path: the packed 16-bit first pass with exact re-scoring (fast.h) and the one-pass
+    exact accumulation.  Each one is also checked against
     the oracle.  Mixed batches: the And /
     min-match / kMax queries stay on their own kernels while the plain disjunctions join."""
     seg = synth.build_segment(num_docs, max_rank, layout=layout)
@@ -549,7 +551,7 @@ def case_paths_agree(L, num_docs=70_000, max_rank=256, layout=synth.LAYOUT_SIMD4
     for scorer in (BM25(), BM25(1.2, 0.0), TFIDF(True), TFIDF(False)):
         for filters, k in ((pure, 1000), (mixed, 40)):
             got = {}
-            for path in (_lib.PATH_ITEMS, _lib.PATH_JOINED, _lib.PATH_AUTO):
+            for path in (_lib.PATH_ITEMS, _lib.PATH_JOINED, _lib.PATH_JOINED_EXACT, _lib.PATH_AUTO):
                 prep = search.prepare(filters, scorer, [parity.segment_stats(seg)])
                 b = sr.batch(prep, k).set_path(path)
                 h, c, t = b.run().results()
@@ -569,6 +571,8 @@ def case_paths_agree(L, num_docs=70_000, max_rank=256, layout=synth.LAYOUT_SIMD4
                 if not counting:
                     assert np.array_equal(hi[qi], hj[qi]), qi
                     assert np.array_equal(got[_lib.PATH_AUTO][0][qi], hj[qi]), qi
+                # (two-pass joined == one-pass joined for every query, counting ones included)
+                assert np.array_equal(got[_lib.PATH_JOINED_EXACT][0][qi], hj[qi]), qi
     sr.close()
 
 

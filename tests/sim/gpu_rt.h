@@ -24,7 +24,13 @@ inline int device_count() { return 1; }
 inline bool set_device(int dev) { return dev == 0; }
 inline int current_device() { return 0; }
 inline size_t pool_cap_bytes() { return size_t(256) << 20; }
-inline void poison(void* p, size_t n) { std::memset(p, 0xCD, n); }   // recycled memory is not zero either
+inline void poison(void* p, size_t n) {   // recycled memory is not zero either
+#ifndef IRS_SIM_NO_POISON
+  std::memset(p, 0xCD, n);
+#else
+  (void)p; (void)n;
+#endif
+}
 inline bool device_arch(int, char* buf, size_t cap) {
   std::strncpy(buf, "gfx950-sim", cap);
   if (cap) buf[cap - 1] = 0;

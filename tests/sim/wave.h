@@ -82,6 +82,20 @@ __device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t s)
 }
 __device__ __forceinline__ uint32_t bfe(uint32_t x, uint32_t bits) { return x & ((1u << bits) - 1u); }
 __device__ __forceinline__ uint64_t undef64() { return 0; }
+__device__ __forceinline__ uint32_t mul_hi(uint32_t a, uint32_t b) { return uint32_t((uint64_t(a) * b) >> 32); }
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+  const uint32_t lo = (a & 0xFFFFu) < (b & 0xFFFFu) ? (a & 0xFFFFu) : (b & 0xFFFFu);
+  const uint32_t hi = (a >> 16) < (b >> 16) ? (a >> 16) : (b >> 16);
+  return (hi << 16) | lo;
+}
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+  const uint32_t lo = (a & 0xFFFFu) > (b & 0xFFFFu) ? (a & 0xFFFFu) : (b & 0xFFFFu);
+  const uint32_t hi = (a >> 16) > (b >> 16) ? (a >> 16) : (b >> 16);
+  return (hi << 16) | lo;
+}
+__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {
+  return (((a >> 16) + (b >> 16)) << 16) | ((a + b) & 0xFFFFu);
+}
 template<typename T>
 __device__ __forceinline__ void count_nonzero4(uint32_t& acc, T a, T b, T c, T d) {
   acc += uint32_t(a != 0) + uint32_t(b != 0) + uint32_t(c != 0) + uint32_t(d != 0);
