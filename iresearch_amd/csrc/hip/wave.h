@@ -108,33 +108,22 @@ __device__ __forceinline__ uint32_t bfe(uint32_t x, uint32_t bits) {
 __device__ __forceinline__ uint32_t mul_hi(uint32_t a, uint32_t b) { return __umulhi(a, b); }
 // Two 16-bit halves of a word at once (VOP3P v_pk_*_u16): the packed first-pass accumulators of
 // fast.h hold two docs per word.
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+// (written as instructions: the compiler lowers vector min / max of two shorts to compares, selects
+// and a byte permute — six instructions for one)
 __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
-  u16x2 x, y;
-  __builtin_memcpy(&x, &a, 4);
-  __builtin_memcpy(&y, &b, 4);
-  const u16x2 r = __builtin_elementwise_min(x, y);
-  uint32_t o;
-  __builtin_memcpy(&o, &r, 4);
-  return o;
+  uint32_t r;
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
 __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
-  u16x2 x, y;
-  __builtin_memcpy(&x, &a, 4);
-  __builtin_memcpy(&y, &b, 4);
-  const u16x2 r = __builtin_elementwise_max(x, y);
-  uint32_t o;
-  __builtin_memcpy(&o, &r, 4);
-  return o;
+  uint32_t r;
+  asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
 __device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {
-  u16x2 x, y;
-  __builtin_memcpy(&x, &a, 4);
-  __builtin_memcpy(&y, &b, 4);
-  const u16x2 r = x + y;
-  uint32_t o;
-  __builtin_memcpy(&o, &r, 4);
-  return o;
+  uint32_t r;
+  asm("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
 
 // Optimisation barrier: the value must exist in a VGPR at this program point.
@@ -185,6 +174,11 @@ __device__ __forceinline__ uint64_t undef64() {
   uint64_t v;
   asm volatile("" : "=v"(v));
   return v;
+}
+
+// Four registers whose content does not matter (no instruction is emitted).
+__device__ __forceinline__ void undef4(uint32_t (&v)[4]) {
+  asm volatile("" : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]));
 }
 
 // v_rcp_f32: <= 1 ulp
@@ -293,6 +287,22 @@ __device__ __forceinline__ uint64_t gload_u64(uint64_t base, uint32_t off) {
 __device__ __forceinline__ uint32_t gload_u32(uint64_t base, uint32_t off) {
   return *(const IRS_GLOBAL uint32_t*)((const IRS_GLOBAL uint8_t*)base + off);
 }
+
+// 16 bytes at (wave-uniform 64-bit base) + (per-lane 32-bit offset), 4-byte aligned:
+// global_load_dwordx4, saddr form
+__device__ __forceinline__ void gload_u32x4(uint64_t base, uint32_t off, uint32_t (&v)[4]) {
+  typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
+  const u32x4a4 x = *(const IRS_GLOBAL u32x4a4*)((const IRS_GLOBAL uint8_t*)base + off);
+  v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+}
+
+// ... at a per-lane address
+__device__ __forceinline__ void gload_u32x4_at(uint64_t addr, uint32_t (&v)[4]) {
+  typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
+  const u32x4a4 x = *(const IRS_GLOBAL u32x4a4*)addr;
+  v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+}
+__device__ __forceinline__ void keep64(uint64_t& v) { asm volatile("" : "+v"(v)); }
 
 // Unaligned little-endian loads from the byte-granular `.doc` stream.
 __device__ __forceinline__ uint64_t load_u64(const uint8_t* p) {

@@ -82,6 +82,7 @@ __device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t s)
 }
 __device__ __forceinline__ uint32_t bfe(uint32_t x, uint32_t bits) { return x & ((1u << bits) - 1u); }
 __device__ __forceinline__ uint64_t undef64() { return 0; }
+__device__ __forceinline__ void undef4(uint32_t (&v)[4]) { v[0] = v[1] = v[2] = v[3] = 0xDEADBEEFu; }
 __device__ __forceinline__ uint32_t mul_hi(uint32_t a, uint32_t b) { return uint32_t((uint64_t(a) * b) >> 32); }
 __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
   const uint32_t lo = (a & 0xFFFFu) < (b & 0xFFFFu) ? (a & 0xFFFFu) : (b & 0xFFFFu);
@@ -137,6 +138,13 @@ __device__ __forceinline__ uint32_t gload_u32(uint64_t base, uint32_t off) {
   __builtin_memcpy(&v, reinterpret_cast<const uint8_t*>(base) + off, 4);
   return v;
 }
+__device__ __forceinline__ void gload_u32x4(uint64_t base, uint32_t off, uint32_t (&v)[4]) {
+  __builtin_memcpy(v, reinterpret_cast<const uint8_t*>(base) + off, 16);
+}
+__device__ __forceinline__ void gload_u32x4_at(uint64_t addr, uint32_t (&v)[4]) {
+  __builtin_memcpy(v, reinterpret_cast<const uint8_t*>(addr), 16);
+}
+__device__ __forceinline__ void keep64(uint64_t&) {}
 template<int N> __device__ __forceinline__ void keep_all(uint32_t (&)[N]) {}
 template<int N> __device__ __forceinline__ void keep_all_f(float (&)[N]) {}
 __device__ __forceinline__ void keep(uint32_t&) {}
