@@ -24,6 +24,10 @@
 //   per posting c = mul_hi(entry, csq) + 1        csq = c0 * Tn * S16 of the (query, term)
 //               acc16[doc] += c                   one v_mul_hi, one v_lshl_add, one v_and, one ds_add
 //
+// The fast entries are a copy of the exact ones (k_fast_pack: same postings, scored once for all
+// queries of the batch) with every (term, half tile) padded to a MULTIPLE OF FOUR entries — a lane
+// takes four consecutive entries with one 16-byte load and never has to tell its entries apart.
+//
 // Sums stay below 2^15 (S16 is the query's scale), so the two halves of a word never carry into
 // each other and SWAR / v_pk_*_u16 tests work on both at once.  Error: |c - x| < 3 units per posting
 // against the real-valued contribution x (u16 floor, the entry's low bits riding along, csq floor,
@@ -40,27 +44,44 @@ constexpr uint32_t kFastKeep = 6;                // x n: slack under the k-th ap
 constexpr uint32_t kFastMaxSum = 32767;          // a doc's accumulator stays below 2^15
 constexpr uint32_t kFastBins = 1024;             // coarse histogram of approximate scores (32 units per bin)
 constexpr uint32_t kFastRound = 4096;            // candidates re-scored per round of k_join_rescore
-constexpr uint32_t kFastPre = 512;               // entries per piece requested behind the previous tile's epilogue
+constexpr uint32_t kFastSlots = 4;               // 256-entry loads a wavefront has in flight per tile
+constexpr uint32_t kFastPackTiles = 16;          // half tiles per k_fast_pack workgroup
 
 // LDS layout of k_join_fast (byte offsets; the accumulators sit at LDS address 0: an entry's low
 // 16 bits ARE the byte address of its doc's word)
+struct alignas(16) FastSlot {   // one 256-entry load of a wavefront's tile
+  uint32_t lo, hi;   // address of its first entry
+  uint32_t cnt;      // entries from there to the end of its piece (a multiple of 4; 0: none)
+  uint32_t csq;      // the term's multiplier
+};
 struct FastOff {
   static constexpr uint32_t acc = 0;                                      // [kJoinTile] u32 = 2 x u16
   static constexpr uint32_t dummy = 4u * kJoinTile;                       // [64] u32: a word per lane nobody reads
   static constexpr uint32_t rng = dummy + 256u;                           // [2 * chunk tiles + 1][kMaxTerms] u32
-  static constexpr uint32_t jts = rng + 4u * (2u * kFastChunkTiles + 1u) * kMaxTerms;   // JoinTerm[kMaxTerms]
-  static constexpr uint32_t share = jts + uint32_t(sizeof(JoinTerm)) * kMaxTerms;       // [16 waves][4] u32
-  static constexpr uint32_t cand = share + 16u * 16u;                     // [2][kJoinCands] u64
+  static constexpr uint32_t fts = rng + 4u * (2u * kFastChunkTiles + 1u) * kMaxTerms;   // FastTerm[kMaxTerms]
+  static constexpr uint32_t share = fts + 32u * kMaxTerms;                // [16 waves][4] u32
+  static constexpr uint32_t ord = share + 16u * 16u;                      // [kMaxTerms] u32: the terms by decreasing size
+  static constexpr uint32_t cand = ord + 4u * kMaxTerms;                  // [2][kJoinCands] u64
   static constexpr uint32_t vars = cand + 8u * 2u * kJoinCands;           // [16] u32
-  static constexpr uint32_t end = vars + 64u;
+  static constexpr uint32_t desc = vars + 64u;                            // [16 waves][chunk tiles][kFastSlots] FastSlot
+  static constexpr uint32_t end = desc + 16u * kFastChunkTiles * kFastSlots * uint32_t(sizeof(FastSlot));
 };
-static_assert(FastOff::cand % 8u == 0u, "candidate keys are 8-byte aligned");
+static_assert(FastOff::cand % 8u == 0u && FastOff::desc % 16u == 0u, "alignment of the staging keys / slot records");
 static_assert(4u * kJoinTile + 256u <= 65536u, "an entry's 16 address bits reach every word and the dummies");
+static_assert(2u * FastOff::end <= 160u * 1024u, "two workgroups per CU");
+
+// Per (unit, term): where the term's fast entries and their tile boundaries are, its multiplier
+struct alignas(16) FastTerm {
+  uint64_t fent;
+  uint64_t fbounds;
+  uint32_t csq, pad[3];
+};
+static_assert(sizeof(FastTerm) == 32, "FastTerm");
 
 struct FastArgs {
   const DevQuery* queries;
-  const JoinTerm* jterms;      // entries / bounds of the EXACT streams; pad[0] = csq
-  int64_t fast_delta;          // fast entries of a stream = its exact entries + this many bytes
+  const FastTerm* fterms;      // parallel to DevQTerm / JoinTerm
+  uint64_t dummies;            // address of 64 x 4 entries that add nothing: lane l's at + 16 l
   const uint32_t* bstar;
   uint64_t* cands;             // [unit][cap] (approximate score << 32) | doc
   uint32_t* cand_count;
@@ -70,65 +91,208 @@ struct FastArgs {
   uint32_t base[kJoinQueues + 1];
   uint32_t first[kJoinQueues + 1];
   uint32_t cpq, n_units, nw_log2, cand_cap, chunk_tiles;
+  const struct FastChunk* chunks;   // [chunk id] k_fast_shares
 };
 
+// ---------------------------------------------------------------- pack --
+
+// Where the half tiles of a stream begin among its FAST entries: every half tile's entries
+// rounded up to a multiple of four.  One wavefront per stream.
+__global__ void __launch_bounds__(64)
+k_fast_layout(const StreamRec* streams, uint32_t n_streams) {
+  if (blockIdx.x >= n_streams) return;
+  const StreamRec S = streams[blockIdx.x];
+  if (!S.fent) return;
+  const unsigned lane = threadIdx.x;
+  const uint32_t* bnd = reinterpret_cast<const uint32_t*>(S.bounds);
+  uint32_t* fb = reinterpret_cast<uint32_t*>(S.fbounds);
+  uint32_t carry = 0;
+  for (uint32_t t0 = 0; t0 <= S.n_tiles; t0 += 64u) {
+    const uint32_t t = t0 + lane;
+    const uint32_t c = t < S.n_tiles ? ((bnd[t + 1u] - bnd[t] + 3u) & ~3u) : 0u;
+    const uint32_t incl = wave::inclusive_scan(c);
+    if (t <= S.n_tiles) fb[t] = carry + incl - c;
+    carry += wave::bcast(incl, 63);
+  }
+}
+
+// The fast entries themselves: one workgroup per kFastPackTiles half tiles of a stream; an exact
+// entry (idx : 14 | tf : 6 | norm : 8 | 00) becomes (T / Tn * 2^16 : 16 | idx * 4 : 16) at its
+// padded place, the padding adds nothing to a word nobody reads.
+__global__ void __launch_bounds__(kThreads)
+k_fast_pack(const StreamRec* streams, const uint32_t* first_wg /*[stream + 1]*/, uint32_t n_streams) {
+  // which stream: binary search of the workgroup in the streams' first workgroups
+  uint32_t a = 0, b = n_streams;
+  while (b - a > 1u) {
+    const uint32_t m = (a + b) >> 1;
+    if (first_wg[m] <= blockIdx.x) a = m; else b = m;
+  }
+  const StreamRec S = streams[a];
+  if (!S.fent) return;
+  const uint32_t* bnd = reinterpret_cast<const uint32_t*>(S.bounds);
+  const uint32_t* fb = reinterpret_cast<const uint32_t*>(S.fbounds);
+  const uint32_t* ent = reinterpret_cast<const uint32_t*>(S.entries);
+  uint32_t* fent = reinterpret_cast<uint32_t*>(S.fent);
+  const uint32_t t0 = (blockIdx.x - first_wg[a]) * kFastPackTiles;
+  const uint32_t t1 = t0 + kFastPackTiles < S.n_tiles ? t0 + kFastPackTiles : S.n_tiles;
+  // the group's entries are one contiguous run of the exact stream; its (at most 17) boundaries
+  // go to LDS, a thread finds an entry's half tile by bisection there
+  __shared__ uint32_t s_b[kFastPackTiles + 1u], s_fb[kFastPackTiles + 1u];
+  const uint32_t nt = t1 - t0;
+  if (threadIdx.x <= nt) {
+    s_b[threadIdx.x] = bnd[t0 + threadIdx.x];
+    s_fb[threadIdx.x] = fb[t0 + threadIdx.x];
+  }
+  __syncthreads();
+  const uint32_t p0 = s_b[0], p1 = s_b[nt];
+  const int32_t kind = S.kind;
+  const float nc = S.nc, nl = S.nl;
+  for (uint32_t p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
+    uint32_t lo = 0, hi = nt;   // the tile i with s_b[i] <= p < s_b[i + 1]
+    while (hi - lo > 1u) {
+      const uint32_t m = (lo + hi) >> 1;
+      if (s_b[m] <= p) lo = m; else hi = m;
+    }
+    const uint32_t e = ent[p];
+    fent[s_fb[lo] + (p - s_b[lo])] = fast_entry(e >> 18, fast_unit(kind, nc, nl, (e >> 10) & kJoinTfMax, (e >> 2) & 0xFFu));
+  }
+  if (threadIdx.x < 4u * nt) {   // <= 3 pad entries per half tile
+    const uint32_t i = threadIdx.x >> 2, k = threadIdx.x & 3u;
+    const uint32_t c = s_b[i + 1u] - s_b[i];
+    if (c + k < ((c + 3u) & ~3u)) fent[s_fb[i] + c + k] = FastOff::dummy + 4u * k;
+  }
+}
+
+// ---------------------------------------------------------------- shares --
+
 // what a wavefront takes of a chunk's entries: from fraction f_lo of term j0 to fraction f_hi of
-// term j1 (32-bit fixed point; 0xFFFFFFFF = the whole term), every term in between whole
+// term j1 (32-bit fixed point; 0xFFFFFFFF = the whole term), every term in between whole; the
+// terms are named by their place in the chunk's order (FastChunk::ord)
 struct FastShare {
   uint32_t j0, j1, f_lo, f_hi;
 };
+// (cuts fall on multiples of four entries: so do the half tiles' boundaries, k_fast_layout)
 __device__ __forceinline__ uint32_t fast_cut(uint32_t n, uint32_t f) {
-  return f == 0xFFFFFFFFu ? n : wave::mul_hi(n, f);
+  return f == 0xFFFFFFFFu ? n : (wave::mul_hi(n, f) & ~3u);
+}
+struct FastChunk {
+  FastShare share[16];   // per wavefront of the workgroup
+  uint32_t ord[16];      // the query's terms with entries in the chunk, largest first
+};
+
+// The wavefronts' shares of EVERY chunk of the launch, one thread per chunk id: the terms in
+// order of decreasing size, the sequence of their entries cut into at most nw consecutive shares
+// of at most T entries that touch at most TWO terms each — the smallest such T (bisection).
+// (Equal shares put the query's rare terms — several of them, a few entries each — into ONE
+// wavefront, which then walks ten pieces per tile while fifteen others wait at the barrier.
+// A kernel of its own: the bisection is serial work, a few microseconds per chunk — spread over
+// 26 000 threads it costs nothing, inside the persistent workgroups it would cost them all.)
+__global__ void __launch_bounds__(kThreads)
+k_fast_shares(const FastArgs* __restrict__ args, FastChunk* out) {
+  const uint32_t chunk = blockIdx.x * blockDim.x + threadIdx.x;
+  if (chunk >= args->base[kJoinQueues]) return;
+  uint32_t group = 0;
+  while (group + 1u < kJoinQueues && chunk >= args->base[group + 1u]) ++group;
+  const uint32_t n_units = args->first[group + 1u] - args->first[group];
+  const uint32_t local = chunk - args->base[group];
+  const uint32_t q = args->order[args->first[group] + local % n_units];
+  const uint32_t tile0 = (local / n_units) * args->chunk_tiles;
+  const DevQuery qd = args->queries[q];
+  const uint32_t n_half = qd.n_tiles, n_tiles = (n_half + 1u) >> 1;
+  const uint32_t ntile = tile0 >= n_tiles ? 0u
+                         : ((n_tiles - tile0) < args->chunk_tiles ? (n_tiles - tile0) : args->chunk_tiles);
+  const uint32_t nw = 1u << args->nw_log2;
+  FastChunk rec;
+  for (uint32_t w = 0; w < 16u; ++w) {
+    rec.share[w] = FastShare{1u, 0u, 0u, 0u};   // (j0 > j1: nothing)
+    rec.ord[w] = 0u;
+  }
+  uint32_t N[kMaxTerms];
+  uint32_t W = 0, nt = 0;
+  if (ntile) {
+    const uint32_t h0 = 2u * tile0, h1 = 2u * (tile0 + ntile) < n_half ? 2u * (tile0 + ntile) : n_half;
+    for (uint32_t j = 0; j < qd.n_terms; ++j) {
+      const uint32_t* fb = reinterpret_cast<const uint32_t*>(args->fterms[qd.first_term + j].fbounds);
+      const uint32_t n = fb[h1] - fb[h0];
+      if (!n) continue;
+      uint32_t at = nt++;
+      for (; at > 0 && N[at - 1] < n; --at) {   // insertion sort, descending
+        N[at] = N[at - 1];
+        rec.ord[at] = rec.ord[at - 1];
+      }
+      N[at] = n;
+      rec.ord[at] = j;
+      W += n;
+    }
+  }
+  // (fewer wavefronts than half the terms: as many terms per share as it takes)
+  const uint32_t max_terms = (nt + nw - 1u) / nw > 2u ? (nt + nw - 1u) / nw : 2u;
+  auto shares = [&](uint32_t T, FastShare* dst) -> uint32_t {   // shares needed with at most T entries each
+    auto frac = [](uint32_t x, uint32_t n) -> uint32_t {   // x < n
+      const float f = (float(x) / float(n)) * 4294967296.f;
+      return f >= 4294967040.f ? 0xFFFFFF00u : uint32_t(f);
+    };
+    uint32_t count = 0, t = 0, o = 0;
+    while (t < nt) {
+      FastShare sh{t, t, frac(o, N[t]), 0u};
+      uint32_t left = T, touched = 0;
+      while (t < nt && left > 0u && touched < max_terms) {
+        const uint32_t take = N[t] - o < left ? N[t] - o : left;
+        o += take;
+        left -= take;
+        ++touched;
+        sh.j1 = t;
+        if (o == N[t]) {
+          sh.f_hi = 0xFFFFFFFFu;
+          ++t;
+          o = 0;
+        } else {
+          sh.f_hi = frac(o, N[t]);
+        }
+      }
+      if (dst && count < nw) dst[count] = sh;
+      ++count;
+    }
+    return count;
+  };
+  if (W) {
+    uint32_t lo = (W + nw - 1u) / nw, hi = W;   // (T = W: a share per max_terms terms: <= nw of them)
+    for (int it = 0; it < 12 && lo < hi; ++it) {
+      const uint32_t mid = lo + (hi - lo) / 2u;
+      if (shares(mid, nullptr) <= nw) hi = mid; else lo = mid + 1u;
+    }
+    shares(hi, rec.share);
+  }
+  out[chunk] = rec;
 }
 
-// `count` consecutive fast entries from `base` (wave-uniform), all of one half tile: the
-// contribution goes to the low (shift 0) or the high (16) half of the doc's word
-__device__ __forceinline__ void fast_post4(const unsigned char* lds, const uint32_t (&e)[4], uint32_t csq,
-                                           uint32_t shift, uint32_t one) {
+// ---------------------------------------------------------------- tiles --
+
+// four entries per lane: the contribution goes to the low (shift 0) or the high (16) half of
+// every doc's word
+template<uint32_t SHIFT>
+__device__ __forceinline__ void fast_post4(const unsigned char* lds, const uint32_t (&e)[4], uint32_t csq) {
   uint32_t c[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) c[k] = (wave::mul_hi(e[k], csq) << shift) + one;
+  for (int k = 0; k < 4; ++k) c[k] = (wave::mul_hi(e[k], csq) << SHIFT) + (1u << SHIFT);
 #pragma unroll
   for (int k = 0; k < 4; ++k) wave::lds_add(lds, FastOff::acc + (e[k] & 0xFFFCu), c[k]);
 }
-// 256 consecutive entries at `base`, lane l holding entries 4l .. 4l+3 (one 16-byte load per
-// lane), of which the first n (1 .. 256) are wanted: lanes behind the end do not load ...
-__device__ __forceinline__ void fast_load(uint64_t base, uint32_t n, unsigned lane, uint32_t (&e)[4]) {
-  // (no initialisation of the other lanes' registers: fast_take replaces what they hold, and a
-  // write here would have to wait for whatever load is still in flight into these registers)
-  wave::undef4(e);
-  if (4u * lane < n) wave::gload_u32x4(base, 16u * lane, e);
-}
-// ... and elements at or behind n add to the lane's dummy word
-__device__ __forceinline__ void fast_take(const unsigned char* lds, uint32_t (&e)[4], uint32_t n,
-                                          uint32_t csq, uint32_t shift, unsigned lane) {
-  if (n < 256u) {   // (wave-uniform)
-    const uint32_t dummy = FastOff::dummy + 4u * lane;   // (score 0: adds `one` to a word nobody reads)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) e[k] = 4u * lane + uint32_t(k) < n ? e[k] : dummy;
-  }
-  fast_post4(lds, e, csq, shift, 1u << shift);
-}
-// `count` consecutive entries from `base`: 512 at a time, both loads of a step in flight together
-__device__ __forceinline__ void fast_run(const unsigned char* lds, uint64_t base, uint32_t count,
-                                         uint32_t csq, uint32_t shift, unsigned lane) {
+// `count` (a multiple of 4) consecutive entries from `base` (wave-uniform), 256 per step — the
+// rare tail of a piece behind the slots of its tile
+template<uint32_t SHIFT>
+__device__ __forceinline__ void fast_run(const unsigned char* lds, uint64_t base, uint64_t dummies, uint32_t count,
+                                         uint32_t csq, unsigned lane) {
   while (count) {
-    const uint32_t n = count < 512u ? count : 512u;
-    uint32_t r0[4], r1[4];
-    fast_load(base, n < 256u ? n : 256u, lane, r0);
-    if (n > 256u) fast_load(base + 1024u, n - 256u, lane, r1);
-    fast_take(lds, r0, n < 256u ? n : 256u, csq, shift, lane);
-    if (n > 256u) fast_take(lds, r1, n - 256u, csq, shift, lane);
-    base += 2048u;
-    count -= n;
+    uint32_t e[4];
+    const uint64_t at = (4u * lane < count ? base : dummies) + 16u * lane;
+    wave::gload_u32x4_at(at, e);
+    fast_post4<SHIFT>(lds, e, csq);
+    base += 1024u;
+    count = count > 256u ? count - 256u : 0u;
   }
 }
 
-// What the tile loop needs of a query term: where its fast entries are and its multiplier
-struct alignas(16) FastTerm {
-  uint64_t fent;
-  uint32_t csq, pad;
-};
 enum : uint32_t {   // more LDS scratch words (behind join.h's kJ*)
   kFUnit = 8,       // the chunk's unit
   kFThr = 9,        // its threshold in 16-bit units
@@ -139,11 +303,24 @@ enum : uint32_t {   // more LDS scratch words (behind join.h's kJ*)
 // The tiles of one chunk.  Everything it needs lives in LDS (tile boundaries, term records, the
 // wavefronts' shares, the chunk's scalars) — a function of its own so that the persistent
 // kernel's bookkeeping does not compete with the tile loop for registers.
+//
+// A wavefront's entries of a tile are PIECES: per term of its share the part in the tile's low
+// half (contributions to the low halves of the words) and the part in its high half.  They are
+// dealt to kFastSlots = 4 SLOTS of up to 256 entries — slots 0, 1 low half, slots 2, 3 high half:
+// a share inside ONE term (the rule) puts the first 512 entries of each half there, a share over
+// two terms the first 256 of each term and half — whose records (address, count, multiplier) are
+// worked out once per chunk, lane-parallel, into LDS.  The tile loop is then straight-line code:
+// four records, four 16-byte loads per lane (lanes past a slot's end read entries that add nothing:
+// an address select, no mask), requested BEFORE the previous tile's barrier so that they fly
+// behind its epilogue; sixteen multiply-adds into LDS; no scalar arithmetic, no branch.  What
+// does not fit the slots (a piece longer than its slots, a share over three terms and more) is
+// flagged per tile and handled by a loop behind the slots — rare by construction (k_fast_shares).
 // Returns the lane's match count: low half | high half.
 __device__ __attribute__((noinline)) uint32_t fast_tiles(unsigned char* smem, const FastArgs* args,
                                                          uint32_t ntile_arg) {
   const uint32_t* rng = reinterpret_cast<const uint32_t*>(smem + FastOff::rng);
-  const FastTerm* fts = reinterpret_cast<const FastTerm*>(smem + FastOff::jts);
+  const FastTerm* fts = reinterpret_cast<const FastTerm*>(smem + FastOff::fts);
+  const uint32_t* ord = reinterpret_cast<const uint32_t*>(smem + FastOff::ord);
   const uint32_t* vars = reinterpret_cast<const uint32_t*>(smem + FastOff::vars);
   const uint32_t tid = threadIdx.x;
   const unsigned lane = tid & 63u;
@@ -157,175 +334,101 @@ __device__ __attribute__((noinline)) uint32_t fast_tiles(unsigned char* smem, co
   const uint32_t f_lo = wave::uniform(sh.f_lo), f_hi = wave::uniform(sh.f_hi);
   const uint32_t thr = wave::uniform(vars[kFThr]);
   const uint32_t thr_k = (0x8000u - (thr < 0x8000u ? thr : 0x8000u)) * 0x00010001u;   // half + K: bit 15 set <=> half >= thr
-  uint32_t hit_pk = 0;
-  // A wavefront's entries of a tile are up to 2 (j1 - j0 + 1) PIECES: per term its low half
-  // tile's part (piece 2 (j - j0)) and its high half tile's (+ 1); piece_of() works one out
-  // (count 0: empty).
-  struct Piece {
-    uint64_t base;
-    uint32_t cnt, par;   // par: csq | (high half) << 16
-  };
-  const uint32_t n_pieces = j1 >= j0 ? 2u * (j1 - j0 + 1u) : 0u;
-  auto piece_of = [&](uint32_t u, uint32_t p) -> Piece {   // (u < ntile, p < n_pieces)
-    const uint32_t j = j0 + (p >> 1);
+  const uint64_t dummies = args->dummies;
+  const uint32_t n_share = j1 >= j0 ? j1 - j0 + 1u : 0u;   // terms of the share
+  // entries [from, to) of the share's term number jp (0 ..) in half `h` of tile u
+  auto piece = [&](uint32_t u, uint32_t jp, uint32_t h, uint32_t& j, uint32_t& from, uint32_t& to) {
+    j = ord[j0 + jp];
     const uint32_t a0 = rng[(2u * u) * kMaxTerms + j];
     const uint32_t b1 = rng[(2u * u + 1u) * kMaxTerms + j];
     const uint32_t a2 = rng[(2u * u + 2u) * kMaxTerms + j];
     const uint32_t n = a2 - a0;
-    const uint32_t lo = a0 + (j == j0 ? fast_cut(n, f_lo) : 0u);
-    const uint32_t hi = a0 + (j == j1 ? fast_cut(n, f_hi) : n);
+    const uint32_t lo = a0 + (jp == 0u ? fast_cut(n, f_lo) : 0u);
+    const uint32_t hi = a0 + (jp + 1u == n_share ? fast_cut(n, f_hi) : n);
     const uint32_t mid = b1 < lo ? lo : (b1 > hi ? hi : b1);
-    const uint32_t from = (p & 1u) ? mid : lo, to = (p & 1u) ? hi : mid;
-    Piece P;
-    P.base = fts[j].fent + 4ull * from;
-    P.cnt = to > from ? to - from : 0u;
-    P.par = fts[j].csq | ((p & 1u) << 16);
-    return P;
+    from = h ? mid : lo;
+    to = h ? hi : mid;
+    if (to < from) to = from;
   };
-  // The first four pieces of every tile of the chunk, worked out ONCE, lane-parallel: lane
-  // 4 u + s holds piece s of tile u — the tile loop reads them with v_readlane (no LDS round
-  // trip, no arithmetic between a barrier and the next tile's loads).
-  static_assert(kFastChunkTiles * 4u == 64u, "one lane per (tile, piece slot)");
-  uint32_t d_lo = 0, d_hi = 0, d_cnt = 0, d_par = 0;
+  // ---- the chunk's slot records: lane 4 u + s works out slot s of tile u
+  FastSlot* desc = reinterpret_cast<FastSlot*>(smem + FastOff::desc) + wv * (kFastChunkTiles * kFastSlots);
+  bool over = false;   // (per lane) the slot's piece is longer than the slots hold
   {
     const uint32_t u = lane >> 2, sl = lane & 3u;
-    if (u < ntile && sl < n_pieces) {
-      const Piece P = piece_of(u, sl);
-      d_lo = uint32_t(P.base);
-      d_hi = uint32_t(P.base >> 32);
-      d_cnt = P.cnt;
-      d_par = P.par;
+    FastSlot D{uint32_t(dummies), uint32_t(dummies >> 32), 0u, 0u};
+    if (u < ntile && n_share) {
+      // one term: slots (0, 1) = its low half's first and second 256 entries, (2, 3) its high
+      // half's; two terms and more: slot (0, 2) = the first term's halves, (1, 3) the second's
+      const uint32_t h = sl >> 1;
+      const uint32_t jp = n_share == 1u ? 0u : (sl & 1u);
+      const uint32_t skip = n_share == 1u ? 256u * (sl & 1u) : 0u;
+      if (jp < n_share) {
+        uint32_t j, from, to;
+        piece(u, jp, h, j, from, to);
+        if (to > from + skip) {
+          const uint64_t at = fts[j].fent + 4ull * (from + skip);
+          D.lo = uint32_t(at);
+          D.hi = uint32_t(at >> 32);
+          D.cnt = to - from - skip;
+          D.csq = fts[j].csq;
+          over = D.cnt > (n_share == 1u && !(sl & 1u) ? 512u : 256u);
+        }
+      }
     }
+    desc[lane] = D;
   }
-  auto slot = [&](uint32_t u, uint32_t sl) -> Piece {   // (wave-uniform arguments)
-    const uint32_t L = 4u * u + sl;
-    Piece P;
-    P.cnt = u < ntile ? wave::read_lane(d_cnt, L & 63u) : 0u;
-    P.base = (uint64_t(wave::read_lane(d_hi, L & 63u)) << 32) | wave::read_lane(d_lo, L & 63u);
-    P.par = wave::read_lane(d_par, L & 63u);
-    return P;
-  };
-  // Pieces 0 and 1 of the NEXT tile — up to kFastPre entries each — are requested before this
-  // tile's barrier: the loads fly behind the epilogue, and a wavefront whose share lies inside
-  // one term (the rule) finds its whole tile waiting.
-  Piece A{0, 0, 0}, B{0, 0, 0};
-  uint32_t ra[4], rb[4], sa[4], sb[4];   // entries 0 .. 255 / 256 .. 511 of the two pieces
+  // tiles with something behind their slots: a long piece, or a share over three terms and more
+  const uint64_t slow_tiles = n_share > 2u ? ~0ull : wave::ballot(over);
+  wave::sync();   // (the records are read by every lane of the wavefront)
+  uint32_t hit_pk = 0;
+  const uint32_t lane16 = 16u * lane, lane4 = 4u * lane;
+  uint32_t r0[4], r1[4], r2[4], r3[4];
+  uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;   // the slots' multipliers
+  // the four loads of tile u: records first, then the addresses, then the loads back to back
   auto request = [&](uint32_t u) {
-    A = slot(u, 0u);
-    B = slot(u, 1u);
-    const uint32_t na = A.cnt < kFastPre ? A.cnt : kFastPre, nb = B.cnt < kFastPre ? B.cnt : kFastPre;
-    // all addresses first, then the loads back to back: whatever the address arithmetic has to
-    // wait for (the registers' previous loads) is waited for BEFORE the first new load is issued
-    uint64_t pa = A.base + 16u * lane, pb = B.base + 16u * lane;
-    wave::keep64(pa);
-    wave::keep64(pb);
-    wave::undef4(ra);
-    wave::undef4(rb);
-    wave::undef4(sa);
-    wave::undef4(sb);
-    if (4u * lane < na) wave::gload_u32x4_at(pa, ra);
-    if (4u * lane < nb) wave::gload_u32x4_at(pb, rb);
-    if (4u * lane + 256u < na) wave::gload_u32x4_at(pa + 1024u, sa);
-    if (4u * lane + 256u < nb) wave::gload_u32x4_at(pb + 1024u, sb);
+    const FastSlot* d = desc + kFastSlots * (u < ntile ? u : 0u);
+    const FastSlot d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3];
+    const bool live = u < ntile;
+    uint64_t a0 = ((live && lane4 < d0.cnt) ? ((uint64_t(d0.hi) << 32) | d0.lo) : dummies) + lane16;
+    uint64_t a1 = ((live && lane4 < d1.cnt) ? ((uint64_t(d1.hi) << 32) | d1.lo) : dummies) + lane16;
+    uint64_t a2 = ((live && lane4 < d2.cnt) ? ((uint64_t(d2.hi) << 32) | d2.lo) : dummies) + lane16;
+    uint64_t a3 = ((live && lane4 < d3.cnt) ? ((uint64_t(d3.hi) << 32) | d3.lo) : dummies) + lane16;
+    wave::keep64(a0);
+    wave::keep64(a1);
+    wave::keep64(a2);
+    wave::keep64(a3);
+    q0 = d0.csq; q1 = d1.csq; q2 = d2.csq; q3 = d3.csq;
+    wave::gload_u32x4_at(a0, r0);
+    wave::gload_u32x4_at(a1, r1);
+    wave::gload_u32x4_at(a2, r2);
+    wave::gload_u32x4_at(a3, r3);
   };
-  auto consume = [&](const Piece& P, uint32_t (&r)[4], uint32_t (&s2)[4]) {
-    const uint32_t n = P.cnt < kFastPre ? P.cnt : kFastPre;
-    const uint32_t csq = P.par & 0xFFFFu, shift = (P.par >> 16) << 4;
-    fast_take(smem, r, n < 256u ? n : 256u, csq, shift, lane);
-    if (n > 256u) fast_take(smem, s2, n - 256u, csq, shift, lane);
-    if (P.cnt > n) fast_run(smem, P.base + 4ull * n, P.cnt - n, csq, shift, lane);
-  };
-  // A share that SPANS terms (one wavefront of 16 as a rule: the query's rare terms together) is
-  // many small pieces.  Its tile is laid out in SLABS of up to 64 entries of one piece, lane
-  // k < 16 holding slab k's address, count and multiplier; all 16 loads are issued before the
-  // previous tile's barrier, like the two big pieces of a one-term share.  (Loaded piece by
-  // piece behind the barrier, every one of them costs a memory round trip while the other 15
-  // wavefronts of the workgroup wait.)
-  const bool multi = n_pieces > 2u;
-  uint32_t g_lo = 0, g_hi = 0, g_cnt = 0, g_par = 0;
-  bool g_over = false;   // the tile has more than 16 slabs
-  // piece p = lane (p < n_pieces <= 32): the piece, its slabs, its first slab's index
-  auto layout = [&](uint32_t u, Piece& P, uint32_t& first, uint32_t& ns) {
-    P = Piece{0, 0, 0};
-    if (u < ntile && lane < n_pieces) P = piece_of(u, lane);
-    ns = (P.cnt + 63u) >> 6;
-    first = wave::inclusive_scan(ns) - ns;
-  };
-  auto request_multi = [&](uint32_t u) {
-    Piece P;
-    uint32_t first, ns;
-    layout(u, P, first, ns);
-    g_cnt = 0;
-    for (uint32_t i = 0; i < n_pieces; ++i) {   // (wave-uniform) slab k = lane belongs to piece i?
-      const uint32_t n = wave::read_lane(ns, i);
-      if (!n) continue;
-      const uint32_t f = wave::read_lane(first, i);
-      if (f >= 16u) break;
-      const uint32_t cnt = wave::read_lane(P.cnt, i), par = wave::read_lane(P.par, i);
-      const uint64_t base = (uint64_t(wave::read_lane(uint32_t(P.base >> 32), i)) << 32) |
-                            wave::read_lane(uint32_t(P.base), i);
-      if (lane >= f && lane < f + n && lane < 16u) {
-        const uint32_t o = lane - f;
-        const uint64_t at = base + 256ull * o;
-        g_lo = uint32_t(at);
-        g_hi = uint32_t(at >> 32);
-        g_cnt = cnt - 64u * o < 64u ? cnt - 64u * o : 64u;
-        g_par = par;
-      }
-    }
-    g_over = wave::read_lane(first + ns, 31u) > 16u;
-    // the 16 loads back to back (saddr form: no address arithmetic in vector registers)
-    uint32_t* const r[16] = {&ra[0], &ra[1], &ra[2], &ra[3], &rb[0], &rb[1], &rb[2], &rb[3],
-                             &sa[0], &sa[1], &sa[2], &sa[3], &sb[0], &sb[1], &sb[2], &sb[3]};
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const uint32_t c = wave::read_lane(g_cnt, uint32_t(k));
-      if (c) {
-        const uint64_t base = (uint64_t(wave::read_lane(g_hi, uint32_t(k))) << 32) | wave::read_lane(g_lo, uint32_t(k));
-        if (lane < c) *r[k] = wave::gload_u32(base, 4u * lane);
-      }
-    }
-  };
-  auto consume_multi = [&](uint32_t u) {
-    uint32_t* const r[16] = {&ra[0], &ra[1], &ra[2], &ra[3], &rb[0], &rb[1], &rb[2], &rb[3],
-                             &sa[0], &sa[1], &sa[2], &sa[3], &sb[0], &sb[1], &sb[2], &sb[3]};
-    const uint32_t dummy = FastOff::dummy + 4u * lane;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const uint32_t c = wave::read_lane(g_cnt, uint32_t(k));
-      if (c) {
-        const uint32_t par = wave::read_lane(g_par, uint32_t(k));
-        const uint32_t shift = (par >> 16) << 4;
-        const uint32_t e = lane < c ? *r[k] : dummy;
-        wave::lds_add(smem, FastOff::acc + (e & 0xFFFCu), (wave::mul_hi(e, par & 0xFFFFu) << shift) + (1u << shift));
-      }
-    }
-    if (g_over) {   // (rare: the slabs behind the 16th, piece by piece)
-      Piece P;
-      uint32_t first, ns;
-      layout(u, P, first, ns);
-      for (uint32_t i = 0; i < n_pieces; ++i) {
-        const uint32_t n = wave::read_lane(ns, i), f = wave::read_lane(first, i);
-        if (!n || f + n <= 16u) continue;
-        const uint32_t skip = f < 16u ? 64u * (16u - f) : 0u;   // entries of the piece in slabs < 16
-        const uint32_t cnt = wave::read_lane(P.cnt, i), par = wave::read_lane(P.par, i);
-        const uint64_t base = (uint64_t(wave::read_lane(uint32_t(P.base >> 32), i)) << 32) |
-                              wave::read_lane(uint32_t(P.base), i);
-        fast_run(smem, base + 4ull * skip, cnt - skip, par & 0xFFFFu, (par >> 16) << 4, lane);
-      }
-    }
-  };
-  if (multi) request_multi(0); else request(0);
+  request(0);
   for (uint32_t u = 0; u < ntile; ++u) {
     // ---- accumulate this wavefront's entries of tile u
-    if (multi) {
-      consume_multi(u);
-      request_multi(u + 1u);
-    } else {
-      if (A.cnt) consume(A, ra, sa);
-      if (B.cnt) consume(B, rb, sb);
-      request(u + 1u);
+    fast_post4<0u>(smem, r0, q0);
+    fast_post4<0u>(smem, r1, q1);
+    fast_post4<16u>(smem, r2, q2);
+    fast_post4<16u>(smem, r3, q3);
+    if ((slow_tiles >> (4u * u)) & 0xFull) {   // (rare) what the slots do not hold
+      for (uint32_t jp = 0; jp < n_share; ++jp) {
+        for (uint32_t h = 0; h < 2u; ++h) {
+          uint32_t j, from, to;
+          piece(u, jp, h, j, from, to);
+          j = wave::uniform(j);
+          from = wave::uniform(from);
+          to = wave::uniform(to);
+          const uint32_t held = n_share == 1u ? 512u : (jp < 2u ? 256u : 0u);
+          if (to > from + held) {
+            const uint64_t base = wave::uniform64(fts[j].fent) + 4ull * (from + held);
+            const uint32_t csq = wave::uniform(fts[j].csq);
+            if (h) fast_run<16u>(smem, base, dummies, to - from - held, csq, lane);
+            else fast_run<0u>(smem, base, dummies, to - from - held, csq, lane);
+          }
+        }
+      }
     }
+    request(u + 1u);
     __syncthreads();   // B1: every accumulation of tile u has landed
     // ---- epilogue: 12 words (24 docs) per lane, read AND cleared by LDS exchanges
     auto candidate = [&](uint32_t word, uint32_t w) {   // rare: everything it needs comes from LDS
@@ -359,7 +462,7 @@ __device__ __attribute__((noinline)) uint32_t fast_tiles(unsigned char* smem, co
         for (uint32_t k = 0; k < 4u; ++k) candidate(i + k, v[k]);
       }
     };
-    // (one exchange at a time: the prefetched entries of the next tile occupy the registers a
+    // (one exchange at a time: the requested entries of the next tile occupy the registers a
     // second one in flight would need)
     for (uint32_t i = tid * 4u; i < kJoinTile; i += n_threads * 4u) {
       uint32_t v0[4];
@@ -383,7 +486,7 @@ k_join_fast(const FastArgs* __restrict__ args) {
   if (!wave::lds_is_at_zero(smem)) __builtin_trap();
   uint32_t* acc = reinterpret_cast<uint32_t*>(smem + FastOff::acc);
   uint32_t* rng = reinterpret_cast<uint32_t*>(smem + FastOff::rng);
-  FastTerm* fts = reinterpret_cast<FastTerm*>(smem + FastOff::jts);
+  FastTerm* fts = reinterpret_cast<FastTerm*>(smem + FastOff::fts);
   FastShare* share = reinterpret_cast<FastShare*>(smem + FastOff::share);
   uint64_t* lcand = reinterpret_cast<uint64_t*>(smem + FastOff::cand);
   uint32_t* vars = reinterpret_cast<uint32_t*>(smem + FastOff::vars);
@@ -442,12 +545,8 @@ k_join_fast(const FastArgs* __restrict__ args) {
       // rng[i][j] = bounds_j[2 * tile0 + i] (a segment with an odd number of half tiles: the
       // last boundary once more)
       if (tid < kMaxTerms) {
-        FastTerm ft{0, 0, 0};
-        if (tid < n_terms) {
-          const JoinTerm jt = args->jterms[qd.first_term + tid];
-          ft.fent = jt.entries + uint64_t(args->fast_delta);
-          ft.csq = jt.pad[0];
-        }
+        FastTerm ft{0, 0, 0, {0, 0, 0}};
+        if (tid < n_terms) ft = args->fterms[qd.first_term + tid];
         fts[tid] = ft;
       }
       for (uint32_t e = tid; e < (2u * ntile + 1u) * kMaxTerms; e += blockDim.x) {
@@ -456,7 +555,7 @@ k_join_fast(const FastArgs* __restrict__ args) {
         if (j < n_terms) {
           uint32_t h = 2u * tile0 + i;
           h = h < n_half ? h : n_half;
-          v = reinterpret_cast<const uint32_t*>(args->jterms[qd.first_term + j].bounds)[h];
+          v = reinterpret_cast<const uint32_t*>(args->fterms[qd.first_term + j].fbounds)[h];
         }
         rng[e] = v;
       }
@@ -475,38 +574,12 @@ k_join_fast(const FastArgs* __restrict__ args) {
         vars[kFParity] = parity;
       }
       __syncthreads();
-      // the wavefronts' shares of the chunk (one thread each)
-      if (tid < nw) {
-        // (32-bit sums: a chunk holds fewer than 2^32 entries of a query's terms; the fractions
-        // only have to be the SAME value wherever two wavefronts meet — float division will do)
-        uint32_t W = 0;
-        for (uint32_t j = 0; j < n_terms; ++j)
-          W += rng[2u * ntile * kMaxTerms + j] - rng[j];
-        const uint32_t lo = uint32_t(uint64_t(W) * tid / nw), hi = uint32_t(uint64_t(W) * (tid + 1u) / nw);
-        auto frac = [](uint32_t x, uint32_t N) -> uint32_t {   // x < N
-          const float f = (float(x) / float(N)) * 4294967296.f;
-          return f >= 4294967040.f ? 0xFFFFFF00u : uint32_t(f);
-        };
-        FastShare s{1u, 0u, 0u, 0u};   // (j0 > j1: nothing)
-        if (hi > lo) {
-          uint32_t P = 0;
-          bool open = false;
-          for (uint32_t j = 0; j < n_terms; ++j) {
-            const uint32_t N = rng[2u * ntile * kMaxTerms + j] - rng[j];
-            if (!N) continue;
-            if (!open && P + N > lo) {
-              open = true;
-              s.j0 = j;
-              s.f_lo = frac(lo - P, N);
-            }
-            if (open && P < hi) {
-              s.j1 = j;
-              s.f_hi = (hi - P >= N) ? 0xFFFFFFFFu : frac(hi - P, N);
-            }
-            P += N;
-          }
-        }
-        share[tid] = s;
+      // the wavefronts' shares of the chunk and the order of its terms: worked out for every
+      // chunk of the launch by k_fast_shares
+      if (tid < 16u) {
+        const FastChunk* rec = args->chunks + chunk;
+        share[tid] = rec->share[tid];
+        reinterpret_cast<uint32_t*>(smem + FastOff::ord)[tid] = rec->ord[tid];
       }
       __syncthreads();
       hit_pk = fast_tiles(smem, args, ntile);

@@ -247,6 +247,20 @@ __device__ __forceinline__ void lds_take4x2(unsigned char*, uint32_t off0, uint3
   a[0] = x[0]; a[1] = x[1]; a[2] = x[2]; a[3] = x[3];
   b[0] = y[0]; b[1] = y[1]; b[2] = y[2]; b[3] = y[3];
 }
+__device__ __forceinline__ void lds_take4x3(unsigned char*, uint32_t off0, uint32_t off1, uint32_t off2,
+                                            uint32_t (&a)[4], uint32_t (&b)[4], uint32_t (&c)[4]) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 x, y, w;
+  uint64_t z = 0;
+  asm volatile("ds_wrxchg2_rtn_b64 %0, %3, %6, %6 offset1:1\n\t"
+               "ds_wrxchg2_rtn_b64 %1, %4, %6, %6 offset1:1\n\t"
+               "ds_wrxchg2_rtn_b64 %2, %5, %6, %6 offset1:1\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&v"(x), "=&v"(y), "=&v"(w) : "v"(off0), "v"(off1), "v"(off2), "v"(z) : "memory");
+  a[0] = x[0]; a[1] = x[1]; a[2] = x[2]; a[3] = x[3];
+  b[0] = y[0]; b[1] = y[1]; b[2] = y[2]; b[3] = y[3];
+  c[0] = w[0]; c[1] = w[1]; c[2] = w[2]; c[3] = w[3];
+}
 // (ds_write2_b64 from ONE zeroed register pair: a ds_write_b128 would pin four zero registers
 // for the whole kernel)
 __device__ __forceinline__ void lds_zero4(unsigned char*, uint32_t off) {

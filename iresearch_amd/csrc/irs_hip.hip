@@ -322,7 +322,9 @@ struct irs_hip_batch {
   // fast.h: plain disjunctions in two passes — fast entries next to the exact ones (same
   // offsets), the first pass's approximate candidates, the kernels' argument records
   bool fast16 = false;
-  DevBuf d_fast, d_acands, d_acand_count, d_fast_args, d_rescore_args;
+  DevBuf d_fast, d_fbounds, d_fterms, d_fast_wg, d_fast_dummies;
+  DevBuf d_acands, d_acand_count, d_fast_args, d_rescore_args, d_fast_chunks;
+  uint32_t n_fast_pack_wgs = 0;
   FastArgs fast_args{}, fast_args_sent{};
   RescoreArgs rescore_args{}, rescore_args_sent{};
   bool fast_args_valid = false, rescore_args_valid = false;
@@ -994,14 +996,20 @@ bool build_streams(irs_hip_batch* b) {
       }
     }
   }
-  uint64_t entries = 0, bounds = 0;
-  std::vector<uint64_t> ent_off, bnd_off;
+  uint64_t entries = 0, bounds = 0, fentries = 0;
+  std::vector<uint64_t> ent_off, bnd_off, fent_off;
+  std::vector<uint32_t> fast_wg(streams.size() + 1, 0);   // k_fast_pack: the streams' first workgroups
   for (size_t si = 0; si < streams.size(); ++si) {
     const irs_hip_segment* sg = b->segs[streams[si].seg];
     const DevTerm& t = sg->terms[streams[si].term];
     ent_off.push_back(entries);
     bnd_off.push_back(bounds);
     const uint32_t n_tiles = (sg->dev.num_docs + kJoinTile - 1) / kJoinTile;
+    // fast.h: the stream once more, every tile padded to a multiple of four entries (16-byte
+    // aligned from the start)
+    fent_off.push_back(fentries);
+    if (stream_fast[si]) fentries += (uint64_t(t.docs_count) + 3ull * n_tiles + 3ull) & ~3ull;
+    fast_wg[si + 1] = fast_wg[si] + (stream_fast[si] ? (n_tiles + kFastPackTiles - 1) / kFastPackTiles : 0u);
     const uint32_t nb = t.nblk + ((t.docs_count == 1 || t.tail_n) ? 1u : 0u);
     for (uint32_t first = 0; first < nb; first += kJoinBlocks)
       wgs.push_back(WgRef{uint32_t(si), first});
@@ -1033,8 +1041,13 @@ bool build_streams(irs_hip_batch* b) {
     wgs.swap(sorted);
   }
   lap("  streams: buffers");
-  if (b->fast16 && !b->d_fast.alloc((entries + kJoinSlack) * 4)) return false;
+  if (b->fast16 &&
+      (!b->d_fast.alloc((fentries + kJoinSlack) * 4) || !b->d_fbounds.alloc((bounds + 1) * 4) ||
+       !b->d_fterms.alloc(jterms.size() * sizeof(FastTerm)) ||
+       !b->d_fast_wg.alloc(fast_wg.size() * 4) || !b->d_fast_dummies.alloc(64 * 16)))
+    return false;
   if (!b->fast16) b->d_fast.release();
+  b->n_fast_pack_wgs = b->fast16 ? fast_wg.back() : 0u;
   if (!b->d_entries.alloc((entries + kJoinSlack) * 4) || !b->d_bounds.alloc((bounds + 1) * 4) ||
       !b->d_streams.alloc(std::max<size_t>(1, streams.size()) * sizeof(StreamRec)) ||
       !b->d_join_wgs.alloc(std::max<size_t>(1, wgs.size()) * sizeof(JoinWg)) ||
@@ -1087,6 +1100,15 @@ bool build_streams(irs_hip_batch* b) {
   for (size_t i = 0; i < streams.size(); ++i) {
     streams[i].entries = reinterpret_cast<uint64_t>(b->d_entries.as<uint32_t>() + ent_off[i]);
     streams[i].bounds = reinterpret_cast<uint64_t>(b->d_bounds.as<uint32_t>() + bnd_off[i]);
+    streams[i].n_tiles = (b->segs[streams[i].seg]->dev.num_docs + kJoinTile - 1) / kJoinTile;
+    const Sig& sig = sigs[stream_sig[i]];
+    streams[i].kind = sig.kind;
+    streams[i].nc = sig.nc;
+    streams[i].nl = sig.nl;
+    if (b->fast16 && stream_fast[i]) {
+      streams[i].fent = reinterpret_cast<uint64_t>(b->d_fast.as<uint32_t>() + fent_off[i]);
+      streams[i].fbounds = reinterpret_cast<uint64_t>(b->d_fbounds.as<uint32_t>() + bnd_off[i]);
+    }
   }
   for (irs_hip_segment* sg : b->segs)
     if (prepare_posting_norms(sg) != IRS_HIP_OK) return false;
@@ -1116,12 +1138,10 @@ bool build_streams(irs_hip_batch* b) {
     w.last_doc = t.last_doc;
     w.n_tiles = (ds.num_docs + kJoinTile - 1) / kJoinTile;
     w.n = sr.n;
-    const Sig& sig = sigs[stream_sig[wgs[i].stream]];
-    w.fast_kind = uint32_t(sig.kind & 0xFF) | (stream_fast[wgs[i].stream] ? 0x100u : 0u);
-    std::memcpy(&w.fast_nc, &sig.nc, 4);
-    std::memcpy(&w.fast_nl, &sig.nl, 4);
+    w.pad[0] = w.pad[1] = w.pad[2] = 0;
   }
   lap("  streams: per-term records");
+  std::vector<FastTerm> fterms(b->fast16 ? jterms.size() : 0);
   for (uint32_t u : b->join_units) {
     DevQuery& dq = b->queries[u];
     const uint32_t rows = table_rows(dq.n_caches);
@@ -1138,8 +1158,14 @@ bool build_streams(irs_hip_batch* b) {
       const DevQTerm& qt = b->qterms[dq.first_term + j];
       const size_t sid = stream_of[dq.first_term + j];
       JoinTerm& jt = jterms[dq.first_term + j];
-      jt.pad[0] = uint32_t(double(qt.c0) * double(fast_tn(qt.kind)) * s16);
-      jt.pad[1] = 0;
+      jt.pad[0] = jt.pad[1] = 0;
+      if (b->fast16) {
+        FastTerm& ft = fterms[dq.first_term + j];
+        ft.fent = streams[sid].fent;
+        ft.fbounds = streams[sid].fbounds;
+        ft.csq = uint32_t(double(qt.c0) * double(fast_tn(qt.kind)) * s16);
+        ft.pad[0] = ft.pad[1] = ft.pad[2] = 0;
+      }
       jt.entries = streams[sid].entries;
       jt.bounds = streams[sid].bounds;
       jt.cs = qt.c0 * dq.fx_mul;
@@ -1157,23 +1183,33 @@ bool build_streams(irs_hip_batch* b) {
       !b->up.copy(b->d_join_units.p, b->join_units.data(), b->join_units.size() * 4) ||
       !b->up.copy(b->d_join_order.p, order.data(), order.size() * 4))
     return false;
+  if (b->fast16) {
+    // entries that add nothing: lane l's four at + 16 l — score 0 into the lane's dummy word
+    uint32_t* dm = static_cast<uint32_t*>(b->up.put(b->d_fast_dummies.p, 64 * 16));
+    if (!dm) return false;
+    for (uint32_t l = 0; l < 64; ++l)
+      for (uint32_t k = 0; k < 4; ++k) dm[4 * l + k] = FastOff::dummy + 4u * l;
+    if (!b->up.copy(b->d_fterms.p, fterms.data(), fterms.size() * sizeof(FastTerm)) ||
+        !b->up.copy(b->d_fast_wg.p, fast_wg.data(), fast_wg.size() * 4))
+      return false;
+  }
   b->n_streams = uint32_t(streams.size());
   b->n_join_wgs = uint32_t(wgs.size());
   b->join_entries = entries;
   return true;
 }
 
-// a stream's fast entries live at the same offset of d_fast as its exact entries of d_entries
-int64_t fast_delta(const irs_hip_batch* b) {
-  return b->fast16 ? int64_t(reinterpret_cast<intptr_t>(b->d_fast.p) - reinterpret_cast<intptr_t>(b->d_entries.p)) : 0;
-}
-
 bool launch_join(irs_hip_batch* b, rt::stream_t st) {
   if (!b->n_join_wgs) return true;
   if (b->seg->dev.layout == kSimd4) {
-    RT_LAUNCH((k_join<kSimd4>), b->n_join_wgs, kThreads, 0, st, b->d_join_wgs.as<JoinWg>(), fast_delta(b));
+    RT_LAUNCH((k_join<kSimd4>), b->n_join_wgs, kThreads, 0, st, b->d_join_wgs.as<JoinWg>());
   } else {
-    RT_LAUNCH((k_join<kScalar>), b->n_join_wgs, kThreads, 0, st, b->d_join_wgs.as<JoinWg>(), fast_delta(b));
+    RT_LAUNCH((k_join<kScalar>), b->n_join_wgs, kThreads, 0, st, b->d_join_wgs.as<JoinWg>());
+  }
+  if (b->fast16 && b->n_fast_pack_wgs) {   // fast.h: the streams once more as padded fast entries
+    RT_LAUNCH(k_fast_layout, b->n_streams, 64, 0, st, b->d_streams.as<StreamRec>(), b->n_streams);
+    RT_LAUNCH(k_fast_pack, b->n_fast_pack_wgs, kThreads, 0, st, b->d_streams.as<StreamRec>(),
+              b->d_fast_wg.as<uint32_t>(), b->n_streams);
   }
   return rt::last_error_ok();
 }
@@ -1326,8 +1362,8 @@ bool launch_join_fast(irs_hip_batch* b, rt::stream_t st) {
   if (!b->d_join_ctr.p && !b->d_join_ctr.alloc(2 * sizeof b->join_ctr_init)) return false;
   FastArgs& a = b->fast_args;
   a.queries = b->d_queries.as<DevQuery>();
-  a.jterms = b->d_jterms.as<JoinTerm>();
-  a.fast_delta = fast_delta(b);
+  a.fterms = b->d_fterms.as<FastTerm>();
+  a.dummies = reinterpret_cast<uint64_t>(b->d_fast_dummies.p);
   a.bstar = b->d_bstar.as<uint32_t>();
   a.cands = b->d_acands.as<uint64_t>();
   a.cand_count = b->d_acand_count.as<uint32_t>();
@@ -1348,6 +1384,9 @@ bool launch_join_fast(irs_hip_batch* b, rt::stream_t st) {
   a.nw_log2 = b->join_nw_log2;
   a.cand_cap = b->cand_cap;
   a.chunk_tiles = chunk_tiles;
+  if (b->d_fast_chunks.n < chunks * sizeof(FastChunk) && !b->d_fast_chunks.alloc(chunks * sizeof(FastChunk)))
+    return false;
+  a.chunks = b->d_fast_chunks.as<FastChunk>();
   uint32_t* d_init = a.work_counter + 2 * kJoinQueues;
   if (!b->fast_args_valid || std::memcmp(&a, &b->fast_args_sent, sizeof a) != 0) {
     if (!b->up.copy(b->d_fast_args.p, &a, sizeof a) ||
@@ -1377,6 +1416,8 @@ bool launch_join_fast(irs_hip_batch* b, rt::stream_t st) {
     return false;
   static const bool trace = std::getenv("IRS_HIP_TRACE") != nullptr;
   if (trace) std::fprintf(stderr, "[irs_hip] k_join_fast: %u units, %u chunks of %u tiles, grid %u\n", n_units, unsigned(chunks), chunk_tiles, grid);
+  RT_LAUNCH(k_fast_shares, uint32_t((chunks + kThreads - 1) / kThreads), kThreads, 0, st,
+            b->d_fast_args.as<FastArgs>(), b->d_fast_chunks.as<FastChunk>());
   RT_LAUNCH(k_join_fast, grid, b->join_threads, smem, st, b->d_fast_args.as<FastArgs>());
   RT_LAUNCH(k_join_rescore, n_units, kTileThreadsMax, kRescoreSmem, st, b->d_rescore_args.as<RescoreArgs>());
   return rt::last_error_ok();

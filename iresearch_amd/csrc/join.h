@@ -58,10 +58,17 @@ struct alignas(16) StreamRec {
   uint64_t entries;   // device address of the first entry (u32 each, posting order)
   uint64_t bounds;    // device address of bounds[0 .. n_tiles]: entry index of the first
                       // posting with doc >= tile's first doc; bounds[n_tiles] = n
+  // fast.h (0: the stream has no fast entries): the stream once more as FAST entries, every
+  // tile's entries padded to a multiple of four, and where its tiles begin there
+  uint64_t fent, fbounds;
   uint32_t seg, term;
   uint32_t n;         // postings
+  uint32_t n_tiles;   // doc tiles of the segment
+  int32_t kind;       // the scorer the fast entries are evaluated with: Kind, norm_const, norm_length
+  float nc, nl;
   uint32_t pad;
 };
+static_assert(sizeof(StreamRec) == 64, "StreamRec");
 // k_join work: kJoinBlocks blocks (the tail counts as one) of a stream, and EVERYTHING the
 // workgroup needs to know about it in one record, read by a scalar load: the kernel used to walk
 // work item -> stream -> segment -> term -> directory (five dependent loads, ~4 us) before its
@@ -81,9 +88,7 @@ struct alignas(16) JoinWg {
   uint32_t last_doc;          // of the list
   uint32_t n_tiles;           // doc tiles of the segment
   uint32_t n;                 // postings of the list
-  // fast.h: the stream also gets FAST entries (bit 8) evaluated with this scorer: Kind (low byte),
-  // norm_const, norm_length (float bits)
-  uint32_t fast_kind, fast_nc, fast_nl;
+  uint32_t pad[3];
 };
 static_assert(sizeof(JoinWg) == 112, "JoinWg");
 // Per (unit, term slot), parallel to DevQTerm: all k_join_score needs in one 32-byte record.
@@ -136,16 +141,10 @@ constexpr uint32_t kJoinRounds = kJoinBlocks / (kWaves * kJoinPerWave);
 static_assert(kJoinRounds * kWaves * kJoinPerWave == kJoinBlocks, "k_join rounds");
 
 // entries + tile boundaries of the two postings a lane holds of one block
-struct JoinFast {   // (wave-uniform) where a stream's fast entries go and how they are scored
-  uint32_t* ent;    // null: the stream has none
-  int32_t kind;
-  float nc, nl;
-};
 __device__ __forceinline__ void join_emit(uint32_t* ent, uint32_t* bnd, uint32_t b, unsigned lane,
                                           uint32_t d0, uint32_t d1, uint32_t f0, uint32_t f1,
                                           uint32_t n0, uint32_t n1, bool v0, bool v1,
-                                          uint32_t prev /*0: the list's first posting*/,
-                                          const JoinFast& F) {
+                                          uint32_t prev /*0: the list's first posting*/) {
   const uint32_t p0 = kBlock * b + 2u * lane;
   const uint32_t t0 = v0 ? (d0 - kDocMin) / kJoinTile : 0u;
   const uint32_t t1 = v1 ? (d1 - kDocMin) / kJoinTile : t0;
@@ -156,16 +155,6 @@ __device__ __forceinline__ void join_emit(uint32_t* ent, uint32_t* bnd, uint32_t
     __builtin_memcpy(ent + p0, &both, 8);
   } else if (v0) {
     ent[p0] = e0;
-  }
-  if (F.ent) {   // (wave-uniform) fast.h: the same postings once more, scored
-    const uint32_t g0 = fast_entry((d0 - kDocMin) - t0 * kJoinTile, fast_unit(F.kind, F.nc, F.nl, f0, n0));
-    const uint32_t g1 = fast_entry((d1 - kDocMin) - t1 * kJoinTile, fast_unit(F.kind, F.nc, F.nl, f1, n1));
-    if (v1) {
-      uint64_t both = (uint64_t(g1) << 32) | g0;
-      __builtin_memcpy(F.ent + p0, &both, 8);
-    } else if (v0) {
-      F.ent[p0] = g0;
-    }
   }
   // tile boundaries: posting p opens every tile in (tile of posting p - 1, tile of p]
   const uint32_t up = __shfl_up(t1, 1, 64);
@@ -180,16 +169,11 @@ __device__ __forceinline__ void join_emit(uint32_t* ent, uint32_t* bnd, uint32_t
 
 template<int LAYOUT>
 __global__ void __launch_bounds__(kThreads)
-k_join(const JoinWg* wgs, int64_t fast_delta) {
+k_join(const JoinWg* wgs) {
   const unsigned lane = threadIdx.x & 63u;
   const uint32_t wv = wave::uniform(threadIdx.x >> 6);
   const JoinWg W = wave::sload<JoinWg>(reinterpret_cast<uint64_t>(wgs) + uint64_t(blockIdx.x) * sizeof(JoinWg));
   uint32_t* ent = reinterpret_cast<uint32_t*>(W.entries);
-  JoinFast F;
-  F.ent = (W.fast_kind & 0x100u) ? reinterpret_cast<uint32_t*>(W.entries + uint64_t(fast_delta)) : nullptr;
-  F.kind = int32_t(W.fast_kind & 0xFFu);
-  F.nc = __uint_as_float(W.fast_nc);
-  F.nl = __uint_as_float(W.fast_nl);
   uint32_t* bnd = reinterpret_cast<uint32_t*>(W.bounds);
   const uint8_t* doc = reinterpret_cast<const uint8_t*>(W.doc);
   const bool tiny = W.pnorm != 0;
@@ -260,7 +244,7 @@ k_join(const JoinWg* wgs, int64_t fast_delta) {
       const uint32_t b = r0 + wv + kWaves * i;
       if (full[i])
         join_emit(ent, bnd, b, lane, d0[i], d1[i], f0[i], f1[i], n0[i], n1[i], true, true,
-                  b ? dir[i].prev_last : 0u, F);
+                  b ? dir[i].prev_last : 0u);
     }
   }
   // the vint tail / single doc, decoded when the segment was opened: the list's last "block"
@@ -276,7 +260,7 @@ k_join(const JoinWg* wgs, int64_t fast_delta) {
     const uint8_t* tnorms = reinterpret_cast<const uint8_t*>(W.tail_norms);
     const uint32_t tn0 = (v0 && tiny) ? tnorms[i0] : 0u;
     const uint32_t tn1 = (v1 && tiny) ? tnorms[i0 + 1u] : 0u;
-    join_emit(ent, bnd, bt, lane, td0, td1, tf0, tf1, tn0, tn1, v0, v1, W.tail_base, F);
+    join_emit(ent, bnd, bt, lane, td0, td1, tf0, tf1, tn0, tn1, v0, v1, W.tail_base);
   }
   // behind the list's last posting every remaining tile is empty: whoever holds the last block
   if (nb && nb - 1u >= W.first && nb - 1u < end && ((nb - 1u - W.first) % kWaves) == wv) {

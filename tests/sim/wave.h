@@ -133,6 +133,12 @@ __device__ __forceinline__ void lds_take4x2(unsigned char* base, uint32_t off0, 
   lds_take4(base, off0, a);
   lds_take4(base, off1, b);
 }
+__device__ __forceinline__ void lds_take4x3(unsigned char* base, uint32_t off0, uint32_t off1, uint32_t off2,
+                                            uint32_t (&a)[4], uint32_t (&b)[4], uint32_t (&c)[4]) {
+  lds_take4(base, off0, a);
+  lds_take4(base, off1, b);
+  lds_take4(base, off2, c);
+}
 __device__ __forceinline__ uint32_t gload_u32(uint64_t base, uint32_t off) {
   uint32_t v;
   __builtin_memcpy(&v, reinterpret_cast<const uint8_t*>(base) + off, 4);

@@ -14,38 +14,26 @@ def rep(old,new):
     global s
     assert s.count(old)==1, old[:60]
     s=s.replace(old,new)
-rep('''    // ---- accumulate this wavefront's entries of tile u
-''','''    // ---- accumulate this wavefront's entries of tile u
-    const unsigned long long t0 = __builtin_readcyclecounter();
+rep('''  request(0);
+  for (uint32_t u = 0; u < ntile; ++u) {
+    // ---- accumulate this wavefront's entries of tile u
+''','''  request(0);
+  uint32_t dd0 = 0, dd1 = 0, dd2 = 0, dd3 = 0, dd4 = 0;
+  for (uint32_t u = 0; u < ntile; ++u) {
+    // ---- accumulate this wavefront's entries of tile u
+    const uint32_t t0 = uint32_t(__builtin_readcyclecounter());
 ''')
-rep('''    if (multi) {
-      consume_multi(u);
-      request_multi(u + 1u);
-    } else {
-      if (A.cnt) consume(A, ra, sa);
-      if (B.cnt) consume(B, rb, sb);
-      request(u + 1u);
-    }
-''','''    unsigned long long t1;
-    if (multi) {
-      consume_multi(u);
-      t1 = __builtin_readcyclecounter();
-      request_multi(u + 1u);
-    } else {
-      if (A.cnt) consume(A, ra, sa);
-      if (B.cnt) consume(B, rb, sb);
-      t1 = __builtin_readcyclecounter();
-      request(u + 1u);
-    }
-    const unsigned long long t2 = __builtin_readcyclecounter();
-''')
-rep('''    __syncthreads();   // B1: every accumulation of tile u has landed''','''    __syncthreads();   // B1: every accumulation of tile u has landed
-    const unsigned long long t3 = __builtin_readcyclecounter();''')
+rep('''    request(u + 1u);
+    __syncthreads();   // B1: every accumulation of tile u has landed''','''    const uint32_t t1 = uint32_t(__builtin_readcyclecounter());
+    request(u + 1u);
+    const uint32_t t2 = uint32_t(__builtin_readcyclecounter());
+    __syncthreads();   // B1: every accumulation of tile u has landed
+    const uint32_t t3 = uint32_t(__builtin_readcyclecounter());''')
 rep('''    __syncthreads();   // B2: accumulators are clear again
   }
-  return hit_pk;''','''    const unsigned long long t4 = __builtin_readcyclecounter();
+  return hit_pk;''','''    const uint32_t t4 = uint32_t(__builtin_readcyclecounter());
     __syncthreads();   // B2: accumulators are clear again
-    const unsigned long long t5 = __builtin_readcyclecounter();
+    const uint32_t t5 = uint32_t(__builtin_readcyclecounter());
     dd0 += t1 - t0; dd1 += t2 - t1; dd2 += t3 - t2; dd3 += t4 - t3; dd4 += t5 - t4;
   }
   if (lane == 0 && blockIdx.x == 7u) {
@@ -53,8 +41,6 @@ rep('''    __syncthreads();   // B2: accumulators are clear again
     d[0] += dd0; d[1] += dd1; d[2] += dd2; d[3] += dd3; d[4] += dd4; d[5] += ntile;
   }
   return hit_pk;''')
-rep('''  if (multi) request_multi(0); else request(0);''','''  unsigned long long dd0 = 0, dd1 = 0, dd2 = 0, dd3 = 0, dd4 = 0;
-  if (multi) request_multi(0); else request(0);''')
 rep('''// The tiles of one chunk.  Everything it needs lives in LDS''','''__device__ unsigned long long g_dbg[8 * 17];
 // The tiles of one chunk.  Everything it needs lives in LDS''')
 rep('''  if (tid == 0) {
@@ -66,7 +52,7 @@ rep('''  if (tid == 0) {
   {
     const uint32_t cap = args->cand_cap;''','''  if (blockIdx.x == 7u && lane == 0) {
     const unsigned long long* d = g_dbg + 8u * (tid >> 6);
-    printf("DBG wave %u tiles %llu acc %llu req %llu b1 %llu epi %llu b2 %llu (cycles per tile)\\n", tid >> 6, d[5],
+    printf("DBG wave %u tiles %llu acc %llu req %llu b1 %llu epi %llu b2 %llu (ticks per tile)\\n", tid >> 6, d[5],
            d[0] / (d[5] + 1), d[1] / (d[5] + 1), d[2] / (d[5] + 1), d[3] / (d[5] + 1), d[4] / (d[5] + 1));
   }
   if (tid == 0) {
