@@ -618,6 +618,51 @@ def case_join_counts(L, num_docs=70_000, max_rank=256):
     sr.close()
 
 
+def case_join_counts_boundary(L, num_docs=70_000, max_rank=256):
+    """Counting accumulators AT their eligibility boundary: a joined min-match unit rounds every
+    posting to 16 fixed-point units, allowed while `upper / (mean of the need smallest per-term
+    minimum scores) <= 125` (count_precise, irs_hip.hip).  The worst case for that rule — every
+    doc as long as a 1-byte norm can say (255), two weakly boosted terms that make a doc exist,
+    13 strongly boosted ones that set the score's range — with the strong boost bisected to the
+    LARGEST value that still joins; just beyond it the unit must fall back to the work items.
+    Both against the oracle (1e-5)."""
+    seg = synth.build_segment(num_docs, max_rank)
+    seg.norms = np.full_like(seg.norms, 255)
+    sr = search.SegmentReader.from_synth(seg, L=L)
+    t = by_term
+    weak = [max_rank // 2, max_rank // 2 + 3]
+    strong = [12 + i for i in range(13)]
+
+    def batch(boost):
+        flt = [Or([t(w, 1.0) for w in weak] + [t(x, boost) for x in strong], min_match=2)]
+        prep = search.prepare(flt, BM25(), [parity.segment_stats(seg)])
+        return flt, sr.batch(prep, 100)
+
+    def joins(boost):
+        _, b = batch(boost)
+        b.run()
+        j = b.path() == _lib.PATH_JOINED
+        b.close()
+        return j
+
+    lo, hi = 1.0, 1000.0   # (equal boosts join; the strong terms a thousand times the weak ones do not)
+    assert joins(lo) and not joins(hi)
+    for _ in range(24):
+        mid = (lo * hi) ** 0.5
+        if joins(mid):
+            lo = mid
+        else:
+            hi = mid
+    for boost, want in ((lo, True), (hi, False)):
+        flt, b = batch(boost)
+        h, c, tot = b.run().results()
+        assert (b.path() == _lib.PATH_JOINED) == want, (boost, b.path())
+        parity.check_single_segment(seg, flt, BM25(), 100, h, c, tot)
+        b.close()
+    assert hi / lo < 1.001
+    sr.close()
+
+
 def case_no_norms(L):
     seg = synth.build_segment(20_000, 128)
     seg.norms = None

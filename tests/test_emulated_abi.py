@@ -116,6 +116,10 @@ def test_join_counts(simlib):
     cases.case_join_counts(simlib)
 
 
+def test_join_counts_boundary(simlib):
+    cases.case_join_counts_boundary(simlib)
+
+
 def test_shared_threshold(simlib):
     cases.case_shared_threshold(simlib)
     cases.case_shared_threshold_misled(simlib)

@@ -189,6 +189,10 @@ def test_join_counts(gpulib):
     cases.case_join_counts(gpulib, num_docs=900_000, max_rank=1024)
 
 
+def test_join_counts_boundary(gpulib):
+    cases.case_join_counts_boundary(gpulib)
+
+
 def test_shared_threshold(gpulib):
     cases.case_shared_threshold(gpulib)
     cases.case_shared_threshold_misled(gpulib)
