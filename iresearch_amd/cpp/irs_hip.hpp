@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <stdexcept>
 #include <string>
 #include <variant>
@@ -628,7 +629,8 @@ inline std::vector<DictTerm> walk_term_dictionary(const uint8_t* tm, uint64_t le
       throw index_error(IRS_HIP_ECORRUPT, "term dictionary: invalid postings block size");
   }
   struct Ent {
-    uint32_t suffix_at, suffix_len;   // into the file
+    uint64_t suffix_at;               // into the file
+    uint32_t suffix_len;
     bool is_block;
     uint64_t child;                   // is_block: file offset of the sub-block
     irs_hip_term_meta meta;           // term
@@ -668,7 +670,7 @@ inline std::vector<DictTerm> walk_term_dictionary(const uint8_t* tm, uint64_t le
       uint32_t v = vread<uint32_t>(sp);
       e.is_block = !leaf && (v & 1u);
       e.suffix_len = leaf ? v : (v >> 1);
-      e.suffix_at = uint32_t(sp - tm);
+      e.suffix_at = uint64_t(sp - tm);
       if (uint64_t(send - sp) < e.suffix_len)
         throw index_error(IRS_HIP_ECORRUPT, "term dictionary: suffix block overrun");
       sp += e.suffix_len;
@@ -679,7 +681,14 @@ inline std::vector<DictTerm> walk_term_dictionary(const uint8_t* tm, uint64_t le
         e.child = b.start - back;
       } else {
         if (st >= stend) throw index_error(IRS_HIP_ECORRUPT, "term dictionary: stats block overrun");
-        st += decode_term_meta(st, has_freq, has_pos, has_pay_or_offs, state);
+        {   // (decoded from a copy: a damaged record cannot send the varint reads past the block)
+          uint8_t buf[64] = {0};
+          const size_t have = size_t(std::min<uint64_t>(uint64_t(stend - st), sizeof buf));
+          std::memcpy(buf, st, have);
+          const size_t used = decode_term_meta(buf, has_freq, has_pos, has_pay_or_offs, state);
+          if (used > have) throw index_error(IRS_HIP_ECORRUPT, "term dictionary: stats block overrun");
+          st += used;
+        }
         e.meta = state;
       }
       b.ents.push_back(e);
@@ -716,7 +725,13 @@ inline std::vector<DictTerm> walk_term_dictionary(const uint8_t* tm, uint64_t le
     for (const Ent& e : b.ents)
       if (e.is_block) referenced[group_at(e.child)] = 1;
   std::vector<DictTerm> out;
-  // depth first from every root group (one per field, in field order)
+  // `.tm` holds the blocks of EVERY field of the segment (field_writer opens it once): without
+  // the term index this walk can only serve a dictionary of one field — several root groups
+  // mean several fields, whose terms (and stats layouts) must not be mixed: read_term_index +
+  // walk_field are the way in then
+  if (std::count(referenced.begin(), referenced.end(), char(0)) > 1)
+    throw not_supported(IRS_HIP_EUNSUPPORTED, "term dictionary: several fields (root blocks) — needs the term index (.ti)");
+  // depth first from the root group
   struct Todo {
     size_t group;
     std::string prefix;
@@ -739,6 +754,264 @@ inline std::vector<DictTerm> walk_term_dictionary(const uint8_t* tm, uint64_t le
     }
   }
   std::sort(out.begin(), out.end(), [](const DictTerm& a, const DictTerm& b) { return a.term < b.term; });
+  return out;
+}
+
+// ---- the term index (`.ti`) and the segment meta (`.sm`): what a field IS ----------------------
+// A bounds-checked cursor over untrusted file bytes: every read says how much it needs.
+class Cursor {
+ public:
+  Cursor(const uint8_t* p, const uint8_t* end, const char* what) : p_{p}, end_{end}, what_{what} {}
+  uint64_t left() const { return uint64_t(end_ - p_); }
+  const uint8_t* at() const { return p_; }
+  void need(uint64_t n) const {
+    if (left() < n) throw index_error(IRS_HIP_ECORRUPT, std::string(what_) + ": truncated");
+  }
+  uint8_t u8() { need(1); return *p_++; }
+  uint32_t u32() { need(4); const uint32_t v = be32(p_); p_ += 4; return v; }
+  uint64_t u64() { need(8); const uint64_t v = be64(p_); p_ += 8; return v; }
+  template<typename T>
+  T v() {   // vint / vlong: at most ceil(bits / 7) bytes, all inside the file
+    T out = 0;
+    for (unsigned shift = 0;; shift += 7) {
+      const uint8_t b = u8();
+      out |= T(b & 0x7Fu) << shift;
+      if (!(b & 0x80u)) break;
+      if (shift + 7 >= sizeof(T) * 8 + 6) throw index_error(IRS_HIP_ECORRUPT, std::string(what_) + ": overlong varint");
+    }
+    return out;
+  }
+  std::string str() {   // read_string: vint size + bytes
+    const uint32_t n = v<uint32_t>();
+    need(n);
+    std::string out(reinterpret_cast<const char*>(p_), n);
+    p_ += n;
+    return out;
+  }
+  void skip(uint64_t n) { need(n); p_ += n; }
+
+ private:
+  const uint8_t* p_;
+  const uint8_t* end_;
+  const char* what_;
+};
+
+// One field of a segment as the term index records it: term_reader_base::prepare
+// (formats_burst_trie.cpp:1509-1545) — name, read_field_features (:741-766: index features, the
+// feature -> column id pairs), term / doc / posting counts, min and max term, the summed
+// frequency of a field with FREQ, the wand mask — followed by the field's FST
+// (ImmutableFstImpl::Read, utils/fstext/immutable_fst.hpp:136-203), of which the final weight of
+// the START state is kept: the record of the field's ROOT block (MergeBlocks :856-911: meta byte,
+// vlong start, the other floor blocks of the group), i.e. where block_iterator starts from
+// (:1751-1764).  The prefix arcs only accelerate seeks.
+struct FieldRecord {
+  std::string name;
+  uint32_t index_features = 0;      // IndexFeatures: FREQ 1, POS 2, OFFS 4, PAY 8
+  int64_t norm_column = -1;         // field_meta::features[Norm2] (-1: the field has no norms)
+  uint64_t terms_count = 0;
+  uint64_t docs_with_field = 0;     // term_reader::docs_count()
+  uint64_t total_doc_freq = 0;
+  uint64_t total_term_freq = 0;     // irs::frequency of the field (FREQ only)
+  std::string min_term, max_term;
+  uint64_t wand_mask = 0;
+  uint8_t root_meta = 0;
+  uint64_t root_start = 0;          // file offset of the root block in `.tm`
+  bool has_freq() const { return (index_features & 1u) != 0; }
+  bool has_pos() const { return (index_features & 2u) != 0; }
+  bool has_offs_or_pay() const { return (index_features & 12u) != 0; }
+  uint32_t wand_count() const { return uint32_t(__builtin_popcountll(wand_mask)); }
+};
+struct TermIndex {
+  uint32_t index_features = 0;            // of the segment
+  std::vector<std::string> features;      // the segment's feature names, by id
+  std::vector<FieldRecord> fields;        // in name order
+  const FieldRecord* find(const std::string& name) const {
+    for (const FieldRecord& f : fields)
+      if (f.name == name) return &f;
+    return nullptr;
+  }
+};
+constexpr const char* kNorm2Feature = "iresearch::norm2";   // irs::Norm2::type_name(), norm.hpp:204-206
+
+// field_reader::prepare (formats_burst_trie.cpp:3323-3440), the `.ti` half
+inline TermIndex read_term_index(const uint8_t* ti, uint64_t len) {
+  size_t hl = 0;
+  const int32_t version = check_header(ti, len, "block_tree_terms_index", 0, 3, &hl);
+  check_footer(ti, len);
+  if (version < 2) throw not_supported(IRS_HIP_EUNSUPPORTED, "term index: formats before the immutable FST (1_3)");
+  if (len < hl + 8 + kFooterLen) throw index_error(IRS_HIP_ECORRUPT, "term index: truncated");
+  const uint64_t fields_count = be64(ti + len - kFooterLen - 8);
+  Cursor in(ti + hl, ti + len - kFooterLen - 8, "term index");
+  if (in.v<uint32_t>()) throw not_supported(IRS_HIP_EUNSUPPORTED, "term index: encrypted segment");
+  TermIndex out;
+  out.index_features = in.u32();   // read_segment_features :711-733
+  if (out.index_features > 15u) throw index_error(IRS_HIP_ECORRUPT, "term index: invalid segment index features");
+  for (uint64_t n = in.v<uint64_t>(); n; --n) out.features.push_back(in.str());
+  for (uint64_t f = 0; f < fields_count; ++f) {
+    FieldRecord r;
+    r.name = in.str();
+    if (!out.fields.empty() && !(out.fields.back().name < r.name))
+      throw index_error(IRS_HIP_ECORRUPT, "term index: invalid field order");
+    r.index_features = in.u32();
+    if (r.index_features > 15u) throw index_error(IRS_HIP_ECORRUPT, "term index: invalid field index features");
+    for (uint64_t n = in.v<uint64_t>(); n; --n) {
+      const uint64_t id = in.v<uint64_t>();
+      const uint64_t column = in.v<uint64_t>();   // field_id + 1
+      if (id >= out.features.size()) throw index_error(IRS_HIP_ECORRUPT, "term index: unknown feature id");
+      if (out.features[id] == kNorm2Feature) r.norm_column = int64_t(column) - 1;
+    }
+    r.terms_count = in.v<uint64_t>();
+    r.docs_with_field = in.v<uint64_t>();
+    r.total_doc_freq = in.v<uint64_t>();
+    r.min_term = in.str();
+    r.max_term = in.str();
+    if (r.has_freq()) r.total_term_freq = in.v<uint64_t>();
+    if (version >= 3) r.wand_mask = in.u64();
+    // the FST: header, states (+ arcs), weights; the start state's final weight is the root
+    if (in.u8() != 0) throw index_error(IRS_HIP_ECORRUPT, "term index: unknown FST version");
+    in.u64();   // properties
+    const uint64_t total_weight = in.u64();
+    const uint32_t nstates = in.u32();
+    const uint32_t back = in.v<uint32_t>();
+    if (!nstates || back == 0 || back > nstates) throw index_error(IRS_HIP_ECORRUPT, "term index: FST without a start state");
+    const uint32_t start = nstates - back;
+    in.v<uint64_t>();   // zig-zag(arcs - states)
+    uint64_t weight_at = 0, root_at = 0, root_len = 0;
+    for (uint32_t st = 0; st < nstates; ++st) {
+      const uint64_t packed = in.v<uint64_t>();
+      const uint64_t wsize = packed >> 1;
+      if (st == start) {
+        root_at = weight_at;
+        root_len = wsize;
+      }
+      weight_at += wsize;
+      if (!(packed & 1u)) {   // has arcs
+        for (uint32_t arcs = uint32_t(in.u8()) + 1u; arcs; --arcs) {
+          in.u8();               // label
+          in.v<uint32_t>();      // next state
+          weight_at += in.v<uint64_t>();
+        }
+      }
+    }
+    if (weight_at != total_weight || root_at + root_len > total_weight)
+      throw index_error(IRS_HIP_ECORRUPT, "term index: FST weights do not add up");
+    in.need(total_weight);
+    {
+      Cursor w(in.at() + root_at, in.at() + root_at + root_len, "term index: root block record");
+      r.root_meta = w.u8();
+      r.root_start = w.v<uint64_t>();
+    }
+    in.skip(total_weight);
+    out.fields.push_back(std::move(r));
+  }
+  if (in.left()) throw index_error(IRS_HIP_ECORRUPT, "term index: bytes behind the last field");
+  return out;
+}
+
+// SegmentMetaReader::read (formats_10.cpp:3147-3218)
+struct SegmentMetaFile {
+  std::string name;
+  uint64_t version = 0, docs_count = 0, live_docs_count = 0, byte_size = 0;
+  bool column_store = false;
+  std::vector<std::string> files;
+};
+inline SegmentMetaFile read_segment_meta(const uint8_t* sm, uint64_t len) {
+  size_t hl = 0;
+  const int32_t version = check_header(sm, len, "iresearch_10_segment_meta", 0, 1, &hl);
+  check_footer(sm, len);
+  Cursor in(sm + hl, sm + len - kFooterLen, "segment meta");
+  SegmentMetaFile m;
+  m.name = in.str();
+  m.version = in.v<uint64_t>();
+  m.live_docs_count = in.v<uint64_t>();
+  m.docs_count = in.v<uint64_t>() + m.live_docs_count;
+  m.byte_size = in.v<uint64_t>();
+  const uint8_t flags = in.u8();
+  if (flags & ~3u) throw index_error(IRS_HIP_ECORRUPT, "segment meta: unsupported flags");
+  uint64_t sort = 0;
+  if (version > 0) sort = in.v<uint64_t>();   // 1 + the sort column, 0 = none
+  if (((flags & 2u) != 0) != (sort != 0)) throw index_error(IRS_HIP_ECORRUPT, "segment meta: sorted flag and column disagree");
+  m.column_store = (flags & 1u) != 0;
+  for (uint64_t n = in.v<uint64_t>(); n; --n) m.files.push_back(in.str());
+  return m;
+}
+
+// The terms of ONE field of `.tm`, in order, from its root block (FieldRecord::root_start): a
+// block group = the blocks from the referenced one to the first with the "last of its group"
+// bit; an entry is a term (suffix + stats record) or a sub-block (suffix + back pointer) whose
+// group is walked in place — entries are stored in suffix order, so the terms come out sorted.
+inline std::vector<DictTerm> walk_field(const uint8_t* tm, uint64_t len, uint64_t root_start,
+                                        bool has_freq, bool has_pos, bool has_pay_or_offs) {
+  size_t hl = 0;
+  const int32_t version = check_header(tm, len, "block_tree_terms_dict", 0, 3, &hl);
+  check_footer(tm, len);
+  const uint8_t* const end = tm + len - kFooterLen;
+  uint64_t first_block = 0;
+  {
+    Cursor in(tm + hl, end, "term dictionary");
+    if (version > 0 && in.v<uint32_t>()) throw not_supported(IRS_HIP_EUNSUPPORTED, "term dictionary: encrypted segment");
+    size_t h2 = 0;   // postings_reader_base::prepare (formats_10.cpp:3404-3416)
+    check_header(in.at(), in.left(), "iresearch_10_postings_terms", 0, 0, &h2);
+    in.skip(h2);
+    if (in.v<uint32_t>() != kBlockSize) throw index_error(IRS_HIP_ECORRUPT, "term dictionary: invalid postings block size");
+    first_block = uint64_t(in.at() - tm);
+  }
+  std::vector<DictTerm> out;
+  struct Todo { uint64_t start; std::string prefix; };
+  // (an explicit stack: sub-block groups are expanded depth first, in entry order)
+  std::function<void(uint64_t, const std::string&, unsigned)> group = [&](uint64_t start, const std::string& prefix, unsigned depth) {
+    if (depth > 512) throw index_error(IRS_HIP_ECORRUPT, "term dictionary: block tree too deep");
+    for (uint64_t at = start;;) {
+      if (at < first_block || at >= uint64_t(end - tm)) throw index_error(IRS_HIP_ECORRUPT, "term dictionary: block pointer out of range");
+      Cursor in(tm + at, end, "term dictionary");
+      const uint32_t head = in.v<uint32_t>();
+      const bool last = (head & 1u) != 0;
+      const uint32_t n = head >> 1;
+      const uint64_t sz = in.v<uint64_t>();
+      const bool leaf = (sz & 1u) != 0;
+      in.need(sz >> 1);
+      Cursor sx(in.at(), in.at() + (sz >> 1), "term dictionary: suffix block");
+      in.skip(sz >> 1);
+      const uint64_t stats_bytes = in.v<uint64_t>();
+      in.need(stats_bytes);
+      const uint8_t* st = in.at();
+      const uint8_t* const stend = st + stats_bytes;
+      in.skip(stats_bytes);
+      irs_hip_term_meta state{};   // (a block's first record is coded against zeros)
+      state.pos_end = ~uint64_t(0);
+      for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t v = sx.v<uint32_t>();
+        const bool is_block = !leaf && (v & 1u);
+        const uint32_t slen = leaf ? v : (v >> 1);
+        sx.need(slen);
+        std::string full = prefix;
+        full.append(reinterpret_cast<const char*>(sx.at()), slen);
+        sx.skip(slen);
+        if (is_block) {
+          const uint64_t back = sx.v<uint64_t>();
+          if (back == 0 || back > at) throw index_error(IRS_HIP_ECORRUPT, "term dictionary: sub-block pointer out of range");
+          group(at - back, full, depth + 1);
+        } else {
+          // (a stats record is at most 5 + 5 + 4 * 10 bytes of varints: decode from a copy that
+          // cannot run past the block)
+          uint8_t buf[64] = {0};
+          const size_t have = size_t(std::min<uint64_t>(uint64_t(stend - st), sizeof buf));
+          if (!have) throw index_error(IRS_HIP_ECORRUPT, "term dictionary: stats block overrun");
+          std::memcpy(buf, st, have);
+          const size_t used = decode_term_meta(buf, has_freq, has_pos, has_pay_or_offs, state);
+          if (used > have) throw index_error(IRS_HIP_ECORRUPT, "term dictionary: stats block overrun");
+          st += used;
+          out.push_back(DictTerm{std::move(full), state});
+        }
+      }
+      if (sx.left() || st != stend) throw index_error(IRS_HIP_ECORRUPT, "term dictionary: block sizes do not add up");
+      if (last) break;
+      at = uint64_t(in.at() - tm);   // the group's next floor block follows
+    }
+  };
+  group(root_start, std::string(), 0);
+  for (size_t i = 1; i < out.size(); ++i)
+    if (!(out[i - 1].term < out[i].term)) throw index_error(IRS_HIP_ECORRUPT, "term dictionary: terms out of order");
   return out;
 }
 
@@ -838,10 +1111,14 @@ inline FixedColumn read_fixed_column(const uint8_t* csi, uint64_t csi_len, const
           col.payload.assign(payload, payload + payload_len);
           col.values.resize(uint64_t(docs) * len);
           for (uint32_t b = 0; b < nblocks; ++b) {
-            const uint64_t at = type == 3 ? be64(p) + uint64_t(b) * kColumnBlock * len : be64(p + 8ull * b);
+            // (offsets come from the file: no sum of them may wrap)
+            const uint64_t limit = csd_len - kFooterLen;
+            const uint64_t first = type == 3 ? be64(p) : be64(p + 8ull * b);
+            const uint64_t shift = type == 3 ? uint64_t(b) * kColumnBlock * len : 0;
             const uint64_t n = std::min<uint64_t>(kColumnBlock, docs - uint64_t(b) * kColumnBlock) * len;
-            if (at < dl || at + n > csd_len - kFooterLen)
+            if (first < dl || first > limit || shift > limit - first || n > limit - first - shift)
               throw index_error(IRS_HIP_ECORRUPT, "columnstore: block outside the data file");
+            const uint64_t at = first + shift;
             std::memcpy(col.values.data() + uint64_t(b) * kColumnBlock * len, csd + at, n);
           }
           return col;
@@ -863,42 +1140,95 @@ inline FixedColumn read_fixed_column(const uint8_t* csi, uint64_t csi_len, const
 // nothing but file bytes.  `terms_out` receives the term bytes per ordinal.
 struct FieldFiles {
   const uint8_t* doc = nullptr;  uint64_t doc_len = 0;
-  const uint8_t* pos = nullptr;  uint64_t pos_len = 0;     // null: no positions
-  const uint8_t* tm = nullptr;   uint64_t tm_len = 0;      // term dictionary
+  const uint8_t* pos = nullptr;  uint64_t pos_len = 0;     // null: not staged (by_phrase unavailable)
+  const uint8_t* tm = nullptr;   uint64_t tm_len = 0;      // term dictionary (all fields)
+  const uint8_t* ti = nullptr;   uint64_t ti_len = 0;      // term index: the fields' records
+  const uint8_t* sm = nullptr;   uint64_t sm_len = 0;      // segment meta: the doc count
   const uint8_t* csi = nullptr;  uint64_t csi_len = 0;     // columnstore index + data
   const uint8_t* csd = nullptr;  uint64_t csd_len = 0;
-  int64_t norm_column = -1;      // field_meta::features[Norm2]
+  std::string field;             // which field of the segment
+  // What the files do not say: which Scorer::WandType the field's wand data was written by
+  // (it is a property of the scorer objects the index was created with, scorer.hpp:196-201).
+  uint32_t wand_type = IRS_HIP_WAND_NONE;
+  // WITHOUT a term index / segment meta (a single-field dictionary, e.g. one written by a test):
+  // what they would have said
+  int64_t norm_column = -1;
   uint32_t num_docs = 0;
-  int32_t layout = IRS_HIP_LAYOUT_SIMD4;
   bool has_freq = true;
-  uint32_t wand_count = 0, wand_type = IRS_HIP_WAND_NONE;
+  uint32_t wand_count = 0;
 };
 struct OpenedField {
   std::vector<std::string> terms;            // ordinal -> term bytes
   std::vector<irs_hip_term_meta> metas;
   FixedColumn norms;
   Norm2Header norm_header;
+  FieldRecord record;                         // (from the term index)
+  uint64_t docs_with_field = 0;
   uint64_t total_term_freq = 0;
+  uint32_t num_docs = 0;
 };
+// Everything irs_hip_segment_open needs for one field of a segment, from file bytes alone:
+// with `ti` and `sm` given, the field's features (FREQ / POS / OFFS / PAY), its Norm2 column id,
+// docs_with_field, the summed term frequency, the wand mask and the root of its term blocks
+// come from the term index, the doc count from the segment meta, the block layout (scalar /
+// simd) from the `.doc` header's version (formats_10.cpp:283-313: odd = simd) — what
+// field_reader::prepare + term_reader_base::prepare + SegmentMetaReader::read establish.
 inline irs_hip_segment_desc describe_field(const FieldFiles& f, int32_t device, OpenedField& o) {
-  const auto dict = walk_term_dictionary(f.tm, f.tm_len, f.has_freq, f.pos != nullptr, false);
+  std::vector<DictTerm> dict;
+  bool has_freq = f.has_freq, has_pos = f.pos != nullptr, has_pay = false;
+  int64_t norm_column = f.norm_column;
+  uint32_t wand_count = f.wand_count;
+  o.num_docs = f.num_docs;
+  o.record = FieldRecord{};
+  if (f.ti) {
+    const TermIndex index = read_term_index(f.ti, f.ti_len);
+    const FieldRecord* rec = index.find(f.field);
+    if (!rec) throw index_error(IRS_HIP_EINVAL, "segment has no field '" + f.field + "'");
+    o.record = *rec;
+    has_freq = rec->has_freq();
+    has_pos = rec->has_pos();
+    has_pay = rec->has_offs_or_pay();
+    norm_column = rec->norm_column;
+    wand_count = rec->wand_count();
+    dict = walk_field(f.tm, f.tm_len, rec->root_start, has_freq, has_pos, has_pay);
+    if (dict.size() != rec->terms_count)
+      throw index_error(IRS_HIP_ECORRUPT, "term dictionary: the field's term count disagrees with the term index");
+  } else {
+    dict = walk_term_dictionary(f.tm, f.tm_len, f.has_freq, f.pos != nullptr, false);
+  }
+  if (f.sm) {
+    const SegmentMetaFile meta = read_segment_meta(f.sm, f.sm_len);
+    if (meta.docs_count == 0 || meta.docs_count > 0x7FFF0000ull)
+      throw index_error(IRS_HIP_ECORRUPT, "segment meta: doc count out of range");
+    o.num_docs = uint32_t(meta.docs_count);
+  }
   o.terms.clear();
   o.metas.clear();
   o.total_term_freq = 0;
+  uint64_t doc_freq = 0;
   for (const DictTerm& t : dict) {
     o.terms.push_back(t.term);
     o.metas.push_back(t.meta);
     o.total_term_freq += t.meta.freq;
+    doc_freq += t.meta.docs_count;
+  }
+  o.docs_with_field = f.ti ? o.record.docs_with_field : o.num_docs;
+  if (f.ti && (doc_freq != o.record.total_doc_freq || (has_freq && o.total_term_freq != o.record.total_term_freq)))
+    throw index_error(IRS_HIP_ECORRUPT, "term dictionary: the field's totals disagree with the term index");
+  int32_t doc_version = 0;
+  {
+    size_t hl = 0;
+    doc_version = check_header(f.doc, f.doc_len, kDocFormatName, 0, 5, &hl);
   }
   irs_hip_segment_desc d{};
   d.device = device;
-  d.layout = f.layout;
+  d.layout = (doc_version & 1) ? IRS_HIP_LAYOUT_SIMD4 : IRS_HIP_LAYOUT_SCALAR;
   d.doc_file = f.doc;
   d.doc_file_len = f.doc_len;
-  d.num_docs = f.num_docs;
-  d.has_freq = f.has_freq ? 1u : 0u;
-  if (f.norm_column >= 0) {
-    o.norms = read_fixed_column(f.csi, f.csi_len, f.csd, f.csd_len, uint32_t(f.norm_column));
+  d.num_docs = o.num_docs;
+  d.has_freq = has_freq ? 1u : 0u;
+  if (norm_column >= 0) {
+    o.norms = read_fixed_column(f.csi, f.csi_len, f.csd, f.csd_len, uint32_t(norm_column));
     if (!read_norm2_header(o.norms.payload.data(), o.norms.payload.size(), o.norm_header) ||
         o.norm_header.num_bytes != o.norms.value_bytes)
       throw index_error(IRS_HIP_ECORRUPT, "norm column: invalid Norm2 header");
@@ -909,10 +1239,14 @@ inline irs_hip_segment_desc describe_field(const FieldFiles& f, int32_t device, 
   }
   d.terms = o.metas.data();
   d.num_terms = uint32_t(o.metas.size());
-  d.wand_count = f.wand_count;
+  d.wand_count = wand_count;
   d.wand_type = f.wand_type;
-  d.pos_file = f.pos;
-  d.pos_file_len = f.pos_len;
+  if (has_pos && f.pos) {
+    d.pos_file = f.pos;
+    d.pos_file_len = f.pos_len;
+    d.pos_features = (o.record.index_features & 4u ? IRS_HIP_POS_OFFSETS : 0u) |
+                     (o.record.index_features & 8u ? IRS_HIP_POS_PAYLOADS : 0u);
+  }
   return d;
 }
 

@@ -11,8 +11,16 @@
 //           writer::prepare / commit  core/formats/columnstore2.cpp:1561-1697
 //           column::flush_block / finish  :1340-1551,  write_header :69-77
 //
-// The term index (`.ti`, an FST over block prefixes) is not written: it only accelerates
-// seeks; the blocks of `.tm` link to each other and are walked without it.
+//   `.ti`   term index: the segment's feature list, then per field (in name order) its record —
+//           name, index features, feature -> column ids, counts, min / max term, wand mask —
+//           and the FST over its block prefixes
+//           field_writer::prepare :1263-1287, write_segment_features :662-681, EndField
+//           :1347-1432, write_field_features :684-708, MergeBlocks :856-911 (what the FST
+//           holds for a block), ImmutableFst::Write utils/fstext/immutable_fst.hpp:269-335
+//           Here the FST of a field has ONE state whose final weight is the root block's
+//           record (the output of the empty prefix — which is where every reader starts);
+//           the prefix arcs that only accelerate seeks are not built.
+//   `.sm`   segment meta: SegmentMetaWriter::write  core/formats/formats_10.cpp:3102-3140
 #include <algorithm>
 #include <cstring>
 #include <string>
@@ -128,6 +136,10 @@ struct DictWriter {
   std::vector<size_t> prefixes;   // prefixes[i]: first stack slot sharing last_term[0..i]
   std::string last_term;
   uint64_t root_start = 0;
+  // the last group written: per (floor) block its start, lead label (-1: none) and meta bits
+  // (1 has terms, 2 has sub-blocks, 4 is one of several floor blocks) — MergeBlocks' input
+  struct Floor { uint64_t start; int label; uint8_t meta; };
+  std::vector<Floor> group;
 
   // One block of entries stack[begin, end) whose terms share `prefix` bytes.
   uint64_t write_block(size_t prefix, size_t begin, size_t end, bool leaf, bool last_of_group) {
@@ -162,14 +174,18 @@ struct DictWriter {
     uint64_t first = 0;
     bool have_first = false;
     int last_label = -2;
-    bool has_blocks = false;
+    bool has_blocks = false, has_terms = false;
+    int lead_label = -1;   // of the block being collected (next_label)
+    group.clear();
     auto flush = [&](size_t from, size_t to) {
       const uint64_t at = write_block(prefix, from, to, !has_blocks, to == end);
       if (!have_first) {
         first = at;
         have_first = true;
       }
-      has_blocks = false;
+      group.push_back(Floor{at, lead_label,
+                            uint8_t((has_terms ? 1u : 0u) | (has_blocks ? 2u : 0u) | (to - from < count ? 4u : 0u))});
+      has_blocks = has_terms = false;
     };
     for (size_t i = begin; i < end; ++i) {
       const Entry& e = stack[i];
@@ -178,11 +194,13 @@ struct DictWriter {
         const size_t size = i - block_start;
         if (size >= min_block && end - block_start > max_block) {
           flush(block_start, i);
+          lead_label = label;
           block_start = i;
         }
         last_label = label;
       }
       has_blocks = has_blocks || e.is_block;
+      has_terms = has_terms || !e.is_block;
     }
     if (block_start < end) flush(block_start, end);
     Entry blk;
@@ -336,6 +354,133 @@ int64_t irs_synth_columnstore(const uint8_t* values, uint32_t value_bytes, uint3
   *csi_len = index.size();
   if (column_id) *column_id = id;
   return 0;
+}
+
+// ---- a segment's `.tm` + `.ti` (every field) and its `.sm` ------------------------------------
+
+int64_t irs_synth_segment_dictionary(const irs_synth_field* fields, uint32_t n_fields,
+                                     uint32_t min_block, uint32_t max_block, uint8_t* tm_out,
+                                     uint64_t tm_cap, uint64_t* tm_len, uint8_t* ti_out,
+                                     uint64_t ti_cap, uint64_t* ti_len) {
+  if (!fields || !n_fields || !tm_len || !ti_len) return -1;
+  if (min_block < 2 || max_block < min_block || 2 * (min_block - 1) > max_block) return -1;
+  Bytes tm, ti;
+  // field_writer::prepare: both files, then the segment's features into the term index
+  put_header(tm, "block_tree_terms_dict", 3);          // burst_trie::Version::WAND
+  put_vint(tm, 0);                                      // irs::encrypt: no cipher = empty header
+  put_header(tm, "iresearch_10_postings_terms", 0);    // postings_writer_base::prepare
+  put_vint(tm, kPostingsBlock);
+  put_header(ti, "block_tree_terms_index", 3);
+  put_vint(ti, 0);
+  uint32_t seg_features = 0;
+  bool any_norm = false;
+  for (uint32_t f = 0; f < n_fields; ++f) {
+    seg_features |= fields[f].index_features;
+    any_norm = any_norm || fields[f].norm_column >= 0;
+    if (f && !(std::string(fields[f - 1].name, fields[f - 1].name_len) <
+               std::string(fields[f].name, fields[f].name_len)))
+      return -3;   // fields are written in name order (field_reader::prepare checks it)
+  }
+  put_be32(ti, seg_features);                           // write_segment_features
+  const char* kNorm2 = "iresearch::norm2";              // irs::Norm2::type_name()
+  put_vlong(ti, any_norm ? 1 : 0);
+  if (any_norm) put_string(ti, kNorm2, std::strlen(kNorm2));
+  uint64_t n_written = 0;
+  for (uint32_t f = 0; f < n_fields; ++f) {
+    const irs_synth_field& fd = fields[f];
+    if ((!fd.terms || !fd.term_lens || !fd.metas) && fd.n_terms) return -1;
+    const bool has_freq = (fd.index_features & 1u) != 0, has_pos = (fd.index_features & 2u) != 0;
+    const bool has_pay = (fd.index_features & 12u) != 0;   // OFFS | PAY
+    DictWriter w{tm, Features{has_freq, has_pos, has_pay}, min_block, max_block, {}, {}, {}, 0, {}};
+    const uint8_t* p = fd.terms;
+    std::string prev, min_term, max_term;
+    uint64_t term_count = 0, sum_df = 0, sum_tf = 0;
+    for (uint32_t i = 0; i < fd.n_terms; ++i) {
+      std::string t(reinterpret_cast<const char*>(p), fd.term_lens[i]);
+      p += fd.term_lens[i];
+      if (i && !(prev < t)) return -3;
+      if (fd.metas[i].docs_count) {   // (field_writer::write drops empty terms)
+        w.add(t, fd.metas[i]);
+        if (!term_count) min_term = t;
+        max_term = t;
+        ++term_count;
+        sum_df += fd.metas[i].docs_count;
+        sum_tf += fd.metas[i].freq;
+      }
+      prev = std::move(t);
+    }
+    if (!term_count) continue;   // EndField: nothing to write
+    w.finish();
+    // EndField: the field's record ...
+    put_string(ti, fd.name, fd.name_len);
+    put_be32(ti, fd.index_features);                    // write_field_features
+    put_vlong(ti, fd.norm_column >= 0 ? 1 : 0);
+    if (fd.norm_column >= 0) {
+      put_vlong(ti, 0);                                 // the feature's id in the segment's list
+      put_vlong(ti, uint64_t(fd.norm_column) + 1);
+    }
+    put_vlong(ti, term_count);
+    put_vlong(ti, fd.docs_with_field);
+    put_vlong(ti, sum_df);
+    put_string(ti, min_term.data(), min_term.size());
+    put_string(ti, max_term.data(), max_term.size());
+    if (has_freq) put_vlong(ti, sum_tf);
+    put_be64(ti, fd.wand_mask);
+    // ... and its FST: one state (the start), no arcs, final weight = the root block's record
+    Bytes root;                                         // MergeBlocks
+    const auto& g = w.group;
+    root.push_back(g.front().meta);
+    put_vlong(root, g.front().start);
+    if (g.front().meta & 4u) {
+      put_vint(root, uint32_t(g.size() - 1));
+      for (size_t i = 1; i < g.size(); ++i) {
+        root.push_back(uint8_t(g[i].label & 0xFF));
+        put_vlong(root, g[i].start - g.front().start);
+        root.push_back(g[i].meta);
+      }
+    }
+    ti.push_back(0);                                    // ImmutableFst::Write: Version::MIN
+    put_be64(ti, 1);                                    // properties (kExpanded)
+    put_be64(ti, root.size());                          // total weight size
+    put_be32(ti, 1);                                    // states
+    put_vint(ti, 1);                                    // states - start
+    put_vlong(ti, 1);                                   // zig-zag(arcs - states = -1)
+    put_vlong(ti, (uint64_t(root.size()) << 1) | 1u);   // final weight size, no arcs
+    ti.insert(ti.end(), root.begin(), root.end());
+    ++n_written;
+  }
+  put_footer(tm);
+  put_be64(ti, n_written);                              // field_writer::end
+  put_footer(ti);
+  if (tm.size() > tm_cap || ti.size() > ti_cap) return -2;
+  std::memcpy(tm_out, tm.data(), tm.size());
+  std::memcpy(ti_out, ti.data(), ti.size());
+  *tm_len = tm.size();
+  *ti_len = ti.size();
+  return int64_t(n_written);
+}
+
+int64_t irs_synth_segment_meta(const char* name, uint32_t name_len, uint64_t version,
+                               uint64_t docs_count, uint64_t live_docs_count, uint64_t byte_size,
+                               uint32_t has_column_store, const char* const* files,
+                               const uint32_t* file_lens, uint32_t n_files, uint8_t* out,
+                               uint64_t out_cap) {
+  if (!name || docs_count < live_docs_count || (n_files && (!files || !file_lens))) return -1;
+  Bytes o;
+  put_header(o, "iresearch_10_segment_meta", 1);
+  put_string(o, name, name_len);
+  put_vlong(o, version);
+  put_vlong(o, live_docs_count);
+  put_vlong(o, docs_count - live_docs_count);
+  put_vlong(o, byte_size);
+  o.push_back(has_column_store ? 1 : 0);               // flags: HAS_COLUMN_STORE, not SORTED
+  put_vlong(o, 0);                                      // 1 + sort, sort = field_limits::invalid()
+  put_vlong(o, n_files);                                // write_strings
+  for (uint32_t i = 0; i < n_files; ++i) put_string(o, files[i], file_lens[i]);
+  put_footer(o);
+  if (o.size() > out_cap) return -2;
+  std::memcpy(out, o.data(), o.size());
+  return int64_t(o.size());
 }
 
 }  // extern "C"

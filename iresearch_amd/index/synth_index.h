@@ -188,6 +188,34 @@ int64_t irs_synth_columnstore(const uint8_t* values, uint32_t value_bytes, uint3
                               uint64_t csd_cap, uint64_t* csd_len, uint8_t* csi_out,
                               uint64_t csi_cap, uint64_t* csi_len, uint32_t* column_id);
 
+/* One field of a segment for irs_synth_segment_dictionary: what field_writer::write is handed. */
+typedef struct irs_synth_field {
+  const char* name;            /* fields must come in name order */
+  uint32_t name_len;
+  uint32_t index_features;     /* IndexFeatures: FREQ 1, POS 2, OFFS 4, PAY 8 */
+  int64_t norm_column;         /* the field's Norm2 column id; < 0: no norms */
+  uint64_t docs_with_field;    /* postings_writer::end_field's doc count */
+  uint64_t wand_mask;          /* bit i: scorer i has wand data in this field */
+  const uint8_t* terms;        /* as irs_synth_term_dictionary */
+  const uint32_t* term_lens;
+  const irs_synth_term_meta* metas;
+  uint32_t n_terms;
+} irs_synth_field;
+/* The term dictionary `.tm` of ALL fields of a segment (one file: field_writer opens it once,
+ * formats_burst_trie.cpp:1235-1290) and the term index `.ti` with the segment's feature list and
+ * every field's record (EndField :1347-1432).  The FST of a field holds the root block's record
+ * only.  Returns the number of fields written (fields without terms are skipped), < 0 on error. */
+int64_t irs_synth_segment_dictionary(const irs_synth_field* fields, uint32_t n_fields,
+                                     uint32_t min_block, uint32_t max_block, uint8_t* tm_out,
+                                     uint64_t tm_cap, uint64_t* tm_len, uint8_t* ti_out,
+                                     uint64_t ti_cap, uint64_t* ti_len);
+/* The segment meta file `.sm` (SegmentMetaWriter::write, formats_10.cpp:3102-3140). */
+int64_t irs_synth_segment_meta(const char* name, uint32_t name_len, uint64_t version,
+                               uint64_t docs_count, uint64_t live_docs_count, uint64_t byte_size,
+                               uint32_t has_column_store, const char* const* files,
+                               const uint32_t* file_lens, uint32_t n_files, uint8_t* out,
+                               uint64_t out_cap);
+
 #ifdef __cplusplus
 }
 #endif

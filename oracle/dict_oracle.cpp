@@ -8,11 +8,17 @@
 //       term index (FST) hands out: block_iterator::load / read_entry_* / next floor block
 //       core/formats/formats_burst_trie.cpp:1765-1848, 1874-1930, 2020-2060, term_iterator::next
 //       :2364-2420 (depth first, sub-blocks pushed when met)
+//   orc_read_term_index — field_reader::prepare's `.ti` half: read_segment_features :711-733, per
+//       field term_reader_base::prepare :1509-1545 + read_field_features :741-766, then the
+//       field's FST (ImmutableFstImpl::Read, utils/fstext/immutable_fst.hpp:136-203) whose start
+//       state's final weight is the root block's header (block_iterator :1751-1764)
+//   orc_read_segment_meta — SegmentMetaReader::read  core/formats/formats_10.cpp:3147-3218
 //   orc_read_fixed_column — columnstore2 reader::prepare_index + (dense_)fixed_length_column
 //       core/formats/columnstore2.cpp:1746-1830, 650-789 (value at data + len*(doc - min)), 792-1011
 // Written from the reader code; the product's own readers (iresearch_amd/cpp/irs_hip.hpp) walk
 // `.tm` WITHOUT the root pointer (parse every block, resolve prefixes backwards) — the two must
 // agree on the emitter's files (iresearch_amd/index/synth_dict.cpp, written from the writers).
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -268,6 +274,155 @@ int orc_read_fixed_column(const uint8_t* csi, uint64_t csi_len, const uint8_t* c
     return 0;
   }
   return c.bad ? -1 : -5;
+}
+
+
+// crc32c of everything in front of the footer's checksum (format_utils::check_footer)
+static uint32_t orc_crc32c(const uint8_t* p, size_t n) {
+  static uint32_t table[256];
+  static bool ready = false;
+  if (!ready) {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+      table[i] = c;
+    }
+    ready = true;
+  }
+  uint32_t c = 0xFFFFFFFFu;
+  for (size_t i = 0; i < n; ++i) c = table[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
+  return c ^ 0xFFFFFFFFu;
+}
+static bool footer_ok(const uint8_t* f, uint64_t len) {
+  if (len < 16) return false;
+  const uint8_t* t = f + len - 16;
+  return be32(t) == uint32_t(-int32_t(0x3fd76c17)) && be32(t + 4) == 0 && be64(t + 8) == orc_crc32c(f, len - 8);
+}
+static bool read_str(Cursor& c, std::string& out) {
+  const uint32_t n = c.vint();
+  const uint8_t* at = c.take(n);
+  if (c.bad) return false;
+  out.assign(reinterpret_cast<const char*>(at), n);
+  return true;
+}
+
+int orc_read_term_index(const uint8_t* ti, uint64_t len, orc_field_record* out, uint32_t cap,
+                        uint32_t* count, uint32_t* segment_index_features) {
+  const size_t hl = header_len(ti, len, "block_tree_terms_index", 3);
+  if (!hl || !footer_ok(ti, len) || len < hl + 24) return -1;
+  if (int32_t(be32(ti + hl - 4)) < 2) return -3;        // (mutable FSTs of formats < 1_3: not restated)
+  const uint64_t fields = be64(ti + len - 24);          // the count sits in front of the footer
+  Cursor c{ti + hl, ti + len - 24};
+  if (c.vint() != 0) return -3;                         // encrypted
+  const uint8_t* f4 = c.take(4);
+  if (c.bad) return -1;
+  const uint32_t seg_features = be32(f4);
+  if (seg_features > 15) return -1;
+  if (segment_index_features) *segment_index_features = seg_features;
+  std::vector<std::string> feature_names;
+  for (uint64_t n = c.vlong(); n && !c.bad; --n) {
+    std::string s;
+    if (!read_str(c, s)) return -1;
+    feature_names.push_back(std::move(s));
+  }
+  std::string prev;
+  for (uint64_t i = 0; i < fields; ++i) {
+    orc_field_record r;
+    std::memset(&r, 0, sizeof r);
+    r.norm_column = -1;
+    std::string name;
+    if (!read_str(c, name)) return -1;
+    if (i && !(prev < name)) return -1;                 // "Invalid field order in segment"
+    prev = name;
+    r.name_len = uint32_t(name.size());
+    std::memcpy(r.name, name.data(), std::min<size_t>(name.size(), sizeof r.name));
+    const uint8_t* ff = c.take(4);
+    if (c.bad) return -1;
+    r.index_features = be32(ff);
+    if (r.index_features > 15) return -1;
+    for (uint64_t n = c.vlong(); n && !c.bad; --n) {
+      const uint64_t id = c.vlong();
+      const uint64_t column = c.vlong() - 1;
+      if (c.bad || id >= feature_names.size()) return -1;
+      if (feature_names[id] == "iresearch::norm2") r.norm_column = int64_t(column);
+    }
+    r.terms_count = c.vlong();
+    r.docs_count = c.vlong();
+    r.total_doc_freq = c.vlong();
+    std::string skip;
+    if (!read_str(c, skip) || !read_str(c, skip)) return -1;   // min / max term
+    if (r.index_features & 1u) r.total_term_freq = c.vlong();
+    const uint8_t* wm = c.take(8);                      // (version >= WAND: checked by header_len's max)
+    if (c.bad) return -1;
+    r.wand_mask = be64(wm);
+    // ImmutableFstImpl::Read
+    const uint8_t* fh = c.take(1 + 8 + 8 + 4);
+    if (c.bad || fh[0] != 0) return -1;
+    const uint64_t total_weight = be64(fh + 9);
+    const uint32_t nstates = be32(fh + 17);
+    const uint32_t start = nstates - c.vint();
+    (void)c.vlong();                                    // zig-zag(arcs - states)
+    if (c.bad || start >= nstates) return -1;
+    uint64_t at = 0, root_at = 0, root_len = 0;
+    for (uint32_t s = 0; s < nstates && !c.bad; ++s) {
+      const uint64_t packed = c.vlong();
+      if (s == start) {
+        root_at = at;
+        root_len = packed >> 1;
+      }
+      at += packed >> 1;
+      if (!(packed & 1u)) {
+        const uint8_t* nb = c.take(1);
+        if (c.bad) return -1;
+        for (uint32_t a = uint32_t(*nb) + 1; a && !c.bad; --a) {
+          (void)c.take(1);
+          (void)c.vint();
+          at += c.vlong();
+        }
+      }
+    }
+    const uint8_t* weights = c.take(total_weight);
+    if (c.bad || at != total_weight || root_at + root_len > total_weight || root_len < 2) return -1;
+    Cursor w{weights + root_at, weights + root_at + root_len};
+    r.root_meta = *w.take(1);                           // block_iterator: meta, start, floor data
+    r.root_start = w.vlong();
+    if (r.root_meta & 4u) r.root_floor_blocks = w.vint();
+    if (w.bad) return -1;
+    if (i < cap && out) out[i] = r;
+  }
+  if (c.bad || c.p != c.end) return -1;
+  if (count) *count = uint32_t(fields);
+  return 0;
+}
+
+int orc_read_segment_meta(const uint8_t* sm, uint64_t len, uint64_t* docs_count,
+                          uint64_t* live_docs_count, uint32_t* has_column_store, uint32_t* n_files) {
+  const size_t hl = header_len(sm, len, "iresearch_10_segment_meta", 1);
+  if (!hl || !footer_ok(sm, len)) return -1;
+  const int32_t version = int32_t(be32(sm + hl - 4));
+  Cursor c{sm + hl, sm + len - 16};
+  std::string name;
+  if (!read_str(c, name)) return -1;
+  (void)c.vlong();                                      // segment version
+  const uint64_t live = c.vlong();
+  const uint64_t docs = c.vlong() + live;
+  (void)c.vlong();                                      // byte size
+  const uint8_t* fl = c.take(1);
+  if (c.bad || (*fl & ~3u)) return -1;
+  uint64_t sort = 0;
+  if (version > 0) sort = c.vlong();
+  if (((*fl & 2u) != 0) != (sort != 0)) return -1;
+  const uint64_t files = c.vlong();
+  for (uint64_t i = 0; i < files; ++i) {
+    std::string s;
+    if (!read_str(c, s)) return -1;
+  }
+  if (c.bad || c.p != c.end) return -1;
+  if (docs_count) *docs_count = docs;
+  if (live_docs_count) *live_docs_count = live;
+  if (has_column_store) *has_column_store = *fl & 1u;
+  if (n_files) *n_files = uint32_t(files);
+  return 0;
 }
 
 }  // extern "C"

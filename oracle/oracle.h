@@ -248,6 +248,28 @@ int orc_read_fixed_column(const uint8_t* csi, uint64_t csi_len, const uint8_t* c
                           uint32_t payload_cap, uint32_t* payload_len, uint8_t* values,
                           uint64_t values_cap);
 
+/* One field's record of the term index `.ti` (term_reader_base::prepare,
+ * formats_burst_trie.cpp:1509-1545) + the root block the field's FST maps the empty prefix to
+ * (ImmutableFstImpl::Read utils/fstext/immutable_fst.hpp:136-203; block_iterator's header
+ * :1751-1764). */
+typedef struct orc_field_record {
+  char name[64];
+  uint32_t name_len;
+  uint32_t index_features;
+  int64_t norm_column;       /* the column id stored for "iresearch::norm2", -1: none */
+  uint64_t terms_count, docs_count, total_doc_freq, total_term_freq, wand_mask;
+  uint64_t root_start;
+  uint32_t root_meta;        /* 1 terms, 2 sub-blocks, 4 floor */
+  uint32_t root_floor_blocks;/* further floor blocks of the root group */
+} orc_field_record;
+/* field_reader::prepare (formats_burst_trie.cpp:3323-3440), the `.ti` half.  *count = fields in
+ * the file; at most `cap` records are written.  0 ok, <0 corrupt / unsupported. */
+int orc_read_term_index(const uint8_t* ti, uint64_t len, orc_field_record* out, uint32_t cap,
+                        uint32_t* count, uint32_t* segment_index_features);
+/* SegmentMetaReader::read (formats_10.cpp:3147-3218). */
+int orc_read_segment_meta(const uint8_t* sm, uint64_t len, uint64_t* docs_count,
+                          uint64_t* live_docs_count, uint32_t* has_column_store, uint32_t* n_files);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,6 +79,23 @@ def test_cpp_segment_from_file_bytes_on_the_gpu(gpulib, tmp_path):
                    source="test_files", args=["1000000", "0"])
 
 
+def test_cpp_segment_of_several_fields_on_the_emulator(simlib, tmp_path):
+    """SURVEY.md §8 f3, the host half: three fields of ONE segment (FREQ|POS + Norm2, no FREQ,
+    FREQ without norms) opened from `.doc` / `.pos` / `.tm` / `.ti` / `.sm` / columnstore bytes
+    and a field name — features, norm column, counts and block roots all come from the term
+    index and the segment meta (tests/cpp/test_segment.cpp)."""
+    _build_and_run(tmp_path, Path(simlib._name), source="test_segment", args=["40000"])
+
+
+@pytest.mark.gpu
+def test_cpp_segment_of_several_fields_on_the_gpu(gpulib, tmp_path):
+    from iresearch_amd import _build
+    rocm = "/opt/rocm/lib"
+    _build_and_run(tmp_path, Path(_build.HIP_LIB),
+                   ["-Wl,-rpath," + rocm, "-Wl,-rpath-link," + rocm, "-Wl,--allow-shlib-undefined"],
+                   source="test_segment", args=["1000000"])
+
+
 @pytest.mark.gpu
 def test_cpp_host_layer_on_the_gpu(gpulib, tmp_path):
     from iresearch_amd import _build
