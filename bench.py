@@ -168,6 +168,9 @@ def main():
                     help="0 (default): every step executes a batch of queries that never ran before "
                          "(created, run and destroyed inside the step); N > 0: the old protocol — N "
                          "persistent batches of the same distribution replayed in rotation (A/B)")
+    ap.add_argument("--no-cross-rank-threshold", action="store_true",
+                    help="N > 1: every rank keeps the threshold of its own segments (A/B against "
+                         "irs_hip_batch_set_comm: one threshold per query over all ranks)")
     ap.add_argument("--no-shared-threshold", action="store_true",
                     help="A/B: every (segment, query) unit of a rank's batch keeps its own threshold")
     ap.add_argument("--per-segment-batches", action="store_true",
@@ -284,19 +287,31 @@ def main():
                 # the per-segment lists are merged (all-gather + k_merge_topk): the segments of
                 # a rank look for a query's k best docs TOGETHER (irs_hip_batch_set_shared_threshold)
                 b.set_shared_threshold(True)
+            if comm_thr is not None:
+                # ... and the ranks TOGETHER: one threshold per query over all segments of the
+                # index, as the harness's one heap has (irs_hip_batch_set_comm: the pilot
+                # histograms are summed over the ranks inside the run)
+                b.set_comm(comm_thr)
             b.profile(True)
             out[lead] = b
         return out
 
+    # the collectives go through the library's own RCCL communicators (irs_hip_comm_*); torch
+    # only carries their 128-byte ids to the other ranks.  Two of them: the top-k exchange of
+    # step i overlaps the batch of step i+1, whose threshold all-reduces need a communicator
+    # nothing else is using
+    comm = comm_thr = None
+    if world > 1:   # (on every rank or on none; torch.distributed remains the way out)
+        comm = distributed.agreed_communicator(L, local_rank, rank, world, dev, log)
+        per_rank = (n_segments + world - 1) // world
+        every_rank_has_one = (world - 1) * per_rank < n_segments
+        if (comm is not None and every_rank_has_one and len(groups) == 1
+                and not args.no_cross_rank_threshold and not args.no_shared_threshold):
+            comm_thr = distributed.agreed_communicator(L, local_rank, rank, world, dev, log)
     batch_sets = [make_batches(i) for i in range(n_rows)] if replay else None
     sptr = None if sim else C_void(torch.cuda.current_stream(dev).cuda_stream)
     # every buffer of the exchange step is allocated once (twice: two sets alternate); each
     # local segment's results are written straight into its slot of the send buffer
-    # the collective goes through the library's own RCCL communicator (irs_hip_comm_*); torch
-    # only carries its 128-byte id to the other ranks
-    comm = None
-    if world > 1:   # (on every rank or on none; torch.distributed remains the way out)
-        comm = distributed.agreed_communicator(L, local_rank, rank, world, dev, log)
     exchange = distributed.PipelinedExchange(L, local_rank, n_segments if multi else 1, rank,
                                              world, nq, k, dev, comm=comm)
     # a multi-segment batch writes [segment][query][k] hits and [segment][query] counts: exactly
@@ -508,7 +523,10 @@ def main():
                               ("irs_hip_topk_allgather (RCCL behind the C ABI)" if comm is not None
                                else "torch.distributed all_gather_into_tensor"),
                 "rccl_library": None if comm is None else comm.library(),
-                "ranks_seen": None if comm is None else comm.ranks_seen},
+                "ranks_seen": None if comm is None else comm.ranks_seen,
+                "threshold": None if world == 1 else
+                             ("one per query over all ranks (irs_hip_batch_set_comm: 2 all-reduces per batch)"
+                              if comm_thr is not None else "one per query and rank")},
             "roofline": roof,
         }
     if rank == 0 and not multi and not args.no_cpu:

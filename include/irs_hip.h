@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define IRS_HIP_ABI_VERSION 7
+#define IRS_HIP_ABI_VERSION 8
 #define IRS_HIP_BLOCK_SIZE 128u  /* postings per block, formats_10.cpp:90 */
 #define IRS_HIP_MAX_TERMS 16u    /* terms per boolean query               */
 #define IRS_HIP_MAX_K 4096u      /* largest top-k                         */
@@ -458,6 +458,26 @@ int irs_hip_comm_library(char* buf, size_t cap);
  * at r * bytes_per_rank.  Asynchronous on `stream` (a hipStream_t). */
 int irs_hip_topk_allgather(irs_hip_comm* comm, const void* d_send, void* d_recv,
                            uint64_t bytes_per_rank, void* stream);
+
+/* ONE threshold per query across RANKS — the harness keeps one heap over all segments of the
+ * index (utils/index-search.cpp:719-779); with the segments sharded over processes that is one
+ * threshold for a query's units on every rank.  With a communicator attached, every run of the
+ * batch sums the pilot histograms of each query over the ranks (one all-reduce of
+ * n_queries * 514 counters between the pilot and the scoring kernels) and picks the threshold
+ * from the sum, so that all segments of the index TOGETHER yield the k best docs (plus the usual
+ * margin); a second, small all-reduce behind the selection sums what each group listed and
+ * matched, so that every rank reaches the same verdict on the estimate and re-runs (or not) in
+ * step with the others.  The merged top k over all ranks' lists is exactly what it is without
+ * the option; a rank's list holds its docs at or above the shared threshold, possibly fewer
+ * than k.  Requirements: the SAME queries in the same order on every rank (statistics are
+ * index-global anyway), every rank runs its batches in the same order, and nothing else uses
+ * `comm` concurrently — give the top-k exchange its own communicator when it overlaps the next
+ * batch.  Applies to units on joined posting streams scored by the BM25 family (their score
+ * bound is the same on every segment); other units keep thresholds of their own while the rank
+ * still takes part in the collectives.  Implies irs_hip_batch_set_shared_threshold for the
+ * rank's own segments.  NULL detaches.  Call before the batch's first run; `comm` must outlive
+ * the batch. */
+int irs_hip_batch_set_comm(irs_hip_batch* batch, irs_hip_comm* comm);
 
 const char* irs_hip_strerror(int status);
 uint32_t irs_hip_abi_version(void);

@@ -22,6 +22,7 @@
 #include <cstdint>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <variant>
@@ -352,6 +353,13 @@ class QueryBatch {
       if (part.h)
         check(irs_hip_batch_set_shared_threshold(part.h, enable ? 1 : 0),
               "irs_hip_batch_set_shared_threshold");
+    return *this;
+  }
+  // ... and one threshold per query across RANKS (irs_hip_batch_set_comm): every rank attaches its
+  // communicator to its batch of the same queries; nullptr detaches
+  QueryBatch& set_comm(irs_hip_comm* comm) {
+    for (Part& part : part_)
+      if (part.h) check(irs_hip_batch_set_comm(part.h, comm), "irs_hip_batch_set_comm");
     return *this;
   }
   // irs::score::Min per query: the k-th best score the caller's heap holds so far (empty: none)
@@ -1295,6 +1303,7 @@ class Communicator {
   void all_gather(const void* d_send, void* d_recv, uint64_t bytes_per_rank, void* stream = nullptr) {
     check(irs_hip_topk_allgather(h_, d_send, d_recv, bytes_per_rank, stream), "irs_hip_topk_allgather");
   }
+  irs_hip_comm* handle() const noexcept { return h_; }
 
  private:
   int32_t device_;
@@ -1330,15 +1339,41 @@ std::vector<std::vector<ScoredDoc>> search_sharded(Communicator& comm,
   std::vector<char> zero(block, 0);   // slots of segments this rank does not have: count 0
   check(irs_hip_device_upload(dev, send.get(), zero.data(), block), "irs_hip_device_upload");
   std::string local_error;
+  std::unique_ptr<QueryBatch> batch;
   try {
     if (!mine.empty()) {   // (a rank without segments has no batch to build)
-      QueryBatch batch(mine, prepare(filters, scorer, index), k);
-      if (wand) batch.set_wand(true);
-      batch.set_shared_threshold(true);   // (the lists are merged below: one threshold per query)
-      batch.run();
-      check(irs_hip_batch_results_to_device(batch.single_part(), send.at(0), send.at(hit_bytes), nullptr),
+      batch = std::make_unique<QueryBatch>(mine, prepare(filters, scorer, index), k);
+      if (wand) batch->set_wand(true);
+      batch->set_shared_threshold(true);   // (the lists are merged below: one threshold per query)
+    }
+  } catch (const std::exception& e) {
+    local_error = e.what();
+    batch.reset();
+  }
+  // ONE threshold per query over ALL ranks' segments (irs_hip_batch_set_comm) needs every rank
+  // inside the batch's collectives: only when every rank holds segments and built its batch —
+  // agreed on with one 8-byte all-gather; otherwise each rank keeps the threshold of its own
+  // segments (same merged result, more candidates)
+  {
+    DeviceBuffer flag(dev, 8), flags(dev, 8 * uint64_t(comm.n_ranks()));
+    const uint64_t ready = batch ? 1 : 0;
+    check(irs_hip_device_upload(dev, flag.get(), &ready, 8), "irs_hip_device_upload");
+    check(irs_hip_device_sync(dev, nullptr), "irs_hip_device_sync");
+    comm.all_gather(flag.get(), flags.get(), 8);
+    std::vector<uint64_t> all(size_t(comm.n_ranks()));
+    check(irs_hip_device_download(dev, all.data(), flags.get(), 8 * all.size()), "irs_hip_device_download");
+    bool everyone = true;
+    for (uint64_t f : all) everyone = everyone && f != 0;
+    if (everyone && comm.n_ranks() > 1) batch->set_comm(comm.handle());
+  }
+  try {
+    if (batch) {
+      batch->run();
+      check(irs_hip_batch_results_to_device(batch->single_part(), send.at(0), send.at(hit_bytes), nullptr),
             "irs_hip_batch_results_to_device");
       check(irs_hip_device_sync(dev, nullptr), "irs_hip_device_sync");
+    } else if (!local_error.empty()) {
+      throw error(IRS_HIP_EHIP, local_error);
     }
   } catch (const std::exception& e) {
     local_error = e.what();

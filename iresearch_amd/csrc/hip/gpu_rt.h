@@ -107,6 +107,8 @@ struct Api {
   int (*get_unique_id)(UniqueId*) = nullptr;
   int (*init_rank)(handle_t*, int, UniqueId, int) = nullptr;
   int (*all_gather)(const void*, void*, size_t, int /*ncclDataType_t*/, handle_t, hipStream_t) = nullptr;
+  int (*all_reduce)(const void*, void*, size_t, int /*ncclDataType_t*/, int /*ncclRedOp_t*/, handle_t,
+                    hipStream_t) = nullptr;
   int (*destroy)(handle_t) = nullptr;
   bool ok = false;
 };
@@ -142,8 +144,9 @@ inline const Api& api() {   // bound once per process, at first use
     x.get_unique_id = reinterpret_cast<decltype(x.get_unique_id)>(dlsym(h, "ncclGetUniqueId"));
     x.init_rank = reinterpret_cast<decltype(x.init_rank)>(dlsym(h, "ncclCommInitRank"));
     x.all_gather = reinterpret_cast<decltype(x.all_gather)>(dlsym(h, "ncclAllGather"));
+    x.all_reduce = reinterpret_cast<decltype(x.all_reduce)>(dlsym(h, "ncclAllReduce"));
     x.destroy = reinterpret_cast<decltype(x.destroy)>(dlsym(h, "ncclCommDestroy"));
-    x.ok = x.get_unique_id && x.init_rank && x.all_gather && x.destroy;
+    x.ok = x.get_unique_id && x.init_rank && x.all_gather && x.all_reduce && x.destroy;
     return x;
   }();
   return a;
@@ -163,6 +166,11 @@ inline bool init_rank(handle_t* out, int nranks, const void* id128, int rank) {
 inline bool all_gather(handle_t c, const void* send, void* recv, size_t bytes, stream_t s) {
   const Api& a = api();
   return a.ok && a.all_gather(send, recv, bytes, 0 /*ncclInt8*/, c, s) == 0;
+}
+// in place: every rank's `count` 32-bit counters summed, the sums on every rank
+inline bool all_reduce_u32(handle_t c, void* buf, size_t count, stream_t s) {
+  const Api& a = api();
+  return a.ok && a.all_reduce(buf, buf, count, 3 /*ncclUint32*/, 0 /*ncclSum*/, c, s) == 0;
 }
 inline void destroy(handle_t c) {
   const Api& a = api();

@@ -338,6 +338,11 @@ struct irs_hip_batch {
   DevBuf d_group_of;           // [unit] group + 1, 0: a threshold of its own
   DevBuf d_group_members;      // [nq_user][n_segs] unit or 0xFFFFFFFF
   DevBuf d_group_hist;         // [nq_user][kBins + 2]
+  DevBuf d_group_sums;         // [nq_user][kGroupSumWords] + 2 status counters (k_group_sums)
+  // ... across ranks (irs_hip_batch_set_comm): the group histograms and the group sums are summed
+  // over the communicator's ranks inside every run
+  irs_hip_comm* comm = nullptr;
+  std::vector<double> group_upper;   // [unit] a score bound that is the same on every segment, 0: none
   JoinArgs join_args[2]{};   // plain disjunctions / units with match counts
   JoinArgs join_args_sent[2]{};   // ... as the device last got them
   bool join_args_valid[2] = {false, false};
@@ -1221,13 +1226,14 @@ bool launch_join(irs_hip_batch* b, rt::stream_t st) {
 bool build_groups(irs_hip_batch* b) {
   b->n_groups = 0;
   const uint32_t n_segs = uint32_t(b->segs.size());
-  if (!b->shared_threshold || n_segs < 2 || n_segs > 64 || b->join_units.empty()) return true;
+  const bool across = b->comm != nullptr && !b->phrase;
+  if (!across && (!b->shared_threshold || n_segs < 2 || n_segs > 64 || b->join_units.empty())) return true;
   const uint32_t nq_user = b->nq_user;
   std::vector<uint8_t> is_join(b->nq, 0);
   for (uint32_t u : b->join_units) is_join[u] = 1;
   std::vector<uint32_t> group_of(b->nq, 0), members(size_t(nq_user) * n_segs, 0xFFFFFFFFu);
   uint32_t grouped = 0;
-  for (uint32_t g = 0; g < nq_user; ++g) {
+  for (uint32_t g = 0; g < nq_user && n_segs <= 64; ++g) {
     bool ok = true;
     uint32_t live = 0;
     for (uint32_t sgi = 0; sgi < n_segs && ok; ++sgi) {
@@ -1235,24 +1241,33 @@ bool build_groups(irs_hip_batch* b) {
       const DevQuery& dq = b->queries[u];
       if (!dq.n_terms) continue;   // (nothing of the query in this segment)
       ok = is_join[u] != 0;
-      for (uint32_t s2 = 0; s2 < sgi && ok; ++s2) {
-        const DevQuery& other = b->queries[s2 * nq_user + g];
-        if (other.n_terms) ok = other.bin_scale == dq.bin_scale && other.k == dq.k;
+      if (across) {
+        // the other ranks' units cannot be asked: only a bound that every segment of the index
+        // arrives at by itself qualifies (the boosts of ALL the query's terms, present or not)
+        ok = ok && b->group_upper[u] > 0.0;
+      } else {
+        for (uint32_t s2 = 0; s2 < sgi && ok; ++s2) {
+          const DevQuery& other = b->queries[s2 * nq_user + g];
+          if (other.n_terms) ok = other.bin_scale == dq.bin_scale && other.k == dq.k;
+        }
       }
       ++live;
     }
-    if (!ok || live < 2) continue;
+    if (!ok || live < (across ? 1u : 2u)) continue;
     for (uint32_t sgi = 0; sgi < n_segs; ++sgi) {
       const uint32_t u = sgi * nq_user + g;
       if (!b->queries[u].n_terms) continue;
+      if (across) b->queries[u].bin_scale = float(double(kBins) / b->group_upper[u]);
       group_of[u] = g + 1;
       members[size_t(g) * n_segs + sgi] = u;
     }
     ++grouped;
   }
-  if (!grouped) return true;
+  // (across ranks the collectives run whatever this rank's own units look like)
+  if (!grouped && !across) return true;
   if (!b->d_group_of.alloc(group_of.size() * 4) || !b->d_group_members.alloc(members.size() * 4) ||
       !b->d_group_hist.alloc(uint64_t(nq_user) * (kBins + 2) * 4) ||
+      !b->d_group_sums.alloc((uint64_t(nq_user) * kGroupSumWords + 2) * 4) ||
       !b->up.copy(b->d_group_of.p, group_of.data(), group_of.size() * 4) ||
       !b->up.copy(b->d_group_members.p, members.data(), members.size() * 4))
     return false;
@@ -1263,19 +1278,27 @@ bool build_groups(irs_hip_batch* b) {
 bool launch_join_pilot(irs_hip_batch* b, rt::stream_t st) {
   const size_t smem = JoinOff::end + kBins * sizeof(uint32_t);
   if (!big_smem(k_join_pilot, smem)) return false;
-  if (b->n_groups && !rt::dmemset(b->d_group_hist.p, 0, b->d_group_hist.n, st)) return false;
   RT_LAUNCH(k_join_pilot, uint32_t(b->join_units.size()), b->join_threads, smem, st,
             b->d_join_units.as<uint32_t>(), b->d_queries.as<DevQuery>(),
             b->d_qterms.as<DevQTerm>(), b->d_jterms.as<JoinTerm>(), b->stride_eff,
             b->join_nw_log2, b->d_bstar.as<uint32_t>(), b->estimate ? kPilotMargin : 0u,
             min_bins(b), b->n_groups ? b->d_group_of.as<uint32_t>() : nullptr,
             b->d_group_hist.as<uint32_t>());
-  if (b->n_groups) {
-    RT_LAUNCH(k_group_threshold, b->n_groups, 64, 0, st, b->d_queries.as<DevQuery>(),
-              b->d_group_members.as<uint32_t>(), uint32_t(b->segs.size()),
-              b->d_group_hist.as<uint32_t>(), b->estimate ? kPilotMargin : 0u, min_bins(b),
-              b->d_bstar.as<uint32_t>());
-  }
+  return rt::last_error_ok();
+}
+
+// One threshold per group from the summed pilot histograms — summed over the ranks first when the
+// batch has a communicator: the units of a query on ALL segments of the index then admit together
+// what one heap over all segments would (index-search.cpp:719-779).
+bool launch_group_threshold(irs_hip_batch* b, rt::stream_t st) {
+  if (!b->n_groups) return true;
+  if (b->comm && !b->phrase &&
+      !rt::comm::all_reduce_u32(b->comm->h, b->d_group_hist.p, size_t(b->n_groups) * (kBins + 2), st))
+    return false;
+  RT_LAUNCH(k_group_threshold, b->n_groups, 64, 0, st, b->d_queries.as<DevQuery>(),
+            b->d_group_members.as<uint32_t>(), uint32_t(b->segs.size()),
+            b->d_group_hist.as<uint32_t>(), b->estimate ? kPilotMargin : 0u, min_bins(b),
+            b->d_bstar.as<uint32_t>());
   return rt::last_error_ok();
 }
 
@@ -2060,6 +2083,7 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
     b->segs.assign(segs, segs + n_segs);
     b->queries.resize(nq);
     b->count_precise.assign(nq, 0);
+    b->group_upper.assign(nq, 0.0);
     b->qterms.reserve(size_t(n_entries) * n_segs);
     std::vector<int> exps;
     exps.reserve(nq);
@@ -2094,8 +2118,8 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
         }
       }
       std::vector<DevQTerm> row;
-      bool absent = false;
-      double upper = 0.0, min_score = 1e300;
+      bool absent = false, same_bound = true;
+      double upper = 0.0, min_score = 1e300, upper_all = 0.0;
       std::vector<double> smins;   // per present term: the smallest score of one posting
       for (uint32_t j = 0; j < in.n_terms; ++j) {
         const irs_hip_term_scorer& ts = terms[in.first_term + j];
@@ -2134,6 +2158,11 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
           default: rc = IRS_HIP_EINVAL;
         }
         if (rc != IRS_HIP_OK) break;
+        // (BM25 family: a posting scores below its boost c0 whatever the segment holds; the
+        // TF-IDF bound grows with the segment's largest frequency)
+        same_bound = same_bound && (ts.kind == IRS_HIP_SCORE_BM25 || ts.kind == IRS_HIP_SCORE_BM15 ||
+                                    ts.kind == IRS_HIP_SCORE_BM1);
+        upper_all += double(ts.c0);
         // TermQuery::execute: no term state in this segment -> empty iterator
         // (term_query.cpp:41-43)
         if (qt.term == IRS_HIP_NO_TERM || seg->terms[qt.term].docs_count == 0) {
@@ -2282,6 +2311,11 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
         break;
       }
       dq.bin_scale = row.empty() ? 0.f : float(double(kBins) / upper);
+      // (irs_hip_batch_set_comm) the bound every segment of the index computes alike
+      b->group_upper[q] = (same_bound && !is_phrase && !row.empty() && upper_all > 0.0 &&
+                           upper_all * (1.0 + 1e-6) >= upper && std::isfinite(upper_all))
+                              ? upper_all * (1.0 + 1e-6)
+                              : 0.0;
       // fixed-point accumulation: upper < 2^e.  32-bit accumulators (2^(30-e) units) lose at
       // most one unit per posting, i.e. <= upper / (2^29 * min_score) relative to any doc's
       // score: used only while that stays below 2e-6 for every query of the batch.
@@ -2427,6 +2461,16 @@ static int batch_set_shared_threshold_impl(irs_hip_batch* b, int enable) {
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
   if (b->ran && !rt::sync(b->stream)) return IRS_HIP_EHIP;
   b->shared_threshold = enable != 0;
+  b->scratch_ready = false;
+  b->planned = false;
+  return IRS_HIP_OK;
+}
+
+static int batch_set_comm_impl(irs_hip_batch* b, irs_hip_comm* comm) {
+  if (!b) return IRS_HIP_EINVAL;
+  if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
+  if (b->ran && !rt::sync(b->stream)) return IRS_HIP_EHIP;
+  b->comm = comm;
   b->scratch_ready = false;
   b->planned = false;
   return IRS_HIP_OK;
@@ -2631,7 +2675,9 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st) {
   }
   // 2. pilot: per-query score-bin threshold (phrase batches have none: few docs match)
   ok = ok && mark(2 * IRS_HIP_K_PILOT);
+  if (b->n_groups) ok = ok && rt::dmemset(b->d_group_hist.p, 0, b->d_group_hist.n, st);
   if (b->joined) ok = ok && launch_join_pilot(b, st);
+  ok = ok && launch_group_threshold(b, st);
   if (tiles)
     ok = ok && (simd ? launch_pilot_acc<kSimd4>(b, st) : launch_pilot_acc<kScalar>(b, st));
   ok = ok && mark(2 * IRS_HIP_K_PILOT + 1);
@@ -2661,12 +2707,20 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st) {
                 b->has_min ? b->d_min_score.as<float>() : static_cast<const float*>(nullptr),
                 b->n_groups ? b->d_group_of.as<uint32_t>() : static_cast<const uint32_t*>(nullptr));
       if (b->n_groups) {
-        RT_LAUNCH(k_group_check, (b->n_groups + 63u) / 64u, 64, 0, st, b->d_queries.as<DevQuery>(),
+        RT_LAUNCH(k_group_sums, (b->n_groups + 63u) / 64u, 64, 0, st, b->d_queries.as<DevQuery>(),
                   b->d_group_members.as<uint32_t>(), uint32_t(b->segs.size()), b->n_groups,
                   b->d_out_count.as<uint32_t>(), b->d_hits.as<unsigned long long>(),
-                  b->d_bstar.as<uint32_t>(), min_bins(b), b->d_status.as<uint32_t>());
+                  b->d_bstar.as<uint32_t>(), min_bins(b), b->d_status.as<uint32_t>(),
+                  b->d_group_sums.as<uint32_t>());
+        ok = rt::last_error_ok();
+        if (ok && b->comm && !b->phrase)
+          ok = rt::comm::all_reduce_u32(b->comm->h, b->d_group_sums.p,
+                                        size_t(b->n_groups) * kGroupSumWords + 2, st);
+        if (ok)
+          RT_LAUNCH(k_group_verdict, (b->n_groups + 63u) / 64u, 64, 0, st, b->d_queries.as<DevQuery>(),
+                    b->n_groups, b->d_group_sums.as<uint32_t>(), b->d_status.as<uint32_t>());
       }
-      ok = rt::last_error_ok();
+      ok = ok && rt::last_error_ok();
     }
   }
   ok = ok && mark(2 * IRS_HIP_K_SELECT + 1);
@@ -2732,7 +2786,9 @@ static int recover_overflow(irs_hip_batch* b) {
       return IRS_HIP_EHIP;
     const uint64_t need = uint64_t(*std::max_element(cc.begin(), cc.end())) + 1024;
     const bool affordable = need * b->nq * sizeof(uint64_t) <= kMaxCandBytes;
-    if (need > b->cand_cap && affordable) {
+    if (b->comm && need - 1024 <= b->cand_cap) {
+      // (the overflow is another rank's: this one only takes part in the re-run's collectives)
+    } else if (need > b->cand_cap && affordable) {
       if (!b->d_cands.alloc(need * b->nq * sizeof(uint64_t)) ||
           (b->fast16 && !b->d_acands.alloc(need * b->nq * sizeof(uint64_t))))
         return IRS_HIP_ENOMEM;
@@ -2945,6 +3001,9 @@ int irs_hip_batch_set_path(irs_hip_batch* b, int path) {
 }
 int irs_hip_batch_set_shared_threshold(irs_hip_batch* b, int enable) {
   return guarded([&] { return batch_set_shared_threshold_impl(b, enable); });
+}
+int irs_hip_batch_set_comm(irs_hip_batch* b, irs_hip_comm* comm) {
+  return guarded([&] { return batch_set_comm_impl(b, comm); });
 }
 int irs_hip_batch_path(irs_hip_batch* b, int* path) {
   return guarded([&] { return batch_path_impl(b, path); });

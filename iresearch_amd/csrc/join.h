@@ -837,25 +837,51 @@ k_group_threshold(const DevQuery* queries, const uint32_t* members, uint32_t n_s
 
 // ... and its soundness check behind k_select: the group's lists together hold min(k, docs that
 // matched) entries, or the (estimated) threshold was too high — kStatusUnderflow, the host re-runs
-// the batch with the sound threshold (what k_select checks per unit for ungrouped units).
+// the batch with the sound threshold (what k_select checks per unit for ungrouped units).  In two
+// steps, because the group may span RANKS (irs_hip_batch_set_comm): k_group_sums leaves three
+// counters per group — entries listed, docs matched (capped at k per unit: only "more than
+// listed" matters), units whose threshold is the caller's own — and the run's status bits so far
+// as two more counters; the host layer's all-reduce sums them over the ranks; k_group_verdict
+// reads the sums, so EVERY rank reaches the same verdict and takes the same recovery path.
+constexpr uint32_t kGroupSumWords = 3;
 __global__ void __launch_bounds__(64)
-k_group_check(const DevQuery* queries, const uint32_t* members, uint32_t n_segs, uint32_t n_groups,
-              const uint32_t* out_count, const unsigned long long* hits, const uint32_t* bstar,
-              const uint32_t* min_bin, uint32_t* status) {
+k_group_sums(const DevQuery* queries, const uint32_t* members, uint32_t n_segs, uint32_t n_groups,
+             const uint32_t* out_count, const unsigned long long* hits, const uint32_t* bstar,
+             const uint32_t* min_bin, const uint32_t* status, uint32_t* sums) {
   const uint32_t g = blockIdx.x * 64u + threadIdx.x;
+  if (g == 0) {
+    const uint32_t st = *status;
+    sums[uint64_t(n_groups) * kGroupSumWords] = (st & kStatusUnderflow) ? 1u : 0u;
+    sums[uint64_t(n_groups) * kGroupSumWords + 1u] = (st & kStatusOverflow) ? 1u : 0u;
+  }
   if (g >= n_groups) return;
-  unsigned long long got = 0, matched = 0;
-  uint32_t k = 0;
-  bool callers = false;
+  uint32_t got = 0, matched = 0, callers = 0;
   for (uint32_t s = 0; s < n_segs; ++s) {
     const uint32_t u = members[uint64_t(g) * n_segs + s];
     if (u == 0xFFFFFFFFu) continue;
-    k = queries[u].k;
+    const uint32_t k = queries[u].k;
     got += out_count[u];
-    matched += hits[u];
-    callers = callers || (min_bin && min_bin[u] != 0u && bstar[u] == min_bin[u]);
+    matched += hits[u] < k ? uint32_t(hits[u]) : k;
+    callers += (min_bin && min_bin[u] != 0u && bstar[u] == min_bin[u]) ? 1u : 0u;
   }
-  if (got < k && matched > got && !callers) atomicOr(status, kStatusUnderflow);
+  sums[uint64_t(g) * kGroupSumWords] = got;
+  sums[uint64_t(g) * kGroupSumWords + 1u] = matched;
+  sums[uint64_t(g) * kGroupSumWords + 2u] = callers;
+}
+// (queries[g] = the query's unit on the first segment: every unit of it carries the same k)
+__global__ void __launch_bounds__(64)
+k_group_verdict(const DevQuery* queries, uint32_t n_groups, const uint32_t* sums, uint32_t* status) {
+  const uint32_t g = blockIdx.x * 64u + threadIdx.x;
+  if (g == 0) {
+    uint32_t st = 0;
+    if (sums[uint64_t(n_groups) * kGroupSumWords]) st |= kStatusUnderflow;
+    if (sums[uint64_t(n_groups) * kGroupSumWords + 1u]) st |= kStatusOverflow;
+    if (st) atomicOr(status, st);
+  }
+  if (g >= n_groups) return;
+  const uint32_t got = sums[uint64_t(g) * kGroupSumWords], matched = sums[uint64_t(g) * kGroupSumWords + 1u];
+  const bool callers = sums[uint64_t(g) * kGroupSumWords + 2u] != 0u;
+  if (got < queries[g].k && matched > got && !callers) atomicOr(status, kStatusUnderflow);
 }
 
 // The tiles of one chunk (k_join_score); everything per query / per chunk arrives in `ctx`.

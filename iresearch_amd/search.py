@@ -377,6 +377,15 @@ class QueryBatch:
                    "irs_hip_batch_set_shared_threshold")
         return self
 
+    def set_comm(self, comm):
+        """One threshold per query across RANKS (irs_hip_batch_set_comm): `comm` = a
+        distributed.Communicator (or None to detach); every rank attaches one to its batch of the
+        same queries and runs the batches in the same order."""
+        self._comm = comm   # (must outlive the batch)
+        _lib.check(self.L, self.L.irs_hip_batch_set_comm(self.handle, comm.handle if comm else None),
+                   "irs_hip_batch_set_comm")
+        return self
+
     def set_path(self, path):
         """PATH_AUTO / PATH_ITEMS / PATH_JOINED (irs_hip_batch_set_path)."""
         _lib.check(self.L, self.L.irs_hip_batch_set_path(self.handle, int(path)),

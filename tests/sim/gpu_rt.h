@@ -181,6 +181,20 @@ inline bool all_gather(handle_t h, const void* send, void* recv, size_t bytes, s
   barrier(c);
   return true;
 }
+inline bool all_reduce_u32(handle_t h, void* buf, size_t count, stream_t) {
+  Comm* c = static_cast<Comm*>(h);
+  if (count * 4 > kSlotBytes) return false;
+  std::memcpy(c->slots + size_t(c->rank) * kSlotBytes, buf, count * 4);
+  barrier(c);
+  uint32_t* out = static_cast<uint32_t*>(buf);
+  for (size_t i = 0; i < count; ++i) out[i] = 0;
+  for (int r = 0; r < c->nranks; ++r) {
+    const uint32_t* in = reinterpret_cast<const uint32_t*>(c->slots + size_t(r) * kSlotBytes);
+    for (size_t i = 0; i < count; ++i) out[i] += in[i];
+  }
+  barrier(c);
+  return true;
+}
 inline bool library(char* buf, size_t cap) {
   std::snprintf(buf, cap, "shared-memory stand-in (tests/sim)");
   return true;

@@ -173,6 +173,159 @@ def test_two_ranks_gloo_phrases_match_oracle(simlib, tmp_path):
     assert some > 0
 
 
+def _misled_segment(si, tile=12288, stride=16, n_tiles=64):
+    """cases.case_shared_threshold_misled's segment: the tiles the pilot samples (unit 0 of a
+    rank's one local segment: phase 0) hold far better docs than the rest."""
+    import cases
+    from iresearch_amd import synth
+    n_docs = tile * n_tiles
+    rng = np.random.default_rng(31 + si)
+    sampled = [t for t in range(n_tiles) if t % stride == 0]
+    hot = np.concatenate([1 + t * tile + np.sort(rng.choice(tile, 400, replace=False))
+                          for t in sampled]).astype(np.uint32)
+    hot_f = rng.integers(1, 64, hot.size).astype(np.uint32)
+    cold = np.sort(rng.choice(n_docs, 3000, replace=False)).astype(np.uint32) + 1
+    return synth.segment_from_lists([(hot, hot_f), (cold, np.ones(cold.size, np.uint32))], n_docs,
+                                    synth.LAYOUT_SIMD4, None)
+
+
+def _threshold_worker(rank, world, port, sim_path, out_dir):
+    """One threshold per query across ranks (irs_hip_batch_set_comm): the pilot histograms are
+    summed over the ranks inside the run; the merged top k must not change by a bit."""
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import parity
+    from iresearch_amd import _lib, distributed, search, synth
+    from iresearch_amd.search import BM25, TFIDF, And, Or, by_term
+    L = _lib.bind(C.CDLL(sim_path))
+    comm = distributed.Communicator(L, 0, rank, world)
+
+    def everyones(local):
+        gathered = [None] * world
+        dist.all_gather_object(gathered, local)
+        out = {}
+        for g in gathered:
+            out.update(g)
+        return out
+
+    # ---- A: 4 segments of different sizes, 2 per rank; a term missing from one of them ----------
+    sizes = (70_000, 30_000, 140_000, 50_000)
+    first = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    my = distributed.segments_of_rank(N_SEGS, rank, world)
+    segs = {s: synth.build_segment(int(sizes[s]), 256, first_doc=int(first[s])) for s in my}
+    if 1 in segs:
+        segs[1].metas[255]["docs_count"] = 0
+    stats = everyones({s: parity.segment_stats(segs[s]) for s in my})
+    ranks = synth.make_queries(6, 8, 12, 256, synth.SEED + 9)
+    filters = [Or([by_term(int(r) - 1) for r in row]) for row in ranks]
+    filters += [by_term(255), Or([by_term(20), by_term(255, 2.0)]),
+                Or([by_term(12), by_term(13), by_term(14)], min_match=2), And([by_term(12), by_term(13)])]
+    nq = len(filters)
+    readers = [search.SegmentReader.from_synth(segs[s], L=L) for s in my]
+    for tag, scorer in (("bm25", BM25()), ("tfidf", TFIDF(True))):
+        prep = search.prepare(filters, scorer, [stats[s] for s in range(N_SEGS)])
+        for k in (10, 300):
+            merged, listed = [], []
+            for across in (False, True):
+                b = search.QueryBatch(readers, prep, k).set_shared_threshold(True)
+                if across:
+                    b.set_comm(comm)
+                b.run()
+                ex = distributed.TopkExchange(L, 0, N_SEGS, rank, world, nq, k, "cpu")
+                b.results_to_device(*ex.slot(0))
+                assert b.reruns() == 0
+                merged.append([t.clone() for t in ex.run()])
+                listed.append(int(b.results()[1][:, :6].sum()))
+                b.close()
+            # bit for bit the merged result of per-rank thresholds
+            assert all(torch.equal(x, y) for x, y in zip(*merged)), (tag, k)
+            both = torch.tensor(listed)
+            dist.all_reduce(both)
+            if tag == "bm25" and k == 300:   # the ranks share the work of finding k docs
+                assert int(both[1]) < int(both[0]), both
+            if tag == "tfidf":               # (no score bound common to all segments: no groups)
+                assert int(both[1]) >= int(both[0])
+            if rank == 0:
+                np.save(os.path.join(out_dir, "A_%s_%d_hits.npy" % (tag, k)), merged[1][0].numpy())
+                np.save(os.path.join(out_dir, "A_%s_%d_counts.npy" % (tag, k)), merged[1][2].numpy())
+    for r in readers:
+        r.close()
+
+    # ---- B: the pilot sample misleads the shared threshold on BOTH ranks: the group sums (also
+    # summed over the ranks) make every rank re-run, together, with the sound threshold ----------
+    seg = _misled_segment(rank)
+    stats = everyones({rank: parity.segment_stats(seg)})
+    sr = search.SegmentReader.from_synth(seg, L=L)
+    filters = [by_term(0), Or([by_term(0), by_term(1)]), by_term(1)]
+    k = 400
+    prep = search.prepare(filters, BM25(1.2, 0.0), [stats[r] for r in range(world)])
+    b = search.QueryBatch([sr], prep, k).configure(0, 16, 0).set_comm(comm)
+    b.run()
+    ex = distributed.TopkExchange(L, 0, world, rank, world, len(filters), k, "cpu")
+    b.results_to_device(*ex.slot(0))
+    assert b.reruns() == 1 and b.path() == _lib.PATH_JOINED
+    oh, osg, oc = ex.run()
+    if rank == 0:
+        np.save(os.path.join(out_dir, "B_hits.npy"), oh.numpy())
+        np.save(os.path.join(out_dir, "B_counts.npy"), oc.numpy())
+    b.close()
+    sr.close()
+    comm.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_share_one_threshold(simlib, tmp_path):
+    """SURVEY.md §8e: the harness keeps ONE heap over all segments (index-search.cpp:719-779);
+    sharded over two ranks that is one threshold per query for both ranks' units.  The merged
+    top k equals — bit for bit — the single-rank batch over all four segments, and the oracle's."""
+    port = 29500 + ((os.getpid() * 5 + 211) % 2000)
+    mp.spawn(_threshold_worker, args=(2, port, simlib._name, str(tmp_path)), nprocs=2, join=True)
+    import cases  # noqa: F401  (sys.path side effects of tests/)
+    import parity
+    from iresearch_amd import _lib, search, synth
+    from iresearch_amd.search import BM25, TFIDF, And, Or, by_term
+    L = simlib
+    sizes = (70_000, 30_000, 140_000, 50_000)
+    first = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    segs = [synth.build_segment(int(n), 256, first_doc=int(f)) for n, f in zip(sizes, first)]
+    segs[1].metas[255]["docs_count"] = 0
+    readers = [search.SegmentReader.from_synth(s, L=L) for s in segs]
+    ranks = synth.make_queries(6, 8, 12, 256, synth.SEED + 9)
+    filters = [Or([by_term(int(r) - 1) for r in row]) for row in ranks]
+    filters += [by_term(255), Or([by_term(20), by_term(255, 2.0)]),
+                Or([by_term(12), by_term(13), by_term(14)], min_match=2), And([by_term(12), by_term(13)])]
+    for tag, scorer in (("bm25", BM25()), ("tfidf", TFIDF(True))):
+        prep = search.prepare(filters, scorer, [parity.segment_stats(s) for s in segs])
+        for k in (10, 300):
+            b = search.QueryBatch(readers, prep, k).set_shared_threshold(True)
+            h, c, _ = b.run().results()
+            one = search.merge_topk_host([(h[i], c[i]) for i in range(len(segs))], k)
+            got_h = np.load(tmp_path / ("A_%s_%d_hits.npy" % (tag, k))).view(_lib.HIT)
+            got_c = np.load(tmp_path / ("A_%s_%d_counts.npy" % (tag, k)))
+            for q, rows in enumerate(one):
+                assert int(got_c[q]) == len(rows), (tag, k, q)
+                two = got_h.reshape(len(filters), k)[q, :len(rows)]
+                assert [r[0] for r in rows] == [float(x) for x in two["score"]], (tag, k, q)
+                assert [r[2] for r in rows] == [int(x) for x in two["doc"]], (tag, k, q)
+            b.close()
+    for r in readers:
+        r.close()
+    # B against the oracle's heap over both segments
+    segs = [_misled_segment(si) for si in range(2)]
+    filters = [by_term(0), Or([by_term(0), by_term(1)]), by_term(1)]
+    ref = parity.oracle_topk(segs, filters, BM25(1.2, 0.0), 400)
+    got_h = np.load(tmp_path / "B_hits.npy").view(_lib.HIT).reshape(len(filters), 400)
+    got_c = np.load(tmp_path / "B_counts.npy")
+    for q, (ohits, total) in enumerate(ref):
+        assert int(got_c[q]) == len(ohits), q
+        assert np.allclose(got_h[q, :len(ohits)]["score"], np.sort(ohits["score"])[::-1],
+                           rtol=parity.REL_TOL, atol=0), q
+
+
 def test_bench_is_launchable_on_two_ranks(simlib):
     """bench.py under the driver's own multi-GPU launch line (torch.distributed.run, one
     process per rank, MASTER_ADDR 127.0.0.1), in its emulator dry-run mode: the whole
@@ -201,6 +354,8 @@ def test_bench_is_launchable_on_two_ranks(simlib):
     # the exchange went through the C ABI's communicator and its self-test saw both ranks
     assert d["config"]["collective"].startswith("irs_hip_topk_allgather")
     assert d["config"]["ranks_seen"] == 2 and d["config"]["rccl_library"]
+    # ... and the ranks shared one threshold per query (irs_hip_batch_set_comm)
+    assert d["config"]["threshold"].startswith("one per query over all ranks")
 
 
 def test_bench_config5_is_launchable_on_two_ranks(simlib):
