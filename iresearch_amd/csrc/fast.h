@@ -154,7 +154,7 @@ k_fast_pack(const StreamRec* streams, const uint32_t* first_wg /*[stream + 1]*/,
       if (s_b[m] <= p) lo = m; else hi = m;
     }
     const uint32_t e = ent[p];
-    fent[s_fb[lo] + (p - s_b[lo])] = fast_entry(e >> 18, fast_unit(kind, nc, nl, (e >> 10) & kJoinTfMax, (e >> 2) & 0xFFu));
+    fent[s_fb[lo] + (p - s_b[lo])] = fast_entry(e >> 18, fast_unit(kind, nc, nl, join_tf(e), (e >> 2) & 0xFFu));
   }
   if (threadIdx.x < 4u * nt) {   // <= 3 pad entries per half tile
     const uint32_t i = threadIdx.x >> 2, k = threadIdx.x & 3u;
@@ -656,7 +656,7 @@ __device__ __forceinline__ uint32_t join_fixed(const float* caches, uint32_t e, 
     return static_cast<uint32_t>(wave::fma(cs, t, 1.f));
   }
   const float t = caches[((e & 0x3FCu) | tabofs) >> 2];
-  const float tf = static_cast<float>((e >> 10) & kJoinTfMax);
+  const float tf = static_cast<float>(join_tf(e));
   const float scaled = (form == kJSqrt) ? wave::fast_sqrt(tf) * cs * t
                                         : wave::fma(-cs, wave::fast_rcp(wave::fma(tf, t, 1.f)), cs);
   return static_cast<uint32_t>(scaled) | 1u;

@@ -924,6 +924,41 @@ int join_and_forced(const irs_hip_batch* b) {   // -1: decide by cost
   if (const char* e = std::getenv("IRS_HIP_JOIN_AND")) return std::atoi(e) != 0;   // tuning / test knob
   return -1;
 }
+// Plain disjunctions as joined streams or as work items?  Measured on one MI355X, BM25, 10 M docs
+// (tools/cost_sweep.py, profiles/r04_sweeps.txt; picoseconds of step time):
+//   joined:     2.9 per posting of every DISTINCT stream (k_join: decode + 4 B written)
+//             + 0.47 per posting a query references + 3800 per (unit, doc tile)
+//   work items: 1.14 per referenced posting + 6200 per (unit, doc tile)
+// A stream pays for itself when it is shared (the headline batch: 5.7 G referenced postings on
+// 0.31 G distinct ones) or when there are many units (the per-tile cost is lower): joining wins
+// iff  2.9 D < 0.67 R + 2400 T.  128 queries x 8 terms without one shared term: 1.51 ms as work
+// items against 1.60 joined; on a corpus of 1000-word docs 0.75 against 1.35.
+bool join_or_pays(const irs_hip_batch* b, const std::vector<uint32_t>& units) {
+  if (units.empty()) return false;
+  uint64_t refs = 0, distinct = 0, tiles = 0;
+  std::vector<std::vector<uint8_t>> seen(b->segs.size());
+  for (uint32_t u : units) {
+    const DevQuery& dq = b->queries[u];
+    const irs_hip_segment* sg = b->segs[dq.seg];
+    tiles += sg->dev.num_docs / kJoinTile + 1;
+    if (seen[dq.seg].empty()) seen[dq.seg].assign(sg->dev.num_terms, 0);
+    for (uint32_t j = 0; j < dq.n_terms; ++j) {
+      const uint32_t term = b->qterms[dq.first_term + j].term;
+      const uint64_t df = sg->terms[term].docs_count;
+      refs += df;
+      if (!seen[dq.seg][term]) {
+        seen[dq.seg][term] = 1;
+        distinct += df;
+      }
+    }
+  }
+  return 29ull * distinct < (67ull * refs) / 10ull + 24000ull * tiles;
+}
+int join_or_forced(const irs_hip_batch* b) {   // -1: decide by cost
+  if (b->path_pref == IRS_HIP_PATH_JOINED || b->path_pref == IRS_HIP_PATH_JOINED_EXACT) return 1;
+  if (const char* e = std::getenv("IRS_HIP_JOIN_OR")) return std::atoi(e) != 0;   // tuning / test knob
+  return -1;
+}
 bool unit_counts_matches(const DevQuery& dq) {   // min-match / the kMin disjunction of two
   return (dq.op & 0xFF) == 1 || query_min_both(dq.op);
 }
@@ -1517,12 +1552,21 @@ bool ensure_scratch(irs_hip_batch* b) {
     b->tile_units.clear();
     b->join_units.clear();
     b->any_and = false;
-    for (uint32_t u : b->all_tile_units) {
-      if (allow && unit_joinable(b, u)) {
-        b->join_units.push_back(u);
-      } else {
-        b->tile_units.push_back(u);
-        b->any_and = b->any_and || unit_counts_matches(b->queries[u]);
+    {
+      std::vector<uint32_t> can;
+      for (uint32_t u : b->all_tile_units)
+        if (allow && unit_joinable(b, u)) can.push_back(u);
+      const int forced = join_or_forced(b);
+      if (forced == 0 || (forced < 0 && !join_or_pays(b, can))) can.clear();
+      size_t at = 0;
+      for (uint32_t u : b->all_tile_units) {
+        if (at < can.size() && can[at] == u) {
+          b->join_units.push_back(u);
+          ++at;
+        } else {
+          b->tile_units.push_back(u);
+          b->any_and = b->any_and || unit_counts_matches(b->queries[u]);
+        }
       }
     }
     if (!b->phrase) {   // (a phrase batch's conj_units are its phrases, fixed at create)
@@ -1540,7 +1584,10 @@ bool ensure_scratch(irs_hip_batch* b) {
           saved += s;
         }
       }
-      if (forced != 1 && saved < kJoinAndLaunchCost) joining.clear();
+      // (a batch that joins plain disjunctions anyway has paid for k_join and the pilot: one more
+      // k_join_score launch is all a joined conjunction adds)
+      if (forced != 1 && saved < (b->join_units.empty() ? kJoinAndLaunchCost : kJoinAndLaunchCost / 10))
+        joining.clear();
       size_t at = 0;
       for (uint32_t u : b->all_conj_units) {
         if (at < joining.size() && joining[at] == u) {
@@ -1554,8 +1601,16 @@ bool ensure_scratch(irs_hip_batch* b) {
     }
     b->joined = !b->join_units.empty();
     b->fast16 = false;
-    if (b->joined && fast16_allowed(b))
-      for (uint32_t u : b->join_units) b->fast16 = b->fast16 || query_need(b->queries[u].op) <= 1u;
+    if (b->joined && fast16_allowed(b)) {
+      bool wide_tf = false;   // (a fast entry's 16-bit unit is scaled for frequencies below 64)
+      for (uint32_t u : b->join_units) {
+        const DevQuery& dq = b->queries[u];
+        b->fast16 = b->fast16 || query_need(dq.op) <= 1u;
+        for (uint32_t j = 0; j < dq.n_terms; ++j)
+          wide_tf = wide_tf || b->segs[dq.seg]->terms[b->qterms[dq.first_term + j].term].tf_bound > 63u;
+      }
+      if (wide_tf) b->fast16 = false;
+    }
   }
   // 32-bit accumulators halve the LDS per doc: twice the tile at the same residency
   // the largest tile that still lets two workgroups share a CU's 160 KB of LDS

@@ -2,7 +2,7 @@
 // batch is decoded ONCE per run, whatever the number of queries that use it.
 //
 //   k_join        decode + norm join: one 4-byte entry per posting
-//                    [ (doc - tile's first doc) * 4 : 16 | tf : 6 | norm : 8 | 00 ]
+//                    [ (doc - tile's first doc) * 4 : 16 | tf & 63 : 6 | norm : 8 | tf >> 6 : 2 ]
 //                 in posting order, plus the entry index at which every doc tile starts
 //   k_join_pilot  scores every P-th doc tile, derives a per-query score-bin threshold
 //   k_join_score  accumulates the streams of a query's terms tile by tile in LDS, emits the
@@ -25,7 +25,9 @@
 //
 // Eligibility (anything else runs on score.h's / conj.h's kernels): sum merge, scorers of the
 // table family over 1-byte norms or none, 32-bit accumulators, every term's frequencies below
-// 64, no block-max pruning.  Conjunctions and min-match disjunctions of at most 15 terms join
+// 256 (the entry's low 16 bits ARE the byte offset of T[tf][norm] for the terms whose frequencies
+// all have table rows — tf < 16, low bits 0; a long document's tf >= 64 continues in the two low
+// bits, which only the general expression reads), no block-max pruning.  Conjunctions and min-match disjunctions of at most 15 terms join
 // too where the rounding of their match-counting accumulators (join_post COUNT) stays below
 // the parity tolerance and — conjunctions — where walking every entry of every term beats
 // decoding only the blocks the rarest term's docs fall into (irs_hip.hip unit_joinable).
@@ -35,7 +37,7 @@
 namespace irs_hip {
 
 constexpr uint32_t kJoinTile = 12288;     // docs per accumulator tile (48 KB of u32 in LDS)
-constexpr uint32_t kJoinTfMax = 63;       // entry layout: 6 bits of tf
+constexpr uint32_t kJoinTfMax = 255;      // entry layout: 6 + 2 bits of tf
 constexpr uint32_t kJoinBlocks = 64;      // blocks per k_join workgroup
 constexpr uint32_t kJoinChunkTiles = 32;  // consecutive tiles of one unit per work-queue item
 constexpr uint32_t kJoinCands = 256;      // candidate staging slots per chunk (x2 buffers)
@@ -102,7 +104,10 @@ struct alignas(16) JoinTerm {
 static_assert(sizeof(JoinTerm) == 32, "JoinTerm");
 
 __host__ __device__ __forceinline__ uint32_t join_entry(uint32_t idx, uint32_t tf, uint32_t norm) {
-  return (idx << 18) | ((tf & kJoinTfMax) << 10) | ((norm & 0xFFu) << 2);
+  return (idx << 18) | ((tf & 63u) << 10) | ((norm & 0xFFu) << 2) | ((tf >> 6) & 3u);
+}
+__host__ __device__ __forceinline__ uint32_t join_tf(uint32_t e) {
+  return ((e >> 10) & 63u) | ((e & 3u) << 6);
 }
 
 // ---- the query-independent factor of a posting, as k_join evaluates it ---------------------
@@ -374,7 +379,7 @@ __device__ __forceinline__ void join_post(const unsigned char* lds, const uint32
       fx[k] = static_cast<uint32_t>(wave::fma(cs, t[k], COUNT ? kJoinCountRound : 1.f));
       if (COUNT) fx[k] = (fx[k] & ~kJoinCountMask) | 1u;
     } else {
-      const float tf = static_cast<float>((e[k] >> 10) & kJoinTfMax);
+      const float tf = static_cast<float>(join_tf(e[k]));
       float scaled = (FORM == kJSqrt) ? wave::fast_sqrt(tf) * cs * t[k]
                                       : wave::fma(-cs, wave::fast_rcp(wave::fma(tf, t[k], 1.f)), cs);
       wave::keep_f(scaled);

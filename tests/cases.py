@@ -150,7 +150,8 @@ def case_join_edge_blocks(L, layout):
     """The joined-stream path (k_join: every list decoded once per batch) over awkward lists:
     all-equal doc and freq blocks, every doc bit width a 200 k-doc segment allows, exactly 128 /
     129 / 256 postings, tail-only and single-doc lists, lists that start late, end early or
-    jump over several 12288-doc tiles, the largest frequency an entry holds (63: no table row)
+    jump over several 12288-doc tiles, frequencies of long documents (64 .. 255: the entry's two
+    low bits; 256 does not fit an entry: that query runs as work items whatever the path asked for)
     — each list alone and all of them in one Or, against the oracle and bit for bit against the
     work-item path."""
     n_docs = 200_000
@@ -174,13 +175,26 @@ def case_join_edge_blocks(L, layout):
     lists.append((np.array([n_docs], np.uint32), np.array([63], np.uint32)))            # last doc only
     lists.append((np.array([12288], np.uint32), np.array([2], np.uint32)))              # a tile's last doc
     lists.append((np.array([12289], np.uint32), np.array([2], np.uint32)))              # a tile's first doc
+    d = np.sort(rng.choice(np.arange(1, n_docs + 1), 700, replace=False)).astype(np.uint32)
+    f = rng.integers(1, 256, 700).astype(np.uint32)
+    f[:6] = (63, 64, 65, 127, 128, 255)
+    lists.append((d, f))                                                                # long documents
+    i_wide = len(lists) - 1
+    lists.append((d[::3].copy(), np.full(d[::3].size, 256, np.uint32)))                 # ... too long for an entry
     norms = rng.integers(1, 256, n_docs).astype(np.uint8)
     seg, sr = open_lists(L, lists, n_docs, layout, norms)
     nt = len(lists)
     filters = [by_term(t) for t in range(nt)]
     filters += [Or([by_term(t) for t in range(0, nt, 2)][:16]), Or([by_term(t) for t in range(1, nt, 2)][:16]),
-                Or([by_term(8), by_term(nt + 3), by_term(12)])]
+                Or([by_term(8), by_term(nt + 3), by_term(12)]),
+                Or([by_term(i_wide), by_term(3), by_term(10)]), Or([by_term(i_wide + 1), by_term(i_wide)])]
     for scorer in (BM25(), TFIDF(True), BM25(1.2, 0.0)):
+        # the long documents' list runs on joined streams when it can choose
+        prep = search.prepare([by_term(i_wide), Or([by_term(i_wide), by_term(3)])], scorer,
+                              [parity.segment_stats(seg)])
+        b = sr.batch(prep, 10).run()
+        assert b.path() == _lib.PATH_JOINED
+        b.close()
         for k in (3, 500):
             hj = run_and_check(L, seg, filters, scorer, k, sr=sr, path=_lib.PATH_JOINED)
             hi = run_and_check(L, seg, filters, scorer, k, sr=sr, path=_lib.PATH_ITEMS)
@@ -555,7 +569,9 @@ def case_paths_agree(L, num_docs=70_000, max_rank=256, layout=synth.LAYOUT_SIMD4
                 prep = search.prepare(filters, scorer, [parity.segment_stats(seg)])
                 b = sr.batch(prep, k).set_path(path)
                 h, c, t = b.run().results()
-                assert b.path() == (_lib.PATH_ITEMS if path == _lib.PATH_ITEMS else _lib.PATH_JOINED)
+                # (PATH_AUTO: whichever the cost rule takes for this batch — join_or_pays)
+                if path != _lib.PATH_AUTO:
+                    assert b.path() == (_lib.PATH_ITEMS if path == _lib.PATH_ITEMS else _lib.PATH_JOINED)
                 parity.check_single_segment(seg, filters, scorer, k, h, c, t)
                 got[path] = (h.copy(), c.copy(), t.copy())
                 b.close()
@@ -636,7 +652,8 @@ def case_join_counts_boundary(L, num_docs=70_000, max_rank=256):
     def batch(boost):
         flt = [Or([t(w, 1.0) for w in weak] + [t(x, boost) for x in strong], min_match=2)]
         prep = search.prepare(flt, BM25(), [parity.segment_stats(seg)])
-        return flt, sr.batch(prep, 100)
+        # (joined wherever the unit is ELIGIBLE: the cost rule is not what is probed here)
+        return flt, sr.batch(prep, 100).set_path(_lib.PATH_JOINED_EXACT)
 
     def joins(boost):
         _, b = batch(boost)
@@ -1208,10 +1225,10 @@ def case_shared_threshold(L, sizes=(70_000, 30_000, 140_000, 50_000), max_rank=2
     for scorer, grouped in ((BM25(), True), (BM25(1.2, 0.0), True), (TFIDF(True), False)):
         prep = search.prepare(filters, scorer, [parity.segment_stats(s) for s in segs])
         for k in (10, 300):
-            plain = search.QueryBatch(readers, prep, k)
+            plain = search.QueryBatch(readers, prep, k).set_path(_lib.PATH_JOINED_EXACT)
             ph, pc, pt = plain.run().results()
             shared = search.QueryBatch(readers, prep, k).set_shared_threshold(True)
-            sh, sc, st = shared.run().results()
+            sh, sc, st = shared.set_path(_lib.PATH_JOINED_EXACT).run().results()
             assert shared.reruns() == 0
             assert np.array_equal(pt, st)
             assert np.all(sc <= pc)

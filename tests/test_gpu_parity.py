@@ -404,5 +404,30 @@ def test_rccl_behind_the_c_abi(gpulib):
     comm.all_gather(send.data_ptr(), recv.data_ptr(), send.numel() * 8)
     torch.cuda.synchronize()
     assert torch.equal(send, recv)
+    # ... and irs_hip_batch_set_comm: the batch's two all-reduces (ncclAllReduce inside the run,
+    # between the pilot and the scoring kernels and behind the selection) on a one-rank
+    # communicator leave the result what it is without them
+    import numpy as np
+
+    import parity
+    from iresearch_amd import search, synth
+    from iresearch_amd.search import BM25, Or, by_term
+    segs = [synth.build_segment(n, 256, first_doc=f) for n, f in ((70_000, 0), (30_000, 70_000))]
+    readers = [search.SegmentReader.from_synth(s, L=gpulib) for s in segs]
+    ranks = synth.make_queries(16, 8, 12, 256, synth.SEED + 9)
+    filters = [Or([by_term(int(r) - 1) for r in row]) for row in ranks]
+    prep = search.prepare(filters, BM25(), [parity.segment_stats(s) for s in segs])
+    plain = search.QueryBatch(readers, prep, 300).set_shared_threshold(True)
+    ph, pc, pt = plain.run().results()
+    across = search.QueryBatch(readers, prep, 300).set_comm(comm)
+    ah, ac, at = across.run().results()
+    assert across.reruns() == 0 and np.array_equal(pt, at)
+    assert (search.merge_topk_host([(ph[i], pc[i]) for i in range(2)], 300)
+            == search.merge_topk_host([(ah[i], ac[i]) for i in range(2)], 300))
+    assert int(ac.sum()) < 2 * 16 * 300      # (the two segments shared the work)
+    plain.close()
+    across.close()
+    for r in readers:
+        r.close()
     comm.close()
 
