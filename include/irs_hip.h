@@ -313,13 +313,21 @@ int irs_hip_batch_configure(irs_hip_batch* batch, uint32_t tile_docs,
  *                        shared by the queries of a batch.  Plain disjunctions run in two passes:
  *                        packed 16-bit accumulators over (doc, approximate score) entries find
  *                        the docs that can reach the top k, those are re-scored exactly from
- *                        (doc, tf, norm) entries (fast.h).  For sum-merged units with table-family
- *                        scorers (BM25 / BM15 / TF-IDF over 1-byte norms or none), frequencies
- *                        < 64, no block-max pruning; units that do not qualify run as ITEMS
- *                        whatever was asked;
+ *                        (doc, tf, norm) entries (fast.h; frequencies < 64).  For sum-merged
+ *                        units with table-family scorers (BM25 / BM15 / TF-IDF over 1-byte
+ *                        norms or none), frequencies < 256 — plain
+ *                        disjunctions, and conjunctions / min-match disjunctions of at most 15
+ *                        terms whose counting accumulators stay within the parity tolerance;
+ *                        units that do not qualify run as ITEMS whatever was asked;
  *   IRS_HIP_PATH_JOINED_EXACT  JOINED with the one-pass exact accumulation for plain
- *                        disjunctions as well (round 3's kernel: A/B and parity tests);
- *   IRS_HIP_PATH_AUTO    (default) JOINED where it applies.
+ *                        disjunctions as well (round 3's kernel; what AUTO takes when it joins);
+ *   IRS_HIP_PATH_AUTO    (default) by measured cost: plain disjunctions join when the batch's
+ *                        streams are shared enough or its units many enough to pay for decoding
+ *                        every distinct stream once (2.9 ps per distinct posting against 0.67 ps
+ *                        per referenced posting + 2.4 ns per (unit, doc tile) saved —
+ *                        tools/cost_sweep.py); a conjunction joins when walking every entry of
+ *                        its terms beats decoding only the blocks its rarest term's docs fall
+ *                        into.
  * Call before the batch's first run (or after a configure). */
 enum { IRS_HIP_PATH_AUTO = 0, IRS_HIP_PATH_ITEMS = 1, IRS_HIP_PATH_JOINED = 2,
        IRS_HIP_PATH_JOINED_EXACT = 3 };
@@ -350,8 +358,11 @@ int irs_hip_batch_set_shared_threshold(irs_hip_batch* batch, int enable);
  * (tests/search/wand_test.cpp:231-241); total_hits only counts the docs that were evaluated,
  * as with the reference's wand mode.  The per-block (max freq, min norm) are derived from the
  * postings on first use (every block gets them, also the last one of a list, for which the
- * skip data has no entry) and kept with the segment.  Applies to IRS_HIP_OP_AND queries and
- * to whole doc tiles of OR queries.  Call before the batch's first run. */
+ * skip data has no entry) and kept with the segment.  Applies to IRS_HIP_OP_AND queries on the
+ * block-driven kernel and to whole doc tiles of OR queries on the work-item kernel; a unit the
+ * cost rules put on joined posting streams (irs_hip_batch_set_path) is executed exhaustively —
+ * its top k is the exhaustive one by construction, its total_hits the full count.  Call before
+ * the batch's first run. */
 int irs_hip_batch_set_wand(irs_hip_batch* batch, int enable);
 
 /* irs::score::Min (score_function.hpp:42-142): the threshold the harness pushes into the

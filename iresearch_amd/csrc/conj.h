@@ -455,15 +455,17 @@ k_conj(ConjArgs A, uint32_t pilot) {
     if (tl.nblk) {
       const uint32_t* last = seg.blk_last + tl.dir_off;
       const uint32_t b_first = seek[i - 1u];
-      uint32_t carry = b_first ? last[b_first - 1u] : 0u;   // last doc of the block before
       for (uint32_t b0 = b_first; b0 < tl.nblk; b0 += 64) {
         const uint32_t bl = b0 + lane;
         const bool valid = bl < tl.nblk;
+        // the block's last doc AND its directory record in one round trip (the record also
+        // holds the preceding block's last doc): the kernel is a chain of dependent loads —
+        // fetching the record only for the blocks that turn out to be wanted made it one longer
         const uint32_t lst = valid ? last[bl] : 0xFFFFFFFFu;
+        BlkDir d{};
+        if (valid) d = seg.blk_dir[tl.dir_off + bl];
         // the block holds docs in (prv, lst], prv = the preceding block's lst
-        uint32_t prv = uint32_t(__shfl_up(lst, 1, 64));
-        if (lane == 0) prv = carry;
-        carry = wave::read_lane(lst, 63);
+        const uint32_t prv = bl ? d.prev_last : 0u;
         const bool reach = valid && prv < dhi && lst >= dlo;
         // some doc every earlier term reached lies in a bucket touching (prv, lst]
         bool want = false;
@@ -472,19 +474,46 @@ k_conj(ConjArgs A, uint32_t pilot) {
           const uint32_t x1 = (lst < dhi ? lst : dhi) - dlo;
           want = alive_below((x1 >> s) + 1u) > alive_below(x0 >> s);
         }
-        BlkDir d{};
-        if (want) d = seg.blk_dir[tl.dir_off + bl];
         uint64_t mask = wave::ballot(want);
         const bool more = wave::ballot(valid && prv >= dhi) == 0;  // no block started behind dhi yet
         while (mask) {
           const uint32_t k = uint32_t(__builtin_ctzll(mask));
           mask &= mask - 1;
-          uint32_t d0, d1, f0, f1;
           const uint32_t kbits = wave::read_lane(d.bits, k);
+          if (counting) bytes += block_bytes(kbits);
+          // two wanted blocks at a time where both live in the packed image: their payload
+          // loads are in flight together (one round trip for the pair)
+          if (mask && pk_both(kbits & 0xFFu, kbits >> 8)) {
+            const uint32_t k2 = uint32_t(__builtin_ctzll(mask));
+            const uint32_t kbits2 = wave::read_lane(d.bits, k2);
+            if (pk_both(kbits2 & 0xFFu, kbits2 >> 8)) {
+              mask &= mask - 1;
+              if (counting) bytes += block_bytes(kbits2);
+              const uint8_t* pl1 = seg.pk + (uint64_t(wave::read_lane(d.aoff, k)) << 4);
+              const uint8_t* pl2 = seg.pk + (uint64_t(wave::read_lane(d.aoff, k2)) << 4);
+              uint64_t da1, db1, fa1, fb1, da2, db2, fa2, fb2;
+              raw_load_packed<LAYOUT>(pl1, kbits & 0xFFu, lane, da1, db1);
+              raw_load_packed<LAYOUT>(pl1 + 16u * (kbits & 0xFFu), kbits >> 8, lane, fa1, fb1);
+              raw_load_packed<LAYOUT>(pl2, kbits2 & 0xFFu, lane, da2, db2);
+              raw_load_packed<LAYOUT>(pl2 + 16u * (kbits2 & 0xFFu), kbits2 >> 8, lane, fa2, fb2);
+              uint32_t x0, x1, f0, f1;
+              extract_fast<LAYOUT>(da1, db1, kbits & 0xFFu, lane, x0, x1);
+              extract_fast<LAYOUT>(fa1, fb1, kbits >> 8, lane, f0, f1);
+              uint32_t d1 = wave::read_lane(d.prev_last, k) + wave::inclusive_scan(x0 + x1);
+              put(d1 - x1, f0);
+              put(d1, f1);
+              extract_fast<LAYOUT>(da2, db2, kbits2 & 0xFFu, lane, x0, x1);
+              extract_fast<LAYOUT>(fa2, fb2, kbits2 >> 8, lane, f0, f1);
+              d1 = wave::read_lane(d.prev_last, k2) + wave::inclusive_scan(x0 + x1);
+              put(d1 - x1, f0);
+              put(d1, f1);
+              continue;
+            }
+          }
+          uint32_t d0, d1, f0, f1;
           decode_dir_block<LAYOUT>(seg, tl.doc_start, kbits, wave::read_lane(d.off, k),
                                    wave::read_lane(d.aoff, k), wave::read_lane(d.prev_last, k),
                                    lane, d0, d1, f0, f1);
-          if (counting) bytes += block_bytes(kbits);
           put(d0, f0);
           put(d1, f1);
         }

@@ -4,6 +4,7 @@
 #include "irs_hip.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -239,6 +240,12 @@ struct irs_hip_segment {
   uint64_t total_blocks = 0;
   uint64_t device_bytes = 0;
   uint32_t cus = 1;  // compute units of the device (persistent grid sizing)
+  // Candidate slots per unit that batches on this segment turned out to need (recover_overflow):
+  // scores that tie by the thousand at the threshold bin (TF-IDF without norms: every doc with
+  // the same frequencies) cannot be cut by a bin threshold; later batches start from what the
+  // earlier ones learned instead of overflowing and running twice each.  Decays never; bounded
+  // by default_cand_cap's ceiling.
+  std::atomic<uint32_t> cand_cap_hint{0};
   // block-max data (WAND), built on first use: the one thing that changes after open
   std::mutex wand_mutex;
   bool wand_ready = false;
@@ -316,6 +323,7 @@ struct irs_hip_batch {
   // joined posting streams (join.h): every distinct (segment, term) of the batch decoded once
   // per run.  path_pref: irs_hip_batch_set_path (0 auto, 1 work items, 2 joined streams).
   int path_pref = 0;
+  uint32_t tile_asked = 0;     // irs_hip_batch_configure's tile (0: ensure_scratch picks one per deal)
   bool joined = false;
   DevBuf d_streams, d_join_wgs, d_jterms, d_entries, d_bounds, d_join_args, d_join_units,
     d_join_order;
@@ -502,7 +510,10 @@ static const uint32_t* min_bins(const irs_hip_batch* b) {
 
 static uint32_t default_cand_cap(const irs_hip_batch* b) {
   const uint64_t per_k = b->estimate ? 16ull : 4ull * b->stride_eff;
-  return uint32_t(std::min<uint64_t>(std::max<uint64_t>(per_k * b->k_max, 16384), 262144));
+  uint64_t learned = 0;   // (block-driven units only: tile units cut ties by their per-tile staging)
+  if (b->phrase || !b->all_conj_units.empty())
+    for (const irs_hip_segment* sg : b->segs) learned = std::max<uint64_t>(learned, sg->cand_cap_hint.load());
+  return uint32_t(std::min<uint64_t>(std::max<uint64_t>({per_k * b->k_max, 16384, learned}), 262144));
 }
 
 // launch helpers: one instantiation per (accumulator width, layout, tile, AND)
@@ -870,7 +881,7 @@ int prepare_blockmax(irs_hip_segment* s) {
 // ---- joined posting streams (join.h) ----------------------------------------------------
 // Can the batch's doc-tile units run as joined streams?  (Anything else keeps score.h's work
 // items: per-doc match counters, Max / Min merged scores, scorers outside the table family,
-// 64-bit accumulators, a frequency that does not fit an entry, block-max pruning.)
+// 64-bit accumulators, a frequency that does not fit an entry.)
 bool join_allowed(const irs_hip_batch* b) {   // batch level
   if (b->path_pref == IRS_HIP_PATH_ITEMS) return false;
   if (const char* e = std::getenv("IRS_HIP_JOIN")) {   // tuning / test knob
@@ -878,7 +889,9 @@ bool join_allowed(const irs_hip_batch* b) {   // batch level
         b->path_pref != IRS_HIP_PATH_JOINED_EXACT)
       return false;
   }
-  return !b->phrase && b->acc32 && !b->wand;
+  // (a unit on joined streams runs exhaustively under ExecutionContext::wand: the top k is the
+  // exhaustive one by construction; pruning stays with the block-driven / work-item kernels)
+  return !b->phrase && b->acc32;
 }
 // plain disjunctions of a joined batch in two passes (fast.h)?
 // (Measured, 1000 OR-8 queries on 10 M docs: the two passes take 5.8 + 0.9 ms against the one-pass
@@ -1615,7 +1628,9 @@ bool ensure_scratch(irs_hip_batch* b) {
   // 32-bit accumulators halve the LDS per doc: twice the tile at the same residency
   // the largest tile that still lets two workgroups share a CU's 160 KB of LDS
   // (AND / min-match batches also keep a match counter byte per doc)
-  if (b->tile == 0) b->tile = b->acc32 ? (b->any_and ? 8192 : 12288) : 6144;
+  // (chosen anew on every deal: set_path / set_wand re-deal the units, and `any_and` with them)
+  if (b->tile_asked) b->tile = b->tile_asked;
+  else if (!b->phrase) b->tile = b->acc32 ? (b->any_and ? 8192 : 12288) : 6144;
   // per unit: tiles of its segment, its slice of the plan table and of the per-tile tables;
   // upper bound of its work items: every block once + one more per tile border it may
   // straddle + the decoded tail
@@ -2457,15 +2472,23 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
     }
   }
   // (the block-driven kernels read the norms of a lead block's docs from the posting-order copy)
+  // — a permanent copy per segment, one byte per posting (irs_hip_segment_device_bytes counts
+  // it): built the first time a conjunction / phrase whose scorer reads norms arrives
   if (rc == IRS_HIP_OK && (b->phrase || !b->all_conj_units.empty())) {
+    bool wanted = false;
+    for (const DevQTerm& qt : b->qterms) wanted = wanted || needs_norm(qt.kind);
     for (irs_hip_segment* sg : b->segs)
-      if (rc == IRS_HIP_OK) rc = prepare_posting_norms(sg);
+      if (wanted && rc == IRS_HIP_OK) rc = prepare_posting_norms(sg);
   }
   if (rc == IRS_HIP_OK) {
     if (b->jt == 0) b->jt = 1;
     if (b->qterms.empty()) b->qterms.push_back(DevQTerm{});
     std::vector<DevSegment> dsegs;
-    for (irs_hip_segment* sg : b->segs) dsegs.push_back(sg->dev);
+    for (irs_hip_segment* sg : b->segs) {
+      // (another thread's batch may be adding the lazily built tables to `dev` right now)
+      std::lock_guard<std::mutex> lock(sg->wand_mutex);
+      dsegs.push_back(sg->dev);
+    }
     if (!b->d_queries.alloc(b->queries.size() * sizeof(DevQuery)) ||
         !b->d_qterms.alloc(b->qterms.size() * sizeof(DevQTerm)) ||
         !b->d_segs.alloc(dsegs.size() * sizeof(DevSegment))) {
@@ -2493,7 +2516,7 @@ static int batch_configure_impl(irs_hip_batch* b, uint32_t tile_docs, uint32_t p
   if (cand_cap && cand_cap < b->k_max) return IRS_HIP_EINVAL;
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
   if (b->ran && !rt::sync(b->stream)) return IRS_HIP_EHIP;
-  if (tile_docs && !b->phrase) b->tile = tile_docs;  // phrase tiles are fixed
+  if (!b->phrase) b->tile_asked = b->tile = tile_docs;  // phrase tiles are fixed; 0: by the units' needs
   if (pilot_stride) b->stride = pilot_stride;
   b->cand_cap = cand_cap;
   b->scratch_ready = false;
@@ -2807,6 +2830,23 @@ static int batch_run_impl(irs_hip_batch* b, void* stream) {
 static int recover_overflow(irs_hip_batch* b);
 static int recover(irs_hip_batch* b, uint32_t status) {
   ++b->reruns;
+  if (std::getenv("IRS_HIP_TRACE")) {   // which units made the batch run again
+    std::vector<uint32_t> cc(b->nq), oc(b->nq);
+    std::vector<unsigned long long> hh(b->nq);
+    if (rt::d2h(cc.data(), b->d_cand_count.p, size_t(b->nq) * 4, b->stream) &&
+        rt::d2h(oc.data(), b->d_out_count.p, size_t(b->nq) * 4, b->stream) &&
+        rt::d2h(hh.data(), b->d_hits.p, size_t(b->nq) * 8, b->stream) && rt::sync(b->stream)) {
+      uint32_t under = 0, over = 0, first_u = ~0u, first_o = ~0u;
+      for (uint32_t u = 0; u < b->nq; ++u) {
+        if (cc[u] > b->cand_cap) { ++over; if (first_o == ~0u) first_o = u; }
+        if (oc[u] < b->queries[u].k && hh[u] > oc[u]) { ++under; if (first_u == ~0u) first_u = u; }
+      }
+      std::fprintf(stderr, "[irs_hip] re-run: status %u, %u units short of k (first %u: listed %u of %llu matches, "
+                   "%u candidates), %u over the candidate cap %u (first %u: %u)\n", status, under, first_u,
+                   first_u != ~0u ? oc[first_u] : 0u, first_u != ~0u ? hh[first_u] : 0ull,
+                   first_u != ~0u ? cc[first_u] : 0u, over, b->cand_cap, first_o, first_o != ~0u ? cc[first_o] : 0u);
+    }
+  }
   if (status & kStatusUnderflow) {
     b->estimate = false;
     // the sound threshold admits about k * (pilot stride) candidates per unit: a denser pilot
@@ -2841,6 +2881,12 @@ static int recover_overflow(irs_hip_batch* b) {
       return IRS_HIP_EHIP;
     const uint64_t need = uint64_t(*std::max_element(cc.begin(), cc.end())) + 1024;
     const bool affordable = need * b->nq * sizeof(uint64_t) <= kMaxCandBytes;
+    if (need - 1024 > b->cand_cap && need <= 262144) {
+      for (irs_hip_segment* sg : b->segs) {   // (what later batches on these segments start with)
+        uint32_t seen = sg->cand_cap_hint.load();
+        while (seen < need && !sg->cand_cap_hint.compare_exchange_weak(seen, uint32_t(need))) {}
+      }
+    }
     if (b->comm && need - 1024 <= b->cand_cap) {
       // (the overflow is another rank's: this one only takes part in the re-run's collectives)
     } else if (need > b->cand_cap && affordable) {

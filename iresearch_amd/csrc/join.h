@@ -19,16 +19,19 @@
 // posting is c0 * T[tf][norm] with a table that only depends on the scorer — so a query's
 // posting costs: one coalesced 4-byte load, one table read, one multiply-add, one LDS add.
 //
-// The score arithmetic is score.h's (same tables, same fixed point): results differ from the
-// work-item path by at most one fixed-point unit per posting, where the two classify a
-// posting differently (table row vs. general expression).
+// The score arithmetic is score.h's (same tables, same fixed point, the same classification of a
+// posting into table row / general expression): the hits of plain disjunctions are BIT-IDENTICAL
+// to the work-item path's (tests: case_paths_agree).  Units that count matches in their
+// accumulators' low bits (conjunctions, min-match: COUNT) round every contribution to a multiple
+// of 16 units — within the parity tolerance where they are allowed to join (count_precise).
 //
 // Eligibility (anything else runs on score.h's / conj.h's kernels): sum merge, scorers of the
 // table family over 1-byte norms or none, 32-bit accumulators, every term's frequencies below
 // 256 (the entry's low 16 bits ARE the byte offset of T[tf][norm] for the terms whose frequencies
 // all have table rows — tf < 16, low bits 0; a long document's tf >= 64 continues in the two low
-// bits, which only the general expression reads), no block-max pruning.  Conjunctions and min-match disjunctions of at most 15 terms join
-// too where the rounding of their match-counting accumulators (join_post COUNT) stays below
+// bits, which only the general expression reads).  A batch with ExecutionContext::wand set runs
+// its joined units exhaustively (nothing is pruned here).  Conjunctions and
+// min-match disjunctions of at most 15 terms join too where the rounding of their match-counting accumulators (join_post COUNT) stays below
 // the parity tolerance and — conjunctions — where walking every entry of every term beats
 // decoding only the blocks the rarest term's docs fall into (irs_hip.hip unit_joinable).
 #pragma once

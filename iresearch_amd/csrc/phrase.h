@@ -638,28 +638,25 @@ k_phrase(ConjArgs A, uint32_t pilot /*1: histogram the scores of the sampled lea
       const uint32_t* last = seg.blk_last + tl.dir_off;
       const uint32_t pos0 = seg.blk_pos[tl.dir_off];
       const uint32_t b_first = seek[i < lead ? i : i - 1u];
-      uint32_t carry = b_first ? last[b_first - 1u] : 0u;   // last doc of the block before
       for (uint32_t b0 = b_first; b0 < tl.nblk; b0 += 64) {
         const uint32_t bl = b0 + lane;
         const bool valid = bl < tl.nblk;
+        // the block's last doc, its directory record (which also holds the preceding block's
+        // last doc) and its first position number in ONE round trip (conj.h)
         const uint32_t lst = valid ? last[bl] : 0xFFFFFFFFu;
-        uint32_t prv = uint32_t(__shfl_up(lst, 1, 64));   // the block holds docs in (prv, lst]
-        if (lane == 0) prv = carry;
-        carry = wave::read_lane(lst, 63);
+        BlkDir d{};
+        uint32_t pos_l = 0;
+        if (valid) {
+          d = seg.blk_dir[tl.dir_off + bl];
+          pos_l = seg.blk_pos[tl.dir_off + bl];
+        }
+        const uint32_t prv = bl ? d.prev_last : 0u;   // the block holds docs in (prv, lst]
         const bool reach = valid && prv < dhi && lst >= dlo;
         bool want = false;
         if (reach) {
           const uint32_t x0 = prv + 1u > dlo ? prv + 1u - dlo : 0u;
           const uint32_t x1 = (lst < dhi ? lst : dhi) - dlo;
           want = alive_below((x1 >> s) + 1u) > alive_below(x0 >> s);
-        }
-        // the directory words of the wanted blocks, one lane each, handed to the whole
-        // wavefront by readlane when the block's turn comes
-        BlkDir d{};
-        uint32_t pos_l = 0;
-        if (want) {
-          d = seg.blk_dir[tl.dir_off + bl];
-          pos_l = seg.blk_pos[tl.dir_off + bl];
         }
         uint64_t mask = wave::ballot(want);
         const bool more = wave::ballot(valid && prv >= dhi) == 0;  // no block started behind dhi yet
@@ -671,6 +668,41 @@ k_phrase(ConjArgs A, uint32_t pilot /*1: histogram the scores of the sampled lea
           const uint32_t base = wave::read_lane(d.prev_last, k);
           uint32_t d0, d1, f0, f1, before;
           const uint32_t dbits = bits & 0xFFu, fbits = bits >> 8;
+          // two wanted blocks at a time where both live in the packed image: their payload
+          // loads are in flight together
+          if (mask && pk_both(dbits, fbits)) {
+            const uint32_t k2 = uint32_t(__builtin_ctzll(mask));
+            const uint32_t bits2 = wave::read_lane(d.bits, k2);
+            if (pk_both(bits2 & 0xFFu, bits2 >> 8)) {
+              mask &= mask - 1;
+              if (counting) bytes += block_bytes(bits2);
+              const uint8_t* pl1 = seg.pk + (uint64_t(wave::read_lane(d.aoff, k)) << 4);
+              const uint8_t* pl2 = seg.pk + (uint64_t(wave::read_lane(d.aoff, k2)) << 4);
+              uint64_t da1, db1, fa1, fb1, da2, db2, fa2, fb2;
+              raw_load_packed<LAYOUT>(pl1, dbits, lane, da1, db1);
+              raw_load_packed<LAYOUT>(pl1 + 16u * dbits, fbits, lane, fa1, fb1);
+              raw_load_packed<LAYOUT>(pl2, bits2 & 0xFFu, lane, da2, db2);
+              raw_load_packed<LAYOUT>(pl2 + 16u * (bits2 & 0xFFu), bits2 >> 8, lane, fa2, fb2);
+              uint32_t x0, x1;
+              extract_fast<LAYOUT>(da1, db1, dbits, lane, x0, x1);
+              extract_fast<LAYOUT>(fa1, fb1, fbits, lane, f0, f1);
+              uint32_t dsum = x0 + x1, fsum = f0 + f1;
+              wave::inclusive_scan2(dsum, fsum);
+              uint32_t p0 = wave::read_lane(pos_l, k) - pos0 + (fsum - f0 - f1);
+              put(base + dsum - x1, f0, p0);
+              put(base + dsum, f1, p0 + f0);
+              extract_fast<LAYOUT>(da2, db2, bits2 & 0xFFu, lane, x0, x1);
+              extract_fast<LAYOUT>(fa2, fb2, bits2 >> 8, lane, f0, f1);
+              dsum = x0 + x1;
+              fsum = f0 + f1;
+              wave::inclusive_scan2(dsum, fsum);
+              const uint32_t base2 = wave::read_lane(d.prev_last, k2);
+              p0 = wave::read_lane(pos_l, k2) - pos0 + (fsum - f0 - f1);
+              put(base2 + dsum - x1, f0, p0);
+              put(base2 + dsum, f1, p0 + f0);
+              continue;
+            }
+          }
           if (pk_both(dbits, fbits)) {
             // both parts 1..31-bit packed: the 16-byte aligned copy in the packed image,
             // one funnel shift + one bit-field extract per value (as k_score's hot loop)

@@ -720,7 +720,7 @@ __device__ __forceinline__ float score_value(const DevQTerm& qt, uint32_t freq, 
     }
   }
 }
-__device__ __forceinline__ bool needs_norm(int32_t kind) {
+__host__ __device__ __forceinline__ bool needs_norm(int32_t kind) {
   return kind == kBM25Tiny || kind == kBM25Wide || kind == kTfidfTiny || kind == kTfidfWide ||
          kind == kBM25Legacy || kind == kTfidfLegacy;
 }

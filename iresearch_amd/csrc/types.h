@@ -11,8 +11,8 @@ constexpr uint32_t kMaxTerms = 16;     // IRS_HIP_MAX_TERMS
 constexpr uint32_t kMaxK = 4096;       // IRS_HIP_MAX_K
 constexpr uint32_t kBins = 512;        // score histogram bins (pilot threshold)
 constexpr uint32_t kMaxCaches = 4;     // distinct (norm_const, norm_length) per query in LDS
-constexpr uint32_t kPadBytes = 64;
-constexpr uint64_t kNoPlan = ~uint64_t(0);  // DevQuery::first_off of a unit without plan tables     // zero padding after the staged `.doc` bytes
+constexpr uint32_t kPadBytes = 64;      // zero padding after the staged `.doc` / `.pos` bytes
+constexpr uint64_t kNoPlan = ~uint64_t(0);  // DevQuery::first_off of a unit without plan tables
 
 enum Layout : int32_t { kScalar = 0, kSimd4 = 1 };
 

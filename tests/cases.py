@@ -58,19 +58,22 @@ def case_wand_equals_exhaustive(L, num_docs=60_000, max_rank=256, layout=synth.L
         for scorer in scorers:
             prep = search.prepare(filters, scorer, stats)
             for k in ks:
-                # (block-max pruning runs on the work-item path: like with like, bit for bit)
-                ex = sr.batch(prep, k).set_path(_lib.PATH_ITEMS)
-                h0, c0, t0 = ex.run().results()
-                ex.close()
-                wb = sr.batch(prep, k).set_wand(True)
-                h1, c1, t1 = wb.run().results()
-                wb.close()
-                assert np.array_equal(c0, c1), (clustered, type(scorer).__name__, k)
-                for q in range(len(filters)):
-                    n = int(c0[q])
-                    assert np.array_equal(h0[q, :n], h1[q, :n]), (clustered, q, k)
-                assert (t1 <= t0).all()
-                pruned += int((t0 - t1).sum())
+                # like with like, bit for bit: the work-item / block-driven kernels (where the
+                # pruning happens), and whatever the cost rules deal the units to (a unit on
+                # joined streams runs exhaustively with or without the option)
+                for path in (_lib.PATH_ITEMS, _lib.PATH_AUTO):
+                    ex = sr.batch(prep, k).set_path(path)
+                    h0, c0, t0 = ex.run().results()
+                    ex.close()
+                    wb = sr.batch(prep, k).set_path(path).set_wand(True)
+                    h1, c1, t1 = wb.run().results()
+                    wb.close()
+                    assert np.array_equal(c0, c1), (clustered, type(scorer).__name__, k)
+                    for q in range(len(filters)):
+                        n = int(c0[q])
+                        assert np.array_equal(h0[q, :n], h1[q, :n]), (clustered, q, k, path)
+                    assert (t1 <= t0).all()
+                    pruned += int((t0 - t1).sum())
             # and the exhaustive run is the oracle's
             parity.check_single_segment(seg, filters, scorer, ks[-1], h0, c0, t0)
         sr.close()
@@ -1499,12 +1502,20 @@ def case_phrase_ragged(L, layout=synth.LAYOUT_SIMD4, one_based=False):
     dd = np.array([7, 2048, 2049, 8999], np.uint32)
     x = (dd, np.full(4, 200, np.uint32), np.tile(np.arange(1, 401, 2, dtype=np.uint32), 4))
     y = (dd, np.full(4, 200, np.uint32), np.tile(np.arange(2, 402, 2, dtype=np.uint32), 4))
-    lists = [a, b, c, one, x, y]
+    # ... and docs in which they occur 500 / 150 times: more positions than the wavefront's merge
+    # stages at once (384 of the first term: one lane walks that doc; 3 x 150: two passes)
+    dz = np.array([100, 101, 102, 103, 5000], np.uint32)
+    fz = np.array([150, 150, 150, 500, 500], np.uint32)
+    z = (dz, fz, np.concatenate([np.arange(1, 2 * n, 2, dtype=np.uint32) for n in fz]))
+    w = (dz, fz, np.concatenate([np.arange(2, 2 * n + 1, 2, dtype=np.uint32) for n in fz]))
+    lists = [a, b, c, one, x, y, z, w]
     seg = synth.segment_from_lists(lists, N, layout, norms=np.full(N, 255, np.uint8),
                                    one_based=one_based)
     phrases = [by_phrase([0, 1]), by_phrase([1, 0]), by_phrase([0, 2]), by_phrase([2, 1, 0]),
                by_phrase([3, 3]), by_phrase([0, 3]), by_phrase([4, 5]), by_phrase([5, 4]),
-               by_phrase([4, 5, 4]), by_phrase([4, 4], [0, 2]), by_phrase([3, 4], [0, 2])]
+               by_phrase([4, 5, 4]), by_phrase([4, 4], [0, 2]), by_phrase([3, 4], [0, 2]),
+               by_phrase([6, 7]), by_phrase([7, 6]), by_phrase([6, 7, 6]), by_phrase([6, 6], [0, 2]),
+               by_phrase([4, 7])]
     for scorer in (BM25(), TFIDF(True)):
         for k in (3, 100):
             run_phrases(L, seg, phrases, scorer, k)

@@ -24,7 +24,8 @@ def main():
                 table[k][c] = sum(v.get(c, 0.0) for v in vs) / len(vs)
     for k in sorted(table, key=lambda k: -table[k].get("SQ_BUSY_CYCLES", table[k].get("SQ_WAVES", 0))):
         if not (k.startswith("k_join") or k.startswith("k_score") or k.startswith("k_select")
-                or k.startswith("k_items") or k.startswith("k_pilot") or k.startswith("k_plan")):
+                or k.startswith("k_items") or k.startswith("k_pilot") or k.startswith("k_plan")
+                or k.startswith("k_conj") or k.startswith("k_phrase") or k.startswith("k_fast")):
             continue
         print("== %s" % k)
         for c in sorted(table[k]):
