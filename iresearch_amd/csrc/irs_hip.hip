@@ -2157,6 +2157,8 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
     b->qterms.reserve(size_t(n_entries) * n_segs);
     std::vector<int> exps;
     exps.reserve(nq);
+    std::vector<DevQTerm> row;
+    std::vector<double> smins;
     for (uint32_t q = 0; q < nq && rc == IRS_HIP_OK; ++q) {
       // unit q = (segment q / nq_user, query q % nq_user); the segment's own term entries
       irs_hip_segment* seg = segs[q / nq_user];
@@ -2187,10 +2189,10 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
           break;
         }
       }
-      std::vector<DevQTerm> row;
+      row.clear();     // (one allocation for the whole batch: 8000 units otherwise pay 16000)
+      smins.clear();   // per present term: the smallest score of one posting
       bool absent = false, same_bound = true;
       double upper = 0.0, min_score = 1e300, upper_all = 0.0;
-      std::vector<double> smins;   // per present term: the smallest score of one posting
       for (uint32_t j = 0; j < in.n_terms; ++j) {
         const irs_hip_term_scorer& ts = terms[in.first_term + j];
         DevQTerm qt{};

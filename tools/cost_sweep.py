@@ -30,6 +30,17 @@ def distinct_queries(n_queries, n_terms, lo, hi, seed):
     return picked.reshape(n_queries, n_terms).astype(np.uint32)
 
 
+def max_tf(seg, lo_rank):
+    """largest frequency among the postings of rank lo_rank (decoded by the test oracle)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        import oracle
+        _, f = oracle.decode_term(seg.doc_file, seg.metas[lo_rank - 1], seg.layout)
+        return int(f.max())
+    except Exception:  # noqa: BLE001
+        return -1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--docs", type=int, default=10_000_000)
@@ -38,6 +49,9 @@ def main():
     ap.add_argument("--shapes", default="1000x4d,128x8d,16x8d,1000x8s,128x8s,16x8s")
     ap.add_argument("--scorer", default="bm25", choices=["bm25", "tfidf"])
     ap.add_argument("--mean-len", type=int, default=0, help="0: the bench corpus (100)")
+    ap.add_argument("--lo-rank", type=int, default=16,
+                    help="most frequent rank the queries draw from (1: with --mean-len 1000 the top "
+                         "terms' frequencies pass 64 — entries with the two low tf bits in use)")
     args = ap.parse_args()
     import torch  # noqa: F401  (one HIP runtime per process)
 
@@ -47,7 +61,8 @@ def main():
     kw = dict(mean_len=args.mean_len, stddev_len=args.mean_len // 3) if args.mean_len else {}
     seg = synth.build_segment(args.docs, 4096, **kw)
     sr = search.SegmentReader.from_synth(seg)
-    print("index built in %.1f s" % (time.perf_counter() - t0), flush=True)
+    print("index built in %.1f s; largest frequency of a queried term: %d" % (
+        time.perf_counter() - t0, max_tf(seg, args.lo_rank)), flush=True)
     df = np.asarray(seg.metas["docs_count"]).astype(np.int64)
     scorer = BM25() if args.scorer == "bm25" else TFIDF(True)
     st = search.SegmentStats(seg.docs_with_field, seg.total_term_freq, df)
@@ -56,9 +71,9 @@ def main():
         q, rest = shape.split("x")
         nq, nt, kind = int(q), int(rest[:-1]), rest[-1]
         if kind == "d":
-            ranks = distinct_queries(nq, nt, 16, 4096, 7)
+            ranks = distinct_queries(nq, nt, args.lo_rank, 4096, 7)
         else:
-            ranks = synth.make_queries(nq, nt, 16, 4096, synth.SEED + 2)
+            ranks = synth.make_queries(nq, nt, args.lo_rank, 4096, synth.SEED + 2)
         rows = ranks.astype(np.int64) - 1
         refs = int(df[rows].sum())
         distinct = int(df[np.unique(rows)].sum())
