@@ -72,6 +72,8 @@ inline bool dmemset(void* d, int v, size_t n, stream_t s) {
   return n == 0 || ok(hipMemsetAsync(d, v, n, s));
 }
 inline bool sync(stream_t s) { return ok(hipStreamSynchronize(s)); }
+// a stream that does not synchronise with the null stream (copies that overlap other streams' kernels)
+inline bool stream_create(stream_t* s) { return ok(hipStreamCreateWithFlags(s, hipStreamNonBlocking)); }
 inline bool last_error_ok() { return ok(hipGetLastError()); }
 
 // Dynamic LDS beyond the default limit needs an explicit opt-in per kernel.

@@ -179,6 +179,22 @@ struct Stager {
   }
 };
 
+// One copy stream per device for the tables of a batch's FIRST run: queued on the caller's stream
+// they would start only when the previous batch's kernels are through (0.2 ms of idle compute per
+// step for the headline batch's 5 MB); on their own stream they travel while those kernels run,
+// and the run waits for them by an event.
+rt::stream_t upload_stream(int device) {
+  static std::mutex m;
+  static std::map<int, rt::stream_t> streams;
+  std::lock_guard<std::mutex> lock(m);
+  auto it = streams.find(device);
+  if (it != streams.end()) return it->second;
+  rt::stream_t s = nullptr;
+  if (!rt::stream_create(&s)) s = nullptr;   // (null: the caller keeps its own stream)
+  streams[device] = s;
+  return s;
+}
+
 // IRS_HIP_TRACE=1: host-side stage times on stderr (what a batch costs before its first kernel)
 struct HostTrace {
   const char* what;
@@ -381,6 +397,8 @@ struct irs_hip_batch {
   // waits for it and for ev_done — never for the stream, which may hold other batches' work)
   rt::event_t ev_used{};
   bool ev_used_ready = false, ev_used_pending = false;
+  rt::event_t ev_up{};         // the first run's table uploads (the device's copy stream)
+  bool ev_up_ready = false;
 };
 
 namespace {
@@ -2732,8 +2750,17 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st) {
   b->stream = st;
   const bool simd = b->seg->dev.layout == kSimd4;
   auto mark = [&](int i) { return !b->profile || rt::event_record(b->ev[i], st); };
-  // the batch's tables (built in page-locked memory since create) go out on this stream
-  bool ok = b->up.flush(st);
+  // the batch's tables (built in page-locked memory since create) go out: before the batch's
+  // first run on the device's copy stream (nothing on the GPU reads or writes these buffers yet),
+  // afterwards in the run's own stream order (a running kernel may still read what they replace)
+  bool ok = true;
+  rt::stream_t up_st = (!b->ran && !b->up.pending.empty()) ? upload_stream(b->seg->device) : nullptr;
+  if (up_st) {
+    if (!b->ev_up_ready) ok = b->ev_up_ready = rt::event_create(&b->ev_up);
+    ok = ok && b->up.flush(up_st) && rt::event_record(b->ev_up, up_st) && rt::stream_wait(st, b->ev_up);
+  } else {
+    ok = b->up.flush(st);
+  }
   if (ok && b->joined && !b->slack_zeroed) {
     // (the slack behind the last stream is only ever read by masked-off look-ahead: zero it once)
     ok = rt::dmemset(b->d_entries.as<uint32_t>() + b->join_entries, 0, kJoinSlack * 4, st);
@@ -3028,6 +3055,7 @@ void irs_hip_batch_destroy(irs_hip_batch* b) {
   if (b->ev_done_ready) rt::event_destroy(b->ev_done);
   if (b->ev_planned_ready) rt::event_destroy(b->ev_planned);
   if (b->ev_used_ready) rt::event_destroy(b->ev_used);
+  if (b->ev_up_ready) rt::event_destroy(b->ev_up);
   delete b;
 }
 

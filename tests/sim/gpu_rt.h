@@ -62,6 +62,7 @@ inline bool dmemset(void* d, int v, size_t n, stream_t) {
   return true;
 }
 inline bool sync(stream_t) { return true; }
+inline bool stream_create(stream_t* s) { *s = nullptr; return true; }
 inline bool last_error_ok() { return true; }
 inline bool allow_dynamic_smem(const void*, size_t bytes) { return bytes <= sim::kMaxSmem; }
 
