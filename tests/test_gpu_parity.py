@@ -417,9 +417,11 @@ def test_rccl_behind_the_c_abi(gpulib):
     ranks = synth.make_queries(16, 8, 12, 256, synth.SEED + 9)
     filters = [Or([by_term(int(r) - 1) for r in row]) for row in ranks]
     prep = search.prepare(filters, BM25(), [parity.segment_stats(s) for s in segs])
-    plain = search.QueryBatch(readers, prep, 300).set_shared_threshold(True)
+    from iresearch_amd import _lib
+    # (joined streams, whatever the cost rule makes of this small batch: groups need them)
+    plain = search.QueryBatch(readers, prep, 300).set_shared_threshold(True).set_path(_lib.PATH_JOINED_EXACT)
     ph, pc, pt = plain.run().results()
-    across = search.QueryBatch(readers, prep, 300).set_comm(comm)
+    across = search.QueryBatch(readers, prep, 300).set_comm(comm).set_path(_lib.PATH_JOINED_EXACT)
     ah, ac, at = across.run().results()
     assert across.reruns() == 0 and np.array_equal(pt, at)
     assert (search.merge_topk_host([(ph[i], pc[i]) for i in range(2)], 300)
