@@ -9,7 +9,7 @@ echo "== tools/cost_sweep.py (plain disjunctions: work items / joined / what PAT
 timeout 900 python tools/cost_sweep.py --docs 10000000 --shapes 1000x4d,128x8d,16x8d,1000x1d,128x1d,16x1d,1000x8s,128x8s,16x8s 2>&1 | grep -v amdgpu >> $O
 echo "== tools/cost_sweep.py --docs 2000000 --mean-len 1000 (1000-word docs)" >> $O
 timeout 600 python tools/cost_sweep.py --docs 2000000 --mean-len 1000 --shapes 1000x8s,128x8d 2>&1 | grep -v amdgpu >> $O
-echo "== tools/cost_sweep.py --docs 2000000 --mean-len 1000 --lo-rank 1 (frequencies of 64 and more: entries with the two low tf bits)" >> $O
+echo "== tools/cost_sweep.py --docs 2000000 --mean-len 1000 --lo-rank 1   (queries that draw the most frequent terms: a term in EVERY doc has idf -> 0, the batch leaves the 32-bit accumulators and with them the joined path, whatever its frequencies; tf >= 64 on joined streams is pinned by case_join_edge_blocks)" >> $O
 timeout 600 python tools/cost_sweep.py --docs 2000000 --mean-len 1000 --lo-rank 1 --shapes 1000x8s 2>&1 | grep -v amdgpu >> $O
 echo "== tools/join_tune.py --runs base:items,base:exact,base:1024   (work items / one-pass joined / two-pass joined, fast.h)" >> $O
 timeout 600 python tools/join_tune.py --runs base:items,base:exact,base:1024 2>&1 | grep -E "path" >> $O
