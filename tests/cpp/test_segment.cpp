@@ -348,6 +348,66 @@ int main(int argc, char** argv) {
     }
     REQUIRE(threw);
   }
+  // ... and damage that the checksum does NOT catch (a writer bug, a forged file: the footer's CRC
+  // recomputed over the damaged bytes): the readers either make sense of the bytes or refuse them
+  // (index_error / not_supported) — they never read outside the buffer (tools/asan_emulator.sh
+  // runs this binary's cases under AddressSanitizer)
+  {
+    auto reseal = [](std::vector<uint8_t>& f) {
+      const uint32_t crc = format10::crc32c(f.data(), f.size() - 8);
+      for (int i = 0; i < 4; ++i) f[f.size() - 8 + i] = 0;
+      for (int i = 0; i < 4; ++i) f[f.size() - 4 + i] = uint8_t(crc >> (24 - 8 * i));
+    };
+    uint64_t state = 0x9E3779B97F4A7C15ull;
+    auto next = [&]() { state ^= state << 13; state ^= state >> 7; state ^= state << 17; return state; };
+    uint32_t refused = 0, read = 0;
+    const int kDamageRounds = argc > 2 ? std::atoi(argv[2]) : 60;
+    for (int round = 0; round < kDamageRounds; ++round) {
+      std::vector<uint8_t> bad(ti.begin(), ti.begin() + ti_len);
+      const size_t at = 40 + next() % (bad.size() - 40 - 16);   // (behind the header, in front of the footer)
+      bad[at] = uint8_t(next());
+      if (round & 1) bad[40 + next() % (bad.size() - 56)] ^= uint8_t(1u << (next() & 7));
+      reseal(bad);
+      try {
+        const format10::TermIndex t = format10::read_term_index(bad.data(), bad.size());
+        for (const format10::FieldRecord& r : t.fields) {
+          try {   // a root that points anywhere: the walk must stay inside `.tm`
+            (void)format10::walk_field(tm.data(), tm_len, r.root_start, r.has_freq(), r.has_pos(), r.has_offs_or_pay());
+          } catch (const error&) {
+          }
+        }
+        ++read;
+      } catch (const error&) {
+        ++refused;
+      }
+    }
+    for (int round = 0; round < kDamageRounds; ++round) {
+      std::vector<uint8_t> bad(sm.begin(), sm.begin() + sm_len);
+      bad[30 + next() % (bad.size() - 30 - 16)] = uint8_t(next());
+      reseal(bad);
+      try {
+        (void)format10::read_segment_meta(bad.data(), bad.size());
+        ++read;
+      } catch (const error&) {
+        ++refused;
+      }
+    }
+    for (int round = 0; round < kDamageRounds / 2; ++round) {   // the dictionary itself, walked from the true roots
+      std::vector<uint8_t> bad(tm.begin(), tm.begin() + tm_len);
+      bad[40 + next() % (bad.size() - 56)] = uint8_t(next());
+      reseal(bad);
+      for (uint32_t f = 0; f < 3; ++f) {
+        try {
+          (void)format10::walk_field(bad.data(), bad.size(), orec[f].root_start, wants[f].has_freq, wants[f].has_pos, false);
+          ++read;
+        } catch (const error&) {
+          ++refused;
+        }
+      }
+    }
+    REQUIRE(refused > 0 && read > 0);
+    std::printf("damaged files with a valid checksum: %u refused, %u read\n", refused, read);
+  }
   irs_synth_free(body.idx);
   irs_synth_free(title.idx);
   std::printf("test_segment OK: %u docs, fields body (%zu terms) / tags (%zu) / title (%zu) from file bytes\n", docs,

@@ -51,3 +51,25 @@ cases.case_shared_threshold(L, sizes=(30_000, 13_000, 40_000), max_rank=128)
 cases.case_shared_threshold_misled(L)
 print("asan emulator run: clean")
 PY
+# ... and the C++ host readers (header only: instrumented with the test binary) over a segment of
+# three fields incl. damaged `.ti` / `.sm` / `.tm` files whose checksums were recomputed
+python - <<'PY'
+import subprocess, sys
+sys.path.insert(0, ".")
+import oracle
+from iresearch_amd import _build
+synth, orc = _build.build_synth(), oracle.build()
+sim = "tests/sim/libirs_hip_sim.so"
+exe = "/tmp/test_segment_asan"
+subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address", "-fno-omit-frame-pointer",
+                "-ffp-contract=off", "-I", "include", "-I", "iresearch_amd/cpp", "-I", "iresearch_amd/index",
+                "-I", "oracle", "tests/cpp/test_segment.cpp", "-o", exe, sim, str(synth), str(orc), "-pthread",
+                "-Wl,-rpath," + str(__import__("pathlib").Path(sim).resolve().parent),
+                "-Wl,-rpath," + str(__import__("pathlib").Path(str(synth)).resolve().parent),
+                "-Wl,-rpath," + str(__import__("pathlib").Path(str(orc)).resolve().parent)], check=True)
+out = subprocess.run([exe, "20000", "600"], capture_output=True, text=True,
+                     env={"ASAN_OPTIONS": "detect_leaks=0", "PATH": "/usr/bin:/bin"})
+assert out.returncode == 0, out.stderr[-3000:]
+print(out.stdout.strip().splitlines()[-2])
+print("asan host readers: clean")
+PY
