@@ -99,8 +99,15 @@ def main():
             parity.check_single_segment(seg, filters, scorer, k, ih, ic, it)
             assert np.array_equal(ic, counts) and np.array_equal(it, totals), "paths: counts"
             ib.close()
-            # block-max pruning (runs on that path): the same top-k, bit for bit
-            wb = sr.batch(prep, k).set_wand(True)
+            # joined streams wherever a unit is eligible, plain disjunctions in two passes (fast.h:
+            # packed 16-bit first pass + exact re-score) — against the oracle, counts as before
+            jb = sr.batch(prep, k).set_path(_lib.PATH_JOINED)
+            jh, jc, jt = (x.copy() for x in jb.run().results())
+            parity.check_single_segment(seg, filters, scorer, k, jh, jc, jt)
+            assert np.array_equal(jc, counts) and np.array_equal(jt, totals), "joined: counts"
+            jb.close()
+            # block-max pruning (on the work-item / block-driven kernels): the same top-k, bit for bit
+            wb = sr.batch(prep, k).set_path(_lib.PATH_ITEMS).set_wand(True)
             wh, wc, wt = wb.run().results()
             assert np.array_equal(ic, wc), "wand: counts"
             for q in range(len(filters)):
