@@ -1260,6 +1260,77 @@ inline irs_hip_segment_desc describe_field(const FieldFiles& f, int32_t device, 
 
 }  // namespace format10
 
+// ---- multi-term expansion filters without scorers ------------------------------
+// by_prefix / by_range / by_terms with an EMPTY order: every term the filter visits is an
+// "unscored" one and the segment's iterator is lazy_bitset_iterator — one postings_reader::bit_union
+// over the visited terms' cookies (multiterm_query.cpp:64-101, 162-167; prefix_filter.cpp:37-60;
+// range_filter.cpp:62-108).  Here the visit is a range of ordinals of the field's sorted term
+// table (OpenedField::terms: what term_reader::iterator() enumerates) and the union is
+// irs_hip_bit_union on the device.
+enum class BoundType { UNBOUNDED, INCLUSIVE, EXCLUSIVE };   // search/search_range.hpp
+struct by_prefix { std::string prefix; };
+struct by_range {
+  std::string min, max;
+  BoundType min_type = BoundType::UNBOUNDED, max_type = BoundType::UNBOUNDED;
+};
+struct by_terms { std::vector<std::string> terms; };
+
+// the ordinals a filter visits in a field's term table (ascending byte order)
+inline std::vector<uint32_t> visit(const std::vector<std::string>& terms, const by_prefix& f) {
+  std::vector<uint32_t> out;   // seek_ge(prefix), then while the term starts with it (prefix_filter.cpp:44-58)
+  auto it = std::lower_bound(terms.begin(), terms.end(), f.prefix);
+  for (; it != terms.end() && it->compare(0, f.prefix.size(), f.prefix) == 0; ++it)
+    out.push_back(uint32_t(it - terms.begin()));
+  return out;
+}
+inline std::vector<uint32_t> visit(const std::vector<std::string>& terms, const by_range& f) {
+  std::vector<uint32_t> out;
+  if (f.min_type != BoundType::UNBOUNDED && f.max_type != BoundType::UNBOUNDED && f.min == f.max &&
+      !(f.min_type == BoundType::INCLUSIVE && f.max_type == BoundType::INCLUSIVE))
+    return out;   // "can't satisfy condition" (range_filter.cpp:122-131)
+  auto it = terms.begin();
+  if (f.min_type == BoundType::INCLUSIVE) it = std::lower_bound(terms.begin(), terms.end(), f.min);
+  else if (f.min_type == BoundType::EXCLUSIVE) it = std::upper_bound(terms.begin(), terms.end(), f.min);
+  for (; it != terms.end(); ++it) {
+    if (f.max_type == BoundType::INCLUSIVE && !(*it <= f.max)) break;
+    if (f.max_type == BoundType::EXCLUSIVE && !(*it < f.max)) break;
+    out.push_back(uint32_t(it - terms.begin()));
+  }
+  return out;
+}
+inline std::vector<uint32_t> visit(const std::vector<std::string>& terms, const by_terms& f) {
+  std::vector<uint32_t> out;   // terms the segment does not hold are skipped (terms_filter.cpp: seek fails)
+  for (const std::string& t : f.terms) {
+    const auto it = std::lower_bound(terms.begin(), terms.end(), t);
+    if (it != terms.end() && *it == t) out.push_back(uint32_t(it - terms.begin()));
+  }
+  std::sort(out.begin(), out.end());
+  out.erase(std::unique(out.begin(), out.end()), out.end());
+  return out;
+}
+
+// The docs of a segment a filter without scorers accepts: bit `doc` of `words` (bit 0 —
+// doc_limits::invalid() — never set), as lazy_bitset_iterator::refill leaves them.
+struct DocSet {
+  std::vector<uint64_t> words;
+  uint64_t postings = 0;   // bit_union's return value: the sum of the visited terms' docs_count
+  bool contains(uint32_t doc) const { return doc / 64 < words.size() && ((words[doc / 64] >> (doc % 64)) & 1u); }
+  uint64_t count() const {
+    uint64_t n = 0;
+    for (uint64_t w : words) n += uint64_t(__builtin_popcountll(w));
+    return n;
+  }
+};
+template<typename Filter>
+DocSet execute_unscored(const SegmentReader& segment, const std::vector<std::string>& field_terms,
+                        uint32_t num_docs, const Filter& flt) {
+  DocSet out;
+  out.words.assign((uint64_t(num_docs) + 1 + 63) / 64, 0);   // docs_count + doc_limits::min() bits
+  const std::vector<uint32_t> ordinals = visit(field_terms, flt);
+  if (!ordinals.empty()) out.postings = segment.bit_union(ordinals, out.words);
+  return out;
+}
+
 // ---- several GPUs: one process per GPU, segments sharded, ONE all-gather per batch -----------
 // (what the harness loop over `reader`'s segments becomes when the segments
 // live on different devices)

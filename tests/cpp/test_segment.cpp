@@ -290,6 +290,49 @@ int main(int argc, char** argv) {
     REQUIRE(set == want);
   }
 
+  // ---- multi-term expansion filters without scorers (by_prefix / by_range / by_terms -> one
+  // bit_union over the visited terms, multiterm_query.cpp:64-101) against the oracle's bit_union
+  {
+    auto expect = [&](const format10::OpenedField& of, bool has_freq, const std::vector<uint32_t>& ords,
+                      const DocSet& got) -> bool {
+      std::vector<orc_term_meta> om(ords.size());
+      for (size_t i = 0; i < ords.size(); ++i) std::memcpy(&om[i], &of.metas[ords[i]], sizeof(orc_term_meta));
+      std::vector<uint64_t> want(got.words.size(), 0);
+      const int64_t sum = om.empty() ? 0
+                          : orc_bit_union(doc_file.data(), uint64_t(doc_file_len), ORC_LAYOUT_SIMD4, has_freq ? 1 : 0,
+                                          om.data(), uint32_t(om.size()), want.data(), want.size());
+      return sum >= 0 && uint64_t(sum) == got.postings && want == got.words && !got.contains(0);
+    };
+    SegmentReader tags(descs[1]), bodyr(descs[0]);
+    const auto& tt = opened[1].terms;   // tag0 .. tag4
+    REQUIRE((visit(tt, by_prefix{"tag"}) == std::vector<uint32_t>{0, 1, 2, 3, 4}));
+    REQUIRE((visit(tt, by_prefix{"tag3"}) == std::vector<uint32_t>{3}) && visit(tt, by_prefix{"tah"}).empty());
+    REQUIRE((visit(tt, by_range{"tag1", "tag3", BoundType::INCLUSIVE, BoundType::EXCLUSIVE}) == std::vector<uint32_t>{1, 2}));
+    REQUIRE((visit(tt, by_range{"tag1", "tag3", BoundType::EXCLUSIVE, BoundType::INCLUSIVE}) == std::vector<uint32_t>{2, 3}));
+    REQUIRE((visit(tt, by_range{"tag3", "", BoundType::INCLUSIVE, BoundType::UNBOUNDED}) == std::vector<uint32_t>{3, 4}));
+    REQUIRE(visit(tt, by_range{"tag2", "tag2", BoundType::INCLUSIVE, BoundType::EXCLUSIVE}).empty());
+    REQUIRE((visit(tt, by_range{"tag2", "tag2", BoundType::INCLUSIVE, BoundType::INCLUSIVE}) == std::vector<uint32_t>{2}));
+    REQUIRE((visit(tt, by_terms{{"tag4", "nope", "tag0", "tag4"}}) == std::vector<uint32_t>{0, 4}));
+    for (const auto& ords : {visit(tt, by_prefix{"tag"}), visit(tt, by_prefix{"tag3"}), visit(tt, by_prefix{"x"})}) {
+      DocSet got;
+      got.words.assign((uint64_t(docs) + 64) / 64, 0);
+      if (!ords.empty()) got.postings = tags.bit_union(ords, got.words);
+      REQUIRE(expect(opened[1], false, ords, got));
+    }
+    const DocSet all_tags = execute_unscored(tags, tt, docs, by_prefix{"tag"});
+    REQUIRE(expect(opened[1], false, visit(tt, by_prefix{"tag"}), all_tags) && all_tags.count() > tag_lists[0].size());
+    // "body": the 256 terms that share the first three bytes of their 4-byte ordinal, and a range
+    const std::string three("\0\0\1", 3);
+    const by_prefix p3{three};
+    const std::vector<uint32_t> o3 = visit(opened[0].terms, p3);
+    REQUIRE(o3.size() > 100 && o3.size() <= 256);
+    REQUIRE(expect(opened[0], true, o3, execute_unscored(bodyr, opened[0].terms, docs, p3)));
+    const by_range r{opened[0].terms[40], opened[0].terms[300], BoundType::EXCLUSIVE, BoundType::INCLUSIVE};
+    const std::vector<uint32_t> orr = visit(opened[0].terms, r);
+    REQUIRE(orr.size() == 260 && orr.front() == 41 && orr.back() == 300);
+    REQUIRE(expect(opened[0], true, orr, execute_unscored(bodyr, opened[0].terms, docs, r)));
+  }
+
   // ---- "body" and "title": BASELINE config 2 against the oracle's harness loop ------------------
   for (uint32_t f : {0u, 2u}) {
     const SynthField& sf = f == 0 ? body : title;
