@@ -188,9 +188,21 @@ k_join(const JoinWg* wgs) {
   const uint32_t nb = W.nblk + (W.tail_n ? 1u : 0u);
   uint32_t end = W.first + kJoinBlocks;
   if (end > nb) end = nb;
+  // this wavefront's blocks of a round: b_i = r0 + wv + kWaves * i  (all wave-uniform); their
+  // directory records by scalar loads — those of round r+1 are REQUESTED as soon as round r's
+  // payload loads are out and arrive while round r decodes: one exposed round trip per round
+  // (the payloads) instead of two (records, then payloads)
+  auto records = [&](uint32_t r0, BlkDir (&out)[kJoinPerWave]) {
+#pragma unroll
+    for (uint32_t i = 0; i < kJoinPerWave; ++i) {
+      const uint32_t b = r0 + wv + kWaves * i;
+      out[i] = BlkDir{0u, 0u, 0u, 0u};
+      if (b < end && b < W.nblk) out[i] = wave::sload<BlkDir>(W.dir + uint64_t(b) * sizeof(BlkDir));
+    }
+  };
+  BlkDir dir[kJoinPerWave];
+  records(W.first, dir);
   for (uint32_t r0 = W.first; r0 < end; r0 += kWaves * kJoinPerWave) {
-    // this wavefront's blocks of the round: b_i = r0 + wv + kWaves * i  (all wave-uniform)
-    BlkDir dir[kJoinPerWave];
     RawPair rd[kJoinPerWave], rf[kJoinPerWave];
     bool full[kJoinPerWave], plain[kJoinPerWave];
     uint32_t pn[kJoinPerWave];
@@ -198,8 +210,6 @@ k_join(const JoinWg* wgs) {
     for (uint32_t i = 0; i < kJoinPerWave; ++i) {
       const uint32_t b = r0 + wv + kWaves * i;
       full[i] = b < end && b < W.nblk;
-      dir[i] = BlkDir{0u, 0u, 0u, 0u};
-      if (full[i]) dir[i] = wave::sload<BlkDir>(W.dir + uint64_t(b) * sizeof(BlkDir));
     }
 #pragma unroll
     for (uint32_t i = 0; i < kJoinPerWave; ++i) {
@@ -217,6 +227,8 @@ k_join(const JoinWg* wgs) {
         pn[i] = *reinterpret_cast<const uint16_t*>(W.pnorm + uint64_t(b) * kBlock + 2u * lane);
       }
     }
+    BlkDir next[kJoinPerWave];
+    records(r0 + kWaves * kJoinPerWave, next);   // (past the end: zeros, nothing is read)
     uint32_t d0[kJoinPerWave], d1[kJoinPerWave], f0[kJoinPerWave], f1[kJoinPerWave];
 #pragma unroll
     for (uint32_t i = 0; i < kJoinPerWave; ++i) {
@@ -254,6 +266,8 @@ k_join(const JoinWg* wgs) {
         join_emit(ent, bnd, b, lane, d0[i], d1[i], f0[i], f1[i], n0[i], n1[i], true, true,
                   b ? dir[i].prev_last : 0u);
     }
+#pragma unroll
+    for (uint32_t i = 0; i < kJoinPerWave; ++i) dir[i] = next[i];
   }
   // the vint tail / single doc, decoded when the segment was opened: the list's last "block"
   const uint32_t bt = W.nblk;
