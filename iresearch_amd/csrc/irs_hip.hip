@@ -786,14 +786,23 @@ bool launch_phrase(irs_hip_batch* b, rt::stream_t st) {
     p.wgs = b->d_conj_pilot.as<PhraseWg>();
     p.n_pilot = b->n_conj_pilot;
     p.touched = nullptr;
-    RT_LAUNCH((k_phrase<LAYOUT, MT>), (b->n_conj_pilot + kPhraseWaves - 1) / kPhraseWaves,
-              kPhraseWaves * 64, 0, st, p, 1u);
+    if (MT == 2) {
+      RT_LAUNCH(k_phrase2<LAYOUT>, (b->n_conj_pilot + kPhraseWaves - 1) / kPhraseWaves,
+                kPhraseWaves * 64, 0, st, p, 1u);
+    } else {
+      RT_LAUNCH((k_phrase<LAYOUT, MT>), (b->n_conj_pilot + kPhraseWaves - 1) / kPhraseWaves,
+                kPhraseWaves * 64, 0, st, p, 1u);
+    }
   }
   RT_LAUNCH(k_conj_threshold, uint32_t(b->conj_units.size()), 64, 0, st,
             b->d_queries.as<DevQuery>(), b->d_conj_units.as<uint32_t>(),
             b->d_conj_items.as<uint32_t>(), b->d_conj_hist.as<uint32_t>(), stride,
             b->estimate ? kPilotMargin : 0u, b->d_bstar.as<uint32_t>(), min_bins(b));
-  RT_LAUNCH((k_phrase<LAYOUT, MT>), b->n_phrase_wgs, kPhraseWaves * 64, 0, st, a, 0u);
+  if (MT == 2) {
+    RT_LAUNCH(k_phrase2<LAYOUT>, b->n_phrase_wgs, kPhraseWaves * 64, 0, st, a, 0u);
+  } else {
+    RT_LAUNCH((k_phrase<LAYOUT, MT>), b->n_phrase_wgs, kPhraseWaves * 64, 0, st, a, 0u);
+  }
   RT_LAUNCH(k_conj_hits, uint32_t(b->conj_units.size()), 64, 0, st, b->d_conj_units.as<uint32_t>(),
             b->d_conj_item_base.as<uint32_t>(), b->d_conj_item_hits.as<uint32_t>(),
             b->d_hits.as<unsigned long long>());

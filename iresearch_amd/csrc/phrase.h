@@ -464,10 +464,9 @@ struct PhraseWave {
 };
 
 template<int LAYOUT, int MT>
-__global__ void __launch_bounds__(kPhraseWaves * 64)
-k_phrase(ConjArgs A, uint32_t pilot /*1: histogram the scores of the sampled lead items, no
-                                       candidates*/) {
-  __shared__ PhraseWave<MT> s_wave[kPhraseWaves];
+__device__ __forceinline__ void phrase_item(const ConjArgs& A, uint32_t pilot /*1: histogram the
+                                            scores of the sampled lead items, no candidates*/,
+                                            PhraseWave<MT>* s_wave) {
   const uint32_t tid = threadIdx.x;
   const unsigned lane = tid & 63u;
   const uint32_t wv = wave::uniform(tid >> 6);
@@ -874,6 +873,23 @@ k_phrase(ConjArgs A, uint32_t pilot /*1: histogram the scores of the sampled lea
       if (my_pos) atomicAdd(&A.touched[2u * unit + 1u], static_cast<unsigned long long>(my_pos));
     }
   }
+}
+
+template<int LAYOUT, int MT>
+__global__ void __launch_bounds__(kPhraseWaves * 64)
+k_phrase(ConjArgs A, uint32_t pilot) {
+  __shared__ PhraseWave<MT> s_wave[kPhraseWaves];
+  phrase_item<LAYOUT, MT>(A, pilot, s_wave);
+}
+// Two-word phrases (the usual case, BASELINE config 5) at the hardware's 8 wavefronts per SIMD: the
+// kernel is a chain of dependent loads, resident wavefronts count for more than the 4 registers
+// over 64 it would like (12 bytes of scratch): 7.34 -> 6.44 ms per 1000 phrases.  Longer phrases
+// keep their registers (their LDS rows limit the occupancy anyway).
+template<int LAYOUT>
+__global__ void __launch_bounds__(kPhraseWaves * 64) RT_WAVES_PER_SIMD(8)
+k_phrase2(ConjArgs A, uint32_t pilot) {
+  __shared__ PhraseWave<2> s_wave[kPhraseWaves];
+  phrase_item<LAYOUT, 2>(A, pilot, s_wave);
 }
 
 }  // namespace irs_hip
