@@ -123,7 +123,11 @@ typedef struct irs_hip_segment irs_hip_segment; /* opaque, immutable after open 
 int irs_hip_segment_open(const irs_hip_segment_desc* desc, irs_hip_segment** out);
 void irs_hip_segment_close(irs_hip_segment* seg);
 
-/* postings_reader::CountMappedMemory analogue: bytes resident in HBM. */
+/* postings_reader::CountMappedMemory analogue: bytes resident in HBM.  Grows after open by the
+ * tables a segment builds on first use and keeps: the block-max pairs of irs_hip_batch_set_wand
+ * (8 bytes per 128-posting block) and the posting-order copy of a 1-byte Norm2 column (one byte
+ * per posting of the whole segment — built by the first batch that joins posting streams, or whose
+ * conjunctions / phrases score with norms). */
 uint64_t irs_hip_segment_device_bytes(const irs_hip_segment* seg);
 
 /* Replaces `postings_reader::iterator(...)` + `while (it->next())`
