@@ -172,10 +172,10 @@ __device__ __forceinline__ void decode_dir_block(const DevSegment& seg, uint64_t
                                                  uint32_t& d1, uint32_t& f0, uint32_t& f1) {
   const uint32_t dbits = bits & 0xFFu, fbits = bits >> 8;
   if (pk_both(dbits, fbits)) {
-    const uint8_t* pl = seg.pk + (uint64_t(aoff) << 4);
+    const uint64_t pl = reinterpret_cast<uint64_t>(seg.pk) + (uint64_t(aoff) << 4);
     uint64_t da, db, fa, fb;
-    raw_load_packed<LAYOUT>(pl, dbits, lane, da, db);
-    raw_load_packed<LAYOUT>(pl + 16u * dbits, fbits, lane, fa, fb);
+    raw_load_packed_g<LAYOUT>(pl, dbits, lane, da, db);
+    raw_load_packed_g<LAYOUT>(pl + 16u * dbits, fbits, lane, fa, fb);
     uint32_t x0, x1;
     extract_fast<LAYOUT>(da, db, dbits, lane, x0, x1);
     extract_fast<LAYOUT>(fa, fb, fbits, lane, f0, f1);
@@ -453,7 +453,10 @@ k_conj(ConjArgs A, uint32_t pilot) {
       if (i + 1u < m) atomicOr(&mark[bk >> 5], 1u << (bk & 31u));   // (alive for the next term)
     };
     if (tl.nblk) {
-      const uint32_t* last = seg.blk_last + tl.dir_off;
+      // (integer addresses: loads through the global address space, see raw_load_packed_g)
+      const uint64_t last_at = reinterpret_cast<uint64_t>(seg.blk_last + tl.dir_off);
+      const uint64_t dir_at = reinterpret_cast<uint64_t>(seg.blk_dir + tl.dir_off);
+      const uint64_t pk_at = reinterpret_cast<uint64_t>(seg.pk);
       const uint32_t b_first = seek[i - 1u];
       for (uint32_t b0 = b_first; b0 < tl.nblk; b0 += 64) {
         const uint32_t bl = b0 + lane;
@@ -461,9 +464,13 @@ k_conj(ConjArgs A, uint32_t pilot) {
         // the block's last doc AND its directory record in one round trip (the record also
         // holds the preceding block's last doc): the kernel is a chain of dependent loads —
         // fetching the record only for the blocks that turn out to be wanted made it one longer
-        const uint32_t lst = valid ? last[bl] : 0xFFFFFFFFu;
+        const uint32_t lst = valid ? wave::gload_u32(last_at, bl * 4u) : 0xFFFFFFFFu;
         BlkDir d{};
-        if (valid) d = seg.blk_dir[tl.dir_off + bl];
+        if (valid) {
+          uint32_t w[4];
+          wave::gload_u32x4(dir_at, bl * uint32_t(sizeof(BlkDir)), w);
+          d = BlkDir{w[0], w[1], w[2], w[3]};
+        }
         // the block holds docs in (prv, lst], prv = the preceding block's lst
         const uint32_t prv = bl ? d.prev_last : 0u;
         const bool reach = valid && prv < dhi && lst >= dlo;
@@ -489,13 +496,13 @@ k_conj(ConjArgs A, uint32_t pilot) {
             if (pk_both(kbits2 & 0xFFu, kbits2 >> 8)) {
               mask &= mask - 1;
               if (counting) bytes += block_bytes(kbits2);
-              const uint8_t* pl1 = seg.pk + (uint64_t(wave::read_lane(d.aoff, k)) << 4);
-              const uint8_t* pl2 = seg.pk + (uint64_t(wave::read_lane(d.aoff, k2)) << 4);
+              const uint64_t pl1 = pk_at + (uint64_t(wave::read_lane(d.aoff, k)) << 4);
+              const uint64_t pl2 = pk_at + (uint64_t(wave::read_lane(d.aoff, k2)) << 4);
               uint64_t da1, db1, fa1, fb1, da2, db2, fa2, fb2;
-              raw_load_packed<LAYOUT>(pl1, kbits & 0xFFu, lane, da1, db1);
-              raw_load_packed<LAYOUT>(pl1 + 16u * (kbits & 0xFFu), kbits >> 8, lane, fa1, fb1);
-              raw_load_packed<LAYOUT>(pl2, kbits2 & 0xFFu, lane, da2, db2);
-              raw_load_packed<LAYOUT>(pl2 + 16u * (kbits2 & 0xFFu), kbits2 >> 8, lane, fa2, fb2);
+              raw_load_packed_g<LAYOUT>(pl1, kbits & 0xFFu, lane, da1, db1);
+              raw_load_packed_g<LAYOUT>(pl1 + 16u * (kbits & 0xFFu), kbits >> 8, lane, fa1, fb1);
+              raw_load_packed_g<LAYOUT>(pl2, kbits2 & 0xFFu, lane, da2, db2);
+              raw_load_packed_g<LAYOUT>(pl2 + 16u * (kbits2 & 0xFFu), kbits2 >> 8, lane, fa2, fb2);
               uint32_t x0, x1, f0, f1;
               extract_fast<LAYOUT>(da1, db1, kbits & 0xFFu, lane, x0, x1);
               extract_fast<LAYOUT>(fa1, fb1, kbits >> 8, lane, f0, f1);

@@ -503,6 +503,26 @@ __device__ __forceinline__ void raw_load_packed(const uint8_t* payload, uint32_t
   }
 }
 
+// The same through the GLOBAL address space (wave::gload_u64: base = a wave-uniform integer
+// address): a payload pointer read out of the DevSegment record is a generic pointer and its
+// loads FLAT ones, which also count on lgkmcnt — in a kernel that interleaves them with LDS
+// operations (conj.h, phrase.h) every wait for an LDS result then drains the payload loads in
+// flight as well.
+template<int LAYOUT>
+__device__ __forceinline__ void raw_load_packed_g(uint64_t payload, uint32_t bits, unsigned lane,
+                                                  uint64_t& a, uint64_t& b) {
+  if (LAYOUT == kSimd4) {
+    const uint32_t k = wave::mul24(lane >> 1, bits) >> 5;
+    const uint32_t voff = 16u * k + ((lane & 1u) << 3);
+    a = wave::gload_u64(payload, voff);
+    b = wave::gload_u64(payload, voff + 16u);
+  } else {
+    const uint32_t voff = (wave::mul24(lane << 1, bits) >> 5) << 2;
+    a = wave::gload_u64(payload, voff);
+    b = wave::gload_u64(payload, voff + 4u);
+  }
+}
+
 // Values 2*lane, 2*lane+1 out of the prefetched payload words, for 1 <= bits <= 31:
 // one funnel shift (v_alignbit_b32) + one bit-field extract (v_bfe_u32) each.
 template<int LAYOUT>

@@ -67,8 +67,9 @@ __device__ __forceinline__ void decode_packed_pos(const uint8_t* pl, uint32_t db
                                                   uint32_t& d0, uint32_t& d1, uint32_t& f0,
                                                   uint32_t& f1, uint32_t& before) {
   uint64_t da, db, fa, fb;
-  raw_load_packed<LAYOUT>(pl, dbits, lane, da, db);
-  raw_load_packed<LAYOUT>(pl + 16u * dbits, fbits, lane, fa, fb);
+  const uint64_t at = reinterpret_cast<uint64_t>(pl);
+  raw_load_packed_g<LAYOUT>(at, dbits, lane, da, db);
+  raw_load_packed_g<LAYOUT>(at + 16u * dbits, fbits, lane, fa, fb);
   uint32_t x0, x1;
   extract_fast<LAYOUT>(da, db, dbits, lane, x0, x1);
   extract_fast<LAYOUT>(fa, fb, fbits, lane, f0, f1);
@@ -634,7 +635,11 @@ __device__ __forceinline__ void phrase_item(const ConjArgs& A, uint32_t pilot /*
       atomicOr(&mark[bk >> 5], 1u << (bk & 31u));
     };
     if (tl.nblk) {
-      const uint32_t* last = seg.blk_last + tl.dir_off;
+      // (integer addresses: loads through the global address space, see raw_load_packed_g)
+      const uint64_t last_at = reinterpret_cast<uint64_t>(seg.blk_last + tl.dir_off);
+      const uint64_t dir_at = reinterpret_cast<uint64_t>(seg.blk_dir + tl.dir_off);
+      const uint64_t pos_at = reinterpret_cast<uint64_t>(seg.blk_pos + tl.dir_off);
+      const uint64_t pk_at = reinterpret_cast<uint64_t>(seg.pk);
       const uint32_t pos0 = seg.blk_pos[tl.dir_off];
       const uint32_t b_first = seek[i < lead ? i : i - 1u];
       for (uint32_t b0 = b_first; b0 < tl.nblk; b0 += 64) {
@@ -642,12 +647,14 @@ __device__ __forceinline__ void phrase_item(const ConjArgs& A, uint32_t pilot /*
         const bool valid = bl < tl.nblk;
         // the block's last doc, its directory record (which also holds the preceding block's
         // last doc) and its first position number in ONE round trip (conj.h)
-        const uint32_t lst = valid ? last[bl] : 0xFFFFFFFFu;
+        const uint32_t lst = valid ? wave::gload_u32(last_at, bl * 4u) : 0xFFFFFFFFu;
         BlkDir d{};
         uint32_t pos_l = 0;
         if (valid) {
-          d = seg.blk_dir[tl.dir_off + bl];
-          pos_l = seg.blk_pos[tl.dir_off + bl];
+          uint32_t w[4];
+          wave::gload_u32x4(dir_at, bl * uint32_t(sizeof(BlkDir)), w);
+          d = BlkDir{w[0], w[1], w[2], w[3]};
+          pos_l = wave::gload_u32(pos_at, bl * 4u);
         }
         const uint32_t prv = bl ? d.prev_last : 0u;   // the block holds docs in (prv, lst]
         const bool reach = valid && prv < dhi && lst >= dlo;
@@ -675,13 +682,13 @@ __device__ __forceinline__ void phrase_item(const ConjArgs& A, uint32_t pilot /*
             if (pk_both(bits2 & 0xFFu, bits2 >> 8)) {
               mask &= mask - 1;
               if (counting) bytes += block_bytes(bits2);
-              const uint8_t* pl1 = seg.pk + (uint64_t(wave::read_lane(d.aoff, k)) << 4);
-              const uint8_t* pl2 = seg.pk + (uint64_t(wave::read_lane(d.aoff, k2)) << 4);
+              const uint64_t pl1 = pk_at + (uint64_t(wave::read_lane(d.aoff, k)) << 4);
+              const uint64_t pl2 = pk_at + (uint64_t(wave::read_lane(d.aoff, k2)) << 4);
               uint64_t da1, db1, fa1, fb1, da2, db2, fa2, fb2;
-              raw_load_packed<LAYOUT>(pl1, dbits, lane, da1, db1);
-              raw_load_packed<LAYOUT>(pl1 + 16u * dbits, fbits, lane, fa1, fb1);
-              raw_load_packed<LAYOUT>(pl2, bits2 & 0xFFu, lane, da2, db2);
-              raw_load_packed<LAYOUT>(pl2 + 16u * (bits2 & 0xFFu), bits2 >> 8, lane, fa2, fb2);
+              raw_load_packed_g<LAYOUT>(pl1, dbits, lane, da1, db1);
+              raw_load_packed_g<LAYOUT>(pl1 + 16u * dbits, fbits, lane, fa1, fb1);
+              raw_load_packed_g<LAYOUT>(pl2, bits2 & 0xFFu, lane, da2, db2);
+              raw_load_packed_g<LAYOUT>(pl2 + 16u * (bits2 & 0xFFu), bits2 >> 8, lane, fa2, fb2);
               uint32_t x0, x1;
               extract_fast<LAYOUT>(da1, db1, dbits, lane, x0, x1);
               extract_fast<LAYOUT>(fa1, fb1, fbits, lane, f0, f1);
