@@ -902,6 +902,45 @@ def case_plan_ahead(L):
     sr.close()
 
 
+def case_fresh_batches_and_trim(L):
+    """The life cycle bench.py times: a NEW batch per step (created, run, read, destroyed), its
+    buffers coming from and going back to the library's pool — results never depend on what an
+    earlier batch left in a recycled buffer (the emulator poisons freed blocks) — with
+    irs_hip_device_trim handing the pool back in between, and a batch destroyed without ever
+    having run."""
+    seg = synth.build_segment(60_000, 256)
+    sr = search.SegmentReader.from_synth(seg, L=L)
+    st = [parity.segment_stats(seg)]
+    sets = []
+    for i in range(4):
+        ranks = synth.make_queries(6 + 3 * i, 2 + 2 * i, 2, 256, synth.SEED + 40 + i)
+        filters = [Or([by_term(int(r) - 1) for r in row]) for row in ranks]
+        filters += [And([by_term(3 + i), by_term(40)]), Or([by_term(5), by_term(7 + i), by_term(90)], min_match=2)]
+        sets.append((filters, search.prepare(filters, BM25(), st)))
+    ref = []
+    for filters, prep in sets:
+        b = sr.batch(prep, 50)
+        ref.append([x.copy() for x in b.run().results()])
+        parity.check_single_segment(seg, filters, BM25(), 50, *ref[-1])
+        b.close()
+    for rnd in range(3):
+        pending = None
+        for i in (2, 0, 3, 1, 1, 3):
+            b = sr.batch(sets[i][1], 50).run()
+            if pending is not None:   # (the previous batch is read after the next one was queued)
+                j, pb = pending
+                got = pb.results()
+                assert all(np.array_equal(a, g) for a, g in zip(ref[j], got)), (rnd, j)
+                pb.close()
+            pending = (i, b)
+        j, pb = pending
+        assert all(np.array_equal(a, g) for a, g in zip(ref[j], pb.results())), (rnd, j)
+        pb.close()
+        sr.batch(sets[rnd][1], 50).close()     # created, never run
+        _lib.check(L, L.irs_hip_device_trim(0), "irs_hip_device_trim")
+    sr.close()
+
+
 def case_min_score_pushdown(L):
     """irs::score::Min (score_function.hpp:42-142; the harness pushes its heap's k-th score,
     index-search.cpp:737-777): with the k-th score of a first run as threshold the same top-k

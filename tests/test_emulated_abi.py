@@ -193,6 +193,10 @@ def test_plan_ahead(simlib):
     cases.case_plan_ahead(simlib)
 
 
+def test_fresh_batches_and_trim(simlib):
+    cases.case_fresh_batches_and_trim(simlib)
+
+
 def test_wand_equals_exhaustive(simlib):
     cases.case_wand_equals_exhaustive(simlib)
 

@@ -240,6 +240,10 @@ def test_plan_ahead(gpulib):
     cases.case_plan_ahead(gpulib)
 
 
+def test_fresh_batches_and_trim(gpulib):
+    cases.case_fresh_batches_and_trim(gpulib)
+
+
 def test_wand_equals_exhaustive(gpulib):
     cases.case_wand_equals_exhaustive(gpulib, num_docs=400_000, max_rank=512, ks=(10, 1000))
 
