@@ -106,25 +106,6 @@ __device__ __forceinline__ uint32_t bfe(uint32_t x, uint32_t bits) {
 
 // high 32 bits of a 32 x 32 bit product (v_mul_hi_u32)
 __device__ __forceinline__ uint32_t mul_hi(uint32_t a, uint32_t b) { return __umulhi(a, b); }
-// Two 16-bit halves of a word at once (VOP3P v_pk_*_u16): the packed first-pass accumulators of
-// fast.h hold two docs per word.
-// (written as instructions: the compiler lowers vector min / max of two shorts to compares, selects
-// and a byte permute — six instructions for one)
-__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
-  uint32_t r;
-  asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
-  uint32_t r;
-  asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {
-  uint32_t r;
-  asm("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
 
 // Optimisation barrier: the value must exist in a VGPR at this program point.
 __device__ __forceinline__ void keep(uint32_t& v) { asm volatile("" : "+v"(v)); }
@@ -218,6 +199,16 @@ __device__ __forceinline__ void lds_add(const unsigned char*, uint32_t off, unsi
                          __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// Read 4 bytes of LDS and leave zero behind (ds_wrxchg_rtn_b32); the compiler places the wait,
+// so several of them issued back to back are in flight together.
+__device__ __forceinline__ uint32_t lds_take(unsigned char*, uint32_t off) {
+  return __hip_atomic_exchange((IRS_LDS uint32_t*)(uintptr_t)off, 0u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint32_t lds_u32(const unsigned char*, uint32_t off) {
+  return *(const IRS_LDS uint32_t*)(uintptr_t)off;
+}
+
 // 16 bytes of LDS at a 16-byte aligned offset: ds_read_b128 / ds_write_b128
 __device__ __forceinline__ void lds_read4(const unsigned char*, uint32_t off, uint32_t (&v)[4]) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -308,6 +299,14 @@ __device__ __forceinline__ void gload_u32x4(uint64_t base, uint32_t off, uint32_
   typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
   const u32x4a4 x = *(const IRS_GLOBAL u32x4a4*)((const IRS_GLOBAL uint8_t*)base + off);
   v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+}
+
+// 4 / 2 bytes at a per-lane global address (global_load_dword / global_load_ushort, vmcnt only)
+__device__ __forceinline__ uint32_t gload_u32_at(uint64_t addr) {
+  return *(const IRS_GLOBAL uint32_t*)addr;
+}
+__device__ __forceinline__ uint32_t gload_u16_at(uint64_t addr) {
+  return *(const IRS_GLOBAL uint16_t*)addr;
 }
 
 // ... at a per-lane address

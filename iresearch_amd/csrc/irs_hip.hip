@@ -21,7 +21,6 @@
 #include "score.h"
 #include "conj.h"
 #include "join.h"
-#include "fast.h"
 
 using namespace irs_hip;
 
@@ -343,15 +342,11 @@ struct irs_hip_batch {
   bool joined = false;
   DevBuf d_streams, d_join_wgs, d_jterms, d_entries, d_bounds, d_join_args, d_join_units,
     d_join_order;
-  // fast.h: plain disjunctions in two passes — fast entries next to the exact ones (same
-  // offsets), the first pass's approximate candidates, the kernels' argument records
-  bool fast16 = false;
-  DevBuf d_fast, d_fbounds, d_fterms, d_fast_wg, d_fast_dummies;
-  DevBuf d_acands, d_acand_count, d_fast_args, d_rescore_args, d_fast_chunks;
-  uint32_t n_fast_pack_wgs = 0;
-  FastArgs fast_args{}, fast_args_sent{};
-  RescoreArgs rescore_args{}, rescore_args_sent{};
-  bool fast_args_valid = false, rescore_args_valid = false;
+  // term-level pruning of plain disjunctions (join.h k_join_ms): doc bitmaps of the dense
+  // streams, every stream's score bound, the units' term split
+  bool pruned = false;         // this deal's plain disjunctions run on k_join_ms
+  DevBuf d_bits, d_bits_wgs, d_stream_tmax, d_join_split, d_ms_stats;
+  uint32_t n_bits_wgs = 0;
   uint32_t join_max_tiles = 0;
   uint32_t n_streams = 0, n_join_wgs = 0;
   uint32_t join_threads = 1024, join_nw_log2 = 4;   // threads per k_join_pilot / k_join_score workgroup
@@ -913,23 +908,38 @@ bool join_allowed(const irs_hip_batch* b) {   // batch level
   if (b->path_pref == IRS_HIP_PATH_ITEMS) return false;
   if (const char* e = std::getenv("IRS_HIP_JOIN")) {   // tuning / test knob
     if (std::atoi(e) == 0 && b->path_pref != IRS_HIP_PATH_JOINED &&
-        b->path_pref != IRS_HIP_PATH_JOINED_EXACT)
+        b->path_pref != IRS_HIP_PATH_JOINED_PRUNED)
       return false;
   }
   // (a unit on joined streams runs exhaustively under ExecutionContext::wand: the top k is the
   // exhaustive one by construction; pruning stays with the block-driven / work-item kernels)
   return !b->phrase && b->acc32;
 }
-// plain disjunctions of a joined batch in two passes (fast.h)?
-// (Measured, 1000 OR-8 queries on 10 M docs: the two passes take 5.8 + 0.9 ms against the one-pass
-// kernel's 5.6 ms — the packed pass halves the tiles but its per-tile skeleton is not yet cheaper
-// than join.h's.  Until it wins it runs only where asked for: IRS_HIP_PATH_JOINED pins it,
-// IRS_HIP_PATH_AUTO takes the one-pass kernel.)
-constexpr bool kFastByDefault = false;
-bool fast16_allowed(const irs_hip_batch* b) {
-  if (b->path_pref == IRS_HIP_PATH_JOINED_EXACT) return false;
-  if (const char* e = std::getenv("IRS_HIP_FAST16")) return std::atoi(e) != 0;   // tuning / test knob
-  return kFastByDefault || b->path_pref == IRS_HIP_PATH_JOINED;
+// Term-level pruning of the joined plain disjunctions (join.h k_join_ms): IRS_HIP_PATH_AUTO and
+// IRS_HIP_PATH_JOINED_PRUNED take it, IRS_HIP_PATH_JOINED keeps the exhaustive kernel (A/B, tests:
+// the two return the same hits bit for bit).
+bool ms_allowed(const irs_hip_batch* b) {
+  if (b->path_pref == IRS_HIP_PATH_JOINED) return false;
+  if (const char* e = std::getenv("IRS_HIP_MS")) {   // tuning / test knob
+    if (std::atoi(e) == 0 && b->path_pref != IRS_HIP_PATH_JOINED_PRUNED) return false;
+  }
+  return true;
+}
+// non-essential terms may take alpha = x / 256 of the threshold (k_join_split)
+uint32_t ms_alpha256() {
+  if (const char* e = std::getenv("IRS_HIP_MS_ALPHA")) {   // tuning knob, percent
+    const int v = std::atoi(e);
+    return uint32_t(std::min(std::max(v, 0), 100) * 256 / 100);
+  }
+  return 154;   // 0.6
+}
+// a stream gets a doc bitmap when it holds at least one posting per this many docs
+uint64_t ms_density() {
+  if (const char* e = std::getenv("IRS_HIP_MS_DENSITY")) {   // tuning knob
+    const int v = std::atoi(e);
+    if (v >= 1) return uint64_t(v);
+  }
+  return 32;
 }
 bool join_counts_allowed() {   // tuning / test knob
   const char* e = std::getenv("IRS_HIP_JOIN_COUNTS");
@@ -959,7 +969,7 @@ int64_t join_and_saving(const irs_hip_batch* b, const DevQuery& dq) {
 // kernel) only pay when the conjunctions that would join save more than that together
 constexpr int64_t kJoinAndLaunchCost = 500000000;   // 0.5 ms
 int join_and_forced(const irs_hip_batch* b) {   // -1: decide by cost
-  if (b->path_pref == IRS_HIP_PATH_JOINED || b->path_pref == IRS_HIP_PATH_JOINED_EXACT)
+  if (b->path_pref == IRS_HIP_PATH_JOINED || b->path_pref == IRS_HIP_PATH_JOINED_PRUNED)
     return 1;   // (forced: wherever it is possible)
   if (const char* e = std::getenv("IRS_HIP_JOIN_AND")) return std::atoi(e) != 0;   // tuning / test knob
   return -1;
@@ -995,7 +1005,7 @@ bool join_or_pays(const irs_hip_batch* b, const std::vector<uint32_t>& units) {
   return 29ull * distinct < (67ull * refs) / 10ull + 24000ull * tiles;
 }
 int join_or_forced(const irs_hip_batch* b) {   // -1: decide by cost
-  if (b->path_pref == IRS_HIP_PATH_JOINED || b->path_pref == IRS_HIP_PATH_JOINED_EXACT) return 1;
+  if (b->path_pref == IRS_HIP_PATH_JOINED || b->path_pref == IRS_HIP_PATH_JOINED_PRUNED) return 1;
   if (const char* e = std::getenv("IRS_HIP_JOIN_OR")) return std::atoi(e) != 0;   // tuning / test knob
   return -1;
 }
@@ -1030,13 +1040,13 @@ bool build_streams(irs_hip_batch* b) {
   std::vector<WgRef> wgs;
   std::vector<JoinTerm> jterms(b->qterms.size());
   // A stream = a distinct (segment, term, scorer signature) of the joined units: the signature
-  // — (kind, norm_const, norm_length), normally ONE per batch — is what k_join evaluates a
-  // stream's fast entries with (fast.h).  stream_of[unit term] by an open-addressing table: the
-  // streams come out in first-use order.
+  // — (kind, norm_const, norm_length), normally ONE per batch — is what k_stream_bits evaluates
+  // a stream's score bound with.  stream_of[unit term] by an open-addressing table: the streams
+  // come out in first-use order.
   struct Sig { int32_t kind; float nc, nl; };
   std::vector<Sig> sigs;
   std::vector<uint32_t> stream_of(b->qterms.size(), 0xFFFFFFFFu);
-  std::vector<uint8_t> stream_fast, stream_sig;
+  std::vector<uint8_t> stream_plain, stream_sig;   // (plain: some plain disjunction reads it)
   {
     size_t slots = 64;
     size_t n_keys = 0;
@@ -1046,7 +1056,7 @@ bool build_streams(irs_hip_batch* b) {
     std::vector<uint32_t> hval(slots, 0);
     for (uint32_t u : b->join_units) {
       const DevQuery& dq = b->queries[u];
-      const bool fast = b->fast16 && query_need(dq.op) <= 1u;
+      const bool plain = query_need(dq.op) <= 1u;
       for (uint32_t j = 0; j < dq.n_terms; ++j) {
         const DevQTerm& qt = b->qterms[dq.first_term + j];
         uint32_t sg_id = 0;
@@ -1068,28 +1078,31 @@ bool build_streams(irs_hip_batch* b) {
           r.term = qt.term;
           r.n = b->segs[dq.seg]->terms[qt.term].docs_count;
           streams.push_back(r);
-          stream_fast.push_back(0);
+          stream_plain.push_back(0);
           stream_sig.push_back(uint8_t(sg_id));
         }
         stream_of[dq.first_term + j] = hval[h];
-        if (fast) stream_fast[hval[h]] = 1;
+        if (plain) stream_plain[hval[h]] = 1;
       }
     }
   }
-  uint64_t entries = 0, bounds = 0, fentries = 0;
-  std::vector<uint64_t> ent_off, bnd_off, fent_off;
-  std::vector<uint32_t> fast_wg(streams.size() + 1, 0);   // k_fast_pack: the streams' first workgroups
+  uint64_t entries = 0, bounds = 0, bits_bytes = 0;
+  std::vector<uint64_t> ent_off, bnd_off, bits_off;
+  // term-level pruning: a stream may become non-essential only where a doc bitmap is cheaper to
+  // consult than its entries — at least one posting per kMsDensity docs
+  std::vector<BitsWg> bits_wgs;
   for (size_t si = 0; si < streams.size(); ++si) {
     const irs_hip_segment* sg = b->segs[streams[si].seg];
     const DevTerm& t = sg->terms[streams[si].term];
     ent_off.push_back(entries);
     bnd_off.push_back(bounds);
     const uint32_t n_tiles = (sg->dev.num_docs + kJoinTile - 1) / kJoinTile;
-    // fast.h: the stream once more, every tile padded to a multiple of four entries (16-byte
-    // aligned from the start)
-    fent_off.push_back(fentries);
-    if (stream_fast[si]) fentries += (uint64_t(t.docs_count) + 3ull * n_tiles + 3ull) & ~3ull;
-    fast_wg[si + 1] = fast_wg[si] + (stream_fast[si] ? (n_tiles + kFastPackTiles - 1) / kFastPackTiles : 0u);
+    bits_off.push_back(~0ull);
+    if (b->pruned && stream_plain[si] &&
+        uint64_t(t.docs_count) * ms_density() >= uint64_t(sg->dev.num_docs) && t.docs_count >= 1024u) {
+      bits_off.back() = bits_bytes;
+      bits_bytes += uint64_t(n_tiles) * kMsTileBytes;
+    }
     const uint32_t nb = t.nblk + ((t.docs_count == 1 || t.tail_n) ? 1u : 0u);
     for (uint32_t first = 0; first < nb; first += kJoinBlocks)
       wgs.push_back(WgRef{uint32_t(si), first});
@@ -1121,13 +1134,11 @@ bool build_streams(irs_hip_batch* b) {
     wgs.swap(sorted);
   }
   lap("  streams: buffers");
-  if (b->fast16 &&
-      (!b->d_fast.alloc((fentries + kJoinSlack) * 4) || !b->d_fbounds.alloc((bounds + 1) * 4) ||
-       !b->d_fterms.alloc(jterms.size() * sizeof(FastTerm)) ||
-       !b->d_fast_wg.alloc(fast_wg.size() * 4) || !b->d_fast_dummies.alloc(64 * 16)))
+  if (b->pruned &&
+      (!b->d_bits.alloc(bits_bytes + 64) || !b->d_stream_tmax.alloc(std::max<size_t>(1, streams.size()) * 4) ||
+       !b->d_join_split.alloc(uint64_t(b->nq) * sizeof(JoinSplit)) || !b->d_ms_stats.alloc(kMsStats * 8)))
     return false;
-  if (!b->fast16) b->d_fast.release();
-  b->n_fast_pack_wgs = b->fast16 ? fast_wg.back() : 0u;
+  if (!b->pruned) b->d_bits.release();
   if (!b->d_entries.alloc((entries + kJoinSlack) * 4) || !b->d_bounds.alloc((bounds + 1) * 4) ||
       !b->d_streams.alloc(std::max<size_t>(1, streams.size()) * sizeof(StreamRec)) ||
       !b->d_join_wgs.alloc(std::max<size_t>(1, wgs.size()) * sizeof(JoinWg)) ||
@@ -1182,14 +1193,38 @@ bool build_streams(irs_hip_batch* b) {
     streams[i].bounds = reinterpret_cast<uint64_t>(b->d_bounds.as<uint32_t>() + bnd_off[i]);
     streams[i].n_tiles = (b->segs[streams[i].seg]->dev.num_docs + kJoinTile - 1) / kJoinTile;
     const Sig& sig = sigs[stream_sig[i]];
+    {
+      const irs_hip_segment* sg = b->segs[streams[i].seg];
+      const DevTerm& t = sg->terms[streams[i].term];
+      const bool norms = sig.kind == kBM25Tiny || sig.kind == kTfidfTiny;
+      streams[i].abytes = uint64_t(t.blocks_bytes) + t.tail_bytes +
+                          (norms ? uint64_t(t.docs_count) * sg->dev.norm_width : 0ull);
+    }
     streams[i].kind = sig.kind;
     streams[i].nc = sig.nc;
     streams[i].nl = sig.nl;
-    if (b->fast16 && stream_fast[i]) {
-      streams[i].fent = reinterpret_cast<uint64_t>(b->d_fast.as<uint32_t>() + fent_off[i]);
-      streams[i].fbounds = reinterpret_cast<uint64_t>(b->d_fbounds.as<uint32_t>() + bnd_off[i]);
+    if (bits_off[i] != ~0ull) {
+      streams[i].bits = reinterpret_cast<uint64_t>(b->d_bits.as<uint8_t>() + bits_off[i]);
+      for (uint32_t t0 = 0; t0 < streams[i].n_tiles; t0 += kMsBitsTiles) {
+        BitsWg w{};
+        w.entries = streams[i].entries;
+        w.bounds = streams[i].bounds;
+        w.bits = streams[i].bits;
+        w.tile0 = t0;
+        w.n_tiles = streams[i].n_tiles;
+        w.sid = uint32_t(i);
+        w.kind = sig.kind;
+        w.nc = sig.nc;
+        w.nl = sig.nl;
+        bits_wgs.push_back(w);
+      }
     }
   }
+  b->n_bits_wgs = uint32_t(bits_wgs.size());
+  if (b->n_bits_wgs &&
+      (!b->d_bits_wgs.alloc(bits_wgs.size() * sizeof(BitsWg)) ||
+       !b->up.copy(b->d_bits_wgs.p, bits_wgs.data(), bits_wgs.size() * sizeof(BitsWg))))
+    return false;
   for (irs_hip_segment* sg : b->segs)
     if (prepare_posting_norms(sg) != IRS_HIP_OK) return false;
   lap("  streams: k_join records");
@@ -1221,31 +1256,17 @@ bool build_streams(irs_hip_batch* b) {
     w.pad[0] = w.pad[1] = w.pad[2] = 0;
   }
   lap("  streams: per-term records");
-  std::vector<FastTerm> fterms(b->fast16 ? jterms.size() : 0);
   for (uint32_t u : b->join_units) {
     DevQuery& dq = b->queries[u];
     const uint32_t rows = table_rows(dq.n_caches);
-    // fast.h: the unit's 16-bit scale — every doc's approximate sum (each posting at most its
-    // term's csq + 1) stays below 2^15
-    double u16 = 0.0;
-    for (uint32_t j = 0; j < dq.n_terms; ++j) {
-      const DevQTerm& qt = b->qterms[dq.first_term + j];
-      u16 += double(qt.c0) * double(fast_tn(qt.kind));
-    }
-    const double s16 = u16 > 0.0 ? double(kFastMaxSum - 2u * dq.n_terms) / (u16 * (1.0 + 1e-6)) : 0.0;
-    dq.s16 = float(s16);
     for (uint32_t j = 0; j < dq.n_terms; ++j) {
       const DevQTerm& qt = b->qterms[dq.first_term + j];
       const size_t sid = stream_of[dq.first_term + j];
       JoinTerm& jt = jterms[dq.first_term + j];
-      jt.pad[0] = jt.pad[1] = 0;
-      if (b->fast16) {
-        FastTerm& ft = fterms[dq.first_term + j];
-        ft.fent = streams[sid].fent;
-        ft.fbounds = streams[sid].fbounds;
-        ft.csq = uint32_t(double(qt.c0) * double(fast_tn(qt.kind)) * s16);
-        ft.pad[0] = ft.pad[1] = ft.pad[2] = 0;
-      }
+      jt.pad = 0;
+      jt.pad64 = 0;
+      jt.sid = uint32_t(sid);
+      jt.bits = streams[sid].bits;
       jt.entries = streams[sid].entries;
       jt.bounds = streams[sid].bounds;
       jt.cs = qt.c0 * dq.fx_mul;
@@ -1263,16 +1284,6 @@ bool build_streams(irs_hip_batch* b) {
       !b->up.copy(b->d_join_units.p, b->join_units.data(), b->join_units.size() * 4) ||
       !b->up.copy(b->d_join_order.p, order.data(), order.size() * 4))
     return false;
-  if (b->fast16) {
-    // entries that add nothing: lane l's four at + 16 l — score 0 into the lane's dummy word
-    uint32_t* dm = static_cast<uint32_t*>(b->up.put(b->d_fast_dummies.p, 64 * 16));
-    if (!dm) return false;
-    for (uint32_t l = 0; l < 64; ++l)
-      for (uint32_t k = 0; k < 4; ++k) dm[4 * l + k] = FastOff::dummy + 4u * l;
-    if (!b->up.copy(b->d_fterms.p, fterms.data(), fterms.size() * sizeof(FastTerm)) ||
-        !b->up.copy(b->d_fast_wg.p, fast_wg.data(), fast_wg.size() * 4))
-      return false;
-  }
   b->n_streams = uint32_t(streams.size());
   b->n_join_wgs = uint32_t(wgs.size());
   b->join_entries = entries;
@@ -1286,10 +1297,15 @@ bool launch_join(irs_hip_batch* b, rt::stream_t st) {
   } else {
     RT_LAUNCH((k_join<kScalar>), b->n_join_wgs, kThreads, 0, st, b->d_join_wgs.as<JoinWg>());
   }
-  if (b->fast16 && b->n_fast_pack_wgs) {   // fast.h: the streams once more as padded fast entries
-    RT_LAUNCH(k_fast_layout, b->n_streams, 64, 0, st, b->d_streams.as<StreamRec>(), b->n_streams);
-    RT_LAUNCH(k_fast_pack, b->n_fast_pack_wgs, kThreads, 0, st, b->d_streams.as<StreamRec>(),
-              b->d_fast_wg.as<uint32_t>(), b->n_streams);
+  if (b->pruned) {
+    // term-level pruning: the dense streams' doc bitmaps + rank directories and every such
+    // stream's score bound, from the entries just written
+    if (!rt::dmemset(b->d_stream_tmax.p, 0, b->d_stream_tmax.n, st) ||
+        !rt::dmemset(b->d_ms_stats.p, 0, b->d_ms_stats.n, st))
+      return false;
+    if (b->n_bits_wgs)
+      RT_LAUNCH(k_stream_bits, b->n_bits_wgs, kThreads, 0, st, b->d_bits_wgs.as<BitsWg>(),
+                b->d_stream_tmax.as<uint32_t>());
   }
   return rt::last_error_ok();
 }
@@ -1379,7 +1395,9 @@ bool launch_group_threshold(irs_hip_batch* b, rt::stream_t st) {
 
 bool launch_join_score(irs_hip_batch* b, rt::stream_t st) {
   const size_t smem = JoinOff::end;
-  if (!big_smem(k_join_score<false>, smem) || !big_smem(k_join_score<true>, smem)) return false;
+  if (!big_smem(k_join_score<false>, smem) || !big_smem(k_join_score<true>, smem) ||
+      !big_smem(k_join_ms, smem))
+    return false;
   const uint32_t waves = b->join_threads / 64;
   uint32_t per_cu = uint32_t((160u * 1024u) / smem);
   per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 32u / waves));
@@ -1393,7 +1411,7 @@ bool launch_join_score(irs_hip_batch* b, rt::stream_t st) {
   // two launches: the plain disjunctions, then the units whose accumulators count matches
   for (uint32_t part = 0; part < 2; ++part) {
     const uint32_t n_units = part ? n_all - b->n_join_plain : b->n_join_plain;
-    if (!n_units || (part == 0 && b->fast16)) continue;   // (fast.h runs the plain disjunctions)
+    if (!n_units) continue;
     const uint64_t chunks = uint64_t(n_units) * cpq;
     if (chunks > 0xFFFF0000ull) return false;
     const uint32_t grid = uint32_t(std::min<uint64_t>(chunks, uint64_t(b->seg->cus) * per_cu));
@@ -1406,6 +1424,8 @@ bool launch_join_score(irs_hip_batch* b, rt::stream_t st) {
     a.cand_count = b->d_cand_count.as<uint32_t>();
     a.hits = b->d_hits.as<unsigned long long>();
     a.order = b->d_join_order.as<uint32_t>();
+    a.split = (part == 0 && b->pruned) ? b->d_join_split.as<JoinSplit>() : nullptr;
+    a.ms_stats = (part == 0 && b->pruned) ? b->d_ms_stats.as<unsigned long long>() : nullptr;
     a.work_counter = b->d_join_ctr.as<uint32_t>() + part * kJoinQueues;
     uint32_t base = 0;
     for (uint32_t g = 0; g <= kJoinQueues; ++g) {
@@ -1434,6 +1454,13 @@ bool launch_join_score(irs_hip_batch* b, rt::stream_t st) {
     if (!rt::d2d(a.work_counter, d_init, sizeof b->join_ctr_init[part], st)) return false;
     if (part) {
       RT_LAUNCH(k_join_score<true>, grid, b->join_threads, smem, st, d_args);
+    } else if (b->pruned) {
+      // the units' term split first: needs the threshold bins the pilot just left
+      RT_LAUNCH(k_join_split, (n_units + 63u) / 64u, 64, 0, st, b->d_join_order.as<uint32_t>(), n_units,
+                b->d_queries.as<DevQuery>(), b->d_jterms.as<JoinTerm>(), b->d_streams.as<StreamRec>(),
+                b->d_stream_tmax.as<uint32_t>(), b->d_bstar.as<uint32_t>(), ms_alpha256(),
+                b->d_join_split.as<JoinSplit>(), b->d_ms_stats.as<unsigned long long>());
+      RT_LAUNCH(k_join_ms, grid, b->join_threads, smem, st, d_args);
     } else {
       RT_LAUNCH(k_join_score<false>, grid, b->join_threads, smem, st, d_args);
     }
@@ -1441,85 +1468,6 @@ bool launch_join_score(irs_hip_batch* b, rt::stream_t st) {
   return rt::last_error_ok();
 }
 
-
-// fast.h: the plain disjunctions of a joined batch — packed first pass, exact re-score
-bool launch_join_fast(irs_hip_batch* b, rt::stream_t st) {
-  const uint32_t n_units = b->n_join_plain;
-  if (!b->fast16 || !n_units) return true;
-  const size_t smem = FastOff::end;
-  if (!big_smem(k_join_fast, smem) || !big_smem(k_join_rescore, kRescoreSmem)) return false;
-  const uint32_t waves = b->join_threads / 64;
-  uint32_t per_cu = uint32_t((160u * 1024u) / smem);
-  per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 32u / waves));
-  const uint32_t tiles = (b->join_max_tiles + 1u) / 2u;   // packed tiles: two join.h tiles each
-  const uint32_t cpq = std::max<uint32_t>(1, (tiles + kFastChunkTiles - 1) / kFastChunkTiles);
-  const uint32_t chunk_tiles = std::max<uint32_t>(1, (tiles + cpq - 1) / cpq);
-  const uint64_t chunks = uint64_t(n_units) * cpq;
-  if (chunks > 0xFFFF0000ull) return false;
-  const uint32_t grid = uint32_t(std::min<uint64_t>(chunks, uint64_t(b->seg->cus) * per_cu));
-  if (!b->d_join_ctr.p && !b->d_join_ctr.alloc(2 * sizeof b->join_ctr_init)) return false;
-  FastArgs& a = b->fast_args;
-  a.queries = b->d_queries.as<DevQuery>();
-  a.fterms = b->d_fterms.as<FastTerm>();
-  a.dummies = reinterpret_cast<uint64_t>(b->d_fast_dummies.p);
-  a.bstar = b->d_bstar.as<uint32_t>();
-  a.cands = b->d_acands.as<uint64_t>();
-  a.cand_count = b->d_acand_count.as<uint32_t>();
-  a.hits = b->d_hits.as<unsigned long long>();
-  a.order = b->d_join_order.as<uint32_t>();
-  a.work_counter = b->d_join_ctr.as<uint32_t>();   // (the plain launch's counters: part 0)
-  uint32_t base = 0;
-  for (uint32_t g = 0; g <= kJoinQueues; ++g) {
-    a.first[g] = b->join_first[0][g];
-    a.base[g] = base;
-    if (g < kJoinQueues) {
-      b->join_ctr_init[0][g] = base;
-      base += (b->join_first[0][g + 1] - b->join_first[0][g]) * cpq;
-    }
-  }
-  a.cpq = cpq;
-  a.n_units = n_units;
-  a.nw_log2 = b->join_nw_log2;
-  a.cand_cap = b->cand_cap;
-  a.chunk_tiles = chunk_tiles;
-  if (b->d_fast_chunks.n < chunks * sizeof(FastChunk) && !b->d_fast_chunks.alloc(chunks * sizeof(FastChunk)))
-    return false;
-  a.chunks = b->d_fast_chunks.as<FastChunk>();
-  uint32_t* d_init = a.work_counter + 2 * kJoinQueues;
-  if (!b->fast_args_valid || std::memcmp(&a, &b->fast_args_sent, sizeof a) != 0) {
-    if (!b->up.copy(b->d_fast_args.p, &a, sizeof a) ||
-        !b->up.copy(d_init, b->join_ctr_init[0], sizeof b->join_ctr_init[0]) || !b->up.flush(st))
-      return false;
-    std::memcpy(&b->fast_args_sent, &a, sizeof a);
-    b->fast_args_valid = true;
-  }
-  RescoreArgs& r = b->rescore_args;
-  r.units = b->d_join_order.as<uint32_t>();   // (the plain units come first in the queue order)
-  r.queries = b->d_queries.as<DevQuery>();
-  r.qterms = b->d_qterms.as<DevQTerm>();
-  r.jterms = b->d_jterms.as<JoinTerm>();
-  r.bstar = b->d_bstar.as<uint32_t>();
-  r.acands = b->d_acands.as<uint64_t>();
-  r.acand_count = b->d_acand_count.as<uint32_t>();
-  r.cands = b->d_cands.as<uint64_t>();
-  r.cand_count = b->d_cand_count.as<uint32_t>();
-  r.cand_cap = b->cand_cap;
-  if (!b->rescore_args_valid || std::memcmp(&r, &b->rescore_args_sent, sizeof r) != 0) {
-    if (!b->up.copy(b->d_rescore_args.p, &r, sizeof r) || !b->up.flush(st)) return false;
-    std::memcpy(&b->rescore_args_sent, &r, sizeof r);
-    b->rescore_args_valid = true;
-  }
-  if (!rt::d2d(a.work_counter, d_init, sizeof b->join_ctr_init[0], st) ||
-      !rt::dmemset(b->d_acand_count.p, 0, b->d_acand_count.n, st))
-    return false;
-  static const bool trace = std::getenv("IRS_HIP_TRACE") != nullptr;
-  if (trace) std::fprintf(stderr, "[irs_hip] k_join_fast: %u units, %u chunks of %u tiles, grid %u\n", n_units, unsigned(chunks), chunk_tiles, grid);
-  RT_LAUNCH(k_fast_shares, uint32_t((chunks + kThreads - 1) / kThreads), kThreads, 0, st,
-            b->d_fast_args.as<FastArgs>(), b->d_fast_chunks.as<FastChunk>());
-  RT_LAUNCH(k_join_fast, grid, b->join_threads, smem, st, b->d_fast_args.as<FastArgs>());
-  RT_LAUNCH(k_join_rescore, n_units, kTileThreadsMax, kRescoreSmem, st, b->d_rescore_args.as<RescoreArgs>());
-  return rt::last_error_ok();
-}
 
 // k_conj work of the batch's block-driven conjunctions (conj_units): the lead term of a unit is
 // its first one (sorted by cost at create); one wavefront per 128-posting block of it (+ one for
@@ -1580,7 +1528,6 @@ bool ensure_scratch(irs_hip_batch* b) {
   if (b->scratch_ready) return true;
   HostTrace trace("ensure_scratch (units dealt, streams, work lists)");
   b->join_args_valid[0] = b->join_args_valid[1] = b->score_args_valid = false;
-  b->fast_args_valid = b->rescore_args_valid = false;
   if (b->phrase) b->tile = 0x40000000u;  // k_phrase is block driven: one "tile" = the segment
   // 32-bit accumulators halve the LDS per doc: twice the tile at the same residency
   // the largest tile that still lets two workgroups share a CU's 160 KB of LDS
@@ -1640,17 +1587,9 @@ bool ensure_scratch(irs_hip_batch* b) {
       if (build_conj_work(b) != IRS_HIP_OK) return false;
     }
     b->joined = !b->join_units.empty();
-    b->fast16 = false;
-    if (b->joined && fast16_allowed(b)) {
-      bool wide_tf = false;   // (a fast entry's 16-bit unit is scaled for frequencies below 64)
-      for (uint32_t u : b->join_units) {
-        const DevQuery& dq = b->queries[u];
-        b->fast16 = b->fast16 || query_need(dq.op) <= 1u;
-        for (uint32_t j = 0; j < dq.n_terms; ++j)
-          wide_tf = wide_tf || b->segs[dq.seg]->terms[b->qterms[dq.first_term + j].term].tf_bound > 63u;
-      }
-      if (wide_tf) b->fast16 = false;
-    }
+    b->pruned = false;
+    if (b->joined && ms_allowed(b))
+      for (uint32_t u : b->join_units) b->pruned = b->pruned || query_need(b->queries[u].op) <= 1u;
   }
   // 32-bit accumulators halve the LDS per doc: twice the tile at the same residency
   // the largest tile that still lets two workgroups share a CU's 160 KB of LDS
@@ -1747,11 +1686,6 @@ bool ensure_scratch(irs_hip_batch* b) {
       !b->d_out_count.alloc(b->nq * sizeof(uint32_t)) || !b->d_status.alloc(4) ||
       !b->d_work.alloc(16) || !b->d_touched.alloc(uint64_t(b->nq) * 16) ||
       !b->d_pruned.alloc(uint64_t(b->nq) * 4))
-    return false;
-  if (b->fast16 &&
-      (!b->d_acands.alloc(uint64_t(b->nq) * b->cand_cap * sizeof(uint64_t)) ||
-       !b->d_acand_count.alloc(b->nq * sizeof(uint32_t)) || !b->d_fast_args.alloc(sizeof(FastArgs)) ||
-       !b->d_rescore_args.alloc(sizeof(RescoreArgs))))
     return false;
   if (b->joined && !build_streams(b)) return false;
   if (!build_groups(b)) return false;
@@ -2554,7 +2488,7 @@ static int batch_configure_impl(irs_hip_batch* b, uint32_t tile_docs, uint32_t p
 }
 
 static int batch_set_path_impl(irs_hip_batch* b, int path) {
-  if (!b || path < IRS_HIP_PATH_AUTO || path > IRS_HIP_PATH_JOINED_EXACT) return IRS_HIP_EINVAL;
+  if (!b || path < IRS_HIP_PATH_AUTO || path > IRS_HIP_PATH_JOINED_PRUNED) return IRS_HIP_EINVAL;
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
   if (b->ran && !rt::sync(b->stream)) return IRS_HIP_EHIP;
   b->path_pref = path;
@@ -2708,6 +2642,17 @@ static int batch_touched_impl(irs_hip_batch* b, uint64_t* doc_bytes, uint64_t* p
   return IRS_HIP_OK;
 }
 
+static int batch_pruning_impl(irs_hip_batch* b, uint64_t stats[4]) {
+  if (!b || !stats || !b->ran) return IRS_HIP_EINVAL;
+  stats[0] = stats[1] = stats[2] = stats[3] = 0;
+  if (!b->pruned || !b->d_ms_stats.p) return IRS_HIP_OK;
+  if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
+  static_assert(kMsStats == 4, "irs_hip_batch_pruning");
+  if (!rt::d2h(stats, b->d_ms_stats.p, kMsStats * 8, b->stream) || !rt::sync(b->stream))
+    return IRS_HIP_EHIP;
+  return IRS_HIP_OK;
+}
+
 static int batch_profile_impl(irs_hip_batch* b, int enable) {
   if (!b) return IRS_HIP_EINVAL;
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
@@ -2803,7 +2748,7 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st) {
     ok = ok && (simd ? launch_phrase_terms<kSimd4>(b, st) : launch_phrase_terms<kScalar>(b, st));
   else if (tiles)
     ok = ok && (simd ? launch_score_acc<kSimd4>(b, st) : launch_score_acc<kScalar>(b, st));
-  if (b->joined) ok = ok && launch_join_fast(b, st) && launch_join_score(b, st);
+  if (b->joined) ok = ok && launch_join_score(b, st);
   if (!b->phrase) ok = ok && (simd ? launch_conj<kSimd4>(b, st) : launch_conj<kScalar>(b, st));
   ok = ok && mark(2 * IRS_HIP_K_SCORE + 1);
   // 4. exact top-k
@@ -2892,9 +2837,7 @@ static int recover(irs_hip_batch* b, uint32_t status) {
     b->stride_eff = std::min<uint32_t>(b->stride_eff, 16);
     const uint32_t cap = default_cand_cap(b);  // the sound threshold admits more candidates
     if (cap > b->cand_cap) {
-      if (!b->d_cands.alloc(uint64_t(b->nq) * cap * sizeof(uint64_t)) ||
-          (b->fast16 && !b->d_acands.alloc(uint64_t(b->nq) * cap * sizeof(uint64_t))))
-        return IRS_HIP_ENOMEM;
+      if (!b->d_cands.alloc(uint64_t(b->nq) * cap * sizeof(uint64_t))) return IRS_HIP_ENOMEM;
       b->cand_cap = cap;
     }
     const int rc = run_impl(b, b->stream);
@@ -2928,9 +2871,7 @@ static int recover_overflow(irs_hip_batch* b) {
     if (b->comm && need - 1024 <= b->cand_cap) {
       // (the overflow is another rank's: this one only takes part in the re-run's collectives)
     } else if (need > b->cand_cap && affordable) {
-      if (!b->d_cands.alloc(need * b->nq * sizeof(uint64_t)) ||
-          (b->fast16 && !b->d_acands.alloc(need * b->nq * sizeof(uint64_t))))
-        return IRS_HIP_ENOMEM;
+      if (!b->d_cands.alloc(need * b->nq * sizeof(uint64_t))) return IRS_HIP_ENOMEM;
       b->cand_cap = uint32_t(need);
     } else if (b->stride_eff != 1) {
       b->stride_eff = 1;
@@ -3226,6 +3167,9 @@ int irs_hip_topk_allgather(irs_hip_comm* c, const void* d_send, void* d_recv,
 }
 int irs_hip_batch_touched(irs_hip_batch* b, uint64_t* doc_bytes, uint64_t* positions) {
   return guarded([&] { return batch_touched_impl(b, doc_bytes, positions); });
+}
+int irs_hip_batch_pruning(irs_hip_batch* b, uint64_t stats[4]) {
+  return guarded([&] { return batch_pruning_impl(b, stats); });
 }
 int irs_hip_batch_plan(irs_hip_batch* b, void* stream) {
   return guarded([&] { return batch_plan_impl(b, stream); });

@@ -144,9 +144,7 @@ struct DevQuery {
   uint32_t run_unit;
   uint32_t tile_base;   // index of the unit's first doc tile in the batch-wide per-tile tables
                         // (DevQuery n_tiles summed over the units in front of it)
-  float s16;            // fast.h: 16-bit accumulator units per unit of score (the unit's packed
-                        // first pass: every doc's approximate sum stays below 2^15)
-  uint32_t pad_q;
+  uint32_t pad_q[2];
 };
 
 struct DevQTerm {

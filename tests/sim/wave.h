@@ -84,19 +84,6 @@ __device__ __forceinline__ uint32_t bfe(uint32_t x, uint32_t bits) { return x & 
 __device__ __forceinline__ uint64_t undef64() { return 0; }
 __device__ __forceinline__ void undef4(uint32_t (&v)[4]) { v[0] = v[1] = v[2] = v[3] = 0xDEADBEEFu; }
 __device__ __forceinline__ uint32_t mul_hi(uint32_t a, uint32_t b) { return uint32_t((uint64_t(a) * b) >> 32); }
-__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
-  const uint32_t lo = (a & 0xFFFFu) < (b & 0xFFFFu) ? (a & 0xFFFFu) : (b & 0xFFFFu);
-  const uint32_t hi = (a >> 16) < (b >> 16) ? (a >> 16) : (b >> 16);
-  return (hi << 16) | lo;
-}
-__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
-  const uint32_t lo = (a & 0xFFFFu) > (b & 0xFFFFu) ? (a & 0xFFFFu) : (b & 0xFFFFu);
-  const uint32_t hi = (a >> 16) > (b >> 16) ? (a >> 16) : (b >> 16);
-  return (hi << 16) | lo;
-}
-__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {
-  return (((a >> 16) + (b >> 16)) << 16) | ((a + b) & 0xFFFFu);
-}
 template<typename T>
 __device__ __forceinline__ void count_nonzero4(uint32_t& acc, T a, T b, T c, T d) {
   acc += uint32_t(a != 0) + uint32_t(b != 0) + uint32_t(c != 0) + uint32_t(d != 0);
@@ -117,6 +104,14 @@ __device__ __forceinline__ void lds_add(const unsigned char* base, uint32_t off,
 }
 __device__ __forceinline__ void lds_add(const unsigned char* base, uint32_t off, unsigned long long v) {
   atomicAdd(reinterpret_cast<unsigned long long*>(const_cast<unsigned char*>(base) + off), v);
+}
+__device__ __forceinline__ uint32_t lds_take(unsigned char* base, uint32_t off) {
+  return __atomic_exchange_n(reinterpret_cast<uint32_t*>(base + off), 0u, __ATOMIC_RELAXED);
+}
+__device__ __forceinline__ uint32_t lds_u32(const unsigned char* base, uint32_t off) {
+  uint32_t v;
+  __builtin_memcpy(&v, base + off, 4);
+  return v;
 }
 __device__ __forceinline__ void lds_read4(const unsigned char* base, uint32_t off, uint32_t (&v)[4]) {
   __builtin_memcpy(v, base + off, 16);
@@ -146,6 +141,16 @@ __device__ __forceinline__ uint32_t gload_u32(uint64_t base, uint32_t off) {
 }
 __device__ __forceinline__ void gload_u32x4(uint64_t base, uint32_t off, uint32_t (&v)[4]) {
   __builtin_memcpy(v, reinterpret_cast<const uint8_t*>(base) + off, 16);
+}
+__device__ __forceinline__ uint32_t gload_u32_at(uint64_t addr) {
+  uint32_t v;
+  __builtin_memcpy(&v, reinterpret_cast<const uint8_t*>(addr), 4);
+  return v;
+}
+__device__ __forceinline__ uint32_t gload_u16_at(uint64_t addr) {
+  uint16_t v;
+  __builtin_memcpy(&v, reinterpret_cast<const uint8_t*>(addr), 2);
+  return v;
 }
 __device__ __forceinline__ void gload_u32x4_at(uint64_t addr, uint32_t (&v)[4]) {
   __builtin_memcpy(v, reinterpret_cast<const uint8_t*>(addr), 16);

@@ -80,7 +80,7 @@ def main():
         line = "%-9s refs %7.1f M  distinct %7.1f M  unit-tiles %7d " % (
             shape, refs / 1e6, distinct / 1e6, nq * tiles)
         out = {}
-        for name, path in (("items", _lib.PATH_ITEMS), ("joined", _lib.PATH_JOINED_EXACT),
+        for name, path in (("items", _lib.PATH_ITEMS), ("joined", _lib.PATH_JOINED),
                            ("auto", _lib.PATH_AUTO)):
             arrays = search.prepare_disjunctions(rows, scorer, [st], [sr], args.k)
             b = search.QueryBatch(sr, arrays).set_path(path).profile(True)
