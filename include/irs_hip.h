@@ -45,7 +45,10 @@ typedef enum irs_hip_status {
   IRS_HIP_ENOMEM = -3,
   IRS_HIP_EHIP = -4,         /* HIP runtime failure / no gfx950 device    */
   IRS_HIP_EOVERFLOW = -5,    /* candidates exceed the memory budget even after the exact re-run */
-  IRS_HIP_EUNSUPPORTED = -6
+  IRS_HIP_EUNSUPPORTED = -6,
+  IRS_HIP_EPEER = -7         /* a batch with a communicator (irs_hip_batch_set_comm): ANOTHER rank
+                              * could not re-execute its batch; no rank did, the results are not
+                              * valid (this rank's own failure is reported as what it was) */
 } irs_hip_status;
 
 typedef enum irs_hip_layout {

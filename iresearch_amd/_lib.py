@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _build
 
-OK, EINVAL, ECORRUPT, ENOMEM, EHIP, EOVERFLOW, EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
+OK, EINVAL, ECORRUPT, ENOMEM, EHIP, EOVERFLOW, EUNSUPPORTED, EPEER = 0, -1, -2, -3, -4, -5, -6, -7
 LAYOUT_SCALAR, LAYOUT_SIMD4 = 0, 1
 OP_OR, OP_AND, OP_MINMATCH, OP_PHRASE = 0, 1, 2, 3
 SCORE_BM25, SCORE_BM15, SCORE_BM1, SCORE_TFIDF, SCORE_TFIDF_NORM = 0, 1, 2, 3, 4

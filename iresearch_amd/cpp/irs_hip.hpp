@@ -39,7 +39,7 @@ struct error : std::runtime_error {
 };
 struct illegal_argument : error { using error::error; };   // IRS_HIP_EINVAL
 struct index_error : error { using error::error; };        // IRS_HIP_ECORRUPT
-struct io_error : error { using error::error; };           // IRS_HIP_EHIP / ENOMEM / EOVERFLOW
+struct io_error : error { using error::error; };           // IRS_HIP_EHIP / ENOMEM / EOVERFLOW / EPEER
 struct not_supported : error { using error::error; };      // IRS_HIP_EUNSUPPORTED
 
 inline void check(int rc, const char* what) {

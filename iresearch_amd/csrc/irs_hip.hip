@@ -312,6 +312,10 @@ struct irs_hip_batch {
   DevBuf d_min_bin;   // [unit] score bin of the caller's irs::score::Min (irs_hip_batch_set_min_scores)
   DevBuf d_min_score; // [unit] ... and the score itself (k_select's exact filter)
   bool has_min = false;
+  // the caller's scores themselves: their bins are worked out when a run's tables go out — AFTER
+  // ensure_scratch, which may change a unit's bin_scale (build_groups across ranks)
+  std::vector<float> min_scores;   // [unit]
+  bool min_dirty = false;
   uint32_t conj_total_items = 0;
   DevBuf d_conj_pilot;             // the lead items the pilot pass samples, {unit, item} each
   uint32_t n_conj_pilot = 0, conj_pilot_stride = 0;
@@ -361,6 +365,7 @@ struct irs_hip_batch {
   // ... across ranks (irs_hip_batch_set_comm): the group histograms and the group sums are summed
   // over the communicator's ranks inside every run
   irs_hip_comm* comm = nullptr;
+  DevBuf d_agree;   // one word: the ranks' vote before a collective re-run (all_ranks_can)
   std::vector<double> group_upper;   // [unit] a score bound that is the same on every segment, 0: none
   JoinArgs join_args[2]{};   // plain disjunctions / units with match counts
   JoinArgs join_args_sent[2]{};   // ... as the device last got them
@@ -380,7 +385,11 @@ struct irs_hip_batch {
   // irs_hip_batch_plan: the planning stage of the NEXT run was queued ahead (on another stream)
   rt::event_t ev_planned{};
   bool ev_planned_ready = false;
-  bool planned = false;
+  bool planned = false;        // ... and the next run may use it (same geometry)
+  // a plan stage is queued on some stream and may still be running — whether or not the next run
+  // will use its tables (`planned` is dropped by every setter that re-deals the units; the kernels
+  // it queued keep reading and writing the batch's buffers until ev_planned)
+  bool plan_pending = false;
   uint32_t* h_status = nullptr;
   PinBuf h_status_buf;
   rt::stream_t stream = nullptr;
@@ -1439,6 +1448,10 @@ bool launch_join_score(irs_hip_batch* b, rt::stream_t st) {
     a.cpq = cpq;
     a.n_units = n_units;
     a.nw_log2 = b->join_nw_log2;
+    if (const char* e = std::getenv("IRS_HIP_JOIN_SPLIT_LOG2")) {   // tuning knob: a tile's entries
+      const uint32_t v = uint32_t(std::atoi(e));                   // among the first 2^v wavefronts only
+      if (v < a.nw_log2) a.nw_log2 = v;
+    }
     a.cand_cap = b->cand_cap;
     a.chunk_tiles = chunk_tiles;
     JoinArgs* d_args = b->d_join_args.as<JoinArgs>() + part;
@@ -1528,6 +1541,7 @@ bool ensure_scratch(irs_hip_batch* b) {
   if (b->scratch_ready) return true;
   HostTrace trace("ensure_scratch (units dealt, streams, work lists)");
   b->join_args_valid[0] = b->join_args_valid[1] = b->score_args_valid = false;
+  b->min_dirty = b->has_min;   // (a unit's bin_scale may change below: build_groups)
   if (b->phrase) b->tile = 0x40000000u;  // k_phrase is block driven: one "tile" = the segment
   // 32-bit accumulators halve the LDS per doc: twice the tile at the same residency
   // the largest tile that still lets two workgroups share a CU's 160 KB of LDS
@@ -1738,6 +1752,7 @@ const char* irs_hip_strerror(int status) {
     case IRS_HIP_EHIP: return "HIP runtime error or no gfx950 device";
     case IRS_HIP_EOVERFLOW: return "candidate buffer overflow";
     case IRS_HIP_EUNSUPPORTED: return "unsupported";
+    case IRS_HIP_EPEER: return "another rank could not re-execute its batch";
     default: return "unknown status";
   }
 }
@@ -2470,6 +2485,18 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
   return IRS_HIP_OK;
 }
 
+// Before a setter re-deals the units (buffers are reallocated, tables rewritten): whatever of the
+// batch is still queued must be through — its last run AND a plan stage queued ahead.
+static bool quiesce(irs_hip_batch* b) {
+  bool ok = true;
+  if (b->plan_pending) {
+    ok = b->ev_planned_ready && rt::event_sync(b->ev_planned);
+    b->plan_pending = false;
+  }
+  if (b->ran) ok = rt::sync(b->stream) && ok;
+  return ok;
+}
+
 static int batch_configure_impl(irs_hip_batch* b, uint32_t tile_docs, uint32_t pilot_stride,
                             uint32_t cand_cap) {
   if (!b) return IRS_HIP_EINVAL;
@@ -2478,7 +2505,7 @@ static int batch_configure_impl(irs_hip_batch* b, uint32_t tile_docs, uint32_t p
     return IRS_HIP_EINVAL;
   if (cand_cap && cand_cap < b->k_max) return IRS_HIP_EINVAL;
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
-  if (b->ran && !rt::sync(b->stream)) return IRS_HIP_EHIP;
+  if (!quiesce(b)) return IRS_HIP_EHIP;
   if (!b->phrase) b->tile_asked = b->tile = tile_docs;  // phrase tiles are fixed; 0: by the units' needs
   if (pilot_stride) b->stride = pilot_stride;
   b->cand_cap = cand_cap;
@@ -2490,7 +2517,7 @@ static int batch_configure_impl(irs_hip_batch* b, uint32_t tile_docs, uint32_t p
 static int batch_set_path_impl(irs_hip_batch* b, int path) {
   if (!b || path < IRS_HIP_PATH_AUTO || path > IRS_HIP_PATH_JOINED_PRUNED) return IRS_HIP_EINVAL;
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
-  if (b->ran && !rt::sync(b->stream)) return IRS_HIP_EHIP;
+  if (!quiesce(b)) return IRS_HIP_EHIP;
   b->path_pref = path;
   b->scratch_ready = false;
   b->planned = false;   // (a plan queued ahead was made for the other path)
@@ -2500,7 +2527,7 @@ static int batch_set_path_impl(irs_hip_batch* b, int path) {
 static int batch_set_shared_threshold_impl(irs_hip_batch* b, int enable) {
   if (!b) return IRS_HIP_EINVAL;
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
-  if (b->ran && !rt::sync(b->stream)) return IRS_HIP_EHIP;
+  if (!quiesce(b)) return IRS_HIP_EHIP;
   b->shared_threshold = enable != 0;
   b->scratch_ready = false;
   b->planned = false;
@@ -2510,7 +2537,8 @@ static int batch_set_shared_threshold_impl(irs_hip_batch* b, int enable) {
 static int batch_set_comm_impl(irs_hip_batch* b, irs_hip_comm* comm) {
   if (!b) return IRS_HIP_EINVAL;
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
-  if (b->ran && !rt::sync(b->stream)) return IRS_HIP_EHIP;
+  if (!quiesce(b)) return IRS_HIP_EHIP;
+  if (comm && !b->d_agree.p && !b->d_agree.alloc(64)) return IRS_HIP_ENOMEM;
   b->comm = comm;
   b->scratch_ready = false;
   b->planned = false;
@@ -2527,6 +2555,7 @@ static int batch_set_wand_impl(irs_hip_batch* b, int enable) {
   if (!b) return IRS_HIP_EINVAL;
   if (b->ran) return IRS_HIP_EINVAL;   // before the first run: the segment records are uploaded once
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
+  if (!quiesce(b)) return IRS_HIP_EHIP;
   b->wand = enable != 0;
   // a plan queued ahead (irs_hip_batch_plan) was made without the tile bounds: run() re-plans
   b->planned = false;
@@ -2550,23 +2579,36 @@ static int batch_set_min_scores_impl(irs_hip_batch* b, const float* min_scores) 
     return IRS_HIP_OK;
   }
   const uint32_t nq_user = b->nq / uint32_t(b->segs.size());
-  std::vector<uint32_t> bins(b->nq, 0u);
   std::vector<float> mins(b->nq, 0.f);
   for (uint32_t u = 0; u < b->nq; ++u) {
     const float m = min_scores[u % nq_user];
     if (!(m >= 0.f)) return IRS_HIP_EINVAL;   // (also NaN)
     mins[u] = m;
+  }
+  if (!quiesce(b)) return IRS_HIP_EHIP;
+  if (!b->d_min_bin.alloc(mins.size() * 4) || !b->d_min_score.alloc(mins.size() * 4))
+    return IRS_HIP_ENOMEM;
+  b->min_scores.swap(mins);
+  b->has_min = true;
+  b->min_dirty = true;   // (the bins go out with the next run: stage_min_bins)
+  return IRS_HIP_OK;
+}
+
+// The caller's min scores as score bins, in the scale the units bin with NOW: ensure_scratch may
+// have re-scaled a unit (build_groups: one bound for a query on every rank), so this runs behind it.
+static bool stage_min_bins(irs_hip_batch* b) {
+  if (!b->has_min || !b->min_dirty) return true;
+  std::vector<uint32_t> bins(b->nq, 0u);
+  for (uint32_t u = 0; u < b->nq; ++u) {
     // the bin score_bin() puts a score of m into: docs at or above m land in it or higher
-    const float x = std::fmin(m * b->queries[u].bin_scale, float(kBins - 1));
+    const float x = std::fmin(b->min_scores[u] * b->queries[u].bin_scale, float(kBins - 1));
     bins[u] = uint32_t(x);
   }
-  if (b->ran && !rt::sync(b->stream)) return IRS_HIP_EHIP;
-  if (!b->d_min_bin.alloc(bins.size() * 4) || !b->d_min_score.alloc(mins.size() * 4) ||
-      !b->up.copy(b->d_min_bin.p, bins.data(), bins.size() * 4) ||
-      !b->up.copy(b->d_min_score.p, mins.data(), mins.size() * 4))
-    return IRS_HIP_ENOMEM;
-  b->has_min = true;
-  return IRS_HIP_OK;
+  if (!b->up.copy(b->d_min_bin.p, bins.data(), bins.size() * 4) ||
+      !b->up.copy(b->d_min_score.p, b->min_scores.data(), b->min_scores.size() * 4))
+    return false;
+  b->min_dirty = false;
+  return true;
 }
 
 static int term_blockmax_impl(irs_hip_segment* seg, uint32_t term, uint32_t* max_freqs,
@@ -2687,20 +2729,23 @@ static bool plan_stage(irs_hip_batch* b, rt::stream_t st) {
 static int batch_plan_impl(irs_hip_batch* b, void* stream) {
   if (!b) return IRS_HIP_EINVAL;
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
-  if (!ensure_scratch(b)) return IRS_HIP_ENOMEM;
+  if (!ensure_scratch(b) || !stage_min_bins(b)) return IRS_HIP_ENOMEM;
   rt::stream_t st = static_cast<rt::stream_t>(stream);
   bool ok = true;
   if (!b->ev_planned_ready) ok = b->ev_planned_ready = rt::event_create(&b->ev_planned);
   // (the tables are rewritten: the batch's own previous run must be through with them)
   if (ok && b->ev_done_ready && b->ran) ok = rt::stream_wait(st, b->ev_done);
+  // (a plan queued earlier and never consumed may still run on ANOTHER stream)
+  if (ok && b->plan_pending) ok = rt::stream_wait(st, b->ev_planned);
   ok = ok && b->up.flush(st) && plan_stage(b, st) && rt::event_record(b->ev_planned, st);
   b->planned = ok;
+  b->plan_pending = b->plan_pending || b->ev_planned_ready;   // (whatever got queued)
   return ok ? IRS_HIP_OK : IRS_HIP_EHIP;
 }
 
 static int run_impl(irs_hip_batch* b, rt::stream_t st) {
   HostTrace trace("batch_run (scratch + uploads + launches queued)");
-  if (!ensure_scratch(b)) return IRS_HIP_ENOMEM;
+  if (!ensure_scratch(b) || !stage_min_bins(b)) return IRS_HIP_ENOMEM;
   b->stream = st;
   const bool simd = b->seg->dev.layout == kSimd4;
   auto mark = [&](int i) { return !b->profile || rt::event_record(b->ev[i], st); };
@@ -2708,7 +2753,13 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st) {
   // first run on the device's copy stream (nothing on the GPU reads or writes these buffers yet),
   // afterwards in the run's own stream order (a running kernel may still read what they replace)
   bool ok = true;
+  // a plan stage that is still queued (used below, or made stale by a setter) reads and writes
+  // the tables this run uploads and rewrites: both streams get behind it
+  const bool after_plan = b->plan_pending && b->ev_planned_ready;
+  if (after_plan) ok = rt::stream_wait(st, b->ev_planned);
   rt::stream_t up_st = (!b->ran && !b->up.pending.empty()) ? upload_stream(b->seg->device) : nullptr;
+  if (up_st && after_plan) ok = ok && rt::stream_wait(up_st, b->ev_planned);
+  b->plan_pending = false;
   if (up_st) {
     if (!b->ev_up_ready) ok = b->ev_up_ready = rt::event_create(&b->ev_up);
     ok = ok && b->up.flush(up_st) && rt::event_record(b->ev_up, up_st) && rt::stream_wait(st, b->ev_up);
@@ -2810,6 +2861,25 @@ static int batch_run_impl(irs_hip_batch* b, void* stream) {
 //     first with a full histogram pass (stride 1), then with the buffer grown to
 //     the largest candidate count seen.
 // Results are never silently truncated.
+// Recovery of a batch whose threshold spans ranks (irs_hip_batch_set_comm) is decided by ALL ranks
+// or by none.  Every rank enters recover() together — the status bits are all-reduced inside the
+// run — but whether a rank CAN re-run is its own business (memory for a larger candidate buffer,
+// an overflow it cannot afford): one that returned by itself would leave the others waiting in the
+// re-run's collectives for ever.  So each such exit is a vote: the ranks all-reduce "I cannot", and
+// a re-run happens only when the sum is zero.  local_rc: what this rank would return by itself
+// (IRS_HIP_OK: it can go on).  Returns IRS_HIP_OK when every rank can, this rank's own error when
+// it cannot, IRS_HIP_EPEER when only others cannot.  Without a communicator: local_rc.
+static int all_ranks_can(irs_hip_batch* b, int local_rc) {
+  if (!b->comm || b->phrase) return local_rc;
+  uint32_t vote = local_rc == IRS_HIP_OK ? 0u : 1u;
+  if (!b->d_agree.p || !rt::h2d(b->d_agree.p, &vote, 4, b->stream) ||
+      !rt::comm::all_reduce_u32(b->comm->h, b->d_agree.p, 1, b->stream) ||
+      !rt::d2h(&vote, b->d_agree.p, 4, b->stream) || !rt::sync(b->stream))
+    return local_rc != IRS_HIP_OK ? local_rc : IRS_HIP_EHIP;
+  if (local_rc != IRS_HIP_OK) return local_rc;
+  return vote ? IRS_HIP_EPEER : IRS_HIP_OK;
+}
+
 static int recover_overflow(irs_hip_batch* b);
 static int recover(irs_hip_batch* b, uint32_t status) {
   ++b->reruns;
@@ -2836,10 +2906,12 @@ static int recover(irs_hip_batch* b, uint32_t status) {
     // keeps the candidate buffer of a large batch (units x cap x 8 bytes) in bounds
     b->stride_eff = std::min<uint32_t>(b->stride_eff, 16);
     const uint32_t cap = default_cand_cap(b);  // the sound threshold admits more candidates
+    int can = IRS_HIP_OK;
     if (cap > b->cand_cap) {
-      if (!b->d_cands.alloc(uint64_t(b->nq) * cap * sizeof(uint64_t))) return IRS_HIP_ENOMEM;
-      b->cand_cap = cap;
+      if (b->d_cands.alloc(uint64_t(b->nq) * cap * sizeof(uint64_t))) b->cand_cap = cap;
+      else can = IRS_HIP_ENOMEM;
     }
+    if (const int all = all_ranks_can(b, can)) return all;
     const int rc = run_impl(b, b->stream);
     if (rc != IRS_HIP_OK) return rc;
     if (!rt::d2h(&status, b->d_status.p, 4, b->stream) || !rt::sync(b->stream))
@@ -2868,16 +2940,18 @@ static int recover_overflow(irs_hip_batch* b) {
         while (seen < need && !sg->cand_cap_hint.compare_exchange_weak(seen, uint32_t(need))) {}
       }
     }
+    int can = IRS_HIP_OK;
     if (b->comm && need - 1024 <= b->cand_cap) {
       // (the overflow is another rank's: this one only takes part in the re-run's collectives)
     } else if (need > b->cand_cap && affordable) {
-      if (!b->d_cands.alloc(need * b->nq * sizeof(uint64_t))) return IRS_HIP_ENOMEM;
-      b->cand_cap = uint32_t(need);
+      if (b->d_cands.alloc(need * b->nq * sizeof(uint64_t))) b->cand_cap = uint32_t(need);
+      else can = IRS_HIP_ENOMEM;
     } else if (b->stride_eff != 1) {
       b->stride_eff = 1;
     } else {
-      return IRS_HIP_EOVERFLOW;
+      can = IRS_HIP_EOVERFLOW;
     }
+    if (const int all = all_ranks_can(b, can)) return all;
     int rc = run_impl(b, b->stream);
     if (rc != IRS_HIP_OK) return rc;
     uint32_t status = 0;
@@ -2997,7 +3071,8 @@ void irs_hip_batch_destroy(irs_hip_batch* b) {
   // Not the whole stream: the caller may have queued the NEXT batch behind this one.
   bool waited = true;
   if (b->ran) waited = b->ev_done_ready && rt::event_sync(b->ev_done);
-  if (b->planned) waited = waited && b->ev_planned_ready && rt::event_sync(b->ev_planned);
+  if (b->planned || b->plan_pending)
+    waited = waited && b->ev_planned_ready && rt::event_sync(b->ev_planned);
   if (b->ev_used_pending) waited = waited && rt::event_sync(b->ev_used);
   if (!waited && b->ran) rt::sync(b->stream);
   if (b->events_ready)

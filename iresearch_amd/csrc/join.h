@@ -57,6 +57,17 @@ constexpr uint32_t kMsBitsTiles = 8;      // doc tiles per k_stream_bits workgro
 enum : uint32_t { kMsUnits = 0, kMsPostings = 1, kMsBytes = 2, kMsLookups = 3, kMsStats = 4 };
 // units that need per-doc match counts (conjunctions, min-match): the low 4 bits of an
 // accumulator count matches (so at most 15 terms), contributions are rounded to multiples of 16
+// ablation hooks of k_join_score (tools/build_variant.sh rewrites them; the product builds with 0):
+// entry counts shifted right (what leaving out a share of the postings would buy), no hit
+// counting, an epilogue that only clears / does nothing, accumulation without its LDS adds /
+// table reads, empty shares that still wait for their requested entries, no barriers
+constexpr uint32_t kAblShift = 0;
+constexpr uint32_t kAblCount = 0;
+constexpr uint32_t kAblEpi = 0;
+constexpr uint32_t kAblNoAdd = 0;
+constexpr uint32_t kAblNoTab = 0;
+constexpr uint32_t kAblWait = 0;
+constexpr uint32_t kAblNoBar = 0;
 constexpr uint32_t kJoinCountMask = 15u;
 constexpr uint32_t kJoinCountTerms = 15u;
 constexpr float kJoinCountRound = 8.f;
@@ -378,7 +389,7 @@ __device__ __forceinline__ void join_post(const unsigned char* lds, const uint32
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     const uint32_t at = (FORM == kJTable) ? ((e[k] & 0xFFFFu) | tabofs) : ((e[k] & 0x3FCu) | tabofs);
-    t[k] = wave::lds_f32(lds, JoinOff::caches + at);
+    t[k] = kAblNoTab ? __uint_as_float(at | 0x3F000000u) : wave::lds_f32(lds, JoinOff::caches + at);
   }
 #pragma unroll
   for (int k = 0; k < N; ++k) wave::keep_f(t[k]);
@@ -397,7 +408,10 @@ __device__ __forceinline__ void join_post(const unsigned char* lds, const uint32
     }
   }
 #pragma unroll
-  for (int k = 0; k < N; ++k) wave::lds_add(lds, JoinOff::acc + (e[k] >> 16), fx[k]);
+  for (int k = 0; k < N; ++k) {
+    if (kAblNoAdd) wave::keep(fx[k]);
+    else wave::lds_add(lds, JoinOff::acc + (e[k] >> 16), fx[k]);
+  }
 }
 // `slabs` (1..4, wave-uniform) of them
 template<int FORM, bool COUNT>
@@ -551,7 +565,10 @@ __device__ __forceinline__ void join_finish(const unsigned char* lds, JoinRun& r
   // (the run's scalars crossed a barrier and a loop back edge inside a struct: the compiler no
   // longer knows they are wave-uniform and would predicate everything below lane by lane)
   const uint32_t pre = wave::uniform(r.pre);
-  if (!pre) return;   // (nothing requested: nothing at all)
+  if (!pre) {   // (nothing requested: nothing at all)
+    if (kAblWait) wave::keep_all(r.e);
+    return;
+  }
   constexpr bool SIMPLE = (M & kJSimple) != 0;
   const uint32_t mode0 = SIMPLE ? 0u : wave::uniform(r.mode);
   const float cs0 = wave::uniform_f(r.cs);
@@ -931,7 +948,7 @@ __device__ __forceinline__ void join_tiles(unsigned char* smem, const JoinTileCt
     uint32_t a = 0, n = 0, c = 0;
     if (lane < kMaxTerms && u < ntile) {
       a = rng[u * kMaxTerms + lane];
-      n = rng[(u + 1u) * kMaxTerms + lane] - a;
+      n = (rng[(u + 1u) * kMaxTerms + lane] - a) >> kAblShift;
       c = cum[u * kMaxTerms + lane];
     }
     join_begin<M>(r, T, a, n, c, wv, nw_log2, safe, lane);
@@ -944,7 +961,7 @@ __device__ __forceinline__ void join_tiles(unsigned char* smem, const JoinTileCt
   begin(1, r1);
   // barrier B1 + epilogue + barrier B2 of tile u
   auto end_tile = [&](uint32_t u) {
-    __syncthreads();   // B1: every accumulation of tile u has landed
+    if (!kAblNoBar) __syncthreads();   // B1: every accumulation of tile u has landed
     const uint32_t doc0 = kDocMin + (tile0 + u) * kJoinTile;
     auto candidate = [&](uint32_t i, uint32_t f) {   // rare
       const float v = COUNT ? from_fixed<uint32_t>(f & ~kJoinCountMask, ctx.fx_inv)
@@ -971,9 +988,10 @@ __device__ __forceinline__ void join_tiles(unsigned char* smem, const JoinTileCt
           my_hits += m ? 1u : 0u;
           v[k] = m ? v[k] : 0u;
         }
-      } else {
+      } else if (!kAblCount) {
         wave::count_nonzero4(my_hits, v[0], v[1], v[2], v[3]);
       }
+      if (kAblEpi) return;
       uint32_t top = v[0] > v[1] ? v[0] : v[1];
       const uint32_t top2 = v[2] > v[3] ? v[2] : v[3];
       top = top > top2 ? top : top2;
@@ -989,7 +1007,7 @@ __device__ __forceinline__ void join_tiles(unsigned char* smem, const JoinTileCt
       }
     };
     const uint32_t step = blockDim.x * 4u;
-    uint32_t i = tid * 4u;
+    uint32_t i = kAblEpi >= 2u ? kJoinTile : tid * 4u;
     for (; i + step < kJoinTile; i += 2u * step) {
       uint32_t v0[4], v1[4];
       wave::lds_take4x2(smem, JoinOff::acc + i * 4u, JoinOff::acc + (i + step) * 4u, v0, v1);
@@ -1001,7 +1019,7 @@ __device__ __forceinline__ void join_tiles(unsigned char* smem, const JoinTileCt
       wave::lds_take4(smem, JoinOff::acc + i * 4u, v0);
       four(i, v0);
     }
-    __syncthreads();   // B2: accumulators are clear again
+    if (!kAblNoBar) __syncthreads();   // B2: accumulators are clear again
   };
   // straight-line pairs of tiles (the compiler's wait-count bookkeeping only sees the fixed
   // distance between a run's loads and its use when no branch separates the two register
@@ -1122,7 +1140,7 @@ k_join_score(const JoinArgs* __restrict__ args) {
         const uint32_t i = e / kMaxTerms, j = e % kMaxTerms;
         uint32_t c = 0;
         for (uint32_t t = 0; t <= j; ++t)
-          c += rng[(i + 1u) * kMaxTerms + t] - rng[i * kMaxTerms + t];
+          c += (rng[(i + 1u) * kMaxTerms + t] - rng[i * kMaxTerms + t]) >> kAblShift;
         cum[e] = c;
       }
       __syncthreads();
