@@ -317,19 +317,12 @@ int irs_hip_batch_configure(irs_hip_batch* batch, uint32_t tile_docs,
  *   IRS_HIP_PATH_JOINED  every DISTINCT (segment, term) of the batch is decoded once per run
  *                        into streams of entries which the queries then only accumulate — what
  *                        block_disjunction::refill (disjunction.hpp:1240-1351) does per query,
- *                        shared by the queries of a batch; every posting of every term is
- *                        accumulated (exhaustive).  For sum-merged units with table-family
+ *                        shared by the queries of a batch (what AUTO takes when it joins).
+ *                        For sum-merged units with table-family
  *                        scorers (BM25 / BM15 / TF-IDF over 1-byte norms or none), frequencies
  *                        < 256 — plain disjunctions, and conjunctions / min-match disjunctions of
  *                        at most 15 terms whose counting accumulators stay within the parity
  *                        tolerance; units that do not qualify run as ITEMS whatever was asked;
- *   IRS_HIP_PATH_JOINED_PRUNED  JOINED, and plain disjunctions leave out their NON-ESSENTIAL
- *                        lists: the most frequent terms whose summed score bounds stay below the
- *                        query's threshold are only looked up for docs the other terms produced
- *                        (term-level MaxScore; the reference prunes per doc window:
- *                        disjunction.hpp:1133-1167, formats_10.cpp:2521-2528).  Same top k, same
- *                        scores, same total hit counts as JOINED, bit for bit (what AUTO takes
- *                        when it joins);
  *   IRS_HIP_PATH_AUTO    (default) by measured cost: plain disjunctions join when the batch's
  *                        streams are shared enough or its units many enough to pay for decoding
  *                        every distinct stream once (2.9 ps per distinct posting against 0.67 ps
@@ -338,8 +331,7 @@ int irs_hip_batch_configure(irs_hip_batch* batch, uint32_t tile_docs,
  *                        its terms beats decoding only the blocks its rarest term's docs fall
  *                        into.
  * Call before the batch's first run (or after a configure). */
-enum { IRS_HIP_PATH_AUTO = 0, IRS_HIP_PATH_ITEMS = 1, IRS_HIP_PATH_JOINED = 2,
-       IRS_HIP_PATH_JOINED_PRUNED = 3 };
+enum { IRS_HIP_PATH_AUTO = 0, IRS_HIP_PATH_ITEMS = 1, IRS_HIP_PATH_JOINED = 2 };
 int irs_hip_batch_set_path(irs_hip_batch* batch, int path);
 /* Which one the batch's last run used (IRS_HIP_PATH_ITEMS / IRS_HIP_PATH_JOINED). */
 int irs_hip_batch_path(irs_hip_batch* batch, int* path);
@@ -423,13 +415,6 @@ int irs_hip_batch_work(irs_hip_batch* batch, uint64_t* algorithmic_bytes,
  * read from `.pos`.  (Doc-tile batches read every block of every term: A(q).)  Needs
  * irs_hip_batch_profile(batch, 2 | ...) before the run. */
 int irs_hip_batch_touched(irs_hip_batch* batch, uint64_t* doc_bytes, uint64_t* positions);
-/* What term-level pruning (IRS_HIP_PATH_JOINED_PRUNED) left out of the last run, next to the
- * algorithmic bytes above: stats[0] units whose terms were split, [1] postings of their
- * non-essential lists (not accumulated), [2] those lists' share of A(q) in bytes (encoded blocks
- * + tail + norm bytes), [3] docs that were looked up in non-essential lists instead.  Zeros when
- * the run did not prune.  The counterpart of what `--search-mode wand` saves the reference's
- * iterators (index-search.cpp:726-737); total hit counts stay exact here. */
-int irs_hip_batch_pruning(irs_hip_batch* batch, uint64_t stats[4]);
 /* How many times fetching results had to re-execute the batch so far: the pilot's
  * estimated threshold left fewer than k candidates for some query (re-run with the
  * provable threshold), or the candidate buffer overflowed (exact re-run, then a

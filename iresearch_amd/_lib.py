@@ -19,7 +19,7 @@ LAYOUT_SCALAR, LAYOUT_SIMD4 = 0, 1
 OP_OR, OP_AND, OP_MINMATCH, OP_PHRASE = 0, 1, 2, 3
 SCORE_BM25, SCORE_BM15, SCORE_BM1, SCORE_TFIDF, SCORE_TFIDF_NORM = 0, 1, 2, 3, 4
 NO_TERM = 0xFFFFFFFF
-PATH_AUTO, PATH_ITEMS, PATH_JOINED, PATH_JOINED_PRUNED = 0, 1, 2, 3
+PATH_AUTO, PATH_ITEMS, PATH_JOINED = 0, 1, 2
 WAND_NONE, WAND_DIV_NORM, WAND_MAX_FREQ, WAND_MIN_NORM = 0, 1, 2, 3   # Scorer::WandType
 MAX_TERMS, MAX_K, MAX_PHRASE_TERMS = 16, 4096, 8
 K_PLAN, K_PILOT, K_SCORE, K_SELECT, K_COUNT = 0, 1, 2, 3, 4
@@ -71,7 +71,7 @@ SYMBOLS = (
     "irs_hip_batch_set_comm",
     "irs_hip_term_blockmax",
     "irs_hip_segment_wand_source",
-    "irs_hip_batch_touched", "irs_hip_batch_pruning",
+    "irs_hip_batch_touched",
     "irs_hip_comm_unique_id", "irs_hip_comm_init_rank", "irs_hip_comm_destroy",
     "irs_hip_comm_library",
     "irs_hip_topk_allgather", "irs_hip_device_alloc", "irs_hip_device_free",
@@ -104,7 +104,6 @@ def bind(L: C.CDLL) -> C.CDLL:
     L.irs_hip_batch_create_multi.argtypes = [vp, u32, vp, u32, vp, u32, P(vp)]
     L.irs_hip_batch_create_multi.restype = C.c_int
     L.irs_hip_batch_run.argtypes, L.irs_hip_batch_run.restype = [vp, vp], C.c_int
-    L.irs_hip_batch_pruning.argtypes, L.irs_hip_batch_pruning.restype = [vp, vp], C.c_int
     L.irs_hip_batch_results.argtypes = [vp, vp, u32, vp, vp]
     L.irs_hip_batch_results.restype = C.c_int
     L.irs_hip_batch_device_results.argtypes = [vp, P(vp), P(vp), P(u32)]

@@ -199,16 +199,6 @@ __device__ __forceinline__ void lds_add(const unsigned char*, uint32_t off, unsi
                          __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// Read 4 bytes of LDS and leave zero behind (ds_wrxchg_rtn_b32); the compiler places the wait,
-// so several of them issued back to back are in flight together.
-__device__ __forceinline__ uint32_t lds_take(unsigned char*, uint32_t off) {
-  return __hip_atomic_exchange((IRS_LDS uint32_t*)(uintptr_t)off, 0u, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ uint32_t lds_u32(const unsigned char*, uint32_t off) {
-  return *(const IRS_LDS uint32_t*)(uintptr_t)off;
-}
-
 // 16 bytes of LDS at a 16-byte aligned offset: ds_read_b128 / ds_write_b128
 __device__ __forceinline__ void lds_read4(const unsigned char*, uint32_t off, uint32_t (&v)[4]) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -299,14 +289,6 @@ __device__ __forceinline__ void gload_u32x4(uint64_t base, uint32_t off, uint32_
   typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
   const u32x4a4 x = *(const IRS_GLOBAL u32x4a4*)((const IRS_GLOBAL uint8_t*)base + off);
   v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
-}
-
-// 4 / 2 bytes at a per-lane global address (global_load_dword / global_load_ushort, vmcnt only)
-__device__ __forceinline__ uint32_t gload_u32_at(uint64_t addr) {
-  return *(const IRS_GLOBAL uint32_t*)addr;
-}
-__device__ __forceinline__ uint32_t gload_u16_at(uint64_t addr) {
-  return *(const IRS_GLOBAL uint16_t*)addr;
 }
 
 // ... at a per-lane address

@@ -346,11 +346,6 @@ struct irs_hip_batch {
   bool joined = false;
   DevBuf d_streams, d_join_wgs, d_jterms, d_entries, d_bounds, d_join_args, d_join_units,
     d_join_order;
-  // term-level pruning of plain disjunctions (join.h k_join_ms): doc bitmaps of the dense
-  // streams, every stream's score bound, the units' term split
-  bool pruned = false;         // this deal's plain disjunctions run on k_join_ms
-  DevBuf d_bits, d_bits_wgs, d_stream_tmax, d_join_split, d_ms_stats;
-  uint32_t n_bits_wgs = 0;
   uint32_t join_max_tiles = 0;
   uint32_t n_streams = 0, n_join_wgs = 0;
   uint32_t join_threads = 1024, join_nw_log2 = 4;   // threads per k_join_pilot / k_join_score workgroup
@@ -916,39 +911,11 @@ int prepare_blockmax(irs_hip_segment* s) {
 bool join_allowed(const irs_hip_batch* b) {   // batch level
   if (b->path_pref == IRS_HIP_PATH_ITEMS) return false;
   if (const char* e = std::getenv("IRS_HIP_JOIN")) {   // tuning / test knob
-    if (std::atoi(e) == 0 && b->path_pref != IRS_HIP_PATH_JOINED &&
-        b->path_pref != IRS_HIP_PATH_JOINED_PRUNED)
-      return false;
+    if (std::atoi(e) == 0 && b->path_pref != IRS_HIP_PATH_JOINED) return false;
   }
   // (a unit on joined streams runs exhaustively under ExecutionContext::wand: the top k is the
   // exhaustive one by construction; pruning stays with the block-driven / work-item kernels)
   return !b->phrase && b->acc32;
-}
-// Term-level pruning of the joined plain disjunctions (join.h k_join_ms): IRS_HIP_PATH_AUTO and
-// IRS_HIP_PATH_JOINED_PRUNED take it, IRS_HIP_PATH_JOINED keeps the exhaustive kernel (A/B, tests:
-// the two return the same hits bit for bit).
-bool ms_allowed(const irs_hip_batch* b) {
-  if (b->path_pref == IRS_HIP_PATH_JOINED) return false;
-  if (const char* e = std::getenv("IRS_HIP_MS")) {   // tuning / test knob
-    if (std::atoi(e) == 0 && b->path_pref != IRS_HIP_PATH_JOINED_PRUNED) return false;
-  }
-  return true;
-}
-// non-essential terms may take alpha = x / 256 of the threshold (k_join_split)
-uint32_t ms_alpha256() {
-  if (const char* e = std::getenv("IRS_HIP_MS_ALPHA")) {   // tuning knob, percent
-    const int v = std::atoi(e);
-    return uint32_t(std::min(std::max(v, 0), 100) * 256 / 100);
-  }
-  return 154;   // 0.6
-}
-// a stream gets a doc bitmap when it holds at least one posting per this many docs
-uint64_t ms_density() {
-  if (const char* e = std::getenv("IRS_HIP_MS_DENSITY")) {   // tuning knob
-    const int v = std::atoi(e);
-    if (v >= 1) return uint64_t(v);
-  }
-  return 32;
 }
 bool join_counts_allowed() {   // tuning / test knob
   const char* e = std::getenv("IRS_HIP_JOIN_COUNTS");
@@ -978,8 +945,7 @@ int64_t join_and_saving(const irs_hip_batch* b, const DevQuery& dq) {
 // kernel) only pay when the conjunctions that would join save more than that together
 constexpr int64_t kJoinAndLaunchCost = 500000000;   // 0.5 ms
 int join_and_forced(const irs_hip_batch* b) {   // -1: decide by cost
-  if (b->path_pref == IRS_HIP_PATH_JOINED || b->path_pref == IRS_HIP_PATH_JOINED_PRUNED)
-    return 1;   // (forced: wherever it is possible)
+  if (b->path_pref == IRS_HIP_PATH_JOINED) return 1;   // (forced: wherever it is possible)
   if (const char* e = std::getenv("IRS_HIP_JOIN_AND")) return std::atoi(e) != 0;   // tuning / test knob
   return -1;
 }
@@ -1014,7 +980,7 @@ bool join_or_pays(const irs_hip_batch* b, const std::vector<uint32_t>& units) {
   return 29ull * distinct < (67ull * refs) / 10ull + 24000ull * tiles;
 }
 int join_or_forced(const irs_hip_batch* b) {   // -1: decide by cost
-  if (b->path_pref == IRS_HIP_PATH_JOINED || b->path_pref == IRS_HIP_PATH_JOINED_PRUNED) return 1;
+  if (b->path_pref == IRS_HIP_PATH_JOINED) return 1;
   if (const char* e = std::getenv("IRS_HIP_JOIN_OR")) return std::atoi(e) != 0;   // tuning / test knob
   return -1;
 }
@@ -1049,13 +1015,12 @@ bool build_streams(irs_hip_batch* b) {
   std::vector<WgRef> wgs;
   std::vector<JoinTerm> jterms(b->qterms.size());
   // A stream = a distinct (segment, term, scorer signature) of the joined units: the signature
-  // — (kind, norm_const, norm_length), normally ONE per batch — is what k_stream_bits evaluates
-  // a stream's score bound with.  stream_of[unit term] by an open-addressing table: the streams
-  // come out in first-use order.
+  // — (kind, norm_const, norm_length) — is normally ONE per batch.  stream_of[unit term] by an
+  // open-addressing table: the streams come out in first-use order.
   struct Sig { int32_t kind; float nc, nl; };
   std::vector<Sig> sigs;
   std::vector<uint32_t> stream_of(b->qterms.size(), 0xFFFFFFFFu);
-  std::vector<uint8_t> stream_plain, stream_sig;   // (plain: some plain disjunction reads it)
+  std::vector<uint8_t> stream_sig;
   {
     size_t slots = 64;
     size_t n_keys = 0;
@@ -1065,7 +1030,6 @@ bool build_streams(irs_hip_batch* b) {
     std::vector<uint32_t> hval(slots, 0);
     for (uint32_t u : b->join_units) {
       const DevQuery& dq = b->queries[u];
-      const bool plain = query_need(dq.op) <= 1u;
       for (uint32_t j = 0; j < dq.n_terms; ++j) {
         const DevQTerm& qt = b->qterms[dq.first_term + j];
         uint32_t sg_id = 0;
@@ -1087,31 +1051,20 @@ bool build_streams(irs_hip_batch* b) {
           r.term = qt.term;
           r.n = b->segs[dq.seg]->terms[qt.term].docs_count;
           streams.push_back(r);
-          stream_plain.push_back(0);
           stream_sig.push_back(uint8_t(sg_id));
         }
         stream_of[dq.first_term + j] = hval[h];
-        if (plain) stream_plain[hval[h]] = 1;
       }
     }
   }
-  uint64_t entries = 0, bounds = 0, bits_bytes = 0;
-  std::vector<uint64_t> ent_off, bnd_off, bits_off;
-  // term-level pruning: a stream may become non-essential only where a doc bitmap is cheaper to
-  // consult than its entries — at least one posting per kMsDensity docs
-  std::vector<BitsWg> bits_wgs;
+  uint64_t entries = 0, bounds = 0;
+  std::vector<uint64_t> ent_off, bnd_off;
   for (size_t si = 0; si < streams.size(); ++si) {
     const irs_hip_segment* sg = b->segs[streams[si].seg];
     const DevTerm& t = sg->terms[streams[si].term];
     ent_off.push_back(entries);
     bnd_off.push_back(bounds);
     const uint32_t n_tiles = (sg->dev.num_docs + kJoinTile - 1) / kJoinTile;
-    bits_off.push_back(~0ull);
-    if (b->pruned && stream_plain[si] &&
-        uint64_t(t.docs_count) * ms_density() >= uint64_t(sg->dev.num_docs) && t.docs_count >= 1024u) {
-      bits_off.back() = bits_bytes;
-      bits_bytes += uint64_t(n_tiles) * kMsTileBytes;
-    }
     const uint32_t nb = t.nblk + ((t.docs_count == 1 || t.tail_n) ? 1u : 0u);
     for (uint32_t first = 0; first < nb; first += kJoinBlocks)
       wgs.push_back(WgRef{uint32_t(si), first});
@@ -1143,11 +1096,6 @@ bool build_streams(irs_hip_batch* b) {
     wgs.swap(sorted);
   }
   lap("  streams: buffers");
-  if (b->pruned &&
-      (!b->d_bits.alloc(bits_bytes + 64) || !b->d_stream_tmax.alloc(std::max<size_t>(1, streams.size()) * 4) ||
-       !b->d_join_split.alloc(uint64_t(b->nq) * sizeof(JoinSplit)) || !b->d_ms_stats.alloc(kMsStats * 8)))
-    return false;
-  if (!b->pruned) b->d_bits.release();
   if (!b->d_entries.alloc((entries + kJoinSlack) * 4) || !b->d_bounds.alloc((bounds + 1) * 4) ||
       !b->d_streams.alloc(std::max<size_t>(1, streams.size()) * sizeof(StreamRec)) ||
       !b->d_join_wgs.alloc(std::max<size_t>(1, wgs.size()) * sizeof(JoinWg)) ||
@@ -1202,38 +1150,10 @@ bool build_streams(irs_hip_batch* b) {
     streams[i].bounds = reinterpret_cast<uint64_t>(b->d_bounds.as<uint32_t>() + bnd_off[i]);
     streams[i].n_tiles = (b->segs[streams[i].seg]->dev.num_docs + kJoinTile - 1) / kJoinTile;
     const Sig& sig = sigs[stream_sig[i]];
-    {
-      const irs_hip_segment* sg = b->segs[streams[i].seg];
-      const DevTerm& t = sg->terms[streams[i].term];
-      const bool norms = sig.kind == kBM25Tiny || sig.kind == kTfidfTiny;
-      streams[i].abytes = uint64_t(t.blocks_bytes) + t.tail_bytes +
-                          (norms ? uint64_t(t.docs_count) * sg->dev.norm_width : 0ull);
-    }
     streams[i].kind = sig.kind;
     streams[i].nc = sig.nc;
     streams[i].nl = sig.nl;
-    if (bits_off[i] != ~0ull) {
-      streams[i].bits = reinterpret_cast<uint64_t>(b->d_bits.as<uint8_t>() + bits_off[i]);
-      for (uint32_t t0 = 0; t0 < streams[i].n_tiles; t0 += kMsBitsTiles) {
-        BitsWg w{};
-        w.entries = streams[i].entries;
-        w.bounds = streams[i].bounds;
-        w.bits = streams[i].bits;
-        w.tile0 = t0;
-        w.n_tiles = streams[i].n_tiles;
-        w.sid = uint32_t(i);
-        w.kind = sig.kind;
-        w.nc = sig.nc;
-        w.nl = sig.nl;
-        bits_wgs.push_back(w);
-      }
-    }
   }
-  b->n_bits_wgs = uint32_t(bits_wgs.size());
-  if (b->n_bits_wgs &&
-      (!b->d_bits_wgs.alloc(bits_wgs.size() * sizeof(BitsWg)) ||
-       !b->up.copy(b->d_bits_wgs.p, bits_wgs.data(), bits_wgs.size() * sizeof(BitsWg))))
-    return false;
   for (irs_hip_segment* sg : b->segs)
     if (prepare_posting_norms(sg) != IRS_HIP_OK) return false;
   lap("  streams: k_join records");
@@ -1272,10 +1192,7 @@ bool build_streams(irs_hip_batch* b) {
       const DevQTerm& qt = b->qterms[dq.first_term + j];
       const size_t sid = stream_of[dq.first_term + j];
       JoinTerm& jt = jterms[dq.first_term + j];
-      jt.pad = 0;
-      jt.pad64 = 0;
-      jt.sid = uint32_t(sid);
-      jt.bits = streams[sid].bits;
+      jt.pad[0] = jt.pad[1] = 0;
       jt.entries = streams[sid].entries;
       jt.bounds = streams[sid].bounds;
       jt.cs = qt.c0 * dq.fx_mul;
@@ -1305,16 +1222,6 @@ bool launch_join(irs_hip_batch* b, rt::stream_t st) {
     RT_LAUNCH((k_join<kSimd4>), b->n_join_wgs, kThreads, 0, st, b->d_join_wgs.as<JoinWg>());
   } else {
     RT_LAUNCH((k_join<kScalar>), b->n_join_wgs, kThreads, 0, st, b->d_join_wgs.as<JoinWg>());
-  }
-  if (b->pruned) {
-    // term-level pruning: the dense streams' doc bitmaps + rank directories and every such
-    // stream's score bound, from the entries just written
-    if (!rt::dmemset(b->d_stream_tmax.p, 0, b->d_stream_tmax.n, st) ||
-        !rt::dmemset(b->d_ms_stats.p, 0, b->d_ms_stats.n, st))
-      return false;
-    if (b->n_bits_wgs)
-      RT_LAUNCH(k_stream_bits, b->n_bits_wgs, kThreads, 0, st, b->d_bits_wgs.as<BitsWg>(),
-                b->d_stream_tmax.as<uint32_t>());
   }
   return rt::last_error_ok();
 }
@@ -1404,9 +1311,7 @@ bool launch_group_threshold(irs_hip_batch* b, rt::stream_t st) {
 
 bool launch_join_score(irs_hip_batch* b, rt::stream_t st) {
   const size_t smem = JoinOff::end;
-  if (!big_smem(k_join_score<false>, smem) || !big_smem(k_join_score<true>, smem) ||
-      !big_smem(k_join_ms, smem))
-    return false;
+  if (!big_smem(k_join_score<false>, smem) || !big_smem(k_join_score<true>, smem)) return false;
   const uint32_t waves = b->join_threads / 64;
   uint32_t per_cu = uint32_t((160u * 1024u) / smem);
   per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 32u / waves));
@@ -1433,8 +1338,6 @@ bool launch_join_score(irs_hip_batch* b, rt::stream_t st) {
     a.cand_count = b->d_cand_count.as<uint32_t>();
     a.hits = b->d_hits.as<unsigned long long>();
     a.order = b->d_join_order.as<uint32_t>();
-    a.split = (part == 0 && b->pruned) ? b->d_join_split.as<JoinSplit>() : nullptr;
-    a.ms_stats = (part == 0 && b->pruned) ? b->d_ms_stats.as<unsigned long long>() : nullptr;
     a.work_counter = b->d_join_ctr.as<uint32_t>() + part * kJoinQueues;
     uint32_t base = 0;
     for (uint32_t g = 0; g <= kJoinQueues; ++g) {
@@ -1467,13 +1370,6 @@ bool launch_join_score(irs_hip_batch* b, rt::stream_t st) {
     if (!rt::d2d(a.work_counter, d_init, sizeof b->join_ctr_init[part], st)) return false;
     if (part) {
       RT_LAUNCH(k_join_score<true>, grid, b->join_threads, smem, st, d_args);
-    } else if (b->pruned) {
-      // the units' term split first: needs the threshold bins the pilot just left
-      RT_LAUNCH(k_join_split, (n_units + 63u) / 64u, 64, 0, st, b->d_join_order.as<uint32_t>(), n_units,
-                b->d_queries.as<DevQuery>(), b->d_jterms.as<JoinTerm>(), b->d_streams.as<StreamRec>(),
-                b->d_stream_tmax.as<uint32_t>(), b->d_bstar.as<uint32_t>(), ms_alpha256(),
-                b->d_join_split.as<JoinSplit>(), b->d_ms_stats.as<unsigned long long>());
-      RT_LAUNCH(k_join_ms, grid, b->join_threads, smem, st, d_args);
     } else {
       RT_LAUNCH(k_join_score<false>, grid, b->join_threads, smem, st, d_args);
     }
@@ -1601,9 +1497,6 @@ bool ensure_scratch(irs_hip_batch* b) {
       if (build_conj_work(b) != IRS_HIP_OK) return false;
     }
     b->joined = !b->join_units.empty();
-    b->pruned = false;
-    if (b->joined && ms_allowed(b))
-      for (uint32_t u : b->join_units) b->pruned = b->pruned || query_need(b->queries[u].op) <= 1u;
   }
   // 32-bit accumulators halve the LDS per doc: twice the tile at the same residency
   // the largest tile that still lets two workgroups share a CU's 160 KB of LDS
@@ -2515,7 +2408,7 @@ static int batch_configure_impl(irs_hip_batch* b, uint32_t tile_docs, uint32_t p
 }
 
 static int batch_set_path_impl(irs_hip_batch* b, int path) {
-  if (!b || path < IRS_HIP_PATH_AUTO || path > IRS_HIP_PATH_JOINED_PRUNED) return IRS_HIP_EINVAL;
+  if (!b || path < IRS_HIP_PATH_AUTO || path > IRS_HIP_PATH_JOINED) return IRS_HIP_EINVAL;
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
   if (!quiesce(b)) return IRS_HIP_EHIP;
   b->path_pref = path;
@@ -2681,17 +2574,6 @@ static int batch_touched_impl(irs_hip_batch* b, uint64_t* doc_bytes, uint64_t* p
   }
   if (doc_bytes) *doc_bytes = bytes;
   if (positions) *positions = pos;
-  return IRS_HIP_OK;
-}
-
-static int batch_pruning_impl(irs_hip_batch* b, uint64_t stats[4]) {
-  if (!b || !stats || !b->ran) return IRS_HIP_EINVAL;
-  stats[0] = stats[1] = stats[2] = stats[3] = 0;
-  if (!b->pruned || !b->d_ms_stats.p) return IRS_HIP_OK;
-  if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
-  static_assert(kMsStats == 4, "irs_hip_batch_pruning");
-  if (!rt::d2h(stats, b->d_ms_stats.p, kMsStats * 8, b->stream) || !rt::sync(b->stream))
-    return IRS_HIP_EHIP;
   return IRS_HIP_OK;
 }
 
@@ -3242,9 +3124,6 @@ int irs_hip_topk_allgather(irs_hip_comm* c, const void* d_send, void* d_recv,
 }
 int irs_hip_batch_touched(irs_hip_batch* b, uint64_t* doc_bytes, uint64_t* positions) {
   return guarded([&] { return batch_touched_impl(b, doc_bytes, positions); });
-}
-int irs_hip_batch_pruning(irs_hip_batch* b, uint64_t stats[4]) {
-  return guarded([&] { return batch_pruning_impl(b, stats); });
 }
 int irs_hip_batch_plan(irs_hip_batch* b, void* stream) {
   return guarded([&] { return batch_plan_impl(b, stream); });

@@ -46,15 +46,6 @@ constexpr uint32_t kJoinChunkTiles = 32;  // consecutive tiles of one unit per w
 constexpr uint32_t kJoinCands = 256;      // candidate staging slots per chunk (x2 buffers)
 constexpr uint32_t kJoinSlack = 1024;     // readable entries behind the last stream
 constexpr uint32_t kJoinQueues = 8;       // work queues of k_join_score: one per XCD
-// term-level pruning (k_join_ms): a stream's docs as a bitmap with a rank directory, per doc tile
-// kMsWords words of 32 docs followed by kMsWords u16 counts (set bits in front of each word)
-constexpr uint32_t kMsWords = kJoinTile / 32u;
-constexpr uint32_t kMsPrefixOff = 4u * kMsWords;
-constexpr uint32_t kMsTileBytes = 6u * kMsWords;
-constexpr uint32_t kMsMaxNe = 4;          // non-essential terms per unit at most
-constexpr uint32_t kMsBitsTiles = 8;      // doc tiles per k_stream_bits workgroup
-// irs_hip_batch_pruning's counters
-enum : uint32_t { kMsUnits = 0, kMsPostings = 1, kMsBytes = 2, kMsLookups = 3, kMsStats = 4 };
 // units that need per-doc match counts (conjunctions, min-match): the low 4 bits of an
 // accumulator count matches (so at most 15 terms), contributions are rounded to multiples of 16
 // ablation hooks of k_join_score (tools/build_variant.sh rewrites them; the product builds with 0):
@@ -83,14 +74,11 @@ struct alignas(16) StreamRec {
   uint64_t entries;   // device address of the first entry (u32 each, posting order)
   uint64_t bounds;    // device address of bounds[0 .. n_tiles]: entry index of the first
                       // posting with doc >= tile's first doc; bounds[n_tiles] = n
-  // term-level pruning (below: k_stream_bits): the stream's docs once more as a bitmap with
-  // rank directory, kMsTileBytes per doc tile — 0: none (the stream is never non-essential)
-  uint64_t bits;
-  uint64_t abytes;    // the list's share of A(q): encoded blocks + tail (+ a norm byte per posting)
+  uint64_t pad64[2];
   uint32_t seg, term;
   uint32_t n;         // postings
   uint32_t n_tiles;   // doc tiles of the segment
-  int32_t kind;       // the scorer the stream's score bound is evaluated with: Kind, norm_const,
+  int32_t kind;       // the scorer signature the stream belongs to: Kind, norm_const,
   float nc, nl;       //   norm_length (one signature per stream: build_streams)
   uint32_t pad;
 };
@@ -117,18 +105,15 @@ struct alignas(16) JoinWg {
   uint32_t pad[3];
 };
 static_assert(sizeof(JoinWg) == 112, "JoinWg");
-// Per (unit, term slot), parallel to DevQTerm: all k_join_score needs in one 48-byte record.
+// Per (unit, term slot), parallel to DevQTerm: all k_join_score needs in one 32-byte record.
 struct alignas(16) JoinTerm {
   uint64_t entries;
   uint64_t bounds;
   float cs;          // c0 * the unit's fixed-point scale
   uint32_t mode;     // table slot offset | kJoinGeneral | kJoinSqrt
-  uint32_t sid;      // the stream (StreamRec) the slot reads
-  uint32_t pad;
-  uint64_t bits;     // StreamRec::bits
-  uint64_t pad64;
+  uint32_t pad[2];
 };
-static_assert(sizeof(JoinTerm) == 48, "JoinTerm");
+static_assert(sizeof(JoinTerm) == 32, "JoinTerm");
 constexpr uint32_t kJoinTermQuads = uint32_t(sizeof(JoinTerm)) / 16u;
 
 __host__ __device__ __forceinline__ uint32_t join_entry(uint32_t idx, uint32_t tf, uint32_t norm) {
@@ -340,8 +325,7 @@ struct JoinOff {
   static constexpr uint32_t sig = cum + 4u * kJoinChunkTiles * kMaxTerms;         // [2][16] u32
   static constexpr uint32_t cand = sig + 4u * 2u * 16u;                // [2][kJoinCands] u64
   static constexpr uint32_t vars = cand + 8u * 2u * kJoinCands;        // [16] u32
-  static constexpr uint32_t ms = vars + 64u;                           // MsSlot[kMsMaxNe] (k_join_ms)
-  static constexpr uint32_t caches = ms + 32u * kMsMaxNe;              // [kTableRows][256] f32
+  static constexpr uint32_t caches = vars + 64u;                       // [kTableRows][256] f32
   static constexpr uint32_t end = caches + 4u * 256u * kTableRows;
 };
 static_assert(JoinOff::cand % 8u == 0u, "candidate keys are 8-byte aligned");
@@ -610,7 +594,7 @@ __device__ __forceinline__ void join_prologue(unsigned char* smem, const DevQuer
       sig[16u + 3u + 3u * qt.cache_id] = __float_as_uint(qt.norm_length);
     }
   }
-  if (tid < kJoinTermQuads * kMaxTerms) {   // a JoinTerm = three 16-byte pieces
+  if (tid < kJoinTermQuads * kMaxTerms) {   // a JoinTerm = two 16-byte halves
     const uint32_t j = tid / kJoinTermQuads;
     uint32_t x = 0, y = 0, z = 0, w = 0;   // (field by field: an aggregate temporary would live in scratch)
     if (j < qd.n_terms) {
@@ -647,13 +631,6 @@ __device__ __forceinline__ JoinLane join_lane(const unsigned char* smem, unsigne
   return T;
 }
 
-// What k_join_split (term-level pruning, below) leaves per unit: its non-essential term slots
-// and their summed bounds.
-struct JoinSplit {
-  uint32_t ne_mask;   // bit j: term slot j is non-essential
-  uint32_t ne_ub;     // fixed-point units no doc gains from those terms together
-};
-
 struct JoinArgs {
   const DevQuery* queries;
   const DevQTerm* qterms;
@@ -663,8 +640,6 @@ struct JoinArgs {
   uint32_t* cand_count;
   unsigned long long* hits;
   const uint32_t* order;  // work-queue order: slot i names the unit that runs i-th in a chunk round
-  const JoinSplit* split;   // [unit] k_join_split's term split (k_join_ms), else null
-  unsigned long long* ms_stats;   // irs_hip_batch_pruning's counters ([kMsLookups]: docs looked up)
   // One work queue per XCD: the units are dealt to kJoinQueues groups of alike units (sorted by
   // their heaviest term), a workgroup pulls from the queue of the XCD it runs on (blockIdx % 8:
   // how the hardware deals workgroups today — a placement assumption that only speed depends on)
@@ -1205,513 +1180,6 @@ k_join_score(const JoinArgs* __restrict__ args) {
     if (tid == 0) vars[kJNc + parity] = 0u;   // (the buffer flushed above becomes the next chunk's)
   }
   // the last chunk's candidates
-  if (tid == 0) {
-    vars[kJPendQ] = pend_q;
-    vars[kJPendBase] = pend_base;
-    vars[kJPendN] = pend_n;
-  }
-  __syncthreads();
-  {
-    const uint32_t pn = vars[kJPendN];
-    if (pn) {
-      const uint32_t pq = vars[kJPendQ], gbase = vars[kJPendBase];
-      const uint64_t* pl = lcand + (parity ^ 1u) * kJoinCands;
-      uint64_t* out = args->cands + uint64_t(pq) * cap;
-      for (uint32_t i = tid; i < pn; i += blockDim.x) {
-        const uint32_t g = gbase + i;
-        if (g < cap) out[g] = pl[i];
-      }
-    }
-  }
-}
-
-// ----------------------------------------------- term-level pruning (MaxScore) --
-//
-// The reference prunes a disjunction per doc window: block_disjunction's min / WAND lambda
-// (disjunction.hpp:1133-1167) and the wanderator's skip by block-max score
-// (formats_10.cpp:2521-2528, 2785-2794) leave out what cannot reach the k-th score the harness
-// pushes back through score::Min (index-search.cpp:726-737).  On a Zipfian OR the same bound pays
-// per TERM: the two or three most frequent lists of a query hold 50 - 80 % of its postings while
-// their score bounds together stay below the threshold (profiles/r05_essential_lists.txt).  With
-// the pilot's threshold bin known (k_join_pilot), a unit's terms are split (k_join_split):
-//   non-essential   the most frequent lists whose summed bounds stay within alpha x threshold —
-//                   a doc found ONLY there cannot be a candidate;
-//   essential       the rest: accumulated tile by tile as in k_join_score.
-// k_join_ms then reads back only the accumulators its postings touched (a second walk over the
-// tile's essential entries with LDS exchanges: the first posting to arrive owns the doc, the
-// others find zero) instead of scanning all 12288 of a tile; an owner whose partial sum plus the
-// non-essential bounds reaches the threshold looks its doc up in the non-essential lists — bit
-// test in the list's doc bitmap, rank by popcount, ONE entry load — and applies the exact test
-// of k_join_score to the exact sum.  Same candidates, same fixed-point sums, bit for bit.  The
-// total hit count stays exact too: per tile the popcount of the non-essential bitmaps' union
-// plus the owners outside it (a count over doc ids only).
-//
-// k_stream_bits builds, in every run and for every stream that may become non-essential (dense
-// enough: build_streams), the doc bitmap with its rank directory from the entries k_join just
-// wrote, and the stream's largest query-independent factor T (its score bound is cs * T).
-
-// One k_stream_bits workgroup: kMsBitsTiles doc tiles of one stream.
-struct alignas(16) BitsWg {
-  uint64_t entries, bounds, bits;   // of the stream (StreamRec)
-  uint32_t tile0, n_tiles;          // the workgroup's first tile; tiles of the stream
-  uint32_t sid;                     // the stream: where its bound goes
-  int32_t kind;                     // scorer signature of the stream (StreamRec)
-  float nc, nl;
-};
-static_assert(sizeof(BitsWg) == 48, "BitsWg");
-
-// the bound is taken a little wide: the general expression of join_post goes through v_rcp /
-// v_sqrt (1 ulp), the tables through IEEE divisions
-constexpr float kMsBoundSlack = 1.00001f;
-
-__global__ void __launch_bounds__(kThreads)
-k_stream_bits(const BitsWg* wgs, uint32_t* tmax) {
-  static_assert(kThreads == 256 && kMsWords <= 2u * 3u * 64u, "k_stream_bits geometry");
-  __shared__ uint32_t s_words[kMsWords];
-  __shared__ float s_tab[256];
-  __shared__ uint32_t s_tot[kWaves];
-  const uint32_t tid = threadIdx.x;
-  const unsigned lane = tid & 63u;
-  const uint32_t wv = tid >> 6;
-  const BitsWg W = wave::sload<BitsWg>(reinterpret_cast<uint64_t>(wgs) + uint64_t(blockIdx.x) * sizeof(BitsWg));
-  const uint32_t* ent = reinterpret_cast<const uint32_t*>(W.entries);
-  const uint32_t* bnd = reinterpret_cast<const uint32_t*>(W.bounds);
-  s_tab[tid] = table_value(W.kind, W.nc, W.nl, tid);
-  const bool root = sqrt_kind(W.kind);
-  uint32_t end = W.tile0 + kMsBitsTiles;
-  if (end > W.n_tiles) end = W.n_tiles;
-  float best = 0.f;
-  for (uint32_t t = W.tile0; t < end; ++t) {
-    for (uint32_t i = tid; i < kMsWords; i += kThreads) s_words[i] = 0u;
-    __syncthreads();
-    const uint32_t a = bnd[t], b = bnd[t + 1u];
-    for (uint32_t i = a + tid; i < b; i += kThreads) {
-      const uint32_t e = ent[i];
-      const uint32_t idx = e >> 18;
-      atomicOr(&s_words[idx >> 5], 1u << (idx & 31u));
-      const float tf = static_cast<float>(join_tf(e));
-      const float tb = s_tab[(e >> 2) & 0xFFu];
-      const float T = root ? sqrtf(tf) * tb : 1.f - 1.f / (1.f + tf * tb);
-      best = T > best ? T : best;
-    }
-    __syncthreads();
-    // rank directory: set bits of the tile in front of every word; two words per thread
-    uint32_t w0 = 0, w1 = 0;
-    if (tid < kMsWords / 2u) {
-      w0 = s_words[2u * tid];
-      w1 = s_words[2u * tid + 1u];
-    }
-    const uint32_t c0 = uint32_t(__builtin_popcount(w0)), c = c0 + uint32_t(__builtin_popcount(w1));
-    const uint32_t incl = wave::inclusive_scan(c);
-    if (lane == 63u) s_tot[wv] = incl;
-    __syncthreads();
-    uint32_t base = 0;
-    for (uint32_t w = 0; w < wv; ++w) base += s_tot[w];
-    if (tid < kMsWords / 2u) {
-      uint8_t* out = reinterpret_cast<uint8_t*>(W.bits) + uint64_t(t) * kMsTileBytes;
-      const uint32_t ex = base + incl - c;
-      const uint64_t both = (uint64_t(w1) << 32) | w0;
-      __builtin_memcpy(out + 8u * tid, &both, 8);
-      const uint32_t pf = ex | ((ex + c0) << 16);   // (<= 12288: two u16)
-      __builtin_memcpy(out + kMsPrefixOff + 4u * tid, &pf, 4);
-    }
-  }
-  const uint32_t top = wave::reduce_max(__float_as_uint(best));   // (T >= 0: bit order = value order)
-  if (lane == 0 && top) atomicMax(&tmax[W.sid], top);
-}
-
-// One thread per plain-disjunction unit, behind the pilot: the most frequent lists first while
-// their summed bounds stay within alpha256 / 256 of the (conservative fixed-point image of the)
-// threshold — and strictly below it, so that a doc without an essential posting is never a
-// candidate.  alpha < 1 trades postings left out against docs to look up: the closer the bounds
-// come to the threshold, the more owners pass the partial-sum test
-// (profiles/r05_essential_lists.txt).
-__global__ void __launch_bounds__(64)
-k_join_split(const uint32_t* units, uint32_t n_units, const DevQuery* queries, const JoinTerm* jterms,
-             const StreamRec* streams, const uint32_t* tmax, const uint32_t* bstar,
-             uint32_t alpha256, JoinSplit* split, unsigned long long* stats) {
-  const uint32_t i = blockIdx.x * 64u + threadIdx.x;
-  if (i >= n_units) return;
-  const uint32_t q = units[i];
-  const DevQuery qd = queries[q];
-  JoinSplit out{0u, 0u};
-  const uint32_t thr = bin_threshold<uint32_t>(bstar[q], qd);
-  if (query_need(qd.op) <= 1u && thr > 1u && alpha256) {
-    const uint64_t want = (uint64_t(thr) * alpha256) >> 8;
-    const uint32_t budget = want < thr ? uint32_t(want) : thr - 1u;
-    uint32_t taken = 0, sum = 0;
-    unsigned long long left_out = 0, left_bytes = 0;
-    for (uint32_t n_ne = 0; n_ne < kMsMaxNe; ++n_ne) {
-      uint32_t best = 0xFFFFFFFFu, best_n = 0, best_ub = 0;
-      unsigned long long best_bytes = 0;
-      for (uint32_t j = 0; j < qd.n_terms; ++j) {
-        if ((taken >> j) & 1u) continue;
-        const JoinTerm jt = jterms[qd.first_term + j];
-        if (!jt.bits) continue;
-        const StreamRec sr = streams[jt.sid];
-        const uint32_t n = sr.n;
-        const float bound = jt.cs * __uint_as_float(tmax[jt.sid]) * kMsBoundSlack + 2.f;
-        if (!(bound < 1073741824.f)) continue;
-        const uint32_t ub = static_cast<uint32_t>(bound) + 1u;
-        if (uint64_t(sum) + ub > budget) continue;
-        if (best == 0xFFFFFFFFu || n > best_n) {
-          best = j;
-          best_n = n;
-          best_ub = ub;
-          best_bytes = sr.abytes;
-        }
-      }
-      if (best == 0xFFFFFFFFu) break;
-      taken |= 1u << best;
-      sum += best_ub;
-      left_out += best_n;
-      left_bytes += best_bytes;
-    }
-    out.ne_mask = taken;
-    out.ne_ub = sum;
-    if (taken) {
-      atomicAdd(&stats[kMsUnits], 1ull);
-      atomicAdd(&stats[kMsPostings], left_out);
-      atomicAdd(&stats[kMsBytes], left_bytes);
-    }
-  }
-  split[q] = out;
-}
-
-// The fixed-point contribution of one entry to its doc's score: what join_post adds (table row
-// where every frequency of the term has one, else the general expression).
-__device__ __forceinline__ uint32_t join_fixed(const unsigned char* lds, uint32_t e, float cs, uint32_t mode) {
-  const uint32_t tabofs = mode & kJoinTabMask;
-  const int form = join_form(mode);
-  if (form == kJTable) {
-    const float t = wave::lds_f32(lds, JoinOff::caches + ((e & 0xFFFFu) | tabofs));
-    return static_cast<uint32_t>(wave::fma(cs, t, 1.f));
-  }
-  const float t = wave::lds_f32(lds, JoinOff::caches + ((e & 0x3FCu) | tabofs));
-  const float tf = static_cast<float>(join_tf(e));
-  const float scaled = (form == kJSqrt) ? wave::fast_sqrt(tf) * cs * t
-                                        : wave::fma(-cs, wave::fast_rcp(wave::fma(tf, t, 1.f)), cs);
-  return static_cast<uint32_t>(scaled) | 1u;
-}
-
-// One non-essential term of the unit a workgroup is on (LDS, JoinOff::ms).
-struct alignas(16) MsSlot {
-  uint64_t bits, entries;   // JoinTerm::bits, ::entries
-  float cs;
-  uint32_t mode;
-  uint32_t j;               // the term's slot in the query
-  uint32_t pad;
-};
-static_assert(sizeof(MsSlot) == 32, "MsSlot");
-
-struct MsTileCtx {
-  JoinTileCtx c;
-  uint32_t ne_n;      // non-essential terms (MsSlot records)
-  uint32_t ne_mask;
-  uint32_t ne_ub;
-};
-
-// The tiles of one chunk, essential terms only.  Per tile and wavefront:
-//   finish(u)    accumulate the wavefront's share of the essential entries (as k_join_score)
-//   count        the non-essential bitmaps' union of the tile: one word per lane, popcount
-//   barrier B1   every accumulation of tile u has landed
-//   take         the same entries once more: exchange the doc's accumulator with zero — non-zero:
-//                this posting owns the doc (hit count, partial-sum test, look-ups); zero: another
-//                posting of the doc came first
-//   begin(u+2)   request the first entries of the tile after next (two runs in flight)
-//   barrier B2   accumulators are clear again
-template<int M>
-__device__ __forceinline__ void join_tiles_ms(unsigned char* smem, const MsTileCtx& mc,
-                                              const JoinLane& T, uint32_t tile0, uint32_t ntile,
-                                              uint32_t wv, uint32_t nw_log2, uint32_t& my_hits,
-                                              uint32_t& my_looks) {
-  const JoinTileCtx& ctx = mc.c;
-  const uint32_t* rng = reinterpret_cast<const uint32_t*>(smem + JoinOff::rng);
-  const uint32_t* cum = reinterpret_cast<const uint32_t*>(smem + JoinOff::cum);
-  const MsSlot* slots = reinterpret_cast<const MsSlot*>(smem + JoinOff::ms);
-  const uint32_t tid = threadIdx.x;
-  const unsigned lane = tid & 63u;
-  const uint64_t safe = reinterpret_cast<uint64_t>(ctx.args->jterms);
-  const uint32_t ne_n = mc.ne_n;
-  auto begin = [&](uint32_t u, JoinRun& r) {   // (u >= ntile: an empty share)
-    uint32_t a = 0, n = 0, c = 0;
-    if (lane < kMaxTerms && u < ntile) {
-      a = rng[u * kMaxTerms + lane];
-      n = ((mc.ne_mask >> lane) & 1u) ? 0u : rng[(u + 1u) * kMaxTerms + lane] - a;
-      c = cum[u * kMaxTerms + lane];
-    }
-    join_begin<M>(r, T, a, n, c, wv, nw_log2, safe, lane);
-  };
-  auto tile_bits = [&](uint32_t s, uint32_t u) {   // (wave-uniform) the tile's record of slot s
-    return wave::uniform64(slots[s].bits) + uint64_t(tile0 + u) * kMsTileBytes;
-  };
-  auto candidate = [&](uint32_t doc, uint32_t f) {
-    const float v = f <= kMaxTerms ? 0.f : from_fixed<uint32_t>(f, ctx.fx_inv);
-    if (score_bin(v, ctx.bin_scale) >= ctx.bs) {
-      const uint64_t key = make_key(v, doc);
-      const uint32_t slot = atomicAdd(ctx.ncand, 1u);
-      if (slot < kJoinCands) {
-        ctx.lc[slot] = key;
-      } else {   // rarer: more candidates in one chunk than staging slots
-        const uint32_t g = atomicAdd(&ctx.args->cand_count[ctx.q], 1u);
-        if (g < ctx.cap) ctx.args->cands[uint64_t(ctx.q) * ctx.cap + g] = key;
-      }
-    }
-  };
-  // `slabs` (1..4, wave-uniform) slabs of entries, one per lane and slab (lanes without a posting
-  // hold their dummy entry)
-  auto take = [&](uint32_t u, const uint32_t (&e)[4], uint32_t slabs) {
-    uint32_t v[4] = {0u, 0u, 0u, 0u};
-    uint32_t real = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (uint32_t(k) < slabs) {
-        const uint32_t off = e[k] >> 16;
-        v[k] = wave::lds_take(smem, JoinOff::acc + off);
-        real |= (off < 4u * kJoinTile ? 1u : 0u) << k;
-      }
-    }
-    uint32_t in_ne = 0;
-    for (uint32_t s = 0; s < ne_n; ++s) {   // (one or two, as a rule)
-      const uint64_t tb = tile_bits(s, u);
-      uint32_t w[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (uint32_t(k) < slabs) w[k] = wave::gload_u32(tb, ((real >> k) & 1u) ? ((e[k] >> 23) << 2) : 0u);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) in_ne |= ((w[k] >> ((e[k] >> 18) & 31u)) & 1u) << k;
-    }
-    uint32_t own = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) own |= (v[k] ? 1u : 0u) << k;
-    own &= real;
-    my_hits += uint32_t(__builtin_popcount(own & ~in_ne));
-    uint32_t cm = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) cm |= (v[k] + mc.ne_ub >= ctx.thr ? 1u : 0u) << k;
-    cm &= own;
-    my_looks += uint32_t(__builtin_popcount(cm));
-    while (cm) {   // per lane, rare: the doc's non-essential postings, then the exact test
-      const uint32_t k = uint32_t(__builtin_ctz(cm));
-      cm &= cm - 1u;
-      const uint32_t ek = k == 0u ? e[0] : (k == 1u ? e[1] : (k == 2u ? e[2] : e[3]));
-      uint32_t f = k == 0u ? v[0] : (k == 1u ? v[1] : (k == 2u ? v[2] : v[3]));
-      const uint32_t idx = ek >> 18;
-      for (uint32_t s = 0; s < ne_n; ++s) {
-        const MsSlot sl = slots[s];
-        const uint64_t tb = sl.bits + uint64_t(tile0 + u) * kMsTileBytes;
-        const uint32_t w = wave::gload_u32_at(tb + ((idx >> 5) << 2));
-        const uint32_t b = idx & 31u;
-        if ((w >> b) & 1u) {
-          const uint32_t rank = wave::gload_u16_at(tb + kMsPrefixOff + ((idx >> 5) << 1)) +
-                                uint32_t(__builtin_popcount(w & ((1u << b) - 1u)));
-          const uint32_t a = rng[u * kMaxTerms + sl.j];
-          f += join_fixed(smem, wave::gload_u32_at(sl.entries + 4ull * (uint64_t(a) + rank)), sl.cs, sl.mode);
-        }
-      }
-      if (f >= ctx.thr) candidate(kDocMin + (tile0 + u) * kJoinTile + idx, f);
-    }
-  };
-  auto walk = [&](uint32_t u, uint64_t base, uint32_t count) {
-    while (count) {
-      const uint32_t n = count < 256u ? count : 256u;
-      uint32_t e[4];
-      join_load(base, n, lane, e);
-      take(u, e, (n + 63u) >> 6);
-      base += 4ull * n;
-      count -= n;
-    }
-  };
-  auto second = [&](uint32_t u, const JoinRun& r) {   // (mirrors join_finish)
-    const uint32_t pre = wave::uniform(r.pre);
-    if (!pre) return;
-    {
-      const uint32_t dummy = join_dummy(lane);
-      uint32_t e[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) e[k] = lane + 64u * uint32_t(k) < pre ? r.e[k] : dummy;
-      take(u, e, (pre + 63u) >> 6);
-    }
-    const uint32_t left = wave::uniform(r.left);
-    if (left) walk(u, wave::uniform64(r.rest), left);
-    uint64_t mask = wave::uniform64(r.mask);
-    while (mask) {
-      const uint32_t j = uint32_t(__builtin_ctzll(mask));
-      mask &= mask - 1ull;
-      walk(u, (uint64_t(wave::read_lane(r.a_hi, j)) << 32) | wave::read_lane(r.a_lo, j),
-           wave::read_lane(r.cnt, j));
-    }
-  };
-  auto end_tile = [&](uint32_t u, JoinRun& r) {
-    if (ne_n) {   // docs of the tile in ANY non-essential list
-      for (uint32_t i = tid; i < kMsWords; i += blockDim.x) {
-        uint32_t w = 0;
-        for (uint32_t s = 0; s < ne_n; ++s) w |= wave::gload_u32_at(slots[s].bits + uint64_t(tile0 + u) * kMsTileBytes + 4u * i);
-        my_hits += uint32_t(__builtin_popcount(w));
-      }
-    }
-    __syncthreads();   // B1
-    second(u, r);
-    begin(u + 2u, r);
-    __syncthreads();   // B2
-  };
-  JoinRun r0, r1;
-  begin(0, r0);
-  begin(1, r1);
-  for (uint32_t u = 0; u < ntile; u += 2u) {
-    join_finish<M>(smem, r0, T, lane);
-    end_tile(u, r0);
-    join_finish<M>(smem, r1, T, lane);
-    if (u + 1u < ntile) end_tile(u + 1u, r1);
-  }
-}
-
-// k_join_score<false> with the split of k_join_split: same queues, same chunk hand-over.
-__global__ void __launch_bounds__(kTileThreadsMax) IRS_WAVES_PER_SIMD(8)
-k_join_ms(const JoinArgs* __restrict__ args) {
-  RT_DYN_SMEM(smem);
-  if (!wave::lds_is_at_zero(smem)) __builtin_trap();
-  uint32_t* acc = reinterpret_cast<uint32_t*>(smem + JoinOff::acc);
-  uint32_t* rng = reinterpret_cast<uint32_t*>(smem + JoinOff::rng);
-  uint32_t* cum = reinterpret_cast<uint32_t*>(smem + JoinOff::cum);
-  uint32_t* sig = reinterpret_cast<uint32_t*>(smem + JoinOff::sig);
-  uint64_t* lcand = reinterpret_cast<uint64_t*>(smem + JoinOff::cand);
-  uint32_t* vars = reinterpret_cast<uint32_t*>(smem + JoinOff::vars);
-  const uint32_t tid = threadIdx.x;
-  const unsigned lane = tid & 63u;
-  const uint32_t wv = wave::uniform(tid >> 6);
-  const uint32_t total_chunks = args->base[kJoinQueues];
-  const uint32_t nw_log2 = args->nw_log2;
-  const uint32_t cap = args->cand_cap;
-
-  for (uint32_t i = tid; i < kJoinTile + 64u; i += blockDim.x) acc[i] = 0u;   // (+ the dummies)
-  if (tid < 16u) vars[tid] = 0u;
-  __syncthreads();
-  if (tid == 0) {
-    sig[0] = 0xFFFFFFFFu;
-    const uint32_t g0 = blockIdx.x % kJoinQueues;
-    uint32_t g = g0;
-    vars[kJChunk] = join_pull(args, g0, atomicAdd(&args->work_counter[g0], 1u), g);
-    vars[kJGroup] = g;
-  }
-  __syncthreads();
-  uint32_t chunk = wave::uniform(vars[kJChunk]);
-  uint32_t group = wave::uniform(vars[kJGroup]);
-  uint32_t parity = 0;
-  uint32_t pend_q = 0, pend_n = 0, pend_base = 0;   // thread 0: the previous chunk's reservation
-  __syncthreads();
-
-  while (chunk < total_chunks) {
-    uint32_t next_raw = 0;
-    if (tid == 0) next_raw = atomicAdd(&args->work_counter[group], 1u);
-    const uint32_t n_units = args->first[group + 1u] - args->first[group];
-    const uint32_t local = chunk - args->base[group];
-    const uint32_t q = wave::uniform(args->order[args->first[group] + local % n_units]);
-    const uint32_t per_chunk = args->chunk_tiles;
-    const uint32_t tile0 = (local / n_units) * per_chunk;
-    const DevQuery qd = args->queries[q];
-    const uint32_t n_tiles = qd.n_tiles;
-    const uint32_t ntile = tile0 >= n_tiles ? 0u
-                           : ((n_tiles - tile0) < per_chunk ? (n_tiles - tile0) : per_chunk);
-    const uint32_t bs = args->bstar[q];
-    const JoinSplit sp = args->split[q];
-    const uint32_t ne_mask = wave::uniform(sp.ne_mask);
-    uint32_t my_hits = 0, my_looks = 0;
-    uint64_t* lc = lcand + parity * kJoinCands;
-    uint32_t* ncand = vars + kJNc + parity;
-    if (ntile) {
-      for (uint32_t e = tid; e < (ntile + 1u) * kMaxTerms; e += blockDim.x) {
-        const uint32_t i = e / kMaxTerms, j = e % kMaxTerms;
-        uint32_t v = 0;
-        if (j < qd.n_terms)
-          v = reinterpret_cast<const uint32_t*>(args->jterms[qd.first_term + j].bounds)[tile0 + i];
-        rng[e] = v;
-      }
-      join_prologue(smem, qd, args->qterms, args->jterms);   // (its barrier publishes rng too)
-      // per tile: the inclusive prefix of the ESSENTIAL terms' entry counts
-      for (uint32_t e = tid; e < ntile * kMaxTerms; e += blockDim.x) {
-        const uint32_t i = e / kMaxTerms, j = e % kMaxTerms;
-        uint32_t c = 0;
-        for (uint32_t t = 0; t <= j; ++t)
-          if (!((ne_mask >> t) & 1u)) c += rng[(i + 1u) * kMaxTerms + t] - rng[i * kMaxTerms + t];
-        cum[e] = c;
-      }
-      if (tid < kMsMaxNe) {   // the unit's non-essential terms, slot after slot
-        uint32_t m = ne_mask;
-        for (uint32_t s = 0; s < tid; ++s) m &= m - 1u;
-        if (m) {
-          const uint32_t j = uint32_t(__builtin_ctz(m));
-          const JoinTerm jt = reinterpret_cast<const JoinTerm*>(smem + JoinOff::jts)[j];
-          MsSlot sl;
-          sl.bits = jt.bits;
-          sl.entries = jt.entries;
-          sl.cs = jt.cs;
-          sl.mode = jt.mode;
-          sl.j = j;
-          sl.pad = 0u;
-          reinterpret_cast<MsSlot*>(smem + JoinOff::ms)[tid] = sl;
-        }
-      }
-      __syncthreads();
-      const JoinLane T = join_lane(smem, lane);
-      const bool simple = wave::ballot(T.mode != 0u) == 0ull;
-      MsTileCtx mc;
-      mc.c.args = args;
-      mc.c.q = q;
-      mc.c.bs = bs;
-      mc.c.thr = bin_threshold<uint32_t>(bs, qd);
-      mc.c.fx_inv = qd.fx_inv;
-      mc.c.bin_scale = qd.bin_scale;
-      mc.c.cap = cap;
-      mc.c.lc = lc;
-      mc.c.ncand = ncand;
-      mc.c.need = 1u;
-      mc.ne_mask = ne_mask;
-      mc.ne_n = uint32_t(__builtin_popcount(ne_mask));
-      mc.ne_ub = wave::uniform(sp.ne_ub);
-      if (simple) join_tiles_ms<kJSimple>(smem, mc, T, tile0, ntile, wv, nw_log2, my_hits, my_looks);
-      else join_tiles_ms<0>(smem, mc, T, tile0, ntile, wv, nw_log2, my_hits, my_looks);
-    }
-    my_looks = wave::reduce_add(my_looks);
-    if (lane == 0 && my_looks)
-      atomicAdd(&args->ms_stats[kMsLookups], static_cast<unsigned long long>(my_looks));
-    // ---- chunk hand-over (k_join_score's)
-    if (tid == 0) {
-      vars[kJPendQ] = pend_q;
-      vars[kJPendBase] = pend_base;
-      vars[kJPendN] = pend_n;
-      uint32_t g = group;
-      vars[kJChunk] = join_pull(args, group, next_raw, g);
-      vars[kJGroup] = g;
-    }
-    my_hits = wave::reduce_add(my_hits);
-    if (lane == 0 && my_hits)
-      atomicAdd(&args->hits[q], static_cast<unsigned long long>(my_hits));
-    __syncthreads();
-    {
-      const uint32_t pn = vars[kJPendN];
-      if (pn) {
-        const uint32_t pq = vars[kJPendQ], gbase = vars[kJPendBase];
-        const uint64_t* pl = lcand + (parity ^ 1u) * kJoinCands;
-        uint64_t* out = args->cands + uint64_t(pq) * cap;
-        for (uint32_t i = tid; i < pn; i += blockDim.x) {
-          const uint32_t g = gbase + i;
-          if (g < cap) out[g] = pl[i];
-        }
-      }
-    }
-    chunk = wave::uniform(vars[kJChunk]);
-    group = wave::uniform(vars[kJGroup]);
-    if (tid == 0) {
-      const uint32_t raw = *ncand;
-      pend_n = raw < kJoinCands ? raw : kJoinCands;
-      pend_q = q;
-      pend_base = pend_n ? atomicAdd(&args->cand_count[q], pend_n) : 0u;
-    }
-    __syncthreads();
-    parity ^= 1u;
-    if (tid == 0) vars[kJNc + parity] = 0u;
-  }
   if (tid == 0) {
     vars[kJPendQ] = pend_q;
     vars[kJPendBase] = pend_base;

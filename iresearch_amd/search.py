@@ -449,14 +449,6 @@ class QueryBatch:
                    "irs_hip_batch_touched")
         return a.value, p.value
 
-    def pruning(self):
-        """What term-level pruning left out of the last run (irs_hip_batch_pruning): units split,
-        postings of their non-essential lists, those lists' algorithmic bytes, docs looked up."""
-        st = np.zeros(4, np.uint64)
-        _lib.check(self.L, self.L.irs_hip_batch_pruning(self.handle, st.ctypes.data),
-                   "irs_hip_batch_pruning")
-        return [int(x) for x in st]
-
     def work(self):
         a, p = C.c_uint64(), C.c_uint64()
         _lib.check(self.L, self.L.irs_hip_batch_work(self.handle, C.byref(a), C.byref(p)),

@@ -553,10 +553,7 @@ def case_paths_agree(L, num_docs=70_000, max_rank=256, layout=synth.LAYOUT_SIMD4
     """The two organisations of a disjunction batch — every query decoding its own blocks (work
     items) and the batch decoding every distinct term once (joined posting streams) — return
     the same docs, scores and hit counts, bit for bit (a posting's fixed-point contribution is
-    computed by the same arithmetic wherever it is decoded) — and so do the two forms of the
-    joined path: every posting accumulated (PATH_JOINED) and the non-essential lists left out
-    and only looked up (PATH_JOINED_PRUNED, term-level MaxScore: join.h k_join_ms) — docs, scores
-    AND total hit counts.  Each one is also checked against
+    computed by the same arithmetic wherever it is decoded).  Each one is also checked against
     the oracle.  Mixed batches: the And /
     min-match / kMax queries stay on their own kernels while the plain disjunctions join."""
     seg = synth.build_segment(num_docs, max_rank, layout=layout)
@@ -569,7 +566,7 @@ def case_paths_agree(L, num_docs=70_000, max_rank=256, layout=synth.LAYOUT_SIMD4
     for scorer in (BM25(), BM25(1.2, 0.0), TFIDF(True), TFIDF(False)):
         for filters, k in ((pure, 1000), (mixed, 40)):
             got = {}
-            for path in (_lib.PATH_ITEMS, _lib.PATH_JOINED, _lib.PATH_JOINED_PRUNED, _lib.PATH_AUTO):
+            for path in (_lib.PATH_ITEMS, _lib.PATH_JOINED, _lib.PATH_AUTO):
                 prep = search.prepare(filters, scorer, [parity.segment_stats(seg)])
                 b = sr.batch(prep, k).set_path(path)
                 h, c, t = b.run().results()
@@ -591,10 +588,6 @@ def case_paths_agree(L, num_docs=70_000, max_rank=256, layout=synth.LAYOUT_SIMD4
                 if not counting:
                     assert np.array_equal(hi[qi], hj[qi]), qi
                     assert np.array_equal(got[_lib.PATH_AUTO][0][qi], hj[qi]), qi
-                # (pruned joined == exhaustive joined for every query, counting ones included)
-                assert np.array_equal(got[_lib.PATH_JOINED_PRUNED][0][qi], hj[qi]), qi
-            assert np.array_equal(got[_lib.PATH_JOINED_PRUNED][1], cj)
-            assert np.array_equal(got[_lib.PATH_JOINED_PRUNED][2], tj)
     sr.close()
 
 
@@ -1273,7 +1266,7 @@ def case_shared_threshold(L, sizes=(70_000, 30_000, 140_000, 50_000), max_rank=2
             plain = search.QueryBatch(readers, prep, k).set_path(_lib.PATH_JOINED)
             ph, pc, pt = plain.run().results()
             shared = search.QueryBatch(readers, prep, k).set_shared_threshold(True)
-            sh, sc, st = shared.set_path(_lib.PATH_JOINED_PRUNED).run().results()
+            sh, sc, st = shared.set_path(_lib.PATH_JOINED).run().results()
             assert shared.reruns() == 0
             assert np.array_equal(pt, st)
             assert np.all(sc <= pc)

@@ -105,14 +105,6 @@ __device__ __forceinline__ void lds_add(const unsigned char* base, uint32_t off,
 __device__ __forceinline__ void lds_add(const unsigned char* base, uint32_t off, unsigned long long v) {
   atomicAdd(reinterpret_cast<unsigned long long*>(const_cast<unsigned char*>(base) + off), v);
 }
-__device__ __forceinline__ uint32_t lds_take(unsigned char* base, uint32_t off) {
-  return __atomic_exchange_n(reinterpret_cast<uint32_t*>(base + off), 0u, __ATOMIC_RELAXED);
-}
-__device__ __forceinline__ uint32_t lds_u32(const unsigned char* base, uint32_t off) {
-  uint32_t v;
-  __builtin_memcpy(&v, base + off, 4);
-  return v;
-}
 __device__ __forceinline__ void lds_read4(const unsigned char* base, uint32_t off, uint32_t (&v)[4]) {
   __builtin_memcpy(v, base + off, 16);
 }
@@ -141,16 +133,6 @@ __device__ __forceinline__ uint32_t gload_u32(uint64_t base, uint32_t off) {
 }
 __device__ __forceinline__ void gload_u32x4(uint64_t base, uint32_t off, uint32_t (&v)[4]) {
   __builtin_memcpy(v, reinterpret_cast<const uint8_t*>(base) + off, 16);
-}
-__device__ __forceinline__ uint32_t gload_u32_at(uint64_t addr) {
-  uint32_t v;
-  __builtin_memcpy(&v, reinterpret_cast<const uint8_t*>(addr), 4);
-  return v;
-}
-__device__ __forceinline__ uint32_t gload_u16_at(uint64_t addr) {
-  uint16_t v;
-  __builtin_memcpy(&v, reinterpret_cast<const uint8_t*>(addr), 2);
-  return v;
 }
 __device__ __forceinline__ void gload_u32x4_at(uint64_t addr, uint32_t (&v)[4]) {
   __builtin_memcpy(v, reinterpret_cast<const uint8_t*>(addr), 16);

@@ -232,7 +232,7 @@ def _threshold_worker(rank, world, port, sim_path, out_dir):
             for across in (False, True):
                 # (joined streams, whatever the cost rule makes of this small corpus)
                 b = search.QueryBatch(readers, prep, k).set_shared_threshold(True)
-                b.set_path(_lib.PATH_JOINED_PRUNED)
+                b.set_path(_lib.PATH_JOINED)
                 if across:
                     b.set_comm(comm)
                 b.run()
@@ -304,7 +304,7 @@ def test_two_ranks_share_one_threshold(simlib, tmp_path):
         prep = search.prepare(filters, scorer, [parity.segment_stats(s) for s in segs])
         for k in (10, 300):
             b = search.QueryBatch(readers, prep, k).set_shared_threshold(True)
-            h, c, _ = b.set_path(_lib.PATH_JOINED_PRUNED).run().results()
+            h, c, _ = b.set_path(_lib.PATH_JOINED).run().results()
             one = search.merge_topk_host([(h[i], c[i]) for i in range(len(segs))], k)
             got_h = np.load(tmp_path / ("A_%s_%d_hits.npy" % (tag, k))).view(_lib.HIT)
             got_c = np.load(tmp_path / ("A_%s_%d_counts.npy" % (tag, k)))

@@ -423,9 +423,9 @@ def test_rccl_behind_the_c_abi(gpulib):
     prep = search.prepare(filters, BM25(), [parity.segment_stats(s) for s in segs])
     from iresearch_amd import _lib
     # (joined streams, whatever the cost rule makes of this small batch: groups need them)
-    plain = search.QueryBatch(readers, prep, 300).set_shared_threshold(True).set_path(_lib.PATH_JOINED_PRUNED)
+    plain = search.QueryBatch(readers, prep, 300).set_shared_threshold(True).set_path(_lib.PATH_JOINED)
     ph, pc, pt = plain.run().results()
-    across = search.QueryBatch(readers, prep, 300).set_comm(comm).set_path(_lib.PATH_JOINED_PRUNED)
+    across = search.QueryBatch(readers, prep, 300).set_comm(comm).set_path(_lib.PATH_JOINED)
     ah, ac, at = across.run().results()
     assert across.reruns() == 0 and np.array_equal(pt, at)
     assert (search.merge_topk_host([(ph[i], pc[i]) for i in range(2)], 300)

@@ -55,22 +55,12 @@ def main():
             libs[name] = (L, search.SegmentReader.from_synth(seg, L=L))
         L, sr = libs[name]
         b = sr.batch(prep, args.k).profile(True)
-        # settings: items | exact[threads] (every posting accumulated) | pruned[threads][@alpha%]
-        # (non-essential lists left out, join.h k_join_ms; alpha: IRS_HIP_MS_ALPHA)
+        # settings: items | exact[threads] | [threads]  (the joined path at 256 / 512 / 1024 threads)
         if setting == "items":
             b.set_path(_lib.PATH_ITEMS)
-        elif setting.startswith("exact"):
-            os.environ["IRS_HIP_JOIN_THREADS"] = setting[5:] or "1024"
-            b.set_path(_lib.PATH_JOINED)
         else:
-            spec = setting[len("pruned"):] if setting.startswith("pruned") else setting
-            threads, _, alpha = spec.partition("@")
-            os.environ["IRS_HIP_JOIN_THREADS"] = threads or "1024"
-            if alpha:
-                os.environ["IRS_HIP_MS_ALPHA"] = alpha
-            else:
-                os.environ.pop("IRS_HIP_MS_ALPHA", None)
-            b.set_path(_lib.PATH_JOINED_PRUNED)
+            os.environ["IRS_HIP_JOIN_THREADS"] = (setting[5:] if setting.startswith("exact") else setting) or "1024"
+            b.set_path(_lib.PATH_JOINED)
         b.run()
         try:
             hits, counts, totals = b.results()
