@@ -30,7 +30,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+# ... and what a read-only stream of 16 B per lane really draws on this part
+# (tools/micro/fetch_calib.hip, profiles/r04_fetch_calib.txt: 6.3 - 6.4 TB/s; 4 B per lane: 4.06)
+HBM_MEASURED_GBS = 6300.0
 
 
 def log(*a):
@@ -215,6 +218,9 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    if not sim:
+        torch.zeros(1, device=dev)   # (the context exists before the first timed open)
+        sync()
 
     # ---- index: built on the host, staged to HBM once (not timed) ------------
     t0 = time.perf_counter()
@@ -245,8 +251,11 @@ def main():
 
     t0 = time.perf_counter()
     readers = {s: search.SegmentReader.from_synth(segs[s], device=local_rank, L=L) for s in my}
-    log("staged to HBM in %.1f s (%.1f MB resident on rank 0)" %
-        (time.perf_counter() - t0, sum(r.device_bytes() for r in readers.values()) / 1e6))
+    sync()
+    open_s = time.perf_counter() - t0
+    open_bytes = sum(segs[s].doc_file.size + segs[s].norms.size for s in my)
+    log("staged to HBM in %.2f s (%.1f MB resident on rank 0)" %
+        (open_s, sum(r.device_bytes() for r in readers.values()) / 1e6))
 
     # ---- queries ---------------------------------------------------------------
     # A step executes a batch of queries THAT HAS NEVER RUN: new term rows (their own seed; set 0
@@ -259,7 +268,7 @@ def main():
     # --query-sets N > 0: the round-1..3 protocol (N persistent batches replayed in rotation).
     replay = args.query_sets > 0
     n_probe = 3            # isolated (unpipelined) fresh batches, timed one by one
-    n_host = 0 if (world > 1 or sim) else max(2, min(args.steps, 8))
+    n_host = 0 if world > 1 else max(2, min(args.steps, 8))
     n_rows = max(1, args.query_sets) if replay else min(64, n_probe + args.warmup + args.steps + n_host)
     rank_sets = [synth.make_queries(args.queries, args.terms, 16, 4096,
                                     synth.SEED + 2 + (10 + i if i else 0)) for i in range(n_rows)]
@@ -317,7 +326,7 @@ def main():
     # a multi-segment batch writes [segment][query][k] hits and [segment][query] counts: exactly
     # consecutive slots of the send buffer
     slots = [{lead: exchange.slot(ph, my.index(lead)) for lead in groups} for ph in (0, 1)]
-    state = {"it": 0, "work": [], "joined": True, "reruns": 0, "retire": []}
+    state = {"it": 0, "work": [], "joined": True, "reruns": 0, "retire": [], "host_hits": 0}
 
     def deliver(prev):
         # a finished step: checked (irs_hip_batch_results_to_device waits for THAT batch's own
@@ -328,9 +337,13 @@ def main():
         if multi:
             exchange.finish(sptr)
         for s in cur:
-            if host_results:
-                cur[s].results()
             cur[s].results_to_device(slots[ph][s][0], slots[ph][s][1], sptr)
+            if host_results:
+                # ... and to page-locked host memory, where the reference's harness ends
+                # (index-search.cpp:782-807): queued on the library's download stream behind THIS
+                # batch's kernels only — the copy crosses PCIe while the next batch executes; the
+                # arrays are read (irs_hip_batch_host_results) when the batch is retired
+                cur[s].results_to_host()
         if rank == 0 and state.get("collect") is not None:
             # per-kernel HIP-event timings of that step (the batch's own events: no stream sync)
             state["collect"].append(np.sum([cur[s].timings() for s in cur], axis=0))
@@ -342,10 +355,17 @@ def main():
             # a delivered batch is destroyed one step LATER: its result copies were queued behind
             # the next step's kernels, and irs_hip_batch_destroy waits for them (its buffers go
             # back to the library's pool) — by then they are through
-            for b in state["retire"]:
-                state["reruns"] += b.reruns()
-                b.close()
-            state["retire"] = list(cur.values())
+            retire()
+            state["retire"] = [(b, host_results) for b in cur.values()]
+
+    def retire():
+        for b, host_results in state["retire"]:
+            if host_results:
+                hits, counts, totals = b.host_results()   # waits for that batch's copy
+                state["host_hits"] += int(counts.sum())   # (the arrays are read)
+            state["reruns"] += b.reruns()
+            b.close()
+        state["retire"] = []
 
     def step(host_results=False):
         # Steps are software-pipelined one deep: the batch of step i is prepared, created and
@@ -353,14 +373,13 @@ def main():
         # step i while the GPU still runs step i-1, and waits on step i-1's event while the GPU
         # already runs step i: no per-step host/device round trip on the critical path.  Every
         # step still ends (one step later; flush() for the last) with a checked,
-        # device-resident top-k.  host_results: the hits also go to host memory
-        # (irs_hip_batch_results), where the reference's harness ends
-        # (index-search.cpp:782-807) — that variant is not pipelined.
+        # device-resident top-k.  host_results: the hits also go to page-locked host memory
+        # (irs_hip_batch_results_to_host), pipelined like everything else.
         ph = state["it"] & 1
         cur = batch_sets[state["it"] % n_rows] if replay else make_batches(state["it"])
         state["it"] += 1
         prev = state.get("prev")
-        if prev is not None and (prev[0] is cur or host_results or prev[2]):
+        if prev is not None and prev[0] is cur:
             deliver(prev)     # the same batch again (replay of one set): its results go out first
             prev = None
         for s in cur:
@@ -376,10 +395,7 @@ def main():
         out = exchange.finish(sptr) if multi else None
         if not replay:
             sync()
-            for b in state["retire"]:
-                state["reruns"] += b.reruns()
-                b.close()
-            state["retire"] = []
+            retire()
         return out
 
     def total_reruns():
@@ -481,6 +497,10 @@ def main():
                 kernel = "k_score"
             roof = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                    "peak_measured": HBM_MEASURED_GBS,
+                    "peak_measured_source": "tools/micro/fetch_calib.hip: read-only stream, 16 B per lane "
+                                            "(profiles/r04_fetch_calib.txt)",
+                    "frac_of_measured": round(achieved / HBM_MEASURED_GBS, 5),
                     # (no fraction of its own for the larger of the two kernels: the algorithmic
                     # bytes are consumed by the decode stage, not by it)
                     "dominant_kernel": {"name": "k_join_score" if joined else "k_score",
@@ -505,6 +525,10 @@ def main():
                             "%d queries/step" % (args.terms, k, args.docs, n_segments, nq),
                 "segments": n_segments, "queries_per_step": nq, "layout": "1_5simd",
                 "indexed_ranks": args.max_rank,
+                # irs_hip_segment_open of this rank's segments (file bytes over PCIe + the block
+                # directory, packed image and tail tables built on the GPU), once per segment
+                "segment_open": {"seconds": round(open_s, 3), "file_bytes": int(open_bytes),
+                                 "GB_per_s": round(open_bytes / open_s / 1e9, 3)},
                 "path": "joined posting streams (k_join once per distinct term of the batch, "
                         "k_join_score per query)" if joined
                         else "work items (every query decodes its own blocks)",

@@ -271,6 +271,15 @@ int irs_hip_batch_create_multi(irs_hip_segment* const* segs, uint32_t n_segs,
                                const irs_hip_query* queries, uint32_t n_queries,
                                const irs_hip_term_scorer* terms, uint32_t n_term_entries,
                                irs_hip_batch** out);
+/* Executes the batch on `stream` (NULL: the default stream).  Asynchronous twice over: the
+ * kernels are only queued, and the host half of a run — dealing the units to the kernels, building
+ * the batch's posting streams and work lists, queueing uploads and launches (about 1 ms per 1000
+ * queries) — is handed to a worker thread of the library (one per device), so that a serving loop
+ * prepares batch i + 1 while batch i is being queued and batch i - 1 executes (the reference runs
+ * its tasks on --threads workers, index-search.cpp:673-722).  Every other call on the batch waits
+ * for that hand-over first; a failure of the run is returned by the next such call (results,
+ * device_results, timings, destroy ...).  IRS_HIP_ASYNC_RUN=0 in the environment keeps the host
+ * half on the caller's thread (and the status in this call's return value). */
 int irs_hip_batch_run(irs_hip_batch* batch, void* stream);
 /* Optional: queue the PLANNING stage of the batch's next run (tile tables, work items: what
  * building the iterator tree is to filter::prepared::execute) on `stream` now; the next
@@ -299,6 +308,18 @@ int irs_hip_query_batch(irs_hip_segment* seg, const irs_hip_query* queries,
                         uint32_t n_term_entries, irs_hip_hit* hits,
                         uint32_t k_stride, uint32_t* counts,
                         uint64_t* total_hits);
+
+/* The checked results of the batch's last run on their way to page-locked HOST memory owned by
+ * the batch — where the reference's harness ends (index-search.cpp:782-807) — without stalling the
+ * caller: results_to_host verifies the run (like irs_hip_batch_device_results) and queues the copy on
+ * `stream` (NULL: the device's download stream) behind the batch's own kernels only, so the hits of
+ * batch i cross PCIe while batch i + 1 executes; host_results waits for that copy and hands out the
+ * arrays: hits [n_queries][*k_stride] (score desc, doc asc; counts[q] valid entries), counts
+ * [n_queries], total_hits [n_queries].  They stay valid until the batch is destroyed, run again or
+ * copied again. */
+int irs_hip_batch_results_to_host(irs_hip_batch* batch, void* stream);
+int irs_hip_batch_host_results(irs_hip_batch* batch, const irs_hip_hit** hits, uint32_t* k_stride,
+                               const uint32_t** counts, const uint64_t** total_hits);
 
 /* Tuning knobs (0 keeps the default). tile_docs in {4096, 6144, 8192, 12288}: docs
  * per LDS accumulator tile (default: the largest one that lets two workgroups share

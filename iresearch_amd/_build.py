@@ -71,7 +71,7 @@ def build_hip(force: bool = False) -> Path:
         raise RuntimeError("hipcc not found and %s is not prebuilt" % HIP_LIB)
     # -ffp-contract=off: BM25 is evaluated with the reference's operation order
     # and no FMA fusion, so per-term scores are bit-identical to the CPU path.
-    _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
           "-ffp-contract=off", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
           "-I", REPO / "include", "-I", HIP_DIR, "-I", HIP_DIR / "hip", "-o", HIP_LIB, *hip_sources()])
     return HIP_LIB

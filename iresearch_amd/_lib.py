@@ -63,6 +63,7 @@ SYMBOLS = (
     "irs_hip_term_directory", "irs_hip_bit_union", "irs_hip_batch_create",
     "irs_hip_batch_create_multi", "irs_hip_batch_run",
     "irs_hip_batch_results", "irs_hip_batch_device_results",
+    "irs_hip_batch_results_to_host", "irs_hip_batch_host_results",
     "irs_hip_batch_results_to_device", "irs_hip_batch_destroy",
     "irs_hip_query_batch", "irs_hip_batch_configure", "irs_hip_batch_profile",
     "irs_hip_batch_timings", "irs_hip_batch_work", "irs_hip_batch_reruns", "irs_hip_merge_topk",
@@ -104,6 +105,10 @@ def bind(L: C.CDLL) -> C.CDLL:
     L.irs_hip_batch_create_multi.argtypes = [vp, u32, vp, u32, vp, u32, P(vp)]
     L.irs_hip_batch_create_multi.restype = C.c_int
     L.irs_hip_batch_run.argtypes, L.irs_hip_batch_run.restype = [vp, vp], C.c_int
+    L.irs_hip_batch_results_to_host.argtypes = [vp, vp]
+    L.irs_hip_batch_results_to_host.restype = C.c_int
+    L.irs_hip_batch_host_results.argtypes = [vp, P(vp), P(u32), P(vp), P(vp)]
+    L.irs_hip_batch_host_results.restype = C.c_int
     L.irs_hip_batch_results.argtypes = [vp, vp, u32, vp, vp]
     L.irs_hip_batch_results.restype = C.c_int
     L.irs_hip_batch_device_results.argtypes = [vp, P(vp), P(vp), P(u32)]

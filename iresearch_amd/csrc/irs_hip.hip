@@ -7,12 +7,15 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "gpu_rt.h"
@@ -182,17 +185,22 @@ struct Stager {
 // they would start only when the previous batch's kernels are through (0.2 ms of idle compute per
 // step for the headline batch's 5 MB); on their own stream they travel while those kernels run,
 // and the run waits for them by an event.
-rt::stream_t upload_stream(int device) {
+rt::stream_t copy_stream(int device, int which) {
   static std::mutex m;
   static std::map<int, rt::stream_t> streams;
   std::lock_guard<std::mutex> lock(m);
-  auto it = streams.find(device);
+  const int key = device * 2 + which;
+  auto it = streams.find(key);
   if (it != streams.end()) return it->second;
   rt::stream_t s = nullptr;
   if (!rt::stream_create(&s)) s = nullptr;   // (null: the caller keeps its own stream)
-  streams[device] = s;
+  streams[key] = s;
   return s;
 }
+rt::stream_t upload_stream(int device) { return copy_stream(device, 0); }
+// ... and one for results on their way to page-locked host memory (irs_hip_batch_results_to_host):
+// the copy of batch i travels while the kernels of batch i + 1 run
+rt::stream_t download_stream(int device) { return copy_stream(device, 1); }
 
 // IRS_HIP_TRACE=1: host-side stage times on stderr (what a batch costs before its first kernel)
 struct HostTrace {
@@ -398,6 +406,17 @@ struct irs_hip_batch {
   bool ev_used_ready = false, ev_used_pending = false;
   rt::event_t ev_up{};         // the first run's table uploads (the device's copy stream)
   bool ev_up_ready = false;
+  // irs_hip_batch_results_to_host: hits, counts and totals in page-locked memory of the batch
+  PinBuf h_res;
+  rt::event_t ev_host{};
+  bool ev_host_ready = false, host_pending = false;
+  // irs_hip_batch_run hands the host half of a run (units dealt, streams and work lists built,
+  // uploads and launches queued: ~1 ms for 1000 queries) to the device's worker thread and returns;
+  // every other entry point waits here for it first.  async_rc: what that run returned.
+  std::mutex am;
+  std::condition_variable acv;
+  bool async_pending = false;
+  int async_rc = 0;
 };
 
 namespace {
@@ -1633,6 +1652,110 @@ int guarded(F&& f) noexcept {
 }
 
 extern "C" {
+static int run_impl(irs_hip_batch* b, rt::stream_t st);
+}
+
+// ---- the host half of a run, off the caller's thread -------------------------------------------
+// One worker thread per device (started with the first run).  A caller that serves batches in a
+// loop prepares and creates batch i + 1 while the worker deals the units of batch i, builds its
+// streams and work lists and queues its uploads and kernels; the GPU meanwhile executes batch
+// i - 1.  At one GPU the kernels hide all of it; with 8 ranks a rank's kernels take as long as this
+// host work (index-search runs its queries on --threads workers for the same reason:
+// index-search.cpp:673-722).  IRS_HIP_ASYNC_RUN=0 runs everything on the caller's thread.
+namespace worker {
+struct Job {
+  irs_hip_batch* b;
+  rt::stream_t st;
+};
+struct Queue {
+  std::mutex m;
+  std::condition_variable cv;
+  std::deque<Job> jobs;
+  std::thread th;
+  bool started = false, stop = false;
+  int device = 0;
+  ~Queue() {
+    {
+      std::lock_guard<std::mutex> lock(m);
+      stop = true;
+    }
+    cv.notify_all();
+    if (th.joinable()) th.join();
+  }
+};
+static Queue& of(int device) {
+  static Queue queues[pool::kMaxDevices];
+  return queues[device >= 0 && device < pool::kMaxDevices ? device : 0];
+}
+static void loop(Queue* q) {
+  rt::set_device(q->device);
+  for (;;) {
+    Job job;
+    {
+      std::unique_lock<std::mutex> lock(q->m);
+      q->cv.wait(lock, [&] { return q->stop || !q->jobs.empty(); });
+      if (q->jobs.empty()) return;   // (stop)
+      job = q->jobs.front();
+      q->jobs.pop_front();
+    }
+    const int rc = guarded([&] {
+      if (!rt::set_device(job.b->seg->device)) return int(IRS_HIP_EHIP);
+      return run_impl(job.b, job.st);
+    });
+    {
+      std::lock_guard<std::mutex> lock(job.b->am);
+      job.b->async_rc = rc;
+      job.b->async_pending = false;
+    }
+    job.b->acv.notify_all();
+  }
+}
+static bool enabled() {
+  static const bool on = [] {
+    const char* e = std::getenv("IRS_HIP_ASYNC_RUN");
+    return !e || std::atoi(e) != 0;
+  }();
+  return on;
+}
+static bool submit(irs_hip_batch* b, rt::stream_t st) {
+  Queue& q = of(b->seg->device);
+  {
+    std::lock_guard<std::mutex> lock(b->am);
+    b->async_pending = true;
+    b->async_rc = IRS_HIP_OK;
+  }
+  std::lock_guard<std::mutex> lock(q.m);
+  if (!q.started) {
+    q.device = b->seg->device;
+    q.th = std::thread(loop, &q);
+    q.started = true;
+  }
+  q.jobs.push_back(Job{b, st});
+  q.cv.notify_one();
+  return true;
+}
+}  // namespace worker
+
+// Before anything else touches a batch: its run, if one was handed to the worker, is queued.
+// Returns what that run returned (once).
+static int settle(irs_hip_batch* b) {
+  if (!b) return IRS_HIP_OK;
+  std::unique_lock<std::mutex> lock(b->am);
+  b->acv.wait(lock, [&] { return !b->async_pending; });
+  const int rc = b->async_rc;
+  b->async_rc = IRS_HIP_OK;
+  return rc;
+}
+// an entry point's body behind the batch's pending run
+template<typename F>
+static int settled(irs_hip_batch* b, F&& f) noexcept {
+  return guarded([&] {
+    if (const int rc = settle(b)) return rc;
+    return f();
+  });
+}
+
+extern "C" {
 
 uint32_t irs_hip_abi_version(void) { return IRS_HIP_ABI_VERSION; }
 
@@ -2732,6 +2855,10 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st) {
 static int batch_run_impl(irs_hip_batch* b, void* stream) {
   if (!b) return IRS_HIP_EINVAL;
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
+  if (worker::enabled()) {   // (what the run returns is reported by the next call on the batch)
+    worker::submit(b, static_cast<rt::stream_t>(stream));
+    return IRS_HIP_OK;
+  }
   return run_impl(b, static_cast<rt::stream_t>(stream));
 }
 
@@ -2945,8 +3072,57 @@ static int batch_results_to_device_impl(irs_hip_batch* b, void* d_hits, void* d_
   return IRS_HIP_OK;
 }
 
+// The checked results on their way to page-locked host memory, asynchronously: where the
+// reference's harness ends (index-search.cpp:782-807: the sorted (score, doc) pairs of every task
+// in host memory).  The copy is queued on `stream` (null: the device's download stream) behind the
+// batch's own last run — NOT behind whatever the caller has queued since, so the results of batch i
+// cross PCIe while the kernels of batch i + 1 run.
+static int batch_results_to_host_impl(irs_hip_batch* b, void* stream) {
+  if (!b || !b->ran) return IRS_HIP_EINVAL;
+  if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
+  const int rc = verify_run(b);
+  if (rc != IRS_HIP_OK) return rc;
+  const size_t hit_bytes = size_t(b->nq) * b->k_max * sizeof(Hit);
+  const size_t cnt_off = (hit_bytes + 63) & ~size_t(63);
+  const size_t tot_off = cnt_off + ((size_t(b->nq) * 4 + 63) & ~size_t(63));
+  const size_t total = tot_off + size_t(b->nq) * 8;
+  if (b->host_pending && !rt::event_sync(b->ev_host)) return IRS_HIP_EHIP;   // (the previous copy)
+  b->host_pending = false;
+  if (b->h_res.n < total && !b->h_res.alloc(total)) return IRS_HIP_ENOMEM;
+  rt::stream_t st = stream ? static_cast<rt::stream_t>(stream) : download_stream(b->seg->device);
+  if (!st) st = b->stream;
+  if (!b->ev_host_ready) b->ev_host_ready = rt::event_create(&b->ev_host);
+  uint8_t* h = b->h_res.as<uint8_t>();
+  if (!b->ev_host_ready || !rt::stream_wait(st, b->ev_done) ||
+      !rt::d2h(h, b->d_out.p, hit_bytes, st) ||
+      !rt::d2h(h + cnt_off, b->d_out_count.p, size_t(b->nq) * 4, st) ||
+      !rt::d2h(h + tot_off, b->d_hits.p, size_t(b->nq) * 8, st) ||
+      !rt::event_record(b->ev_host, st))
+    return IRS_HIP_EHIP;
+  b->host_pending = true;
+  return IRS_HIP_OK;
+}
+
+static int batch_host_results_impl(irs_hip_batch* b, const irs_hip_hit** hits, uint32_t* k_stride,
+                                   const uint32_t** counts, const uint64_t** total_hits) {
+  if (!b || !b->host_pending) return IRS_HIP_EINVAL;
+  if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
+  if (!rt::event_sync(b->ev_host)) return IRS_HIP_EHIP;
+  const size_t hit_bytes = size_t(b->nq) * b->k_max * sizeof(Hit);
+  const size_t cnt_off = (hit_bytes + 63) & ~size_t(63);
+  const size_t tot_off = cnt_off + ((size_t(b->nq) * 4 + 63) & ~size_t(63));
+  const uint8_t* h = b->h_res.as<uint8_t>();
+  static_assert(sizeof(irs_hip_hit) == sizeof(Hit), "irs_hip_hit is the device's Hit");
+  if (hits) *hits = reinterpret_cast<const irs_hip_hit*>(h);
+  if (k_stride) *k_stride = b->k_max;
+  if (counts) *counts = reinterpret_cast<const uint32_t*>(h + cnt_off);
+  if (total_hits) *total_hits = reinterpret_cast<const uint64_t*>(h + tot_off);
+  return IRS_HIP_OK;
+}
+
 void irs_hip_batch_destroy(irs_hip_batch* b) {
   if (!b) return;
+  settle(b);
   rt::set_device(b->seg->device);
   // Its buffers go back to the pool: every piece of queued work that touches them must be
   // through — the batch's own last run (ev_done), a plan queued ahead, copies out of d_out.
@@ -2956,6 +3132,7 @@ void irs_hip_batch_destroy(irs_hip_batch* b) {
   if (b->planned || b->plan_pending)
     waited = waited && b->ev_planned_ready && rt::event_sync(b->ev_planned);
   if (b->ev_used_pending) waited = waited && rt::event_sync(b->ev_used);
+  if (b->host_pending) waited = waited && rt::event_sync(b->ev_host);
   if (!waited && b->ran) rt::sync(b->stream);
   if (b->events_ready)
     for (auto& e : b->ev) rt::event_destroy(e);
@@ -2963,6 +3140,7 @@ void irs_hip_batch_destroy(irs_hip_batch* b) {
   if (b->ev_planned_ready) rt::event_destroy(b->ev_planned);
   if (b->ev_used_ready) rt::event_destroy(b->ev_used);
   if (b->ev_up_ready) rt::event_destroy(b->ev_up);
+  if (b->ev_host_ready) rt::event_destroy(b->ev_host);
   delete b;
 }
 
@@ -3029,28 +3207,28 @@ int irs_hip_batch_create_multi(irs_hip_segment* const* segs, uint32_t n_segs, co
   return guarded([&] { return batch_create_multi_impl(segs, n_segs, queries, nq_user, all_terms, n_entries, out); });
 }
 int irs_hip_batch_configure(irs_hip_batch* b, uint32_t tile_docs, uint32_t pilot_stride, uint32_t cand_cap) {
-  return guarded([&] { return batch_configure_impl(b, tile_docs, pilot_stride, cand_cap); });
+  return settled(b, [&] { return batch_configure_impl(b, tile_docs, pilot_stride, cand_cap); });
 }
 int irs_hip_batch_profile(irs_hip_batch* b, int enable) {
-  return guarded([&] { return batch_profile_impl(b, enable); });
+  return settled(b, [&] { return batch_profile_impl(b, enable); });
 }
 int irs_hip_batch_set_path(irs_hip_batch* b, int path) {
-  return guarded([&] { return batch_set_path_impl(b, path); });
+  return settled(b, [&] { return batch_set_path_impl(b, path); });
 }
 int irs_hip_batch_set_shared_threshold(irs_hip_batch* b, int enable) {
-  return guarded([&] { return batch_set_shared_threshold_impl(b, enable); });
+  return settled(b, [&] { return batch_set_shared_threshold_impl(b, enable); });
 }
 int irs_hip_batch_set_comm(irs_hip_batch* b, irs_hip_comm* comm) {
-  return guarded([&] { return batch_set_comm_impl(b, comm); });
+  return settled(b, [&] { return batch_set_comm_impl(b, comm); });
 }
 int irs_hip_batch_path(irs_hip_batch* b, int* path) {
-  return guarded([&] { return batch_path_impl(b, path); });
+  return settled(b, [&] { return batch_path_impl(b, path); });
 }
 int irs_hip_batch_set_wand(irs_hip_batch* b, int enable) {
-  return guarded([&] { return batch_set_wand_impl(b, enable); });
+  return settled(b, [&] { return batch_set_wand_impl(b, enable); });
 }
 int irs_hip_batch_set_min_scores(irs_hip_batch* b, const float* min_scores) {
-  return guarded([&] { return batch_set_min_scores_impl(b, min_scores); });
+  return settled(b, [&] { return batch_set_min_scores_impl(b, min_scores); });
 }
 int irs_hip_term_blockmax(irs_hip_segment* seg, uint32_t term, uint32_t* max_freqs,
                           uint32_t* min_norms, uint32_t cap, uint32_t* count) {
@@ -3123,31 +3301,38 @@ int irs_hip_topk_allgather(irs_hip_comm* c, const void* d_send, void* d_recv,
   return guarded([&] { return topk_allgather_impl(c, d_send, d_recv, bytes_per_rank, stream); });
 }
 int irs_hip_batch_touched(irs_hip_batch* b, uint64_t* doc_bytes, uint64_t* positions) {
-  return guarded([&] { return batch_touched_impl(b, doc_bytes, positions); });
+  return settled(b, [&] { return batch_touched_impl(b, doc_bytes, positions); });
 }
 int irs_hip_batch_plan(irs_hip_batch* b, void* stream) {
-  return guarded([&] { return batch_plan_impl(b, stream); });
+  return settled(b, [&] { return batch_plan_impl(b, stream); });
 }
 int irs_hip_batch_run(irs_hip_batch* b, void* stream) {
-  return guarded([&] { return batch_run_impl(b, stream); });
+  return settled(b, [&] { return batch_run_impl(b, stream); });
+}
+int irs_hip_batch_results_to_host(irs_hip_batch* b, void* stream) {
+  return settled(b, [&] { return batch_results_to_host_impl(b, stream); });
+}
+int irs_hip_batch_host_results(irs_hip_batch* b, const irs_hip_hit** hits, uint32_t* k_stride,
+                               const uint32_t** counts, const uint64_t** total_hits) {
+  return settled(b, [&] { return batch_host_results_impl(b, hits, k_stride, counts, total_hits); });
 }
 int irs_hip_batch_timings(irs_hip_batch* b, float ms[IRS_HIP_K_COUNT]) {
-  return guarded([&] { return batch_timings_impl(b, ms); });
+  return settled(b, [&] { return batch_timings_impl(b, ms); });
 }
 int irs_hip_batch_reruns(irs_hip_batch* b, uint32_t* count) {
-  return guarded([&] { return batch_reruns_impl(b, count); });
+  return settled(b, [&] { return batch_reruns_impl(b, count); });
 }
 int irs_hip_batch_work(irs_hip_batch* b, uint64_t* algorithmic_bytes, uint64_t* postings) {
-  return guarded([&] { return batch_work_impl(b, algorithmic_bytes, postings); });
+  return settled(b, [&] { return batch_work_impl(b, algorithmic_bytes, postings); });
 }
 int irs_hip_batch_results(irs_hip_batch* b, irs_hip_hit* hits, uint32_t k_stride, uint32_t* counts, uint64_t* total_hits) {
-  return guarded([&] { return batch_results_impl(b, hits, k_stride, counts, total_hits); });
+  return settled(b, [&] { return batch_results_impl(b, hits, k_stride, counts, total_hits); });
 }
 int irs_hip_batch_device_results(irs_hip_batch* b, void** d_hits, void** d_counts, uint32_t* k_max) {
-  return guarded([&] { return batch_device_results_impl(b, d_hits, d_counts, k_max); });
+  return settled(b, [&] { return batch_device_results_impl(b, d_hits, d_counts, k_max); });
 }
 int irs_hip_batch_results_to_device(irs_hip_batch* b, void* d_hits, void* d_counts, void* stream) {
-  return guarded([&] { return batch_results_to_device_impl(b, d_hits, d_counts, stream); });
+  return settled(b, [&] { return batch_results_to_device_impl(b, d_hits, d_counts, stream); });
 }
 int irs_hip_query_batch(irs_hip_segment* seg, const irs_hip_query* queries, uint32_t nq, const irs_hip_term_scorer* terms, uint32_t n_entries, irs_hip_hit* hits, uint32_t k_stride, uint32_t* counts, uint64_t* total_hits) {
   return guarded([&] { return query_batch_impl(seg, queries, nq, terms, n_entries, hits, k_stride, counts, total_hits); });

@@ -468,6 +468,31 @@ class QueryBatch:
                     totals.reshape(n, self.nq_user))
         return hits, counts, totals
 
+    def results_to_host(self, stream=None):
+        """Queue the copy of the checked results to page-locked host memory
+        (irs_hip_batch_results_to_host); host_results() waits for it."""
+        _lib.check(self.L, self.L.irs_hip_batch_results_to_host(self.handle, stream),
+                   "irs_hip_batch_results_to_host")
+        return self
+
+    def host_results(self):
+        """(hits HIT[nq][k_max], counts[nq], totals[nq]) as numpy VIEWS of the batch's page-locked
+        result memory: valid until the batch is closed, run or copied again."""
+        hp, cp, tp, ks = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint32()
+        _lib.check(self.L, self.L.irs_hip_batch_host_results(
+            self.handle, C.byref(hp), C.byref(ks), C.byref(cp), C.byref(tp)),
+            "irs_hip_batch_host_results")
+        k = int(ks.value)
+        hits = np.frombuffer((C.c_uint8 * (self.nq * k * HIT.itemsize)).from_address(hp.value), HIT)
+        counts = np.frombuffer((C.c_uint8 * (self.nq * 4)).from_address(cp.value), np.uint32)
+        totals = np.frombuffer((C.c_uint8 * (self.nq * 8)).from_address(tp.value), np.uint64)
+        hits = hits.reshape(self.nq, k)
+        if self.multi:
+            n = len(self.segs)
+            return (hits.reshape(n, self.nq_user, k), counts.reshape(n, self.nq_user),
+                    totals.reshape(n, self.nq_user))
+        return hits, counts, totals
+
     def device_results(self):
         dh, dc, km = C.c_void_p(), C.c_void_p(), C.c_uint32()
         _lib.check(self.L, self.L.irs_hip_batch_device_results(

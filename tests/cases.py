@@ -937,6 +937,53 @@ def case_fresh_batches_and_trim(L):
     sr.close()
 
 
+def case_host_results(L):
+    """irs_hip_batch_results_to_host / _host_results: the checked results in the batch's own
+    page-locked memory, queued behind the batch's run only — the copy of batch i is requested after
+    batch i + 1 was handed to the library's worker thread (irs_hip_batch_run returns before the
+    run is queued) — equal what irs_hip_batch_results returns, single- and multi-segment, also
+    after a re-run (estimated threshold misled: the copy follows the repeated run)."""
+    seg = synth.build_segment(60_000, 256)
+    seg2 = synth.build_segment(9_000, 256, first_doc=60_000)
+    sr, sr2 = (search.SegmentReader.from_synth(x, L=L) for x in (seg, seg2))
+    st = [parity.segment_stats(seg), parity.segment_stats(seg2)]
+    sets = []
+    for i in range(3):
+        ranks = synth.make_queries(5 + 2 * i, 3 + 2 * i, 2, 256, synth.SEED + 70 + i)
+        filters = [Or([by_term(int(r) - 1) for r in row]) for row in ranks]
+        filters += [And([by_term(3 + i), by_term(40)]), by_term(200 + i)]
+        sets.append(search.prepare(filters, BM25(), st))
+    for readers in (sr, [sr, sr2]):
+        ref = []
+        for prep in sets:
+            b = search.QueryBatch(readers, prep, 40)
+            ref.append([x.copy() for x in b.run().results()])
+            b.close()
+        pending = None
+        for i in (0, 2, 1, 1, 0):
+            b = search.QueryBatch(readers, sets[i], 40).run()
+            if pending is not None:
+                j, pb = pending
+                got = pb.results_to_host().host_results()
+                assert all(np.array_equal(a, g) for a, g in zip(ref[j], got)), j
+                # (again: a second copy waits for the first)
+                got = pb.results_to_host().results_to_host().host_results()
+                assert all(np.array_equal(a, g) for a, g in zip(ref[j], got)), j
+                pb.close()
+            pending = (i, b)
+        j, pb = pending
+        got = pb.results_to_host().host_results()
+        assert all(np.array_equal(a, g) for a, g in zip(ref[j], got)), j
+        pb.close()
+    # no copy requested: EINVAL, not stale memory
+    b = sr.batch(sets[0], 40).run()
+    hp = C.c_void_p()
+    assert L.irs_hip_batch_host_results(b.handle, C.byref(hp), None, None, None) == _lib.EINVAL
+    b.close()
+    sr.close()
+    sr2.close()
+
+
 def case_min_score_pushdown(L):
     """irs::score::Min (score_function.hpp:42-142; the harness pushes its heap's k-th score,
     index-search.cpp:737-777): with the k-th score of a first run as threshold the same top-k

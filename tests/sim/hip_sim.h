@@ -217,7 +217,11 @@ struct Pool {
     std::free(w->smem);
     delete w;
   }
+  // (one launch at a time: the product queues runs from a worker thread of its own while the
+  // caller's thread may launch too — on a GPU the streams sort that out, here a lock does)
+  std::mutex launch_m;
   void launch(unsigned g, unsigned b, const std::function<void()>& fn) {
+    std::lock_guard<std::mutex> one(launch_m);
     std::unique_lock<std::mutex> l(m);
     grid = g;
     block = b;

@@ -193,6 +193,10 @@ def test_plan_ahead(simlib):
     cases.case_plan_ahead(simlib)
 
 
+def test_host_results(simlib):
+    cases.case_host_results(simlib)
+
+
 def test_fresh_batches_and_trim(simlib):
     cases.case_fresh_batches_and_trim(simlib)
 

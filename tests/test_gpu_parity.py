@@ -240,6 +240,12 @@ def test_plan_ahead(gpulib):
     cases.case_plan_ahead(gpulib)
 
 
+@pytest.mark.gpu
+def test_host_results(gpulib):
+    cases.case_host_results(gpulib)
+
+
+@pytest.mark.gpu
 def test_fresh_batches_and_trim(gpulib):
     cases.case_fresh_batches_and_trim(gpulib)
 
