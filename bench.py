@@ -180,7 +180,17 @@ def main():
                     help="one batch per local segment instead of one batch over all of them (A/B)")
     ap.add_argument("--force-segments", action="store_true",
                     help="use the multi-segment path (merge kernel) even on one GPU")
+    ap.add_argument("--tasks", action="store_true",
+                    help="replay the reference harness's task classes (scripts/iresearch-benchmark.tasks: "
+                         "HighTerm ... MinMatch2High2Med) through the C ABI and through the restated CPU "
+                         "loop, one line per category; not the headline metric")
+    ap.add_argument("--tasks-file", default=None,
+                    help="a task list in the harness's grammar (default: the reference's own, "
+                         "tests/golden/benchmark_tasks.json)")
+    ap.add_argument("--scorer", default="bm25", choices=["bm25", "tfidf"])
     args = ap.parse_args()
+    if args.tasks:
+        return main_tasks(args)
     if args.config == 5:
         return main_config5(args)
 
@@ -802,6 +812,125 @@ def main_config5(args):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main_tasks(args):
+    """The reference's own task classes (index-search.cpp:91-449 over
+    scripts/iresearch-benchmark.tasks), each as a batch of --queries distinct queries of the class
+    — the task's words mapped to the Zipf ranks of the same document-frequency share, jittered
+    +-25 % per query — executed (a) through the C ABI: every step a new batch, created, run,
+    results delivered to host memory, destroyed, pipelined one deep; (b) by the restated CPU loop
+    (oracle: index-search's heap loop) on the container's CPUs; with a parity check of the first
+    queries of every class.  One line per category."""
+    import concurrent.futures as cf
+
+    import torch
+
+    import oracle
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import parity
+    from iresearch_amd import _lib, search, synth, tasks
+    from iresearch_amd.search import BM25, TFIDF
+    sim = os.environ.get("IRS_BENCH_SIM")
+    if sim:
+        import ctypes
+        L = _lib.bind(ctypes.CDLL(sim))
+        sync = lambda: None
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+        torch.cuda.set_device(0)
+        L = _lib.lib()
+        sync = torch.cuda.synchronize
+    max_rank = args.max_rank if args.max_rank != 4096 else 262144
+    nq = args.queries if args.queries != 1000 else 256
+    k = args.k if args.k != 1000 else 100          # scripts/search-benchmark.sh: --topN=100
+    t0 = time.perf_counter()
+    seg = synth.build_segment(args.docs, max_rank, with_positions=True)
+    log("built %d docs, ranks 1..%d with positions in %.1f s" % (args.docs, max_rank, time.perf_counter() - t0))
+    sr = search.SegmentReader.from_synth(seg, device=0, L=L)
+    st = [parity.segment_stats(seg)]
+    scorer = BM25() if args.scorer == "bm25" else TFIDF(False)
+    osc = parity.oracle_scorer(scorer)
+    view = parity.oracle_view(seg)
+    if args.tasks_file:
+        with open(args.tasks_file) as f:
+            lines = f.read().splitlines()
+    else:   # the reference's own list, as tests/golden/make_tasks_golden.py extracted it
+        with open(os.path.join(ROOT, "tests", "golden", "benchmark_tasks.json")) as f:
+            lines = json.load(f)["lines"]
+    cores = usable_cpus()
+    native = False if sim else oracle.use_native()
+    rows = []
+    print("# %s, %d docs, ranks 1..%d, top-%d, %d distinct queries per class and step, CPU: %d threads (%s)" % (
+        args.scorer, args.docs, max_rank, k, nq, cores, "-O3 -march=native" if native else "-O2"))
+    print("# category            terms  ranks of the task's words          hits/query   GPU q/s    CPU q/s   GPU/CPU  parity")
+    for t in tasks.parse_tasks(lines, 1):
+        if t.category in tasks.EXPANSION:
+            print("%-20s (multi-term expansion filter: not on this path)" % t.category)
+            continue
+        rng = np.random.default_rng(20260926 + len(rows))
+        base = tasks.ranks_of(t, max_rank)
+        queries = [tasks.ranks_of(t, max_rank, 0.25, rng) for _ in range(nq)]
+        filters = [tasks.filter_of(t, r) for r in queries]
+        phrase = t.category in tasks.PHRASE
+
+        def make():
+            prep = search.prepare(filters, scorer, st)          # (inside the step, as the harness)
+            return sr.batch(prep, k).run()
+        # parity of the first queries of the class
+        b = make()
+        hits, counts, totals = (x.copy() for x in b.results_to_host().host_results())
+        b.close()
+        n_par = min(nq, 4 if args.docs > 2_000_000 else 8)
+        check = parity.check_phrase_segment if phrase else parity.check_single_segment
+        check(seg, filters[:n_par], scorer, k, hits[:n_par], counts[:n_par], totals[:n_par])
+        # GPU: fresh batches, one deep
+        steps = max(2, args.steps)
+        for timed in (False, True):
+            sync()
+            t0 = time.perf_counter()
+            prev = None
+            for _ in range(steps if timed else 1):
+                cur = make()
+                if prev is not None:
+                    prev.results_to_host().host_results()
+                    prev.close()
+                prev = cur
+            prev.results_to_host().host_results()
+            prev.close()
+            sync()
+            gpu_dt = (time.perf_counter() - t0) / (steps if timed else 1)
+        # CPU: the same queries (a bounded sample), the threads pop one task queue
+        metas = [parity.metas_for(seg, [r - 1 for r in q])[None] for q in queries]
+
+        def run_cpu(i):
+            if phrase:
+                oracle.search_phrase([view], metas[i], list(range(len(queries[i]))), osc, k, 1.0)
+            else:
+                flt = filters[i]
+                op = parity.oracle_op(flt, search._terms_of(flt)[0])
+                oracle.search([view], metas[i], op, osc, k, None)
+
+        def timed_cpu(n):
+            t0 = time.perf_counter()
+            with cf.ThreadPoolExecutor(cores) as ex:
+                list(ex.map(run_cpu, [i % nq for i in range(n)]))
+            return time.perf_counter() - t0
+        probe = min(nq, 2 * cores)
+        dt = max(timed_cpu(probe), 1e-6)
+        n_cpu = int(min(4 * nq, max(probe, probe * 3.0 / dt)))
+        cpu_dt = timed_cpu(n_cpu)
+        row = {"category": t.category, "terms": len(base), "ranks": base,
+               "hits_per_query": float(totals.mean()), "gpu_qps": nq / gpu_dt,
+               "cpu_qps": n_cpu / cpu_dt, "cpu_sample": n_cpu, "parity_checked": n_par}
+        rows.append(row)
+        print("%-20s %5d  %-34s %10.0f %10.0f %10.1f %8.0fx  ok (%d queries)" % (
+            t.category, len(base), str(base if len(base) <= 4 else base[:4] + ["..."]), row["hits_per_query"],
+            row["gpu_qps"], row["cpu_qps"], row["gpu_qps"] / row["cpu_qps"], n_par), flush=True)
+    print(json.dumps({"tasks": rows, "docs": args.docs, "max_rank": max_rank, "k": k, "queries_per_step": nq,
+                      "scorer": args.scorer, "cpu_threads": cores,
+                      "data": "synthetic" if not sim else "synthetic (EMULATOR DRY RUN)"}), flush=True)
+    sr.close()
 
 
 def kernel_sources_sha():
