@@ -338,7 +338,7 @@ struct irs_hip_batch {
   uint32_t pj_first_elig = 0, pj_first_heavy = 0;
   uint32_t pj_block_units = 0;     // this deal: conj_units[0 .. pj_block_units) stay block driven
   uint32_t pj_cpq = 0;             // k_phrase_acc workgroups per joined unit
-  DevBuf d_pj_terms, d_pj_units, d_pj_matches, d_pj_runs, d_pj_count;
+  DevBuf d_pj_terms, d_pj_units, d_pj_matches, d_pj_count;
   PinBuf h_pin;                // page-locked staging for irs_hip_batch_results
   uint32_t n_phrase_wgs = 0;   // k_phrase workgroups: kPhraseWaves lead blocks each
   bool acc32 = true;   // 32-bit fixed-point accumulators are precise enough for every query
@@ -1479,9 +1479,7 @@ int64_t phrase_join_saving(const irs_hip_batch* b, uint32_t u) {
   const uint64_t d1 = sg->terms[b->qterms[dq.first_term + 1].term].docs_count;
   const uint64_t tiles = sg->dev.num_docs / kJoinTile + 1;
   const uint64_t lead_blocks = std::min(d0, d1) / kBlock + 1;
-  uint64_t tile_ps = 10000;
-  if (const char* e = std::getenv("IRS_HIP_PJ_TILE_PS")) tile_ps = uint64_t(std::atoll(e));   // tuning knob
-  return int64_t(lead_blocks * 3100ull) - int64_t(tile_ps * tiles + (3ull * (d0 + d1)) / 2);
+  return int64_t(lead_blocks * 3100ull) - int64_t(1000ull * tiles + (3ull * (d0 + d1)) / 2);
 }
 int phrase_join_forced(const irs_hip_batch* b) {   // -1: decide by cost
   if (b->path_pref == IRS_HIP_PATH_ITEMS) return 0;
@@ -1524,11 +1522,7 @@ bool build_phrase_join(irs_hip_batch* b) {
   }
   if (!b->d_pj_terms.alloc(pt.size() * sizeof(PjTerm)) ||
       !b->d_pj_units.alloc(b->join_units.size() * 4) ||
-      !b->d_pj_matches.alloc((bound + 64) * sizeof(PhraseMatch)) ||
-      // (a run per flush of a workgroup: at most one per tile and one at its end)
-      !b->d_pj_runs.alloc((uint64_t(b->join_units.size()) * (uint64_t(b->pj_cpq) * (kPjChunkTiles * 14u + 2u)) + 64) *
-                          sizeof(PhraseRun)) ||
-      !b->d_pj_count.alloc(16))
+      !b->d_pj_matches.alloc((bound + 64) * sizeof(PhraseMatch)) || !b->d_pj_count.alloc(8))
     return false;
   // (the entry streams' addresses: what build_streams gave the unit's term slots)
   const JoinTerm* jt = nullptr;
@@ -1546,7 +1540,7 @@ bool build_phrase_join(irs_hip_batch* b) {
 template<int LAYOUT>
 bool launch_phrase_join(irs_hip_batch* b, rt::stream_t st) {
   if (!b->phrase || b->join_units.empty()) return true;
-  const size_t smem = kPjSmem;
+  const size_t smem = 4u * kJoinTile + kPjStage * sizeof(PhraseMatch);
   if (!big_smem(k_phrase_acc, smem)) return false;
   PjArgs a{};
   a.segs = b->d_segs.as<DevSegment>();
@@ -1557,8 +1551,7 @@ bool launch_phrase_join(irs_hip_batch* b, rt::stream_t st) {
   a.units = b->d_pj_units.as<uint32_t>();
   a.bstar = b->d_bstar.as<uint32_t>();
   a.matches = b->d_pj_matches.as<PhraseMatch>();
-  a.runs = b->d_pj_runs.as<PhraseRun>();
-  a.counters = b->d_pj_count.as<unsigned long long>();
+  a.n_matches = b->d_pj_count.as<unsigned long long>();
   a.cands = b->d_cands.as<uint64_t>();
   a.cand_count = b->d_cand_count.as<uint32_t>();
   a.hits = b->d_hits.as<unsigned long long>();
@@ -1566,7 +1559,7 @@ bool launch_phrase_join(irs_hip_batch* b, rt::stream_t st) {
   a.n_units = uint32_t(b->join_units.size());
   a.cpq = b->pj_cpq;
   a.cand_cap = b->cand_cap;
-  if (!rt::dmemset(b->d_pj_count.p, 0, 16, st)) return false;
+  if (!rt::dmemset(b->d_pj_count.p, 0, 8, st)) return false;
   RT_LAUNCH(k_phrase_acc, a.n_units * a.cpq, b->join_threads, smem, st, a);
   const uint32_t grid = std::max<uint32_t>(1, b->seg->cus * 16);
   RT_LAUNCH((k_phrase_merge<LAYOUT>), grid, kThreads, 0, st, a);
@@ -1769,8 +1762,7 @@ bool ensure_scratch(irs_hip_batch* b) {
     });
     for (uint32_t i = 0; i < work.size(); ++i) b->queries[i].run_unit = work[i].second;
   }
-  // (a phrase batch's pilot samples lead ITEMS, whatever kernels its units run on)
-  b->stride_eff = (b->phrase || (b->tile_units.empty() && b->join_units.empty()))
+  b->stride_eff = (b->tile_units.empty() && b->join_units.empty())
                       ? b->stride
                       : std::max<uint32_t>(1, std::min<uint32_t>(b->stride, b->n_tiles / 2));
   if (const char* e = std::getenv("IRS_HIP_WG_THREADS")) {  // tuning knob
