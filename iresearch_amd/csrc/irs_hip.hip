@@ -24,7 +24,6 @@
 #include "score.h"
 #include "conj.h"
 #include "join.h"
-#include "pjoin.h"
 
 using namespace irs_hip;
 
@@ -277,9 +276,6 @@ struct irs_hip_segment {
   // first joined batch; 1-byte Norm2 columns only
   DevBuf d_pnorm, d_tail_norms;
   bool pnorm_ready = false;
-  // where every posting's positions start (pjoin.h), built on the segment's first joined phrase batch
-  DevBuf d_pstart, d_tail_pstart;
-  bool pstart_ready = false;
   DevBuf d_blk_maxf, d_blk_minn;
   std::vector<uint64_t> skip_at;   // per term: absolute offset of its skip data (0: none)
   bool has_pos = false;
@@ -332,13 +328,6 @@ struct irs_hip_batch {
   DevBuf d_conj_pilot;             // the lead items the pilot pass samples, {unit, item} each
   uint32_t n_conj_pilot = 0, conj_pilot_stride = 0;
   bool phrase = false;  // a batch of by_phrase queries (k_phrase instead of k_pilot + k_score)
-  // two-word phrases of frequent words run on joined streams (pjoin.h).  conj_units of a phrase
-  // batch are ordered [not eligible | eligible, block driven by the cost rule | joined by it]:
-  // a deal takes a SUFFIX of them off k_phrase (pj_first_*: where the eligible / the paying begin)
-  uint32_t pj_first_elig = 0, pj_first_heavy = 0;
-  uint32_t pj_block_units = 0;     // this deal: conj_units[0 .. pj_block_units) stay block driven
-  uint32_t pj_cpq = 0;             // k_phrase_acc workgroups per joined unit
-  DevBuf d_pj_terms, d_pj_units, d_pj_matches, d_pj_count;
   PinBuf h_pin;                // page-locked staging for irs_hip_batch_results
   uint32_t n_phrase_wgs = 0;   // k_phrase workgroups: kPhraseWaves lead blocks each
   bool acc32 = true;   // 32-bit fixed-point accumulators are precise enough for every query
@@ -777,8 +766,6 @@ bool ensure_pilot_list(irs_hip_batch* b, uint32_t stride, rt::stream_t st) {
 
 // by_phrase: lead-item records + start blocks -> pilot pass over every P-th lead block ->
 // threshold bins -> full pass.
-template<int LAYOUT>
-bool launch_phrase_join(irs_hip_batch* b, rt::stream_t st);   // (the kernels of pjoin.h, below)
 template<int LAYOUT, int MT>
 bool launch_phrase(irs_hip_batch* b, rt::stream_t st) {
   if (b->n_phrase_wgs == 0) return true;  // no query has all its terms in its segment
@@ -790,12 +777,7 @@ bool launch_phrase(irs_hip_batch* b, rt::stream_t st) {
   a.queries = b->d_queries.as<DevQuery>();
   a.qterms = b->d_qterms.as<DevQTerm>();
   a.wgs = nullptr;
-  // the full pass covers the lead items of the block-driven units: conj_units[0 .. pj_block_units)
-  // (the others run on joined streams, pjoin.h; the PILOT pass samples every unit's items)
-  uint32_t block_items = 0;
-  for (uint32_t c = 0; c < b->pj_block_units && c < b->conj_items.size(); ++c) block_items += b->conj_items[c];
-  const uint32_t full_wgs = (block_items + kPhraseWaves - 1) / kPhraseWaves;
-  a.n_items = block_items;
+  a.n_items = b->conj_total_items;
   a.tails = b->d_tails.as<DevTail>();
   a.bstar = b->d_bstar.as<uint32_t>();
   a.cands = b->d_cands.as<uint64_t>();
@@ -834,18 +816,15 @@ bool launch_phrase(irs_hip_batch* b, rt::stream_t st) {
             b->d_queries.as<DevQuery>(), b->d_conj_units.as<uint32_t>(),
             b->d_conj_items.as<uint32_t>(), b->d_conj_hist.as<uint32_t>(), stride,
             b->estimate ? kPilotMargin : 0u, b->d_bstar.as<uint32_t>(), min_bins(b));
-  if (full_wgs) {
-    if (MT == 2) {
-      RT_LAUNCH(k_phrase2<LAYOUT>, full_wgs, kPhraseWaves * 64, 0, st, a, 0u);
-    } else {
-      RT_LAUNCH((k_phrase<LAYOUT, MT>), full_wgs, kPhraseWaves * 64, 0, st, a, 0u);
-    }
+  if (MT == 2) {
+    RT_LAUNCH(k_phrase2<LAYOUT>, b->n_phrase_wgs, kPhraseWaves * 64, 0, st, a, 0u);
+  } else {
+    RT_LAUNCH((k_phrase<LAYOUT, MT>), b->n_phrase_wgs, kPhraseWaves * 64, 0, st, a, 0u);
   }
-  if (b->pj_block_units)
-    RT_LAUNCH(k_conj_hits, b->pj_block_units, 64, 0, st, b->d_conj_units.as<uint32_t>(),
-              b->d_conj_item_base.as<uint32_t>(), b->d_conj_item_hits.as<uint32_t>(),
-              b->d_hits.as<unsigned long long>());
-  return rt::last_error_ok() && launch_phrase_join<LAYOUT>(b, st);
+  RT_LAUNCH(k_conj_hits, uint32_t(b->conj_units.size()), 64, 0, st, b->d_conj_units.as<uint32_t>(),
+            b->d_conj_item_base.as<uint32_t>(), b->d_conj_item_hits.as<uint32_t>(),
+            b->d_hits.as<unsigned long long>());
+  return rt::last_error_ok();
 }
 template<int LAYOUT>
 bool launch_phrase_terms(irs_hip_batch* b, rt::stream_t st) {
@@ -896,37 +875,6 @@ int prepare_posting_norms(irs_hip_segment* s) {
     s->dev.tail_norms = s->d_tail_norms.as<uint8_t>();
   }
   s->pnorm_ready = true;
-  return IRS_HIP_OK;
-}
-
-// Where every posting's positions start in its term's position list, posting order (pjoin.h):
-// built once per segment, on its first batch with phrases on joined streams.
-int prepare_posting_pstart(irs_hip_segment* s) {
-  std::lock_guard<std::mutex> lock(s->wand_mutex);
-  if (s->pstart_ready) return IRS_HIP_OK;
-  const DevSegment& d = s->dev;
-  if (!s->has_pos) return IRS_HIP_EINVAL;
-  const uint64_t rows = s->total_blocks, tails = s->d_tail_docs.n / 4;
-  if (!s->d_pstart.alloc((rows + 1) * kBlock * 4) || !s->d_tail_pstart.alloc((tails + 1) * 4))
-    return IRS_HIP_ENOMEM;
-  if (rows && d.num_terms) {
-    const uint32_t slices = std::max<uint32_t>(1, std::min<uint32_t>(64, s->cus * 8 / d.num_terms));
-    if (d.layout == kSimd4) {
-      RT_LAUNCH((k_posting_pstart<kSimd4>), d.num_terms * slices, kThreads, 0, nullptr, d, slices,
-                s->d_pstart.as<uint32_t>());
-    } else {
-      RT_LAUNCH((k_posting_pstart<kScalar>), d.num_terms * slices, kThreads, 0, nullptr, d, slices,
-                s->d_pstart.as<uint32_t>());
-    }
-  }
-  if (d.num_terms)
-    RT_LAUNCH(k_tail_pstart, (d.num_terms + kThreads - 1) / kThreads, kThreads, 0, nullptr, d,
-              s->d_tail_pstart.as<uint32_t>());
-  if (!rt::last_error_ok() || !rt::sync(nullptr)) return IRS_HIP_EHIP;
-  s->device_bytes += s->d_pstart.n + s->d_tail_pstart.n;
-  s->dev.pstart = s->d_pstart.as<uint32_t>();
-  s->dev.tail_pstart = s->d_tail_pstart.as<uint32_t>();
-  s->pstart_ready = true;
   return IRS_HIP_OK;
 }
 
@@ -1453,119 +1401,6 @@ bool launch_join_score(irs_hip_batch* b, rt::stream_t st) {
 // its first one (sorted by cost at create); one wavefront per 128-posting block of it (+ one for
 // its vint tail / single doc), its record and the other terms' start blocks written by
 // k_conj_seek every run.  Rebuilt whenever ensure_scratch deals the conjunctions anew.
-// ---- two-word phrases of frequent words on joined streams (pjoin.h) -------------------------
-// Eligible: two words, both present, frequencies that fit an entry.
-bool phrase_join_eligible(const irs_hip_batch* b, uint32_t u) {
-  const DevQuery& dq = b->queries[u];
-  if (dq.n_terms != 2u) return false;
-  const irs_hip_segment* sg = b->segs[dq.seg];
-  for (uint32_t j = 0; j < 2u; ++j) {
-    const DevQTerm& qt = b->qterms[dq.first_term + j];
-    if (qt.term >= sg->dev.num_terms) return false;
-    const DevTerm& t = sg->terms[qt.term];
-    if (!t.docs_count || t.tf_bound > kJoinTfMax) return false;
-  }
-  return true;
-}
-// Picoseconds saved by joining (<= 0: block driven is cheaper).  Block driven: ~3100 per
-// 128-posting block of the rarer word (k_phrase: its decode, a directory scan and block decodes in
-// the other word — the figure of join_and_saving for two terms).  Joined: ~1000 per doc tile
-// (k_phrase_acc: bounds, three barriers) + 1.5 per posting of either word (the direct-address join
-// + a share of k_join's decode).
-int64_t phrase_join_saving(const irs_hip_batch* b, uint32_t u) {
-  const DevQuery& dq = b->queries[u];
-  const irs_hip_segment* sg = b->segs[dq.seg];
-  const uint64_t d0 = sg->terms[b->qterms[dq.first_term].term].docs_count;
-  const uint64_t d1 = sg->terms[b->qterms[dq.first_term + 1].term].docs_count;
-  const uint64_t tiles = sg->dev.num_docs / kJoinTile + 1;
-  const uint64_t lead_blocks = std::min(d0, d1) / kBlock + 1;
-  return int64_t(lead_blocks * 3100ull) - int64_t(1000ull * tiles + (3ull * (d0 + d1)) / 2);
-}
-int phrase_join_forced(const irs_hip_batch* b) {   // -1: decide by cost
-  if (b->path_pref == IRS_HIP_PATH_ITEMS) return 0;
-  if (b->path_pref == IRS_HIP_PATH_JOINED) return 1;   // (forced: wherever it is possible)
-  if (const char* e = std::getenv("IRS_HIP_PHRASE_JOIN")) return std::atoi(e) != 0;   // tuning / test knob
-  return -1;
-}
-
-// The per-word records of k_phrase_merge, the joined units' list, the match buffer (sized for the
-// most a conjunction can yield: the rarer word's postings).
-bool build_phrase_join(irs_hip_batch* b) {
-  if (b->join_units.empty()) return true;
-  std::vector<PjTerm> pt(b->qterms.size());
-  uint64_t bound = 0;
-  for (uint32_t u : b->join_units) {
-    const DevQuery& dq = b->queries[u];
-    irs_hip_segment* sg = b->segs[dq.seg];
-    if (prepare_posting_pstart(sg) != IRS_HIP_OK) return false;
-    uint64_t lead = ~0ull;
-    for (uint32_t j = 0; j < 2u; ++j) {
-      const DevQTerm& qt = b->qterms[dq.first_term + j];
-      const DevTerm& t = sg->terms[qt.term];
-      PjTerm& r = pt[dq.first_term + j];
-      r.entries = 0;   // (filled from the stream table below)
-      r.pstart = reinterpret_cast<uint64_t>(sg->d_pstart.as<uint32_t>() + t.dir_off * kBlock);
-      r.tail_pstart = reinterpret_cast<uint64_t>(sg->d_tail_pstart.as<uint32_t>() + t.tail_row);
-      r.pt = sg->pterms[qt.term];
-      r.n_block = t.nblk * kBlock;
-      r.off = qt.pad0;
-      r.bytes = t.blocks_bytes + t.tail_bytes;
-      r.pad = 0;
-      lead = std::min<uint64_t>(lead, t.docs_count);
-    }
-    bound += lead;
-  }
-  b->pj_cpq = 1;
-  for (uint32_t u : b->join_units) {
-    const uint32_t tiles = (b->segs[b->queries[u].seg]->dev.num_docs + kJoinTile - 1) / kJoinTile;
-    b->pj_cpq = std::max(b->pj_cpq, (tiles + kPjChunkTiles - 1) / kPjChunkTiles);
-  }
-  if (!b->d_pj_terms.alloc(pt.size() * sizeof(PjTerm)) ||
-      !b->d_pj_units.alloc(b->join_units.size() * 4) ||
-      !b->d_pj_matches.alloc((bound + 64) * sizeof(PhraseMatch)) || !b->d_pj_count.alloc(8))
-    return false;
-  // (the entry streams' addresses: what build_streams gave the unit's term slots)
-  const JoinTerm* jt = nullptr;
-  for (const Stager::Piece& pc : b->up.pending)
-    if (pc.dst == b->d_jterms.p) jt = static_cast<const JoinTerm*>(pc.src);
-  if (!jt) return false;
-  for (uint32_t u : b->join_units) {
-    const DevQuery& dq = b->queries[u];
-    for (uint32_t j = 0; j < 2u; ++j) pt[dq.first_term + j].entries = jt[dq.first_term + j].entries;
-  }
-  return b->up.copy(b->d_pj_terms.p, pt.data(), pt.size() * sizeof(PjTerm)) &&
-         b->up.copy(b->d_pj_units.p, b->join_units.data(), b->join_units.size() * 4);
-}
-
-template<int LAYOUT>
-bool launch_phrase_join(irs_hip_batch* b, rt::stream_t st) {
-  if (!b->phrase || b->join_units.empty()) return true;
-  const size_t smem = 4u * kJoinTile + kPjStage * sizeof(PhraseMatch);
-  if (!big_smem(k_phrase_acc, smem)) return false;
-  PjArgs a{};
-  a.segs = b->d_segs.as<DevSegment>();
-  a.queries = b->d_queries.as<DevQuery>();
-  a.qterms = b->d_qterms.as<DevQTerm>();
-  a.jterms = b->d_jterms.as<JoinTerm>();
-  a.pterms = b->d_pj_terms.as<PjTerm>();
-  a.units = b->d_pj_units.as<uint32_t>();
-  a.bstar = b->d_bstar.as<uint32_t>();
-  a.matches = b->d_pj_matches.as<PhraseMatch>();
-  a.n_matches = b->d_pj_count.as<unsigned long long>();
-  a.cands = b->d_cands.as<uint64_t>();
-  a.cand_count = b->d_cand_count.as<uint32_t>();
-  a.hits = b->d_hits.as<unsigned long long>();
-  a.touched = b->count_touched ? b->d_touched.as<unsigned long long>() : nullptr;
-  a.n_units = uint32_t(b->join_units.size());
-  a.cpq = b->pj_cpq;
-  a.cand_cap = b->cand_cap;
-  if (!rt::dmemset(b->d_pj_count.p, 0, 8, st)) return false;
-  RT_LAUNCH(k_phrase_acc, a.n_units * a.cpq, b->join_threads, smem, st, a);
-  const uint32_t grid = std::max<uint32_t>(1, b->seg->cus * 16);
-  RT_LAUNCH((k_phrase_merge<LAYOUT>), grid, kThreads, 0, st, a);
-  return rt::last_error_ok();
-}
-
 int build_conj_work(irs_hip_batch* b) {
   const uint32_t nq = b->nq;
   int rc = IRS_HIP_OK;
@@ -1680,24 +1515,6 @@ bool ensure_scratch(irs_hip_batch* b) {
       }
       if (build_conj_work(b) != IRS_HIP_OK) return false;
     }
-    if (b->phrase) {   // (conj_units fixed at create: a suffix of them may leave k_phrase)
-      const int forced = phrase_join_forced(b);
-      const uint32_t n = uint32_t(b->conj_units.size());
-      b->pj_block_units = forced == 0 ? n : (forced == 1 ? b->pj_first_elig : b->pj_first_heavy);
-      b->join_units.assign(b->conj_units.begin() + b->pj_block_units, b->conj_units.end());
-      // (the match buffer holds the rarer word's postings of every joined unit at most: 16 bytes each)
-      uint64_t bound = 0;
-      for (uint32_t u : b->join_units) {
-        const DevQuery& dq = b->queries[u];
-        const irs_hip_segment* sg = b->segs[dq.seg];
-        bound += std::min(sg->terms[b->qterms[dq.first_term].term].docs_count,
-                          sg->terms[b->qterms[dq.first_term + 1].term].docs_count);
-      }
-      if (bound * sizeof(PhraseMatch) > (24ull << 30)) {
-        b->join_units.clear();
-        b->pj_block_units = n;
-      }
-    }
     b->joined = !b->join_units.empty();
   }
   // 32-bit accumulators halve the LDS per doc: twice the tile at the same residency
@@ -1723,8 +1540,7 @@ bool ensure_scratch(irs_hip_batch* b) {
     dq.n_tiles = tiled ? (b->segs[dq.seg]->dev.num_docs + tile_docs - 1) / tile_docs : 0u;
     if (b->phrase) dq.n_tiles = 1;
     if (tiled) b->n_tiles = std::min(b->n_tiles, dq.n_tiles);
-    // (a phrase on joined streams keeps its plan records: the block-driven PILOT samples it too)
-    if (is_join[u] && !b->phrase) {   // no plan table, no work items (k_plan / k_items_* skip the unit)
+    if (is_join[u]) {   // no plan table, no work items (k_plan / k_items_* skip the unit)
       dq.first_off = kNoPlan;
       dq.tile_base = 0;
       b->join_max_tiles = std::max(b->join_max_tiles, dq.n_tiles);
@@ -1798,7 +1614,6 @@ bool ensure_scratch(irs_hip_batch* b) {
       !b->d_pruned.alloc(uint64_t(b->nq) * 4))
     return false;
   if (b->joined && !build_streams(b)) return false;
-  if (b->joined && b->phrase && !build_phrase_join(b)) return false;
   if (!build_groups(b)) return false;
   if (!b->tile_units.empty()) {
     if (!b->d_tile_units.alloc(b->tile_units.size() * 4) ||
@@ -2616,38 +2431,6 @@ static int batch_create_multi_impl(irs_hip_segment* const* segs, uint32_t n_segs
         b->conj_units.push_back(u);
         b->conj_items.push_back(items);
       }
-      {
-        // two-word phrases of frequent words may run on joined streams (pjoin.h): the units in the
-        // order [not eligible | eligible | paying by the cost rule], so that whatever a deal
-        // takes off k_phrase is a suffix of the list (and of the lead items' records)
-        std::vector<uint32_t> key(b->conj_units.size()), idx(b->conj_units.size());
-        int64_t saved = 0;
-        for (size_t c = 0; c < idx.size(); ++c) {
-          idx[c] = uint32_t(c);
-          const uint32_t u = b->conj_units[c];
-          key[c] = 0;
-          if (phrase_join_eligible(b, u)) {
-            const int64_t sv = phrase_join_saving(b, u);
-            key[c] = sv > 0 ? 2u : 1u;
-            if (sv > 0) saved += sv;
-          }
-        }
-        // (the launches of k_join / k_phrase_acc / k_phrase_merge only pay from ~0.5 ms saved)
-        if (saved < kJoinAndLaunchCost)
-          for (auto& k : key) k = k ? 1u : 0u;
-        std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return key[x] < key[y]; });
-        std::vector<uint32_t> cu, ci;
-        b->pj_first_elig = b->pj_first_heavy = uint32_t(idx.size());
-        for (size_t c = 0; c < idx.size(); ++c) {
-          cu.push_back(b->conj_units[idx[c]]);
-          ci.push_back(b->conj_items[idx[c]]);
-          if (key[idx[c]] >= 1u) b->pj_first_elig = std::min<uint32_t>(b->pj_first_elig, uint32_t(c));
-          if (key[idx[c]] >= 2u) b->pj_first_heavy = std::min<uint32_t>(b->pj_first_heavy, uint32_t(c));
-        }
-        b->conj_units.swap(cu);
-        b->conj_items.swap(ci);
-        b->pj_block_units = uint32_t(b->conj_units.size());
-      }
       std::vector<uint32_t> item_base(b->conj_units.size() + 1, 0), unit_items(nq, 0);
       uint64_t total = 0;
       for (size_t c = 0; c < b->conj_units.size(); ++c) {
@@ -3010,7 +2793,7 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st) {
   // 2. pilot: per-query score-bin threshold (phrase batches have none: few docs match)
   ok = ok && mark(2 * IRS_HIP_K_PILOT);
   if (b->n_groups) ok = ok && rt::dmemset(b->d_group_hist.p, 0, b->d_group_hist.n, st);
-  if (b->joined && !b->phrase) ok = ok && launch_join_pilot(b, st);
+  if (b->joined) ok = ok && launch_join_pilot(b, st);
   ok = ok && launch_group_threshold(b, st);
   if (tiles)
     ok = ok && (simd ? launch_pilot_acc<kSimd4>(b, st) : launch_pilot_acc<kScalar>(b, st));
@@ -3021,7 +2804,7 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st) {
     ok = ok && (simd ? launch_phrase_terms<kSimd4>(b, st) : launch_phrase_terms<kScalar>(b, st));
   else if (tiles)
     ok = ok && (simd ? launch_score_acc<kSimd4>(b, st) : launch_score_acc<kScalar>(b, st));
-  if (b->joined && !b->phrase) ok = ok && launch_join_score(b, st);
+  if (b->joined) ok = ok && launch_join_score(b, st);
   if (!b->phrase) ok = ok && (simd ? launch_conj<kSimd4>(b, st) : launch_conj<kScalar>(b, st));
   ok = ok && mark(2 * IRS_HIP_K_SCORE + 1);
   // 4. exact top-k

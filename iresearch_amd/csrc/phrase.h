@@ -306,57 +306,6 @@ k_decode_positions(DevSegment seg, uint32_t term, uint32_t* out) {
   }
 }
 
-// Phrase frequency of ONE doc for a two-word phrase (FixedPhraseFrequency::NextPosition,
-// phrase_iterator.hpp:109-151): #{p in the first word's positions : p + off in the second's}.
-// P = the doc's first position number in either list, T = its frequency there.  ONE loop that
-// reads one position per trip, of whichever list is behind (the term's records selected per lane).
-// The nested form (lead.next(), then seek in the other list) costs a wavefront the SUM over lead
-// positions of the LONGEST seek among its 64 docs; this one the longest tf_a + tf_b — what very
-// frequent phrases (thousands of matching docs per block of the lead) are bound by: 43 -> 36 ms
-// per 1000 such queries.  (Keeping two deltas of either list in flight was tried and is slower:
-// the loop is bound by the instructions of a random-access position read, not by its latency.)
-// `ps`: the segment's position fields (pos, pblk_off, pblk_bits, ptail, pos_base).
-template<int LAYOUT>
-__device__ __forceinline__ uint32_t phrase_freq2(const DevSegment& ps, const DevPosTerm& pa,
-                                                 const DevPosTerm& pb, uint32_t off, uint32_t Pa,
-                                                 uint32_t Ta, uint32_t Pb, uint32_t Tb,
-                                                 uint32_t& reads) {
-  uint32_t pf = 0;
-  uint32_t ka = 0, kb = 0, va = ps.pos_base, vb = ps.pos_base;
-  PosCursor ca{0, 0xFFFFFFFFu, 0}, cb{0, 0xFFFFFFFFu, 0};
-  for (;;) {
-    bool adv_a;
-    if (ka == 0u) {
-      adv_a = true;                       // lead.next()
-    } else if (kb == 0u || vb < va + off) {
-      adv_a = false;                      // position::seek(target) :1578-1604
-    } else {
-      pf += vb == va + off ? 1u : 0u;     // reached the target, or sought too far
-      adv_a = true;
-    }
-    if (adv_a ? ka == Ta : kb == Tb) break;   // exhausted: no later position can match
-    DevPosTerm pt;
-    pt.pos_start = adv_a ? pa.pos_start : pb.pos_start;
-    pt.row = adv_a ? pa.row : pb.row;
-    pt.nfull = adv_a ? pa.nfull : pb.nfull;
-    pt.tail_row = adv_a ? pa.tail_row : pb.tail_row;
-    PosCursor cur = adv_a ? ca : cb;
-    const uint32_t d = pos_delta_cached<LAYOUT>(ps, pt, cur, adv_a ? Pa + ka : Pb + kb);
-    ++reads;
-    if (adv_a) {
-      ca = cur;
-      va += d;
-      ++ka;
-      if (va + off < va) break;           // !pos_limits::valid(term_position)
-    } else {
-      cb = cur;
-      vb += d;
-      ++kb;
-    }
-  }
-  return pf;
-}
-
 // ------------------------------------------------------------ query time --
 
 constexpr uint32_t kPhraseWaves = 4;  // wavefronts (= lead blocks) per workgroup
@@ -833,7 +782,47 @@ __device__ __forceinline__ void phrase_item(const ConjArgs& A, uint32_t pilot /*
       uint32_t pf = 0, head = ps.pos_base;
       bool done = false;
       if (MT == 2 && m == 2u) {
-        pf = phrase_freq2<LAYOUT>(ps, W.pt[0], W.pt[1], W.off[1], P[0], T[0], P[1], T[1], my_pos);
+        // Two terms: ONE loop that reads one position per trip, of whichever list is behind
+        // (the term's records selected per lane).  The nested form below costs a wavefront the
+        // SUM over lead positions of the LONGEST seek among its 64 docs; this one the longest
+        // tf_a + tf_b — what very frequent phrases (thousands of matching docs per block of
+        // the lead) are bound by: 43 -> 36 ms per 1000 such queries.  (Keeping two deltas of
+        // either list in flight was tried and is slower: the loop is bound by the instructions
+        // of a random-access position read, not by its latency.)
+        const DevPosTerm pa = W.pt[0], pb = W.pt[1];
+        const uint32_t off = W.off[1];
+        uint32_t ka = 0, kb = 0, va = ps.pos_base, vb = ps.pos_base;
+        PosCursor ca{0, 0xFFFFFFFFu, 0}, cb{0, 0xFFFFFFFFu, 0};
+        for (;;) {
+          bool adv_a;
+          if (ka == 0u) {
+            adv_a = true;                       // lead.next()
+          } else if (kb == 0u || vb < va + off) {
+            adv_a = false;                      // position::seek(target) :1578-1604
+          } else {
+            pf += vb == va + off ? 1u : 0u;     // reached the target, or sought too far
+            adv_a = true;
+          }
+          if (adv_a ? ka == T[0] : kb == T[1]) break;   // exhausted: no later position can match
+          DevPosTerm pt;
+          pt.pos_start = adv_a ? pa.pos_start : pb.pos_start;
+          pt.row = adv_a ? pa.row : pb.row;
+          pt.nfull = adv_a ? pa.nfull : pb.nfull;
+          pt.tail_row = adv_a ? pa.tail_row : pb.tail_row;
+          PosCursor cur = adv_a ? ca : cb;
+          const uint32_t d = pos_delta_cached<LAYOUT>(ps, pt, cur, adv_a ? P[0] + ka : P[1] + kb);
+          ++my_pos;
+          if (adv_a) {
+            ca = cur;
+            va += d;
+            ++ka;
+            if (va + off < va) break;           // !pos_limits::valid(term_position)
+          } else {
+            cb = cur;
+            vb += d;
+            ++kb;
+          }
+        }
         done = true;
       }
       for (uint32_t a = 0; a < T[0] && !done; ++a) {

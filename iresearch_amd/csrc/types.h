@@ -122,11 +122,6 @@ struct DevSegment {
   // prepare_posting_norms): 128 bytes per directory row, and per entry of tail_docs
   const uint8_t* pnorm;
   const uint8_t* tail_norms;
-  // fields with positions: where every posting's positions START in its term's position list
-  // (position numbers, 0-based per term), in posting order like pnorm — 128 per directory row,
-  // and per entry of tail_docs (null until a joined phrase batch asks: prepare_posting_pstart)
-  const uint32_t* pstart;
-  const uint32_t* tail_pstart;
 };
 
 struct DevQuery {

@@ -1571,61 +1571,6 @@ def case_phrase_queries(L, layout, num_docs=30_000):
     sr.close()
 
 
-def case_phrase_paths_agree(L, layout=synth.LAYOUT_SIMD4, num_docs=40_000):
-    """The two organisations of a phrase batch — every phrase block driven from its rarer word
-    (k_phrase: PATH_ITEMS) and two-word phrases on joined posting streams (pjoin.h: a
-    direct-address join of the two entry streams per doc tile, then the position merge per doc;
-    PATH_JOINED forces it wherever a unit is eligible) — return the same docs, scores and hit
-    counts, bit for bit; each is checked against the oracle; PATH_AUTO (the cost rule) agrees too.
-    Longer phrases and phrases with an absent word stay block driven in the same batch.  One and
-    two segments (a term missing from one of them), tile borders inside the lists."""
-    segs = [synth.build_segment(num_docs, 128, with_positions=True, layout=layout),
-            synth.build_segment(num_docs // 3, 128, with_positions=True, layout=layout,
-                                first_doc=num_docs)]
-    segs[1].metas[9]["docs_count"] = 0
-    readers = [search.SegmentReader.from_synth(x, L=L) for x in segs]
-    phrases = [
-        by_phrase([0, 1]), by_phrase([2, 0]), by_phrase([0, 0]), by_phrase([1, 0]),
-        by_phrase([0, 3], [0, 3]), by_phrase([9, 19]), by_phrase([5, 2], boost=2.5),
-        by_phrase([120, 127]), by_phrase([127, 0]), by_phrase([60, 61]),
-        by_phrase([1, 4, 0]), by_phrase([3, 10_000]), by_phrase([7]),
-    ]
-    st = [parity.segment_stats(x) for x in segs]
-    for scorer in (BM25(), TFIDF(False), TFIDF(True)):
-        for k in (10, 1000):
-            for rd, sg in ((readers[0], segs[:1]), (readers, segs)):
-                prep = search.prepare(phrases, scorer, st[:len(sg)])
-                got = {}
-                for path in (_lib.PATH_ITEMS, _lib.PATH_JOINED, _lib.PATH_AUTO):
-                    b = search.QueryBatch(rd, prep, k).set_path(path)
-                    h, c, t = (x.copy() for x in b.run().results())
-                    if path != _lib.PATH_AUTO:
-                        assert b.path() == path
-                    if len(sg) == 1:
-                        parity.check_phrase_segment(sg[0], phrases, scorer, k, h, c, t)
-                    else:
-                        for i, x in enumerate(sg):
-                            parity.check_phrase_segment(x, phrases, scorer, k, h[i], c[i], t[i], sg)
-                    got[path] = (h, c, t)
-                    b.close()
-                for path in (_lib.PATH_JOINED, _lib.PATH_AUTO):
-                    for a, g in zip(got[_lib.PATH_ITEMS], got[path]):
-                        assert np.array_equal(a, g), (type(scorer).__name__, k, len(sg), path)
-    # what the kernels read (irs_hip_batch_touched): a joined unit reads both lists in full
-    prep = search.prepare(phrases[:2], BM25(), st[:1])
-    b = readers[0].batch(prep, 10).set_path(_lib.PATH_JOINED).profile(3)
-    b.run().results()
-    bytes_j, pos_j = b.touched()
-    b.close()
-    b = readers[0].batch(prep, 10).set_path(_lib.PATH_ITEMS).profile(3)
-    b.run().results()
-    bytes_i, pos_i = b.touched()
-    b.close()
-    assert bytes_j > 0 and pos_j == pos_i and bytes_i > 0
-    for r in readers:
-        r.close()
-
-
 def case_phrase_ragged(L, layout=synth.LAYOUT_SIMD4, one_based=False):
     """Explicit lists: single-doc terms, lists shorter than a block, phrases that exist
     only across block / tile borders, very frequent terms in one doc."""

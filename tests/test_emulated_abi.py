@@ -152,10 +152,6 @@ def test_phrase_reference_vectors(simlib, layout):
     cases.case_phrase_reference_vectors(simlib, layout)
 
 
-def test_phrase_paths_agree(simlib):
-    cases.case_phrase_paths_agree(simlib)
-
-
 def test_phrase_ragged(simlib):
     cases.case_phrase_ragged(simlib)
     cases.case_phrase_ragged(simlib, synth.LAYOUT_SCALAR, one_based=True)

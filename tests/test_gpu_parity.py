@@ -136,12 +136,6 @@ def test_phrase_reference_vectors(gpulib, layout):
     cases.case_phrase_reference_vectors(gpulib, layout)
 
 
-@pytest.mark.gpu
-def test_phrase_paths_agree(gpulib):
-    cases.case_phrase_paths_agree(gpulib)
-
-
-@pytest.mark.gpu
 def test_phrase_ragged(gpulib):
     cases.case_phrase_ragged(gpulib)
     cases.case_phrase_ragged(gpulib, synth.LAYOUT_SCALAR)
