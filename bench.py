@@ -757,6 +757,7 @@ def main_config5(args):
     if rank == 0:
         ms = {n: float(np.mean([x[n][_lib.K_SCORE] for x in kms])) for n in bat}
         stages = {n: [round(float(v), 4) for v in np.mean([x[n] for x in kms], axis=0)] for n in bat}
+        tr5 = measured_traffic("traffic_config5_latest.json") if world == 1 else None
         rank0_touched = touched["and"][0] + touched["phrase"][0]
         rank0_alg = alg["and"][0] + alg["phrase"][0]
         out = {
@@ -791,7 +792,10 @@ def main_config5(args):
                          "achieved": round(rank0_touched / ((ms["and"] + ms["phrase"]) * 1e-3) / 1e9, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(rank0_touched / ((ms["and"] + ms["phrase"]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                         "traffic": None, "kernel_ms": {"k_conj": round(ms["and"], 4),
+                         # HBM-side bytes per step of those kernels (PMC passes of this command at these
+                         # kernel sources, profiles/traffic_config5_latest.json), else null
+                         "traffic": None if tr5 is None else int(tr5["bytes"]), "traffic_detail": tr5,
+                         "kernel_ms": {"k_conj": round(ms["and"], 4),
                                                         "k_phrase": round(ms["phrase"], 4)},
                          # the same kernel time priced on A(q): every byte of the queries' lists
                          # (what the reference's iterators would at most decode)
@@ -945,12 +949,12 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
-def measured_traffic():
+def measured_traffic(name="traffic_latest.json"):
     """HBM bytes per k_score launch from rocprofv3 PMC passes of this same command
     (FETCH_SIZE and WRITE_SIZE in their own --pmc runs, tools/summarize_prof.py), committed
     under profiles/ — reported only while the kernel sources are the ones it was measured
     with; null otherwise (a stale figure is worse than none)."""
-    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    path = os.path.join(ROOT, "profiles", name)
     try:
         with open(path) as f:
             t = json.load(f)

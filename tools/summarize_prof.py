@@ -16,7 +16,40 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def config5(tag, pmc_dirs):
+    """FETCH_SIZE / WRITE_SIZE passes over `bench.py --config 5` -> profiles/<tag>_pmc_config5.json
+    (per kernel and launch) and profiles/traffic_config5_latest.json: HBM-side bytes per STEP (one
+    AND batch + one phrase batch) of the kernels the config-5 roofline prices — summed over their
+    launches of the profiled run, divided by its steps (two k_select launches per step)."""
+    out = os.path.join(ROOT, "profiles")
+    tot = collections.defaultdict(lambda: collections.defaultdict(float))
+    launches = collections.defaultdict(lambda: collections.defaultdict(set))
+    for d in pmc_dirs:
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("irs_hip::", "")
+                tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
+                launches[k][r["Counter_Name"]].add(r["Dispatch_Id"])
+    summary = {k: {c + "_per_launch": v / max(1, len(launches[k][c])) for c, v in cs.items()}
+               for k, cs in tot.items()}
+    for k in summary:
+        summary[k]["launches"] = max(len(x) for x in launches[k].values())
+    json.dump(summary, open(os.path.join(out, "%s_pmc_config5.json" % tag), "w"), indent=1, sort_keys=True)
+    steps = {c: len(launches["k_select"][c]) / 2.0 for c in ("FETCH_SIZE", "WRITE_SIZE") if launches["k_select"][c]}
+    priced = [k for k in tot if k.startswith(("k_conj<", "k_phrase", "k_join_score", "k_join<"))]
+    fetch = sum(tot[k]["FETCH_SIZE"] for k in priced) * 1024 / max(steps.get("FETCH_SIZE", 1.0), 1.0)
+    write = sum(tot[k]["WRITE_SIZE"] for k in priced) * 1024 / max(steps.get("WRITE_SIZE", 1.0), 1.0)
+    t = {"kernels": sorted(priced), "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) "
+         "over bench.py --config 5, %s" % tag, "fetch_bytes_raw": fetch, "write_bytes": write,
+         "fetch_bytes_x2_correction": 2 * fetch, "bytes": 2 * fetch + write,
+         "kernel_sources_sha": __import__("bench").kernel_sources_sha(), "unit": "bytes per step (2000 queries)"}
+    json.dump(t, open(os.path.join(out, "traffic_config5_latest.json"), "w"), indent=1)
+    print(json.dumps(t))
+
+
 def main():
+    if sys.argv[1] == "--config5":
+        return config5(sys.argv[2], sys.argv[3:])
     tag, stats_dir, pmc_dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
