@@ -412,6 +412,43 @@ class QueryBatch {
     }
     return r;
   }
+  // The serving-loop form of results(): results_to_host() verifies the run and queues the copy
+  // to page-locked memory of the batch behind ITS kernels only (irs_hip_batch_results_to_host:
+  // the hits of this batch cross PCIe while the next batch executes); host_results() waits for
+  // that copy and stitches the caller's order back together.
+  QueryBatch& results_to_host(void* stream = nullptr) {
+    for (Part& part : part_)
+      if (part.h) check(irs_hip_batch_results_to_host(part.h, stream), "irs_hip_batch_results_to_host");
+    return *this;
+  }
+  Results host_results() {
+    Results r;
+    r.n_segments = n_segments_;
+    r.n_queries = n_queries_;
+    r.k = k_;
+    const size_t units = size_t(n_segments_) * n_queries_;
+    r.hits.resize(units * k_);
+    r.counts.resize(units);
+    r.total_hits.resize(units);
+    for (Part& part : part_) {
+      if (!part.h) continue;
+      const irs_hip_hit* hits = nullptr;
+      const uint32_t* counts = nullptr;
+      const uint64_t* totals = nullptr;
+      uint32_t stride = 0;
+      check(irs_hip_batch_host_results(part.h, &hits, &stride, &counts, &totals),
+            "irs_hip_batch_host_results");
+      const size_t nq = part.index.size();
+      for (uint32_t s = 0; s < n_segments_; ++s)
+        for (size_t i = 0; i < nq; ++i) {
+          const size_t from = s * nq + i, to = size_t(s) * n_queries_ + part.index[i];
+          std::copy_n(hits + from * stride, counts[from], r.hits.begin() + to * k_);
+          r.counts[to] = counts[from];
+          r.total_hits[to] = totals[from];
+        }
+    }
+    return r;
+  }
   // the one device batch of a list of queries that are all boolean or all by_phrase
   // (what search_sharded hands to irs_hip_batch_results_to_device)
   irs_hip_batch* single_part() const {

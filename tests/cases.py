@@ -894,6 +894,19 @@ def case_plan_ahead(L):
         assert all(np.array_equal(a, g) for a, g in zip(ref, got))
         got = b.plan().plan().run().results()     # planning twice is harmless
         assert all(np.array_equal(a, g) for a, g in zip(ref, got))
+        # a plan queued ahead, then the batch is re-dealt (the setters drop the plan's tables and
+        # reallocate: they wait for the queued plan first — plan_pending), then run
+        for path in (_lib.PATH_ITEMS, _lib.PATH_AUTO):
+            got = b.plan().set_path(path).run().results()
+            assert all(np.array_equal(a, g) for a, g in zip(ref[1:], got[1:]))   # (counts, totals)
+        got = b.plan().configure(0, 8, 0).plan().run().results()
+        assert all(np.array_equal(a, g) for a, g in zip(ref[1:], got[1:]))
+        b.close()
+        # ... and a plan queued, the batch reconfigured and destroyed without ever running it
+        b = sr.batch(prep, 25).plan()
+        b.configure(0, 4, 0)
+        b.close()
+        b = sr.batch(prep, 25).plan().plan()
         b.close()
     sr.close()
 

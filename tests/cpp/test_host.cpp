@@ -132,6 +132,12 @@ int main() {
   QueryBatch batch({a.reader.get(), b.reader.get()}, prepared, kTop);
   const auto res = batch.run().results();
   REQUIRE(res.n_segments == 2 && res.n_queries == filters.size());
+  {  // the serving-loop form: the copy queued behind the run, read later — the same arrays
+    const auto again = batch.results_to_host().host_results();
+    REQUIRE(again.counts == res.counts && again.total_hits == res.total_hits);
+    for (size_t i = 0; i < res.hits.size(); ++i)
+      REQUIRE(again.hits[i].doc == res.hits[i].doc && again.hits[i].score == res.hits[i].score);
+  }
   const auto top = merge(res);  // the harness heap over both segments
 
   // the oracle's harness loop over both segments (utils/index-search.cpp:719-787)

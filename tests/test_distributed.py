@@ -244,6 +244,21 @@ def _threshold_worker(rank, world, port, sim_path, out_dir):
                 b.close()
             # bit for bit the merged result of per-rank thresholds
             assert all(torch.equal(x, y) for x, y in zip(*merged)), (tag, k)
+            # ... and with the merged k-th score pushed back as irs::score::Min (the harness's heap
+            # root, index-search.cpp:737-777) next to the cross-rank threshold: the same top k.  The
+            # caller's scores are binned in the scale the group ends up with — a term missing from a
+            # segment makes the group's bound larger than that unit's own (bins worked
+            # out before the re-scaling dropped docs at or above the caller's score)
+            oh, _, oc = merged[1]
+            hv = oh.numpy().view(_lib.HIT)["score"].reshape(nq, k)
+            kth = np.array([hv[q, int(oc[q]) - 1] if int(oc[q]) else 0.0 for q in range(nq)], np.float32)
+            b = search.QueryBatch(readers, prep, k).set_shared_threshold(True).set_path(_lib.PATH_JOINED)
+            b.set_comm(comm).set_min_scores(kth).run()
+            ex = distributed.TopkExchange(L, 0, N_SEGS, rank, world, nq, k, "cpu")
+            b.results_to_device(*ex.slot(0))
+            again = [t.clone() for t in ex.run()]
+            b.close()
+            assert all(torch.equal(x, y) for x, y in zip(merged[1], again)), (tag, k, "score::Min")
             both = torch.tensor(listed)
             dist.all_reduce(both)
             if tag == "bm25" and k == 300:   # the ranks share the work of finding k docs
