@@ -279,7 +279,7 @@ def main():
     replay = args.query_sets > 0
     n_probe = 3            # isolated (unpipelined) fresh batches, timed one by one
     n_host = 0 if world > 1 else max(2, min(args.steps, 8))
-    n_rows = max(1, args.query_sets) if replay else min(64, n_probe + args.warmup + args.steps + n_host)
+    n_rows = max(1, args.query_sets) if replay else min(64, n_probe + args.warmup + args.steps + n_host + 2)
     rank_sets = [synth.make_queries(args.queries, args.terms, 16, 4096,
                                     synth.SEED + 2 + (10 + i if i else 0)) for i in range(n_rows)]
     ranks = rank_sets[0]
@@ -450,6 +450,9 @@ def main():
     # the same steps with the hits copied to host memory in every step (not `value`)
     host_elapsed = None
     if n_host:
+        for _ in range(2):               # (warm-up: the page-locked result buffers enter the pool)
+            step(host_results=True)
+        flush()
         sync()
         t0 = time.perf_counter()
         for _ in range(n_host):

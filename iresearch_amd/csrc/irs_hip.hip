@@ -1335,8 +1335,22 @@ bool launch_join_score(irs_hip_batch* b, rt::stream_t st) {
   uint32_t per_cu = uint32_t((160u * 1024u) / smem);
   per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 32u / waves));
   // chunks of up to kJoinChunkTiles tiles, the unit's tiles cut evenly (102 tiles: 4 x 26, not
-  // 3 x 32 + 6 — a short last chunk pays the whole per-chunk prologue for a few tiles)
-  const uint32_t cpq = std::max<uint32_t>(1, (b->join_max_tiles + kJoinChunkTiles - 1) / kJoinChunkTiles);
+  // 3 x 32 + 6 — a short last chunk pays the whole per-chunk prologue for a few tiles).  A small
+  // batch takes shorter chunks: with fewer than ~20 chunks per resident workgroup the last round
+  // of the work queue leaves CUs idle (1000 units x 102 tiles: 8 chunks per workgroup at 26 tiles,
+  // 1.12 ms; 21 at 10 tiles, 0.95 ms — profiles/r05_chunks.txt), while a large batch loses to the
+  // per-chunk prologue below 26 (10 M docs: 5.61 ms at 32, 5.88 at 16, 6.50 at 8).
+  uint32_t max_chunk = kJoinChunkTiles;
+  {
+    const uint64_t tiles = uint64_t(b->join_units.size()) * b->join_max_tiles;
+    const uint64_t wgs = uint64_t(b->seg->cus) * per_cu;
+    max_chunk = uint32_t(std::min<uint64_t>(kJoinChunkTiles, std::max<uint64_t>(8, tiles / (20 * wgs))));
+  }
+  if (const char* e = std::getenv("IRS_HIP_JOIN_CHUNK")) {   // tuning knob: tiles per chunk at most
+    const uint32_t v = uint32_t(std::atoi(e));
+    if (v >= 1 && v <= kJoinChunkTiles) max_chunk = v;
+  }
+  const uint32_t cpq = std::max<uint32_t>(1, (b->join_max_tiles + max_chunk - 1) / max_chunk);
   const uint32_t chunk_tiles = std::max<uint32_t>(1, (b->join_max_tiles + cpq - 1) / cpq);
   const uint32_t n_all = uint32_t(b->join_units.size());
   // [0]: the live counters, [1]: their start values (copied over [0] on the device every run)
