@@ -77,7 +77,7 @@ k_block_max(DevSegment seg, uint32_t slices, uint32_t* blk_maxf, uint32_t* blk_m
   }
 }
 
-// The index's OWN block-max data, where the field was indexed with scorers: one thread per term
+// The index's OWN block-max data, where the field was indexed with scorers: one wavefront per term
 // walks level 0 of the term's skip list (SkipWriter layout: per level a vlong length + bytes,
 // level 0 last; formats_10.cpp:501-533, 1063-1080) and takes, for every entry, the payload of
 // scorer 0 — FreqNormSource::Read (wand_writer.hpp:318-334): vint(max freq) [+ vint(norm -
@@ -86,81 +86,181 @@ k_block_max(DevSegment seg, uint32_t slices, uint32_t* blk_maxf, uint32_t* blk_m
 // wand_writer.hpp:198-209; a valid bound because a doc's norm is never below its frequency);
 // the last block of a list has no entry and keeps the derived pair.  `taken` counts the
 // entries read.
+// The header (root entry, level count, the upper levels' lengths) is read where it lies; level 0 —
+// one entry per full block but the last, a chain of dependent byte reads — is staged through LDS
+// kSkipWindow bytes at a time: lane 0 parses the window's entries into lists, all lanes check them
+// against the directory and write the pairs (a thread per term reading global bytes took 87 ms
+// for the 48 k entries of a 6.25 M-doc segment's longest list).
+constexpr uint32_t kSkipWindow = 8192;
+constexpr uint32_t kSkipList = 512;                            // entries listed per window at most
+constexpr uint32_t kSkipHead = 4u * 10u + 16u;                 // vlongs + size bytes of an entry
+struct alignas(16) SkipLine {
+  uint64_t lo, hi;
+};
+
 __global__ void __launch_bounds__(kThreads)
 k_wand_skip0(DevSegment seg, const uint64_t* skip_at /*[term] absolute offset of the skip data,
              0 = the list has none*/, uint32_t has_pos, uint32_t* blk_maxf, uint32_t* blk_minn,
              unsigned long long* taken, uint32_t* status) {
-  const uint32_t term = blockIdx.x * kThreads + threadIdx.x;
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[kWaves][kSkipWindow + 64];
+  __shared__ uint32_t s_last[kWaves][kSkipList], s_f[kWaves][kSkipList], s_nrm[kWaves][kSkipList];
+  const unsigned lane = threadIdx.x & 63u;
+  const uint32_t wv = threadIdx.x >> 6;
+  const uint32_t term = blockIdx.x * kWaves + wv;
   if (term >= seg.num_terms) return;
   const DevTerm t = seg.terms[term];
   const uint64_t at = skip_at[term];
   if (!at || !t.nblk) return;
-  const uint8_t* p = seg.doc + at;
-  const uint8_t* end = seg.doc + seg.doc_len;   // (the staged copy is zero padded behind it)
-  bool bad = false;
-  auto vlong = [&]() {
-    uint64_t v = 0;
-    for (uint32_t sh = 0; sh < 64 && p < end; sh += 7) {
-      const uint8_t b = *p++;
-      v |= uint64_t(b & 0x7Fu) << sh;
-      if (!(b & 0x80u)) return v;
-    }
-    bad = true;
-    return v;
-  };
-  auto sizes = [&](uint32_t& first) {   // one size byte per scorer (CommonSkipWandData :1962-1979)
+  uint64_t cur = 0, stop = 0;
+  uint32_t bad = 0;
+  if (lane == 0) {
+    const uint8_t* p = seg.doc + at;
+    const uint8_t* end = seg.doc + seg.doc_len;   // (the staged copy is zero padded behind it)
+    auto vlong = [&]() {
+      uint64_t v = 0;
+      for (uint32_t sh = 0; sh < 64 && p < end; sh += 7) {
+        const uint8_t b = *p++;
+        v |= uint64_t(b & 0x7Fu) << sh;
+        if (!(b & 0x80u)) return v;
+      }
+      bad = 1;
+      return v;
+    };
+    // the root entry in front of the level count: one size byte per scorer, then the payloads
+    // (CommonSkipWandData :1962-1979)
     uint64_t total = 0;
-    first = 0;
-    for (uint32_t w = 0; w < seg.wand_count && p < end; ++w) {
-      if (w == 0) first = *p;
-      total += *p++;
+    for (uint32_t w = 0; w < seg.wand_count && p < end; ++w) total += *p++;
+    p += total;
+    const uint32_t levels = p < end ? uint32_t(vlong()) : 0u;
+    if (!levels || bad) {
+      bad = 2;   // nothing to take (as before: not an error)
+    } else {
+      for (uint32_t l = levels; l-- > 1 && !bad;) {   // levels n..1
+        const uint64_t len = vlong();
+        if (!len || uint64_t(end - p) < len) bad = 1; else p += len;
+      }
+      const uint64_t len0 = bad ? 0 : vlong();
+      if (bad || !len0 || uint64_t(end - p) < len0) {
+        bad = 1;
+      } else {
+        cur = uint64_t(p - seg.doc);
+        stop = cur + len0;
+      }
     }
-    return total;
-  };
-  uint32_t s0;
-  p += sizes(s0);                              // the root entry in front of the level count
-  const uint32_t levels = uint32_t(vlong());
-  if (!levels || bad) return;
-  for (uint32_t l = levels; l-- > 1 && !bad;) {   // levels n..1
-    const uint64_t len = vlong();
-    if (!len || uint64_t(end - p) < len) bad = true; else p += len;
   }
-  uint64_t len0 = bad ? 0 : vlong();
-  if (bad || !len0 || uint64_t(end - p) < len0) {
-    atomicOr(status, kStatusCorrupt);
+  bad = wave::bcast(bad, 0);
+  if (bad) {
+    if (lane == 0 && bad == 1) atomicOr(status, kStatusCorrupt);
     return;
   }
-  const uint8_t* stop = p + len0;
-  uint32_t n = 0;
-  while (p < stop && n < t.nblk && !bad) {
-    // last doc of the block: must be the directory's — anything else means the entries are
-    // framed differently from what this walk assumes (the caller then keeps the derived pairs)
-    if (uint32_t(vlong()) != seg.blk_last[t.dir_off + n]) {
-      atomicOr(status, kStatusWandFraming);
-      return;
-    }
-    (void)vlong();   // delta of the next block's pointer
-    if (has_pos) {   // pend_pos, delta of the `.pos` pointer (ReadState :1063-1080)
-      (void)vlong();
-      (void)vlong();
-    }
-    const uint64_t total = sizes(s0);
-    if (uint64_t(end - p) < total) { bad = true; break; }
-    if (s0) {
-      const uint8_t* payload = p;
-      const uint32_t f = uint32_t(vlong());
-      // (no more bytes: norm == freq — what a frequency-only payload means to a scorer that
-      // wants a norm, "compatibility between BM25 in the index and TFIDF in the query")
-      const uint32_t nrm = uint32_t(p - payload) != s0 ? f + uint32_t(vlong()) : f;
-      blk_maxf[t.dir_off + n] = f;
-      blk_minn[t.dir_off + n] = nrm;
-      p = payload;
-    }
-    p += total;
-    ++n;
+  {
+    const uint32_t lo = wave::bcast(uint32_t(cur), 0), hi = wave::bcast(uint32_t(cur >> 32), 0);
+    cur = (uint64_t(hi) << 32) | lo;
+    const uint32_t slo = wave::bcast(uint32_t(stop), 0), shi = wave::bcast(uint32_t(stop >> 32), 0);
+    stop = (uint64_t(shi) << 32) | slo;
   }
-  if (bad) atomicOr(status, kStatusCorrupt);
-  else if (n) atomicAdd(taken, static_cast<unsigned long long>(n));
+  uint8_t* win = s_win[wv];
+  const uint64_t staged = seg.doc_len + kPadBytes;
+  uint32_t n = 0, framing = 0;
+  while (cur < stop && n < t.nblk) {
+    const uint64_t win_lo = cur & ~uint64_t(15);
+    uint64_t bytes = staged - win_lo;
+    if (bytes > kSkipWindow) bytes = kSkipWindow;
+    bytes &= ~uint64_t(15);
+    for (uint32_t o = lane * 16u; o < bytes; o += 64u * 16u)
+      *reinterpret_cast<SkipLine*>(win + o) = *reinterpret_cast<const SkipLine*>(seg.doc + win_lo + o);
+    wave::sync();
+    // every lane runs the parse on the same bytes (wave-uniform: scalar registers and branches;
+    // one lane under an exec mask pays several times that); entry m waits in lane m mod 64
+    uint32_t m = 0, my_last = 0, my_f = 0, my_nrm = 0;
+    {
+      uint32_t o = wave::uniform(uint32_t(cur - win_lo));
+      const uint32_t lim = wave::uniform(uint32_t(bytes)), left = t.nblk - n;
+      const uint64_t room = seg.doc_len - win_lo;            // bytes of the file from the window's start
+      const uint64_t stop_o = stop - win_lo;
+      auto vlong = [&]() {   // (a window ends in the staged zero padding at the latest: terminates)
+        uint64_t v = 0;
+        for (uint32_t sh = 0; sh < 64; sh += 7) {
+          const uint32_t b = wave::uniform(uint32_t(win[o]));
+          ++o;
+          v |= uint64_t(b & 0x7Fu) << sh;
+          if (!(b & 0x80u)) return v;
+        }
+        bad = 1;
+        return v;
+      };
+      while (o < stop_o && m < left && m < kSkipList && (m == 0 || o + kSkipHead <= lim)) {
+        const uint32_t e0 = o;
+        const uint32_t last = uint32_t(vlong());   // last doc of the block
+        (void)vlong();                             // delta of the next block's pointer
+        if (has_pos) {   // pend_pos, delta of the `.pos` pointer (ReadState :1063-1080)
+          (void)vlong();
+          (void)vlong();
+        }
+        uint32_t s0 = 0, total = 0;   // one size byte per scorer
+        for (uint32_t w = 0; w < seg.wand_count; ++w) {
+          const uint32_t sz = wave::uniform(uint32_t(win[o]));
+          ++o;
+          if (w == 0) s0 = sz;
+          total += sz;
+        }
+        if (bad || o + uint64_t(total) > room) { bad = 1; break; }
+        if (o + total > lim) {   // the payloads end behind the window: the next one starts here
+          o = e0;                // (the first entry of a window always fits: 4136 bytes at most)
+          break;
+        }
+        uint32_t f = 0xFFFFFFFFu, nrm = 0;   // (a frequency is never 2^32 - 1: "no payload")
+        if (s0) {
+          const uint32_t payload = o;
+          f = uint32_t(vlong());
+          // (no more bytes: norm == freq — what a frequency-only payload means to a scorer that
+          // wants a norm, "compatibility between BM25 in the index and TFIDF in the query")
+          nrm = (o - payload) != s0 ? f + uint32_t(vlong()) : f;
+          o = payload;
+        }
+        const bool here = lane == (m & 63u);
+        my_last = here ? last : my_last;
+        my_f = here ? f : my_f;
+        my_nrm = here ? nrm : my_nrm;
+        o += total;
+        ++m;
+        if ((m & 63u) == 0) {
+          s_last[wv][m - 64u + lane] = my_last;
+          s_f[wv][m - 64u + lane] = my_f;
+          s_nrm[wv][m - 64u + lane] = my_nrm;
+        }
+      }
+      if (lane < (m & 63u)) {
+        s_last[wv][(m & ~63u) + lane] = my_last;
+        s_f[wv][(m & ~63u) + lane] = my_f;
+        s_nrm[wv][(m & ~63u) + lane] = my_nrm;
+      }
+      cur = win_lo + o;
+    }
+    wave::sync();   // the lists are complete
+    // the entries against the directory: a last doc that is not the block's means the entries
+    // are framed differently from what this walk assumes (the caller then keeps the derived pairs)
+    bool off = false;
+    for (uint32_t i = lane; i < m; i += 64u) {
+      const uint64_t e = t.dir_off + n + i;
+      if (s_last[wv][i] != seg.blk_last[e]) {
+        off = true;
+      } else if (s_f[wv][i] != 0xFFFFFFFFu) {
+        blk_maxf[e] = s_f[wv][i];
+        blk_minn[e] = s_nrm[wv][i];
+      }
+    }
+    if (wave::ballot(off) != 0) { framing = 1; break; }   // (before `bad`: a walk that is off
+    if (bad) break;                                        //  the framing may run into anything)
+    n += m;
+    if (m == 0) break;   // (cannot happen: the first entry of a window is always taken or refused)
+    wave::sync();   // the window and the lists are rewritten next
+  }
+  if (lane == 0) {
+    if (framing) atomicOr(status, kStatusWandFraming);
+    else if (bad) atomicOr(status, kStatusCorrupt);
+    else if (n) atomicAdd(taken, static_cast<unsigned long long>(n));
+  }
 }
 
 // Doc block `e` of a term, from the packed image when both parts live there (one funnel

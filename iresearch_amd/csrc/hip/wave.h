@@ -89,6 +89,13 @@ __device__ __forceinline__ float uniform_f(float v) {
 __device__ __forceinline__ uint32_t read_lane(uint32_t v, uint32_t k) {
   return uint32_t(__builtin_amdgcn_readlane(int(v), int(k)));
 }
+// `v` with lane `k` (wave-uniform index) replaced by the wave-uniform `x` (v_writelane_b32).
+// (this clang has no __builtin_amdgcn_writelane: the intrinsic is bound by its name; the
+// compiler moves the lane select into m0 itself)
+extern "C" __device__ int irs_llvm_writelane(int, int, int) __asm("llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ uint32_t write_lane(uint32_t v, uint32_t x, uint32_t k) {
+  return uint32_t(irs_llvm_writelane(int(x), int(k), int(v)));
+}
 __device__ __forceinline__ float read_lane_f(float v, uint32_t k) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), int(k)));
 }

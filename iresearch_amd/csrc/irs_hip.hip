@@ -111,16 +111,17 @@ struct PoolBuf {  // owning allocation out of the pool of the device that was cu
   size_t n = 0;     // bytes asked for
   size_t cap = 0;   // the block's capacity
   int device = 0;
+  bool owned = true;   // false: a view into another PoolBuf (view())
   PoolBuf() = default;
   PoolBuf(const PoolBuf&) = delete;
   PoolBuf& operator=(const PoolBuf&) = delete;
-  PoolBuf(PoolBuf&& o) noexcept : p(o.p), n(o.n), cap(o.cap), device(o.device) {
+  PoolBuf(PoolBuf&& o) noexcept : p(o.p), n(o.n), cap(o.cap), device(o.device), owned(o.owned) {
     o.p = nullptr;
     o.n = o.cap = 0;
   }
   ~PoolBuf() { release(); }
   bool alloc(size_t bytes) {
-    if (p && bytes <= cap && pool::size_class(bytes) == cap) {   // the same block would come back
+    if (p && owned && bytes <= cap && pool::size_class(bytes) == cap) {   // the same block would come back
       n = bytes;
       return true;
     }
@@ -131,9 +132,17 @@ struct PoolBuf {  // owning allocation out of the pool of the device that was cu
     return p != nullptr;
   }
   void release() {
-    pool::give(device, PINNED, p, cap);
+    if (owned) pool::give(device, PINNED, p, cap);
     p = nullptr;
     n = cap = 0;
+    owned = true;
+  }
+  // `bytes` at `ptr` inside a block somebody else owns (and outlives this view)
+  void view(void* ptr, size_t bytes) {
+    release();
+    p = ptr;
+    n = bytes;
+    owned = false;
   }
   template<typename T>
   T* as() const { return static_cast<T*>(p); }
@@ -340,6 +349,7 @@ struct irs_hip_batch {
   // the 32-byte records themselves
   DevBuf d_tile_off, d_scan_parts, d_items, d_score_args, d_tile_ub;
   DevBuf d_pruned;    // [unit] u32: block-max pruning skipped something of the unit in this run
+  DevBuf d_zeroed;    // owns d_status, d_bstar, d_cand_count, d_hits, d_touched, d_pruned (views): one fill per run
   DevBuf d_touched;   // [unit][2] u64: bytes decoded / positions read by the block-driven kernels
   ScoreArgs score_args{}, score_args_sent{};
   bool score_args_valid = false;
@@ -468,7 +478,7 @@ int build_packed_image(irs_hip_segment* s) {
 
 template<int LAYOUT>
 int build_directory(irs_hip_segment* s) {
-  const uint32_t grid = (s->dev.num_terms + kWaves - 1) / kWaves;
+  const uint32_t grid = s->dev.num_terms;   // a workgroup per term
   if (!rt::dmemset(s->d_status.p, 0, 4, nullptr)) return IRS_HIP_EHIP;
   if (grid) {
     RT_LAUNCH((k_build_directory<LAYOUT>), grid, kThreads, 0, nullptr, s->dev,
@@ -899,7 +909,7 @@ int prepare_blockmax(irs_hip_segment* s) {
       if (!rt::h2d(d_at.p, s->skip_at.data(), s->skip_at.size() * 8, nullptr) ||
           !rt::dmemset(d_taken.p, 0, 8, nullptr) || !rt::dmemset(s->d_status.p, 0, 4, nullptr))
         return IRS_HIP_EHIP;
-      RT_LAUNCH(k_wand_skip0, (s->dev.num_terms + kThreads - 1) / kThreads, kThreads, 0, nullptr,
+      RT_LAUNCH(k_wand_skip0, (s->dev.num_terms + kWaves - 1) / kWaves, kThreads, 0, nullptr,
                 s->dev, d_at.as<uint64_t>(), s->has_pos ? 1u : 0u, s->d_blk_maxf.as<uint32_t>(),
                 s->d_blk_minn.as<uint32_t>(), d_taken.as<unsigned long long>(),
                 s->d_status.as<uint32_t>());
@@ -1616,16 +1626,29 @@ bool ensure_scratch(irs_hip_batch* b) {
   while ((64u << b->join_nw_log2) < b->join_threads) ++b->join_nw_log2;
   if (b->cand_cap == 0) b->cand_cap = default_cand_cap(b);
   const uint64_t rows = uint64_t(b->nq) * b->jt;
+  // what every run starts from zero lives in ONE block (one fill per run instead of six: each is
+  // a dispatch of its own in front of the first kernel): status, thresholds, candidate and hit
+  // counters, the touched / pruned tallies
+  {
+    const uint64_t nq = b->nq;
+    auto up = [](uint64_t v) { return (v + 255u) & ~uint64_t(255); };
+    const uint64_t o_status = 0, o_bstar = 256, o_count = o_bstar + up(nq * 4),
+                   o_hits = o_count + up(nq * 4), o_touched = o_hits + up(nq * 8),
+                   o_pruned = o_touched + up(nq * 16), total = o_pruned + up(nq * 4);
+    if (!b->d_zeroed.alloc(total)) return false;
+    uint8_t* z = b->d_zeroed.as<uint8_t>();
+    b->d_status.view(z + o_status, 4);
+    b->d_bstar.view(z + o_bstar, nq * 4);
+    b->d_cand_count.view(z + o_count, nq * 4);
+    b->d_hits.view(z + o_hits, nq * 8);
+    b->d_touched.view(z + o_touched, nq * 16);
+    b->d_pruned.view(z + o_pruned, nq * 4);
+  }
   if (!b->d_first.alloc(std::max<uint64_t>(first_words, 1) * sizeof(uint32_t)) ||
       !b->d_tails.alloc(rows * sizeof(DevTail)) ||
-      !b->d_bstar.alloc(b->nq * sizeof(uint32_t)) ||
       !b->d_cands.alloc(uint64_t(b->nq) * b->cand_cap * sizeof(uint64_t)) ||
-      !b->d_cand_count.alloc(b->nq * sizeof(uint32_t)) ||
-      !b->d_hits.alloc(b->nq * sizeof(uint64_t)) ||
       !b->d_out.alloc(uint64_t(b->nq) * b->k_max * sizeof(Hit)) ||
-      !b->d_out_count.alloc(b->nq * sizeof(uint32_t)) || !b->d_status.alloc(4) ||
-      !b->d_work.alloc(16) || !b->d_touched.alloc(uint64_t(b->nq) * 16) ||
-      !b->d_pruned.alloc(uint64_t(b->nq) * 4))
+      !b->d_out_count.alloc(b->nq * sizeof(uint32_t)) || !b->d_work.alloc(16))
     return false;
   if (b->joined && !build_streams(b)) return false;
   if (!build_groups(b)) return false;
@@ -2790,12 +2813,7 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st) {
     ok = rt::dmemset(b->d_entries.as<uint32_t>() + b->join_entries, 0, kJoinSlack * 4, st);
     b->slack_zeroed = ok;
   }
-  ok = ok && rt::dmemset(b->d_cand_count.p, 0, b->d_cand_count.n, st) &&
-            rt::dmemset(b->d_hits.p, 0, b->d_hits.n, st) &&
-            rt::dmemset(b->d_status.p, 0, 4, st) &&
-            rt::dmemset(b->d_bstar.p, 0, b->d_bstar.n, st) &&
-            rt::dmemset(b->d_touched.p, 0, b->d_touched.n, st) &&
-            rt::dmemset(b->d_pruned.p, 0, b->d_pruned.n, st);
+  ok = ok && rt::dmemset(b->d_zeroed.p, 0, b->d_zeroed.n, st);   // (ensure_scratch: six tables)
   // 1. plan (already queued by irs_hip_batch_plan: wait for it instead)
   const bool tiles = !b->phrase && !b->tile_units.empty();
   if (b->planned) {

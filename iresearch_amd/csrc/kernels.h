@@ -42,12 +42,123 @@ __device__ __forceinline__ bool pk_both(uint32_t dbits, uint32_t fbits) {
   return (dbits - 1u) <= 30u && (fbits - 1u) <= 30u;
 }
 
-// One wavefront per term walks the term's full blocks front to back: header
-// byte -> payload size (bitpack::skip_block32, bitpack.hpp:60-69); the block's
-// last doc is base + sum(deltas).  Lane 0 then decodes the vint tail
-// (formats_10.cpp:1765-1792) into the per-term tail tables.  The stream is staged through
-// LDS (kDirWindow bytes per refill and wavefront): the walk is a chain of dependent reads.
+// ---- the header chain, speculatively -------------------------------------------------------
+// Block headers of the 1_x formats form a chain: the header byte `bits` at p is followed by
+// 16 * bits payload bytes (1..32) or, for ALL_EQUAL (0), by one vint (bitpack.hpp:60-69, 159).
+// The headers behind p therefore lie at p + a + 16 * S: a = header / value bytes passed, S = bit
+// widths passed.  A wavefront reads every candidate at once — register a, lane S <- the byte at
+// p + a + 16 * S, kSpecBytes LDS reads in flight — and then follows the chain through
+// v_readlane_b32 with the running S as the lane: a few scalar cycles per header where a walk
+// by dependent LDS reads pays the LDS latency (and, run by one lane under exec masks, some
+// 500 cycles) per header.  Everything here is wave-uniform: all lanes run it, the compiler
+// keeps the state in scalar registers.
+constexpr uint32_t kSpecBytes = 8;     // registers of candidates = header / value bytes per round
+constexpr uint32_t kSpecSpan = 2048;   // a round reads up to p + 7 + 16 * 63, its blocks end
+                                       // before p + 8 + 16 * (63 + 32): rounded up
+
+// The headers a walk lists, (offset in the window << 8) | bits: entry base + i waits in lane i
+// of `rec` (v_writelane_b32) until the register is spilled to the list in LDS.
+struct HeaderList {
+  uint32_t* list;
+  uint32_t base;   // entries in the list (wave-uniform)
+  uint32_t cnt;    // entries in `rec`
+  uint32_t rec;
+  __device__ __forceinline__ uint32_t n() const { return base + cnt; }
+  __device__ __forceinline__ void spill(unsigned lane) {
+    if (lane < cnt) list[base + lane] = rec;
+    base += cnt;
+    cnt = 0;
+  }
+  __device__ __forceinline__ void push(uint32_t r, unsigned lane) {
+    if (cnt == 64u) spill(lane);   // (a round may leave the register exactly full)
+    rec = wave::write_lane(rec, r, cnt);
+    ++cnt;
+  }
+};
+
+// One round from window offset `o`: lists up to kSpecBytes headers and moves `o` behind the last
+// block taken.  The caller guarantees that o + kSpecSpan bytes of the window lie inside the
+// file (a listed block cannot run past its end), that kSpecBytes headers are still to come and
+// that `rec` has room for them.  bad: a header above 32.  slow: the next header is an ALL_EQUAL
+// block whose value takes more than one byte — the caller reads that block byte by byte.
+// Per header: v_readlane (candidate: position << 8 | byte), two range tests, v_writelane, two
+// adds — about a dozen scalar instructions.
+#define IRS_SPEC_HOP(A, SKIP)                                                        \
+  {                                                                                  \
+    const uint32_t t = wave::read_lane(T[A], S);                                     \
+    const uint32_t v = t & 0xFFu;                                                    \
+    if (__builtin_expect(v - 1u > 31u, 0)) {                                         \
+      o = t >> 8; /* (where the next walk starts unless the block is taken) */       \
+      if (v != 0) { bad = 1; goto done; }                                            \
+      if ((A) + 1u == kSpecBytes) goto done;                                         \
+      if (wave::read_lane(T[((A) + 1u) % kSpecBytes], S) & 0x80u) {                  \
+        slow = 1;                                                                    \
+        goto done;                                                                   \
+      }                                                                              \
+      h.rec = wave::write_lane(h.rec, t, h.cnt);                                     \
+      ++h.cnt;                                                                       \
+      o += 2u;                                                                       \
+      goto SKIP;                                                                     \
+    }                                                                                \
+    h.rec = wave::write_lane(h.rec, t, h.cnt);                                       \
+    ++h.cnt;                                                                         \
+    S += v;                                                                          \
+    o = (t >> 8) + 1u + 16u * v;                                                     \
+    if (S > 63u) goto done;                                                          \
+  }
+
+__device__ __forceinline__ void spec_round(const uint8_t* win, uint32_t& o, HeaderList& h,
+                                           unsigned lane, uint32_t& bad, uint32_t& slow) {
+  const uint64_t w = wave::load_u64(win + o + 16u * lane);
+  const uint32_t at = (o + 16u * lane) << 8;
+  uint32_t T[kSpecBytes];
+#pragma unroll
+  for (uint32_t a = 0; a < kSpecBytes; ++a)
+    T[a] = (uint32_t(w >> (8u * a)) & 0xFFu) | (at + (a << 8));
+  uint32_t S = 0;
+  h.cnt = wave::uniform(h.cnt);
+  IRS_SPEC_HOP(0u, hop2)
+  IRS_SPEC_HOP(1u, hop3)
+hop2:
+  IRS_SPEC_HOP(2u, hop4)
+hop3:
+  IRS_SPEC_HOP(3u, hop5)
+hop4:
+  IRS_SPEC_HOP(4u, hop6)
+hop5:
+  IRS_SPEC_HOP(5u, hop7)
+hop6:
+  IRS_SPEC_HOP(6u, done)
+hop7:
+  IRS_SPEC_HOP(7u, done)
+done:
+  return;
+}
+#undef IRS_SPEC_HOP
+
+// LEB128 length at a wave-uniform LDS address, byte by byte (the careful path)
+__device__ __forceinline__ uint32_t vint_len_uniform(const uint8_t* p) {
+  uint32_t n = 0;
+  for (;;) {
+    const uint32_t b = wave::uniform(uint32_t(p[n]));
+    ++n;
+    if (!(b & 0x80u) || n == 5) break;
+  }
+  return n;
+}
+
+// One workgroup per term walks the term's full blocks front to back: header byte -> payload
+// size (bitpack::skip_block32, bitpack.hpp:60-69); the block's last doc is base + sum(deltas).
+// Thread 0 then decodes the vint tail (formats_10.cpp:1765-1792) into the per-term tail tables.
+// Only the header chain is serial (header -> size -> next header), and the longest list of the
+// segment sets the kernel's duration (10 M docs: 78 k blocks), so per window of kDirWindow
+// bytes staged in LDS
+//   1. wavefront 0 follows the chain (spec_round above) and lists (offset, bit width) per header;
+//   2. the four wavefronts decode the listed blocks' delta sums side by side;
+//   3. wavefront 0 turns the sums into last docs (a scan), everyone writes the rows coalesced.
+// Round 4 did all of it inside the chain, one wavefront per term: 0.89 us per block, 69.5 ms.
 constexpr uint32_t kDirWindow = 8192;
+constexpr uint32_t kDirList = 256;     // blocks listed per window at most (2 headers each)
 struct alignas(16) DirLine {
   uint64_t lo, hi;
 };
@@ -57,14 +168,20 @@ __global__ void __launch_bounds__(kThreads)
 k_build_directory(DevSegment seg, DevTerm* terms, uint32_t* blk_off,
                   uint32_t* blk_last, uint16_t* blk_bits, uint32_t* blk_units, BlkDir* blk_dir,
                   uint32_t* tail_docs, uint32_t* tail_freqs, uint32_t* status) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_win[kWaves][kDirWindow];
-  const unsigned lane = threadIdx.x & 63u;
-  const uint32_t term = blockIdx.x * kWaves + (threadIdx.x >> 6);
+  // (+64: the unpackers read whole 8-byte words, up to 24 bytes past a payload's end)
+  __shared__ __attribute__((aligned(16))) uint8_t win[kDirWindow + 64];
+  __shared__ __attribute__((aligned(16))) uint32_t s_sum[kDirList];   // delta sums, then last docs
+  __shared__ uint32_t s_tf[kDirList];    // the block's frequency bound
+  __shared__ uint32_t s_hdr[2 * kDirList];   // headers: (offset in the window << 8) | bits
+  __shared__ uint64_t s_cur;
+  __shared__ uint32_t s_n, s_bad, s_tfb;
+  const unsigned tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+  const uint32_t term = blockIdx.x;
   if (term >= seg.num_terms) return;
-  DevTerm t = terms[term];
+  const DevTerm t = terms[term];
   if (t.docs_count == 0) return;
   if (t.docs_count == 1) {  // single_doc_iterator, formats_10.cpp:1876-1890
-    if (lane == 0) {
+    if (tid == 0) {
       tail_docs[t.tail_row] = t.single_doc;
       tail_freqs[t.tail_row] = t.single_freq;
       terms[term].last_doc = t.single_doc;
@@ -78,68 +195,146 @@ k_build_directory(DevSegment seg, DevTerm* terms, uint32_t* blk_off,
   uint32_t base = kDocMin;  // formats_10.cpp:636 / :2100-2105
   uint32_t tfb = 0;
   bool bad = false;
-  // The walk is a chain of dependent reads (header -> payload -> next header), so the
-  // stream is staged through LDS, kDirWindow bytes at a time: all 64 lanes copy, then the
-  // blocks inside the window are parsed at LDS latency.
-  uint8_t* win = s_win[threadIdx.x >> 6];
   const uint64_t staged = seg.doc_len + kPadBytes;  // the device copy ends with zero padding
-  uint64_t win_lo = 0, win_hi = 0;
-  constexpr uint32_t kMaxPair = 2u * (1u + 16u * 32u) + 16u;  // doc block + freq block
-  for (uint32_t b = 0; b < t.nblk; ++b) {
+  uint32_t b = 0;
+  while (b < t.nblk && !bad) {
     if (cur + 2 > seg.doc_len) { bad = true; break; }
-    if (cur + kMaxPair > win_hi) {
-      wave::sync();  // every lane is done with the old window
-      win_lo = cur & ~uint64_t(15);
-      uint64_t bytes = staged - win_lo;
-      if (bytes > kDirWindow) bytes = kDirWindow;
-      bytes &= ~uint64_t(15);
-      for (uint32_t o = lane * 16u; o < bytes; o += 64u * 16u)
-        *reinterpret_cast<DirLine*>(win + o) = *reinterpret_cast<const DirLine*>(seg.doc + win_lo + o);
-      win_hi = win_lo + bytes;
+    // the window: from the 16-byte line holding `cur`
+    const uint64_t win_lo = cur & ~uint64_t(15);
+    uint64_t bytes = staged - win_lo;
+    if (bytes > kDirWindow) bytes = kDirWindow;
+    bytes &= ~uint64_t(15);
+    for (uint32_t o = tid * 16u; o < bytes; o += kThreads * 16u)
+      *reinterpret_cast<DirLine*>(win + o) = *reinterpret_cast<const DirLine*>(seg.doc + win_lo + o);
+    __syncthreads();
+    const uint32_t per = seg.has_freq ? 2u : 1u;   // headers per block
+    if (wv == 0) {
+      // 1. the chain.  Rounds of up to kSpecBytes headers while kSpecSpan bytes of the file lie
+      // ahead in the window; near the end of the file header by header with every bound checked.
+      HeaderList h{s_hdr, 0u, 0u, 0u};
+      uint32_t o = wave::uniform(uint32_t(cur - win_lo)), wbad = 0, slow = 0;
+      const uint32_t lim = wave::uniform(uint32_t(bytes));
+      const uint64_t room64 = seg.doc_len - win_lo;   // bytes of the file from the window's start
+      const uint32_t room = wave::uniform(room64 < lim ? uint32_t(room64) : lim);
+      const bool more = lim == kDirWindow;            // the staged file goes on behind the window
+      const uint32_t left = wave::uniform((t.nblk - b) * per);
+      while (h.n() < left && h.n() + kSpecBytes <= per * kDirList && !wbad) {
+        if (!slow && o + kSpecSpan <= room && h.n() + kSpecBytes <= left) {
+          if (h.cnt > 64u - kSpecBytes) h.spill(lane);
+          spec_round(win, o, h, lane, wbad, slow);
+          continue;
+        }
+        if (!slow && more && o + kSpecSpan > room) break;   // the next window starts here
+        const uint64_t at = win_lo + o;
+        if (at + 2 > seg.doc_len) { wbad = 1; break; }
+        const uint32_t bits = wave::uniform(uint32_t(win[o]));
+        if (bits > 32 || at + 1 + 16ull * bits > seg.doc_len) { wbad = 1; break; }
+        h.push((o << 8) | bits, lane);
+        o += bits ? 1u + 16u * bits : 1u + vint_len_uniform(win + o + 1);
+        slow = 0;
+      }
+      h.spill(lane);
       wave::sync();
-    }
-    const uint8_t* blk = win + (cur - win_lo);
-    const uint32_t dbits = blk[0];
-    if (dbits > 32 || cur + 1 + 16ull * dbits > seg.doc_len) { bad = true; break; }
-    uint32_t x0, x1;
-    uint32_t size = read_block_pair<LAYOUT>(blk, dbits, lane, x0, x1);
-    const uint32_t last = base + wave::reduce_add(x0 + x1);
-    // doc ids ascend and stay inside the segment (a doc block of valid data ends at least
-    // 127 docs behind the previous one)
-    if (last <= base || last > seg.num_docs) { bad = true; break; }
-    uint32_t fbits = 0;
-    if (seg.has_freq) {
-      if (cur + size + 2 > seg.doc_len) { bad = true; break; }
-      const uint8_t* fb = blk + size;
-      fbits = fb[0];
-      if (fbits > 32 || cur + size + 1 + 16ull * fbits > seg.doc_len) { bad = true; break; }
-      if (fbits) {
-        size += 1u + 16u * fbits;
-        const uint32_t bound = fbits >= 32 ? 0xFFFFFFFFu : ((1u << fbits) - 1u);
-        tfb = bound > tfb ? bound : tfb;
-      } else {
-        uint32_t len;
-        const uint32_t v = vint_from(wave::load_u64(fb + 1), &len);
-        size += 1u + len;
-        tfb = v > tfb ? v : tfb;
+      if (per == 2u && (h.base & 1u)) {   // a doc header without its freq header: the next window's
+        --h.base;
+        o = s_hdr[h.base] >> 8;
+      }
+      if (lane == 0) {
+        s_n = h.base / per;
+        s_bad = wbad;
+        s_cur = win_lo + o;
       }
     }
-    if (lane == 0) {
-      blk_off[t.dir_off + b] = uint32_t(cur - t.doc_start);
-      blk_last[t.dir_off + b] = last;
-      blk_bits[t.dir_off + b] = uint16_t(dbits | (fbits << 8));
-      blk_units[t.dir_off + b] = pk_units(dbits, fbits);
-      BlkDir d;
-      d.off = uint32_t(cur - t.doc_start);
-      d.prev_last = base;
-      d.aoff = 0;   // k_dir_aoff fills it in once the image offsets are known
-      d.bits = dbits | (fbits << 8);
-      blk_dir[t.dir_off + b] = d;
+    __syncthreads();
+    const uint32_t n = s_n;
+    // 2. delta sums and frequency bounds of the listed blocks, a wavefront per block
+    for (uint32_t i = wv; i < n; i += kWaves) {
+      const uint32_t dh = s_hdr[per * i];
+      const uint32_t dbits = dh & 0xFFu;
+      uint32_t x0, x1;
+      (void)read_block_pair<LAYOUT>(win + (dh >> 8), dbits, lane, x0, x1);
+      const uint32_t sum = wave::reduce_add(x0 + x1);
+      uint32_t tf = 0;
+      if (seg.has_freq) {
+        const uint32_t fh = s_hdr[per * i + 1u];
+        const uint32_t fbits = fh & 0xFFu;
+        if (fbits) {
+          tf = fbits >= 32 ? 0xFFFFFFFFu : ((1u << fbits) - 1u);
+        } else {
+          uint32_t len;
+          tf = vint_from(wave::load_u64(win + (fh >> 8) + 1), &len);
+        }
+      }
+      if (lane == 0) {
+        s_sum[i] = sum;
+        s_tf[i] = tf;
+      }
     }
-    cur += size;
-    base = last;
+    __syncthreads();
+    // 3. last docs: base + running sum.  Doc ids ascend and stay inside the segment (a doc
+    // block of valid data ends at least 127 docs behind the previous one): a zero sum or a last
+    // doc beyond the segment is corrupt data.  Exact in 64 bits from two 32-bit scans (a sum
+    // that passed the first test is < 2^32, 256 of them stay below 2^24 per half).
+    if (wv == 0) {
+      uint32_t v[4], lo = 0, hi = 0, mx = 0;
+      bool wbad = false;
+#pragma unroll
+      for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t i = 4u * lane + k;
+        v[k] = i < n ? s_sum[i] : 0u;
+        if (i < n) {
+          if (v[k] == 0 || v[k] > seg.num_docs) wbad = true;
+          const uint32_t tf = s_tf[i];
+          mx = tf > mx ? tf : mx;
+        }
+        lo += v[k] & 0xFFFFu;
+        hi += v[k] >> 16;
+      }
+      uint32_t ilo = lo, ihi = hi;
+      wave::inclusive_scan2(ilo, ihi);
+      uint64_t run = uint64_t(base) + (uint64_t(ihi - hi) << 16) + (ilo - lo);
+#pragma unroll
+      for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t i = 4u * lane + k;
+        run += v[k];
+        if (i < n) {
+          if (run > seg.num_docs) wbad = true;
+          s_sum[i] = uint32_t(run);
+        }
+      }
+      mx = wave::reduce_max(mx);
+      const bool any_bad = wave::ballot(wbad) != 0;
+      if (lane == 0) {
+        s_tfb = mx;
+        if (any_bad) s_bad = 1;
+      }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += kThreads) {
+      const uint64_t e = t.dir_off + b + i;
+      const uint32_t dh = s_hdr[per * i];
+      const uint32_t dbits = dh & 0xFFu, fbits = seg.has_freq ? s_hdr[per * i + 1u] & 0xFFu : 0u;
+      const uint32_t bits = dbits | (fbits << 8);
+      const uint32_t off = uint32_t(win_lo + (dh >> 8) - t.doc_start);
+      blk_off[e] = off;
+      blk_last[e] = s_sum[i];
+      blk_bits[e] = uint16_t(bits);
+      blk_units[e] = pk_units(dbits, fbits);
+      BlkDir d;
+      d.off = off;
+      d.prev_last = i ? s_sum[i - 1] : base;
+      d.aoff = 0;   // k_dir_aoff fills it in once the image offsets are known
+      d.bits = bits;
+      blk_dir[e] = d;
+    }
+    if (n) base = s_sum[n - 1];
+    tfb = s_tfb > tfb ? s_tfb : tfb;
+    bad = s_bad != 0;
+    cur = s_cur;
+    b += n;
+    __syncthreads();   // the window and the lists are rewritten next
   }
-  if (lane == 0) {
+  if (tid == 0) {
     // a list without a skip list carries its wand root in front of the tail
     // (formats_10.cpp:686-688): one size byte per scorer, then the payloads
     // (CommonSkipWandData :1962-1979).  A 128-doc list has it behind its only block,

@@ -164,9 +164,11 @@ k_check_freq_totals(DevSegment seg, const DevPosTerm* pterms, uint32_t* status) 
 // One wavefront per term walks the term's pos blocks (header byte -> size,
 // bitpack::skip_block32) and decodes the vint tail (read_tail_block :1515-1537).  The walk
 // is a chain of dependent one-byte reads, so the stream is staged through LDS 8 KB at a
-// time (all 64 lanes copy, lane 0 walks the window at LDS latency): 0.29 s -> see DESIGN.md
-// for the 10 M-doc segment, whose longest term has 540 k pos blocks.
+// time: all 64 lanes copy, the wavefront follows the chain speculatively (spec_round,
+// kernels.h) and lists the headers, all lanes write the directory rows.  The 10 M-doc
+// segment's longest term has 540 k pos blocks.
 constexpr uint32_t kWalkWindow = 8192;
+constexpr uint32_t kWalkList = 512;   // blocks listed per window at most
 struct alignas(16) Bytes16 {
   uint64_t lo, hi;
 };
@@ -175,6 +177,7 @@ __global__ void __launch_bounds__(kThreads)
 k_pos_directory(DevSegment seg, DevPosTerm* pterms, uint32_t* pblk_off, uint8_t* pblk_bits,
                 uint32_t* ptail, const uint64_t* pos_end, uint32_t* status) {
   __shared__ __attribute__((aligned(16))) uint8_t s_win[kWaves][kWalkWindow];
+  __shared__ uint32_t s_hdr[kWaves][kWalkList];   // (offset in the window << 8) | bits
   const unsigned lane = threadIdx.x & 63u;
   const uint32_t wv = threadIdx.x >> 6;
   const uint32_t term = blockIdx.x * kWaves + wv;
@@ -198,36 +201,46 @@ k_pos_directory(DevSegment seg, DevPosTerm* pterms, uint32_t* pblk_off, uint8_t*
     win_hi = win_lo + bytes;
     wave::sync();
   };
+  uint32_t* l_hdr = s_hdr[wv];
   while (b < pt.nfull && !bad) {
     if (cur + 8 > seg.pos_len) { bad = 1; break; }
     refill(cur);
-    if (lane == 0) {
-      // every block that starts with its header and a possible 5-byte vint inside the window
-      while (b < pt.nfull && cur + 6 <= win_hi) {
-        const uint32_t bits = win[cur - win_lo];
-        uint32_t size;
-        if (bits == 0) {
-          uint32_t len;
-          (void)vint_bytes(win + (cur + 1 - win_lo), &len);
-          size = 1u + len;
-        } else {
-          size = 1u + 16u * bits;
-        }
-        if (bits > 32 || cur + size > seg.pos_len || cur - pt.pos_start > 0xFFFFFFFFull) {
-          bad = 1;
-          break;
-        }
-        pblk_off[pt.row + b] = uint32_t(cur - pt.pos_start);
-        pblk_bits[pt.row + b] = uint8_t(bits);
-        cur += size;
-        ++b;
+    // the chain (spec_round, kernels.h): rounds of up to kSpecBytes headers while kSpecSpan
+    // bytes of the file lie ahead in the window, block by block near the end of the file
+    HeaderList h{l_hdr, 0u, 0u, 0u};
+    uint32_t o = wave::uniform(uint32_t(cur - win_lo)), slow = 0;
+    const uint32_t lim = wave::uniform(uint32_t(win_hi - win_lo));
+    const uint64_t room64 = seg.pos_len - win_lo;   // bytes of the file from the window's start
+    const uint32_t room = wave::uniform(room64 < lim ? uint32_t(room64) : lim);
+    const bool more = lim == kWalkWindow;           // the staged file goes on behind the window
+    const uint32_t left = wave::uniform(pt.nfull - b);
+    while (h.n() < left && h.n() + kSpecBytes <= kWalkList && !bad) {
+      if (!slow && o + kSpecSpan <= room && h.n() + kSpecBytes <= left) {
+        if (h.cnt > 64u - kSpecBytes) h.spill(lane);
+        spec_round(win, o, h, lane, bad, slow);
+        continue;
       }
+      if ((!slow && more && o + kSpecSpan > room) || o + 6 > lim) break;   // the next window starts here
+      const uint32_t bits = wave::uniform(uint32_t(win[o]));
+      const uint32_t size = bits ? 1u + 16u * bits : 1u + vint_len_uniform(win + o + 1);
+      if (bits > 32 || o + size > room64) { bad = 1; break; }
+      h.push((o << 8) | bits, lane);
+      o += size;
+      slow = 0;
     }
-    b = wave::bcast(b, 0);
-    bad = wave::bcast(bad, 0);
-    const uint32_t lo = wave::bcast(uint32_t(cur), 0), hi = wave::bcast(uint32_t(cur >> 32), 0);
-    cur = (uint64_t(hi) << 32) | lo;
-    wave::sync();  // the window is rewritten next
+    h.spill(lane);
+    cur = win_lo + o;
+    const uint32_t n = h.base;
+    wave::sync();  // the list is complete
+    // (offsets are kept in 32 bits: a term's positions beyond 4 GB are refused)
+    if (n && win_lo + (l_hdr[n - 1] >> 8) - pt.pos_start > 0xFFFFFFFFull) bad = 1;
+    for (uint32_t i = lane; i < n && !bad; i += 64u) {
+      const uint32_t rec = l_hdr[i];
+      pblk_off[pt.row + b + i] = uint32_t(win_lo + (rec >> 8) - pt.pos_start);
+      pblk_bits[pt.row + b + i] = uint8_t(rec);
+    }
+    b += n;
+    wave::sync();  // the window and the list are rewritten next
   }
   // where the writer says the tail starts (EndTerm :719-722; reader :2270-2278)
   if (!bad && pt.total > kBlock && pos_end[term] != cur - pt.pos_start) bad = 1;

@@ -1035,6 +1035,93 @@ def case_min_score_pushdown(L):
     sr.close()
 
 
+def case_header_chain(L, layout, n_docs=120_000):
+    """The directory kernels follow the chain of block headers speculatively (spec_round,
+    kernels.h): lists long enough for many LDS windows whose headers take every path —
+    ALL_EQUAL runs with a one-byte value (the fast path's value byte), with a two-byte value
+    (handed to the careful path), packed blocks from 1 to 32 bits (a round ends when the widths
+    passed exceed the 64 lanes), mixed — for `.doc` with and without frequencies and for `.pos`.
+    Checked through the decoders and the directory against the lists and the oracle."""
+    rng = np.random.default_rng(23)
+    N = n_docs
+
+    def some(n):
+        return np.sort(rng.choice(np.arange(1, N + 1), n, replace=False)).astype(np.uint32)
+
+    every = np.arange(1, N + 1, dtype=np.uint32)                 # delta 1 throughout
+    stride = np.arange(1, N + 1, 300, dtype=np.uint32)[:128 * 3 + 5]   # delta 300: 2-byte value
+    lists = [
+        (every, np.full(every.size, 3, np.uint32)),               # both parts ALL_EQUAL
+        (every, rng.integers(1, 4, every.size).astype(np.uint32)),   # ALL_EQUAL docs, 2-bit freqs
+        (every[::2].copy(), np.full(every.size // 2, 200, np.uint32)),  # freqs ALL_EQUAL, 2 bytes
+        (stride, np.ones(stride.size, np.uint32)),
+        (some(N // 3), rng.integers(1, 60, N // 3).astype(np.uint32)),
+        (some(5000), rng.integers(1, 2**20, 5000).astype(np.uint32)),   # wide freq blocks
+    ]
+    # wide doc deltas: a big segment id space would be needed for 32 bits; 17+ bits here
+    wide = np.cumsum(rng.integers(1, 2 * N // 700, 700)).astype(np.uint32)
+    lists.append((wide[wide <= N], np.ones(int((wide <= N).sum()), np.uint32)))
+    seg, sr = open_lists(L, lists, N, layout)
+    for t, (d, f) in enumerate(lists):
+        assert_decode(sr, seg, t, d, f)
+        last, offs = sr.term_directory(t)
+        nb = d.size // 128
+        assert np.array_equal(last[:nb], d[127::128][:nb]), ("last docs", t)
+        assert (np.diff(offs[:nb].astype(np.int64)) > 0).all()
+    sr.close()
+    # a field without frequencies: one header per block
+    nseg = synth.segment_from_lists([(d, None) for d, _ in lists], N, layout, norms=False)
+    nsr = search.SegmentReader.from_synth(nseg, L=L, has_freq=False)
+    for t, (d, _) in enumerate(lists):
+        got, _ = nsr.decode_term(t, want_freq=False)
+        od, _ = oracle.decode_term(nseg.doc_file, nseg.metas[t], layout, want_freq=False,
+                                   field_has_freq=False)
+        assert np.array_equal(got, d) and np.array_equal(od, d), ("no freq", t)
+    nsr.close()
+    # positions: constant deltas (ALL_EQUAL pos blocks, one- and two-byte values), 1..7-bit
+    # packed blocks over many windows, and wide ones
+    n1 = 40_000
+    d1 = some(n1)
+    f1 = np.full(n1, 4, np.uint32)
+    plists = [
+        (d1, f1, np.tile(np.array([2, 4, 6, 8], np.uint32), n1)),
+        (d1[:3000], f1[:3000], np.tile(np.array([200, 400, 600, 800], np.uint32), 3000)),
+    ]
+    f2 = rng.integers(1, 9, n1).astype(np.uint32)
+    plists.append((d1, f2, np.concatenate([np.cumsum(rng.integers(1, 100, int(k))) for k in f2])
+                   .astype(np.uint32)))
+    f3 = rng.integers(1, 3, 2000).astype(np.uint32)
+    plists.append((d1[:2000], f3, np.concatenate([np.cumsum(rng.integers(1, 2**28, int(k)))
+                                                  for k in f3]).astype(np.uint32)))
+    pseg = synth.segment_from_lists(plists, N, layout)
+    psr = search.SegmentReader.from_synth(pseg, L=L)
+    for t, (d, f, p) in enumerate(plists):
+        assert_decode(psr, pseg, t, d, f)
+        got = psr.decode_positions(t)
+        assert np.array_equal(got, p), ("positions", layout, t)
+        assert np.array_equal(got, oracle.decode_positions(pseg.doc_file, pseg.pos_file,
+                                                           pseg.metas[t], layout)), t
+    psr.close()
+    # skip lists longer than one window / one entry list of k_wand_skip0 (937 entries, 1 and 3
+    # scorers): the pairs taken from the index are the oracle's
+    norms = rng.integers(40, 256, N).astype(np.uint8)
+    half = some(N // 2)
+    wl = [(every, np.minimum(rng.integers(1, 30, N), norms).astype(np.uint32)),
+          (half, np.minimum(rng.integers(1, 200, half.size), norms[half - 1]).astype(np.uint32))]
+    for kinds in ([synth.WAND_MIN_NORM], [synth.WAND_MAX_FREQ, synth.WAND_DIV_NORM, synth.WAND_MIN_NORM]):
+        wseg = synth.segment_from_lists(wl, N, layout, norms, wand_kinds=kinds)
+        wsr = search.SegmentReader.from_synth(wseg, L=L)
+        for t, (d, f) in enumerate(wl):
+            sl, sp, levels, mf, nm = oracle.read_skip0(wseg.doc_file, wseg.metas[t], len(kinds), True)
+            assert len(sl) == d.size // 128 - (1 if d.size % 128 == 0 else 0) and levels >= 2
+            gmf, gmn = wsr.term_blockmax(t)
+            assert np.array_equal(gmf[:len(sl)], mf) and np.array_equal(gmn[:len(sl)], nm), (kinds, t)
+            assert np.array_equal(gmf, f[:128 * len(gmf)].reshape(-1, 128).max(axis=1))
+        from_index, total = wsr.wand_source()
+        assert from_index == sum(d.size // 128 - (1 if d.size % 128 == 0 else 0) for d, _ in wl)
+        wsr.close()
+
+
 def case_decode_without_freq(L, layout):
     """Iterator requested without IndexFeatures::FREQ on a FREQ field: freq blocks are
     skipped (formats_10.cpp:1746-1750) — docs must be identical."""

@@ -75,6 +75,9 @@ __device__ __forceinline__ void inclusive_scan2(uint32_t& a, uint32_t& b) {
   b = inclusive_scan(b);
 }
 __device__ __forceinline__ uint32_t read_lane(uint32_t v, uint32_t k) { return __shfl(v, int(k), 64); }
+__device__ __forceinline__ uint32_t write_lane(uint32_t v, uint32_t x, uint32_t k) {
+  return lane_id() == k ? x : v;
+}
 __device__ __forceinline__ float read_lane_f(float v, uint32_t k) { return __shfl(v, int(k), 64); }
 __device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
 __device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t s) {

@@ -70,6 +70,11 @@ def test_decode_without_freq(simlib, layout):
     cases.case_decode_without_freq(simlib, layout)
 
 
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_header_chain(simlib, layout):
+    cases.case_header_chain(simlib, layout)
+
+
 @pytest.mark.parametrize("layout", [0, 1])
 def test_wand_data(simlib, layout):
     cases.case_wand_data(simlib, layout)

@@ -110,6 +110,11 @@ def test_decode_without_freq(gpulib, layout):
     cases.case_decode_without_freq(gpulib, layout)
 
 
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_header_chain(gpulib, layout):
+    cases.case_header_chain(gpulib, layout)
+
+
 @pytest.mark.parametrize("layout", [0, 1])
 def test_wand_data(gpulib, layout):
     cases.case_wand_data(gpulib, layout)
