@@ -41,20 +41,16 @@ namespace irs_hip {
 // Per full block: largest frequency and smallest non-zero norm value of its docs — what
 // FreqNormProducer keeps per skip entry (wand_writer.hpp:170-209), recomputed from the
 // postings so that it exists for every block of every index (the skip data has no entry for
-// a list's last block).  grid = num_terms * slices, as k_pack_payloads.
+// a list's last block).  Work split by directory row, as k_pack_payloads.
 template<int LAYOUT>
 __global__ void __launch_bounds__(kThreads)
-k_block_max(DevSegment seg, uint32_t slices, uint32_t* blk_maxf, uint32_t* blk_minn) {
+k_block_max(DevSegment seg, uint64_t rows, uint32_t* blk_maxf, uint32_t* blk_minn) {
   const unsigned lane = threadIdx.x & 63u;
-  const uint32_t slice = blockIdx.x % slices;
-  const DevTerm t = seg.terms[blockIdx.x / slices];
-  if (t.docs_count < 2) return;
-  for (uint32_t b = slice * kWaves + (threadIdx.x >> 6); b < t.nblk; b += slices * kWaves) {
-    const uint64_t e = t.dir_off + b;
+  IRS_FOR_ROWS(e, rows) {
     const uint32_t bits = seg.blk_bits[e];
-    const uint32_t base = b ? seg.blk_last[e - 1] : kDocMin;
+    const uint32_t base = seg.blk_dir[e].prev_last;
     uint32_t d0, d1, f0, f1;
-    decode_block<LAYOUT, true>(seg.doc + t.doc_start + seg.blk_off[e], bits & 0xFFu, bits >> 8,
+    decode_block<LAYOUT, true>(row_block(seg, e), bits & 0xFFu, bits >> 8,
                                base, lane, d0, d1, f0, f1);
     uint32_t mf = f0 > f1 ? f0 : f1;
     uint32_t mn = 0xFFFFFFFFu;

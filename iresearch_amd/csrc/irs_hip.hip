@@ -263,6 +263,7 @@ struct irs_hip_segment {
   DevBuf d_doc, d_norms, d_terms, d_blk_off, d_blk_last, d_blk_bits, d_status;
   DevBuf d_blk_aoff, d_pk;     // packed-payload image (DevSegment::pk) and its offsets
   DevBuf d_blk_dir;            // BlkDir per block
+  DevBuf d_blk_term;           // the row's term
   DevBuf d_tail_docs, d_tail_freqs;  // decoded vint tails, [num_terms][128]
   // positions (fields with POS): `.pos` bytes, per-term records, pos block directory,
   // positions in front of every doc block, decoded position tails
@@ -466,10 +467,8 @@ int build_packed_image(irs_hip_segment* s) {
   if (!s->d_pk.alloc(bytes + kPadBytes)) return IRS_HIP_ENOMEM;
   if (!rt::dmemset(s->d_pk.as<uint8_t>() + bytes, 0, kPadBytes, nullptr)) return IRS_HIP_EHIP;
   s->dev.pk = s->d_pk.as<uint8_t>();
-  if (total_units && s->dev.num_terms) {
-    const uint32_t slices =
-        std::max<uint32_t>(1, std::min<uint32_t>(64, s->cus * 8 / s->dev.num_terms));
-    RT_LAUNCH(k_pack_payloads, s->dev.num_terms * slices, kThreads, 0, nullptr, s->dev, slices,
+  if (total_units && n) {
+    RT_LAUNCH(k_pack_payloads, row_grid(n, s->cus), kThreads, 0, nullptr, s->dev, n,
               s->d_pk.as<uint8_t>());
     if (!rt::last_error_ok() || !rt::sync(nullptr)) return IRS_HIP_EHIP;
   }
@@ -485,6 +484,7 @@ int build_directory(irs_hip_segment* s) {
               s->d_terms.as<DevTerm>(), s->d_blk_off.as<uint32_t>(),
               s->d_blk_last.as<uint32_t>(), s->d_blk_bits.as<uint16_t>(),
               s->d_blk_aoff.as<uint32_t>(), s->d_blk_dir.as<BlkDir>(),
+              s->d_blk_term.as<uint32_t>(),
               s->d_tail_docs.as<uint32_t>(), s->d_tail_freqs.as<uint32_t>(),
               s->d_status.as<uint32_t>());
   }
@@ -509,10 +509,8 @@ int build_positions(irs_hip_segment* s, const std::vector<uint64_t>& pos_end) {
   const uint64_t n = s->total_blocks;
   if (!rt::dmemset(s->d_blk_pos.p, 0, s->d_blk_pos.n, nullptr)) return IRS_HIP_EHIP;
   if (n && s->dev.num_terms) {
-    const uint32_t slices =
-        std::max<uint32_t>(1, std::min<uint32_t>(64, s->cus * 8 / s->dev.num_terms));
-    RT_LAUNCH((k_freq_sums<LAYOUT>), s->dev.num_terms * slices, kThreads, 0, nullptr, s->dev,
-              slices, s->d_blk_pos.as<uint32_t>());
+    RT_LAUNCH((k_freq_sums<LAYOUT>), row_grid(n, s->cus), kThreads, 0, nullptr, s->dev,
+              n, s->d_blk_pos.as<uint32_t>());
     if (!rt::last_error_ok() || !rt::sync(nullptr)) return IRS_HIP_EHIP;
   }
   uint64_t total = 0;
@@ -845,14 +843,13 @@ bool launch_phrase_terms(irs_hip_batch* b, rt::stream_t st) {
 
 // Block-max data of a segment (conj.h k_block_max), built once, on first use.
 static bool launch_block_max(irs_hip_segment* s) {
-  const uint32_t slices =
-      std::max<uint32_t>(1, std::min<uint32_t>(64, s->cus * 8 / s->dev.num_terms));
+  const uint64_t rows = s->total_blocks;
   if (s->dev.layout == kSimd4) {
-    RT_LAUNCH((k_block_max<kSimd4>), s->dev.num_terms * slices, kThreads, 0, nullptr, s->dev,
-              slices, s->d_blk_maxf.as<uint32_t>(), s->d_blk_minn.as<uint32_t>());
+    RT_LAUNCH((k_block_max<kSimd4>), row_grid(rows, s->cus), kThreads, 0, nullptr, s->dev,
+              rows, s->d_blk_maxf.as<uint32_t>(), s->d_blk_minn.as<uint32_t>());
   } else {
-    RT_LAUNCH((k_block_max<kScalar>), s->dev.num_terms * slices, kThreads, 0, nullptr, s->dev,
-              slices, s->d_blk_maxf.as<uint32_t>(), s->d_blk_minn.as<uint32_t>());
+    RT_LAUNCH((k_block_max<kScalar>), row_grid(rows, s->cus), kThreads, 0, nullptr, s->dev,
+              rows, s->d_blk_maxf.as<uint32_t>(), s->d_blk_minn.as<uint32_t>());
   }
   return rt::last_error_ok() && rt::sync(nullptr);
 }
@@ -866,12 +863,11 @@ int prepare_posting_norms(irs_hip_segment* s) {
     if (!s->d_pnorm.alloc((rows + 1) * kBlock) || !s->d_tail_norms.alloc(tails + 1))
       return IRS_HIP_ENOMEM;
     if (rows && d.num_terms) {
-      const uint32_t slices = std::max<uint32_t>(1, std::min<uint32_t>(64, s->cus * 8 / d.num_terms));
       if (d.layout == kSimd4) {
-        RT_LAUNCH((k_posting_norms<kSimd4>), d.num_terms * slices, kThreads, 0, nullptr, d, slices,
+        RT_LAUNCH((k_posting_norms<kSimd4>), row_grid(rows, s->cus), kThreads, 0, nullptr, d, rows,
                   s->d_pnorm.as<uint8_t>());
       } else {
-        RT_LAUNCH((k_posting_norms<kScalar>), d.num_terms * slices, kThreads, 0, nullptr, d, slices,
+        RT_LAUNCH((k_posting_norms<kScalar>), row_grid(rows, s->cus), kThreads, 0, nullptr, d, rows,
                   s->d_pnorm.as<uint8_t>());
       }
     }
@@ -1904,6 +1900,7 @@ static int segment_open_impl(const irs_hip_segment_desc* d, irs_hip_segment** ou
         !s->d_blk_off.alloc((blocks + 1) * 4) || !s->d_blk_last.alloc((blocks + 1) * 4) ||
         !s->d_blk_bits.alloc((blocks + 1) * 2) || !s->d_blk_aoff.alloc((blocks + 1) * 4) ||
         !s->d_blk_dir.alloc((blocks + 1) * sizeof(BlkDir)) ||
+        !s->d_blk_term.alloc((blocks + 1) * 4) ||
         !s->d_tail_docs.alloc((tail_rows + 1) * 4) || !s->d_tail_freqs.alloc((tail_rows + 1) * 4) ||
         !s->d_status.alloc(4)) {
       rc = IRS_HIP_ENOMEM;
@@ -1936,6 +1933,7 @@ static int segment_open_impl(const irs_hip_segment_desc* d, irs_hip_segment** ou
     v.blk_bits = s->d_blk_bits.as<uint16_t>();
     v.blk_aoff = s->d_blk_aoff.as<uint32_t>();
     v.blk_dir = s->d_blk_dir.as<BlkDir>();
+    v.blk_term = s->d_blk_term.as<uint32_t>();
     v.tail_docs = s->d_tail_docs.as<uint32_t>();
     v.tail_freqs = s->d_tail_freqs.as<uint32_t>();
     v.pk = nullptr;  // set by build_packed_image
@@ -2003,7 +2001,7 @@ static int segment_open_impl(const irs_hip_segment_desc* d, irs_hip_segment** ou
                                              : build_positions<kScalar>(s, pos_end);
     }
     s->device_bytes = s->d_doc.n + s->d_norms.n + s->d_terms.n + s->d_blk_off.n +
-                      s->d_blk_last.n + s->d_blk_bits.n + s->d_blk_aoff.n + s->d_blk_dir.n + s->d_pk.n +
+                      s->d_blk_last.n + s->d_blk_bits.n + s->d_blk_aoff.n + s->d_blk_dir.n + s->d_blk_term.n + s->d_pk.n +
                       s->d_tail_docs.n + s->d_tail_freqs.n + s->d_pos.n + s->d_pterms.n +
                       s->d_pblk_off.n + s->d_pblk_bits.n + s->d_blk_pos.n + s->d_ptail.n;
   } while (false);

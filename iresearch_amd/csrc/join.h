@@ -281,20 +281,17 @@ k_join(const JoinWg* wgs) {
 // The norm byte of every posting, in posting order (1-byte Norm2 columns): built once per segment,
 // on its first joined batch — k_join then reads a block's 128 norm bytes with one coalesced
 // 2-byte load per lane instead of gathering them by doc id for every batch (the gathers were
-// 0.4 of its 1.3 ms).  128 bytes per directory row (= full block); grid = num_terms * slices, as
+// 0.4 of its 1.3 ms).  128 bytes per directory row (= full block); work split by row, as
 // k_pack_payloads.
 template<int LAYOUT>
 __global__ void __launch_bounds__(kThreads)
-k_posting_norms(DevSegment seg, uint32_t slices, uint8_t* pnorm) {
+k_posting_norms(DevSegment seg, uint64_t rows, uint8_t* pnorm) {
   const unsigned lane = threadIdx.x & 63u;
-  const uint32_t slice = blockIdx.x % slices;
-  const DevTerm t = seg.terms[blockIdx.x / slices];
   const uint8_t* norms = seg.norms - seg.norm_min_doc;   // (indexed by doc id)
-  for (uint32_t b = slice * kWaves + (threadIdx.x >> 6); b < t.nblk; b += slices * kWaves) {
-    const uint64_t e = t.dir_off + b;
-    const uint32_t base = b ? seg.blk_last[e - 1] : kDocMin;
+  IRS_FOR_ROWS(e, rows) {
+    const uint32_t base = seg.blk_dir[e].prev_last;
     uint32_t d0, d1, f0, f1;
-    decode_block<LAYOUT, false>(seg.doc + t.doc_start + seg.blk_off[e], seg.blk_bits[e] & 0xFFu,
+    decode_block<LAYOUT, false>(row_block(seg, e), seg.blk_bits[e] & 0xFFu,
                                 0, base, lane, d0, d1, f0, f1);
     const uint16_t both = uint16_t(uint32_t(norms[d0]) | (uint32_t(norms[d1]) << 8));
     *reinterpret_cast<uint16_t*>(pnorm + e * kBlock + 2u * lane) = both;

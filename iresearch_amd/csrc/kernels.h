@@ -167,7 +167,7 @@ template<int LAYOUT>
 __global__ void __launch_bounds__(kThreads)
 k_build_directory(DevSegment seg, DevTerm* terms, uint32_t* blk_off,
                   uint32_t* blk_last, uint16_t* blk_bits, uint32_t* blk_units, BlkDir* blk_dir,
-                  uint32_t* tail_docs, uint32_t* tail_freqs, uint32_t* status) {
+                  uint32_t* blk_term, uint32_t* tail_docs, uint32_t* tail_freqs, uint32_t* status) {
   // (+64: the unpackers read whole 8-byte words, up to 24 bytes past a payload's end)
   __shared__ __attribute__((aligned(16))) uint8_t win[kDirWindow + 64];
   __shared__ __attribute__((aligned(16))) uint32_t s_sum[kDirList];   // delta sums, then last docs
@@ -320,6 +320,7 @@ k_build_directory(DevSegment seg, DevTerm* terms, uint32_t* blk_off,
       blk_last[e] = s_sum[i];
       blk_bits[e] = uint16_t(bits);
       blk_units[e] = pk_units(dbits, fbits);
+      blk_term[e] = term;
       BlkDir d;
       d.off = off;
       d.prev_last = i ? s_sum[i - 1] : base;
@@ -459,20 +460,32 @@ k_dir_aoff(const uint32_t* blk_aoff, uint64_t n, BlkDir* blk_dir) {
   if (i < n) blk_dir[i].aoff = blk_aoff[i];
 }
 
+// The passes over every block of the segment (payload image, frequency sums, block maxima,
+// posting-order norms) split their work by directory ROW: a wavefront takes rows gw, gw + all
+// wavefronts, ...  A Zipfian index holds most of its blocks in a few lists — split by term
+// (rounds 1-4: one workgroup per term once there are 2048 terms) the longest list's 78 k blocks
+// went through 4 wavefronts while the chip idled: k_pack_payloads copied 550 MB in 15.5 ms.
+__host__ __device__ inline uint32_t row_grid(uint64_t rows, uint32_t cus) {
+  const uint64_t wgs = (rows + kWaves - 1) / kWaves;
+  return uint32_t(wgs < uint64_t(cus) * 16u ? wgs : uint64_t(cus) * 16u);
+}
+#define IRS_FOR_ROWS(e, rows)                                                        \
+  for (uint64_t e = uint64_t(blockIdx.x) * kWaves + (threadIdx.x >> 6); e < (rows);  \
+       e += uint64_t(gridDim.x) * kWaves)
+// where row e's block starts in `.doc`
+__device__ __forceinline__ const uint8_t* row_block(const DevSegment& seg, uint64_t e) {
+  return seg.doc + seg.terms[seg.blk_term[e]].doc_start + seg.blk_off[e];
+}
+
 // Copies the payloads of the decodable blocks into the packed-payload image.
-// grid = num_terms * slices, as k_bit_union.
 __global__ void __launch_bounds__(kThreads)
-k_pack_payloads(DevSegment seg, uint32_t slices, uint8_t* pk) {
+k_pack_payloads(DevSegment seg, uint64_t rows, uint8_t* pk) {
   const unsigned lane = threadIdx.x & 63u;
-  const uint32_t slice = blockIdx.x % slices;
-  const DevTerm t = seg.terms[blockIdx.x / slices];
-  if (t.docs_count < 2) return;
-  for (uint32_t b = slice * kWaves + (threadIdx.x >> 6); b < t.nblk; b += slices * kWaves) {
-    const uint64_t e = t.dir_off + b;
+  IRS_FOR_ROWS(e, rows) {
     const uint32_t bits = seg.blk_bits[e];
     const uint32_t dbits = bits & 0xFFu, fbits = bits >> 8;
     if (!pk_units(dbits, fbits)) continue;
-    const uint8_t* blk = seg.doc + t.doc_start + seg.blk_off[e];
+    const uint8_t* blk = row_block(seg, e);
     uint64_t* dst = reinterpret_cast<uint64_t*>(pk + (uint64_t(seg.blk_aoff[e]) << 4));
     // 8-byte pieces: 2*dbits of the doc payload (after its header byte), then
     // 2*fbits of the freq payload (after the second header byte)

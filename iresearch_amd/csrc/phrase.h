@@ -127,19 +127,15 @@ __device__ __forceinline__ uint32_t pos_delta_cached(const DevSegment& seg, cons
 // ------------------------------------------------------------ open time --
 
 // Sum of the frequencies of every full doc block (-> exclusive scan -> blk_pos).
-// grid = num_terms * slices, as k_pack_payloads.
+// Work split by directory row, as k_pack_payloads.
 template<int LAYOUT>
 __global__ void __launch_bounds__(kThreads)
-k_freq_sums(DevSegment seg, uint32_t slices, uint32_t* sums) {
+k_freq_sums(DevSegment seg, uint64_t rows, uint32_t* sums) {
   const unsigned lane = threadIdx.x & 63u;
-  const uint32_t slice = blockIdx.x % slices;
-  const DevTerm t = seg.terms[blockIdx.x / slices];
-  if (t.docs_count < 2) return;
-  for (uint32_t b = slice * kWaves + (threadIdx.x >> 6); b < t.nblk; b += slices * kWaves) {
-    const uint64_t e = t.dir_off + b;
+  IRS_FOR_ROWS(e, rows) {
     const uint32_t bits = seg.blk_bits[e];
     uint32_t d0, d1, f0, f1;
-    decode_block<LAYOUT, true>(seg.doc + t.doc_start + seg.blk_off[e], bits & 0xFFu, bits >> 8,
+    decode_block<LAYOUT, true>(row_block(seg, e), bits & 0xFFu, bits >> 8,
                                0u, lane, d0, d1, f0, f1);
     const uint32_t s = wave::reduce_add(f0 + f1);
     if (lane == 0) sums[e] = s;

@@ -94,6 +94,8 @@ struct DevSegment {
   const uint8_t* pk;
   const uint32_t* blk_aoff;  // offset of the block in `pk`, in 16-byte units
   const BlkDir* blk_dir;     // the same facts per block, gathered
+  const uint32_t* blk_term;  // ... and the term whose list the block belongs to: the per-block
+                             // passes over the whole directory split their work by ROW
   // block-max data (null until a WAND batch asks for it): largest frequency and smallest
   // non-zero norm of every full block — what FreqNormProducer stores per skip entry
   // (wand_writer.hpp:170-209)
