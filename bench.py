@@ -727,12 +727,16 @@ def main_config5(args):
     t0 = time.perf_counter()
     kms = []
     reruns_warm = it.get("reruns", 0) + sum(b.reruns() for b in it["retire"])
+    marks = []
     for _ in range(args.steps):
         step()
+        marks.append(time.perf_counter())   # (host clock after each step's submissions: where a stall sits)
     flush()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    marks.append(time.perf_counter())
+    step_marks_ms = [round(1e3 * (b - a), 2) for a, b in zip([t0] + marks[:-1], marks)]
     for b in it["retire"]:
         it["reruns"] = it.get("reruns", 0) + b.reruns()
         b.close()
@@ -810,6 +814,7 @@ def main_config5(args):
                                  "kernels touch less than A(q))"},
             "cpu_baseline": None,
         }
+        out["config"]["host_ms_between_steps"] = step_marks_ms   # (the last entry: flush)
         if world == 1 and not sim and not args.no_cpu:
             for b in bat.values():
                 b.close()

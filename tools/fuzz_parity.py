@@ -92,6 +92,11 @@ def main():
             b = sr.batch(prep, k)
             hits, counts, totals = (x.copy() for x in b.run().results())
             parity.check_single_segment(seg, filters, scorer, k, hits, counts, totals)
+            if rounds % 3 == 0:   # the same results through page-locked host memory, a run later
+                hh, hc, ht = b.run().results_to_host().host_results()
+                assert np.array_equal(hc, counts) and np.array_equal(ht, totals), "host results: counts"
+                for q in range(len(filters)):
+                    assert np.array_equal(hh[q, :counts[q]], hits[q, :counts[q]]), "host results: hits"
             # the other execution path (work items / block-driven kernels): checked against the
             # oracle like the first run (which took the joined streams wherever it could)
             ib = sr.batch(prep, k).set_path(_lib.PATH_ITEMS)
