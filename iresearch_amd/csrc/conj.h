@@ -82,34 +82,55 @@ k_block_max(DevSegment seg, uint64_t rows, uint32_t* blk_maxf, uint32_t* blk_min
 // wand_writer.hpp:198-209; a valid bound because a doc's norm is never below its frequency);
 // the last block of a list has no entry and keeps the derived pair.  `taken` counts the
 // entries read.
-// The header (root entry, level count, the upper levels' lengths) is read where it lies; level 0 —
-// one entry per full block but the last, a chain of dependent byte reads — is staged through LDS
-// kSkipWindow bytes at a time: lane 0 parses the window's entries into lists, all lanes check them
-// against the directory and write the pairs (a thread per term reading global bytes took 87 ms
-// for the 48 k entries of a 6.25 M-doc segment's longest list).
-constexpr uint32_t kSkipWindow = 8192;
-constexpr uint32_t kSkipList = 512;                            // entries listed per window at most
-constexpr uint32_t kSkipHead = 4u * 10u + 16u;                 // vlongs + size bytes of an entry
-struct alignas(16) SkipLine {
-  uint64_t lo, hi;
+// The header (root entry, level count, the upper levels' lengths) is read where it lies.  Level 0
+// — one entry per full block but the last, a chain of LEB128 fields — goes through LDS windows:
+// the entries of a window are found by pointer doubling (chain_orbit, kernels.h: "if an entry
+// starts at byte p, the next one starts at link(p)" for every p at once), then every entry is
+// parsed, checked against the block directory and written by a thread of its own.  (A thread per
+// term reading global bytes took 87 ms for the 48 k entries of a 6.25 M-doc segment's longest
+// list; a lone wavefront walking an LDS window 34 ms.)
+struct skip_link {
+  const uint8_t* win;
+  uint32_t vlongs;       // per entry: last doc, pointer delta [, pend_pos, pos pointer delta]
+  uint32_t wand_count;   // then one size byte per scorer and the payloads
+  uint32_t stop;         // level 0 ends here (window offset; beyond the window: anything larger)
+  __device__ __forceinline__ uint32_t operator()(uint32_t p) const {
+    if (p >= stop) return kLinkNone;   // (not an entry: the chain ends in front of it)
+    uint32_t o = p;
+    for (uint32_t f = 0; f < vlongs; ++f) {
+      uint32_t n = 0;
+      while (win[o++] & 0x80u) {
+        // (the 64 readable bytes behind the window are as far as a field may run: the caller
+        // re-stages from any entry that starts in the window's last kSkipHead bytes)
+        if (++n == 10u) return kLinkBad;
+      }
+    }
+    uint32_t total = 0;
+    for (uint32_t w = 0; w < wand_count; ++w) total += win[o++];
+    return o + total;
+  }
 };
 
-__global__ void __launch_bounds__(kThreads)
+constexpr uint32_t kSkipHead = 4u * 10u + 16u;   // vlongs + size bytes of an entry
+
+__global__ void __launch_bounds__(kChainThreads)
 k_wand_skip0(DevSegment seg, const uint64_t* skip_at /*[term] absolute offset of the skip data,
              0 = the list has none*/, uint32_t has_pos, uint32_t* blk_maxf, uint32_t* blk_minn,
              unsigned long long* taken, uint32_t* status) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_win[kWaves][kSkipWindow + 64];
-  __shared__ uint32_t s_last[kWaves][kSkipList], s_f[kWaves][kSkipList], s_nrm[kWaves][kSkipList];
-  const unsigned lane = threadIdx.x & 63u;
-  const uint32_t wv = threadIdx.x >> 6;
-  const uint32_t term = blockIdx.x * kWaves + wv;
+  __shared__ __attribute__((aligned(16))) uint8_t win[kChainWindow + 64];
+  __shared__ ChainTables s_chain;
+  __shared__ uint32_t s_at[kChainCap];
+  __shared__ uint64_t s_cur, s_stop;
+  __shared__ uint32_t s_flag;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t term = blockIdx.x;
   if (term >= seg.num_terms) return;
   const DevTerm t = seg.terms[term];
   const uint64_t at = skip_at[term];
   if (!at || !t.nblk) return;
-  uint64_t cur = 0, stop = 0;
-  uint32_t bad = 0;
-  if (lane == 0) {
+  if (tid == 0) {
+    uint32_t bad = 0;
+    uint64_t cur = 0, stop = 0;
     const uint8_t* p = seg.doc + at;
     const uint8_t* end = seg.doc + seg.doc_len;   // (the staged copy is zero padded behind it)
     auto vlong = [&]() {
@@ -129,7 +150,7 @@ k_wand_skip0(DevSegment seg, const uint64_t* skip_at /*[term] absolute offset of
     p += total;
     const uint32_t levels = p < end ? uint32_t(vlong()) : 0u;
     if (!levels || bad) {
-      bad = 2;   // nothing to take (as before: not an error)
+      bad = 2;   // nothing to take (not an error)
     } else {
       for (uint32_t l = levels; l-- > 1 && !bad;) {   // levels n..1
         const uint64_t len = vlong();
@@ -143,116 +164,81 @@ k_wand_skip0(DevSegment seg, const uint64_t* skip_at /*[term] absolute offset of
         stop = cur + len0;
       }
     }
+    s_cur = cur;
+    s_stop = stop;
+    s_flag = bad;
   }
-  bad = wave::bcast(bad, 0);
-  if (bad) {
-    if (lane == 0 && bad == 1) atomicOr(status, kStatusCorrupt);
+  __syncthreads();
+  if (s_flag) {
+    if (tid == 0 && s_flag == 1) atomicOr(status, kStatusCorrupt);
     return;
   }
-  {
-    const uint32_t lo = wave::bcast(uint32_t(cur), 0), hi = wave::bcast(uint32_t(cur >> 32), 0);
-    cur = (uint64_t(hi) << 32) | lo;
-    const uint32_t slo = wave::bcast(uint32_t(stop), 0), shi = wave::bcast(uint32_t(stop >> 32), 0);
-    stop = (uint64_t(shi) << 32) | slo;
-  }
-  uint8_t* win = s_win[wv];
+  uint64_t cur = s_cur;
+  const uint64_t stop = s_stop;
   const uint64_t staged = seg.doc_len + kPadBytes;
-  uint32_t n = 0, framing = 0;
+  const uint32_t vlongs = has_pos ? 4u : 2u;
+  uint32_t n = 0, bad = 0, framing = 0;
+  __syncthreads();
   while (cur < stop && n < t.nblk) {
     const uint64_t win_lo = cur & ~uint64_t(15);
     uint64_t bytes = staged - win_lo;
-    if (bytes > kSkipWindow) bytes = kSkipWindow;
+    if (bytes > kChainWindow) bytes = kChainWindow;
     bytes &= ~uint64_t(15);
-    for (uint32_t o = lane * 16u; o < bytes; o += 64u * 16u)
-      *reinterpret_cast<SkipLine*>(win + o) = *reinterpret_cast<const SkipLine*>(seg.doc + win_lo + o);
-    wave::sync();
-    // every lane runs the parse on the same bytes (wave-uniform: scalar registers and branches;
-    // one lane under an exec mask pays several times that); entry m waits in lane m mod 64
-    uint32_t m = 0, my_last = 0, my_f = 0, my_nrm = 0;
-    {
-      uint32_t o = wave::uniform(uint32_t(cur - win_lo));
-      const uint32_t lim = wave::uniform(uint32_t(bytes)), left = t.nblk - n;
-      const uint64_t room = seg.doc_len - win_lo;            // bytes of the file from the window's start
-      const uint64_t stop_o = stop - win_lo;
-      auto vlong = [&]() {   // (a window ends in the staged zero padding at the latest: terminates)
+    for (uint32_t o = tid * 16u; o < bytes; o += kChainThreads * 16u)
+      *reinterpret_cast<ChainLine*>(win + o) = *reinterpret_cast<const ChainLine*>(seg.doc + win_lo + o);
+    if (tid == 0) s_flag = 0;
+    __syncthreads();
+    // entries that start in the window's last kSkipHead bytes are the next window's: their
+    // fields may run past the staged bytes (an entry is at most 4136 bytes: the first always fits)
+    const uint32_t lim = uint32_t(bytes);
+    const uint64_t stop_o = stop - win_lo;
+    const uint32_t head_lim = lim == kChainWindow ? lim - kSkipHead : lim;
+    const uint32_t stop_w = stop_o < head_lim ? uint32_t(stop_o) : head_lim;
+    const uint32_t left = t.nblk - n;
+    uint32_t next;
+    const uint32_t m = chain_orbit(win, s_chain, uint32_t(cur - win_lo), lim, seg.doc_len - win_lo,
+                                   left < kChainCap ? left : kChainCap, s_at, &next, &bad,
+                                   skip_link{win, vlongs, seg.wand_count, stop_w});
+    // every entry by a thread of its own: its last doc must be the directory's — anything else
+    // means the entries are framed differently from what this walk assumes (the caller then
+    // keeps the derived pairs) — and the payload of scorer 0 is the block's pair
+    for (uint32_t i = tid; i < m; i += kChainThreads) {
+      uint32_t o = s_at[i] >> 8;
+      auto vlong = [&]() {
         uint64_t v = 0;
         for (uint32_t sh = 0; sh < 64; sh += 7) {
-          const uint32_t b = wave::uniform(uint32_t(win[o]));
-          ++o;
+          const uint32_t b = win[o++];
           v |= uint64_t(b & 0x7Fu) << sh;
-          if (!(b & 0x80u)) return v;
+          if (!(b & 0x80u)) break;
         }
-        bad = 1;
         return v;
       };
-      while (o < stop_o && m < left && m < kSkipList && (m == 0 || o + kSkipHead <= lim)) {
-        const uint32_t e0 = o;
-        const uint32_t last = uint32_t(vlong());   // last doc of the block
-        (void)vlong();                             // delta of the next block's pointer
-        if (has_pos) {   // pend_pos, delta of the `.pos` pointer (ReadState :1063-1080)
-          (void)vlong();
-          (void)vlong();
-        }
-        uint32_t s0 = 0, total = 0;   // one size byte per scorer
-        for (uint32_t w = 0; w < seg.wand_count; ++w) {
-          const uint32_t sz = wave::uniform(uint32_t(win[o]));
-          ++o;
-          if (w == 0) s0 = sz;
-          total += sz;
-        }
-        if (bad || o + uint64_t(total) > room) { bad = 1; break; }
-        if (o + total > lim) {   // the payloads end behind the window: the next one starts here
-          o = e0;                // (the first entry of a window always fits: 4136 bytes at most)
-          break;
-        }
-        uint32_t f = 0xFFFFFFFFu, nrm = 0;   // (a frequency is never 2^32 - 1: "no payload")
-        if (s0) {
-          const uint32_t payload = o;
-          f = uint32_t(vlong());
-          // (no more bytes: norm == freq — what a frequency-only payload means to a scorer that
-          // wants a norm, "compatibility between BM25 in the index and TFIDF in the query")
-          nrm = (o - payload) != s0 ? f + uint32_t(vlong()) : f;
-          o = payload;
-        }
-        const bool here = lane == (m & 63u);
-        my_last = here ? last : my_last;
-        my_f = here ? f : my_f;
-        my_nrm = here ? nrm : my_nrm;
-        o += total;
-        ++m;
-        if ((m & 63u) == 0) {
-          s_last[wv][m - 64u + lane] = my_last;
-          s_f[wv][m - 64u + lane] = my_f;
-          s_nrm[wv][m - 64u + lane] = my_nrm;
-        }
-      }
-      if (lane < (m & 63u)) {
-        s_last[wv][(m & ~63u) + lane] = my_last;
-        s_f[wv][(m & ~63u) + lane] = my_f;
-        s_nrm[wv][(m & ~63u) + lane] = my_nrm;
-      }
-      cur = win_lo + o;
-    }
-    wave::sync();   // the lists are complete
-    // the entries against the directory: a last doc that is not the block's means the entries
-    // are framed differently from what this walk assumes (the caller then keeps the derived pairs)
-    bool off = false;
-    for (uint32_t i = lane; i < m; i += 64u) {
+      const uint32_t last = uint32_t(vlong());
+      for (uint32_t f = 1; f < vlongs; ++f) (void)vlong();   // pointer delta [, pend_pos, pos pointer delta]
+      const uint32_t s0 = seg.wand_count ? win[o] : 0u;
+      o += seg.wand_count;
       const uint64_t e = t.dir_off + n + i;
-      if (s_last[wv][i] != seg.blk_last[e]) {
-        off = true;
-      } else if (s_f[wv][i] != 0xFFFFFFFFu) {
-        blk_maxf[e] = s_f[wv][i];
-        blk_minn[e] = s_nrm[wv][i];
+      if (last != seg.blk_last[e]) {
+        s_flag = 1;
+      } else if (s0) {
+        const uint32_t payload = o;
+        const uint32_t f = uint32_t(vlong());
+        // (no more bytes: norm == freq — what a frequency-only payload means to a scorer that
+        // wants a norm, "compatibility between BM25 in the index and TFIDF in the query")
+        const uint32_t nrm = (o - payload) != s0 ? f + uint32_t(vlong()) : f;
+        blk_maxf[e] = f;
+        blk_minn[e] = nrm;
       }
     }
-    if (wave::ballot(off) != 0) { framing = 1; break; }   // (before `bad`: a walk that is off
-    if (bad) break;                                        //  the framing may run into anything)
+    __syncthreads();
+    if (s_flag) { framing = 1; break; }   // (before `bad`: a walk that is off the framing may
+    if (bad) break;                       //  run into anything)
     n += m;
-    if (m == 0) break;   // (cannot happen: the first entry of a window is always taken or refused)
-    wave::sync();   // the window and the lists are rewritten next
+    cur = win_lo + next;
+    if (m == 0) break;   // (an entry that does not fit a window of its own: not from a writer)
+    __syncthreads();     // the window and the lists are rewritten next
   }
-  if (lane == 0) {
+  if (tid == 0) {
     if (framing) atomicOr(status, kStatusWandFraming);
     else if (bad) atomicOr(status, kStatusCorrupt);
     else if (n) atomicAdd(taken, static_cast<unsigned long long>(n));

@@ -480,7 +480,7 @@ int build_directory(irs_hip_segment* s) {
   const uint32_t grid = s->dev.num_terms;   // a workgroup per term
   if (!rt::dmemset(s->d_status.p, 0, 4, nullptr)) return IRS_HIP_EHIP;
   if (grid) {
-    RT_LAUNCH((k_build_directory<LAYOUT>), grid, kThreads, 0, nullptr, s->dev,
+    RT_LAUNCH((k_build_directory<LAYOUT>), grid, kChainThreads, 0, nullptr, s->dev,
               s->d_terms.as<DevTerm>(), s->d_blk_off.as<uint32_t>(),
               s->d_blk_last.as<uint32_t>(), s->d_blk_bits.as<uint16_t>(),
               s->d_blk_aoff.as<uint32_t>(), s->d_blk_dir.as<BlkDir>(),
@@ -529,7 +529,7 @@ int build_positions(irs_hip_segment* s, const std::vector<uint64_t>& pos_end) {
     // kernels past their buffers: refuse the segment (IRS_HIP_ECORRUPT)
     RT_LAUNCH(k_check_freq_totals, (s->dev.num_terms + kThreads - 1) / kThreads, kThreads, 0,
               nullptr, s->dev, s->d_pterms.as<DevPosTerm>(), s->d_status.as<uint32_t>());
-    RT_LAUNCH(k_pos_directory, grid, kThreads, 0, nullptr, s->dev, s->d_pterms.as<DevPosTerm>(),
+    RT_LAUNCH(k_pos_directory, s->dev.num_terms, kChainThreads, 0, nullptr, s->dev, s->d_pterms.as<DevPosTerm>(),
               s->d_pblk_off.as<uint32_t>(), s->d_pblk_bits.as<uint8_t>(),
               s->d_ptail.as<uint32_t>(), d_pos_end.as<uint64_t>(), s->d_status.as<uint32_t>());
   }
@@ -905,7 +905,7 @@ int prepare_blockmax(irs_hip_segment* s) {
       if (!rt::h2d(d_at.p, s->skip_at.data(), s->skip_at.size() * 8, nullptr) ||
           !rt::dmemset(d_taken.p, 0, 8, nullptr) || !rt::dmemset(s->d_status.p, 0, 4, nullptr))
         return IRS_HIP_EHIP;
-      RT_LAUNCH(k_wand_skip0, (s->dev.num_terms + kWaves - 1) / kWaves, kThreads, 0, nullptr,
+      RT_LAUNCH(k_wand_skip0, s->dev.num_terms, kChainThreads, 0, nullptr,
                 s->dev, d_at.as<uint64_t>(), s->has_pos ? 1u : 0u, s->d_blk_maxf.as<uint32_t>(),
                 s->d_blk_minn.as<uint32_t>(), d_taken.as<unsigned long long>(),
                 s->d_status.as<uint32_t>());

@@ -42,108 +42,139 @@ __device__ __forceinline__ bool pk_both(uint32_t dbits, uint32_t fbits) {
   return (dbits - 1u) <= 30u && (fbits - 1u) <= 30u;
 }
 
-// ---- the header chain, speculatively -------------------------------------------------------
+// ---- the header chain, by pointer doubling ---------------------------------------------------
 // Block headers of the 1_x formats form a chain: the header byte `bits` at p is followed by
-// 16 * bits payload bytes (1..32) or, for ALL_EQUAL (0), by one vint (bitpack.hpp:60-69, 159).
-// The headers behind p therefore lie at p + a + 16 * S: a = header / value bytes passed, S = bit
-// widths passed.  A wavefront reads every candidate at once — register a, lane S <- the byte at
-// p + a + 16 * S, kSpecBytes LDS reads in flight — and then follows the chain through
-// v_readlane_b32 with the running S as the lane: a few scalar cycles per header where a walk
-// by dependent LDS reads pays the LDS latency (and, run by one lane under exec masks, some
-// 500 cycles) per header.  Everything here is wave-uniform: all lanes run it, the compiler
-// keeps the state in scalar registers.
-constexpr uint32_t kSpecBytes = 8;     // registers of candidates = header / value bytes per round
-constexpr uint32_t kSpecSpan = 2048;   // a round reads up to p + 7 + 16 * 63, its blocks end
-                                       // before p + 8 + 16 * (63 + 32): rounded up
+// 16 * bits payload bytes (1..32) or, for ALL_EQUAL (0), by one vint (bitpack.hpp:60-69, 159), and
+// the next header by that.  Followed step by step the chain costs a dependent LDS read — and, for
+// a lone wavefront, some hundred instruction issues — per header, and the longest list of the
+// segment sets the duration of the kernel.  Here the chain is data parallel: for EVERY byte p of
+// the window f[p] = "where the next header lies if p is one"; composing the table with itself
+// gives f^2, f^4, ... (all 256 threads, a window's table in a few passes), and the orbit of the
+// start doubles with it: pos[i + 2^k] = f^(2^k)[pos[i]].  log2(headers in the window) rounds.
+constexpr uint32_t kChainThreads = 1024;           // 16 wavefronts: a workgroup of a long list has its
+                                                   // CU to itself — one wavefront per SIMD issues an
+                                                   // instruction every 10-14 cycles, four hide each other
+constexpr uint32_t kChainWindow = 8192;            // bytes of the stream staged per window
+constexpr uint32_t kChainCap = 1024;               // chain links listed per window at most
+constexpr uint32_t kChainEnd = kChainWindow + 1;   // "the block does not end inside the window"
+constexpr uint32_t kChainBad = kChainWindow + 2;   // malformed: bits > 32, or past the end of the file
+constexpr uint32_t kLinkNone = 0xFFFFFFFEu;        // a link function's verdicts: nothing starts here
+constexpr uint32_t kLinkBad = 0xFFFFFFFFu;         //   / malformed
+struct ChainTables {
+  uint16_t f[2][kChainWindow + 4];   // [0, kChainWindow]: positions (kChainWindow = the byte
+                                     // behind a full window); then the two sentinels
+  uint16_t pos[2 * kChainCap + 2];   // the orbit of the start
+  uint32_t n;
+};
+struct alignas(16) ChainLine {
+  uint64_t lo, hi;
+};
 
-// The headers a walk lists, (offset in the window << 8) | bits: entry base + i waits in lane i
-// of `rec` (v_writelane_b32) until the register is spilled to the list in LDS.
-struct HeaderList {
-  uint32_t* list;
-  uint32_t base;   // entries in the list (wave-uniform)
-  uint32_t cnt;    // entries in `rec`
-  uint32_t rec;
-  __device__ __forceinline__ uint32_t n() const { return base + cnt; }
-  __device__ __forceinline__ void spill(unsigned lane) {
-    if (lane < cnt) list[base + lane] = rec;
-    base += cnt;
-    cnt = 0;
+// LEB128 read one byte at a time (safe for LDS and for unaligned global bytes).
+__device__ __forceinline__ uint32_t vint_bytes(const uint8_t* p, uint32_t* len) {
+  uint32_t v = 0, n = 0, shift = 0;
+  for (;;) {
+    const uint32_t b = p[n++];
+    v |= (b & 0x7Fu) << shift;
+    if (!(b & 0x80u) || n == 5) break;
+    shift += 7;
   }
-  __device__ __forceinline__ void push(uint32_t r, unsigned lane) {
-    if (cnt == 64u) spill(lane);   // (a round may leave the register exactly full)
-    rec = wave::write_lane(rec, r, cnt);
-    ++cnt;
+  *len = n;
+  return v;
+}
+
+// The link of the block streams: a header byte and what it stands in front of.
+struct block_link {
+  const uint8_t* win;
+  __device__ __forceinline__ uint32_t operator()(uint32_t p) const {
+    const uint32_t bits = win[p];
+    if (bits > 32u) return kLinkBad;
+    if (bits) return p + 1u + 16u * bits;
+    uint32_t len;
+    (void)vint_bytes(win + p + 1, &len);
+    return p + 1u + len;
   }
 };
 
-// One round from window offset `o`: lists up to kSpecBytes headers and moves `o` behind the last
-// block taken.  The caller guarantees that o + kSpecSpan bytes of the window lie inside the
-// file (a listed block cannot run past its end), that kSpecBytes headers are still to come and
-// that `rec` has room for them.  bad: a header above 32.  slow: the next header is an ALL_EQUAL
-// block whose value takes more than one byte — the caller reads that block byte by byte.
-// Per header: v_readlane (candidate: position << 8 | byte), two range tests, v_writelane, two
-// adds — about a dozen scalar instructions.
-#define IRS_SPEC_HOP(A, SKIP)                                                        \
-  {                                                                                  \
-    const uint32_t t = wave::read_lane(T[A], S);                                     \
-    const uint32_t v = t & 0xFFu;                                                    \
-    if (__builtin_expect(v - 1u > 31u, 0)) {                                         \
-      o = t >> 8; /* (where the next walk starts unless the block is taken) */       \
-      if (v != 0) { bad = 1; goto done; }                                            \
-      if ((A) + 1u == kSpecBytes) goto done;                                         \
-      if (wave::read_lane(T[((A) + 1u) % kSpecBytes], S) & 0x80u) {                  \
-        slow = 1;                                                                    \
-        goto done;                                                                   \
-      }                                                                              \
-      h.rec = wave::write_lane(h.rec, t, h.cnt);                                     \
-      ++h.cnt;                                                                       \
-      o += 2u;                                                                       \
-      goto SKIP;                                                                     \
-    }                                                                                \
-    h.rec = wave::write_lane(h.rec, t, h.cnt);                                       \
-    ++h.cnt;                                                                         \
-    S += v;                                                                          \
-    o = (t >> 8) + 1u + 16u * v;                                                     \
-    if (S > 63u) goto done;                                                          \
-  }
-
-__device__ __forceinline__ void spec_round(const uint8_t* win, uint32_t& o, HeaderList& h,
-                                           unsigned lane, uint32_t& bad, uint32_t& slow) {
-  const uint64_t w = wave::load_u64(win + o + 16u * lane);
-  const uint32_t at = (o + 16u * lane) << 8;
-  uint32_t T[kSpecBytes];
+// All kChainThreads threads of a workgroup.  win[0, lim) holds the stream from a 16-byte boundary
+// (readable 64 bytes further), `room` bytes of it lie inside the file; the walk starts at
+// `start` < lim and wants `want` (1..kChainCap) more headers.  Returns n = the headers whose
+// blocks END inside the window and the file, hdr[i] = (offset << 8) | bits for i < n, and
+// *next = the offset the walk goes on from.  *bad: a header above 32 or a block past the end of
+// the file was met right behind the n-th header.  Ends with a barrier.
+// `link(p)` = where the next link lies if one starts at p (or kLinkBad / kLinkNone); block_link below is the
+// block headers', k_wand_skip0 has the skip entries'.
+template<typename LINK>
+__device__ inline uint32_t chain_orbit(const uint8_t* win, ChainTables& T, uint32_t start,
+                                       uint32_t lim, uint64_t room, uint32_t want, uint32_t* hdr,
+                                       uint32_t* next, uint32_t* bad, LINK link) {
+  const uint32_t tid = threadIdx.x;
+  const uint32_t limit = room < lim ? uint32_t(room) : lim;
+  const bool inside = lim <= room;   // the file goes on behind the window
+  // f^1; the entries behind the staged bytes and the sentinels are fixed points of every power
+  for (uint32_t p0 = tid; p0 <= kChainBad; p0 += 8u * kChainThreads) {
 #pragma unroll
-  for (uint32_t a = 0; a < kSpecBytes; ++a)
-    T[a] = (uint32_t(w >> (8u * a)) & 0xFFu) | (at + (a << 8));
-  uint32_t S = 0;
-  h.cnt = wave::uniform(h.cnt);
-  IRS_SPEC_HOP(0u, hop2)
-  IRS_SPEC_HOP(1u, hop3)
-hop2:
-  IRS_SPEC_HOP(2u, hop4)
-hop3:
-  IRS_SPEC_HOP(3u, hop5)
-hop4:
-  IRS_SPEC_HOP(4u, hop6)
-hop5:
-  IRS_SPEC_HOP(5u, hop7)
-hop6:
-  IRS_SPEC_HOP(6u, done)
-hop7:
-  IRS_SPEC_HOP(7u, done)
-done:
-  return;
-}
-#undef IRS_SPEC_HOP
-
-// LEB128 length at a wave-uniform LDS address, byte by byte (the careful path)
-__device__ __forceinline__ uint32_t vint_len_uniform(const uint8_t* p) {
-  uint32_t n = 0;
-  for (;;) {
-    const uint32_t b = wave::uniform(uint32_t(p[n]));
-    ++n;
-    if (!(b & 0x80u) || n == 5) break;
+    for (uint32_t k = 0; k < 8; ++k) {
+      const uint32_t p = p0 + k * kChainThreads;
+      if (p > kChainBad) continue;
+      uint32_t v = p == kChainBad ? kChainBad : kChainEnd;
+      if (p < lim) {
+        const uint32_t nxt = link(p);
+        v = nxt == kLinkBad ? kChainBad : nxt == kLinkNone ? kChainEnd
+            : nxt <= limit ? nxt : inside ? kChainEnd : kChainBad;
+      }
+      T.f[0][p] = uint16_t(v);
+      if (p >= lim) T.f[1][p] = uint16_t(v);
+    }
   }
+  if (tid == 0) {
+    T.pos[0] = uint16_t(start);
+    T.n = 0;
+  }
+  __syncthreads();
+  uint32_t cur = 0, have = 1;   // pos[0, have) is known, f[cur] = f^have
+  while (have <= want) {
+    const uint16_t* f = T.f[cur];
+    for (uint32_t i = tid; i < have; i += kChainThreads) T.pos[i + have] = f[T.pos[i]];
+    uint16_t* g = T.f[cur ^ 1u];
+    // (eight entries a thread at a time: the two dependent reads of each overlap with the others'
+    // — a workgroup of a long list has its SIMDs to itself, nothing else hides the LDS latency)
+    for (uint32_t p0 = tid; p0 < lim; p0 += 8u * kChainThreads) {
+      uint32_t a[8];
+#pragma unroll
+      for (uint32_t k = 0; k < 8; ++k) {
+        const uint32_t p = p0 + k * kChainThreads;
+        a[k] = f[p < lim ? p : kChainEnd];
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < 8; ++k) a[k] = f[a[k]];
+#pragma unroll
+      for (uint32_t k = 0; k < 8; ++k) {
+        const uint32_t p = p0 + k * kChainThreads;
+        if (p < lim) g[p] = uint16_t(a[k]);
+      }
+    }
+    __syncthreads();
+    cur ^= 1u;
+    have *= 2u;
+    if (T.pos[have - 1u] > kChainWindow) break;   // the orbit has left the window
+  }
+  // header i is taken iff its block ends inside: pos[i + 1] is a position (a prefix of the orbit)
+  const uint32_t known = have - 1u < want ? have - 1u : want;
+  uint32_t mine = 0;
+  for (uint32_t i = tid; i < known; i += kChainThreads) {
+    const uint32_t at = T.pos[i];
+    if (T.pos[i + 1u] <= kChainWindow) {
+      hdr[i] = (at << 8) | win[at];
+      ++mine;
+    }
+  }
+  mine = wave::reduce_add(mine);
+  if ((tid & 63u) == 0 && mine) atomicAdd(&T.n, mine);
+  __syncthreads();
+  const uint32_t n = T.n;
+  *next = T.pos[n];
+  *bad = n < want && T.pos[n + 1u] == kChainBad ? 1u : 0u;
   return n;
 }
 
@@ -153,23 +184,24 @@ __device__ __forceinline__ uint32_t vint_len_uniform(const uint8_t* p) {
 // Only the header chain is serial (header -> size -> next header), and the longest list of the
 // segment sets the kernel's duration (10 M docs: 78 k blocks), so per window of kDirWindow
 // bytes staged in LDS
-//   1. wavefront 0 follows the chain (spec_round above) and lists (offset, bit width) per header;
+//   1. all threads list the window's headers (chain_orbit above): (offset, bit width) each;
 //   2. the four wavefronts decode the listed blocks' delta sums side by side;
 //   3. wavefront 0 turns the sums into last docs (a scan), everyone writes the rows coalesced.
 // Round 4 did all of it inside the chain, one wavefront per term: 0.89 us per block, 69.5 ms.
-constexpr uint32_t kDirWindow = 8192;
+constexpr uint32_t kDirWindow = kChainWindow;
 constexpr uint32_t kDirList = 256;     // blocks listed per window at most (2 headers each)
 struct alignas(16) DirLine {
   uint64_t lo, hi;
 };
 
 template<int LAYOUT>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kChainThreads)
 k_build_directory(DevSegment seg, DevTerm* terms, uint32_t* blk_off,
                   uint32_t* blk_last, uint16_t* blk_bits, uint32_t* blk_units, BlkDir* blk_dir,
                   uint32_t* blk_term, uint32_t* tail_docs, uint32_t* tail_freqs, uint32_t* status) {
   // (+64: the unpackers read whole 8-byte words, up to 24 bytes past a payload's end)
   __shared__ __attribute__((aligned(16))) uint8_t win[kDirWindow + 64];
+  __shared__ ChainTables s_chain;
   __shared__ __attribute__((aligned(16))) uint32_t s_sum[kDirList];   // delta sums, then last docs
   __shared__ uint32_t s_tf[kDirList];    // the block's frequency bound
   __shared__ uint32_t s_hdr[2 * kDirList];   // headers: (offset in the window << 8) | bits
@@ -204,51 +236,35 @@ k_build_directory(DevSegment seg, DevTerm* terms, uint32_t* blk_off,
     uint64_t bytes = staged - win_lo;
     if (bytes > kDirWindow) bytes = kDirWindow;
     bytes &= ~uint64_t(15);
-    for (uint32_t o = tid * 16u; o < bytes; o += kThreads * 16u)
+    for (uint32_t o = tid * 16u; o < bytes; o += kChainThreads * 16u)
       *reinterpret_cast<DirLine*>(win + o) = *reinterpret_cast<const DirLine*>(seg.doc + win_lo + o);
     __syncthreads();
     const uint32_t per = seg.has_freq ? 2u : 1u;   // headers per block
-    if (wv == 0) {
-      // 1. the chain.  Rounds of up to kSpecBytes headers while kSpecSpan bytes of the file lie
-      // ahead in the window; near the end of the file header by header with every bound checked.
-      HeaderList h{s_hdr, 0u, 0u, 0u};
-      uint32_t o = wave::uniform(uint32_t(cur - win_lo)), wbad = 0, slow = 0;
-      const uint32_t lim = wave::uniform(uint32_t(bytes));
-      const uint64_t room64 = seg.doc_len - win_lo;   // bytes of the file from the window's start
-      const uint32_t room = wave::uniform(room64 < lim ? uint32_t(room64) : lim);
-      const bool more = lim == kDirWindow;            // the staged file goes on behind the window
-      const uint32_t left = wave::uniform((t.nblk - b) * per);
-      while (h.n() < left && h.n() + kSpecBytes <= per * kDirList && !wbad) {
-        if (!slow && o + kSpecSpan <= room && h.n() + kSpecBytes <= left) {
-          if (h.cnt > 64u - kSpecBytes) h.spill(lane);
-          spec_round(win, o, h, lane, wbad, slow);
-          continue;
-        }
-        if (!slow && more && o + kSpecSpan > room) break;   // the next window starts here
-        const uint64_t at = win_lo + o;
-        if (at + 2 > seg.doc_len) { wbad = 1; break; }
-        const uint32_t bits = wave::uniform(uint32_t(win[o]));
-        if (bits > 32 || at + 1 + 16ull * bits > seg.doc_len) { wbad = 1; break; }
-        h.push((o << 8) | bits, lane);
-        o += bits ? 1u + 16u * bits : 1u + vint_len_uniform(win + o + 1);
-        slow = 0;
+    {
+      // 1. the chain: the headers whose blocks end inside the window (and the file)
+      const uint32_t left = (t.nblk - b) * per;
+      const uint32_t cap = per * kDirList;
+      uint32_t next, wbad;
+      uint32_t nh = chain_orbit(win, s_chain, uint32_t(cur - win_lo), uint32_t(bytes),
+                                seg.doc_len - win_lo, left < cap ? left : cap, s_hdr, &next, &wbad,
+                                block_link{win});
+      if (per == 2u && (nh & 1u)) {   // a doc header without its freq header: the next window's
+        --nh;
+        next = s_hdr[nh] >> 8;
+        wbad = 0;   // (what lies behind the freq header is that window's to judge)
       }
-      h.spill(lane);
-      wave::sync();
-      if (per == 2u && (h.base & 1u)) {   // a doc header without its freq header: the next window's
-        --h.base;
-        o = s_hdr[h.base] >> 8;
-      }
-      if (lane == 0) {
-        s_n = h.base / per;
+      // a window from `cur` holds at least one whole block of a valid list (<= 1026 bytes)
+      if (nh == 0) wbad = 1;
+      if (tid == 0) {
+        s_n = nh / per;
         s_bad = wbad;
-        s_cur = win_lo + o;
+        s_cur = win_lo + next;
       }
     }
     __syncthreads();
     const uint32_t n = s_n;
     // 2. delta sums and frequency bounds of the listed blocks, a wavefront per block
-    for (uint32_t i = wv; i < n; i += kWaves) {
+    for (uint32_t i = wv; i < n; i += kChainThreads / 64u) {
       const uint32_t dh = s_hdr[per * i];
       const uint32_t dbits = dh & 0xFFu;
       uint32_t x0, x1;
@@ -310,7 +326,7 @@ k_build_directory(DevSegment seg, DevTerm* terms, uint32_t* blk_off,
       }
     }
     __syncthreads();
-    for (uint32_t i = tid; i < n; i += kThreads) {
+    for (uint32_t i = tid; i < n; i += kChainThreads) {
       const uint64_t e = t.dir_off + b + i;
       const uint32_t dh = s_hdr[per * i];
       const uint32_t dbits = dh & 0xFFu, fbits = seg.has_freq ? s_hdr[per * i + 1u] & 0xFFu : 0u;
@@ -494,19 +510,6 @@ k_pack_payloads(DevSegment seg, uint64_t rows, uint8_t* pk) {
       dst[i] = wave::load_u64(src);
     }
   }
-}
-
-// LEB128 read one byte at a time (safe for LDS and for unaligned global bytes).
-__device__ __forceinline__ uint32_t vint_bytes(const uint8_t* p, uint32_t* len) {
-  uint32_t v = 0, n = 0, shift = 0;
-  for (;;) {
-    const uint32_t b = p[n++];
-    v |= (b & 0x7Fu) << shift;
-    if (!(b & 0x80u) || n == 5) break;
-    shift += 7;
-  }
-  *len = n;
-  return v;
 }
 
 // One-lane sequential decode of a vint tail

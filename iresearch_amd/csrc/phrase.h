@@ -157,86 +157,59 @@ k_check_freq_totals(DevSegment seg, const DevPosTerm* pterms, uint32_t* status) 
   if (sum != pterms[term].total) atomicOr(status, kStatusCorrupt);
 }
 
-// One wavefront per term walks the term's pos blocks (header byte -> size,
-// bitpack::skip_block32) and decodes the vint tail (read_tail_block :1515-1537).  The walk
-// is a chain of dependent one-byte reads, so the stream is staged through LDS 8 KB at a
-// time: all 64 lanes copy, the wavefront follows the chain speculatively (spec_round,
-// kernels.h) and lists the headers, all lanes write the directory rows.  The 10 M-doc
-// segment's longest term has 540 k pos blocks.
-constexpr uint32_t kWalkWindow = 8192;
-constexpr uint32_t kWalkList = 512;   // blocks listed per window at most
-struct alignas(16) Bytes16 {
-  uint64_t lo, hi;
-};
-
-__global__ void __launch_bounds__(kThreads)
+// One workgroup per term lists the term's pos blocks (header byte -> size,
+// bitpack::skip_block32) and decodes the vint tail (read_tail_block :1515-1537).  The headers
+// form a chain of dependent one-byte reads; the stream is staged through LDS 8 KB at a time
+// and the chain of a window is followed by pointer doubling (chain_orbit, kernels.h), all
+// threads write the directory rows.  The 10 M-doc segment's longest term has 540 k pos blocks.
+__global__ void __launch_bounds__(kChainThreads)
 k_pos_directory(DevSegment seg, DevPosTerm* pterms, uint32_t* pblk_off, uint8_t* pblk_bits,
                 uint32_t* ptail, const uint64_t* pos_end, uint32_t* status) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_win[kWaves][kWalkWindow];
-  __shared__ uint32_t s_hdr[kWaves][kWalkList];   // (offset in the window << 8) | bits
-  const unsigned lane = threadIdx.x & 63u;
-  const uint32_t wv = threadIdx.x >> 6;
-  const uint32_t term = blockIdx.x * kWaves + wv;
+  __shared__ __attribute__((aligned(16))) uint8_t win[kChainWindow + 64];
+  __shared__ ChainTables s_chain;
+  __shared__ uint32_t s_hdr[kChainCap];   // (offset in the window << 8) | bits
+  __shared__ uint64_t s_cur;
+  __shared__ uint32_t s_bad;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t term = blockIdx.x;
   if (term >= seg.num_terms) return;
   const DevPosTerm pt = pterms[term];
   if (pt.total == 0) return;
-  uint8_t* win = s_win[wv];
   const uint64_t staged = seg.pos_len + kPadBytes;  // the device copy ends with zero padding
-  uint64_t cur = pt.pos_start, win_lo = 0, win_hi = 0;
-  uint32_t b = 0;
-  uint32_t bad = 0;
-  // window [win_lo, win_hi) of the stream, starting at the 16-byte line holding `at`
+  uint64_t cur = pt.pos_start, win_lo = 0;
+  uint32_t b = 0, bad = 0, lim = 0;
+  // window [win_lo, win_lo + lim) of the stream, starting at the 16-byte line holding `at`
   auto refill = [&](uint64_t at) {
     win_lo = at & ~uint64_t(15);
     uint64_t bytes = staged - win_lo;
-    if (bytes > kWalkWindow) bytes = kWalkWindow;
+    if (bytes > kChainWindow) bytes = kChainWindow;
     bytes &= ~uint64_t(15);
-    for (uint32_t o = lane * 16u; o < bytes; o += 64u * 16u)
-      *reinterpret_cast<Bytes16*>(win + o) =
-        *reinterpret_cast<const Bytes16*>(seg.pos + win_lo + o);
-    win_hi = win_lo + bytes;
-    wave::sync();
+    for (uint32_t o = tid * 16u; o < bytes; o += kChainThreads * 16u)
+      *reinterpret_cast<ChainLine*>(win + o) =
+        *reinterpret_cast<const ChainLine*>(seg.pos + win_lo + o);
+    lim = uint32_t(bytes);
+    __syncthreads();
   };
-  uint32_t* l_hdr = s_hdr[wv];
   while (b < pt.nfull && !bad) {
     if (cur + 8 > seg.pos_len) { bad = 1; break; }
     refill(cur);
-    // the chain (spec_round, kernels.h): rounds of up to kSpecBytes headers while kSpecSpan
-    // bytes of the file lie ahead in the window, block by block near the end of the file
-    HeaderList h{l_hdr, 0u, 0u, 0u};
-    uint32_t o = wave::uniform(uint32_t(cur - win_lo)), slow = 0;
-    const uint32_t lim = wave::uniform(uint32_t(win_hi - win_lo));
-    const uint64_t room64 = seg.pos_len - win_lo;   // bytes of the file from the window's start
-    const uint32_t room = wave::uniform(room64 < lim ? uint32_t(room64) : lim);
-    const bool more = lim == kWalkWindow;           // the staged file goes on behind the window
-    const uint32_t left = wave::uniform(pt.nfull - b);
-    while (h.n() < left && h.n() + kSpecBytes <= kWalkList && !bad) {
-      if (!slow && o + kSpecSpan <= room && h.n() + kSpecBytes <= left) {
-        if (h.cnt > 64u - kSpecBytes) h.spill(lane);
-        spec_round(win, o, h, lane, bad, slow);
-        continue;
-      }
-      if ((!slow && more && o + kSpecSpan > room) || o + 6 > lim) break;   // the next window starts here
-      const uint32_t bits = wave::uniform(uint32_t(win[o]));
-      const uint32_t size = bits ? 1u + 16u * bits : 1u + vint_len_uniform(win + o + 1);
-      if (bits > 32 || o + size > room64) { bad = 1; break; }
-      h.push((o << 8) | bits, lane);
-      o += size;
-      slow = 0;
-    }
-    h.spill(lane);
-    cur = win_lo + o;
-    const uint32_t n = h.base;
-    wave::sync();  // the list is complete
+    const uint32_t left = pt.nfull - b;
+    uint32_t next;
+    const uint32_t n = chain_orbit(win, s_chain, uint32_t(cur - win_lo), lim, seg.pos_len - win_lo,
+                                   left < kChainCap ? left : kChainCap, s_hdr, &next, &bad,
+                                   block_link{win});
+    // a window from `cur` holds at least one whole block of a valid stream (<= 513 bytes)
+    if (n == 0) bad = 1;
     // (offsets are kept in 32 bits: a term's positions beyond 4 GB are refused)
-    if (n && win_lo + (l_hdr[n - 1] >> 8) - pt.pos_start > 0xFFFFFFFFull) bad = 1;
-    for (uint32_t i = lane; i < n && !bad; i += 64u) {
-      const uint32_t rec = l_hdr[i];
+    if (n && win_lo + (s_hdr[n - 1] >> 8) - pt.pos_start > 0xFFFFFFFFull) bad = 1;
+    for (uint32_t i = tid; i < n && !bad; i += kChainThreads) {
+      const uint32_t rec = s_hdr[i];
       pblk_off[pt.row + b + i] = uint32_t(win_lo + (rec >> 8) - pt.pos_start);
       pblk_bits[pt.row + b + i] = uint8_t(rec);
     }
     b += n;
-    wave::sync();  // the window and the list are rewritten next
+    cur = win_lo + next;
+    __syncthreads();  // the window and the list are rewritten next
   }
   // where the writer says the tail starts (EndTerm :719-722; reader :2270-2278)
   if (!bad && pt.total > kBlock && pos_end[term] != cur - pt.pos_start) bad = 1;
@@ -245,21 +218,25 @@ k_pos_directory(DevSegment seg, DevPosTerm* pterms, uint32_t* pblk_off, uint8_t*
       bad = 1;
     } else {
       refill(cur);  // at most 127 vints of <= 5 bytes
-      if (lane == 0) {
+      if (tid == 0) {
+        uint64_t c = cur;
+        uint32_t tb = 0;
         for (uint32_t i = 0; i < pt.tail_n; ++i) {
-          if (cur + 1 > seg.pos_len) { bad = 1; break; }
+          if (c + 1 > seg.pos_len) { tb = 1; break; }
           uint32_t len;
-          ptail[pt.tail_row + i] = vint_bytes(win + (cur - win_lo), &len);
-          cur += len;
+          ptail[pt.tail_row + i] = vint_bytes(win + (c - win_lo), &len);
+          c += len;
         }
-        if (cur > seg.pos_len) bad = 1;
+        if (c > seg.pos_len) tb = 1;
+        s_cur = c;
+        s_bad = tb;
       }
-      bad = wave::bcast(bad, 0);
-      const uint32_t lo = wave::bcast(uint32_t(cur), 0), hi = wave::bcast(uint32_t(cur >> 32), 0);
-      cur = (uint64_t(hi) << 32) | lo;
+      __syncthreads();
+      cur = s_cur;
+      bad = s_bad;
     }
   }
-  if (lane == 0) {
+  if (tid == 0) {
     pterms[term].bytes = uint32_t(cur - pt.pos_start);
     if (bad) atomicOr(status, kStatusCorrupt);
   }

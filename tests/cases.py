@@ -1036,11 +1036,11 @@ def case_min_score_pushdown(L):
 
 
 def case_header_chain(L, layout, n_docs=120_000):
-    """The directory kernels follow the chain of block headers speculatively (spec_round,
-    kernels.h): lists long enough for many LDS windows whose headers take every path —
-    ALL_EQUAL runs with a one-byte value (the fast path's value byte), with a two-byte value
-    (handed to the careful path), packed blocks from 1 to 32 bits (a round ends when the widths
-    passed exceed the 64 lanes), mixed — for `.doc` with and without frequencies and for `.pos`.
+    """The directory kernels follow the chain of block headers window by window (chain_orbit,
+    kernels.h: pointer doubling over "the next header if one starts here"): lists long enough for
+    many LDS windows whose headers take every path — ALL_EQUAL runs with a one-byte value and
+    with a two-byte value, packed blocks from 1 to 32 bits, more headers in a window than one
+    link list holds, mixed — for `.doc` with and without frequencies and for `.pos`.
     Checked through the decoders and the directory against the lists and the oracle."""
     rng = np.random.default_rng(23)
     N = n_docs
