@@ -48,7 +48,7 @@ for stage in "$@"; do
     bench) py $R/bench.py --gpus 1 --steps ${STEPS:-20} --warmup 5 > $O/${TAG}_bench_plain.json 2> $O/${TAG}_bench_plain.err; line $O/${TAG}_bench_plain.json ;;
     quick) py $R/bench.py --steps ${STEPS:-10} --warmup 3 --no-cpu ${BENCH_ARGS} > $O/${TAG}_bench_quick.json 2> $O/${TAG}_bench_quick.err; line $O/${TAG}_bench_quick.json ;;
     stats) rocprofv3 --kernel-trace --stats -d $O/${TAG}_stats -o $TAG --output-format csv -- \
-             python $R/bench.py --steps 5 --warmup 1 --no-cpu > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; line $O/${TAG}_bench.json ;;
+             python $R/bench.py --steps 5 --warmup 3 --no-cpu > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; line $O/${TAG}_bench.json ;;
     pmc) i=0; for grp in "${pmc_groups[@]}"; do i=$((i+1))
            rocprofv3 --pmc $grp -d $O/${TAG}_pmc_$i -o p --output-format csv -- \
              python $R/bench.py --steps 2 --warmup 1 --no-cpu > $O/${TAG}_pmc_$i.log 2>&1; echo "group $i rc=$?"; done ;;
