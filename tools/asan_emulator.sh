@@ -20,6 +20,7 @@ L = _lib.bind(C.CDLL(sys.argv[1]))
 for layout in (1, 0):
     cases.case_decode_positions(L, layout)
     cases.case_decode_sizes(L, layout)
+    cases.case_header_chain(L, layout, 40_000)
     cases.case_bit_union(L, layout)
     cases.case_queries_ragged(L, layout)
     cases.case_phrase_reference_vectors(L, layout)
