@@ -875,7 +875,8 @@ def main_tasks(args):
     rows = []
     print("# %s, %d docs, ranks 1..%d, top-%d, %d distinct queries per class and step, CPU: %d threads (%s)" % (
         args.scorer, args.docs, max_rank, k, nq, cores, "-O3 -march=native" if native else "-O2"))
-    print("# category            terms  ranks of the task's words          hits/query   GPU q/s    CPU q/s   GPU/CPU  parity")
+    print("# category            terms  ranks of the task's words          hits/query   GPU q/s    CPU q/s   GPU/CPU  parity"
+          "           path   ms/step  plan/pilot/score/select ms  postings/step  re-runs (profiled batch + timed steps)")
     for t in tasks.parse_tasks(lines, 1):
         if t.category in tasks.EXPANSION:
             print("%-20s (multi-term expansion filter: not on this path)" % t.category)
@@ -886,32 +887,54 @@ def main_tasks(args):
         filters = [tasks.filter_of(t, r) for r in queries]
         phrase = t.category in tasks.PHRASE
 
-        def make():
-            prep = search.prepare(filters, scorer, st)          # (inside the step, as the harness)
-            return sr.batch(prep, k).run()
+        def make():   # (the filters are prepared inside the step, as the harness does)
+            return sr.batch(search.prepare_filters(filters, scorer, st, [sr], k), k).run()
         # parity of the first queries of the class
         b = make()
         hits, counts, totals = (x.copy() for x in b.results_to_host().host_results())
         b.close()
-        n_par = min(nq, 4 if args.docs > 2_000_000 else 8)
+        n_par = min(nq, 32)
         check = parity.check_phrase_segment if phrase else parity.check_single_segment
         check(seg, filters[:n_par], scorer, k, hits[:n_par], counts[:n_par], totals[:n_par])
+        # where a step of the class goes: one more batch with the kernels timed (HIP events on the
+        # batch's stream), the path it took, re-runs, postings and the host stages in front of it
+        t0 = time.perf_counter()
+        prep = search.prepare_filters(filters, scorer, st, [sr], k)
+        t1 = time.perf_counter()
+        b = sr.batch(prep, k)
+        t2 = time.perf_counter()
+        b.profile(1).run()
+        b.results_to_host().host_results()
+        t3 = time.perf_counter()
+        stage_ms = dict(zip(("plan", "pilot", "score", "select"), b.timings()))
+        diag = {"path": {_lib.PATH_ITEMS: "items", _lib.PATH_JOINED: "joined"}.get(b.path(), "?")
+                        if not phrase else "phrase",
+                "reruns": b.reruns(), "postings_per_step": b.work()[1],
+                "stage_ms": {n: round(v, 3) for n, v in stage_ms.items()},
+                "host_ms": {"prepare": round((t1 - t0) * 1e3, 3), "create": round((t2 - t1) * 1e3, 3),
+                            "run_to_results": round((t3 - t2) * 1e3, 3)}}
+        b.close()
         # GPU: fresh batches, one deep
         steps = max(2, args.steps)
         for timed in (False, True):
             sync()
             t0 = time.perf_counter()
             prev = None
-            for _ in range(steps if timed else 1):
+            reruns = 0
+            # (untimed first: three pipelined steps, so that the pool holds the blocks of two
+            # batches of this class — a first-use hipMalloc / hipHostMalloc costs more than a step)
+            for _ in range(steps if timed else 3):
                 cur = make()
                 if prev is not None:
                     prev.results_to_host().host_results()
+                    reruns += prev.reruns()
                     prev.close()
                 prev = cur
             prev.results_to_host().host_results()
+            reruns += prev.reruns()
             prev.close()
             sync()
-            gpu_dt = (time.perf_counter() - t0) / (steps if timed else 1)
+            gpu_dt = (time.perf_counter() - t0) / (steps if timed else 3)
         # CPU: the same queries (a bounded sample), the threads pop one task queue
         metas = [parity.metas_for(seg, [r - 1 for r in q])[None] for q in queries]
 
@@ -934,11 +957,15 @@ def main_tasks(args):
         cpu_dt = timed_cpu(n_cpu)
         row = {"category": t.category, "terms": len(base), "ranks": base,
                "hits_per_query": float(totals.mean()), "gpu_qps": nq / gpu_dt,
-               "cpu_qps": n_cpu / cpu_dt, "cpu_sample": n_cpu, "parity_checked": n_par}
+               "cpu_qps": n_cpu / cpu_dt, "cpu_sample": n_cpu, "parity_checked": n_par,
+               "ms_per_step": gpu_dt * 1e3, "reruns_in_timed_steps": reruns, **diag}
         rows.append(row)
-        print("%-20s %5d  %-34s %10.0f %10.0f %10.1f %8.0fx  ok (%d queries)" % (
+        sm = diag["stage_ms"]
+        print("%-20s %5d  %-34s %10.0f %10.0f %10.1f %8.0fx  ok (%d queries)  %-6s %7.3f  %5.2f/%5.2f/%5.2f/%5.2f  %6.1f M  %d+%d" % (
             t.category, len(base), str(base if len(base) <= 4 else base[:4] + ["..."]), row["hits_per_query"],
-            row["gpu_qps"], row["cpu_qps"], row["gpu_qps"] / row["cpu_qps"], n_par), flush=True)
+            row["gpu_qps"], row["cpu_qps"], row["gpu_qps"] / row["cpu_qps"], n_par, diag["path"],
+            row["ms_per_step"], sm["plan"], sm["pilot"], sm["score"], sm["select"],
+            diag["postings_per_step"] / 1e6, diag["reruns"], reruns), flush=True)
     print(json.dumps({"tasks": rows, "docs": args.docs, "max_rank": max_rank, "k": k, "queries_per_step": nq,
                       "scorer": args.scorer, "cpu_threads": cores,
                       "data": "synthetic" if not sim else "synthetic (EMULATOR DRY RUN)"}), flush=True)

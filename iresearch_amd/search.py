@@ -341,6 +341,83 @@ def prepare_disjunctions(term_rows, scorer, segment_stats, segs, k, boost=1.0):
     return QueryArrays(len(segs), queries, terms, k)
 
 
+def prepare_filters(filters, scorer, segment_stats, segs, k):
+    """prepare() + QueryArrays.from_prepared for ANY list of the flat filters of this path
+    (by_term, Or, Or with min_match, And, by_phrase — one list may mix the boolean kinds; phrases
+    go in batches of their own) with the statistics of all terms computed at once: value for value
+    what the term-by-term prepare() yields (tests/test_host_prepare.py compares the two).  The
+    reference harness builds and prepares every task's filter inside its timer
+    (index-search.cpp:694-722, in C++); this is that stage for a batch without a Python loop over
+    the terms."""
+    nq = len(filters)
+    ops, nts, mms, mgs = (np.zeros(nq, np.int64) for _ in range(4))
+    tl, bl, ol = [], [], []
+    for q, flt in enumerate(filters):
+        if isinstance(flt, by_phrase):
+            ops[q], nts[q] = OP_PHRASE, len(flt.terms)
+            tl.extend(flt.terms)
+            bl.extend([flt.boost] * len(flt.terms))
+            ol.extend(flt.offsets)
+            continue
+        op, subs = _terms_of(flt)
+        ops[q], nts[q] = op, len(subs)
+        mms[q] = int(getattr(flt, "min_match", 0))
+        mgs[q] = int(getattr(flt, "merge", MERGE_SUM))
+        tl.extend(s.term for s in subs)
+        bl.extend(s.boost for s in subs)
+        ol.extend([0] * len(subs))
+    flat = np.asarray(tl, np.int64)
+    boost = np.asarray(bl, np.float32)
+    first = np.zeros(nq, np.int64)
+    np.cumsum(nts[:-1], out=first[1:])
+    dwf = sum(s.docs_with_field for s in segment_stats)
+    ttf = sum(s.total_term_freq for s in segment_stats)
+    dwt = np.zeros(flat.size, np.float64)
+    for st in segment_stats:
+        dc = np.asarray(st.docs_count)
+        ok = (flat >= 0) & (flat < len(dc))
+        dwt[ok] += dc[flat[ok]]
+    if isinstance(scorer, BM25):
+        idf = np.log1p((float(dwf) - dwt + 0.5) / (dwt + 0.5)).astype(np.float32)
+        probe = scorer.collect(dwf, 1, ttf)
+        kind = scorer.term_scorer(probe)[0]
+        nc, nl = probe.norm_const, probe.norm_length
+    else:
+        idf = np.log1p((dwf + 1.0) / (dwt + 1.0)).astype(np.float32)
+        kind, nc, nl = scorer.term_scorer(TermStats(f32(1)))[0], f32(0), f32(0)
+    # by_phrase: ONE stats blob per phrase, into which every term's idf was added in phrase order
+    # (float32 `idf +=`: bm25.cpp:381-383, tfidf.cpp:272-275) — every entry carries that sum
+    ph = np.nonzero(ops == OP_PHRASE)[0]
+    if ph.size:
+        acc = np.zeros(ph.size, np.float32)
+        for j in range(int(nts[ph].max())):
+            on = nts[ph] > j
+            acc[on] = (acc[on] + idf[first[ph[on]] + j]).astype(np.float32)
+        of_q = np.repeat(np.arange(nq), nts)
+        slot = np.full(nq, -1, np.int64)
+        slot[ph] = np.arange(ph.size)
+        is_ph = slot[of_q] >= 0
+        idf = idf.copy()
+        idf[is_ph] = acc[slot[of_q[is_ph]]]
+    if isinstance(scorer, BM25):
+        c0 = ((boost * f32(scorer.k + f32(1))).astype(np.float32) * idf).astype(np.float32)
+    else:
+        c0 = (boost * idf).astype(np.float32)
+    queries = np.zeros(nq, QUERY)
+    queries["op"], queries["n_terms"], queries["first_term"] = ops, nts, first
+    queries["k"], queries["min_match"], queries["merge"] = int(k), mms, mgs
+    terms = np.zeros((len(segs), max(flat.size, 1)), TERM_SCORER)
+    for s, sr in enumerate(segs):
+        present = (flat >= 0) & (flat < len(sr.metas))
+        terms["term"][s, :flat.size] = np.where(present, flat, NO_TERM).astype(np.uint32)
+    terms["kind"][:, :flat.size] = kind
+    terms["c0"][:, :flat.size] = c0
+    terms["norm_const"][:, :flat.size] = nc
+    terms["norm_length"][:, :flat.size] = nl
+    terms["phrase_offset"][:, :flat.size] = np.asarray(ol, np.uint32)
+    return QueryArrays(len(segs), queries, terms, k)
+
+
 class QueryBatch:
     """A batch of prepared queries on one segment — or on several segments of one device
     at once (irs_hip_batch_create_multi): then every result array gets a leading segment

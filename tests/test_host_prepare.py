@@ -29,3 +29,36 @@ def test_prepare_disjunctions_equals_term_by_term(scorer):
     for name in search.TERM_SCORER.names:
         assert np.array_equal(slow.terms[name], fast.terms[name]), name
     assert (fast.terms["term"][1] == search.NO_TERM).any()
+
+
+@pytest.mark.parametrize("scorer", [BM25(), BM25(1.2, 0.0), TFIDF(False), TFIDF(True)])
+def test_prepare_filters_equals_term_by_term(scorer):
+    """The vectorised prepare of ANY flat filter list (what bench.py --tasks runs per step) against
+    the term-by-term mirror: boolean kinds mixed in one list, phrases in one of their own."""
+    from iresearch_amd.search import And, by_phrase
+    rng = np.random.default_rng(11)
+    stats = [search.SegmentStats(100_000, 9_700_000, rng.integers(0, 50_000, 400)),
+             search.SegmentStats(60_000, 5_100_000, rng.integers(0, 30_000, 300))]
+    segs = [_Seg(400), _Seg(300)]
+    booleans = []
+    for i in range(96):
+        n = int(rng.integers(1, 13))
+        subs = [by_term(int(t), float(rng.choice([1.0, 0.5, 2.25]))) for t in rng.integers(0, 400, n)]
+        kind = i % 4
+        if kind == 0:
+            booleans.append(subs[0])
+        elif kind == 1:
+            booleans.append(Or(subs, merge=int(rng.integers(0, 3))))
+        elif kind == 2:
+            booleans.append(Or(subs, min_match=int(rng.integers(2, 5))))
+        else:
+            booleans.append(And(subs))
+    phrases = [by_phrase([int(t) for t in rng.integers(0, 400, int(rng.integers(1, 6)))],
+                         boost=float(rng.choice([1.0, 3.0]))) for _ in range(40)]
+    phrases.append(by_phrase([5, 9, 2], offsets=[0, 2, 5]))
+    for filters in (booleans, phrases):
+        slow = search.QueryArrays.from_prepared(segs, search.prepare(filters, scorer, stats), 9)
+        fast = search.prepare_filters(filters, scorer, stats, segs, 9)
+        assert slow.queries.tobytes() == fast.queries.tobytes()
+        for name in search.TERM_SCORER.names:
+            assert np.array_equal(slow.terms[name], fast.terms[name]), name
