@@ -878,6 +878,41 @@ def main_tasks(args):
     print("# category            terms  ranks of the task's words          hits/query   GPU q/s    CPU q/s   GPU/CPU  parity"
           "           path   ms/step  plan/pilot/score/select ms  postings/step  re-runs (profiled batch + timed steps)")
     for t in tasks.parse_tasks(lines, 1):
+        if t.category in tasks.UNION:
+            # by_prefix / by_wildcard WITHOUT scorers: the visited terms' postings
+            # ORed into a doc bitset — postings_reader::bit_union (formats_10.cpp:3716-3806) behind
+            # lazy_bitset_iterator (multiterm_query.cpp:64-101).  The scored form the harness builds
+            # (scored_terms_limit, index-search.cpp:368-386) is not built.
+            rng = np.random.default_rng(20260926 + len(rows))
+            visits = [tasks.expansion_of(t, max_rank, rng) for _ in range(nq)]
+            n_words = (seg.num_docs + 64) // 64
+            t0 = time.perf_counter()
+            sets = [sr.bit_union(v, n_words) for v in visits]
+            gpu_dt = time.perf_counter() - t0
+            metas_all = np.zeros(len(seg.metas), oracle.TERM_META)
+            for name in oracle.TERM_META.names:
+                metas_all[name] = seg.metas[name]
+
+            def cpu_one(i):
+                return oracle.bit_union(seg.doc_file, metas_all[visits[i]], seg.layout, True, n_words)
+            t0 = time.perf_counter()
+            with cf.ThreadPoolExecutor(cores) as ex:
+                ref = list(ex.map(cpu_one, range(nq)))
+            cpu_dt = time.perf_counter() - t0
+            for (gb, gn), (cb, cn) in zip(sets, ref):
+                assert gn == cn and np.array_equal(gb, cb), "bit_union differs from the oracle's"
+            hits = float(np.mean([int(np.unpackbits(b.view(np.uint8)).sum()) for b, _ in sets[:16]]))
+            row = {"category": t.category, "terms": int(np.mean([len(v) for v in visits])),
+                   "form": "unscored: one bit_union over the visited terms",
+                   "hits_per_query": hits, "gpu_qps": nq / gpu_dt, "cpu_qps": nq / cpu_dt,
+                   "cpu_sample": nq, "parity_checked": nq, "ms_per_step": gpu_dt * 1e3,
+                   "path": "bit_union", "postings_per_step": int(sum(n for _, n in sets))}
+            rows.append(row)
+            print("%-20s %5d  %-34s %10.0f %10.0f %10.1f %8.1fx  ok (%d bitsets)  %-6s %7.3f  (unscored: bit_union; scored_terms_limit form not built)  %6.1f M" % (
+                t.category, row["terms"], "'%s' -> terms visited" % t.text.strip(), hits, row["gpu_qps"],
+                row["cpu_qps"], row["gpu_qps"] / row["cpu_qps"], nq, "union", row["ms_per_step"],
+                row["postings_per_step"] / 1e6), flush=True)
+            continue
         if t.category in tasks.EXPANSION:
             print("%-20s (multi-term expansion filter: not on this path)" % t.category)
             continue

@@ -11,7 +11,12 @@ turns (category, text) into a filter:
   OrHighHigh / OrHighMed / OrHighLow /
     Or4High / Or6High4Med2Low                   Or of by_term
   MinMatch2High2Med                             Or with min_match_count (first token)
-  Prefix3 / Wildcard / Fuzzy1 / Fuzzy2 / *NGram multi-term expansion filters — not on this path
+  Prefix3 / Wildcard                            by_prefix / by_wildcard: multi-term expansion — the
+                                                UNSCORED form is on this path (one bit_union over the
+                                                visited terms, SURVEY §8 f4: `expansion_of`); the
+                                                scored form (`scored_terms_limit` best terms as a
+                                                disjunction, index-search.cpp:368-386) is not built
+  Fuzzy1 / Fuzzy2 / *NGram                      not on this path
 
 The synthetic index has ranks, not words.  A task's words carry their document frequency in the
 reference's benchmark index (`# freq=541190`, Wikipedia lines, 5 M docs in
@@ -34,6 +39,7 @@ AND = ("AndHighHigh", "AndHighMed", "AndHighLow")
 OR = ("OrHighHigh", "OrHighMed", "OrHighLow", "Or4High", "Or6High4Med2Low")
 MINMATCH = ("MinMatch2High2Med",)
 EXPANSION = ("Prefix3", "Wildcard", "Fuzzy1", "Fuzzy2", "HighNGram", "MedNGram", "LowNGram")
+UNION = ("Prefix3", "Wildcard")      # ... of which these run as ONE postings_reader::bit_union
 CATEGORIES = TERM + PHRASE + AND + OR + MINMATCH + EXPANSION
 
 REFERENCE_DOCS = 5_000_000     # scripts/search-benchmark.sh: MAX_LINES=5000000
@@ -136,3 +142,36 @@ def filter_of(task: Task, ranks):
     if task.category in MINMATCH:
         return Or([by_term(t) for t in terms], min_match=task.min_match)
     return None
+
+
+def expansion_of(task: Task, n_terms: int, rng=None):
+    """The term ordinals a Prefix3 / Wildcard task VISITS in the synthetic field's sorted term table
+    — what by_prefix's / by_wildcard's term visitor enumerates from the dictionary
+    (prefix_filter.cpp:37-60; wildcard_filter.cpp -> the same visit under an automaton) — as a sorted
+    uint32 array.  A synthetic term is its ordinal's 4-byte big-endian number (synth.term_bytes_of),
+    so the task's pattern keeps its SHAPE and takes synthetic bytes: `sec*` (three fixed bytes, then
+    anything) = the 256 ordinals sharing one 3-byte prefix; `re*f` (two fixed bytes, anything, one
+    fixed last byte) = every 256th ordinal of one 65536-term range.  The fixed bytes are drawn per
+    query (`rng`) from the ranges the vocabulary fills."""
+    import numpy as np
+    text = task.text.strip()
+    star = text.find("*")
+    if task.category not in UNION or star < 0:
+        return None
+    n_pre, n_suf = star, len(text) - star - 1
+    if n_pre + n_suf > 4:
+        return np.zeros(0, np.uint32)
+    top = max(int(n_terms) - 1, 0).to_bytes(4, "big")
+    pre = bytearray()
+    for i in range(n_pre):      # leading bytes stay inside the vocabulary [0, n_terms)
+        hi = top[i] if bytes(pre) == top[:i] else 255
+        pre.append(int(rng.integers(0, hi + 1)) if rng is not None else hi // 2)
+    suf = bytes(int(rng.integers(0, 256)) if rng is not None else 0x66 for _ in range(n_suf))
+    # the visit itself: the sorted term table against prefix and suffix, byte by byte
+    table = np.arange(int(n_terms), dtype=">u4").view(np.uint8).reshape(-1, 4)
+    ok = np.ones(len(table), bool)
+    for i, b in enumerate(pre):
+        ok &= table[:, i] == b
+    for i, b in enumerate(suf):
+        ok &= table[:, 4 - n_suf + i] == b
+    return np.nonzero(ok)[0].astype(np.uint32)

@@ -242,10 +242,13 @@ def read_skip0_pos(doc_file: np.ndarray, meta, wand_count: int = 0):
 
 def bit_union(doc_file: np.ndarray, metas, layout: int, has_freq: bool, n_words: int,
               initial: np.ndarray | None = None, wand_count: int = 0):
-    m = np.zeros(len(metas), TERM_META)
-    for i, meta in enumerate(metas):
-        for k in TERM_META.names:
-            m[i][k] = meta[k]
+    if isinstance(metas, np.ndarray) and metas.dtype == TERM_META:
+        m = np.ascontiguousarray(metas)
+    else:
+        m = np.zeros(len(metas), TERM_META)
+        for i, meta in enumerate(metas):
+            for k in TERM_META.names:
+                m[i][k] = meta[k]
     bits = np.zeros(n_words, np.uint64) if initial is None else initial.copy()
     n = lib().orc_bit_union_wand(doc_file.ctypes.data, doc_file.size, layout, int(has_freq),
                                  wand_count, m.ctypes.data, len(metas), bits.ctypes.data, n_words)

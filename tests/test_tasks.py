@@ -33,31 +33,62 @@ def test_task_grammar_against_the_reference_list():
     assert len(set(r["MinMatch2High2Med"])) == 4      # equal frequencies -> still distinct terms
 
 
-def _one_of_each(L, docs, max_rank):
+def _one_of_each(L, docs, max_rank, per_class=1):
+    """`per_class` queries of every class (the task's ranks jittered +-25 % like bench.py --tasks)
+    through the C ABI against the oracle; the two expansion classes as bit_union."""
+    import oracle
     seg = synth.build_segment(docs, max_rank, with_positions=True)
     sr = search.SegmentReader.from_synth(seg, L=L)
     st = [parity.segment_stats(seg)]
     lines = json.load(open(GOLDEN))["lines"]
     parsed = [t for t in tasks.parse_tasks(lines, 1) if t.category not in tasks.EXPANSION]
     assert len(parsed) == 15
+    rng = np.random.default_rng(5)
     for scorer in (BM25(), TFIDF(False)):
         boolean, phrases = [], []
         for t in parsed:
-            flt = tasks.filter_of(t, tasks.ranks_of(t, max_rank))
-            (phrases if t.category in tasks.PHRASE else boolean).append(flt)
+            for i in range(per_class):
+                ranks = tasks.ranks_of(t, max_rank) if i == 0 else tasks.ranks_of(t, max_rank, 0.25, rng)
+                (phrases if t.category in tasks.PHRASE else boolean).append(tasks.filter_of(t, ranks))
         for filters, check in ((boolean, parity.check_single_segment), (phrases, parity.check_phrase_segment)):
-            b = sr.batch(search.prepare(filters, scorer, st), 100)
+            b = sr.batch(search.prepare_filters(filters, scorer, st, [sr], 100), 100)
             hits, counts, totals = (x.copy() for x in b.run().results_to_host().host_results())
             check(seg, filters, scorer, 100, hits, counts, totals)
-            assert (totals > 0).sum() >= len(filters) - 2     # (the classes really match docs)
+            assert (totals > 0).sum() >= len(filters) - 2 * per_class   # (the classes really match docs)
             b.close()
+    # Prefix3 / Wildcard without scorers: the visit, then ONE bit_union (SURVEY §8 f4)
+    n_words = (seg.num_docs + 64) // 64
+    for t in tasks.parse_tasks(lines, 1):
+        if t.category not in tasks.UNION:
+            continue
+        for i in range(per_class):
+            v = tasks.expansion_of(t, max_rank, rng)
+            assert len(v) and (np.diff(v.astype(np.int64)) > 0).all() and v[-1] < max_rank
+            gb, gn = sr.bit_union(v, n_words)
+            ob, on = oracle.bit_union(seg.doc_file, [seg.metas[int(x)] for x in v], seg.layout, True, n_words)
+            assert gn == on and np.array_equal(gb, ob)
     sr.close()
 
 
+def test_expansion_visits_the_sorted_term_table():
+    """expansion_of against a brute-force match of the pattern on the terms' bytes."""
+    g = {t.category: t for t in tasks.parse_tasks(json.load(open(GOLDEN))["lines"], 1)}
+    rng = np.random.default_rng(3)
+    for n_terms in (5000, 70000, 262144):
+        for cat, n_pre, n_suf in (("Prefix3", 3, 0), ("Wildcard", 2, 1)):
+            v = tasks.expansion_of(g[cat], n_terms, rng)
+            terms = [synth.term_bytes_of(i) for i in range(n_terms)]
+            pre = terms[int(v[0])][:n_pre]
+            suf = terms[int(v[0])][4 - n_suf:] if n_suf else b""
+            want = [i for i, tb in enumerate(terms) if tb.startswith(pre) and tb.endswith(suf)]
+            assert v.tolist() == want
+    assert tasks.expansion_of(g["HighTerm"], 1000, rng) is None
+
+
 def test_one_query_of_every_task_class(simlib):
-    _one_of_each(simlib, 60_000, 2048)
+    _one_of_each(simlib, 60_000, 2048, per_class=2)
 
 
 @pytest.mark.gpu
 def test_one_query_of_every_task_class_gpu(gpulib):
-    _one_of_each(gpulib, 2_000_000, 65536)
+    _one_of_each(gpulib, 2_000_000, 65536, per_class=8)
