@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define IRS_HIP_ABI_VERSION 9
+#define IRS_HIP_ABI_VERSION 10
 #define IRS_HIP_BLOCK_SIZE 128u  /* postings per block, formats_10.cpp:90 */
 #define IRS_HIP_MAX_TERMS 16u    /* terms per boolean query               */
 #define IRS_HIP_MAX_K 4096u      /* largest top-k                         */
@@ -114,6 +114,21 @@ typedef struct irs_hip_segment_desc {
                              * for MaxFreq / MinNorm queries) — those are read from the index;
                              * with DIV_NORM or NONE the per-block (max freq, min norm) pairs
                              * are derived from the postings, which is always sound. */
+  const uint32_t* doc_mask; /* the segment's DocumentMask: ids of its deleted docs, in any order, as
+                             * index_utils::ReadDocumentMask (index_utils.cpp:476) fills it from the
+                             * `.doc_mask` file (DocumentMaskReader::read, formats_10.cpp:3275-3312);
+                             * NULL / 0: none.  The reference filters every iterator a caller wraps
+                             * with SegmentReaderImpl::mask (segment_reader_impl.cpp:69-101, 286:
+                             * MaskDocIterator skips the docs the mask contains); a batch cannot be
+                             * wrapped afterwards — it only yields the k best docs — so the mask
+                             * belongs to the segment here: no query of a batch (Or / And /
+                             * min-match / by_phrase) returns, counts or scores a masked doc, and
+                             * irs_hip_bit_union does not set its bit.  The postings-level surfaces
+                             * (irs_hip_decode_term / _positions / _term_directory: what
+                             * postings_reader::iterator yields) are not filtered, and neither are
+                             * the statistics of the scorers (the reference's are index statistics
+                             * too).  Ids outside 1..num_docs are ignored. */
+  uint64_t doc_mask_count;
 } irs_hip_segment_desc;
 
 typedef struct irs_hip_segment irs_hip_segment; /* opaque, immutable after open */
@@ -132,6 +147,8 @@ void irs_hip_segment_close(irs_hip_segment* seg);
  * per posting of the whole segment — built by the first batch that joins posting streams, or whose
  * conjunctions / phrases score with norms). */
 uint64_t irs_hip_segment_device_bytes(const irs_hip_segment* seg);
+/* SubReader::live_docs_count (index_reader.hpp): num_docs minus the docs of doc_mask. */
+uint64_t irs_hip_segment_live_docs(const irs_hip_segment* seg);
 
 /* Replaces `postings_reader::iterator(...)` + `while (it->next())`
  * (formats_10.cpp:3491-3533, 2089-2119): decodes the whole posting list of
@@ -151,7 +168,8 @@ int irs_hip_decode_positions(irs_hip_segment* seg, uint32_t term, uint32_t* posi
 /* postings_reader::bit_union (core/formats/formats_10.cpp:3716-3806; virtual at
  * core/formats/formats.hpp:182-190): ORs bit `doc` into the caller's bitset
  * (`size_t* set` in the reference: 64-bit little-endian words, bit index = doc id,
- * so the set needs num_docs + 1 bits) for every posting of every listed term;
+ * so the set needs num_docs + 1 bits) for every posting of every listed term (of every doc that
+ * is not in the segment's doc_mask);
  * freq blocks are skipped.  IRS_HIP_NO_TERM entries are ignored.  *count receives
  * what the reference returns: the SUM of the terms' docs_count (not a popcount).
  * Docs at or beyond 64 * n_words are not representable and are dropped. */
@@ -278,9 +296,22 @@ int irs_hip_batch_create_multi(irs_hip_segment* const* segs, uint32_t n_segs,
  * prepares batch i + 1 while batch i is being queued and batch i - 1 executes (the reference runs
  * its tasks on --threads workers, index-search.cpp:673-722).  Every other call on the batch waits
  * for that hand-over first; a failure of the run is returned by the next such call (results,
- * device_results, timings, destroy ...).  IRS_HIP_ASYNC_RUN=0 in the environment keeps the host
- * half on the caller's thread (and the status in this call's return value). */
+ * device_results, timings, destroy ...).  IRS_HIP_ASYNC_RUN=0 in the environment, or
+ * irs_hip_batch_set_async(batch, 0) for one batch, keeps the host half on the caller's thread
+ * (and the status in this call's return value).
+ * What asynchronous means for the caller's own work on `stream`: when this returns, nothing of
+ * the run may be on the stream yet.  An event the caller records, a kernel it launches or a
+ * hipStreamSynchronize it makes right after is NOT ordered behind the run — get behind it with a
+ * call on the batch (irs_hip_batch_device_results waits for the run; irs_hip_batch_results_to_device
+ * / _to_host queue their copies behind it), or switch the hand-over off for that batch.  The same
+ * holds for a device pointer obtained from irs_hip_batch_device_results BEFORE a re-run of the
+ * batch: use it only behind a later call on the batch. */
 int irs_hip_batch_run(irs_hip_batch* batch, void* stream);
+/* Per batch: 1 = hand the host half of irs_hip_batch_run to the library's worker thread, 0 = keep
+ * it on the caller's thread, -1 = the process default (on; IRS_HIP_ASYNC_RUN=0 turns it off).  A
+ * batch with a communicator (irs_hip_batch_set_comm) issues its collectives — also those of a
+ * recovery re-run — in the order of the calls made on this device either way. */
+int irs_hip_batch_set_async(irs_hip_batch* batch, int enable);
 /* Optional: queue the PLANNING stage of the batch's next run (tile tables, work items: what
  * building the iterator tree is to filter::prepared::execute) on `stream` now; the next
  * irs_hip_batch_run then only waits for it (an event) and starts with scoring.  The stage reads

@@ -47,6 +47,7 @@ class SegmentDesc(C.Structure):
         ("norm_count", C.c_uint64), ("terms", C.c_void_p), ("num_terms", C.c_uint32),
         ("wand_count", C.c_uint32), ("pos_file", C.c_void_p), ("pos_file_len", C.c_uint64),
         ("pos_features", C.c_uint32), ("norm_kind", C.c_uint32), ("wand_type", C.c_uint32),
+        ("doc_mask", C.c_void_p), ("doc_mask_count", C.c_uint64),
     ]
 
 
@@ -58,7 +59,8 @@ class IrsHipError(RuntimeError):
 
 SYMBOLS = (
     "irs_hip_abi_version", "irs_hip_strerror", "irs_hip_device_arch", "irs_hip_segment_open",
-    "irs_hip_segment_close", "irs_hip_segment_device_bytes", "irs_hip_decode_term",
+    "irs_hip_segment_close", "irs_hip_segment_device_bytes", "irs_hip_segment_live_docs",
+    "irs_hip_decode_term",
     "irs_hip_decode_positions",
     "irs_hip_term_directory", "irs_hip_bit_union", "irs_hip_batch_create",
     "irs_hip_batch_create_multi", "irs_hip_batch_run",
@@ -69,6 +71,7 @@ SYMBOLS = (
     "irs_hip_batch_timings", "irs_hip_batch_work", "irs_hip_batch_reruns", "irs_hip_merge_topk",
     "irs_hip_batch_plan", "irs_hip_batch_set_wand", "irs_hip_batch_set_min_scores",
     "irs_hip_batch_set_path", "irs_hip_batch_path", "irs_hip_batch_set_shared_threshold",
+    "irs_hip_batch_set_async",
     "irs_hip_batch_set_comm",
     "irs_hip_term_blockmax",
     "irs_hip_segment_wand_source",
@@ -92,6 +95,8 @@ def bind(L: C.CDLL) -> C.CDLL:
     L.irs_hip_segment_close.argtypes, L.irs_hip_segment_close.restype = [vp], None
     L.irs_hip_segment_device_bytes.argtypes = [vp]
     L.irs_hip_segment_device_bytes.restype = u64
+    L.irs_hip_segment_live_docs.argtypes = [vp]
+    L.irs_hip_segment_live_docs.restype = u64
     L.irs_hip_decode_term.argtypes = [vp, u32, vp, vp, u32, P(u32)]
     L.irs_hip_decode_term.restype = C.c_int
     L.irs_hip_decode_positions.argtypes = [vp, u32, vp, u64, P(u64)]
@@ -132,6 +137,7 @@ def bind(L: C.CDLL) -> C.CDLL:
     L.irs_hip_batch_plan.argtypes, L.irs_hip_batch_plan.restype = [vp, vp], C.c_int
     L.irs_hip_batch_set_path.argtypes, L.irs_hip_batch_set_path.restype = [vp, C.c_int], C.c_int
     L.irs_hip_batch_path.argtypes, L.irs_hip_batch_path.restype = [vp, P(C.c_int)], C.c_int
+    L.irs_hip_batch_set_async.argtypes, L.irs_hip_batch_set_async.restype = [vp, C.c_int], C.c_int
     L.irs_hip_batch_set_shared_threshold.argtypes = [vp, C.c_int]
     L.irs_hip_batch_set_shared_threshold.restype = C.c_int
     L.irs_hip_batch_set_comm.argtypes, L.irs_hip_batch_set_comm.restype = [vp, vp], C.c_int

@@ -243,6 +243,8 @@ class SegmentReader {
   irs_hip_segment* handle() const noexcept { return h_; }
   uint32_t num_terms() const noexcept { return num_terms_; }
   uint64_t CountMappedMemory() const noexcept { return irs_hip_segment_device_bytes(h_); }
+  // SubReader::live_docs_count: docs that are not in the segment's DocumentMask
+  uint64_t live_docs_count() const noexcept { return irs_hip_segment_live_docs(h_); }
 
   // postings_reader::iterator(...) drained: (docs, freqs) of one term
   void postings(uint32_t term, std::vector<uint32_t>& docs, std::vector<uint32_t>* freqs,
@@ -981,6 +983,20 @@ inline SegmentMetaFile read_segment_meta(const uint8_t* sm, uint64_t len) {
   return m;
 }
 
+// DocumentMaskReader::read (formats_10.cpp:3275-3312): the ids of a segment's deleted docs, in
+// file order (the writer iterates a hash set: any order) — what index_utils::ReadDocumentMask
+// (index_utils.cpp:476) hands SegmentReaderImpl::Update, and irs_hip_segment_desc::doc_mask here.
+inline std::vector<uint32_t> read_document_mask(const uint8_t* dm, uint64_t len) {
+  size_t hl = 0;
+  check_header(dm, len, "iresearch_10_doc_mask", 0, 0, &hl);
+  check_footer(dm, len);
+  Cursor in(dm + hl, dm + len - kFooterLen, "document mask");
+  std::vector<uint32_t> docs;
+  for (uint32_t n = in.v<uint32_t>(); n; --n) docs.push_back(in.v<uint32_t>());
+  if (in.left()) throw index_error(IRS_HIP_ECORRUPT, "document mask: bytes behind the last doc id");
+  return docs;
+}
+
 // The terms of ONE field of `.tm`, in order, from its root block (FieldRecord::root_start): a
 // block group = the blocks from the referenced one to the first with the "last of its group"
 // bit; an entry is a term (suffix + stats record) or a sub-block (suffix + back pointer) whose
@@ -1191,6 +1207,7 @@ struct FieldFiles {
   const uint8_t* sm = nullptr;   uint64_t sm_len = 0;      // segment meta: the doc count
   const uint8_t* csi = nullptr;  uint64_t csi_len = 0;     // columnstore index + data
   const uint8_t* csd = nullptr;  uint64_t csd_len = 0;
+  const uint8_t* doc_mask = nullptr;  uint64_t doc_mask_len = 0;   // `.doc_mask`: deleted docs (optional file)
   std::string field;             // which field of the segment
   // What the files do not say: which Scorer::WandType the field's wand data was written by
   // (it is a property of the scorer objects the index was created with, scorer.hpp:196-201).
@@ -1211,6 +1228,7 @@ struct OpenedField {
   uint64_t docs_with_field = 0;
   uint64_t total_term_freq = 0;
   uint32_t num_docs = 0;
+  std::vector<uint32_t> doc_mask;            // the segment's deleted docs (DocumentMask)
 };
 // Everything irs_hip_segment_open needs for one field of a segment, from file bytes alone:
 // with `ti` and `sm` given, the field's features (FREQ / POS / OFFS / PAY), its Norm2 column id,
@@ -1291,6 +1309,19 @@ inline irs_hip_segment_desc describe_field(const FieldFiles& f, int32_t device, 
     d.pos_file_len = f.pos_len;
     d.pos_features = (o.record.index_features & 4u ? IRS_HIP_POS_OFFSETS : 0u) |
                      (o.record.index_features & 8u ? IRS_HIP_POS_PAYLOADS : 0u);
+  }
+  // SegmentReaderImpl::Open (segment_reader_impl.cpp:167-172): the optional `.doc_mask`; every
+  // batch on the segment then behaves like an iterator behind SegmentReaderImpl::mask
+  o.doc_mask.clear();
+  if (f.doc_mask) {
+    o.doc_mask = read_document_mask(f.doc_mask, f.doc_mask_len);
+    if (f.sm) {   // (SegmentMeta::live_docs_count = docs_count - the mask's size: index_writer)
+      const SegmentMetaFile meta = read_segment_meta(f.sm, f.sm_len);
+      if (meta.live_docs_count + o.doc_mask.size() != meta.docs_count)
+        throw index_error(IRS_HIP_ECORRUPT, "document mask: size disagrees with the segment meta's live docs");
+    }
+    d.doc_mask = o.doc_mask.data();
+    d.doc_mask_count = o.doc_mask.size();
   }
   return d;
 }

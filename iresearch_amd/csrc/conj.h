@@ -391,6 +391,7 @@ k_conj(ConjArgs A, uint32_t pilot) {
     return 2u + (db ? 16u * db : 1u) + (fb ? 16u * fb : 1u);
   };
   uint32_t ld_d[2], ld_e[2];   // this lane's two lead docs and their entry indices
+  bool live[2];                // ... and whether they are docs of the conjunction at all
   {
     uint32_t f[2], estep;
     if (item < ld.nblk) {
@@ -415,7 +416,10 @@ k_conj(ConjArgs A, uint32_t pilot) {
       docs[ld_e[h]] = on ? ld_d[h] : 0xFFFFFFFFu;
       W.fr[0][ld_e[h]] = f[h];
       score[ld_e[h]] = 0.f;
-      cnt[ld_e[h]] = on ? 1u : 0u;
+      // a deleted doc (SegmentReaderImpl::mask) keeps its place among the lead docs — the doc range
+      // and the ranks of the others do not change — but is never alive: no term can reach it
+      live[h] = on && !(seg.dead && doc_dead(seg.dead, ld_d[h]));
+      cnt[ld_e[h]] = live[h] ? 1u : 0u;
     }
     // (words 2*lane, 2*lane+1 of the three bitmaps; the 4 slack words stay zero from here)
     if (lane < (kConjWords + 4u) / 2u) {
@@ -460,11 +464,15 @@ k_conj(ConjArgs A, uint32_t pilot) {
   const uint32_t span = dhi - dlo;
   const uint32_t s = span < 32u * kConjWords ? 0u
                      : 32u - uint32_t(__builtin_clz(span)) - (5u + uint32_t(__builtin_ctz(kConjWords)));
+  const bool masked = seg.dead != nullptr;   // (wave-uniform)
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     if (ld_e[h] < n) {
       const uint32_t bk = (ld_d[h] - dlo) >> s;
       atomicOr(&W.bm[0][bk >> 5], 1u << (bk & 31u));
+      // (bm[0] ranks the lead docs, deleted ones included; what the first other term may reach is
+      // the live ones: bm[2], free until the third term marks into it)
+      if (masked && live[h]) atomicOr(&W.bm[2][bk >> 5], 1u << (bk & 31u));
     }
   }
   wave::sync();
@@ -497,11 +505,11 @@ k_conj(ConjArgs A, uint32_t pilot) {
     // alive = the docs every earlier term reached: the lead bitmap, then what the previous
     // term marked; `mark` collects what this term reaches
     const uint32_t mk = 1u + ((i - 1u) & 1u);
-    const uint32_t* alive = i == 1u ? W.bm[0] : W.bm[3u - mk];
+    const uint32_t* alive = i == 1u ? (masked ? W.bm[2] : W.bm[0]) : W.bm[3u - mk];
     uint32_t* mark = W.bm[mk];
     const uint8_t* apre = W.lpre;
-    if (i > 1u) {
-      if (lane < kConjWords / 2u) {
+    if (i > 1u || masked) {
+      if (i > 1u && lane < kConjWords / 2u) {
         mark[2u * lane] = 0u;
         mark[2u * lane + 1u] = 0u;
       }

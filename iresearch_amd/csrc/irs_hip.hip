@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -286,6 +287,8 @@ struct irs_hip_segment {
   // first joined batch; 1-byte Norm2 columns only
   DevBuf d_pnorm, d_tail_norms;
   bool pnorm_ready = false;
+  DevBuf d_dead;                   // the DocumentMask as a bitmap (DevSegment::dead)
+  uint64_t live_docs = 0;          // num_docs - deleted docs
   DevBuf d_blk_maxf, d_blk_minn;
   std::vector<uint64_t> skip_at;   // per term: absolute offset of its skip data (0: none)
   bool has_pos = false;
@@ -428,6 +431,7 @@ struct irs_hip_batch {
   std::condition_variable acv;
   bool async_pending = false;
   int async_rc = 0;
+  int async_pref = -1;   // irs_hip_batch_set_async: -1 the process default (IRS_HIP_ASYNC_RUN), 0 / 1
 };
 
 namespace {
@@ -1207,7 +1211,9 @@ bool build_streams(irs_hip_batch* b) {
     w.last_doc = t.last_doc;
     w.n_tiles = (ds.num_docs + kJoinTile - 1) / kJoinTile;
     w.n = sr.n;
-    w.pad[0] = w.pad[1] = w.pad[2] = 0;
+    w.dead_lo = uint32_t(reinterpret_cast<uint64_t>(ds.dead));
+    w.dead_hi = uint32_t(reinterpret_cast<uint64_t>(ds.dead) >> 32);
+    w.pad = 0;
   }
   lap("  streams: per-term records");
   for (uint32_t u : b->join_units) {
@@ -1696,9 +1702,13 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st);
 // host work (index-search runs its queries on --threads workers for the same reason:
 // index-search.cpp:673-722).  IRS_HIP_ASYNC_RUN=0 runs everything on the caller's thread.
 namespace worker {
+// A job = the host half of a run, or the recovery of a batch whose threshold spans ranks: both
+// issue collectives on the batch's communicator, and RCCL pairs collectives by issue ORDER — so
+// everything of a device that may issue one goes through this one FIFO (a re-run of
+// batch i on the caller's thread raced the worker's run of batch i + 1 on the same communicator).
 struct Job {
   irs_hip_batch* b;
-  rt::stream_t st;
+  std::function<int()> fn;
 };
 struct Queue {
   std::mutex m;
@@ -1733,7 +1743,7 @@ static void loop(Queue* q) {
     }
     const int rc = guarded([&] {
       if (!rt::set_device(job.b->seg->device)) return int(IRS_HIP_EHIP);
-      return run_impl(job.b, job.st);
+      return job.fn();
     });
     {
       std::lock_guard<std::mutex> lock(job.b->am);
@@ -1750,23 +1760,36 @@ static bool enabled() {
   }();
   return on;
 }
-static bool submit(irs_hip_batch* b, rt::stream_t st) {
+// Queues `fn` for the batch on its device's worker; false: the worker cannot take it (no thread,
+// no memory) — nothing is pending, the caller runs `fn` itself.
+static bool submit(irs_hip_batch* b, std::function<int()> fn) {
   Queue& q = of(b->seg->device);
-  {
-    std::lock_guard<std::mutex> lock(b->am);
-    b->async_pending = true;
-    b->async_rc = IRS_HIP_OK;
+  try {
+    std::lock_guard<std::mutex> lock(q.m);
+    if (!q.started) {
+      q.device = b->seg->device;
+      q.th = std::thread(loop, &q);
+      q.started = true;
+    }
+    {
+      std::lock_guard<std::mutex> block(b->am);
+      b->async_pending = true;
+      b->async_rc = IRS_HIP_OK;
+    }
+    try {
+      q.jobs.push_back(Job{b, std::move(fn)});
+    } catch (...) {
+      std::lock_guard<std::mutex> block(b->am);
+      b->async_pending = false;   // (nothing was queued: nobody would ever clear it)
+      throw;
+    }
+    q.cv.notify_one();
+    return true;
+  } catch (...) {
+    return false;
   }
-  std::lock_guard<std::mutex> lock(q.m);
-  if (!q.started) {
-    q.device = b->seg->device;
-    q.th = std::thread(loop, &q);
-    q.started = true;
-  }
-  q.jobs.push_back(Job{b, st});
-  q.cv.notify_one();
-  return true;
 }
+static bool wanted(const irs_hip_batch* b) { return b->async_pref < 0 ? enabled() : b->async_pref != 0; }
 }  // namespace worker
 
 // Before anything else touches a batch: its run, if one was handed to the worker, is queued.
@@ -1818,7 +1841,8 @@ static int segment_open_impl(const irs_hip_segment_desc* d, irs_hip_segment** ou
   *out = nullptr;
   if (!d->doc_file || !d->num_docs || d->num_docs > 0x7FFF0000u ||
       (d->layout != IRS_HIP_LAYOUT_SCALAR && d->layout != IRS_HIP_LAYOUT_SIMD4) ||
-      (d->num_terms && !d->terms) || d->wand_count > 16 || d->wand_type > IRS_HIP_WAND_MIN_NORM)
+      (d->num_terms && !d->terms) || d->wand_count > 16 || d->wand_type > IRS_HIP_WAND_MIN_NORM ||
+      (d->doc_mask_count && !d->doc_mask))
     return IRS_HIP_EINVAL;
   if (d->norm_kind != IRS_HIP_NORM2 && d->norm_kind != IRS_HIP_NORM_LEGACY) return IRS_HIP_EINVAL;
   if (d->norms) {
@@ -1940,6 +1964,39 @@ static int segment_open_impl(const irs_hip_segment_desc* d, irs_hip_segment** ou
     v.has_freq = d->has_freq ? 1 : 0;
     v.layout = d->layout;
     v.wand_count = d->wand_count;
+    s->live_docs = d->num_docs;
+    if (d->doc_mask_count) {
+      // DocumentMask -> bitmap, bit (doc - kDocMin); a whole doc tile behind the last doc stays
+      // readable (the tile kernels test their accumulators' docs group by group)
+      const uint64_t words = (uint64_t(d->num_docs) + 12288u + 31u) / 32u + 16u;
+      std::vector<uint32_t> bits;
+      try {
+        bits.assign(words, 0u);
+      } catch (...) {
+        rc = IRS_HIP_ENOMEM;
+        break;
+      }
+      uint64_t gone = 0;
+      for (uint64_t i = 0; i < d->doc_mask_count; ++i) {
+        const uint32_t doc = d->doc_mask[i];
+        if (doc < kDocMin || doc > d->num_docs) continue;
+        const uint32_t j = doc - kDocMin;
+        gone += (bits[j >> 5] >> (j & 31u)) & 1u ? 0u : 1u;
+        bits[j >> 5] |= 1u << (j & 31u);
+      }
+      if (gone) {
+        if (!s->d_dead.alloc(words * 4)) {
+          rc = IRS_HIP_ENOMEM;
+          break;
+        }
+        if (!rt::h2d(s->d_dead.p, bits.data(), words * 4, nullptr) || !rt::sync(nullptr)) {
+          rc = IRS_HIP_EHIP;
+          break;
+        }
+        v.dead = s->d_dead.as<uint32_t>();
+        s->live_docs = d->num_docs - gone;
+      }
+    }
     rc = d->layout == IRS_HIP_LAYOUT_SIMD4 ? build_directory<kSimd4>(s)
                                            : build_directory<kScalar>(s);
     if (rc == IRS_HIP_OK && d->pos_file) {
@@ -2003,7 +2060,7 @@ static int segment_open_impl(const irs_hip_segment_desc* d, irs_hip_segment** ou
     s->device_bytes = s->d_doc.n + s->d_norms.n + s->d_terms.n + s->d_blk_off.n +
                       s->d_blk_last.n + s->d_blk_bits.n + s->d_blk_aoff.n + s->d_blk_dir.n + s->d_blk_term.n + s->d_pk.n +
                       s->d_tail_docs.n + s->d_tail_freqs.n + s->d_pos.n + s->d_pterms.n +
-                      s->d_pblk_off.n + s->d_pblk_bits.n + s->d_blk_pos.n + s->d_ptail.n;
+                      s->d_pblk_off.n + s->d_pblk_bits.n + s->d_blk_pos.n + s->d_ptail.n + s->d_dead.n;
   } while (false);
   if (rc != IRS_HIP_OK) {
     delete s;
@@ -2022,6 +2079,7 @@ void irs_hip_segment_close(irs_hip_segment* seg) {
 uint64_t irs_hip_segment_device_bytes(const irs_hip_segment* seg) {
   return seg ? seg->device_bytes : 0;
 }
+uint64_t irs_hip_segment_live_docs(const irs_hip_segment* seg) { return seg ? seg->live_docs : 0; }
 
 static int decode_term_impl(irs_hip_segment* seg, uint32_t term, uint32_t* docs, uint32_t* freqs,
                         uint32_t cap, uint32_t* count) {
@@ -2596,6 +2654,12 @@ static int batch_set_comm_impl(irs_hip_batch* b, irs_hip_comm* comm) {
   return IRS_HIP_OK;
 }
 
+static int batch_set_async_impl(irs_hip_batch* b, int enable) {
+  if (!b) return IRS_HIP_EINVAL;
+  b->async_pref = enable < 0 ? -1 : (enable ? 1 : 0);
+  return IRS_HIP_OK;
+}
+
 static int batch_path_impl(irs_hip_batch* b, int* path) {
   if (!b || !path) return IRS_HIP_EINVAL;
   *path = b->joined ? IRS_HIP_PATH_JOINED : IRS_HIP_PATH_ITEMS;
@@ -2787,6 +2851,13 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st) {
   HostTrace trace("batch_run (scratch + uploads + launches queued)");
   if (!ensure_scratch(b) || !stage_min_bins(b)) return IRS_HIP_ENOMEM;
   b->stream = st;
+  // a copy of the PREVIOUS run's results to host memory may still be reading d_out / d_hits on the
+  // download stream: this run rewrites them only behind it (and those host results are stale then:
+  // irs_hip_batch_host_results refuses them until the next irs_hip_batch_results_to_host)
+  if (b->host_pending) {
+    if (!rt::stream_wait(st, b->ev_host)) return IRS_HIP_EHIP;
+    b->host_pending = false;
+  }
   const bool simd = b->seg->dev.layout == kSimd4;
   auto mark = [&](int i) { return !b->profile || rt::event_record(b->ev[i], st); };
   // the batch's tables (built in page-locked memory since create) go out: before the batch's
@@ -2885,11 +2956,10 @@ static int run_impl(irs_hip_batch* b, rt::stream_t st) {
 static int batch_run_impl(irs_hip_batch* b, void* stream) {
   if (!b) return IRS_HIP_EINVAL;
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
-  if (worker::enabled()) {   // (what the run returns is reported by the next call on the batch)
-    worker::submit(b, static_cast<rt::stream_t>(stream));
-    return IRS_HIP_OK;
-  }
-  return run_impl(b, static_cast<rt::stream_t>(stream));
+  rt::stream_t st = static_cast<rt::stream_t>(stream);
+  // (what a queued run returns is reported by the next call on the batch)
+  if (worker::wanted(b) && worker::submit(b, [b, st] { return run_impl(b, st); })) return IRS_HIP_OK;
+  return run_impl(b, st);
 }
 
 // k_select flagged a problem with the candidates of some query.
@@ -2920,7 +2990,23 @@ static int all_ranks_can(irs_hip_batch* b, int local_rc) {
 }
 
 static int recover_overflow(irs_hip_batch* b);
+static int recover_now(irs_hip_batch* b, uint32_t status);
+// The re-run of a batch whose threshold spans ranks issues collectives (the vote, the run's two
+// all-reduces): it takes its turn in the device's worker queue BEHIND the runs the caller has
+// submitted since — on every rank alike, because every rank makes the same calls in the same order
+// and reaches the same verdict — instead of racing them from the caller's thread.
 static int recover(irs_hip_batch* b, uint32_t status) {
+  if (b->comm && !b->phrase && worker::wanted(b) &&
+      worker::submit(b, [b, status] { return recover_now(b, status); })) {
+    std::unique_lock<std::mutex> lock(b->am);
+    b->acv.wait(lock, [&] { return !b->async_pending; });
+    const int rc = b->async_rc;
+    b->async_rc = IRS_HIP_OK;
+    return rc;
+  }
+  return recover_now(b, status);
+}
+static int recover_now(irs_hip_batch* b, uint32_t status) {
   ++b->reruns;
   if (std::getenv("IRS_HIP_TRACE")) {   // which units made the batch run again
     std::vector<uint32_t> cc(b->nq), oc(b->nq);
@@ -3250,6 +3336,9 @@ int irs_hip_batch_set_shared_threshold(irs_hip_batch* b, int enable) {
 }
 int irs_hip_batch_set_comm(irs_hip_batch* b, irs_hip_comm* comm) {
   return settled(b, [&] { return batch_set_comm_impl(b, comm); });
+}
+int irs_hip_batch_set_async(irs_hip_batch* b, int enable) {
+  return settled(b, [&] { return batch_set_async_impl(b, enable); });
 }
 int irs_hip_batch_path(irs_hip_batch* b, int* path) {
   return settled(b, [&] { return batch_path_impl(b, path); });

@@ -102,7 +102,8 @@ struct alignas(16) JoinWg {
   uint32_t last_doc;          // of the list
   uint32_t n_tiles;           // doc tiles of the segment
   uint32_t n;                 // postings of the list
-  uint32_t pad[3];
+  uint32_t dead_lo, dead_hi;  // DevSegment::dead (the deleted-docs bitmap; 0: none)
+  uint32_t pad;
 };
 static_assert(sizeof(JoinWg) == 112, "JoinWg");
 // Per (unit, term slot), parallel to DevQTerm: all k_join_score needs in one 32-byte record.
@@ -139,12 +140,19 @@ static_assert(kJoinRounds * kWaves * kJoinPerWave == kJoinBlocks, "k_join rounds
 __device__ __forceinline__ void join_emit(uint32_t* ent, uint32_t* bnd, uint32_t b, unsigned lane,
                                           uint32_t d0, uint32_t d1, uint32_t f0, uint32_t f1,
                                           uint32_t n0, uint32_t n1, bool v0, bool v1,
-                                          uint32_t prev /*0: the list's first posting*/) {
+                                          uint32_t prev /*0: the list's first posting*/,
+                                          const uint32_t* dead /*deleted docs, or null*/) {
   const uint32_t p0 = kBlock * b + 2u * lane;
   const uint32_t t0 = v0 ? (d0 - kDocMin) / kJoinTile : 0u;
   const uint32_t t1 = v1 ? (d1 - kDocMin) / kJoinTile : t0;
-  const uint32_t e0 = join_entry((d0 - kDocMin) - t0 * kJoinTile, f0, n0);
-  const uint32_t e1 = join_entry((d1 - kDocMin) - t1 * kJoinTile, f1, n1);
+  uint32_t e0 = join_entry((d0 - kDocMin) - t0 * kJoinTile, f0, n0);
+  uint32_t e1 = join_entry((d1 - kDocMin) - t1 * kJoinTile, f1, n1);
+  if (dead) {   // (wave-uniform) a deleted doc's posting keeps its place in the stream and adds to
+                // a dummy accumulator behind the tile's (JoinOff::dummy): no query ever sees it
+    const uint32_t nowhere = (4u * kJoinTile + 4u * lane) << 16;
+    if (v0 && doc_dead(dead, d0)) e0 = (e0 & 0xFFFFu) | nowhere;
+    if (v1 && doc_dead(dead, d1)) e1 = (e1 & 0xFFFFu) | nowhere;
+  }
   if (v1) {
     uint64_t both = (uint64_t(e1) << 32) | e0;
     __builtin_memcpy(ent + p0, &both, 8);
@@ -172,6 +180,7 @@ k_join(const JoinWg* wgs) {
   uint32_t* bnd = reinterpret_cast<uint32_t*>(W.bounds);
   const uint8_t* doc = reinterpret_cast<const uint8_t*>(W.doc);
   const bool tiny = W.pnorm != 0;
+  const uint32_t* dead = reinterpret_cast<const uint32_t*>((uint64_t(W.dead_hi) << 32) | W.dead_lo);
   const uint32_t nb = W.nblk + (W.tail_n ? 1u : 0u);
   uint32_t end = W.first + kJoinBlocks;
   if (end > nb) end = nb;
@@ -251,7 +260,7 @@ k_join(const JoinWg* wgs) {
       const uint32_t b = r0 + wv + kWaves * i;
       if (full[i])
         join_emit(ent, bnd, b, lane, d0[i], d1[i], f0[i], f1[i], n0[i], n1[i], true, true,
-                  b ? dir[i].prev_last : 0u);
+                  b ? dir[i].prev_last : 0u, dead);
     }
 #pragma unroll
     for (uint32_t i = 0; i < kJoinPerWave; ++i) dir[i] = next[i];
@@ -269,7 +278,7 @@ k_join(const JoinWg* wgs) {
     const uint8_t* tnorms = reinterpret_cast<const uint8_t*>(W.tail_norms);
     const uint32_t tn0 = (v0 && tiny) ? tnorms[i0] : 0u;
     const uint32_t tn1 = (v1 && tiny) ? tnorms[i0 + 1u] : 0u;
-    join_emit(ent, bnd, bt, lane, td0, td1, tf0, tf1, tn0, tn1, v0, v1, W.tail_base);
+    join_emit(ent, bnd, bt, lane, td0, td1, tf0, tf1, tn0, tn1, v0, v1, W.tail_base, dead);
   }
   // behind the list's last posting every remaining tile is empty: whoever holds the last block
   if (nb && nb - 1u >= W.first && nb - 1u < end && ((nb - 1u - W.first) % kWaves) == wv) {

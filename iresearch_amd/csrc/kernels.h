@@ -603,8 +603,9 @@ k_bit_union(DevSegment seg, const UnionWg* wgs, uint32_t* set32, uint64_t n_bits
   const unsigned lane = threadIdx.x & 63u;
   const UnionWg wg = wgs[blockIdx.x];
   const DevTerm t = seg.terms[wg.term];
+  const uint32_t* dead = seg.dead;   // (deleted docs never enter the set: SegmentReaderImpl::mask)
   auto mark = [&](uint32_t doc) {
-    if (doc < n_bits) atomicOr(&set32[doc >> 5], 1u << (doc & 31u));
+    if (doc < n_bits && !(dead && doc_dead(dead, doc))) atomicOr(&set32[doc >> 5], 1u << (doc & 31u));
   };
   uint32_t end = wg.first_block + kUnionBlocks;
   if (end > t.nblk) end = t.nblk;

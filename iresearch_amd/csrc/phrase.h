@@ -496,6 +496,7 @@ __device__ __forceinline__ void phrase_item(const ConjArgs& A, uint32_t pilot /*
     return 2u + (db ? 16u * db : 1u) + (fb ? 16u * fb : 1u);
   };
   uint32_t ld_d[2], ld_e[2];
+  bool live[2];   // the lane's lead docs that are docs of the segment at all (not deleted)
   {
     uint32_t f[2], p[2], estep;
     if (item < ld.nblk) {
@@ -527,9 +528,12 @@ __device__ __forceinline__ void phrase_item(const ConjArgs& A, uint32_t pilot /*
     for (int h = 0; h < 2; ++h) {
       const uint32_t idx = ld_e[h];
       docs[idx] = idx < n ? ld_d[h] : 0xFFFFFFFFu;
+      // a deleted doc (SegmentReaderImpl::mask) keeps its place among the lead docs but counts as
+      // not reached by the lead: it can never be a match
+      live[h] = idx < n && !(seg.dead && doc_dead(seg.dead, ld_d[h]));
       for (uint32_t i = 0; i < m; ++i) {
         W.pidx[i][idx] = i == lead ? p[h] : 0u;
-        W.tf[i][idx] = (i == lead && idx < n) ? f[h] : 0u;
+        W.tf[i][idx] = (i == lead && live[h]) ? f[h] : 0u;
       }
     }
     if (lane < (kConjWords + 4u) / 2u) {
@@ -546,11 +550,14 @@ __device__ __forceinline__ void phrase_item(const ConjArgs& A, uint32_t pilot /*
   const uint32_t span = dhi - dlo;
   const uint32_t s = span < 32u * kConjWords ? 0u
                      : 32u - uint32_t(__builtin_clz(span)) - (5u + uint32_t(__builtin_ctz(kConjWords)));
+  const bool masked = seg.dead != nullptr;   // (wave-uniform)
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     if (ld_e[h] < n) {
       const uint32_t bk = (ld_d[h] - dlo) >> s;
       atomicOr(&W.bm[0][bk >> 5], 1u << (bk & 31u));
+      // (conj.h: bm[0] ranks all lead docs; the first other term may only reach the live ones)
+      if (masked && live[h]) atomicOr(&W.bm[2][bk >> 5], 1u << (bk & 31u));
     }
   }
   wave::sync();
@@ -580,11 +587,11 @@ __device__ __forceinline__ void phrase_item(const ConjArgs& A, uint32_t pilot /*
     // alive = docs every term so far reached: the lead bitmap, then what the previous term
     // marked; `mark` collects what this term reaches
     const uint32_t mk = 1u + (step & 1u);
-    const uint32_t* alive = step == 0u ? W.bm[0] : W.bm[3u - mk];
+    const uint32_t* alive = step == 0u ? (masked ? W.bm[2] : W.bm[0]) : W.bm[3u - mk];
     uint32_t* mark = W.bm[mk];
     const uint8_t* apre = W.lpre;
-    if (step > 0u) {
-      if (lane < kConjWords / 2u) {
+    if (step > 0u || masked) {
+      if (step > 0u && lane < kConjWords / 2u) {
         mark[2u * lane] = 0u;
         mark[2u * lane + 1u] = 0u;
       }

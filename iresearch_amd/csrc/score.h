@@ -1033,6 +1033,7 @@ k_pilot(const uint32_t* units, const DevSegment* segs, const DevQuery* queries,
   const uint64_t norms1 = tiny ? reinterpret_cast<uint64_t>(seg.norms) + (kDocMin - seg.norm_min_doc) : 0;
   const uint64_t norm_count = tiny ? seg.norm_count - (kDocMin - seg.norm_min_doc) : 0;
   const uint32_t n_tiles = qd.n_tiles;
+  const uint32_t* dead = seg.dead;
   for (uint32_t i = tid; i < kBins; i += blockDim.x) hist[i] = 0u;
   for (uint32_t i = tid; i < uint32_t(TILE) + 64u; i += blockDim.x) sm.acc[i] = ACC(0);
   if (AND) {
@@ -1069,6 +1070,8 @@ k_pilot(const uint32_t* units, const DevSegment* segs, const DevQuery* queries,
       const uint32_t c = AND ? (sm.cnt[i >> 2] >> (8u * (i & 3u))) & 0xFFu : 0u;
       if (AND && (qd.op & 0xFF) == 1)  // AND / min-match: op = 1 | required matches << 8
         m = c >= query_need(qd.op);
+      // (a deleted doc never leaves the iterator: SegmentReaderImpl::mask)
+      if (dead && m) m = !doc_dead(dead, kDocMin + tile * uint32_t(TILE) + i);
       if (m) {
         ACC f = merged_fixed<ACC>(a, query_merge(qd.op));
         if (AND && query_min_both(qd.op) && c < 2u) f = ACC(0);
@@ -1228,6 +1231,7 @@ k_score(uint64_t args /*address of a ScoreArgs*/) {
     const uint64_t norms1 = tiny ? reinterpret_cast<uint64_t>(seg.norms) + (kDocMin - seg.norm_min_doc) : 0;
     const uint64_t norm_count = tiny ? seg.norm_count - (kDocMin - seg.norm_min_doc) : 0;
     const uint32_t n_tiles = qd.n_tiles;
+    const uint32_t* dead = seg.dead;   // the segment's deleted docs (null: none)
     const uint32_t ntile = tile0 >= n_tiles ? 0u
                            : ((n_tiles - tile0) < kChunkTiles ? (n_tiles - tile0) : kChunkTiles);
     const uint32_t bs = IRS_ARG(bstar)[q];
@@ -1340,6 +1344,14 @@ k_score(uint64_t args /*address of a ScoreArgs*/) {
           if (!two) {
 #pragma unroll
             for (int e = 4; e < 8; ++e) a[e] = ACC(0);
+          }
+          if (dead) {   // (wave-uniform) deleted docs look untouched: SegmentReaderImpl::mask.
+            // Bit (doc - kDocMin) = tile * TILE + i: four docs of a group are one aligned nibble
+            const uint32_t j = tile * uint32_t(TILE) + i, j2 = tile * uint32_t(TILE) + i2;
+            const uint32_t g0 = (dead[j >> 5] >> (j & 31u)) & 0xFu, g1 = (dead[j2 >> 5] >> (j2 & 31u)) & 0xFu;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              a[e] = (((e < 4 ? g0 : g1) >> (uint32_t(e) & 3u)) & 1u) ? ACC(0) : a[e];
           }
           if (AND && is_and) {
             // AND / min-match: a doc counts only with >= `need` matching terms; the others

@@ -124,7 +124,18 @@ struct DevSegment {
   // prepare_posting_norms): 128 bytes per directory row, and per entry of tail_docs
   const uint8_t* pnorm;
   const uint8_t* tail_norms;
+  // the segment's DocumentMask as a bitmap (null: no deleted docs): bit (doc - kDocMin) set = the
+  // doc is deleted — what SegmentReaderImpl::mask wraps every iterator with
+  // (core/index/segment_reader_impl.cpp:69-101, 286); padded so that the bits of a whole last doc
+  // tile are readable
+  const uint32_t* dead;
 };
+
+// MaskDocIterator::next (segment_reader_impl.cpp:74-82): `!mask_.contains(value())`
+__device__ __forceinline__ bool doc_dead(const uint32_t* dead, uint32_t doc) {
+  const uint32_t j = doc - kDocMin;
+  return (dead[j >> 5] >> (j & 31u)) & 1u;
+}
 
 struct DevQuery {
   int32_t op;

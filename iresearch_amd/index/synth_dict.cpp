@@ -483,4 +483,19 @@ int64_t irs_synth_segment_meta(const char* name, uint32_t name_len, uint64_t ver
   return int64_t(o.size());
 }
 
+// `.doc_mask` — DocumentMaskWriter::write (formats_10.cpp:3245-3268): header
+// ("iresearch_10_doc_mask", version 0), vint count, one vint per deleted doc id in the mask's
+// iteration order (a hash set's: any order), footer.
+int64_t irs_synth_document_mask(const uint32_t* docs, uint64_t n, uint8_t* out, uint64_t out_cap) {
+  if ((n && !docs) || n > 0xFFFFFFFFull) return -1;
+  Bytes o;
+  put_header(o, "iresearch_10_doc_mask", 0);
+  put_vint(o, uint32_t(n));
+  for (uint64_t i = 0; i < n; ++i) put_vint(o, docs[i]);
+  put_footer(o);
+  if (o.size() > out_cap) return -2;
+  std::memcpy(out, o.data(), o.size());
+  return int64_t(o.size());
+}
+
 }  // extern "C"

@@ -215,6 +215,9 @@ int64_t irs_synth_segment_meta(const char* name, uint32_t name_len, uint64_t ver
                                uint32_t has_column_store, const char* const* files,
                                const uint32_t* file_lens, uint32_t n_files, uint8_t* out,
                                uint64_t out_cap);
+/* `.doc_mask` of a segment (DocumentMaskWriter::write, formats_10.cpp:3245-3268): the ids of its
+ * deleted docs.  Returns bytes written, <0 on error / short buffer. */
+int64_t irs_synth_document_mask(const uint32_t* docs, uint64_t n, uint8_t* out, uint64_t out_cap);
 
 #ifdef __cplusplus
 }

@@ -164,7 +164,8 @@ class SegmentReader:
 
     def __init__(self, doc_file, metas, num_docs, layout, norms=None, norm_width=1,
                  docs_with_field=None, total_term_freq=0, device=0, has_freq=True, L=None,
-                 wand_count=0, pos_file=None, pos_features=0, norm_kind=0, wand_type=0):
+                 wand_count=0, pos_file=None, pos_features=0, norm_kind=0, wand_type=0,
+                 doc_mask=None):
         self.L = L or _lib.lib()
         self.doc_file = np.ascontiguousarray(doc_file, np.uint8)
         self.metas = np.zeros(len(metas), TERM_META)
@@ -176,6 +177,8 @@ class SegmentReader:
         self.docs_with_field = int(num_docs if docs_with_field is None else docs_with_field)
         self.total_term_freq = int(total_term_freq)
         self.pos_file = None if pos_file is None else np.ascontiguousarray(pos_file, np.uint8)
+        # the segment's DocumentMask (deleted doc ids): SegmentReaderImpl::mask, applied by every batch
+        self.doc_mask = None if doc_mask is None else np.ascontiguousarray(doc_mask, np.uint32)
         desc = SegmentDesc(
             device, layout, self.doc_file.ctypes.data, self.doc_file.size, num_docs,
             int(has_freq), None if self.norms is None else self.norms.ctypes.data, norm_width, 1,
@@ -183,18 +186,21 @@ class SegmentReader:
             self.metas.ctypes.data, len(self.metas), int(wand_count),
             None if self.pos_file is None else self.pos_file.ctypes.data,
             0 if self.pos_file is None else self.pos_file.size, int(pos_features), int(norm_kind),
-            int(wand_type))
+            int(wand_type),
+            None if self.doc_mask is None or not self.doc_mask.size else self.doc_mask.ctypes.data,
+            0 if self.doc_mask is None else self.doc_mask.size)
         h = C.c_void_p()
         _lib.check(self.L, self.L.irs_hip_segment_open(C.byref(desc), C.byref(h)),
                    "irs_hip_segment_open")
         self.handle = h
 
     @classmethod
-    def from_synth(cls, seg, device=0, L=None, has_freq=True):
+    def from_synth(cls, seg, device=0, L=None, has_freq=True, doc_mask=None):
         return cls(seg.doc_file, seg.metas, seg.num_docs, seg.layout, seg.norms, 1,
                    seg.docs_with_field, seg.total_term_freq, device, has_freq, L,
                    getattr(seg, "wand_count", 0), getattr(seg, "pos_file", None),
-                   wand_type=getattr(seg, "wand_type", 0))
+                   wand_type=getattr(seg, "wand_type", 0),
+                   doc_mask=getattr(seg, "doc_mask", None) if doc_mask is None else doc_mask)
 
     def close(self):
         if self.handle:
@@ -209,6 +215,10 @@ class SegmentReader:
 
     def device_bytes(self) -> int:
         return self.L.irs_hip_segment_device_bytes(self.handle)
+
+    def live_docs_count(self) -> int:
+        """SubReader::live_docs_count: docs that are not in the segment's doc_mask."""
+        return self.L.irs_hip_segment_live_docs(self.handle)
 
     def decode_term(self, term: int, want_freq: bool = True):
         n = int(self.metas[term]["docs_count"])
@@ -467,6 +477,13 @@ class QueryBatch:
         """PATH_AUTO / PATH_ITEMS / PATH_JOINED (irs_hip_batch_set_path)."""
         _lib.check(self.L, self.L.irs_hip_batch_set_path(self.handle, int(path)),
                    "irs_hip_batch_set_path")
+        return self
+
+    def set_async(self, enable=True):
+        """Hand the host half of run() to the library's worker thread (1), keep it on the caller's
+        thread (0), or follow the process default (-1): irs_hip_batch_set_async."""
+        _lib.check(self.L, self.L.irs_hip_batch_set_async(self.handle, int(enable)),
+                   "irs_hip_batch_set_async")
         return self
 
     def path(self):

@@ -98,6 +98,8 @@ def lib():
         L.irs_synth_term_meta_stream.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                                  C.c_uint32, C.c_void_p, C.c_uint64]
         L.irs_synth_term_meta_stream.restype = C.c_int64
+        L.irs_synth_document_mask.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+        L.irs_synth_document_mask.restype = C.c_int64
         L.irs_synth_term_dictionary.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                                 C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                                 C.c_uint32, C.c_void_p, C.c_uint64,
@@ -134,6 +136,7 @@ class SynthSegment:
     positions: dict | None = None        # rank -> u32[Σ freqs] positions, doc after doc, when kept
     pos_one_based: bool = False          # formats 1_0..1_2: one-based position storage
     wand_type: int = 0                   # Scorer::WandType of the scorer that wrote the wand data
+    doc_mask: np.ndarray | None = None   # uint32 ids of deleted docs (the segment's DocumentMask)
 
     def meta(self, rank: int) -> np.void:
         return self.metas[rank - 1]
@@ -358,6 +361,16 @@ def term_dictionary(terms, metas, has_freq=True, has_pos=False, has_pay=False, m
     if n < 0:
         raise ValueError("irs_synth_term_dictionary failed: %d" % n)
     return out[:n].copy(), int(root.value)
+
+
+def document_mask(docs) -> np.ndarray:
+    """`.doc_mask` (DocumentMaskWriter::write, formats_10.cpp:3245-3268) of the deleted doc ids."""
+    d = np.ascontiguousarray(docs, np.uint32)
+    out = np.zeros(5 * d.size + 128, np.uint8)
+    n = lib().irs_synth_document_mask(d.ctypes.data if d.size else None, d.size, out.ctypes.data, out.size)
+    if n < 0:
+        raise ValueError("irs_synth_document_mask failed: %d" % n)
+    return out[:n].copy()
 
 
 def norm2_header(width: int, lo: int, hi: int) -> bytes:

@@ -69,8 +69,11 @@ def split_freq(text: str):
 
 
 def parse_tasks(lines, tasks_per_category: int = 1 << 30):
-    """prepareTasks + the text handling of prepareFilter -> [Task]; unknown categories and
-    lines that do not match are dropped like there."""
+    """prepareTasks + the text handling of prepareFilter -> [Task]; lines that do not match are
+    dropped like there.  One difference: the reference files a line of an unknown category under
+    UNKNOWN, counts it and keeps it in the list, where it later yields a null filter and is skipped
+    (index-search.cpp:451-473, 240-449) — here such a line is dropped at once; the tasks that
+    execute are the same."""
     counts: dict = {}
     out = []
     for line in lines:
@@ -91,7 +94,10 @@ def parse_tasks(lines, tasks_per_category: int = 1 << 30):
             if cat in AND:
                 toks = [w[1:] for w in toks]              # skip '+' at the start of the term
             if cat in MINMATCH:
-                t.min_match, toks = int(toks[0]), toks[1:]
+                try:          # (std::stoi of the first token; a line it cannot parse is skipped)
+                    t.min_match, toks = int(toks[0]), toks[1:]
+                except (ValueError, IndexError):
+                    continue
             t.words = toks
             # `freq=a|b|c` (phrase: phrase | word | word) or `freq=a freq=b ...`
             nums = [int(x) for x in re.findall(r"\d+", " ".join(re.findall(r"freq=[\d|]+", note)))]

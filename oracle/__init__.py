@@ -30,7 +30,8 @@ class Segment(C.Structure):
     _fields_ = [("doc_file", C.c_void_p), ("doc_file_len", C.c_uint64), ("layout", C.c_int32),
                 ("num_docs", C.c_uint32), ("norms", C.c_void_p), ("norm_width", C.c_uint32),
                 ("wand_count", C.c_uint32), ("pos_file", C.c_void_p), ("pos_file_len", C.c_uint64),
-                ("pos_one_based", C.c_int32)]
+                ("pos_one_based", C.c_int32), ("doc_mask", C.c_void_p),
+                ("doc_mask_count", C.c_uint64)]
 
 
 class Scorer(C.Structure):
@@ -140,6 +141,8 @@ def lib(path=None):
         L.orc_encode_term_meta.restype = C.c_int64
         L.orc_decode_term_meta.argtypes = [vp, u64, C.c_int, C.c_int, C.c_int, vp]
         L.orc_decode_term_meta.restype = C.c_int64
+        L.orc_read_document_mask.argtypes = [vp, u64, vp, u64]
+        L.orc_read_document_mask.restype = C.c_int64
         L.orc_walk_term_dictionary.argtypes = [vp, u64, u64, C.c_int, C.c_int, C.c_int,
                                                C.POINTER(u32), C.POINTER(u64), vp, vp, vp]
         L.orc_walk_term_dictionary.restype = C.c_int
@@ -293,7 +296,7 @@ class SegmentView:
     """Keeps the numpy buffers of one segment alive next to the C struct."""
 
     def __init__(self, doc_file, norms, layout, num_docs, docs_with_field, total_term_freq,
-                 norm_width=1, wand_count=0, pos_file=None, pos_one_based=False):
+                 norm_width=1, wand_count=0, pos_file=None, pos_one_based=False, doc_mask=None):
         self.doc_file = np.ascontiguousarray(doc_file, np.uint8)
         self.norms = None if norms is None else np.ascontiguousarray(norms, np.uint8)
         self.layout, self.num_docs, self.norm_width = layout, num_docs, norm_width
@@ -301,6 +304,8 @@ class SegmentView:
         self.wand_count = wand_count
         self.pos_file = None if pos_file is None else np.ascontiguousarray(pos_file, np.uint8)
         self.pos_one_based = bool(pos_one_based)
+        # the segment's DocumentMask (deleted doc ids): every search masks its iterator with it
+        self.doc_mask = None if doc_mask is None else np.ascontiguousarray(doc_mask, np.uint32)
 
     def struct(self) -> Segment:
         return Segment(self.doc_file.ctypes.data, self.doc_file.size, self.layout, self.num_docs,
@@ -308,7 +313,9 @@ class SegmentView:
                        self.wand_count,
                        None if self.pos_file is None else self.pos_file.ctypes.data,
                        0 if self.pos_file is None else self.pos_file.size,
-                       int(self.pos_one_based))
+                       int(self.pos_one_based),
+                       None if self.doc_mask is None or not self.doc_mask.size else self.doc_mask.ctypes.data,
+                       0 if self.doc_mask is None else self.doc_mask.size)
 
 
 def _metas_array(metas) -> np.ndarray:
@@ -444,6 +451,17 @@ def decode_term_metas(stream, n: int, has_freq: bool = True, has_pos: bool = Fal
         out[i] = state[0]
     assert at == buf.size, (at, buf.size)
     return out
+
+
+def read_document_mask(dm) -> np.ndarray:
+    """DocumentMaskReader::read (formats_10.cpp:3275-3312): the deleted doc ids of a `.doc_mask`."""
+    b = np.ascontiguousarray(dm, np.uint8)
+    n = lib().orc_read_document_mask(b.ctypes.data, b.size, None, 0)
+    if n < 0:
+        raise ValueError("orc_read_document_mask: corrupt")
+    out = np.zeros(max(int(n), 1), np.uint32)
+    lib().orc_read_document_mask(b.ctypes.data, b.size, out.ctypes.data, out.size)
+    return out[:n]
 
 
 def walk_term_dictionary(tm, root_start: int, has_freq=True, has_pos=False, has_pay=False):

@@ -425,4 +425,20 @@ int orc_read_segment_meta(const uint8_t* sm, uint64_t len, uint64_t* docs_count,
   return 0;
 }
 
+// DocumentMaskReader::read (core/formats/formats_10.cpp:3275-3312): checksum, header
+// ("iresearch_10_doc_mask", versions 0..0), vint count, `count` vint doc ids, footer.
+int64_t orc_read_document_mask(const uint8_t* dm, uint64_t len, uint32_t* docs, uint64_t cap) {
+  const size_t hl = header_len(dm, len, "iresearch_10_doc_mask", 0);
+  if (!hl || !footer_ok(dm, len)) return -1;
+  Cursor c{dm + hl, dm + len - 16};
+  const uint64_t count = c.vint();
+  for (uint64_t i = 0; i < count; ++i) {
+    const uint32_t d = c.vint();
+    if (c.bad) return -1;
+    if (docs && i < cap) docs[i] = d;
+  }
+  if (c.bad || c.p != c.end) return -1;
+  return int64_t(count);
+}
+
 }  // extern "C"

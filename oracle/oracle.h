@@ -158,6 +158,10 @@ typedef struct orc_segment {
   const uint8_t* pos_file; /* `.pos` image of a field with POS, or NULL */
   uint64_t pos_file_len;
   int32_t pos_one_based;   /* formats 1_0..1_2 */
+  const uint32_t* doc_mask; /* the segment's DocumentMask (deleted doc ids, any order) or NULL:
+                               every iterator is wrapped as SegmentReaderImpl::mask does
+                               (core/index/segment_reader_impl.cpp:69-101, 286) */
+  uint64_t doc_mask_count;
 } orc_segment;
 
 typedef struct orc_scorer {
@@ -269,6 +273,9 @@ int orc_read_term_index(const uint8_t* ti, uint64_t len, orc_field_record* out, 
 /* SegmentMetaReader::read (formats_10.cpp:3147-3218). */
 int orc_read_segment_meta(const uint8_t* sm, uint64_t len, uint64_t* docs_count,
                           uint64_t* live_docs_count, uint32_t* has_column_store, uint32_t* n_files);
+/* DocumentMaskReader::read (formats_10.cpp:3275-3312): the deleted doc ids of `.doc_mask` in file
+ * order; returns their number (at most `cap` are written), <0 corrupt. */
+int64_t orc_read_document_mask(const uint8_t* dm, uint64_t len, uint32_t* docs, uint64_t cap);
 
 #ifdef __cplusplus
 }

@@ -314,11 +314,28 @@ void run_and(std::vector<Sub>& itrs, int merge, Emit&& emit) {
   }
 }
 
+// SegmentReaderImpl::mask (core/index/segment_reader_impl.cpp:286-292) -> MaskDocIterator
+// (:69-101): next() skips every doc the segment's DocumentMask contains.
+struct DocMask {
+  std::vector<uint64_t> bits;
+  explicit DocMask(const orc_segment& seg) {
+    if (!seg.doc_mask || !seg.doc_mask_count) return;   // docs_mask_.empty(): the iterator as it is
+    bits.assign(size_t(seg.num_docs) / 64 + 2, 0);
+    for (uint64_t i = 0; i < seg.doc_mask_count; ++i) {
+      const uint32_t d = seg.doc_mask[i];
+      if (d <= seg.num_docs) bits[d >> 6] |= 1ull << (d & 63u);
+    }
+  }
+  bool contains(uint32_t doc) const {
+    return !bits.empty() && (doc >> 6) < bits.size() && ((bits[doc >> 6] >> (doc & 63u)) & 1u);
+  }
+};
+
 // filter->execute(segment) for by_term / Or / And
 template<typename Emit>
-void execute_segment(const orc_segment& seg, const orc_term_meta* metas,
-                     uint32_t n_terms, int32_t op, const orc_scorer& scorer,
-                     const float* boosts, const TermStats* stats, Emit&& emit) {
+void execute_segment_unmasked(const orc_segment& seg, const orc_term_meta* metas,
+                              uint32_t n_terms, int32_t op, const orc_scorer& scorer,
+                              const float* boosts, const TermStats* stats, Emit&& emit) {
   // op = ORC_OP_OR | ORC_OP_AND | ORC_OP_MINMATCH + (min_match << 8), + (ORC_MERGE_* << 24)
   const int merge = (op >> 24) & 3;   // boolean_filter::merge_type(), boolean_filter.hpp:39-43
   op &= 0xFFFFFF;
@@ -371,6 +388,18 @@ void execute_segment(const orc_segment& seg, const orc_term_meta* metas,
   } else {
     run_block_or(itrs, merge, emit);  // :1465
   }
+}
+
+// segment.mask(filter->execute(segment))
+template<typename Emit>
+void execute_segment(const orc_segment& seg, const orc_term_meta* metas,
+                     uint32_t n_terms, int32_t op, const orc_scorer& scorer,
+                     const float* boosts, const TermStats* stats, Emit&& emit) {
+  const DocMask mask(seg);
+  execute_segment_unmasked(seg, metas, n_terms, op, scorer, boosts, stats,
+                           [&](uint32_t doc, float score_value) {
+                             if (!mask.contains(doc)) emit(doc, score_value);
+                           });
 }
 
 // ---------------------------------------------------------------------------
@@ -428,6 +457,7 @@ template<typename Emit>
 void execute_phrase(const orc_segment& seg, const orc_term_meta* metas, uint32_t n_terms,
                     const uint32_t* offsets, Emit&& emit) {
   if (!seg.pos_file) return;
+  const DocMask mask(seg);   // segment.mask(...): a deleted doc never leaves the iterator
   std::vector<PSub> subs(n_terms);
   for (uint32_t t = 0; t < n_terms; ++t) {
     if (metas[t].docs_count == 0) return;  // phrase state absent for the segment
@@ -457,7 +487,7 @@ void execute_phrase(const orc_segment& seg, const orc_term_meta* metas, uint32_t
       }
     }
     const uint32_t pf = phrase_frequency(phrase);
-    if (pf) emit(target, pf);
+    if (pf && !mask.contains(target)) emit(target, pf);
   }
 }
 

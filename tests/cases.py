@@ -1671,6 +1671,90 @@ def case_phrase_queries(L, layout, num_docs=30_000):
     sr.close()
 
 
+def case_doc_mask(L, layout=synth.LAYOUT_SIMD4, num_docs=70_000, max_rank=256):
+    """A segment with deleted documents (irs_hip_segment_desc.doc_mask — the DocumentMask the
+    reference wraps every iterator with: SegmentReaderImpl::mask -> MaskDocIterator,
+    core/index/segment_reader_impl.cpp:69-101, 286): 5 % random deletions plus the first doc, the
+    last doc, a run longer than a posting block and every doc of one term.  Totals, doc sets, scores
+    and order equal the oracle's masked run on every execution path (work items, joined streams,
+    block-driven conjunctions with and without block-max pruning, phrases, 64-bit accumulators);
+    bit_union leaves the deleted docs out; the postings-level surfaces are not filtered."""
+    import os
+    seg = synth.build_segment(num_docs, max_rank, layout=layout, with_positions=True)
+    rng = np.random.default_rng(2026)
+    victim = max_rank - 3                                   # a rare term: all of its docs go
+    vd, _ = oracle.decode_term(seg.doc_file, seg.metas[victim], layout)
+    mask = np.concatenate([
+        rng.choice(num_docs, num_docs // 20, replace=False).astype(np.uint32) + 1,
+        np.array([1, num_docs, 0, num_docs + 5, 7, 7], np.uint32),     # ends, out of range, twice
+        np.arange(20_000, 20_400, dtype=np.uint32), vd.astype(np.uint32)])
+    rng.shuffle(mask)
+    gone = np.unique(mask[(mask >= 1) & (mask <= num_docs)])
+    plain = search.SegmentReader.from_synth(seg, L=L)        # the same segment without its mask
+    seg.doc_mask = mask
+    sr = search.SegmentReader.from_synth(seg, L=L)
+    assert sr.live_docs_count() == num_docs - gone.size and plain.live_docs_count() == num_docs
+    st = [parity.segment_stats(seg)]
+    ranks = synth.make_queries(5, 8, 2, max_rank, synth.SEED + 9)
+    filters = [Or([by_term(int(r) - 1) for r in row]) for row in ranks]
+    filters += standard_filters(max_rank, n_or8=1)
+    filters += [by_term(victim), And([by_term(victim), by_term(0)]), Or([by_term(victim), by_term(victim - 1)]),
+                And([by_term(max_rank - 1), by_term(0)]), And([by_term(0), by_term(1)]),
+                And([by_term(0), by_term(1), by_term(2), by_term(3), by_term(4)])]
+    for scorer in (BM25(), TFIDF(True), TFIDF(False)):
+        for path in (_lib.PATH_ITEMS, _lib.PATH_JOINED, _lib.PATH_AUTO):
+            for k in (25, 1000):
+                b = sr.batch(search.prepare(filters, scorer, st), k).set_path(path)
+                h, c, t = b.run().results()
+                parity.check_single_segment(seg, filters, scorer, k, h, c, t)
+                b.close()
+        # (the victim's docs are all gone)
+        assert int(t[len(filters) - 6]) == 0 and int(t[len(filters) - 5]) == 0
+    # ... the mask really changed something: the unmasked reader counts more
+    b = plain.batch(search.prepare(filters[:5], BM25(), st), 25)
+    _, _, t_plain = b.run().results()
+    b.close()
+    b = sr.batch(search.prepare(filters[:5], BM25(), st), 25)
+    _, _, t_masked = b.run().results()
+    b.close()
+    assert (t_masked < t_plain).all()
+    # block-max pruning (ExecutionContext::wand) and 64-bit accumulators
+    b = sr.batch(search.prepare(filters, BM25(), st), 25).set_wand(True)
+    h, c, t = b.run().results()
+    b.close()
+    b = sr.batch(search.prepare(filters, BM25(), st), 25)
+    h0, c0, _ = b.run().results()
+    b.close()
+    assert np.array_equal(h, h0) and np.array_equal(c, c0)     # wand == exhaustive, masked too
+    os.environ["IRS_HIP_ACC"] = "64"
+    try:
+        b = sr.batch(search.prepare(filters, BM25(), st), 25)
+        h, c, t = b.run().results()
+        parity.check_single_segment(seg, filters, BM25(), 25, h, c, t)
+        b.close()
+    finally:
+        del os.environ["IRS_HIP_ACC"]
+    # by_phrase
+    phrases = [by_phrase([0, 1]), by_phrase([2, 0]), by_phrase([1, 4, 0]), by_phrase([5]),
+               by_phrase([victim]), by_phrase([max_rank - 1, 0]), by_phrase([0, 3], [0, 3])]
+    for scorer in (BM25(), TFIDF(False)):
+        for k in (10, 1000):
+            run_phrases(L, seg, phrases, scorer, k, sr=sr)
+    # bit_union: what segment.mask(lazy_bitset_iterator) yields
+    n_words = (num_docs + 64) // 64
+    terms = [0, 5, victim, max_rank - 1]
+    got, cnt = sr.bit_union(terms, n_words)
+    want, ocnt = oracle.bit_union(seg.doc_file, [seg.metas[x] for x in terms], layout, True, n_words)
+    dead = np.zeros(n_words, np.uint64)
+    np.bitwise_or.at(dead, gone // 64, np.uint64(1) << (gone % 64).astype(np.uint64))
+    assert cnt == ocnt and np.array_equal(got, want & ~dead) and not np.array_equal(got, want)
+    # postings-level surfaces are the postings_reader's: not filtered
+    d, f = sr.decode_term(victim)
+    assert np.array_equal(d, vd)
+    sr.close()
+    plain.close()
+
+
 def case_phrase_ragged(L, layout=synth.LAYOUT_SIMD4, one_based=False):
     """Explicit lists: single-doc terms, lists shorter than a block, phrases that exist
     only across block / tile borders, very frequent terms in one doc."""

@@ -379,6 +379,111 @@ int main(int argc, char** argv) {
         REQUIRE(std::fabs(res.of(0, q)[i].score - want[size_t(i)].score) <= 1e-5f * std::fabs(want[size_t(i)].score));
     }
   }
+  // ---- the same segment with DELETED documents: `.doc_mask` (+ the segment meta's live count) ---
+  // emitter (DocumentMaskWriter::write) -> the product's reader and the oracle's twin
+  // (DocumentMaskReader::read) -> irs_hip_segment_desc::doc_mask: every query behaves like an
+  // iterator behind SegmentReaderImpl::mask (segment_reader_impl.cpp:69-101, 286)
+  {
+    std::vector<uint32_t> gone;
+    uint64_t state = 88172645463325252ull;
+    for (uint32_t d = 1; d <= docs; ++d) {
+      state ^= state << 13; state ^= state >> 7; state ^= state << 17;
+      if (state % 20 == 0 || d == 1 || d == docs || (d >= 5000 && d < 5300)) gone.push_back(d);
+    }
+    std::reverse(gone.begin(), gone.end());   // (a hash set's order is no order)
+    std::vector<uint8_t> dm(5 * gone.size() + 128), sm2(1024);
+    const int64_t dm_len = irs_synth_document_mask(gone.data(), gone.size(), dm.data(), dm.size());
+    REQUIRE(dm_len > 0);
+    const char* names2[] = {"_1.doc", "_1.pos", "_1.tm", "_1.ti", "_1.csd", "_1.csi", "_1.2.doc_mask"};
+    const uint32_t lens2[] = {6, 6, 5, 5, 6, 6, 13};
+    const int64_t sm2_len = irs_synth_segment_meta("_1", 2, 2, docs, docs - gone.size(), uint64_t(doc_file_len), 1,
+                                                   names2, lens2, 7, sm2.data(), sm2.size());
+    REQUIRE(sm2_len > 0);
+    REQUIRE(format10::read_document_mask(dm.data(), uint64_t(dm_len)) == gone);
+    std::vector<uint32_t> ogone(gone.size());
+    REQUIRE(orc_read_document_mask(dm.data(), uint64_t(dm_len), ogone.data(), ogone.size()) == int64_t(gone.size()));
+    REQUIRE(ogone == gone);
+    {   // a damaged mask file is refused; so is one that disagrees with the segment meta
+      std::vector<uint8_t> bad(dm.begin(), dm.begin() + dm_len);
+      bad[bad.size() / 2] ^= 4;
+      bool threw = false;
+      try { (void)format10::read_document_mask(bad.data(), bad.size()); } catch (const index_error&) { threw = true; }
+      REQUIRE(threw && orc_read_document_mask(bad.data(), bad.size(), nullptr, 0) < 0);
+    }
+    format10::FieldFiles masked = files;
+    masked.field = "body";
+    masked.doc_mask = dm.data();  masked.doc_mask_len = uint64_t(dm_len);
+    format10::OpenedField of;
+    {
+      bool threw = false;   // (`files.sm` still says: every doc is live)
+      try { (void)format10::describe_field(masked, 0, of); } catch (const index_error&) { threw = true; }
+      REQUIRE(threw);
+    }
+    masked.sm = sm2.data();  masked.sm_len = uint64_t(sm2_len);
+    const irs_hip_segment_desc dd = format10::describe_field(masked, 0, of);
+    REQUIRE(dd.doc_mask_count == gone.size() && dd.num_docs == docs);
+    SegmentReader reader(dd);
+    REQUIRE(reader.live_docs_count() == docs - gone.size());
+    std::vector<uint32_t> ordinal_of(body.max_rank, IRS_HIP_NO_TERM);
+    for (uint32_t t = 0, o = 0; t < body.max_rank; ++t)
+      if (body.metas[t].docs_count) ordinal_of[t] = o++;
+    std::vector<filter> filters;
+    std::vector<uint32_t> ranks(kQueries * 2);
+    REQUIRE(irs_synth_queries(20260926 + 7, kQueries, 2, 4, body.max_rank, ranks.data()) == 0);
+    for (uint32_t q = 0; q < kQueries; ++q) {
+      if (q % 3 == 2) {
+        And flt;
+        for (int t = 0; t < 2; ++t) flt.subs.push_back(by_term{ordinal_of[ranks[q * 2 + t] - 1]});
+        filters.push_back(flt);
+      } else {
+        Or flt;
+        for (int t = 0; t < 2; ++t) flt.subs.push_back(by_term{ordinal_of[ranks[q * 2 + t] - 1]});
+        filters.push_back(flt);
+      }
+    }
+    const SegmentStats stats{of.docs_with_field, of.total_term_freq, of.metas.data(), uint32_t(of.metas.size())};
+    const BM25 scorer;
+    QueryBatch batch({&reader}, prepare(filters, scorer, {stats}), kTop);
+    const auto res = batch.run().results();
+    orc_segment view{};
+    view.doc_file = doc_file.data();
+    view.doc_file_len = uint64_t(doc_file_len);
+    view.layout = ORC_LAYOUT_SIMD4;
+    view.num_docs = docs;
+    view.norms = norms;
+    view.norm_width = 1;
+    view.doc_mask = gone.data();
+    view.doc_mask_count = gone.size();
+    const uint64_t dwf = of.docs_with_field, ttf = of.total_term_freq;
+    const orc_scorer osc{ORC_SCORER_BM25, scorer.k(), scorer.b(), 0};
+    uint64_t fewer = 0;
+    for (uint32_t q = 0; q < kQueries; ++q) {
+      orc_term_meta om[2];
+      float boosts[2] = {1.f, 1.f};
+      for (int t = 0; t < 2; ++t) std::memcpy(&om[t], &body.metas[ranks[q * 2 + t] - 1], sizeof om[t]);
+      std::vector<orc_hit> want(kTop);
+      uint64_t want_total = 0, unmasked_total = 0;
+      const int32_t op = q % 3 == 2 ? ORC_OP_AND : ORC_OP_OR;
+      const int64_t n = orc_search(&view, 1, om, 2, op, &osc, boosts, &dwf, &ttf, kTop, want.data(), &want_total);
+      REQUIRE(n >= 0 && res.total(0, q) == want_total && res.count(0, q) == uint32_t(n));
+      std::sort(want.begin(), want.begin() + n, [](const orc_hit& x, const orc_hit& y) { return x.score > y.score; });
+      for (int64_t i = 0; i < n; ++i) {
+        REQUIRE(std::fabs(res.of(0, q)[i].score - want[size_t(i)].score) <= 1e-5f * std::fabs(want[size_t(i)].score));
+        REQUIRE(!std::binary_search(gone.rbegin(), gone.rend(), res.of(0, q)[i].doc));
+      }
+      orc_segment plain = view;
+      plain.doc_mask = nullptr;
+      plain.doc_mask_count = 0;
+      (void)orc_search(&plain, 1, om, 2, op, &osc, boosts, &dwf, &ttf, kTop, want.data(), &unmasked_total);
+      fewer += unmasked_total - want_total;
+    }
+    REQUIRE(fewer > 0);
+    // the unscored expansion filters leave the deleted docs out too
+    const by_prefix p{std::string(of.terms[3].substr(0, 1))};
+    const DocSet set = execute_unscored(reader, of.terms, docs, p);
+    for (uint32_t d : gone) REQUIRE(!set.contains(d));
+    REQUIRE(set.count() > 0);
+  }
   // a damaged term index is refused
   {
     std::vector<uint8_t> bad(ti.begin(), ti.begin() + ti_len);

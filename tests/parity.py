@@ -29,7 +29,8 @@ def oracle_view(seg) -> oracle.SegmentView:
     return oracle.SegmentView(seg.doc_file, seg.norms, seg.layout, seg.num_docs,
                               seg.docs_with_field, seg.total_term_freq,
                               getattr(seg, "norm_width", 1), getattr(seg, "wand_count", 0),
-                              getattr(seg, "pos_file", None), getattr(seg, "pos_one_based", False))
+                              getattr(seg, "pos_file", None), getattr(seg, "pos_one_based", False),
+                              getattr(seg, "doc_mask", None))
 
 
 def segment_stats(seg) -> search.SegmentStats:

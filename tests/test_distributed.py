@@ -289,6 +289,36 @@ def _threshold_worker(rank, world, port, sim_path, out_dir):
         np.save(os.path.join(out_dir, "B_hits.npy"), oh.numpy())
         np.save(os.path.join(out_dir, "B_counts.npy"), oc.numpy())
     b.close()
+    # ---- C: batch i is re-run WHILE batch i + 1 is already submitted (a serving loop pipelined one
+    # deep: run(cur), then deliver(prev)).  Both batches issue collectives on the same communicator;
+    # the recovery of i takes its turn in the library's per-device queue behind the run of i + 1 on
+    # every rank alike (issued from the caller's thread it raced the worker's run)
+    prep2 = search.prepare(filters[::-1], BM25(1.2, 0.0), [stats[r] for r in range(world)])
+    alone = search.QueryBatch([sr], prep2, 50).set_comm(comm)
+    alone.run()
+    ex2 = distributed.TopkExchange(L, 0, world, rank, world, len(filters), 50, "cpu")
+    alone.results_to_device(*ex2.slot(0))
+    want2 = [t.clone() for t in ex2.run()]
+    alone.close()
+    for use_worker in (1, 0):
+        b1 = search.QueryBatch([sr], prep, k).configure(0, 16, 0).set_comm(comm).set_async(use_worker)
+        b2 = search.QueryBatch([sr], prep2, 50).set_comm(comm).set_async(use_worker)
+        b1.run()
+        if use_worker:
+            b2.run()          # submitted before anybody looked at b1's status
+        ex1 = distributed.TopkExchange(L, 0, world, rank, world, len(filters), k, "cpu")
+        b1.results_to_device(*ex1.slot(0))      # verifies b1 -> collective re-run
+        assert b1.reruns() == 1
+        if not use_worker:
+            b2.run()
+        ex2 = distributed.TopkExchange(L, 0, world, rank, world, len(filters), 50, "cpu")
+        b2.results_to_device(*ex2.slot(0))
+        assert b2.reruns() == 0
+        got1, got2 = ex1.run(), ex2.run()
+        assert all(torch.equal(x, y) for x, y in zip(got1, (oh, osg, oc))), use_worker
+        assert all(torch.equal(x, y) for x, y in zip(got2, want2)), use_worker
+        b1.close()
+        b2.close()
     sr.close()
     comm.close()
     dist.barrier()

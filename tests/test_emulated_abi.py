@@ -117,6 +117,11 @@ def test_paths_agree(simlib, layout):
     cases.case_paths_agree(simlib, layout=layout)
 
 
+@pytest.mark.parametrize("layout", [0, 1])
+def test_deleted_documents(simlib, layout):
+    cases.case_doc_mask(simlib, layout=layout, num_docs=40_000, max_rank=128)
+
+
 def test_join_counts(simlib):
     cases.case_join_counts(simlib)
 

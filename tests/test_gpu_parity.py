@@ -190,6 +190,13 @@ def test_paths_agree(gpulib, layout):
     cases.case_paths_agree(gpulib, layout=layout)
 
 
+@pytest.mark.parametrize("layout", [0, 1])
+def test_deleted_documents(gpulib, layout):
+    """5 % random deletions (+ runs, ends, a whole term): totals, doc sets and top-k equal the
+    oracle's masked run on every path."""
+    cases.case_doc_mask(gpulib, layout=layout, num_docs=400_000, max_rank=512)
+
+
 def test_join_counts(gpulib):
     cases.case_join_counts(gpulib, num_docs=900_000, max_rank=1024)
 

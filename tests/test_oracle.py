@@ -299,3 +299,35 @@ def test_term_dictionary_and_columnstore_files():
             assert (vb, mn, payload) == (width, 1, hdr) and np.array_equal(values, vals)
         with pytest.raises(ValueError):
             oracle.read_fixed_column(csi, csd, cid + 1)   # a mask column: not a fixed-length one
+
+
+def test_document_mask_file_writer_and_reader_twins():
+    """`.doc_mask`: the emitter (DocumentMaskWriter::write, formats_10.cpp:3245-3268) against the
+    oracle's reader (DocumentMaskReader::read :3275-3312); the product's host reader is the third
+    (tests/cpp/test_segment.cpp).  And what the mask means to a search: MaskDocIterator."""
+    rng = np.random.default_rng(4)
+    for n in (0, 1, 127, 128, 5000):
+        docs = rng.integers(1, 1 << 31, n).astype(np.uint32)
+        f = synth.document_mask(docs)
+        assert np.array_equal(oracle.read_document_mask(f), docs)
+        if n:
+            bad = f.copy()
+            bad[len(bad) // 2] ^= 1
+            with pytest.raises(ValueError):
+                oracle.read_document_mask(bad)
+    # a masked search = the unmasked one without the deleted docs (MaskDocIterator::next)
+    seg = synth.build_segment(30_000, 64)
+    gone = np.unique(rng.integers(1, 30_001, 3000).astype(np.uint32))
+    import parity
+    metas = parity.metas_for(seg, [0, 5, 9])
+    sc = oracle.Scorer(oracle.SCORER_BM25, 1.2, 0.75, 0)
+    plain = parity.oracle_view(seg)
+    seg.doc_mask = gone
+    masked = parity.oracle_view(seg)
+    dwt = [int(m["docs_count"]) for m in metas]
+    s0, m0 = oracle.score_all(plain, metas, oracle.OP_OR, sc, seg.docs_with_field, dwt, seg.total_term_freq)
+    s1, m1 = oracle.score_all(masked, metas, oracle.OP_OR, sc, seg.docs_with_field, dwt, seg.total_term_freq)
+    keep = np.ones(len(m0), bool)
+    keep[gone] = False
+    assert np.array_equal(m1.astype(bool), m0.astype(bool) & keep) and m1.sum() < m0.sum()
+    assert np.array_equal(s1[keep], s0[keep]) and not s1[gone].any()
