@@ -500,10 +500,11 @@ void irs_hip_device_free(int32_t device, void* d_ptr);
 int irs_hip_device_upload(int32_t device, void* d_dst, const void* h_src, uint64_t bytes);
 int irs_hip_device_download(int32_t device, void* h_dst, const void* d_src, uint64_t bytes);
 int irs_hip_device_sync(int32_t device, void* stream);
-/* The library recycles the device and page-locked memory of destroyed batches and closed
- * segments (hipMalloc / hipFree / hipHostMalloc cost more than a batch's kernels, and hipFree
- * synchronises the device): up to 64 GB per device stay with the library (IRS_HIP_POOL_MB
- * overrides).  This hands all of it back to the runtime — postings_reader::CountMappedMemory's
+/* The library recycles the device and page-locked memory of destroyed batches (hipMalloc /
+ * hipFree / hipHostMalloc cost more than a batch's kernels, and hipFree synchronises the device):
+ * up to 16 GB of device memory and 1 GB of page-locked host memory per device stay with the
+ * library (IRS_HIP_POOL_MB / IRS_HIP_PINNED_POOL_MB override); a closed segment's memory is freed
+ * at once.  This hands all of it back to the runtime — postings_reader::CountMappedMemory's
  * counterpart for callers that watch their memory (formats.hpp:190). */
 int irs_hip_device_trim(int32_t device);
 

@@ -280,16 +280,19 @@ __device__ __forceinline__ float merge_scores(uint32_t merge, bool first, float 
 constexpr uint32_t kConjWaves = 4;  // wavefronts (= lead blocks) per workgroup
 constexpr uint32_t kConjRows = 4;   // frequency rows per wavefront (terms scored per flush)
 
-// LDS of one wavefront.  The lead block's docs are mirrored in a bitmap over its doc range
-// [dlo, dhi], one bit per 2^s docs (s = 0 whenever the range is below 32 * kConjWords docs —
-// every lead dense enough to matter): "is this doc one of the lead docs still alive" is one
-// word read and a bit test for a decoded posting, and "does this block hold such a doc" two
-// prefix-count reads for a directory entry, where a search of the sorted docs would walk seven
-// dependent reads.
+// LDS of one wavefront.  The lead block's doc range [dlo, dhi] is cut into kConjBuckets buckets of
+// 2^s docs (s = 0 when the range is that small).  Per bucket: the entry index of its FIRST lead
+// doc (`first`, 0 = none) — "is this decoded posting's doc a lead doc, and which" is one byte
+// read, a walk over the bucket's lead docs (1.1 on average) and a compare, where a search of the
+// sorted docs walks seven dependent reads (round 6: the search ran for ~every decoded block of a
+// sparse lead, a third of the kernel's instructions); "has every earlier term reached it" is
+// cnt[].  And one BIT per bucket in doc-range bitmaps: "does this block of the other term hold a
+// doc still alive" is two prefix-count reads for a directory entry.
 struct ConjWave {
   uint32_t docs[kBlock];
   float score[kBlock];
   uint32_t fr[kConjRows][kBlock];       // frequencies of the current terms
+  alignas(16) uint8_t first[kConjBuckets];   // bucket -> 1 + entry index of its first lead doc
   uint32_t bm[3][kConjWords + 4];       // bitmaps: [0] the lead docs, [1] / [2] alternately the
                                         // docs the current term reached (= alive for the next)
   uint8_t lpre[kConjWords + 4];         // lead-bitmap bits in the words before word w
@@ -318,7 +321,9 @@ k_conj(ConjArgs A, uint32_t pilot) {
   }
   // (wave-uniform records are read with scalar loads, at the point of use)
   const ConjItem R = wave::sload<ConjItem>(reinterpret_cast<uint64_t>(A.recs) + uint64_t(e) * sizeof(ConjItem));
-  const uint32_t unit = R.unit, item = R.item;
+  const uint32_t unit = R.unit, item = R.item & kConjItemBlock;
+  // (a piece of a lead block: postings [piece * (n >> lg) ...) of it, ConjItem)
+  const uint32_t split_lg = R.item >> 28, piece = (R.item >> 24) & 15u;
   const DevQuery qd = wave::sload<DevQuery>(reinterpret_cast<uint64_t>(A.queries) + uint64_t(unit) * sizeof(DevQuery));
   const uint32_t m = qd.n_terms;
   if (m == 0) return;
@@ -353,7 +358,8 @@ k_conj(ConjArgs A, uint32_t pilot) {
         // blocks of term i overlapping [r_lo, r_hi]: rows [a, z): from the seek table (the next
         // lead item starts behind r_hi, so its first row bounds this item's last one)
         const uint32_t a = seek[i - 1u];
-        uint32_t z = item + 1u < n_items ? seek[(A.jt - 1u) + i - 1u] + 1u : tl.nblk;
+        // (the pieces of one lead block share its seek row: the next BLOCK's is the bound)
+        uint32_t z = item + 1u < n_items ? seek[((1u << split_lg) - piece) * (A.jt - 1u) + i - 1u] + 1u : tl.nblk;
         z = z < tl.nblk ? z : tl.nblk;
         for (uint32_t k = a + lane; k < z; k += 64) {
           const float sc = block_bound(qt, seg.blk_maxf[tl.dir_off + k], seg.blk_minn[tl.dir_off + k]);
@@ -392,6 +398,7 @@ k_conj(ConjArgs A, uint32_t pilot) {
   };
   uint32_t ld_d[2], ld_e[2];   // this lane's two lead docs and their entry indices
   bool live[2];                // ... and whether they are docs of the conjunction at all
+  uint32_t sub_lo = 0;         // first posting of the block that is this item's (a piece: > 0)
   {
     uint32_t f[2], estep;
     if (item < ld.nblk) {
@@ -410,10 +417,21 @@ k_conj(ConjArgs A, uint32_t pilot) {
       estep = 64u;
     }
     ld_e[1] = ld_e[0] + estep;
+    if (split_lg) {   // (wave-uniform) this item's piece of the block: its postings move to the front
+      const uint32_t per = (n + (1u << split_lg) - 1u) >> split_lg;
+      sub_lo = piece * per;
+      n = sub_lo < n ? (n - sub_lo < per ? n - sub_lo : per) : 0u;
+      ld_e[0] -= sub_lo;   // (in front of the piece: wraps to "not one of mine")
+      ld_e[1] -= sub_lo;
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const bool on = ld_e[h] < n;
-      docs[ld_e[h]] = on ? ld_d[h] : 0xFFFFFFFFu;
+      if (!on) {
+        live[h] = false;
+        continue;
+      }
+      docs[ld_e[h]] = ld_d[h];
       W.fr[0][ld_e[h]] = f[h];
       score[ld_e[h]] = 0.f;
       // a deleted doc (SegmentReaderImpl::mask) keeps its place among the lead docs — the doc range
@@ -429,6 +447,8 @@ k_conj(ConjArgs A, uint32_t pilot) {
         W.bm[k][2u * lane + 1u] = 0u;
       }
     }
+    static_assert(kConjBuckets == 64u * 16u, "one 16-byte store per lane clears `first`");
+    reinterpret_cast<ConjQuad*>(W.first)[lane] = ConjQuad{0u, 0u, 0u, 0u};
   }
   // the docs every one of the terms [g0, g1) reached (and every earlier one) get those terms'
   // scores: norm read here, once per flush, for these docs only — they are postings of the lead
@@ -437,7 +457,7 @@ k_conj(ConjArgs A, uint32_t pilot) {
   const bool with_norm = needs_norm(term_q(0).kind);
   const uint8_t* lead_norms = nullptr;
   if (seg.pnorm)
-    lead_norms = item < ld.nblk ? seg.pnorm + (ld.dir_off + item) * kBlock : seg.tail_norms + ld.tail_row;
+    lead_norms = (item < ld.nblk ? seg.pnorm + (ld.dir_off + item) * kBlock : seg.tail_norms + ld.tail_row) + sub_lo;
   auto lead_norm = [&](uint32_t sl, uint32_t doc) {
     return lead_norms ? uint32_t(lead_norms[sl]) : norm_value(seg, doc);
   };
@@ -459,10 +479,11 @@ k_conj(ConjArgs A, uint32_t pilot) {
     if (with_norm) bytes += scored * seg.norm_width;
   };
   wave::sync();
+  if (n == 0) return;   // (a piece behind the end of a short tail)
   const uint32_t dlo = wave::uniform(docs[0]), dhi = wave::uniform(docs[n - 1]);
   // bucket of a doc: (doc - dlo) >> s, below 32 * kConjWords
   const uint32_t span = dhi - dlo;
-  const uint32_t s = span < 32u * kConjWords ? 0u
+  const uint32_t s = span < kConjBuckets ? 0u
                      : 32u - uint32_t(__builtin_clz(span)) - (5u + uint32_t(__builtin_ctz(kConjWords)));
   const bool masked = seg.dead != nullptr;   // (wave-uniform)
 #pragma unroll
@@ -470,9 +491,11 @@ k_conj(ConjArgs A, uint32_t pilot) {
     if (ld_e[h] < n) {
       const uint32_t bk = (ld_d[h] - dlo) >> s;
       atomicOr(&W.bm[0][bk >> 5], 1u << (bk & 31u));
-      // (bm[0] ranks the lead docs, deleted ones included; what the first other term may reach is
-      // the live ones: bm[2], free until the third term marks into it)
+      // (what the first other term may reach is the LIVE lead docs: bm[2], free until the third
+      // term marks into it)
       if (masked && live[h]) atomicOr(&W.bm[2][bk >> 5], 1u << (bk & 31u));
+      // the bucket's first lead doc (entries are in doc order: its predecessor lies in another)
+      if (ld_e[h] == 0u || ((docs[ld_e[h] - 1u] - dlo) >> s) != bk) W.first[bk] = uint8_t(ld_e[h] + 1u);
     }
   }
   wave::sync();
@@ -529,17 +552,11 @@ k_conj(ConjArgs A, uint32_t pilot) {
       const uint32_t x = doc - dlo;
       if (f == 0 || x > span) return;
       const uint32_t bk = x >> s;
-      if (!((alive[bk >> 5] >> (bk & 31u)) & 1u)) return;
-      uint32_t c;   // the doc's entry index + 1
-      if (s == 0) {   // (wave-uniform) one doc per bit: the rank of the bit among the lead's
-        c = 1u + uint32_t(W.lpre[bk >> 5]) +
-            uint32_t(__builtin_popcount(W.bm[0][bk >> 5] & ((1u << (bk & 31u)) - 1u)));
-      } else {        // a bit stands for 2^s docs: look the doc up among the sorted lead docs
-        c = count_le(docs, 0u, n, doc);
-        if (c == 0u || docs[c - 1u] != doc || cnt[c - 1u] != i) return;
-      }
-      row[c - 1u] = f;
-      cnt[c - 1u] = uint8_t(i + 1u);
+      const uint32_t t = lead_index(W.first, docs, n, bk, s, doc);
+      // (a lead doc every earlier term reached: deleted lead docs count 0 and stay out)
+      if (t == n || cnt[t] != i) return;
+      row[t] = f;
+      cnt[t] = uint8_t(i + 1u);
       if (i + 1u < m) atomicOr(&mark[bk >> 5], 1u << (bk & 31u));   // (alive for the next term)
     };
     if (tl.nblk) {
@@ -547,7 +564,22 @@ k_conj(ConjArgs A, uint32_t pilot) {
       const uint64_t last_at = reinterpret_cast<uint64_t>(seg.blk_last + tl.dir_off);
       const uint64_t dir_at = reinterpret_cast<uint64_t>(seg.blk_dir + tl.dir_off);
       const uint64_t pk_at = reinterpret_cast<uint64_t>(seg.pk);
-      const uint32_t b_first = seek[i - 1u];
+      uint32_t b_first = seek[i - 1u];
+      if (piece) {   // (wave-uniform) the seek row is the whole lead block's: this piece starts
+        // further on — the first block of term i whose last doc reaches the piece's first doc, by a
+        // 64-ary search of the directory's last docs (one load per lane and round)
+        uint32_t hi = tl.nblk;
+        while (hi - b_first > 64u) {
+          const uint32_t step = (hi - b_first + 63u) / 64u;
+          const uint32_t p = b_first + lane * step;
+          const uint32_t v = p < hi ? wave::gload_u32(last_at, p * 4u) : 0xFFFFFFFFu;
+          const uint64_t ge = wave::ballot(v >= dlo);
+          const uint32_t j = ge ? uint32_t(__builtin_ctzll(ge)) : 64u;
+          const uint32_t reach = b_first + j * step;   // (j < 64: block `reach` reaches dlo)
+          if (j < 64u && reach < hi) hi = reach;
+          if (j) b_first += (j - 1u) * step + 1u;
+        }
+      }
       for (uint32_t b0 = b_first; b0 < tl.nblk; b0 += 64) {
         const uint32_t bl = b0 + lane;
         const bool valid = bl < tl.nblk;
@@ -636,7 +668,7 @@ k_conj(ConjArgs A, uint32_t pilot) {
   const uint64_t below = (1ull << lane) - 1ull;
   const uint32_t c0 = uint32_t(__builtin_popcountll(m0));
   const uint32_t total = c0 + uint32_t(__builtin_popcountll(m1));
-  uint8_t* list = W.apre;   // (the alive prefix counts have served)
+  uint8_t* list = W.first;   // (the bucket table has served: room for the 128 entry indices)
   if (h0) list[__builtin_popcountll(m0 & below)] = uint8_t(lane);
   if (h1) list[c0 + uint32_t(__builtin_popcountll(m1 & below))] = uint8_t(lane + 64u);
   wave::sync();

@@ -56,10 +56,19 @@ inline size_t size_class(size_t n) {
   while (step * 16 <= n) step <<= 1;   // step = 2^floor(log2 n) / 8 for n >= 64 KB
   return (std::max<size_t>(n, 1) + step - 1) / step * step;
 }
-inline size_t cap_bytes() {
-  if (const char* e = std::getenv("IRS_HIP_POOL_MB")) return size_t(std::atoll(e)) << 20;
-  return rt::pool_cap_bytes();
+// What stays with the library per device: device memory up to rt::pool_cap_bytes() (the buffers of
+// a few large batches: a config-5 batch holds ~6 GB), page-locked HOST memory up to 1 GB — a batch
+// pins a few MB of tables and its results (8 MB for 1000 x top-1000), and pinned pages are taken
+// from every process on the node (8 ranks x the old 64 GB default was the whole host).
+// IRS_HIP_POOL_MB / IRS_HIP_PINNED_POOL_MB override.
+inline size_t cap_bytes(bool pinned) {
+  if (const char* e = std::getenv(pinned ? "IRS_HIP_PINNED_POOL_MB" : "IRS_HIP_POOL_MB"))
+    return size_t(std::atoll(e)) << 20;
+  return pinned ? std::min<size_t>(rt::pool_cap_bytes(), size_t(1) << 30) : rt::pool_cap_bytes();
 }
+// A closing segment's memory goes back to the runtime, not into the pool: it is hundreds of MB in
+// sizes no batch asks for (irs_hip_segment_close sets this around its destructor).
+inline thread_local bool tl_free_now = false;
 inline void release_all(int device, bool pinned) {
   Bin& b = bin(device, pinned);
   std::lock_guard<std::mutex> lock(b.m);
@@ -94,9 +103,9 @@ inline void* take(int device, bool pinned, size_t bytes, size_t* cap) {
 inline void give(int device, bool pinned, void* p, size_t cap) {
   if (!p) return;
   Bin& b = bin(device, pinned);
-  {
+  if (!tl_free_now) {
     std::lock_guard<std::mutex> lock(b.m);
-    if (b.cached + cap <= cap_bytes()) {
+    if (b.cached + cap <= cap_bytes(pinned)) {
       b.blocks.emplace(cap, p);
       b.cached += cap;
       return;
@@ -328,6 +337,7 @@ struct irs_hip_batch {
   uint32_t n_conj_wgs = 0;
   DevBuf d_tile_units, d_conj_units, d_conj_items, d_conj_hist;
   DevBuf d_conj_item_base, d_conj_unit_items, d_conj_seek, d_conj_recs;   // k_conj_seek
+  DevBuf d_conj_lg;   // [conj unit] log2 of the pieces a lead block is cut into (ConjItem)
   DevBuf d_conj_item_hits;   // [lead item] matches (ConjArgs::item_hits, k_conj_hits)
   DevBuf d_lead_of;   // by_phrase: slot of every unit's lead term
   DevBuf d_min_bin;   // [unit] score bin of the caller's irs::score::Min (irs_hip_batch_set_min_scores)
@@ -714,7 +724,7 @@ bool launch_conj(irs_hip_batch* b, rt::stream_t st) {
             b->d_segs.as<DevSegment>(), b->d_queries.as<DevQuery>(), b->d_tails.as<DevTail>(),
             b->jt, b->d_conj_units.as<uint32_t>(), b->d_conj_item_base.as<uint32_t>(),
             uint32_t(b->conj_units.size()), static_cast<const uint32_t*>(nullptr),
-            b->d_conj_seek.as<uint32_t>(), b->d_conj_recs.as<ConjItem>());
+            b->d_conj_lg.as<uint32_t>(), b->d_conj_seek.as<uint32_t>(), b->d_conj_recs.as<ConjItem>());
   if (b->n_conj_pilot) {
     ConjArgs p = a;
     p.wgs = b->d_conj_pilot.as<PhraseWg>();
@@ -810,7 +820,8 @@ bool launch_phrase(irs_hip_batch* b, rt::stream_t st) {
             b->d_segs.as<DevSegment>(), b->d_queries.as<DevQuery>(), b->d_tails.as<DevTail>(),
             b->jt, b->d_conj_units.as<uint32_t>(), b->d_conj_item_base.as<uint32_t>(),
             uint32_t(b->conj_units.size()), b->d_lead_of.as<uint32_t>(),
-            b->d_conj_seek.as<uint32_t>(), b->d_conj_recs.as<ConjItem>());
+            static_cast<const uint32_t*>(nullptr), b->d_conj_seek.as<uint32_t>(),
+            b->d_conj_recs.as<ConjItem>());
   if (b->n_conj_pilot) {
     ConjArgs p = a;
     p.wgs = b->d_conj_pilot.as<PhraseWg>();
@@ -1437,14 +1448,44 @@ int build_conj_work(irs_hip_batch* b) {
   b->conj_pilot_stride = 0;
   if (b->conj_units.empty()) return rc;
   try {
+    // A lead block whose 128 docs fall into many blocks of the other terms — a rare lead against
+    // frequent terms — is one wavefront decoding those blocks one after the other: it is cut into
+    // 2^lg pieces, a wavefront each (ConjItem).  A lead doc falls into at most one block per term,
+    // and a term has df_j / df_lead blocks per lead doc: W = sum_j min(128, df_j / df_lead) blocks
+    // per lead block; pieces of about 16.  (Measured on the reference's AndHighLow class — lead df
+    // ~280 against 720 k: 0.98 -> 0.11 ms per 256 queries.)  Only while the batch cannot fill the
+    // chip anyway: with more lead blocks than wavefront slots every wavefront's chain hides behind
+    // the others', and the pieces' repeated lead decodes and shared border blocks only add work
+    // (config 5's AND batch: 13.4 -> 15.7 ms with the cut applied to every unit).
+    uint64_t lead_items = 0;
     for (uint32_t u : b->conj_units) {
       const DevQuery& dq = b->queries[u];
-      uint32_t items = 0;
+      if (dq.n_terms) lead_items += b->segs[dq.seg]->terms[b->qterms[dq.first_term].term].nblk + 1u;
+    }
+    const bool roomy = lead_items < 2ull * 32ull * b->seg->cus;   // (8 wavefronts per SIMD)
+    int forced_lg = -1;
+    if (const char* e = std::getenv("IRS_HIP_CONJ_SPLIT_LOG2")) {   // tuning / test knob
+      forced_lg = std::atoi(e);
+      if (forced_lg < 0 || forced_lg > int(kConjSplitMax)) forced_lg = -1;
+    }
+    std::vector<uint32_t> split_lg;
+    for (uint32_t u : b->conj_units) {
+      const DevQuery& dq = b->queries[u];
+      uint32_t items = 0, lg = 0;
       if (dq.n_terms) {
-        const DevTerm& t = b->segs[dq.seg]->terms[b->qterms[dq.first_term].term];
+        const irs_hip_segment* sg = b->segs[dq.seg];
+        const DevTerm& t = sg->terms[b->qterms[dq.first_term].term];
         items = t.nblk + ((t.docs_count == 1 || t.tail_n) ? 1u : 0u);
+        uint64_t want = 0;
+        for (uint32_t j = 1; j < dq.n_terms; ++j) {
+          const uint64_t df = sg->terms[b->qterms[dq.first_term + j].term].docs_count;
+          want += std::min<uint64_t>(kBlock, df / std::max<uint32_t>(1u, t.docs_count));
+        }
+        while (roomy && lg < kConjSplitMax && (want >> lg) > 16u) ++lg;
+        if (forced_lg >= 0) lg = uint32_t(forced_lg);
       }
-      b->conj_items.push_back(items);
+      split_lg.push_back(lg);
+      b->conj_items.push_back(items << lg);
     }
     // rows of the seek table: the lead items of the conj units, unit after unit
     std::vector<uint32_t> item_base(b->conj_units.size() + 1, 0), unit_items(nq, 0);
@@ -1465,12 +1506,14 @@ int build_conj_work(irs_hip_batch* b) {
         !b->d_conj_item_hits.alloc((total + 1) * 4) ||
         !b->d_conj_units.alloc(b->conj_units.size() * 4) ||
         !b->d_conj_items.alloc(b->conj_items.size() * 4) ||
+        !b->d_conj_lg.alloc(split_lg.size() * 4) ||
         !b->d_conj_hist.alloc(uint64_t(nq) * kBins * 4))
       return IRS_HIP_ENOMEM;
     if (!b->up.copy(b->d_conj_item_base.p, item_base.data(), item_base.size() * 4) ||
         !b->up.copy(b->d_conj_unit_items.p, unit_items.data(), unit_items.size() * 4) ||
         !b->up.copy(b->d_conj_units.p, b->conj_units.data(), b->conj_units.size() * 4) ||
-        !b->up.copy(b->d_conj_items.p, b->conj_items.data(), b->conj_items.size() * 4))
+        !b->up.copy(b->d_conj_items.p, b->conj_items.data(), b->conj_items.size() * 4) ||
+        !b->up.copy(b->d_conj_lg.p, split_lg.data(), split_lg.size() * 4))
       return IRS_HIP_ENOMEM;
   } catch (...) {
     rc = IRS_HIP_ENOMEM;
@@ -2073,7 +2116,9 @@ static int segment_open_impl(const irs_hip_segment_desc* d, irs_hip_segment** ou
 void irs_hip_segment_close(irs_hip_segment* seg) {
   if (!seg) return;
   rt::set_device(seg->device);
+  pool::tl_free_now = true;   // (its buffers are freed, not pooled)
   delete seg;
+  pool::tl_free_now = false;
 }
 
 uint64_t irs_hip_segment_device_bytes(const irs_hip_segment* seg) {

@@ -295,7 +295,8 @@ k_decode_positions(DevSegment seg, uint32_t term, uint32_t* out) {
 // ------------------------------------------------------------ query time --
 
 constexpr uint32_t kPhraseWaves = 4;  // wavefronts (= lead blocks) per workgroup
-constexpr uint32_t kConjWords = 128;  // 32-bit words of a wavefront's doc-range bitmaps
+constexpr uint32_t kConjWords = 32;   // 32-bit words of a wavefront's doc-range bitmaps: 1024 buckets
+constexpr uint32_t kConjBuckets = 32u * kConjWords;
 
 // One entry of a pilot list: a sampled lead item of a unit.
 struct PhraseWg {
@@ -315,13 +316,35 @@ __device__ __forceinline__ uint32_t count_le(const uint32_t* sorted, uint32_t a,
 
 // ---- block-driven execution (irs::And in conj.h, by_phrase below): shared pieces
 
+// A wavefront's bucket table (conj.h ConjWave::first): the entry index (< n) of lead doc `doc` of
+// bucket bk, or n: not a lead doc
+__device__ __forceinline__ uint32_t lead_index(const uint8_t* first, const uint32_t* docs, uint32_t n,
+                                               uint32_t bk, uint32_t s, uint32_t doc) {
+  uint32_t t = first[bk];
+  if (!t) return n;
+  --t;
+  if (s) {   // (wave-uniform) a bucket may hold several lead docs, in entry order
+    while (docs[t] < doc && t + 1u < n) ++t;
+  }
+  return docs[t] == doc ? t : n;
+}
+struct alignas(16) ConjQuad {   // 16 bytes cleared at once
+  uint32_t x, y, z, w;
+};
+
 // One lead item (a 128-posting block of the conjunction's rarest term, or its decoded vint
 // tail), everything its wavefront needs to start decoding — written by the pre-pass so that
 // the wavefront's first load is this record (one scalar load) instead of a chain of dependent
 // ones (unit -> query -> term record -> directory words).
+// A lead block whose docs spread over many blocks of the other terms (a rare lead against frequent
+// terms: the reference's AndHighLow) is cut into 2^lg lead items of 128 >> lg consecutive postings:
+// one wavefront would decode up to 128 blocks per other term one after the other, a chain of
+// dependent loads with nobody to overlap it.
+constexpr uint32_t kConjItemBlock = 0xFFFFFFu;   // ConjItem::item: block index (nblk <= 2^24)
+constexpr uint32_t kConjSplitMax = 4;            //   | piece << 24 | lg << 28: 16 pieces at most
 struct alignas(32) ConjItem {
   uint32_t unit;
-  uint32_t item;    // block index in the lead's list; == its nblk: the vint tail
+  uint32_t item;    // block index in the lead's list; == its nblk: the vint tail (+ piece, lg above)
   uint32_t base;    // doc the block's first delta is relative to (formats_10.cpp:636)
   uint32_t r_lo;    // the item's docs lie in [r_lo, r_hi] (from the directory)
   uint32_t r_hi;
@@ -340,6 +363,7 @@ __global__ void __launch_bounds__(kThreads)
 k_conj_seek(const DevSegment* segs, const DevQuery* queries, const DevTail* tails, uint32_t jt,
             const uint32_t* conj_units, const uint32_t* item_base /*[n_conj + 1]*/,
             uint32_t n_conj, const uint32_t* lead_of /*[unit] slot of the lead term; null: 0*/,
+            const uint32_t* split_lg /*[n_conj] log2 of the pieces per lead block; null: 0*/,
             uint32_t* seek, ConjItem* recs) {
   const uint32_t t = blockIdx.x * kThreads + threadIdx.x;
   if (t >= item_base[n_conj]) return;
@@ -348,7 +372,9 @@ k_conj_seek(const DevSegment* segs, const DevQuery* queries, const DevTail* tail
     const uint32_t mid = (lo + hi) >> 1;
     if (item_base[mid] <= t) lo = mid; else hi = mid;
   }
-  const uint32_t unit = conj_units[lo], item = t - item_base[lo];
+  const uint32_t lg = split_lg ? split_lg[lo] : 0u;
+  const uint32_t unit = conj_units[lo], item = (t - item_base[lo]) >> lg;
+  const uint32_t piece = (t - item_base[lo]) & ((1u << lg) - 1u);
   const DevQuery qd = queries[unit];
   const DevSegment& seg = segs[qd.seg];
   const DevTail* tl = tails + uint64_t(unit) * jt;
@@ -356,7 +382,7 @@ k_conj_seek(const DevSegment* segs, const DevQuery* queries, const DevTail* tail
   const DevTail ld = tl[lead];
   ConjItem r{};
   r.unit = unit;
-  r.item = item;
+  r.item = item | (piece << 24) | (lg << 28);
   if (item < ld.nblk) {
     const uint64_t e = ld.dir_off + item;
     r.base = item ? seg.blk_last[e - 1] : kDocMin;
@@ -442,6 +468,7 @@ struct PhraseWave {
   uint32_t docs[kBlock];
   uint32_t pidx[MT][kBlock];          // first position number of the doc in term i's list
   uint32_t tf[MT][kBlock];            // its frequency there (0: the term has not reached the doc)
+  alignas(16) uint8_t first[kConjBuckets];   // bucket -> 1 + entry index of its first lead doc (conj.h)
   uint32_t bm[3][kConjWords + 4];     // bitmaps over [dlo, dhi]: lead docs, alive / marked
   uint8_t lpre[kConjWords + 4];       // lead-bitmap bits in the words before word w
   uint8_t apre[kConjWords + 4];       // the same for the alive bitmap of the current term
@@ -543,12 +570,14 @@ __device__ __forceinline__ void phrase_item(const ConjArgs& A, uint32_t pilot /*
         W.bm[k][2u * lane + 1u] = 0u;
       }
     }
+    static_assert(kConjBuckets == 64u * 16u, "one 16-byte store per lane clears `first`");
+    reinterpret_cast<ConjQuad*>(W.first)[lane] = ConjQuad{0u, 0u, 0u, 0u};
   }
   wave::sync();
   const uint32_t dlo = wave::uniform(docs[0]), dhi = wave::uniform(docs[n - 1]);
-  // bucket of a doc: (doc - dlo) >> s, below 32 * kConjWords (s = 0: one doc per bit)
+  // bucket of a doc: (doc - dlo) >> s, below kConjBuckets (s = 0: one doc per bucket)
   const uint32_t span = dhi - dlo;
-  const uint32_t s = span < 32u * kConjWords ? 0u
+  const uint32_t s = span < kConjBuckets ? 0u
                      : 32u - uint32_t(__builtin_clz(span)) - (5u + uint32_t(__builtin_ctz(kConjWords)));
   const bool masked = seg.dead != nullptr;   // (wave-uniform)
 #pragma unroll
@@ -556,8 +585,10 @@ __device__ __forceinline__ void phrase_item(const ConjArgs& A, uint32_t pilot /*
     if (ld_e[h] < n) {
       const uint32_t bk = (ld_d[h] - dlo) >> s;
       atomicOr(&W.bm[0][bk >> 5], 1u << (bk & 31u));
-      // (conj.h: bm[0] ranks all lead docs; the first other term may only reach the live ones)
+      // (conj.h: the first other term may only reach the LIVE lead docs)
       if (masked && live[h]) atomicOr(&W.bm[2][bk >> 5], 1u << (bk & 31u));
+      // the bucket's first lead doc (entries are in doc order: its predecessor lies in another)
+      if (ld_e[h] == 0u || ((docs[ld_e[h] - 1u] - dlo) >> s) != bk) W.first[bk] = uint8_t(ld_e[h] + 1u);
     }
   }
   wave::sync();
@@ -611,20 +642,14 @@ __device__ __forceinline__ void phrase_item(const ConjArgs& A, uint32_t pilot /*
       const uint32_t x = doc - dlo;
       if (f == 0 || x > span) return;
       const uint32_t bk = x >> s;
-      if (!((alive[bk >> 5] >> (bk & 31u)) & 1u)) return;
-      uint32_t c;   // the doc's entry index + 1
-      if (s == 0) {
-        c = 1u + uint32_t(W.lpre[bk >> 5]) +
-            uint32_t(__builtin_popcount(W.bm[0][bk >> 5] & ((1u << (bk & 31u)) - 1u)));
-      } else {
-        c = count_le(docs, 0u, n, doc);
-        if (c == 0u || docs[c - 1u] != doc) return;
-        // (alive at bucket granularity: every earlier term must have reached THIS doc)
-        for (uint32_t j = 0; j < i; ++j)
-          if (W.tf[j][c - 1u] == 0u) return;
-      }
-      W.pidx[i][c - 1u] = p;
-      W.tf[i][c - 1u] = f;
+      const uint32_t t = lead_index(W.first, docs, n, bk, s, doc);
+      if (t == n) return;
+      // every earlier term — and the lead, whose deleted docs count as not reached — holds THIS doc
+      if (W.tf[lead][t] == 0u) return;
+      for (uint32_t j = 0; j < i; ++j)
+        if (W.tf[j][t] == 0u) return;
+      W.pidx[i][t] = p;
+      W.tf[i][t] = f;
       atomicOr(&mark[bk >> 5], 1u << (bk & 31u));
     };
     if (tl.nblk) {
@@ -742,7 +767,7 @@ __device__ __forceinline__ void phrase_item(const ConjArgs& A, uint32_t pilot /*
   const uint64_t below = (1ull << lane) - 1ull;
   const uint32_t c0 = uint32_t(__builtin_popcountll(m01[0]));
   const uint32_t total = c0 + uint32_t(__builtin_popcountll(m01[1]));
-  uint8_t* list = W.apre;   // (the alive prefix counts have served)
+  uint8_t* list = W.first;   // (the bucket table has served: room for the 128 entry indices)
   if (h01[0]) list[__builtin_popcountll(m01[0] & below)] = uint8_t(lane);
   if (h01[1]) list[c0 + uint32_t(__builtin_popcountll(m01[1] & below))] = uint8_t(lane + 64u);
   wave::sync();

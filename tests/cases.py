@@ -1671,6 +1671,64 @@ def case_phrase_queries(L, layout, num_docs=30_000):
     sr.close()
 
 
+def case_conj_sparse_lead(L, layout=synth.LAYOUT_SIMD4, n_docs=400_000):
+    """Conjunctions whose rarest term is FAR rarer than the others (the reference's AndHighLow
+    class): a lead block's 128 docs then fall into up to 128 different blocks of every other term,
+    and the block is cut into pieces, a wavefront each (ConjItem: build_conj_work's rule; the
+    pieces find their own start in the other terms' directories).  Explicit lists: leads of two
+    blocks + a tail, of a tail only and of one doc against dense terms; with and without block-max
+    pruning, deleted docs, and every forced cut (IRS_HIP_CONJ_SPLIT_LOG2) — the same results,
+    bit for bit, as uncut."""
+    import os
+    rng = np.random.default_rng(77)
+    pick = lambda n: np.sort(rng.choice(n_docs, n, replace=False)).astype(np.uint32) + 1
+    lists = [np.arange(2, n_docs, 3, dtype=np.uint32),      # 0: dense, regular
+             pick(300),                                      # 1: two blocks + a tail of 44
+             pick(n_docs // 2),                              # 2: dense, random
+             pick(40),                                       # 3: tail only
+             np.array([n_docs // 2 + 1], np.uint32),         # 4: one doc
+             pick(128 * 5)]                                  # 5: exactly five blocks, no tail
+    lists[1][:3] = [2, 5, 8]                                 # (some docs of the dense term for sure)
+    lists[1] = np.unique(lists[1])
+    freqs = [rng.integers(1, 6, l.size).astype(np.uint32) for l in lists]
+    norms = rng.integers(20, 200, n_docs).astype(np.uint8)
+    seg = synth.segment_from_lists(list(zip(lists, freqs)), n_docs, layout, norms=norms)
+    st = [parity.segment_stats(seg)]
+    filters = [And([by_term(1), by_term(0)]), And([by_term(1), by_term(0), by_term(2)]),
+               And([by_term(3), by_term(0)]), And([by_term(4), by_term(0)]), And([by_term(4), by_term(2)]),
+               And([by_term(3), by_term(2), by_term(0)]), And([by_term(1), by_term(2)]),
+               And([by_term(5), by_term(2)]), And([by_term(5), by_term(0), by_term(2)]),
+               And([by_term(0), by_term(2)]), And([by_term(1), by_term(5)])]
+    for masked in (False, True):
+        if masked:
+            seg.doc_mask = np.concatenate([lists[1][::7], lists[5][::3], pick(n_docs // 10)])
+        sr = search.SegmentReader.from_synth(seg, L=L)
+        for scorer in (BM25(), TFIDF(True)):
+            ref = None
+            for forced in (None, "0", "1", "2", "3", "4"):
+                if forced is None:
+                    os.environ.pop("IRS_HIP_CONJ_SPLIT_LOG2", None)
+                else:
+                    os.environ["IRS_HIP_CONJ_SPLIT_LOG2"] = forced
+                try:
+                    for wand in (False, True):
+                        b = sr.batch(search.prepare(filters, scorer, st), 50).set_path(_lib.PATH_ITEMS)
+                        if wand:
+                            b.set_wand(True)
+                        h, c, t = b.run().results()
+                        b.close()
+                        if ref is None:
+                            parity.check_single_segment(seg, filters, scorer, 50, h, c, t)
+                            ref = (h.copy(), c.copy(), t.copy())
+                            assert int(t[0]) > 0 and int(t[3]) <= 1
+                        assert np.array_equal(h, ref[0]) and np.array_equal(c, ref[1]), (masked, forced, wand)
+                        if not wand:   # (pruned runs only count the docs they evaluated)
+                            assert np.array_equal(t, ref[2]), (masked, forced)
+                finally:
+                    os.environ.pop("IRS_HIP_CONJ_SPLIT_LOG2", None)
+        sr.close()
+
+
 def case_doc_mask(L, layout=synth.LAYOUT_SIMD4, num_docs=70_000, max_rank=256):
     """A segment with deleted documents (irs_hip_segment_desc.doc_mask — the DocumentMask the
     reference wraps every iterator with: SegmentReaderImpl::mask -> MaskDocIterator,

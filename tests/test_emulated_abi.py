@@ -118,6 +118,11 @@ def test_paths_agree(simlib, layout):
 
 
 @pytest.mark.parametrize("layout", [0, 1])
+def test_conjunctions_with_a_sparse_lead(simlib, layout):
+    cases.case_conj_sparse_lead(simlib, layout=layout, n_docs=150_000)
+
+
+@pytest.mark.parametrize("layout", [0, 1])
 def test_deleted_documents(simlib, layout):
     cases.case_doc_mask(simlib, layout=layout, num_docs=40_000, max_rank=128)
 

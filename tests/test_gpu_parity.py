@@ -191,6 +191,11 @@ def test_paths_agree(gpulib, layout):
 
 
 @pytest.mark.parametrize("layout", [0, 1])
+def test_conjunctions_with_a_sparse_lead(gpulib, layout):
+    cases.case_conj_sparse_lead(gpulib, layout=layout, n_docs=2_000_000)
+
+
+@pytest.mark.parametrize("layout", [0, 1])
 def test_deleted_documents(gpulib, layout):
     """5 % random deletions (+ runs, ends, a whole term): totals, doc sets and top-k equal the
     oracle's masked run on every path."""
