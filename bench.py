@@ -799,6 +799,11 @@ def main_config5(args):
                          "achieved": round(rank0_touched / ((ms["and"] + ms["phrase"]) * 1e-3) / 1e9, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(rank0_touched / ((ms["and"] + ms["phrase"]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                         "peak_measured": HBM_MEASURED_GBS,
+                         "frac_of_measured": round(rank0_touched / ((ms["and"] + ms["phrase"]) * 1e-3) / 1e9 / HBM_MEASURED_GBS, 5),
+                         # (name and launch time only: the AND stage's bytes are not its)
+                         "dominant_kernel": {"name": "k_phrase2" if ms["phrase"] >= ms["and"] else "k_conj",
+                                             "stage_ms": round(max(ms["phrase"], ms["and"]), 4)},
                          # HBM-side bytes per step of those kernels (PMC passes of this command at these
                          # kernel sources, profiles/traffic_config5_latest.json), else null
                          "traffic": None if tr5 is None else int(tr5["bytes"]), "traffic_detail": tr5,

@@ -403,54 +403,18 @@ __device__ __forceinline__ void join_post(const unsigned char* lds, const uint32
     else wave::lds_add(lds, JoinOff::acc + (e[k] >> 16), fx[k]);
   }
 }
-// `slabs` (1..4, wave-uniform) of them.  The three stages of join_post, each entered at the slab
-// the group ends with and falling through to slab 0: every slab's code names ITS registers (four
-// copies join_post<.., N> had their common tails merged by the compiler into one that indexes
-// e[] dynamically — a 16-byte scratch array, four stores and a dependent scratch load per group).
+// `slabs` (1..4, wave-uniform) of them.  (The compiler merges the tails of the four copies into
+// one that indexes e[] dynamically — a 16-byte scratch array per group.  Round 6 wrote the stages
+// as fall-through switches instead, every slab naming its own registers: no scratch access left on
+// this path, 490 more branches, k_join_score 5.68 -> 6.62 ms; and slab after slab with early
+// exits / always four slabs with dummies: profiles/r06_join_models.txt.  This form stays.)
 template<int FORM, bool COUNT>
 __device__ __forceinline__ void join_post_n(const unsigned char* lds, const uint32_t (&e)[4],
                                             uint32_t slabs, float cs, uint32_t tabofs) {
-  if (slabs >= 4u) {
-    join_post<FORM, 4, COUNT>(lds, e, cs, tabofs);
-    return;
-  }
-  float t0 = 0.f, t1 = 0.f, t2 = 0.f;
-  auto at = [&](uint32_t x) {
-    const uint32_t o = (FORM == kJTable) ? ((x & 0xFFFFu) | tabofs) : ((x & 0x3FCu) | tabofs);
-    return kAblNoTab ? __uint_as_float(o | 0x3F000000u) : wave::lds_f32(lds, JoinOff::caches + o);
-  };
-  auto fixed = [&](uint32_t x, float t) {
-    if (FORM == kJTable) {
-      const uint32_t fx = static_cast<uint32_t>(wave::fma(cs, t, COUNT ? kJoinCountRound : 1.f));
-      return COUNT ? ((fx & ~kJoinCountMask) | 1u) : fx;
-    }
-    const float tf = static_cast<float>(join_tf(x));
-    float scaled = (FORM == kJSqrt) ? wave::fast_sqrt(tf) * cs * t
-                                    : wave::fma(-cs, wave::fast_rcp(wave::fma(tf, t, 1.f)), cs);
-    wave::keep_f(scaled);
-    return COUNT ? ((static_cast<uint32_t>(scaled + kJoinCountRound) & ~kJoinCountMask) | 1u)
-                 : (static_cast<uint32_t>(scaled) | 1u);
-  };
-  auto add = [&](uint32_t x, uint32_t fx) {
-    if (kAblNoAdd) wave::keep(fx);
-    else wave::lds_add(lds, JoinOff::acc + (x >> 16), fx);
-  };
-  switch (slabs) {
-    case 3: t2 = at(e[2]); [[fallthrough]];
-    case 2: t1 = at(e[1]); [[fallthrough]];
-    default: t0 = at(e[0]);
-  }
-  uint32_t f0 = 0, f1 = 0, f2 = 0;
-  switch (slabs) {
-    case 3: f2 = fixed(e[2], t2); [[fallthrough]];
-    case 2: f1 = fixed(e[1], t1); [[fallthrough]];
-    default: f0 = fixed(e[0], t0);
-  }
-  switch (slabs) {
-    case 3: add(e[2], f2); [[fallthrough]];
-    case 2: add(e[1], f1); [[fallthrough]];
-    default: add(e[0], f0);
-  }
+  if (slabs >= 4u) join_post<FORM, 4, COUNT>(lds, e, cs, tabofs);
+  else if (slabs == 3u) join_post<FORM, 3, COUNT>(lds, e, cs, tabofs);
+  else if (slabs == 2u) join_post<FORM, 2, COUNT>(lds, e, cs, tabofs);
+  else join_post<FORM, 1, COUNT>(lds, e, cs, tabofs);
 }
 // M: kJSimple | kJCount (template mode bits of the tile loop)
 enum : int { kJSimple = 1, kJCount = 2 };
