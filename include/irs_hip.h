@@ -502,7 +502,7 @@ int irs_hip_device_download(int32_t device, void* h_dst, const void* d_src, uint
 int irs_hip_device_sync(int32_t device, void* stream);
 /* The library recycles the device and page-locked memory of destroyed batches (hipMalloc /
  * hipFree / hipHostMalloc cost more than a batch's kernels, and hipFree synchronises the device):
- * up to 16 GB of device memory and 1 GB of page-locked host memory per device stay with the
+ * up to 64 GB of device memory and 4 GB of page-locked host memory per device stay with the
  * library (IRS_HIP_POOL_MB / IRS_HIP_PINNED_POOL_MB override); a closed segment's memory is freed
  * at once.  This hands all of it back to the runtime — postings_reader::CountMappedMemory's
  * counterpart for callers that watch their memory (formats.hpp:190). */

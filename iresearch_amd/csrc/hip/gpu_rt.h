@@ -31,7 +31,7 @@ inline int current_device() {
 // bytes of freed device / page-locked memory the library keeps for reuse per device (irs_hip.hip
 // `pool`): hipMalloc / hipFree / hipHostMalloc cost 0.1-1 ms each and hipFree synchronises the
 // device, so a batch's buffers are recycled instead
-inline size_t pool_cap_bytes() { return size_t(16) << 30; }
+inline size_t pool_cap_bytes() { return size_t(64) << 30; }
 inline void poison(void*, size_t) {}   // (the CPU test tier marks recycled memory)
 inline bool device_arch(int dev, char* buf, size_t cap) {
   hipDeviceProp_t p;

@@ -56,15 +56,17 @@ inline size_t size_class(size_t n) {
   while (step * 16 <= n) step <<= 1;   // step = 2^floor(log2 n) / 8 for n >= 64 KB
   return (std::max<size_t>(n, 1) + step - 1) / step * step;
 }
-// What stays with the library per device: device memory up to rt::pool_cap_bytes() (the buffers of
-// a few large batches: a config-5 batch holds ~6 GB), page-locked HOST memory up to 1 GB — a batch
-// pins a few MB of tables and its results (8 MB for 1000 x top-1000), and pinned pages are taken
-// from every process on the node (8 ranks x the old 64 GB default was the whole host).
+// What stays with the library per device: device memory up to rt::pool_cap_bytes() — the buffers
+// of the batches a pipelined serving loop has alive (a config-5 step holds two batches of ~6 GB, and
+// three steps overlap; a cap of 16 GB was tried: blocks then go back to the runtime, hipFree
+// synchronises the device and the steps stall — 45 -> 150 ms) —, page-locked HOST memory up to 4 GB:
+// a batch pins a few MB of tables and its results (8 MB for 1000 x top-1000), and pinned pages are
+// taken from every process on the node (8 ranks x the old 64 GB default was the whole host).
 // IRS_HIP_POOL_MB / IRS_HIP_PINNED_POOL_MB override.
 inline size_t cap_bytes(bool pinned) {
   if (const char* e = std::getenv(pinned ? "IRS_HIP_PINNED_POOL_MB" : "IRS_HIP_POOL_MB"))
     return size_t(std::atoll(e)) << 20;
-  return pinned ? std::min<size_t>(rt::pool_cap_bytes(), size_t(1) << 30) : rt::pool_cap_bytes();
+  return pinned ? std::min<size_t>(rt::pool_cap_bytes(), size_t(4) << 30) : rt::pool_cap_bytes();
 }
 // A closing segment's memory goes back to the runtime, not into the pool: it is hundreds of MB in
 // sizes no batch asks for (irs_hip_segment_close sets this around its destructor).

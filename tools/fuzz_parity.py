@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Randomised differential run of the C ABI against the oracle (test infrastructure: imports
 oracle/ through tests/parity.py).  Every round builds a fresh segment (random size, vocabulary,
-layout, clustering, wand data, positions), a batch of random Or / And / min-match / by_term
+layout, clustering, wand data, positions, every second round a random set of DELETED documents —
+the segment's DocumentMask, which the oracle applies as SegmentReaderImpl::mask does), a batch of
+random Or / And / min-match / by_term
 filters with random boosts and merge types (or by_phrase filters), a random scorer and k, and
 checks the results as the parity tests do; the same batch is then re-run with block-max pruning
 (top-k must not change) and with the k-th score pushed down as irs::score::Min.
@@ -52,6 +54,13 @@ def main():
                   topic_terms=12) if clustered else {}
         seg = synth.build_segment(docs, max_rank, layout=layout, wand_count=wand_count,
                                   with_positions=positions, seed=int(rng.integers(1, 1 << 30)), **kw)
+        if rounds % 2 == 1:   # deleted docs: a random share, a run of consecutive ones, the ends
+            share = float(rng.choice([0.001, 0.05, 0.5]))
+            run0 = int(rng.integers(1, docs))
+            seg.doc_mask = np.concatenate([
+                (rng.choice(docs, max(1, int(docs * share)), replace=False) + 1).astype(np.uint32),
+                np.arange(run0, min(docs, run0 + int(rng.integers(1, 700))) + 1, dtype=np.uint32),
+                np.array([1, docs], np.uint32)[:int(rng.integers(0, 3))]])
         sr = search.SegmentReader.from_synth(seg, L=L)
         st = [parity.segment_stats(seg)]
         scorer = [BM25(), BM25(1.2, 0.0), BM25(0.0, 0.0), BM25(2.0, 1.0), TFIDF(False),
@@ -83,6 +92,9 @@ def main():
                 if kind == 0 or n == 1:
                     filters.append(Or(subs, merge=merge()))
                 elif kind == 1:
+                    if rng.integers(0, 3) == 0:   # a rare lead against frequent terms (lead blocks in pieces)
+                        subs = [by_term(int(rng.integers(max_rank // 2, max_rank)))] + \
+                               [by_term(int(rng.integers(0, 6))) for _ in range(int(rng.integers(1, 4)))]
                     filters.append(And(subs[:int(rng.integers(2, 6))] if n > 2 else subs, merge=merge()))
                 elif kind == 2:
                     filters.append(Or(subs, min_match=int(rng.integers(2, n + 1)), merge=merge()))
