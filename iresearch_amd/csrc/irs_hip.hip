@@ -1227,6 +1227,8 @@ bool build_streams(irs_hip_batch* b) {
     w.dead_lo = uint32_t(reinterpret_cast<uint64_t>(ds.dead));
     w.dead_hi = uint32_t(reinterpret_cast<uint64_t>(ds.dead) >> 32);
     w.pad = 0;
+    w.pk = reinterpret_cast<uint64_t>(ds.pk);
+    w.pad2 = 0;
   }
   lap("  streams: per-term records");
   for (uint32_t u : b->join_units) {
