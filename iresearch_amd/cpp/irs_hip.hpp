@@ -382,6 +382,16 @@ class QueryBatch {
       if (part.h) check(irs_hip_batch_plan(part.h, stream), "irs_hip_batch_plan");
     return *this;
   }
+  // run() hands the host half of a run to the library's worker thread and returns at once (a
+  // failure then surfaces from the next call on the batch, and NOTHING of the run may be on
+  // `stream` yet: the caller's own work on the stream is ordered behind the run only through a
+  // call on the batch — results(), host_results(), device results).  set_async(false) keeps the
+  // run on the caller's thread: launch-time semantics of a plain kernel launch, status from run()
+  QueryBatch& set_async(bool enable) {
+    for (Part& part : part_)
+      if (part.h) check(irs_hip_batch_set_async(part.h, enable ? 1 : 0), "irs_hip_batch_set_async");
+    return *this;
+  }
   QueryBatch& run(void* stream = nullptr) {
     for (Part& part : part_)
       if (part.h) check(irs_hip_batch_run(part.h, stream), "irs_hip_batch_run");

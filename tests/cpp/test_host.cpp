@@ -195,7 +195,9 @@ int main() {
         REQUIRE(planned[q][i].score == top[q][i].score && planned[q][i].doc == top[q][i].doc);
       if (!top[q].empty()) kth[q] = top[q].back().score;
     }
-    const auto pushed = merge(batch.set_min_scores(kth).run().results());
+    // (... with the run kept on the caller's thread: irs_hip_batch_set_async)
+    const auto pushed = merge(batch.set_min_scores(kth).set_async(false).run().results());
+    batch.set_async(true);
     for (size_t q = 0; q < top.size(); ++q) {
       REQUIRE(pushed[q].size() == top[q].size());
       for (size_t i = 0; i < top[q].size(); ++i)

@@ -50,6 +50,8 @@ cases.case_join_counts(L, num_docs=40_000, max_rank=128)
 cases.case_accumulator_switch(L)
 cases.case_shared_threshold(L, sizes=(30_000, 13_000, 40_000), max_rank=128)
 cases.case_shared_threshold_misled(L)
+cases.case_doc_mask(L, 1, num_docs=30_000, max_rank=128)
+cases.case_conj_sparse_lead(L, 1, n_docs=120_000)
 print("asan emulator run: clean")
 PY
 # ... and the C++ host readers (header only: instrumented with the test binary) over a segment of
