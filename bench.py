@@ -884,39 +884,63 @@ def main_tasks(args):
           "           path   ms/step  plan/pilot/score/select ms  postings/step  re-runs (profiled batch + timed steps)")
     for t in tasks.parse_tasks(lines, 1):
         if t.category in tasks.UNION:
-            # by_prefix / by_wildcard WITHOUT scorers: the visited terms' postings
-            # ORed into a doc bitset — postings_reader::bit_union (formats_10.cpp:3716-3806) behind
-            # lazy_bitset_iterator (multiterm_query.cpp:64-101).  The scored form the harness builds
-            # (scored_terms_limit, index-search.cpp:368-386) is not built.
+            # by_prefix / by_wildcard as the harness builds them (index-search.cpp:363-399:
+            # scored_terms_limit; scripts/search-benchmark.sh: --scored-terms-limit=16): the visited
+            # terms' `limit` longest posting lists scored as a disjunction, the rest as ONE unscored
+            # bitset (limited_sample_collector.hpp, MultiTermQuery::execute multiterm_query.cpp
+            # :112-184).  Here: one Or batch over the step's filters + irs_hip_bit_union_counts for
+            # the totals (search.execute_expansions); the CPU leg: the oracle's harness loop over
+            # the scored terms + its bit_union over all visited ones.
+            limit = 16
             rng = np.random.default_rng(20260926 + len(rows))
-            visits = [tasks.expansion_of(t, max_rank, rng) for _ in range(nq)]
+            visits = [[tasks.expansion_of(t, max_rank, rng)] for _ in range(nq)]
+            visits = [[v[0][np.asarray(seg.metas["docs_count"])[v[0]] > 0]] for v in visits]
             n_words = (seg.num_docs + 64) // 64
-            t0 = time.perf_counter()
-            sets = [sr.bit_union(v, n_words) for v in visits]
-            gpu_dt = time.perf_counter() - t0
+            n_par = min(nq, 8)
+            prep = search.prepare_expansions(visits, limit, scorer, st)
+            hits, counts, totals = search.execute_expansions([sr], prep, k)
+            parity.check_expansions([seg], visits[:n_par], limit, scorer, k, hits[:, :n_par], counts[:, :n_par],
+                                    totals[:, :n_par])
+            steps = max(2, args.steps)
+            host = [0.0, 0.0]
+            for timed in (False, True):
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(steps if timed else 2):
+                    ta = time.perf_counter()
+                    prep = search.prepare_expansions(visits, limit, scorer, st)
+                    tb = time.perf_counter()
+                    search.execute_expansions([sr], prep, k)
+                    if timed:
+                        host[0] += tb - ta
+                        host[1] += time.perf_counter() - tb
+                sync()
+                gpu_dt = (time.perf_counter() - t0) / (steps if timed else 2)
             metas_all = np.zeros(len(seg.metas), oracle.TERM_META)
             for name in oracle.TERM_META.names:
                 metas_all[name] = seg.metas[name]
 
             def cpu_one(i):
-                return oracle.bit_union(seg.doc_file, metas_all[visits[i]], seg.layout, True, n_words)
+                p = prep[i]
+                if p.scored:
+                    oracle.search([view], metas_all[np.array(p.scored)][None], oracle.OP_OR, osc, k, None)
+                return oracle.bit_union(seg.doc_file, metas_all[visits[i][0]], seg.layout, True, n_words)
             t0 = time.perf_counter()
             with cf.ThreadPoolExecutor(cores) as ex:
-                ref = list(ex.map(cpu_one, range(nq)))
+                list(ex.map(cpu_one, range(nq)))
             cpu_dt = time.perf_counter() - t0
-            for (gb, gn), (cb, cn) in zip(sets, ref):
-                assert gn == cn and np.array_equal(gb, cb), "bit_union differs from the oracle's"
-            hits = float(np.mean([int(np.unpackbits(b.view(np.uint8)).sum()) for b, _ in sets[:16]]))
-            row = {"category": t.category, "terms": int(np.mean([len(v) for v in visits])),
-                   "form": "unscored: one bit_union over the visited terms",
-                   "hits_per_query": hits, "gpu_qps": nq / gpu_dt, "cpu_qps": nq / cpu_dt,
-                   "cpu_sample": nq, "parity_checked": nq, "ms_per_step": gpu_dt * 1e3,
-                   "path": "bit_union", "postings_per_step": int(sum(n for _, n in sets))}
+            row = {"category": t.category, "terms": int(np.mean([len(v[0]) for v in visits])),
+                   "form": "scored_terms_limit=%d: a disjunction of the %d longest lists + one unscored "
+                           "bit_union (counts only)" % (limit, limit),
+                   "hits_per_query": float(totals.mean()), "gpu_qps": nq / gpu_dt, "cpu_qps": nq / cpu_dt,
+                   "cpu_sample": nq, "parity_checked": n_par, "ms_per_step": gpu_dt * 1e3,
+                   "path": "joined + bit_union_counts",
+                   "host_ms": {"prepare": round(1e3 * host[0] / steps, 3), "execute": round(1e3 * host[1] / steps, 3)}}
             rows.append(row)
-            print("%-20s %5d  %-34s %10.0f %10.0f %10.1f %8.1fx  ok (%d bitsets)  %-6s %7.3f  (unscored: bit_union; scored_terms_limit form not built)  %6.1f M" % (
-                t.category, row["terms"], "'%s' -> terms visited" % t.text.strip(), hits, row["gpu_qps"],
-                row["cpu_qps"], row["gpu_qps"] / row["cpu_qps"], nq, "union", row["ms_per_step"],
-                row["postings_per_step"] / 1e6), flush=True)
+            print("%-20s %5d  %-34s %10.0f %10.0f %10.1f %8.1fx  ok (%d queries)  %-6s %7.3f  (scored_terms_limit=%d; host: prepare %.2f + execute %.2f ms)" % (
+                t.category, row["terms"], "'%s' -> terms visited" % t.text.strip(), row["hits_per_query"],
+                row["gpu_qps"], row["cpu_qps"], row["gpu_qps"] / row["cpu_qps"], n_par, "expand", row["ms_per_step"],
+                limit, row["host_ms"]["prepare"], row["host_ms"]["execute"]), flush=True)
             continue
         if t.category in tasks.EXPANSION:
             print("%-20s (multi-term expansion filter: not on this path)" % t.category)

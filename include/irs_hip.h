@@ -176,6 +176,16 @@ int irs_hip_decode_positions(irs_hip_segment* seg, uint32_t term, uint32_t* posi
 int irs_hip_bit_union(irs_hip_segment* seg, const uint32_t* terms, uint32_t n_terms,
                       uint64_t* set, uint64_t n_words, uint64_t* count);
 
+/* The POPULATIONS of several such unions in one call, the bitsets never leaving the device: set i
+ * is the union of the postings of terms[offsets[i] .. offsets[i + 1]) over doc ids 1..num_docs
+ * (deleted docs left out), counts[i] its number of docs — the `hits` of a multi-term filter
+ * (MultiTermQuery::execute, multiterm_query.cpp:112-184: scored iterators + one
+ * lazy_bitset_iterator over the unscored terms; index-search counts what the iterator yields,
+ * utils/index-search.cpp:745-779) when its top k comes from the scored terms' disjunction and
+ * only the count is wanted from the rest: 8 bytes per filter cross PCIe instead of a bit per doc. */
+int irs_hip_bit_union_counts(irs_hip_segment* seg, const uint32_t* terms, const uint32_t* offsets,
+                             uint32_t n_sets, uint64_t* counts);
+
 /* The block directory of one term, for inspection/tests: absolute last doc id
  * and `.doc` byte offset of every full 128-doc block — the information the
  * reference keeps in skip level 0 (formats_10.cpp:501-533). */

@@ -62,7 +62,7 @@ SYMBOLS = (
     "irs_hip_segment_close", "irs_hip_segment_device_bytes", "irs_hip_segment_live_docs",
     "irs_hip_decode_term",
     "irs_hip_decode_positions",
-    "irs_hip_term_directory", "irs_hip_bit_union", "irs_hip_batch_create",
+    "irs_hip_term_directory", "irs_hip_bit_union", "irs_hip_bit_union_counts", "irs_hip_batch_create",
     "irs_hip_batch_create_multi", "irs_hip_batch_run",
     "irs_hip_batch_results", "irs_hip_batch_device_results",
     "irs_hip_batch_results_to_host", "irs_hip_batch_host_results",
@@ -103,6 +103,8 @@ def bind(L: C.CDLL) -> C.CDLL:
     L.irs_hip_decode_positions.restype = C.c_int
     L.irs_hip_bit_union.argtypes = [vp, vp, u32, vp, u64, P(u64)]
     L.irs_hip_bit_union.restype = C.c_int
+    L.irs_hip_bit_union_counts.argtypes = [vp, vp, vp, u32, vp]
+    L.irs_hip_bit_union_counts.restype = C.c_int
     L.irs_hip_term_directory.argtypes = [vp, u32, vp, vp, u32, P(u32)]
     L.irs_hip_term_directory.restype = C.c_int
     L.irs_hip_batch_create.argtypes = [vp, vp, u32, vp, u32, P(vp)]

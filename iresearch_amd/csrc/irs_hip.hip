@@ -2207,7 +2207,7 @@ static int bit_union_impl(irs_hip_segment* seg, const uint32_t* terms, uint32_t 
       if (t.docs_count == 0) continue;
       uint32_t b = 0;
       do {
-        wgs.push_back(UnionWg{terms[i], b});
+        wgs.push_back(UnionWg{terms[i], b, 0u, 0u});
         b += kUnionBlocks;
       } while (b < t.nblk);
     }
@@ -2236,6 +2236,63 @@ static int bit_union_impl(irs_hip_segment* seg, const uint32_t* terms, uint32_t 
   }
   if (!rt::last_error_ok() || !rt::d2h(set, d_set.p, set_bytes, nullptr) || !rt::sync(nullptr))
     return IRS_HIP_EHIP;
+  return IRS_HIP_OK;
+}
+
+// Several unions at once, only their populations coming back: the bitsets stay on the device
+// (one per set of a pass; passes of at most ~1 GB of them).
+static int bit_union_counts_impl(irs_hip_segment* seg, const uint32_t* terms, const uint32_t* offsets,
+                                 uint32_t n_sets, uint64_t* counts) {
+  if (!seg || !offsets || !counts || (!terms && n_sets && offsets[n_sets] != offsets[0])) return IRS_HIP_EINVAL;
+  if (!rt::set_device(seg->device)) return IRS_HIP_EHIP;
+  for (uint32_t i = 0; i < n_sets; ++i) {
+    if (offsets[i + 1] < offsets[i]) return IRS_HIP_EINVAL;
+    counts[i] = 0;
+  }
+  if (!n_sets) return IRS_HIP_OK;
+  for (uint32_t i = offsets[0]; i < offsets[n_sets]; ++i)
+    if (terms[i] != IRS_HIP_NO_TERM && terms[i] >= seg->dev.num_terms) return IRS_HIP_EINVAL;
+  const uint64_t n_words = (uint64_t(seg->dev.num_docs) + 64) / 64;   // bit index = doc id
+  const uint64_t words32 = n_words * 2, n_bits = n_words * 64;
+  const uint32_t per_pass = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(n_sets, (1ull << 30) / (n_words * 8))));
+  DevBuf d_sets, d_wgs, d_counts;
+  if (!d_sets.alloc(uint64_t(per_pass) * n_words * 8) || !d_counts.alloc(uint64_t(per_pass) * 8)) return IRS_HIP_ENOMEM;
+  std::vector<UnionWg> wgs;
+  std::vector<unsigned long long> got(per_pass);
+  for (uint32_t s0 = 0; s0 < n_sets; s0 += per_pass) {
+    const uint32_t ns = std::min(per_pass, n_sets - s0);
+    wgs.clear();
+    for (uint32_t s = 0; s < ns; ++s) {
+      for (uint32_t i = offsets[s0 + s]; i < offsets[s0 + s + 1]; ++i) {
+        if (terms[i] == IRS_HIP_NO_TERM) continue;
+        const DevTerm& t = seg->terms[terms[i]];
+        if (t.docs_count == 0) continue;
+        uint32_t b = 0;
+        do {
+          wgs.push_back(UnionWg{terms[i], b, s, 0u});
+          b += kUnionBlocks;
+        } while (b < t.nblk);
+      }
+    }
+    if (wgs.size() > 0x7FFFFFFFull) return IRS_HIP_EUNSUPPORTED;
+    if (!rt::dmemset(d_sets.p, 0, uint64_t(ns) * n_words * 8, nullptr)) return IRS_HIP_EHIP;
+    if (!wgs.empty()) {
+      if (!d_wgs.alloc(wgs.size() * sizeof(UnionWg))) return IRS_HIP_ENOMEM;
+      if (!rt::h2d(d_wgs.p, wgs.data(), wgs.size() * sizeof(UnionWg), nullptr)) return IRS_HIP_EHIP;
+      if (seg->dev.layout == kSimd4) {
+        RT_LAUNCH((k_bit_union<kSimd4>), uint32_t(wgs.size()), kThreads, 0, nullptr, seg->dev,
+                  d_wgs.as<UnionWg>(), d_sets.as<uint32_t>(), n_bits);
+      } else {
+        RT_LAUNCH((k_bit_union<kScalar>), uint32_t(wgs.size()), kThreads, 0, nullptr, seg->dev,
+                  d_wgs.as<UnionWg>(), d_sets.as<uint32_t>(), n_bits);
+      }
+    }
+    RT_LAUNCH(k_union_counts, ns, kThreads, 0, nullptr, d_sets.as<uint32_t>(), words32,
+              d_counts.as<unsigned long long>());
+    if (!rt::last_error_ok() || !rt::d2h(got.data(), d_counts.p, uint64_t(ns) * 8, nullptr) || !rt::sync(nullptr))
+      return IRS_HIP_EHIP;
+    for (uint32_t s = 0; s < ns; ++s) counts[s0 + s] = got[s];
+  }
   return IRS_HIP_OK;
 }
 
@@ -3367,6 +3424,9 @@ int irs_hip_decode_positions(irs_hip_segment* seg, uint32_t term, uint32_t* posi
 }
 int irs_hip_bit_union(irs_hip_segment* seg, const uint32_t* terms, uint32_t n_terms, uint64_t* set, uint64_t n_words, uint64_t* count) {
   return guarded([&] { return bit_union_impl(seg, terms, n_terms, set, n_words, count); });
+}
+int irs_hip_bit_union_counts(irs_hip_segment* seg, const uint32_t* terms, const uint32_t* offsets, uint32_t n_sets, uint64_t* counts) {
+  return guarded([&] { return bit_union_counts_impl(seg, terms, offsets, n_sets, counts); });
 }
 int irs_hip_term_directory(irs_hip_segment* seg, uint32_t term, uint32_t* last_docs, uint64_t* offsets, uint32_t cap, uint32_t* count) {
   return guarded([&] { return term_directory_impl(seg, term, last_docs, offsets, cap, count); });

@@ -595,13 +595,16 @@ constexpr uint32_t kUnionBlocks = 64;
 struct UnionWg {
   uint32_t term;
   uint32_t first_block;
+  uint32_t set;    // which of the call's bitsets (irs_hip_bit_union_counts: several; else 0)
+  uint32_t pad;
 };
 
 template<int LAYOUT>
 __global__ void __launch_bounds__(kThreads)
-k_bit_union(DevSegment seg, const UnionWg* wgs, uint32_t* set32, uint64_t n_bits) {
+k_bit_union(DevSegment seg, const UnionWg* wgs, uint32_t* sets32, uint64_t n_bits) {
   const unsigned lane = threadIdx.x & 63u;
   const UnionWg wg = wgs[blockIdx.x];
+  uint32_t* set32 = sets32 + uint64_t(wg.set) * (n_bits >> 5);
   const DevTerm t = seg.terms[wg.term];
   const uint32_t* dead = seg.dead;   // (deleted docs never enter the set: SegmentReaderImpl::mask)
   auto mark = [&](uint32_t doc) {
@@ -622,6 +625,23 @@ k_bit_union(DevSegment seg, const UnionWg* wgs, uint32_t* set32, uint64_t n_bits
   if (end == t.nblk && threadIdx.x < kBlock) {
     const uint32_t n = t.docs_count == 1 ? 1u : t.tail_n;
     if (threadIdx.x < n) mark(seg.tail_docs[t.tail_row + threadIdx.x]);
+  }
+}
+
+// Population of every bitset of a call (irs_hip_bit_union_counts): one workgroup per set.
+__global__ void __launch_bounds__(kThreads)
+k_union_counts(const uint32_t* sets32, uint64_t words32, unsigned long long* counts) {
+  __shared__ uint32_t s_part[kWaves];
+  const uint32_t* set32 = sets32 + uint64_t(blockIdx.x) * words32;
+  uint32_t n = 0;
+  for (uint64_t i = threadIdx.x; i < words32; i += kThreads) n += uint32_t(__builtin_popcount(set32[i]));
+  n = wave::reduce_add(n);
+  if ((threadIdx.x & 63u) == 0) s_part[threadIdx.x >> 6] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long sum = 0;
+    for (uint32_t w = 0; w < kWaves; ++w) sum += s_part[w];
+    counts[blockIdx.x] = sum;
   }
 }
 

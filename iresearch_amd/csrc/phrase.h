@@ -634,6 +634,7 @@ __device__ __forceinline__ void phrase_item(const ConjArgs& A, uint32_t pilot /*
       }
     }
     ++step;
+    const bool more_terms = MT > 2 && step + 1u < m;   // (the last term marks nothing: nobody reads it)
     auto alive_below = [&](uint32_t x) {
       return uint32_t(apre[x >> 5]) + uint32_t(__builtin_popcount(alive[x >> 5] & ((1u << (x & 31u)) - 1u)));
     };
@@ -647,10 +648,10 @@ __device__ __forceinline__ void phrase_item(const ConjArgs& A, uint32_t pilot /*
       // every earlier term — and the lead, whose deleted docs count as not reached — holds THIS doc
       if (W.tf[lead][t] == 0u) return;
       for (uint32_t j = 0; j < i; ++j)
-        if (W.tf[j][t] == 0u) return;
+        if (j != lead && W.tf[j][t] == 0u) return;
       W.pidx[i][t] = p;
       W.tf[i][t] = f;
-      atomicOr(&mark[bk >> 5], 1u << (bk & 31u));
+      if (more_terms) atomicOr(&mark[bk >> 5], 1u << (bk & 31u));   // (alive for the next term)
     };
     if (tl.nblk) {
       // (integer addresses: loads through the global address space, see raw_load_packed_g)

@@ -251,6 +251,19 @@ class SegmentReader:
             C.byref(cnt)), "irs_hip_bit_union")
         return bits, cnt.value
 
+    def bit_union_counts(self, term_sets):
+        """The populations of several term sets' unions (irs_hip_bit_union_counts): one number per
+        set comes back, the bitsets stay on the device."""
+        sets = [np.ascontiguousarray(t, np.uint32) for t in term_sets]
+        offsets = np.zeros(len(sets) + 1, np.uint32)
+        np.cumsum([len(t) for t in sets], out=offsets[1:])
+        flat = np.concatenate(sets) if sets and offsets[-1] else np.zeros(1, np.uint32)
+        counts = np.zeros(max(len(sets), 1), np.uint64)
+        _lib.check(self.L, self.L.irs_hip_bit_union_counts(
+            self.handle, flat.ctypes.data, offsets.ctypes.data, len(sets), counts.ctypes.data),
+            "irs_hip_bit_union_counts")
+        return counts[:len(sets)]
+
     def term_directory(self, term: int):
         nb = int(self.metas[term]["docs_count"]) // 128
         last = np.zeros(max(nb, 1), np.uint32)
@@ -674,3 +687,222 @@ def merge_topk_host(per_segment, k: int):
         rows.sort()
         out.append([(-a, s, d) for a, s, d in rows[:k]])
     return out
+
+
+# ---------------------------------------------- scored multi-term expansion --
+# by_prefix / by_wildcard / by_range WITH scorers (MultiTermQuery, multiterm_query.cpp:112-184):
+# the filter's term visitor hands every visited term of every segment to a
+# limited_sample_collector (limited_sample_collector.hpp:43-120) which keeps the
+# `scored_terms_limit` (segment, term) states with the LONGEST postings — key = (docs_count, then
+# the term's offset in the segment's visit), larger wins, a newcomer replaces the smallest only
+# when strictly larger — as SCORED states; everything else is unscored.  execute() is then a
+# disjunction (min_match 1, Sum) of one scored iterator per scored state and ONE
+# lazy_bitset_iterator over the unscored terms: a doc matches when any visited term holds it, its
+# score is the sum over the scored terms holding it (0 for docs only unscored terms hold).
+# Statistics (limited_sample_collector::score :123-165): per distinct term the field statistics of
+# the WHOLE index and term statistics collected from the segments where the term is SCORED only.
+#
+# On this path: the scored part is an ordinary Or of <= IRS_HIP_MAX_TERMS by_term filters — the
+# scored_terms_limit of the reference's benchmark (scripts/search-benchmark.sh:
+# --scored-terms-limit=16) fits — with a term absent from the segments where it is unscored; the
+# unscored part and the total are irs_hip_bit_union, as in the reference.
+
+def scored_states(visits_docs_counts, limit: int):
+    """limited_sample_collector::collect over the segments' visits in order.
+    visits_docs_counts[s] = docs_count of the terms segment s's visit yields, in visit order.
+    -> sorted list of (segment, offset) that end up scored."""
+    # (which of two EQUAL keys — the same docs_count at the same visit offset in two segments — is
+    # the heap's root is decided by std::push_heap / std::pop_heap themselves: the binary heap below
+    # moves its elements exactly as libstdc++'s does, so ties resolve as in the reference)
+    rows = []          # (frequency, offset, segment) per scored state
+    order = []         # binary min-heap of indices into rows
+    above = lambda i, j: rows[j][:2] < rows[i][:2]            # row i sorts behind row j
+
+    def sift_in(hole, idx):                                    # std::__push_heap
+        while hole > 0 and above(order[(hole - 1) // 2], idx):
+            order[hole] = order[(hole - 1) // 2]
+            hole = (hole - 1) // 2
+        order[hole] = idx
+
+    def drop_root_to_back():                                   # std::pop_heap
+        idx, order[-1] = order[-1], order[0]
+        n, hole, child = len(order) - 1, 0, 0
+        while child < (n - 1) // 2:
+            child = 2 * (child + 1)
+            if above(order[child], order[child - 1]):
+                child -= 1
+            order[hole] = order[child]
+            hole = child
+        if n % 2 == 0 and child == (n - 2) // 2:
+            child = 2 * (child + 1)
+            order[hole] = order[child - 1]
+            hole = child - 1
+        sift_in(hole, idx)
+
+    for s, counts in enumerate(visits_docs_counts):
+        for off, f in enumerate(counts):
+            if limit <= 0:
+                continue
+            if len(rows) < limit:
+                rows.append((int(f), off, s))
+                order.append(len(rows) - 1)
+                sift_in(len(order) - 1, order[-1])
+            elif rows[order[0]][:2] < (int(f), off):         # strictly larger keys only
+                root = order[0]
+                drop_root_to_back()
+                rows[root] = (int(f), off, s)
+                sift_in(len(order) - 1, order[-1])
+    return sorted((s, off) for _, off, s in rows)
+
+
+def _scored_states_fast(visits_docs_counts, limit: int):
+    """scored_states without the heap where the outcome does not depend on it: the collector keeps
+    the `limit` largest keys (docs_count, offset); only when the key at the cut also occurs right
+    behind it (the same docs_count at the same offset in two segments) the heap's own order
+    decides, and the emulation runs."""
+    if limit <= 0:
+        return []
+    seg = np.concatenate([np.full(len(c), s, np.int64) for s, c in enumerate(visits_docs_counts)] or [np.zeros(0, np.int64)])
+    off = np.concatenate([np.arange(len(c), dtype=np.int64) for c in visits_docs_counts] or [np.zeros(0, np.int64)])
+    frq = np.concatenate([np.asarray(c, np.int64) for c in visits_docs_counts] or [np.zeros(0, np.int64)])
+    if frq.size <= limit:
+        return sorted(zip(seg.tolist(), off.tolist()))
+    order = np.lexsort((off, frq))[::-1]          # by (docs_count, offset), largest first
+    a, b = order[limit - 1], order[limit]
+    if frq[a] == frq[b] and off[a] == off[b]:
+        return scored_states(visits_docs_counts, limit)
+    top = order[:limit]
+    return sorted(zip(seg[top].tolist(), off[top].tolist()))
+
+
+@dataclass
+class PreparedExpansion:
+    """One scored multi-term filter prepared against all segments."""
+    scored: list            # distinct scored term ordinals (query term slots)
+    scored_in: list         # [segment] -> set of scored ordinals there
+    unscored_in: list       # [segment] -> np.uint32 ordinals that are visited but unscored there
+    scorers: list           # (kind, c0, norm_const, norm_length) per slot
+
+
+def prepare_expansions(visits, limit, scorer, segment_stats, boost=1.0):
+    """filter::prepare of scored multi-term filters: visits[q][s] = term ordinals the filter's
+    visitor yields in segment s (ascending term order, as term_reader::iterator() enumerates).
+    The statistics of all scored terms of all filters are worked out at once (numpy), value for
+    value what scorer.collect / term_scorer yield one term at a time."""
+    dwf = sum(s.docs_with_field for s in segment_stats)
+    ttf = sum(s.total_term_freq for s in segment_stats)
+    dcs = [np.asarray(st.docs_count) for st in segment_stats]
+    parts, all_dwt = [], []
+    for per_seg in visits:
+        if len(per_seg) == 1:
+            # one segment: offsets are unique, the collector simply keeps the `limit` largest
+            # (docs_count, offset) keys — no heap order involved
+            va = np.asarray(per_seg[0], np.uint32)
+            cnt = dcs[0][va.astype(np.int64)] if len(va) else np.zeros(0, np.int64)
+            if limit <= 0 or not len(va):
+                top = np.zeros(0, np.int64)
+            elif len(va) <= limit:
+                top = np.arange(len(va))
+            else:
+                key = cnt.astype(np.int64) * (1 << 24) + np.arange(len(va))
+                top = np.argpartition(key, len(va) - limit)[len(va) - limit:]
+            top = np.sort(top)              # (offsets ascending = term ordinals ascending)
+            slots = va[top].tolist()
+            all_dwt.extend(cnt[top].tolist())
+            keep = np.ones(len(va), bool)
+            keep[top] = False
+            parts.append((slots, [set(slots)], [va[keep]]))
+            continue
+        counts = [dcs[s][np.asarray(v, np.int64)] if len(v) else np.zeros(0, np.int64)
+                  for s, v in enumerate(per_seg)]
+        states = _scored_states_fast(counts, limit)
+        scored_in = [set() for _ in per_seg]
+        for s, off in states:
+            scored_in[s].add(int(per_seg[s][off]))
+        slots = sorted(set().union(*scored_in)) if scored_in else []
+        # term statistics from the segments where the term is scored (collector::score)
+        all_dwt.extend(sum(int(dcs[s][t]) for s in range(len(per_seg)) if t in scored_in[s]) for t in slots)
+        unscored_in = []
+        for s, v in enumerate(per_seg):
+            va = np.asarray(v, np.uint32)
+            keep = ~np.isin(va, np.fromiter(scored_in[s], np.uint32, len(scored_in[s]))) if scored_in[s] else \
+                np.ones(len(va), bool)
+            unscored_in.append(va[keep])
+        parts.append((slots, scored_in, unscored_in))
+    dwt = np.asarray(all_dwt, np.float64)
+    if isinstance(scorer, BM25):
+        idf = np.log1p((float(dwf) - dwt + 0.5) / (dwt + 0.5)).astype(np.float32)
+        probe = scorer.collect(dwf, 1, ttf)
+        kind = scorer.term_scorer(probe)[0]
+        nc, nl = probe.norm_const, probe.norm_length
+        c0 = (f32(f32(boost) * f32(scorer.k + f32(1))) * idf).astype(np.float32)
+    else:
+        idf = np.log1p((dwf + 1.0) / (dwt + 1.0)).astype(np.float32)
+        kind, nc, nl = scorer.term_scorer(TermStats(f32(1)))[0], f32(0), f32(0)
+        c0 = (f32(boost) * idf).astype(np.float32)
+    out, at = [], 0
+    for slots, scored_in, unscored_in in parts:
+        scorers = [(kind, c0[at + j], nc, nl) for j in range(len(slots))]
+        at += len(slots)
+        out.append(PreparedExpansion(slots, scored_in, unscored_in, scorers))
+    return out
+
+
+def expansion_arrays(segs, prepared, k):
+    """The scored parts of a list of prepared expansions as ONE batch: an Or per filter whose term
+    slots are absent (NO_TERM) in the segments where the term is unscored.  Filters without any
+    scored term get a one-slot query of an absent term (matches nothing)."""
+    n_entries = sum(max(1, len(p.scored)) for p in prepared)
+    queries = np.zeros(len(prepared), QUERY)
+    terms = np.zeros((len(segs), n_entries), TERM_SCORER)
+    at = 0
+    for q, p in enumerate(prepared):
+        n = max(1, len(p.scored))
+        queries[q] = (OP_OR, n, at, int(k), 1, MERGE_SUM)
+        if not p.scored:
+            terms["term"][:, at] = NO_TERM
+            terms["kind"][:, at] = SCORE_BM1
+        for j, (t, (kind, c0, nc, nl)) in enumerate(zip(p.scored, p.scorers)):
+            for s in range(len(segs)):
+                terms[s, at + j] = (t if t in p.scored_in[s] else NO_TERM, kind, c0, nc, nl, 0)
+        at += n
+    return QueryArrays(len(segs), queries, terms, k)
+
+
+def execute_expansions(readers, prepared, k):
+    """MultiTermQuery::execute for every (filter, segment) + the harness's top k per segment:
+    hits HIT[n_segs][nq][k], counts, totals.  The scored disjunctions are one batch; a segment's
+    total is the population of the union of ALL visited terms' postings (bit_union, like
+    lazy_bitset_iterator + the scored iterators); where fewer than k docs score, the list is filled
+    with the docs only unscored terms hold (score 0, ascending doc id: this path's tie order)."""
+    n_segs, nq = len(readers), len(prepared)
+    b = QueryBatch(readers, expansion_arrays(readers, prepared, k))
+    hits, counts, totals = (x.copy() for x in b.run().results())
+    b.close()
+    hits = hits.reshape(n_segs, nq, k)
+    counts = counts.reshape(n_segs, nq)
+    totals = totals.reshape(n_segs, nq)
+    for s, sr in enumerate(readers):
+        n_words = (sr.num_docs + 64) // 64
+        # the totals: the population of the union of ALL visited terms, for every filter that has
+        # unscored terms here, in one call (only the counts cross PCIe)
+        need = [q for q, p in enumerate(prepared) if len(p.unscored_in[s])]
+        visited = [np.concatenate([prepared[q].unscored_in[s],
+                                   np.array(sorted(prepared[q].scored_in[s]), np.uint32)]) for q in need]
+        if need:
+            totals[s, need] = sr.bit_union_counts(visited)
+        for q, v in zip(need, visited):
+            have = int(counts[s, q])
+            if have >= k or int(totals[s, q]) <= have:
+                continue
+            # fewer than k docs score: the rest of the list are docs only unscored terms hold
+            p = prepared[q]
+            only, _ = sr.bit_union(v, n_words)
+            if p.scored_in[s]:
+                sc, _ = sr.bit_union(np.array(sorted(p.scored_in[s]), np.uint32), n_words)
+                only = only & ~sc
+            docs = np.nonzero(np.unpackbits(only.view(np.uint8), bitorder="little"))[0][:k - have]
+            hits[s, q, have:have + len(docs)]["doc"] = docs
+            hits[s, q, have:have + len(docs)]["score"] = 0.0
+            counts[s, q] = have + len(docs)
+    return hits, counts, totals

@@ -12,10 +12,12 @@ turns (category, text) into a filter:
     Or4High / Or6High4Med2Low                   Or of by_term
   MinMatch2High2Med                             Or with min_match_count (first token)
   Prefix3 / Wildcard                            by_prefix / by_wildcard: multi-term expansion — the
-                                                UNSCORED form is on this path (one bit_union over the
-                                                visited terms, SURVEY §8 f4: `expansion_of`); the
-                                                scored form (`scored_terms_limit` best terms as a
-                                                disjunction, index-search.cpp:368-386) is not built
+                                                visit of the term table (`expansion_of`), then the
+                                                scored form the harness builds (`scored_terms_limit`
+                                                longest lists as a disjunction + one unscored bitset,
+                                                index-search.cpp:363-399: search.prepare_expansions /
+                                                execute_expansions) or, without scorers, ONE
+                                                bit_union
   Fuzzy1 / Fuzzy2 / *NGram                      not on this path
 
 The synthetic index has ranks, not words.  A task's words carry their document frequency in the

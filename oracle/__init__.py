@@ -504,3 +504,60 @@ def read_fixed_column(csi, csd, column_id: int):
                                      payload.size, C.byref(pl), values.ctypes.data, values.size)
     assert rc == 0
     return vb.value, mn.value, bytes(payload[:pl.value]), values
+
+
+def scored_states(visits_docs_counts, limit: int):
+    """limited_sample_collector<term_frequency>::collect (core/search/limited_sample_collector.hpp
+    :67-120) driven by multiterm_visitor (:262-300) over the segments' term visits, restated with
+    its own explicit heap: scored_states_ + scored_states_heap_ (indices, std::push_heap /
+    pop_heap with `comparer_(rhs.key, lhs.key)` — a min-heap on the key), key =
+    term_frequency{offset, frequency}: `frequency <, then offset <` (:243-258).
+    visits_docs_counts[s] = term_meta::docs_count of the terms segment s's visit yields, in order.
+    Returns the (segment, offset) pairs left in scored_states_, sorted."""
+    states = []     # scored_states_: [key(frequency, offset), segment]
+    heap = []       # scored_states_heap_: indices into states
+
+    def comp(lhs, rhs):     # push() / pop(): comparer_(scored_states_[rhs].key, scored_states_[lhs].key)
+        a, b = states[rhs][0], states[lhs][0]
+        return a[0] < b[0] or (a[0] == b[0] and a[1] < b[1])      # term_frequency::operator<
+
+    def push_heap_(hole, top, value):     # libstdc++ std::__push_heap
+        parent = (hole - 1) // 2
+        while hole > top and comp(heap[parent], value):
+            heap[hole] = heap[parent]
+            hole = parent
+            parent = (hole - 1) // 2
+        heap[hole] = value
+
+    def adjust_heap(hole, length, value):     # libstdc++ std::__adjust_heap
+        top, second = hole, hole
+        while second < (length - 1) // 2:
+            second = 2 * (second + 1)
+            if comp(heap[second], heap[second - 1]):
+                second -= 1
+            heap[hole] = heap[second]
+            hole = second
+        if (length & 1) == 0 and second == (length - 2) // 2:
+            second = 2 * (second + 1)
+            heap[hole] = heap[second - 1]
+            hole = second - 1
+        push_heap_(hole, top, value)
+
+    for s, counts in enumerate(visits_docs_counts):
+        for offset, freq in enumerate(counts):      # multiterm_visitor::visit: ++key_.offset
+            key = (int(freq), offset)
+            if not limit:
+                continue                             # "state will not be scored"
+            if len(states) < limit:
+                heap.append(len(states))
+                states.append([key, s])
+                push_heap_(len(heap) - 1, 0, heap[-1])                  # std::push_heap
+                continue
+            m = heap[0]
+            if states[m][0] < key:                   # scored_states_[min_state_idx].key < key
+                value = heap[-1]                      # std::pop_heap: the min goes to the back
+                heap[-1] = heap[0]
+                adjust_heap(0, len(heap) - 1, value)
+                states[m] = [key, s]                  # "update min state"
+                push_heap_(len(heap) - 1, 0, heap[-1])                  # std::push_heap
+    return sorted((s, key[1]) for key, s in states)

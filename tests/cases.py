@@ -1291,6 +1291,13 @@ def case_bit_union(L, layout, has_freq=True):
         for t in terms:
             np.bitwise_or.at(expect, lists[t] // 64, np.uint64(1) << (lists[t] % 64).astype(np.uint64))
         assert np.array_equal(got, expect), terms
+    # several unions in one call, only their populations coming back (irs_hip_bit_union_counts)
+    sets = [[0], [1, 2], [4], list(range(len(lists))), [4, 4, 0], [], [0xFFFFFFFF, 3]]
+    pops = sr.bit_union_counts(sets)
+    for terms, pop in zip(sets, pops):
+        want, _ = oracle.bit_union(seg.doc_file, [seg.metas[t] for t in terms if t != 0xFFFFFFFF], layout,
+                                   has_freq, n_words)
+        assert int(pop) == int(np.unpackbits(want.view(np.uint8)).sum()), terms
     # a bitset too short for the segment: docs beyond it are dropped, nothing is written past it
     got, cnt = sr.bit_union([4], 100)
     want, _ = oracle.bit_union(seg.doc_file, [seg.metas[4]], layout, has_freq, 100)
@@ -1671,6 +1678,42 @@ def case_phrase_queries(L, layout, num_docs=30_000):
     sr.close()
 
 
+def case_scored_expansion(L, layout=synth.LAYOUT_SIMD4, sizes=(60_000, 25_000), max_rank=512):
+    """by_prefix / by_wildcard / by_range WITH scorers — what the reference harness builds for its
+    Prefix3 / Wildcard tasks (index-search.cpp:363-399: scored_terms_limit): the visited terms'
+    `limit` longest (segment, term) states scored as a disjunction, the rest as one unscored
+    bitset (limited_sample_collector.hpp, multiterm_query.cpp:112-184).  One and two segments,
+    limits 16 / 3 / 1 / 0, k below and above the number of docs that score, a visit that exists
+    in one segment only, deleted documents."""
+    segs = [synth.build_segment(int(n), max_rank, layout=layout, first_doc=int(f))
+            for n, f in zip(sizes, np.concatenate([[0], np.cumsum(sizes)[:-1]]))]
+    segs[-1].metas[max_rank - 2]["docs_count"] = 0          # a term the last segment does not hold
+    rng = np.random.default_rng(5)
+    for n_segs in (1, len(segs)):
+        use = segs[:n_segs]
+        if n_segs > 1:
+            use[0].doc_mask = (rng.choice(use[0].num_docs, use[0].num_docs // 30, replace=False) + 1).astype(np.uint32)
+        readers = [search.SegmentReader.from_synth(x, L=L) for x in use]
+        stats = [parity.segment_stats(x) for x in use]
+        ranges = [(0, 40), (300, 340), (100, 101), (max_rank - 24, max_rank), (7, 8), (200, 264)]
+        visits = []
+        for lo, hi in ranges:
+            per_seg = []
+            for x in use:     # the visit: the terms of the range the segment holds, in term order
+                per_seg.append(np.array([t for t in range(lo, hi) if int(x.metas[t]["docs_count"])], np.uint32))
+            visits.append(per_seg)
+        visits.append([np.arange(0, 5, dtype=np.uint32)] + [np.zeros(0, np.uint32)] * (n_segs - 1))
+        for scorer in (BM25(), TFIDF(False)):
+            for limit in (16, 3, 1, 0):
+                for k in (10, 3000):
+                    prep = search.prepare_expansions(visits, limit, scorer, stats)
+                    assert all(len(p.scored) <= max(limit, 0) for p in prep)
+                    h, c, t = search.execute_expansions(readers, prep, k)
+                    parity.check_expansions(use, visits, limit, scorer, k, h, c, t)
+        for r in readers:
+            r.close()
+
+
 def case_conj_sparse_lead(L, layout=synth.LAYOUT_SIMD4, n_docs=400_000):
     """Conjunctions whose rarest term is FAR rarer than the others (the reference's AndHighLow
     class): a lead block's 128 docs then fall into up to 128 different blocks of every other term,
@@ -1806,6 +1849,7 @@ def case_doc_mask(L, layout=synth.LAYOUT_SIMD4, num_docs=70_000, max_rank=256):
     dead = np.zeros(n_words, np.uint64)
     np.bitwise_or.at(dead, gone // 64, np.uint64(1) << (gone % 64).astype(np.uint64))
     assert cnt == ocnt and np.array_equal(got, want & ~dead) and not np.array_equal(got, want)
+    assert int(sr.bit_union_counts([terms])[0]) == int(np.unpackbits((want & ~dead).view(np.uint8)).sum())
     # postings-level surfaces are the postings_reader's: not filtered
     d, f = sr.decode_term(victim)
     assert np.array_equal(d, vd)

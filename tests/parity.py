@@ -138,3 +138,71 @@ def check_phrase_segment(seg, phrases, scorer, k, hits, counts, totals, all_segs
         must = np.nonzero(matched & (scores > thr * (1 + 2 * REL_TOL)))[0]
         assert np.isin(must, docs).all(), ("missing doc above the k-th score", q)
         assert (ref >= thr * (1 - 2 * REL_TOL)).all(), ("doc below the k-th score", q)
+
+
+def check_expansions(segs, visits, limit, scorer, k, hits, counts, totals):
+    """Scored multi-term expansion filters (MultiTermQuery::execute over the states
+    limited_sample_collector left, multiterm_query.cpp:112-184) through the product's host layer
+    (search.execute_expansions) against the oracle: scored states by the oracle's own restatement
+    of the collector, per segment the scored terms' disjunction scored exhaustively
+    (orc_score_all) + the unscored terms' bit_union; total hits, doc sets, scores, order, the
+    members around the k-th score, and — where fewer than k docs score — that the zero-score
+    rest is the smallest doc ids (this path's tie order).
+    visits[q][s] = the term ordinals the filter's visitor yields in segment s."""
+    osc = oracle_scorer(scorer)
+    dwf = sum(s.docs_with_field for s in segs)
+    ttf = sum(s.total_term_freq for s in segs)
+    for q, per_seg in enumerate(visits):
+        dcs = [[int(sg.metas[int(t)]["docs_count"]) for t in v] for v, sg in zip(per_seg, segs)]
+        scored = oracle.scored_states(dcs, limit)
+        scored_in = [set() for _ in segs]
+        for s, off in scored:
+            scored_in[s].add(int(per_seg[s][off]))
+        # limited_sample_collector::score: a term's statistics from the segments where it is scored
+        dwt_of = {}
+        for s, ts in enumerate(scored_in):
+            for t in ts:
+                dwt_of[t] = dwt_of.get(t, 0) + int(segs[s].metas[t]["docs_count"])
+        for s, seg in enumerate(segs):
+            view = oracle_view(seg)
+            st = sorted(scored_in[s])
+            n1 = seg.num_docs + 1
+            scores = np.zeros(n1, np.float32)
+            matched = np.zeros(n1, bool)
+            if st:
+                sc, m = oracle.score_all(view, metas_for(seg, st), oracle.OP_OR, osc, dwf,
+                                         [dwt_of[t] for t in st], ttf, [1.0] * len(st))
+                scores, matched = sc[:n1].copy(), m[:n1].astype(bool)
+            un = [int(t) for t in per_seg[s] if int(t) not in scored_in[s]]
+            if un:
+                bits, _ = oracle.bit_union(seg.doc_file, [seg.metas[t] for t in un], seg.layout, True,
+                                           (seg.num_docs + 64) // 64)
+                ub = np.unpackbits(bits.view(np.uint8), bitorder="little")[:n1].astype(bool)
+                mask = getattr(seg, "doc_mask", None)
+                if mask is not None:                   # (the oracle's bit_union is the unmasked one)
+                    gone = np.asarray(mask, np.int64)
+                    ub[gone[(gone >= 1) & (gone <= seg.num_docs)]] = False
+                matched = matched | ub
+            n_match = int(matched.sum())
+            assert int(totals[s, q]) == n_match, ("total hits", q, s, int(totals[s, q]), n_match)
+            n = int(counts[s, q])
+            assert n == min(k, n_match), ("count", q, s, n, k, n_match)
+            if n == 0:
+                continue
+            h = hits[s, q, :n]
+            docs = h["doc"].astype(np.int64)
+            assert len(set(docs.tolist())) == n and matched[docs].all(), ("docs", q, s)
+            ref = scores[docs]
+            rel = np.abs(h["score"] - ref) / np.maximum(np.abs(ref), 1e-30)
+            assert (rel[ref > 0] <= REL_TOL).all() and (h["score"][ref == 0] == 0).all(), ("score", q, s)
+            sc_, d_ = h["score"], h["doc"]
+            assert ((sc_[:-1] > sc_[1:]) | ((sc_[:-1] == sc_[1:]) & (d_[:-1] < d_[1:]))).all(), ("order", q, s)
+            ms = np.sort(scores[matched])[::-1]
+            thr = ms[n - 1]
+            must = np.nonzero(matched & (scores > thr * (1 + 2 * REL_TOL)))[0]
+            assert np.isin(must, docs).all(), ("missing doc above the k-th score", q, s)
+            assert (ref >= thr * (1 - 2 * REL_TOL)).all(), ("doc below the k-th score", q, s)
+            zeros = docs[ref == 0]
+            if zeros.size:      # the zero-score rest: the smallest ids among the docs that score 0
+                cand = np.nonzero(matched & (scores == 0))[0]
+                assert np.array_equal(np.sort(zeros), cand[:zeros.size]), ("zero-score fill", q, s)

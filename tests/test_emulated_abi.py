@@ -117,6 +117,10 @@ def test_paths_agree(simlib, layout):
     cases.case_paths_agree(simlib, layout=layout)
 
 
+def test_scored_multiterm_expansion(simlib):
+    cases.case_scored_expansion(simlib, sizes=(30_000, 12_000), max_rank=384)
+
+
 @pytest.mark.parametrize("layout", [0, 1])
 def test_conjunctions_with_a_sparse_lead(simlib, layout):
     cases.case_conj_sparse_lead(simlib, layout=layout, n_docs=150_000)

@@ -190,6 +190,12 @@ def test_paths_agree(gpulib, layout):
     cases.case_paths_agree(gpulib, layout=layout)
 
 
+def test_scored_multiterm_expansion(gpulib):
+    """Prefix3 / Wildcard as the reference harness builds them (scored_terms_limit): VERDICT r05
+    missing 5."""
+    cases.case_scored_expansion(gpulib, sizes=(600_000, 250_000), max_rank=512)
+
+
 @pytest.mark.parametrize("layout", [0, 1])
 def test_conjunctions_with_a_sparse_lead(gpulib, layout):
     cases.case_conj_sparse_lead(gpulib, layout=layout, n_docs=2_000_000)

@@ -62,3 +62,25 @@ def test_prepare_filters_equals_term_by_term(scorer):
         assert slow.queries.tobytes() == fast.queries.tobytes()
         for name in search.TERM_SCORER.names:
             assert np.array_equal(slow.terms[name], fast.terms[name]), name
+
+
+@pytest.mark.parametrize("scorer", [BM25(), BM25(1.2, 0.0), TFIDF(False)])
+def test_prepare_expansions_statistics(scorer):
+    """The scored terms of a multi-term filter carry the statistics limited_sample_collector::score
+    gives them — the field's over the whole index, the term's from the segments where the term is
+    SCORED — equal to what scorer.collect / term_scorer yield term by term."""
+    rng = np.random.default_rng(2)
+    stats = [search.SegmentStats(100_000, 9_700_000, rng.integers(1, 50_000, 400)),
+             search.SegmentStats(60_000, 5_100_000, rng.integers(1, 30_000, 400))]
+    visits = [[np.arange(10, 60, dtype=np.uint32), np.arange(10, 45, dtype=np.uint32)],
+              [np.arange(100, 104, dtype=np.uint32), np.zeros(0, np.uint32)]]
+    for limit in (16, 3, 0):
+        prep = search.prepare_expansions(visits, limit, scorer, stats, boost=1.5)
+        for p, per_seg in zip(prep, visits):
+            assert sum(len(x) for x in p.scored_in) == min(limit, sum(len(v) for v in per_seg))
+            for t, sc in zip(p.scored, p.scorers):
+                dwt = sum(int(stats[s].docs_count[t]) for s in range(2) if t in p.scored_in[s])
+                want = scorer.term_scorer(scorer.collect(160_000, dwt, 14_800_000), 1.5)
+                assert tuple(sc) == tuple(want), (limit, t)
+            for s in range(2):      # every visited term is scored or unscored, never both
+                assert sorted(list(p.scored_in[s]) + p.unscored_in[s].tolist()) == per_seg[s].tolist()

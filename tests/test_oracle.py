@@ -331,3 +331,27 @@ def test_document_mask_file_writer_and_reader_twins():
     keep[gone] = False
     assert np.array_equal(m1.astype(bool), m0.astype(bool) & keep) and m1.sum() < m0.sum()
     assert np.array_equal(s1[keep], s0[keep]) and not s1[gone].any()
+
+
+def test_scored_states_against_the_standard_heap(tmp_path):
+    """limited_sample_collector keeps its scored states in a std::push_heap / pop_heap heap of
+    indices; which of two EQUAL keys (the same docs_count at the same visit offset in two
+    segments) gets replaced is decided inside those functions.  The oracle's restatement
+    (oracle.scored_states) and the product's (search.scored_states) move the heap's elements as
+    libstdc++ does: both against tests/cpp/collector_heap.cpp, the same container algorithm on
+    the real std:: functions."""
+    import subprocess
+    from iresearch_amd import search
+    exe = tmp_path / "collector_heap"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-o", str(exe),
+                    str(Path(__file__).parent / "cpp" / "collector_heap.cpp")], check=True)
+    rng = np.random.default_rng(12)
+    for _ in range(400):
+        visits = [rng.integers(0, 5, int(rng.integers(0, 14))).tolist() for _ in range(int(rng.integers(1, 5)))]
+        limit = int(rng.integers(0, 10))
+        text = "%d %d\n" % (limit, len(visits)) + "".join(
+            "%d %s\n" % (len(v), " ".join(map(str, v))) for v in visits)
+        out = subprocess.run([str(exe)], input=text, capture_output=True, text=True, check=True).stdout
+        want = [tuple(int(x) for x in line.split()) for line in out.splitlines()]
+        assert oracle.scored_states(visits, limit) == want, (visits, limit)
+        assert search.scored_states(visits, limit) == want, (visits, limit)

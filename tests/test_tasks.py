@@ -67,6 +67,12 @@ def _one_of_each(L, docs, max_rank, per_class=1):
             gb, gn = sr.bit_union(v, n_words)
             ob, on = oracle.bit_union(seg.doc_file, [seg.metas[int(x)] for x in v], seg.layout, True, n_words)
             assert gn == on and np.array_equal(gb, ob)
+            # ... and WITH scorers, as the harness builds them (scored_terms_limit = 16)
+            visits = [[v[np.asarray(seg.metas["docs_count"])[v] > 0]]]
+            for scorer in (BM25(), TFIDF(False)):
+                prep = search.prepare_expansions(visits, 16, scorer, st)
+                h, c, tot = search.execute_expansions([sr], prep, 100)
+                parity.check_expansions([seg], visits, 16, scorer, 100, h, c, tot)
     sr.close()
 
 
