@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define IRS_HIP_ABI_VERSION 10
+#define IRS_HIP_ABI_VERSION 11
 #define IRS_HIP_BLOCK_SIZE 128u  /* postings per block, formats_10.cpp:90 */
 #define IRS_HIP_MAX_TERMS 16u    /* terms per boolean query               */
 #define IRS_HIP_MAX_K 4096u      /* largest top-k                         */

@@ -24,6 +24,7 @@
 #include <functional>
 #include <memory>
 #include <stdexcept>
+#include <utility>
 #include <string>
 #include <variant>
 #include <vector>
@@ -169,7 +170,10 @@ struct PreparedQuery {
   int32_t op = IRS_HIP_OP_OR;
   uint32_t min_match = 0;
   uint32_t merge = IRS_HIP_MERGE_SUM;
-  std::vector<irs_hip_term_scorer> terms;  // .term = the ordinal; same for every segment here
+  std::vector<irs_hip_term_scorer> terms;  // .term = the ordinal; same for every segment here ...
+  // ... unless segment_terms[s][i] names slot i's ordinal in segment s (IRS_HIP_NO_TERM: the
+  // segment has no state for it) — what a scored multi-term filter prepares (prepare_expansion)
+  std::vector<std::vector<uint32_t>> segment_terms;
 };
 
 // filter::prepare for a list of filters against ALL segments (statistics are index-global:
@@ -273,6 +277,21 @@ class SegmentReader {
           "irs_hip_bit_union");
     return count;
   }
+  // the population of the union of each term set's postings, all sets in one call; only the
+  // counts come back (irs_hip_bit_union_counts: the `hits=` of multi-term filters)
+  std::vector<uint64_t> bit_union_counts(const std::vector<std::vector<uint32_t>>& sets) const {
+    std::vector<uint32_t> terms, offsets{0};
+    for (const auto& set : sets) {
+      terms.insert(terms.end(), set.begin(), set.end());
+      offsets.push_back(uint32_t(terms.size()));
+    }
+    std::vector<uint64_t> counts(sets.size());
+    if (!sets.empty())
+      check(irs_hip_bit_union_counts(h_, terms.data(), offsets.data(), uint32_t(sets.size()),
+                                     counts.data()),
+            "irs_hip_bit_union_counts");
+    return counts;
+  }
 
  private:
   irs_hip_segment* h_ = nullptr;
@@ -319,11 +338,22 @@ class QueryBatch {
         }
         std::vector<irs_hip_term_scorer> all;
         std::vector<irs_hip_segment*> handles;
-        for (const SegmentReader* s : segments) {
+        for (size_t si = 0; si < segments.size(); ++si) {
+          const SegmentReader* s = segments[si];
           handles.push_back(s->handle());
+          const size_t base = all.size();
           for (irs_hip_term_scorer e : entries) {
             if (e.term >= s->num_terms()) e.term = IRS_HIP_NO_TERM;
             all.push_back(e);
+          }
+          for (size_t i = 0; i < part.index.size(); ++i) {
+            const PreparedQuery& p = prepared[part.index[i]];
+            if (p.segment_terms.empty()) continue;
+            if (p.segment_terms.size() != segments.size() ||
+                p.segment_terms[si].size() != p.terms.size())
+              throw illegal_argument(IRS_HIP_EINVAL, "segment_terms: [segment][term slot]");
+            for (size_t j = 0; j < p.terms.size(); ++j)
+              all[base + queries[i].first_term + j].term = p.segment_terms[si][j];
           }
         }
         check(irs_hip_batch_create_multi(handles.data(), n_segments_, queries.data(),
@@ -1407,6 +1437,152 @@ DocSet execute_unscored(const SegmentReader& segment, const std::vector<std::str
   const std::vector<uint32_t> ordinals = visit(field_terms, flt);
   if (!ordinals.empty()) out.postings = segment.bit_union(ordinals, out.words);
   return out;
+}
+
+// ---- scored multi-term filters: by_prefix / by_wildcard / by_range with scored_terms_limit ----
+// MultiTermQuery (core/search/multiterm_query.cpp:77-145) over the states that
+// limited_sample_collector<term_frequency> keeps (core/search/limited_sample_collector.hpp
+// :67-120, 126-170): the `scored_terms_limit` visited terms with the largest (docs_count, visit
+// offset) keys are scored, each with the statistics of the segments where it IS scored; every other
+// visited term only contributes documents (score 0).
+struct PreparedExpansion {
+  PreparedQuery scored;                            // Or of the scored terms, segment_terms filled
+  std::vector<std::vector<uint32_t>> scored_in;    // [segment]: ordinals scored there (ascending)
+  std::vector<std::vector<uint32_t>> unscored_in;  // [segment]: visited, not scored (visit order)
+};
+
+// limited_sample_collector::collect over the segments in order -> (segment, visit offset) of the
+// states left scored.  The container algorithm is the reference's: an index min-heap moved by
+// std::push_heap / std::pop_heap, a new key replaces the root only when strictly larger.
+inline std::vector<std::pair<uint32_t, uint32_t>> scored_states(
+    const std::vector<std::vector<uint32_t>>& visits_docs_counts, size_t limit) {
+  struct State {
+    uint32_t frequency, offset, segment;
+    bool less(uint32_t f, uint32_t o) const { return frequency < f || (frequency == f && offset < o); }
+  };
+  std::vector<State> states;
+  std::vector<size_t> heap;
+  auto comp = [&](size_t l, size_t r) { return states[r].less(states[l].frequency, states[l].offset); };
+  for (uint32_t s = 0; limit && s < visits_docs_counts.size(); ++s) {
+    const auto& counts = visits_docs_counts[s];
+    for (uint32_t off = 0; off < counts.size(); ++off) {
+      if (states.size() < limit) {
+        heap.push_back(states.size());
+        states.push_back(State{counts[off], off, s});
+        std::push_heap(heap.begin(), heap.end(), comp);
+      } else if (const size_t root = heap.front(); states[root].less(counts[off], off)) {
+        std::pop_heap(heap.begin(), heap.end(), comp);
+        states[root] = State{counts[off], off, s};
+        std::push_heap(heap.begin(), heap.end(), comp);
+      }
+    }
+  }
+  std::vector<std::pair<uint32_t, uint32_t>> out;
+  for (const State& st : states) out.emplace_back(st.segment, st.offset);
+  std::sort(out.begin(), out.end());
+  return out;
+}
+
+// filter::prepare of ONE scored multi-term filter: visits[s] = the ordinals the filter's visitor
+// yields in segment s, in term order (visit(field_terms, flt) per segment).
+template<typename Scorer>
+PreparedExpansion prepare_expansion(const std::vector<std::vector<uint32_t>>& visits,
+                                    size_t scored_terms_limit, const Scorer& scorer,
+                                    const std::vector<SegmentStats>& index, float boost = 1.f) {
+  if (visits.size() != index.size())
+    throw illegal_argument(IRS_HIP_EINVAL, "prepare_expansion: one visit per segment");
+  uint64_t dwf = 0, ttf = 0;
+  for (const auto& s : index) {
+    dwf += s.docs_with_field;
+    ttf += s.total_term_freq;
+  }
+  std::vector<std::vector<uint32_t>> counts(visits.size());
+  for (size_t s = 0; s < visits.size(); ++s)
+    for (uint32_t t : visits[s]) counts[s].push_back(uint32_t(index[s].docs_count(t)));
+  PreparedExpansion out;
+  out.scored_in.resize(visits.size());
+  out.unscored_in.resize(visits.size());
+  std::vector<std::vector<bool>> is_scored(visits.size());
+  for (size_t s = 0; s < visits.size(); ++s) is_scored[s].assign(visits[s].size(), false);
+  for (const auto& [s, off] : scored_states(counts, scored_terms_limit)) is_scored[s][off] = true;
+  std::vector<uint32_t> slots;
+  for (size_t s = 0; s < visits.size(); ++s) {
+    for (size_t off = 0; off < visits[s].size(); ++off)
+      (is_scored[s][off] ? out.scored_in[s] : out.unscored_in[s]).push_back(visits[s][off]);
+    std::sort(out.scored_in[s].begin(), out.scored_in[s].end());
+    slots.insert(slots.end(), out.scored_in[s].begin(), out.scored_in[s].end());
+  }
+  std::sort(slots.begin(), slots.end());
+  slots.erase(std::unique(slots.begin(), slots.end()), slots.end());
+  PreparedQuery& q = out.scored;
+  q.op = IRS_HIP_OP_OR;
+  q.segment_terms.assign(visits.size(), std::vector<uint32_t>(std::max<size_t>(1, slots.size()),
+                                                              IRS_HIP_NO_TERM));
+  for (size_t j = 0; j < slots.size(); ++j) {
+    uint64_t dwt = 0;   // (collector::score: the term's statistics where its state is scored)
+    for (size_t s = 0; s < visits.size(); ++s)
+      if (std::binary_search(out.scored_in[s].begin(), out.scored_in[s].end(), slots[j])) {
+        dwt += index[s].docs_count(slots[j]);
+        q.segment_terms[s][j] = slots[j];
+      }
+    TermStats st;
+    scorer.collect(st, dwf, dwt, ttf);
+    irs_hip_term_scorer e = scorer.term_scorer(st, boost);
+    e.term = slots[j];
+    q.terms.push_back(e);
+  }
+  if (slots.empty()) {   // nothing scored: a one-slot query of an absent term (matches nothing)
+    TermStats st;
+    scorer.collect(st, dwf ? dwf : 1, 1, ttf);
+    irs_hip_term_scorer e = scorer.term_scorer(st, boost);
+    e.term = IRS_HIP_NO_TERM;
+    q.terms.push_back(e);
+  }
+  return out;
+}
+
+// MultiTermQuery::execute on every (filter, segment) + the harness's top k per segment.  The
+// scored disjunctions of all filters are ONE batch; total(s, q) is the population of the union of
+// ALL visited terms' postings (what the disjunction of the scored iterators and the
+// lazy_bitset_iterator of the unscored ones yields); where fewer than k docs score, the list is
+// filled with the docs only unscored terms hold (score 0, ascending doc id).
+inline QueryBatch::Results execute_expansions(const std::vector<const SegmentReader*>& segments,
+                                              const std::vector<uint32_t>& segment_docs,
+                                              const std::vector<PreparedExpansion>& prepared,
+                                              uint32_t k) {
+  std::vector<PreparedQuery> queries;
+  for (const auto& p : prepared) queries.push_back(p.scored);
+  QueryBatch batch(segments, queries, k);
+  QueryBatch::Results r = batch.run().results();
+  for (uint32_t s = 0; s < r.n_segments; ++s) {
+    std::vector<uint32_t> need;
+    std::vector<std::vector<uint32_t>> visited;
+    for (uint32_t q = 0; q < r.n_queries; ++q) {
+      const auto& p = prepared[q];
+      if (p.unscored_in[s].empty()) continue;
+      need.push_back(q);
+      visited.push_back(p.unscored_in[s]);
+      visited.back().insert(visited.back().end(), p.scored_in[s].begin(), p.scored_in[s].end());
+    }
+    const std::vector<uint64_t> totals = segments[s]->bit_union_counts(visited);
+    const size_t words = (uint64_t(segment_docs[s]) + 1 + 63) / 64;
+    for (size_t i = 0; i < need.size(); ++i) {
+      const size_t unit = size_t(s) * r.n_queries + need[i];
+      r.total_hits[unit] = totals[i];
+      const uint32_t have = r.counts[unit];
+      if (have >= k || totals[i] <= have) continue;
+      std::vector<uint64_t> all(words, 0), sc(words, 0);
+      segments[s]->bit_union(visited[i], all);
+      if (!prepared[need[i]].scored_in[s].empty())
+        segments[s]->bit_union(prepared[need[i]].scored_in[s], sc);
+      uint32_t n = have;
+      for (size_t w = 0; w < words && n < k; ++w)
+        for (uint64_t bits = all[w] & ~sc[w]; bits && n < k; bits &= bits - 1)
+          r.hits[unit * k + n++] = irs_hip_hit{0.f, uint32_t(w * 64 + __builtin_ctzll(bits))};
+      r.counts[unit] = n;
+    }
+  }
+  return r;
 }
 
 // ---- several GPUs: one process per GPU, segments sharded, ONE all-gather per batch -----------

@@ -782,6 +782,33 @@ class PreparedExpansion:
     scored_in: list         # [segment] -> set of scored ordinals there
     unscored_in: list       # [segment] -> np.uint32 ordinals that are visited but unscored there
     scorers: list           # (kind, c0, norm_const, norm_length) per slot
+    visited_in: list = None  # [segment] -> np.uint32 ordinals the visitor yielded there (all of them)
+    slots: np.ndarray = None    # `scored` as np.uint32
+    present: np.ndarray = None  # bool [segment][slot]: the slot's term is scored in the segment
+    c0: np.ndarray = None       # float32 per slot (scorers[j][1])
+
+
+def _top_offsets_one_segment(visit_arrays, counts_of, limit):
+    """The collector's choice for MANY filters over ONE segment at once: offsets are unique within
+    a visit, so it keeps the `limit` largest (docs_count, offset) keys — no heap order involved.
+    -> (rows, cols): for filter q the scored visit offsets cols[rows == q], ascending."""
+    nq = len(visit_arrays)
+    lens = np.fromiter((len(v) for v in visit_arrays), np.int64, nq)
+    width = int(lens.max()) if nq else 0
+    if limit <= 0 or width == 0:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64), lens
+    flat = np.concatenate(visit_arrays)
+    inside = np.arange(width)[None, :] < lens[:, None]       # row-major order = concatenation order
+    key = np.full((nq, width), -1, np.int64)
+    key[inside] = counts_of[flat] * (1 << 24) + np.broadcast_to(np.arange(width), (nq, width))[inside]
+    if width > limit:
+        top = np.argpartition(key, width - limit, axis=1)[:, width - limit:]
+    else:
+        top = np.broadcast_to(np.arange(width), (nq, width)).copy()
+    top.sort(axis=1)                                          # offsets ascending = ordinals ascending
+    ok = np.take_along_axis(key, top, axis=1) >= 0
+    rows = np.broadcast_to(np.arange(nq)[:, None], top.shape)[ok]
+    return rows, top[ok], lens
 
 
 def prepare_expansions(visits, limit, scorer, segment_stats, boost=1.0):
@@ -792,43 +819,45 @@ def prepare_expansions(visits, limit, scorer, segment_stats, boost=1.0):
     dwf = sum(s.docs_with_field for s in segment_stats)
     ttf = sum(s.total_term_freq for s in segment_stats)
     dcs = [np.asarray(st.docs_count) for st in segment_stats]
+    n_segs = len(segment_stats)
     parts, all_dwt = [], []
-    for per_seg in visits:
-        if len(per_seg) == 1:
-            # one segment: offsets are unique, the collector simply keeps the `limit` largest
-            # (docs_count, offset) keys — no heap order involved
-            va = np.asarray(per_seg[0], np.uint32)
-            cnt = dcs[0][va.astype(np.int64)] if len(va) else np.zeros(0, np.int64)
-            if limit <= 0 or not len(va):
-                top = np.zeros(0, np.int64)
-            elif len(va) <= limit:
-                top = np.arange(len(va))
-            else:
-                key = cnt.astype(np.int64) * (1 << 24) + np.arange(len(va))
-                top = np.argpartition(key, len(va) - limit)[len(va) - limit:]
-            top = np.sort(top)              # (offsets ascending = term ordinals ascending)
-            slots = va[top].tolist()
-            all_dwt.extend(cnt[top].tolist())
-            keep = np.ones(len(va), bool)
-            keep[top] = False
-            parts.append((slots, [set(slots)], [va[keep]]))
-            continue
-        counts = [dcs[s][np.asarray(v, np.int64)] if len(v) else np.zeros(0, np.int64)
-                  for s, v in enumerate(per_seg)]
-        states = _scored_states_fast(counts, limit)
-        scored_in = [set() for _ in per_seg]
-        for s, off in states:
-            scored_in[s].add(int(per_seg[s][off]))
-        slots = sorted(set().union(*scored_in)) if scored_in else []
-        # term statistics from the segments where the term is scored (collector::score)
-        all_dwt.extend(sum(int(dcs[s][t]) for s in range(len(per_seg)) if t in scored_in[s]) for t in slots)
-        unscored_in = []
-        for s, v in enumerate(per_seg):
-            va = np.asarray(v, np.uint32)
-            keep = ~np.isin(va, np.fromiter(scored_in[s], np.uint32, len(scored_in[s]))) if scored_in[s] else \
-                np.ones(len(va), bool)
-            unscored_in.append(va[keep])
-        parts.append((slots, scored_in, unscored_in))
+    if n_segs == 1 and len(visits):
+        # one segment: every filter's choice in a few array operations
+        vas = [np.asarray(per_seg[0], np.uint32) for per_seg in visits]
+        rows, cols, lens = _top_offsets_one_segment(vas, dcs[0].astype(np.int64), limit)
+        starts = np.cumsum(lens) - lens
+        flat = np.concatenate(vas) if len(vas) else np.zeros(0, np.uint32)
+        at = starts[rows] + cols
+        scored_flat = flat[at]
+        all_dwt = dcs[0][scored_flat.astype(np.int64)].astype(np.float64)
+        keep = np.ones(len(flat), bool)
+        keep[at] = False
+        per_q = np.bincount(rows, minlength=len(vas)) if len(rows) else np.zeros(len(vas), np.int64)
+        cut = np.cumsum(per_q)[:-1]
+        scored_parts = np.split(scored_flat, cut)
+        un_lens = lens - per_q
+        unscored_parts = np.split(flat[keep], np.cumsum(un_lens)[:-1])
+        for va, sp, up in zip(vas, scored_parts, unscored_parts):
+            parts.append((sp, None, [up], [va]))
+    else:
+        for per_seg in visits:
+            counts = [dcs[s][np.asarray(v, np.int64)] if len(v) else np.zeros(0, np.int64)
+                      for s, v in enumerate(per_seg)]
+            states = _scored_states_fast(counts, limit)
+            scored_in = [set() for _ in per_seg]
+            for s, off in states:
+                scored_in[s].add(int(per_seg[s][off]))
+            slots = sorted(set().union(*scored_in)) if scored_in else []
+            # term statistics from the segments where the term is scored (collector::score)
+            all_dwt.extend(sum(int(dcs[s][t]) for s in range(len(per_seg)) if t in scored_in[s]) for t in slots)
+            unscored_in, visited_in = [], []
+            for s, v in enumerate(per_seg):
+                va = np.asarray(v, np.uint32)
+                keep = ~np.isin(va, np.fromiter(scored_in[s], np.uint32, len(scored_in[s]))) if scored_in[s] else \
+                    np.ones(len(va), bool)
+                unscored_in.append(va[keep])
+                visited_in.append(va)
+            parts.append((np.asarray(slots, np.uint32), scored_in, unscored_in, visited_in))
     dwt = np.asarray(all_dwt, np.float64)
     if isinstance(scorer, BM25):
         idf = np.log1p((float(dwf) - dwt + 0.5) / (dwt + 0.5)).astype(np.float32)
@@ -841,10 +870,18 @@ def prepare_expansions(visits, limit, scorer, segment_stats, boost=1.0):
         kind, nc, nl = scorer.term_scorer(TermStats(f32(1)))[0], f32(0), f32(0)
         c0 = (f32(boost) * idf).astype(np.float32)
     out, at = [], 0
-    for slots, scored_in, unscored_in in parts:
-        scorers = [(kind, c0[at + j], nc, nl) for j in range(len(slots))]
-        at += len(slots)
-        out.append(PreparedExpansion(slots, scored_in, unscored_in, scorers))
+    for slots, scored_in, unscored_in, visited_in in parts:
+        n = len(slots)
+        mine = c0[at:at + n]
+        at += n
+        slot_list = slots.tolist()
+        if scored_in is None:                       # (one segment: every slot is scored there)
+            scored_in = [set(slot_list)]
+            present = np.ones((1, n), bool)
+        else:
+            present = np.array([[t in sc for t in slot_list] for sc in scored_in], bool).reshape(n_segs, n)
+        out.append(PreparedExpansion(slot_list, scored_in, unscored_in,
+                                     [(kind, x, nc, nl) for x in mine], visited_in, slots, present, mine))
     return out
 
 
@@ -852,21 +889,28 @@ def expansion_arrays(segs, prepared, k):
     """The scored parts of a list of prepared expansions as ONE batch: an Or per filter whose term
     slots are absent (NO_TERM) in the segments where the term is unscored.  Filters without any
     scored term get a one-slot query of an absent term (matches nothing)."""
-    n_entries = sum(max(1, len(p.scored)) for p in prepared)
-    queries = np.zeros(len(prepared), QUERY)
-    terms = np.zeros((len(segs), n_entries), TERM_SCORER)
-    at = 0
-    for q, p in enumerate(prepared):
-        n = max(1, len(p.scored))
-        queries[q] = (OP_OR, n, at, int(k), 1, MERGE_SUM)
-        if not p.scored:
-            terms["term"][:, at] = NO_TERM
-            terms["kind"][:, at] = SCORE_BM1
-        for j, (t, (kind, c0, nc, nl)) in enumerate(zip(p.scored, p.scorers)):
-            for s in range(len(segs)):
-                terms[s, at + j] = (t if t in p.scored_in[s] else NO_TERM, kind, c0, nc, nl, 0)
-        at += n
-    return QueryArrays(len(segs), queries, terms, k)
+    n_segs, nq = len(segs), len(prepared)
+    n_slots = np.fromiter((max(1, len(p.scored)) for p in prepared), np.int64, nq)
+    first = np.cumsum(n_slots) - n_slots
+    n_entries = int(n_slots.sum())
+    queries = np.zeros(nq, QUERY)
+    queries["op"], queries["n_terms"], queries["first_term"] = OP_OR, n_slots, first
+    queries["k"], queries["min_match"], queries["merge"] = int(k), 1, MERGE_SUM
+    terms = np.zeros((n_segs, n_entries), TERM_SCORER)
+    terms["term"] = NO_TERM                      # (also the one slot of a filter without scored terms)
+    terms["kind"] = SCORE_BM1
+    real = [q for q, p in enumerate(prepared) if p.scored]
+    if real:
+        where = np.concatenate([first[q] + np.arange(len(prepared[q].scored)) for q in real])
+        slots = np.concatenate([prepared[q].slots for q in real])
+        present = np.concatenate([prepared[q].present for q in real], axis=1)      # [seg][slot]
+        kind, _, nc, nl = prepared[real[0]].scorers[0]
+        terms["term"][:, where] = np.where(present, slots[None, :], np.uint32(NO_TERM))
+        terms["kind"][:, where] = kind
+        terms["c0"][:, where] = np.concatenate([prepared[q].c0 for q in real])[None, :]
+        terms["norm_const"][:, where] = nc
+        terms["norm_length"][:, where] = nl
+    return QueryArrays(n_segs, queries, terms, k)
 
 
 def execute_expansions(readers, prepared, k):
@@ -887,8 +931,7 @@ def execute_expansions(readers, prepared, k):
         # the totals: the population of the union of ALL visited terms, for every filter that has
         # unscored terms here, in one call (only the counts cross PCIe)
         need = [q for q, p in enumerate(prepared) if len(p.unscored_in[s])]
-        visited = [np.concatenate([prepared[q].unscored_in[s],
-                                   np.array(sorted(prepared[q].scored_in[s]), np.uint32)]) for q in need]
+        visited = [prepared[q].visited_in[s] for q in need]
         if need:
             totals[s, need] = sr.bit_union_counts(visited)
         for q, v in zip(need, visited):

@@ -244,6 +244,112 @@ int main() {
     REQUIRE(set == oset);
   }
 
+  // scored multi-term filters (by_prefix / by_wildcard with scored_terms_limit): the collector's
+  // choice, the statistics of a term where it is scored, totals over ALL visited terms, the fill
+  {
+    auto range = [](uint32_t lo, uint32_t hi) {
+      std::vector<uint32_t> v;
+      for (uint32_t t = lo; t < hi; ++t) v.push_back(t);
+      return v;
+    };
+    struct Case { std::vector<std::vector<uint32_t>> visits; size_t limit; };
+    const std::vector<Case> cases{
+      {{range(10, 60), range(20, 70)}, 8},          // more visited terms than scored ones
+      {{range(100, 128), range(90, 128)}, 3},       // rare terms: fewer than k docs score somewhere
+      {{range(5, 9), {}}, 16},                      // everything scored; nothing visited in b
+      {{range(40, 50), range(40, 50)}, 0},          // nothing scored at all
+      {{range(120, 128), range(120, 128)}, 1},      // one state scored: the other segment only fills
+    };
+    uint64_t filled_anywhere = 0;
+    std::vector<PreparedExpansion> prepared_x;
+    for (const Case& c : cases)
+      prepared_x.push_back(prepare_expansion(c.visits, c.limit, scorer, {a.stats(), b.stats()}));
+    const auto rx = execute_expansions({a.reader.get(), b.reader.get()}, {a.num_docs, b.num_docs},
+                                       prepared_x, kTop);
+    const auto topx = merge(rx);
+    for (size_t q = 0; q < cases.size(); ++q) {
+      const PreparedExpansion& p = prepared_x[q];
+      size_t n_scored = 0;
+      for (int s = 0; s < 2; ++s) {
+        n_scored += p.scored_in[s].size();
+        REQUIRE(p.scored_in[s].size() + p.unscored_in[s].size() == cases[q].visits[s].size());
+      }
+      size_t n_visited = cases[q].visits[0].size() + cases[q].visits[1].size();
+      REQUIRE(n_scored == std::min(cases[q].limit, n_visited));
+      // the oracle: a disjunction of the scored slots, a term's meta zero where it is unscored
+      const uint32_t n = uint32_t(p.scored.terms.size());
+      std::vector<orc_term_meta> metas(2 * n);
+      std::vector<float> boosts(n, 1.f);
+      for (uint32_t s = 0; s < 2; ++s)
+        for (uint32_t t = 0; t < n; ++t)
+          if (p.scored.segment_terms[s][t] != IRS_HIP_NO_TERM)
+            std::memcpy(&metas[s * n + t], &segs[s]->metas[p.scored.segment_terms[s][t]],
+                        sizeof(orc_term_meta));
+      std::vector<orc_hit> want(kTop);
+      uint64_t scored_total = 0;
+      const int64_t got_n = orc_search(views, 2, metas.data(), n, ORC_OP_OR, &osc, boosts.data(), dwf,
+                                       ttf, kTop, want.data(), &scored_total);
+      REQUIRE(got_n >= 0);
+      std::sort(want.begin(), want.begin() + got_n,
+                [](const orc_hit& x, const orc_hit& y) { return x.score > y.score; });
+      uint64_t visited_total = 0, filled = 0;
+      for (uint32_t s = 0; s < 2; ++s) {
+        std::vector<orc_term_meta> om;
+        for (uint32_t t : cases[q].visits[s]) {
+          om.emplace_back();
+          std::memcpy(&om.back(), &segs[s]->metas[t], sizeof(orc_term_meta));
+        }
+        std::vector<uint64_t> all((segs[s]->num_docs + 64) / 64, 0), sc(all.size(), 0);
+        if (!om.empty())
+          (void)orc_bit_union(segs[s]->doc, segs[s]->doc_len, ORC_LAYOUT_SIMD4, 1, om.data(),
+                              uint32_t(om.size()), all.data(), all.size());
+        om.clear();
+        for (uint32_t t : p.scored_in[s]) {
+          om.emplace_back();
+          std::memcpy(&om.back(), &segs[s]->metas[t], sizeof(orc_term_meta));
+        }
+        if (!om.empty())
+          (void)orc_bit_union(segs[s]->doc, segs[s]->doc_len, ORC_LAYOUT_SIMD4, 1, om.data(),
+                              uint32_t(om.size()), sc.data(), sc.size());
+        uint64_t pop = 0, pop_scored = 0;
+        for (size_t w = 0; w < all.size(); ++w) {
+          pop += uint64_t(__builtin_popcountll(all[w]));
+          pop_scored += uint64_t(__builtin_popcountll(sc[w]));
+        }
+        REQUIRE(rx.total(s, uint32_t(q)) == pop);
+        visited_total += pop;
+        // this segment's list: the scored docs first, then docs only unscored terms hold
+        const irs_hip_hit* h = rx.of(s, uint32_t(q));
+        const uint32_t cnt = rx.count(s, uint32_t(q));
+        REQUIRE(cnt == std::min<uint64_t>(kTop, pop));
+        uint32_t prev = 0;
+        for (uint32_t i = 0; i < cnt; ++i) {
+          const bool in_scored = (sc[h[i].doc / 64] >> (h[i].doc % 64)) & 1;
+          REQUIRE((all[h[i].doc / 64] >> (h[i].doc % 64)) & 1);
+          if (i < std::min<uint64_t>(kTop, pop_scored)) {
+            REQUIRE(in_scored && h[i].score > 0.f);
+          } else {
+            REQUIRE(!in_scored && h[i].score == 0.f && h[i].doc > prev);
+            prev = h[i].doc;
+            ++filled;
+          }
+        }
+      }
+      REQUIRE(visited_total >= scored_total);
+      filled_anywhere += filled;
+      // merged over both segments: the scored docs' scores are the oracle's
+      const size_t n_cmp = std::min<size_t>(size_t(got_n), topx[q].size());
+      REQUIRE(topx[q].size() == std::min<uint64_t>(kTop, std::min<uint64_t>(visited_total, uint64_t(got_n) + filled)));
+      for (size_t i = 0; i < n_cmp; ++i) REQUIRE(close_rel(topx[q][i].score, want[i].score));
+    }
+    REQUIRE(filled_anywhere > 0);
+    // only a strictly larger (docs_count, offset) key replaces the heap's root: segment 1's
+    // (5, 0) leaves segment 0's (5, 0) alone, its (5, 1) replaces it (tests/test_oracle.py pins
+    // the heap's own order on random ties against tests/cpp/collector_heap.cpp)
+    const auto st = scored_states({{5, 5}, {5, 5}}, 2);
+    REQUIRE((st == std::vector<std::pair<uint32_t, uint32_t>>{{0, 1}, {1, 1}}));
+  }
+
   // adapter groundwork (format10::): the files' headers and footers, the term dictionary's
   // term_meta entries, the Norm2 column header (norm.cpp:107-115); tests/cpp/test_files.cpp
   // opens a whole segment from file bytes

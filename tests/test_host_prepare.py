@@ -84,3 +84,39 @@ def test_prepare_expansions_statistics(scorer):
                 assert tuple(sc) == tuple(want), (limit, t)
             for s in range(2):      # every visited term is scored or unscored, never both
                 assert sorted(list(p.scored_in[s]) + p.unscored_in[s].tolist()) == per_seg[s].tolist()
+
+
+def test_prepare_expansions_one_segment_equals_the_collector():
+    """One segment: the array form (all filters at once) chooses what limited_sample_collector
+    chooses filter by filter — ragged visits, equal docs_counts, empty and short visits."""
+    rng = np.random.default_rng(7)
+    stats = [search.SegmentStats(500_000, 40_000_000, rng.integers(1, 40, 3000))]   # many ties
+    visits = [[np.sort(rng.choice(3000, int(n), replace=False)).astype(np.uint32)]
+              for n in [0, 1, 5, 16, 17, 40, 333, 1200, 2, 0, 64]]
+    scorer = BM25()
+    for limit in (16, 1, 0, 5000):
+        prep = search.prepare_expansions(visits, limit, scorer, stats)
+        assert len(prep) == len(visits)
+        for p, (va,) in zip(prep, visits):
+            counts = np.asarray(stats[0].docs_count)[va.astype(np.int64)]
+            want = sorted(int(va[off]) for _, off in search.scored_states([counts], limit))
+            assert p.scored == want and p.scored_in == [set(want)]
+            assert p.slots.tolist() == want and p.present.shape == (1, len(want)) and p.present.all()
+            assert sorted(want + p.unscored_in[0].tolist()) == va.tolist()
+            assert p.visited_in[0] is va or np.array_equal(p.visited_in[0], va)
+            for t, sc in zip(p.scored, p.scorers):
+                assert tuple(sc) == tuple(scorer.term_scorer(
+                    scorer.collect(500_000, int(stats[0].docs_count[t]), 40_000_000)))
+        arrays = search.expansion_arrays([None], prep, 10)
+        at = 0
+        for q, p in enumerate(prep):
+            n = max(1, len(p.scored))
+            assert tuple(arrays.queries[q]) == (search.OP_OR, n, at, 10, 1, search.MERGE_SUM)
+            got = arrays.terms[0, at:at + n]
+            if p.scored:
+                assert got["term"].tolist() == p.scored
+                assert [tuple(x) for x in got[["kind", "c0", "norm_const", "norm_length"]].tolist()] == \
+                    [tuple(float(v) if i else int(v) for i, v in enumerate(sc)) for sc in p.scorers]
+            else:
+                assert got["term"].tolist() == [search.NO_TERM]
+            at += n
