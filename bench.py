@@ -20,6 +20,7 @@ oracle's restatement of utils/index-search timed on this host (N = 1, rank 0).
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -163,6 +164,9 @@ def main():
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--stride", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--two-streams", action="store_true",
+                    help="config 5: queue the AND batch and the phrase batch on a stream each (measured: "
+                         "41.3 against 42.0 ms per step, DESIGN.md §3.12; the stage times then overlap)")
     ap.add_argument("--config", type=int, default=3, choices=[3, 5],
                     help="3 (default, with --gpus > 1: config 4): OR-of-8 BM25 top-1000 on 10 M docs; "
                          "5: AND-of-2..4 + 2-word by_phrase, TF-IDF, block-max WAND, on --docs "
@@ -668,6 +672,16 @@ def main_config5(args):
             out[name] = b
         return out
     sptr = None if sim else C_void(torch.cuda.current_stream(dev).cuda_stream)
+    # --two-streams: a stream per batch class, each class's exchange, verification and merge on ITS
+    # stream.  The two batches' kernels then share the chip; both are bound by the SIMDs' issue
+    # slots, so side by side they take 41.3 ms where one after the other takes 42.0 (r06v) — not the
+    # default: the per-stage times of the line would overlap.
+    two = not sim and args.two_streams
+    streams = {name: (torch.cuda.Stream(device=dev) if two else None) for name in ("and", "phrase")}
+    sptrs = {name: (C_void(streams[name].cuda_stream) if two else sptr) for name in streams}
+
+    def on(name):
+        return torch.cuda.stream(streams[name]) if two else contextlib.nullcontext()
     # the collective goes through the library's own RCCL communicator (irs_hip_comm_*), as in
     # the headline config; one communicator serves both exchanges
     comm = None
@@ -684,10 +698,11 @@ def main_config5(args):
         # copied into the exchange slots, the all-gathers started
         bat, ph = prev
         for name, b in bat.items():
-            ex[name].finish(sptr)
-            hp, cp = ex[name].slot(ph, 0)
-            b.results_to_device(hp, cp, sptr)
-            ex[name].start(ph)
+            with on(name):
+                ex[name].finish(sptrs[name])
+                hp, cp = ex[name].slot(ph, 0)
+                b.results_to_device(hp, cp, sptrs[name])
+                ex[name].start(ph)
         if rank == 0 and kms is not None:
             kms.append({n: b.timings() for n, b in bat.items()})
         # (destroyed one step later: irs_hip_batch_destroy waits for the copies just queued)
@@ -704,7 +719,7 @@ def main_config5(args):
         bat = make_batches(it["n"])
         it["n"] += 1
         for name, b in bat.items():
-            b.run(sptr)
+            b.run(sptrs[name])
         prev = it.get("prev")
         if prev is not None:
             deliver(prev)
@@ -714,8 +729,9 @@ def main_config5(args):
         prev = it.pop("prev", None)
         if prev is not None:
             deliver(prev)
-        for e in ex.values():
-            e.finish(sptr)
+        for name, e in ex.items():
+            with on(name):
+                e.finish(sptrs[name])
         sync()
 
     for _ in range(max(1, args.warmup)):
