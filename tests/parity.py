@@ -176,7 +176,8 @@ def check_expansions(segs, visits, limit, scorer, k, hits, counts, totals):
             un = [int(t) for t in per_seg[s] if int(t) not in scored_in[s]]
             if un:
                 bits, _ = oracle.bit_union(seg.doc_file, [seg.metas[t] for t in un], seg.layout, True,
-                                           (seg.num_docs + 64) // 64)
+                                           (seg.num_docs + 64) // 64,
+                                           wand_count=int(getattr(seg, "wand_count", 0)))
                 ub = np.unpackbits(bits.view(np.uint8), bitorder="little")[:n1].astype(bool)
                 mask = getattr(seg, "doc_mask", None)
                 if mask is not None:                   # (the oracle's bit_union is the unmasked one)

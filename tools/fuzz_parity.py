@@ -156,6 +156,33 @@ def main():
                 sb.close()
                 for r in readers[1:]:
                     r.close()
+        # every fourth round: scored multi-term filters (scored_terms_limit) over one or two
+        # segments — the collector's choice, totals over ALL visited terms, the zero-score fill
+        if rounds % 4 == 0:
+            xsegs, xreaders = [seg], [sr]
+            if rng.integers(0, 2):
+                x = synth.build_segment(int(rng.integers(1_000, max(2_000, docs // 2))), max_rank,
+                                        layout=layout, first_doc=docs, seed=int(rng.integers(1, 1 << 30)))
+                xsegs.append(x)
+                xreaders.append(search.SegmentReader.from_synth(x, L=L))
+            limit = int(rng.choice([0, 1, 3, 16]))
+            visits = []
+            for _ in range(6):
+                per_seg = []
+                for x in xsegs:
+                    n_terms = len(x.metas)
+                    lo = int(rng.integers(0, n_terms))
+                    ords = np.arange(lo, min(n_terms, lo + int(rng.integers(0, 60))), dtype=np.uint32)
+                    ords = ords[rng.random(len(ords)) < 0.8]          # (a wildcard skips terms)
+                    per_seg.append(ords[np.asarray(x.metas["docs_count"])[ords] > 0])
+                visits.append(per_seg)
+            xk = int(rng.choice([1, 10, 100]))
+            xprep = search.prepare_expansions(visits, limit, scorer, [parity.segment_stats(x) for x in xsegs])
+            xh, xc, xt = search.execute_expansions(xreaders, xprep, xk)
+            parity.check_expansions(xsegs, visits, limit, scorer, xk, xh, xc, xt)
+            for r in xreaders[1:]:
+                r.close()
+            queries += len(visits)
         # irs::score::Min = the k-th score: the same top-k again
         kth = np.array([hits[q, counts[q] - 1]["score"] if counts[q] else 0.0
                         for q in range(len(filters))], np.float32)
