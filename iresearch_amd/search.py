@@ -806,32 +806,44 @@ def _scored_states_fast(visits_docs_counts, limit: int):
     return sorted(zip(seg[top].tolist(), off[top].tolist()))
 
 
-@dataclass
 class PreparedExpansion:
     """One scored multi-term filter prepared against all segments."""
-    scored: list            # distinct scored term ordinals (query term slots)
-    scored_in: list         # [segment] -> set of scored ordinals there
-    unscored_in: list       # [segment] -> np.uint32 ordinals that are visited but unscored there
-    scorers: list           # (kind, c0, norm_const, norm_length) per slot
-    visited_in: list = None  # [segment] -> np.uint32 ordinals the visitor yielded there (all of them)
-    slots: np.ndarray = None    # `scored` as np.uint32
-    present: np.ndarray = None  # bool [segment][slot]: the slot's term is scored in the segment
-    c0: np.ndarray = None       # float32 per slot (scorers[j][1])
+
+    def __init__(self, scored, scored_in, unscored_in, scorers, visited_in=None, slots=None,
+                 present=None, c0=None):
+        self.scored = scored            # distinct scored term ordinals (query term slots)
+        self.scored_in = scored_in      # [segment] -> set of scored ordinals there
+        self._unscored_in = unscored_in  # (None: worked out from visited_in when asked for)
+        self.scorers = scorers          # (kind, c0, norm_const, norm_length) per slot
+        self.visited_in = visited_in    # [segment] -> np.uint32 ordinals the visitor yielded there
+        self.slots = slots              # `scored` as np.uint32
+        self.present = present          # bool [segment][slot]: the slot's term is scored in the segment
+        self.c0 = c0                    # float32 per slot (scorers[j][1])
+
+    @property
+    def unscored_in(self):
+        """[segment] -> np.uint32 ordinals that are visited but unscored there (visit order)."""
+        if self._unscored_in is None:
+            self._unscored_in = [
+                va[~np.isin(va, np.fromiter(sc, np.uint32, len(sc)))] if sc else va
+                for va, sc in zip(self.visited_in, self.scored_in)]
+        return self._unscored_in
+
+    def n_unscored(self, s: int) -> int:
+        return len(self.visited_in[s]) - len(self.scored_in[s]) if self._unscored_in is None \
+            else len(self._unscored_in[s])
 
 
-def _top_offsets_one_segment(visit_arrays, counts_of, limit):
-    """The collector's choice for MANY filters over ONE segment at once: offsets are unique within
-    a visit, so it keeps the `limit` largest (docs_count, offset) keys — no heap order involved.
-    -> (rows, cols): for filter q the scored visit offsets cols[rows == q], ascending."""
+def _top_offsets_padded(visit_arrays, lens, flat_counts, limit):
+    """-> (rows, cols) of the `limit` largest (docs_count, offset) keys of every visit, offsets
+    ascending within a row; flat_counts = the docs_counts of the concatenated visits."""
     nq = len(visit_arrays)
-    lens = np.fromiter((len(v) for v in visit_arrays), np.int64, nq)
     width = int(lens.max()) if nq else 0
     if limit <= 0 or width == 0:
-        return np.zeros(0, np.int64), np.zeros(0, np.int64), lens
-    flat = np.concatenate(visit_arrays)
+        return np.zeros(0, np.int64), np.zeros(0, np.int64)
     inside = np.arange(width)[None, :] < lens[:, None]       # row-major order = concatenation order
     key = np.full((nq, width), -1, np.int64)
-    key[inside] = counts_of[flat] * (1 << 24) + np.broadcast_to(np.arange(width), (nq, width))[inside]
+    key[inside] = flat_counts * (1 << 24) + np.broadcast_to(np.arange(width), (nq, width))[inside]
     if width > limit:
         top = np.argpartition(key, width - limit, axis=1)[:, width - limit:]
     else:
@@ -839,7 +851,69 @@ def _top_offsets_one_segment(visit_arrays, counts_of, limit):
     top.sort(axis=1)                                          # offsets ascending = ordinals ascending
     ok = np.take_along_axis(key, top, axis=1) >= 0
     rows = np.broadcast_to(np.arange(nq)[:, None], top.shape)[ok]
-    return rows, top[ok], lens
+    return rows, top[ok]
+
+
+def _top_offsets_one_segment(visit_arrays, counts_of, limit):
+    """The collector's choice for MANY filters over ONE segment at once: offsets are unique within
+    a visit, so it keeps the `limit` largest (docs_count, offset) keys — no heap order involved.
+    -> (rows, cols, lens): for filter q the scored visit offsets cols[rows == q], ascending.
+    Long visits (a wildcard: thousands of mostly rare terms) first drop everything below a
+    docs_count that still leaves every filter its `limit` largest: the keys are then sorted out
+    among a few percent of the elements."""
+    nq = len(visit_arrays)
+    lens = np.fromiter((len(v) for v in visit_arrays), np.int64, nq)
+    if limit <= 0 or nq == 0 or int(lens.max()) == 0:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64), lens
+    flat = np.concatenate(visit_arrays)
+    cnt = counts_of[flat]
+    keep_about = 4 * limit * nq
+    if len(flat) <= 4 * keep_about:
+        rows, cols = _top_offsets_padded(visit_arrays, lens, cnt, limit)
+        return rows, cols, lens
+    # a docs_count that about 4 * limit elements per filter reach (from a sample)
+    sample = cnt[:: max(1, len(flat) // 16384)]
+    cut = np.partition(sample, len(sample) - 1 - min(len(sample) - 1, (keep_about * len(sample)) // len(flat)))[
+        len(sample) - 1 - min(len(sample) - 1, (keep_about * len(sample)) // len(flat))]
+    at = np.flatnonzero(cnt >= cut)
+    ends = np.cumsum(lens)
+    row_at = np.searchsorted(ends, at, side="right")
+    above = np.bincount(row_at, minlength=nq)
+    settled = (above >= limit) | (above == lens)       # the `limit` largest are all at or above the cut
+    rows_out, cols_out = [], []
+    if settled.any():
+        sel = settled[row_at]
+        sub_rows_all, sub_at = row_at[sel], at[sel]
+        ids = np.flatnonzero(settled)
+        # the kept elements of the settled filters as (shorter) visits of their own: positions in
+        # the original visit are what the keys need, so they ride along
+        sub_lens = above[ids]
+        sub_col = sub_at - (ends - lens)[sub_rows_all]            # offset in the original visit
+        width = int(sub_lens.max())
+        inside = np.arange(width)[None, :] < sub_lens[:, None]
+        key = np.full((len(ids), width), -1, np.int64)
+        key[inside] = cnt[sub_at] * (1 << 24) + sub_col
+        if width > limit:
+            top = np.argpartition(key, width - limit, axis=1)[:, width - limit:]
+        else:
+            top = np.broadcast_to(np.arange(width), (len(ids), width)).copy()
+        picked = np.take_along_axis(key, top, axis=1)
+        picked = np.where(picked >= 0, picked & ((1 << 24) - 1), 1 << 30)     # -> original offsets
+        picked.sort(axis=1)
+        ok = picked < (1 << 30)
+        rows_out.append(np.broadcast_to(ids[:, None], picked.shape)[ok])
+        cols_out.append(picked[ok])
+    rest = np.flatnonzero(~settled)
+    if rest.size:                                       # (few: the cut was too high for them)
+        starts = ends - lens
+        sub = [visit_arrays[q] for q in rest]
+        sub_cnt = np.concatenate([cnt[starts[q]:ends[q]] for q in rest])
+        r, c = _top_offsets_padded(sub, lens[rest], sub_cnt, limit)
+        rows_out.append(rest[r])
+        cols_out.append(c)
+    rows, cols = np.concatenate(rows_out), np.concatenate(cols_out)
+    order = np.lexsort((cols, rows))
+    return rows[order], cols[order], lens
 
 
 def prepare_expansions(visits, limit, scorer, segment_stats, boost=1.0):
@@ -861,15 +935,10 @@ def prepare_expansions(visits, limit, scorer, segment_stats, boost=1.0):
         at = starts[rows] + cols
         scored_flat = flat[at]
         all_dwt = dcs[0][scored_flat.astype(np.int64)].astype(np.float64)
-        keep = np.ones(len(flat), bool)
-        keep[at] = False
         per_q = np.bincount(rows, minlength=len(vas)) if len(rows) else np.zeros(len(vas), np.int64)
-        cut = np.cumsum(per_q)[:-1]
-        scored_parts = np.split(scored_flat, cut)
-        un_lens = lens - per_q
-        unscored_parts = np.split(flat[keep], np.cumsum(un_lens)[:-1])
-        for va, sp, up in zip(vas, scored_parts, unscored_parts):
-            parts.append((sp, None, [up], [va]))
+        scored_parts = np.split(scored_flat, np.cumsum(per_q)[:-1])
+        for va, sp in zip(vas, scored_parts):
+            parts.append((sp, None, None, [va]))
     else:
         for per_seg in visits:
             counts = [dcs[s][np.asarray(v, np.int64)] if len(v) else np.zeros(0, np.int64)
@@ -961,7 +1030,7 @@ def execute_expansions(readers, prepared, k):
         n_words = (sr.num_docs + 64) // 64
         # the totals: the population of the union of ALL visited terms, for every filter that has
         # unscored terms here, in one call (only the counts cross PCIe)
-        need = [q for q, p in enumerate(prepared) if len(p.unscored_in[s])]
+        need = [q for q, p in enumerate(prepared) if p.n_unscored(s)]
         visited = [prepared[q].visited_in[s] for q in need]
         if need:
             totals[s, need] = sr.bit_union_counts(visited)

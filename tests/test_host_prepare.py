@@ -120,3 +120,27 @@ def test_prepare_expansions_one_segment_equals_the_collector():
             else:
                 assert got["term"].tolist() == [search.NO_TERM]
             at += n
+
+
+def test_prepare_expansions_long_visits_prefiltered():
+    """Long visits (wildcards: thousands of mostly rare terms) take the array form's prefilter — a
+    docs_count cut that leaves every filter its `limit` largest keys — and filters the cut is too
+    high for fall back to the plain form: the same choice as the collector's, filter by filter."""
+    rng = np.random.default_rng(11)
+    n_terms = 60_000
+    dc = np.maximum(1, (2_000_000 / np.arange(1, n_terms + 1) ** 1.1)).astype(np.int64)   # Zipf: many ties at the tail
+    rng.shuffle(dc)
+    stats = [search.SegmentStats(3_000_000, 250_000_000, dc)]
+    rare = np.flatnonzero(dc <= 20)
+    visits = [[np.sort(rng.choice(n_terms, int(n), replace=False)).astype(np.uint32)]
+              for n in [3000, 2500, 40, 0, 5000, 7, 1800]]
+    visits.append([np.sort(rng.choice(rare, 900, replace=False)).astype(np.uint32)])   # only rare terms
+    visits.append([np.sort(rng.choice(rare, 10, replace=False)).astype(np.uint32)])    # fewer than limit
+    scorer = BM25()
+    for limit in (16, 3, 64):
+        prep = search.prepare_expansions(visits, limit, scorer, stats)
+        for p, (va,) in zip(prep, visits):
+            want = sorted(int(va[off]) for _, off in search.scored_states([dc[va.astype(np.int64)]], limit))
+            assert p.scored == want, limit
+            assert p.n_unscored(0) == len(va) - len(want)
+            assert sorted(want + p.unscored_in[0].tolist()) == va.tolist()
