@@ -134,7 +134,10 @@ __host__ __device__ __forceinline__ uint32_t join_tf(uint32_t e) {
 // block's norm bytes: three memory round trips per round instead of three per block (a block is
 // 100 VALU instructions behind 3 dependent loads).  Decode as decode.h (bit-exact doc ids +
 // frequencies); entries are written coalesced (posting i is entry i).
-constexpr uint32_t kJoinPerWave = 4;
+// (Two blocks per wavefront, not four: 50 VGPRs instead of 93 let 8 wavefronts share a SIMD
+// instead of 5 — 0.80 against 0.85 ms on the headline batch, bit-identical entries; one block
+// 0.85, three 0.81, four with the registers capped by spilling 1.08 - 1.36: DESIGN §3.12.)
+constexpr uint32_t kJoinPerWave = 2;
 constexpr uint32_t kJoinRounds = kJoinBlocks / (kWaves * kJoinPerWave);
 static_assert(kJoinRounds * kWaves * kJoinPerWave == kJoinBlocks, "k_join rounds");
 
