@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define IRS_HIP_ABI_VERSION 11
+#define IRS_HIP_ABI_VERSION 12
 #define IRS_HIP_BLOCK_SIZE 128u  /* postings per block, formats_10.cpp:90 */
 #define IRS_HIP_MAX_TERMS 16u    /* terms per boolean query               */
 #define IRS_HIP_MAX_K 4096u      /* largest top-k                         */
@@ -397,6 +397,17 @@ enum { IRS_HIP_PATH_AUTO = 0, IRS_HIP_PATH_ITEMS = 1, IRS_HIP_PATH_JOINED = 2 };
 int irs_hip_batch_set_path(irs_hip_batch* batch, int path);
 /* Which one the batch's last run used (IRS_HIP_PATH_ITEMS / IRS_HIP_PATH_JOINED). */
 int irs_hip_batch_path(irs_hip_batch* batch, int* path);
+
+/* Paired doc tiles for the joined plain disjunctions (ABI 12; on by default) — a tuning / test
+ * knob like set_path: a visit of k_join_score then covers two consecutive doc tiles whose sums
+ * share an accumulator word (16 bits each, contributions rounded up), which only PICKS the docs;
+ * their exact 32-bit sums are formed afterwards from the streams (k_join_rescore) with the
+ * arithmetic of the unpaired kernel, so hits, scores, order and totals are BIT-IDENTICAL either
+ * way.  Taken unless a segment of the batch's plain joined units has deleted documents;
+ * otherwise — or with enable = 0 — the units run on 32-bit tiles.
+ * irs_hip_batch_paired_tiles: whether the last run took them. */
+int irs_hip_batch_set_paired_tiles(irs_hip_batch* batch, int enable);
+int irs_hip_batch_paired_tiles(irs_hip_batch* batch, int* used);
 
 /* A batch over several segments (irs_hip_batch_create_multi) whose per-segment lists the caller
  * MERGES into one top k per query — what the harness does with its segments

@@ -71,7 +71,7 @@ SYMBOLS = (
     "irs_hip_batch_timings", "irs_hip_batch_work", "irs_hip_batch_reruns", "irs_hip_merge_topk",
     "irs_hip_batch_plan", "irs_hip_batch_set_wand", "irs_hip_batch_set_min_scores",
     "irs_hip_batch_set_path", "irs_hip_batch_path", "irs_hip_batch_set_shared_threshold",
-    "irs_hip_batch_set_async",
+    "irs_hip_batch_set_async", "irs_hip_batch_set_paired_tiles", "irs_hip_batch_paired_tiles",
     "irs_hip_batch_set_comm",
     "irs_hip_term_blockmax",
     "irs_hip_segment_wand_source",
@@ -140,6 +140,9 @@ def bind(L: C.CDLL) -> C.CDLL:
     L.irs_hip_batch_set_path.argtypes, L.irs_hip_batch_set_path.restype = [vp, C.c_int], C.c_int
     L.irs_hip_batch_path.argtypes, L.irs_hip_batch_path.restype = [vp, P(C.c_int)], C.c_int
     L.irs_hip_batch_set_async.argtypes, L.irs_hip_batch_set_async.restype = [vp, C.c_int], C.c_int
+    L.irs_hip_batch_set_paired_tiles.argtypes = [vp, C.c_int]
+    L.irs_hip_batch_set_paired_tiles.restype = C.c_int
+    L.irs_hip_batch_paired_tiles.argtypes, L.irs_hip_batch_paired_tiles.restype = [vp, P(C.c_int)], C.c_int
     L.irs_hip_batch_set_shared_threshold.argtypes = [vp, C.c_int]
     L.irs_hip_batch_set_shared_threshold.restype = C.c_int
     L.irs_hip_batch_set_comm.argtypes, L.irs_hip_batch_set_comm.restype = [vp, vp], C.c_int

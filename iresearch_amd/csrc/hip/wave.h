@@ -146,6 +146,37 @@ __device__ __forceinline__ void count_nonzero4(uint32_t& acc, unsigned long long
   acc += (a != 0) + (b != 0) + (c != 0) + (d != 0);
 }
 
+// Two 16-bit halves per register (k_join_score's paired tiles): v_pk_min_u16 / v_pk_max_u16 /
+// v_pk_add_u16 — one instruction for both halves (vector types, not inline assembly: the compiler
+// then knows the instructions' hazards and may keep uniform operands in SGPRs).
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a),
+                                                                __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a),
+                                                                __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b));
+}
+// acc (two 16-bit counters) += the non-zero low halves / high halves among a..d: v_pk_min_u16
+// against 1|1 folded by v_pk_add_u16, in one block — written out because the optimiser turns
+// min(x, 1) into compare + select per half (a VCC round trip with wait states each).  (A packed
+// result needs one wait state before a dependent read — the compiler puts s_nop 0 between its own
+// dependent v_pk_* — hence the order of the block and its one s_nop.)
+__device__ __forceinline__ void count_nonzero_halves4(uint32_t& acc, uint32_t a, uint32_t b,
+                                                      uint32_t c, uint32_t d) {
+  uint32_t t0, t1;
+  const uint32_t one = 0x00010001u;
+  asm("v_pk_min_u16 %1, %3, %7\n\tv_pk_min_u16 %2, %4, %7\n\tv_pk_add_u16 %0, %0, %1\n\t"
+      "v_pk_min_u16 %1, %5, %7\n\tv_pk_add_u16 %0, %0, %2\n\tv_pk_min_u16 %2, %6, %7\n\t"
+      "v_pk_add_u16 %0, %0, %1\n\ts_nop 0\n\tv_pk_add_u16 %0, %0, %2"
+      : "+v"(acc), "=&v"(t0), "=&v"(t1)
+      : "v"(a), "v"(b), "v"(c), "v"(d), "s"(one));
+}
+
 // A wave-uniform value the optimiser may not reason about (stays in an SGPR).
 __device__ __forceinline__ uint32_t opaque(uint32_t v) {
   asm volatile("" : "+s"(v));

@@ -386,6 +386,8 @@ struct irs_hip_batch {
   uint64_t join_entries = 0;
   // one threshold per query for its units on the batch's segments (irs_hip_batch_set_shared_threshold)
   bool shared_threshold = false;
+  bool pairs_allowed = true;   // irs_hip_batch_set_paired_tiles
+  bool pairs_used = false;     // ... and whether the last run's plain disjunctions took them
   uint32_t n_groups = 0;       // groups in force this run (0: none)
   DevBuf d_group_of;           // [unit] group + 1, 0: a threshold of its own
   DevBuf d_group_members;      // [nq_user][n_segs] unit or 0xFFFFFFFF
@@ -1357,9 +1359,30 @@ bool launch_group_threshold(irs_hip_batch* b, rt::stream_t st) {
   return rt::last_error_ok();
 }
 
+// Paired tiles (join.h join_pairs) for the launch of the plain disjunctions: no segment of theirs
+// has deleted docs (their entries leave the doc order k_join_rescore searches in).
+// IRS_HIP_JOIN_HALF=0 / irs_hip_batch_set_paired_tiles(0) keeps the 32-bit tiles (A/B runs, tests:
+// the two must agree bit for bit).
+bool join_half_ok(const irs_hip_batch* b) {
+  if (const char* e = std::getenv("IRS_HIP_JOIN_HALF")) {
+    if (std::atoi(e) == 0) return false;
+  }
+  if (!b->pairs_allowed || !b->acc32 || !b->n_join_plain) return false;
+  for (uint32_t u : b->join_units) {
+    const DevQuery& dq = b->queries[u];
+    if (query_need(dq.op) > 1u) continue;
+    if (b->segs[dq.seg]->dev.dead) return false;
+  }
+  return true;
+}
+
 bool launch_join_score(irs_hip_batch* b, rt::stream_t st) {
   const size_t smem = JoinOff::end;
-  if (!big_smem(k_join_score<false>, smem) || !big_smem(k_join_score<true>, smem)) return false;
+  if (!big_smem(k_join_score<kJKPlain>, smem) || !big_smem(k_join_score<kJKCount>, smem) ||
+      !big_smem(k_join_score<kJKHalf>, smem) || !big_smem(k_join_rescore, smem))
+    return false;
+  const bool half = join_half_ok(b);
+  b->pairs_used = half;
   const uint32_t waves = b->join_threads / 64;
   uint32_t per_cu = uint32_t((160u * 1024u) / smem);
   per_cu = std::max<uint32_t>(1, std::min<uint32_t>(per_cu, 32u / waves));
@@ -1431,9 +1454,16 @@ bool launch_join_score(irs_hip_batch* b, rt::stream_t st) {
     }
     if (!rt::d2d(a.work_counter, d_init, sizeof b->join_ctr_init[part], st)) return false;
     if (part) {
-      RT_LAUNCH(k_join_score<true>, grid, b->join_threads, smem, st, d_args);
+      RT_LAUNCH(k_join_score<kJKCount>, grid, b->join_threads, smem, st, d_args);
+    } else if (half) {
+      // (d_join_order: the plain units first — one k_join_rescore workgroup each)
+      RT_LAUNCH(k_join_score<kJKHalf>, grid, b->join_threads, smem, st, d_args);
+      RT_LAUNCH(k_join_rescore, n_units, b->join_threads, smem, st, b->d_join_order.as<uint32_t>(),
+                b->d_queries.as<DevQuery>(), b->d_qterms.as<DevQTerm>(), b->d_jterms.as<JoinTerm>(),
+                b->d_bstar.as<uint32_t>(), b->d_cands.as<uint64_t>(), b->d_cand_count.as<uint32_t>(),
+                b->cand_cap);
     } else {
-      RT_LAUNCH(k_join_score<false>, grid, b->join_threads, smem, st, d_args);
+      RT_LAUNCH(k_join_score<kJKPlain>, grid, b->join_threads, smem, st, d_args);
     }
   }
   return rt::last_error_ok();
@@ -2772,6 +2802,19 @@ static int batch_set_async_impl(irs_hip_batch* b, int enable) {
   return IRS_HIP_OK;
 }
 
+static int batch_set_paired_tiles_impl(irs_hip_batch* b, int enable) {
+  if (!b) return IRS_HIP_EINVAL;
+  if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
+  if (!quiesce(b)) return IRS_HIP_EHIP;
+  b->pairs_allowed = enable != 0;
+  return IRS_HIP_OK;
+}
+static int batch_paired_tiles_impl(irs_hip_batch* b, int* used) {
+  if (!b || !used) return IRS_HIP_EINVAL;
+  *used = (b->joined && b->pairs_used) ? 1 : 0;
+  return IRS_HIP_OK;
+}
+
 static int batch_path_impl(irs_hip_batch* b, int* path) {
   if (!b || !path) return IRS_HIP_EINVAL;
   *path = b->joined ? IRS_HIP_PATH_JOINED : IRS_HIP_PATH_ITEMS;
@@ -3457,6 +3500,12 @@ int irs_hip_batch_set_async(irs_hip_batch* b, int enable) {
 }
 int irs_hip_batch_path(irs_hip_batch* b, int* path) {
   return settled(b, [&] { return batch_path_impl(b, path); });
+}
+int irs_hip_batch_set_paired_tiles(irs_hip_batch* b, int enable) {
+  return settled(b, [&] { return batch_set_paired_tiles_impl(b, enable); });
+}
+int irs_hip_batch_paired_tiles(irs_hip_batch* b, int* used) {
+  return settled(b, [&] { return batch_paired_tiles_impl(b, used); });
 }
 int irs_hip_batch_set_wand(irs_hip_batch* b, int enable) {
   return settled(b, [&] { return batch_set_wand_impl(b, enable); });

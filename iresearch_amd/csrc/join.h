@@ -67,7 +67,10 @@ enum : uint32_t {
   kJoinGeneral = 1u << 30,   // JoinTerm::mode: some tf of the term has no table row
   kJoinSqrt = 1u << 31,      //   square-root score form (TF-IDF family)
   kJoinTabMask = 0xFFFFu,    //   LDS byte offset of the term's table slot inside the tables
+  kJoinHiHalf = 1u << 29,    // (paired tiles, lane view only) the pair's second tile: high 16 bits
 };
+// the shift of a paired-tile lane's contributions: 0 or 16
+__host__ __device__ __forceinline__ uint32_t join_half_shift(uint32_t mode) { return (mode >> 25) & 16u; }
 
 // One distinct (segment, term) of a batch: where its entries and tile boundaries live.
 struct alignas(16) StreamRec {
@@ -392,9 +395,15 @@ __device__ __forceinline__ uint32_t join_dummy(unsigned lane) {
 // terms that hold the doc — every contribution is rounded to a multiple of 16 units and carries
 // a 1 there (one v_and_or_b32 more per slab: no second LDS access, no counter array); the unit's
 // eligibility bounds the rounding error (irs_hip.hip unit_joinable).
-template<int FORM, int N, bool COUNT>
+//
+// HALF (paired tiles, k_join_score<kJKHalf>): the accumulator word of a doc offset is shared by the
+// two tiles of a pair — 16 bits each; a contribution is the 16-bit image of the 32-bit one
+// (cs arrives scaled by 2^-15), rounded UP by at least one unit (+ 2.0 before the truncation) and
+// shifted into its tile's half (`sh`: 0 or 16, wave-uniform): the sums only pick the docs whose
+// exact 32-bit sum k_join_rescore then works out.
+template<int FORM, int N, bool COUNT, bool HALF = false>
 __device__ __forceinline__ void join_post(const unsigned char* lds, const uint32_t (&e)[4],
-                                          float cs, uint32_t tabofs) {
+                                          float cs, uint32_t tabofs, uint32_t sh = 0u) {
   float t[N];
   uint32_t fx[N];
 #pragma unroll
@@ -407,15 +416,17 @@ __device__ __forceinline__ void join_post(const unsigned char* lds, const uint32
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     if (FORM == kJTable) {
-      fx[k] = static_cast<uint32_t>(wave::fma(cs, t[k], COUNT ? kJoinCountRound : 1.f));
+      fx[k] = static_cast<uint32_t>(wave::fma(cs, t[k], HALF ? 2.f : (COUNT ? kJoinCountRound : 1.f)));
       if (COUNT) fx[k] = (fx[k] & ~kJoinCountMask) | 1u;
+      if (HALF) fx[k] <<= sh;
     } else {
       const float tf = static_cast<float>(join_tf(e[k]));
       float scaled = (FORM == kJSqrt) ? wave::fast_sqrt(tf) * cs * t[k]
                                       : wave::fma(-cs, wave::fast_rcp(wave::fma(tf, t[k], 1.f)), cs);
       wave::keep_f(scaled);
       fx[k] = COUNT ? ((static_cast<uint32_t>(scaled + kJoinCountRound) & ~kJoinCountMask) | 1u)
-                    : (static_cast<uint32_t>(scaled) | 1u);
+                    : (HALF ? (static_cast<uint32_t>(scaled + 2.f) << sh)
+                            : (static_cast<uint32_t>(scaled) | 1u));
     }
   }
 #pragma unroll
@@ -429,21 +440,34 @@ __device__ __forceinline__ void join_post(const unsigned char* lds, const uint32
 // as fall-through switches instead, every slab naming its own registers: no scratch access left on
 // this path, 490 more branches, k_join_score 5.68 -> 6.62 ms; and slab after slab with early
 // exits / always four slabs with dummies: profiles/r06_join_models.txt.  This form stays.)
-template<int FORM, bool COUNT>
+template<int FORM, bool COUNT, bool HALF = false>
 __device__ __forceinline__ void join_post_n(const unsigned char* lds, const uint32_t (&e)[4],
-                                            uint32_t slabs, float cs, uint32_t tabofs) {
-  if (slabs >= 4u) join_post<FORM, 4, COUNT>(lds, e, cs, tabofs);
-  else if (slabs == 3u) join_post<FORM, 3, COUNT>(lds, e, cs, tabofs);
-  else if (slabs == 2u) join_post<FORM, 2, COUNT>(lds, e, cs, tabofs);
-  else join_post<FORM, 1, COUNT>(lds, e, cs, tabofs);
+                                            uint32_t slabs, float cs, uint32_t tabofs, uint32_t sh = 0u) {
+  if (slabs >= 4u) join_post<FORM, 4, COUNT, HALF>(lds, e, cs, tabofs, sh);
+  else if (slabs == 3u) join_post<FORM, 3, COUNT, HALF>(lds, e, cs, tabofs, sh);
+  else if (slabs == 2u) join_post<FORM, 2, COUNT, HALF>(lds, e, cs, tabofs, sh);
+  else join_post<FORM, 1, COUNT, HALF>(lds, e, cs, tabofs, sh);
 }
-// M: kJSimple | kJCount (template mode bits of the tile loop)
-enum : int { kJSimple = 1, kJCount = 2 };
+// M: kJSimple | kJCount | kJHalf (template mode bits of the tile loop).  kJHalf: paired tiles —
+// lane j < 2 * kMaxTerms is term j % kMaxTerms in tile j / kMaxTerms of the pair; a lane's mode
+// word also says which half its tile's sums live in (kJoinHiHalf; JoinLane of join_lane_half)
+enum : int { kJSimple = 1, kJCount = 2, kJHalf = 4 };
 template<int M>
 __device__ __forceinline__ void join_post_any(const unsigned char* lds, const uint32_t (&e)[4],
                                               uint32_t slabs, float cs, uint32_t mode) {
   constexpr bool COUNT = (M & kJCount) != 0;
-  if (M & kJSimple) {
+  if (M & kJHalf) {
+    const uint32_t sh = join_half_shift(mode);
+    if (M & kJSimple) {
+      join_post_n<kJTable, false, true>(lds, e, slabs, cs, 0u, sh);
+    } else {
+      const uint32_t tabofs = mode & kJoinTabMask;
+      const int form = join_form(mode);   // (wave-uniform)
+      if (form == kJTable) join_post_n<kJTable, false, true>(lds, e, slabs, cs, tabofs, sh);
+      else if (form == kJRcp) join_post_n<kJRcp, false, true>(lds, e, slabs, cs, tabofs, sh);
+      else join_post_n<kJSqrt, false, true>(lds, e, slabs, cs, tabofs, sh);
+    }
+  } else if (M & kJSimple) {
     join_post_n<kJTable, COUNT>(lds, e, slabs, cs, 0u);
   } else {
     const uint32_t tabofs = mode & kJoinTabMask;
@@ -472,23 +496,23 @@ __device__ __forceinline__ void join_load(uint64_t base, uint32_t count, unsigne
 }
 
 // `count` consecutive entries from address `base` (wave-uniform), 256 per step.
-template<int FORM, bool COUNT>
+template<int FORM, bool COUNT, bool HALF = false>
 __device__ __forceinline__ void join_run(const unsigned char* lds, uint64_t base, uint32_t count,
-                                         float cs, uint32_t tabofs, unsigned lane) {
+                                         float cs, uint32_t tabofs, unsigned lane, uint32_t sh = 0u) {
   const uint32_t off = lane * 4u;
   while (count >= 256u) {
     uint32_t e[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) e[k] = wave::gload_u32(base, off + 256u * uint32_t(k));
     wave::keep_all(e);
-    join_post<FORM, 4, COUNT>(lds, e, cs, tabofs);
+    join_post<FORM, 4, COUNT, HALF>(lds, e, cs, tabofs, sh);
     base += 1024u;
     count -= 256u;
   }
   if (count) {
     uint32_t e[4];
     join_load(base, count, lane, e);
-    join_post_n<FORM, COUNT>(lds, e, (count + 63u) >> 6, cs, tabofs);
+    join_post_n<FORM, COUNT, HALF>(lds, e, (count + 63u) >> 6, cs, tabofs, sh);
   }
 }
 
@@ -522,7 +546,7 @@ template<int M>
 __device__ __forceinline__ void join_begin(JoinRun& r, const JoinLane& T, uint32_t a, uint32_t n,
                                            uint32_t c, uint32_t wv, uint32_t nw_log2,
                                            uint64_t safe, unsigned lane) {
-  const uint32_t N = wave::read_lane(c, kMaxTerms - 1u);
+  const uint32_t N = wave::read_lane(c, ((M & kJHalf) ? 2u * kMaxTerms : kMaxTerms) - 1u);
   const uint32_t lo = (N * wv) >> nw_log2, hi = (N * (wv + 1u)) >> nw_log2;
   const uint32_t first = c - n;                      // the term's position in the sequence
   const uint32_t st = lo > first ? lo : first;
@@ -544,7 +568,9 @@ __device__ __forceinline__ void join_begin(JoinRun& r, const JoinLane& T, uint32
     base = (uint64_t(wave::read_lane(r.a_hi, j)) << 32) | wave::read_lane(r.a_lo, j);
     const uint32_t cnt = wave::read_lane(r.cnt, j);
     r.cs = wave::read_lane_f(T.cs, j);
-    if (!(M & kJSimple)) r.mode = wave::read_lane(T.mode, j);
+    // (paired tiles, one table: the mode word is just the half — the term's index says which)
+    if ((M & kJSimple) && (M & kJHalf)) r.mode = j >= kMaxTerms ? uint32_t(kJoinHiHalf) : 0u;
+    else if (!(M & kJSimple)) r.mode = wave::read_lane(T.mode, j);
     take = cnt < kJoinPre ? cnt : kJoinPre;
     r.left = cnt - take;
     r.rest = base + 4ull * take;
@@ -563,7 +589,18 @@ template<int M>
 __device__ __forceinline__ void join_some(const unsigned char* lds, uint64_t base, uint32_t cnt,
                                           float cs, uint32_t mode, unsigned lane) {
   constexpr bool COUNT = (M & kJCount) != 0;
-  if (M & kJSimple) {
+  if (M & kJHalf) {
+    const uint32_t sh = join_half_shift(mode);
+    if (M & kJSimple) {
+      join_run<kJTable, false, true>(lds, base, cnt, cs, 0u, lane, sh);
+    } else {
+      const uint32_t tabofs = mode & kJoinTabMask;
+      const int form = join_form(mode);
+      if (form == kJTable) join_run<kJTable, false, true>(lds, base, cnt, cs, tabofs, lane, sh);
+      else if (form == kJRcp) join_run<kJRcp, false, true>(lds, base, cnt, cs, tabofs, lane, sh);
+      else join_run<kJSqrt, false, true>(lds, base, cnt, cs, tabofs, lane, sh);
+    }
+  } else if (M & kJSimple) {
     join_run<kJTable, COUNT>(lds, base, cnt, cs, 0u, lane);
   } else {
     const uint32_t tabofs = mode & kJoinTabMask;
@@ -584,7 +621,7 @@ __device__ __forceinline__ void join_finish(const unsigned char* lds, JoinRun& r
     if (kAblWait) wave::keep_all(r.e);
     return;
   }
-  constexpr bool SIMPLE = (M & kJSimple) != 0;
+  constexpr bool SIMPLE = (M & kJSimple) != 0 && (M & kJHalf) == 0;   // (no mode word needed)
   const uint32_t mode0 = SIMPLE ? 0u : wave::uniform(r.mode);
   const float cs0 = wave::uniform_f(r.cs);
   {
@@ -601,8 +638,10 @@ __device__ __forceinline__ void join_finish(const unsigned char* lds, JoinRun& r
     const uint32_t j = uint32_t(__builtin_ctzll(mask));
     mask &= mask - 1ull;
     const uint64_t base = (uint64_t(wave::read_lane(r.a_hi, j)) << 32) | wave::read_lane(r.a_lo, j);
-    join_some<M>(lds, base, wave::read_lane(r.cnt, j), wave::read_lane_f(T.cs, j),
-                      SIMPLE ? 0u : wave::read_lane(T.mode, j), lane);
+    const uint32_t mode = SIMPLE ? 0u
+                          : (((M & kJSimple) && (M & kJHalf)) ? (j >= kMaxTerms ? uint32_t(kJoinHiHalf) : 0u)
+                                                              : wave::read_lane(T.mode, j));
+    join_some<M>(lds, base, wave::read_lane(r.cnt, j), wave::read_lane_f(T.cs, j), mode, lane);
   }
 }
 
@@ -658,6 +697,23 @@ __device__ __forceinline__ JoinLane join_lane(const unsigned char* smem, unsigne
     T.ent_hi = lo.y;
     T.cs = __uint_as_float(hi.x);
     T.mode = hi.y;
+  }
+  return T;
+}
+
+// ... of a pair of tiles (kJHalf): lane j < 2 * kMaxTerms = term j % kMaxTerms in the pair's tile
+// j / kMaxTerms; cs in 16-bit units (2^-15: exact), mode = the half's shift
+static_assert(kMaxTerms == 16u, "join_lane_half / join_pairs: lane >> 4 is the tile of the pair");
+__device__ __forceinline__ JoinLane join_lane_half(const unsigned char* smem, unsigned lane) {
+  JoinLane T{};
+  if (lane < 2u * kMaxTerms) {
+    const uint32_t j = lane & (kMaxTerms - 1u);
+    const JoinQuad lo = reinterpret_cast<const JoinQuad*>(smem + JoinOff::jts)[kJoinTermQuads * j];
+    const JoinQuad hi = reinterpret_cast<const JoinQuad*>(smem + JoinOff::jts)[kJoinTermQuads * j + 1u];
+    T.ent_lo = lo.x;
+    T.ent_hi = lo.y;
+    T.cs = __uint_as_float(hi.x) * (1.f / 32768.f);
+    T.mode = hi.y | (lane >= kMaxTerms ? uint32_t(kJoinHiHalf) : 0u);
   }
   return T;
 }
@@ -1040,6 +1096,103 @@ __device__ __forceinline__ void join_tiles(unsigned char* smem, const JoinTileCt
   }
 }
 
+// PAIRED TILES (k_join_score<kJKHalf>).  The per-(query, tile) visit — two barriers, the share
+// bookkeeping, the wait for the first entries, the dense read-and-clear of 48 KB — is what
+// k_join_score spends its time on, not the postings (profiles/r05_pruning.txt: 2.27 of 5.7 ms with
+// no entries at all, and the first quarter of the entries costs as much as the other three).  A
+// visit here covers TWO consecutive tiles: a term's entries of both are contiguous in its stream,
+// and the accumulator word of a doc offset holds the first tile's sum in its low 16 bits and the
+// second tile's in its high 16 bits — 16-bit images of the 32-bit contributions, each rounded up
+// by one to two units (join_post HALF), so that
+//     exact 32-bit sum f >= thr  ==>  16-bit sum >= max(thr >> 15, 1)
+// (f / 2^15 <= sum_i x_i + m * 65 / 2^15 with x_i = cs t_i / 2^15 and 64 units of float rounding
+// per term; every 16-bit contribution exceeds x_i + 1 - 2^-9).  The docs that pass are staged by
+// doc id only; k_join_rescore looks their postings up in the streams, forms f exactly as join_post
+// does and applies the bin test: the candidate list k_select sees is the 32-bit kernel's, bit for
+// bit.  A sum stays below 2^16: sum_i x_i < 2^15 (fx_mul) and at most 2 * 16 units of rounding.
+// (The general forms scale exactly: cs / 2^15 is a power-of-two multiple, so their 16-bit value
+// is the 32-bit one / 2^15 before the + 2.)  Half the visits, the same LDS bytes per visit;
+// eligibility (irs_hip.hip join_half_ok): the plain disjunctions of a batch, no deleted docs in
+// their segments (those entries leave the doc order k_join_rescore's search relies on).
+template<int M>
+__device__ __forceinline__ void join_pairs(unsigned char* smem, const JoinTileCtx& ctx,
+                                           const JoinLane& T, uint32_t tile0, uint32_t ntile,
+                                           uint32_t wv, uint32_t nw_log2, uint32_t& my_hits) {
+  static_assert((M & kJHalf) != 0 && (M & kJCount) == 0, "join_pairs: plain disjunctions");
+  const uint32_t* rng = reinterpret_cast<const uint32_t*>(smem + JoinOff::rng);
+  const uint32_t* cum = reinterpret_cast<const uint32_t*>(smem + JoinOff::cum);
+  const uint32_t tid = threadIdx.x;
+  const unsigned lane = tid & 63u;
+  const uint64_t safe = reinterpret_cast<uint64_t>(ctx.args->jterms);
+  const uint32_t npair = (ntile + 1u) >> 1;
+  auto begin = [&](uint32_t p, JoinRun& r) {   // (p >= npair: an empty share)
+    uint32_t a = 0, n = 0, c = 0;
+    if (lane < 2u * kMaxTerms && p < npair) {
+      const uint32_t i = 2u * p + (lane >> 4), j = lane & (kMaxTerms - 1u);
+      if (i < ntile) {   // (an odd tile count: the last pair's second tile is empty)
+        a = rng[i * kMaxTerms + j];
+        n = rng[(i + 1u) * kMaxTerms + j] - a;
+      }
+      c = cum[p * 2u * kMaxTerms + lane];
+    }
+    join_begin<M>(r, T, a, n, c, wv, nw_log2, safe, lane);
+  };
+  JoinRun r0, r1;
+  begin(0, r0);
+  begin(1, r1);
+  const uint32_t thr = wave::uniform(ctx.thr);       // in 16-bit units, >= 1
+  const uint32_t below = (thr - 1u) * 0x00010001u;   // both halves: the largest sum that is no candidate
+  uint32_t hits2 = 0;                                // matches per half (<= 12 per visit and lane)
+  auto end_pair = [&](uint32_t p) {
+    __syncthreads();   // B1: every accumulation of the pair has landed
+    const uint32_t doc0 = kDocMin + (tile0 + 2u * p) * kJoinTile;
+    auto candidate = [&](uint32_t doc, uint32_t sum16) {   // rare: the doc and its 16-bit sum
+      const uint64_t key = (uint64_t(sum16) << 32) | uint64_t(0xFFFFFFFFu - doc);
+      const uint32_t slot = atomicAdd(ctx.ncand, 1u);
+      if (slot < kJoinCands) {
+        ctx.lc[slot] = key;
+      } else {
+        const uint32_t g = atomicAdd(&ctx.args->cand_count[ctx.q], 1u);
+        if (g < ctx.cap) ctx.args->cands[uint64_t(ctx.q) * ctx.cap + g] = key;
+      }
+    };
+    auto four = [&](uint32_t i, const uint32_t (&v)[4]) {
+      wave::count_nonzero_halves4(hits2, v[0], v[1], v[2], v[3]);
+      const uint32_t top = wave::pk_max_u16(wave::pk_max_u16(v[0], v[1]), wave::pk_max_u16(v[2], v[3]));
+      if (wave::pk_max_u16(top, below) != below) {   // rare: some half reaches the threshold
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+          if ((v[k] & 0xFFFFu) >= thr) candidate(doc0 + i + k, v[k] & 0xFFFFu);
+          if ((v[k] >> 16) >= thr) candidate(doc0 + kJoinTile + i + k, v[k] >> 16);
+        }
+      }
+    };
+    const uint32_t step = blockDim.x * 4u;
+    uint32_t i = tid * 4u;
+    for (; i + step < kJoinTile; i += 2u * step) {
+      uint32_t v0[4], v1[4];
+      wave::lds_take4x2(smem, JoinOff::acc + i * 4u, JoinOff::acc + (i + step) * 4u, v0, v1);
+      four(i, v0);
+      four(i + step, v1);
+    }
+    if (i < kJoinTile) {
+      uint32_t v0[4];
+      wave::lds_take4(smem, JoinOff::acc + i * 4u, v0);
+      four(i, v0);
+    }
+    __syncthreads();   // B2: accumulators are clear again
+  };
+  for (uint32_t p = 0; p < npair; p += 2u) {
+    join_finish<M>(smem, r0, T, lane);
+    begin(p + 2u, r0);
+    end_pair(p);
+    join_finish<M>(smem, r1, T, lane);
+    begin(p + 3u, r1);
+    if (p + 1u < npair) end_pair(p + 1u);
+  }
+  my_hits += (hits2 & 0xFFFFu) + (hits2 >> 16);
+}
+
 // Persistent workgroups pulling chunks of kJoinChunkTiles consecutive tiles of one unit
 // (chunk-major ids, heaviest units first: score.h k_score).  Per tile and wavefront:
 //   finish(u)     consume the requested entries of tile u, stream the rest of its share
@@ -1079,10 +1232,14 @@ enum : uint32_t {   // LDS scratch words
 
 // COUNT: the launch's units are conjunctions / min-match disjunctions (accumulators with match
 // counts); a kernel of its own, so that the plain disjunctions' code stays as small as it is.
-template<bool COUNT>
+// HALF: plain disjunctions on paired tiles (join_pairs); k_join_rescore follows.
+enum : int { kJKPlain = 0, kJKCount = 1, kJKHalf = 2 };
+template<int KIND>
 __global__ void __launch_bounds__(kTileThreadsMax) IRS_WAVES_PER_SIMD(8)
 k_join_score(const JoinArgs* __restrict__ args) {
   RT_DYN_SMEM(smem);
+  constexpr bool COUNT = KIND == kJKCount;
+  constexpr bool HALF = KIND == kJKHalf;
   if (!wave::lds_is_at_zero(smem)) __builtin_trap();
   uint32_t* acc = reinterpret_cast<uint32_t*>(smem + JoinOff::acc);
   uint32_t* rng = reinterpret_cast<uint32_t*>(smem + JoinOff::rng);
@@ -1142,17 +1299,31 @@ k_join_score(const JoinArgs* __restrict__ args) {
       }
       join_prologue(smem, qd, args->qterms, args->jterms);   // (its barrier publishes rng too)
       // per tile: the inclusive prefix of the terms' entry counts (what join_begin splits)
-      for (uint32_t e = tid; e < ntile * kMaxTerms; e += blockDim.x) {
-        const uint32_t i = e / kMaxTerms, j = e % kMaxTerms;
-        uint32_t c = 0;
-        for (uint32_t t = 0; t <= j; ++t)
-          c += (rng[(i + 1u) * kMaxTerms + t] - rng[i * kMaxTerms + t]) >> kAblShift;
-        cum[e] = c;
+      if (HALF) {   // per pair of tiles: over the first tile's terms, then the second's
+        const uint32_t npair = (ntile + 1u) >> 1;
+        for (uint32_t e = tid; e < npair * 2u * kMaxTerms; e += blockDim.x) {
+          const uint32_t p = e / (2u * kMaxTerms), l = e % (2u * kMaxTerms);
+          uint32_t c = 0;
+          for (uint32_t t = 0; t <= l; ++t) {
+            const uint32_t i = 2u * p + t / kMaxTerms, j = t % kMaxTerms;
+            if (i < ntile) c += rng[(i + 1u) * kMaxTerms + j] - rng[i * kMaxTerms + j];
+          }
+          cum[e] = c;
+        }
+      } else {
+        for (uint32_t e = tid; e < ntile * kMaxTerms; e += blockDim.x) {
+          const uint32_t i = e / kMaxTerms, j = e % kMaxTerms;
+          uint32_t c = 0;
+          for (uint32_t t = 0; t <= j; ++t)
+            c += (rng[(i + 1u) * kMaxTerms + t] - rng[i * kMaxTerms + t]) >> kAblShift;
+          cum[e] = c;
+        }
       }
       __syncthreads();
-      const JoinLane T = join_lane(smem, lane);
+      const JoinLane T = HALF ? join_lane_half(smem, lane) : join_lane(smem, lane);
       // every term through table slot 0?  (wave-uniform, the same in every wavefront)
-      const bool simple = wave::ballot(T.mode != 0u) == 0ull;
+      const bool simple = HALF ? wave::ballot((T.mode & ~uint32_t(kJoinHiHalf)) != 0u) == 0ull
+                               : wave::ballot(T.mode != 0u) == 0ull;
       JoinTileCtx ctx;
       ctx.args = args;
       ctx.q = q;
@@ -1164,7 +1335,12 @@ k_join_score(const JoinArgs* __restrict__ args) {
       ctx.lc = lc;
       ctx.ncand = ncand;
       ctx.need = query_need(qd.op);
-      if (COUNT) {   // conjunction / min-match: accumulators carry match counts
+      if (HALF) {
+        const uint32_t thr16 = ctx.thr >> 15;
+        ctx.thr = thr16 ? thr16 : 1u;
+        if (simple) join_pairs<kJHalf | kJSimple>(smem, ctx, T, tile0, ntile, wv, nw_log2, my_hits);
+        else join_pairs<kJHalf>(smem, ctx, T, tile0, ntile, wv, nw_log2, my_hits);
+      } else if (COUNT) {   // conjunction / min-match: accumulators carry match counts
         if (simple) join_tiles<kJSimple | kJCount>(smem, ctx, T, tile0, ntile, wv, nw_log2, my_hits);
         else join_tiles<kJCount>(smem, ctx, T, tile0, ntile, wv, nw_log2, my_hits);
       } else {
@@ -1229,6 +1405,258 @@ k_join_score(const JoinArgs* __restrict__ args) {
       }
     }
   }
+}
+// Behind k_join_score<kJKHalf>: one workgroup per unit turns the staged docs into a candidate list
+// that yields what the 32-bit kernel's yields — for a staged doc and every term of the query the
+// posting is looked up in the term's stream (the tile's entries are in doc order), the
+// contributions are formed and summed exactly as join_post<FORM, N, false> does (same tables, same
+// expressions, same truncation: integer sums do not depend on the order), then the 32-bit
+// threshold and the exact bin test of join_tiles' candidate() decide.
+//
+// Not every staged doc needs that.  A staged doc carries its 16-bit sum S, and
+//     (S - 2 m - 1) 2^15  <  f  <  S 2^15          (m terms; join_pairs' bounds, both sides)
+// so with S_k the k-th largest S of the unit, the k docs at or above it all have
+// f > (S_k - 2 m - 1) 2^15 while a doc with S <= S_k - 2 m - 3 has f < (S_k - 2 m - 3) 2^15: it
+// is not among the k best and k_select would drop it.  Only the docs with S >= S_k - 2 m - 2 are
+// looked up (about k of the ~3 k an estimated threshold stages); if fewer than k of them pass the
+// exact test — the k-th score sits within 2 m units of the threshold — the rest is looked up
+// too, and the list is exactly the 32-bit kernel's.  Either way k_select sees >= k candidates
+// exactly when that list has >= k, and the k best of both are the same docs with the same sums.
+//
+// The look-up: the docs of a term are spread evenly, so the posting of doc offset o among the n
+// entries of a tile sits near n o / 12288: sixteen entries around that guess (four independent
+// 16-byte loads, one round trip) settle most searches; a binary search over what is left of the
+// range the others.
+constexpr uint32_t kRescoreMax = 6144;    // docs in LDS at a time: doc + sum = 8 B each
+static_assert(kRescoreMax * 8u <= 4u * kJoinTile, "k_join_rescore's arrays fit the accumulator area");
+// the 32-bit contribution of one entry: join_post<FORM, N, false>, one posting
+__device__ __forceinline__ uint32_t join_fx(const unsigned char* lds, uint32_t e, float cs, uint32_t mode) {
+  const uint32_t tabofs = mode & kJoinTabMask;
+  const int form = join_form(mode);
+  if (form == kJTable) {
+    const float t = wave::lds_f32(lds, JoinOff::caches + ((e & 0xFFFFu) | tabofs));
+    return static_cast<uint32_t>(wave::fma(cs, t, 1.f));
+  }
+  const float t = wave::lds_f32(lds, JoinOff::caches + ((e & 0x3FCu) | tabofs));
+  const float tf = static_cast<float>(join_tf(e));
+  float scaled = (form == kJSqrt) ? wave::fast_sqrt(tf) * cs * t
+                                  : wave::fma(-cs, wave::fast_rcp(wave::fma(tf, t, 1.f)), cs);
+  wave::keep_f(scaled);
+  return static_cast<uint32_t>(scaled) | 1u;
+}
+// the entry of doc offset `off` among ent[lo .. end) (ascending offsets), or 0xFFFFFFFF.
+// [lo, hi] brackets the first entry at or behind the doc throughout.  A long range starts with
+// one probe at the evenly-spread guess and corrects the guess by the local density (the error of
+// the second guess is a few entries whatever the range); then sixteen entries around the guess
+// (four independent 16-byte loads — behind the last stream kJoinSlack entries are readable), a
+// gallop from the window's edge if it missed, a binary search over what is left.
+__device__ __forceinline__ uint32_t join_find(const uint32_t* ent, uint32_t lo, const uint32_t end,
+                                              const uint32_t off) {
+  if (lo >= end) return 0xFFFFFFFFu;
+  const uint32_t n = end - lo;
+  uint32_t hi = end;
+  uint32_t g = lo + (n * off) / kJoinTile;   // (n, off <= 12288: no overflow)
+  if (g >= end) g = end - 1u;
+  if (n > 256u) {
+    const uint32_t eg = ent[g];
+    const uint32_t og = eg >> 18;
+    if (og == off) return eg;
+    const int32_t d = int32_t(off) - int32_t(og);
+    const int32_t g2 = int32_t(g) + (d * int32_t(n)) / int32_t(kJoinTile);
+    if (og < off) lo = g + 1u; else hi = g;
+    g = uint32_t(g2 < int32_t(lo) ? int32_t(lo) : g2);
+    if (g > hi) g = hi;
+    if (lo >= hi) return 0xFFFFFFFFu;   // (the doc would sit between g and its neighbour)
+  }
+  {
+    uint32_t w0 = g > lo + 8u ? g - 8u : lo;
+    if (w0 + 16u > hi) w0 = hi > lo + 16u ? hi - 16u : lo;
+    uint32_t v[16];
+#pragma unroll
+    for (uint32_t q4 = 0; q4 < 4u; ++q4) {
+      uint32_t x[4];
+      wave::gload_u32x4_at(reinterpret_cast<uint64_t>(ent + w0 + 4u * q4), x);
+      v[4u * q4] = x[0]; v[4u * q4 + 1u] = x[1]; v[4u * q4 + 2u] = x[2]; v[4u * q4 + 3u] = x[3];
+    }
+    uint32_t below = 0, hit = 0xFFFFFFFFu;
+    const uint32_t live = hi - w0;   // window slots inside the bracket (>= 1)
+#pragma unroll
+    for (uint32_t i = 0; i < 16u; ++i) {
+      const bool in = i < live;
+      below += (in && (v[i] >> 18) < off) ? 1u : 0u;
+      if (in && (v[i] >> 18) == off) hit = v[i];
+    }
+    if (hit != 0xFFFFFFFFu) return hit;
+    const uint32_t seen = live < 16u ? live : 16u;
+    if (below == 0u) {
+      if (w0 == lo) return 0xFFFFFFFFu;
+      hi = w0;                                   // everything seen lies behind the doc
+      for (uint32_t s = 16u; hi > lo; s *= 4u) {  // gallop to the left
+        if (hi - lo < s) break;
+        const uint32_t p = hi - s;
+        if ((ent[p] >> 18) >= off) { hi = p; } else { lo = p + 1u; break; }
+      }
+    } else if (below == seen) {
+      lo = w0 + seen;                            // ... in front of it
+      if (seen < 16u) return 0xFFFFFFFFu;        // (the bracket ended inside the window)
+      for (uint32_t s = 16u; lo < hi; s *= 4u) {  // gallop to the right
+        if (hi - lo < s) break;
+        const uint32_t p = lo + s - 1u;
+        if ((ent[p] >> 18) < off) { lo = p + 1u; } else { hi = p; break; }
+      }
+    } else {
+      return 0xFFFFFFFFu;   // the doc would sit inside the window: no posting
+    }
+  }
+  while (lo < hi) {   // the first entry at or behind the doc
+    const uint32_t mid = (lo + hi) >> 1;
+    if ((ent[mid] >> 18) < off) lo = mid + 1u; else hi = mid;
+  }
+  if (lo < end) {
+    const uint32_t e = ent[lo];
+    if ((e >> 18) == off) return e;
+  }
+  return 0xFFFFFFFFu;
+}
+__global__ void __launch_bounds__(kTileThreadsMax)
+k_join_rescore(const uint32_t* units, const DevQuery* queries, const DevQTerm* qterms,
+               const JoinTerm* jterms, const uint32_t* bstar, uint64_t* cands,
+               uint32_t* cand_count, uint32_t cap) {
+  RT_DYN_SMEM(smem);
+  uint32_t* docs = reinterpret_cast<uint32_t*>(smem + JoinOff::acc);   // [kRescoreMax]
+  uint32_t* fsum = docs + kRescoreMax;                                 // [kRescoreMax]
+  uint32_t* hist = reinterpret_cast<uint32_t*>(smem + JoinOff::cand);  // [256]
+  uint32_t* sig = reinterpret_cast<uint32_t*>(smem + JoinOff::sig);
+  uint32_t* vars = reinterpret_cast<uint32_t*>(smem + JoinOff::vars);
+  enum : uint32_t { kOut = 0, kSel = 1, kPass = 2, kDigit = 3, kWant = 4 };
+  const uint32_t tid = threadIdx.x;
+  const unsigned lane = tid & 63u;
+  const uint32_t q = units[blockIdx.x];
+  const uint32_t n = cand_count[q];
+  // (more staged docs than slots: k_select raises kStatusOverflow, the host re-runs the batch)
+  if (!n || n > cap) return;
+  const DevQuery qd = queries[q];
+  if (tid == 0) {
+    sig[0] = 0xFFFFFFFFu;
+    vars[kOut] = vars[kSel] = vars[kPass] = 0u;
+  }
+  __syncthreads();
+  join_prologue(smem, qd, qterms, jterms);
+  const uint32_t bs = bstar[q];
+  const uint32_t thr = bin_threshold<uint32_t>(bs, qd);
+  const uint32_t nt = qd.n_terms;
+  const JoinTerm* jts = reinterpret_cast<const JoinTerm*>(smem + JoinOff::jts);
+  uint64_t* list = cands + uint64_t(q) * cap;
+  // the docs[0 .. count) in LDS: look their postings up, sum; returns with the sums visible
+  auto look_up = [&](uint32_t count) {
+    for (uint32_t it = tid; it < count * nt; it += blockDim.x) {
+      const uint32_t c = it / nt, j = it % nt;
+      const uint32_t at = docs[c] - kDocMin;
+      const uint32_t tile = at / kJoinTile, off = at - tile * kJoinTile;
+      const uint32_t* bnd = reinterpret_cast<const uint32_t*>(jts[j].bounds);
+      const uint32_t e = join_find(reinterpret_cast<const uint32_t*>(jts[j].entries), bnd[tile],
+                                   bnd[tile + 1u], off);
+      if (e != 0xFFFFFFFFu) atomicAdd(&fsum[c], join_fx(smem, e, jts[j].cs, jts[j].mode));
+    }
+    __syncthreads();
+  };
+  auto passes = [&](uint32_t f) {   // the exact test of join_tiles' candidate()
+    const float v = f <= kMaxTerms ? 0.f : from_fixed<uint32_t>(f, qd.fx_inv);
+    return f >= thr && score_bin(v, qd.bin_scale) >= bs;
+  };
+  auto key_of = [&](uint32_t c) {
+    const uint32_t f = fsum[c];
+    return make_key(f <= kMaxTerms ? 0.f : from_fixed<uint32_t>(f, qd.fx_inv), docs[c]);
+  };
+  // the 8-bit digit (at `shift`) holding the want-th largest S among the staged docs whose higher
+  // bits equal `prefix`: histogram in LDS, suffix search by one wavefront (lane L owns the four
+  // digits of group 63 - L); leaves the digit and the rank inside it in vars[kDigit], vars[kWant]
+  auto digit_pass = [&](uint32_t shift, uint32_t prefix, uint32_t want) {
+    if (tid < 256u) hist[tid] = 0u;
+    __syncthreads();
+    for (uint32_t c = tid; c < n; c += blockDim.x) {
+      const uint32_t sv = uint32_t(list[c] >> 32);
+      if (shift == 8u || (sv >> 8) == prefix) atomicAdd(&hist[(sv >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid < 64u) {
+      const uint32_t g = 63u - lane;
+      const uint32_t sum = hist[4u * g] + hist[4u * g + 1u] + hist[4u * g + 2u] + hist[4u * g + 3u];
+      const uint32_t incl = wave::inclusive_scan(sum);
+      const uint64_t reach = wave::ballot(incl >= want);
+      uint32_t digit = 0, rank = 1;
+      if (reach) {
+        const int src = __builtin_ctzll(reach);
+        uint32_t cum = wave::bcast(incl - sum, src);
+        const uint32_t gs = 63u - uint32_t(src);
+        for (int i = 3; i >= 0; --i) {
+          const uint32_t h = hist[4u * gs + uint32_t(i)];
+          if (cum + h >= want) { digit = 4u * gs + uint32_t(i); rank = want - cum; break; }
+          cum += h;
+        }
+      }
+      if (lane == 0) {
+        vars[kDigit] = digit;
+        vars[kWant] = rank;
+      }
+    }
+    __syncthreads();
+  };
+  bool done = false;
+  if (n > qd.k && qd.k) {
+    // the docs whose S is within 2 m + 2 of the k-th largest S: looked up first
+    digit_pass(8u, 0u, qd.k);
+    const uint32_t d1 = vars[kDigit], w1 = vars[kWant];
+    __syncthreads();
+    digit_pass(0u, d1, w1);
+    const uint32_t sk = (d1 << 8) | vars[kDigit];
+    const uint32_t cut = sk > 2u * nt + 2u ? sk - (2u * nt + 2u) : 0u;
+    for (uint32_t c = tid; c < n; c += blockDim.x) {
+      const uint64_t key = list[c];
+      if (uint32_t(key >> 32) >= cut) {
+        const uint32_t slot = atomicAdd(&vars[kSel], 1u);
+        if (slot < kRescoreMax) {
+          docs[slot] = key_hit(key).doc;
+          fsum[slot] = 0u;
+        }
+      }
+    }
+    __syncthreads();
+    const uint32_t sel = vars[kSel];
+    if (sel <= kRescoreMax) {
+      look_up(sel);
+      uint32_t mine = 0;
+      for (uint32_t c = tid; c < sel; c += blockDim.x) mine += passes(fsum[c]) ? 1u : 0u;
+      if (mine) atomicAdd(&vars[kPass], mine);
+      __syncthreads();
+      // k of them pass (or nothing was left out): they are the list; else — the k-th score sits
+      // within 2 m units of the threshold, rare — every staged doc is looked up below
+      if (vars[kPass] >= qd.k || sel == n) {
+        for (uint32_t c = tid; c < sel; c += blockDim.x)
+          if (passes(fsum[c])) list[atomicAdd(&vars[kOut], 1u)] = key_of(c);
+        done = true;
+      }
+    }
+    __syncthreads();
+  }
+  if (!done) {
+    // every staged doc, kRescoreMax at a time, compacted in place (a pass's docs sit in LDS before
+    // its first survivor is written, and survivors never outnumber the docs read so far)
+    for (uint32_t base = 0; base < n; base += kRescoreMax) {
+      const uint32_t nb = n - base < kRescoreMax ? n - base : kRescoreMax;
+      for (uint32_t c = tid; c < nb; c += blockDim.x) {
+        docs[c] = key_hit(list[base + c]).doc;
+        fsum[c] = 0u;
+      }
+      __syncthreads();
+      look_up(nb);
+      for (uint32_t c = tid; c < nb; c += blockDim.x)
+        if (passes(fsum[c])) list[atomicAdd(&vars[kOut], 1u)] = key_of(c);
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  if (tid == 0) cand_count[q] = vars[kOut];
 }
 
 }  // namespace irs_hip

@@ -536,6 +536,19 @@ class QueryBatch:
         _lib.check(self.L, self.L.irs_hip_batch_path(self.handle, C.byref(v)), "irs_hip_batch_path")
         return int(v.value)
 
+    def set_paired_tiles(self, enable=True):
+        """Joined plain disjunctions on paired doc tiles (default) or on 32-bit tiles: bit-identical."""
+        _lib.check(self.L, self.L.irs_hip_batch_set_paired_tiles(self.handle, int(enable)),
+                   "irs_hip_batch_set_paired_tiles")
+        return self
+
+    def paired_tiles(self):
+        """Whether the last run's joined plain disjunctions ran on paired tiles."""
+        v = C.c_int(0)
+        _lib.check(self.L, self.L.irs_hip_batch_paired_tiles(self.handle, C.byref(v)),
+                   "irs_hip_batch_paired_tiles")
+        return bool(v.value)
+
     def set_wand(self, enable=True):
         """ExecutionContext::wand (index-search --search-mode wand): block-max pruning."""
         _lib.check(self.L, self.L.irs_hip_batch_set_wand(self.handle, int(enable)),

@@ -549,6 +549,45 @@ def case_pilot_misled(L, k=600, joined=False):
     sr.close()
 
 
+def case_paired_tiles(L, num_docs=61_000, max_rank=256, layout=synth.LAYOUT_SIMD4):
+    """Joined plain disjunctions on paired doc tiles (16-bit halves pick the docs, k_join_rescore
+    forms their exact sums) against the same batch on 32-bit tiles: docs, scores, order, counts
+    and totals bit for bit, each also against the oracle.  61 000 docs = 5 tiles: the last pair
+    has one tile only.  k = 3 puts the threshold high (few docs pass), k = 1000 low; a batch with
+    a two-signature query or a long-frequency term does not qualify and says so."""
+    seg = synth.build_segment(num_docs, max_rank, layout=layout)
+    sr = search.SegmentReader.from_synth(seg, L=L)
+    ranks = synth.make_queries(10, 8, 2, max_rank, synth.SEED + 15)
+    pure = [Or([by_term(int(r) - 1) for r in row]) for row in ranks]
+    pure += [by_term(3), by_term(max_rank - 1), Or([by_term(1), by_term(2, 3.0)]),
+             Or([by_term(0), by_term(10 * max_rank)]), Or([by_term(0), by_term(1), by_term(2)])]
+    for scorer in (BM25(), BM25(1.2, 0.0), TFIDF(True)):
+        for k in (3, 100, 1000):
+            got = {}
+            for paired in (True, False):
+                prep = search.prepare(pure, scorer, [parity.segment_stats(seg)])
+                b = sr.batch(prep, k).set_path(_lib.PATH_JOINED).set_paired_tiles(paired)
+                h, c, t = b.run().results()
+                assert b.path() == _lib.PATH_JOINED
+                assert b.paired_tiles() == paired, (scorer, k, paired)
+                parity.check_single_segment(seg, pure, scorer, k, h, c, t)
+                got[paired] = (h.copy(), c.copy(), t.copy())
+                # a second run of the same batch (replayed): the same again
+                h2, c2, t2 = b.run().results()
+                assert np.array_equal(h, h2) and np.array_equal(c, c2) and np.array_equal(t, t2)
+                b.close()
+            for x, y in zip(got[True], got[False]):
+                assert np.array_equal(x, y), (scorer, k)
+    # a mixed batch: the plain disjunctions pair, the counting units keep their kernel
+    mixed = pure + standard_filters(max_rank, n_or8=1)
+    prep = search.prepare(mixed, BM25(), [parity.segment_stats(seg)])
+    b = sr.batch(prep, 40).set_path(_lib.PATH_JOINED)
+    h, c, t = b.run().results()
+    parity.check_single_segment(seg, mixed, BM25(), 40, h, c, t)
+    b.close()
+    sr.close()
+
+
 def case_paths_agree(L, num_docs=70_000, max_rank=256, layout=synth.LAYOUT_SIMD4):
     """The two organisations of a disjunction batch — every query decoding its own blocks (work
     items) and the batch decoding every distinct term once (joined posting streams) — return

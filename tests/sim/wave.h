@@ -91,6 +91,25 @@ template<typename T>
 __device__ __forceinline__ void count_nonzero4(uint32_t& acc, T a, T b, T c, T d) {
   acc += uint32_t(a != 0) + uint32_t(b != 0) + uint32_t(c != 0) + uint32_t(d != 0);
 }
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+  const uint32_t lo = (a & 0xFFFFu) < (b & 0xFFFFu) ? (a & 0xFFFFu) : (b & 0xFFFFu);
+  const uint32_t hi = (a >> 16) < (b >> 16) ? (a >> 16) : (b >> 16);
+  return (hi << 16) | lo;
+}
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+  const uint32_t lo = (a & 0xFFFFu) > (b & 0xFFFFu) ? (a & 0xFFFFu) : (b & 0xFFFFu);
+  const uint32_t hi = (a >> 16) > (b >> 16) ? (a >> 16) : (b >> 16);
+  return (hi << 16) | lo;
+}
+__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {
+  return (((a >> 16) + (b >> 16)) << 16) | ((a + b) & 0xFFFFu);
+}
+__device__ __forceinline__ void count_nonzero_halves4(uint32_t& acc, uint32_t a, uint32_t b,
+                                                      uint32_t c, uint32_t d) {
+  const uint32_t one = 0x00010001u;
+  acc = pk_add_u16(acc, pk_add_u16(pk_add_u16(pk_min_u16(a, one), pk_min_u16(b, one)),
+                                   pk_add_u16(pk_min_u16(c, one), pk_min_u16(d, one))));
+}
 __device__ __forceinline__ uint32_t opaque(uint32_t v) { return v; }
 __device__ __forceinline__ uint64_t opaque64(uint64_t v) { return v; }
 

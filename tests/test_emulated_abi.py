@@ -117,6 +117,11 @@ def test_paths_agree(simlib, layout):
     cases.case_paths_agree(simlib, layout=layout)
 
 
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_paired_tiles(simlib, layout):
+    cases.case_paired_tiles(simlib, layout=layout)
+
+
 def test_scored_multiterm_expansion(simlib):
     cases.case_scored_expansion(simlib, sizes=(30_000, 12_000), max_rank=384)
 

@@ -190,6 +190,11 @@ def test_paths_agree(gpulib, layout):
     cases.case_paths_agree(gpulib, layout=layout)
 
 
+@pytest.mark.parametrize("layout", [0, 1])
+def test_paired_tiles(gpulib, layout):
+    cases.case_paired_tiles(gpulib, layout=layout)
+
+
 def test_scored_multiterm_expansion(gpulib):
     """Prefix3 / Wildcard as the reference harness builds them (scored_terms_limit): VERDICT r05
     missing 5."""

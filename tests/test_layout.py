@@ -24,7 +24,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), n
     assert sorted(_lib.SYMBOLS) == names
-    assert _lib.bind(L).irs_hip_abi_version() == 11
+    assert _lib.bind(L).irs_hip_abi_version() == 12
     assert _lib.bind(L).irs_hip_strerror(-2) == b"corrupt postings data"
     out = subprocess.run(["nm", "-D", "--defined-only", str(so)], capture_output=True, text=True)
     exported = set(re.findall(r" T (irs_hip_[a-z0-9_]+)", out.stdout))

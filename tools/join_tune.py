@@ -56,6 +56,10 @@ def main():
         L, sr = libs[name]
         b = sr.batch(prep, args.k).profile(True)
         # settings: items | exact[threads] | [threads]  (the joined path at 256 / 512 / 1024 threads)
+        # (a trailing "-np": the joined plain disjunctions on 32-bit tiles, not on paired tiles)
+        if setting.endswith("-np"):
+            setting = setting[:-3]
+            b.set_paired_tiles(False)
         if setting == "items":
             b.set_path(_lib.PATH_ITEMS)
         else:
