@@ -1392,18 +1392,18 @@ bool launch_join_score(irs_hip_batch* b, rt::stream_t st) {
   // of the work queue leaves CUs idle (1000 units x 102 tiles: 8 chunks per workgroup at 26 tiles,
   // 1.12 ms; 21 at 10 tiles, 0.95 ms — profiles/r05_chunks.txt), while a large batch loses to the
   // per-chunk prologue below 26 (10 M docs: 5.61 ms at 32, 5.88 at 16, 6.50 at 8).
-  uint32_t max_chunk = kJoinChunkTiles;
-  {
+  // (paired tiles: up to kJoinChunkTiles = 64 tiles = 32 visits per chunk, 4.98 -> 4.91 ms)
+  auto chunking = [&](uint32_t cap, uint32_t& cpq, uint32_t& chunk_tiles) {
     const uint64_t tiles = uint64_t(b->join_units.size()) * b->join_max_tiles;
     const uint64_t wgs = uint64_t(b->seg->cus) * per_cu;
-    max_chunk = uint32_t(std::min<uint64_t>(kJoinChunkTiles, std::max<uint64_t>(8, tiles / (20 * wgs))));
-  }
-  if (const char* e = std::getenv("IRS_HIP_JOIN_CHUNK")) {   // tuning knob: tiles per chunk at most
-    const uint32_t v = uint32_t(std::atoi(e));
-    if (v >= 1 && v <= kJoinChunkTiles) max_chunk = v;
-  }
-  const uint32_t cpq = std::max<uint32_t>(1, (b->join_max_tiles + max_chunk - 1) / max_chunk);
-  const uint32_t chunk_tiles = std::max<uint32_t>(1, (b->join_max_tiles + cpq - 1) / cpq);
+    uint32_t max_chunk = uint32_t(std::min<uint64_t>(cap, std::max<uint64_t>(8, tiles / (20 * wgs))));
+    if (const char* e = std::getenv("IRS_HIP_JOIN_CHUNK")) {   // tuning knob: tiles per chunk at most
+      const uint32_t v = uint32_t(std::atoi(e));
+      if (v >= 1 && v <= cap) max_chunk = v;
+    }
+    cpq = std::max<uint32_t>(1, (b->join_max_tiles + max_chunk - 1) / max_chunk);
+    chunk_tiles = std::max<uint32_t>(1, (b->join_max_tiles + cpq - 1) / cpq);
+  };
   const uint32_t n_all = uint32_t(b->join_units.size());
   // [0]: the live counters, [1]: their start values (copied over [0] on the device every run)
   if (!b->d_join_ctr.p && !b->d_join_ctr.alloc(2 * sizeof b->join_ctr_init)) return false;
@@ -1411,6 +1411,8 @@ bool launch_join_score(irs_hip_batch* b, rt::stream_t st) {
   for (uint32_t part = 0; part < 2; ++part) {
     const uint32_t n_units = part ? n_all - b->n_join_plain : b->n_join_plain;
     if (!n_units) continue;
+    uint32_t cpq = 1, chunk_tiles = 1;
+    chunking((!part && half) ? kJoinChunkTiles : kJoinChunkPlain, cpq, chunk_tiles);
     const uint64_t chunks = uint64_t(n_units) * cpq;
     if (chunks > 0xFFFF0000ull) return false;
     const uint32_t grid = uint32_t(std::min<uint64_t>(chunks, uint64_t(b->seg->cus) * per_cu));

@@ -42,7 +42,8 @@ namespace irs_hip {
 constexpr uint32_t kJoinTile = 12288;     // docs per accumulator tile (48 KB of u32 in LDS)
 constexpr uint32_t kJoinTfMax = 255;      // entry layout: 6 + 2 bits of tf
 constexpr uint32_t kJoinBlocks = 64;      // blocks per k_join workgroup
-constexpr uint32_t kJoinChunkTiles = 32;  // consecutive tiles of one unit per work-queue item
+constexpr uint32_t kJoinChunkTiles = 64;  // consecutive tiles of one unit per work-queue item, at most
+constexpr uint32_t kJoinChunkPlain = 32;  // ... of the 32-bit kernels (paired tiles take up to 64: 32 visits)
 constexpr uint32_t kJoinCands = 256;      // candidate staging slots per chunk (x2 buffers)
 constexpr uint32_t kJoinSlack = 1024;     // readable entries behind the last stream
 constexpr uint32_t kJoinQueues = 8;       // work queues of k_join_score: one per XCD
@@ -1168,14 +1169,7 @@ __device__ __forceinline__ void join_pairs(unsigned char* smem, const JoinTileCt
       }
     };
     const uint32_t step = blockDim.x * 4u;
-    uint32_t i = tid * 4u;
-    for (; i + step < kJoinTile; i += 2u * step) {
-      uint32_t v0[4], v1[4];
-      wave::lds_take4x2(smem, JoinOff::acc + i * 4u, JoinOff::acc + (i + step) * 4u, v0, v1);
-      four(i, v0);
-      four(i + step, v1);
-    }
-    if (i < kJoinTile) {
+    for (uint32_t i = tid * 4u; i < kJoinTile; i += step) {
       uint32_t v0[4];
       wave::lds_take4(smem, JoinOff::acc + i * 4u, v0);
       four(i, v0);
