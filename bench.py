@@ -340,7 +340,7 @@ def main():
     # a multi-segment batch writes [segment][query][k] hits and [segment][query] counts: exactly
     # consecutive slots of the send buffer
     slots = [{lead: exchange.slot(ph, my.index(lead)) for lead in groups} for ph in (0, 1)]
-    state = {"it": 0, "work": [], "joined": True, "reruns": 0, "retire": [], "host_hits": 0}
+    state = {"it": 0, "work": [], "joined": True, "paired": True, "reruns": 0, "retire": [], "host_hits": 0}
 
     def deliver(prev):
         # a finished step: checked (irs_hip_batch_results_to_device waits for THAT batch's own
@@ -363,6 +363,7 @@ def main():
             state["collect"].append(np.sum([cur[s].timings() for s in cur], axis=0))
             state["work"].append(np.sum([cur[s].work() for s in cur], axis=0))
         state["joined"] = state["joined"] and all(b.path() == _lib.PATH_JOINED for b in cur.values())
+        state["paired"] = state["paired"] and all(b.paired_tiles() for b in cur.values())
         if multi:
             exchange.start(ph)
         if not replay:
@@ -482,6 +483,7 @@ def main():
                 b.close()
     batches = groups
     joined = state["joined"]
+    paired = joined and state["paired"]
     rank0_alg_bytes = alg_bytes
     if world > 1:
         t = torch.tensor([alg_bytes, postings], dtype=torch.float64, device=dev)
@@ -505,7 +507,9 @@ def main():
                 stage_ms = float(avg[_lib.K_PLAN] + avg[_lib.K_SCORE])
                 achieved = rank0_alg_bytes / (stage_ms * 1e-3) / 1e9
                 names = _lib.KERNEL_NAMES_JOINED
-                kernel = "k_join + k_join_score"
+                # (paired doc tiles: the score stage is k_join_score<2> — two tiles per visit in
+                # 16-bit halves — followed by k_join_rescore, the exact sums of the docs it picked)
+                kernel = "k_join + k_join_score + k_join_rescore" if paired else "k_join + k_join_score"
             else:
                 # k_score on rank 0: its algorithmic bytes / its summed launch time per step
                 stage_ms = float(avg[_lib.K_SCORE])
@@ -520,7 +524,8 @@ def main():
                     "frac_of_measured": round(achieved / HBM_MEASURED_GBS, 5),
                     # (no fraction of its own for the larger of the two kernels: the algorithmic
                     # bytes are consumed by the decode stage, not by it)
-                    "dominant_kernel": {"name": "k_join_score" if joined else "k_score",
+                    "dominant_kernel": {"name": ("k_join_score<2> + k_join_rescore (one stage)" if paired
+                                                 else "k_join_score") if joined else "k_score",
                                         "avg_launch_ms": round(float(avg[_lib.K_SCORE]), 4)},
                     # HBM-side bytes per step of those kernels (PMC: 2 x FETCH_SIZE + WRITE_SIZE,
                     # separate rocprofv3 passes of this command at these kernel sources), else null
@@ -546,8 +551,9 @@ def main():
                 # directory, packed image and tail tables built on the GPU), once per segment
                 "segment_open": {"seconds": round(open_s, 3), "file_bytes": int(open_bytes),
                                  "GB_per_s": round(open_bytes / open_s / 1e9, 3)},
-                "path": "joined posting streams (k_join once per distinct term of the batch, "
-                        "k_join_score per query)" if joined
+                "path": ("joined posting streams (k_join once per distinct term of the batch, "
+                         "k_join_score per query%s)" % (" on paired doc tiles, k_join_rescore for the exact "
+                                                        "sums of the docs it picks" if paired else "")) if joined
                         else "work items (every query decodes its own blocks)",
                 "postings_per_step": int(postings), "algorithmic_bytes_per_step": int(alg_bytes),
                 "batches": ("%d persistent batches replayed in rotation (--query-sets)" % n_rows) if replay
@@ -987,8 +993,8 @@ def main_tasks(args):
         b.results_to_host().host_results()
         t3 = time.perf_counter()
         stage_ms = dict(zip(("plan", "pilot", "score", "select"), b.timings()))
-        diag = {"path": {_lib.PATH_ITEMS: "items", _lib.PATH_JOINED: "joined"}.get(b.path(), "?")
-                        if not phrase else "phrase",
+        diag = {"path": ({_lib.PATH_ITEMS: "items", _lib.PATH_JOINED: "joined"}.get(b.path(), "?")
+                         + ("+pairs" if b.paired_tiles() else "")) if not phrase else "phrase",
                 "reruns": b.reruns(), "postings_per_step": b.work()[1],
                 "stage_ms": {n: round(v, 3) for n, v in stage_ms.items()},
                 "host_ms": {"prepare": round((t1 - t0) * 1e3, 3), "create": round((t2 - t1) * 1e3, 3),

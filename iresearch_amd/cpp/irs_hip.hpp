@@ -422,6 +422,23 @@ class QueryBatch {
       if (part.h) check(irs_hip_batch_set_async(part.h, enable ? 1 : 0), "irs_hip_batch_set_async");
     return *this;
   }
+  // joined plain disjunctions on paired doc tiles (default) or on 32-bit tiles
+  // (irs_hip_batch_set_paired_tiles: the results are bit-identical, a tuning / test knob)
+  QueryBatch& set_paired_tiles(bool enable) {
+    for (Part& part : part_)
+      if (part.h)
+        check(irs_hip_batch_set_paired_tiles(part.h, enable ? 1 : 0), "irs_hip_batch_set_paired_tiles");
+    return *this;
+  }
+  bool paired_tiles() {   // whether the last run took them (any part)
+    bool any = false;
+    for (Part& part : part_) {
+      int used = 0;
+      if (part.h) check(irs_hip_batch_paired_tiles(part.h, &used), "irs_hip_batch_paired_tiles");
+      any = any || used != 0;
+    }
+    return any;
+  }
   QueryBatch& run(void* stream = nullptr) {
     for (Part& part : part_)
       if (part.h) check(irs_hip_batch_run(part.h, stream), "irs_hip_batch_run");

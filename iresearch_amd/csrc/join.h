@@ -501,14 +501,37 @@ template<int FORM, bool COUNT, bool HALF = false>
 __device__ __forceinline__ void join_run(const unsigned char* lds, uint64_t base, uint32_t count,
                                          float cs, uint32_t tabofs, unsigned lane, uint32_t sh = 0u) {
   const uint32_t off = lane * 4u;
-  while (count >= 256u) {
-    uint32_t e[4];
+  if (HALF) {
+    // paired tiles: a share is several groups long — group g + 1 is requested before group g is
+    // accumulated (the wait for g leaves g + 1 in flight)
+    if (count >= 256u) {
+      uint32_t cur[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) e[k] = wave::gload_u32(base, off + 256u * uint32_t(k));
-    wave::keep_all(e);
-    join_post<FORM, 4, COUNT, HALF>(lds, e, cs, tabofs, sh);
-    base += 1024u;
-    count -= 256u;
+      for (int k = 0; k < 4; ++k) cur[k] = wave::gload_u32(base, off + 256u * uint32_t(k));
+      base += 1024u;
+      count -= 256u;
+      while (count >= 256u) {
+        uint32_t nxt[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) nxt[k] = wave::gload_u32(base, off + 256u * uint32_t(k));
+        join_post<FORM, 4, COUNT, HALF>(lds, cur, cs, tabofs, sh);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
+        base += 1024u;
+        count -= 256u;
+      }
+      join_post<FORM, 4, COUNT, HALF>(lds, cur, cs, tabofs, sh);
+    }
+  } else {
+    while (count >= 256u) {
+      uint32_t e[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) e[k] = wave::gload_u32(base, off + 256u * uint32_t(k));
+      wave::keep_all(e);
+      join_post<FORM, 4, COUNT, HALF>(lds, e, cs, tabofs, sh);
+      base += 1024u;
+      count -= 256u;
+    }
   }
   if (count) {
     uint32_t e[4];

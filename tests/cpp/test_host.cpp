@@ -204,6 +204,16 @@ int main() {
         REQUIRE(pushed[q][i].score == top[q][i].score && pushed[q][i].doc == top[q][i].doc);
     }
     batch.set_min_scores({});
+    // the joined plain disjunctions on 32-bit tiles instead of paired tiles
+    // (irs_hip_batch_set_paired_tiles): the same lists, bit for bit
+    const auto unpaired = merge(batch.set_paired_tiles(false).run().results());
+    REQUIRE(!batch.paired_tiles());
+    batch.set_paired_tiles(true);
+    for (size_t q = 0; q < top.size(); ++q) {
+      REQUIRE(unpaired[q].size() == top[q].size());
+      for (size_t i = 0; i < top[q].size(); ++i)
+        REQUIRE(unpaired[q][i].score == top[q][i].score && unpaired[q][i].doc == top[q][i].doc);
+    }
   }
   // the one-call form gives the same lists
   {

@@ -36,7 +36,7 @@ def config5(tag, pmc_dirs):
         summary[k]["launches"] = max(len(x) for x in launches[k].values())
     json.dump(summary, open(os.path.join(out, "%s_pmc_config5.json" % tag), "w"), indent=1, sort_keys=True)
     steps = {c: len(launches["k_select"][c]) / 2.0 for c in ("FETCH_SIZE", "WRITE_SIZE") if launches["k_select"][c]}
-    priced = [k for k in tot if k.startswith(("k_conj<", "k_phrase", "k_join_score", "k_join<"))]
+    priced = [k for k in tot if k.startswith(("k_conj<", "k_phrase", "k_join_score", "k_join_rescore", "k_join<"))]
     fetch = sum(tot[k]["FETCH_SIZE"] for k in priced) * 1024 / max(steps.get("FETCH_SIZE", 1.0), 1.0)
     write = sum(tot[k]["WRITE_SIZE"] for k in priced) * 1024 / max(steps.get("WRITE_SIZE", 1.0), 1.0)
     t = {"kernels": sorted(priced), "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) "
@@ -72,10 +72,11 @@ def main():
     json.dump(summary, open(os.path.join(out, "%s_pmc.json" % tag), "w"), indent=1, sort_keys=True)
     # the kernels the roofline prices (bench.py): the work-item path's k_score, or the joined
     # path's two stages k_join + k_join_score (the pilot kernels are apart)
-    staged = [k for k in summary if (k.startswith("k_join<") or k.startswith("k_join_score"))
+    # (paired tiles: k_join_score<2> + k_join_rescore are the score stage)
+    staged = [k for k in summary if k.startswith(("k_join<", "k_join_score", "k_join_rescore"))
               and "FETCH_SIZE_per_launch" in summary[k]]
     scored = [k for k in summary if k.startswith("k_score") and "FETCH_SIZE_per_launch" in summary[k]]
-    for group in ([staged] if len(staged) == 2 else [[k] for k in scored]):
+    for group in ([staged] if len(staged) in (2, 3) else [[k] for k in scored]):
         if group:
             k = " + ".join(sorted(group))
             fetch_kb = sum(summary[g]["FETCH_SIZE_per_launch"] for g in group)
