@@ -403,8 +403,11 @@ int irs_hip_batch_path(irs_hip_batch* batch, int* path);
  * share an accumulator word (16 bits each, contributions rounded up), which only PICKS the docs;
  * their exact 32-bit sums are formed afterwards from the streams (k_join_rescore) with the
  * arithmetic of the unpaired kernel, so hits, scores, order and totals are BIT-IDENTICAL either
- * way.  Taken unless a segment of the batch's plain joined units has deleted documents;
- * otherwise — or with enable = 0 — the units run on 32-bit tiles.
+ * way.  enable = 1 (default): taken where it pays — the visits saved (doc tiles per unit) against
+ * the look-ups added (about min(3 k / units sharing the threshold, k) docs per term): a 10 M-doc
+ * segment at k = 1000 pairs, a lone 1.25 M-doc segment does not — unless a segment of the batch's
+ * plain joined units has deleted documents; enable = 2: whatever the size (tests); enable = 0:
+ * never — the units run on 32-bit tiles.
  * irs_hip_batch_paired_tiles: whether the last run took them. */
 int irs_hip_batch_set_paired_tiles(irs_hip_batch* batch, int enable);
 int irs_hip_batch_paired_tiles(irs_hip_batch* batch, int* used);

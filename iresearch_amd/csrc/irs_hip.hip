@@ -386,7 +386,8 @@ struct irs_hip_batch {
   uint64_t join_entries = 0;
   // one threshold per query for its units on the batch's segments (irs_hip_batch_set_shared_threshold)
   bool shared_threshold = false;
-  bool pairs_allowed = true;   // irs_hip_batch_set_paired_tiles
+  bool pairs_allowed = true;   // irs_hip_batch_set_paired_tiles (0: never; 1: by size; 2: whatever the size)
+  bool pairs_forced = false;
   bool pairs_used = false;     // ... and whether the last run's plain disjunctions took them
   uint32_t n_groups = 0;       // groups in force this run (0: none)
   DevBuf d_group_of;           // [unit] group + 1, 0: a threshold of its own
@@ -1368,18 +1369,37 @@ bool join_half_ok(const irs_hip_batch* b) {
     if (std::atoi(e) == 0) return false;
   }
   if (!b->pairs_allowed || !b->acc32 || !b->n_join_plain) return false;
+  // Where it pays (measured on one MI355X, GPU time summed over the chip): a (unit, doc tile)
+  // visited in a pair saves ~1.4 ns — half of that when the batch is too small to keep the chip
+  // busy through the tail of the work queue (fewer than ~400 k visits) —, a look-up of
+  // k_join_rescore costs ~40 ps, and a unit looks up about min(3 k / G, k) docs in each of its
+  // terms (G: the units that share its threshold — the segments of a batch with a shared
+  // threshold times the ranks of its communicator; 3 = kPilotMargin).  10 M docs in one segment,
+  // k = 1000: 1.14 us saved against 0.35 per unit (5.65 -> 4.74 ms per 1000 units); a 1.25 M-doc
+  // share of it alone: 0.07 against 0.2 (stays on 32-bit tiles: 0.97 against 1.10 ms); the
+  // same as 8 segments of one batch: 0.14 against 0.08 (5.79 -> 5.27 ms).
+  // IRS_HIP_JOIN_HALF=1 / set_paired_tiles(2) pair whatever the size (tests on small segments).
+  bool forced = b->pairs_forced;
+  if (const char* e = std::getenv("IRS_HIP_JOIN_HALF")) forced = forced || std::atoi(e) == 1;
+  uint64_t visits = 0, lookups = 0;
   for (uint32_t u : b->join_units) {
     const DevQuery& dq = b->queries[u];
     if (query_need(dq.op) > 1u) continue;
     if (b->segs[dq.seg]->dev.dead) return false;
+    const uint64_t group = uint64_t((b->shared_threshold || b->comm) ? b->segs.size() : 1) *
+                           uint64_t(b->comm ? std::max(1, b->comm->n_ranks) : 1);
+    visits += b->segs[dq.seg]->dev.num_docs / kJoinTile + 1;
+    lookups += std::min<uint64_t>((uint64_t(kPilotMargin) * dq.k + group - 1) / group, uint64_t(dq.k) + 64) *
+               dq.n_terms;
   }
+  if (!forced && (visits >= 400000 ? 1400ull : 700ull) * visits <= 40ull * lookups) return false;
   return true;
 }
 
 bool launch_join_score(irs_hip_batch* b, rt::stream_t st) {
   const size_t smem = JoinOff::end;
   if (!big_smem(k_join_score<kJKPlain>, smem) || !big_smem(k_join_score<kJKCount>, smem) ||
-      !big_smem(k_join_score<kJKHalf>, smem) || !big_smem(k_join_rescore, smem))
+      !big_smem(k_join_score<kJKHalf>, smem))
     return false;
   const bool half = join_half_ok(b);
   b->pairs_used = half;
@@ -1460,7 +1480,7 @@ bool launch_join_score(irs_hip_batch* b, rt::stream_t st) {
     } else if (half) {
       // (d_join_order: the plain units first — one k_join_rescore workgroup each)
       RT_LAUNCH(k_join_score<kJKHalf>, grid, b->join_threads, smem, st, d_args);
-      RT_LAUNCH(k_join_rescore, n_units, b->join_threads, smem, st, b->d_join_order.as<uint32_t>(),
+      RT_LAUNCH(k_join_rescore, n_units, kRescoreThreads, 0, st, b->d_join_order.as<uint32_t>(),
                 b->d_queries.as<DevQuery>(), b->d_qterms.as<DevQTerm>(), b->d_jterms.as<JoinTerm>(),
                 b->d_bstar.as<uint32_t>(), b->d_cands.as<uint64_t>(), b->d_cand_count.as<uint32_t>(),
                 b->cand_cap);
@@ -2809,6 +2829,7 @@ static int batch_set_paired_tiles_impl(irs_hip_batch* b, int enable) {
   if (!rt::set_device(b->seg->device)) return IRS_HIP_EHIP;
   if (!quiesce(b)) return IRS_HIP_EHIP;
   b->pairs_allowed = enable != 0;
+  b->pairs_forced = enable == 2;
   return IRS_HIP_OK;
 }
 static int batch_paired_tiles_impl(irs_hip_batch* b, int* used) {

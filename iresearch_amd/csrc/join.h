@@ -1444,17 +1444,18 @@ k_join_score(const JoinArgs* __restrict__ args) {
 // entries of a tile sits near n o / 12288: sixteen entries around that guess (four independent
 // 16-byte loads, one round trip) settle most searches; a binary search over what is left of the
 // range the others.
-constexpr uint32_t kRescoreMax = 6144;    // docs in LDS at a time: doc + sum = 8 B each
-static_assert(kRescoreMax * 8u <= 4u * kJoinTile, "k_join_rescore's arrays fit the accumulator area");
-// the 32-bit contribution of one entry: join_post<FORM, N, false>, one posting
-__device__ __forceinline__ uint32_t join_fx(const unsigned char* lds, uint32_t e, float cs, uint32_t mode) {
-  const uint32_t tabofs = mode & kJoinTabMask;
+constexpr uint32_t kRescoreMax = 2048;      // docs in LDS at a time: doc + sum = 8 B each
+constexpr uint32_t kRescoreThreads = 512;   // 4 workgroups of 19 KB LDS per CU: every unit of a batch in flight
+// the 32-bit contribution of one entry: join_post<FORM, N, false>, one posting — the table entry
+// the kernel reads from LDS evaluated on the spot (table_entry: what build_tables stores)
+__device__ __forceinline__ uint32_t join_fx(const DevQTerm& qt, uint32_t e, float cs, uint32_t mode) {
   const int form = join_form(mode);
+  const uint32_t norm = (e >> 2) & 255u;
   if (form == kJTable) {
-    const float t = wave::lds_f32(lds, JoinOff::caches + ((e & 0xFFFFu) | tabofs));
+    const float t = table_entry(qt.kind, qt.norm_const, qt.norm_length, (e >> 10) & 63u, norm);
     return static_cast<uint32_t>(wave::fma(cs, t, 1.f));
   }
-  const float t = wave::lds_f32(lds, JoinOff::caches + ((e & 0x3FCu) | tabofs));
+  const float t = table_entry(qt.kind, qt.norm_const, qt.norm_length, 0u, norm);
   const float tf = static_cast<float>(join_tf(e));
   float scaled = (form == kJSqrt) ? wave::fast_sqrt(tf) * cs * t
                                   : wave::fma(-cs, wave::fast_rcp(wave::fma(tf, t, 1.f)), cs);
@@ -1535,16 +1536,16 @@ __device__ __forceinline__ uint32_t join_find(const uint32_t* ent, uint32_t lo, 
   }
   return 0xFFFFFFFFu;
 }
-__global__ void __launch_bounds__(kTileThreadsMax)
+__global__ void __launch_bounds__(kRescoreThreads)
 k_join_rescore(const uint32_t* units, const DevQuery* queries, const DevQTerm* qterms,
                const JoinTerm* jterms, const uint32_t* bstar, uint64_t* cands,
                uint32_t* cand_count, uint32_t cap) {
-  RT_DYN_SMEM(smem);
-  uint32_t* docs = reinterpret_cast<uint32_t*>(smem + JoinOff::acc);   // [kRescoreMax]
-  uint32_t* fsum = docs + kRescoreMax;                                 // [kRescoreMax]
-  uint32_t* hist = reinterpret_cast<uint32_t*>(smem + JoinOff::cand);  // [256]
-  uint32_t* sig = reinterpret_cast<uint32_t*>(smem + JoinOff::sig);
-  uint32_t* vars = reinterpret_cast<uint32_t*>(smem + JoinOff::vars);
+  __shared__ uint32_t docs[kRescoreMax];
+  __shared__ uint32_t fsum[kRescoreMax];
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t vars[8];
+  __shared__ DevQTerm qts[kMaxTerms];
+  __shared__ JoinTerm jts[kMaxTerms];
   enum : uint32_t { kOut = 0, kSel = 1, kPass = 2, kDigit = 3, kWant = 4 };
   const uint32_t tid = threadIdx.x;
   const unsigned lane = tid & 63u;
@@ -1553,16 +1554,15 @@ k_join_rescore(const uint32_t* units, const DevQuery* queries, const DevQTerm* q
   // (more staged docs than slots: k_select raises kStatusOverflow, the host re-runs the batch)
   if (!n || n > cap) return;
   const DevQuery qd = queries[q];
-  if (tid == 0) {
-    sig[0] = 0xFFFFFFFFu;
-    vars[kOut] = vars[kSel] = vars[kPass] = 0u;
+  if (tid == 0) vars[kOut] = vars[kSel] = vars[kPass] = 0u;
+  if (tid < qd.n_terms) {
+    qts[tid] = qterms[qd.first_term + tid];
+    jts[tid] = jterms[qd.first_term + tid];
   }
   __syncthreads();
-  join_prologue(smem, qd, qterms, jterms);
   const uint32_t bs = bstar[q];
   const uint32_t thr = bin_threshold<uint32_t>(bs, qd);
   const uint32_t nt = qd.n_terms;
-  const JoinTerm* jts = reinterpret_cast<const JoinTerm*>(smem + JoinOff::jts);
   uint64_t* list = cands + uint64_t(q) * cap;
   // the docs[0 .. count) in LDS: look their postings up, sum; returns with the sums visible
   auto look_up = [&](uint32_t count) {
@@ -1573,7 +1573,7 @@ k_join_rescore(const uint32_t* units, const DevQuery* queries, const DevQTerm* q
       const uint32_t* bnd = reinterpret_cast<const uint32_t*>(jts[j].bounds);
       const uint32_t e = join_find(reinterpret_cast<const uint32_t*>(jts[j].entries), bnd[tile],
                                    bnd[tile + 1u], off);
-      if (e != 0xFFFFFFFFu) atomicAdd(&fsum[c], join_fx(smem, e, jts[j].cs, jts[j].mode));
+      if (e != 0xFFFFFFFFu) atomicAdd(&fsum[c], join_fx(qts[j], e, jts[j].cs, jts[j].mode));
     }
     __syncthreads();
   };

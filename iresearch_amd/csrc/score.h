@@ -117,6 +117,16 @@ __device__ __forceinline__ float table_value(int32_t kind, float nc, float nl, u
   }
 }
 
+// entry [r][n] of a scorer's table: row 0 holds the norm factor, row r > 0 the whole expression at
+// frequency r (build_tables fills the LDS tables with it; k_join_rescore evaluates it per posting:
+// one function, the same float)
+__device__ __forceinline__ float table_entry(int32_t kind, float nc, float nl, uint32_t r, uint32_t n) {
+  const float t = table_value(kind, nc, nl, n);
+  if (r == 0) return t;
+  if (sqrt_kind(kind)) return sqrtf(static_cast<float>(r)) * t;
+  return 1.f - 1.f / (1.f + static_cast<float>(r) * t);
+}
+
 template<typename ACC>
 struct TileSmemT {
   ACC* acc;          // [TILE + 64] fixed-point score accumulators (score_buf of
@@ -166,10 +176,7 @@ __device__ __forceinline__ void build_tables(const SM& sm, uint32_t n_caches, ui
     float v = 0.f;
     for (uint32_t j = 0; j < n_terms; ++j) {
       if (sm.qts[j].cache_id == c) {
-        const float t = table_value(sm.qts[j].kind, sm.qts[j].norm_const, sm.qts[j].norm_length, n);
-        if (r == 0) v = t;
-        else if (sqrt_kind(sm.qts[j].kind)) v = sqrtf(static_cast<float>(r)) * t;
-        else v = 1.f - 1.f / (1.f + static_cast<float>(r) * t);
+        v = table_entry(sm.qts[j].kind, sm.qts[j].norm_const, sm.qts[j].norm_length, r, n);
         break;
       }
     }

@@ -537,7 +537,9 @@ class QueryBatch:
         return int(v.value)
 
     def set_paired_tiles(self, enable=True):
-        """Joined plain disjunctions on paired doc tiles (default) or on 32-bit tiles: bit-identical."""
+        """Joined plain disjunctions on paired doc tiles: 1 / True = where it pays (default: segments
+        of ~2.4 M docs and more), 2 = whatever the size, 0 / False = never (32-bit tiles).  The results
+        are bit-identical either way."""
         _lib.check(self.L, self.L.irs_hip_batch_set_paired_tiles(self.handle, int(enable)),
                    "irs_hip_batch_set_paired_tiles")
         return self

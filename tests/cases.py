@@ -554,7 +554,8 @@ def case_paired_tiles(L, num_docs=61_000, max_rank=256, layout=synth.LAYOUT_SIMD
     forms their exact sums) against the same batch on 32-bit tiles: docs, scores, order, counts
     and totals bit for bit, each also against the oracle.  61 000 docs = 5 tiles: the last pair
     has one tile only.  k = 3 puts the threshold high (few docs pass), k = 1000 low; a batch with
-    a two-signature query or a long-frequency term does not qualify and says so."""
+    (set_paired_tiles(2): whatever the segment's size — by default segments below ~2.4 M docs stay on
+    32-bit tiles, where the look-ups cost more than the visits save.)"""
     seg = synth.build_segment(num_docs, max_rank, layout=layout)
     sr = search.SegmentReader.from_synth(seg, L=L)
     ranks = synth.make_queries(10, 8, 2, max_rank, synth.SEED + 15)
@@ -566,7 +567,7 @@ def case_paired_tiles(L, num_docs=61_000, max_rank=256, layout=synth.LAYOUT_SIMD
             got = {}
             for paired in (True, False):
                 prep = search.prepare(pure, scorer, [parity.segment_stats(seg)])
-                b = sr.batch(prep, k).set_path(_lib.PATH_JOINED).set_paired_tiles(paired)
+                b = sr.batch(prep, k).set_path(_lib.PATH_JOINED).set_paired_tiles(2 if paired else 0)
                 h, c, t = b.run().results()
                 assert b.path() == _lib.PATH_JOINED
                 assert b.paired_tiles() == paired, (scorer, k, paired)
@@ -581,8 +582,9 @@ def case_paired_tiles(L, num_docs=61_000, max_rank=256, layout=synth.LAYOUT_SIMD
     # a mixed batch: the plain disjunctions pair, the counting units keep their kernel
     mixed = pure + standard_filters(max_rank, n_or8=1)
     prep = search.prepare(mixed, BM25(), [parity.segment_stats(seg)])
-    b = sr.batch(prep, 40).set_path(_lib.PATH_JOINED)
+    b = sr.batch(prep, 40).set_path(_lib.PATH_JOINED).set_paired_tiles(2)
     h, c, t = b.run().results()
+    assert b.paired_tiles()
     parity.check_single_segment(seg, mixed, BM25(), 40, h, c, t)
     b.close()
     sr.close()

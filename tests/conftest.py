@@ -13,6 +13,13 @@ sys.path.insert(0, str(ROOT / "tests"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950) GPU")
+    # Test segments are small: by its size rule the library would keep their joined disjunctions on
+    # 32-bit tiles and the paired-tile kernels (k_join_score<kJKHalf>, k_join_rescore) would only
+    # run in case_paired_tiles.  Pair whatever the size, so that every plain-disjunction case
+    # checks them against the oracle; the 32-bit tiles keep their coverage through
+    # case_paired_tiles (unpaired run), every conjunction / min-match / deleted-docs case and
+    # IRS_HIP_JOIN_HALF=0 runs of this suite.
+    os.environ.setdefault("IRS_HIP_JOIN_HALF", "1")
 
 
 def _sim_stale(so: Path) -> bool:

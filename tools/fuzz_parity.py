@@ -118,10 +118,16 @@ def main():
             ib.close()
             # joined streams wherever a unit is eligible (whatever the cost rules would deal) —
             # against the oracle, counts as before
-            jb = sr.batch(prep, k).set_path(_lib.PATH_JOINED)
+            # (on paired doc tiles whatever the segment's size: k_join_score<kJKHalf> + k_join_rescore)
+            jb = sr.batch(prep, k).set_path(_lib.PATH_JOINED).set_paired_tiles(2)
             jh, jc, jt = (x.copy() for x in jb.run().results())
             parity.check_single_segment(seg, filters, scorer, k, jh, jc, jt)
             assert np.array_equal(jc, counts) and np.array_equal(jt, totals), "joined: counts"
+            # ... and on 32-bit tiles: bit for bit the same lists
+            ub = sr.batch(prep, k).set_path(_lib.PATH_JOINED).set_paired_tiles(0)
+            uh, uc, ut = ub.run().results()
+            assert np.array_equal(uc, jc) and np.array_equal(ut, jt) and np.array_equal(uh, jh), "paired tiles"
+            ub.close()
             jb.close()
             # block-max pruning (on the work-item / block-driven kernels): the same top-k, bit for bit
             wb = sr.batch(prep, k).set_path(_lib.PATH_ITEMS).set_wand(True)
