@@ -282,7 +282,7 @@ def main():
     # --query-sets N > 0: the round-1..3 protocol (N persistent batches replayed in rotation).
     replay = args.query_sets > 0
     n_probe = 3            # isolated (unpipelined) fresh batches, timed one by one
-    n_host = 0 if world > 1 else max(2, min(args.steps, 8))
+    n_host = 0 if world > 1 else max(2, min(args.steps, 20))
     n_rows = max(1, args.query_sets) if replay else min(64, n_probe + args.warmup + args.steps + n_host + 2)
     rank_sets = [synth.make_queries(args.queries, args.terms, 16, 4096,
                                     synth.SEED + 2 + (10 + i if i else 0)) for i in range(n_rows)]
