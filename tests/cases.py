@@ -3,6 +3,7 @@ each takes the bound C-ABI library `L` and a size scale."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -556,6 +557,8 @@ def case_paired_tiles(L, num_docs=61_000, max_rank=256, layout=synth.LAYOUT_SIMD
     has one tile only.  k = 3 puts the threshold high (few docs pass), k = 1000 low; a batch with
     (set_paired_tiles(2): whatever the segment's size — by default segments below ~2.4 M docs stay on
     32-bit tiles, where the look-ups cost more than the visits save.)"""
+    if os.environ.get("IRS_HIP_JOIN_HALF") == "0":
+        pytest.skip("IRS_HIP_JOIN_HALF=0: a run of the suite on 32-bit tiles only")
     seg = synth.build_segment(num_docs, max_rank, layout=layout)
     sr = search.SegmentReader.from_synth(seg, L=L)
     ranks = synth.make_queries(10, 8, 2, max_rank, synth.SEED + 15)
