@@ -38,8 +38,12 @@ def simlib():
     exercises the real host code and kernel logic on the GPU-less build box."""
     from iresearch_amd import _lib
     so = ROOT / "tests" / "sim" / "libirs_hip_sim.so"
-    if _sim_stale(so):
-        subprocess.run([str(ROOT / "tests" / "sim" / "build_sim.sh")], check=True)
+    # (pytest-xdist: every worker has its own session — one of them builds, the others wait)
+    import fcntl
+    with open(ROOT / "tests" / "sim" / ".build.lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if _sim_stale(so):
+            subprocess.run([str(ROOT / "tests" / "sim" / "build_sim.sh")], check=True)
     return _lib.bind(C.CDLL(str(so)))
 
 
